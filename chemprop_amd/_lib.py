@@ -1,0 +1,145 @@
+"""Build and load ``libdmpnn_gfx950.so`` (the C-ABI of include/dmpnn.h) through ctypes.
+
+The library is compiled IN-TREE with ``hipcc --offload-arch=gfx950`` (cross-compiles without a GPU)
+and travels with the source snapshot.  It must be loaded *after* ``import torch`` so the process
+binds torch's bundled HIP runtime (same SONAME ``libamdhip64.so.7``) and device pointers of torch
+tensors are valid in it.  There is no fallback: if the library is missing or cannot be loaded,
+every engine entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(_ROOT, "include")
+LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
+SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_backward.hip"]
+
+# every symbol include/dmpnn.h declares; tests check the .so exports all of them
+EXPORTS = [
+    "dmpnn_version", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
+    "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
+    "dmpnn_linear_fwd", "dmpnn_forward",
+]
+
+ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
+F_UNDIRECTED = 1
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("N", C.c_int64), ("K1", C.c_int64), ("K2", C.c_int64),
+        ("A1", C.c_void_p), ("lda1", C.c_int64), ("gather1", C.c_void_p),
+        ("A2", C.c_void_p), ("lda2", C.c_int64),
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("bias", C.c_void_p),
+        ("Cadd", C.c_void_p), ("ldcadd", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("Zpre", C.c_void_p), ("ldz", C.c_int64),
+        ("act", C.c_int), ("act_slope", C.c_float), ("act_slope_ptr", C.c_void_p),
+    ]
+
+
+class FwdArgs(C.Structure):
+    _fields_ = [
+        ("plan", C.c_void_p), ("n_atoms", C.c_int64), ("n_edges", C.c_int64),
+        ("d_v", C.c_int64), ("d_e", C.c_int64), ("d_h", C.c_int64), ("d_vd", C.c_int64),
+        ("depth", C.c_int32), ("flags", C.c_uint32),
+        ("act", C.c_int32), ("act_slope", C.c_float), ("act_slope_ptr", C.c_void_p),
+        ("V", C.c_void_p), ("ldv", C.c_int64),
+        ("E", C.c_void_p), ("lde", C.c_int64),
+        ("V_d", C.c_void_p), ("ldvd", C.c_int64),
+        ("W_i", C.c_void_p), ("b_i", C.c_void_p),
+        ("W_h", C.c_void_p), ("b_h", C.c_void_p),
+        ("W_o", C.c_void_p), ("b_o", C.c_void_p),
+        ("W_d", C.c_void_p), ("b_d", C.c_void_p),
+        ("ldh", C.c_int64), ("H0", C.c_void_p), ("Hs", C.c_void_p), ("n_hslots", C.c_int32),
+        ("Ms", C.c_void_p), ("n_mslots", C.c_int32),
+        ("Mv", C.c_void_p), ("Hv", C.c_void_p),
+        ("out", C.c_void_p), ("ldout", C.c_int64),
+    ]
+
+
+def sources() -> list[str]:
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.isfile(os.path.join(CSRC, s))]
+
+
+def _stale() -> bool:
+    if not os.path.isfile(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + [os.path.join(CSRC, "dmpnn_common.hpp"), os.path.join(INCLUDE, "dmpnn.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``chemprop_amd/libdmpnn_gfx950.so``."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.isfile(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libdmpnn_gfx950.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}",
+           f"-I{CSRC}", *sources(), "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library (building it first when a compiler is present and it is stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (bind torch's HIP runtime first)
+
+    if _stale() and (shutil.which("hipcc") or os.path.isfile("/opt/rocm/bin/hipcc")):
+        build()
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the MI355X engine has no CPU / eager fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.dmpnn_version.restype = C.c_int
+    lib.dmpnn_last_error_string.restype = C.c_char_p
+    lib.dmpnn_last_launch_count.restype = C.c_int
+    lib.dmpnn_plan_bytes.restype = C.c_size_t
+    lib.dmpnn_plan_bytes.argtypes = [C.c_int64, C.c_int64]
+    lib.dmpnn_plan_layout.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    lib.dmpnn_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.dmpnn_message_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint, C.c_void_p]
+    lib.dmpnn_aggregate_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    lib.dmpnn_linear_fwd.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+    lib.dmpnn_forward.argtypes = [C.POINTER(FwdArgs), C.c_void_p]
+    for name in EXPORTS:
+        if name not in ("dmpnn_last_error_string", "dmpnn_plan_bytes"):
+            getattr(lib, name).restype = C.c_int
+    if lib.dmpnn_version() != 1:
+        raise RuntimeError(f"libdmpnn ABI version {lib.dmpnn_version()} != 1 (stale build?)")
+    _lib = lib
+    return lib
+
+
+class DmpnnError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dmpnn_last_error_string().decode(errors="replace")
+        raise DmpnnError(f"{what} failed (code {rc}): {msg}")

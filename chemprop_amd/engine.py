@@ -1,0 +1,220 @@
+"""Thin host side of the engine: torch tensors in, C-ABI calls (include/dmpnn.h) out.
+
+torch is plumbing here — device memory (caching allocator), streams, autograd bookkeeping.  All
+arithmetic on the path runs in the HIP kernels of ``chemprop_amd/csrc``.  There is no CPU or eager
+fallback: tensors that are not on a HIP device raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ACT, F_UNDIRECTED, FwdArgs, GemmArgs
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_device(t: Tensor, name: str) -> None:
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            f"chemprop_amd: `{name}` lives on {t.device}; the MI355X engine runs HIP kernels only "
+            "(no CPU fallback) — move the batch and the module to a GPU device first")
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    _require_device(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class GraphPlan:
+    """K0: int32 indices + stable incoming-edge CSR of one batch, built on device (no host sync)."""
+
+    __slots__ = ("buf", "n_atoms", "n_edges", "device")
+
+    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int):
+        _require_device(edge_index, "edge_index")
+        lib = _lib.load()
+        dev = edge_index.device
+        n_edges = int(edge_index.shape[1])
+        ei = edge_index if edge_index.dtype == torch.int64 else edge_index.long()
+        ei = ei.contiguous()
+        rev = rev_edge_index if rev_edge_index.dtype == torch.int64 else rev_edge_index.long()
+        rev = rev.contiguous()
+        nbytes = lib.dmpnn_plan_bytes(n_atoms, n_edges)
+        self.buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+        self.n_atoms, self.n_edges, self.device = int(n_atoms), n_edges, dev
+        with torch.cuda.device(dev):
+            _lib.check(lib.dmpnn_prepare(ei.data_ptr(), rev.data_ptr(), n_atoms, n_edges,
+                                         self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
+
+    @classmethod
+    def from_bmg(cls, bmg) -> "GraphPlan":
+        return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]))
+
+    # ---- views for tests / diagnostics (these synchronise) ----
+    def arrays(self) -> dict:
+        off = self._offsets()
+        b = self.buf.cpu()
+        E, V = self.n_edges, self.n_atoms
+        return dict(hdr=b[:16], src=b[off[0]:off[0] + E], dst=b[off[1]:off[1] + E], rev=b[off[2]:off[2] + E],
+                    row_ptr=b[off[3]:off[3] + V + 1], perm=b[off[4]:off[4] + E])
+
+    def _offsets(self):
+        off = (C.c_int64 * 5)()
+        _lib.check(_lib.load().dmpnn_plan_layout(self.n_atoms, self.n_edges, off), "dmpnn_plan_layout")
+        return off
+
+    @property
+    def src32(self) -> Tensor:
+        off = self._offsets()
+        return self.buf[off[0]:off[0] + self.n_edges]
+
+    @property
+    def dst32(self) -> Tensor:
+        off = self._offsets()
+        return self.buf[off[1]:off[1] + self.n_edges]
+
+    @property
+    def rev64(self) -> Tensor:
+        off = self._offsets()
+        return self.buf[off[2]:off[2] + self.n_edges].long()
+
+
+def act_code(name: str) -> int:
+    return ACT[str(name).lower()]
+
+
+# ------------------------------------------------------------------------------------------------
+# row kernels (used by per-row parity tests, by the custom-activation / dropout path, and by bench)
+# ------------------------------------------------------------------------------------------------
+def message(plan: GraphPlan, H: Tensor, act_on_load: str = "none", slope: float = 0.0,
+            slope_t: Optional[Tensor] = None, undirected: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    H = _f32c(H, "H")
+    M = out if out is not None else torch.empty_like(H)
+    with torch.cuda.device(H.device):
+        _lib.check(_lib.load().dmpnn_message_fwd(
+            plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, H.shape[1], H.data_ptr(), H.stride(0),
+            M.data_ptr(), M.stride(0), act_code(act_on_load), float(slope), _ptr(slope_t),
+            F_UNDIRECTED if undirected else 0, _stream_ptr(H.device)), "dmpnn_message_fwd")
+    return M
+
+
+def aggregate(plan: GraphPlan, H: Tensor, act_on_load: str = "none", slope: float = 0.0,
+              slope_t: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    H = _f32c(H, "H")
+    Mv = out if out is not None else torch.empty(plan.n_atoms, H.shape[1], dtype=torch.float32, device=H.device)
+    with torch.cuda.device(H.device):
+        _lib.check(_lib.load().dmpnn_aggregate_fwd(
+            plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, H.shape[1], H.data_ptr(), H.stride(0),
+            Mv.data_ptr(), Mv.stride(0), act_code(act_on_load), float(slope), _ptr(slope_t),
+            _stream_ptr(H.device)), "dmpnn_aggregate_fwd")
+    return Mv
+
+
+def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Tensor] = None,
+           gather1: Optional[Tensor] = None, n_rows: Optional[int] = None, Cadd: Optional[Tensor] = None,
+           act: str = "none", slope: float = 0.0, slope_t: Optional[Tensor] = None,
+           out: Optional[Tensor] = None, zpre: Optional[Tensor] = None) -> Tensor:
+    """``act([A1[gather] || A2] @ W.T + bias + Cadd)`` on the fp32-MFMA kernel."""
+    A1 = _f32c(A1, "A1")
+    W = _f32c(W, "W")
+    if A2 is not None:
+        A2 = _f32c(A2, "A2")
+    M = int(n_rows) if n_rows is not None else (int(gather1.shape[0]) if gather1 is not None else int(A1.shape[0]))
+    N = int(W.shape[0])
+    K1, K2 = int(A1.shape[1]), (int(A2.shape[1]) if A2 is not None else 0)
+    if W.shape[1] != K1 + K2:
+        raise RuntimeError(f"linear: W has in_features {W.shape[1]} but operands give {K1}+{K2}")
+    C_ = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A1.device)
+    g = GemmArgs()
+    g.M, g.N, g.K1, g.K2 = M, N, K1, K2
+    g.A1, g.lda1, g.gather1 = A1.data_ptr(), A1.stride(0), _ptr(gather1)
+    g.A2, g.lda2 = _ptr(A2), (A2.stride(0) if A2 is not None else 0)
+    g.W, g.ldw = W.data_ptr(), W.stride(0)
+    g.bias = _ptr(bias)
+    g.Cadd, g.ldcadd = _ptr(Cadd), (Cadd.stride(0) if Cadd is not None else 0)
+    g.C, g.ldc = C_.data_ptr(), C_.stride(0)
+    g.Zpre, g.ldz = _ptr(zpre), (zpre.stride(0) if zpre is not None else 0)
+    g.act, g.act_slope, g.act_slope_ptr = act_code(act), float(slope), _ptr(slope_t)
+    with torch.cuda.device(A1.device):
+        _lib.check(_lib.load().dmpnn_linear_fwd(C.byref(g), _stream_ptr(A1.device)), "dmpnn_linear_fwd")
+    return C_
+
+
+# ------------------------------------------------------------------------------------------------
+# whole forward (builtin activation, dropout inactive): one C call, kernels chained on the stream
+# ------------------------------------------------------------------------------------------------
+class ForwardState:
+    """Workspace of one forward; kept alive for the backward pass when ``keep`` is set."""
+
+    __slots__ = ("plan", "H0", "Hs", "Ms", "Mv", "Hv", "ldh", "n_hslots", "n_mslots", "out")
+
+
+def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o: Tensor, b_o: Tensor,
+            b_i: Optional[Tensor] = None, b_h: Optional[Tensor] = None, W_d: Optional[Tensor] = None,
+            b_d: Optional[Tensor] = None, V_d: Optional[Tensor] = None, depth: int = 3, act: str = "relu",
+            slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
+            keep: bool = False) -> tuple[Tensor, ForwardState]:
+    lib = _lib.load()
+    V = _f32c(V, "V")
+    E = _f32c(E, "E")
+    dev = V.device
+    nV, nE = plan.n_atoms, plan.n_edges
+    if V.shape[0] != nV or E.shape[0] != nE:
+        raise RuntimeError(f"forward: plan is for V={nV}, E={nE} but got V={V.shape[0]}, E={E.shape[0]}")
+    d_v, d_e, d_h = int(V.shape[1]), int(E.shape[1]), int(W_h.shape[0])
+    d_vd = int(V_d.shape[1]) if (W_d is not None and V_d is not None) else 0
+    ldh = (d_h + 3) // 4 * 4
+    n_steps = max(depth - 1, 0)
+    n_hslots = max(n_steps, 1) if keep else 1
+    n_mslots = max(n_steps, 1) if keep else 1
+
+    st = ForwardState()
+    st.plan, st.ldh, st.n_hslots, st.n_mslots = plan, ldh, n_hslots, n_mslots
+    edge_ws = torch.empty((1 + n_hslots + n_mslots, nE, ldh), dtype=torch.float32, device=dev)
+    atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
+    if ldh != d_h:  # pad columns are read by vector loads of later kernels: keep them finite
+        edge_ws.zero_()
+        atom_ws.zero_()
+    st.H0, st.Hs, st.Ms = edge_ws[0], edge_ws[1:1 + n_hslots], edge_ws[1 + n_hslots:]
+    st.Mv, st.Hv = atom_ws[0], atom_ws[1]
+    out = torch.empty(nV, d_h + d_vd, dtype=torch.float32, device=dev)
+    st.out = out
+
+    a = FwdArgs()
+    a.plan, a.n_atoms, a.n_edges = plan.buf.data_ptr(), nV, nE
+    a.d_v, a.d_e, a.d_h, a.d_vd = d_v, d_e, d_h, d_vd
+    a.depth, a.flags = int(depth), (F_UNDIRECTED if undirected else 0)
+    a.act, a.act_slope, a.act_slope_ptr = act_code(act), float(slope), _ptr(slope_t)
+    a.V, a.ldv = V.data_ptr(), V.stride(0)
+    a.E, a.lde = E.data_ptr(), E.stride(0)
+    if d_vd:
+        V_d = _f32c(V_d, "V_d")
+        a.V_d, a.ldvd = V_d.data_ptr(), V_d.stride(0)
+    Wc = lambda t, n: None if t is None else _f32c(t, n).contiguous()
+    W_i, W_h, W_o, b_o, b_i, b_h = Wc(W_i, "W_i"), Wc(W_h, "W_h"), Wc(W_o, "W_o"), Wc(b_o, "b_o"), Wc(b_i, "b_i"), Wc(b_h, "b_h")
+    a.W_i, a.b_i, a.W_h, a.b_h, a.W_o, a.b_o = _ptr(W_i), _ptr(b_i), _ptr(W_h), _ptr(b_h), _ptr(W_o), _ptr(b_o)
+    if d_vd:
+        W_d, b_d = Wc(W_d, "W_d"), Wc(b_d, "b_d")
+        a.W_d, a.b_d = _ptr(W_d), _ptr(b_d)
+    a.ldh, a.H0, a.Hs, a.n_hslots = ldh, st.H0.data_ptr(), st.Hs.data_ptr(), n_hslots
+    a.Ms, a.n_mslots = st.Ms.data_ptr(), n_mslots
+    a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
+    a.out, a.ldout = out.data_ptr(), out.stride(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
+    return out, st

@@ -1,0 +1,121 @@
+"""Host-side mirror of the reference's message-passing interface for the accelerated path.
+
+:class:`BondMessagePassing` has the constructor, attributes, parameter names/shapes (hence
+``state_dict`` keys), ``hparams`` and ``forward(bmg, V_d=None)`` contract of
+``chemprop.nn.BondMessagePassing`` (``chemprop/nn/message_passing/base.py:16-92,196-251``,
+interface ``proto.py:9-34``), so a state dict moves between the two unchanged, and the parity tests
+read like the reference's own.  Where chemprop itself is importable, use
+:mod:`chemprop_amd.integration` instead: it subclasses the *real* class and overrides only
+``forward``.
+
+``forward`` runs on the HIP kernels only.  Inputs on a non-HIP device raise (no CPU fallback).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import engine
+from .autograd import mp_forward
+
+DEFAULT_ATOM_FDIM, DEFAULT_BOND_FDIM = 72, 14  # chemprop/conf.py:8 (v2 featurizers)
+DEFAULT_HIDDEN_DIM = 300  # chemprop/conf.py:9
+
+
+class InvalidShapeError(ValueError):
+    """Mirror of ``chemprop/exceptions.py`` (raised for a mis-shaped ``V_d``, base.py:189-192)."""
+
+    def __init__(self, var_name, received, expected):
+        super().__init__(f"arg '{var_name}' has incorrect shape! got: `{tuple(received)}`. "
+                         f"expected: `{tuple(expected)}`")
+
+
+def get_activation_function(activation) -> nn.Module:
+    """``chemprop/nn/utils.py:19-55``."""
+    if isinstance(activation, nn.Module):
+        return activation
+    name = str(getattr(activation, "value", activation)).lower()
+    if name == "selu":
+        return nn.SELU()
+    try:
+        return {"relu": nn.ReLU, "leakyrelu": lambda: nn.LeakyReLU(0.1), "prelu": nn.PReLU,
+                "tanh": nn.Tanh, "elu": nn.ELU}[name]()
+    except KeyError:
+        raise ValueError(f"unknown activation {activation!r}") from None
+
+
+def classify_activation(tau: nn.Module) -> tuple[str, float, Optional[Tensor]]:
+    """Map a ``tau`` module to a kernel activation code: ``(name, slope, slope_tensor)``;
+    ``("custom", ...)`` means the module is applied by torch between the kernels."""
+    if type(tau) is nn.ReLU:
+        return "relu", 0.0, None
+    if type(tau) is nn.LeakyReLU and tau.negative_slope > 0:
+        return "leakyrelu", float(tau.negative_slope), None
+    if type(tau) is nn.PReLU and tau.weight.numel() == 1:
+        return "prelu", 0.0, tau.weight
+    if type(tau) is nn.Tanh:
+        return "tanh", 0.0, None
+    if type(tau) is nn.ELU and tau.alpha == 1.0:
+        return "elu", 0.0, None
+    return "custom", 0.0, None
+
+
+class _HParams(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class BondMessagePassing(nn.Module):
+    """Directed-bond message passing (D-MPNN encoder) on MI355X HIP kernels."""
+
+    def __init__(self, d_v: int = DEFAULT_ATOM_FDIM, d_e: int = DEFAULT_BOND_FDIM,
+                 d_h: int = DEFAULT_HIDDEN_DIM, bias: bool = False, depth: int = 3, dropout: float = 0.0,
+                 activation="relu", undirected: bool = False, d_vd: Optional[int] = None,
+                 V_d_transform: Optional[nn.Module] = None, graph_transform: Optional[nn.Module] = None):
+        super().__init__()
+        self.hparams = _HParams(d_v=d_v, d_e=d_e, d_h=d_h, bias=bias, depth=depth, dropout=dropout,
+                                activation=activation, undirected=undirected, d_vd=d_vd,
+                                V_d_transform=V_d_transform, graph_transform=graph_transform,
+                                cls=self.__class__)
+        # same construction order as base.py:238-251 -> same RNG stream -> same initial weights
+        self.W_i = nn.Linear(d_v + d_e, d_h, bias)
+        self.W_h = nn.Linear(d_h, d_h, bias)
+        self.W_o = nn.Linear(d_v + d_h, d_h)
+        self.W_d = nn.Linear(d_h + d_vd, d_h + d_vd) if d_vd else None
+        self.depth = depth
+        self.undirected = undirected
+        self.dropout = nn.Dropout(dropout)
+        self.tau = get_activation_function(activation)
+        self.V_d_transform = V_d_transform if V_d_transform is not None else nn.Identity()
+        self.graph_transform = graph_transform if graph_transform is not None else nn.Identity()
+
+    @property
+    def output_dim(self) -> int:
+        return self.W_d.out_features if self.W_d is not None else self.W_o.out_features
+
+    def forward(self, bmg, V_d: Optional[Tensor] = None) -> Tensor:
+        return bond_message_passing_forward(self, bmg, V_d)
+
+
+def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tensor:
+    """``_MessagePassingBase.forward`` (base.py:196-212) for any module with the reference's
+    attributes (``W_i, W_h, W_o, W_d, depth, undirected, dropout, tau, graph_transform,
+    V_d_transform``); shared by :class:`BondMessagePassing` and the chemprop subclass."""
+    bmg = mp.graph_transform(bmg)  # Identity, or eval-only scaling on a shallow copy (transforms.py:65-74)
+    engine._require_device(bmg.V, "bmg.V")
+    if mp.W_i.weight.device != bmg.V.device:
+        raise RuntimeError(f"module is on {mp.W_i.weight.device} but the batch is on {bmg.V.device}")
+    n_atoms = int(bmg.V.shape[0])
+    if V_d is not None:
+        V_d = mp.V_d_transform(V_d)
+        d_vd = (mp.W_d.in_features - mp.W_o.out_features) if mp.W_d is not None else None
+        if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
+            raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
+    plan = engine.GraphPlan.from_bmg(bmg)
+    return mp_forward(mp, plan, bmg.V, bmg.E, V_d)

@@ -1,0 +1,167 @@
+/*
+ * dmpnn.h — C ABI of the MI355X (gfx950) D-MPNN bond-message-passing engine.
+ *
+ * This is the drop-in boundary for ONE path of chemprop (v2.3.1):
+ *     chemprop.nn.BondMessagePassing.forward        chemprop/nn/message_passing/base.py:196-212
+ *       initialize / message (mixin)                chemprop/nn/message_passing/mixins.py:8-18
+ *       update                                      chemprop/nn/message_passing/base.py:135-141
+ *       finalize                                    chemprop/nn/message_passing/base.py:180-194
+ * chemprop has no native code and no FFI of its own (it issues ATen ops); the binding a maintainer
+ * would add is a ctypes (or pybind) stub inside a BondMessagePassing subclass — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross this boundary.
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors in practice) unless it
+ *     is a pointer to one of the argument structs below (host memory).
+ *   - matrices are row-major with an explicit leading dimension (elements, not bytes);
+ *     weights are in nn.Linear layout [out_features, in_features].
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*); no call synchronises,
+ *     allocates or frees device memory, so every call is hipGraph-capture safe.
+ *   - every function returns 0 on success, a negative DMPNN_E* code otherwise, never throws,
+ *     never exits; dmpnn_last_error_string() describes the last failure on the calling thread.
+ *   - dtype of the arithmetic is fp32 (fp32 MFMA v_mfma_f32_16x16x4_f32 for the contractions).
+ */
+#ifndef DMPNN_H
+#define DMPNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMPNN_ABI_VERSION 1
+
+enum dmpnn_status {
+    DMPNN_OK = 0,
+    DMPNN_EINVAL = -1,  /* bad argument (null pointer, negative size, unsupported option)        */
+    DMPNN_EHIP = -2,    /* a HIP runtime call failed; see dmpnn_last_error_string()             */
+    DMPNN_ENOSPC = -3   /* caller-provided workspace too small                                   */
+};
+
+/* tau of chemprop/nn/utils.py:19-55.  DMPNN_ACT_NONE lets the caller apply an arbitrary nn.Module
+ * itself (the kernels then emit pre-activations). */
+enum dmpnn_activation {
+    DMPNN_ACT_NONE = 0,
+    DMPNN_ACT_RELU = 1,
+    DMPNN_ACT_LEAKYRELU = 2, /* slope = act_slope (chemprop uses 0.1, nn/utils.py:47)            */
+    DMPNN_ACT_PRELU = 3,     /* slope read on device from *act_slope_ptr (single learnable scalar) */
+    DMPNN_ACT_TANH = 4,
+    DMPNN_ACT_ELU = 5        /* alpha = 1                                                         */
+};
+
+enum dmpnn_flags {
+    DMPNN_F_UNDIRECTED = 1u << 0 /* base.py:202-203: H <- (H + H[rev]) / 2 before every message()  */
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * K0  graph plan.  Replaces nothing in the reference (which rebuilds a dense [E,h] int64 index on
+ * every call, mixins.py:12 / base.py:208).  Converts the int64 COO arrays of a BatchMolGraph
+ * (chemprop/data/collate.py:13-73) to int32, builds the stable incoming-edge CSR by destination
+ * atom (row order = increasing edge id = the reference's sequential scatter order) and validates
+ * the graph invariants on device.  The plan is an opaque int32 blob in caller-owned device memory.
+ * ------------------------------------------------------------------------------------------- */
+size_t dmpnn_plan_bytes(int64_t n_atoms, int64_t n_edges);
+
+int dmpnn_prepare(const int64_t* edge_index, /* [2, n_edges] row 0 = src atom, row 1 = dst atom */
+                  const int64_t* rev_edge_index, /* [n_edges]                                   */
+                  int64_t n_atoms, int64_t n_edges, void* plan, size_t plan_bytes, void* stream);
+
+/* Plan header words (int32) readable by the caller after a stream sync (diagnostics/tests). */
+enum dmpnn_plan_hdr {
+    DMPNN_HDR_FLAGS = 0,   /* bit0: graph is NOT symmetric (rev is not an involution with
+                              src(rev e)==dst(e)): the general edge-form message kernel runs;
+                              bit1: an index was out of range (clamped; results undefined)      */
+    DMPNN_HDR_MAXDEG = 1,
+    DMPNN_HDR_NATOMS = 2,
+    DMPNN_HDR_NEDGES = 3,
+    DMPNN_HDR_WORDS = 16
+};
+/* Word offsets of the arrays inside the plan (for tests): src, dst, rev, row_ptr, perm. */
+int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t offsets_out[5]);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row kernels (each replaces the reference lines cited; exported for per-row parity tests and
+ * roofline measurement; dmpnn_forward below chains them).
+ * ------------------------------------------------------------------------------------------- */
+
+/* K2  mixins.py:11-18 (+ base.py:200 tau-on-load, + base.py:202-203 undirected):
+ *     Hin' = tau_in(Hin) [averaged with its reverse if undirected];
+ *     M[e] = sum_{e': dst(e') = src(e)} Hin'[e'] - Hin'[rev(e)]                                  */
+int dmpnn_message_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h,
+                      const float* Hin, int64_t ld_in, float* M, int64_t ld_m,
+                      int act_on_load, float act_slope, const float* act_slope_ptr,
+                      unsigned flags, void* stream);
+
+/* K4  base.py:208-211:  Mv[v] = sum_{e': dst(e') = v} tau_in(Hin[e'])                            */
+int dmpnn_aggregate_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h,
+                        const float* Hin, int64_t ld_in, float* Mv, int64_t ld_mv,
+                        int act_on_load, float act_slope, const float* act_slope_ptr, void* stream);
+
+/* Shared contraction (fp32 MFMA):
+ *     C[r, :] = act( [A1[g(r), 0:K1] || A2[r, 0:K2]] . W^T + bias + Cadd[r, :] ),  g = gather or id
+ *   K1  mixins.py:8-9     A1 = V gathered by src, A2 = E, W = W_i          act = none (H0 is pre-act)
+ *   K3  base.py:135-141   A1 = M, W = W_h, Cadd = H0                        act = tau
+ *   K5  base.py:180-183   A1 = V, A2 = Mv, W = W_o, bias = b_o              act = tau
+ *       base.py:185-188   A1 = H_v, A2 = V_d, W = W_d, bias = b_d           act = none
+ * Zpre (optional) receives the pre-activation (needed by the backward of PReLU / custom tau).   */
+typedef struct dmpnn_gemm_args {
+    int64_t M, N, K1, K2;
+    const float* A1; int64_t lda1; const int32_t* gather1; /* gather1 may be NULL                */
+    const float* A2; int64_t lda2;                          /* A2 may be NULL iff K2 == 0         */
+    const float* W;  int64_t ldw;                           /* [N, K1+K2]                         */
+    const float* bias;                                      /* [N] or NULL                        */
+    const float* Cadd; int64_t ldcadd;                      /* [M, N] or NULL                     */
+    float* C; int64_t ldc;                                  /* [M, N]                             */
+    float* Zpre; int64_t ldz;                               /* [M, N] or NULL                     */
+    int act; float act_slope; const float* act_slope_ptr;
+} dmpnn_gemm_args;
+int dmpnn_linear_fwd(const dmpnn_gemm_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole forward: base.py:196-212 for BondMessagePassing (graph_transform / V_d_transform /
+ * dropout are applied by the caller: they are torch modules outside the kernels).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dmpnn_fwd_args {
+    /* graph */
+    const void* plan; int64_t n_atoms, n_edges;
+    /* dimensions and options */
+    int64_t d_v, d_e, d_h, d_vd; int32_t depth; uint32_t flags;
+    int32_t act; float act_slope; const float* act_slope_ptr;
+    /* inputs */
+    const float* V; int64_t ldv;      /* [n_atoms, d_v]                                           */
+    const float* E; int64_t lde;      /* [n_edges, d_e]                                           */
+    const float* V_d; int64_t ldvd;   /* [n_atoms, d_vd] or NULL                                  */
+    /* parameters, nn.Linear layout */
+    const float* W_i; const float* b_i;   /* [d_h, d_v+d_e], [d_h] or NULL                        */
+    const float* W_h; const float* b_h;   /* [d_h, d_h],     [d_h] or NULL                        */
+    const float* W_o; const float* b_o;   /* [d_h, d_v+d_h], [d_h]                                */
+    const float* W_d; const float* b_d;   /* [d_h+d_vd, d_h+d_vd] or NULL                         */
+    /* caller-owned workspace, all with leading dimension ldh >= d_h:
+     *   H0      [n_edges, ldh]            pre-activation W_i(...)                                 *
+     *   Hs      n_hslots x [n_edges, ldh] H^(t) lives in slot t % n_hslots  (t = 1..depth-1);     *
+     *                                     n_hslots = depth-1 keeps every H^(t) for backward,      *
+     *                                     n_hslots = 2 ping-pongs (inference)                     *
+     *   Ms      n_mslots x [n_edges, ldh] message M^(t) in slot (t-1) % n_mslots                  *
+     *   Mv      [n_atoms, ldh]                                                                    *
+     *   Hv      [n_atoms, ldh]            only when W_d != NULL (tau(W_o(.)) before W_d)          */
+    int64_t ldh; float* H0; float* Hs; int32_t n_hslots; float* Ms; int32_t n_mslots;
+    float* Mv; float* Hv;
+    /* output [n_atoms, d_h (+ d_vd)] */
+    float* out; int64_t ldout;
+} dmpnn_fwd_args;
+int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Misc
+ * ------------------------------------------------------------------------------------------- */
+int dmpnn_version(void);
+const char* dmpnn_last_error_string(void);
+/* Number of kernels the last dmpnn_forward on this thread enqueued (diagnostics). */
+int dmpnn_last_launch_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMPNN_H */

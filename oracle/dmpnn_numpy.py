@@ -1,0 +1,202 @@
+"""ORACLE (test infrastructure, never shipped, never measured as the product).
+
+Second, independent CPU restatement of the same path in numpy, written in the *CSR / atom-centric
+form the HIP kernels use* rather than the scatter form the reference uses.  It exists to prove —
+on CPU, against the executed reference — that the restructured algorithm is the same function:
+
+  * stable counting sort of edges by destination  ->  ``row_ptr[V+1]``, ``perm[E]``
+    (reference has no counterpart; it re-derives a dense ``[E,h]`` int64 index every call,
+    ``mixins.py:12``, ``base.py:208``).  Stability keeps each atom's summation order equal to the
+    reference's sequential ``scatter_reduce_`` order (increasing edge id), so the segment sums are
+    bit-identical to ATen's on CPU.
+  * atom-centric message: for atom ``v`` with incoming edges ``e'_1..e'_d``:
+    ``S = ((H[e'_1] + H[e'_2]) + ...)``, then ``M[rev(e'_i)] = S - H[e'_i]``.  For a valid molecular
+    graph (``rev`` an involution with ``src(rev(e)) == dst(e)``) this equals
+    ``M[e] = S[src(e)] - H[rev(e)]`` (``mixins.py:11-18``) with every ``H`` row read exactly once.
+  * analytic backward of the whole block (what ``K6`` implements), checked against torch autograd of
+    :mod:`oracle.dmpnn_torch`.
+
+Only ``tests/`` may import this file.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def build_csr(dst: np.ndarray, n_atoms: int):
+    """Incoming-edge CSR by destination atom; stable (edge ids ascending inside a row)."""
+    dst = np.asarray(dst, dtype=np.int64)
+    perm = np.argsort(dst, kind="stable").astype(np.int64)
+    counts = np.bincount(dst, minlength=n_atoms).astype(np.int64)
+    row_ptr = np.zeros(n_atoms + 1, dtype=np.int64)
+    np.cumsum(counts, out=row_ptr[1:])
+    return row_ptr, perm
+
+
+def graph_is_symmetric(src, dst, rev) -> bool:
+    """The invariants every featurizer-produced graph satisfies: ``rev`` is an
+    involution and the reverse edge runs dst -> src."""
+    src, dst, rev = (np.asarray(a, dtype=np.int64) for a in (src, dst, rev))
+    if len(rev) == 0:
+        return True
+    if rev.min() < 0 or rev.max() >= len(rev):
+        return False
+    return bool(np.all(rev[rev] == np.arange(len(rev))) and np.all(src[rev] == dst) and np.all(dst[rev] == src))
+
+
+def segment_sum_csr(H: np.ndarray, row_ptr: np.ndarray, perm: np.ndarray) -> np.ndarray:
+    """S[v] = sum of H[perm[row_ptr[v]:row_ptr[v+1]]] taken left to right in float32."""
+    n_atoms = len(row_ptr) - 1
+    S = np.zeros((n_atoms, H.shape[1]), dtype=H.dtype)
+    deg = np.diff(row_ptr)
+    for r in range(int(deg.max()) if n_atoms and len(perm) else 0):
+        rows = np.flatnonzero(deg > r)
+        e = perm[row_ptr[rows] + r]
+        if r == 0:
+            S[rows] = H[e]  # include_self=False: the first addend is copied, not added to 0
+        else:
+            S[rows] = S[rows] + H[e]
+    return S
+
+
+def message_edge_form(H, src, rev, row_ptr, perm):
+    """mixins.py:11-18 literally: M[e] = S[src(e)] - H[rev(e)]."""
+    S = segment_sum_csr(H, row_ptr, perm)
+    return S[src] - H[rev]
+
+
+def message_atom_form(H, rev, row_ptr, perm):
+    """Atom-centric form used by the HIP kernel (valid graphs): M[rev(e')] = S[dst(e')] - H[e']."""
+    S = segment_sum_csr(H, row_ptr, perm)
+    dst_of = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr))  # dst of perm[k]
+    M = np.empty_like(H)
+    M[rev[perm]] = S[dst_of] - H[perm]
+    return M
+
+
+def _act(name, x, slope=None):
+    name = str(name).lower()
+    if name == "relu":
+        return np.maximum(x, 0)
+    if name == "leakyrelu":
+        return np.where(x > 0, x, np.float32(0.1) * x)
+    if name == "prelu":
+        return np.where(x > 0, x, np.float32(0.25 if slope is None else slope) * x)
+    if name == "tanh":
+        return np.tanh(x)
+    if name == "elu":
+        return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+    if name in ("identity", "none"):
+        return x
+    raise ValueError(name)
+
+
+def _act_grad(name, z, y, slope=None):
+    """d tau / dz given pre-activation z and output y."""
+    name = str(name).lower()
+    one = np.ones_like(z)
+    if name == "relu":
+        return (z > 0).astype(z.dtype)
+    if name == "leakyrelu":
+        return np.where(z > 0, one, np.float32(0.1) * one)
+    if name == "prelu":
+        return np.where(z > 0, one, np.float32(0.25 if slope is None else slope) * one)
+    if name == "tanh":
+        return 1 - y * y
+    if name == "elu":
+        return np.where(z > 0, one, y + 1)
+    if name in ("identity", "none"):
+        return one
+    raise ValueError(name)
+
+
+def forward(V, E, edge_index, rev, W, depth=3, activation="relu", undirected=False, V_d=None,
+            atom_form=True, keep=False):
+    """``W`` is a dict with W_i, W_h, W_o, b_o and optional b_i, b_h, W_d, b_d (``[out,in]``)."""
+    V = np.asarray(V, np.float32)
+    E = np.asarray(E, np.float32)
+    src = np.asarray(edge_index[0], np.int64)
+    dst = np.asarray(edge_index[1], np.int64)
+    rev = np.asarray(rev, np.int64)
+    nV = V.shape[0]
+    row_ptr, perm = build_csr(dst, nV)
+    use_atom = atom_form and graph_is_symmetric(src, dst, rev)
+    f32 = lambda k: None if W.get(k) is None else np.asarray(W[k], np.float32)
+    W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d = (f32(k) for k in ("W_i", "W_h", "W_o", "b_o", "b_i", "b_h", "W_d", "b_d"))
+    X = np.concatenate([V[src], E], axis=1)
+    H0 = X @ W_i.T
+    if b_i is not None:
+        H0 = H0 + b_i
+    H = _act(activation, H0)
+    saved = {"X": X, "H0": H0, "Hs": [H], "Ms": [], "Zs": [H0], "Hbar": []}
+    for _ in range(1, depth):
+        Hb = (H + H[rev]) / np.float32(2) if undirected else H
+        M = message_atom_form(Hb, rev, row_ptr, perm) if use_atom else message_edge_form(Hb, src, rev, row_ptr, perm)
+        Z = M @ W_h.T
+        if b_h is not None:
+            Z = Z + b_h
+        Z = H0 + Z
+        H = _act(activation, Z)
+        saved["Ms"].append(M); saved["Zs"].append(Z); saved["Hs"].append(H); saved["Hbar"].append(Hb)
+    Mv = segment_sum_csr(H, row_ptr, perm)
+    XO = np.concatenate([V, Mv], axis=1)
+    ZO = XO @ W_o.T + b_o
+    HO = _act(activation, ZO)
+    out = HO
+    if V_d is not None:
+        XD = np.concatenate([HO, np.asarray(V_d, np.float32)], axis=1)
+        out = XD @ W_d.T + b_d
+        saved["XD"] = XD
+    if keep:
+        saved.update(Mv=Mv, XO=XO, ZO=ZO, HO=HO, row_ptr=row_ptr, perm=perm, src=src, dst=dst, rev=rev)
+        return out, saved
+    return out
+
+
+def backward(gout, saved, W, depth=3, activation="relu", undirected=False, has_Vd=False):
+    """Analytic gradient of ``sum(out * gout)`` w.r.t. the parameters (float64 accumulation is NOT
+    used: this mirrors the fp32 kernels).  Derivation (SURVEY §7 'Backward of message'):
+
+      S[v] = sum_{dst(e)=v} H[e],  M[e] = S[src(e)] - H[rev(e)]
+      => gH[e'] = gS[dst(e')] - gM[rev(e')],   gS[v] = sum_{src(e)=v} gM[e]
+    """
+    g = {}
+    src, dst, rev = saved["src"], saved["dst"], saved["rev"]
+    nV = len(saved["row_ptr"]) - 1
+    h = W["W_h"].shape[0]
+    W_o = np.asarray(W["W_o"], np.float32)
+    W_h = np.asarray(W["W_h"], np.float32)
+    gout = np.asarray(gout, np.float32)
+    if has_Vd:
+        W_d = np.asarray(W["W_d"], np.float32)
+        g["W_d"] = gout.T @ saved["XD"]
+        g["b_d"] = gout.sum(0)
+        gHO = (gout @ W_d)[:, :h]
+    else:
+        gHO = gout
+    gZO = gHO * _act_grad(activation, saved["ZO"], saved["HO"])
+    g["W_o"] = gZO.T @ saved["XO"]
+    g["b_o"] = gZO.sum(0)
+    d_v = saved["XO"].shape[1] - h
+    gMv = (gZO @ W_o)[:, d_v:]
+    gH = gMv[dst]  # final aggregation: every edge receives its destination atom's gradient
+    gH0 = np.zeros_like(saved["H0"])
+    g["W_h"] = np.zeros_like(W_h)
+    if W.get("b_h") is not None:
+        g["b_h"] = np.zeros(h, np.float32)
+    for t in range(depth - 1, 0, -1):
+        gZ = gH * _act_grad(activation, saved["Zs"][t], saved["Hs"][t])
+        g["W_h"] += gZ.T @ saved["Ms"][t - 1]
+        if "b_h" in g:
+            g["b_h"] += gZ.sum(0)
+        gH0 += gZ
+        gM = gZ @ W_h
+        gS = np.zeros((nV, h), np.float32)
+        np.add.at(gS, src, gM)
+        gHb = gS[dst] - gM[rev]
+        gH = (gHb + gHb[rev]) / np.float32(2) if undirected else gHb
+    gH0 += gH * _act_grad(activation, saved["Zs"][0], saved["Hs"][0])
+    g["W_i"] = gH0.T @ saved["X"]
+    if W.get("b_i") is not None:
+        g["b_i"] = gH0.sum(0)
+    return g

@@ -1,0 +1,113 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+class Golden:
+    """One frozen case of tests/golden/*.npz (made by tests/golden/make_golden.py from the executed reference)."""
+
+    def __init__(self, path):
+        z = np.load(path)
+        self.arr = {k: z[k] for k in z.files}
+        self.meta = json.loads(bytes(self.arr.pop("meta")).decode())
+        self.name = self.meta["name"]
+        self.cfg = self.meta["cfg"]
+
+    def __getitem__(self, k):
+        return self.arr[k]
+
+    def __contains__(self, k):
+        return k in self.arr
+
+    def weights(self):
+        """state_dict of the block as numpy (stored, or regenerated from the seed and sha-checked)."""
+        import hashlib
+
+        import torch
+
+        stored = {k[2:]: v for k, v in self.arr.items() if k.startswith("w.")}
+        if not stored:
+            from chemprop_amd.nn import BondMessagePassing
+
+            torch.manual_seed(self.meta["seed"])
+            mp = BondMessagePassing(**self.cfg)
+            stored = {k: v.detach().numpy() for k, v in mp.state_dict().items()}
+        m = hashlib.sha256()
+        for k in sorted(stored):
+            m.update(k.encode())
+            m.update(np.ascontiguousarray(stored[k], dtype=np.float32).tobytes())
+        assert m.hexdigest() == self.meta["weights_sha"], f"{self.name}: weights do not match the golden sha (RNG drift?)"
+        return stored
+
+    def module(self, device="cpu"):
+        import torch
+
+        from chemprop_amd.nn import BondMessagePassing
+
+        mp = BondMessagePassing(**self.cfg)
+        mp.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in self.weights().items()})
+        return mp.eval().to(device)
+
+    def bmg(self, device="cpu"):
+        import torch
+
+        from chemprop_amd.data import BatchMolGraph
+
+        t = lambda k: torch.from_numpy(self.arr[k])
+        b = BatchMolGraph.from_tensors(t("V"), t("E"), t("edge_index"), t("rev_edge_index"), t("batch"), self.meta["n_mols"])
+        if device != "cpu":
+            b.to(device)
+        return b
+
+
+def golden_paths():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_ids():
+    return [os.path.basename(p)[:-4] for p in golden_paths()]
+
+
+@pytest.fixture(params=golden_paths(), ids=golden_ids())
+def golden(request):
+    return Golden(request.param)
+
+
+def parity_err(got, ref):
+    """Norm-wise relative error of SURVEY §8(d): max|got-ref| / max(1, max|ref|)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"shape {got.shape} != {ref.shape}"
+    if ref.size == 0:
+        return 0.0
+    return float(np.max(np.abs(got - ref)) / max(1.0, float(np.max(np.abs(ref)))))
+
+
+TOL = 1e-5  # BASELINE.json north_star: "<= 1e-5 relative fp32"
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("`-m gpu` tests need a HIP device (torch.cuda.is_available() is False); "
+                    "they never fall back to CPU")
+    from chemprop_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")

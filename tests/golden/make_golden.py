@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Freeze golden vectors from the EXECUTED reference (run in the build container only).
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+
+Every case runs the reference's own ``chemprop.nn.BondMessagePassing`` (imported from
+``/root/reference`` through ``oracle/ref_shim.py``; CPU torch, fp32, eval mode, dropout 0) on a
+``chemprop.data.BatchMolGraph`` built by the reference's own collate code, and stores
+
+  inputs   V, E, edge_index, rev_edge_index, batch, [V_d]
+  weights  every parameter of the block (also reproducible from ``seed``; ``weights_sha`` pins them)
+  outputs  out = forward(bmg, V_d); H0 = initialize(bmg); M1 = message(tau(H0), bmg) (depth >= 2);
+           Mv = the final atom aggregation; grads of ``sum(out * G)`` w.r.t. every parameter.
+
+``/root/reference`` does not exist on the GPU box: the tests read only the ``.npz`` files.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from chemprop_amd import synth  # noqa: E402
+from chemprop_amd.data import MolGraph  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def weights_sha(named: dict) -> str:
+    m = hashlib.sha256()
+    for k in sorted(named):
+        m.update(k.encode())
+        m.update(np.ascontiguousarray(named[k], dtype=np.float32).tobytes())
+    return m.hexdigest()
+
+
+def single_atoms(n, d_v=72, d_e=14):
+    return [MolGraph(np.ones((1, d_v), np.float32) * (i + 1) / n, np.zeros((0, d_e), np.float32),
+                     np.zeros((2, 0), np.int64), np.zeros(0, np.int64)) for i in range(n)]
+
+
+def star(n_leaves, d_v, d_e, seed):
+    rng = np.random.default_rng(seed)
+    V = rng.standard_normal((n_leaves + 1, d_v)).astype(np.float32)
+    Eb = rng.standard_normal((n_leaves, d_e)).astype(np.float32)
+    src = np.stack([np.zeros(n_leaves, np.int64), np.arange(1, n_leaves + 1)], 1).ravel()
+    dst = np.stack([np.arange(1, n_leaves + 1), np.zeros(n_leaves, np.int64)], 1).ravel()
+    rev = np.arange(2 * n_leaves).reshape(-1, 2)[:, ::-1].ravel()
+    return MolGraph(V, np.repeat(Eb, 2, 0), np.stack([src, dst]), rev)
+
+
+def tiny_pair():
+    """3-atom + 2-atom molecules with 1-dim features (cf. tests/unit/data/test_dataloader.py:10-45)."""
+    mg1 = MolGraph(np.array([[1.0], [2.0], [3.0]], np.float32), np.array([[4.0], [4.0], [5.0], [5.0]], np.float32),
+                   np.array([[0, 1, 1, 2], [1, 0, 2, 1]]), np.array([1, 0, 3, 2]))
+    mg2 = MolGraph(np.array([[6.0], [7.0]], np.float32), np.array([[8.0], [8.0]], np.float32),
+                   np.array([[0, 1], [1, 0]]), np.array([1, 0]))
+    return [mg1, mg2]
+
+
+def garbage(seed, n_atoms=9, n_edges=20, d_v=10, d_e=6):
+    """Indices in range but NOT a symmetric graph: rev is a random map, edges are random pairs."""
+    rng = np.random.default_rng(seed)
+    return [MolGraph(rng.standard_normal((n_atoms, d_v)).astype(np.float32),
+                     rng.standard_normal((n_edges, d_e)).astype(np.float32),
+                     rng.integers(0, n_atoms, size=(2, n_edges)), rng.integers(0, n_edges, size=n_edges))]
+
+
+CASES = {
+    # name: (molgraph builder, block kwargs, seed)
+    "chain5x2_default": (lambda: [synth.chain_molgraph(5)] * 2, dict(), 0),
+    "tiny_pair_h7": (tiny_pair, dict(d_v=1, d_e=1, d_h=7, depth=3), 1),
+    "no_edges": (lambda: single_atoms(4), dict(d_h=32), 2),
+    "qm9x8_h300": (lambda: synth.random_molgraphs(8, "qm9", seed=3), dict(), 3),
+    "block_h64": (lambda: synth.random_molgraphs(6, "qm9", seed=4, layout="block"), dict(d_h=64), 4),
+    "shuffled_h100_d4": (lambda: synth.random_molgraphs(5, "zinc", seed=5, layout="shuffled"), dict(d_h=100, depth=4), 5),
+    "undirected_h48": (lambda: synth.random_molgraphs(6, "qm9", seed=6), dict(d_h=48, undirected=True), 6),
+    "bias_h36": (lambda: synth.random_molgraphs(6, "qm9", seed=7), dict(d_h=36, bias=True), 7),
+    "vd5_h32": (lambda: synth.random_molgraphs(6, "qm9", seed=8), dict(d_h=32, d_vd=5), 8),
+    "leakyrelu_h40": (lambda: synth.random_molgraphs(5, "qm9", seed=9), dict(d_h=40, activation="leakyrelu"), 9),
+    "prelu_h40": (lambda: synth.random_molgraphs(5, "qm9", seed=10), dict(d_h=40, activation="prelu"), 10),
+    "tanh_h40": (lambda: synth.random_molgraphs(5, "qm9", seed=11), dict(d_h=40, activation="tanh"), 11),
+    "elu_h40": (lambda: synth.random_molgraphs(5, "qm9", seed=12), dict(d_h=40, activation="elu"), 12),
+    "depth1_h52": (lambda: synth.random_molgraphs(5, "qm9", seed=13), dict(d_h=52, depth=1), 13),
+    "depth2_h52": (lambda: synth.random_molgraphs(5, "qm9", seed=14), dict(d_h=52, depth=2), 14),
+    "depth6_h52": (lambda: synth.random_molgraphs(5, "zinc", seed=15), dict(d_h=52, depth=6), 15),
+    "cgr_h128": (lambda: synth.random_molgraphs(6, "cgr", seed=16), dict(d_v=106, d_e=28, d_h=128), 16),
+    "garbage_h24": (lambda: garbage(17), dict(d_v=10, d_e=6, d_h=24), 17),
+    "star12_h20": (lambda: [star(12, 9, 5, 18), star(7, 9, 5, 19)], dict(d_v=9, d_e=5, d_h=20), 18),
+    "mixed_single_h44": (lambda: synth.random_molgraphs(3, "qm9", seed=20) + single_atoms(2) + synth.random_molgraphs(2, "qm9", seed=21),
+                         dict(d_h=44), 20),
+    "synth40x4_h300": (lambda: synth.random_molgraphs(4, "synth40", seed=22), dict(), 22),
+}
+
+
+def run_case(name, build, kw, seed, BMP, BMG, trained=None):
+    mgs = build()
+    bmg = BMG(mgs)
+    torch.manual_seed(seed)
+    mp = BMP(**kw)
+    if trained is not None:
+        mp.load_state_dict(trained)
+    mp.eval()
+    d_vd = kw.get("d_vd")
+    gen = torch.Generator().manual_seed(1000 + seed)
+    V_d = torch.randn(bmg.V.shape[0], d_vd, generator=gen) if d_vd else None
+
+    out = mp(bmg, V_d)
+    G = torch.randn(out.shape, generator=gen)
+    mp.zero_grad()
+    (out * G).sum().backward()
+    with torch.no_grad():
+        H0 = mp.initialize(bmg)
+        arrs = dict(V=bmg.V.numpy(), E=bmg.E.numpy(), edge_index=bmg.edge_index.numpy(),
+                    rev_edge_index=bmg.rev_edge_index.numpy(), batch=bmg.batch.numpy(),
+                    out=out.detach().numpy(), G=G.numpy(), H0=H0.numpy())
+        if mp.depth >= 2 and not mp.undirected:
+            arrs["M1"] = mp.message(mp.tau(H0), bmg).numpy()
+        # Mv: replay the loop with the reference's own methods
+        H = mp.tau(H0)
+        for _ in range(1, mp.depth):
+            if mp.undirected:
+                H = (H + H[bmg.rev_edge_index]) / 2
+            H = mp.update(mp.message(H, bmg), H0)
+        idx = bmg.edge_index[1].unsqueeze(1).repeat(1, H.shape[1])
+        arrs["Mv"] = torch.zeros(bmg.V.shape[0], H.shape[1]).scatter_reduce_(0, idx, H, reduce="sum", include_self=False).numpy()
+        arrs["H_last"] = H.numpy()
+    if V_d is not None:
+        arrs["V_d"] = V_d.numpy()
+    weights = {k: v.detach().numpy() for k, v in mp.state_dict().items()}
+    for k, v in weights.items():
+        arrs["w." + k] = v
+    n_w = sum(v.size for v in weights.values())
+    big = n_w > 40_000
+    for k, p in mp.named_parameters():
+        g = p.grad.numpy() if p.grad is not None else np.zeros_like(p.detach().numpy())
+        if big and g.size > 4096:
+            # pin big gradients by 2048 sampled entries (indices reproducible from the seed) + sums
+            idx = np.random.default_rng(seed).choice(g.size, size=2048, replace=False)
+            arrs["gs." + k] = g.ravel()[idx]
+            arrs["gsum." + k] = np.array([g.sum(dtype=np.float64), np.abs(g).sum(dtype=np.float64)])
+        else:
+            arrs["g." + k] = g
+    if big:
+        for k in ("H0", "M1", "H_last"):
+            arrs.pop(k, None)
+    cfg = dict(kw)
+    cfg.setdefault("d_v", 72); cfg.setdefault("d_e", 14); cfg.setdefault("d_h", 300)
+    cfg.setdefault("depth", 3); cfg.setdefault("bias", False); cfg.setdefault("undirected", False)
+    cfg.setdefault("activation", "relu"); cfg.setdefault("d_vd", None)
+    meta = dict(name=name, seed=seed, cfg=cfg, n_mols=len(mgs), weights_sha=weights_sha(weights),
+                trained=trained is not None, torch=torch.__version__, out_sum=float(out.detach().sum()))
+    arrs["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    # large random weights are reproducible from the seed: drop them, keep the sha
+    if big and trained is None:
+        for k in weights:
+            del arrs["w." + k]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(f"{name:24s} V={bmg.V.shape[0]:4d} E={bmg.E.shape[0]:4d} out_sum={meta['out_sum']:.6f} "
+          f"{'seeded' if (big and trained is None) else 'stored'}")
+
+
+def main():
+    BMP, BMG, _ = ref_shim.load_reference()
+    torch.set_num_threads(1)
+    for name, (build, kw, seed) in CASES.items():
+        run_case(name, build, kw, seed, BMP, BMG)
+    # trained weights from the reference's own fixture checkpoint (realistic weight distribution)
+    ck = os.path.join(ref_shim.REFERENCE_ROOT, "tests", "data", "example_model_v2_regression_mol.pt")
+    if os.path.isfile(ck):
+        d = torch.load(ck, map_location="cpu", weights_only=False)
+        sd = {k[len("message_passing."):]: v for k, v in d["state_dict"].items() if k.startswith("message_passing.")}
+        run_case("trained_v2_mol", lambda: synth.random_molgraphs(12, "qm9", seed=30), dict(), 30, BMP, BMG, trained=sd)
+
+
+if __name__ == "__main__":
+    main()
