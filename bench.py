@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the accelerated path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mols 512] [--kind qm9] [--mode fwd|train]
+
+A *step* is one pass of the hot path — ``BondMessagePassing.forward`` (graph plan K0 + K1..K5,
+chemprop/nn/message_passing/base.py:196-212) — over one batch of synthetic QM9-shaped molecules that
+is already resident in HBM (BASELINE.json configs[1]: depth 3, hidden 300, batch 512 molecules per
+GPU).  ``--mode train`` adds the backward pass (K6) and, for N > 1, the RCCL gradient all-reduce.
+The metric is BASELINE.json's: million directed-edge-updates / s = E * (depth - 1) / t.
+
+For N > 1 the driver launches one process per GPU (torch.distributed.run); molecules are sharded
+across ranks (every rank owns its own batch: weak scaling) and the forward needs no collective.
+
+Rank 0 prints ONE JSON line, with two extra objects:
+  roofline      dominant kernel (fp32-MFMA `k_linear`, the W_h contraction) timed live with HIP
+                events on the launch stream: achieved = algorithmic FLOP / mean launch time
+  cpu_baseline  the oracle (same ATen op sequence as the reference) timed on the host cores,
+                bounded to ~15 s (kind "port")
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TF = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0      # spec; 6290 GB/s measured copy ceiling (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mols", type=int, default=512, help="molecules per GPU per step")
+    ap.add_argument("--kind", default="qm9", choices=["qm9", "zinc", "synth40", "cgr"])
+    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--hidden", type=int, default=300)
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"])
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches only (no hipGraph replay)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def time_events(fn, reps, torch):
+    """Mean device time of ``fn`` in ms, HIP events on the current (= launch) stream."""
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from chemprop_amd import _lib, engine, synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    _lib.load()
+
+    # ---- workload: this rank's shard (molecules hash-partitioned by id -> independent batches) ----
+    bmg = synth.random_batch(args.mols, args.kind, seed=1000 + rank)
+    d_v, d_e = int(bmg.V.shape[1]), int(bmg.E.shape[1])
+    torch.manual_seed(0)
+    mp = BondMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth)
+    cpu_state = {k: v.clone() for k, v in mp.state_dict().items()}
+    mp = mp.to(dev)
+    cpu_bmg = synth.random_batch(args.mols, args.kind, seed=1000 + rank) if rank == 0 else None
+    bmg.to(dev)
+    nV, nE = int(bmg.V.shape[0]), int(bmg.E.shape[0])
+    updates = nE * (args.depth - 1)
+
+    train = args.mode == "train"
+    if train:
+        from chemprop_amd import distributed as ddp
+
+        mp.train()
+        params = [p for p in mp.parameters()]
+        G = torch.randn(nV, mp.output_dim, device=dev)
+
+        def step():
+            for p in params:
+                p.grad = None
+            out = mp(bmg)
+            out.backward(G)
+            if world > 1:
+                ddp.allreduce_grads(params)
+    else:
+        mp.eval()
+
+        def step():
+            with torch.no_grad():
+                return mp(bmg)
+
+    def run_steps(fn, n):
+        for _ in range(n):
+            fn()
+
+    def timed(fn, n):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(fn, n)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # ---- eager: W warm-up steps, then exactly K timed steps ----
+    run_steps(step, args.warmup)
+    eager_s = timed(step, args.steps)
+    eager_ms = eager_s / args.steps * 1e3
+
+    # ---- hipGraph replay of the same step (launch-bound regime: 512 molecules ~ 10 short kernels) ----
+    graph_ms, graph_err = None, None
+    if not args.no_graph and not (train and world > 1):
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                run_steps(step, 3)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            run_steps(g.replay, args.warmup)
+            graph_ms = timed(g.replay, args.steps) / args.steps * 1e3
+        except Exception as e:  # report, never hide
+            graph_err = f"{type(e).__name__}: {e}"[:300]
+    ms_per_step = min(eager_ms, graph_ms) if graph_ms is not None else eager_ms
+    value = world * updates / (ms_per_step * 1e-3) / 1e6
+
+    out = {
+        "metric": "million directed-edge-updates/sec (depth=%d, hidden=%d)" % (args.depth, args.hidden),
+        "value": round(value, 3), "unit": "M edge-updates/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.kind}-shaped synthetic molecules, {args.mols} mols/GPU/step, "
+                               f"BondMessagePassing depth={args.depth} hidden={args.hidden}, "
+                               + ("forward+backward" + ("+RCCL grad all-reduce" if world > 1 else "") if train else "forward (plan K0 + K1..K5)"),
+                   "mols_per_gpu": args.mols, "atoms_per_gpu": nV, "directed_edges_per_gpu": nE,
+                   "parallelism": f"dp{world} (molecule shards, no data-path collective)",
+                   "launch": "hipGraph replay" if (graph_ms is not None and graph_ms <= eager_ms) else "eager"},
+        "eager_ms_per_step": round(eager_ms, 5),
+        "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 5),
+        "edges_per_s_M": round(world * nE / (ms_per_step * 1e-3) / 1e6, 3),
+    }
+    if graph_err:
+        out["graph_error"] = graph_err
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the W_h contraction (K3), live HIP-event timing ----
+        h = args.hidden
+        Mbuf = torch.randn(nE, h, device=dev)
+        H0buf = torch.randn(nE, h, device=dev)
+        Cbuf = torch.empty(nE, h, device=dev)
+        Wh = mp.W_h.weight.detach()
+        k3 = lambda: engine.linear(Mbuf, Wh, None, Cadd=H0buf, act="relu", out=Cbuf)
+        run_steps(k3, 10)
+        t_k3 = time_events(k3, 50, torch)
+        flops = 2.0 * nE * h * h
+        achieved = flops / (t_k3 * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_linear (K3 update: H = relu(H0 + M @ W_h^T), fp32 MFMA 16x16x4)",
+                           "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TF,
+                           "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TF, 4), "traffic": None,
+                           "launch_us": round(t_k3 * 1e3, 3), "flop_per_launch": flops}
+        # ---- the scatter/gather step (K2) against the HBM roofline, same batch and a >L3 batch ----
+        plan = engine.GraphPlan.from_bmg(bmg)
+        Hbuf = torch.randn(nE, h, device=dev)
+        Mout = torch.empty(nE, h, device=dev)
+        k2 = lambda: engine.message(plan, Hbuf, out=Mout)
+        run_steps(k2, 10)
+        t_k2 = time_events(k2, 50, torch)
+        bytes_k2 = 2.0 * nE * h * 4 + 3.0 * nE * 4
+        gbs = bytes_k2 / (t_k2 * 1e-3) / 1e9
+        out["roofline_scatter"] = {"kernel": "k_segment<message> (K2)", "bound": "hbm", "achieved": round(gbs, 1),
+                                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                   "traffic": None, "launch_us": round(t_k2 * 1e3, 3), "bytes_per_launch": bytes_k2,
+                                   "note": "working set fits the 256 MiB Infinity Cache at this batch"}
+        try:
+            big = synth.random_batch(32768, args.kind, seed=5)
+            big.to(dev)
+            bplan = engine.GraphPlan.from_bmg(big)
+            bE = int(big.E.shape[0])
+            Hb = torch.randn(bE, h, device=dev)
+            Mb = torch.empty(bE, h, device=dev)
+            k2b = lambda: engine.message(bplan, Hb, out=Mb)
+            run_steps(k2b, 3)
+            t_b = time_events(k2b, 10, torch)
+            bb = 2.0 * bE * h * 4 + 3.0 * bE * 4
+            gb = bb / (t_b * 1e-3) / 1e9
+            out["roofline_scatter_large"] = {"kernel": "k_segment<message> (K2), 32768 mols", "bound": "hbm",
+                                             "achieved": round(gb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                             "frac": round(gb / PEAK_HBM_GBS, 4), "traffic": None,
+                                             "launch_us": round(t_b * 1e3, 3), "bytes_per_launch": bb,
+                                             "directed_edges": bE}
+            del big, bplan, Hb, Mb
+        except Exception as e:
+            out["roofline_scatter_large"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
+        # ---- CPU baseline: the oracle (reference op sequence) on the host cores, bounded sample ----
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import dmpnn_torch as ot
+
+            cpu_mp = BondMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth)
+            cpu_mp.load_state_dict(cpu_state)
+            w = ot.MPWeights.from_module(cpu_mp)
+            cores = torch.get_num_threads()
+
+            def cpu_step():
+                if train:
+                    for t in (w.W_i, w.W_h, w.W_o, w.b_o):
+                        t.requires_grad_(True)
+                        t.grad = None
+                    o = ot.forward_bmg(cpu_bmg, w, depth=args.depth)
+                    o.sum().backward()
+                else:
+                    with torch.no_grad():
+                        ot.forward_bmg(cpu_bmg, w, depth=args.depth)
+
+            cpu_step(); cpu_step()
+            times = []
+            t_end = time.perf_counter() + args.cpu_seconds
+            while time.perf_counter() < t_end or len(times) < 5:
+                t0 = time.perf_counter()
+                cpu_step()
+                times.append(time.perf_counter() - t0)
+            times.sort()
+            med = times[len(times) // 2]
+            out["cpu_baseline"] = {"value": round(updates / med / 1e6, 4), "unit": "M edge-updates/s",
+                                   "cores": cores, "kind": "port",
+                                   "sample": f"{len(times)} repetitions (~{args.cpu_seconds:.0f} s) of the same "
+                                             f"{args.mols}-molecule batch, oracle/dmpnn_torch.py (the reference's ATen op "
+                                             f"sequence), torch {torch.__version__} CPU, median; best "
+                                             f"{updates / times[0] / 1e6:.4f}",
+                                   "ms_per_step": round(med * 1e3, 3)}
+            out["speedup_vs_cpu"] = round(value / (updates / med / 1e6), 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""The C-ABI library builds, loads and exports every symbol include/dmpnn.h declares; argument
+validation returns error codes (never throws / exits).  No compute call is made here (no GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from chemprop_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "dmpnn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmpnn_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dmpnn.h but not exported"
+    assert set(_lib.EXPORTS) == set(names), set(_lib.EXPORTS) ^ set(names)
+
+
+def test_version_and_plan_bytes():
+    lib = _lib.load()
+    assert lib.dmpnn_version() == 1
+    assert lib.dmpnn_plan_bytes(0, 0) >= 64
+    b = lib.dmpnn_plan_bytes(4319, 8328)
+    assert b % 16 == 0 and b >= 4 * (16 + 4 * 8328 + 2 * 4319)
+    off = (C.c_int64 * 5)()
+    assert lib.dmpnn_plan_layout(10, 20, off) == 0
+    assert list(off) == sorted(off) and all(o % 4 == 0 for o in off)
+
+
+def test_argument_errors_are_codes_not_crashes():
+    lib = _lib.load()
+    assert lib.dmpnn_forward(None, None) == -1
+    assert b"null args" in lib.dmpnn_last_error_string()
+    assert lib.dmpnn_linear_fwd(None, None) == -1
+    assert lib.dmpnn_prepare(None, None, 4, 8, None, 0, None) == -1
+    assert lib.dmpnn_prepare(None, None, -1, 8, None, 0, None) == -1
+    assert lib.dmpnn_message_fwd(None, 1, 1, 4, None, 4, None, 4, 0, 0.0, None, 0, None) == -1
+    a = _lib.FwdArgs()
+    a.plan = 16  # non-null dummy; validation must stop before any dereference
+    a.n_atoms, a.n_edges, a.d_v, a.d_e, a.d_h, a.depth, a.act = 1, 0, 4, 2, 8, 3, 0
+    assert lib.dmpnn_forward(C.byref(a), None) == -1
+    assert b"activation" in lib.dmpnn_last_error_string()
+
+
+def test_struct_layout_matches_header_field_order():
+    """ctypes mirrors must list the fields in the order of the C structs."""
+    src = open(os.path.join(ROOT, "include", "dmpnn.h")).read()
+    for struct, mirror in (("dmpnn_gemm_args", _lib.GemmArgs), ("dmpnn_fwd_args", _lib.FwdArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), src, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                fields.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
+        assert fields == [f[0] for f in mirror._fields_], struct
+
+
+def test_build_is_gfx950_only():
+    import subprocess
+
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],
+                         capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("llvm-objdump --offloading unavailable")
+    assert "gfx950" in out.stdout
+    assert "gfx942" not in out.stdout and "gfx90a" not in out.stdout

@@ -1,0 +1,111 @@
+"""Host logic: the BatchMolGraph / BondMessagePassing mirrors follow the reference contract."""
+import numpy as np
+import pytest
+import torch
+
+from chemprop_amd import synth
+from chemprop_amd.data import BatchMolGraph, MolGraph
+from chemprop_amd.nn import BondMessagePassing, classify_activation
+from oracle import dmpnn_numpy as onp
+from oracle import ref_shim
+
+
+def test_batching_semantics():
+    """collate.py:37-62: offsets, dtypes, batch vector, len()."""
+    mgs = synth.random_molgraphs(5, "qm9", seed=0)
+    b = BatchMolGraph(mgs)
+    assert len(b) == 5
+    assert b.V.dtype == torch.float32 and b.E.dtype == torch.float32
+    assert b.edge_index.dtype == torch.int64 and b.rev_edge_index.dtype == torch.int64 and b.batch.dtype == torch.int64
+    nV = sum(len(m.V) for m in mgs)
+    nE = sum(m.edge_index.shape[1] for m in mgs)
+    assert b.V.shape == (nV, 72) and b.E.shape == (nE, 14) and b.edge_index.shape == (2, nE)
+    assert torch.all(b.batch[1:] >= b.batch[:-1]) and int(b.batch[-1]) == 4
+    # edges never cross molecules and rev is an involution running dst -> src
+    assert torch.equal(b.batch[b.edge_index[0]], b.batch[b.edge_index[1]])
+    assert onp.graph_is_symmetric(b.edge_index[0].numpy(), b.edge_index[1].numpy(), b.rev_edge_index.numpy())
+    assert b.to("cpu") is None  # in-place move returning None, like collate.py:68-73
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not present")
+def test_batching_equals_reference_collate():
+    _, BMG, _ = ref_shim.load_reference()
+    for layout in ("interleaved", "block", "shuffled"):
+        mgs = synth.random_molgraphs(7, "zinc", seed=3, layout=layout)
+        mine, ref = BatchMolGraph(mgs), BMG(mgs)
+        for f in ("V", "E", "edge_index", "rev_edge_index", "batch"):
+            assert torch.equal(getattr(mine, f), getattr(ref, f)), f
+        assert len(mine) == len(ref)
+
+
+@pytest.mark.parametrize("layout", ["interleaved", "block", "shuffled"])
+def test_synth_graphs_are_valid_molecules(layout):
+    for kind in ("qm9", "zinc", "synth40", "cgr"):
+        for mg in synth.random_molgraphs(20, kind, seed=1, layout=layout):
+            src, dst = mg.edge_index
+            assert onp.graph_is_symmetric(src, dst, mg.rev_edge_index)
+            assert np.bincount(dst, minlength=len(mg.V)).max() <= 4
+            assert np.array_equal(mg.E, mg.E[mg.rev_edge_index])  # both directions share bond features
+            assert mg.V.shape[1] == (106 if kind == "cgr" else 72)
+
+
+def test_qm9_shape_statistics():
+    b = synth.random_batch(512, "qm9", seed=0)
+    assert 7.5 < b.V.shape[0] / 512 < 10.5
+    assert 1.9 < b.E.shape[0] / b.V.shape[0] < 2.3
+
+
+def test_module_mirror_contract():
+    """state_dict keys / shapes / hparams of base.py:75-92,238-251."""
+    mp = BondMessagePassing()
+    sd = mp.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        "W_i.weight": (300, 86), "W_h.weight": (300, 300), "W_o.weight": (300, 372), "W_o.bias": (300,)}
+    assert mp.output_dim == 300 and mp.W_i.in_features == 86
+    assert mp.hparams["cls"] is BondMessagePassing and mp.hparams["d_h"] == 300
+    clone = mp.hparams["cls"](**{k: v for k, v in mp.hparams.items() if k != "cls"})
+    assert clone.state_dict().keys() == sd.keys()
+    mp2 = BondMessagePassing(d_v=10, d_e=6, d_h=24, bias=True, d_vd=5, activation="prelu")
+    assert set(mp2.state_dict()) == {"W_i.weight", "W_i.bias", "W_h.weight", "W_h.bias", "W_o.weight", "W_o.bias",
+                                     "W_d.weight", "W_d.bias", "tau.weight"}
+    assert mp2.output_dim == 29
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not present")
+def test_same_seed_same_initial_weights_as_reference():
+    BMP, _, _ = ref_shim.load_reference()
+    for kw in (dict(), dict(d_h=64, bias=True, d_vd=3)):
+        torch.manual_seed(11)
+        ref = BMP(**kw)
+        torch.manual_seed(11)
+        mine = BondMessagePassing(**kw)
+        for k, v in ref.state_dict().items():
+            assert torch.equal(v, mine.state_dict()[k]), k
+        mine.load_state_dict(ref.state_dict())  # and the reference's files load unchanged
+
+
+def test_activation_classification():
+    nn = torch.nn
+    assert classify_activation(nn.ReLU())[0] == "relu"
+    assert classify_activation(nn.LeakyReLU(0.1))[:2] == ("leakyrelu", pytest.approx(0.1))
+    assert classify_activation(nn.PReLU())[0] == "prelu"
+    assert classify_activation(nn.PReLU(4))[0] == "custom"
+    assert classify_activation(nn.ELU())[0] == "elu" and classify_activation(nn.ELU(0.5))[0] == "custom"
+    assert classify_activation(nn.Tanh())[0] == "tanh" and classify_activation(nn.Softplus())[0] == "custom"
+
+
+def test_no_cpu_fallback():
+    mp = BondMessagePassing(d_h=16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mp(synth.random_batch(2, "qm9", seed=0))
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must never reach into oracle/ (parity claims depend on it)."""
+    import glob
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "chemprop_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path

@@ -1,0 +1,205 @@
+"""Parity of the HIP path against the oracle — runs on a real MI355X only (`-m gpu`).
+
+Every call goes through the C-ABI (ctypes -> libdmpnn_gfx950.so).  Bars:
+  * integer / index work (graph plan): bit-exact against the numpy CSR restatement;
+  * segment kernels (message, aggregate): bit-exact against the golden vectors of the executed
+    reference (same fp32 addition order by construction);
+  * contractions and whole forward: <= 1e-5 norm-wise relative (BASELINE.json north_star) —
+    `max|a-b| <= 1e-5 * max(1, max|ref|)`.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL, parity_err
+from oracle import dmpnn_numpy as onp
+from oracle import dmpnn_torch as ot
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(golden, dev):
+    from chemprop_amd.engine import GraphPlan
+
+    return GraphPlan(torch.from_numpy(golden["edge_index"]).to(dev), torch.from_numpy(golden["rev_edge_index"]).to(dev),
+                     golden["V"].shape[0])
+
+
+def test_plan_is_bit_exact(golden, gpu_device):
+    plan = _plan(golden, gpu_device)
+    a = {k: v.numpy() for k, v in plan.arrays().items()}
+    src, dst = golden["edge_index"]
+    rev = golden["rev_edge_index"]
+    nV = golden["V"].shape[0]
+    row_ptr, perm = onp.build_csr(dst, nV)
+    assert np.array_equal(a["src"], src) and np.array_equal(a["dst"], dst) and np.array_equal(a["rev"], rev)
+    assert np.array_equal(a["row_ptr"], row_ptr)
+    assert np.array_equal(a["perm"], perm)
+    assert bool(a["hdr"][0] & 1) == (not onp.graph_is_symmetric(src, dst, rev))
+    assert not (a["hdr"][0] & 2)
+    assert a["hdr"][1] == (np.diff(row_ptr).max() if len(perm) else 0)
+
+
+def test_message_kernel_bit_exact(golden, gpu_device):
+    from chemprop_amd import engine
+
+    if "M1" not in golden:
+        pytest.skip("no stored message for this case")
+    act = golden.cfg["activation"]
+    plan = _plan(golden, gpu_device)
+    H0 = torch.from_numpy(golden["H0"]).to(gpu_device)
+    slope_t = torch.tensor([0.25], device=gpu_device) if act == "prelu" else None
+    M = engine.message(plan, H0, act_on_load=act, slope=0.1, slope_t=slope_t)
+    if act in ("relu", "leakyrelu", "prelu"):
+        assert np.array_equal(M.cpu().numpy(), golden["M1"])
+    else:  # tanhf / expm1f differ from the host libm by an ulp
+        assert parity_err(M.cpu().numpy(), golden["M1"]) <= 1e-6
+    # tau applied beforehand by torch + act_on_load="none" must agree bit-for-bit on exact activations
+    if act == "relu":
+        M2 = engine.message(plan, torch.relu(H0))
+        assert torch.equal(M, M2)
+
+
+def test_aggregate_kernel_bit_exact(golden, gpu_device):
+    from chemprop_amd import engine
+
+    if "H_last" not in golden:
+        pytest.skip("no stored H_last for this case")
+    plan = _plan(golden, gpu_device)
+    H = torch.from_numpy(golden["H_last"]).to(gpu_device)
+    Mv = engine.aggregate(plan, H)
+    assert np.array_equal(Mv.cpu().numpy(), golden["Mv"])
+
+
+def test_initialize_kernel(golden, gpu_device):
+    """K1: gather + concat fused into the A-operand loader of the MFMA contraction."""
+    from chemprop_amd import engine
+
+    if "H0" not in golden:
+        pytest.skip("big case")
+    plan = _plan(golden, gpu_device)
+    w = golden.weights()
+    t = lambda a: torch.from_numpy(np.array(a)).to(gpu_device)
+    b = t(w["W_i.bias"]) if "W_i.bias" in w else None
+    H0 = engine.linear(t(golden["V"]), t(w["W_i.weight"]), b, A2=t(golden["E"]), gather1=plan.src32,
+                       n_rows=plan.n_edges)
+    assert parity_err(H0.cpu().numpy(), golden["H0"]) <= TOL
+
+
+def test_forward_matches_executed_reference(golden, gpu_device):
+    """Whole BondMessagePassing.forward through the mirror module (state_dict-compatible)."""
+    mp = golden.module(gpu_device)
+    bmg = golden.bmg(gpu_device)
+    V_d = torch.from_numpy(golden["V_d"]).to(gpu_device) if "V_d" in golden else None
+    before = [bmg.V.clone(), bmg.E.clone(), bmg.edge_index.clone(), bmg.rev_edge_index.clone()]
+    with torch.no_grad():
+        out = mp(bmg, V_d)
+    assert out.shape == golden["out"].shape
+    err = parity_err(out.cpu().numpy(), golden["out"])
+    assert err <= TOL, f"{golden.name}: {err:.3e}"
+    # forward must not mutate the batch (tests/integration/test_regression_mol.py:217-226)
+    for a, b in zip(before, [bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (16, 64, 32), (33, 300, 300), (257, 300, 86),
+                                   (130, 129, 372), (1000, 320, 45), (48, 2400, 100)])
+def test_linear_kernel_vs_torch_fp32(M, N, K, gpu_device):
+    """fp32-MFMA contraction (with an ASYMMETRIC W so a transposed tile cannot pass) vs torch fp32 on CPU."""
+    from chemprop_amd import engine
+
+    g = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * (1 + torch.arange(N).float().unsqueeze(1) / N)
+    b = torch.randn(N, generator=g)
+    Cadd = torch.randn(M, N, generator=g)
+    ref = torch.relu(Cadd.double() + (A.double() @ W.double().T + b.double())).float()
+    out = engine.linear(A.to(gpu_device), W.to(gpu_device), b.to(gpu_device), Cadd=Cadd.to(gpu_device), act="relu")
+    assert parity_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+@pytest.mark.parametrize("n_mols,kind,seed", [(512, "qm9", 0), (4096, "qm9", 1), (512, "synth40", 2), (512, "zinc", 3)])
+def test_forward_full_size_vs_oracle(n_mols, kind, seed, gpu_device):
+    """BASELINE.json sizes: batch of 512 QM9-shaped molecules (configs[1]) etc., against the CPU oracle."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    depth, d_h = (6, 512) if kind == "zinc" else (3, 300)
+    bmg = synth.random_batch(n_mols, kind, seed=seed)
+    torch.manual_seed(seed)
+    mp = BondMessagePassing(d_h=d_h, depth=depth).eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(bmg, ot.MPWeights.from_module(mp), depth=depth)
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    with torch.no_grad():
+        out = mp(bmg)
+    err = parity_err(out.cpu().numpy(), ref.numpy())
+    assert err <= TOL, f"{kind}-{n_mols}: {err:.3e}"
+
+
+def test_size_independent_properties_at_scale(gpu_device):
+    """32 768 QM9-shaped molecules (E ~ 6e5, working set > Infinity Cache): properties that need no oracle.
+      * conservation: column sums of Mv equal column sums of H (every edge has exactly one destination);
+      * the message of a symmetric graph satisfies  sum_e M[e] = sum_v (deg(v) - 1) * S[v];
+      * linearity: message(a*H + b*G) == a*message(H) + b*message(G) to rounding;
+      * determinism: two runs are bit-identical (no atomics on the data path).
+    """
+    from chemprop_amd import engine, synth
+
+    bmg = synth.random_batch(32768, "qm9", seed=7)
+    bmg.to(gpu_device)
+    plan = engine.GraphPlan.from_bmg(bmg)
+    E = bmg.E.shape[0]
+    g = torch.Generator(device=gpu_device).manual_seed(0)
+    H = torch.randn(E, 300, device=gpu_device, generator=g)
+    G = torch.randn(E, 300, device=gpu_device, generator=g)
+    Mv = engine.aggregate(plan, H)
+    assert parity_err(Mv.double().sum(0).cpu().numpy(), H.double().sum(0).cpu().numpy()) <= 1e-6
+    M = engine.message(plan, H)
+    deg = torch.bincount(bmg.edge_index[1], minlength=bmg.V.shape[0]).double().unsqueeze(1)
+    lhs = M.double().sum(0)
+    rhs = ((deg - 1) * Mv.double()).sum(0)
+    assert parity_err(lhs.cpu().numpy(), rhs.cpu().numpy()) <= 1e-6
+    M_lin = engine.message(plan, 0.5 * H - 2.0 * G)
+    M_g = engine.message(plan, G)
+    assert parity_err(M_lin.cpu().numpy(), (0.5 * M - 2.0 * M_g).cpu().numpy()) <= 1e-5
+    assert torch.equal(engine.message(plan, H), M)
+
+
+def test_cpu_tensors_fail_loudly(gpu_device):
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    mp = BondMessagePassing(d_h=32)
+    bmg = synth.random_batch(2, "qm9", seed=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mp(bmg)
+
+
+def test_invalid_vd_shape_raises(gpu_device):
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing, InvalidShapeError
+
+    mp = BondMessagePassing(d_h=32, d_vd=3).to(gpu_device)
+    bmg = synth.random_batch(2, "qm9", seed=0)
+    bmg.to(gpu_device)
+    with pytest.raises(InvalidShapeError):
+        mp(bmg, torch.zeros(bmg.V.shape[0], 4, device=gpu_device))
+
+
+def test_custom_activation_and_dropout_rows_route(gpu_device):
+    """Arbitrary nn.Module activation (reference tests use Softplus) and eval-mode dropout."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = synth.random_batch(8, "qm9", seed=5)
+    torch.manual_seed(5)
+    mp = BondMessagePassing(d_h=64, depth=4, activation=torch.nn.Softplus(), dropout=0.3).eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(bmg, ot.MPWeights.from_module(mp), depth=4, activation=torch.nn.functional.softplus)
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    with torch.no_grad():
+        out = mp(bmg)
+    assert parity_err(out.cpu().numpy(), ref.numpy()) <= TOL
