@@ -25,7 +25,8 @@ SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gem
 EXPORTS = [
     "dmpnn_version", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
     "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
-    "dmpnn_linear_fwd", "dmpnn_forward",
+    "dmpnn_linear_fwd", "dmpnn_forward", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
+    "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -66,6 +67,15 @@ class FwdArgs(C.Structure):
     ]
 
 
+class BwdArgs(C.Structure):
+    _fields_ = [
+        ("f", FwdArgs), ("gout", C.c_void_p), ("ldgout", C.c_int64),
+        ("gW_i", C.c_void_p), ("gb_i", C.c_void_p), ("gW_h", C.c_void_p), ("gb_h", C.c_void_p),
+        ("gW_o", C.c_void_p), ("gb_o", C.c_void_p), ("gW_d", C.c_void_p), ("gb_d", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+    ]
+
+
 def sources() -> list[str]:
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.isfile(os.path.join(CSRC, s))]
 
@@ -85,13 +95,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.isfile(hipcc):
         raise RuntimeError("hipcc not found: cannot build libdmpnn_gfx950.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}",
-           f"-I{CSRC}", *sources(), "-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+    import concurrent.futures as cf
+    import tempfile
+
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+    with tempfile.TemporaryDirectory(prefix="dmpnn_build_") as tmp:
+        def cc(src):
+            obj = os.path.join(tmp, os.path.basename(src) + ".o")
+            cmd = [hipcc, *flags, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src} ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+            return obj
+
+        with cf.ThreadPoolExecutor(max_workers=8) as ex:
+            objs = list(ex.map(cc, sources()))
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 
@@ -126,8 +152,19 @@ def load() -> C.CDLL:
                                         C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     lib.dmpnn_linear_fwd.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
     lib.dmpnn_forward.argtypes = [C.POINTER(FwdArgs), C.c_void_p]
+    lib.dmpnn_backward_ws_bytes.argtypes = [C.POINTER(FwdArgs)]
+    lib.dmpnn_backward.argtypes = [C.POINTER(BwdArgs), C.c_void_p]
+    lib.dmpnn_message_bwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_int64, C.c_void_p]
+    lib.dmpnn_aggregate_bwd.argtypes = lib.dmpnn_message_bwd.argtypes
+    lib.dmpnn_linear_wgrad_ws_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int]
+    lib.dmpnn_linear_wgrad.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes")
+    for name in size_t_fns:
+        getattr(lib, name).restype = C.c_size_t
     for name in EXPORTS:
-        if name not in ("dmpnn_last_error_string", "dmpnn_plan_bytes"):
+        if name != "dmpnn_last_error_string" and name not in size_t_fns:
             getattr(lib, name).restype = C.c_int
     if lib.dmpnn_version() != 1:
         raise RuntimeError(f"libdmpnn ABI version {lib.dmpnn_version()} != 1 (stale build?)")

@@ -1,0 +1,106 @@
+"""autograd wiring of the engine (training: chemprop/models/model.py:148-161 calls loss.backward()
+through the block).  Gradients are produced by the K6 HIP kernels; torch only routes them.
+
+* :class:`FusedMP`       one ``dmpnn_forward`` (workspace kept) + one ``dmpnn_backward`` per step.
+* ``linear_fn`` / ``message_fn`` / ``aggregate_fn``  row-level Functions for the *rows* route
+  (arbitrary activation module, learnable PReLU, active dropout run in torch between kernels).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import engine
+
+_PARAM_ORDER = ("W_i", "b_i", "W_h", "b_h", "W_o", "b_o", "W_d", "b_d")
+
+
+class FusedMP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mp, plan, V, E, V_d, act, slope, slope_t, W_i, b_i, W_h, b_h, W_o, b_o, W_d, b_d):
+        has_vd = V_d is not None and W_d is not None
+        out, st = engine.forward(plan, V, E, W_i, W_h, W_o, b_o, b_i, b_h, W_d if has_vd else None,
+                                 b_d if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
+                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True)
+        ctx.st = st
+        ctx.has_vd = has_vd
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        st = ctx.st
+        need = {k: ctx.needs_input_grad[8 + i] for i, k in enumerate(_PARAM_ORDER)}
+        if not ctx.has_vd:
+            need["W_d"] = need["b_d"] = False
+        grads = engine.backward(st, gout.contiguous(), need)
+        ctx.st = None  # release the kept workspace
+        return (None,) * 8 + tuple(grads[k] for k in _PARAM_ORDER)
+
+
+class _Linear(torch.autograd.Function):
+    """``[A1[gather] || A2] @ W.T + b + Cadd``; grads for W, b, A1 (ungathered only), A2, Cadd."""
+
+    @staticmethod
+    def forward(ctx, A1, W, b, A2, gather, n_rows, Cadd):
+        out = engine.linear(A1, W, b, A2=A2, gather1=gather, n_rows=n_rows, Cadd=Cadd)
+        ctx.save_for_backward(A1, W, A2, gather)
+        ctx.has_b = b is not None
+        ctx.has_cadd = Cadd is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gZ):
+        A1, W, A2, gather = ctx.saved_tensors
+        gZ = gZ.contiguous()
+        need_A1, need_W, need_b, need_A2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        gW = gb = gA1 = gA2 = None
+        if need_W or (need_b and ctx.has_b):
+            gW, gb = engine.linear_wgrad(gZ, A1, A2, gather, want_bias=ctx.has_b and need_b)
+            if not need_W:
+                gW = None
+        if need_A1 or need_A2:
+            if gather is not None and need_A1:
+                raise NotImplementedError("gradient w.r.t. gathered features is not provided")
+            gA = engine.linear(gZ, W.t().contiguous(), None)  # data gradient: the same MFMA kernel on W^T
+            K1 = A1.shape[1]
+            gA1 = gA[:, :K1] if need_A1 else None
+            gA2 = gA[:, K1:] if (need_A2 and A2 is not None) else None
+        gCadd = gZ if (ctx.has_cadd and ctx.needs_input_grad[6]) else None
+        return gA1, gW, gb, gA2, None, None, gCadd
+
+
+class _Message(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, H):
+        ctx.plan = plan
+        return engine.message(plan, H)
+
+    @staticmethod
+    def backward(ctx, gM):
+        return None, engine.message_bwd(ctx.plan, gM.contiguous())
+
+
+class _Aggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, H):
+        ctx.plan = plan
+        return engine.aggregate(plan, H)
+
+    @staticmethod
+    def backward(ctx, gMv):
+        return None, engine.aggregate_bwd(ctx.plan, gMv.contiguous())
+
+
+def linear_fn(A1: Tensor, W: Tensor, b: Optional[Tensor], A2: Optional[Tensor] = None,
+              gather: Optional[Tensor] = None, n_rows: Optional[int] = None, Cadd: Optional[Tensor] = None) -> Tensor:
+    return _Linear.apply(A1, W, b, A2, gather, n_rows, Cadd)
+
+
+def message_fn(plan, H: Tensor) -> Tensor:
+    return _Message.apply(plan, H)
+
+
+def aggregate_fn(plan, H: Tensor) -> Tensor:
+    return _Aggregate.apply(plan, H)

@@ -1,0 +1,737 @@
+// K6 — backward of the path (what autograd does through base.py:196-212 / mixins.py:8-18).
+//
+// With S[v] = sum_{dst(e)=v} Hb[e],  M[e] = S[src(e)] - Hb[rev(e)]  (Hb = H, or (H+H[rev])/2 when
+// undirected),  Z = H0 + M.W_h^T (+b),  H' = tau(Z):
+//
+//   gZ  = gH' * tau'(.)                         (mask, fused into the producer of gH')
+//   gW_h += gZ^T . M        gb_h += colsum(gZ)   (k_wgrad: MFMA, split over edges, slab reduce)
+//   gM  = gZ . W_h                               (the forward contraction kernel on W_h^T)
+//   gHb[e'] = gS[dst(e')] - gM[rev(e')],  gS[v] = sum_{src(e)=v} gM[e] = sum_{dst(e')=v} gM[rev(e')]
+//                                               (k_edge_bwd<MESSAGE>: the forward atom-centric
+//                                                kernel with read row rev(e') and write row e')
+//   gH0 accumulates every gZ^(t) plus gH^(0) * tau'(tau(H0)).
+//
+// Graph must be symmetric (every featurizer-produced graph is); on an asymmetric plan the message
+// backward writes NaN (loud) — gradients through arbitrary index arrays are not provided.
+#include <string.h>
+
+#include "dmpnn_common.hpp"
+
+namespace dmpnn {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// edge-space backward kernels
+// ------------------------------------------------------------------------------------------------
+enum : int { EB_GATHER = 0, EB_MESSAGE = 1, EB_AVG = 2 };
+
+struct EdgeBwdArgs {
+    PlanView pv;
+    int nV, nE, h;
+    const float* gin;  // GATHER: gMv [V]   MESSAGE: gM [E]   AVG: raw gHb [E]
+    int64_t ld_gin;
+    const float* Y;    // activation output (or pre-activation when y_preact) of the TARGET rows; may be null
+    int64_t ldy;
+    int y_preact;
+    float* gZ;         // masked gradient out [E]; may be null
+    int64_t ldgz;
+    float* acc;        // gH0 accumulator [E]; may be null
+    int64_t ldacc;
+    int acc_init;      // 1: acc = g, 0: acc += g
+    int act;
+    float slope;
+    const float* slope_ptr;
+};
+
+template <int ACT>
+__device__ __forceinline__ float mask1(float g, float y, int act_rt, float slope, int preact) {
+    if (ACT == DMPNN_ACT_NONE) return g;
+    if (ACT == DMPNN_ACT_RELU) return y > 0.f ? g : 0.f;  // sign(relu(z)) == sign(z): no need to re-apply tau
+    // generic
+    if (preact) y = apply_act(y, act_rt, slope);
+    return g * act_grad_from_out(y, act_rt, slope);
+}
+
+// finish one float4 (or float) of target row `row`: mask, store gZ, accumulate gH0
+template <int VEC, int ACT>
+__device__ __forceinline__ void finish(const EdgeBwdArgs& a, int row, int c, bool ok, float slope,
+                                       float gx, float gy, float gz, float gw,
+                                       float yx, float yy, float yz, float yw,
+                                       float ax, float ay, float az, float aw) {
+    float o0 = mask1<ACT>(gx, yx, a.act, slope, a.y_preact);
+    float o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    if (VEC == 4) {
+        o1 = mask1<ACT>(gy, yy, a.act, slope, a.y_preact);
+        o2 = mask1<ACT>(gz, yz, a.act, slope, a.y_preact);
+        o3 = mask1<ACT>(gw, yw, a.act, slope, a.y_preact);
+    }
+    if (!ok) return;
+    if (a.gZ) {
+        float* p = a.gZ + (int64_t)row * a.ldgz + c;
+        if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(o0, o1, o2, o3);
+        else *p = o0;
+    }
+    if (a.acc) {
+        float* p = a.acc + (int64_t)row * a.ldacc + c;
+        if (!a.acc_init) { o0 += ax; o1 += ay; o2 += az; o3 += aw; }
+        if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(o0, o1, o2, o3);
+        else *p = o0;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ float4 ld(const float* p) {
+    if (VEC == 4) return *reinterpret_cast<const float4*>(p);
+    return make_float4(*p, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// MESSAGE mode, atom with in-degree exactly D: D rows of gM, D rows of Y, D rows of acc in flight.
+template <int VEC, int ACT, int D>
+__device__ __forceinline__ void msg_bwd_body(const EdgeBwdArgs& a, int beg, int lane, int n_cols, float slope,
+                                             const float* Yp, int64_t ldy, const float* Ap, int64_t lda) {
+    int eid[D], erev[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) eid[i] = a.pv.perm[beg + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) erev[i] = a.pv.rev[eid[i]];
+    for (int cg0 = 0; cg0 < n_cols; cg0 += 64) {
+        const int cg = cg0 + lane;
+        const bool ok = cg < n_cols;
+        const int c = (ok ? cg : 0) * VEC;
+        float4 r[D], y[D], ac[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            r[i] = ld<VEC>(a.gin + (int64_t)erev[i] * a.ld_gin + c);
+            y[i] = ld<VEC>(Yp + (int64_t)eid[i] * ldy + c);
+            ac[i] = ld<VEC>(Ap + (int64_t)eid[i] * lda + c);
+        }
+        float4 S = r[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) S = add4(S, r[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float4 g = sub4(S, r[i]);
+            finish<VEC, ACT>(a, eid[i], c, ok, slope, g.x, g.y, g.z, g.w, y[i].x, y[i].y, y[i].z, y[i].w,
+                             ac[i].x, ac[i].y, ac[i].z, ac[i].w);
+        }
+    }
+}
+
+template <int VEC, int ACT>
+__device__ __forceinline__ void msg_bwd_any(const EdgeBwdArgs& a, int beg, int d, int lane, int n_cols, float slope,
+                                            const float* Yp, int64_t ldy, const float* Ap, int64_t lda) {
+    for (int cg = lane; cg < n_cols; cg += 64) {
+        const int c = cg * VEC;
+        float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < d; ++i) S = add4(S, ld<VEC>(a.gin + (int64_t)a.pv.rev[a.pv.perm[beg + i]] * a.ld_gin + c));
+        for (int i = 0; i < d; ++i) {
+            const int e = a.pv.perm[beg + i];
+            const float4 g = sub4(S, ld<VEC>(a.gin + (int64_t)a.pv.rev[e] * a.ld_gin + c));
+            const float4 y = ld<VEC>(Yp + (int64_t)e * ldy + c);
+            const float4 ac = ld<VEC>(Ap + (int64_t)e * lda + c);
+            finish<VEC, ACT>(a, e, c, true, slope, g.x, g.y, g.z, g.w, y.x, y.y, y.z, y.w, ac.x, ac.y, ac.z, ac.w);
+        }
+    }
+}
+
+template <int VEC, int MODE, int ACT>
+__global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    const float slope = a.slope_ptr ? *a.slope_ptr : a.slope;
+    const int n_cols = a.h / VEC;
+    // dummy bases keep every load unconditional
+    const float* Yp = a.Y ? a.Y : a.gin;
+    const int64_t ldy = a.Y ? a.ldy : 0;
+    const float* Ap = (a.acc && !a.acc_init) ? a.acc : a.gin;
+    const int64_t lda = (a.acc && !a.acc_init) ? a.ldacc : 0;
+
+    if (MODE == EB_MESSAGE) {
+        const bool asym = a.pv.hdr[DMPNN_HDR_FLAGS] & PLAN_ASYMMETRIC;
+        if (asym) {  // gradients through a non-molecular index structure are not provided: poison loudly
+            const float nanv = __int_as_float(0x7fc00000);
+            for (int e = wave; e < a.nE; e += n_waves)
+                for (int c = lane; c < a.h; c += 64) {
+                    if (a.gZ) a.gZ[(int64_t)e * a.ldgz + c] = nanv;
+                    if (a.acc) a.acc[(int64_t)e * a.ldacc + c] = nanv;
+                }
+            return;
+        }
+        for (int v = wave; v < a.nV; v += n_waves) {
+            const int beg = a.pv.row_ptr[v];
+            const int d = a.pv.row_ptr[v + 1] - beg;
+            if (ACT == -1) {
+                msg_bwd_any<VEC, ACT>(a, beg, d, lane, n_cols, slope, Yp, ldy, Ap, lda);
+                continue;
+            }
+            switch (d) {
+                case 0: break;
+                case 1: msg_bwd_body<VEC, ACT, 1>(a, beg, lane, n_cols, slope, Yp, ldy, Ap, lda); break;
+                case 2: msg_bwd_body<VEC, ACT, 2>(a, beg, lane, n_cols, slope, Yp, ldy, Ap, lda); break;
+                case 3: msg_bwd_body<VEC, ACT, 3>(a, beg, lane, n_cols, slope, Yp, ldy, Ap, lda); break;
+                case 4: msg_bwd_body<VEC, ACT, 4>(a, beg, lane, n_cols, slope, Yp, ldy, Ap, lda); break;
+                default: msg_bwd_any<VEC, ACT>(a, beg, d, lane, n_cols, slope, Yp, ldy, Ap, lda); break;
+            }
+        }
+    } else {
+        // GATHER: g = gMv[dst(e)]      AVG: g = (gHb[e] + gHb[rev(e)]) / 2       one wave per edge
+        for (int e = wave; e < a.nE; e += n_waves) {
+            const int r0 = (MODE == EB_GATHER) ? a.pv.dst[e] : e;
+            const int r1 = (MODE == EB_GATHER) ? r0 : a.pv.rev[e];
+            for (int cg = lane; cg < n_cols; cg += 64) {
+                const int c = cg * VEC;
+                float4 g = ld<VEC>(a.gin + (int64_t)r0 * a.ld_gin + c);
+                const float4 g1 = ld<VEC>(a.gin + (int64_t)r1 * a.ld_gin + c);
+                const float4 y = ld<VEC>(Yp + (int64_t)e * ldy + c);
+                const float4 ac = ld<VEC>(Ap + (int64_t)e * lda + c);
+                if (MODE == EB_AVG) g = make_float4((g.x + g1.x) / 2.f, (g.y + g1.y) / 2.f, (g.z + g1.z) / 2.f, (g.w + g1.w) / 2.f);
+                finish<VEC, ACT>(a, e, c, true, slope, g.x, g.y, g.z, g.w, y.x, y.y, y.z, y.w, ac.x, ac.y, ac.z, ac.w);
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch_edge_bwd(EdgeBwdArgs a, hipStream_t s, const char* name) {
+    if (a.nE == 0 || a.h == 0) return DMPNN_OK;
+    if (!a.Y) a.act = DMPNN_ACT_NONE;
+    const int64_t items = (MODE == EB_MESSAGE) ? a.nV : a.nE;
+    int64_t blocks = (items + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    bool vec = (a.h % 4 == 0) && (a.ld_gin % 4 == 0) && aligned16(a.gin);
+    if (a.Y) vec = vec && (a.ldy % 4 == 0) && aligned16(a.Y);
+    if (a.gZ) vec = vec && (a.ldgz % 4 == 0) && aligned16(a.gZ);
+    if (a.acc) vec = vec && (a.ldacc % 4 == 0) && aligned16(a.acc);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (vec && a.act == DMPNN_ACT_NONE) hipLaunchKernelGGL((k_edge_bwd<4, MODE, DMPNN_ACT_NONE>), grid, block, 0, s, a);
+    else if (vec && a.act == DMPNN_ACT_RELU) hipLaunchKernelGGL((k_edge_bwd<4, MODE, DMPNN_ACT_RELU>), grid, block, 0, s, a);
+    else if (vec) hipLaunchKernelGGL((k_edge_bwd<4, MODE, -1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_edge_bwd<1, MODE, -1>), grid, block, 0, s, a);
+    DMPNN_CHECK_LAUNCH(name);
+    return DMPNN_OK;
+}
+
+// elementwise: gZ = g * tau'(Y)      (finalize: atoms x h)
+__global__ void k_act_bwd(const float* __restrict__ g, int64_t ldg, const float* __restrict__ Y, int64_t ldy,
+                          float* __restrict__ out, int64_t ldo, int64_t rows, int h, int act, float slope,
+                          const float* slope_ptr) {
+    const float sl = slope_ptr ? *slope_ptr : slope;
+    const int64_t n = rows * h;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / h;
+        const int c = (int)(i % h);
+        out[r * ldo + c] = g[r * ldg + c] * act_grad_from_out(Y[r * ldy + c], act, sl);
+    }
+}
+
+// out[c][r] = in[r][c]   (weights only: a few hundred KB)
+__global__ void k_transpose(const float* __restrict__ in, int64_t ldi, float* __restrict__ out, int64_t ldo,
+                            int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(int64_t)r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (c < cols && r < rows) out[(int64_t)c * ldo + r] = tile[threadIdx.x][j];
+    }
+}
+
+int launch_transpose(const float* in, int64_t ldi, float* out, int64_t ldo, int rows, int cols, hipStream_t s) {
+    if (rows == 0 || cols == 0) return DMPNN_OK;
+    hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, in, ldi, out, ldo, rows, cols);
+    DMPNN_CHECK_LAUNCH("k_transpose");
+    return DMPNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  slab[split][n][k] = sum_{m in split} gZ[m][n] * Acat[m][k],   Acat = [A1[g(m)] || A2 || 1]
+// ------------------------------------------------------------------------------------------------
+// Both operands are "reduction-major" (m is the row index of gZ and of Acat), i.e. contiguous along
+// the OUTPUT index.  MFMA 16x16x4 wants A[i][kk] from lane (i = l&15, kk = l>>4): lane loads ONE
+// float4 gZ[m0+kk][n0+4i .. +3] and ONE float4 Acat[m0+kk][k0+4j .. +3]; component jn of the first
+// and jk of the second feed the accumulator of the INTERLEAVED tile (jn, jk), whose rows are
+// n = n0+4i+jn and columns k = k0+4j+jk.  One 16-byte load per operand per lane drives 16 MFMAs,
+// straight from global memory (coalesced 256-B row segments), no LDS staging.
+struct WgradArgs {
+    int64_t M;
+    int N, K1, K2, ones;
+    const float* gZ; int64_t ldz;
+    const float* A1; int64_t lda1; const int* gather1;
+    const float* A2; int64_t lda2;
+    float* slab; int ldk; int64_t slab_stride;
+    int rows_per_wg;
+    int vecZ, vecA;
+};
+
+constexpr int WG_U = 4;  // k-steps (of 4 rows) per batch of loads
+
+__device__ __forceinline__ float4 wg_load_z(const WgradArgs& a, int64_t m, bool mok, int n) {
+    // 4 consecutive output rows n..n+3 of gZ row m
+    if (a.vecZ) {
+        const bool ok = mok && n < a.N;
+        float4 v = *reinterpret_cast<const float4*>(a.gZ + (ok ? m * a.ldz + n : 0));
+        v.x = (ok) ? v.x : 0.f;
+        v.y = (ok && n + 1 < a.N) ? v.y : 0.f;
+        v.z = (ok && n + 2 < a.N) ? v.z : 0.f;
+        v.w = (ok && n + 3 < a.N) ? v.w : 0.f;
+        return v;
+    }
+    float x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool ok = mok && (n + t) < a.N;
+        const float raw = a.gZ[ok ? m * a.ldz + n + t : 0];
+        x[t] = ok ? raw : 0.f;
+    }
+    return make_float4(x[0], x[1], x[2], x[3]);
+}
+
+template <bool FULL>
+__device__ __forceinline__ float4 wg_load_a(const WgradArgs& a, int64_t m, int64_t g1, bool mok, int k) {
+    const int K = a.K1 + a.K2;
+    if (FULL) {  // the block's 64 columns are all < K and K1, K2 are multiples of 4: one 16-byte load
+        const float* p = (k < a.K1) ? a.A1 + g1 * a.lda1 + k : a.A2 + m * a.lda2 + (k - a.K1);
+        float4 v = *reinterpret_cast<const float4*>(mok ? p : a.A1);
+        return mok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kt = k + t;
+        const bool ok = mok && kt < K;
+        const float* p = (kt < a.K1) ? a.A1 + g1 * a.lda1 + kt : a.A2 + m * a.lda2 + (kt - a.K1);
+        const float raw = *(ok ? p : a.gZ);
+        x[t] = ok ? raw : ((mok && a.ones && kt == K) ? 1.f : 0.f);
+    }
+    return make_float4(x[0], x[1], x[2], x[3]);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void wgrad_loop(const WgradArgs& a, f32x4 (&acc)[4][4], int64_t m_lo, int64_t m_hi, int n0,
+                                           int k0, int wave, int li, int lg) {
+    for (int64_t mb = m_lo + 4 * wave; mb < m_hi; mb += 16 * WG_U) {
+        float4 z[WG_U], x[WG_U];
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const int64_t m = mb + 16 * u + lg;
+            const bool mok = m < m_hi;
+            const int64_t mc = mok ? m : m_lo;
+            const int64_t g1 = a.gather1 ? (int64_t)a.gather1[mc] : mc;
+            z[u] = wg_load_z(a, mc, mok, n0 + 4 * li);
+            x[u] = wg_load_a<FULL>(a, mc, g1, mok, k0 + 4 * li);
+        }
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const float zz[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+            const float xx[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                for (int jk = 0; jk < 4; ++jk)
+                    acc[jn][jk] = __builtin_amdgcn_mfma_f32_16x16x4f32(zz[jn], xx[jk], acc[jn][jk], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][64][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int Kt = a.K1 + a.K2 + a.ones;
+    const int kb = (Kt + 63) / 64;
+    const int n0 = (blockIdx.x / kb) * 64, k0 = (blockIdx.x % kb) * 64;
+    const int64_t m_lo = (int64_t)blockIdx.y * a.rows_per_wg;
+    int64_t m_hi = m_lo + a.rows_per_wg;
+    if (m_hi > a.M) m_hi = a.M;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // wave w owns k-steps t = w, w+4, ...; a batch is WG_U of them
+    const bool full = a.vecA && (k0 + 64 <= a.K1 + a.K2);  // uniform: picks one straight-line loop
+    if (full) wgrad_loop<true>(a, acc, m_lo, m_hi, n0, k0, wave, li, lg);
+    else wgrad_loop<false>(a, acc, m_lo, m_hi, n0, k0, wave, li, lg);
+    // cross-wave reduction through LDS, then one slab write per workgroup
+    float* mine = red + wave * 4096;
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+        for (int jk = 0; jk < 4; ++jk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nl = 4 * (lg * 4 + r) + jn, kl = 4 * li + jk;
+                mine[nl * 64 + kl] = acc[jn][jk][r];
+            }
+    __syncthreads();
+    float* slab = a.slab + (int64_t)blockIdx.y * a.slab_stride;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int nl = idx >> 6, kl = idx & 63;
+        const int n = n0 + nl, k = k0 + kl;
+        if (n < a.N && k < Kt) slab[(int64_t)n * a.ldk + k] = red[idx] + red[4096 + idx] + red[8192 + idx] + red[12288 + idx];
+    }
+}
+
+// gW[n][k] = sum_s slab[s][n][k] (k < K),  gb[n] = sum_s slab[s][n][K]
+__global__ void k_wgrad_reduce(const float* __restrict__ slab, int64_t slab_stride, int n_slabs, int ldk, int N, int K,
+                               int ones, float* __restrict__ gW, int64_t ldgw, float* __restrict__ gb) {
+    const int Kt = K + ones;
+    const int64_t total = (int64_t)N * Kt;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kt), k = (int)(i % Kt);
+        float s = 0.f;
+        for (int t = 0; t < n_slabs; ++t) s += slab[(int64_t)t * slab_stride + (int64_t)n * ldk + k];
+        if (k < K) {
+            if (gW) gW[(int64_t)n * ldgw + k] = s;
+        } else if (gb) {
+            gb[n] = s;
+        }
+    }
+}
+
+struct WgradPlan {
+    int splits, rows_per_wg, ldk;
+    int64_t slab_stride;
+};
+WgradPlan plan_wgrad(int64_t M, int N, int Kt) {
+    WgradPlan p;
+    const int nb = (N + 63) / 64, kb = (Kt + 63) / 64;
+    int splits = 512 / (nb * kb);
+    if (splits < 1) splits = 1;
+    const int64_t max_splits = (M + 63) / 64;
+    if (splits > max_splits) splits = (int)(max_splits > 0 ? max_splits : 1);
+    int64_t rows = (M + splits - 1) / splits;
+    rows = (rows + 15) / 16 * 16;
+    if (rows < 16) rows = 16;
+    p.splits = (int)((M + rows - 1) / rows);
+    if (p.splits < 1) p.splits = 1;
+    p.rows_per_wg = (int)rows;
+    p.ldk = (Kt + 3) / 4 * 4;
+    p.slab_stride = (int64_t)N * p.ldk;
+    return p;
+}
+
+int launch_wgrad(WgradArgs a, const WgradPlan& p, float* slab, hipStream_t s) {
+    if (a.N == 0) return DMPNN_OK;
+    const int Kt = a.K1 + a.K2 + a.ones;
+    if (Kt == 0) return DMPNN_OK;
+    a.slab = slab; a.ldk = p.ldk; a.slab_stride = p.slab_stride; a.rows_per_wg = p.rows_per_wg;
+    a.vecZ = aligned16(a.gZ) && a.ldz % 4 == 0;
+    a.vecA = (a.K1 == 0 || (aligned16(a.A1) && a.lda1 % 4 == 0)) && a.K1 % 4 == 0 &&
+             (a.K2 == 0 || (aligned16(a.A2) && a.lda2 % 4 == 0 && a.K2 % 4 == 0));
+    if (a.K1 == 0) { a.A1 = a.A2; a.lda1 = a.lda2; a.gather1 = nullptr; }
+    if (a.K2 == 0) { a.A2 = a.A1; a.lda2 = a.lda1; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(k_wgrad): %s", hipGetErrorString(e));
+            return DMPNN_EHIP;
+        }
+        attr_set = true;
+    }
+    const int nb = (a.N + 63) / 64, kb = (Kt + 63) / 64;
+    hipLaunchKernelGGL(k_wgrad, dim3(nb * kb, p.splits), dim3(256), 65536, s, a);
+    DMPNN_CHECK_LAUNCH("k_wgrad");
+    return DMPNN_OK;
+}
+
+int launch_wgrad_reduce(const float* slab, const WgradPlan& p, int n_slabs, int N, int K, int ones, float* gW,
+                        int64_t ldgw, float* gb, hipStream_t s) {
+    const int64_t total = (int64_t)N * (K + ones);
+    if (total == 0 || (!gW && !gb)) return DMPNN_OK;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, slab, p.slab_stride, n_slabs, p.ldk, N,
+                       K, ones, gW, ldgw, gb);
+    DMPNN_CHECK_LAUNCH("k_wgrad_reduce");
+    return DMPNN_OK;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct BwdLayout {
+    size_t gZa, gZb, gH0, gZO, gMv, gHO, WhT, WoT, WdT, slab_h, slab_x, total;
+    WgradPlan p_h, p_i, p_o, p_d;
+};
+BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
+    BwdLayout L;
+    const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dvd = f.W_d ? f.d_vd : 0;
+    const size_t edge = align_up((size_t)nE * f.ldh, 4), atom = align_up((size_t)nV * f.ldh, 4);
+    size_t o = 0;
+    L.gZa = o; o += edge;
+    L.gZb = o; o += edge;
+    L.gH0 = o; o += edge;
+    L.gZO = o; o += atom;
+    L.gMv = o; o += atom;
+    L.gHO = o; o += atom;
+    L.WhT = o; o += align_up((size_t)h * h, 4);
+    L.WoT = o; o += align_up((size_t)h * h, 4);
+    L.WdT = o; o += align_up((size_t)h * (h + dvd), 4);
+    L.p_h = plan_wgrad(nE, (int)h, (int)h + (f.b_h ? 1 : 0));
+    L.p_i = plan_wgrad(nE, (int)h, (int)(f.d_v + f.d_e) + (f.b_i ? 1 : 0));
+    L.p_o = plan_wgrad(nV, (int)h, (int)(f.d_v + h) + 1);
+    L.p_d = plan_wgrad(nV, (int)(h + dvd), (int)(h + dvd) + 1);
+    const int steps = f.depth > 1 ? f.depth - 1 : 1;
+    L.slab_h = o; o += align_up((size_t)L.p_h.splits * steps * L.p_h.slab_stride, 4);
+    size_t x = (size_t)L.p_i.splits * L.p_i.slab_stride;
+    const size_t xo = (size_t)L.p_o.splits * L.p_o.slab_stride, xd = dvd ? (size_t)L.p_d.splits * L.p_d.slab_stride : 0;
+    if (xo > x) x = xo;
+    if (xd > x) x = xd;
+    L.slab_x = o; o += align_up(x, 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+}  // namespace dmpnn
+
+using namespace dmpnn;
+
+extern "C" {
+
+size_t dmpnn_backward_ws_bytes(const dmpnn_fwd_args* f) {
+    if (!f) return 0;
+    return bwd_layout(*f).total * sizeof(float);
+}
+
+int dmpnn_message_bwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h, const float* gM, int64_t ld_gm,
+                      float* gH, int64_t ld_gh, void* stream) {
+    DMPNN_CHECK_ARG(plan && d_h >= 0 && ld_gm >= d_h && ld_gh >= d_h, "message_bwd: bad arguments");
+    DMPNN_CHECK_ARG(n_edges == 0 || (gM && gH), "message_bwd: null tensor");
+    EdgeBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pv = plan_view(plan, n_atoms, n_edges);
+    a.nV = (int)n_atoms; a.nE = (int)n_edges; a.h = (int)d_h;
+    a.gin = gM; a.ld_gin = ld_gm; a.gZ = gH; a.ldgz = ld_gh;
+    return launch_edge_bwd<EB_MESSAGE>(a, static_cast<hipStream_t>(stream), "k_edge_bwd<message>");
+}
+
+int dmpnn_aggregate_bwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h, const float* gMv,
+                        int64_t ld_gmv, float* gH, int64_t ld_gh, void* stream) {
+    DMPNN_CHECK_ARG(plan && d_h >= 0 && ld_gmv >= d_h && ld_gh >= d_h, "aggregate_bwd: bad arguments");
+    DMPNN_CHECK_ARG(n_edges == 0 || (gMv && gH), "aggregate_bwd: null tensor");
+    EdgeBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pv = plan_view(plan, n_atoms, n_edges);
+    a.nV = (int)n_atoms; a.nE = (int)n_edges; a.h = (int)d_h;
+    a.gin = gMv; a.ld_gin = ld_gmv; a.gZ = gH; a.ldgz = ld_gh;
+    return launch_edge_bwd<EB_GATHER>(a, static_cast<hipStream_t>(stream), "k_edge_bwd<gather>");
+}
+
+size_t dmpnn_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K, int has_bias) {
+    const WgradPlan p = plan_wgrad(M, (int)N, (int)K + (has_bias ? 1 : 0));
+    return (size_t)p.splits * p.slab_stride * sizeof(float);
+}
+
+/* gW[N, K1+K2] = gZ^T . [A1[gather] || A2],  gb[N] = colsum(gZ)   (either output may be NULL) */
+int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, float* gW, int64_t ldgw, float* gb,
+                       void* ws, size_t ws_bytes, void* stream) {
+    DMPNN_CHECK_ARG(g && gZ, "linear_wgrad: null args");
+    DMPNN_CHECK_ARG(g->M >= 0 && g->N > 0 && g->K1 + g->K2 > 0, "linear_wgrad: bad sizes");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int K = (int)(g->K1 + g->K2);
+    const int ones = gb ? 1 : 0;
+    const WgradPlan p = plan_wgrad(g->M, (int)g->N, K + ones);
+    if (ws_bytes < (size_t)p.splits * p.slab_stride * sizeof(float)) {
+        set_error("linear_wgrad: workspace too small");
+        return DMPNN_ENOSPC;
+    }
+    if (g->M == 0) {
+        if (gW) for (int64_t n = 0; n < g->N; ++n) hipMemsetAsync(gW + n * ldgw, 0, (size_t)K * sizeof(float), s);
+        if (gb) hipMemsetAsync(gb, 0, (size_t)g->N * sizeof(float), s);
+        return DMPNN_OK;
+    }
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = g->M; a.N = (int)g->N; a.K1 = (int)g->K1; a.K2 = (int)g->K2; a.ones = ones;
+    a.gZ = gZ; a.ldz = ldgz;
+    a.A1 = g->A1; a.lda1 = g->lda1; a.gather1 = g->gather1;
+    a.A2 = g->A2; a.lda2 = g->lda2;
+    DMPNN_TRY(launch_wgrad(a, p, static_cast<float*>(ws), s));
+    return launch_wgrad_reduce(static_cast<float*>(ws), p, p.splits, (int)g->N, K, ones, gW, ldgw, gb, s);
+}
+
+int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
+    DMPNN_CHECK_ARG(b != nullptr, "backward: null args");
+    const dmpnn_fwd_args& f = b->f;
+    const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dv = f.d_v, de = f.d_e;
+    const bool has_vd = f.W_d != nullptr;
+    const int64_t dvd = has_vd ? f.d_vd : 0;
+    const int T = f.depth;
+    DMPNN_CHECK_ARG(f.plan && h > 0 && dv > 0 && T >= 1, "backward: bad forward description");
+    DMPNN_CHECK_ARG(f.act >= DMPNN_ACT_RELU && f.act <= DMPNN_ACT_ELU && f.act != DMPNN_ACT_PRELU,
+                    "backward: activation %d has no fused backward (use the row kernels)", f.act);
+    DMPNN_CHECK_ARG(nV == 0 || b->gout, "backward: null gout");
+    DMPNN_CHECK_ARG(T == 1 || nE == 0 || (f.n_hslots >= T - 1 && f.n_mslots >= T - 1),
+                    "backward: the forward did not keep every H^(t) / M^(t) (n_hslots, n_mslots must be depth-1)");
+    const BwdLayout L = bwd_layout(f);
+    if (b->ws_bytes < L.total * sizeof(float) || !b->ws) {
+        set_error("backward: workspace too small (%zu < %zu bytes)", b->ws_bytes, L.total * sizeof(float));
+        return DMPNN_ENOSPC;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* ws = b->ws;
+    float *gZa = ws + L.gZa, *gZb = ws + L.gZb, *gH0 = ws + L.gH0, *gZO = ws + L.gZO, *gMv = ws + L.gMv;
+    float *gHO = ws + L.gHO, *WhT = ws + L.WhT, *WoT = ws + L.WoT, *WdT = ws + L.WdT;
+    float *slab_h = ws + L.slab_h, *slab_x = ws + L.slab_x;
+    const PlanView pv = plan_view(f.plan, nV, nE);
+    const int64_t ldh = f.ldh, slot = nE * ldh;
+
+    auto zero2d = [&](float* p, int64_t rows, int64_t cols) {
+        if (p && rows * cols > 0) hipMemsetAsync(p, 0, (size_t)(rows * cols) * sizeof(float), s);
+    };
+    if (nV == 0) {
+        zero2d(b->gW_i, h, dv + de); zero2d(b->gb_i, 1, h); zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h);
+        zero2d(b->gW_o, h, dv + h); zero2d(b->gb_o, 1, h); zero2d(b->gW_d, h + dvd, h + dvd); zero2d(b->gb_d, 1, h + dvd);
+        return DMPNN_OK;
+    }
+
+    // ---- finalize backward (base.py:180-194) ----
+    const float* gHO_p = b->gout;
+    int64_t ld_gHO = b->ldgout;
+    const float* HO = f.out;
+    int64_t ldHO = f.ldout;
+    if (has_vd) {
+        HO = f.Hv; ldHO = ldh;
+        if (b->gW_d || b->gb_d) {
+            WgradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.M = nV; a.N = (int)(h + dvd); a.K1 = (int)h; a.K2 = (int)dvd; a.ones = 1;
+            a.gZ = b->gout; a.ldz = b->ldgout;
+            a.A1 = f.Hv; a.lda1 = ldh; a.A2 = f.V_d; a.lda2 = f.ldvd;
+            DMPNN_TRY(launch_wgrad(a, L.p_d, slab_x, s));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_d, L.p_d.splits, (int)(h + dvd), (int)(h + dvd), 1, b->gW_d, h + dvd, b->gb_d, s));
+        }
+        // gHO = gout . W_d[:, :h]      via WdT[k][n] = W_d[n][k]
+        DMPNN_TRY(launch_transpose(f.W_d, h + dvd, WdT, h + dvd, (int)(h + dvd), (int)h, s));
+        dmpnn_gemm_args g;
+        memset(&g, 0, sizeof(g));
+        g.M = nV; g.N = h; g.K1 = h + dvd; g.A1 = b->gout; g.lda1 = b->ldgout;
+        g.W = WdT; g.ldw = h + dvd; g.C = gHO; g.ldc = ldh; g.act = DMPNN_ACT_NONE;
+        DMPNN_TRY(launch_linear(g, s));
+        gHO_p = gHO; ld_gHO = ldh;
+    }
+    {
+        const int64_t n = nV * h;
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)blocks), dim3(256), 0, s, gHO_p, ld_gHO, HO, ldHO, gZO, ldh, nV, (int)h,
+                           f.act, f.act_slope, f.act_slope_ptr);
+        DMPNN_CHECK_LAUNCH("k_act_bwd");
+    }
+    if (b->gW_o || b->gb_o) {
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.M = nV; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)h; a.ones = 1;
+        a.gZ = gZO; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.A2 = f.Mv; a.lda2 = ldh;
+        DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s));
+        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, L.p_o.splits, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s));
+    }
+    const bool need_edges = b->gW_i || b->gb_i || b->gW_h || b->gb_h;
+    if (!need_edges) return DMPNN_OK;
+    if (nE == 0) {
+        zero2d(b->gW_i, h, dv + de); zero2d(b->gb_i, 1, h); zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h);
+        return DMPNN_OK;
+    }
+    // gMv = gZO . W_o[:, d_v:]
+    {
+        DMPNN_TRY(launch_transpose(f.W_o + dv, dv + h, WoT, h, (int)h, (int)h, s));
+        dmpnn_gemm_args g;
+        memset(&g, 0, sizeof(g));
+        g.M = nV; g.N = h; g.K1 = h; g.A1 = gZO; g.lda1 = ldh; g.W = WoT; g.ldw = h; g.C = gMv; g.ldc = ldh;
+        g.act = DMPNN_ACT_NONE;
+        DMPNN_TRY(launch_linear(g, s));
+    }
+    EdgeBwdArgs e;
+    memset(&e, 0, sizeof(e));
+    e.pv = pv; e.nV = (int)nV; e.nE = (int)nE; e.h = (int)h;
+    e.act = f.act; e.slope = f.act_slope; e.slope_ptr = f.act_slope_ptr;
+    const bool undirected = f.flags & DMPNN_F_UNDIRECTED;
+    int n_slabs_h = 0;
+    if (T >= 2) {
+        DMPNN_TRY(launch_transpose(f.W_h, h, WhT, h, (int)h, (int)h, s));
+        // gZ^(T-1) = gMv[dst] * tau'(H^(T-1));  gH0 = gZ^(T-1)
+        EdgeBwdArgs g0 = e;
+        g0.gin = gMv; g0.ld_gin = ldh;
+        g0.Y = f.Hs + (int64_t)(T - 2) * slot; g0.ldy = ldh; g0.y_preact = 0;
+        g0.gZ = gZa; g0.ldgz = ldh; g0.acc = gH0; g0.ldacc = ldh; g0.acc_init = 1;
+        DMPNN_TRY(launch_edge_bwd<EB_GATHER>(g0, s, "k_edge_bwd<gather>"));
+        float* gZ = gZa;
+        float* other = gZb;
+        for (int t = T - 1; t >= 1; --t) {
+            const float* Mt = f.Ms + (int64_t)(t - 1) * slot;
+            if (b->gW_h || b->gb_h) {
+                WgradArgs a;
+                memset(&a, 0, sizeof(a));
+                a.M = nE; a.N = (int)h; a.K1 = (int)h; a.K2 = 0; a.ones = f.b_h ? 1 : 0;
+                a.gZ = gZ; a.ldz = ldh; a.A1 = Mt; a.lda1 = ldh;
+                DMPNN_TRY(launch_wgrad(a, L.p_h, slab_h + (int64_t)n_slabs_h * L.p_h.slab_stride, s));
+                n_slabs_h += L.p_h.splits;
+            }
+            // gM = gZ . W_h
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = nE; g.N = h; g.K1 = h; g.A1 = gZ; g.lda1 = ldh; g.W = WhT; g.ldw = h; g.C = other; g.ldc = ldh;
+            g.act = DMPNN_ACT_NONE;
+            DMPNN_TRY(launch_linear(g, s));
+            // gH^(t-1) -> masked gZ^(t-1), accumulated into gH0
+            const bool first = (t - 1) == 0;
+            const float* Yprev = first ? f.H0 : f.Hs + (int64_t)(t - 2) * slot;
+            EdgeBwdArgs m = e;
+            m.gin = other; m.ld_gin = ldh;
+            if (!undirected) {
+                m.Y = Yprev; m.ldy = ldh; m.y_preact = first ? 1 : 0;
+                m.gZ = first ? nullptr : gZ; m.ldgz = ldh;
+                m.acc = gH0; m.ldacc = ldh; m.acc_init = 0;
+                DMPNN_TRY(launch_edge_bwd<EB_MESSAGE>(m, s, "k_edge_bwd<message>"));
+            } else {
+                m.gZ = gZ; m.ldgz = ldh;  // raw gHb
+                DMPNN_TRY(launch_edge_bwd<EB_MESSAGE>(m, s, "k_edge_bwd<message>"));
+                EdgeBwdArgs v = e;
+                v.gin = gZ; v.ld_gin = ldh;
+                v.Y = Yprev; v.ldy = ldh; v.y_preact = first ? 1 : 0;
+                v.gZ = first ? nullptr : other; v.ldgz = ldh;
+                v.acc = gH0; v.ldacc = ldh; v.acc_init = 0;
+                DMPNN_TRY(launch_edge_bwd<EB_AVG>(v, s, "k_edge_bwd<avg>"));
+                float* tmp = gZ; gZ = other; other = tmp;
+            }
+        }
+        if (b->gW_h || b->gb_h)
+            DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_h, n_slabs_h, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s));
+    } else {
+        // depth 1: gH0 = gMv[dst] * tau'(tau(H0))
+        EdgeBwdArgs g0 = e;
+        g0.gin = gMv; g0.ld_gin = ldh;
+        g0.Y = f.H0; g0.ldy = ldh; g0.y_preact = 1;
+        g0.acc = gH0; g0.ldacc = ldh; g0.acc_init = 1;
+        DMPNN_TRY(launch_edge_bwd<EB_GATHER>(g0, s, "k_edge_bwd<gather>"));
+        zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h);
+    }
+    if (b->gW_i || b->gb_i) {
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.M = nE; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)de; a.ones = f.b_i ? 1 : 0;
+        a.gZ = gH0; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.gather1 = pv.src; a.A2 = f.E; a.lda2 = f.lde;
+        DMPNN_TRY(launch_wgrad(a, L.p_i, slab_x, s));
+        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, L.p_i.splits, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s));
+    }
+    return DMPNN_OK;
+}
+
+}  // extern "C"

@@ -144,12 +144,138 @@ __global__ void k_sort_rows(int* __restrict__ plan, PlanLayout L, int nV) {
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&plan[DMPNN_HDR_MAXDEG], m);
 }
 
+// ---- single-workgroup plan for small batches (the launch-bound regime: 512 QM9 molecules are
+// ~9k edges / ~4.6k atoms) -----------------------------------------------------------------------
+// All five phases in ONE launch; the per-atom counters live in LDS (workgroup-coherent, so no
+// cross-CU visibility protocol is needed), global memory only sees plain stores that are re-read
+// after a workgroup barrier by waves of the same CU.
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallMaxAtoms = 16384;
+constexpr int kSmallMaxEdges = 32768;
+constexpr int kSmallItems = kSmallMaxAtoms / kSmallThreads;  // 16 counters per thread in the scan
+
+__global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* __restrict__ edge_index,
+                                                                const int64_t* __restrict__ rev64,
+                                                                int* __restrict__ plan, PlanLayout L, int nV, int nE) {
+    extern __shared__ int cnt[];  // [nV] in-degree, then fill cursor
+    __shared__ int wave_tot[kSmallThreads / 64];
+    __shared__ int flags_s, maxdeg_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < nV; i += kSmallThreads) cnt[i] = 0;
+    if (tid == 0) { flags_s = 0; maxdeg_s = 0; }
+    __syncthreads();
+    // phase 1: narrow + validate + histogram
+    int bad = 0;
+    for (int e = tid; e < nE; e += kSmallThreads) {
+        int64_t s = edge_index[e], d = edge_index[(int64_t)nE + e], r = rev64[e];
+        if (s < 0 || s >= nV || d < 0 || d >= nV || r < 0 || r >= nE) {
+            bad |= PLAN_RANGE_ERROR | PLAN_ASYMMETRIC;
+            s = s < 0 ? 0 : (s >= nV ? nV - 1 : s);
+            d = d < 0 ? 0 : (d >= nV ? nV - 1 : d);
+            r = r < 0 ? 0 : (r >= nE ? nE - 1 : r);
+        } else {
+            const int64_t rr = rev64[r];
+            const int64_t sr = edge_index[r], dr = edge_index[(int64_t)nE + r];
+            if (rr != e || sr != d || dr != s) bad |= PLAN_ASYMMETRIC;
+        }
+        plan[L.src + e] = (int)s;
+        plan[L.dst + e] = (int)d;
+        plan[L.rev + e] = (int)r;
+        atomicAdd(&cnt[d], 1);
+    }
+    if (bad) atomicOr(&flags_s, bad);
+    __syncthreads();
+    // phase 2: exclusive scan of cnt[0..nV) (16 consecutive counters per thread)
+    {
+        int v[kSmallItems];
+        int tot = 0;
+        const int i0 = tid * kSmallItems;
+#pragma unroll
+        for (int j = 0; j < kSmallItems; ++j) {
+            v[j] = (i0 + j < nV) ? cnt[i0 + j] : 0;
+            tot += v[j];
+        }
+        int inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_tot[wid] = inc;
+        __syncthreads();
+        int wave_base = 0;
+        for (int w = 0; w < wid; ++w) wave_base += wave_tot[w];
+        int run = wave_base + inc - tot;
+        int md = 0;
+#pragma unroll
+        for (int j = 0; j < kSmallItems; ++j) {
+            if (i0 + j < nV) {
+                plan[L.row_ptr + i0 + j] = run;
+                cnt[i0 + j] = run;
+            }
+            run += v[j];
+            md = max(md, v[j]);
+        }
+        if (tid == kSmallThreads - 1) plan[L.row_ptr + nV] = run;
+        for (int off = 32; off > 0; off >>= 1) md = max(md, __shfl_xor(md, off));
+        if (lane == 0 && md > 0) atomicMax(&maxdeg_s, md);
+    }
+    __syncthreads();
+    // phase 3: fill rows (order inside a row is arbitrary here)
+    for (int e = tid; e < nE; e += kSmallThreads) {
+        const int d = plan[L.dst + e];
+        const int pos = atomicAdd(&cnt[d], 1);
+        plan[L.perm + pos] = e;
+    }
+    __syncthreads();
+    // phase 4: restore increasing edge id inside every row (the reference's summation order)
+    for (int v = tid; v < nV; v += kSmallThreads) {
+        const int b = plan[L.row_ptr + v];
+        const int n = cnt[v] - b;  // cursor has advanced to the end of the row
+        int* row = plan + L.perm + b;
+        for (int i = 1; i < n; ++i) {
+            const int key = row[i];
+            int j = i - 1;
+            while (j >= 0 && row[j] > key) {
+                row[j + 1] = row[j];
+                --j;
+            }
+            row[j + 1] = key;
+        }
+    }
+    if (tid < DMPNN_HDR_WORDS) {
+        int v = 0;
+        if (tid == DMPNN_HDR_FLAGS) v = flags_s;
+        if (tid == DMPNN_HDR_MAXDEG) v = maxdeg_s;
+        if (tid == DMPNN_HDR_NATOMS) v = nV;
+        if (tid == DMPNN_HDR_NEDGES) v = nE;
+        plan[tid] = v;
+    }
+}
+
 }  // namespace
 
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, int64_t nE64,
                    int* plan, hipStream_t s) {
     const int nV = (int)nV64, nE = (int)nE64;
     const PlanLayout L = plan_layout(nV, nE);
+    if (nV <= kSmallMaxAtoms && nE <= kSmallMaxEdges) {
+        const size_t lds = (size_t)(nV > 0 ? nV : 1) * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_small),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(kSmallMaxAtoms * sizeof(int)));
+            if (e != hipSuccess) {
+                set_error("hipFuncSetAttribute(k_prepare_small): %s", hipGetErrorString(e));
+                return DMPNN_EHIP;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(kSmallThreads), lds, s, edge_index, rev, plan, L, nV, nE);
+        DMPNN_CHECK_LAUNCH("k_prepare_small");
+        return DMPNN_OK;
+    }
     {
         const int64_t n = nV > DMPNN_HDR_WORDS ? nV : DMPNN_HDR_WORDS;
         int grid = (int)((n + kBlock - 1) / kBlock);

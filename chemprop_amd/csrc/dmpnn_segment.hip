@@ -27,7 +27,6 @@ namespace dmpnn {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kKeep = 8;  // incoming rows kept in registers (in-degree of molecules is <= ~6)
 
 template <int VEC>
 struct Vec;
@@ -70,20 +69,113 @@ struct SegArgs {
 };
 
 // Load row e (element offset c) of the message input: tau-on-load and undirected averaging.
-template <int VEC>
-__device__ __forceinline__ typename Vec<VEC>::T load_row(const SegArgs& a, int e, int c, float slope) {
+// UNDIR and ACT are template parameters (-1 = decided at run time, the slow generic build) so that
+// in the hot instantiations no load sits under a runtime branch and no activation switch separates
+// a load from its use (hipcc would wait vmcnt(0) per load, serialising the row reads).
+template <int ACT>
+__device__ __forceinline__ float act1(float z, int act_rt, float slope) {
+    if (ACT == DMPNN_ACT_NONE) return z;
+    if (ACT == DMPNN_ACT_RELU) return z < 0.f ? 0.f : z;
+    return apply_act(z, act_rt, slope);
+}
+template <int VEC, int ACT>
+__device__ __forceinline__ typename Vec<VEC>::T actv(typename Vec<VEC>::T r, int act_rt, float slope);
+template <>
+__device__ __forceinline__ float actv<1, DMPNN_ACT_NONE>(float r, int, float) { return r; }
+template <>
+__device__ __forceinline__ float actv<1, DMPNN_ACT_RELU>(float r, int a, float s) { return act1<DMPNN_ACT_RELU>(r, a, s); }
+template <>
+__device__ __forceinline__ float actv<1, -1>(float r, int a, float s) { return apply_act(r, a, s); }
+template <>
+__device__ __forceinline__ float4 actv<4, DMPNN_ACT_NONE>(float4 r, int, float) { return r; }
+template <>
+__device__ __forceinline__ float4 actv<4, DMPNN_ACT_RELU>(float4 r, int, float) {
+    return make_float4(r.x < 0.f ? 0.f : r.x, r.y < 0.f ? 0.f : r.y, r.z < 0.f ? 0.f : r.z, r.w < 0.f ? 0.f : r.w);
+}
+template <>
+__device__ __forceinline__ float4 actv<4, -1>(float4 r, int a, float s) { return apply_act4(r, a, s); }
+
+template <int VEC, int UNDIR, int ACT>
+__device__ __forceinline__ typename Vec<VEC>::T load_row(const SegArgs& a, int e, int er, int c, float slope) {
     using V = Vec<VEC>;
-    typename V::T r = V::act(V::load(a.Hin + (int64_t)e * a.ld_in + c), a.act, slope);
-    if (a.undirected) {
-        const int er = a.pv.rev[e];
-        typename V::T q = V::act(V::load(a.Hin + (int64_t)er * a.ld_in + c), a.act, slope);
-        r = V::half_sum(r, q);
+    typename V::T r = V::load(a.Hin + (int64_t)e * a.ld_in + c);
+    if (UNDIR == 1 || (UNDIR == -1 && a.undirected)) {
+        typename V::T q = V::load(a.Hin + (int64_t)er * a.ld_in + c);
+        r = V::half_sum(actv<VEC, ACT>(r, a.act, slope), actv<VEC, ACT>(q, a.act, slope));
+    } else {
+        r = actv<VEC, ACT>(r, a.act, slope);
     }
     return r;
 }
 
+// One atom with in-degree exactly D (all D row loads issued back to back, unconditionally), two
+// column groups per pass (lane and lane+64: a 300-float row is 75 float4).
+template <int VEC, int MODE, int UNDIR, int ACT, int D>
+__device__ __forceinline__ void atom_body(const SegArgs& a, int v, int beg, int lane, int n_cols, float slope) {
+    using V = Vec<VEC>;
+    using T = typename V::T;
+    int eid[D], erev[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) eid[i] = a.pv.perm[beg + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) erev[i] = (MODE == 0 || UNDIR != 0) ? a.pv.rev[eid[i]] : 0;
+    for (int cg0 = 0; cg0 < n_cols; cg0 += 128) {
+        const int cgA = cg0 + lane, cgB = cg0 + 64 + lane;
+        const bool okA = cgA < n_cols, okB = cgB < n_cols;
+        const int cA = (okA ? cgA : 0) * VEC, cB = (okB ? cgB : 0) * VEC;
+        T rA[D], rB[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            rA[i] = load_row<VEC, UNDIR, ACT>(a, eid[i], erev[i], cA, slope);
+            rB[i] = load_row<VEC, UNDIR, ACT>(a, eid[i], erev[i], cB, slope);
+        }
+        T SA = rA[0], SB = rB[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) {
+            SA = V::add(SA, rA[i]);
+            SB = V::add(SB, rB[i]);
+        }
+        if (MODE == 1) {
+            if (okA) V::store(a.out + (int64_t)v * a.ld_out + cA, SA);
+            if (okB) V::store(a.out + (int64_t)v * a.ld_out + cB, SB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float* o = a.out + (int64_t)erev[i] * a.ld_out;
+                if (okA) V::store(o + cA, V::sub(SA, rA[i]));
+                if (okB) V::store(o + cB, V::sub(SB, rB[i]));
+            }
+        }
+    }
+}
+
+// Any in-degree (used for d > 6): running sum, rows re-read for the write-back (they hit L1/L2).
+template <int VEC, int MODE, int UNDIR, int ACT>
+__device__ __forceinline__ void atom_body_any(const SegArgs& a, int v, int beg, int d, int lane, int n_cols, float slope) {
+    using V = Vec<VEC>;
+    using T = typename V::T;
+    for (int cg = lane; cg < n_cols; cg += 64) {
+        const int c = cg * VEC;
+        T S = V::zero();
+        for (int i = 0; i < d; ++i) {
+            const int e = a.pv.perm[beg + i];
+            const T r = load_row<VEC, UNDIR, ACT>(a, e, a.pv.rev[e], c, slope);
+            S = (i == 0) ? r : V::add(S, r);
+        }
+        if (MODE == 1) {
+            V::store(a.out + (int64_t)v * a.ld_out + c, S);
+        } else {
+            for (int i = 0; i < d; ++i) {
+                const int e = a.pv.perm[beg + i];
+                const int er = a.pv.rev[e];
+                V::store(a.out + (int64_t)er * a.ld_out + c, V::sub(S, load_row<VEC, UNDIR, ACT>(a, e, er, c, slope)));
+            }
+        }
+    }
+}
+
 // MODE 0: message (atom form when the graph is symmetric, edge form otherwise); MODE 1: aggregate.
-template <int VEC, int MODE>
+template <int VEC, int MODE, int UNDIR, int ACT>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void k_segment(SegArgs a) {
     using V = Vec<VEC>;
     using T = typename V::T;
@@ -98,33 +190,22 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_segment(SegArgs a) {
         for (int v = wave; v < a.nV; v += n_waves) {
             const int beg = a.pv.row_ptr[v];
             const int d = a.pv.row_ptr[v + 1] - beg;
-            if (MODE == 0 && d == 0) continue;
-            int eid[kKeep];
-#pragma unroll
-            for (int i = 0; i < kKeep; ++i) eid[i] = (i < d) ? a.pv.perm[beg + i] : 0;
-            for (int cg = lane; cg < n_cols; cg += 64) {
-                const int c = cg * VEC;
-                T r[kKeep];
-#pragma unroll
-                for (int i = 0; i < kKeep; ++i)
-                    if (i < d) r[i] = load_row<VEC>(a, eid[i], c, slope);
-                T S = d > 0 ? r[0] : V::zero();
-#pragma unroll
-                for (int i = 1; i < kKeep; ++i)
-                    if (i < d) S = V::add(S, r[i]);
-                for (int i = kKeep; i < d; ++i)  // rare: in-degree > kKeep
-                    S = V::add(S, load_row<VEC>(a, a.pv.perm[beg + i], c, slope));
-                if (MODE == 1) {
-                    V::store(a.out + (int64_t)v * a.ld_out + c, S);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < kKeep; ++i)
-                        if (i < d) V::store(a.out + (int64_t)a.pv.rev[eid[i]] * a.ld_out + c, V::sub(S, r[i]));
-                    for (int i = kKeep; i < d; ++i) {
-                        const int e = a.pv.perm[beg + i];
-                        V::store(a.out + (int64_t)a.pv.rev[e] * a.ld_out + c, V::sub(S, load_row<VEC>(a, e, c, slope)));
-                    }
-                }
+            if (ACT == -1) {  // generic build: one compact loop for every in-degree
+                if (d > 0 || MODE == 1) atom_body_any<VEC, MODE, UNDIR, ACT>(a, v, beg, d, lane, n_cols, slope);
+                continue;
+            }
+            switch (d) {  // wave-uniform: one straight-line body per in-degree
+                case 0:
+                    if (MODE == 1)
+                        for (int cg = lane; cg < n_cols; cg += 64) V::store(a.out + (int64_t)v * a.ld_out + cg * VEC, V::zero());
+                    break;
+                case 1: atom_body<VEC, MODE, UNDIR, ACT, 1>(a, v, beg, lane, n_cols, slope); break;
+                case 2: atom_body<VEC, MODE, UNDIR, ACT, 2>(a, v, beg, lane, n_cols, slope); break;
+                case 3: atom_body<VEC, MODE, UNDIR, ACT, 3>(a, v, beg, lane, n_cols, slope); break;
+                case 4: atom_body<VEC, MODE, UNDIR, ACT, 4>(a, v, beg, lane, n_cols, slope); break;
+                case 5: atom_body<VEC, MODE, UNDIR, ACT, 5>(a, v, beg, lane, n_cols, slope); break;
+                case 6: atom_body<VEC, MODE, UNDIR, ACT, 6>(a, v, beg, lane, n_cols, slope); break;
+                default: atom_body_any<VEC, MODE, UNDIR, ACT>(a, v, beg, d, lane, n_cols, slope); break;
             }
         }
     } else {
@@ -138,10 +219,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void k_segment(SegArgs a) {
                 const int c = cg * VEC;
                 T S = V::zero();
                 for (int i = 0; i < d; ++i) {
-                    T r = load_row<VEC>(a, a.pv.perm[beg + i], c, slope);
+                    const int ei = a.pv.perm[beg + i];
+                    const T r = load_row<VEC, UNDIR, ACT>(a, ei, a.pv.rev[ei], c, slope);
                     S = (i == 0) ? r : V::add(S, r);
                 }
-                V::store(a.out + (int64_t)e * a.ld_out + c, V::sub(S, load_row<VEC>(a, er, c, slope)));
+                V::store(a.out + (int64_t)e * a.ld_out + c, V::sub(S, load_row<VEC, UNDIR, ACT>(a, er, a.pv.rev[er], c, slope)));
             }
         }
     }
@@ -155,10 +237,16 @@ int launch_segment(const SegArgs& a, hipStream_t s, const char* name) {
     const int64_t cap = 256 * 32;  // grid-stride beyond 32 blocks per CU
     if (blocks > cap) blocks = cap;
     const bool vec = (a.h % 4 == 0) && (a.ld_in % 4 == 0) && (a.ld_out % 4 == 0) && aligned16(a.Hin) && aligned16(a.out);
-    if (vec)
-        hipLaunchKernelGGL((k_segment<4, MODE>), dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+    const dim3 grid((unsigned)blocks), block(kWavesPerBlock * 64);
+    // hot instantiations: 16-byte lanes, directed, tau in {identity, ReLU}; everything else -> generic build
+    if (vec && !a.undirected && a.act == DMPNN_ACT_NONE)
+        hipLaunchKernelGGL((k_segment<4, MODE, 0, DMPNN_ACT_NONE>), grid, block, 0, s, a);
+    else if (vec && !a.undirected && a.act == DMPNN_ACT_RELU)
+        hipLaunchKernelGGL((k_segment<4, MODE, 0, DMPNN_ACT_RELU>), grid, block, 0, s, a);
+    else if (vec)
+        hipLaunchKernelGGL((k_segment<4, MODE, -1, -1>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((k_segment<1, MODE>), dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), 0, s, a);
+        hipLaunchKernelGGL((k_segment<1, MODE, -1, -1>), grid, block, 0, s, a);
     DMPNN_CHECK_LAUNCH(name);
     return DMPNN_OK;
 }

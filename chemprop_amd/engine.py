@@ -161,7 +161,7 @@ def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Te
 class ForwardState:
     """Workspace of one forward; kept alive for the backward pass when ``keep`` is set."""
 
-    __slots__ = ("plan", "H0", "Hs", "Ms", "Mv", "Hv", "ldh", "n_hslots", "n_mslots", "out")
+    __slots__ = ("plan", "H0", "Hs", "Ms", "Mv", "Hv", "ldh", "n_hslots", "n_mslots", "out", "args", "refs", "dims")
 
 
 def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o: Tensor, b_o: Tensor,
@@ -217,4 +217,78 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     a.out, a.ldout = out.data_ptr(), out.stride(0)
     with torch.cuda.device(dev):
         _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
+    st.args = a
+    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws)
+    st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)
     return out, st
+
+
+def backward(st: ForwardState, gout: Tensor, need: dict) -> dict:
+    """K6: parameter gradients of a kept forward.  ``need`` maps W_i/b_i/W_h/b_h/W_o/b_o/W_d/b_d -> bool."""
+    from ._lib import BwdArgs
+
+    lib = _lib.load()
+    gout = _f32c(gout, "grad_output")
+    dev = gout.device
+    d = st.dims
+    h, dv, de, dvd = d["d_h"], d["d_v"], d["d_e"], d["d_vd"]
+    shapes = dict(W_i=(h, dv + de), b_i=(h,), W_h=(h, h), b_h=(h,), W_o=(h, dv + h), b_o=(h,),
+                  W_d=(h + dvd, h + dvd), b_d=(h + dvd,))
+    present = dict(W_i=True, b_i=d["has_bi"], W_h=True, b_h=d["has_bh"], W_o=True, b_o=True, W_d=dvd > 0, b_d=dvd > 0)
+    grads = {k: (torch.empty(shapes[k], dtype=torch.float32, device=dev) if (need.get(k) and present[k]) else None)
+             for k in shapes}
+    b = BwdArgs()
+    b.f = st.args
+    b.gout, b.ldgout = gout.data_ptr(), gout.stride(0)
+    for k, g in grads.items():
+        setattr(b, "g" + k, _ptr(g))
+    nbytes = lib.dmpnn_backward_ws_bytes(C.byref(st.args))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+    b.ws, b.ws_bytes = ws.data_ptr(), nbytes
+    with torch.cuda.device(dev):
+        _lib.check(lib.dmpnn_backward(C.byref(b), _stream_ptr(dev)), "dmpnn_backward")
+    return grads
+
+
+def message_bwd(plan: GraphPlan, gM: Tensor) -> Tensor:
+    gM = _f32c(gM, "gM")
+    gH = torch.empty_like(gM)
+    with torch.cuda.device(gM.device):
+        _lib.check(_lib.load().dmpnn_message_bwd(plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, gM.shape[1],
+                                                 gM.data_ptr(), gM.stride(0), gH.data_ptr(), gH.stride(0),
+                                                 _stream_ptr(gM.device)), "dmpnn_message_bwd")
+    return gH
+
+
+def aggregate_bwd(plan: GraphPlan, gMv: Tensor) -> Tensor:
+    gMv = _f32c(gMv, "gMv")
+    gH = torch.empty(plan.n_edges, gMv.shape[1], dtype=torch.float32, device=gMv.device)
+    with torch.cuda.device(gMv.device):
+        _lib.check(_lib.load().dmpnn_aggregate_bwd(plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, gMv.shape[1],
+                                                   gMv.data_ptr(), gMv.stride(0), gH.data_ptr(), gH.stride(0),
+                                                   _stream_ptr(gMv.device)), "dmpnn_aggregate_bwd")
+    return gH
+
+
+def linear_wgrad(gZ: Tensor, A1: Tensor, A2: Optional[Tensor] = None, gather1: Optional[Tensor] = None,
+                 want_bias: bool = False) -> tuple[Tensor, Optional[Tensor]]:
+    """``gW = gZ^T @ [A1[gather] || A2]`` (and ``gb = gZ.sum(0)``) on the split-M MFMA kernel."""
+    gZ = _f32c(gZ, "gZ")
+    A1 = _f32c(A1, "A1")
+    if A2 is not None:
+        A2 = _f32c(A2, "A2")
+    lib = _lib.load()
+    M, N = int(gZ.shape[0]), int(gZ.shape[1])
+    K1, K2 = int(A1.shape[1]), (int(A2.shape[1]) if A2 is not None else 0)
+    g = GemmArgs()
+    g.M, g.N, g.K1, g.K2 = M, N, K1, K2
+    g.A1, g.lda1, g.gather1 = A1.data_ptr(), A1.stride(0), _ptr(gather1)
+    g.A2, g.lda2 = _ptr(A2), (A2.stride(0) if A2 is not None else 0)
+    gW = torch.empty(N, K1 + K2, dtype=torch.float32, device=gZ.device)
+    gb = torch.empty(N, dtype=torch.float32, device=gZ.device) if want_bias else None
+    nbytes = lib.dmpnn_linear_wgrad_ws_bytes(M, N, K1 + K2, 1 if want_bias else 0)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=gZ.device)
+    with torch.cuda.device(gZ.device):
+        _lib.check(lib.dmpnn_linear_wgrad(C.byref(g), gZ.data_ptr(), gZ.stride(0), gW.data_ptr(), gW.stride(0),
+                                          _ptr(gb), ws.data_ptr(), nbytes, _stream_ptr(gZ.device)), "dmpnn_linear_wgrad")
+    return gW, gb

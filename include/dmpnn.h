@@ -154,6 +154,38 @@ typedef struct dmpnn_fwd_args {
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K6  backward.  The reference has no backward code of its own: gradients come from torch autograd
+ * through the ATen ops of base.py:196-212 / mixins.py:8-18 (training: models/model.py:148-161).
+ * These entry points are what a torch.autograd.Function around the forward calls.
+ * Gradients are produced for the parameters only (features and indices are data).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dmpnn_bwd_args {
+    dmpnn_fwd_args f;                    /* the forward call, with its KEPT workspace
+                                            (n_hslots = n_mslots = depth-1) and its output         */
+    const float* gout; int64_t ldgout;   /* dL/d out  [n_atoms, d_h (+ d_vd)]                       */
+    /* outputs, dense nn.Linear layout; any may be NULL (not needed / frozen)                      */
+    float* gW_i; float* gb_i; float* gW_h; float* gb_h;
+    float* gW_o; float* gb_o; float* gW_d; float* gb_d;
+    float* ws; size_t ws_bytes;          /* caller-owned scratch, >= dmpnn_backward_ws_bytes(&f)   */
+} dmpnn_bwd_args;
+size_t dmpnn_backward_ws_bytes(const dmpnn_fwd_args* f);
+int dmpnn_backward(const dmpnn_bwd_args* a, void* stream);
+
+/* Row-level backward (used when the activation / dropout modules run in torch between kernels).
+ *   message_bwd    gH[e'] = sum_{e: src(e)=dst(e')} gM[e] - gM[rev(e')]   (transpose of K2, directed)
+ *   aggregate_bwd  gH[e]  = gMv[dst(e)]                                   (transpose of K4)
+ *   linear_wgrad   gW = gZ^T . [A1[gather] || A2],  gb = colsum(gZ)       (g describes the FORWARD
+ *                  operands A1/A2/gather/M/N/K1/K2; W, C, act fields are ignored)
+ * The data gradient of a contraction is dmpnn_linear_fwd on the transposed weight.               */
+int dmpnn_message_bwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h,
+                      const float* gM, int64_t ld_gm, float* gH, int64_t ld_gh, void* stream);
+int dmpnn_aggregate_bwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h,
+                        const float* gMv, int64_t ld_gmv, float* gH, int64_t ld_gh, void* stream);
+size_t dmpnn_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K, int has_bias);
+int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, float* gW, int64_t ldgw,
+                       float* gb, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Misc
  * ------------------------------------------------------------------------------------------- */
 int dmpnn_version(void);

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Timing probe for the fp32-MFMA contraction: separates fixed cost from per-k-chunk cost."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from chemprop_amd import engine, synth
+
+dev = torch.device("cuda:0")
+def t_ms(fn, reps=30):
+    for _ in range(5): fn()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); b.synchronize()
+    return a.elapsed_time(b) / reps
+
+only = sys.argv[1] if len(sys.argv) > 1 else "all"
+print(f"{'M':>8} {'N':>5} {'K':>5} {'cadd':>5} {'us':>9} {'TF':>8}")
+shapes = [(9120, 300, 32, 0), (9120, 300, 96, 0), (9120, 300, 300, 0), (9120, 300, 300, 1), (9120, 300, 600, 1),
+          (9120, 300, 88, 0), (9120, 300, 86, 0), (4636, 300, 372, 0), (12288, 300, 300, 1), (36864, 300, 300, 1),
+          (73728, 300, 300, 1), (582580, 300, 300, 1), (9120, 64, 300, 1), (256 * 48, 300, 304, 1)]
+if only == "one":
+    shapes = [(9120, 300, 300, 1)]
+for (M, N, K, cadd) in shapes:
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
+    C = torch.empty(M, N, device=dev); Cadd = torch.randn(M, N, device=dev) if cadd else None
+    fn = lambda: engine.linear(A, W, None, Cadd=Cadd, act="relu", out=C)
+    ms = t_ms(fn)
+    print(f"{M:8d} {N:5d} {K:5d} {cadd:5d} {ms*1e3:9.2f} {2.0*M*N*K/ms/1e9:8.2f}")
+# K1-like: gather + concat, scalar path
+bmg = synth.random_batch(512, "qm9", seed=1000); bmg.to(dev)
+plan = engine.GraphPlan.from_bmg(bmg)
+Wi = torch.randn(300, 86, device=dev)
+fn = lambda: engine.linear(bmg.V, Wi, None, A2=bmg.E, gather1=plan.src32, n_rows=plan.n_edges)
+print("K1 (gather+concat, K=86):", round(t_ms(fn) * 1e3, 2), "us")
+fn = lambda: engine.GraphPlan.from_bmg(bmg)
+print("K0 plan (512 mols):", round(t_ms(fn) * 1e3, 2), "us")
+H = torch.randn(plan.n_edges, 300, device=dev); Mo = torch.empty_like(H)
+print("K2 message:", round(t_ms(lambda: engine.message(plan, H, out=Mo)) * 1e3, 2), "us")
+print("K4 aggregate:", round(t_ms(lambda: engine.aggregate(plan, H)) * 1e3, 2), "us")

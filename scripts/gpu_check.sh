@@ -18,7 +18,7 @@ timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/be
 cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err | tee -a $OUT/summary.txt
 echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $OUT/prof_bench.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $OUT/prof_bench.json 2> $OUT/prof.err
 echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 find $OUT/prof -name "*stats*" | head; 
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -25 $f | tee -a $OUT/summary.txt; done

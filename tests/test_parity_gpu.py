@@ -203,3 +203,117 @@ def test_custom_activation_and_dropout_rows_route(gpu_device):
     with torch.no_grad():
         out = mp(bmg)
     assert parity_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# K6: gradients
+# ------------------------------------------------------------------------------------------------
+def _check_grads(golden, named_grads, tol):
+    checked = 0
+    for key, g in named_grads.items():
+        g = g.detach().cpu().numpy()
+        if "g." + key in golden:
+            err = parity_err(g, golden["g." + key])
+            assert err <= tol, f"{golden.name}: d{key} {err:.3e}"
+            checked += 1
+        elif "gs." + key in golden:
+            idx = np.random.default_rng(golden.meta["seed"]).choice(g.size, size=2048, replace=False)
+            ref = golden["gs." + key]
+            scale = max(1.0, float(golden["gsum." + key][1]) / g.size * 50)  # sampled: scale by the tensor's magnitude
+            assert float(np.max(np.abs(g.ravel()[idx] - ref))) <= tol * max(scale, float(np.max(np.abs(ref)))), key
+            checked += 1
+    return checked
+
+
+def test_backward_matches_executed_reference(golden, gpu_device):
+    """Parameter gradients of sum(out * G) against autograd of the executed reference."""
+    mp = golden.module(gpu_device).train()  # dropout p = 0 in every golden case
+    bmg = golden.bmg(gpu_device)
+    V_d = torch.from_numpy(golden["V_d"]).to(gpu_device) if "V_d" in golden else None
+    G = torch.from_numpy(golden["G"]).to(gpu_device)
+    out = mp(bmg, V_d)
+    assert parity_err(out.detach().cpu().numpy(), golden["out"]) <= TOL
+    (out * G).sum().backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in mp.named_parameters()}
+    if golden.name.startswith("garbage"):
+        # not a molecular graph: the engine refuses (loudly, NaN) to differentiate through it
+        assert torch.isnan(grads["W_h.weight"]).any() and torch.isnan(grads["W_i.weight"]).any()
+        assert parity_err(grads["W_o.weight"].cpu().numpy(), golden["g.W_o.weight"]) <= TOL
+        return
+    assert _check_grads(golden, grads, 2e-5) >= 4
+
+
+@pytest.mark.parametrize("n_mols,kind,kw", [
+    (512, "qm9", dict()),
+    (256, "synth40", dict(bias=True, undirected=True)),
+    (64, "zinc", dict(d_h=128, depth=5, activation="elu")),
+    (64, "qm9", dict(d_h=96, depth=4, activation=torch.nn.Softplus())),   # rows route (custom module)
+    (64, "qm9", dict(d_h=64, activation="prelu")),                         # rows route (learnable slope)
+])
+def test_backward_full_size_vs_oracle_autograd(n_mols, kind, kw, gpu_device):
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = synth.random_batch(n_mols, kind, seed=11)
+    torch.manual_seed(3)
+    ref_mp = BondMessagePassing(**kw)
+    mp = BondMessagePassing(**kw)
+    mp.load_state_dict(ref_mp.state_dict())
+    act = kw.get("activation", "relu")
+    G = torch.randn(bmg.V.shape[0], ref_mp.output_dim, generator=torch.Generator().manual_seed(5))
+    w = ot.MPWeights(ref_mp.W_i.weight, ref_mp.W_h.weight, ref_mp.W_o.weight, ref_mp.W_o.bias,
+                     ref_mp.W_i.bias, ref_mp.W_h.bias)
+    act_fn = ref_mp.tau if isinstance(act, torch.nn.Module) or act == "prelu" else act
+    ref = ot.forward_bmg(bmg, w, depth=ref_mp.depth, activation=act_fn, undirected=ref_mp.undirected)
+    (ref * G).sum().backward()
+    mp = mp.to(gpu_device).train()
+    bmg.to(gpu_device)
+    out = mp(bmg)
+    (out * G.to(gpu_device)).sum().backward()
+    assert parity_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
+    for (k, p), (_, q) in zip(mp.named_parameters(), ref_mp.named_parameters()):
+        err = parity_err(p.grad.cpu().numpy(), q.grad.numpy())
+        assert err <= 2e-5, f"{k}: {err:.3e}"
+
+
+def test_frozen_encoder_and_no_grad(gpu_device):
+    """requires_grad_(False) on the block (cli/train.py:1826-1828) and torch.no_grad() both work."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = synth.random_batch(8, "qm9", seed=2)
+    bmg.to(gpu_device)
+    mp = BondMessagePassing(d_h=32).to(gpu_device)
+    mp.W_i.requires_grad_(False)
+    mp.W_h.requires_grad_(False)
+    out = mp(bmg)
+    out.sum().backward()
+    assert mp.W_i.weight.grad is None and mp.W_h.weight.grad is None and mp.W_o.weight.grad is not None
+    mp.requires_grad_(False)
+    assert not mp(bmg).requires_grad
+
+
+def test_overfit_small_regression(gpu_device):
+    """Analogue of tests/integration/test_regression_mol.py:56-89: the gradients are good enough to train."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    torch.manual_seed(0)
+    bmg = synth.random_batch(48, "qm9", seed=9)
+    bmg.to(gpu_device)
+    y = torch.randn(48, 1, device=gpu_device)
+    mp = BondMessagePassing(d_h=64).to(gpu_device)
+    head = torch.nn.Linear(64, 1).to(gpu_device)
+    opt = torch.optim.Adam(list(mp.parameters()) + list(head.parameters()), lr=3e-3)
+    n_mols = len(bmg)
+    losses = []
+    for _ in range(300):
+        opt.zero_grad()
+        Hv = mp(bmg)
+        pooled = torch.zeros(n_mols, 64, device=gpu_device).index_add_(0, bmg.batch, Hv)
+        pooled = pooled / torch.bincount(bmg.batch, minlength=n_mols).unsqueeze(1)
+        loss = torch.nn.functional.mse_loss(head(pooled), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] <= 0.05 and losses[-1] < 0.1 * losses[0], (losses[0], losses[-1])
