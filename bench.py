@@ -13,8 +13,9 @@ For N > 1 the driver launches one process per GPU (torch.distributed.run); molec
 across ranks (every rank owns its own batch: weak scaling) and the forward needs no collective.
 
 Rank 0 prints ONE JSON line, with two extra objects:
-  roofline      dominant kernel (fp32-MFMA `k_linear`, the W_h contraction) timed live with HIP
-                events on the launch stream: achieved = algorithmic FLOP / mean launch time
+  roofline      dominant kernel (the fused per-depth update: fp32-MFMA W_h contraction with the
+                segment-sum / reverse-subtract epilogue) timed live with HIP events on the launch
+                stream: achieved = algorithmic FLOP / mean launch time
   cpu_baseline  the oracle (same ATen op sequence as the reference) timed on the host cores,
                 bounded to ~15 s (kind "port")
 """
@@ -181,23 +182,61 @@ def main():
         out["graph_error"] = graph_err
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: the W_h contraction (K3), live HIP-event timing ----
+        # ---- roofline of the dominant kernel: the fused per-depth update (K3 + K2), live HIP-event timing ----
+        # k_gemm<EPI_SEG>: H' = relu(H0 + M W_h^T), then M_next[rev r] = S[dst r] - H'[r] from the LDS tile.
+        # fp32 has no reduced-precision matrix path on gfx950: the exact fp32 MFMA (157.3 TF) bounds it.
         h = args.hidden
+        plan = engine.GraphPlan.from_bmg(bmg)
         Mbuf = torch.randn(nE, h, device=dev)
         H0buf = torch.randn(nE, h, device=dev)
-        Cbuf = torch.empty(nE, h, device=dev)
+        Mnext = torch.empty(nE, h, device=dev)
         Wh = mp.W_h.weight.detach()
-        k3 = lambda: engine.linear(Mbuf, Wh, None, Cadd=H0buf, act="relu", out=Cbuf)
+        fusable = h % 4 == 0 and h <= 320
+        if fusable:
+            k3 = lambda: engine.update_fused(plan, Mbuf, H0buf, Wh, None, act="relu", want_M=True, M_next=Mnext)
+            kname = "k_gemm<3,5,4,false,EPI_SEG> (fused per-depth update: H'=relu(H0+M@W_h^T); M_next[rev]=S[dst]-H', fp32 MFMA 16x16x4)"
+        else:
+            Cbuf = torch.empty(nE, h, device=dev)
+            k3 = lambda: engine.linear(Mbuf, Wh, None, Cadd=H0buf, act="relu", out=Cbuf)
+            kname = "k_gemm<EPI_PLAIN> (K3 update: H = relu(H0 + M @ W_h^T), fp32 MFMA 16x16x4)"
         run_steps(k3, 10)
         t_k3 = time_events(k3, 50, torch)
         flops = 2.0 * nE * h * h
+        bytes_k3 = 3.0 * nE * h * 4 + 3.0 * nE * 4  # SURVEY §8d B_upd: read M, read H0, write M_next (+ indices)
         achieved = flops / (t_k3 * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_linear (K3 update: H = relu(H0 + M @ W_h^T), fp32 MFMA 16x16x4)",
-                           "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TF,
-                           "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TF, 4), "traffic": None,
-                           "launch_us": round(t_k3 * 1e3, 3), "flop_per_launch": flops}
-        # ---- the scatter/gather step (K2) against the HBM roofline, same batch and a >L3 batch ----
-        plan = engine.GraphPlan.from_bmg(bmg)
+        traffic = None
+        try:  # PMC-derived HBM bytes per launch, produced by scripts/pmc_traffic.py from rocprofv3 --pmc passes
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("directed_edges") == nE and pmc.get("hidden") == h:
+                traffic = pmc.get("update_kernel_bytes_per_launch")
+        except Exception:
+            pass
+        out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TF,
+                           "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TF, 4), "traffic": traffic,
+                           "launch_us": round(t_k3 * 1e3, 3), "flop_per_launch": flops,
+                           "algorithmic_bytes_per_launch": bytes_k3,
+                           "algorithmic_GBps": round(bytes_k3 / (t_k3 * 1e-3) / 1e9, 1)}
+        # per-kernel breakdown of one forward (HIP events around each C-ABI call)
+        try:
+            Hn = torch.empty(nE, h, device=dev)
+            Mv_ = torch.empty(nV, h, device=dev)
+            kplan = lambda: engine.GraphPlan.from_bmg(bmg)
+            run_steps(kplan, 5)
+            br = {"plan_us": round(time_events(kplan, 30, torch) * 1e3, 2)}
+            if fusable:
+                kagg = lambda: engine.update_fused(plan, Mbuf, H0buf, Wh, None, act="relu", want_M=False, want_Mv=True, Mv=Mv_)
+                run_steps(kagg, 5)
+                br["update_agg_us"] = round(time_events(kagg, 30, torch) * 1e3, 2)
+            kfin = lambda: engine.linear(bmg.V, mp.W_o.weight.detach(), mp.W_o.bias.detach(), A2=Mv_, act="relu")
+            run_steps(kfin, 5)
+            br["finalize_us"] = round(time_events(kfin, 30, torch) * 1e3, 2)
+            kini = lambda: engine.linear(bmg.V, mp.W_i.weight.detach(), None, A2=bmg.E, gather1=plan.src32, n_rows=nE, out=Hn)
+            run_steps(kini, 5)
+            br["init_unfused_us"] = round(time_events(kini, 30, torch) * 1e3, 2)
+            out["kernel_breakdown"] = br
+        except Exception as e:
+            out["kernel_breakdown"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        # ---- the stand-alone scatter/gather step (K2, general route) against the HBM roofline ----
         Hbuf = torch.randn(nE, h, device=dev)
         Mout = torch.empty(nE, h, device=dev)
         k2 = lambda: engine.message(plan, Hbuf, out=Mout)
@@ -205,7 +244,7 @@ def main():
         t_k2 = time_events(k2, 50, torch)
         bytes_k2 = 2.0 * nE * h * 4 + 3.0 * nE * 4
         gbs = bytes_k2 / (t_k2 * 1e-3) / 1e9
-        out["roofline_scatter"] = {"kernel": "k_segment<message> (K2)", "bound": "hbm", "achieved": round(gbs, 1),
+        out["roofline_scatter"] = {"kernel": "k_segment<message> (K2, general route)", "bound": "hbm", "achieved": round(gbs, 1),
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                    "traffic": None, "launch_us": round(t_k2 * 1e3, 3), "bytes_per_launch": bytes_k2,
                                    "note": "working set fits the 256 MiB Infinity Cache at this batch"}
@@ -226,6 +265,19 @@ def main():
                                              "frac": round(gb / PEAK_HBM_GBS, 4), "traffic": None,
                                              "launch_us": round(t_b * 1e3, 3), "bytes_per_launch": bb,
                                              "directed_edges": bE}
+            if fusable:  # the fused update at a batch whose working set exceeds the Infinity Cache
+                H0b = torch.randn(bE, h, device=dev)
+                Mn = torch.empty(bE, h, device=dev)
+                k3b = lambda: engine.update_fused(bplan, Hb, H0b, Wh, None, act="relu", want_M=True, M_next=Mn)
+                run_steps(k3b, 3)
+                t3b = time_events(k3b, 10, torch)
+                out["roofline_large"] = {"kernel": "fused per-depth update, 32768 mols", "bound": "mfma",
+                                         "achieved": round(2.0 * bE * h * h / (t3b * 1e-3) / 1e12, 3),
+                                         "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                                         "frac": round(2.0 * bE * h * h / (t3b * 1e-3) / 1e12 / PEAK_FP32_MFMA_TF, 4),
+                                         "launch_us": round(t3b * 1e3, 3), "directed_edges": bE,
+                                         "algorithmic_GBps": round((3.0 * bE * h * 4 + 12.0 * bE) / (t3b * 1e-3) / 1e9, 1)}
+                del H0b, Mn
             del big, bplan, Hb, Mb
         except Exception as e:
             out["roofline_scatter_large"] = {"error": f"{type(e).__name__}: {e}"[:200]}

@@ -19,24 +19,30 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
-SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_backward.hip"]
+SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
+           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_backward.hip"]
+HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp"]
+ABI_VERSION = 2
+PLAN_NOFFSETS = 12
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
 EXPORTS = [
     "dmpnn_version", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
     "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
-    "dmpnn_linear_fwd", "dmpnn_forward", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
+    "dmpnn_linear_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
 F_UNDIRECTED = 1
+F_FUSED = 2
+PLAN_NOFUSE_MASK = 7  # asymmetric | index out of range | in-degree > 24
 
 
 class GemmArgs(C.Structure):
     _fields_ = [
         ("M", C.c_int64), ("N", C.c_int64), ("K1", C.c_int64), ("K2", C.c_int64),
-        ("A1", C.c_void_p), ("lda1", C.c_int64), ("gather1", C.c_void_p),
+        ("A1", C.c_void_p), ("lda1", C.c_int64), ("gather1", C.c_void_p), ("gather1_rows", C.c_int64),
         ("A2", C.c_void_p), ("lda2", C.c_int64),
         ("W", C.c_void_p), ("ldw", C.c_int64),
         ("bias", C.c_void_p),
@@ -84,7 +90,7 @@ def _stale() -> bool:
     if not os.path.isfile(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(CSRC, "dmpnn_common.hpp"), os.path.join(INCLUDE, "dmpnn.h")]
+    deps = sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "dmpnn.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
@@ -145,12 +151,16 @@ def load() -> C.CDLL:
     lib.dmpnn_plan_bytes.restype = C.c_size_t
     lib.dmpnn_plan_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_plan_layout.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    lib.dmpnn_forward_can_fuse.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dmpnn_message_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint, C.c_void_p]
     lib.dmpnn_aggregate_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     lib.dmpnn_linear_fwd.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+    lib.dmpnn_update_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     lib.dmpnn_forward.argtypes = [C.POINTER(FwdArgs), C.c_void_p]
     lib.dmpnn_backward_ws_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_backward.argtypes = [C.POINTER(BwdArgs), C.c_void_p]
@@ -166,8 +176,8 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         if name != "dmpnn_last_error_string" and name not in size_t_fns:
             getattr(lib, name).restype = C.c_int
-    if lib.dmpnn_version() != 1:
-        raise RuntimeError(f"libdmpnn ABI version {lib.dmpnn_version()} != 1 (stale build?)")
+    if lib.dmpnn_version() != ABI_VERSION:
+        raise RuntimeError(f"libdmpnn ABI version {lib.dmpnn_version()} != {ABI_VERSION} (stale build?)")
     _lib = lib
     return lib
 

@@ -1,6 +1,7 @@
 // extern "C" surface of libdmpnn (see include/dmpnn.h) and the forward driver that chains the
 // row kernels exactly as chemprop/nn/message_passing/base.py:196-212 chains its ATen ops.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "dmpnn_common.hpp"
@@ -16,7 +17,22 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-void count_launch() { ++g_launches; }
+// DMPNN_TRACE=1: print every kernel launch and synchronise after it, so a device fault is
+// attributed to the launch that caused it (debugging aid; never set in production).
+void count_launch(const char* name) {
+    ++g_launches;
+    static const bool trace = [] {
+        const char* e = getenv("DMPNN_TRACE");
+        return e && e[0] == '1';
+    }();
+    if (trace) {
+        fprintf(stderr, "[dmpnn] launch %d: %s ... ", g_launches, name);
+        fflush(stderr);
+        const hipError_t e = hipDeviceSynchronize();
+        fprintf(stderr, "%s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+        fflush(stderr);
+    }
+}
 
 static int check_graph_sizes(int64_t nV, int64_t nE) {
     DMPNN_CHECK_ARG(nV >= 0 && nE >= 0, "negative graph size (n_atoms=%lld n_edges=%lld)", (long long)nV, (long long)nE);
@@ -40,11 +56,13 @@ size_t dmpnn_plan_bytes(int64_t n_atoms, int64_t n_edges) {
     return (size_t)plan_layout(n_atoms, n_edges).words * sizeof(int);
 }
 
-int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t off[5]) {
+int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t off[DMPNN_PLAN_NOFFSETS]) {
     DMPNN_CHECK_ARG(off != nullptr, "plan_layout: null output");
     DMPNN_TRY(check_graph_sizes(n_atoms, n_edges));
     const PlanLayout L = plan_layout(n_atoms, n_edges);
     off[0] = L.src; off[1] = L.dst; off[2] = L.rev; off[3] = L.row_ptr; off[4] = L.perm;
+    off[5] = L.inv; off[6] = L.srcp; off[7] = L.dstp; off[8] = L.revp;
+    off[9] = L.tile_row; off[10] = L.tile_atom; off[11] = L.max_tiles;
     return DMPNN_OK;
 }
 
@@ -90,6 +108,58 @@ int dmpnn_linear_fwd(const dmpnn_gemm_args* a, void* stream) {
     return launch_linear(*a, static_cast<hipStream_t>(stream));
 }
 
+int dmpnn_update_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h, const float* M, int64_t ld_m,
+                     const float* H0, int64_t ld_h0, const float* W_h, const float* b_h, float* H_out, int64_t ld_hout,
+                     float* M_next, int64_t ld_mnext, float* Mv, int64_t ld_mv, int act, float act_slope,
+                     const float* act_slope_ptr, void* stream) {
+    DMPNN_TRY(check_graph_sizes(n_atoms, n_edges));
+    DMPNN_CHECK_ARG(plan && d_h > 0, "update_fwd: bad arguments");
+    DMPNN_CHECK_ARG(n_edges == 0 || (M && H0 && W_h), "update_fwd: null tensor");
+    DMPNN_CHECK_ARG(M_next || Mv || H_out, "update_fwd: no output");
+    DMPNN_CHECK_ARG(act != DMPNN_ACT_PRELU || act_slope_ptr, "update_fwd: PReLU needs act_slope_ptr");
+    if (n_edges == 0) {
+        if (Mv && n_atoms > 0) {
+            for (int64_t v = 0; v < n_atoms; ++v)
+                if (hipMemsetAsync(Mv + v * ld_mv, 0, (size_t)d_h * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess) {
+                    set_error("update_fwd: memset failed");
+                    return DMPNN_EHIP;
+                }
+        }
+        return DMPNN_OK;
+    }
+    const int* plan_i = static_cast<const int*>(plan);
+    const PlanLayout L = plan_layout(n_atoms, n_edges);
+    dmpnn_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.M = n_edges; g.N = d_h; g.K1 = d_h;
+    g.A1 = M; g.lda1 = ld_m;
+    g.W = W_h; g.ldw = d_h; g.bias = b_h;
+    g.Cadd = H0; g.ldcadd = ld_h0;
+    g.C = H_out; g.ldc = ld_hout;
+    g.act = act; g.act_slope = act_slope; g.act_slope_ptr = act_slope_ptr;
+    GemmExtra x;
+    memset(&x, 0, sizeof(x));
+    x.seg = true;
+    x.tile_row = plan_i + L.tile_row; x.tile_atom = plan_i + L.tile_atom; x.n_tiles = (int)L.max_tiles;
+    x.row_ptr = plan_i + L.row_ptr; x.revp = plan_i + L.revp;
+    x.Mout = M_next; x.ldm = ld_mnext; x.Sout = Mv; x.lds = ld_mv;
+    return launch_linear_ex(g, x, static_cast<hipStream_t>(stream));
+}
+
+static bool al_ptr(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
+
+int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a) {
+    if (!a) return 0;
+    const int64_t h = a->d_h, dv = a->d_v, de = a->d_e;
+    if (a->flags & DMPNN_F_UNDIRECTED) return 0;
+    if (h <= 0 || h % 4 != 0 || h > 320 || a->ldh % 4 != 0) return 0;
+    if (dv % 2 != 0 || de % 2 != 0 || a->ldv % 2 != 0 || a->lde % 2 != 0) return 0;
+    if (!al_ptr(a->V, 8) || !al_ptr(a->E, 8) || !al_ptr(a->W_i, 8) || !al_ptr(a->W_h, 16)) return 0;
+    if (!al_ptr(a->H0, 16) || !al_ptr(a->Ms, 16) || !al_ptr(a->Mv, 16) || (a->Hs && !al_ptr(a->Hs, 16))) return 0;
+    if (a->n_atoms * a->ldv * 4 > 0x7FFFFFFF || a->n_edges * a->lde * 4 > 0x7FFFFFFF) return 0;
+    return 1;
+}
+
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     g_launches = 0;
     DMPNN_CHECK_ARG(a != nullptr, "forward: null args");
@@ -108,19 +178,98 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     DMPNN_CHECK_ARG(!has_vd || (a->d_vd > 0 && a->V_d && a->b_d && a->Hv && a->ldvd >= a->d_vd),
                     "forward: W_d given but V_d / b_d / Hv / d_vd missing");
     DMPNN_CHECK_ARG(a->ldout >= h + (has_vd ? a->d_vd : 0), "forward: ldout too small");
-    if (a->depth > 1 && nE > 0)
-        DMPNN_CHECK_ARG(a->Hs && a->Ms && a->n_hslots >= 1 && a->n_mslots >= 1, "forward: missing Hs / Ms workspace");
+    const bool fused = a->flags & DMPNN_F_FUSED;
+    if (a->depth > 1 && nE > 0) {
+        DMPNN_CHECK_ARG(a->Ms && a->n_mslots >= 1, "forward: missing Ms workspace");
+        DMPNN_CHECK_ARG(fused || (a->Hs && a->n_hslots >= 1), "forward: missing Hs workspace");
+    }
 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const PlanView pv = plan_view(a->plan, nV, nE);
     const int64_t slot = nE * a->ldh;
+    const int* plan_i = static_cast<const int*>(a->plan);
 
+    if (fused) {
+        // ---- fused route: edge tensors in CSR-row order, segment sums in the contraction epilogues ----
+        DMPNN_CHECK_ARG(dmpnn_forward_can_fuse(a), "forward: DMPNN_F_FUSED given but the shapes / alignment do not allow it "
+                        "(d_h %% 4, d_h <= 320, even d_v / d_e, directed); call dmpnn_forward_can_fuse first");
+        DMPNN_CHECK_ARG(a->depth <= 2 || a->n_mslots >= 2, "forward(fused): depth > 2 needs at least two message slots");
+        const PlanLayout L = plan_layout(nV, nE);
+        GemmExtra x;
+        memset(&x, 0, sizeof(x));
+        x.seg = true;
+        x.tile_row = plan_i + L.tile_row; x.tile_atom = plan_i + L.tile_atom; x.n_tiles = nE > 0 ? (int)L.max_tiles : 0;
+        x.row_ptr = plan_i + L.row_ptr; x.revp = plan_i + L.revp;
+        const int T = a->depth;
+        if (nE == 0 && nV > 0) {
+            hipError_t e = hipMemsetAsync(a->Mv, 0, (size_t)nV * a->ldh * sizeof(float), s);
+            if (e != hipSuccess) { set_error("forward: memset failed: %s", hipGetErrorString(e)); return DMPNN_EHIP; }
+        }
+        if (nE > 0) {
+            // K1 + tau + first message (or the final aggregate when depth == 1)
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = nE; g.N = h; g.K1 = dv; g.K2 = de;
+            g.A1 = a->V; g.lda1 = a->ldv; g.gather1 = plan_i + L.srcp; g.gather1_rows = nV;
+            g.A2 = a->E; g.lda2 = a->lde;
+            g.W = a->W_i; g.ldw = dv + de; g.bias = a->b_i;
+            g.Zpre = a->H0; g.ldz = a->ldh;  // pre-activation: the residual of every later step
+            g.act = a->act; g.act_slope = a->act_slope; g.act_slope_ptr = a->act_slope_ptr;
+            GemmExtra xi = x;
+            xi.gather2 = plan_i + L.perm; xi.gather2_rows = nE;
+            if (T > 1) { xi.Mout = a->Ms; xi.ldm = a->ldh; }
+            else { xi.Sout = a->Mv; xi.lds = a->ldh; }
+            DMPNN_TRY(launch_linear_ex(g, xi, s));
+            for (int t = 1; t < T; ++t) {
+                // K3 + next message / final aggregate
+                memset(&g, 0, sizeof(g));
+                g.M = nE; g.N = h; g.K1 = h;
+                g.A1 = a->Ms + ((t - 1) % a->n_mslots) * slot; g.lda1 = a->ldh;
+                g.W = a->W_h; g.ldw = h; g.bias = a->b_h;
+                g.Cadd = a->H0; g.ldcadd = a->ldh;
+                g.C = a->Hs ? a->Hs + ((t - 1) % a->n_hslots) * slot : nullptr; g.ldc = a->ldh;
+                g.act = a->act; g.act_slope = a->act_slope; g.act_slope_ptr = a->act_slope_ptr;
+                GemmExtra xu = x;
+                if (t < T - 1) { xu.Mout = a->Ms + (t % a->n_mslots) * slot; xu.ldm = a->ldh; }
+                else { xu.Sout = a->Mv; xu.lds = a->ldh; }
+                DMPNN_TRY(launch_linear_ex(g, xu, s));
+            }
+        }
+        // K5 finalize (atom rows: plain epilogue); a graph the fused tiling cannot hold poisons the output
+        GemmExtra xf;
+        memset(&xf, 0, sizeof(xf));
+        xf.poison_flags = plan_i + DMPNN_HDR_FLAGS; xf.poison_mask = kPlanNoFuse;
+        {
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = nV; g.N = h; g.K1 = dv; g.K2 = h;
+            g.A1 = a->V; g.lda1 = a->ldv;
+            g.A2 = a->Mv; g.lda2 = a->ldh;
+            g.W = a->W_o; g.ldw = dv + h; g.bias = a->b_o;
+            g.C = has_vd ? a->Hv : a->out; g.ldc = has_vd ? a->ldh : a->ldout;
+            g.act = a->act; g.act_slope = a->act_slope; g.act_slope_ptr = a->act_slope_ptr;
+            DMPNN_TRY(launch_linear_ex(g, xf, s));
+        }
+        if (has_vd) {
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = nV; g.N = h + a->d_vd; g.K1 = h; g.K2 = a->d_vd;
+            g.A1 = a->Hv; g.lda1 = a->ldh;
+            g.A2 = a->V_d; g.lda2 = a->ldvd;
+            g.W = a->W_d; g.ldw = h + a->d_vd; g.bias = a->b_d;
+            g.C = a->out; g.ldc = a->ldout; g.act = DMPNN_ACT_NONE;
+            DMPNN_TRY(launch_linear(g, s));
+        }
+        return DMPNN_OK;
+    }
+
+    // ---- general route: any index arrays, undirected, edge tensors in the caller's edge order ----
     // K1  H0 = W_i([V[src] || E]) (+ b_i)                         mixins.py:8-9
     {
         dmpnn_gemm_args g;
         memset(&g, 0, sizeof(g));
         g.M = nE; g.N = h; g.K1 = dv; g.K2 = de;
-        g.A1 = a->V; g.lda1 = a->ldv; g.gather1 = pv.src;
+        g.A1 = a->V; g.lda1 = a->ldv; g.gather1 = pv.src; g.gather1_rows = nV;
         g.A2 = a->E; g.lda2 = a->lde;
         g.W = a->W_i; g.ldw = dv + de; g.bias = a->b_i;
         g.C = a->H0; g.ldc = a->ldh; g.act = DMPNN_ACT_NONE;

@@ -44,6 +44,7 @@ struct EdgeBwdArgs {
     int act;
     float slope;
     const float* slope_ptr;
+    int poison_mask;   // plan flags that make the message backward write NaN
 };
 
 template <int ACT>
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd(EdgeBwdArgs a) {
     const int64_t lda = (a.acc && !a.acc_init) ? a.ldacc : 0;
 
     if (MODE == EB_MESSAGE) {
-        const bool asym = a.pv.hdr[DMPNN_HDR_FLAGS] & PLAN_ASYMMETRIC;
+        const bool asym = a.pv.hdr[DMPNN_HDR_FLAGS] & a.poison_mask;
         if (asym) {  // gradients through a non-molecular index structure are not provided: poison loudly
             const float nanv = __int_as_float(0x7fc00000);
             for (int e = wave; e < a.nE; e += n_waves)
@@ -201,6 +202,7 @@ template <int MODE>
 int launch_edge_bwd(EdgeBwdArgs a, hipStream_t s, const char* name) {
     if (a.nE == 0 || a.h == 0) return DMPNN_OK;
     if (!a.Y) a.act = DMPNN_ACT_NONE;
+    if (!a.poison_mask) a.poison_mask = PLAN_ASYMMETRIC;
     const int64_t items = (MODE == EB_MESSAGE) ? a.nV : a.nE;
     int64_t blocks = (items + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -268,7 +270,7 @@ struct WgradArgs {
     int N, K1, K2, ones;
     const float* gZ; int64_t ldz;
     const float* A1; int64_t lda1; const int* gather1;
-    const float* A2; int64_t lda2;
+    const float* A2; int64_t lda2; const int* gather2;
     float* slab; int ldk; int64_t slab_stride;
     int rows_per_wg;
     int vecZ, vecA;
@@ -298,10 +300,10 @@ __device__ __forceinline__ float4 wg_load_z(const WgradArgs& a, int64_t m, bool 
 }
 
 template <bool FULL>
-__device__ __forceinline__ float4 wg_load_a(const WgradArgs& a, int64_t m, int64_t g1, bool mok, int k) {
+__device__ __forceinline__ float4 wg_load_a(const WgradArgs& a, int64_t g2, int64_t g1, bool mok, int k) {
     const int K = a.K1 + a.K2;
     if (FULL) {  // the block's 64 columns are all < K and K1, K2 are multiples of 4: one 16-byte load
-        const float* p = (k < a.K1) ? a.A1 + g1 * a.lda1 + k : a.A2 + m * a.lda2 + (k - a.K1);
+        const float* p = (k < a.K1) ? a.A1 + g1 * a.lda1 + k : a.A2 + g2 * a.lda2 + (k - a.K1);
         float4 v = *reinterpret_cast<const float4*>(mok ? p : a.A1);
         return mok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -310,7 +312,7 @@ __device__ __forceinline__ float4 wg_load_a(const WgradArgs& a, int64_t m, int64
     for (int t = 0; t < 4; ++t) {
         const int kt = k + t;
         const bool ok = mok && kt < K;
-        const float* p = (kt < a.K1) ? a.A1 + g1 * a.lda1 + kt : a.A2 + m * a.lda2 + (kt - a.K1);
+        const float* p = (kt < a.K1) ? a.A1 + g1 * a.lda1 + kt : a.A2 + g2 * a.lda2 + (kt - a.K1);
         const float raw = *(ok ? p : a.gZ);
         x[t] = ok ? raw : ((mok && a.ones && kt == K) ? 1.f : 0.f);
     }
@@ -328,8 +330,9 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, f32x4 (&acc)[4][4
             const bool mok = m < m_hi;
             const int64_t mc = mok ? m : m_lo;
             const int64_t g1 = a.gather1 ? (int64_t)a.gather1[mc] : mc;
+            const int64_t g2 = a.gather2 ? (int64_t)a.gather2[mc] : mc;
             z[u] = wg_load_z(a, mc, mok, n0 + 4 * li);
-            x[u] = wg_load_a<FULL>(a, mc, g1, mok, k0 + 4 * li);
+            x[u] = wg_load_a<FULL>(a, g2, g1, mok, k0 + 4 * li);
         }
 #pragma unroll
         for (int u = 0; u < WG_U; ++u) {
@@ -387,13 +390,16 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
 
 // gW[n][k] = sum_s slab[s][n][k] (k < K),  gb[n] = sum_s slab[s][n][K]
 __global__ void k_wgrad_reduce(const float* __restrict__ slab, int64_t slab_stride, int n_slabs, int ldk, int N, int K,
-                               int ones, float* __restrict__ gW, int64_t ldgw, float* __restrict__ gb) {
+                               int ones, float* __restrict__ gW, int64_t ldgw, float* __restrict__ gb,
+                               const int* __restrict__ poison_flags, int poison_mask) {
     const int Kt = K + ones;
+    const bool poison = poison_flags && (poison_flags[0] & poison_mask);
     const int64_t total = (int64_t)N * Kt;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / Kt), k = (int)(i % Kt);
         float s = 0.f;
         for (int t = 0; t < n_slabs; ++t) s += slab[(int64_t)t * slab_stride + (int64_t)n * ldk + k];
+        if (poison) s = __int_as_float(0x7fc00000);
         if (k < K) {
             if (gW) gW[(int64_t)n * ldgw + k] = s;
         } else if (gb) {
@@ -433,7 +439,7 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, float* slab, hipStream_t s) {
     a.vecA = (a.K1 == 0 || (aligned16(a.A1) && a.lda1 % 4 == 0)) && a.K1 % 4 == 0 &&
              (a.K2 == 0 || (aligned16(a.A2) && a.lda2 % 4 == 0 && a.K2 % 4 == 0));
     if (a.K1 == 0) { a.A1 = a.A2; a.lda1 = a.lda2; a.gather1 = nullptr; }
-    if (a.K2 == 0) { a.A2 = a.A1; a.lda2 = a.lda1; }
+    if (a.K2 == 0) { a.A2 = a.A1; a.lda2 = a.lda1; a.gather2 = nullptr; }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad),
@@ -451,13 +457,13 @@ int launch_wgrad(WgradArgs a, const WgradPlan& p, float* slab, hipStream_t s) {
 }
 
 int launch_wgrad_reduce(const float* slab, const WgradPlan& p, int n_slabs, int N, int K, int ones, float* gW,
-                        int64_t ldgw, float* gb, hipStream_t s) {
+                        int64_t ldgw, float* gb, hipStream_t s, const int* poison_flags = nullptr, int poison_mask = 0) {
     const int64_t total = (int64_t)N * (K + ones);
     if (total == 0 || (!gW && !gb)) return DMPNN_OK;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, slab, p.slab_stride, n_slabs, p.ldk, N,
-                       K, ones, gW, ldgw, gb);
+                       K, ones, gW, ldgw, gb, poison_flags, poison_mask);
     DMPNN_CHECK_LAUNCH("k_wgrad_reduce");
     return DMPNN_OK;
 }
@@ -590,7 +596,14 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
     float *gZa = ws + L.gZa, *gZb = ws + L.gZb, *gH0 = ws + L.gH0, *gZO = ws + L.gZO, *gMv = ws + L.gMv;
     float *gHO = ws + L.gHO, *WhT = ws + L.WhT, *WoT = ws + L.WoT, *WdT = ws + L.WdT;
     float *slab_h = ws + L.slab_h, *slab_x = ws + L.slab_x;
-    const PlanView pv = plan_view(f.plan, nV, nE);
+    // fused forward: the kept edge tensors (H0, H^(t), M^(t)) are in CSR-row order -> the graph in row coordinates
+    const bool fused = f.flags & DMPNN_F_FUSED;
+    const PlanView pv = fused ? plan_view_rows(f.plan, nV, nE) : plan_view(f.plan, nV, nE);
+    const int* pflags = fused ? static_cast<const int*>(f.plan) + DMPNN_HDR_FLAGS : nullptr;
+    const int pmask = fused ? kPlanNoFuse : 0;
+    const int* e_gather = fused ? static_cast<const int*>(f.plan) + plan_layout(nV, nE).perm : nullptr;
+    DMPNN_CHECK_ARG(!fused || !(f.flags & DMPNN_F_UNDIRECTED), "backward: fused + undirected is not a valid forward");
+    DMPNN_CHECK_ARG(!fused || T == 1 || nE == 0 || f.Hs, "backward: the fused forward did not keep H^(t) (Hs was NULL)");
     const int64_t ldh = f.ldh, slot = nE * ldh;
 
     auto zero2d = [&](float* p, int64_t rows, int64_t cols) {
@@ -616,7 +629,7 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             a.gZ = b->gout; a.ldz = b->ldgout;
             a.A1 = f.Hv; a.lda1 = ldh; a.A2 = f.V_d; a.lda2 = f.ldvd;
             DMPNN_TRY(launch_wgrad(a, L.p_d, slab_x, s));
-            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_d, L.p_d.splits, (int)(h + dvd), (int)(h + dvd), 1, b->gW_d, h + dvd, b->gb_d, s));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_d, L.p_d.splits, (int)(h + dvd), (int)(h + dvd), 1, b->gW_d, h + dvd, b->gb_d, s, pflags, pmask));
         }
         // gHO = gout . W_d[:, :h]      via WdT[k][n] = W_d[n][k]
         DMPNN_TRY(launch_transpose(f.W_d, h + dvd, WdT, h + dvd, (int)(h + dvd), (int)h, s));
@@ -641,7 +654,7 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         a.M = nV; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)h; a.ones = 1;
         a.gZ = gZO; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.A2 = f.Mv; a.lda2 = ldh;
         DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s));
-        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, L.p_o.splits, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s));
+        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, L.p_o.splits, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s, pflags, pmask));
     }
     const bool need_edges = b->gW_i || b->gb_i || b->gW_h || b->gb_h;
     if (!need_edges) return DMPNN_OK;
@@ -662,6 +675,7 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
     memset(&e, 0, sizeof(e));
     e.pv = pv; e.nV = (int)nV; e.nE = (int)nE; e.h = (int)h;
     e.act = f.act; e.slope = f.act_slope; e.slope_ptr = f.act_slope_ptr;
+    e.poison_mask = fused ? kPlanNoFuse : PLAN_ASYMMETRIC;
     const bool undirected = f.flags & DMPNN_F_UNDIRECTED;
     int n_slabs_h = 0;
     if (T >= 2) {
@@ -713,7 +727,7 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             }
         }
         if (b->gW_h || b->gb_h)
-            DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_h, n_slabs_h, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s));
+            DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_h, n_slabs_h, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s, pflags, pmask));
     } else {
         // depth 1: gH0 = gMv[dst] * tau'(tau(H0))
         EdgeBwdArgs g0 = e;
@@ -728,8 +742,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         memset(&a, 0, sizeof(a));
         a.M = nE; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)de; a.ones = f.b_i ? 1 : 0;
         a.gZ = gH0; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.gather1 = pv.src; a.A2 = f.E; a.lda2 = f.lde;
+        a.gather2 = e_gather;
         DMPNN_TRY(launch_wgrad(a, L.p_i, slab_x, s));
-        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, L.p_i.splits, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s));
+        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, L.p_i.splits, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s, pflags, pmask));
     }
     return DMPNN_OK;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "dmpnn.h"
 
@@ -11,7 +12,7 @@ namespace dmpnn {
 
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
-void count_launch();
+void count_launch(const char* name);
 
 #define DMPNN_CHECK_ARG(cond, ...)                 \
     do {                                           \
@@ -28,7 +29,7 @@ void count_launch();
             ::dmpnn::set_error("launch of %s failed: %s", name, hipGetErrorString(e__)); \
             return DMPNN_EHIP;                                                           \
         }                                                                                \
-        ::dmpnn::count_launch();                                                         \
+        ::dmpnn::count_launch(name);                                                     \
     } while (0)
 
 #define DMPNN_TRY(expr)               \
@@ -38,12 +39,23 @@ void count_launch();
     } while (0)
 
 // ---- plan layout ----------------------------------------------------------------------------
-// One int32 blob:  hdr[16] | src[E] | dst[E] | rev[E] | row_ptr[V+1] | perm[E] | cursor[V]
-// every array starts on a 16-byte boundary.
+// One int32 blob, every array on a 16-byte boundary:
+//   hdr[16] | src[E] dst[E] rev[E] row_ptr[V+1] perm[E] cursor[V]          original edge ids
+//           | inv[E] srcp[E] dstp[E] revp[E] ident[E]                      CSR-row coordinates
+//           | tile_row[T+2] tile_atom[T+2]                                 row tiles of whole atoms
+// CSR-row coordinates: row i is the edge perm[i]; rows of one destination atom are contiguous and in
+// increasing edge id.  srcp/dstp/revp are src/dst/rev expressed in rows (revp[i] = inv[rev[perm[i]]]),
+// ident[i] = i.  The fused forward keeps every edge tensor in row order, so a row tile of the
+// contraction holds WHOLE destination atoms and the segment sums are formed in its epilogue.
+constexpr int kFusedBM = 48;        // rows of a fused tile (RT = 3)
+constexpr int kFusedMaxDeg = 24;    // largest in-degree the tiling supports ((BM + 1) / 2)
+constexpr int kFusedMinB0 = kFusedBM - kFusedMaxDeg + 1;  // 25: smallest nominal tile stride
 struct PlanLayout {
-    int64_t src, dst, rev, row_ptr, perm, cursor, words;
+    int64_t src, dst, rev, row_ptr, perm, cursor, inv, srcp, dstp, revp, ident, tile_row, tile_atom, words;
+    int64_t max_tiles;
 };
 inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
+inline int64_t fused_max_tiles(int64_t nE) { return (nE + kFusedMinB0 - 1) / kFusedMinB0 + 1; }
 inline PlanLayout plan_layout(int64_t nV, int64_t nE) {
     PlanLayout L;
     int64_t o = DMPNN_HDR_WORDS;
@@ -53,11 +65,21 @@ inline PlanLayout plan_layout(int64_t nV, int64_t nE) {
     L.row_ptr = o; o += align4(nV + 1);
     L.perm = o; o += align4(nE);
     L.cursor = o; o += align4(nV);
+    L.inv = o; o += align4(nE);
+    L.srcp = o; o += align4(nE);
+    L.dstp = o; o += align4(nE);
+    L.revp = o; o += align4(nE);
+    L.ident = o; o += align4(nE);
+    L.max_tiles = fused_max_tiles(nE);
+    L.tile_row = o; o += align4(L.max_tiles + 2);
+    L.tile_atom = o; o += align4(L.max_tiles + 2);
     L.words = o;
     return L;
 }
 
-enum : int { PLAN_ASYMMETRIC = 1, PLAN_RANGE_ERROR = 2 };
+enum : int { PLAN_ASYMMETRIC = 1, PLAN_RANGE_ERROR = 2, PLAN_HUGE_DEGREE = 4 };
+// graphs the fused (row-tiled) forward cannot represent: its kernels poison their output with NaN
+constexpr int kPlanNoFuse = PLAN_ASYMMETRIC | PLAN_RANGE_ERROR | PLAN_HUGE_DEGREE;
 
 // Device view of a plan (pointers into the blob).
 struct PlanView {
@@ -72,6 +94,12 @@ inline PlanView plan_view(const void* plan, int64_t nV, int64_t nE) {
     const int* p = static_cast<const int*>(plan);
     PlanLayout L = plan_layout(nV, nE);
     return PlanView{p, p + L.src, p + L.dst, p + L.rev, p + L.row_ptr, p + L.perm};
+}
+// The same graph in CSR-row coordinates (perm = identity): what the fused path's kept tensors use.
+inline PlanView plan_view_rows(const void* plan, int64_t nV, int64_t nE) {
+    const int* p = static_cast<const int*>(plan);
+    PlanLayout L = plan_layout(nV, nE);
+    return PlanView{p, p + L.srcp, p + L.dstp, p + L.revp, p + L.row_ptr, p + L.ident};
 }
 
 // ---- activations ----------------------------------------------------------------------------
@@ -111,6 +139,19 @@ int launch_aggregate(const PlanView& pv, int64_t nV, int64_t nE, int64_t h, cons
                      int64_t ld_in, float* Mv, int64_t ld_mv, int act, float slope,
                      const float* slope_ptr, hipStream_t s);
 int launch_linear(const dmpnn_gemm_args& a, hipStream_t s);
+
+// Internal extensions of a contraction launch (not part of the C ABI): second gather, row tiles
+// from the plan, the fused segment epilogue, NaN poisoning driven by the plan flags.
+struct GemmExtra {
+    const int* gather2; int64_t gather2_rows;   // row gather of A2 (E[perm] in the fused initialize)
+    const int* tile_row; int n_tiles;           // row tiles (plan tile table); null = uniform 16*RT-row tiles
+    bool seg;                                   // EPI_SEG: rows are CSR-ordered edges, tiles hold whole atoms
+    const int* tile_atom; const int* row_ptr; const int* revp;
+    float* Mout; int64_t ldm;                   // Mout[revp[r]] = S[dst(r)] - Y[r]
+    float* Sout; int64_t lds;                   // Sout[v] = sum of Y over the rows of v
+    const int* poison_flags; int poison_mask;   // plan header word 0 and the mask that makes the output NaN
+};
+int launch_linear_ex(const dmpnn_gemm_args& a, const GemmExtra& x, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

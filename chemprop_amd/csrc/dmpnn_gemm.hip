@@ -1,6 +1,7 @@
-// K1 / K3 / K5 — the dense contractions of the path on fp32 MFMA.
+// K1 / K3 / K5 — dispatcher of the dense contractions of the path onto the fp32-MFMA kernel
+// template of dmpnn_gemm_impl.hpp.
 //
-//   C[r, :] = act( [A1[g(r), 0:K1] || A2[r, 0:K2]] . W^T + bias + Cadd[r, :] )
+//   C[r, :] = act( [A1[g1(r), 0:K1] || A2[g2(r), 0:K2]] . W^T + bias + Cadd[r, :] )
 //
 //   K1 initialize  mixins.py:8-9    A1 = V gathered by src(e), A2 = E          W = W_i  (no act: H0)
 //   K3 update      base.py:135-141  A1 = M                    Cadd = H0        W = W_h  act = tau
@@ -10,418 +11,199 @@
 // The reference materialises torch.cat(...) ([E, d_v+d_e] / [V, d_v+d_h]) and the gathered
 // V[src] before every nn.Linear; here concatenation and gather happen in the A-operand loader.
 //
-// gfx950 mapping.  fp32 has no reduced-precision matrix path on CDNA4 (no xf32): the exact-fp32
-// v_mfma_f32_16x16x4_f32 (32 cycles / SIMD, 256 FLOP/clk/CU = the fp32 vector peak, 157 TF chip)
-// is the roof.  A 256-thread workgroup (4 waves, one per SIMD) owns a BM x BN output panel,
-// BM = 16*RT rows, BN = 64*WN columns; wave w owns the 16*WN-column slice w.  With d_h = 300,
-// WN = 5 gives BN = 320 >= N, so a panel holds COMPLETE output rows: the A tile is read once and
-// the residual / activation epilogue sees whole rows.  K is walked in 32-wide chunks through a
-// 2-slot LDS ring plus one chunk in staging registers: global loads run two chunks ahead, the LDS
-// writes of chunk c+1 are issued right before the MFMAs of chunk c (one barrier per chunk).
-//
-// k-permutation.  MFMA 16x16x4 takes A[i][k] from lane (i = l&15, k = l>>4).  Since a dot product
-// does not care in which order k is visited, lane group g = l>>4 reads 8 CONSECUTIVE k
-// (two ds_read_b128) and feeds them to 8 successive MFMAs: MFMA q of a chunk contracts
-// k = {8g + q : g = 0..3}.  A and B use the same assignment, so the result is the exact fp32 dot
-// product (an fmaf chain in a fixed, deterministic k order), started from residual + bias.
-//
-// Load discipline (cdna_hip_programming.md §5 trap (c)): every global load is UNCONDITIONAL — an
-// out-of-range slot reads a clamped, valid address and is zeroed by a select when it is written to
-// LDS, after the MFMA block.  A load under a runtime branch makes hipcc wait vmcnt(0) per load.
+// Instantiation choice
+//   G   operand load granularity (floats per buffer load): 4 when every operand row is 16-byte
+//       aligned and K1, K2 are multiples of 4 (W_h, W_o: 300/372 columns), 2 for 8-byte alignment
+//       (W_i: 86 = 72 + 14 columns; CGR 134 = 106 + 28), 1 otherwise (odd test shapes).
+//   WN  column tiles per wave: 5 (BN = 320 >= d_h = 300: whole rows per workgroup), 4, 2 or 1 —
+//       the one that pads N least.
+//   RT  row tiles: 3 (48 rows) unless the matrix is so short that 16-row panels fill more CUs.
 #include <stdlib.h>
 
-#include "dmpnn_common.hpp"
+#include "dmpnn_gemm_impl.hpp"
 
 namespace dmpnn {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BK = 32;        // k chunk
-constexpr int BKP = BK + 4;   // padded LDS row (floats): 144 B rows keep ds_read_b128 16-B aligned
-constexpr int kThreads = 256;
-
-struct GemmDev {
-    dmpnn_gemm_args a;
-};
-
-// ---- global -> register staging of one k-chunk ------------------------------------------------
-// Tile element (r, k) lives in float4 slot f = r*8 + k/4; thread t owns slots f = t + 256*j.
-template <int RT>
-struct AStage {
-    static constexpr int BM = 16 * RT;
-    static constexpr int SLOTS = (BM * (BK / 4) + kThreads - 1) / kThreads;
-    float4 v[SLOTS];
-    unsigned ok[SLOTS];      // 4 validity bits per slot (bit t: element k+t is inside the matrix)
-    int64_t off1[SLOTS];     // A1 row offset (elements) of the slot's (gathered) row; chunk-invariant
-    int64_t off2[SLOTS];     // A2 row offset
-    unsigned rowok;          // bit j: the slot's row is inside the matrix
-};
-template <int WN>
-struct BStage {
-    static constexpr int BN = 64 * WN;
-    static constexpr int SLOTS = BN * (BK / 4) / kThreads;  // 2*WN
-    float4 v[SLOTS];
-    unsigned ok[SLOTS];
-    int64_t off[SLOTS];      // W row offset of the slot's output column
-    unsigned colok;
-};
-
-template <int RT>
-__device__ __forceinline__ void init_a(const dmpnn_gemm_args& a, AStage<RT>& st, int64_t row0, int tid) {
-    st.rowok = 0;
-#pragma unroll
-    for (int j = 0; j < AStage<RT>::SLOTS; ++j) {
-        const int r = (tid + kThreads * j) >> 3;
-        const int64_t row = row0 + r;
-        const bool ok = (r < 16 * RT) && (row < a.M);
-        const int64_t rc = ok ? row : 0;
-        const int64_t g = a.gather1 ? (int64_t)a.gather1[rc] : rc;
-        st.off1[j] = g * a.lda1;
-        st.off2[j] = rc * a.lda2;
-        st.rowok |= (ok ? 1u : 0u) << j;
-    }
-}
-template <int WN>
-__device__ __forceinline__ void init_b(const dmpnn_gemm_args& a, BStage<WN>& st, int64_t col0, int tid) {
-    st.colok = 0;
-#pragma unroll
-    for (int j = 0; j < BStage<WN>::SLOTS; ++j) {
-        const int64_t col = col0 + ((tid + kThreads * j) >> 3);
-        const bool ok = col < a.N;
-        st.off[j] = (ok ? col : 0) * a.ldw;
-        st.colok |= (ok ? 1u : 0u) << j;
-    }
-}
-
-template <int RT, bool VEC>
-__device__ __forceinline__ void load_a(const dmpnn_gemm_args& a, AStage<RT>& st, int k0, int tid) {
-    const int K1 = (int)a.K1, K = (int)(a.K1 + a.K2);
-#pragma unroll
-    for (int j = 0; j < AStage<RT>::SLOTS; ++j) {
-        const int kk = k0 + ((tid + kThreads * j) & 7) * 4;
-        const bool rok = (st.rowok >> j) & 1u;
-        if (VEC) {  // K1, K2 multiples of 4: a quad is entirely in A1, entirely in A2, or past K
-            const bool ok = rok && kk < K;
-            const float* p = (kk < K1) ? a.A1 + st.off1[j] + kk : a.A2 + st.off2[j] + (kk - K1);
-            st.v[j] = *reinterpret_cast<const float4*>(ok ? p : a.A1);
-            st.ok[j] = ok ? 0xFu : 0u;
-        } else {
-            float x[4];
-            unsigned m = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kt = kk + t;
-                const bool ok = rok && kt < K;
-                const float* p = (kt < K1) ? a.A1 + st.off1[j] + kt : a.A2 + st.off2[j] + (kt - K1);
-                x[t] = *(ok ? p : a.W);
-                m |= (ok ? 1u : 0u) << t;
-            }
-            st.v[j] = make_float4(x[0], x[1], x[2], x[3]);
-            st.ok[j] = m;
-        }
-    }
-}
-
-template <int WN, bool VEC>
-__device__ __forceinline__ void load_b(const dmpnn_gemm_args& a, BStage<WN>& st, int k0, int tid) {
-    const int K = (int)(a.K1 + a.K2);
-#pragma unroll
-    for (int j = 0; j < BStage<WN>::SLOTS; ++j) {
-        const int kk = k0 + ((tid + kThreads * j) & 7) * 4;
-        const bool cok = (st.colok >> j) & 1u;
-        if (VEC) {
-            const bool ok = cok && kk < K;
-            st.v[j] = *reinterpret_cast<const float4*>(a.W + (ok ? st.off[j] + kk : 0));
-            st.ok[j] = ok ? 0xFu : 0u;
-        } else {
-            float x[4];
-            unsigned m = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bool ok = cok && (kk + t) < K;
-                x[t] = a.W[ok ? st.off[j] + kk + t : 0];
-                m |= (ok ? 1u : 0u) << t;
-            }
-            st.v[j] = make_float4(x[0], x[1], x[2], x[3]);
-            st.ok[j] = m;
-        }
-    }
-}
-
-__device__ __forceinline__ float4 masked(float4 v, unsigned m) {
-    return make_float4((m & 1u) ? v.x : 0.f, (m & 2u) ? v.y : 0.f, (m & 4u) ? v.z : 0.f, (m & 8u) ? v.w : 0.f);
-}
-
-template <int RT>
-__device__ __forceinline__ void store_a(const AStage<RT>& st, float* As, int tid) {
-    constexpr int BM = 16 * RT;
-#pragma unroll
-    for (int j = 0; j < AStage<RT>::SLOTS; ++j) {
-        const int f = tid + kThreads * j;
-        const int r = f >> 3, kq = f & 7;
-        if (r < BM) *reinterpret_cast<float4*>(As + r * BKP + kq * 4) = masked(st.v[j], st.ok[j]);
-    }
-}
-template <int WN>
-__device__ __forceinline__ void store_b(const BStage<WN>& st, float* Bs, int tid) {
-#pragma unroll
-    for (int j = 0; j < BStage<WN>::SLOTS; ++j) {
-        const int f = tid + kThreads * j;
-        const int n = f >> 3, kq = f & 7;
-        *reinterpret_cast<float4*>(Bs + n * BKP + kq * 4) = masked(st.v[j], st.ok[j]);
-    }
-}
-
-// activation with a compile-time code: the epilogue is straight-line code per activation
-template <int ACT>
-__device__ __forceinline__ float act_ct(float z, float slope) {
-    if (ACT == DMPNN_ACT_RELU) return z < 0.f ? 0.f : z;
-    if (ACT == DMPNN_ACT_LEAKYRELU || ACT == DMPNN_ACT_PRELU) return z > 0.f ? z : slope * z;
-    if (ACT == DMPNN_ACT_TANH) return tanhf(z);
-    if (ACT == DMPNN_ACT_ELU) return z > 0.f ? z : expm1f(z);
-    return z;
-}
-
-template <int RT, int WN, int ACT>
-__device__ __forceinline__ void epilogue(const dmpnn_gemm_args& a, const f32x4 (&acc)[RT][WN], int64_t row0,
-                                         int64_t colw, int li, int lg, float slope) {
-    // C/D layout of 16x16x4: col = l&15, row = (l>>4)*4 + reg
-#pragma unroll
-    for (int ct = 0; ct < WN; ++ct) {
-        const int64_t col = colw + ct * 16 + li;
-        if (col >= a.N) continue;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + rt * 16 + lg * 4 + r;
-                if (row >= a.M) continue;
-                const float z = acc[rt][ct][r];
-                if (a.Zpre) a.Zpre[row * a.ldz + col] = z;
-                a.C[row * a.ldc + col] = act_ct<ACT>(z, slope);
-            }
-        }
-    }
-}
-
-template <int RT, int WN, bool VEC>
-__global__ __launch_bounds__(kThreads) void k_linear(GemmDev g) {
-    constexpr int BM = 16 * RT, BN = 64 * WN;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                      // [2][BM][BKP]
-    float* Bs = smem + 2 * BM * BKP;       // [2][BN][BKP]
-    const dmpnn_gemm_args& a = g.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int64_t col0 = (int64_t)blockIdx.y * BN;
-    const int64_t colw = col0 + wave * (16 * WN);
-    const int K = (int)(a.K1 + a.K2);
-    const int n_chunks = (K + BK - 1) / BK;
-
-    AStage<RT> sa;
-    BStage<WN> sb;
-    init_a<RT>(a, sa, row0, tid);
-    init_b<WN>(a, sb, col0, tid);
-    load_a<RT, VEC>(a, sa, 0, tid);
-    load_b<WN, VEC>(a, sb, 0, tid);
-
-    // Accumulators start from residual + bias (the C-in of the first MFMA): the H0 tile is fetched
-    // here, under the first chunk's staging loads, instead of in a load-bound epilogue.
-    f32x4 acc[RT][WN];
-    {
-        const float* bias_p = a.bias ? a.bias : a.W;  // dummy bases keep the loads unconditional
-        const float* cadd_p = a.Cadd ? a.Cadd : a.W;
-        const int64_t ldcadd = a.Cadd ? a.ldcadd : 0;
-        const int64_t cmask = a.Cadd ? ~int64_t(0) : 0;
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const int64_t col = colw + ct * 16 + li;
-            const bool okc = col < a.N;
-            const float braw = bias_p[okc ? col : 0];
-            const float bv = a.bias ? braw : 0.f;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + rt * 16 + lg * 4 + r;
-                    const bool ok = okc && row < a.M;
-                    const float craw = cadd_p[ok ? (row * ldcadd + (col & cmask)) : 0];
-                    acc[rt][ct][r] = a.Cadd ? craw + bv : bv;
-                }
-            }
-        }
-    }
-    store_a<RT>(sa, As, tid);
-    store_b<WN>(sb, Bs, tid);
-    if (n_chunks > 1) {  // chunk 1 waits in registers while chunk 0 is contracted
-        load_a<RT, VEC>(a, sa, BK, tid);
-        load_b<WN, VEC>(a, sb, BK, tid);
-    }
-    __syncthreads();
-
-    // Software pipeline, one barrier per chunk.  At the top of iteration c: LDS[cur] holds chunk c,
-    // the staging registers hold chunk c+1 (loaded a whole iteration ago), LDS[cur^1] is free.
-    //   ds_read fragments(c)  ->  ds_write regs(c+1) -> LDS[cur^1]  ->  global loads (c+2) -> regs
-    //   ->  120 MFMAs (the LDS writes and the global loads complete underneath them)  ->  barrier
-    for (int c = 0; c < n_chunks; ++c) {
-        const int cur = c & 1;
-        const float* Ac = As + cur * BM * BKP;
-        const float* Bc = Bs + cur * BN * BKP + wave * (16 * WN) * BKP;
-        // fragments: lane (li, lg) holds k = 8*lg .. 8*lg+7 of row li of every 16-row tile
-        float af[RT][8], bf[WN][8];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const float* p = Ac + (rt * 16 + li) * BKP + lg * 8;
-            const float4 t0 = *reinterpret_cast<const float4*>(p);
-            const float4 t1 = *reinterpret_cast<const float4*>(p + 4);
-            af[rt][0] = t0.x; af[rt][1] = t0.y; af[rt][2] = t0.z; af[rt][3] = t0.w;
-            af[rt][4] = t1.x; af[rt][5] = t1.y; af[rt][6] = t1.z; af[rt][7] = t1.w;
-        }
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const float* p = Bc + (ct * 16 + li) * BKP + lg * 8;
-            const float4 t0 = *reinterpret_cast<const float4*>(p);
-            const float4 t1 = *reinterpret_cast<const float4*>(p + 4);
-            bf[ct][0] = t0.x; bf[ct][1] = t0.y; bf[ct][2] = t0.z; bf[ct][3] = t0.w;
-            bf[ct][4] = t1.x; bf[ct][5] = t1.y; bf[ct][6] = t1.z; bf[ct][7] = t1.w;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < n_chunks) {  // uniform branches around WHOLE blocks only
-            store_a<RT>(sa, As + (cur ^ 1) * BM * BKP, tid);
-            store_b<WN>(sb, Bs + (cur ^ 1) * BN * BKP, tid);
-        }
-        if (c + 2 < n_chunks) {
-            load_a<RT, VEC>(a, sa, (c + 2) * BK, tid);
-            load_b<WN, VEC>(a, sb, (c + 2) * BK, tid);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // q outermost: RT*WN independent accumulators between two MFMAs on the same one
-        // (dependent-accumulator latency of 16x16x4 f32 is 40 cycles vs 32-cycle issue).
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][q], bf[ct][q], acc[rt][ct], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-
-    const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
-    switch (a.act) {
-        case DMPNN_ACT_RELU: epilogue<RT, WN, DMPNN_ACT_RELU>(a, acc, row0, colw, li, lg, slope); break;
-        case DMPNN_ACT_LEAKYRELU:
-        case DMPNN_ACT_PRELU: epilogue<RT, WN, DMPNN_ACT_LEAKYRELU>(a, acc, row0, colw, li, lg, slope); break;
-        case DMPNN_ACT_TANH: epilogue<RT, WN, DMPNN_ACT_TANH>(a, acc, row0, colw, li, lg, slope); break;
-        case DMPNN_ACT_ELU: epilogue<RT, WN, DMPNN_ACT_ELU>(a, acc, row0, colw, li, lg, slope); break;
-        default: epilogue<RT, WN, DMPNN_ACT_NONE>(a, acc, row0, colw, li, lg, slope); break;
-    }
-}
+using gemm::GemmK;
 
 // Plain one-thread-per-output kernel.  NOT a product path: selected only by the environment
 // variable DMPNN_DEBUG_VALU_GEMM=1 to triage an MFMA-layout failure on real hardware.
-__global__ void k_linear_valu(GemmDev g) {
-    const dmpnn_gemm_args& a = g.a;
+__global__ void k_linear_valu(dmpnn_gemm_args a, const int* gather2) {
     const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (idx >= a.M * a.N) return;
     const int64_t row = idx / a.N, col = idx % a.N;
     const int K1 = (int)a.K1, K = (int)(a.K1 + a.K2);
     const int64_t arow1 = a.gather1 ? (int64_t)a.gather1[row] : row;
+    const int64_t arow2 = gather2 ? (int64_t)gather2[row] : row;
     float z = 0.f;
     for (int k = 0; k < K; ++k) {
-        const float x = k < K1 ? a.A1[arow1 * a.lda1 + k] : a.A2[row * a.lda2 + (k - K1)];
+        const float x = k < K1 ? a.A1[arow1 * a.lda1 + k] : a.A2[arow2 * a.lda2 + (k - K1)];
         z = fmaf(x, a.W[col * a.ldw + k], z);
     }
     if (a.bias) z += a.bias[col];
     if (a.Cadd) z = a.Cadd[row * a.ldcadd + col] + z;
     if (a.Zpre) a.Zpre[row * a.ldz + col] = z;
     const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
-    a.C[row * a.ldc + col] = apply_act(z, a.act, slope);
+    if (a.C) a.C[row * a.ldc + col] = apply_act(z, a.act, slope);
 }
 
-template <int RT, int WN, bool VEC>
-int launch_tile(const GemmDev& g, hipStream_t s) {
-    constexpr int BM = 16 * RT, BN = 64 * WN;
-    const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear<RT, WN, VEC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(k_linear<%d,%d>, %zu B LDS): %s", RT, WN, lds, hipGetErrorString(e));
-            return DMPNN_EHIP;
-        }
-        attr_set = true;
+inline bool al(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
+
+// largest G in {4, 2, 1} every operand of the contraction supports
+int pick_g(const dmpnn_gemm_args& a) {
+    for (int G : {4, 2}) {
+        const int B = 4 * G;
+        bool ok = (a.K1 % G == 0) && (a.K2 % G == 0) && (a.ldw % G == 0) && al(a.W, B);
+        if (a.K1 > 0) ok = ok && (a.lda1 % G == 0) && al(a.A1, B);
+        if (a.K2 > 0) ok = ok && (a.lda2 % G == 0) && al(a.A2, B);
+        if (a.Cadd) ok = ok && (a.ldcadd % G == 0) && al(a.Cadd, B) && (a.N % G == 0);
+        if (ok) return G;
     }
-    dim3 grid((unsigned)((g.a.M + BM - 1) / BM), (unsigned)((g.a.N + BN - 1) / BN));
-    hipLaunchKernelGGL((k_linear<RT, WN, VEC>), grid, dim3(kThreads), lds, s, g);
-    DMPNN_CHECK_LAUNCH("k_linear");
-    return DMPNN_OK;
+    return 1;
 }
 
-// Pick the row-tile height: minimise (#rounds over 256 CUs) x (rows per tile + fixed cost of
-// streaming W through the CU once per tile).
+int pick_wn(int64_t N) {
+    static const int cand[] = {5, 4, 2, 1};
+    int best = 5;
+    int64_t best_cost = INT64_MAX;
+    for (int wn : cand) {
+        const int64_t cost = ((N + 64 * wn - 1) / (64 * wn)) * wn;
+        if (cost < best_cost) { best_cost = cost; best = wn; }
+    }
+    return best;
+}
+
+// Row-tile height: minimise (#rounds over 256 CUs) x (rows per tile + fixed per-tile cost).
 int pick_rt(int64_t M, int64_t n_col_blocks) {
-    static const int cand[] = {1, 2, 3, 4, 6, 8};
-    int best = 1;
+    int best = 3;
     double best_cost = 1e300;
-    for (int rt : cand) {
+    for (int rt : {3, 1}) {
         const int64_t tiles = ((M + 16 * rt - 1) / (16 * rt)) * n_col_blocks;
         const int64_t rounds = (tiles + 255) / 256;
-        const double cost = (double)rounds * (rt + 0.6);
-        if (cost < best_cost - 1e-9) {
-            best_cost = cost;
-            best = rt;
-        }
+        const double cost = (double)rounds * (rt + 0.3);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = rt; }
     }
     return best;
 }
 
 }  // namespace
 
-int launch_linear(const dmpnn_gemm_args& a, hipStream_t s) {
+int launch_linear_ex(const dmpnn_gemm_args& a0, const GemmExtra& x, hipStream_t s) {
+    dmpnn_gemm_args a = a0;
     DMPNN_CHECK_ARG(a.M >= 0 && a.N >= 0 && a.K1 >= 0 && a.K2 >= 0, "linear: negative size");
     if (a.M == 0 || a.N == 0) return DMPNN_OK;
-    DMPNN_CHECK_ARG(a.W && a.C, "linear: null W or C");
+    DMPNN_CHECK_ARG(a.W, "linear: null W");
+    DMPNN_CHECK_ARG(a.C || a.Zpre || x.seg, "linear: no output");
     DMPNN_CHECK_ARG(a.K1 + a.K2 > 0, "linear: empty contraction");
     DMPNN_CHECK_ARG(a.K1 == 0 || a.A1, "linear: null A1 with K1 > 0");
     DMPNN_CHECK_ARG(a.K2 == 0 || a.A2, "linear: null A2 with K2 > 0");
-    GemmDev g;
-    g.a = a;
-    // keep the never-dereferenced side of the A1/A2 pointer select on a valid base
-    if (a.K1 == 0) { g.a.A1 = a.A2; g.a.lda1 = a.lda2; g.a.gather1 = nullptr; }
-    if (a.K2 == 0) { g.a.A2 = g.a.A1; g.a.lda2 = g.a.lda1; }
-    const bool vecA = (a.K1 == 0 || (aligned16(a.A1) && a.lda1 % 4 == 0)) && (a.K1 % 4 == 0) &&
-                      (a.K2 == 0 || (aligned16(a.A2) && a.lda2 % 4 == 0 && a.K2 % 4 == 0));
-    const bool vecB = aligned16(a.W) && (a.ldw % 4 == 0) && ((a.K1 + a.K2) % 4 == 0);
-    const bool vec = vecA && vecB;
+    DMPNN_CHECK_ARG(a.M < (int64_t(1) << 31) && a.N < (1 << 24) && a.K1 + a.K2 < (1 << 24), "linear: size out of range");
+    const int* gather2 = x.gather2;
+    int64_t rows1 = a.gather1 ? a.gather1_rows : a.M, rows2 = gather2 ? x.gather2_rows : a.M;
+    if (a.K1 == 0) {  // single operand lives in the A1 slot
+        a.A1 = a.A2; a.lda1 = a.lda2; a.K1 = a.K2; a.gather1 = gather2; rows1 = rows2;
+        a.A2 = nullptr; a.K2 = 0; a.lda2 = 0; gather2 = nullptr;
+    }
+    // 32-bit buffer addressing: a gathered source tensor must span < 2 GiB; contiguous operands are
+    // addressed relative to their row tile, so only one tile's extent matters
+    const int64_t lim = 0x7FFFFFFF;
+    if (a.gather1) {
+        const int64_t b1 = (rows1 > 0 ? rows1 : (lim / 4) / (a.lda1 > 0 ? a.lda1 : 1)) * a.lda1 * 4;
+        DMPNN_CHECK_ARG(rows1 <= 0 || b1 <= lim, "linear: gathered A1 spans %lld bytes (>= 2 GiB): split the batch", (long long)b1);
+    }
+    if (gather2 && a.K2 > 0) {
+        const int64_t b2 = rows2 * a.lda2 * 4;
+        DMPNN_CHECK_ARG(rows2 > 0 && b2 <= lim, "linear: gathered A2 spans %lld bytes (>= 2 GiB or unknown)", (long long)b2);
+    }
+    DMPNN_CHECK_ARG(a.N * a.ldw * 4 <= lim, "linear: weight matrix >= 2 GiB");
+    DMPNN_CHECK_ARG(a.lda1 * 4 * 64 <= lim && a.lda2 * 4 * 64 <= lim && a.ldcadd * 4 * 64 <= lim, "linear: leading dimension too large");
 
     static const bool debug_valu = [] {
         const char* e = getenv("DMPNN_DEBUG_VALU_GEMM");
         return e && e[0] == '1';
     }();
-    if (debug_valu) {
+    if (debug_valu && !x.seg) {
         const int64_t n = a.M * a.N;
-        hipLaunchKernelGGL(k_linear_valu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(k_linear_valu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, gather2);
         DMPNN_CHECK_LAUNCH("k_linear_valu");
         return DMPNN_OK;
     }
 
-    const int wn = (a.N <= 128) ? 2 : 5;
+    GemmK g;
+    memset(&g, 0, sizeof(g));
+    g.M = (int)a.M; g.N = (int)a.N; g.K1 = (int)a.K1; g.K2 = (int)a.K2;
+    g.A1 = a.A1; g.A2 = a.K2 > 0 ? a.A2 : a.A1; g.W = a.W; g.bias = a.bias; g.Cadd = a.Cadd;
+    g.C = a.C; g.Zpre = a.Zpre;
+    g.gather1 = a.gather1; g.gather2 = a.K2 > 0 ? gather2 : nullptr;
+    g.lda1 = (int)a.lda1; g.lda2 = (int)(a.K2 > 0 ? a.lda2 : 0); g.ldw = (int)a.ldw; g.ldcadd = (int)a.ldcadd;
+    g.ldc = (int)a.ldc; g.ldz = (int)a.ldz;
+    g.a1_bytes = a.gather1 ? (rows1 > 0 ? (unsigned)(rows1 * a.lda1 * 4) : 0x7FFFFFFFu) : 0u;
+    g.a2_bytes = (gather2 && a.K2 > 0) ? (unsigned)(rows2 * a.lda2 * 4) : 0u;
+    g.act = a.act; g.slope = a.act_slope; g.slope_ptr = a.act_slope_ptr;
+    const bool vec_c = (a.N % 4 == 0) && (!a.C || (a.ldc % 4 == 0 && al(a.C, 16))) && (!a.Zpre || (a.ldz % 4 == 0 && al(a.Zpre, 16)));
+    g.poison_flags = x.poison_flags; g.poison_mask = x.poison_mask;
+
+    // builds with G >= 2 store 16-byte row segments: outputs that cannot take them use the any-shape build
+    const int G = vec_c ? pick_g(a) : 1;
+    const bool has_a2 = a.K2 > 0;
+
+    if (x.seg) {
+        DMPNN_CHECK_ARG(x.tile_row && x.tile_atom && x.row_ptr && x.revp && x.n_tiles >= 0, "linear(seg): missing tile tables");
+        DMPNN_CHECK_ARG(a.N % 4 == 0 && a.N <= 320, "linear(seg): d_h must be a multiple of 4 and <= 320 (got %lld)", (long long)a.N);
+        DMPNN_CHECK_ARG(G >= 2, "linear(seg): operands must be 8-byte aligned with even widths");
+        DMPNN_CHECK_ARG(!x.Mout || (x.ldm % 4 == 0 && al(x.Mout, 16)), "linear(seg): Mout misaligned");
+        DMPNN_CHECK_ARG(!x.Sout || (x.lds % 4 == 0 && al(x.Sout, 16)), "linear(seg): Sout misaligned");
+        DMPNN_CHECK_ARG(vec_c, "linear(seg): C / Zpre must be 16-byte aligned");
+        if (x.n_tiles == 0) return DMPNN_OK;
+        g.tile_row = x.tile_row; g.tile_atom = x.tile_atom; g.row_ptr = x.row_ptr; g.revp = x.revp;
+        g.Mout = x.Mout; g.ldm = (int)x.ldm; g.Sout = x.Sout; g.lds = (int)x.lds;
+        const unsigned qn = (unsigned)(a.N / 4);
+        g.qmagic = qn > 1 ? (unsigned)(((1ull << 32) + qn - 1) / qn) : 0u;
+        const int wn = a.N <= 64 ? 1 : (a.N <= 128 ? 2 : 5);
+        const int key = wn * 100 + G * 10 + (has_a2 ? 1 : 0);
+        switch (key) {
+#define SEG_CASE(WN_, G_, A2_) \
+    case WN_ * 100 + G_ * 10 + (A2_ ? 1 : 0): return gemm::launch_gemm<3, WN_, G_, A2_, gemm::EPI_SEG>(g, x.n_tiles, s);
+            SEG_CASE(1, 4, false) SEG_CASE(1, 4, true) SEG_CASE(1, 2, true)
+            SEG_CASE(2, 4, false) SEG_CASE(2, 4, true) SEG_CASE(2, 2, true)
+            SEG_CASE(5, 4, false) SEG_CASE(5, 4, true) SEG_CASE(5, 2, true)
+#undef SEG_CASE
+            case 120: return gemm::launch_gemm<3, 1, 2, true, gemm::EPI_SEG>(g, x.n_tiles, s);  // G = 2 single operand: A2 slot reads nothing
+            case 220: return gemm::launch_gemm<3, 2, 2, true, gemm::EPI_SEG>(g, x.n_tiles, s);
+            case 520: return gemm::launch_gemm<3, 5, 2, true, gemm::EPI_SEG>(g, x.n_tiles, s);
+        }
+        set_error("linear(seg): no instantiation for wn=%d G=%d a2=%d", wn, G, (int)has_a2);
+        return DMPNN_EINVAL;
+    }
+
+    if (x.tile_row) { g.tile_row = x.tile_row; }
+    const int wn = pick_wn(a.N);
     const int64_t ncb = (a.N + 64 * wn - 1) / (64 * wn);
-    const int rt = pick_rt(a.M, ncb);
-#define DMPNN_TILE(R, W_)                                                   \
-    if (rt == R && wn == W_)                                                \
-        return vec ? launch_tile<R, W_, true>(g, s) : launch_tile<R, W_, false>(g, s);
-    DMPNN_TILE(1, 2) DMPNN_TILE(2, 2) DMPNN_TILE(3, 2) DMPNN_TILE(4, 2) DMPNN_TILE(6, 2) DMPNN_TILE(8, 2)
-    DMPNN_TILE(1, 5) DMPNN_TILE(2, 5) DMPNN_TILE(3, 5) DMPNN_TILE(4, 5) DMPNN_TILE(6, 5) DMPNN_TILE(8, 5)
-#undef DMPNN_TILE
-    set_error("linear: no tile for rt=%d wn=%d", rt, wn);
+    const int rt = x.tile_row ? 3 : pick_rt(a.M, ncb);
+    const int n_tiles = x.tile_row ? x.n_tiles : (int)((a.M + 16 * rt - 1) / (16 * rt));
+    // variant: 0 = G4 single operand, 1 = G4 two operands, 2 = G2 (two-operand build), 3 = G1 (two-operand build)
+    const int var = G == 4 ? (has_a2 ? 1 : 0) : (G == 2 ? 2 : 3);
+    const int key = rt * 100 + wn * 10 + var;
+    switch (key) {
+#define PLAIN_CASES(RT_, WN_)                                                                                          \
+    case RT_ * 100 + WN_ * 10 + 0: return gemm::launch_gemm<RT_, WN_, 4, false, gemm::EPI_PLAIN>(g, n_tiles, s);       \
+    case RT_ * 100 + WN_ * 10 + 1: return gemm::launch_gemm<RT_, WN_, 4, true, gemm::EPI_PLAIN>(g, n_tiles, s);        \
+    case RT_ * 100 + WN_ * 10 + 2: return gemm::launch_gemm<RT_, WN_, 2, true, gemm::EPI_PLAIN>(g, n_tiles, s);        \
+    case RT_ * 100 + WN_ * 10 + 3: return gemm::launch_gemm<RT_, WN_, 1, true, gemm::EPI_PLAIN>(g, n_tiles, s);
+        PLAIN_CASES(1, 1) PLAIN_CASES(1, 2) PLAIN_CASES(1, 4) PLAIN_CASES(1, 5)
+        PLAIN_CASES(3, 1) PLAIN_CASES(3, 2) PLAIN_CASES(3, 4) PLAIN_CASES(3, 5)
+#undef PLAIN_CASES
+    }
+    set_error("linear: no instantiation for rt=%d wn=%d G=%d", rt, wn, G);
     return DMPNN_EINVAL;
+}
+
+int launch_linear(const dmpnn_gemm_args& a, hipStream_t s) {
+    GemmExtra x;
+    memset(&x, 0, sizeof(x));
+    return launch_linear_ex(a, x, s);
 }
 
 }  // namespace dmpnn

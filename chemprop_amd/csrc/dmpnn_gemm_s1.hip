@@ -1,0 +1,17 @@
+// Instantiations of the fp32-MFMA contraction (see dmpnn_gemm_impl.hpp); split over several
+// translation units so the build runs in parallel.
+#include "dmpnn_gemm_impl.hpp"
+
+namespace dmpnn {
+namespace gemm {
+DMPNN_DEFINE_GEMM(3, 1, 4, false, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 1, 4, true, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 1, 2, true, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 2, 4, false, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 2, 4, true, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 2, 2, true, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 5, 4, false, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 5, 4, true, EPI_SEG)
+DMPNN_DEFINE_GEMM(3, 5, 2, true, EPI_SEG)
+}  // namespace gemm
+}  // namespace dmpnn

@@ -4,10 +4,16 @@
 // scatter (mixins.py:12, base.py:208).  Here the int64 COO arrays are narrowed to int32 once per
 // batch and a STABLE incoming-edge CSR keyed by destination atom is built, so every later kernel
 // walks an atom's incoming rows in increasing edge id — the order of the reference's sequential
-// scatter_reduce_ — with coalesced 1200-byte row reads and no atomics on the data path.
+// scatter_reduce_ — with coalesced row reads and no atomics on the data path.  The plan also
+// carries the same graph in CSR-ROW coordinates (row i = edge perm[i]) and a table of row tiles
+// that hold whole destination atoms: the fused forward keeps its edge tensors in row order and
+// forms the segment sums in the epilogue of the contraction that produced them.
 //
-// Four short launches (init | convert+count+validate | scan | fill+sort).  All integer work,
-// HBM/latency bound: 3 int64 reads + 5 int32 writes per edge.
+// All integer work, latency bound.  Two builds of the same algorithm:
+//   * k_prepare_small: ONE workgroup, every intermediate (dst, rev, perm, inv as uint16, the
+//     per-atom counters) in LDS — a 512-molecule QM9 batch (E ~ 9.6k, V ~ 4.6k) needs ~110 KB;
+//     global memory sees one batched read of the int64 arrays and one pass of int32 writes.
+//   * the general path: count | scan | fill | sort | inverse | rows+tiles, seven short launches.
 #include "dmpnn_common.hpp"
 
 namespace dmpnn {
@@ -144,48 +150,151 @@ __global__ void k_sort_rows(int* __restrict__ plan, PlanLayout L, int nV) {
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&plan[DMPNN_HDR_MAXDEG], m);
 }
 
-// ---- single-workgroup plan for small batches (the launch-bound regime: 512 QM9 molecules are
-// ~9k edges / ~4.6k atoms) -----------------------------------------------------------------------
-// All five phases in ONE launch; the per-atom counters live in LDS (workgroup-coherent, so no
-// cross-CU visibility protocol is needed), global memory only sees plain stores that are re-read
-// after a workgroup barrier by waves of the same CU.
+__global__ void k_inverse(int* __restrict__ plan, PlanLayout L, int nE) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nE) plan[L.inv + plan[L.perm + i]] = i;
+}
+
+// ---- row tiles of whole atoms ------------------------------------------------------------------
+// Nominal stride B0 = BM - maxdeg + 1: atom v belongs to tile row_ptr[v] / B0, so a tile's rows start
+// inside [t*B0, (t+1)*B0) and run at most maxdeg-1 rows past it: never more than BM rows, and no
+// sequential packing pass is needed.  Trailing tiles (up to the launch bound) are empty.
+struct TileGeom {
+    int b0, n_tiles;  // n_tiles == 0: no fused tiling (no edges, or an in-degree the tiling cannot hold)
+};
+__device__ __forceinline__ TileGeom tile_geom(int maxdeg, int nE) {
+    TileGeom g;
+    const int md = maxdeg < 1 ? 1 : maxdeg;
+    g.b0 = kFusedBM - md + 1;
+    g.n_tiles = (md > kFusedMaxDeg || nE == 0) ? 0 : (nE + g.b0 - 1) / g.b0;
+    return g;
+}
+__device__ __forceinline__ int tile_of(int row_start, const TileGeom& g) {
+    const int t = row_start / g.b0;
+    return t < g.n_tiles - 1 ? t : g.n_tiles - 1;
+}
+// thread `i` of `n_threads` cooperating threads writes its share of the two tables
+__device__ __forceinline__ void write_tiles(int* __restrict__ plan, const PlanLayout& L, const int* __restrict__ row_ptr,
+                                            int nV, int nE, const TileGeom& g, int i, int n_threads) {
+    int* tile_row = plan + L.tile_row;
+    int* tile_atom = plan + L.tile_atom;
+    const int slots = (int)L.max_tiles + 2;
+    if (g.n_tiles == 0) {
+        for (int t = i; t < slots; t += n_threads) { tile_row[t] = nE; tile_atom[t] = nV; }
+        return;
+    }
+    for (int v = i; v < nV; v += n_threads) {
+        const int rs = row_ptr[v];
+        const int tv = tile_of(rs, g);
+        const int tp = v == 0 ? -1 : tile_of(row_ptr[v - 1], g);
+        for (int t = tp + 1; t <= tv; ++t) { tile_row[t] = rs; tile_atom[t] = v; }
+    }
+    const int tl = nV > 0 ? tile_of(row_ptr[nV - 1], g) : -1;
+    for (int t = tl + 1 + i; t < slots; t += n_threads) { tile_row[t] = nE; tile_atom[t] = nV; }
+}
+
+// CSR-row coordinates + tile tables + final header words (general path, after k_inverse).
+__global__ void k_rows_tiles(int* __restrict__ plan, PlanLayout L, int nV, int nE) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_threads = gridDim.x * blockDim.x;
+    const int maxdeg = plan[DMPNN_HDR_MAXDEG];
+    const TileGeom g = tile_geom(maxdeg, nE);
+    for (int r = i; r < nE; r += n_threads) {
+        const int e = plan[L.perm + r];
+        plan[L.srcp + r] = plan[L.src + e];
+        plan[L.dstp + r] = plan[L.dst + e];
+        plan[L.revp + r] = plan[L.inv + plan[L.rev + e]];
+        plan[L.ident + r] = r;
+    }
+    write_tiles(plan, L, plan + L.row_ptr, nV, nE, g, i, n_threads);
+    if (i == 0) {
+        plan[DMPNN_HDR_NTILES] = g.n_tiles;
+        plan[DMPNN_HDR_TILE_STRIDE] = g.b0;
+        if (maxdeg > kFusedMaxDeg) atomicOr(&plan[DMPNN_HDR_FLAGS], PLAN_HUGE_DEGREE);
+    }
+}
+
+// ---- single-workgroup plan for small batches (the launch-bound regime) -------------------------
 constexpr int kSmallThreads = 1024;
-constexpr int kSmallMaxAtoms = 16384;
-constexpr int kSmallMaxEdges = 32768;
-constexpr int kSmallItems = kSmallMaxAtoms / kSmallThreads;  // 16 counters per thread in the scan
+constexpr int kSmallMaxAtoms = 6144;
+constexpr int kSmallMaxEdges = 12288;
+constexpr int kSmallItems = kSmallMaxAtoms / kSmallThreads;  // 6 counters per thread in the scan
+constexpr int kSmallEPT = kSmallMaxEdges / kSmallThreads;    // 12 edges per thread at most
+typedef unsigned short u16;
 
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* __restrict__ edge_index,
                                                                 const int64_t* __restrict__ rev64,
                                                                 int* __restrict__ plan, PlanLayout L, int nV, int nE) {
-    extern __shared__ int cnt[];  // [nV] in-degree, then fill cursor
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];
+    // layout: cnt[nV] int | row0[nV + 1] int | dst16[nE] | rev16[nE] | perm16[nE] | inv16[nE]
+    int* cnt = lds_i;
+    int* rowp = lds_i + nV;
+    u16* dst16 = reinterpret_cast<u16*>(rowp + nV + 1);
+    u16* rev16 = dst16 + nE;
+    u16* perm16 = rev16 + nE;
+    u16* inv16 = perm16 + nE;
     __shared__ int wave_tot[kSmallThreads / 64];
     __shared__ int flags_s, maxdeg_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < nV; i += kSmallThreads) cnt[i] = 0;
     if (tid == 0) { flags_s = 0; maxdeg_s = 0; }
-    __syncthreads();
-    // phase 1: narrow + validate + histogram
+
+    // phase 1: ONE batched read of the int64 arrays (all loads of a thread in flight together)
+    int64_t s64[kSmallEPT], d64[kSmallEPT], r64[kSmallEPT];
+#pragma unroll
+    for (int j = 0; j < kSmallEPT; ++j) {
+        const int e = tid + kSmallThreads * j;
+        const int ec = e < nE ? e : 0;
+        s64[j] = edge_index[ec];
+        d64[j] = edge_index[(int64_t)nE + ec];
+        r64[j] = rev64[ec];
+    }
+    __syncthreads();  // cnt zeroed
     int bad = 0;
-    for (int e = tid; e < nE; e += kSmallThreads) {
-        int64_t s = edge_index[e], d = edge_index[(int64_t)nE + e], r = rev64[e];
-        if (s < 0 || s >= nV || d < 0 || d >= nV || r < 0 || r >= nE) {
-            bad |= PLAN_RANGE_ERROR | PLAN_ASYMMETRIC;
-            s = s < 0 ? 0 : (s >= nV ? nV - 1 : s);
-            d = d < 0 ? 0 : (d >= nV ? nV - 1 : d);
-            r = r < 0 ? 0 : (r >= nE ? nE - 1 : r);
+    int src32[kSmallEPT];
+#pragma unroll
+    for (int j = 0; j < kSmallEPT; ++j) {
+        const int e = tid + kSmallThreads * j;
+        int64_t s = s64[j], d = d64[j], r = r64[j];
+        if (e < nE) {
+            if (s < 0 || s >= nV || d < 0 || d >= nV || r < 0 || r >= nE) {
+                bad |= PLAN_RANGE_ERROR | PLAN_ASYMMETRIC;
+                s = s < 0 ? 0 : (s >= nV ? nV - 1 : s);
+                d = d < 0 ? 0 : (d >= nV ? nV - 1 : d);
+                r = r < 0 ? 0 : (r >= nE ? nE - 1 : r);
+            }
+            src32[j] = (int)s;
+            dst16[e] = (u16)d;
+            rev16[e] = (u16)r;
+            plan[L.src + e] = (int)s;
+            plan[L.dst + e] = (int)d;
+            plan[L.rev + e] = (int)r;
+            atomicAdd(&cnt[(int)d], 1);
         } else {
-            const int64_t rr = rev64[r];
-            const int64_t sr = edge_index[r], dr = edge_index[(int64_t)nE + r];
-            if (rr != e || sr != d || dr != s) bad |= PLAN_ASYMMETRIC;
+            src32[j] = 0;
         }
-        plan[L.src + e] = (int)s;
-        plan[L.dst + e] = (int)d;
-        plan[L.rev + e] = (int)r;
-        atomicAdd(&cnt[d], 1);
+    }
+    __syncthreads();
+    // phase 1b: symmetric-graph invariants, from LDS (src of the reverse edge: one more batched read)
+    {
+        int sr[kSmallEPT];
+#pragma unroll
+        for (int j = 0; j < kSmallEPT; ++j) {
+            const int e = tid + kSmallThreads * j;
+            const int r = e < nE ? rev16[e] : 0;
+            sr[j] = nE > 0 ? (int)edge_index[r] : 0;  // read-only input: no visibility question
+        }
+#pragma unroll
+        for (int j = 0; j < kSmallEPT; ++j) {
+            const int e = tid + kSmallThreads * j;
+            if (e < nE) {
+                const int r = rev16[e];
+                if (rev16[r] != e || sr[j] != dst16[e] || dst16[r] != src32[j]) bad |= PLAN_ASYMMETRIC;
+            }
+        }
     }
     if (bad) atomicOr(&flags_s, bad);
-    __syncthreads();
-    // phase 2: exclusive scan of cnt[0..nV) (16 consecutive counters per thread)
+    // phase 2: exclusive scan of cnt[0..nV) (6 consecutive counters per thread)
     {
         int v[kSmallItems];
         int tot = 0;
@@ -210,31 +319,31 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
 #pragma unroll
         for (int j = 0; j < kSmallItems; ++j) {
             if (i0 + j < nV) {
-                plan[L.row_ptr + i0 + j] = run;
+                rowp[i0 + j] = run;
                 cnt[i0 + j] = run;
+                plan[L.row_ptr + i0 + j] = run;
             }
             run += v[j];
             md = max(md, v[j]);
         }
-        if (tid == kSmallThreads - 1) plan[L.row_ptr + nV] = run;
+        if (tid == kSmallThreads - 1) { rowp[nV] = run; plan[L.row_ptr + nV] = run; }
         for (int off = 32; off > 0; off >>= 1) md = max(md, __shfl_xor(md, off));
         if (lane == 0 && md > 0) atomicMax(&maxdeg_s, md);
     }
     __syncthreads();
     // phase 3: fill rows (order inside a row is arbitrary here)
     for (int e = tid; e < nE; e += kSmallThreads) {
-        const int d = plan[L.dst + e];
-        const int pos = atomicAdd(&cnt[d], 1);
-        plan[L.perm + pos] = e;
+        const int pos = atomicAdd(&cnt[dst16[e]], 1);
+        perm16[pos] = (u16)e;
     }
     __syncthreads();
     // phase 4: restore increasing edge id inside every row (the reference's summation order)
     for (int v = tid; v < nV; v += kSmallThreads) {
-        const int b = plan[L.row_ptr + v];
-        const int n = cnt[v] - b;  // cursor has advanced to the end of the row
-        int* row = plan + L.perm + b;
+        const int b = rowp[v];
+        const int n = rowp[v + 1] - b;
+        u16* row = perm16 + b;
         for (int i = 1; i < n; ++i) {
-            const int key = row[i];
+            const u16 key = row[i];
             int j = i - 1;
             while (j >= 0 && row[j] > key) {
                 row[j + 1] = row[j];
@@ -243,12 +352,32 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
             row[j + 1] = key;
         }
     }
+    __syncthreads();
+    // phase 5: inverse permutation
+    for (int i = tid; i < nE; i += kSmallThreads) inv16[perm16[i]] = (u16)i;
+    __syncthreads();
+    // phase 6: everything out — perm, inv, CSR-row coordinates, tile tables, header
+    for (int i = tid; i < nE; i += kSmallThreads) {
+        const int e = perm16[i];
+        plan[L.perm + i] = e;
+        plan[L.inv + i] = inv16[i];
+        int64_t se = edge_index[e];  // read-only input (L2 hit); clamped like plan.src
+        se = se < 0 ? 0 : (se >= nV ? nV - 1 : se);
+        plan[L.srcp + i] = (int)se;
+        plan[L.dstp + i] = dst16[e];
+        plan[L.revp + i] = inv16[rev16[e]];
+        plan[L.ident + i] = i;
+    }
+    const TileGeom g = tile_geom(maxdeg_s, nE);
+    write_tiles(plan, L, rowp, nV, nE, g, tid, kSmallThreads);
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
-        if (tid == DMPNN_HDR_FLAGS) v = flags_s;
+        if (tid == DMPNN_HDR_FLAGS) v = flags_s | (maxdeg_s > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0);
         if (tid == DMPNN_HDR_MAXDEG) v = maxdeg_s;
         if (tid == DMPNN_HDR_NATOMS) v = nV;
         if (tid == DMPNN_HDR_NEDGES) v = nE;
+        if (tid == DMPNN_HDR_NTILES) v = g.n_tiles;
+        if (tid == DMPNN_HDR_TILE_STRIDE) v = g.b0;
         plan[tid] = v;
     }
 }
@@ -260,12 +389,14 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
     const int nV = (int)nV64, nE = (int)nE64;
     const PlanLayout L = plan_layout(nV, nE);
     if (nV <= kSmallMaxAtoms && nE <= kSmallMaxEdges) {
-        const size_t lds = (size_t)(nV > 0 ? nV : 1) * sizeof(int);
+        size_t lds = (size_t)(2 * nV + 1) * sizeof(int) + (size_t)4 * nE * sizeof(u16);
+        lds = (lds + 15) & ~size_t(15);
+        if (lds < 16) lds = 16;
         static bool attr_set = false;
         if (!attr_set) {
+            const size_t max_lds = (size_t)(2 * kSmallMaxAtoms + 1) * sizeof(int) + (size_t)4 * kSmallMaxEdges * sizeof(u16) + 16;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_small),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)(kSmallMaxAtoms * sizeof(int)));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
             if (e != hipSuccess) {
                 set_error("hipFuncSetAttribute(k_prepare_small): %s", hipGetErrorString(e));
                 return DMPNN_EHIP;
@@ -297,6 +428,16 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
         const int gridv = (nV + kBlock - 1) / kBlock;
         hipLaunchKernelGGL(k_sort_rows, dim3(gridv), dim3(kBlock), 0, s, plan, L, nV);
         DMPNN_CHECK_LAUNCH("k_sort_rows");
+        hipLaunchKernelGGL(k_inverse, dim3(grid), dim3(kBlock), 0, s, plan, L, nE);
+        DMPNN_CHECK_LAUNCH("k_inverse");
+    }
+    {
+        const int64_t n = nV > nE ? nV : nE;
+        int grid = (int)((n + kBlock - 1) / kBlock);
+        if (grid < 1) grid = 1;
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_rows_tiles, dim3(grid), dim3(kBlock), 0, s, plan, L, nV, nE);
+        DMPNN_CHECK_LAUNCH("k_rows_tiles");
     }
     return DMPNN_OK;
 }

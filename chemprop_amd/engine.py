@@ -7,13 +7,14 @@ fallback: tensors that are not on a HIP device raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT, F_UNDIRECTED, FwdArgs, GemmArgs
+from ._lib import ACT, F_FUSED, F_UNDIRECTED, PLAN_NOFUSE_MASK, FwdArgs, GemmArgs
 
 
 def _stream_ptr(device) -> int:
@@ -69,29 +70,46 @@ class GraphPlan:
     def arrays(self) -> dict:
         off = self._offsets()
         b = self.buf.cpu()
-        E, V = self.n_edges, self.n_atoms
-        return dict(hdr=b[:16], src=b[off[0]:off[0] + E], dst=b[off[1]:off[1] + E], rev=b[off[2]:off[2] + E],
-                    row_ptr=b[off[3]:off[3] + V + 1], perm=b[off[4]:off[4] + E])
+        E, V, T = self.n_edges, self.n_atoms, int(off[11])
+        cut = lambda o, n: b[o:o + n]
+        return dict(hdr=b[:16], src=cut(off[0], E), dst=cut(off[1], E), rev=cut(off[2], E),
+                    row_ptr=cut(off[3], V + 1), perm=cut(off[4], E), inv=cut(off[5], E), srcp=cut(off[6], E),
+                    dstp=cut(off[7], E), revp=cut(off[8], E), tile_row=cut(off[9], T + 2),
+                    tile_atom=cut(off[10], T + 2))
+
+    def flags(self) -> int:
+        """Plan flag word (synchronises): bit0 asymmetric, bit1 index out of range, bit2 in-degree > 24."""
+        return int(self.buf[0].item())
+
+    def fusable(self) -> bool:
+        """True when the fused (row-tiled) forward represents this graph exactly (synchronises)."""
+        return (self.flags() & PLAN_NOFUSE_MASK) == 0
 
     def _offsets(self):
-        off = (C.c_int64 * 5)()
+        off = (C.c_int64 * _lib.PLAN_NOFFSETS)()
         _lib.check(_lib.load().dmpnn_plan_layout(self.n_atoms, self.n_edges, off), "dmpnn_plan_layout")
         return off
 
+    def _view(self, k: int) -> Tensor:
+        off = self._offsets()
+        return self.buf[off[k]:off[k] + self.n_edges]
+
     @property
     def src32(self) -> Tensor:
-        off = self._offsets()
-        return self.buf[off[0]:off[0] + self.n_edges]
+        return self._view(0)
 
     @property
     def dst32(self) -> Tensor:
-        off = self._offsets()
-        return self.buf[off[1]:off[1] + self.n_edges]
+        return self._view(1)
 
     @property
     def rev64(self) -> Tensor:
-        off = self._offsets()
-        return self.buf[off[2]:off[2] + self.n_edges].long()
+        return self._view(2).long()
+
+    @property
+    def perm64(self) -> Tensor:
+        """CSR row -> edge id (row i of a fused-forward edge tensor is edge perm[i])."""
+        return self._view(4).long()
 
 
 def act_code(name: str) -> int:
@@ -143,6 +161,7 @@ def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Te
     g = GemmArgs()
     g.M, g.N, g.K1, g.K2 = M, N, K1, K2
     g.A1, g.lda1, g.gather1 = A1.data_ptr(), A1.stride(0), _ptr(gather1)
+    g.gather1_rows = int(A1.shape[0])
     g.A2, g.lda2 = _ptr(A2), (A2.stride(0) if A2 is not None else 0)
     g.W, g.ldw = W.data_ptr(), W.stride(0)
     g.bias = _ptr(bias)
@@ -155,20 +174,48 @@ def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Te
     return C_
 
 
+def update_fused(plan: GraphPlan, M: Tensor, H0: Tensor, W_h: Tensor, b_h: Optional[Tensor] = None,
+                 act: str = "relu", slope: float = 0.0, slope_t: Optional[Tensor] = None, want_H: bool = False,
+                 want_M: bool = True, want_Mv: bool = False, H_out: Optional[Tensor] = None,
+                 M_next: Optional[Tensor] = None, Mv: Optional[Tensor] = None):
+    """One fused depth step on CSR-row-ordered tensors: ``H' = tau(H0 + M W_h^T + b)`` and, from the
+    same kernel's epilogue, the next message ``M_next`` and / or the per-atom aggregate ``Mv``."""
+    M, H0, W_h = _f32c(M, "M"), _f32c(H0, "H0"), _f32c(W_h, "W_h").contiguous()
+    dev, (nE, h) = M.device, M.shape
+    if want_H and H_out is None:
+        H_out = torch.empty_like(M)
+    if want_M and M_next is None:
+        M_next = torch.empty_like(M)
+    if want_Mv and Mv is None:
+        Mv = torch.empty(plan.n_atoms, h, dtype=torch.float32, device=dev)
+    ld = lambda t: t.stride(0) if t is not None else 0
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().dmpnn_update_fwd(
+            plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, h, M.data_ptr(), M.stride(0), H0.data_ptr(), H0.stride(0),
+            W_h.data_ptr(), _ptr(b_h), _ptr(H_out), ld(H_out), _ptr(M_next), ld(M_next), _ptr(Mv), ld(Mv),
+            act_code(act), float(slope), _ptr(slope_t), _stream_ptr(dev)), "dmpnn_update_fwd")
+    return H_out, M_next, Mv
+
+
 # ------------------------------------------------------------------------------------------------
 # whole forward (builtin activation, dropout inactive): one C call, kernels chained on the stream
 # ------------------------------------------------------------------------------------------------
 class ForwardState:
     """Workspace of one forward; kept alive for the backward pass when ``keep`` is set."""
 
-    __slots__ = ("plan", "H0", "Hs", "Ms", "Mv", "Hv", "ldh", "n_hslots", "n_mslots", "out", "args", "refs", "dims")
+    __slots__ = ("plan", "H0", "Hs", "Ms", "Mv", "Hv", "ldh", "n_hslots", "n_mslots", "out", "args", "refs", "dims",
+                 "fused")
 
 
 def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o: Tensor, b_o: Tensor,
             b_i: Optional[Tensor] = None, b_h: Optional[Tensor] = None, W_d: Optional[Tensor] = None,
             b_d: Optional[Tensor] = None, V_d: Optional[Tensor] = None, depth: int = 3, act: str = "relu",
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
-            keep: bool = False) -> tuple[Tensor, ForwardState]:
+            keep: bool = False, fused: Optional[bool] = None) -> tuple[Tensor, ForwardState]:
+    """One ``dmpnn_forward`` call.  ``fused=None`` picks the fused route (edge tensors in CSR-row order,
+    segment sums formed in the contraction epilogues) whenever the shapes allow it; ``fused=False``
+    forces the general route (arbitrary index arrays).  A graph the fused tiling cannot represent
+    (asymmetric, in-degree > 24) makes the fused route return NaN — see ``GraphPlan.fusable``."""
     lib = _lib.load()
     V = _f32c(V, "V")
     E = _f32c(E, "E")
@@ -180,20 +227,6 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     d_vd = int(V_d.shape[1]) if (W_d is not None and V_d is not None) else 0
     ldh = (d_h + 3) // 4 * 4
     n_steps = max(depth - 1, 0)
-    n_hslots = max(n_steps, 1) if keep else 1
-    n_mslots = max(n_steps, 1) if keep else 1
-
-    st = ForwardState()
-    st.plan, st.ldh, st.n_hslots, st.n_mslots = plan, ldh, n_hslots, n_mslots
-    edge_ws = torch.empty((1 + n_hslots + n_mslots, nE, ldh), dtype=torch.float32, device=dev)
-    atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
-    if ldh != d_h:  # pad columns are read by vector loads of later kernels: keep them finite
-        edge_ws.zero_()
-        atom_ws.zero_()
-    st.H0, st.Hs, st.Ms = edge_ws[0], edge_ws[1:1 + n_hslots], edge_ws[1 + n_hslots:]
-    st.Mv, st.Hv = atom_ws[0], atom_ws[1]
-    out = torch.empty(nV, d_h + d_vd, dtype=torch.float32, device=dev)
-    st.out = out
 
     a = FwdArgs()
     a.plan, a.n_atoms, a.n_edges = plan.buf.data_ptr(), nV, nE
@@ -211,10 +244,42 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     if d_vd:
         W_d, b_d = Wc(W_d, "W_d"), Wc(b_d, "b_d")
         a.W_d, a.b_d = _ptr(W_d), _ptr(b_d)
-    a.ldh, a.H0, a.Hs, a.n_hslots = ldh, st.H0.data_ptr(), st.Hs.data_ptr(), n_hslots
-    a.Ms, a.n_mslots = st.Ms.data_ptr(), n_mslots
+    a.ldh = ldh
+
+    # route: the shape / alignment part of the decision is the library's (dmpnn_forward_can_fuse)
+    want_fused = fused is not False and os.environ.get("DMPNN_GENERAL", "0") != "1" and not undirected
+    a.H0 = a.Ms = a.Mv = plan.buf.data_ptr()  # any 16-byte aligned pointer: the real workspace is allocated below
+    use_fused = bool(want_fused and lib.dmpnn_forward_can_fuse(C.byref(a)))
+    if fused is True and not use_fused:
+        raise RuntimeError("forward: fused=True but the shapes do not allow the fused route "
+                           "(needs d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed)")
+
+    st = ForwardState()
+    st.fused = use_fused
+    if use_fused:
+        n_hslots = n_steps if keep else 0           # H^(t) only matters to the backward pass
+        n_mslots = n_steps if keep else min(n_steps, 2)
+    else:
+        n_hslots = max(n_steps, 1) if keep else 1
+        n_mslots = max(n_steps, 1) if keep else 1
+    st.plan, st.ldh, st.n_hslots, st.n_mslots = plan, ldh, n_hslots, n_mslots
+    edge_ws = torch.empty((1 + n_hslots + max(n_mslots, 1), nE, ldh), dtype=torch.float32, device=dev)
+    atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
+    if ldh != d_h:  # pad columns are read by vector loads of later kernels: keep them finite
+        edge_ws.zero_()
+        atom_ws.zero_()
+    st.H0, st.Hs, st.Ms = edge_ws[0], edge_ws[1:1 + n_hslots], edge_ws[1 + n_hslots:]
+    st.Mv, st.Hv = atom_ws[0], atom_ws[1]
+    out = torch.empty(nV, d_h + d_vd, dtype=torch.float32, device=dev)
+    st.out = out
+
+    a.H0 = st.H0.data_ptr()
+    a.Hs, a.n_hslots = (st.Hs.data_ptr() if n_hslots else None), n_hslots
+    a.Ms, a.n_mslots = st.Ms.data_ptr(), max(n_mslots, 1)
     a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
     a.out, a.ldout = out.data_ptr(), out.stride(0)
+    if use_fused:
+        a.flags |= F_FUSED
     with torch.cuda.device(dev):
         _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
@@ -283,6 +348,7 @@ def linear_wgrad(gZ: Tensor, A1: Tensor, A2: Optional[Tensor] = None, gather1: O
     g = GemmArgs()
     g.M, g.N, g.K1, g.K2 = M, N, K1, K2
     g.A1, g.lda1, g.gather1 = A1.data_ptr(), A1.stride(0), _ptr(gather1)
+    g.gather1_rows = int(A1.shape[0])
     g.A2, g.lda2 = _ptr(A2), (A2.stride(0) if A2 is not None else 0)
     gW = torch.empty(N, K1 + K2, dtype=torch.float32, device=gZ.device)
     gb = torch.empty(N, dtype=torch.float32, device=gZ.device) if want_bias else None

@@ -13,6 +13,7 @@ read like the reference's own.  Where chemprop itself is importable, use
 from __future__ import annotations
 
 import copy
+import os
 from typing import Optional
 
 import torch
@@ -118,4 +119,24 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
     plan = engine.GraphPlan.from_bmg(bmg)
-    return mp_forward(mp, plan, bmg.V, bmg.E, V_d)
+    return mp_forward(mp, plan, bmg.V, bmg.E, V_d, fused=_route(mp, plan))
+
+
+_VALIDATE_FIRST_N = 2
+
+
+def _route(mp, plan) -> Optional[bool]:
+    """Fused route (``None`` = when the shapes allow) or general route (``False``) for this batch.
+
+    The fused kernels assume a molecular graph (``rev`` an involution with ``src(rev e) == dst(e)``,
+    in-degree <= 24); ``dmpnn_prepare`` checks that ON THE DEVICE and a violating batch makes the
+    fused route return NaN (never a silently wrong number).  Reading the verdict needs a host sync,
+    so by default (``DMPNN_VALIDATE=first``) only the first batches a module sees are checked
+    synchronously — featurizer-produced graphs never violate the invariants; ``always`` checks every
+    batch (a sync per forward), ``never`` trusts.  A batch found in violation runs the general route."""
+    mode = os.environ.get("DMPNN_VALIDATE", "first")
+    seen = getattr(mp, "_dmpnn_batches_checked", 0)
+    if mode == "always" or (mode == "first" and seen < _VALIDATE_FIRST_N):
+        object.__setattr__(mp, "_dmpnn_batches_checked", seen + 1)
+        return None if plan.fusable() else False
+    return None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 1
+#define DMPNN_ABI_VERSION 2
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -52,7 +52,11 @@ enum dmpnn_activation {
 };
 
 enum dmpnn_flags {
-    DMPNN_F_UNDIRECTED = 1u << 0 /* base.py:202-203: H <- (H + H[rev]) / 2 before every message()  */
+    DMPNN_F_UNDIRECTED = 1u << 0, /* base.py:202-203: H <- (H + H[rev]) / 2 before every message() */
+    DMPNN_F_FUSED = 1u << 1       /* dmpnn_forward / dmpnn_backward: edge tensors live in CSR-row
+                                     order and the segment sums are formed in the contraction
+                                     epilogues (molecular graphs: symmetric, in-degree <= 24;
+                                     not with DMPNN_F_UNDIRECTED)                                   */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -72,14 +76,24 @@ int dmpnn_prepare(const int64_t* edge_index, /* [2, n_edges] row 0 = src atom, r
 enum dmpnn_plan_hdr {
     DMPNN_HDR_FLAGS = 0,   /* bit0: graph is NOT symmetric (rev is not an involution with
                               src(rev e)==dst(e)): the general edge-form message kernel runs;
-                              bit1: an index was out of range (clamped; results undefined)      */
+                              bit1: an index was out of range (clamped; results undefined);
+                              bit2: an in-degree exceeds what the fused row tiling supports (24).
+                              Any bit set: a forward with DMPNN_F_FUSED returns NaN (loud) — run
+                              such graphs without DMPNN_F_FUSED                                    */
     DMPNN_HDR_MAXDEG = 1,
     DMPNN_HDR_NATOMS = 2,
     DMPNN_HDR_NEDGES = 3,
+    DMPNN_HDR_NTILES = 4,  /* fused row tiles actually used (<= the launch bound)                */
+    DMPNN_HDR_TILE_STRIDE = 5,
     DMPNN_HDR_WORDS = 16
 };
-/* Word offsets of the arrays inside the plan (for tests): src, dst, rev, row_ptr, perm. */
-int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t offsets_out[5]);
+/* Word offsets of the arrays inside the plan (for tests):
+ *   [0..4]  src, dst, rev, row_ptr, perm                  (original edge ids)
+ *   [5..8]  inv, srcp, dstp, revp                         (CSR-row coordinates: row i = edge perm[i])
+ *   [9..10] tile_row, tile_atom                           (row tiles of whole atoms, fused forward)
+ *   [11]    number of tile slots (launch bound)                                                  */
+#define DMPNN_PLAN_NOFFSETS 12
+int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t offsets_out[DMPNN_PLAN_NOFFSETS]);
 
 /* ---------------------------------------------------------------------------------------------
  * Row kernels (each replaces the reference lines cited; exported for per-row parity tests and
@@ -109,6 +123,8 @@ int dmpnn_aggregate_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int6
 typedef struct dmpnn_gemm_args {
     int64_t M, N, K1, K2;
     const float* A1; int64_t lda1; const int32_t* gather1; /* gather1 may be NULL                */
+    int64_t gather1_rows;                                   /* rows of the A1 tensor when gather1 is given
+                                                               (bounds the hardware range check; 0 = unknown) */
     const float* A2; int64_t lda2;                          /* A2 may be NULL iff K2 == 0         */
     const float* W;  int64_t ldw;                           /* [N, K1+K2]                         */
     const float* bias;                                      /* [N] or NULL                        */
@@ -118,6 +134,20 @@ typedef struct dmpnn_gemm_args {
     int act; float act_slope; const float* act_slope_ptr;
 } dmpnn_gemm_args;
 int dmpnn_linear_fwd(const dmpnn_gemm_args* a, void* stream);
+
+/* K3 + K2 (or + K4) fused — ONE per-depth update of the fused route, the dominant kernel of the path:
+ *     H'      = tau(H0 + M . W_h^T + b_h)                                   base.py:135-141
+ *     M_next[rev(r)] = S[dst(r)] - H'[r],  S[v] = sum_{rows r of v} H'[r]   mixins.py:11-18   (if M_next)
+ *     Mv[v]   = S[v]                                                        base.py:208-211   (if Mv)
+ * Rows are the plan's CSR-row order (row i = edge perm[i]); the segment sums are formed from the
+ * LDS-resident output tile in the epilogue of the fp32-MFMA contraction.  H_out may be NULL
+ * (inference).  Needs d_h % 4 == 0, d_h <= 320, 16-byte aligned tensors, ld % 4 == 0.            */
+int dmpnn_update_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h,
+                     const float* M, int64_t ld_m, const float* H0, int64_t ld_h0,
+                     const float* W_h, const float* b_h,
+                     float* H_out, int64_t ld_hout, float* M_next, int64_t ld_mnext,
+                     float* Mv, int64_t ld_mv,
+                     int act, float act_slope, const float* act_slope_ptr, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole forward: base.py:196-212 for BondMessagePassing (graph_transform / V_d_transform /
@@ -140,18 +170,29 @@ typedef struct dmpnn_fwd_args {
     const float* W_d; const float* b_d;   /* [d_h+d_vd, d_h+d_vd] or NULL                         */
     /* caller-owned workspace, all with leading dimension ldh >= d_h:
      *   H0      [n_edges, ldh]            pre-activation W_i(...)                                 *
-     *   Hs      n_hslots x [n_edges, ldh] H^(t) lives in slot t % n_hslots  (t = 1..depth-1);     *
-     *                                     n_hslots = depth-1 keeps every H^(t) for backward,      *
-     *                                     n_hslots = 2 ping-pongs (inference)                     *
-     *   Ms      n_mslots x [n_edges, ldh] message M^(t) in slot (t-1) % n_mslots                  *
+     *   Hs      n_hslots x [n_edges, ldh] H^(t) lives in slot (t-1) % n_hslots (t = 1..depth-1);  *
+     *                                     n_hslots = depth-1 keeps every H^(t) for backward.      *
+     *                                     General route: required (n_hslots >= 1).  Fused route:  *
+     *                                     optional — NULL skips the H^(t) stores (inference)      *
+     *   Ms      n_mslots x [n_edges, ldh] message M^(t) in slot (t-1) % n_mslots; n_mslots =      *
+     *                                     depth-1 keeps them for backward; the fused route needs  *
+     *                                     >= 2 slots when depth > 2 (M^(t+1) is produced while    *
+     *                                     M^(t) is consumed)                                      *
      *   Mv      [n_atoms, ldh]                                                                    *
-     *   Hv      [n_atoms, ldh]            only when W_d != NULL (tau(W_o(.)) before W_d)          */
+     *   Hv      [n_atoms, ldh]            only when W_d != NULL (tau(W_o(.)) before W_d)          *
+     * With DMPNN_F_FUSED the rows of H0 / Hs / Ms are in the plan's CSR-row order (row i = edge   *
+     * perm[i]); without it they are in the caller's edge order.  Mv, Hv, out are per atom.        */
     int64_t ldh; float* H0; float* Hs; int32_t n_hslots; float* Ms; int32_t n_mslots;
     float* Mv; float* Hv;
     /* output [n_atoms, d_h (+ d_vd)] */
     float* out; int64_t ldout;
 } dmpnn_fwd_args;
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
+/* 1 when the shapes / alignment of `a` allow DMPNN_F_FUSED (d_h % 4 == 0, d_h <= 320, even d_v and
+ * d_e, directed), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
+ * dmpnn_prepare: a fused forward on a graph that violates them returns NaN and leaves the plan flags
+ * set (DMPNN_HDR_FLAGS) — run such graphs without DMPNN_F_FUSED. */
+int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  backward.  The reference has no backward code of its own: gradients come from torch autograd

@@ -44,6 +44,39 @@ def graph_is_symmetric(src, dst, rev) -> bool:
     return bool(np.all(rev[rev] == np.arange(len(rev))) and np.all(src[rev] == dst) and np.all(dst[rev] == src))
 
 
+def row_coordinates(src, dst, rev, perm):
+    """The graph in CSR-row coordinates (row i = edge perm[i]; what the fused forward's edge tensors
+    use): ``inv`` (edge -> row), ``srcp/dstp`` (atoms of row i), ``revp`` (row of the reverse edge)."""
+    src, dst, rev, perm = (np.asarray(a, dtype=np.int64) for a in (src, dst, rev, perm))
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    return dict(inv=inv, srcp=src[perm], dstp=dst[perm], revp=inv[rev[perm]])
+
+
+def tile_tables(row_ptr, n_edges, n_slots, bm=48, max_deg_supported=24):
+    """Row tiles of WHOLE atoms for the fused contraction (restates csrc/dmpnn_prepare.hip
+    ``tile_geom`` / ``write_tiles``): nominal stride ``b0 = bm - maxdeg + 1``; atom ``v`` belongs to
+    tile ``min(row_ptr[v] // b0, n_tiles - 1)``; a tile therefore spans at most ``bm`` rows.
+    Returns (tile_row[n_slots + 2], tile_atom[n_slots + 2], n_tiles, b0)."""
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    n_atoms = len(row_ptr) - 1
+    deg = np.diff(row_ptr)
+    maxdeg = int(deg.max()) if n_atoms else 0
+    md = max(maxdeg, 1)
+    b0 = bm - md + 1
+    n_tiles = 0 if (md > max_deg_supported or n_edges == 0) else -(-n_edges // b0)
+    tile_row = np.full(n_slots + 2, n_edges, dtype=np.int64)
+    tile_atom = np.full(n_slots + 2, n_atoms, dtype=np.int64)
+    if n_tiles:
+        t_of = np.minimum(row_ptr[:-1] // b0, n_tiles - 1)
+        for t in range(n_tiles):
+            atoms = np.flatnonzero(t_of >= t)
+            if len(atoms):
+                tile_atom[t] = atoms[0]
+                tile_row[t] = row_ptr[atoms[0]]
+    return tile_row, tile_atom, n_tiles, b0
+
+
 def segment_sum_csr(H: np.ndarray, row_ptr: np.ndarray, perm: np.ndarray) -> np.ndarray:
     """S[v] = sum of H[perm[row_ptr[v]:row_ptr[v+1]]] taken left to right in float32."""
     n_atoms = len(row_ptr) - 1

@@ -38,3 +38,18 @@ print("K0 plan (512 mols):", round(t_ms(fn) * 1e3, 2), "us")
 H = torch.randn(plan.n_edges, 300, device=dev); Mo = torch.empty_like(H)
 print("K2 message:", round(t_ms(lambda: engine.message(plan, H, out=Mo)) * 1e3, 2), "us")
 print("K4 aggregate:", round(t_ms(lambda: engine.aggregate(plan, H)) * 1e3, 2), "us")
+# fused route pieces
+H0 = torch.randn(plan.n_edges, 300, device=dev); Wh = torch.randn(300, 300, device=dev) * 0.05
+Mn = torch.empty_like(H); Mv = torch.empty(plan.n_atoms, 300, device=dev)
+print("fused update (K3+K2):", round(t_ms(lambda: engine.update_fused(plan, H, H0, Wh, M_next=Mn)) * 1e3, 2), "us")
+print("fused update (K3+K4):", round(t_ms(lambda: engine.update_fused(plan, H, H0, Wh, want_M=False, want_Mv=True, Mv=Mv)) * 1e3, 2), "us")
+Wo = torch.randn(300, 372, device=dev) * 0.05; bo = torch.randn(300, device=dev)
+print("K5 finalize:", round(t_ms(lambda: engine.linear(bmg.V, Wo, bo, A2=Mv, act="relu")) * 1e3, 2), "us")
+import torch.nn as nn
+from chemprop_amd.nn import BondMessagePassing
+mp = BondMessagePassing().to(dev).eval()
+with torch.no_grad():
+    for fused in (None, False):
+        os.environ["DMPNN_GENERAL"] = "1" if fused is False else "0"
+        print("whole forward, eager,", "general" if fused is False else "fused", ":", round(t_ms(lambda: mp(bmg)) * 1e3, 2), "us")
+os.environ["DMPNN_GENERAL"] = "0"

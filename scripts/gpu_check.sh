@@ -1,7 +1,9 @@
 #!/bin/bash
-# One gpurun call: smoke, GPU parity tests, bench, rocprofv3 kernel stats.  Everything lands in gpurun_out/.
-# usage: gpurun --timeout 1500 -- 'bash scripts/gpu_check.sh [tag]'
+# One gpurun call: smoke, GPU parity tests, bench, probe, rocprofv3 kernel stats + PMC traffic passes.
+# Everything lands in gpurun_out/<tag>/.
+# usage: gpurun --timeout 1500 -- 'bash scripts/gpu_check.sh [tag] [quick]'
 TAG=${1:-r01}
+QUICK=${2:-full}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -9,19 +11,39 @@ cd $REPO
 export PYTHONUNBUFFERED=1
 echo "== smoke" | tee $OUT/summary.txt
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt
-tail -5 $OUT/smoke.log | tee -a $OUT/summary.txt
+tail -6 $OUT/smoke.log | tee -a $OUT/summary.txt
 echo "== pytest -m gpu" | tee -a $OUT/summary.txt
-timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/summary.txt
-tail -40 $OUT/pytest_gpu.log | tee -a $OUT/summary.txt
+timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; RC=$?; echo "pytest rc=$RC" | tee -a $OUT/summary.txt
+grep -v "^  File\|^Extension modules" $OUT/pytest_gpu.log | tail -40 | cut -c1-400 | tee -a $OUT/summary.txt
+if [ $RC -ne 0 ] && [ $RC -ne 1 ]; then
+  echo "== pytest crashed: traced re-run (kernel-by-kernel sync)" | tee -a $OUT/summary.txt
+  DMPNN_TRACE=1 timeout 600 python -m pytest tests -q -x -m gpu -p no:cacheprovider -s > $OUT/pytest_trace.log 2>&1
+  grep -v "^  File\|^Extension modules" $OUT/pytest_trace.log | grep -B2 -A12 "fault\|Abort\|error\|FAILED" | head -60 | cut -c1-300 | tee -a $OUT/summary.txt
+  grep "\[dmpnn\] launch" $OUT/pytest_trace.log | tail -5 | tee -a $OUT/summary.txt
+fi
+echo "== probe" | tee -a $OUT/summary.txt
+timeout 300 python scripts/gemm_probe.py > $OUT/probe.txt 2>&1; cat $OUT/probe.txt | tail -30 | tee -a $OUT/summary.txt
 echo "== bench" | tee -a $OUT/summary.txt
 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err | tee -a $OUT/summary.txt
+if [ "$QUICK" != "quick" ]; then
+echo "== bench train" | tee -a $OUT/summary.txt
+timeout 600 python bench.py --steps 100 --warmup 10 --mode train --no-cpu-baseline > $OUT/bench_train.json 2> $OUT/bench_train.err; echo "bench train rc=$?" | tee -a $OUT/summary.txt
+cut -c1-900 $OUT/bench_train.json | tee -a $OUT/summary.txt; tail -3 $OUT/bench_train.err | tee -a $OUT/summary.txt
+fi
 echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $OUT/prof_bench.json 2> $OUT/prof.err
 echo "rocprof rc=$?" | tee -a $OUT/summary.txt
-find $OUT/prof -name "*stats*" | head; 
-for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -25 $f | tee -a $OUT/summary.txt; done
+for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -16 $f | cut -c1-260 | tee -a $OUT/summary.txt; done
+if [ "$QUICK" != "quick" ]; then
+echo "== rocprofv3 PMC passes (separate runs, counters only)" | tee -a $OUT/summary.txt
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $OUT/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $OUT/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $OUT/pmc_sq -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $OUT/pmc_sq.log 2>&1
+cd $REPO
+python scripts/pmc_traffic.py $OUT | tee -a $OUT/summary.txt
+fi
 # keep the merge small
-find $OUT/prof -name "*.db" -size +20M -delete; find $OUT/prof -name "*trace.csv" -size +20M -delete
+find $OUT -name "*.db" -size +20M -delete; find $OUT -name "*trace.csv" -size +30M -delete
 echo "== done" | tee -a $OUT/summary.txt

@@ -28,13 +28,33 @@ def test_header_symbols_all_exported():
 
 def test_version_and_plan_bytes():
     lib = _lib.load()
-    assert lib.dmpnn_version() == 1
+    assert lib.dmpnn_version() == _lib.ABI_VERSION == 2
     assert lib.dmpnn_plan_bytes(0, 0) >= 64
     b = lib.dmpnn_plan_bytes(4319, 8328)
-    assert b % 16 == 0 and b >= 4 * (16 + 4 * 8328 + 2 * 4319)
-    off = (C.c_int64 * 5)()
+    assert b % 16 == 0 and b >= 4 * (16 + 9 * 8328 + 2 * 4319)
+    off = (C.c_int64 * _lib.PLAN_NOFFSETS)()
     assert lib.dmpnn_plan_layout(10, 20, off) == 0
-    assert list(off) == sorted(off) and all(o % 4 == 0 for o in off)
+    arrays = list(off)[:11]
+    assert arrays == sorted(arrays) and all(o % 4 == 0 for o in arrays)
+    assert off[11] >= (20 + 24) // 25  # tile slots cover the smallest nominal tile stride
+
+
+def test_can_fuse_is_a_shape_rule():
+    """dmpnn_forward_can_fuse inspects shapes / alignment only (no device access)."""
+    lib = _lib.load()
+    a = _lib.FwdArgs()
+    a.n_atoms, a.n_edges, a.d_v, a.d_e, a.d_h, a.depth = 100, 200, 72, 14, 300, 3
+    a.ldv, a.lde, a.ldh = 72, 14, 300
+    for f in ("V", "E", "W_i", "W_h", "H0", "Ms", "Mv"):
+        setattr(a, f, 4096)
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 1
+    a.flags = _lib.F_UNDIRECTED
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 0
+    a.flags = 0
+    a.d_h, a.ldh = 512, 512
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 0   # rows wider than one workgroup panel
+    a.d_h, a.ldh, a.d_e, a.lde = 300, 300, 13, 13
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 0   # odd feature width: 4-byte operand rows
 
 
 def test_argument_errors_are_codes_not_crashes():

@@ -1,0 +1,96 @@
+"""N > 1 path on CPU: world_size-2 gloo.  Sharding is by molecule, the forward needs no collective,
+and the ONE collective of a training step (flat gradient all-reduce) reproduces the single-process
+gradient of the union batch — because molecules are independent the gradient is additive."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from chemprop_amd import distributed as ddp
+from chemprop_amd import synth
+from chemprop_amd.data import BatchMolGraph
+from chemprop_amd.nn import BondMessagePassing
+from oracle import dmpnn_torch as ot
+
+
+def test_hash_partition_is_a_partition():
+    n, world = 1003, 8
+    shards = [ddp.hash_partition(n, r, world, equalize=False) for r in range(world)]
+    allidx = np.concatenate(shards)
+    assert len(allidx) == n and len(np.unique(allidx)) == n
+    sizes = [len(s) for s in shards]
+    assert max(sizes) - min(sizes) < 0.25 * n / world  # hash is well mixed
+    eq = [ddp.hash_partition(n, r, world) for r in range(world)]
+    assert len({len(s) for s in eq}) == 1 and len(eq[0]) == min(sizes)
+    # deterministic, sampler-independent
+    assert np.array_equal(ddp.hash_partition(n, 3, world), ddp.hash_partition(n, 3, world))
+    with pytest.raises(ValueError):
+        ddp.hash_partition(10, 8, 8)
+
+
+def test_weighted_partition_balances_edges():
+    mgs = synth.random_molgraphs(400, "zinc", seed=4)
+    w = [m.edge_index.shape[1] for m in mgs]
+    loads = []
+    for r in range(8):
+        idx = ddp.hash_partition(len(mgs), r, 8, equalize=False, weights=w)
+        loads.append(sum(w[i] for i in idx))
+    assert (max(loads) - min(loads)) / np.mean(loads) < 0.05
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_mols, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    mgs = synth.random_molgraphs(n_mols, "qm9", seed=0)
+    torch.manual_seed(100 + rank)  # deliberately different initial weights per rank ...
+    mp_ = BondMessagePassing(d_h=48)
+    ddp.broadcast_params(mp_)      # ... made identical by the broadcast
+    idx = ddp.hash_partition(n_mols, rank, world, equalize=False)
+    bmg = BatchMolGraph([mgs[i] for i in idx])
+    w = ot.MPWeights(mp_.W_i.weight, mp_.W_h.weight, mp_.W_o.weight, mp_.W_o.bias)
+    out = ot.forward_bmg(bmg, w, depth=mp_.depth)  # CPU stand-in for the engine (it has no CPU path)
+    # per-molecule cotangent so the union loss is well defined whatever the shard
+    g = torch.stack([torch.full((48,), float(i % 7) - 3.0) for i in idx])[bmg.batch]
+    (out * g).sum().backward()
+    ddp.allreduce_grads(list(mp_.parameters()))
+    torch.save({k: p.grad.clone() for k, p in mp_.named_parameters()} | {"w0": mp_.W_h.weight.detach().clone()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_union_batch(tmp_path):
+    world, n_mols = 2, 24
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_mols, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k  # replicas agree bit-for-bit after the all-reduce
+    # single-process reference on the union batch, with rank 0's (broadcast) weights
+    mgs = synth.random_molgraphs(n_mols, "qm9", seed=0)
+    torch.manual_seed(100)
+    ref = BondMessagePassing(d_h=48)
+    assert torch.equal(ref.W_h.weight, r0["w0"])
+    bmg = BatchMolGraph(mgs)
+    w = ot.MPWeights(ref.W_i.weight, ref.W_h.weight, ref.W_o.weight, ref.W_o.bias)
+    out = ot.forward_bmg(bmg, w, depth=ref.depth)
+    g = torch.stack([torch.full((48,), float(i % 7) - 3.0) for i in range(n_mols)])[bmg.batch]
+    (out * g).sum().backward()
+    for k, p in ref.named_parameters():
+        err = float((p.grad - r0[k]).abs().max() / max(1.0, float(p.grad.abs().max())))
+        assert err <= 1e-5, (k, err)

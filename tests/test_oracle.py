@@ -81,6 +81,37 @@ def test_segment_ops_are_bit_exact(golden):
             assert np.array_equal(onp.message_atom_form(H, rev, row_ptr, perm), M_edge)
 
 
+def test_row_coordinate_form_is_the_same_function(golden):
+    """The fused forward keeps edge tensors in CSR-row order and emits, from the epilogue of the
+    kernel that produced H, ``M[revp[r]] = S[dstp[r]] - H[r]``.  On every symmetric golden graph that
+    is bit-for-bit ``M1[perm]`` of the executed reference; the row tiles partition whole atoms."""
+    src, dst = golden["edge_index"]
+    rev = golden["rev_edge_index"]
+    nV = golden["V"].shape[0]
+    row_ptr, perm = onp.build_csr(dst, nV)
+    rc = onp.row_coordinates(src, dst, rev, perm)
+    E = len(perm)
+    assert np.array_equal(rc["dstp"], np.repeat(np.arange(nV), np.diff(row_ptr)))
+    n_slots = (E + 24) // 25 + 1
+    tile_row, tile_atom, n_tiles, b0 = onp.tile_tables(row_ptr, E, n_slots)
+    maxdeg = int(np.diff(row_ptr).max()) if E else 0
+    assert (n_tiles == 0) == (E == 0 or maxdeg > 24)
+    if n_tiles:
+        assert tile_row[0] == 0 and tile_atom[0] == 0 and tile_row[n_tiles] == E and tile_atom[n_tiles] == nV
+        assert (np.diff(tile_row[:n_tiles + 1]) <= 48).all()
+        assert np.array_equal(tile_row[:n_tiles + 1], row_ptr[tile_atom[:n_tiles + 1]])
+    if "M1" not in golden or not onp.graph_is_symmetric(src, dst, rev):
+        return
+    act = golden.cfg["activation"]
+    if act not in ("relu", "leakyrelu"):
+        return
+    Y = onp._act(act, golden["H0"])[perm]                      # rows
+    S = onp.segment_sum_csr(Y, row_ptr, np.arange(E))          # contiguous rows per atom
+    M_rows = np.empty_like(Y)
+    M_rows[rc["revp"]] = S[rc["dstp"]] - Y
+    assert np.array_equal(M_rows, golden["M1"][perm])
+
+
 def test_torch_oracle_gradients_match_golden(golden):
     w, w_t = _weights_t(golden)
     params = {}

@@ -37,7 +37,18 @@ def test_plan_is_bit_exact(golden, gpu_device):
     assert np.array_equal(a["perm"], perm)
     assert bool(a["hdr"][0] & 1) == (not onp.graph_is_symmetric(src, dst, rev))
     assert not (a["hdr"][0] & 2)
-    assert a["hdr"][1] == (np.diff(row_ptr).max() if len(perm) else 0)
+    maxdeg = int(np.diff(row_ptr).max()) if len(perm) else 0
+    assert a["hdr"][1] == maxdeg
+    assert bool(a["hdr"][0] & 4) == (maxdeg > 24)
+    # CSR-row coordinates and the row tiles of whole atoms (fused forward)
+    rc = onp.row_coordinates(src, dst, rev, perm)
+    for k in ("inv", "srcp", "dstp", "revp"):
+        assert np.array_equal(a[k], rc[k]), k
+    n_slots = len(a["tile_row"]) - 2
+    tile_row, tile_atom, n_tiles, b0 = onp.tile_tables(row_ptr, len(perm), n_slots)
+    assert a["hdr"][4] == n_tiles and (n_tiles == 0 or a["hdr"][5] == b0)
+    assert np.array_equal(a["tile_row"], tile_row) and np.array_equal(a["tile_atom"], tile_atom)
+    assert n_tiles <= n_slots and (np.diff(tile_row) <= 48).all() and (np.diff(tile_row) >= 0).all()
 
 
 def test_message_kernel_bit_exact(golden, gpu_device):
@@ -100,6 +111,54 @@ def test_forward_matches_executed_reference(golden, gpu_device):
     # forward must not mutate the batch (tests/integration/test_regression_mol.py:217-226)
     for a, b in zip(before, [bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index]):
         assert torch.equal(a, b)
+
+
+def _engine_forward(golden, dev, fused, keep=False):
+    from chemprop_amd import engine
+    from chemprop_amd.nn import classify_activation
+
+    mp = golden.module(dev)
+    bmg = golden.bmg(dev)
+    plan = engine.GraphPlan.from_bmg(bmg)
+    act, slope, slope_t = classify_activation(mp.tau)
+    V_d = torch.from_numpy(golden["V_d"]).to(dev) if "V_d" in golden else None
+    has_vd = mp.W_d is not None and V_d is not None
+    with torch.no_grad():
+        out, st = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias,
+                                 mp.W_i.bias, mp.W_h.bias, mp.W_d.weight if has_vd else None,
+                                 mp.W_d.bias if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
+                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=keep, fused=fused)
+    return plan, out, st
+
+
+def test_fused_route_is_bit_identical_to_general_route(golden, gpu_device):
+    """The fused route (CSR-row order, segment sums in the contraction epilogues) performs the same
+    fp32 operations in the same order as the general route: outputs must agree BIT FOR BIT, and the
+    kept intermediates are the general route's rows permuted by ``perm``."""
+    if golden.cfg.get("undirected") or golden.cfg["d_h"] % 4 or golden.cfg["d_h"] > 320:
+        pytest.skip("fused route does not apply (undirected / d_h)")
+    if str(golden.cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
+        pytest.skip("custom activation: rows route")
+    plan, out_g, st_g = _engine_forward(golden, gpu_device, fused=False, keep=True)
+    if not plan.fusable():
+        plan2, out_f, _ = _engine_forward(golden, gpu_device, fused=True)
+        assert torch.isnan(out_f).all(), "a graph the fused tiling cannot hold must come back as NaN, loudly"
+        return
+    plan, out_f, st_f = _engine_forward(golden, gpu_device, fused=True, keep=True)
+    assert st_f.fused and not st_g.fused
+    assert torch.equal(out_f, out_g)
+    assert parity_err(out_f.cpu().numpy(), golden["out"]) <= TOL
+    if plan.n_edges:
+        perm = plan.perm64
+        assert torch.equal(st_f.H0, st_g.H0[perm])
+        d = golden.cfg["depth"]
+        for t in range(d - 1):
+            assert torch.equal(st_f.Ms[t], st_g.Ms[t][perm]), f"M^({t + 1})"
+            assert torch.equal(st_f.Hs[t], st_g.Hs[t][perm]), f"H^({t + 1})"
+    assert torch.equal(st_f.Mv, st_g.Mv)
+    # inference variant (no H stores, two ping-pong message slots) gives the same output
+    _, out_i, st_i = _engine_forward(golden, gpu_device, fused=True, keep=False)
+    assert torch.equal(out_i, out_f)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (16, 64, 32), (33, 300, 300), (257, 300, 86),
