@@ -79,7 +79,7 @@ int pick_wn(int64_t N) {
 int pick_rt(int64_t M, int64_t n_col_blocks) {
     int best = 3;
     double best_cost = 1e300;
-    for (int rt : {3, 1}) {
+    for (int rt : {3, 2, 1}) {
         const int64_t tiles = ((M + 16 * rt - 1) / (16 * rt)) * n_col_blocks;
         const int64_t rounds = (tiles + 255) / 256;
         const double cost = (double)rounds * (rt + 0.3);
@@ -181,7 +181,8 @@ int launch_linear_ex(const dmpnn_gemm_args& a0, const GemmExtra& x, hipStream_t 
     if (x.tile_row) { g.tile_row = x.tile_row; }
     const int wn = pick_wn(a.N);
     const int64_t ncb = (a.N + 64 * wn - 1) / (64 * wn);
-    const int rt = x.tile_row ? 3 : pick_rt(a.M, ncb);
+    int rt = x.tile_row ? 3 : pick_rt(a.M, ncb);
+    if (rt == 2 && G != 4) rt = 3;  // 32-row panels are only built for the 16-byte operand path
     const int n_tiles = x.tile_row ? x.n_tiles : (int)((a.M + 16 * rt - 1) / (16 * rt));
     // variant: 0 = G4 single operand, 1 = G4 two operands, 2 = G2 (two-operand build), 3 = G1 (two-operand build)
     const int var = G == 4 ? (has_a2 ? 1 : 0) : (G == 2 ? 2 : 3);
@@ -193,6 +194,11 @@ int launch_linear_ex(const dmpnn_gemm_args& a0, const GemmExtra& x, hipStream_t 
     case RT_ * 100 + WN_ * 10 + 2: return gemm::launch_gemm<RT_, WN_, 2, true, gemm::EPI_PLAIN>(g, n_tiles, s);        \
     case RT_ * 100 + WN_ * 10 + 3: return gemm::launch_gemm<RT_, WN_, 1, true, gemm::EPI_PLAIN>(g, n_tiles, s);
         PLAIN_CASES(1, 1) PLAIN_CASES(1, 2) PLAIN_CASES(1, 4) PLAIN_CASES(1, 5)
+#define PLAIN_G4(RT_, WN_)                                                                                           \
+    case RT_ * 100 + WN_ * 10 + 0: return gemm::launch_gemm<RT_, WN_, 4, false, gemm::EPI_PLAIN>(g, n_tiles, s);     \
+    case RT_ * 100 + WN_ * 10 + 1: return gemm::launch_gemm<RT_, WN_, 4, true, gemm::EPI_PLAIN>(g, n_tiles, s);
+        PLAIN_G4(2, 1) PLAIN_G4(2, 2) PLAIN_G4(2, 4) PLAIN_G4(2, 5)
+#undef PLAIN_G4
         PLAIN_CASES(3, 1) PLAIN_CASES(3, 2) PLAIN_CASES(3, 4) PLAIN_CASES(3, 5)
 #undef PLAIN_CASES
     }

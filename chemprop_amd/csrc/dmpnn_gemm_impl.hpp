@@ -30,6 +30,8 @@
 //     (bias + residual + tau, coalesced 16-byte stores) -> optional segment pass from LDS.
 #pragma once
 
+#include <type_traits>
+
 #include "dmpnn_common.hpp"
 
 namespace dmpnn {
@@ -127,8 +129,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmK& g, float* Ct, int rs,
         const int it = tid + kThreads * j;
         const int r = it / QN, q = it - r * QN;  // QN is a compile-time constant
         z[j] = *reinterpret_cast<const float4*>(Ct + r * LDC + 4 * q);
-        const float4 c = cadd_pref[j];
         if (has_cadd) {  // residual added AFTER the contraction: H0 + W_h(M)   (base.py:141)
+            const float4 c = cadd_pref[j];
             z[j].x = c.x + z[j].x; z[j].y = c.y + z[j].y; z[j].z = c.z + z[j].z; z[j].w = c.w + z[j].w;
         }
         if (poison) z[j] = make_float4(nanv, nanv, nanv, nanv);
@@ -213,15 +215,19 @@ __global__ __launch_bounds__(kThreads) void k_gemm(GemmK g) {
     // back to back instead of one load + wait per uniform branch)
     unsigned offA1[SLOTS_A], offA2[SLOTS_A], offB[SLOTS_B];
     {
-        const int* gp1 = gat1 ? g.gather1 : reinterpret_cast<const int*>(g.W);
-        const int* gp2 = gat2 ? g.gather2 : reinterpret_cast<const int*>(g.W);
         int i1[SLOTS_A], i2[SLOTS_A];
 #pragma unroll
-        for (int j = 0; j < SLOTS_A; ++j) {
-            const int r = (tid + kThreads * j) >> 3;
-            const bool ok = r < BM && r < nrows;
-            i1[j] = gp1[(ok && gat1) ? rs + r : 0];
-            i2[j] = HAS_A2 ? gp2[(ok && gat2) ? rs + r : 0] : 0;
+        for (int j = 0; j < SLOTS_A; ++j) { i1[j] = 0; i2[j] = 0; }
+        if (gat1 || gat2) {  // ONE uniform branch around the whole batch of index loads
+            const int* gp1 = gat1 ? g.gather1 : g.gather2;
+            const int* gp2 = gat2 ? g.gather2 : g.gather1;
+#pragma unroll
+            for (int j = 0; j < SLOTS_A; ++j) {
+                const int r = (tid + kThreads * j) >> 3;
+                const bool ok = r < BM && r < nrows;
+                i1[j] = gp1[ok ? rs + r : 0];
+                i2[j] = HAS_A2 ? gp2[ok ? rs + r : 0] : 0;
+            }
         }
 #pragma unroll
         for (int j = 0; j < SLOTS_A; ++j) {
@@ -317,10 +323,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm(GemmK g) {
         }
     }
 
-    // residual tile prefetch registers (filled during the last chunk's MFMAs)
+    // residual tile prefetch registers (filled while the LAST chunk is contracted)
     float4 cadd_pref[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) cadd_pref[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool has_cadd = g.Cadd != nullptr;
     const rsrc_t rC = has_cadd ? make_rsrc(g.Cadd + (int64_t)rs * g.ldcadd, clamp_bytes(((int64_t)nrows * g.ldcadd) * 4)) : rW;
     auto load_cadd = [&]() {
@@ -340,51 +344,110 @@ __global__ __launch_bounds__(kThreads) void k_gemm(GemmK g) {
         }
     };
 
-    // ---- pipeline prologue ----
-    load_chunk(0);
-    store_chunk(0);
-    if (n_chunks > 1) load_chunk(1);
-    else if (has_cadd) load_cadd();
-    __syncthreads();
-
-    for (int c = 0; c < n_chunks; ++c) {
-        const int cur = c & 1;
-        const float* Ac = As + cur * BM * BKP;
-        const float* Bc = Bs + cur * BN * BKP + wave * (16 * WN) * BKP;
-        float af[RT][8], bf[WN][8];
+    // fragments: lane (li, lg) holds k = 8*lg .. 8*lg+7 of row li of every 16-row tile; two register sets,
+    // the set of chunk c+1 is read from LDS while the second half of chunk c is contracted
+    auto read_frags = [&](int slot, float (&fa)[RT][8], float (&fb)[WN][8]) {
+        const float* Ac = As + slot * BM * BKP;
+        const float* Bc = Bs + slot * BN * BKP + wave * (16 * WN) * BKP;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const float* p = Ac + (rt * 16 + li) * BKP + lg * 8;
             const float4 t0 = *reinterpret_cast<const float4*>(p);
             const float4 t1 = *reinterpret_cast<const float4*>(p + 4);
-            af[rt][0] = t0.x; af[rt][1] = t0.y; af[rt][2] = t0.z; af[rt][3] = t0.w;
-            af[rt][4] = t1.x; af[rt][5] = t1.y; af[rt][6] = t1.z; af[rt][7] = t1.w;
+            fa[rt][0] = t0.x; fa[rt][1] = t0.y; fa[rt][2] = t0.z; fa[rt][3] = t0.w;
+            fa[rt][4] = t1.x; fa[rt][5] = t1.y; fa[rt][6] = t1.z; fa[rt][7] = t1.w;
         }
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) {
             const float* p = Bc + (ct * 16 + li) * BKP + lg * 8;
             const float4 t0 = *reinterpret_cast<const float4*>(p);
             const float4 t1 = *reinterpret_cast<const float4*>(p + 4);
-            bf[ct][0] = t0.x; bf[ct][1] = t0.y; bf[ct][2] = t0.z; bf[ct][3] = t0.w;
-            bf[ct][4] = t1.x; bf[ct][5] = t1.y; bf[ct][6] = t1.z; bf[ct][7] = t1.w;
+            fb[ct][0] = t0.x; fb[ct][1] = t0.y; fb[ct][2] = t0.z; fb[ct][3] = t0.w;
+            fb[ct][4] = t1.x; fb[ct][5] = t1.y; fb[ct][6] = t1.z; fb[ct][7] = t1.w;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // staging traffic of the following chunks, issued in the shadow of this chunk's MFMAs
-        if (c + 1 < n_chunks) store_chunk(cur ^ 1);          // uniform branches around WHOLE blocks only
-        if (c + 2 < n_chunks) load_chunk(c + 2);
-        else if (c + 2 == n_chunks && has_cadd) load_cadd();  // = while the last chunk is contracted
-        // q outermost: RT*WN independent accumulators between two MFMAs on the same one
-        // (dependent-accumulator latency of 16x16x4 f32 is 40 cycles vs 32-cycle issue).
+    };
+    // q outermost: RT*WN independent accumulators between two MFMAs on the same one
+    // (dependent-accumulator latency of 16x16x4 f32 is 40 cycles vs 32-cycle issue).
+    auto mfma_half = [&](int q0, const float (&fa)[RT][8], const float (&fb)[WN][8]) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = q0; q < q0 + 4; ++q)
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][q], bf[ct][q], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rt][q], fb[ct][q], acc[rt][ct], 0, 0, 0);
+    };
+
+    // One k-chunk.  At entry: (fa, fb) hold chunk c; the staging registers hold chunk c+1 (if any).
+    //   [ds_write chunk c+1 -> LDS[(c+1)&1]] [global loads chunk c+2 -> regs]   <- issued between the
+    //   first-half MFMAs (one per MFMA: the matrix pipe never waits for the staging traffic)
+    //   barrier; ds_read fragments(c+1) -> (ga, gb);  second-half MFMAs cover the LDS latency
+    // HAS_NEXT / HAS_NEXT2 are compile-time so each variant is one straight-line basic block.
+    constexpr int N_STAGE_LOADS = (SLOTS_A * (HAS_A2 ? 2 : 1) + SLOTS_B) * NS;
+    constexpr int N_STAGE_WRITES = SLOTS_A + SLOTS_B;
+    constexpr int N_HALF = 4 * RT * WN;
+    auto chunk = [&](auto has_next, auto has_next2, auto is_last, int c, float (&fa)[RT][8], float (&fb)[WN][8],
+                     float (&ga)[RT][8], float (&gb)[WN][8]) {
+        constexpr bool NEXT = decltype(has_next)::value, NEXT2 = decltype(has_next2)::value, LAST = decltype(is_last)::value;
+        if constexpr (NEXT) store_chunk((c + 1) & 1);
+        if constexpr (NEXT2) load_chunk(c + 2);
+        if constexpr (LAST) {
+            if (has_cadd) load_cadd();
+        }
+        mfma_half(0, fa, fb);
+        if constexpr (NEXT) {
+            constexpr int NW = N_STAGE_WRITES < N_HALF ? N_STAGE_WRITES : N_HALF;
+            constexpr int NL = NEXT2 ? (N_STAGE_LOADS < N_HALF - NW ? N_STAGE_LOADS : N_HALF - NW) : 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 DS write
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if constexpr (NEXT) {
+            __syncthreads();  // chunk c+1 is in LDS for every wave
+            read_frags((c + 1) & 1, ga, gb);
+        }
+        mfma_half(4, fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    // ---- pipeline prologue ----
+    float f0a[RT][8], f0b[WN][8], f1a[RT][8], f1b[WN][8];
+    load_chunk(0);
+    store_chunk(0);
+    if (n_chunks > 1) load_chunk(1);
+    __syncthreads();
+    read_frags(0, f0a, f0b);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // steady state: chunks with two successors, two per trip (static fragment-set indices)
+    int c = 0;
+    for (; c + 3 < n_chunks; c += 2) {
+        chunk(T_{}, T_{}, F_{}, c, f0a, f0b, f1a, f1b);
+        chunk(T_{}, T_{}, F_{}, c + 1, f1a, f1b, f0a, f0b);
     }
+    // tail: c is even here, 1..3 chunks left
+    const int left = n_chunks - c;
+    if (left == 3) {
+        chunk(T_{}, T_{}, F_{}, c, f0a, f0b, f1a, f1b);
+        chunk(T_{}, F_{}, F_{}, c + 1, f1a, f1b, f0a, f0b);
+        chunk(F_{}, F_{}, T_{}, c + 2, f0a, f0b, f1a, f1b);
+    } else if (left == 2) {
+        chunk(T_{}, F_{}, F_{}, c, f0a, f0b, f1a, f1b);
+        chunk(F_{}, F_{}, T_{}, c + 1, f1a, f1b, f0a, f0b);
+    } else {
+        chunk(F_{}, F_{}, T_{}, c, f0a, f0b, f1a, f1b);
+    }
+    __syncthreads();  // every wave is done with the staging ring before it is reused as the output tile
 
     // ---- epilogue: accumulators -> LDS tile (reuses the staging ring; the loop's last barrier
     // guarantees every fragment read is done) ----

@@ -12,5 +12,9 @@ DMPNN_DEFINE_GEMM(3, 1, 4, false, EPI_PLAIN)
 DMPNN_DEFINE_GEMM(3, 2, 4, false, EPI_PLAIN)
 DMPNN_DEFINE_GEMM(3, 4, 4, false, EPI_PLAIN)
 DMPNN_DEFINE_GEMM(3, 5, 4, false, EPI_PLAIN)
+DMPNN_DEFINE_GEMM(2, 1, 4, false, EPI_PLAIN)
+DMPNN_DEFINE_GEMM(2, 2, 4, false, EPI_PLAIN)
+DMPNN_DEFINE_GEMM(2, 4, 4, false, EPI_PLAIN)
+DMPNN_DEFINE_GEMM(2, 5, 4, false, EPI_PLAIN)
 }  // namespace gemm
 }  // namespace dmpnn

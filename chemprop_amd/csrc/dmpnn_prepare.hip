@@ -242,12 +242,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     // phase 1: ONE batched read of the int64 arrays (all loads of a thread in flight together)
     int64_t s64[kSmallEPT], d64[kSmallEPT], r64[kSmallEPT];
 #pragma unroll
-    for (int j = 0; j < kSmallEPT; ++j) {
-        const int e = tid + kSmallThreads * j;
-        const int ec = e < nE ? e : 0;
-        s64[j] = edge_index[ec];
-        d64[j] = edge_index[(int64_t)nE + ec];
-        r64[j] = rev64[ec];
+    for (int j = 0; j < kSmallEPT; ++j) { s64[j] = 0; d64[j] = 0; r64[j] = 0; }
+    if (nE > 0) {  // uniform: an edgeless batch has no (possibly null) index arrays to read
+#pragma unroll
+        for (int j = 0; j < kSmallEPT; ++j) {
+            const int e = tid + kSmallThreads * j;
+            const int ec = e < nE ? e : 0;
+            s64[j] = edge_index[ec];
+            d64[j] = edge_index[(int64_t)nE + ec];
+            r64[j] = rev64[ec];
+        }
     }
     __syncthreads();  // cnt zeroed
     int bad = 0;
