@@ -1,0 +1,78 @@
+"""Drop-in for an installed chemprop: a subclass of the REAL ``chemprop.nn.BondMessagePassing`` that
+overrides ``forward`` only.  Parameters, ``hparams`` (``cls`` is reported as the
+reference class so a saved checkpoint loads in stock chemprop, ``models/model.py:267-271``),
+``state_dict`` keys, ``output_dim``, ``graph_transform`` / ``V_d_transform`` and every attribute the
+CLI reads (``cli/predict.py:256-263``, ``cli/train.py:943-969,1826-1828``) are inherited untouched, so
+Lightning training / evaluation and the CLI run as they are.
+
+chemprop (with rdkit, lightning, ...) is NOT importable in the build container; this module imports
+it lazily and raises a clear error when it is missing.  The parity tests therefore exercise the
+state-dict-compatible mirror ``chemprop_amd.nn.BondMessagePassing`` against the executed reference.
+
+    from chemprop_amd.integration import HipBondMessagePassing, accelerate
+    mp = HipBondMessagePassing(d_h=300, depth=3)            # instead of chemprop.nn.BondMessagePassing
+    model = chemprop.models.MPNN(mp, agg, ffn, ...)          # everything else unchanged
+    accelerate(existing_model)                               # or: swap the block of a built / loaded model
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+from torch import Tensor
+
+from .nn import bond_message_passing_forward
+
+_cls_cache = None
+
+
+def _reference_class():
+    try:
+        from chemprop.nn import BondMessagePassing as Ref  # noqa: WPS433
+    except Exception as e:  # pragma: no cover - chemprop is absent from the build container
+        raise ImportError(
+            "chemprop_amd.integration needs an importable `chemprop` (with rdkit / lightning); "
+            "without it use the state-dict-compatible mirror chemprop_amd.nn.BondMessagePassing") from e
+    return Ref
+
+
+def hip_bond_message_passing_class():
+    """Build (once) ``class HipBondMessagePassing(chemprop.nn.BondMessagePassing)``."""
+    global _cls_cache
+    if _cls_cache is not None:
+        return _cls_cache
+    Ref = _reference_class()
+
+    class HipBondMessagePassing(Ref):  # type: ignore[misc, valid-type]
+        """``chemprop.nn.BondMessagePassing`` whose ``forward`` (base.py:196-212) runs on the MI355X
+        HIP kernels.  Raises on non-HIP tensors: there is no CPU fallback inside the engine — keep the
+        stock class for CPU runs."""
+
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.hparams["cls"] = Ref  # checkpoints stay loadable by stock chemprop
+
+        def forward(self, bmg, V_d: Optional[Tensor] = None) -> Tensor:
+            return bond_message_passing_forward(self, bmg, V_d)
+
+    _cls_cache = HipBondMessagePassing
+    return HipBondMessagePassing
+
+
+def __getattr__(name):
+    if name == "HipBondMessagePassing":
+        return hip_bond_message_passing_class()
+    raise AttributeError(name)
+
+
+def accelerate(model):
+    """Swap the class of every ``BondMessagePassing`` block inside ``model`` (an ``MPNN``, a
+    ``MulticomponentMessagePassing`` or the block itself) for the HIP subclass, in place.  No
+    parameter is copied or re-created; optimizer state and checkpoints stay valid."""
+    Ref = _reference_class()
+    Hip = hip_bond_message_passing_class()
+    n = 0
+    for m in model.modules():
+        if type(m) is Ref:
+            m.__class__ = Hip
+            n += 1
+    return n
