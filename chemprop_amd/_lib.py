@@ -20,10 +20,10 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
-           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_backward.hip"]
-HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp"]
+           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_backward.hip"]
+HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp"]
 ABI_VERSION = 2
-PLAN_NOFFSETS = 12
+PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
 EXPORTS = [
@@ -36,6 +36,9 @@ EXPORTS = [
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
 F_UNDIRECTED = 1
 F_FUSED = 2
+F_MEGA = 4
+F_KEEP = 8
+PLAN_NOMEGA_MASK = 15  # ... | no piece tiles (a molecule larger than a tile)
 PLAN_NOFUSE_MASK = 7  # asymmetric | index out of range | in-degree > 24
 
 

@@ -63,6 +63,7 @@ int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t off[DMPNN_PLAN_N
     off[0] = L.src; off[1] = L.dst; off[2] = L.rev; off[3] = L.row_ptr; off[4] = L.perm;
     off[5] = L.inv; off[6] = L.srcp; off[7] = L.dstp; off[8] = L.revp;
     off[9] = L.tile_row; off[10] = L.tile_atom; off[11] = L.max_tiles;
+    off[12] = L.mtile_row; off[13] = L.mtile_atom; off[14] = L.max_mtiles;
     return DMPNN_OK;
 }
 
@@ -157,7 +158,7 @@ int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a) {
     if (!al_ptr(a->V, 8) || !al_ptr(a->E, 8) || !al_ptr(a->W_i, 8) || !al_ptr(a->W_h, 16)) return 0;
     if (!al_ptr(a->H0, 16) || !al_ptr(a->Ms, 16) || !al_ptr(a->Mv, 16) || (a->Hs && !al_ptr(a->Hs, 16))) return 0;
     if (a->n_atoms * a->ldv * 4 > 0x7FFFFFFF || a->n_edges * a->lde * 4 > 0x7FFFFFFF) return 0;
-    return 1;
+    return mega_shapes_ok(*a) ? 2 : 1;
 }
 
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
@@ -173,13 +174,13 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     DMPNN_CHECK_ARG(a->W_i && a->W_h && a->W_o && a->b_o, "forward: null weight");
     DMPNN_CHECK_ARG(a->ldh >= h && a->ldv >= dv && a->lde >= de, "forward: leading dimension too small");
     DMPNN_CHECK_ARG(nV == 0 || (a->V && a->Mv && a->out), "forward: null V / Mv / out");
-    DMPNN_CHECK_ARG(nE == 0 || (a->E && a->H0), "forward: null E / H0");
+    DMPNN_CHECK_ARG(nE == 0 || (a->E && (a->H0 || (a->flags & DMPNN_F_MEGA))), "forward: null E / H0");
     const bool has_vd = a->W_d != nullptr;
     DMPNN_CHECK_ARG(!has_vd || (a->d_vd > 0 && a->V_d && a->b_d && a->Hv && a->ldvd >= a->d_vd),
                     "forward: W_d given but V_d / b_d / Hv / d_vd missing");
     DMPNN_CHECK_ARG(a->ldout >= h + (has_vd ? a->d_vd : 0), "forward: ldout too small");
     const bool fused = a->flags & DMPNN_F_FUSED;
-    if (a->depth > 1 && nE > 0) {
+    if (a->depth > 1 && nE > 0 && !(a->flags & DMPNN_F_MEGA)) {
         DMPNN_CHECK_ARG(a->Ms && a->n_mslots >= 1, "forward: missing Ms workspace");
         DMPNN_CHECK_ARG(fused || (a->Hs && a->n_hslots >= 1), "forward: missing Hs workspace");
     }
@@ -195,6 +196,25 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
                         "(d_h %% 4, d_h <= 320, even d_v / d_e, directed); call dmpnn_forward_can_fuse first");
         DMPNN_CHECK_ARG(a->depth <= 2 || a->n_mslots >= 2, "forward(fused): depth > 2 needs at least two message slots");
         const PlanLayout L = plan_layout(nV, nE);
+        if (a->flags & DMPNN_F_MEGA) {
+            // ---- whole forward of every tile of whole molecules in one launch ----
+            DMPNN_CHECK_ARG(mega_shapes_ok(*a), "forward: DMPNN_F_MEGA given but the shapes do not allow it");
+            DMPNN_CHECK_ARG(!(a->flags & DMPNN_F_KEEP) || a->depth == 1 || nE == 0 ||
+                            (a->Hs && a->n_hslots >= a->depth - 1 && a->n_mslots >= a->depth - 1),
+                            "forward(mega, keep): needs depth-1 H and M slots");
+            if (nV > 0) DMPNN_TRY(launch_mega_forward(*a, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s));
+            if (has_vd) {
+                dmpnn_gemm_args g;
+                memset(&g, 0, sizeof(g));
+                g.M = nV; g.N = h + a->d_vd; g.K1 = h; g.K2 = a->d_vd;
+                g.A1 = a->Hv; g.lda1 = a->ldh;
+                g.A2 = a->V_d; g.lda2 = a->ldvd;
+                g.W = a->W_d; g.ldw = h + a->d_vd; g.bias = a->b_d;
+                g.C = a->out; g.ldc = a->ldout; g.act = DMPNN_ACT_NONE;
+                DMPNN_TRY(launch_linear(g, s));
+            }
+            return DMPNN_OK;
+        }
         GemmExtra x;
         memset(&x, 0, sizeof(x));
         x.seg = true;

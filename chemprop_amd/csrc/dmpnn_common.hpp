@@ -43,6 +43,7 @@ void count_launch(const char* name);
 //   hdr[16] | src[E] dst[E] rev[E] row_ptr[V+1] perm[E] cursor[V]          original edge ids
 //           | inv[E] srcp[E] dstp[E] revp[E] ident[E]                      CSR-row coordinates
 //           | tile_row[T+2] tile_atom[T+2]                                 row tiles of whole atoms
+//           | mtile_row[MT+2] mtile_atom[MT+2]                             row tiles of whole connected pieces
 // CSR-row coordinates: row i is the edge perm[i]; rows of one destination atom are contiguous and in
 // increasing edge id.  srcp/dstp/revp are src/dst/rev expressed in rows (revp[i] = inv[rev[perm[i]]]),
 // ident[i] = i.  The fused forward keeps every edge tensor in row order, so a row tile of the
@@ -50,12 +51,16 @@ void count_launch(const char* name);
 constexpr int kFusedBM = 48;        // rows of a fused tile (RT = 3)
 constexpr int kFusedMaxDeg = 24;    // largest in-degree the tiling supports ((BM + 1) / 2)
 constexpr int kFusedMinB0 = kFusedBM - kFusedMaxDeg + 1;  // 25: smallest nominal tile stride
+constexpr int kMegaBM = 48;         // rows of a piece tile (whole connected pieces = molecules)
+constexpr int kMegaBA = 32;         // atoms of a piece tile (rows of the finalize contraction, RT = 2)
 struct PlanLayout {
-    int64_t src, dst, rev, row_ptr, perm, cursor, inv, srcp, dstp, revp, ident, tile_row, tile_atom, words;
-    int64_t max_tiles;
+    int64_t src, dst, rev, row_ptr, perm, cursor, inv, srcp, dstp, revp, ident, tile_row, tile_atom, mtile_row, mtile_atom, words;
+    int64_t max_tiles, max_mtiles;
 };
 inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 inline int64_t fused_max_tiles(int64_t nE) { return (nE + kFusedMinB0 - 1) / kFusedMinB0 + 1; }
+// greedy packing: two consecutive piece tiles cannot be merged, so together they exceed a limit
+inline int64_t mega_max_tiles(int64_t nV, int64_t nE) { return 2 * (nE / kMegaBM + nV / kMegaBA) + 4; }
 inline PlanLayout plan_layout(int64_t nV, int64_t nE) {
     PlanLayout L;
     int64_t o = DMPNN_HDR_WORDS;
@@ -73,13 +78,18 @@ inline PlanLayout plan_layout(int64_t nV, int64_t nE) {
     L.max_tiles = fused_max_tiles(nE);
     L.tile_row = o; o += align4(L.max_tiles + 2);
     L.tile_atom = o; o += align4(L.max_tiles + 2);
+    L.max_mtiles = mega_max_tiles(nV, nE);
+    L.mtile_row = o; o += align4(L.max_mtiles + 2);
+    L.mtile_atom = o; o += align4(L.max_mtiles + 2);
     L.words = o;
     return L;
 }
 
-enum : int { PLAN_ASYMMETRIC = 1, PLAN_RANGE_ERROR = 2, PLAN_HUGE_DEGREE = 4 };
+enum : int { PLAN_ASYMMETRIC = 1, PLAN_RANGE_ERROR = 2, PLAN_HUGE_DEGREE = 4, PLAN_NO_PIECE_TILES = 8 };
 // graphs the fused (row-tiled) forward cannot represent: its kernels poison their output with NaN
 constexpr int kPlanNoFuse = PLAN_ASYMMETRIC | PLAN_RANGE_ERROR | PLAN_HUGE_DEGREE;
+// graphs the whole-forward tile kernel cannot take (a connected piece larger than a tile, or no piece tiles built)
+constexpr int kPlanNoMega = kPlanNoFuse | PLAN_NO_PIECE_TILES;
 
 // Device view of a plan (pointers into the blob).
 struct PlanView {
@@ -152,6 +162,9 @@ struct GemmExtra {
     const int* poison_flags; int poison_mask;   // plan header word 0 and the mask that makes the output NaN
 };
 int launch_linear_ex(const dmpnn_gemm_args& a, const GemmExtra& x, hipStream_t s);
+// whole-forward tile kernel (dmpnn_mega.hip): writes tau(W_o[V || Mv] + b_o) to out[ldout]
+bool mega_shapes_ok(const dmpnn_fwd_args& a);
+int launch_mega_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -14,6 +14,8 @@
 //     per-atom counters) in LDS — a 512-molecule QM9 batch (E ~ 9.6k, V ~ 4.6k) needs ~110 KB;
 //     global memory sees one batched read of the int64 arrays and one pass of int32 writes.
 //   * the general path: count | scan | fill | sort | inverse | rows+tiles, seven short launches.
+#include <limits.h>
+
 #include "dmpnn_common.hpp"
 
 namespace dmpnn {
@@ -207,10 +209,13 @@ __global__ void k_rows_tiles(int* __restrict__ plan, PlanLayout L, int nV, int n
         plan[L.ident + r] = r;
     }
     write_tiles(plan, L, plan + L.row_ptr, nV, nE, g, i, n_threads);
+    // piece tiles are built by the single-workgroup plan only (round 1): none here
+    for (int t = i; t < (int)L.max_mtiles + 2; t += n_threads) { plan[L.mtile_row + t] = nE; plan[L.mtile_atom + t] = nV; }
     if (i == 0) {
         plan[DMPNN_HDR_NTILES] = g.n_tiles;
         plan[DMPNN_HDR_TILE_STRIDE] = g.b0;
-        if (maxdeg > kFusedMaxDeg) atomicOr(&plan[DMPNN_HDR_FLAGS], PLAN_HUGE_DEGREE);
+        plan[DMPNN_HDR_NMTILES] = 0;
+        atomicOr(&plan[DMPNN_HDR_FLAGS], PLAN_NO_PIECE_TILES | (maxdeg > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0));
     }
 }
 
@@ -222,22 +227,141 @@ constexpr int kSmallItems = kSmallMaxAtoms / kSmallThreads;  // 6 counters per t
 constexpr int kSmallEPT = kSmallMaxEdges / kSmallThreads;    // 12 edges per thread at most
 typedef unsigned short u16;
 
+
+// In-place inclusive scan of a[0..n) (n <= kSmallItems * kSmallThreads) by the whole workgroup.
+// MAX = false: sum, MAX = true: max.  Ends with a barrier.
+template <bool MAX>
+__device__ __forceinline__ void block_scan_inclusive(int* a, int n, int* wave_tot, int tid) {
+    const int lane = tid & 63, wid = tid >> 6;
+    int v[kSmallItems];
+    const int i0 = tid * kSmallItems;
+    int run = MAX ? INT_MIN : 0;
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int x = (i0 + j < n) ? a[i0 + j] : (MAX ? INT_MIN : 0);
+        run = MAX ? max(run, x) : run + x;
+        v[j] = run;
+    }
+    int inc = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc = MAX ? max(inc, t) : inc + t;
+    }
+    __syncthreads();  // callers may still be reading wave_tot from a previous scan
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    int base = MAX ? INT_MIN : 0;
+    for (int w = 0; w < wid; ++w) base = MAX ? max(base, wave_tot[w]) : base + wave_tot[w];
+    const int prev = __shfl_up(inc, 1);
+    const int excl = lane == 0 ? base : (MAX ? max(base, prev) : base + prev);
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j)
+        if (i0 + j < n) a[i0 + j] = MAX ? max(excl, v[j]) : excl + v[j];
+    __syncthreads();
+}
+
+// ---- piece tiles: row tiles made of WHOLE connected pieces (molecules) --------------------------
+// A cut after atom v is safe when no edge joins atoms <= v with atoms > v; with atoms of a molecule
+// contiguous (data/collate.py:48-56) the cuts are the molecule boundaries (and fragment boundaries).
+// Consecutive pieces are packed greedily into tiles of <= kMegaBM rows and <= kMegaBA atoms; the chain
+// of tile starts is marked by pointer jumping (log2 V rounds) instead of a sequential walk.
+// X, Y: int scratch of nV + 2 entries each.  X enters holding maxnbr[v] = max(v, largest neighbour).
+// Returns the number of tiles, or -1 when a piece does not fit (tables are then emptied).
+__device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const PlanLayout& L, const int* rowp, int* X,
+                                                 int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid) {
+    int* mrow = plan + L.mtile_row;
+    int* matom = plan + L.mtile_atom;
+    const int slots = (int)L.max_mtiles + 2;
+    block_scan_inclusive<true>(X, nV, wave_tot, tid);          // X[v] = max neighbour index over atoms <= v
+    for (int u = tid; u < nV; u += kSmallThreads) Y[u] = (u == 0 || X[u - 1] == u - 1) ? u : 0;  // piece starts
+    __syncthreads();
+    block_scan_inclusive<true>(Y, nV, wave_tot, tid);          // Y[u] = last piece start <= u
+    // next tile start for every piece start
+    int nxt[kSmallItems];
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int v = tid * kSmallItems + j;
+        nxt[j] = nV;
+        if (v < nV && Y[v] == v) {
+            const int r0 = rowp[v];
+            int u = v + 1;  // u ends as the largest index with atoms(v..u-1) <= BA and rows <= BM
+            while (u < nV && u - v < kMegaBA && rowp[u + 1] - r0 <= kMegaBM) ++u;
+            if (rowp[u] - r0 > kMegaBM) u = v;  // the first atom alone is too large (cannot happen: deg <= 24)
+            const int cand = u >= nV ? nV : Y[u];  // back to the last safe cut
+            if (cand <= v) { atomicOr(bad_s, 1); nxt[j] = nV; }
+            else nxt[j] = cand;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int v = tid * kSmallItems + j;
+        if (v < nV) { X[v] = nxt[j]; Y[v] = (v == 0) ? 1 : 0; }  // X = jump pointer, Y = mark
+    }
+    if (tid == 0) { X[nV] = nV; Y[nV] = 0; }
+    __syncthreads();
+    for (int span = 1; span < nV; span <<= 1) {  // after k rounds every chain node at distance < 2^k is marked
+        int jj[kSmallItems];
+#pragma unroll
+        for (int j = 0; j < kSmallItems; ++j) {
+            const int v = tid * kSmallItems + j;
+            jj[j] = nV;
+            if (v < nV) {
+                const int t = X[v];
+                if (Y[v] && t < nV) Y[t] = 1;
+                jj[j] = X[t];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSmallItems; ++j) {
+            const int v = tid * kSmallItems + j;
+            if (v < nV) X[v] = jj[j];
+        }
+        __syncthreads();
+    }
+    // tile index = rank among the marked atoms
+    int mk[kSmallItems];
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int v = tid * kSmallItems + j;
+        mk[j] = v < nV ? Y[v] : 0;
+    }
+    block_scan_inclusive<false>(Y, nV, wave_tot, tid);
+    const int n_tiles = nV > 0 ? Y[nV - 1] : 0;
+    const bool bad = *bad_s != 0 || n_tiles > (int)L.max_mtiles;
+    if (bad) {
+        for (int t = tid; t < slots; t += kSmallThreads) { mrow[t] = nE; matom[t] = nV; }
+        return -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int v = tid * kSmallItems + j;
+        if (v < nV && mk[j]) { mrow[Y[v] - 1] = rowp[v]; matom[Y[v] - 1] = v; }
+    }
+    for (int t = n_tiles + tid; t < slots; t += kSmallThreads) { mrow[t] = nE; matom[t] = nV; }
+    return n_tiles;
+}
+
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* __restrict__ edge_index,
                                                                 const int64_t* __restrict__ rev64,
                                                                 int* __restrict__ plan, PlanLayout L, int nV, int nE) {
     extern __shared__ __attribute__((aligned(16))) int lds_i[];
-    // layout: cnt[nV] int | row0[nV + 1] int | dst16[nE] | rev16[nE] | perm16[nE] | inv16[nE]
+    // layout: cnt[nV + 2] int | row0[nV + 2] int | dst16[nE] | rev16[nE] | perm16[nE] | inv16[nE]
+    // (the piece-tile phase reuses cnt as X and the dead edge arrays as Y: the host sizes the edge
+    // region as max(8 nE, 4 (nV + 2)) bytes)
     int* cnt = lds_i;
-    int* rowp = lds_i + nV;
-    u16* dst16 = reinterpret_cast<u16*>(rowp + nV + 1);
+    int* rowp = lds_i + nV + 2;
+    u16* dst16 = reinterpret_cast<u16*>(rowp + nV + 2);
     u16* rev16 = dst16 + nE;
     u16* perm16 = rev16 + nE;
     u16* inv16 = perm16 + nE;
     __shared__ int wave_tot[kSmallThreads / 64];
-    __shared__ int flags_s, maxdeg_s;
+    __shared__ int flags_s, maxdeg_s, piece_bad_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < nV; i += kSmallThreads) cnt[i] = 0;
-    if (tid == 0) { flags_s = 0; maxdeg_s = 0; }
+    if (tid == 0) { flags_s = 0; maxdeg_s = 0; piece_bad_s = 0; }
 
     // phase 1: ONE batched read of the int64 arrays (all loads of a thread in flight together)
     int64_t s64[kSmallEPT], d64[kSmallEPT], r64[kSmallEPT];
@@ -374,9 +498,18 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     }
     const TileGeom g = tile_geom(maxdeg_s, nE);
     write_tiles(plan, L, rowp, nV, nE, g, tid, kSmallThreads);
+    // phase 7: piece tiles.  maxnbr from LDS only (src of row r = dst of the reverse edge on a symmetric graph)
+    for (int v = tid; v < nV; v += kSmallThreads) {
+        int m = v;
+        for (int r = rowp[v]; r < rowp[v + 1]; ++r) m = max(m, (int)dst16[rev16[perm16[r]]]);
+        cnt[v] = m;
+    }
+    __syncthreads();  // the edge arrays are dead from here on: Y overlays them
+    const int n_mtiles = build_piece_tiles(plan, L, rowp, cnt, reinterpret_cast<int*>(dst16), wave_tot, &piece_bad_s, nV, nE, tid);
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
-        if (tid == DMPNN_HDR_FLAGS) v = flags_s | (maxdeg_s > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0);
+        if (tid == DMPNN_HDR_FLAGS) v = flags_s | (maxdeg_s > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0);
+        if (tid == DMPNN_HDR_NMTILES) v = n_mtiles < 0 ? 0 : n_mtiles;
         if (tid == DMPNN_HDR_MAXDEG) v = maxdeg_s;
         if (tid == DMPNN_HDR_NATOMS) v = nV;
         if (tid == DMPNN_HDR_NEDGES) v = nE;
@@ -393,12 +526,13 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
     const int nV = (int)nV64, nE = (int)nE64;
     const PlanLayout L = plan_layout(nV, nE);
     if (nV <= kSmallMaxAtoms && nE <= kSmallMaxEdges) {
-        size_t lds = (size_t)(2 * nV + 1) * sizeof(int) + (size_t)4 * nE * sizeof(u16);
+        size_t edge_region = (size_t)4 * nE * sizeof(u16), y_region = (size_t)(nV + 2) * sizeof(int);
+        size_t lds = (size_t)(2 * nV + 4) * sizeof(int) + (edge_region > y_region ? edge_region : y_region);
         lds = (lds + 15) & ~size_t(15);
         if (lds < 16) lds = 16;
         static bool attr_set = false;
         if (!attr_set) {
-            const size_t max_lds = (size_t)(2 * kSmallMaxAtoms + 1) * sizeof(int) + (size_t)4 * kSmallMaxEdges * sizeof(u16) + 16;
+            const size_t max_lds = (size_t)(2 * kSmallMaxAtoms + 4) * sizeof(int) + (size_t)4 * kSmallMaxEdges * sizeof(u16) + 16;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_small),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
             if (e != hipSuccess) {

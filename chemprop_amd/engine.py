@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT, F_FUSED, F_UNDIRECTED, PLAN_NOFUSE_MASK, FwdArgs, GemmArgs
+from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_UNDIRECTED, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
 
 
 def _stream_ptr(device) -> int:
@@ -75,7 +75,8 @@ class GraphPlan:
         return dict(hdr=b[:16], src=cut(off[0], E), dst=cut(off[1], E), rev=cut(off[2], E),
                     row_ptr=cut(off[3], V + 1), perm=cut(off[4], E), inv=cut(off[5], E), srcp=cut(off[6], E),
                     dstp=cut(off[7], E), revp=cut(off[8], E), tile_row=cut(off[9], T + 2),
-                    tile_atom=cut(off[10], T + 2))
+                    tile_atom=cut(off[10], T + 2), mtile_row=cut(off[12], int(off[14]) + 2),
+                    mtile_atom=cut(off[13], int(off[14]) + 2))
 
     def flags(self) -> int:
         """Plan flag word (synchronises): bit0 asymmetric, bit1 index out of range, bit2 in-degree > 24."""
@@ -84,6 +85,11 @@ class GraphPlan:
     def fusable(self) -> bool:
         """True when the fused (row-tiled) forward represents this graph exactly (synchronises)."""
         return (self.flags() & PLAN_NOFUSE_MASK) == 0
+
+    def mega_ok(self) -> bool:
+        """True when every molecule fits a piece tile (<= 48 edge rows, <= 32 atoms): the whole-forward
+        tile kernel applies (synchronises)."""
+        return (self.flags() & PLAN_NOMEGA_MASK) == 0
 
     def _offsets(self):
         off = (C.c_int64 * _lib.PLAN_NOFFSETS)()
@@ -204,18 +210,25 @@ class ForwardState:
     """Workspace of one forward; kept alive for the backward pass when ``keep`` is set."""
 
     __slots__ = ("plan", "H0", "Hs", "Ms", "Mv", "Hv", "ldh", "n_hslots", "n_mslots", "out", "args", "refs", "dims",
-                 "fused")
+                 "fused", "route")
 
 
 def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o: Tensor, b_o: Tensor,
             b_i: Optional[Tensor] = None, b_h: Optional[Tensor] = None, W_d: Optional[Tensor] = None,
             b_d: Optional[Tensor] = None, V_d: Optional[Tensor] = None, depth: int = 3, act: str = "relu",
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
-            keep: bool = False, fused: Optional[bool] = None) -> tuple[Tensor, ForwardState]:
-    """One ``dmpnn_forward`` call.  ``fused=None`` picks the fused route (edge tensors in CSR-row order,
-    segment sums formed in the contraction epilogues) whenever the shapes allow it; ``fused=False``
-    forces the general route (arbitrary index arrays).  A graph the fused tiling cannot represent
-    (asymmetric, in-degree > 24) makes the fused route return NaN — see ``GraphPlan.fusable``."""
+            keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None) -> tuple[Tensor, ForwardState]:
+    """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
+    the shapes allow):
+
+    * ``mega``    — the whole forward of every tile of whole molecules in ONE launch (small batches,
+                    molecules of <= 24 bonds);
+    * ``fused``   — per depth step one contraction whose epilogue forms the segment sums (CSR-row order);
+    * ``general`` — arbitrary index arrays / undirected / any ``d_h`` (caller's edge order).
+
+    ``fused=False`` is shorthand for ``route="general"``; ``fused=True`` demands at least ``fused``.
+    Graph properties are decided on the device by the plan: a graph a route cannot represent makes that
+    route return NaN (see ``GraphPlan.fusable`` / ``GraphPlan.mega_ok``)."""
     lib = _lib.load()
     V = _f32c(V, "V")
     E = _f32c(E, "E")
@@ -245,41 +258,58 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         W_d, b_d = Wc(W_d, "W_d"), Wc(b_d, "b_d")
         a.W_d, a.b_d = _ptr(W_d), _ptr(b_d)
     a.ldh = ldh
+    out = torch.empty(nV, d_h + d_vd, dtype=torch.float32, device=dev)
+    a.out, a.ldout = out.data_ptr(), out.stride(0)
 
     # route: the shape / alignment part of the decision is the library's (dmpnn_forward_can_fuse)
-    want_fused = fused is not False and os.environ.get("DMPNN_GENERAL", "0") != "1" and not undirected
+    if fused is False:
+        route = "general"
+    if os.environ.get("DMPNN_GENERAL", "0") == "1":
+        route = "general"
     a.H0 = a.Ms = a.Mv = plan.buf.data_ptr()  # any 16-byte aligned pointer: the real workspace is allocated below
-    use_fused = bool(want_fused and lib.dmpnn_forward_can_fuse(C.byref(a)))
-    if fused is True and not use_fused:
-        raise RuntimeError("forward: fused=True but the shapes do not allow the fused route "
-                           "(needs d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed)")
+    level = 0 if (route == "general" or undirected) else int(lib.dmpnn_forward_can_fuse(C.byref(a)))
+    if route == "fused" or os.environ.get("DMPNN_MEGA", "1") == "0":
+        level = min(level, 1)
+    if (fused is True or route in ("fused", "mega")) and level < (2 if route == "mega" else 1):
+        raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
+                           "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "
+                           "<= 6144 atoms and <= 12288 edges)")
+    use_fused, use_mega = level >= 1, level >= 2
 
     st = ForwardState()
     st.fused = use_fused
-    if use_fused:
+    st.route = "mega" if use_mega else ("fused" if use_fused else "general")
+    if use_mega:
+        n_hslots = n_steps if keep else 0           # inference: H / M never leave the CU
+        n_mslots = n_steps if keep else 0
+    elif use_fused:
         n_hslots = n_steps if keep else 0           # H^(t) only matters to the backward pass
         n_mslots = n_steps if keep else min(n_steps, 2)
     else:
         n_hslots = max(n_steps, 1) if keep else 1
         n_mslots = max(n_steps, 1) if keep else 1
     st.plan, st.ldh, st.n_hslots, st.n_mslots = plan, ldh, n_hslots, n_mslots
-    edge_ws = torch.empty((1 + n_hslots + max(n_mslots, 1), nE, ldh), dtype=torch.float32, device=dev)
+    need_h0 = not (use_mega and not keep)
+    edge_ws = torch.empty(((1 if need_h0 else 0) + n_hslots + n_mslots, nE, ldh), dtype=torch.float32, device=dev)
     atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
     if ldh != d_h:  # pad columns are read by vector loads of later kernels: keep them finite
         edge_ws.zero_()
         atom_ws.zero_()
-    st.H0, st.Hs, st.Ms = edge_ws[0], edge_ws[1:1 + n_hslots], edge_ws[1 + n_hslots:]
+    i0 = 1 if need_h0 else 0
+    st.H0, st.Hs, st.Ms = (edge_ws[0] if need_h0 else None), edge_ws[i0:i0 + n_hslots], edge_ws[i0 + n_hslots:]
     st.Mv, st.Hv = atom_ws[0], atom_ws[1]
-    out = torch.empty(nV, d_h + d_vd, dtype=torch.float32, device=dev)
     st.out = out
 
-    a.H0 = st.H0.data_ptr()
+    a.H0 = st.H0.data_ptr() if need_h0 else None
     a.Hs, a.n_hslots = (st.Hs.data_ptr() if n_hslots else None), n_hslots
-    a.Ms, a.n_mslots = st.Ms.data_ptr(), max(n_mslots, 1)
+    a.Ms, a.n_mslots = (st.Ms.data_ptr() if n_mslots else None), max(n_mslots, 1)
     a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
-    a.out, a.ldout = out.data_ptr(), out.stride(0)
     if use_fused:
         a.flags |= F_FUSED
+    if use_mega:
+        a.flags |= F_MEGA
+    if keep:
+        a.flags |= F_KEEP
     with torch.cuda.device(dev):
         _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a

@@ -119,24 +119,36 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
     plan = engine.GraphPlan.from_bmg(bmg)
-    return mp_forward(mp, plan, bmg.V, bmg.E, V_d, fused=_route(mp, plan))
+    n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    return mp_forward(mp, plan, bmg.V, bmg.E, V_d, route=_route(mp, plan, n_mols))
 
 
 _VALIDATE_FIRST_N = 2
 
 
-def _route(mp, plan) -> Optional[bool]:
-    """Fused route (``None`` = when the shapes allow) or general route (``False``) for this batch.
+def _route(mp, plan, n_mols: int = 0) -> Optional[str]:
+    """Route of this batch: ``None`` (the best the shapes allow), ``"fused"`` or ``"general"``.
 
     The fused kernels assume a molecular graph (``rev`` an involution with ``src(rev e) == dst(e)``,
-    in-degree <= 24); ``dmpnn_prepare`` checks that ON THE DEVICE and a violating batch makes the
-    fused route return NaN (never a silently wrong number).  Reading the verdict needs a host sync,
+    in-degree <= 24) and the whole-forward tile kernel additionally molecules of <= 48 directed edges /
+    <= 32 atoms; ``dmpnn_prepare`` checks all of that ON THE DEVICE and a violating batch makes the
+    affected route return NaN (never a silently wrong number).  Reading the verdict needs a host sync,
     so by default (``DMPNN_VALIDATE=first``) only the first batches a module sees are checked
-    synchronously — featurizer-produced graphs never violate the invariants; ``always`` checks every
-    batch (a sync per forward), ``never`` trusts.  A batch found in violation runs the general route."""
+    synchronously — featurizer-produced graphs never violate the graph invariants; ``always`` checks
+    every batch (a sync per forward), ``never`` trusts.  A batch found in violation runs the next more
+    general route; one oversize molecule switches the tile kernel off for the module (datasets of
+    larger molecules use the per-step fused route)."""
     mode = os.environ.get("DMPNN_VALIDATE", "first")
     seen = getattr(mp, "_dmpnn_batches_checked", 0)
+    no_mega = getattr(mp, "_dmpnn_no_mega", False)
+    if n_mols > 0 and plan.n_edges > 30 * n_mols:  # average molecule already near the tile: do not try
+        no_mega = True
     if mode == "always" or (mode == "first" and seen < _VALIDATE_FIRST_N):
         object.__setattr__(mp, "_dmpnn_batches_checked", seen + 1)
-        return None if plan.fusable() else False
-    return None
+        flags = plan.flags()
+        if flags & 7:
+            return "general"
+        if flags & 8:
+            object.__setattr__(mp, "_dmpnn_no_mega", True)
+            return "fused"
+    return "fused" if no_mega else None

@@ -53,10 +53,15 @@ enum dmpnn_activation {
 
 enum dmpnn_flags {
     DMPNN_F_UNDIRECTED = 1u << 0, /* base.py:202-203: H <- (H + H[rev]) / 2 before every message() */
-    DMPNN_F_FUSED = 1u << 1       /* dmpnn_forward / dmpnn_backward: edge tensors live in CSR-row
+    DMPNN_F_FUSED = 1u << 1,      /* dmpnn_forward / dmpnn_backward: edge tensors live in CSR-row
                                      order and the segment sums are formed in the contraction
                                      epilogues (molecular graphs: symmetric, in-degree <= 24;
                                      not with DMPNN_F_UNDIRECTED)                                   */
+    DMPNN_F_MEGA = 1u << 2,       /* with DMPNN_F_FUSED: the whole forward of a tile of whole molecules
+                                     (<= 48 edge rows, <= 32 atoms) in ONE launch, H / M never leave the
+                                     CU (dmpnn_forward_can_fuse returns 2 when the shapes allow it)   */
+    DMPNN_F_KEEP = 1u << 3        /* dmpnn_backward will follow: H0, H^(t), M^(t), Mv are written to
+                                     the workspace (always the case outside DMPNN_F_MEGA)             */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -78,21 +83,26 @@ enum dmpnn_plan_hdr {
                               src(rev e)==dst(e)): the general edge-form message kernel runs;
                               bit1: an index was out of range (clamped; results undefined);
                               bit2: an in-degree exceeds what the fused row tiling supports (24).
-                              Any bit set: a forward with DMPNN_F_FUSED returns NaN (loud) — run
-                              such graphs without DMPNN_F_FUSED                                    */
+                              Any of bits 0-2 set: a forward with DMPNN_F_FUSED returns NaN (loud) —
+                              run such graphs without DMPNN_F_FUSED;
+                              bit3: no piece tiles (a connected piece exceeds 48 rows / 32 atoms, or the
+                              batch is too large for the single-workgroup plan): DMPNN_F_MEGA returns NaN */
     DMPNN_HDR_MAXDEG = 1,
     DMPNN_HDR_NATOMS = 2,
     DMPNN_HDR_NEDGES = 3,
     DMPNN_HDR_NTILES = 4,  /* fused row tiles actually used (<= the launch bound)                */
     DMPNN_HDR_TILE_STRIDE = 5,
+    DMPNN_HDR_NMTILES = 6, /* piece tiles actually used                                            */
     DMPNN_HDR_WORDS = 16
 };
 /* Word offsets of the arrays inside the plan (for tests):
  *   [0..4]  src, dst, rev, row_ptr, perm                  (original edge ids)
  *   [5..8]  inv, srcp, dstp, revp                         (CSR-row coordinates: row i = edge perm[i])
  *   [9..10] tile_row, tile_atom                           (row tiles of whole atoms, fused forward)
- *   [11]    number of tile slots (launch bound)                                                  */
-#define DMPNN_PLAN_NOFFSETS 12
+ *   [11]    number of tile slots (launch bound)
+ *   [12..13] mtile_row, mtile_atom                        (row tiles of whole connected pieces)
+ *   [14]    number of piece-tile slots (launch bound)                                            */
+#define DMPNN_PLAN_NOFFSETS 15
 int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t offsets_out[DMPNN_PLAN_NOFFSETS]);
 
 /* ---------------------------------------------------------------------------------------------
@@ -189,7 +199,8 @@ typedef struct dmpnn_fwd_args {
 } dmpnn_fwd_args;
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
 /* 1 when the shapes / alignment of `a` allow DMPNN_F_FUSED (d_h % 4 == 0, d_h <= 320, even d_v and
- * d_e, directed), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
+ * d_e, directed), 2 when they also allow DMPNN_F_MEGA (batch within the single-workgroup plan:
+ * <= 6144 atoms, <= 12288 edges), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
  * dmpnn_prepare: a fused forward on a graph that violates them returns NaN and leaves the plan flags
  * set (DMPNN_HDR_FLAGS) — run such graphs without DMPNN_F_FUSED. */
 int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a);

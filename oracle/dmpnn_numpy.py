@@ -77,6 +77,41 @@ def tile_tables(row_ptr, n_edges, n_slots, bm=48, max_deg_supported=24):
     return tile_row, tile_atom, n_tiles, b0
 
 
+def piece_tiles(src, dst, row_ptr, n_slots, bm=48, ba=32):
+    """Row tiles made of WHOLE connected pieces (restates ``build_piece_tiles`` of
+    csrc/dmpnn_prepare.hip): a cut after atom ``v`` is safe when no edge joins atoms <= v with atoms
+    > v; consecutive pieces are packed greedily into tiles of <= ``bm`` rows and <= ``ba`` atoms.
+    Returns (mtile_row[n_slots + 2], mtile_atom[n_slots + 2], n_tiles) or n_tiles = -1 if a piece
+    does not fit."""
+    src, dst, row_ptr = (np.asarray(a, dtype=np.int64) for a in (src, dst, row_ptr))
+    n_atoms, n_edges = len(row_ptr) - 1, len(src)
+    mrow = np.full(n_slots + 2, n_edges, dtype=np.int64)
+    matom = np.full(n_slots + 2, n_atoms, dtype=np.int64)
+    maxnbr = np.arange(n_atoms, dtype=np.int64)
+    if n_edges:
+        np.maximum.at(maxnbr, dst, src)
+        np.maximum.at(maxnbr, src, dst)
+    pm = np.maximum.accumulate(maxnbr) if n_atoms else maxnbr
+    starts = [u for u in range(n_atoms) if u == 0 or pm[u - 1] == u - 1]
+    start_set = set(starts)
+    tiles, v = [], 0
+    while v < n_atoms:
+        u = v + 1
+        while u < n_atoms and u - v < ba and row_ptr[u + 1] - row_ptr[v] <= bm:
+            u += 1
+        cand = n_atoms if u >= n_atoms else max(s for s in starts if s <= u)
+        if cand <= v or row_ptr[u] - row_ptr[v] > bm:
+            return mrow, matom, -1
+        tiles.append(v)
+        v = cand
+    if len(tiles) > n_slots:
+        return mrow, matom, -1
+    for t, a in enumerate(tiles):
+        matom[t] = a
+        mrow[t] = row_ptr[a]
+    return mrow, matom, len(tiles)
+
+
 def segment_sum_csr(H: np.ndarray, row_ptr: np.ndarray, perm: np.ndarray) -> np.ndarray:
     """S[v] = sum of H[perm[row_ptr[v]:row_ptr[v+1]]] taken left to right in float32."""
     n_atoms = len(row_ptr) - 1

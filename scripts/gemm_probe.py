@@ -49,7 +49,11 @@ import torch.nn as nn
 from chemprop_amd.nn import BondMessagePassing
 mp = BondMessagePassing().to(dev).eval()
 with torch.no_grad():
-    for fused in (None, False):
-        os.environ["DMPNN_GENERAL"] = "1" if fused is False else "0"
-        print("whole forward, eager,", "general" if fused is False else "fused", ":", round(t_ms(lambda: mp(bmg)) * 1e3, 2), "us")
-os.environ["DMPNN_GENERAL"] = "0"
+    for name, env in (("mega", {}), ("fused", {"DMPNN_MEGA": "0"}), ("general", {"DMPNN_GENERAL": "1"})):
+        os.environ.update({"DMPNN_MEGA": "1", "DMPNN_GENERAL": "0"}); os.environ.update(env)
+        print("whole forward, eager,", name, ":", round(t_ms(lambda: mp(bmg)) * 1e3, 2), "us")
+    os.environ.update({"DMPNN_MEGA": "1", "DMPNN_GENERAL": "0"})
+    from chemprop_amd import _lib
+    plan2 = engine.GraphPlan.from_bmg(bmg)
+    fw = lambda: engine.forward(plan2, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega")
+    print("mega kernel only (plan reused):", round(t_ms(fw) * 1e3, 2), "us")

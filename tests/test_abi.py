@@ -47,7 +47,11 @@ def test_can_fuse_is_a_shape_rule():
     a.ldv, a.lde, a.ldh = 72, 14, 300
     for f in ("V", "E", "W_i", "W_h", "H0", "Ms", "Mv"):
         setattr(a, f, 4096)
-    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 1
+    a.ldout = 300
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 2   # fused, and small enough for the whole-forward tile kernel
+    a.n_atoms, a.n_edges = 100000, 200000
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 1   # fused per depth step only
+    a.n_atoms, a.n_edges = 100, 200
     a.flags = _lib.F_UNDIRECTED
     assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 0
     a.flags = 0

@@ -49,6 +49,16 @@ def test_plan_is_bit_exact(golden, gpu_device):
     assert a["hdr"][4] == n_tiles and (n_tiles == 0 or a["hdr"][5] == b0)
     assert np.array_equal(a["tile_row"], tile_row) and np.array_equal(a["tile_atom"], tile_atom)
     assert n_tiles <= n_slots and (np.diff(tile_row) <= 48).all() and (np.diff(tile_row) >= 0).all()
+    # row tiles of whole connected pieces (whole-forward tile kernel); built by the single-workgroup plan
+    m_slots = len(a["mtile_row"]) - 2
+    small = nV <= 6144 and len(perm) <= 12288
+    if small and onp.graph_is_symmetric(src, dst, rev):
+        mrow, matom, n_m = onp.piece_tiles(src, dst, row_ptr, m_slots)
+        assert bool(a["hdr"][0] & 8) == (n_m < 0)
+        assert a["hdr"][6] == max(n_m, 0)
+        assert np.array_equal(a["mtile_row"], mrow) and np.array_equal(a["mtile_atom"], matom)
+    elif not small:
+        assert a["hdr"][0] & 8 and a["hdr"][6] == 0
 
 
 def test_message_kernel_bit_exact(golden, gpu_device):
@@ -113,7 +123,7 @@ def test_forward_matches_executed_reference(golden, gpu_device):
         assert torch.equal(a, b)
 
 
-def _engine_forward(golden, dev, fused, keep=False):
+def _engine_forward(golden, dev, fused=None, keep=False, route=None):
     from chemprop_amd import engine
     from chemprop_amd.nn import classify_activation
 
@@ -127,7 +137,8 @@ def _engine_forward(golden, dev, fused, keep=False):
         out, st = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias,
                                  mp.W_i.bias, mp.W_h.bias, mp.W_d.weight if has_vd else None,
                                  mp.W_d.bias if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
-                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=keep, fused=fused)
+                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=keep, fused=fused,
+                                 route=route)
     return plan, out, st
 
 
@@ -143,11 +154,11 @@ def test_fused_route_is_bit_identical_to_general_route(golden, gpu_device):
         pytest.skip("custom activation: rows route")
     plan, out_g, st_g = _engine_forward(golden, gpu_device, fused=False, keep=True)
     if not plan.fusable():
-        plan2, out_f, _ = _engine_forward(golden, gpu_device, fused=True)
+        plan2, out_f, _ = _engine_forward(golden, gpu_device, route="fused")
         assert torch.isnan(out_f).all(), "a graph the fused tiling cannot hold must come back as NaN, loudly"
         return
-    plan, out_f, st_f = _engine_forward(golden, gpu_device, fused=True, keep=True)
-    assert st_f.fused and not st_g.fused
+    plan, out_f, st_f = _engine_forward(golden, gpu_device, route="fused", keep=True)
+    assert st_f.route == "fused" and st_g.route == "general"
     assert torch.equal(out_f, out_g)
     assert parity_err(out_f.cpu().numpy(), golden["out"]) <= TOL
     if plan.n_edges:
@@ -159,8 +170,40 @@ def test_fused_route_is_bit_identical_to_general_route(golden, gpu_device):
             assert torch.equal(st_f.Hs[t], st_g.Hs[t][perm]), f"H^({t + 1})"
     assert torch.equal(st_f.Mv, st_g.Mv)
     # inference variant (no H stores, two ping-pong message slots) gives the same output
-    _, out_i, st_i = _engine_forward(golden, gpu_device, fused=True, keep=False)
+    _, out_i, st_i = _engine_forward(golden, gpu_device, route="fused", keep=False)
     assert torch.equal(out_i, out_f)
+
+
+def test_whole_forward_tile_kernel(golden, gpu_device):
+    """Route "mega": the whole forward of a tile of whole molecules in ONE launch.  The kept
+    intermediates (H0, M^(t), H^(t), Mv) are bit-identical to the per-step fused route (same MFMA / k
+    order); the output differs only by the summation order of the finalize contraction (the Mv columns
+    are contracted before the V columns) and is held to the parity bar; a batch with a molecule larger
+    than a tile comes back as NaN, loudly."""
+    if golden.cfg.get("undirected") or golden.cfg["d_h"] % 4 or golden.cfg["d_h"] > 320:
+        pytest.skip("fused routes do not apply (undirected / d_h)")
+    if golden["V"].shape[1] % 2 or golden["E"].shape[1] % 2:
+        pytest.skip("fused routes do not apply (odd feature width)")
+    if str(golden.cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
+        pytest.skip("custom activation: rows route")
+    if golden["V"].shape[0] > 6144 or golden["E"].shape[0] > 12288:
+        pytest.skip("batch beyond the single-workgroup plan")
+    plan, out_m, st_m = _engine_forward(golden, gpu_device, route="mega", keep=True)
+    assert st_m.route == "mega"
+    if not plan.mega_ok():
+        assert torch.isnan(out_m).all()
+        return
+    assert parity_err(out_m.cpu().numpy(), golden["out"]) <= TOL
+    _, out_f, st_f = _engine_forward(golden, gpu_device, route="fused", keep=True)
+    assert parity_err(out_m.cpu().numpy(), out_f.cpu().numpy()) <= 2e-6
+    if plan.n_edges:
+        assert torch.equal(st_m.H0, st_f.H0)
+        for t in range(golden.cfg["depth"] - 1):
+            assert torch.equal(st_m.Ms[t], st_f.Ms[t]), f"M^({t + 1})"
+            assert torch.equal(st_m.Hs[t], st_f.Hs[t]), f"H^({t + 1})"
+    assert torch.equal(st_m.Mv, st_f.Mv)
+    _, out_i, st_i = _engine_forward(golden, gpu_device, route="mega", keep=False)
+    assert st_i.H0 is None and torch.equal(out_i, out_m)   # inference: nothing but `out` leaves the CU
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (16, 64, 32), (33, 300, 300), (257, 300, 86),
