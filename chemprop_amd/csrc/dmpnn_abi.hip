@@ -194,8 +194,9 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         // ---- fused route: edge tensors in CSR-row order, segment sums in the contraction epilogues ----
         DMPNN_CHECK_ARG(dmpnn_forward_can_fuse(a), "forward: DMPNN_F_FUSED given but the shapes / alignment do not allow it "
                         "(d_h %% 4, d_h <= 320, even d_v / d_e, directed); call dmpnn_forward_can_fuse first");
-        DMPNN_CHECK_ARG(a->depth <= 2 || a->n_mslots >= 2, "forward(fused): depth > 2 needs at least two message slots");
         const PlanLayout L = plan_layout(nV, nE);
+        DMPNN_CHECK_ARG((a->flags & DMPNN_F_MEGA) || a->depth <= 2 || a->n_mslots >= 2,
+                        "forward(fused): depth > 2 needs at least two message slots");
         if (a->flags & DMPNN_F_MEGA) {
             // ---- whole forward of every tile of whole molecules in one launch ----
             DMPNN_CHECK_ARG(mega_shapes_ok(*a), "forward: DMPNN_F_MEGA given but the shapes do not allow it");

@@ -265,71 +265,104 @@ __device__ __forceinline__ void block_scan_inclusive(int* a, int n, int* wave_to
 // A cut after atom v is safe when no edge joins atoms <= v with atoms > v; with atoms of a molecule
 // contiguous (data/collate.py:48-56) the cuts are the molecule boundaries (and fragment boundaries).
 // Consecutive pieces are packed greedily into tiles of <= kMegaBM rows and <= kMegaBA atoms; the chain
-// of tile starts is marked by pointer jumping (log2 V rounds) instead of a sequential walk.
-// X, Y: int scratch of nV + 2 entries each.  X enters holding maxnbr[v] = max(v, largest neighbour).
-// Returns the number of tiles, or -1 when a piece does not fit (tables are then emptied).
+// of tile starts is marked by pointer jumping over the PIECES (log2 #pieces rounds) instead of a
+// sequential walk.  X, Y: int scratch of nV + 2 entries each; X enters holding
+// maxnbr[v] = max(v, largest neighbour).  Returns the number of tiles, or -1 when a piece does not fit
+// (the tables are then emptied).
 __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const PlanLayout& L, const int* rowp, int* X,
                                                  int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid) {
     int* mrow = plan + L.mtile_row;
     int* matom = plan + L.mtile_atom;
     const int slots = (int)L.max_mtiles + 2;
-    block_scan_inclusive<true>(X, nV, wave_tot, tid);          // X[v] = max neighbour index over atoms <= v
-    for (int u = tid; u < nV; u += kSmallThreads) Y[u] = (u == 0 || X[u - 1] == u - 1) ? u : 0;  // piece starts
-    __syncthreads();
-    block_scan_inclusive<true>(Y, nV, wave_tot, tid);          // Y[u] = last piece start <= u
-    // next tile start for every piece start
-    int nxt[kSmallItems];
+    constexpr int kMark = 0x40000000;
+    block_scan_inclusive<true>(X, nV, wave_tot, tid);          // X[v] = largest neighbour index over atoms <= v
+    int st[kSmallItems];
 #pragma unroll
     for (int j = 0; j < kSmallItems; ++j) {
-        const int v = tid * kSmallItems + j;
-        nxt[j] = nV;
-        if (v < nV && Y[v] == v) {
-            const int r0 = rowp[v];
-            int u = v + 1;  // u ends as the largest index with atoms(v..u-1) <= BA and rows <= BM
-            while (u < nV && u - v < kMegaBA && rowp[u + 1] - r0 <= kMegaBM) ++u;
-            if (rowp[u] - r0 > kMegaBM) u = v;  // the first atom alone is too large (cannot happen: deg <= 24)
-            const int cand = u >= nV ? nV : Y[u];  // back to the last safe cut
-            if (cand <= v) { atomicOr(bad_s, 1); nxt[j] = nV; }
-            else nxt[j] = cand;
+        const int u = tid * kSmallItems + j;
+        st[j] = (u < nV && (u == 0 || X[u - 1] == u - 1)) ? 1 : 0;   // u starts a piece
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int u = tid * kSmallItems + j;
+        if (u < nV) Y[u] = st[j];
+    }
+    __syncthreads();
+    block_scan_inclusive<false>(Y, nV, wave_tot, tid);         // Y[u] = number of piece starts <= u
+    const int np = nV > 0 ? Y[nV - 1] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {                    // X[p] = first atom of piece p (pm is dead)
+        const int u = tid * kSmallItems + j;
+        if (u < nV && st[j]) X[Y[u] - 1] = u;
+    }
+    if (tid == 0) X[np] = nV;
+    __syncthreads();
+    // next tile start (a piece index) for every piece; Y becomes the jump / mark word
+    int nx[kSmallItems];
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int p = tid + kSmallThreads * j;
+        nx[j] = np;
+        if (p < np) {
+            const int v = X[p], r0 = rowp[v];
+            int q = p + 1;  // pieces p .. q-1 fit
+            if (X[q] - v > kMegaBA || rowp[X[q]] - r0 > kMegaBM) {
+                atomicOr(bad_s, 1);  // one piece alone exceeds a tile
+            } else {
+                while (q < np && X[q + 1] - v <= kMegaBA && rowp[X[q + 1]] - r0 <= kMegaBM) ++q;
+            }
+            nx[j] = q;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kSmallItems; ++j) {
-        const int v = tid * kSmallItems + j;
-        if (v < nV) { X[v] = nxt[j]; Y[v] = (v == 0) ? 1 : 0; }  // X = jump pointer, Y = mark
+        const int p = tid + kSmallThreads * j;
+        if (p <= np) Y[p] = (p < np ? nx[j] : np) | (p == 0 && np > 0 ? kMark : 0);
     }
-    if (tid == 0) { X[nV] = nV; Y[nV] = 0; }
     __syncthreads();
-    for (int span = 1; span < nV; span <<= 1) {  // after k rounds every chain node at distance < 2^k is marked
+    for (int span = 1; span < np; span <<= 1) {  // after k rounds every chain node at distance < 2^k is marked
         int jj[kSmallItems];
 #pragma unroll
         for (int j = 0; j < kSmallItems; ++j) {
-            const int v = tid * kSmallItems + j;
-            jj[j] = nV;
-            if (v < nV) {
-                const int t = X[v];
-                if (Y[v] && t < nV) Y[t] = 1;
-                jj[j] = X[t];
+            const int p = tid + kSmallThreads * j;
+            if (p < np) {
+                const int w = Y[p];
+                if ((w & kMark) && (w & ~kMark) < np) atomicOr(&Y[w & ~kMark], kMark);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kSmallItems; ++j) {
-            const int v = tid * kSmallItems + j;
-            if (v < nV) X[v] = jj[j];
+            const int p = tid + kSmallThreads * j;
+            jj[j] = p < np ? (Y[Y[p] & ~kMark] & ~kMark) : np;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSmallItems; ++j) {
+            const int p = tid + kSmallThreads * j;
+            if (p < np) Y[p] = (Y[p] & kMark) | jj[j];
         }
         __syncthreads();
     }
-    // tile index = rank among the marked atoms
+    // tile index = rank among the marked pieces (consecutive layout for the scan)
     int mk[kSmallItems];
 #pragma unroll
     for (int j = 0; j < kSmallItems; ++j) {
-        const int v = tid * kSmallItems + j;
-        mk[j] = v < nV ? Y[v] : 0;
+        const int p = tid * kSmallItems + j;
+        mk[j] = (p < np && (Y[p] & kMark)) ? 1 : 0;
     }
-    block_scan_inclusive<false>(Y, nV, wave_tot, tid);
-    const int n_tiles = nV > 0 ? Y[nV - 1] : 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int p = tid * kSmallItems + j;
+        if (p < np) Y[p] = mk[j];
+    }
+    __syncthreads();
+    block_scan_inclusive<false>(Y, np, wave_tot, tid);
+    const int n_tiles = np > 0 ? Y[np - 1] : 0;
     const bool bad = *bad_s != 0 || n_tiles > (int)L.max_mtiles;
     if (bad) {
         for (int t = tid; t < slots; t += kSmallThreads) { mrow[t] = nE; matom[t] = nV; }
@@ -337,8 +370,8 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
     }
 #pragma unroll
     for (int j = 0; j < kSmallItems; ++j) {
-        const int v = tid * kSmallItems + j;
-        if (v < nV && mk[j]) { mrow[Y[v] - 1] = rowp[v]; matom[Y[v] - 1] = v; }
+        const int p = tid * kSmallItems + j;
+        if (p < np && mk[j]) { const int v = X[p]; mrow[Y[p] - 1] = rowp[v]; matom[Y[p] - 1] = v; }
     }
     for (int t = n_tiles + tid; t < slots; t += kSmallThreads) { mrow[t] = nE; matom[t] = nV; }
     return n_tiles;
