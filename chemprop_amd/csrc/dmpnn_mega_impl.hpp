@@ -77,9 +77,16 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile(MegaK g) {
     const int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
     const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
     const int nrows = re - rs, na = vb - va;
-    if (na <= 0 || nrows > BM || na > BA) return;  // trailing slots of the launch bound
     const int N = g.h, qn = N >> 2;
     const bool poison = (g.flags[0] & g.poison_mask) != 0;
+    if (poison) {  // a graph this kernel cannot represent (tables may be empty): the whole output is NaN, loudly
+        const float nanv = __int_as_float(0x7fc00000);
+        const long long total = (long long)g.nV * N;
+        for (long long i = (long long)blockIdx.x * kThreads + tid; i < total; i += (long long)gridDim.x * kThreads)
+            g.out[(i / N) * g.ldout + (i % N)] = nanv;
+        return;
+    }
+    if (na <= 0 || nrows > BM || na > BA) return;  // trailing slots of the launch bound
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
     const bool simple_act = !(g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU);

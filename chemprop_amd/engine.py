@@ -217,7 +217,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             b_i: Optional[Tensor] = None, b_h: Optional[Tensor] = None, W_d: Optional[Tensor] = None,
             b_d: Optional[Tensor] = None, V_d: Optional[Tensor] = None, depth: int = 3, act: str = "relu",
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
-            keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None) -> tuple[Tensor, ForwardState]:
+            keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
+            max_level: int = 2) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -226,7 +227,9 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     * ``fused``   — per depth step one contraction whose epilogue forms the segment sums (CSR-row order);
     * ``general`` — arbitrary index arrays / undirected / any ``d_h`` (caller's edge order).
 
-    ``fused=False`` is shorthand for ``route="general"``; ``fused=True`` demands at least ``fused``.
+    ``route`` is a demand (raises when the shapes do not allow it); ``max_level`` (0 general, 1 fused,
+    2 mega) only caps the automatic choice.  ``fused=False`` is shorthand for ``route="general"``;
+    ``fused=True`` demands at least ``fused``.
     Graph properties are decided on the device by the plan: a graph a route cannot represent makes that
     route return NaN (see ``GraphPlan.fusable`` / ``GraphPlan.mega_ok``)."""
     lib = _lib.load()
@@ -270,6 +273,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     level = 0 if (route == "general" or undirected) else int(lib.dmpnn_forward_can_fuse(C.byref(a)))
     if route == "fused" or os.environ.get("DMPNN_MEGA", "1") == "0":
         level = min(level, 1)
+    if route is None:
+        level = min(level, int(max_level))
     if (fused is True or route in ("fused", "mega")) and level < (2 if route == "mega" else 1):
         raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
                            "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "

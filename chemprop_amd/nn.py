@@ -120,14 +120,14 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
     plan = engine.GraphPlan.from_bmg(bmg)
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
-    return mp_forward(mp, plan, bmg.V, bmg.E, V_d, route=_route(mp, plan, n_mols))
+    return mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols))
 
 
 _VALIDATE_FIRST_N = 2
 
 
-def _route(mp, plan, n_mols: int = 0) -> Optional[str]:
-    """Route of this batch: ``None`` (the best the shapes allow), ``"fused"`` or ``"general"``.
+def _route(mp, plan, n_mols: int = 0) -> int:
+    """Cap on the route of this batch: 2 (whole-forward tile kernel), 1 (per-step fused) or 0 (general).
 
     The fused kernels assume a molecular graph (``rev`` an involution with ``src(rev e) == dst(e)``,
     in-degree <= 24) and the whole-forward tile kernel additionally molecules of <= 48 directed edges /
@@ -147,8 +147,8 @@ def _route(mp, plan, n_mols: int = 0) -> Optional[str]:
         object.__setattr__(mp, "_dmpnn_batches_checked", seen + 1)
         flags = plan.flags()
         if flags & 7:
-            return "general"
+            return 0
         if flags & 8:
             object.__setattr__(mp, "_dmpnn_no_mega", True)
-            return "fused"
-    return "fused" if no_mega else None
+            return 1
+    return 1 if no_mega else 2
