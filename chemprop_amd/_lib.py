@@ -20,8 +20,8 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
-           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_backward.hip"]
-HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp"]
+           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_backward.hip"]
+HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp"]
 ABI_VERSION = 2
 PLAN_NOFFSETS = 15
 
@@ -29,7 +29,7 @@ PLAN_NOFFSETS = 15
 EXPORTS = [
     "dmpnn_version", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
     "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
-    "dmpnn_linear_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
+    "dmpnn_linear_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
 ]
 
@@ -38,6 +38,7 @@ F_UNDIRECTED = 1
 F_FUSED = 2
 F_MEGA = 4
 F_KEEP = 8
+F_SPLIT16 = 16
 PLAN_NOMEGA_MASK = 15  # ... | no piece tiles (a molecule larger than a tile)
 PLAN_NOFUSE_MASK = 7  # asymmetric | index out of range | in-degree > 24
 
@@ -73,6 +74,7 @@ class FwdArgs(C.Structure):
         ("Ms", C.c_void_p), ("n_mslots", C.c_int32),
         ("Mv", C.c_void_p), ("Hv", C.c_void_p),
         ("out", C.c_void_p), ("ldout", C.c_int64),
+        ("wsplit", C.c_void_p), ("wsplit_bytes", C.c_size_t),
     ]
 
 
@@ -173,7 +175,8 @@ def load() -> C.CDLL:
     lib.dmpnn_linear_wgrad_ws_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int]
     lib.dmpnn_linear_wgrad.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-    size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes")
+    size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes")
+    lib.dmpnn_forward_wsplit_bytes.argtypes = [C.POINTER(FwdArgs)]
     for name in size_t_fns:
         getattr(lib, name).restype = C.c_size_t
     for name in EXPORTS:

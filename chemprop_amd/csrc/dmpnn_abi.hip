@@ -147,6 +147,11 @@ int dmpnn_update_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t
     return launch_linear_ex(g, x, static_cast<hipStream_t>(stream));
 }
 
+size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a) {
+    if (!a || a->d_h <= 0 || a->d_v <= 0 || a->d_e < 0) return 0;
+    return mega16_wsplit_bytes(*a);
+}
+
 static bool al_ptr(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
 
 int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a) {
@@ -203,7 +208,10 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
             DMPNN_CHECK_ARG(!(a->flags & DMPNN_F_KEEP) || a->depth == 1 || nE == 0 ||
                             (a->Hs && a->n_hslots >= a->depth - 1 && a->n_mslots >= a->depth - 1),
                             "forward(mega, keep): needs depth-1 H and M slots");
-            if (nV > 0) DMPNN_TRY(launch_mega_forward(*a, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s));
+            if (nV > 0) {
+                if (a->flags & DMPNN_F_SPLIT16) DMPNN_TRY(launch_mega16_forward(*a, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s));
+                else DMPNN_TRY(launch_mega_forward(*a, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s));
+            }
             if (has_vd) {
                 dmpnn_gemm_args g;
                 memset(&g, 0, sizeof(g));

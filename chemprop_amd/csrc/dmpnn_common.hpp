@@ -165,6 +165,9 @@ int launch_linear_ex(const dmpnn_gemm_args& a, const GemmExtra& x, hipStream_t s
 // whole-forward tile kernel (dmpnn_mega.hip): writes tau(W_o[V || Mv] + b_o) to out[ldout]
 bool mega_shapes_ok(const dmpnn_fwd_args& a);
 int launch_mega_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
+// the same on the f16 matrix pipe with the exact 3-term split (dmpnn_mega16.hip)
+size_t mega16_wsplit_bytes(const dmpnn_fwd_args& a);
+int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

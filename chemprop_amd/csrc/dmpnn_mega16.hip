@@ -1,0 +1,82 @@
+// Launcher + instantiations of the split-MFMA whole-forward tile kernel (dmpnn_mega16_impl.hpp).
+#include "dmpnn_mega16_impl.hpp"
+
+namespace dmpnn {
+namespace mega16 {
+DMPNN_DEFINE_MEGA16(1)
+DMPNN_DEFINE_MEGA16(2)
+DMPNN_DEFINE_MEGA16(5)
+}  // namespace mega16
+
+namespace {
+inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+struct WsLayout {
+    size_t wi, wh, wom, wov, sc_i, sc_h, sc_o, total;
+    int nc_i, nc_h, nc_v;
+};
+WsLayout ws_layout(const dmpnn_fwd_args& a) {
+    WsLayout L;
+    const size_t N = (size_t)a.d_h;
+    L.nc_i = (int)((a.d_v + a.d_e + 31) / 32); L.nc_h = (int)((a.d_h + 31) / 32); L.nc_v = (int)((a.d_v + 31) / 32);
+    size_t o = 0;
+    L.wi = o; o += al256(N * L.nc_i * 128);
+    L.wh = o; o += al256(N * L.nc_h * 128);
+    L.wom = o; o += al256(N * L.nc_h * 128);
+    L.wov = o; o += al256(N * L.nc_v * 128);
+    L.sc_i = o; o += al256(N * 4);
+    L.sc_h = o; o += al256(N * 4);
+    L.sc_o = o; o += al256(N * 4);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+size_t mega16_wsplit_bytes(const dmpnn_fwd_args& a) { return ws_layout(a).total; }
+
+int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s) {
+    const int64_t nV = a.n_atoms, nE = a.n_edges;
+    const WsLayout W = ws_layout(a);
+    if (!a.wsplit || a.wsplit_bytes < W.total) {
+        set_error("forward(split16): wsplit workspace missing or too small (%zu < %zu bytes)", a.wsplit_bytes, W.total);
+        return DMPNN_ENOSPC;
+    }
+    unsigned char* ws = static_cast<unsigned char*>(a.wsplit);
+    const int N = (int)a.d_h, dv = (int)a.d_v, de = (int)a.d_e;
+    // ---- pre-split of the three weight matrices (once per forward: weights change every training step) ----
+    mega16::SplitArgs sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.N = N; sp.n_jobs = 4;
+    sp.job[0] = mega16::SplitJob{a.W_i, dv + de, 0, dv + de, 0, dv + de, ws + W.wi, W.nc_i, reinterpret_cast<float*>(ws + W.sc_i)};
+    sp.job[1] = mega16::SplitJob{a.W_h, N, 0, N, 0, N, ws + W.wh, W.nc_h, reinterpret_cast<float*>(ws + W.sc_h)};
+    sp.job[2] = mega16::SplitJob{a.W_o, dv + N, dv, N, 0, dv + N, ws + W.wom, W.nc_h, reinterpret_cast<float*>(ws + W.sc_o)};
+    sp.job[3] = mega16::SplitJob{a.W_o, dv + N, 0, dv, 0, dv + N, ws + W.wov, W.nc_v, nullptr};
+    hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)((4 * N + 3) / 4)), dim3(256), 0, s, sp);
+    DMPNN_CHECK_LAUNCH("k_split_weights");
+
+    const PlanLayout L = plan_layout(nV, nE);
+    const int* plan_i = static_cast<const int*>(a.plan);
+    mega16::Mega16K G;
+    memset(&G, 0, sizeof(G));
+    mega::MegaK& g = G.m;
+    g.mtile_row = plan_i + L.mtile_row; g.mtile_atom = plan_i + L.mtile_atom; g.row_ptr = plan_i + L.row_ptr;
+    g.srcp = plan_i + L.srcp; g.perm = plan_i + L.perm; g.revp = plan_i + L.revp;
+    g.flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoMega;
+    g.nV = (int)nV; g.nE = (int)nE; g.d_v = dv; g.d_e = de; g.h = N; g.depth = a.depth;
+    g.V = a.V; g.ldv = (int)a.ldv; g.E = a.E ? a.E : a.V; g.lde = (int)a.lde;
+    g.v_bytes = (unsigned)(nV * a.ldv * 4); g.e_bytes = a.E ? (unsigned)(nE * a.lde * 4) : 0u;
+    g.W_i = a.W_i; g.b_i = a.b_i; g.W_h = a.W_h; g.b_h = a.b_h; g.W_o = a.W_o; g.b_o = a.b_o;
+    g.act = a.act; g.slope = a.act_slope; g.slope_ptr = a.act_slope_ptr;
+    g.out = out; g.ldout = (int)ldout;
+    g.ldh = (int)a.ldh; g.slot = (long long)nE * a.ldh;
+    if (a.flags & DMPNN_F_KEEP) { g.H0 = a.H0; g.Hs = a.Hs; g.Ms = a.Ms; g.Mv = a.Mv; }
+    G.Wi = mega16::SplitW{ws + W.wi, reinterpret_cast<const float*>(ws + W.sc_i), W.nc_i};
+    G.Wh = mega16::SplitW{ws + W.wh, reinterpret_cast<const float*>(ws + W.sc_h), W.nc_h};
+    G.WoM = mega16::SplitW{ws + W.wom, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_h};
+    G.WoV = mega16::SplitW{ws + W.wov, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_v};
+    const int n_tiles = (int)L.max_mtiles;
+    if (a.d_h <= 64) return mega16::launch_mega16<1>(G, n_tiles, s);
+    if (a.d_h <= 128) return mega16::launch_mega16<2>(G, n_tiles, s);
+    return mega16::launch_mega16<5>(G, n_tiles, s);
+}
+
+}  // namespace dmpnn

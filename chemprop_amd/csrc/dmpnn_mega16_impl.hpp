@@ -1,0 +1,580 @@
+// Whole BondMessagePassing.forward for one tile of whole molecules in one launch — fp32-equivalent
+// arithmetic on the f16 matrix pipe ("3 x f16 split").
+//
+// gfx950 has no reduced-precision fp32 matrix path (no xf32/TF32): the exact fp32 MFMA runs at the
+// vector rate (157 TF), 1/16 of the f16 MFMA rate.  Every fp32 operand x is therefore split exactly,
+// after an exact power-of-two scaling s that puts the operand's largest magnitude at 2^13..2^14,
+//     x * s = hi + lo + e,   hi = f16(x s),  lo = f16(x s - hi),  |e| <= 2^-24 |x s|  (or <= 2^-25 absolute)
+// and a product of two fp32 numbers becomes three f16 MFMA products with fp32 accumulation,
+//     a b  ~  hi_a hi_b + hi_a lo_b + lo_a hi_b        (f16 x f16 is exact in fp32; the dropped terms are
+//                                                        <= 3 * 2^-24 |a b|: fp32 rounding class)
+// 3 x v_mfma_f32_16x16x32_f16 instead of 8 x v_mfma_f32_16x16x4_f32 per 16x16x32 block: 5.3x the
+// matrix throughput at the accuracy of the fp32 path (oracle parity 1e-7-class, tests/).
+// Scales: one per tile and contraction for the A operand (tile maximum, LDS atomic), one per output
+// column for the weights (pre-split once per forward by k_split_weights into the staging layout
+// [N][chunk][hi 32 | lo 32] halfs, so the B staging is a plain 16-byte copy without tail handling).
+//
+// Structure, tiling, LDS ring, piece tiles and the segment epilogue are those of dmpnn_mega_impl.hpp;
+// the fp32 epilogue tile overlays the (idle) B ring, the split A tile of the next step has its own region.
+#pragma once
+
+#include <type_traits>
+
+#include "dmpnn_mega_impl.hpp"
+
+namespace dmpnn {
+namespace mega16 {
+
+using gemm::BK;
+using gemm::f32x4;
+using gemm::kOOB;
+using gemm::kThreads;
+using gemm::rsrc_t;
+using gemm::u32x4;
+using gemm::u32x2;
+using mega::RT_A;
+using mega::RT_E;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr int ROWB = 144;  // bytes of one staged operand row of a chunk: [hi 32 halfs | lo 32 halfs] + 16 pad
+
+// Packed pre-split weight matrix: rows of nc chunks x 128 bytes, plus the inverse scale of every row.
+struct SplitW {
+    const unsigned char* p;  // [N][nc][128]
+    const float* inv_scale;  // [N]  1 / s_n
+    int nc;
+};
+
+struct Mega16K {
+    mega::MegaK m;           // same graph / feature / output description as the fp32 kernel
+    SplitW Wi, Wh, WoM, WoV; // W_i [N, d_v + d_e], W_h [N, N], W_o[:, d_v:], W_o[:, :d_v]  (WoM and WoV share inv_scale)
+};
+
+// exact power-of-two scale that puts `maxabs` at [2^13, 2^14); 1 for 0 / inf / nan
+__device__ __forceinline__ float scale_for(float maxabs) {
+    if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(maxabs, &e);  // maxabs = m 2^e, m in [0.5, 1)
+    return ldexpf(1.f, 14 - e);
+}
+__device__ __forceinline__ void split4(float4 x, float s, h4& hi, h4& lo) {
+    const float a = x.x * s, b = x.y * s, c = x.z * s, d = x.w * s;
+    hi = h4{(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    lo = h4{(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1]), (_Float16)(c - (float)hi[2]), (_Float16)(d - (float)hi[3])};
+}
+
+// ---- pre-split of the weights: one wave per (matrix, row) -----------------------------------------
+struct SplitJob {
+    const float* W; int ldw; int col0; int K;   // source columns [col0, col0 + K) of row n
+    int scale_col0, scale_K;                    // columns the row scale is taken over (W_o: the whole row)
+    unsigned char* out; int nc; float* inv_scale;
+};
+struct SplitArgs {
+    SplitJob job[4];
+    int n_jobs, N;
+};
+__global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = wave / a.N, n = wave - j * a.N;
+    if (j >= a.n_jobs) return;
+    const SplitJob& J = a.job[j];
+    const float* row = J.W + (long long)n * J.ldw;
+    float mx = 0.f;
+    for (int k = lane; k < J.scale_K; k += 64) mx = fmaxf(mx, fabsf(row[J.scale_col0 + k]));
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float s = scale_for(mx);
+    if (lane == 0 && J.inv_scale) J.inv_scale[n] = 1.f / s;
+    _Float16* out = reinterpret_cast<_Float16*>(J.out + (long long)n * J.nc * 128);
+    for (int k = lane; k < J.nc * 32; k += 64) {
+        const float x = k < J.K ? row[J.col0 + k] * s : 0.f;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        const int c = k >> 5, kk = k & 31;
+        out[c * 64 + kk] = hi;
+        out[c * 64 + 32 + kk] = lo;
+    }
+}
+
+template <int WN>
+constexpr size_t lds_bytes() {
+    return (size_t)kMegaBM * (64 * WN * 4 + 16) + (size_t)2 * (64 * WN) * ROWB + (size_t)(2 * kMegaBM + kMegaBA + 16) * sizeof(int);
+}
+
+template <int WN>
+__global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
+    const mega::MegaK& g = G.m;
+    constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
+    constexpr int TS = BN * 4 + 16;            // bytes of one row of the split A tile: BN/32 chunks x 128 + 16
+    constexpr int ITEMS = BM * QN / kThreads;
+    constexpr int SLOTS_B = BN * 8 / kThreads;  // 16-byte pieces of the B chunk per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* T16 = lds;                               // [BM][TS]   split A operand of the LDS-A contractions
+    unsigned char* As = lds;                                // [2][BM][ROWB] staging ring of the global-A contractions (overlays T16)
+    unsigned char* Bs = lds + BM * TS;                      // [2][BN][ROWB]
+    float* T = reinterpret_cast<float*>(Bs);                // [BM][LDC] fp32 epilogue tile (overlays the idle B ring)
+    int* revl = reinterpret_cast<int*>(Bs + 2 * BN * ROWB); // [BM]
+    int* aor = revl + BM;                                   // [BM]
+    int* rp = aor + BM;                                     // [BA + 1]
+    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [4] tile maxima (float bits)
+    static_assert(BM * LDC * 4 <= 2 * BN * ROWB, "epilogue tile must fit the B ring");
+
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int li = lane & 15, lg = lane >> 4;
+    int kq = tid & 7;
+    auto launder = [&]() {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4; kq = tid & 7;
+    };
+    const int t = blockIdx.x;
+    const int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
+    const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
+    const int nrows = re - rs, na = vb - va;
+    const int N = g.h, qn = N >> 2;
+    const bool poison = (g.flags[0] & g.poison_mask) != 0;
+    if (poison) {
+        const float nanv = __int_as_float(0x7fc00000);
+        const long long total = (long long)g.nV * N;
+        for (long long i = (long long)blockIdx.x * kThreads + tid; i < total; i += (long long)gridDim.x * kThreads)
+            g.out[(i / N) * g.ldout + (i % N)] = nanv;
+        return;
+    }
+    if (na <= 0 || nrows > BM || na > BA) return;
+    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
+    const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
+    const bool simple_act = !(g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU);
+    auto tau = [&](float z) -> float {
+        if (simple_act) return (z > 0.f ? z : neg_slope * z) + 0.f;
+        return apply_act(z, g.act, slope);
+    };
+
+    for (int i = tid; i < BM * TS / 16; i += kThreads) reinterpret_cast<float4*>(T16)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < BM) revl[tid] = tid < nrows ? g.revp[rs + tid] - rs : 0;
+    if (tid <= BA) rp[tid] = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
+    if (tid < 4) maxbits[tid] = 0u;
+    __syncthreads();
+    if (tid < na) {
+        for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
+    }
+
+    // tile maximum of |x| over per-thread values -> exact power-of-two scale (slot: which LDS word)
+    auto tile_scale = [&](float local_max, int slot) -> float {
+        for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
+        if (lane == 0) atomicMax(&maxbits[slot], __float_as_uint(local_max));  // non-negative floats order like their bits
+        __syncthreads();
+        const float mx = __uint_as_float(maxbits[slot]);
+        return scale_for(mx);
+    };
+
+    // ---- one contraction: acc[RT][WN] += (A s_A) . (W s_W)^T in the split domain -------------------
+    // A_LDS: A fragments straight from T16;  else A = [A1 | A2] fp32 from global memory, scaled by sA and
+    // split while it is staged (ring overlays T16).  B: pre-split packed weights, plain 16-byte staging.
+    auto contract = [&](auto rt_c, auto a_lds_c, auto has_a2_c, f32x4 (&acc)[decltype(rt_c)::value][WN], int K1, int K2,
+                        rsrc_t rA1, rsrc_t rA2, const unsigned (&offA1)[2], const unsigned (&offA2)[2], float sA,
+                        const SplitW& W) {
+        constexpr int RT = decltype(rt_c)::value;
+        constexpr bool A_LDS = decltype(a_lds_c)::value, HAS_A2 = decltype(has_a2_c)::value;
+        constexpr int BMr = 16 * RT;
+        constexpr int SLOTS_A = A_LDS ? 0 : (BMr * 8 + kThreads - 1) / kThreads;  // fp32 quads of the A chunk per thread (<= 2)
+        const int K = K1 + K2;
+        const int n_chunks = A_LDS ? (K + BK - 1) / BK : W.nc;
+        const rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(N * W.nc * 128));
+        launder();
+        unsigned offB[SLOTS_B];
+#pragma unroll
+        for (int j = 0; j < SLOTS_B; ++j) {
+            const int col = (tid + kThreads * j) >> 3;
+            offB[j] = (unsigned)col * (unsigned)(W.nc * 128) + (unsigned)kq * 16u;  // col >= N is out of range: reads 0
+        }
+        u32x4 stA[SLOTS_A > 0 ? SLOTS_A : 1], stB[SLOTS_B];
+        auto load_chunk = [&](int c) {
+            const int kk = c * BK + kq * 4;
+            unsigned k1o[2], k2o[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = kk + s * 2;
+                k1o[s] = k < K1 ? (unsigned)k * 4u : kOOB;
+                k2o[s] = (k >= K1 && k < K) ? (unsigned)(k - K1) * 4u : kOOB;
+            }
+#pragma unroll
+            for (int j = 0; j < SLOTS_A; ++j) {
+                unsigned o1[2] = {gemm::join_off(offA1[j], k1o[0]), gemm::join_off(offA1[j], k1o[1])};
+                u32x4 v = gemm::load_quad<2>(rA1, o1);
+                if constexpr (HAS_A2) {
+                    unsigned o2[2] = {gemm::join_off(offA2[j], k2o[0]), gemm::join_off(offA2[j], k2o[1])};
+                    v = v | gemm::load_quad<2>(rA2, o2);
+                }
+                stA[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < SLOTS_B; ++j)
+                stB[j] = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[j] + (unsigned)c * 128u, 0, 0);
+        };
+        auto store_chunk = [&](int slot) {
+            unsigned char* Ad = As + slot * BMr * ROWB;
+            unsigned char* Bd = Bs + slot * BN * ROWB;
+#pragma unroll
+            for (int j = 0; j < SLOTS_A; ++j) {
+                const int r = (tid + kThreads * j) >> 3;
+                if (r < BMr) {
+                    h4 hi, lo;
+                    split4(gemm::as_f4(stA[j]), sA, hi, lo);
+                    *reinterpret_cast<h4*>(Ad + r * ROWB + kq * 8) = hi;
+                    *reinterpret_cast<h4*>(Ad + r * ROWB + 64 + kq * 8) = lo;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SLOTS_B; ++j) {
+                const int n = (tid + kThreads * j) >> 3;
+                *reinterpret_cast<u32x4*>(Bd + n * ROWB + kq * 16) = stB[j];
+            }
+        };
+        auto read_frags = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN]) {
+            const int slot = c & 1;
+            const unsigned char* Bc = Bs + slot * BN * ROWB + wave * (16 * WN) * ROWB;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const unsigned char* p = A_LDS ? T16 + (rt * 16 + li) * TS + c * 128 + lg * 16
+                                               : As + slot * BMr * ROWB + (rt * 16 + li) * ROWB + lg * 16;
+                ah[rt] = *reinterpret_cast<const h8*>(p);
+                al[rt] = *reinterpret_cast<const h8*>(p + 64);
+            }
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) {
+                const unsigned char* p = Bc + (ct * 16 + li) * ROWB + lg * 16;
+                bh[ct] = *reinterpret_cast<const h8*>(p);
+                bl[ct] = *reinterpret_cast<const h8*>(p + 64);
+            }
+        };
+        auto chunk = [&](auto has_next, auto has_next2, int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN],
+                         h8 (&nah)[RT], h8 (&nal)[RT], h8 (&nbh)[WN], h8 (&nbl)[WN]) {
+            constexpr bool NEXT = decltype(has_next)::value, NEXT2 = decltype(has_next2)::value;
+            if constexpr (NEXT) store_chunk((c + 1) & 1);
+            if constexpr (NEXT2) load_chunk(c + 2);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NEXT) {
+                __syncthreads();
+                read_frags(c + 1, nah, nal, nbh, nbl);
+            }
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        h8 a0h[RT], a0l[RT], b0h[WN], b0l[WN], a1h[RT], a1l[RT], b1h[WN], b1l[WN];
+        __syncthreads();  // the previous phase is done with T16 / the rings / T
+        launder();
+        load_chunk(0);
+        store_chunk(0);
+        if (n_chunks > 1) load_chunk(1);
+        __syncthreads();
+        read_frags(0, a0h, a0l, b0h, b0l);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+        for (; c + 3 < n_chunks; c += 2) {
+            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
+            chunk(T_{}, T_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l, b0h, b0l);
+        }
+        const int left = n_chunks - c;
+        if (left == 3) {
+            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
+            chunk(T_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l, b0h, b0l);
+            chunk(F_{}, F_{}, c + 2, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
+        } else if (left == 2) {
+            chunk(T_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
+            chunk(F_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l, b0h, b0l);
+        } else {
+            chunk(F_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
+        }
+        __syncthreads();
+    };
+    // maximum |x| of the A operand a global-A contraction is going to stage (same loads, L2 hits later)
+    auto global_a_max = [&](auto has_a2_c, int rows_cap, int K1, int K2, rsrc_t rA1, rsrc_t rA2, const unsigned (&offA1)[2],
+                            const unsigned (&offA2)[2]) -> float {
+        constexpr bool HAS_A2 = decltype(has_a2_c)::value;
+        const int K = K1 + K2;
+        const int n_chunks = (K + BK - 1) / BK;
+        const int slots = (rows_cap * 8 + kThreads - 1) / kThreads;  // 1 or 2
+        float mx = 0.f;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int kk = c * BK + kq * 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j < slots) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int k = kk + s * 2;
+                        const unsigned k1o = k < K1 ? (unsigned)k * 4u : kOOB;
+                        const u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(rA1, gemm::join_off(offA1[j], k1o), 0, 0);
+                        mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v1.x)), fabsf(__uint_as_float(v1.y))));
+                        if constexpr (HAS_A2) {
+                            const unsigned k2o = (k >= K1 && k < K) ? (unsigned)(k - K1) * 4u : kOOB;
+                            const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(rA2, gemm::join_off(offA2[j], k2o), 0, 0);
+                            mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v2.x)), fabsf(__uint_as_float(v2.y))));
+                        }
+                    }
+                }
+            }
+        }
+        return mx;
+    };
+    auto zero_acc = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN]) {
+        constexpr int RT = decltype(rt_c)::value;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // split domain -> fp32:  z = acc / (sA sW[col]) + bias[col]
+    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], float inv_sA, const float* inv_sW, const float* bias) {
+        constexpr int RT = decltype(rt_c)::value;
+        launder();
+        const float* bp = bias ? bias : inv_sW;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const int col = wave * (16 * WN) + ct * 16 + li;
+            const bool okc = col < N;
+            const float isw = inv_sW[okc ? col : 0] * inv_sA;
+            const float braw = bp[okc ? col : 0];
+            const float bv = (okc && bias) ? braw : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * isw + bv;
+        }
+    };
+    auto frag_to_tile = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WN]) {
+        constexpr int RT = decltype(rt_c)::value;
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const int col = wave * (16 * WN) + ct * 16 + li;
+            if (col < N) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(rt * 16 + lg * 4 + r) * LDC + col] = y[rt][ct][r];
+            }
+        }
+    };
+    auto tile_to_global = [&](float* dst, long long row0, int ld, int n_r) {
+        launder();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = tid + kThreads * j;
+            const int r = it / QN, q = it - r * QN;
+            if (r < n_r && q < qn)
+                *reinterpret_cast<float4*>(dst + (row0 + r) * ld + 4 * q) = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
+        }
+    };
+    // message / aggregate from the fp32 tile T into the split A tile T16 of the next contraction:
+    //   last == false:  T16[rev(r)] <- split(S[dst(r)] - T[r])     (mixins.py:11-18), fp32 copy streamed to `keep`
+    //   last == true :  T16[a]      <- split(S[a])                 (base.py:208-211)
+    // Returns the scale the rows were split with.
+    auto segment_pass = [&](bool last, float* keep, int keep_ld, int slot) -> float {
+        launder();
+        float4 res[ITEMS];
+        int dstrow[ITEMS];
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = tid + kThreads * j;
+            const int r = it / QN, q = it - r * QN;
+            dstrow[j] = -1;
+            res[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int lim = last ? na : nrows;
+            if (r < lim && q < qn) {
+                const int a = last ? r : aor[r];
+                const int r0 = rp[a], r1 = rp[a + 1];
+                float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int rr = r0; rr < r1; ++rr) {  // increasing edge id: the reference's sequential scatter order
+                    const float4 y = *reinterpret_cast<const float4*>(T + rr * LDC + 4 * q);
+                    if (rr == r0) S = y;
+                    else { S.x += y.x; S.y += y.y; S.z += y.z; S.w += y.w; }
+                }
+                if (last) {
+                    res[j] = S;
+                    dstrow[j] = r;
+                } else {
+                    const float4 y = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
+                    res[j] = make_float4(S.x - y.x, S.y - y.y, S.z - y.z, S.w - y.w);
+                    dstrow[j] = revl[r];
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(res[j].x), fabsf(res[j].y)), fmaxf(fabsf(res[j].z), fabsf(res[j].w))));
+            }
+        }
+        const float s = tile_scale(mx, slot);  // (contains the barrier: every read of T is done)
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = tid + kThreads * j;
+            const int q = it % QN;
+            if (dstrow[j] >= 0) {
+                h4 hi, lo;
+                split4(res[j], s, hi, lo);
+                unsigned char* p = T16 + dstrow[j] * TS + (q >> 3) * 128 + (q & 7) * 8;
+                *reinterpret_cast<h4*>(p) = hi;
+                *reinterpret_cast<h4*>(p + 64) = lo;
+                if (keep) *reinterpret_cast<float4*>(keep + ((long long)(last ? va : rs) + dstrow[j]) * keep_ld + 4 * q) = res[j];
+            }
+        }
+        return s;
+    };
+
+    using RE = std::integral_constant<int, RT_E>;
+    using RA = std::integral_constant<int, RT_A>;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    const int T_steps = g.depth;
+    const unsigned dummy[2] = {kOOB, kOOB};
+
+    // ================= K1: H0 = W_i [V[src] || E] =================
+    f32x4 h0[RT_E][WN];
+    {
+        unsigned offA1[2], offA2[2];
+        int i1[2], i2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (tid + kThreads * j) >> 3;
+            const bool ok = r < BM && r < nrows;
+            i1[j] = g.srcp[ok ? rs + r : 0];
+            i2[j] = g.perm[ok ? rs + r : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (tid + kThreads * j) >> 3;
+            const bool ok = r < BM && r < nrows;
+            offA1[j] = ok ? (unsigned)i1[j] * (unsigned)g.ldv * 4u : kOOB;
+            offA2[j] = ok ? (unsigned)i2[j] * (unsigned)g.lde * 4u : kOOB;
+        }
+        const rsrc_t rV = gemm::make_rsrc(g.V, g.v_bytes), rE = gemm::make_rsrc(g.E, g.e_bytes);
+        const float sA = tile_scale(global_a_max(T_{}, BM, g.d_v, g.d_e, rV, rE, offA1, offA2), 0);
+        zero_acc(RE{}, h0);
+        contract(RE{}, F_{}, T_{}, h0, g.d_v, g.d_e, rV, rE, offA1, offA2, sA, G.Wi);
+        unscale(RE{}, h0, 1.f / sA, G.Wi.inv_scale, g.b_i);
+    }
+    // the staging ring overlaid T16: restore the zeros its pad columns must hold
+    for (int i = tid; i < BM * TS / 16; i += kThreads) reinterpret_cast<float4*>(T16)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.H0) {  // training: the pre-activation is needed by the backward pass
+        frag_to_tile(RE{}, h0);
+        __syncthreads();
+        tile_to_global(g.H0, rs, g.ldh, nrows);
+        __syncthreads();
+    }
+    {
+        f32x4 y[RT_E][WN];
+#pragma unroll
+        for (int rt = 0; rt < RT_E; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[rt][ct][r] = tau(h0[rt][ct][r]);
+        frag_to_tile(RE{}, y);
+    }
+    __syncthreads();
+    if (tid < 4) maxbits[tid] = 0u;  // slot 0 was consumed before the contraction; re-arm all
+    __syncthreads();
+    float sA = segment_pass(T_steps == 1, T_steps == 1 ? g.Mv : g.Ms, g.ldh, 1);
+
+    // ================= K3 x (depth - 1): H = tau(H0 + W_h M) =================
+    for (int step = 1; step < T_steps; ++step) {
+        f32x4 acc[RT_E][WN];
+        zero_acc(RE{}, acc);
+        const rsrc_t rnull = gemm::make_rsrc(g.W_h, 0);
+        contract(RE{}, T_{}, F_{}, acc, N, 0, rnull, rnull, dummy, dummy, sA, G.Wh);
+        unscale(RE{}, acc, 1.f / sA, G.Wh.inv_scale, g.b_h);
+#pragma unroll
+        for (int rt = 0; rt < RT_E; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt][ct][r] = tau(h0[rt][ct][r] + acc[rt][ct][r]);  // H0 + W_h(M): base.py:141
+        frag_to_tile(RE{}, acc);
+        __syncthreads();
+        if (g.Hs) tile_to_global(g.Hs + (long long)(step - 1) * g.slot, rs, g.ldh, nrows);
+        const bool last = step == T_steps - 1;
+        if (tid < 4) maxbits[tid] = 0u;
+        __syncthreads();
+        sA = segment_pass(last, last ? g.Mv : (g.Ms ? g.Ms + (long long)step * g.slot : nullptr), g.ldh, 2);
+    }
+
+    // ================= K5: out = tau(W_o [V || Mv] + b_o) on the tile's atoms =================
+    {
+        f32x4 acc[RT_A][WN];
+        zero_acc(RA{}, acc);
+        const rsrc_t rnull = gemm::make_rsrc(g.W_o, 0);
+        // Mv part first (A = T16 rows 0..atoms-1), then the V part (its staging ring overlays T16)
+        contract(RA{}, T_{}, F_{}, acc, N, 0, rnull, rnull, dummy, dummy, sA, G.WoM);
+        unsigned offA1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (tid + kThreads * j) >> 3;
+            offA1[j] = (r < BA && r < na) ? (unsigned)r * (unsigned)g.ldv * 4u : kOOB;
+        }
+        const rsrc_t rV = gemm::make_rsrc(g.V + (long long)va * g.ldv, (unsigned)(na * g.ldv) * 4u);
+        if (tid < 4) maxbits[tid] = 0u;
+        __syncthreads();
+        const float sV = tile_scale(global_a_max(F_{}, BA, g.d_v, 0, rV, rnull, offA1, dummy), 3);
+        {   // bring the accumulated Mv part into the V part's scale (exact: powers of two)
+            const float f = sV / sA;
+#pragma unroll
+            for (int rt = 0; rt < RT_A; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= f;
+        }
+        contract(RA{}, F_{}, F_{}, acc, g.d_v, 0, rV, rnull, offA1, dummy, sV, G.WoV);
+        unscale(RA{}, acc, 1.f / sV, G.WoM.inv_scale, g.b_o);
+#pragma unroll
+        for (int rt = 0; rt < RT_A; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt][ct][r] = tau(acc[rt][ct][r]);
+        frag_to_tile(RA{}, acc);
+        __syncthreads();
+        tile_to_global(g.out, va, g.ldout, na);
+    }
+}
+
+template <int WN>
+int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
+
+#define DMPNN_DEFINE_MEGA16(WN)                                                                            \
+    template <>                                                                                            \
+    int launch_mega16<WN>(const Mega16K& g, int n_tiles, hipStream_t s) {                                  \
+        constexpr size_t lds = lds_bytes<WN>();                                                            \
+        static bool attr_set = false;                                                                      \
+        if (!attr_set) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN>),          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            if (e != hipSuccess) {                                                                         \
+                set_error("hipFuncSetAttribute(k_mpnn_tile16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
+                return DMPNN_EHIP;                                                                         \
+            }                                                                                              \
+            attr_set = true;                                                                               \
+        }                                                                                                  \
+        hipLaunchKernelGGL((k_mpnn_tile16<WN>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);       \
+        DMPNN_CHECK_LAUNCH("k_mpnn_tile16");                                                               \
+        return DMPNN_OK;                                                                                   \
+    }
+
+}  // namespace mega16
+}  // namespace dmpnn

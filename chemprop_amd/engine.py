@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_UNDIRECTED, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
+from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_SPLIT16, F_UNDIRECTED, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
 
 
 def _stream_ptr(device) -> int:
@@ -218,7 +218,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             b_d: Optional[Tensor] = None, V_d: Optional[Tensor] = None, depth: int = 3, act: str = "relu",
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
             keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
-            max_level: int = 2) -> tuple[Tensor, ForwardState]:
+            max_level: int = 2, mfma: Optional[str] = None) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -227,6 +227,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     * ``fused``   — per depth step one contraction whose epilogue forms the segment sums (CSR-row order);
     * ``general`` — arbitrary index arrays / undirected / any ``d_h`` (caller's edge order).
 
+    ``mfma`` picks the matrix arithmetic of the mega route: ``"split16"`` (default; fp32-equivalent exact
+    3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
     ``route`` is a demand (raises when the shapes do not allow it); ``max_level`` (0 general, 1 fused,
     2 mega) only caps the automatic choice.  ``fused=False`` is shorthand for ``route="general"``;
     ``fused=True`` demands at least ``fused``.
@@ -311,14 +313,21 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
     if use_fused:
         a.flags |= F_FUSED
+    wsplit = None
     if use_mega:
         a.flags |= F_MEGA
+        if (mfma or os.environ.get("DMPNN_MFMA", "split16")) != "f32":
+            a.flags |= F_SPLIT16
+            nb = int(lib.dmpnn_forward_wsplit_bytes(C.byref(a)))
+            wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
+            a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
+            st.route = "mega16"
     if keep:
         a.flags |= F_KEEP
     with torch.cuda.device(dev):
         _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
-    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws)
+    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, wsplit)
     st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)
     return out, st
 

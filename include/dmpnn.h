@@ -60,8 +60,11 @@ enum dmpnn_flags {
     DMPNN_F_MEGA = 1u << 2,       /* with DMPNN_F_FUSED: the whole forward of a tile of whole molecules
                                      (<= 48 edge rows, <= 32 atoms) in ONE launch, H / M never leave the
                                      CU (dmpnn_forward_can_fuse returns 2 when the shapes allow it)   */
-    DMPNN_F_KEEP = 1u << 3        /* dmpnn_backward will follow: H0, H^(t), M^(t), Mv are written to
+    DMPNN_F_KEEP = 1u << 3,       /* dmpnn_backward will follow: H0, H^(t), M^(t), Mv are written to
                                      the workspace (always the case outside DMPNN_F_MEGA)             */
+    DMPNN_F_SPLIT16 = 1u << 4     /* with DMPNN_F_MEGA: contractions on the f16 matrix pipe with the exact
+                                     3-term split (x s = hi + lo, fp32 accumulate): fp32-class accuracy at
+                                     5.3x the fp32-MFMA rate; needs the `wsplit` workspace                */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -196,7 +199,10 @@ typedef struct dmpnn_fwd_args {
     float* Mv; float* Hv;
     /* output [n_atoms, d_h (+ d_vd)] */
     float* out; int64_t ldout;
+    /* DMPNN_F_SPLIT16: caller-owned scratch for the pre-split weights, >= dmpnn_forward_wsplit_bytes() */
+    void* wsplit; size_t wsplit_bytes;
 } dmpnn_fwd_args;
+size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
 /* 1 when the shapes / alignment of `a` allow DMPNN_F_FUSED (d_h % 4 == 0, d_h <= 320, even d_v and
  * d_e, directed), 2 when they also allow DMPNN_F_MEGA (batch within the single-workgroup plan:

@@ -55,5 +55,6 @@ with torch.no_grad():
     os.environ.update({"DMPNN_MEGA": "1", "DMPNN_GENERAL": "0"})
     from chemprop_amd import _lib
     plan2 = engine.GraphPlan.from_bmg(bmg)
-    fw = lambda: engine.forward(plan2, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega")
-    print("mega kernel only (plan reused):", round(t_ms(fw) * 1e3, 2), "us")
+    for mf in ("f32", "split16"):
+        fw = lambda: engine.forward(plan2, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega", mfma=mf)
+        print(f"mega kernel only (plan reused), mfma={mf}:", round(t_ms(fw) * 1e3, 2), "us")

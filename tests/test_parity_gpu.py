@@ -123,7 +123,7 @@ def test_forward_matches_executed_reference(golden, gpu_device):
         assert torch.equal(a, b)
 
 
-def _engine_forward(golden, dev, fused=None, keep=False, route=None):
+def _engine_forward(golden, dev, fused=None, keep=False, route=None, mfma=None):
     from chemprop_amd import engine
     from chemprop_amd.nn import classify_activation
 
@@ -138,7 +138,7 @@ def _engine_forward(golden, dev, fused=None, keep=False, route=None):
                                  mp.W_i.bias, mp.W_h.bias, mp.W_d.weight if has_vd else None,
                                  mp.W_d.bias if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
                                  slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=keep, fused=fused,
-                                 route=route)
+                                 route=route, mfma=mfma)
     return plan, out, st
 
 
@@ -188,7 +188,7 @@ def test_whole_forward_tile_kernel(golden, gpu_device):
         pytest.skip("custom activation: rows route")
     if golden["V"].shape[0] > 6144 or golden["E"].shape[0] > 12288:
         pytest.skip("batch beyond the single-workgroup plan")
-    plan, out_m, st_m = _engine_forward(golden, gpu_device, route="mega", keep=True)
+    plan, out_m, st_m = _engine_forward(golden, gpu_device, route="mega", keep=True, mfma="f32")
     assert st_m.route == "mega"
     if not plan.mega_ok():
         assert torch.isnan(out_m).all()
@@ -202,8 +202,39 @@ def test_whole_forward_tile_kernel(golden, gpu_device):
             assert torch.equal(st_m.Ms[t], st_f.Ms[t]), f"M^({t + 1})"
             assert torch.equal(st_m.Hs[t], st_f.Hs[t]), f"H^({t + 1})"
     assert torch.equal(st_m.Mv, st_f.Mv)
-    _, out_i, st_i = _engine_forward(golden, gpu_device, route="mega", keep=False)
+    _, out_i, st_i = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="f32")
     assert st_i.H0 is None and torch.equal(out_i, out_m)   # inference: nothing but `out` leaves the CU
+
+
+def test_whole_forward_tile_kernel_split_f16(golden, gpu_device):
+    """Route "mega" on the f16 matrix pipe with the exact 3-term split (x s = hi + lo, fp32
+    accumulate): held to the SAME parity bar as the fp32-MFMA path against the executed reference,
+    intermediates included."""
+    if golden.cfg.get("undirected") or golden.cfg["d_h"] % 4 or golden.cfg["d_h"] > 320:
+        pytest.skip("fused routes do not apply (undirected / d_h)")
+    if golden["V"].shape[1] % 2 or golden["E"].shape[1] % 2:
+        pytest.skip("fused routes do not apply (odd feature width)")
+    if str(golden.cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
+        pytest.skip("custom activation: rows route")
+    if golden["V"].shape[0] > 6144 or golden["E"].shape[0] > 12288:
+        pytest.skip("batch beyond the single-workgroup plan")
+    plan, out_s, st_s = _engine_forward(golden, gpu_device, route="mega", keep=True, mfma="split16")
+    assert st_s.route == "mega16"
+    if not plan.mega_ok():
+        assert torch.isnan(out_s).all()
+        return
+    err = parity_err(out_s.cpu().numpy(), golden["out"])
+    assert err <= TOL, f"{golden.name}: {err:.3e}"
+    _, out_f, st_f = _engine_forward(golden, gpu_device, route="fused", keep=True)
+    assert parity_err(out_s.cpu().numpy(), out_f.cpu().numpy()) <= 3e-6
+    if plan.n_edges:
+        assert parity_err(st_s.H0.cpu().numpy(), st_f.H0.cpu().numpy()) <= 3e-6
+        for t in range(golden.cfg["depth"] - 1):
+            assert parity_err(st_s.Ms[t].cpu().numpy(), st_f.Ms[t].cpu().numpy()) <= 3e-6, f"M^({t + 1})"
+            assert parity_err(st_s.Hs[t].cpu().numpy(), st_f.Hs[t].cpu().numpy()) <= 3e-6, f"H^({t + 1})"
+    assert parity_err(st_s.Mv.cpu().numpy(), st_f.Mv.cpu().numpy()) <= 3e-6
+    _, out_i, _ = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16")
+    assert torch.equal(out_i, out_s)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (16, 64, 32), (33, 300, 300), (257, 300, 86),
