@@ -27,8 +27,8 @@ PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
 EXPORTS = [
-    "dmpnn_version", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
-    "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
+    "dmpnn_version", "dmpnn_debug_timestamps", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
+    "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_prepare_light", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
     "dmpnn_linear_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
 ]
@@ -158,6 +158,7 @@ def load() -> C.CDLL:
     lib.dmpnn_plan_layout.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
     lib.dmpnn_forward_can_fuse.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.dmpnn_prepare_light.argtypes = lib.dmpnn_prepare.argtypes
     lib.dmpnn_message_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint, C.c_void_p]
     lib.dmpnn_aggregate_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
@@ -177,6 +178,7 @@ def load() -> C.CDLL:
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes")
     lib.dmpnn_forward_wsplit_bytes.argtypes = [C.POINTER(FwdArgs)]
+    lib.dmpnn_debug_timestamps.argtypes = [C.c_void_p]
     for name in size_t_fns:
         getattr(lib, name).restype = C.c_size_t
     for name in EXPORTS:

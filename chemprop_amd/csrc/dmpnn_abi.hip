@@ -44,10 +44,15 @@ static int check_graph_sizes(int64_t nV, int64_t nE) {
 }  // namespace dmpnn
 
 using namespace dmpnn;
+namespace dmpnn { extern long long* g_debug_stamps; }
 
 extern "C" {
 
 int dmpnn_version(void) { return DMPNN_ABI_VERSION; }
+int dmpnn_debug_timestamps(void* device_buf) {
+    g_debug_stamps = static_cast<long long*>(device_buf);
+    return DMPNN_OK;
+}
 const char* dmpnn_last_error_string(void) { return g_err; }
 int dmpnn_last_launch_count(void) { return g_launches; }
 
@@ -67,8 +72,8 @@ int dmpnn_plan_layout(int64_t n_atoms, int64_t n_edges, int64_t off[DMPNN_PLAN_N
     return DMPNN_OK;
 }
 
-int dmpnn_prepare(const int64_t* edge_index, const int64_t* rev, int64_t n_atoms, int64_t n_edges,
-                  void* plan, size_t plan_bytes, void* stream) {
+static int prepare_impl(const int64_t* edge_index, const int64_t* rev, int64_t n_atoms, int64_t n_edges, void* plan,
+                        size_t plan_bytes, int light, void* stream) {
     DMPNN_TRY(check_graph_sizes(n_atoms, n_edges));
     DMPNN_CHECK_ARG(plan != nullptr, "prepare: null plan");
     DMPNN_CHECK_ARG(n_edges == 0 || (edge_index && rev), "prepare: null index arrays");
@@ -77,7 +82,15 @@ int dmpnn_prepare(const int64_t* edge_index, const int64_t* rev, int64_t n_atoms
         return DMPNN_ENOSPC;
     }
     DMPNN_CHECK_ARG(aligned16(plan), "prepare: plan must be 16-byte aligned");
-    return launch_prepare(edge_index, rev, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream));
+    return launch_prepare(edge_index, rev, n_atoms, n_edges, static_cast<int*>(plan), light, static_cast<hipStream_t>(stream));
+}
+int dmpnn_prepare(const int64_t* edge_index, const int64_t* rev, int64_t n_atoms, int64_t n_edges, void* plan,
+                  size_t plan_bytes, void* stream) {
+    return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 0, stream);
+}
+int dmpnn_prepare_light(const int64_t* edge_index, const int64_t* rev, int64_t n_atoms, int64_t n_edges, void* plan,
+                        size_t plan_bytes, void* stream) {
+    return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 1, stream);
 }
 
 int dmpnn_message_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h, const float* Hin,

@@ -141,7 +141,15 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
 
 // ---- host launchers implemented in the .hip files -------------------------------------------
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV, int64_t nE, int* plan,
-                   hipStream_t s);
+                   int light, hipStream_t s);
+// batches the single-workgroup plan (and therefore the piece tiles / the whole-forward tile kernel) takes
+constexpr int kSmallPlanMaxAtoms = 6144, kSmallPlanMaxEdges = 10240;
+inline size_t small_plan_lds_bytes(int64_t nV, int64_t nE) {
+    return ((size_t)(3 * (nV + 2)) * 4 + (size_t)(5 * nE + 2) * 2 + 31) & ~size_t(15);
+}
+inline bool small_plan_fits(int64_t nV, int64_t nE) {
+    return nV <= kSmallPlanMaxAtoms && nE <= kSmallPlanMaxEdges && small_plan_lds_bytes(nV, nE) <= 160 * 1024 - 512;
+}
 int launch_message(const PlanView& pv, int64_t nV, int64_t nE, int64_t h, const float* Hin,
                    int64_t ld_in, float* M, int64_t ld_m, int act, float slope,
                    const float* slope_ptr, unsigned flags, hipStream_t s);

@@ -8,6 +8,8 @@ DMPNN_DEFINE_MEGA16(2)
 DMPNN_DEFINE_MEGA16(5)
 }  // namespace mega16
 
+long long* g_debug_stamps = nullptr;
+
 namespace {
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 struct WsLayout {
@@ -73,6 +75,7 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     G.Wh = mega16::SplitW{ws + W.wh, reinterpret_cast<const float*>(ws + W.sc_h), W.nc_h};
     G.WoM = mega16::SplitW{ws + W.wom, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_h};
     G.WoV = mega16::SplitW{ws + W.wov, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_v};
+    g.dbg = g_debug_stamps;
     const int n_tiles = (int)L.max_mtiles;
     if (a.d_h <= 64) return mega16::launch_mega16<1>(G, n_tiles, s);
     if (a.d_h <= 128) return mega16::launch_mega16<2>(G, n_tiles, s);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
 
 template <int WN>
 constexpr size_t lds_bytes() {
-    return (size_t)kMegaBM * (64 * WN * 4 + 16) + (size_t)2 * (64 * WN) * ROWB + (size_t)(2 * kMegaBM + kMegaBA + 16) * sizeof(int);
+    return (size_t)kMegaBM * (64 * WN * 4 + 16) + (size_t)2 * (64 * WN) * ROWB + (size_t)(2 * kMegaBM + kMegaBA + 24) * sizeof(int);
 }
 
 template <int WN>
@@ -119,9 +119,11 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     int* revl = reinterpret_cast<int*>(Bs + 2 * BN * ROWB); // [BM]
     int* aor = revl + BM;                                   // [BM]
     int* rp = aor + BM;                                     // [BA + 1]
-    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [4] tile maxima (float bits)
+    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [0..3] tile maxima (float bits), [4] tile max in-degree
     static_assert(BM * LDC * 4 <= 2 * BN * ROWB, "epilogue tile must fit the B ring");
 
+    using T_ = std::true_type;
+    using F_ = std::false_type;
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int li = lane & 15, lg = lane >> 4;
     int kq = tid & 7;
@@ -129,6 +131,12 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4; kq = tid & 7;
     };
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0 && n_stamp < 32) g.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();  // 0: kernel entry
     const int t = blockIdx.x;
     const int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
     const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
@@ -151,14 +159,16 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         return apply_act(z, g.act, slope);
     };
 
-    for (int i = tid; i < BM * TS / 16; i += kThreads) reinterpret_cast<float4*>(T16)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < BM) revl[tid] = tid < nrows ? g.revp[rs + tid] - rs : 0;
     if (tid <= BA) rp[tid] = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
-    if (tid < 4) maxbits[tid] = 0u;
+    if (tid < 8) maxbits[tid] = 0u;
     __syncthreads();
     if (tid < na) {
         for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
+        atomicMax(&maxbits[4], (unsigned)(rp[tid + 1] - rp[tid]));
     }
+    __syncthreads();
+    const int tile_maxdeg = (int)maxbits[4];
 
     // tile maximum of |x| over per-thread values -> exact power-of-two scale (slot: which LDS word)
     auto tile_scale = [&](float local_max, int slot) -> float {
@@ -167,6 +177,20 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         __syncthreads();
         const float mx = __uint_as_float(maxbits[slot]);
         return scale_for(mx);
+    };
+
+    // chunk 0 of the NEXT contraction's weights, fetched into registers while the current epilogue runs
+    u32x4 preB[SLOTS_B];
+    bool have_pre = false;
+    auto prefetch_b = [&](const SplitW& W) {
+        launder();
+        const rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(N * W.nc * 128));
+#pragma unroll
+        for (int j = 0; j < SLOTS_B; ++j) {
+            const int col = (tid + kThreads * j) >> 3;
+            preB[j] = __builtin_amdgcn_raw_buffer_load_b128(rW, (unsigned)col * (unsigned)(W.nc * 128) + (unsigned)kq * 16u, 0, 0);
+        }
+        have_pre = true;
     };
 
     // ---- one contraction: acc[RT][WN] += (A s_A) . (W s_W)^T in the split domain -------------------
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             offB[j] = (unsigned)col * (unsigned)(W.nc * 128) + (unsigned)kq * 16u;  // col >= N is out of range: reads 0
         }
         u32x4 stA[SLOTS_A > 0 ? SLOTS_A : 1], stB[SLOTS_B];
-        auto load_chunk = [&](int c) {
+        auto load_chunk = [&](int c, bool skip_b = false) {
             const int kk = c * BK + kq * 4;
             unsigned k1o[2], k2o[2];
 #pragma unroll
@@ -209,9 +233,11 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                 }
                 stA[j] = v;
             }
+            if (!skip_b) {
 #pragma unroll
-            for (int j = 0; j < SLOTS_B; ++j)
-                stB[j] = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[j] + (unsigned)c * 128u, 0, 0);
+                for (int j = 0; j < SLOTS_B; ++j)
+                    stB[j] = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[j] + (unsigned)c * 128u, 0, 0);
+            }
         };
         auto store_chunk = [&](int slot) {
             unsigned char* Ad = As + slot * BMr * ROWB;
@@ -249,6 +275,13 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                 bl[ct] = *reinterpret_cast<const h8*>(p + 64);
             }
         };
+        // One k-chunk = 3 x RT x WN MFMAs.  The staging traffic of the following chunks is issued in the
+        // shadow of the hi.hi block (one LDS write + global loads per MFMA), the fragments of chunk c+1 are
+        // read in the shadow of the hi.lo / lo.hi blocks: with one wave per SIMD nothing else hides them.
+        constexpr int N_WR = SLOTS_B + 2 * SLOTS_A;
+        constexpr int N_LD = SLOTS_B + SLOTS_A * 2 * (HAS_A2 ? 2 : 1);
+        constexpr int N_M1 = RT * WN;
+        constexpr int N_RD = 2 * (RT + WN);
         auto chunk = [&](auto has_next, auto has_next2, int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN],
                          h8 (&nah)[RT], h8 (&nal)[RT], h8 (&nbh)[WN], h8 (&nbl)[WN]) {
             constexpr bool NEXT = decltype(has_next)::value, NEXT2 = decltype(has_next2)::value;
@@ -259,6 +292,15 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+            if constexpr (NEXT) {
+                constexpr int WR_PER = (N_WR + N_M1 - 1) / N_M1, LD_PER = NEXT2 ? (N_LD + N_M1 - 1) / N_M1 : 0;
+#pragma unroll
+                for (int i = 0; i < N_M1; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, WR_PER, 0);
+                    if constexpr (LD_PER > 0) __builtin_amdgcn_sched_group_barrier(0x020, LD_PER, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NEXT) {
                 __syncthreads();
@@ -274,6 +316,13 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+            if constexpr (NEXT) {
+#pragma unroll
+                for (int i = 0; i < N_RD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         using T_ = std::true_type;
@@ -281,7 +330,14 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         h8 a0h[RT], a0l[RT], b0h[WN], b0l[WN], a1h[RT], a1l[RT], b1h[WN], b1l[WN];
         __syncthreads();  // the previous phase is done with T16 / the rings / T
         launder();
-        load_chunk(0);
+        if (have_pre) {  // (uniform) the weights of chunk 0 were fetched during the previous epilogue
+#pragma unroll
+            for (int j = 0; j < SLOTS_B; ++j) stB[j] = preB[j];
+            load_chunk(0, true);
+            have_pre = false;
+        } else {
+            load_chunk(0);
+        }
         store_chunk(0);
         if (n_chunks > 1) load_chunk(1);
         __syncthreads();
@@ -342,22 +398,59 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // split domain -> fp32:  z = acc / (sA sW[col]) + bias[col]
-    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], float inv_sA, const float* inv_sW, const float* bias) {
-        constexpr int RT = decltype(rt_c)::value;
+    // per-lane column constants of a contraction (inverse weight scale, bias), fetched BEFORE the
+    // contraction so their latency hides under it
+    struct ColConst { float isw[WN], bv[WN]; };
+    auto col_consts = [&](const float* inv_sW, const float* bias) -> ColConst {
+        ColConst cc;
         launder();
         const float* bp = bias ? bias : inv_sW;
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) {
             const int col = wave * (16 * WN) + ct * 16 + li;
             const bool okc = col < N;
-            const float isw = inv_sW[okc ? col : 0] * inv_sA;
+            cc.isw[ct] = inv_sW[okc ? col : 0];
             const float braw = bp[okc ? col : 0];
-            const float bv = (okc && bias) ? braw : 0.f;
+            cc.bv[ct] = (okc && bias) ? braw : 0.f;
+        }
+        return cc;
+    };
+    // split domain -> fp32:  z = acc / (sA sW[col]) + bias[col]
+    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], float inv_sA, const ColConst& cc) {
+        constexpr int RT = decltype(rt_c)::value;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const float isw = cc.isw[ct] * inv_sA;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * isw + bv;
+                for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * isw + cc.bv[ct];
+        }
+    };
+    // y = tau(z [+ res]) elementwise on C/D fragments
+    auto act_frags = [&](auto rt_c, auto use_res_c, f32x4 (&z)[decltype(rt_c)::value][WN], const f32x4 (&res)[decltype(rt_c)::value][WN]) {
+        constexpr int RT = decltype(rt_c)::value;
+        constexpr bool USE_RES = decltype(use_res_c)::value;
+        if (simple_act) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = USE_RES ? res[rt][ct][r] + z[rt][ct][r] : z[rt][ct][r];
+                        z[rt][ct][r] = (v > 0.f ? v : neg_slope * v) + 0.f;
+                    }
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = USE_RES ? res[rt][ct][r] + z[rt][ct][r] : z[rt][ct][r];
+                        z[rt][ct][r] = apply_act(v, g.act, slope);
+                    }
         }
     };
     auto frag_to_tile = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WN]) {
@@ -387,51 +480,112 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     // message / aggregate from the fp32 tile T into the split A tile T16 of the next contraction:
     //   last == false:  T16[rev(r)] <- split(S[dst(r)] - T[r])     (mixins.py:11-18), fp32 copy streamed to `keep`
     //   last == true :  T16[a]      <- split(S[a])                 (base.py:208-211)
-    // Returns the scale the rows were split with.
+    // S[a] is summed in ROUNDS over the in-degree (round d adds row d of every atom that has one: the
+    // loads of all items of a thread are independent, and every atom still sums in increasing edge id =
+    // the reference's sequential scatter order).  Returns the scale the rows were split with.
+    constexpr int ITEMS_A = BA * QN / kThreads;  // (atom, quad) items per thread
+    float* Sbuf = reinterpret_cast<float*>(T16); // [BA][LDC] per-atom sums (the A tile is dead during the epilogue)
+    const int qn_pad = ((N + 31) / 32) * 8;      // quads up to the k-padding of the last chunk (written as zeros)
     auto segment_pass = [&](bool last, float* keep, int keep_ld, int slot) -> float {
         launder();
+        float4 S[ITEMS_A];
+        int sr0[ITEMS_A], sdg[ITEMS_A];
+#pragma unroll
+        for (int j = 0; j < ITEMS_A; ++j) {
+            const int it = tid + kThreads * j;
+            const int a = it / QN, q = it - a * QN;
+            const bool ok = a < na && q < qn;
+            const int ac = ok ? a : 0;
+            const int b0 = rp[ac], b1 = rp[ac + 1];
+            sr0[j] = ok ? b0 : 0;
+            sdg[j] = ok ? b1 - b0 : 0;
+            S[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int d = 0; d < tile_maxdeg; ++d) {
+            float4 y[ITEMS_A];
+#pragma unroll
+            for (int j = 0; j < ITEMS_A; ++j) {  // all loads first (unconditional, clamped), then branch-free adds
+                const int q = (tid + kThreads * j) % QN;
+                y[j] = *reinterpret_cast<const float4*>(T + (sr0[j] + (d < sdg[j] ? d : 0)) * LDC + 4 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS_A; ++j) {
+                const bool on = d < sdg[j];
+                const bool first = d == 0;
+                S[j].x = on ? (first ? y[j].x : S[j].x + y[j].x) : S[j].x;
+                S[j].y = on ? (first ? y[j].y : S[j].y + y[j].y) : S[j].y;
+                S[j].z = on ? (first ? y[j].z : S[j].z + y[j].z) : S[j].z;
+                S[j].w = on ? (first ? y[j].w : S[j].w + y[j].w) : S[j].w;
+            }
+        }
+        if (slot == 2) stamp();  // s1: per-atom sums
         float4 res[ITEMS];
         int dstrow[ITEMS];
+        if (last) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) { dstrow[j] = -1; res[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int j = 0; j < ITEMS_A; ++j) {
+                const int it = tid + kThreads * j;
+                const int a = it / QN, q = it - a * QN;
+                if (a < na && q < qn_pad) { res[j] = q < qn ? S[j] : make_float4(0.f, 0.f, 0.f, 0.f); dstrow[j] = a; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < ITEMS_A; ++j) {
+                const int it = tid + kThreads * j;
+                const int a = it / QN, q = it - a * QN;
+                if (a < na && q < qn) *reinterpret_cast<float4*>(Sbuf + a * LDC + 4 * q) = S[j];
+            }
+            int ar[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {  // index loads of every item first
+                const int it = tid + kThreads * j;
+                const int r = it / QN, q = it - r * QN;
+                const bool ok = r < nrows && q < qn_pad;
+                const int rc = ok ? r : 0;
+                ar[j] = aor[rc];
+                dstrow[j] = ok ? revl[rc] : -1;
+            }
+            __syncthreads();
+            float4 Sv[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {  // then the data loads of every item, then the arithmetic
+                const int it = tid + kThreads * j;
+                const int r = it / QN, q = it - r * QN;
+                const int rc = r < nrows ? r : 0, qc = q < qn ? q : 0;
+                Sv[j] = *reinterpret_cast<const float4*>(Sbuf + ar[j] * LDC + 4 * qc);
+                res[j] = *reinterpret_cast<const float4*>(T + rc * LDC + 4 * qc);
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int q = (tid + kThreads * j) % QN;
+                const bool live = q < qn;
+                res[j] = make_float4(live ? Sv[j].x - res[j].x : 0.f, live ? Sv[j].y - res[j].y : 0.f,
+                                     live ? Sv[j].z - res[j].z : 0.f, live ? Sv[j].w - res[j].w : 0.f);
+            }
+        }
         float mx = 0.f;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const int it = tid + kThreads * j;
-            const int r = it / QN, q = it - r * QN;
-            dstrow[j] = -1;
-            res[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int lim = last ? na : nrows;
-            if (r < lim && q < qn) {
-                const int a = last ? r : aor[r];
-                const int r0 = rp[a], r1 = rp[a + 1];
-                float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int rr = r0; rr < r1; ++rr) {  // increasing edge id: the reference's sequential scatter order
-                    const float4 y = *reinterpret_cast<const float4*>(T + rr * LDC + 4 * q);
-                    if (rr == r0) S = y;
-                    else { S.x += y.x; S.y += y.y; S.z += y.z; S.w += y.w; }
-                }
-                if (last) {
-                    res[j] = S;
-                    dstrow[j] = r;
-                } else {
-                    const float4 y = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
-                    res[j] = make_float4(S.x - y.x, S.y - y.y, S.z - y.z, S.w - y.w);
-                    dstrow[j] = revl[r];
-                }
-                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(res[j].x), fabsf(res[j].y)), fmaxf(fabsf(res[j].z), fabsf(res[j].w))));
-            }
+            const float m4 = fmaxf(fmaxf(fabsf(res[j].x), fabsf(res[j].y)), fmaxf(fabsf(res[j].z), fabsf(res[j].w)));
+            mx = dstrow[j] >= 0 ? fmaxf(mx, m4) : mx;
         }
-        const float s = tile_scale(mx, slot);  // (contains the barrier: every read of T is done)
+        if (slot == 2) stamp();  // s2: messages in registers
+        const float s = tile_scale(mx, slot);  // (contains the barrier: every read of T / Sbuf is done)
+        if (slot == 2) stamp();  // s3: scale
+        h4 hi[ITEMS], lo[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) split4(res[j], s, hi[j], lo[j]);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int it = tid + kThreads * j;
             const int q = it % QN;
-            if (dstrow[j] >= 0) {
-                h4 hi, lo;
-                split4(res[j], s, hi, lo);
+            if (dstrow[j] >= 0) {  // q < qn_pad: the k-padding of the last chunk is written as zeros
                 unsigned char* p = T16 + dstrow[j] * TS + (q >> 3) * 128 + (q & 7) * 8;
-                *reinterpret_cast<h4*>(p) = hi;
-                *reinterpret_cast<h4*>(p + 64) = lo;
-                if (keep) *reinterpret_cast<float4*>(keep + ((long long)(last ? va : rs) + dstrow[j]) * keep_ld + 4 * q) = res[j];
+                *reinterpret_cast<h4*>(p) = hi[j];
+                *reinterpret_cast<h4*>(p + 64) = lo[j];
+                if (keep && q < qn) *reinterpret_cast<float4*>(keep + ((long long)(last ? va : rs) + dstrow[j]) * keep_ld + 4 * q) = res[j];
             }
         }
         return s;
@@ -439,8 +593,6 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 
     using RE = std::integral_constant<int, RT_E>;
     using RA = std::integral_constant<int, RT_A>;
-    using T_ = std::true_type;
-    using F_ = std::false_type;
     const int T_steps = g.depth;
     const unsigned dummy[2] = {kOOB, kOOB};
 
@@ -464,13 +616,16 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             offA2[j] = ok ? (unsigned)i2[j] * (unsigned)g.lde * 4u : kOOB;
         }
         const rsrc_t rV = gemm::make_rsrc(g.V, g.v_bytes), rE = gemm::make_rsrc(g.E, g.e_bytes);
+        stamp();  // 1: metadata done
+        const ColConst cc = col_consts(G.Wi.inv_scale, g.b_i);
         const float sA = tile_scale(global_a_max(T_{}, BM, g.d_v, g.d_e, rV, rE, offA1, offA2), 0);
+        stamp();  // 2: init A maximum
         zero_acc(RE{}, h0);
         contract(RE{}, F_{}, T_{}, h0, g.d_v, g.d_e, rV, rE, offA1, offA2, sA, G.Wi);
-        unscale(RE{}, h0, 1.f / sA, G.Wi.inv_scale, g.b_i);
+        prefetch_b(T_steps > 1 ? G.Wh : G.WoM);
+        unscale(RE{}, h0, 1.f / sA, cc);
+        stamp();  // 3: K1 contraction
     }
-    // the staging ring overlaid T16: restore the zeros its pad columns must hold
-    for (int i = tid; i < BM * TS / 16; i += kThreads) reinterpret_cast<float4*>(T16)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.H0) {  // training: the pre-activation is needed by the backward pass
         frag_to_tile(RE{}, h0);
         __syncthreads();
@@ -482,36 +637,37 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
         for (int rt = 0; rt < RT_E; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[rt][ct][r] = tau(h0[rt][ct][r]);
+            for (int ct = 0; ct < WN; ++ct) y[rt][ct] = h0[rt][ct];
+        act_frags(RE{}, F_{}, y, y);
         frag_to_tile(RE{}, y);
     }
     __syncthreads();
     if (tid < 4) maxbits[tid] = 0u;  // slot 0 was consumed before the contraction; re-arm all
     __syncthreads();
     float sA = segment_pass(T_steps == 1, T_steps == 1 ? g.Mv : g.Ms, g.ldh, 1);
+    stamp();  // 4: K1 epilogue + first message
 
     // ================= K3 x (depth - 1): H = tau(H0 + W_h M) =================
     for (int step = 1; step < T_steps; ++step) {
         f32x4 acc[RT_E][WN];
         zero_acc(RE{}, acc);
         const rsrc_t rnull = gemm::make_rsrc(g.W_h, 0);
+        const ColConst cc = col_consts(G.Wh.inv_scale, g.b_h);
         contract(RE{}, T_{}, F_{}, acc, N, 0, rnull, rnull, dummy, dummy, sA, G.Wh);
-        unscale(RE{}, acc, 1.f / sA, G.Wh.inv_scale, g.b_h);
-#pragma unroll
-        for (int rt = 0; rt < RT_E; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[rt][ct][r] = tau(h0[rt][ct][r] + acc[rt][ct][r]);  // H0 + W_h(M): base.py:141
+        stamp();  // 5, 7, ...: update contraction
+        prefetch_b(step + 1 < T_steps ? G.Wh : G.WoM);
+        unscale(RE{}, acc, 1.f / sA, cc);
+        act_frags(RE{}, T_{}, acc, h0);  // tau(H0 + W_h(M)): base.py:141
+        stamp();  // E: unscale + tau
         frag_to_tile(RE{}, acc);
         __syncthreads();
+        stamp();  // E: tile written
         if (g.Hs) tile_to_global(g.Hs + (long long)(step - 1) * g.slot, rs, g.ldh, nrows);
         const bool last = step == T_steps - 1;
         if (tid < 4) maxbits[tid] = 0u;
         __syncthreads();
         sA = segment_pass(last, last ? g.Mv : (g.Ms ? g.Ms + (long long)step * g.slot : nullptr), g.ldh, 2);
+        stamp();  // 6, 8, ...: update epilogue + message / aggregate
     }
 
     // ================= K5: out = tau(W_o [V || Mv] + b_o) on the tile's atoms =================
@@ -519,8 +675,11 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         f32x4 acc[RT_A][WN];
         zero_acc(RA{}, acc);
         const rsrc_t rnull = gemm::make_rsrc(g.W_o, 0);
+        const ColConst cc = col_consts(G.WoM.inv_scale, g.b_o);
         // Mv part first (A = T16 rows 0..atoms-1), then the V part (its staging ring overlays T16)
         contract(RA{}, T_{}, F_{}, acc, N, 0, rnull, rnull, dummy, dummy, sA, G.WoM);
+        stamp();  // finalize: Mv part
+        prefetch_b(G.WoV);
         unsigned offA1[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -540,17 +699,15 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= f;
         }
+        stamp();  // finalize: V maximum
         contract(RA{}, F_{}, F_{}, acc, g.d_v, 0, rV, rnull, offA1, dummy, sV, G.WoV);
-        unscale(RA{}, acc, 1.f / sV, G.WoM.inv_scale, g.b_o);
-#pragma unroll
-        for (int rt = 0; rt < RT_A; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[rt][ct][r] = tau(acc[rt][ct][r]);
+        stamp();  // finalize: V part
+        unscale(RA{}, acc, 1.f / sV, cc);
+        act_frags(RA{}, F_{}, acc, acc);
         frag_to_tile(RA{}, acc);
         __syncthreads();
         tile_to_global(g.out, va, g.ldout, na);
+        stamp();  // output stored
     }
 }
 

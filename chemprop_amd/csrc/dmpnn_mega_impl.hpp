@@ -44,6 +44,7 @@ struct MegaK {
     float* out; int ldout;
     float* H0; float* Hs; float* Ms; float* Mv; int ldh; long long slot;  // kept tensors (training) or null
     unsigned qmagic;
+    long long* dbg;   // optional [32] cycle stamps of workgroup 0 (dmpnn_debug_timestamps), else null
 };
 
 template <int WN>

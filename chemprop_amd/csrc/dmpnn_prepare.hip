@@ -20,6 +20,8 @@
 
 namespace dmpnn {
 
+extern long long* g_debug_stamps;
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -222,9 +224,9 @@ __global__ void k_rows_tiles(int* __restrict__ plan, PlanLayout L, int nV, int n
 // ---- single-workgroup plan for small batches (the launch-bound regime) -------------------------
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallMaxAtoms = 6144;
-constexpr int kSmallMaxEdges = 12288;
+constexpr int kSmallMaxEdges = 10240;
 constexpr int kSmallItems = kSmallMaxAtoms / kSmallThreads;  // 6 counters per thread in the scan
-constexpr int kSmallEPT = kSmallMaxEdges / kSmallThreads;    // 12 edges per thread at most
+constexpr int kSmallEPT = kSmallMaxEdges / kSmallThreads;    // 10 edges per thread at most
 typedef unsigned short u16;
 
 
@@ -269,13 +271,22 @@ __device__ __forceinline__ void block_scan_inclusive(int* a, int n, int* wave_to
 // sequential walk.  X, Y: int scratch of nV + 2 entries each; X enters holding
 // maxnbr[v] = max(v, largest neighbour).  Returns the number of tiles, or -1 when a piece does not fit
 // (the tables are then emptied).
+template <class Other>
 __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const PlanLayout& L, const int* rowp, int* X,
-                                                 int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid) {
+                                                 int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid,
+                                                 Other&& other_work, long long* dbg = nullptr) {
+    int n_st = 0;
+    auto stamp = [&]() {
+        if (dbg && tid == 0 && n_st < 12) dbg[n_st] = (long long)__builtin_readcyclecounter();
+        ++n_st;
+    };
+    stamp();
     int* mrow = plan + L.mtile_row;
     int* matom = plan + L.mtile_atom;
     const int slots = (int)L.max_mtiles + 2;
     constexpr int kMark = 0x40000000;
     block_scan_inclusive<true>(X, nV, wave_tot, tid);          // X[v] = largest neighbour index over atoms <= v
+    stamp();  // p1: prefix max
     int st[kSmallItems];
 #pragma unroll
     for (int j = 0; j < kSmallItems; ++j) {
@@ -290,6 +301,7 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
     }
     __syncthreads();
     block_scan_inclusive<false>(Y, nV, wave_tot, tid);         // Y[u] = number of piece starts <= u
+    stamp();  // p2: start ranks
     const int np = nV > 0 ? Y[nV - 1] : 0;
     __syncthreads();
 #pragma unroll
@@ -299,6 +311,7 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
     }
     if (tid == 0) X[np] = nV;
     __syncthreads();
+    stamp();  // p3: piece starts
     // next tile start (a piece index) for every piece; Y becomes the jump / mark word
     int nx[kSmallItems];
 #pragma unroll
@@ -320,58 +333,54 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
 #pragma unroll
     for (int j = 0; j < kSmallItems; ++j) {
         const int p = tid + kSmallThreads * j;
-        if (p <= np) Y[p] = (p < np ? nx[j] : np) | (p == 0 && np > 0 ? kMark : 0);
+        if (p <= np) Y[p] = (p < np ? nx[j] : np);
     }
     __syncthreads();
-    for (int span = 1; span < np; span <<= 1) {  // after k rounds every chain node at distance < 2^k is marked
-        int jj[kSmallItems];
-#pragma unroll
-        for (int j = 0; j < kSmallItems; ++j) {
-            const int p = tid + kSmallThreads * j;
-            if (p < np) {
-                const int w = Y[p];
-                if ((w & kMark) && (w & ~kMark) < np) atomicOr(&Y[w & ~kMark], kMark);
+    stamp();  // p4: next pointers
+    // The chain of tile starts 0 -> nx[0] -> nx[nx[0]] -> ... is walked by ONE wave, 64 pieces at a time:
+    // lane l holds nx of piece base + l in a register, a hop is a v_readlane (no LDS round trip), the chain
+    // nodes of the block are the set bits of a wave-uniform mask, their rank a popcount.
+    __shared__ int ntile_s;
+    if (tid == 0) ntile_s = 0;
+    __syncthreads();
+    // waves 1..15 write the plan's arrays (other_work) while wave 0 walks the chain (latency bound, ~100
+    // cycles per tile); wave 0 joins the output work afterwards
+    if (tid >= 64) other_work(tid - 64, kSmallThreads - 64);
+    if (tid < 64 && *bad_s == 0) {
+        const int lane = tid;
+        int e = 0, rank = 0;  // next chain node (wave-uniform), tiles emitted so far
+        for (int base = 0; base < np; base += 64) {
+            const int p = base + lane;
+            const int my_nx = p < np ? Y[p] : np;
+            unsigned long long mask = 0ull;
+            int es = __builtin_amdgcn_readfirstlane(e);  // scalar chain cursor: a hop is one v_readlane_b32
+            const int lim = (base + 64 < np ? base + 64 : np);
+            while (es < lim) {
+                mask |= 1ull << (es - base);
+                es = __builtin_amdgcn_readlane(my_nx, es - base);
             }
+            e = es;
+            const bool on = (mask >> lane) & 1ull;
+            const int r = rank + __popcll(mask & ((1ull << lane) - 1ull));
+            if (on && r < (int)L.max_mtiles) {
+                const int v = X[p];
+                mrow[r] = rowp[v];
+                matom[r] = v;
+            }
+            rank += __popcll(mask);
         }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kSmallItems; ++j) {
-            const int p = tid + kSmallThreads * j;
-            jj[j] = p < np ? (Y[Y[p] & ~kMark] & ~kMark) : np;
+        if (lane == 0) {
+            if (rank > (int)L.max_mtiles) atomicOr(bad_s, 1);
+            ntile_s = rank;
         }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kSmallItems; ++j) {
-            const int p = tid + kSmallThreads * j;
-            if (p < np) Y[p] = (Y[p] & kMark) | jj[j];
-        }
-        __syncthreads();
-    }
-    // tile index = rank among the marked pieces (consecutive layout for the scan)
-    int mk[kSmallItems];
-#pragma unroll
-    for (int j = 0; j < kSmallItems; ++j) {
-        const int p = tid * kSmallItems + j;
-        mk[j] = (p < np && (Y[p] & kMark)) ? 1 : 0;
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kSmallItems; ++j) {
-        const int p = tid * kSmallItems + j;
-        if (p < np) Y[p] = mk[j];
-    }
-    __syncthreads();
-    block_scan_inclusive<false>(Y, np, wave_tot, tid);
-    const int n_tiles = np > 0 ? Y[np - 1] : 0;
-    const bool bad = *bad_s != 0 || n_tiles > (int)L.max_mtiles;
+    stamp();  // p5: chain walk
+    const int n_tiles = ntile_s;
+    const bool bad = *bad_s != 0;
     if (bad) {
         for (int t = tid; t < slots; t += kSmallThreads) { mrow[t] = nE; matom[t] = nV; }
         return -1;
-    }
-#pragma unroll
-    for (int j = 0; j < kSmallItems; ++j) {
-        const int p = tid * kSmallItems + j;
-        if (p < np && mk[j]) { const int v = X[p]; mrow[Y[p] - 1] = rowp[v]; matom[Y[p] - 1] = v; }
     }
     for (int t = n_tiles + tid; t < slots; t += kSmallThreads) { mrow[t] = nE; matom[t] = nV; }
     return n_tiles;
@@ -379,17 +388,25 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
 
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* __restrict__ edge_index,
                                                                 const int64_t* __restrict__ rev64,
-                                                                int* __restrict__ plan, PlanLayout L, int nV, int nE) {
+                                                                int* __restrict__ plan, PlanLayout L, int nV, int nE,
+                                                                int light, long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) int lds_i[];
-    // layout: cnt[nV + 2] int | row0[nV + 2] int | dst16[nE] | rev16[nE] | perm16[nE] | inv16[nE]
-    // (the piece-tile phase reuses cnt as X and the dead edge arrays as Y: the host sizes the edge
-    // region as max(8 nE, 4 (nV + 2)) bytes)
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (dbg && threadIdx.x == 0 && n_stamp < 16) dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();
+    // layout: cnt[nV + 2] int | row0[nV + 2] int | src16[nE] | dst16[nE] | rev16[nE] | perm16[nE] | inv16[nE] | Y[nV + 2] int
+    // (the piece-tile phase reuses cnt as X)
     int* cnt = lds_i;
     int* rowp = lds_i + nV + 2;
-    u16* dst16 = reinterpret_cast<u16*>(rowp + nV + 2);
+    u16* src16 = reinterpret_cast<u16*>(rowp + nV + 2);
+    u16* dst16 = src16 + nE;
     u16* rev16 = dst16 + nE;
     u16* perm16 = rev16 + nE;
     u16* inv16 = perm16 + nE;
+    int* Ybuf = reinterpret_cast<int*>(lds_i) + 2 * (nV + 2) + (5 * nE + 1) / 2;  // [nV + 2] scratch of the piece tiles
     __shared__ int wave_tot[kSmallThreads / 64];
     __shared__ int flags_s, maxdeg_s, piece_bad_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -411,8 +428,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
         }
     }
     __syncthreads();  // cnt zeroed
+    stamp();  // 1: int64 arrays loaded
     int bad = 0;
-    int src32[kSmallEPT];
 #pragma unroll
     for (int j = 0; j < kSmallEPT; ++j) {
         const int e = tid + kSmallThreads * j;
@@ -424,37 +441,21 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
                 d = d < 0 ? 0 : (d >= nV ? nV - 1 : d);
                 r = r < 0 ? 0 : (r >= nE ? nE - 1 : r);
             }
-            src32[j] = (int)s;
+            src16[e] = (u16)s;
             dst16[e] = (u16)d;
             rev16[e] = (u16)r;
-            plan[L.src + e] = (int)s;
-            plan[L.dst + e] = (int)d;
-            plan[L.rev + e] = (int)r;
             atomicAdd(&cnt[(int)d], 1);
-        } else {
-            src32[j] = 0;
         }
     }
     __syncthreads();
-    // phase 1b: symmetric-graph invariants, from LDS (src of the reverse edge: one more batched read)
-    {
-        int sr[kSmallEPT];
-#pragma unroll
-        for (int j = 0; j < kSmallEPT; ++j) {
-            const int e = tid + kSmallThreads * j;
-            const int r = e < nE ? rev16[e] : 0;
-            sr[j] = nE > 0 ? (int)edge_index[r] : 0;  // read-only input: no visibility question
-        }
-#pragma unroll
-        for (int j = 0; j < kSmallEPT; ++j) {
-            const int e = tid + kSmallThreads * j;
-            if (e < nE) {
-                const int r = rev16[e];
-                if (rev16[r] != e || sr[j] != dst16[e] || dst16[r] != src32[j]) bad |= PLAN_ASYMMETRIC;
-            }
-        }
+    stamp();  // 2: narrowed + histogram
+    // phase 1b: symmetric-graph invariants, from LDS
+    for (int e = tid; e < nE; e += kSmallThreads) {
+        const int r = rev16[e];
+        if (rev16[r] != e || src16[r] != dst16[e] || dst16[r] != src16[e]) bad |= PLAN_ASYMMETRIC;
     }
     if (bad) atomicOr(&flags_s, bad);
+    stamp();  // 3: validated
     // phase 2: exclusive scan of cnt[0..nV) (6 consecutive counters per thread)
     {
         int v[kSmallItems];
@@ -492,13 +493,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
         if (lane == 0 && md > 0) atomicMax(&maxdeg_s, md);
     }
     __syncthreads();
+    stamp();  // 4: scan
     // phase 3: fill rows (order inside a row is arbitrary here)
     for (int e = tid; e < nE; e += kSmallThreads) {
         const int pos = atomicAdd(&cnt[dst16[e]], 1);
         perm16[pos] = (u16)e;
     }
     __syncthreads();
-    // phase 4: restore increasing edge id inside every row (the reference's summation order)
+    stamp();  // 5: fill
+    // phase 4: restore increasing edge id inside every row (the reference's summation order); the fill
+    // cursor array is dead now and becomes maxnbr[v] = max(v, largest neighbour) for the piece tiles
     for (int v = tid; v < nV; v += kSmallThreads) {
         const int b = rowp[v];
         const int n = rowp[v + 1] - b;
@@ -512,37 +516,48 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
             }
             row[j + 1] = key;
         }
+        cnt[v] = v;
     }
     __syncthreads();
-    // phase 5: inverse permutation
-    for (int i = tid; i < nE; i += kSmallThreads) inv16[perm16[i]] = (u16)i;
-    __syncthreads();
-    // phase 6: everything out — perm, inv, CSR-row coordinates, tile tables, header
+    stamp();  // 6: sort
+    // phase 5: inverse permutation; maxnbr by one LDS atomic per edge
     for (int i = tid; i < nE; i += kSmallThreads) {
-        const int e = perm16[i];
-        plan[L.perm + i] = e;
-        plan[L.inv + i] = inv16[i];
-        int64_t se = edge_index[e];  // read-only input (L2 hit); clamped like plan.src
-        se = se < 0 ? 0 : (se >= nV ? nV - 1 : se);
-        plan[L.srcp + i] = (int)se;
-        plan[L.dstp + i] = dst16[e];
-        plan[L.revp + i] = inv16[rev16[e]];
-        plan[L.ident + i] = i;
+        inv16[perm16[i]] = (u16)i;
+        atomicMax(&cnt[dst16[i]], (int)src16[i]);
     }
+    __syncthreads();
+    stamp();  // 7: inverse
+    // phase 6 (runs on waves 1..15 while wave 0 walks the tile chain of phase 7): everything out.  A light
+    // plan (forward of the fused routes only) skips the six arrays only the general route, the backward
+    // pass and the tests read.
     const TileGeom g = tile_geom(maxdeg_s, nE);
-    write_tiles(plan, L, rowp, nV, nE, g, tid, kSmallThreads);
-    // phase 7: piece tiles.  maxnbr from LDS only (src of row r = dst of the reverse edge on a symmetric graph)
-    for (int v = tid; v < nV; v += kSmallThreads) {
-        int m = v;
-        for (int r = rowp[v]; r < rowp[v + 1]; ++r) m = max(m, (int)dst16[rev16[perm16[r]]]);
-        cnt[v] = m;
-    }
-    __syncthreads();  // the edge arrays are dead from here on: Y overlays them
-    const int n_mtiles = build_piece_tiles(plan, L, rowp, cnt, reinterpret_cast<int*>(dst16), wave_tot, &piece_bad_s, nV, nE, tid);
+    auto outputs = [&](int i0, int n_thr) {
+        for (int i = i0; i < nE; i += n_thr) {
+            const int e = perm16[i];
+            plan[L.perm + i] = e;
+            plan[L.srcp + i] = src16[e];
+            plan[L.revp + i] = inv16[rev16[e]];
+            if (!light) {
+                plan[L.src + i] = src16[i];
+                plan[L.dst + i] = dst16[i];
+                plan[L.rev + i] = rev16[i];
+                plan[L.inv + i] = inv16[i];
+                plan[L.dstp + i] = dst16[e];
+                plan[L.ident + i] = i;
+            }
+        }
+        write_tiles(plan, L, rowp, nV, nE, g, i0, n_thr);
+    };
+    stamp();  // 8: (outputs moved into phase 7)
+    stamp();  // 9: (maxnbr folded into phase 5)
+    // phase 7: piece tiles (scans by the whole workgroup, chain walk by wave 0 || outputs by waves 1..15)
+    const int n_mtiles = build_piece_tiles(plan, L, rowp, cnt, Ybuf, wave_tot, &piece_bad_s, nV, nE, tid, outputs, dbg ? dbg + 16 : nullptr);
+    stamp();  // 10: piece tiles
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
         if (tid == DMPNN_HDR_FLAGS) v = flags_s | (maxdeg_s > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0);
         if (tid == DMPNN_HDR_NMTILES) v = n_mtiles < 0 ? 0 : n_mtiles;
+        if (tid == DMPNN_HDR_LIGHT) v = light;
         if (tid == DMPNN_HDR_MAXDEG) v = maxdeg_s;
         if (tid == DMPNN_HDR_NATOMS) v = nV;
         if (tid == DMPNN_HDR_NEDGES) v = nE;
@@ -555,26 +570,23 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
 }  // namespace
 
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, int64_t nE64,
-                   int* plan, hipStream_t s) {
+                   int* plan, int light, hipStream_t s) {
     const int nV = (int)nV64, nE = (int)nE64;
     const PlanLayout L = plan_layout(nV, nE);
-    if (nV <= kSmallMaxAtoms && nE <= kSmallMaxEdges) {
-        size_t edge_region = (size_t)4 * nE * sizeof(u16), y_region = (size_t)(nV + 2) * sizeof(int);
-        size_t lds = (size_t)(2 * nV + 4) * sizeof(int) + (edge_region > y_region ? edge_region : y_region);
-        lds = (lds + 15) & ~size_t(15);
-        if (lds < 16) lds = 16;
+    if (small_plan_fits(nV, nE)) {
+        const size_t lds = small_plan_lds_bytes(nV, nE);
         static bool attr_set = false;
         if (!attr_set) {
-            const size_t max_lds = (size_t)(2 * kSmallMaxAtoms + 4) * sizeof(int) + (size_t)4 * kSmallMaxEdges * sizeof(u16) + 16;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_small),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
             if (e != hipSuccess) {
                 set_error("hipFuncSetAttribute(k_prepare_small): %s", hipGetErrorString(e));
                 return DMPNN_EHIP;
             }
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(kSmallThreads), lds, s, edge_index, rev, plan, L, nV, nE);
+        hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(kSmallThreads), lds, s, edge_index, rev, plan, L, nV, nE, light,
+                           g_debug_stamps ? g_debug_stamps + 32 : nullptr);
         DMPNN_CHECK_LAUNCH("k_prepare_small");
         return DMPNN_OK;
     }

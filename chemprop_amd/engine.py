@@ -17,6 +17,13 @@ from . import _lib
 from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_SPLIT16, F_UNDIRECTED, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
 
 
+def small_plan_fits(n_atoms: int, n_edges: int) -> bool:
+    """Batches the single-workgroup plan takes (mirror of csrc/dmpnn_common.hpp small_plan_fits): only
+    those get piece tiles, hence the whole-forward tile kernel, and a light plan."""
+    lds = ((3 * (n_atoms + 2)) * 4 + (5 * n_edges + 2) * 2 + 31) & ~15
+    return n_atoms <= 6144 and n_edges <= 10240 and lds <= 160 * 1024 - 512
+
+
 def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -44,9 +51,9 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 class GraphPlan:
     """K0: int32 indices + stable incoming-edge CSR of one batch, built on device (no host sync)."""
 
-    __slots__ = ("buf", "n_atoms", "n_edges", "device")
+    __slots__ = ("buf", "n_atoms", "n_edges", "device", "light")
 
-    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int):
+    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light: bool = False):
         _require_device(edge_index, "edge_index")
         lib = _lib.load()
         dev = edge_index.device
@@ -58,13 +65,17 @@ class GraphPlan:
         nbytes = lib.dmpnn_plan_bytes(n_atoms, n_edges)
         self.buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
         self.n_atoms, self.n_edges, self.device = int(n_atoms), n_edges, dev
+        # a light plan holds only what a forward of the fused routes reads (inference); batches beyond the
+        # single-workgroup plan always get the full one
+        self.light = bool(light) and small_plan_fits(n_atoms, n_edges)
+        prep = lib.dmpnn_prepare_light if self.light else lib.dmpnn_prepare
         with torch.cuda.device(dev):
-            _lib.check(lib.dmpnn_prepare(ei.data_ptr(), rev.data_ptr(), n_atoms, n_edges,
-                                         self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
+            _lib.check(prep(ei.data_ptr(), rev.data_ptr(), n_atoms, n_edges,
+                            self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
 
     @classmethod
-    def from_bmg(cls, bmg) -> "GraphPlan":
-        return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]))
+    def from_bmg(cls, bmg, light: bool = False) -> "GraphPlan":
+        return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]), light=light)
 
     # ---- views for tests / diagnostics (these synchronise) ----
     def arrays(self) -> dict:
@@ -282,6 +293,9 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
                            "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "
                            "<= 6144 atoms and <= 12288 edges)")
     use_fused, use_mega = level >= 1, level >= 2
+    if getattr(plan, "light", False) and (not use_fused or keep):
+        raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
+                           "(build the plan with light=False for the general route or for training)")
 
     st = ForwardState()
     st.fused = use_fused

@@ -118,12 +118,26 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         d_vd = (mp.W_d.in_features - mp.W_o.out_features) if mp.W_d is not None else None
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
-    plan = engine.GraphPlan.from_bmg(bmg)
+    plan = engine.GraphPlan.from_bmg(bmg, light=_light_plan_ok(mp))
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
     return mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols))
 
 
 _VALIDATE_FIRST_N = 2
+
+
+def _light_plan_ok(mp) -> bool:
+    """Inference forward that is certain to take a fused route whatever the batch: the plan may skip the
+    arrays only the general route / the backward pass read (``dmpnn_prepare_light``)."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in mp.parameters()):
+        return False
+    if mp.undirected or (mp.training and mp.dropout.p > 0) or classify_activation(mp.tau)[0] == "custom":
+        return False
+    if os.environ.get("DMPNN_GENERAL", "0") == "1" or getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N:
+        return False  # the first batches may still be routed to the general kernels by the validation
+    d_h, d_in = mp.W_h.weight.shape[0], mp.W_i.weight.shape[1]
+    d_v = mp.W_o.weight.shape[1] - d_h
+    return d_h % 4 == 0 and d_h <= 320 and d_v % 2 == 0 and (d_in - d_v) % 2 == 0
 
 
 def _route(mp, plan, n_mols: int = 0) -> int:

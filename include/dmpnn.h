@@ -79,6 +79,11 @@ size_t dmpnn_plan_bytes(int64_t n_atoms, int64_t n_edges);
 int dmpnn_prepare(const int64_t* edge_index, /* [2, n_edges] row 0 = src atom, row 1 = dst atom */
                   const int64_t* rev_edge_index, /* [n_edges]                                   */
                   int64_t n_atoms, int64_t n_edges, void* plan, size_t plan_bytes, void* stream);
+/* The same, writing only what a FORWARD of the fused routes reads (row_ptr, perm, srcp, revp, the tile
+ * tables, the header): for inference.  dmpnn_backward, the general route and the row kernels need the
+ * full plan.  Batches beyond the single-workgroup plan (6144 atoms / 10240 edges) get the full plan. */
+int dmpnn_prepare_light(const int64_t* edge_index, const int64_t* rev_edge_index, int64_t n_atoms, int64_t n_edges,
+                        void* plan, size_t plan_bytes, void* stream);
 
 /* Plan header words (int32) readable by the caller after a stream sync (diagnostics/tests). */
 enum dmpnn_plan_hdr {
@@ -96,6 +101,8 @@ enum dmpnn_plan_hdr {
     DMPNN_HDR_NTILES = 4,  /* fused row tiles actually used (<= the launch bound)                */
     DMPNN_HDR_TILE_STRIDE = 5,
     DMPNN_HDR_NMTILES = 6, /* piece tiles actually used                                            */
+    DMPNN_HDR_LIGHT = 7,   /* 1: light plan (dmpnn_prepare_light): src / dst / rev / inv / dstp / ident
+                              were NOT written — valid for forwards of the fused routes only           */
     DMPNN_HDR_WORDS = 16
 };
 /* Word offsets of the arrays inside the plan (for tests):
@@ -206,7 +213,7 @@ size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
 /* 1 when the shapes / alignment of `a` allow DMPNN_F_FUSED (d_h % 4 == 0, d_h <= 320, even d_v and
  * d_e, directed), 2 when they also allow DMPNN_F_MEGA (batch within the single-workgroup plan:
- * <= 6144 atoms, <= 12288 edges), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
+ * <= 6144 atoms, <= 10240 edges), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
  * dmpnn_prepare: a fused forward on a graph that violates them returns NaN and leaves the plan flags
  * set (DMPNN_HDR_FLAGS) — run such graphs without DMPNN_F_FUSED. */
 int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a);
@@ -247,6 +254,9 @@ int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, 
  * Misc
  * ------------------------------------------------------------------------------------------- */
 int dmpnn_version(void);
+/* Debug aid: a device buffer of 32 int64 that workgroup 0 of the whole-forward tile kernel fills with
+ * shader-clock stamps at its phase boundaries (NULL switches it off; never set in production). */
+int dmpnn_debug_timestamps(void* device_buf);
 const char* dmpnn_last_error_string(void);
 /* Number of kernels the last dmpnn_forward on this thread enqueued (diagnostics). */
 int dmpnn_last_launch_count(void);

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Phase timing of the split-MFMA whole-forward tile kernel (workgroup 0), from in-kernel cycle stamps."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from chemprop_amd import engine, synth, _lib
+from chemprop_amd.nn import BondMessagePassing
+dev = torch.device("cuda:0")
+lib = _lib.load()
+nm = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+bmg = synth.random_batch(nm, "qm9", seed=1000); bmg.to(dev)
+print("molecules", nm, "edges", bmg.E.shape[0])
+mp = BondMessagePassing().to(dev).eval()
+plan = engine.GraphPlan.from_bmg(bmg)
+buf = torch.zeros(64, dtype=torch.int64, device=dev)
+fw = lambda: engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega", mfma="split16")
+with torch.no_grad():
+    for _ in range(5): fw()
+    lib.dmpnn_debug_timestamps(buf.data_ptr())
+    plan = engine.GraphPlan.from_bmg(bmg)
+    fw(); torch.cuda.synchronize()
+    lib.dmpnn_debug_timestamps(None)
+st = buf.cpu().tolist()
+names = ["entry", "meta", "init A max", "K1 contract", "K1 epilogue+msg", "upd1 contract", "upd1 unscale+tau", "upd1 tile written",
+         "u1 sums", "u1 msgs", "u1 scale", "u1 pads", "upd1 split written", "upd2 contract", "upd2 unscale+tau", "upd2 tile written", "u2 sums", "u2 msgs", "u2 scale", "u2 pads", "upd2 split written",
+         "fin Mv part", "fin V max", "fin V part", "out stored"]
+prev = st[0]
+for i, n in enumerate(names):
+    if i < len(st) and st[i]:
+        print(f"{n:18s} +{(st[i]-prev):8d} cycles   (t={(st[i]-st[0])})")
+        prev = st[i]
+
+print("--- plan kernel (k_prepare_small)")
+pn = ["entry", "int64 loaded", "narrow+hist", "validate", "scan", "fill", "sort", "inverse", "outputs+atom tiles", "maxnbr", "piece tiles"]
+ps = st[32:]
+prev = ps[0]
+for i, n in enumerate(pn):
+    if ps[i]:
+        print(f"{n:20s} +{(ps[i]-prev):8d} cycles   (t={(ps[i]-ps[0])})")
+        prev = ps[i]
+
+print("--- piece tiles")
+qs = st[48:]
+prev = qs[0]
+for i, n in enumerate(["entry", "prefix max", "start ranks", "piece starts", "next ptrs", "chain walk"]):
+    if qs[i]:
+        print(f"{n:20s} +{(qs[i]-prev):8d} cycles"); prev = qs[i]

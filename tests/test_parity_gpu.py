@@ -12,6 +12,13 @@ import pytest
 import torch
 
 from conftest import TOL, parity_err
+
+
+def small_fits(nV, nE):
+    from chemprop_amd.engine import small_plan_fits
+
+    return small_plan_fits(nV, nE)
+
 from oracle import dmpnn_numpy as onp
 from oracle import dmpnn_torch as ot
 
@@ -51,7 +58,8 @@ def test_plan_is_bit_exact(golden, gpu_device):
     assert n_tiles <= n_slots and (np.diff(tile_row) <= 48).all() and (np.diff(tile_row) >= 0).all()
     # row tiles of whole connected pieces (whole-forward tile kernel); built by the single-workgroup plan
     m_slots = len(a["mtile_row"]) - 2
-    small = nV <= 6144 and len(perm) <= 12288
+    from chemprop_amd.engine import small_plan_fits
+    small = small_plan_fits(nV, len(perm))
     if small and onp.graph_is_symmetric(src, dst, rev):
         mrow, matom, n_m = onp.piece_tiles(src, dst, row_ptr, m_slots)
         assert bool(a["hdr"][0] & 8) == (n_m < 0)
@@ -59,6 +67,20 @@ def test_plan_is_bit_exact(golden, gpu_device):
         assert np.array_equal(a["mtile_row"], mrow) and np.array_equal(a["mtile_atom"], matom)
     elif not small:
         assert a["hdr"][0] & 8 and a["hdr"][6] == 0
+
+
+def test_light_plan_matches_full_plan(golden, gpu_device):
+    """dmpnn_prepare_light writes the same row_ptr / perm / srcp / revp / tile tables / header as the full plan."""
+    from chemprop_amd.engine import GraphPlan
+
+    ei = torch.from_numpy(golden["edge_index"]).to(gpu_device)
+    rev = torch.from_numpy(golden["rev_edge_index"]).to(gpu_device)
+    full = GraphPlan(ei, rev, golden["V"].shape[0]).arrays()
+    lp = GraphPlan(ei, rev, golden["V"].shape[0], light=True)
+    light = lp.arrays()
+    for k in ("row_ptr", "perm", "srcp", "revp", "tile_row", "tile_atom", "mtile_row", "mtile_atom"):
+        assert torch.equal(full[k], light[k]), k
+    assert torch.equal(full["hdr"][:7], light["hdr"][:7]) and int(light["hdr"][7]) == int(lp.light)
 
 
 def test_message_kernel_bit_exact(golden, gpu_device):
@@ -186,7 +208,7 @@ def test_whole_forward_tile_kernel(golden, gpu_device):
         pytest.skip("fused routes do not apply (odd feature width)")
     if str(golden.cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
         pytest.skip("custom activation: rows route")
-    if golden["V"].shape[0] > 6144 or golden["E"].shape[0] > 12288:
+    if not small_fits(golden["V"].shape[0], golden["E"].shape[0]):
         pytest.skip("batch beyond the single-workgroup plan")
     plan, out_m, st_m = _engine_forward(golden, gpu_device, route="mega", keep=True, mfma="f32")
     assert st_m.route == "mega"
@@ -216,7 +238,7 @@ def test_whole_forward_tile_kernel_split_f16(golden, gpu_device):
         pytest.skip("fused routes do not apply (odd feature width)")
     if str(golden.cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
         pytest.skip("custom activation: rows route")
-    if golden["V"].shape[0] > 6144 or golden["E"].shape[0] > 12288:
+    if not small_fits(golden["V"].shape[0], golden["E"].shape[0]):
         pytest.skip("batch beyond the single-workgroup plan")
     plan, out_s, st_s = _engine_forward(golden, gpu_device, route="mega", keep=True, mfma="split16")
     assert st_s.route == "mega16"
