@@ -167,7 +167,9 @@ def main():
         "metric": "million directed-edge-updates/sec (depth=%d, hidden=%d)" % (args.depth, args.hidden),
         "value": round(value, 3), "unit": "M edge-updates/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (contractions: 3-term exact f16 split of the fp32 operands, fp32 accumulate; fp32-MFMA build: DMPNN_MFMA=f32)"
+                 if os.environ.get("DMPNN_MFMA", "split16") != "f32" else "f32", "data": "synthetic",
         "config": {"workload": f"{args.kind}-shaped synthetic molecules, {args.mols} mols/GPU/step, "
                                f"BondMessagePassing depth={args.depth} hidden={args.hidden}, "
                                + ("forward+backward" + ("+RCCL grad all-reduce" if world > 1 else "") if train else "forward (plan K0 + K1..K5)"),
@@ -182,19 +184,50 @@ def main():
         out["graph_error"] = graph_err
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: the fused per-depth update (K3 + K2), live HIP-event timing ----
-        # k_gemm<EPI_SEG>: H' = relu(H0 + M W_h^T), then M_next[rev r] = S[dst r] - H'[r] from the LDS tile.
-        # fp32 has no reduced-precision matrix path on gfx950: the exact fp32 MFMA (157.3 TF) bounds it.
+        # ---- roofline of the dominant kernel, live HIP-event timing on the launch stream ----
         h = args.hidden
         plan = engine.GraphPlan.from_bmg(bmg)
+        Wh = mp.W_h.weight.detach()
+        fusable = h % 4 == 0 and h <= 320
+        fwd_flop = 2.0 * nE * (d_v + d_e) * h + 2.0 * nE * h * h * (args.depth - 1) + 2.0 * nV * (d_v + h) * h
+        route_used = None
+        try:
+            with torch.no_grad():
+                _, st0 = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias,
+                                        depth=args.depth)
+            route_used = st0.route
+        except Exception as e:
+            out["route_error"] = f"{type(e).__name__}: {e}"[:200]
+        out["route"] = route_used
+        if route_used in ("mega16", "mega"):
+            # ONE launch = the whole forward of every tile of whole molecules (k_mpnn_tile16 / k_mpnn_tile)
+            def kdom():
+                with torch.no_grad():
+                    engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=args.depth)
+            run_steps(kdom, 10)
+            t_dom = time_events(kdom, 50, torch)
+            if route_used == "mega16":
+                kname = ("k_mpnn_tile16<5> (+ k_split_weights): whole forward per tile of whole molecules in one launch; "
+                         "contractions as 3 x v_mfma_f32_16x16x32_f16 on exactly split fp32 operands (x s = hi + lo), fp32 accumulate")
+                peak, peak_note = 2500.0 / 3.0, "f16 MFMA dense peak 2.5 PF / 3 MFMA passes per fp32 product"
+            else:
+                kname = "k_mpnn_tile<5>: whole forward per tile in one launch, exact fp32 MFMA 16x16x4"
+                peak, peak_note = PEAK_FP32_MFMA_TF, "fp32 MFMA (= vector) peak"
+            achieved = fwd_flop / (t_dom * 1e-3) / 1e12
+            # algorithmic bytes of the launch: features + indices in, output out, weights once (they stream from L2 per tile)
+            bytes_dom = 4.0 * (nV * d_v + nE * d_e + nV * h) + 12.0 * nE + 4.0 * h * ((d_v + d_e) + h + (d_v + h))
+            out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1),
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
+                               "launch_us": round(t_dom * 1e3, 3), "flop_per_launch": fwd_flop,
+                               "algorithmic_bytes_per_launch": bytes_dom,
+                               "frac_of_fp32_mfma_peak": round(achieved / PEAK_FP32_MFMA_TF, 4),
+                               "note": "launch time includes the weight pre-split kernel; H / M never leave the CU in this route"}
         Mbuf = torch.randn(nE, h, device=dev)
         H0buf = torch.randn(nE, h, device=dev)
         Mnext = torch.empty(nE, h, device=dev)
-        Wh = mp.W_h.weight.detach()
-        fusable = h % 4 == 0 and h <= 320
         if fusable:
             k3 = lambda: engine.update_fused(plan, Mbuf, H0buf, Wh, None, act="relu", want_M=True, M_next=Mnext)
-            kname = "k_gemm<3,5,4,false,EPI_SEG> (fused per-depth update: H'=relu(H0+M@W_h^T); M_next[rev]=S[dst]-H', fp32 MFMA 16x16x4)"
+            kname = "k_gemm<3,5,4,false,EPI_SEG> (per-step fused update: H'=relu(H0+M@W_h^T); M_next[rev]=S[dst]-H', fp32 MFMA 16x16x4)"
         else:
             Cbuf = torch.empty(nE, h, device=dev)
             k3 = lambda: engine.linear(Mbuf, Wh, None, Cadd=H0buf, act="relu", out=Cbuf)
@@ -209,13 +242,19 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pmc.get("directed_edges") == nE and pmc.get("hidden") == h:
                 traffic = pmc.get("update_kernel_bytes_per_launch")
+                if "roofline" in out and pmc.get("mega_kernel_bytes_per_launch"):
+                    out["roofline"]["traffic"] = pmc.get("mega_kernel_bytes_per_launch")
         except Exception:
             pass
-        out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TF,
-                           "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TF, 4), "traffic": traffic,
-                           "launch_us": round(t_k3 * 1e3, 3), "flop_per_launch": flops,
-                           "algorithmic_bytes_per_launch": bytes_k3,
-                           "algorithmic_GBps": round(bytes_k3 / (t_k3 * 1e-3) / 1e9, 1)}
+        step_roof = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TF,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TF, 4), "traffic": traffic,
+                     "launch_us": round(t_k3 * 1e3, 3), "flop_per_launch": flops,
+                     "algorithmic_bytes_per_launch": bytes_k3,
+                     "algorithmic_GBps": round(bytes_k3 / (t_k3 * 1e-3) / 1e9, 1)}
+        if "roofline" in out:
+            out["roofline_per_step_kernel"] = step_roof   # the per-depth-step kernel of the fused route (large batches)
+        else:
+            out["roofline"] = step_roof
         # per-kernel breakdown of one forward (HIP events around each C-ABI call)
         try:
             Hn = torch.empty(nE, h, device=dev)

@@ -53,8 +53,12 @@ try:
 except Exception:
     pass
 upd = [r for r in rows if "k_gemmILi3ELi5ELi4ELb0ELi1" in r["kernel"] or ("k_gemm<3, 5, 4, false, 1>" in r["kernel"])]
-if upd and bench:
+meg = [r for r in rows if "k_mpnn_tile16" in r["kernel"]]
+if meg:
+    res["mega_kernel_bytes_per_launch"] = meg[0]["hbm_bytes_per_launch"]
+if upd:
     res["update_kernel_bytes_per_launch"] = upd[0]["hbm_bytes_per_launch"]
+if bench:
     res["directed_edges"] = bench.get("config", {}).get("directed_edges_per_gpu")
     res["hidden"] = 300
 json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
