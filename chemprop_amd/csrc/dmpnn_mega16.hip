@@ -21,10 +21,11 @@ WsLayout ws_layout(const dmpnn_fwd_args& a) {
     const size_t N = (size_t)a.d_h;
     L.nc_i = (int)((a.d_v + a.d_e + 31) / 32); L.nc_h = (int)((a.d_h + 31) / 32); L.nc_v = (int)((a.d_v + 31) / 32);
     size_t o = 0;
-    L.wi = o; o += al256(N * L.nc_i * 128);
-    L.wh = o; o += al256(N * L.nc_h * 128);
-    L.wom = o; o += al256(N * L.nc_h * 128);
-    L.wov = o; o += al256(N * L.nc_v * 128);
+    const size_t NT = (N + 15) / 16;  // column tiles: the packed layout is [tile][chunk][hi|lo][64 lanes][16 B]
+    L.wi = o; o += al256(NT * L.nc_i * 2048);
+    L.wh = o; o += al256(NT * L.nc_h * 2048);
+    L.wom = o; o += al256(NT * L.nc_h * 2048);
+    L.wov = o; o += al256(NT * L.nc_v * 2048);
     L.sc_i = o; o += al256(N * 4);
     L.sc_h = o; o += al256(N * 4);
     L.sc_o = o; o += al256(N * 4);

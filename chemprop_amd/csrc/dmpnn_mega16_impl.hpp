@@ -41,9 +41,10 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int ROWB = 144;  // bytes of one staged operand row of a chunk: [hi 32 halfs | lo 32 halfs] + 16 pad
 
-// Packed pre-split weight matrix: rows of nc chunks x 128 bytes, plus the inverse scale of every row.
+// Packed pre-split weight matrix in fragment-major order [column tile][chunk][hi|lo][lane][16 B] (see k_split_weights),
+// plus the inverse scale of every row.
 struct SplitW {
-    const unsigned char* p;  // [N][nc][128]
+    const unsigned char* p;  // [ceil(N/16)][nc][2][64][16 B]
     const float* inv_scale;  // [N]  1 / s_n
     int nc;
 };
@@ -88,20 +89,24 @@ __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     const float s = scale_for(mx);
     if (lane == 0 && J.inv_scale) J.inv_scale[n] = 1.f / s;
-    _Float16* out = reinterpret_cast<_Float16*>(J.out + (long long)n * J.nc * 128);
+    // Fragment-major layout: the 16 B a lane of the tile kernel loads for (column tile T = n / 16, chunk c,
+    // part hi|lo) are contiguous per wave instruction: [T][c][part][lg][li][8 halfs]  (1 KiB per instruction).
+    _Float16* out = reinterpret_cast<_Float16*>(J.out);
+    const int T = n >> 4, li = n & 15;
     for (int k = lane; k < J.nc * 32; k += 64) {
         const float x = k < J.K ? row[J.col0 + k] * s : 0.f;
         const _Float16 hi = (_Float16)x;
         const _Float16 lo = (_Float16)(x - (float)hi);
-        const int c = k >> 5, kk = k & 31;
-        out[c * 64 + kk] = hi;
-        out[c * 64 + 32 + kk] = lo;
+        const int c = k >> 5, kk = k & 31, lg = kk >> 3, j = kk & 7;
+        const long long base = (((long long)T * J.nc + c) * 2) * 512 + (lg * 16 + li) * 8 + j;
+        out[base] = hi;
+        out[base + 512] = lo;
     }
 }
 
 template <int WN>
 constexpr size_t lds_bytes() {
-    return (size_t)kMegaBM * (64 * WN * 4 + 16) + (size_t)2 * (64 * WN) * ROWB + (size_t)(2 * kMegaBM + kMegaBA + 24) * sizeof(int);
+    return (size_t)kMegaBM * (64 * WN * 4 + 16) * 2 + (size_t)(2 * kMegaBM + kMegaBA + 24) * sizeof(int);
 }
 
 template <int WN>
@@ -110,17 +115,14 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
     constexpr int TS = BN * 4 + 16;            // bytes of one row of the split A tile: BN/32 chunks x 128 + 16
     constexpr int ITEMS = BM * QN / kThreads;
-    constexpr int SLOTS_B = BN * 8 / kThreads;  // 16-byte pieces of the B chunk per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* T16 = lds;                               // [BM][TS]   split A operand of the LDS-A contractions
     unsigned char* As = lds;                                // [2][BM][ROWB] staging ring of the global-A contractions (overlays T16)
-    unsigned char* Bs = lds + BM * TS;                      // [2][BN][ROWB]
-    float* T = reinterpret_cast<float*>(Bs);                // [BM][LDC] fp32 epilogue tile (overlays the idle B ring)
-    int* revl = reinterpret_cast<int*>(Bs + 2 * BN * ROWB); // [BM]
+    float* T = reinterpret_cast<float*>(lds + BM * TS);     // [BM][LDC] fp32 epilogue tile
+    int* revl = reinterpret_cast<int*>(lds + BM * TS + BM * LDC * 4);  // [BM]
     int* aor = revl + BM;                                   // [BM]
     int* rp = aor + BM;                                     // [BA + 1]
     unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [0..3] tile maxima (float bits), [4] tile max in-degree
-    static_assert(BM * LDC * 4 <= 2 * BN * ROWB, "epilogue tile must fit the B ring");
 
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -179,23 +181,40 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         return scale_for(mx);
     };
 
+    // ---- weight fragments: straight from L2 to registers --------------------------------------------
+    // The four waves of a workgroup own disjoint column ranges, so a weight element is used by exactly one
+    // wave: staging the weight tile in LDS would buy no reuse and cost a write + a read + a barrier per
+    // chunk.  Lane (li, lg) of column tile ct reads its own fragment of chunk c from the pre-split layout:
+    // hi 16 B at [col][c][lg*16], lo at +64 (col = wave*16*WN + ct*16 + li; col >= N is out of range: 0).
+    auto load_bfrags = [&](rsrc_t rW, const unsigned (&offB)[WN], int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0);
+            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0);
+            bh[ct] = __builtin_bit_cast(h8, vh);
+            bl[ct] = __builtin_bit_cast(h8, vl);
+        }
+    };
+    auto bfrag_offsets = [&](const SplitW& W, unsigned (&offB)[WN]) {
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)  // fragment-major layout [column tile][chunk][hi|lo][lane][16 B]
+            offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
+    };
     // chunk 0 of the NEXT contraction's weights, fetched into registers while the current epilogue runs
-    u32x4 preB[SLOTS_B];
+    h8 preBh[WN], preBl[WN];
     bool have_pre = false;
     auto prefetch_b = [&](const SplitW& W) {
-        launder();
-        const rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(N * W.nc * 128));
-#pragma unroll
-        for (int j = 0; j < SLOTS_B; ++j) {
-            const int col = (tid + kThreads * j) >> 3;
-            preB[j] = __builtin_amdgcn_raw_buffer_load_b128(rW, (unsigned)col * (unsigned)(W.nc * 128) + (unsigned)kq * 16u, 0, 0);
-        }
+        unsigned offB[WN];
+        bfrag_offsets(W, offB);
+        load_bfrags(gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048)), offB, 0, preBh, preBl);
         have_pre = true;
     };
 
     // ---- one contraction: acc[RT][WN] += (A s_A) . (W s_W)^T in the split domain -------------------
-    // A_LDS: A fragments straight from T16;  else A = [A1 | A2] fp32 from global memory, scaled by sA and
-    // split while it is staged (ring overlays T16).  B: pre-split packed weights, plain 16-byte staging.
+    // A_LDS: A fragments straight from T16 (static during the contraction: NO barrier in the main loop);
+    // else A = [A1 | A2] fp32 from global memory, scaled by sA and split while it is staged through the LDS
+    // ring (shared by the four waves; one barrier per chunk; the ring overlays T16).
     auto contract = [&](auto rt_c, auto a_lds_c, auto has_a2_c, f32x4 (&acc)[decltype(rt_c)::value][WN], int K1, int K2,
                         rsrc_t rA1, rsrc_t rA2, const unsigned (&offA1)[2], const unsigned (&offA2)[2], float sA,
                         const SplitW& W) {
@@ -205,16 +224,11 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         constexpr int SLOTS_A = A_LDS ? 0 : (BMr * 8 + kThreads - 1) / kThreads;  // fp32 quads of the A chunk per thread (<= 2)
         const int K = K1 + K2;
         const int n_chunks = A_LDS ? (K + BK - 1) / BK : W.nc;
-        const rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(N * W.nc * 128));
-        launder();
-        unsigned offB[SLOTS_B];
-#pragma unroll
-        for (int j = 0; j < SLOTS_B; ++j) {
-            const int col = (tid + kThreads * j) >> 3;
-            offB[j] = (unsigned)col * (unsigned)(W.nc * 128) + (unsigned)kq * 16u;  // col >= N is out of range: reads 0
-        }
-        u32x4 stA[SLOTS_A > 0 ? SLOTS_A : 1], stB[SLOTS_B];
-        auto load_chunk = [&](int c, bool skip_b = false) {
+        const rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048));  // column tiles beyond N: out of range, 0
+        unsigned offB[WN];
+        bfrag_offsets(W, offB);
+        u32x4 stA[SLOTS_A > 0 ? SLOTS_A : 1];
+        auto load_a = [&](int c) {
             const int kk = c * BK + kq * 4;
             unsigned k1o[2], k2o[2];
 #pragma unroll
@@ -233,15 +247,9 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                 }
                 stA[j] = v;
             }
-            if (!skip_b) {
-#pragma unroll
-                for (int j = 0; j < SLOTS_B; ++j)
-                    stB[j] = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[j] + (unsigned)c * 128u, 0, 0);
-            }
         };
-        auto store_chunk = [&](int slot) {
+        auto store_a = [&](int slot) {
             unsigned char* Ad = As + slot * BMr * ROWB;
-            unsigned char* Bd = Bs + slot * BN * ROWB;
 #pragma unroll
             for (int j = 0; j < SLOTS_A; ++j) {
                 const int r = (tid + kThreads * j) >> 3;
@@ -252,59 +260,33 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                     *reinterpret_cast<h4*>(Ad + r * ROWB + 64 + kq * 8) = lo;
                 }
             }
-#pragma unroll
-            for (int j = 0; j < SLOTS_B; ++j) {
-                const int n = (tid + kThreads * j) >> 3;
-                *reinterpret_cast<u32x4*>(Bd + n * ROWB + kq * 16) = stB[j];
-            }
         };
-        auto read_frags = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN]) {
-            const int slot = c & 1;
-            const unsigned char* Bc = Bs + slot * BN * ROWB + wave * (16 * WN) * ROWB;
+        auto read_afrags = [&](int c, h8 (&ah)[RT], h8 (&al)[RT]) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const unsigned char* p = A_LDS ? T16 + (rt * 16 + li) * TS + c * 128 + lg * 16
-                                               : As + slot * BMr * ROWB + (rt * 16 + li) * ROWB + lg * 16;
+                                               : As + (c & 1) * BMr * ROWB + (rt * 16 + li) * ROWB + lg * 16;
                 ah[rt] = *reinterpret_cast<const h8*>(p);
                 al[rt] = *reinterpret_cast<const h8*>(p + 64);
             }
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct) {
-                const unsigned char* p = Bc + (ct * 16 + li) * ROWB + lg * 16;
-                bh[ct] = *reinterpret_cast<const h8*>(p);
-                bl[ct] = *reinterpret_cast<const h8*>(p + 64);
-            }
         };
-        // One k-chunk = 3 x RT x WN MFMAs.  The staging traffic of the following chunks is issued in the
-        // shadow of the hi.hi block (one LDS write + global loads per MFMA), the fragments of chunk c+1 are
-        // read in the shadow of the hi.lo / lo.hi blocks: with one wave per SIMD nothing else hides them.
-        constexpr int N_WR = SLOTS_B + 2 * SLOTS_A;
-        constexpr int N_LD = SLOTS_B + SLOTS_A * 2 * (HAS_A2 ? 2 : 1);
-        constexpr int N_M1 = RT * WN;
-        constexpr int N_RD = 2 * (RT + WN);
+        // One k-chunk = 3 x RT x WN MFMAs on (ah, al, bh, bl).  While they run: the A staging of chunk c+1
+        // (global-A only), the A fragments of chunk c+1 into (nah, nal), and — once the last MFMA that reads
+        // (bh, bl) has been issued — the weight fragments of chunk c+2 into the same registers.
         auto chunk = [&](auto has_next, auto has_next2, int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN],
-                         h8 (&nah)[RT], h8 (&nal)[RT], h8 (&nbh)[WN], h8 (&nbl)[WN]) {
+                         h8 (&nah)[RT], h8 (&nal)[RT]) {
             constexpr bool NEXT = decltype(has_next)::value, NEXT2 = decltype(has_next2)::value;
-            if constexpr (NEXT) store_chunk((c + 1) & 1);
-            if constexpr (NEXT2) load_chunk(c + 2);
+            if constexpr (!A_LDS && NEXT) store_a((c + 1) & 1);
+            if constexpr (!A_LDS && NEXT2) load_a(c + 2);
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
-            if constexpr (NEXT) {
-                constexpr int WR_PER = (N_WR + N_M1 - 1) / N_M1, LD_PER = NEXT2 ? (N_LD + N_M1 - 1) / N_M1 : 0;
-#pragma unroll
-                for (int i = 0; i < N_M1; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, WR_PER, 0);
-                    if constexpr (LD_PER > 0) __builtin_amdgcn_sched_group_barrier(0x020, LD_PER, 0);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NEXT) {
-                __syncthreads();
-                read_frags(c + 1, nah, nal, nbh, nbl);
+                if constexpr (!A_LDS) __syncthreads();  // chunk c+1 of A is in the ring for every wave
+                read_afrags(c + 1, nah, nal);
             }
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
@@ -316,50 +298,45 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
-            if constexpr (NEXT) {
-#pragma unroll
-                for (int i = 0; i < N_RD; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NEXT2) load_bfrags(rW, offB, c + 2, bh, bl);
         };
-        using T_ = std::true_type;
-        using F_ = std::false_type;
         h8 a0h[RT], a0l[RT], b0h[WN], b0l[WN], a1h[RT], a1l[RT], b1h[WN], b1l[WN];
-        __syncthreads();  // the previous phase is done with T16 / the rings / T
-        launder();
         if (have_pre) {  // (uniform) the weights of chunk 0 were fetched during the previous epilogue
 #pragma unroll
-            for (int j = 0; j < SLOTS_B; ++j) stB[j] = preB[j];
-            load_chunk(0, true);
+            for (int ct = 0; ct < WN; ++ct) { b0h[ct] = preBh[ct]; b0l[ct] = preBl[ct]; }
             have_pre = false;
         } else {
-            load_chunk(0);
+            load_bfrags(rW, offB, 0, b0h, b0l);
         }
-        store_chunk(0);
-        if (n_chunks > 1) load_chunk(1);
-        __syncthreads();
-        read_frags(0, a0h, a0l, b0h, b0l);
+        if (n_chunks > 1) load_bfrags(rW, offB, 1, b1h, b1l);
+        __syncthreads();  // the previous phase is done with T16 / the A ring / T
+        launder();
+        if constexpr (!A_LDS) {
+            load_a(0);
+            store_a(0);
+            if (n_chunks > 1) load_a(1);
+            __syncthreads();
+        }
+        read_afrags(0, a0h, a0l);
         __builtin_amdgcn_sched_barrier(0);
         int c = 0;
         for (; c + 3 < n_chunks; c += 2) {
-            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
-            chunk(T_{}, T_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l, b0h, b0l);
+            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
+            chunk(T_{}, T_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l);
         }
         const int left = n_chunks - c;
         if (left == 3) {
-            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
-            chunk(T_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l, b0h, b0l);
-            chunk(F_{}, F_{}, c + 2, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
+            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
+            chunk(T_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l);
+            chunk(F_{}, F_{}, c + 2, a0h, a0l, b0h, b0l, a1h, a1l);
         } else if (left == 2) {
-            chunk(T_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
-            chunk(F_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l, b0h, b0l);
+            chunk(T_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
+            chunk(F_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l);
         } else {
-            chunk(F_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l, b1h, b1l);
+            chunk(F_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
         }
-        __syncthreads();
+        __syncthreads();  // every wave is done with T16 / the A ring before the epilogue reuses LDS
     };
     // maximum |x| of the A operand a global-A contraction is going to stage (same loads, L2 hits later)
     auto global_a_max = [&](auto has_a2_c, int rows_cap, int K1, int K2, rsrc_t rA1, rsrc_t rA2, const unsigned (&offA1)[2],
