@@ -53,7 +53,7 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     sp.job[1] = mega16::SplitJob{a.W_h, N, 0, N, 0, N, ws + W.wh, W.nc_h, reinterpret_cast<float*>(ws + W.sc_h)};
     sp.job[2] = mega16::SplitJob{a.W_o, dv + N, dv, N, 0, dv + N, ws + W.wom, W.nc_h, reinterpret_cast<float*>(ws + W.sc_o)};
     sp.job[3] = mega16::SplitJob{a.W_o, dv + N, 0, dv, 0, dv + N, ws + W.wov, W.nc_v, nullptr};
-    hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)((4 * N + 3) / 4)), dim3(256), 0, s, sp);
+    hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)(((N + 15) / 16) * 16)), dim3(256), 0, s, sp);  // 4 jobs x whole column tiles, 4 waves per block
     DMPNN_CHECK_LAUNCH("k_split_weights");
 
     const PlanLayout L = plan_layout(nV, nE);

@@ -80,21 +80,23 @@ struct SplitArgs {
 __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int j = wave / a.N, n = wave - j * a.N;
+    const int Np = (a.N + 15) & ~15;  // whole column tiles: the padding rows of the last tile are written as zeros
+    const int j = wave / Np, n = wave - j * Np;
     if (j >= a.n_jobs) return;
     const SplitJob& J = a.job[j];
-    const float* row = J.W + (long long)n * J.ldw;
+    const bool live = n < a.N;
+    const float* row = J.W + (long long)(live ? n : 0) * J.ldw;
     float mx = 0.f;
     for (int k = lane; k < J.scale_K; k += 64) mx = fmaxf(mx, fabsf(row[J.scale_col0 + k]));
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    const float s = scale_for(mx);
-    if (lane == 0 && J.inv_scale) J.inv_scale[n] = 1.f / s;
+    const float s = live ? scale_for(mx) : 0.f;
+    if (lane == 0 && J.inv_scale && live) J.inv_scale[n] = 1.f / s;
     // Fragment-major layout: the 16 B a lane of the tile kernel loads for (column tile T = n / 16, chunk c,
     // part hi|lo) are contiguous per wave instruction: [T][c][part][lg][li][8 halfs]  (1 KiB per instruction).
     _Float16* out = reinterpret_cast<_Float16*>(J.out);
     const int T = n >> 4, li = n & 15;
     for (int k = lane; k < J.nc * 32; k += 64) {
-        const float x = k < J.K ? row[J.col0 + k] * s : 0.f;
+        const float x = (k < J.K && live) ? row[J.col0 + k] * s : 0.f;
         const _Float16 hi = (_Float16)x;
         const _Float16 lo = (_Float16)(x - (float)hi);
         const int c = k >> 5, kk = k & 31, lg = kk >> 3, j = kk & 7;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
 
 template <int WN>
 constexpr size_t lds_bytes() {
-    return (size_t)kMegaBM * (64 * WN * 4 + 16) * 2 + (size_t)(2 * kMegaBM + kMegaBA + 24) * sizeof(int);
+    return (size_t)kMegaBM * (64 * WN * 4 + 16) * 2 + (size_t)(2 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
 }
 
 template <int WN>
@@ -122,7 +124,9 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     int* revl = reinterpret_cast<int*>(lds + BM * TS + BM * LDC * 4);  // [BM]
     int* aor = revl + BM;                                   // [BM]
     int* rp = aor + BM;                                     // [BA + 1]
-    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [0..3] tile maxima (float bits), [4] tile max in-degree
+    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [0..3] tile maxima (float bits, rotating), [4] spare
+    // [10][64] incidence fragments of the segment MFMAs (see segment_mfma): 16-byte aligned behind the metadata
+    h8* cfrag = reinterpret_cast<h8*>(lds + BM * TS + BM * LDC * 4 + (((2 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);
 
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -165,19 +169,53 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     if (tid <= BA) rp[tid] = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
     if (tid < 8) maxbits[tid] = 0u;
     __syncthreads();
-    if (tid < na) {
+    if (tid < na)
         for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
-        atomicMax(&maxbits[4], (unsigned)(rp[tid + 1] - rp[tid]));
+    __syncthreads();
+    // Incidence fragments (B operands of the segment MFMAs, constant over the depth loop).  The k index of
+    // those MFMAs runs over the tile's rows in the order the C/D fragments of a contraction already hold
+    // them: k-step 0, lane group lg, slot s -> row lg*4+s (s<4) | 16+lg*4+(s-4);  k-step 1 -> row 32+lg*4+s
+    // (s<4) | none.  Fragments 0..5: message, C[r'][r] = 1 iff r enters the source atom of r' and r != rev(r')
+    // (message_passing/base.py:144-146 with the reverse edge's cancelling term left out of the sum);
+    // 6..9: aggregate, C[a][r] = 1 iff r enters atom a (base.py:208-211).
+    for (int f = wave; f < 10; f += 4) {
+        const bool agg = f >= 6;
+        const int ff = agg ? f - 6 : f, jt = ff >> 1, ks = ff & 1;
+        const int j = jt * 16 + li;
+        int a_t = -1, rv = -1;
+        if (agg) {
+            a_t = j < na ? j : -1;
+        } else if (j < nrows) {
+            rv = revl[j];
+            a_t = aor[rv];
+        }
+        h8 v;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const int row = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
+            const bool on = row >= 0 && row < nrows && aor[row < 0 ? 0 : row] == a_t && row != rv;
+            v[sl] = on ? (_Float16)1.f : (_Float16)0.f;
+        }
+        cfrag[f * 64 + lane] = v;
     }
     __syncthreads();
-    const int tile_maxdeg = (int)maxbits[4];
 
-    // tile maximum of |x| over per-thread values -> exact power-of-two scale (slot: which LDS word)
-    auto tile_scale = [&](float local_max, int slot) -> float {
-        for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_xor(local_max, off));
+    auto wave_max = [&](float v) -> float {
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        return v;
+    };
+    // tile maximum of |x| over per-thread values -> exact power-of-two scale.  The LDS word rotates over
+    // four slots: call p uses slot p & 3 and re-arms slot (p + 2) & 3 behind its barrier (last read before
+    // barrier p - 1, next written after barrier p + 1), so no extra barrier is spent on the reset.
+    int scale_phase = 0;
+    auto tile_scale = [&](float local_max) -> float {
+        const int slot = scale_phase & 3;
+        local_max = wave_max(local_max);
         if (lane == 0) atomicMax(&maxbits[slot], __float_as_uint(local_max));  // non-negative floats order like their bits
         __syncthreads();
         const float mx = __uint_as_float(maxbits[slot]);
+        if (tid == 0) maxbits[(slot + 2) & 3] = 0u;
+        ++scale_phase;
         return scale_for(mx);
     };
 
@@ -454,115 +492,88 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                 *reinterpret_cast<float4*>(dst + (row0 + r) * ld + 4 * q) = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
         }
     };
-    // message / aggregate from the fp32 tile T into the split A tile T16 of the next contraction:
-    //   last == false:  T16[rev(r)] <- split(S[dst(r)] - T[r])     (mixins.py:11-18), fp32 copy streamed to `keep`
-    //   last == true :  T16[a]      <- split(S[a])                 (base.py:208-211)
-    // S[a] is summed in ROUNDS over the in-degree (round d adds row d of every atom that has one: the
-    // loads of all items of a thread are independent, and every atom still sums in increasing edge id =
-    // the reference's sequential scatter order).  Returns the scale the rows were split with.
-    constexpr int ITEMS_A = BA * QN / kThreads;  // (atom, quad) items per thread
-    float* Sbuf = reinterpret_cast<float*>(T16); // [BA][LDC] per-atom sums (the A tile is dead during the epilogue)
-    const int qn_pad = ((N + 31) / 32) * 8;      // quads up to the k-padding of the last chunk (written as zeros)
-    auto segment_pass = [&](bool last, float* keep, int keep_ld, int slot) -> float {
+    // message / aggregate as MFMAs on the contraction's own C/D fragments (no LDS round trip, no barrier):
+    //   last == false:  M[r']  = sum_r C[r'][r] H[r]   (= S[src r'] - H[rev r'], mixins.py:11-18)
+    //   last == true :  Mv[a]  = sum_r C[a][r]  H[r]   (base.py:208-211)
+    // computed transposed, D[col][r'] = sum_k H^T[col][k] C^T[k][r']: lane (li, lg) of a C/D fragment holds
+    // column li of rows lg*4.. of each row tile, which is exactly the A-operand slice (row li, k = lg*8..) of
+    // H^T once the k order is the one of the incidence fragments above.  H is split per wave
+    // (x s_H = hi + lo, 22 bits relative to the wave maximum), C is exact in f16, accumulation fp32.
+    // The result lands as 4 consecutive columns of row r' (li) per lane: split with the tile scale of the
+    // next contraction and written to T16 as 8-byte pieces; the fp32 copy streams to `keep`.
+    static_assert(RT_E == 3 && RT_A == 2, "segment MFMAs are laid out for 48-row / 32-atom tiles");
+    auto segment_mfma = [&](const f32x4 (&H)[RT_E][WN], bool last, float* keep, int keep_ld) -> float {
         launder();
-        float4 S[ITEMS_A];
-        int sr0[ITEMS_A], sdg[ITEMS_A];
+        float hm = 0.f;
 #pragma unroll
-        for (int j = 0; j < ITEMS_A; ++j) {
-            const int it = tid + kThreads * j;
-            const int a = it / QN, q = it - a * QN;
-            const bool ok = a < na && q < qn;
-            const int ac = ok ? a : 0;
-            const int b0 = rp[ac], b1 = rp[ac + 1];
-            sr0[j] = ok ? b0 : 0;
-            sdg[j] = ok ? b1 - b0 : 0;
-            S[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        for (int d = 0; d < tile_maxdeg; ++d) {
-            float4 y[ITEMS_A];
+        for (int rt = 0; rt < RT_E; ++rt)
 #pragma unroll
-            for (int j = 0; j < ITEMS_A; ++j) {  // all loads first (unconditional, clamped), then branch-free adds
-                const int q = (tid + kThreads * j) % QN;
-                y[j] = *reinterpret_cast<const float4*>(T + (sr0[j] + (d < sdg[j] ? d : 0)) * LDC + 4 * q);
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hm = fmaxf(hm, fabsf(H[rt][ct][r]));
+        const float sH = scale_for(wave_max(hm));
+        const h8* Cf = cfrag + lane + (last ? 6 * 64 : 0);
+        h8 cf[RT_E][2];
+#pragma unroll
+        for (int jt = 0; jt < RT_E; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) cf[jt][ks] = Cf[((jt < RT_A || !last ? jt : 0) * 2 + ks) * 64];
+        f32x4 m[WN][RT_E];
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            h8 ah0, al0, ah1, al1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x0 = H[0][ct][r] * sH, x1 = H[1][ct][r] * sH, x2 = H[2][ct][r] * sH;
+                const _Float16 h0_ = (_Float16)x0, h1_ = (_Float16)x1, h2_ = (_Float16)x2;
+                ah0[r] = h0_; al0[r] = (_Float16)(x0 - (float)h0_);
+                ah0[4 + r] = h1_; al0[4 + r] = (_Float16)(x1 - (float)h1_);
+                ah1[r] = h2_; al1[r] = (_Float16)(x2 - (float)h2_);
+                ah1[4 + r] = (_Float16)0.f; al1[4 + r] = (_Float16)0.f;
             }
 #pragma unroll
-            for (int j = 0; j < ITEMS_A; ++j) {
-                const bool on = d < sdg[j];
-                const bool first = d == 0;
-                S[j].x = on ? (first ? y[j].x : S[j].x + y[j].x) : S[j].x;
-                S[j].y = on ? (first ? y[j].y : S[j].y + y[j].y) : S[j].y;
-                S[j].z = on ? (first ? y[j].z : S[j].z + y[j].z) : S[j].z;
-                S[j].w = on ? (first ? y[j].w : S[j].w + y[j].w) : S[j].w;
-            }
-        }
-        if (slot == 2) stamp();  // s1: per-atom sums
-        float4 res[ITEMS];
-        int dstrow[ITEMS];
-        if (last) {
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) { dstrow[j] = -1; res[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-            for (int j = 0; j < ITEMS_A; ++j) {
-                const int it = tid + kThreads * j;
-                const int a = it / QN, q = it - a * QN;
-                if (a < na && q < qn_pad) { res[j] = q < qn ? S[j] : make_float4(0.f, 0.f, 0.f, 0.f); dstrow[j] = a; }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < ITEMS_A; ++j) {
-                const int it = tid + kThreads * j;
-                const int a = it / QN, q = it - a * QN;
-                if (a < na && q < qn) *reinterpret_cast<float4*>(Sbuf + a * LDC + 4 * q) = S[j];
-            }
-            int ar[ITEMS];
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {  // index loads of every item first
-                const int it = tid + kThreads * j;
-                const int r = it / QN, q = it - r * QN;
-                const bool ok = r < nrows && q < qn_pad;
-                const int rc = ok ? r : 0;
-                ar[j] = aor[rc];
-                dstrow[j] = ok ? revl[rc] : -1;
-            }
-            __syncthreads();
-            float4 Sv[ITEMS];
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {  // then the data loads of every item, then the arithmetic
-                const int it = tid + kThreads * j;
-                const int r = it / QN, q = it - r * QN;
-                const int rc = r < nrows ? r : 0, qc = q < qn ? q : 0;
-                Sv[j] = *reinterpret_cast<const float4*>(Sbuf + ar[j] * LDC + 4 * qc);
-                res[j] = *reinterpret_cast<const float4*>(T + rc * LDC + 4 * qc);
-            }
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const int q = (tid + kThreads * j) % QN;
-                const bool live = q < qn;
-                res[j] = make_float4(live ? Sv[j].x - res[j].x : 0.f, live ? Sv[j].y - res[j].y : 0.f,
-                                     live ? Sv[j].z - res[j].z : 0.f, live ? Sv[j].w - res[j].w : 0.f);
+            for (int jt = 0; jt < RT_E; ++jt) {
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (jt < RT_A || !last) {
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, cf[jt][0], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, cf[jt][1], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, cf[jt][0], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, cf[jt][1], z, 0, 0, 0);
+                }
+                m[ct][jt] = z;
             }
         }
+        stamp();  // s1: segment MFMAs
+        const float isH = 1.f / sH;
         float mx = 0.f;
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const float m4 = fmaxf(fmaxf(fabsf(res[j].x), fabsf(res[j].y)), fmaxf(fabsf(res[j].z), fabsf(res[j].w)));
-            mx = dstrow[j] >= 0 ? fmaxf(mx, m4) : mx;
-        }
-        if (slot == 2) stamp();  // s2: messages in registers
-        const float s = tile_scale(mx, slot);  // (contains the barrier: every read of T / Sbuf is done)
-        if (slot == 2) stamp();  // s3: scale
-        h4 hi[ITEMS], lo[ITEMS];
+        for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) split4(res[j], s, hi[j], lo[j]);
+            for (int jt = 0; jt < RT_E; ++jt)
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int it = tid + kThreads * j;
-            const int q = it % QN;
-            if (dstrow[j] >= 0) {  // q < qn_pad: the k-padding of the last chunk is written as zeros
-                unsigned char* p = T16 + dstrow[j] * TS + (q >> 3) * 128 + (q & 7) * 8;
-                *reinterpret_cast<h4*>(p) = hi[j];
-                *reinterpret_cast<h4*>(p + 64) = lo[j];
-                if (keep && q < qn) *reinterpret_cast<float4*>(keep + ((long long)(last ? va : rs) + dstrow[j]) * keep_ld + 4 * q) = res[j];
+                for (int r = 0; r < 4; ++r) {
+                    m[ct][jt][r] *= isH;
+                    mx = fmaxf(mx, fabsf(m[ct][jt][r]));
+                }
+        const float s = tile_scale(mx);  // (contains a barrier: every wave is past its reads of T16)
+        stamp();  // s2: tile scale
+        const int n_keep = last ? na : nrows;
+        const long long keep0 = last ? va : rs;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                if (jt < RT_A || !last) {
+                    const int row = jt * 16 + li;
+                    const float4 v = make_float4(m[ct][jt][0], m[ct][jt][1], m[ct][jt][2], m[ct][jt][3]);
+                    h4 hi, lo;
+                    split4(v, s, hi, lo);
+                    unsigned char* p = T16 + row * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
+                    *reinterpret_cast<h4*>(p) = hi;
+                    *reinterpret_cast<h4*>(p + 64) = lo;
+                    if (keep && row < n_keep && col4 < N) *reinterpret_cast<float4*>(keep + (keep0 + row) * keep_ld + col4) = v;
+                }
             }
         }
         return s;
@@ -595,7 +606,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         const rsrc_t rV = gemm::make_rsrc(g.V, g.v_bytes), rE = gemm::make_rsrc(g.E, g.e_bytes);
         stamp();  // 1: metadata done
         const ColConst cc = col_consts(G.Wi.inv_scale, g.b_i);
-        const float sA = tile_scale(global_a_max(T_{}, BM, g.d_v, g.d_e, rV, rE, offA1, offA2), 0);
+        const float sA = tile_scale(global_a_max(T_{}, BM, g.d_v, g.d_e, rV, rE, offA1, offA2));
         stamp();  // 2: init A maximum
         zero_acc(RE{}, h0);
         contract(RE{}, F_{}, T_{}, h0, g.d_v, g.d_e, rV, rE, offA1, offA2, sA, G.Wi);
@@ -609,6 +620,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         tile_to_global(g.H0, rs, g.ldh, nrows);
         __syncthreads();
     }
+    float sA;
     {
         f32x4 y[RT_E][WN];
 #pragma unroll
@@ -616,12 +628,8 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct) y[rt][ct] = h0[rt][ct];
         act_frags(RE{}, F_{}, y, y);
-        frag_to_tile(RE{}, y);
+        sA = segment_mfma(y, T_steps == 1, T_steps == 1 ? g.Mv : g.Ms, g.ldh);
     }
-    __syncthreads();
-    if (tid < 4) maxbits[tid] = 0u;  // slot 0 was consumed before the contraction; re-arm all
-    __syncthreads();
-    float sA = segment_pass(T_steps == 1, T_steps == 1 ? g.Mv : g.Ms, g.ldh, 1);
     stamp();  // 4: K1 epilogue + first message
 
     // ================= K3 x (depth - 1): H = tau(H0 + W_h M) =================
@@ -636,14 +644,13 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         unscale(RE{}, acc, 1.f / sA, cc);
         act_frags(RE{}, T_{}, acc, h0);  // tau(H0 + W_h(M)): base.py:141
         stamp();  // E: unscale + tau
-        frag_to_tile(RE{}, acc);
-        __syncthreads();
-        stamp();  // E: tile written
-        if (g.Hs) tile_to_global(g.Hs + (long long)(step - 1) * g.slot, rs, g.ldh, nrows);
+        if (g.Hs) {
+            frag_to_tile(RE{}, acc);
+            __syncthreads();
+            tile_to_global(g.Hs + (long long)(step - 1) * g.slot, rs, g.ldh, nrows);
+        }
         const bool last = step == T_steps - 1;
-        if (tid < 4) maxbits[tid] = 0u;
-        __syncthreads();
-        sA = segment_pass(last, last ? g.Mv : (g.Ms ? g.Ms + (long long)step * g.slot : nullptr), g.ldh, 2);
+        sA = segment_mfma(acc, last, last ? g.Mv : (g.Ms ? g.Ms + (long long)step * g.slot : nullptr), g.ldh);
         stamp();  // 6, 8, ...: update epilogue + message / aggregate
     }
 
@@ -664,9 +671,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             offA1[j] = (r < BA && r < na) ? (unsigned)r * (unsigned)g.ldv * 4u : kOOB;
         }
         const rsrc_t rV = gemm::make_rsrc(g.V + (long long)va * g.ldv, (unsigned)(na * g.ldv) * 4u);
-        if (tid < 4) maxbits[tid] = 0u;
-        __syncthreads();
-        const float sV = tile_scale(global_a_max(F_{}, BA, g.d_v, 0, rV, rnull, offA1, dummy), 3);
+        const float sV = tile_scale(global_a_max(F_{}, BA, g.d_v, 0, rV, rnull, offA1, dummy));
         {   // bring the accumulated Mv part into the V part's scale (exact: powers of two)
             const float f = sV / sA;
 #pragma unroll

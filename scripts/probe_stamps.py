@@ -21,9 +21,10 @@ with torch.no_grad():
     fw(); torch.cuda.synchronize()
     lib.dmpnn_debug_timestamps(None)
 st = buf.cpu().tolist()
-names = ["entry", "meta", "init A max", "K1 contract", "K1 epilogue+msg", "upd1 contract", "upd1 unscale+tau", "upd1 tile written",
-         "u1 sums", "u1 msgs", "u1 scale", "u1 pads", "upd1 split written", "upd2 contract", "upd2 unscale+tau", "upd2 tile written", "u2 sums", "u2 msgs", "u2 scale", "u2 pads", "upd2 split written",
-         "fin Mv part", "fin V max", "fin V part", "out stored"]
+names = ["entry", "meta", "init A max", "K1 contract", "K1 seg mfma", "K1 tile scale", "K1 split written"]
+for u in (1, 2):
+    names += [f"upd{u} contract", f"upd{u} unscale+tau", f"upd{u} seg mfma", f"upd{u} tile scale", f"upd{u} split written"]
+names += ["fin Mv part", "fin V max", "fin V part", "out stored"]
 prev = st[0]
 for i, n in enumerate(names):
     if i < len(st) and st[i]:
