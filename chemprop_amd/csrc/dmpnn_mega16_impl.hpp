@@ -39,7 +39,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-constexpr int ROWB = 144;  // bytes of one staged operand row of a chunk: [hi 32 halfs | lo 32 halfs] + 16 pad
 
 // Packed pre-split weight matrix in fragment-major order [column tile][chunk][hi|lo][lane][16 B] (see k_split_weights),
 // plus the inverse scale of every row.
@@ -119,7 +118,6 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     constexpr int ITEMS = BM * QN / kThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* T16 = lds;                               // [BM][TS]   split A operand of the LDS-A contractions
-    unsigned char* As = lds;                                // [2][BM][ROWB] staging ring of the global-A contractions (overlays T16)
     float* T = reinterpret_cast<float*>(lds + BM * TS);     // [BM][LDC] fp32 epilogue tile
     int* revl = reinterpret_cast<int*>(lds + BM * TS + BM * LDC * 4);  // [BM]
     int* aor = revl + BM;                                   // [BM]
@@ -165,8 +163,39 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         return apply_act(z, g.act, slope);
     };
 
-    if (tid < BM) revl[tid] = tid < nrows ? g.revp[rs + tid] - rs : 0;
-    if (tid <= BA) rp[tid] = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
+    // index loads first: the tile metadata and the gather rows of the K1 operand (row wave + 4 j of the tile)
+    const int revl_v = tid < nrows ? g.revp[rs + tid] - rs : 0;
+    const int rp_v = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
+    unsigned ro1[4 * RT_E], ro2[4 * RT_E];
+    {
+        int i1[4 * RT_E], i2[4 * RT_E];
+#pragma unroll
+        for (int j = 0; j < 4 * RT_E; ++j) {
+            const int r = wave + 4 * j;
+            i1[j] = g.srcp[r < nrows ? rs + r : 0];
+            i2[j] = g.perm[r < nrows ? rs + r : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * RT_E; ++j) {
+            const bool ok = wave + 4 * j < nrows;
+            ro1[j] = ok ? (unsigned)i1[j] * (unsigned)g.ldv * 4u : kOOB;
+            ro2[j] = ok ? (unsigned)i2[j] * (unsigned)g.lde * 4u : kOOB;
+        }
+    }
+    // the first 128 columns of [V[src] | E] are in flight while the LDS metadata is built
+    const rsrc_t rVg = gemm::make_rsrc(g.V, g.v_bytes), rEg = gemm::make_rsrc(g.E, g.e_bytes);
+    u32x2 a_grp[4 * RT_E];
+    {
+        const int k = lane * 2;
+        const unsigned k1o = k < g.d_v ? (unsigned)k * 4u : kOOB;
+        const unsigned k2o = (k >= g.d_v && k < g.d_v + g.d_e) ? (unsigned)(k - g.d_v) * 4u : kOOB;
+#pragma unroll
+        for (int j = 0; j < 4 * RT_E; ++j)
+            a_grp[j] = __builtin_amdgcn_raw_buffer_load_b64(rVg, gemm::join_off(ro1[j], k1o), 0, 0) |
+                       __builtin_amdgcn_raw_buffer_load_b64(rEg, gemm::join_off(ro2[j], k2o), 0, 0);
+    }
+    if (tid < BM) revl[tid] = revl_v;
+    if (tid <= BA) rp[tid] = rp_v;
     if (tid < 8) maxbits[tid] = 0u;
     __syncthreads();
     if (tid < na)
@@ -200,9 +229,17 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     }
     __syncthreads();
 
+    // maximum of a non-negative float over the wave (their bit patterns order like the values): DPP within
+    // the rows of 16 lanes, then the four row results through scalar registers.  Uniform result.
     auto wave_max = [&](float v) -> float {
-        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-        return v;
+        int u = (int)__float_as_uint(v);
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x141, 0xf, 0xf, true));  // row_half_mirror
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x140, 0xf, 0xf, true));  // row_mirror
+        const int m = max(max(__builtin_amdgcn_readlane(u, 0), __builtin_amdgcn_readlane(u, 16)),
+                          max(__builtin_amdgcn_readlane(u, 32), __builtin_amdgcn_readlane(u, 48)));
+        return __uint_as_float((unsigned)m);
     };
     // tile maximum of |x| over per-thread values -> exact power-of-two scale.  The LDS word rotates over
     // four slots: call p uses slot p & 3 and re-arms slot (p + 2) & 3 behind its barrier (last read before
@@ -250,82 +287,38 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     };
 
     // ---- one contraction: acc[RT][WN] += (A s_A) . (W s_W)^T in the split domain -------------------
-    // A_LDS: A fragments straight from T16 (static during the contraction: NO barrier in the main loop);
-    // else A = [A1 | A2] fp32 from global memory, scaled by sA and split while it is staged through the LDS
-    // ring (shared by the four waves; one barrier per chunk; the ring overlays T16).
-    auto contract = [&](auto rt_c, auto a_lds_c, auto has_a2_c, f32x4 (&acc)[decltype(rt_c)::value][WN], int K1, int K2,
-                        rsrc_t rA1, rsrc_t rA2, const unsigned (&offA1)[2], const unsigned (&offA2)[2], float sA,
-                        const SplitW& W) {
+    // A fragments straight from a split tile in LDS (static during the contraction: NO barrier in the main
+    // loop): row stride `astride` bytes, chunk c at +c*128 as [hi 32 halfs | lo 32 halfs].  Weight chunks
+    // wc0 .. wc0 + n_chunks - 1 of W.
+    auto contract = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], const unsigned char* Ab, int astride, int n_chunks,
+                        int wc0, const SplitW& W) {
         constexpr int RT = decltype(rt_c)::value;
-        constexpr bool A_LDS = decltype(a_lds_c)::value, HAS_A2 = decltype(has_a2_c)::value;
-        constexpr int BMr = 16 * RT;
-        constexpr int SLOTS_A = A_LDS ? 0 : (BMr * 8 + kThreads - 1) / kThreads;  // fp32 quads of the A chunk per thread (<= 2)
-        const int K = K1 + K2;
-        const int n_chunks = A_LDS ? (K + BK - 1) / BK : W.nc;
         const rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048));  // column tiles beyond N: out of range, 0
         unsigned offB[WN];
         bfrag_offsets(W, offB);
-        u32x4 stA[SLOTS_A > 0 ? SLOTS_A : 1];
-        auto load_a = [&](int c) {
-            const int kk = c * BK + kq * 4;
-            unsigned k1o[2], k2o[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k = kk + s * 2;
-                k1o[s] = k < K1 ? (unsigned)k * 4u : kOOB;
-                k2o[s] = (k >= K1 && k < K) ? (unsigned)(k - K1) * 4u : kOOB;
-            }
-#pragma unroll
-            for (int j = 0; j < SLOTS_A; ++j) {
-                unsigned o1[2] = {gemm::join_off(offA1[j], k1o[0]), gemm::join_off(offA1[j], k1o[1])};
-                u32x4 v = gemm::load_quad<2>(rA1, o1);
-                if constexpr (HAS_A2) {
-                    unsigned o2[2] = {gemm::join_off(offA2[j], k2o[0]), gemm::join_off(offA2[j], k2o[1])};
-                    v = v | gemm::load_quad<2>(rA2, o2);
-                }
-                stA[j] = v;
-            }
-        };
-        auto store_a = [&](int slot) {
-            unsigned char* Ad = As + slot * BMr * ROWB;
-#pragma unroll
-            for (int j = 0; j < SLOTS_A; ++j) {
-                const int r = (tid + kThreads * j) >> 3;
-                if (r < BMr) {
-                    h4 hi, lo;
-                    split4(gemm::as_f4(stA[j]), sA, hi, lo);
-                    *reinterpret_cast<h4*>(Ad + r * ROWB + kq * 8) = hi;
-                    *reinterpret_cast<h4*>(Ad + r * ROWB + 64 + kq * 8) = lo;
-                }
-            }
-        };
+        for (int ct = 0; ct < WN; ++ct) offB[ct] += (unsigned)wc0 * 2048u;
         auto read_afrags = [&](int c, h8 (&ah)[RT], h8 (&al)[RT]) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const unsigned char* p = A_LDS ? T16 + (rt * 16 + li) * TS + c * 128 + lg * 16
-                                               : As + (c & 1) * BMr * ROWB + (rt * 16 + li) * ROWB + lg * 16;
+                const unsigned char* p = Ab + (rt * 16 + li) * astride + c * 128 + lg * 16;
                 ah[rt] = *reinterpret_cast<const h8*>(p);
                 al[rt] = *reinterpret_cast<const h8*>(p + 64);
             }
         };
-        // One k-chunk = 3 x RT x WN MFMAs on (ah, al, bh, bl).  While they run: the A staging of chunk c+1
-        // (global-A only), the A fragments of chunk c+1 into (nah, nal), and — once the last MFMA that reads
-        // (bh, bl) has been issued — the weight fragments of chunk c+2 into the same registers.
+        // One k-chunk = 3 x RT x WN MFMAs on (ah, al, bh, bl).  While they run: the A fragments of chunk c+1
+        // into (nah, nal), and — once the last MFMA that reads (bh, bl) has been issued — the weight
+        // fragments of chunk c+2 into the same registers.
         auto chunk = [&](auto has_next, auto has_next2, int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN],
                          h8 (&nah)[RT], h8 (&nal)[RT]) {
             constexpr bool NEXT = decltype(has_next)::value, NEXT2 = decltype(has_next2)::value;
-            if constexpr (!A_LDS && NEXT) store_a((c + 1) & 1);
-            if constexpr (!A_LDS && NEXT2) load_a(c + 2);
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NEXT) {
-                if constexpr (!A_LDS) __syncthreads();  // chunk c+1 of A is in the ring for every wave
-                read_afrags(c + 1, nah, nal);
-            }
+            if constexpr (NEXT) read_afrags(c + 1, nah, nal);
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
@@ -340,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             if constexpr (NEXT2) load_bfrags(rW, offB, c + 2, bh, bl);
         };
         h8 a0h[RT], a0l[RT], b0h[WN], b0l[WN], a1h[RT], a1l[RT], b1h[WN], b1l[WN];
-        if (have_pre) {  // (uniform) the weights of chunk 0 were fetched during the previous epilogue
+        if (have_pre && wc0 == 0) {  // (uniform) the weights of chunk 0 were fetched during the previous epilogue
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct) { b0h[ct] = preBh[ct]; b0l[ct] = preBl[ct]; }
             have_pre = false;
@@ -348,14 +341,8 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             load_bfrags(rW, offB, 0, b0h, b0l);
         }
         if (n_chunks > 1) load_bfrags(rW, offB, 1, b1h, b1l);
-        __syncthreads();  // the previous phase is done with T16 / the A ring / T
+        __syncthreads();  // the split A tile is complete
         launder();
-        if constexpr (!A_LDS) {
-            load_a(0);
-            store_a(0);
-            if (n_chunks > 1) load_a(1);
-            __syncthreads();
-        }
         read_afrags(0, a0h, a0l);
         __builtin_amdgcn_sched_barrier(0);
         int c = 0;
@@ -374,37 +361,57 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         } else {
             chunk(F_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
         }
-        __syncthreads();  // every wave is done with T16 / the A ring before the epilogue reuses LDS
+        // (no trailing barrier: every writer of the A tile sits behind the barrier of a tile_scale call)
     };
-    // maximum |x| of the A operand a global-A contraction is going to stage (same loads, L2 hits later)
-    auto global_a_max = [&](auto has_a2_c, int rows_cap, int K1, int K2, rsrc_t rA1, rsrc_t rA2, const unsigned (&offA1)[2],
-                            const unsigned (&offA2)[2]) -> float {
+
+    // ---- A operand from global memory, in groups of up to 4 k-chunks (128 columns) ---------------------
+    // Item j of a thread: row wave + 4 j, column pair `lane` of the group (k = 128 grp + 2 lane), so one
+    // wave instruction reads 512 contiguous bytes of one (gathered) row.  The group is held in registers:
+    // its maximum gives the tile scale, then it is split into the LDS tile Ag (overlays T16 / T) — the
+    // operand is read from memory exactly once and the contraction over it is the barrier-free one above.
+    constexpr int TSG = 4 * 128 + 16;
+    unsigned char* Ag = lds;
+    auto ga_load = [&](auto rt_c, auto has_a2_c, int grp, int K1, int K2, rsrc_t rA1, rsrc_t rA2,
+                       const unsigned (&ro1)[4 * decltype(rt_c)::value], const unsigned (&ro2)[4 * decltype(rt_c)::value],
+                       u32x2 (&v)[4 * decltype(rt_c)::value]) {
+        constexpr int J = 4 * decltype(rt_c)::value;
         constexpr bool HAS_A2 = decltype(has_a2_c)::value;
-        const int K = K1 + K2;
-        const int n_chunks = (K + BK - 1) / BK;
-        const int slots = (rows_cap * 8 + kThreads - 1) / kThreads;  // 1 or 2
-        float mx = 0.f;
-        for (int c = 0; c < n_chunks; ++c) {
-            const int kk = c * BK + kq * 4;
+        const int k = grp * 128 + lane * 2;
+        const unsigned k1o = k < K1 ? (unsigned)k * 4u : kOOB;
+        const unsigned k2o = (k >= K1 && k < K1 + K2) ? (unsigned)(k - K1) * 4u : kOOB;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j < slots) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int k = kk + s * 2;
-                        const unsigned k1o = k < K1 ? (unsigned)k * 4u : kOOB;
-                        const u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(rA1, gemm::join_off(offA1[j], k1o), 0, 0);
-                        mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v1.x)), fabsf(__uint_as_float(v1.y))));
-                        if constexpr (HAS_A2) {
-                            const unsigned k2o = (k >= K1 && k < K) ? (unsigned)(k - K1) * 4u : kOOB;
-                            const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(rA2, gemm::join_off(offA2[j], k2o), 0, 0);
-                            mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v2.x)), fabsf(__uint_as_float(v2.y))));
-                        }
-                    }
-                }
-            }
+        for (int j = 0; j < J; ++j) {
+            v[j] = __builtin_amdgcn_raw_buffer_load_b64(rA1, gemm::join_off(ro1[j], k1o), 0, 0);
+            if constexpr (HAS_A2) v[j] = v[j] | __builtin_amdgcn_raw_buffer_load_b64(rA2, gemm::join_off(ro2[j], k2o), 0, 0);
         }
-        return mx;
+    };
+    // scale of the group, rescale of what `acc` holds from the previous scale, split + store
+    auto ga_stage = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], const u32x2 (&v)[4 * decltype(rt_c)::value], float s_prev) -> float {
+        constexpr int RT = decltype(rt_c)::value, J = 4 * RT;
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v[j].x)), fabsf(__uint_as_float(v[j].y))));
+        const float s = tile_scale(mx);  // (barrier: every wave is past its reads of the LDS tiles)
+        if (s_prev != 0.f && s_prev != s) {  // bring the accumulated part into this group's scale (exact: powers of two)
+            const float f = s / s_prev;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= f;
+        }
+        launder();
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float x = __uint_as_float(v[j].x) * s, y = __uint_as_float(v[j].y) * s;
+            const h2 hi = h2{(_Float16)x, (_Float16)y};
+            const h2 lo = h2{(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
+            unsigned char* p = Ag + (wave + 4 * j) * TSG + (lane >> 4) * 128 + (lane & 15) * 4;
+            *reinterpret_cast<h2*>(p) = hi;
+            *reinterpret_cast<h2*>(p + 64) = lo;
+        }
+        return s;
     };
     auto zero_acc = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN]) {
         constexpr int RT = decltype(rt_c)::value;
@@ -582,43 +589,30 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     using RE = std::integral_constant<int, RT_E>;
     using RA = std::integral_constant<int, RT_A>;
     const int T_steps = g.depth;
-    const unsigned dummy[2] = {kOOB, kOOB};
 
     // ================= K1: H0 = W_i [V[src] || E] =================
     f32x4 h0[RT_E][WN];
     {
-        unsigned offA1[2], offA2[2];
-        int i1[2], i2[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (tid + kThreads * j) >> 3;
-            const bool ok = r < BM && r < nrows;
-            i1[j] = g.srcp[ok ? rs + r : 0];
-            i2[j] = g.perm[ok ? rs + r : 0];
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (tid + kThreads * j) >> 3;
-            const bool ok = r < BM && r < nrows;
-            offA1[j] = ok ? (unsigned)i1[j] * (unsigned)g.ldv * 4u : kOOB;
-            offA2[j] = ok ? (unsigned)i2[j] * (unsigned)g.lde * 4u : kOOB;
-        }
-        const rsrc_t rV = gemm::make_rsrc(g.V, g.v_bytes), rE = gemm::make_rsrc(g.E, g.e_bytes);
         stamp();  // 1: metadata done
         const ColConst cc = col_consts(G.Wi.inv_scale, g.b_i);
-        const float sA = tile_scale(global_a_max(T_{}, BM, g.d_v, g.d_e, rV, rE, offA1, offA2));
-        stamp();  // 2: init A maximum
         zero_acc(RE{}, h0);
-        contract(RE{}, F_{}, T_{}, h0, g.d_v, g.d_e, rV, rE, offA1, offA2, sA, G.Wi);
+        float s_prev = 0.f;
+        for (int grp = 0; grp * 4 < G.Wi.nc; ++grp) {
+            if (grp > 0) ga_load(RE{}, T_{}, grp, g.d_v, g.d_e, rVg, rEg, ro1, ro2, a_grp);
+            s_prev = ga_stage(RE{}, h0, a_grp, s_prev);
+            if (grp == 0) stamp();  // 2: init A staged
+            const int ncg = G.Wi.nc - grp * 4 < 4 ? G.Wi.nc - grp * 4 : 4;
+            contract(RE{}, h0, Ag, TSG, ncg, grp * 4, G.Wi);
+        }
         prefetch_b(T_steps > 1 ? G.Wh : G.WoM);
-        unscale(RE{}, h0, 1.f / sA, cc);
+        unscale(RE{}, h0, 1.f / s_prev, cc);
         stamp();  // 3: K1 contraction
     }
     if (g.H0) {  // training: the pre-activation is needed by the backward pass
+        __syncthreads();  // (the fp32 tile may overlay the K1 operand tile)
         frag_to_tile(RE{}, h0);
         __syncthreads();
         tile_to_global(g.H0, rs, g.ldh, nrows);
-        __syncthreads();
     }
     float sA;
     {
@@ -636,9 +630,8 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     for (int step = 1; step < T_steps; ++step) {
         f32x4 acc[RT_E][WN];
         zero_acc(RE{}, acc);
-        const rsrc_t rnull = gemm::make_rsrc(g.W_h, 0);
         const ColConst cc = col_consts(G.Wh.inv_scale, g.b_h);
-        contract(RE{}, T_{}, F_{}, acc, N, 0, rnull, rnull, dummy, dummy, sA, G.Wh);
+        contract(RE{}, acc, T16, TS, (N + BK - 1) / BK, 0, G.Wh);
         stamp();  // 5, 7, ...: update contraction
         prefetch_b(step + 1 < T_steps ? G.Wh : G.WoM);
         unscale(RE{}, acc, 1.f / sA, cc);
@@ -658,34 +651,31 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     {
         f32x4 acc[RT_A][WN];
         zero_acc(RA{}, acc);
-        const rsrc_t rnull = gemm::make_rsrc(g.W_o, 0);
         const ColConst cc = col_consts(G.WoM.inv_scale, g.b_o);
-        // Mv part first (A = T16 rows 0..atoms-1), then the V part (its staging ring overlays T16)
-        contract(RA{}, T_{}, F_{}, acc, N, 0, rnull, rnull, dummy, dummy, sA, G.WoM);
+        // the first 128 columns of the tile's V rows are fetched under the Mv contraction
+        const rsrc_t rV = gemm::make_rsrc(g.V + (long long)va * g.ldv, (unsigned)(na * g.ldv) * 4u);
+        const rsrc_t rnull = gemm::make_rsrc(g.W_o, 0);
+        unsigned rov[4 * RT_A];
+#pragma unroll
+        for (int j = 0; j < 4 * RT_A; ++j) rov[j] = wave + 4 * j < na ? (unsigned)(wave + 4 * j) * (unsigned)g.ldv * 4u : kOOB;
+        u32x2 v_grp[4 * RT_A];
+        ga_load(RA{}, F_{}, 0, g.d_v, 0, rV, rnull, rov, rov, v_grp);
+        // Mv part first (A = T16 rows 0..atoms-1), then the V part in the scale of its own groups
+        contract(RA{}, acc, T16, TS, (N + BK - 1) / BK, 0, G.WoM);
         stamp();  // finalize: Mv part
         prefetch_b(G.WoV);
-        unsigned offA1[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (tid + kThreads * j) >> 3;
-            offA1[j] = (r < BA && r < na) ? (unsigned)r * (unsigned)g.ldv * 4u : kOOB;
+        float sV = sA;
+        for (int grp = 0; grp * 4 < G.WoV.nc; ++grp) {
+            if (grp > 0) ga_load(RA{}, F_{}, grp, g.d_v, 0, rV, rnull, rov, rov, v_grp);
+            sV = ga_stage(RA{}, acc, v_grp, sV);
+            if (grp == 0) stamp();  // finalize: V staged
+            const int ncg = G.WoV.nc - grp * 4 < 4 ? G.WoV.nc - grp * 4 : 4;
+            contract(RA{}, acc, Ag, TSG, ncg, grp * 4, G.WoV);
         }
-        const rsrc_t rV = gemm::make_rsrc(g.V + (long long)va * g.ldv, (unsigned)(na * g.ldv) * 4u);
-        const float sV = tile_scale(global_a_max(F_{}, BA, g.d_v, 0, rV, rnull, offA1, dummy));
-        {   // bring the accumulated Mv part into the V part's scale (exact: powers of two)
-            const float f = sV / sA;
-#pragma unroll
-            for (int rt = 0; rt < RT_A; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= f;
-        }
-        stamp();  // finalize: V maximum
-        contract(RA{}, F_{}, F_{}, acc, g.d_v, 0, rV, rnull, offA1, dummy, sV, G.WoV);
         stamp();  // finalize: V part
         unscale(RA{}, acc, 1.f / sV, cc);
         act_frags(RA{}, F_{}, acc, acc);
+        __syncthreads();  // (the fp32 tile may overlay the V operand tile)
         frag_to_tile(RA{}, acc);
         __syncthreads();
         tile_to_global(g.out, va, g.ldout, na);

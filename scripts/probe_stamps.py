@@ -21,10 +21,10 @@ with torch.no_grad():
     fw(); torch.cuda.synchronize()
     lib.dmpnn_debug_timestamps(None)
 st = buf.cpu().tolist()
-names = ["entry", "meta", "init A max", "K1 contract", "K1 seg mfma", "K1 tile scale", "K1 split written"]
+names = ["entry", "meta", "init A staged", "K1 contract", "K1 seg mfma", "K1 tile scale", "K1 split written"]
 for u in (1, 2):
     names += [f"upd{u} contract", f"upd{u} unscale+tau", f"upd{u} seg mfma", f"upd{u} tile scale", f"upd{u} split written"]
-names += ["fin Mv part", "fin V max", "fin V part", "out stored"]
+names += ["fin Mv part", "fin V staged", "fin V part", "out stored"]
 prev = st[0]
 for i, n in enumerate(names):
     if i < len(st) and st[i]:
