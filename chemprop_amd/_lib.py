@@ -39,6 +39,7 @@ F_FUSED = 2
 F_MEGA = 4
 F_KEEP = 8
 F_SPLIT16 = 16
+F_WSPLIT_READY = 32
 PLAN_NOMEGA_MASK = 15  # ... | no piece tiles (a molecule larger than a tile)
 PLAN_NOFUSE_MASK = 7  # asymmetric | index out of range | in-degree > 24
 

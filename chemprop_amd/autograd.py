@@ -59,7 +59,8 @@ def mp_forward(mp, plan: engine.GraphPlan, V: Tensor, E: Tensor, V_d: Optional[T
         out, _ = engine.forward(plan, V, E, p["W_i"], p["W_h"], p["W_o"], p["b_o"], p["b_i"], p["b_h"],
                                 p["W_d"] if has_vd else None, p["b_d"] if has_vd else None,
                                 V_d if has_vd else None, depth=mp.depth, act=act, slope=slope,
-                                slope_t=slope_t, undirected=mp.undirected, keep=False, max_level=max_level)
+                                slope_t=slope_t, undirected=mp.undirected, keep=False, max_level=max_level,
+                                wcache=mp.__dict__.setdefault("_dmpnn_wcache", {}))
         return out
 
     # ---- rows route: kernels for every contraction / segment op, torch modules in between ----

@@ -59,8 +59,9 @@ struct PlanLayout {
 };
 inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 inline int64_t fused_max_tiles(int64_t nE) { return (nE + kFusedMinB0 - 1) / kFusedMinB0 + 1; }
-// greedy packing: two consecutive piece tiles cannot be merged, so together they exceed a limit
-inline int64_t mega_max_tiles(int64_t nV, int64_t nE) { return 2 * (nE / kMegaBM + nV / kMegaBA) + 4; }
+// greedy packing: two consecutive piece tiles cannot be merged, so together they exceed a limit; plus one
+// under-filled tile per block of 64 pieces (build_piece_tiles)
+inline int64_t mega_max_tiles(int64_t nV, int64_t nE) { return 2 * (nE / kMegaBM + nV / kMegaBA) + 4 + nV / 64 + 1; }
 inline PlanLayout plan_layout(int64_t nV, int64_t nE) {
     PlanLayout L;
     int64_t o = DMPNN_HDR_WORDS;
@@ -148,7 +149,7 @@ inline size_t small_plan_lds_bytes(int64_t nV, int64_t nE) {
     return ((size_t)(3 * (nV + 2)) * 4 + (size_t)(5 * nE + 2) * 2 + 31) & ~size_t(15);
 }
 inline bool small_plan_fits(int64_t nV, int64_t nE) {
-    return nV <= kSmallPlanMaxAtoms && nE <= kSmallPlanMaxEdges && small_plan_lds_bytes(nV, nE) <= 160 * 1024 - 512;
+    return nV <= kSmallPlanMaxAtoms && nE <= kSmallPlanMaxEdges && small_plan_lds_bytes(nV, nE) <= 160 * 1024 - 2048;
 }
 int launch_message(const PlanView& pv, int64_t nV, int64_t nE, int64_t h, const float* Hin,
                    int64_t ld_in, float* M, int64_t ld_m, int act, float slope,

@@ -45,7 +45,9 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     }
     unsigned char* ws = static_cast<unsigned char*>(a.wsplit);
     const int N = (int)a.d_h, dv = (int)a.d_v, de = (int)a.d_e;
-    // ---- pre-split of the three weight matrices (once per forward: weights change every training step) ----
+    // ---- pre-split of the three weight matrices: once per forward (weights change every training step) unless
+    // the caller vouches that the workspace still holds the pre-split of these weights (frozen weights) ----
+    if (!(a.flags & DMPNN_F_WSPLIT_READY)) {
     mega16::SplitArgs sp;
     memset(&sp, 0, sizeof(sp));
     sp.N = N; sp.n_jobs = 4;
@@ -55,6 +57,7 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     sp.job[3] = mega16::SplitJob{a.W_o, dv + N, 0, dv, 0, dv + N, ws + W.wov, W.nc_v, nullptr};
     hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)(((N + 15) / 16) * 16)), dim3(256), 0, s, sp);  // 4 jobs x whole column tiles, 4 waves per block
     DMPNN_CHECK_LAUNCH("k_split_weights");
+    }
 
     const PlanLayout L = plan_layout(nV, nE);
     const int* plan_i = static_cast<const int*>(a.plan);

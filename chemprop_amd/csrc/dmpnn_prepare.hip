@@ -267,10 +267,10 @@ __device__ __forceinline__ void block_scan_inclusive(int* a, int n, int* wave_to
 // A cut after atom v is safe when no edge joins atoms <= v with atoms > v; with atoms of a molecule
 // contiguous (data/collate.py:48-56) the cuts are the molecule boundaries (and fragment boundaries).
 // Consecutive pieces are packed greedily into tiles of <= kMegaBM rows and <= kMegaBA atoms; the chain
-// of tile starts is marked by pointer jumping over the PIECES (log2 #pieces rounds) instead of a
-// sequential walk.  X, Y: int scratch of nV + 2 entries each; X enters holding
-// maxnbr[v] = max(v, largest neighbour).  Returns the number of tiles, or -1 when a piece does not fit
-// (the tables are then emptied).
+// of tile starts is walked per block of 64 pieces, all blocks in parallel (a tile starts at every block
+// start).  X, Y: int scratch of nV + 2 entries each; Y enters holding one byte per atom boundary
+// (byte u != 0: an edge joins atoms < u with atoms >= u).
+// Returns the number of tiles, or -1 when a piece does not fit (the tables are then emptied).
 template <class Other>
 __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const PlanLayout& L, const int* rowp, int* X,
                                                  int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid,
@@ -285,29 +285,50 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
     int* matom = plan + L.mtile_atom;
     const int slots = (int)L.max_mtiles + 2;
     constexpr int kMark = 0x40000000;
-    block_scan_inclusive<true>(X, nV, wave_tot, tid);          // X[v] = largest neighbour index over atoms <= v
-    stamp();  // p1: prefix max
-    int st[kSmallItems];
-#pragma unroll
-    for (int j = 0; j < kSmallItems; ++j) {
-        const int u = tid * kSmallItems + j;
-        st[j] = (u < nV && (u == 0 || X[u - 1] == u - 1)) ? 1 : 0;   // u starts a piece
+    // piece starts = uncovered boundaries.  Y enters holding one covered-flag byte per atom boundary; a
+    // ballot per 64 atoms turns them into start-bit words (behind the bytes), ranked by one wave scan over
+    // the word popcounts.
+    const int n_words = (nV + 31) >> 5;
+    const unsigned char* covb = reinterpret_cast<const unsigned char*>(Y);
+    unsigned* stw = reinterpret_cast<unsigned*>(Y + (nV + 3) / 4 + 1);  // [2 ceil(nV / 64)] start-bit words
+    int* wrank = reinterpret_cast<int*>(stw) + 2 * ((nV + 63) >> 6);    // [n_words] start bits in the words before
+    for (int u0 = (tid >> 6) * 64; u0 < nV; u0 += kSmallThreads) {
+        const int u = u0 + (tid & 63);
+        const unsigned long long m = __ballot(u < nV && covb[u] == 0);
+        if ((tid & 63) == 0) { stw[u0 >> 5] = (unsigned)m; stw[(u0 >> 5) + 1] = (unsigned)(m >> 32); }
     }
     __syncthreads();
+    const unsigned my_starts = tid < n_words ? stw[tid] : 0u;
+    stamp();  // p1: start bits
+    __shared__ int np_s;
+    {   // kSmallMaxAtoms / 32 = 192 words: wave w scans words 64 w .. 64 w + 63, totals through LDS
+        const int lane = tid & 63, w = tid >> 6;
+        const int pc = __popc(my_starts);
+        int inc = pc;
 #pragma unroll
-    for (int j = 0; j < kSmallItems; ++j) {
-        const int u = tid * kSmallItems + j;
-        if (u < nV) Y[u] = st[j];
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_tot[w] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < w; ++k) base += wave_tot[k];
+        if (tid < n_words) wrank[tid] = base + inc - pc;
+        if (tid == n_words - 1) np_s = base + inc;
+        if (n_words == 0 && tid == 0) np_s = 0;
     }
     __syncthreads();
-    block_scan_inclusive<false>(Y, nV, wave_tot, tid);         // Y[u] = number of piece starts <= u
     stamp();  // p2: start ranks
-    const int np = nV > 0 ? Y[nV - 1] : 0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kSmallItems; ++j) {                    // X[p] = first atom of piece p (pm is dead)
-        const int u = tid * kSmallItems + j;
-        if (u < nV && st[j]) X[Y[u] - 1] = u;
+    const int np = np_s;
+    if (tid < n_words) {                                       // X[p] = first atom of piece p (the cursors are dead)
+        int p = wrank[tid];
+        unsigned bits = my_starts;
+        while (bits) {
+            const int bpos = __ffs(bits) - 1;
+            bits &= bits - 1u;
+            X[p++] = tid * 32 + bpos;
+        }
     }
     if (tid == 0) X[np] = nV;
     __syncthreads();
@@ -337,29 +358,42 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
     }
     __syncthreads();
     stamp();  // p4: next pointers
-    // The chain of tile starts 0 -> nx[0] -> nx[nx[0]] -> ... is walked by ONE wave, 64 pieces at a time:
-    // lane l holds nx of piece base + l in a register, a hop is a v_readlane (no LDS round trip), the chain
-    // nodes of the block are the set bits of a wave-uniform mask, their rank a popcount.
+    // The chain of tile starts is walked per BLOCK of 64 consecutive pieces, one wave per block, all blocks
+    // in parallel: a tile starts at every block start (at most one under-filled tile per block; the tile
+    // before it simply ends there), lane l holds nx of piece base + l in a register, a hop is a v_readlane
+    // (no LDS round trip), the chain nodes of the block are the set bits of a wave-uniform mask, their rank a
+    // popcount on top of the tile count of the blocks before.
+    constexpr int kMaxBlocks = kSmallMaxAtoms / 64 + 1;
     __shared__ int ntile_s;
+    __shared__ int blk_cnt[kMaxBlocks];
+    __shared__ unsigned long long blk_mask[kMaxBlocks];
     if (tid == 0) ntile_s = 0;
     __syncthreads();
-    // waves 1..15 write the plan's arrays (other_work) while wave 0 walks the chain (latency bound, ~100
-    // cycles per tile); wave 0 joins the output work afterwards
-    if (tid >= 64) other_work(tid - 64, kSmallThreads - 64);
-    if (tid < 64 && *bad_s == 0) {
-        const int lane = tid;
-        int e = 0, rank = 0;  // next chain node (wave-uniform), tiles emitted so far
-        for (int base = 0; base < np; base += 64) {
-            const int p = base + lane;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nblk = (np + 63) >> 6;
+    const bool walk = *bad_s == 0;
+    if (walk) {
+        for (int blk = wave; blk < nblk; blk += kSmallThreads / 64) {
+            const int base = blk * 64, p = base + lane;
             const int my_nx = p < np ? Y[p] : np;
-            unsigned long long mask = 0ull;
-            int es = __builtin_amdgcn_readfirstlane(e);  // scalar chain cursor: a hop is one v_readlane_b32
             const int lim = (base + 64 < np ? base + 64 : np);
+            unsigned long long mask = 0ull;
+            int es = base;  // scalar chain cursor
             while (es < lim) {
                 mask |= 1ull << (es - base);
                 es = __builtin_amdgcn_readlane(my_nx, es - base);
             }
-            e = es;
+            if (lane == 0) { blk_mask[blk] = mask; blk_cnt[blk] = __popcll(mask); }
+        }
+    }
+    __syncthreads();
+    if (walk) {
+        for (int blk = wave; blk < nblk; blk += kSmallThreads / 64) {
+            int rank = 0;
+            for (int b2 = lane; b2 < blk; b2 += 64) rank += blk_cnt[b2];
+            for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off);
+            const unsigned long long mask = blk_mask[blk];
+            const int p = blk * 64 + lane;
             const bool on = (mask >> lane) & 1ull;
             const int r = rank + __popcll(mask & ((1ull << lane) - 1ull));
             if (on && r < (int)L.max_mtiles) {
@@ -367,13 +401,14 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
                 mrow[r] = rowp[v];
                 matom[r] = v;
             }
-            rank += __popcll(mask);
-        }
-        if (lane == 0) {
-            if (rank > (int)L.max_mtiles) atomicOr(bad_s, 1);
-            ntile_s = rank;
+            if (blk == nblk - 1 && lane == 0) {
+                const int total = rank + __popcll(mask);
+                if (total > (int)L.max_mtiles) atomicOr(bad_s, 1);
+                ntile_s = total;
+            }
         }
     }
+    other_work(tid, kSmallThreads);
     __syncthreads();
     stamp();  // p5: chain walk
     const int n_tiles = ntile_s;
@@ -494,39 +529,65 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     }
     __syncthreads();
     stamp();  // 4: scan
-    // phase 3: fill rows (order inside a row is arbitrary here)
+    // phase 3: fill rows (order inside a row is arbitrary here); the scratch of the piece tiles is zeroed for
+    // the covered-boundary bytes of phase 4
+    unsigned char* covb = reinterpret_cast<unsigned char*>(Ybuf);  // covb[u] != 0: an edge joins atoms < u with atoms >= u
+    for (int w = tid; w < (nV + 3) / 4 + 1; w += kSmallThreads) Ybuf[w] = 0;
     for (int e = tid; e < nE; e += kSmallThreads) {
         const int pos = atomicAdd(&cnt[dst16[e]], 1);
         perm16[pos] = (u16)e;
     }
     __syncthreads();
     stamp();  // 5: fill
-    // phase 4: restore increasing edge id inside every row (the reference's summation order); the fill
-    // cursor array is dead now and becomes maxnbr[v] = max(v, largest neighbour) for the piece tiles
+    // phase 4, one thread per atom: restore increasing edge id inside the row (the reference's summation
+    // order), record the inverse permutation, and mark the atom boundaries the row's bonds reach across
+    // (for the piece tiles).  Rows of <= 4 entries (molecules) are sorted in registers.
     for (int v = tid; v < nV; v += kSmallThreads) {
         const int b = rowp[v];
         const int n = rowp[v + 1] - b;
         u16* row = perm16 + b;
-        for (int i = 1; i < n; ++i) {
-            const u16 key = row[i];
-            int j = i - 1;
-            while (j >= 0 && row[j] > key) {
-                row[j + 1] = row[j];
-                --j;
+        int far = v;  // largest neighbour
+        if (n <= 4) {
+            const int last = n > 0 ? n - 1 : 0;
+            unsigned e0 = row[0 <= last ? 0 : last], e1 = row[1 <= last ? 1 : last], e2 = row[2 <= last ? 2 : last], e3 = row[3 <= last ? 3 : last];
+            e0 = n > 0 ? e0 : 0xffffu; e1 = n > 1 ? e1 : 0xffffu; e2 = n > 2 ? e2 : 0xffffu; e3 = n > 3 ? e3 : 0xffffu;
+            unsigned t;
+#define DMPNN_CSWAP(x, y) t = min(x, y); y = max(x, y); x = t
+            DMPNN_CSWAP(e0, e1); DMPNN_CSWAP(e2, e3); DMPNN_CSWAP(e0, e2); DMPNN_CSWAP(e1, e3); DMPNN_CSWAP(e1, e2);
+#undef DMPNN_CSWAP
+            const unsigned ee[4] = {e0, e1, e2, e3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < n) {
+                    row[k] = (u16)ee[k];
+                    inv16[ee[k]] = (u16)(b + k);
+                    far = max(far, (int)src16[ee[k]]);
+                }
             }
-            row[j + 1] = key;
+        } else {
+            for (int i = 1; i < n; ++i) {
+                const u16 key = row[i];
+                int j = i - 1;
+                while (j >= 0 && row[j] > key) {
+                    row[j + 1] = row[j];
+                    --j;
+                }
+                row[j + 1] = key;
+            }
+            for (int k = 0; k < n; ++k) {
+                inv16[row[k]] = (u16)(b + k);
+                far = max(far, (int)src16[row[k]]);
+            }
         }
-        cnt[v] = v;
+        if (far - v >= kMegaBA) {
+            atomicOr(&piece_bad_s, 1);  // this bond alone spans more atoms than a tile holds: no piece tiles
+        } else {
+            for (int u = v + 1; u <= far; ++u) covb[u] = 1;
+        }
     }
     __syncthreads();
     stamp();  // 6: sort
-    // phase 5: inverse permutation; maxnbr by one LDS atomic per edge
-    for (int i = tid; i < nE; i += kSmallThreads) {
-        inv16[perm16[i]] = (u16)i;
-        atomicMax(&cnt[dst16[i]], (int)src16[i]);
-    }
-    __syncthreads();
-    stamp();  // 7: inverse
+    stamp();  // 7: (inverse folded into phase 4)
     // phase 6 (runs on waves 1..15 while wave 0 walks the tile chain of phase 7): everything out.  A light
     // plan (forward of the fused routes only) skips the six arrays only the general route, the backward
     // pass and the tests read.
@@ -578,7 +639,7 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_small),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
             if (e != hipSuccess) {
                 set_error("hipFuncSetAttribute(k_prepare_small): %s", hipGetErrorString(e));
                 return DMPNN_EHIP;

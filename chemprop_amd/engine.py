@@ -14,14 +14,14 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_SPLIT16, F_UNDIRECTED, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
+from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_SPLIT16, F_UNDIRECTED, F_WSPLIT_READY, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
 
 
 def small_plan_fits(n_atoms: int, n_edges: int) -> bool:
     """Batches the single-workgroup plan takes (mirror of csrc/dmpnn_common.hpp small_plan_fits): only
     those get piece tiles, hence the whole-forward tile kernel, and a light plan."""
     lds = ((3 * (n_atoms + 2)) * 4 + (5 * n_edges + 2) * 2 + 31) & ~15
-    return n_atoms <= 6144 and n_edges <= 10240 and lds <= 160 * 1024 - 512
+    return n_atoms <= 6144 and n_edges <= 10240 and lds <= 160 * 1024 - 2048
 
 
 def _stream_ptr(device) -> int:
@@ -229,7 +229,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             b_d: Optional[Tensor] = None, V_d: Optional[Tensor] = None, depth: int = 3, act: str = "relu",
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
             keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
-            max_level: int = 2, mfma: Optional[str] = None) -> tuple[Tensor, ForwardState]:
+            max_level: int = 2, mfma: Optional[str] = None, wcache: Optional[dict] = None) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -237,6 +237,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
                     molecules of <= 24 bonds);
     * ``fused``   — per depth step one contraction whose epilogue forms the segment sums (CSR-row order);
     * ``general`` — arbitrary index arrays / undirected / any ``d_h`` (caller's edge order).
+
+    ``wcache``: a dict owned by the caller (one per module) in which the pre-split weights of the split-MFMA
+    route survive between calls; they are reused while W_i / W_h / W_o are the same tensors at the same
+    ``_version`` (frozen weights; ``DMPNN_WCACHE=0`` disables it).
 
     ``mfma`` picks the matrix arithmetic of the mega route: ``"split16"`` (default; fp32-equivalent exact
     3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
@@ -333,7 +337,18 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if (mfma or os.environ.get("DMPNN_MFMA", "split16")) != "f32":
             a.flags |= F_SPLIT16
             nb = int(lib.dmpnn_forward_wsplit_bytes(C.byref(a)))
-            wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
+            # pre-split weights are reusable while the weight tensors are the same objects at the same
+            # autograd version (every in-place update bumps `_version`): inference with frozen weights
+            key = None
+            if wcache is not None and os.environ.get("DMPNN_WCACHE", "1") != "0":
+                key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (W_i, W_h, W_o)) + (nb, d_v, d_e, str(dev))
+                if wcache.get("key") == key:
+                    wsplit = wcache["buf"]
+                    a.flags |= F_WSPLIT_READY
+            if wsplit is None:
+                wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
+                if key is not None:
+                    wcache["key"], wcache["buf"] = key, wsplit
             a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
             st.route = "mega16"
     if keep:

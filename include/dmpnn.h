@@ -62,9 +62,13 @@ enum dmpnn_flags {
                                      CU (dmpnn_forward_can_fuse returns 2 when the shapes allow it)   */
     DMPNN_F_KEEP = 1u << 3,       /* dmpnn_backward will follow: H0, H^(t), M^(t), Mv are written to
                                      the workspace (always the case outside DMPNN_F_MEGA)             */
-    DMPNN_F_SPLIT16 = 1u << 4     /* with DMPNN_F_MEGA: contractions on the f16 matrix pipe with the exact
+    DMPNN_F_SPLIT16 = 1u << 4,    /* with DMPNN_F_MEGA: contractions on the f16 matrix pipe with the exact
                                      3-term split (x s = hi + lo, fp32 accumulate): fp32-class accuracy at
                                      5.3x the fp32-MFMA rate; needs the `wsplit` workspace                */
+    DMPNN_F_WSPLIT_READY = 1u << 5 /* with DMPNN_F_SPLIT16: `wsplit` still holds the pre-split an earlier
+                                     dmpnn_forward wrote for exactly these W_i / W_h / W_o values and shapes
+                                     (the CALLER vouches for it, e.g. inference with frozen weights): the
+                                     pre-split launch is skipped                                          */
 };
 
 /* ---------------------------------------------------------------------------------------------

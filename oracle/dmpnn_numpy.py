@@ -77,10 +77,11 @@ def tile_tables(row_ptr, n_edges, n_slots, bm=48, max_deg_supported=24):
     return tile_row, tile_atom, n_tiles, b0
 
 
-def piece_tiles(src, dst, row_ptr, n_slots, bm=48, ba=32):
+def piece_tiles(src, dst, row_ptr, n_slots, bm=48, ba=32, block=64):
     """Row tiles made of WHOLE connected pieces (restates ``build_piece_tiles`` of
     csrc/dmpnn_prepare.hip): a cut after atom ``v`` is safe when no edge joins atoms <= v with atoms
-    > v; consecutive pieces are packed greedily into tiles of <= ``bm`` rows and <= ``ba`` atoms.
+    > v; consecutive pieces are packed greedily into tiles of <= ``bm`` rows and <= ``ba`` atoms, and a
+    tile also starts at every ``block``-th piece (the kernel walks blocks of pieces in parallel).
     Returns (mtile_row[n_slots + 2], mtile_atom[n_slots + 2], n_tiles) or n_tiles = -1 if a piece
     does not fit."""
     src, dst, row_ptr = (np.asarray(a, dtype=np.int64) for a in (src, dst, row_ptr))
@@ -92,18 +93,19 @@ def piece_tiles(src, dst, row_ptr, n_slots, bm=48, ba=32):
         np.maximum.at(maxnbr, dst, src)
         np.maximum.at(maxnbr, src, dst)
     pm = np.maximum.accumulate(maxnbr) if n_atoms else maxnbr
-    starts = [u for u in range(n_atoms) if u == 0 or pm[u - 1] == u - 1]
-    start_set = set(starts)
-    tiles, v = [], 0
-    while v < n_atoms:
-        u = v + 1
-        while u < n_atoms and u - v < ba and row_ptr[u + 1] - row_ptr[v] <= bm:
-            u += 1
-        cand = n_atoms if u >= n_atoms else max(s for s in starts if s <= u)
-        if cand <= v or row_ptr[u] - row_ptr[v] > bm:
+    starts = [u for u in range(n_atoms) if u == 0 or pm[u - 1] == u - 1] + [n_atoms]
+    n_pieces = len(starts) - 1
+    tiles, p = [], 0
+    while p < n_pieces:
+        v = starts[p]
+        if starts[p + 1] - v > ba or row_ptr[starts[p + 1]] - row_ptr[v] > bm:
             return mrow, matom, -1
+        q = p + 1
+        lim = min(n_pieces, (p // block + 1) * block)
+        while q < lim and starts[q + 1] - v <= ba and row_ptr[starts[q + 1]] - row_ptr[v] <= bm:
+            q += 1
         tiles.append(v)
-        v = cand
+        p = q
     if len(tiles) > n_slots:
         return mrow, matom, -1
     for t, a in enumerate(tiles):

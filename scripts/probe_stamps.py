@@ -43,6 +43,6 @@ for i, n in enumerate(pn):
 print("--- piece tiles")
 qs = st[48:]
 prev = qs[0]
-for i, n in enumerate(["entry", "prefix max", "start ranks", "piece starts", "next ptrs", "chain walk"]):
+for i, n in enumerate(["entry", "start bits", "start ranks", "piece starts", "next ptrs", "chain walk"]):
     if qs[i]:
         print(f"{n:20s} +{(qs[i]-prev):8d} cycles"); prev = qs[i]

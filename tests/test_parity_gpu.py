@@ -433,6 +433,32 @@ def test_backward_full_size_vs_oracle_autograd(n_mols, kind, kw, gpu_device):
         assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
+def test_presplit_weight_cache_follows_weight_updates(gpu_device):
+    """Inference reuses the pre-split weights of the split-MFMA route between calls (same tensors, same
+    ``_version``); any in-place update (optimizer step, load_state_dict) must invalidate them."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = synth.random_batch(16, "qm9", seed=5)
+    bmg.to(gpu_device)
+    torch.manual_seed(3)
+    mp = BondMessagePassing(d_h=300).to(gpu_device).eval()
+    with torch.no_grad():
+        a = mp(bmg)
+        b = mp(bmg)  # second call: cached pre-split
+        cache = mp.__dict__.get("_dmpnn_wcache")
+        assert cache and cache.get("buf") is not None, "the default route of this batch is the split-MFMA tile kernel"
+        assert torch.equal(a, b)
+        mp.W_h.weight.mul_(1.5)
+        mp.W_o.weight.add_(0.01)
+        c = mp(bmg)
+        fresh = BondMessagePassing(d_h=300).to(gpu_device).eval()
+        fresh.load_state_dict(mp.state_dict())
+        d = fresh(bmg)
+    assert not torch.equal(a, c)
+    assert torch.equal(c, d)
+
+
 def test_frozen_encoder_and_no_grad(gpu_device):
     """requires_grad_(False) on the block (cli/train.py:1826-1828) and torch.no_grad() both work."""
     from chemprop_amd import synth
