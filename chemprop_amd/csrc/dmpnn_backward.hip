@@ -322,8 +322,8 @@ __device__ __forceinline__ float4 wg_load_a(const WgradArgs& a, int64_t g2, int6
 template <bool FULL>
 __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, f32x4 (&acc)[4][4], int64_t m_lo, int64_t m_hi, int n0,
                                            int k0, int wave, int li, int lg) {
-    for (int64_t mb = m_lo + 4 * wave; mb < m_hi; mb += 16 * WG_U) {
-        float4 z[WG_U], x[WG_U];
+    // software pipeline: the loads of batch b+1 are in flight while the 64 MFMAs of batch b run
+    auto load_batch = [&](int64_t mb, float4 (&z)[WG_U], float4 (&x)[WG_U]) {
 #pragma unroll
         for (int u = 0; u < WG_U; ++u) {
             const int64_t m = mb + 16 * u + lg;
@@ -334,6 +334,8 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, f32x4 (&acc)[4][4
             z[u] = wg_load_z(a, mc, mok, n0 + 4 * li);
             x[u] = wg_load_a<FULL>(a, g2, g1, mok, k0 + 4 * li);
         }
+    };
+    auto mfma_batch = [&](const float4 (&z)[WG_U], const float4 (&x)[WG_U]) {
 #pragma unroll
         for (int u = 0; u < WG_U; ++u) {
             const float zz[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
@@ -344,6 +346,21 @@ __device__ __forceinline__ void wgrad_loop(const WgradArgs& a, f32x4 (&acc)[4][4
                 for (int jk = 0; jk < 4; ++jk)
                     acc[jn][jk] = __builtin_amdgcn_mfma_f32_16x16x4f32(zz[jn], xx[jk], acc[jn][jk], 0, 0, 0);
         }
+    };
+    int64_t mb = m_lo + 4 * wave;
+    if (mb >= m_hi) return;
+    float4 z0[WG_U], x0[WG_U], z1[WG_U], x1[WG_U];
+    load_batch(mb, z0, x0);
+    for (;;) {
+        const int64_t mb1 = mb + 16 * WG_U;
+        if (mb1 < m_hi) load_batch(mb1, z1, x1);
+        mfma_batch(z0, x0);
+        if (mb1 >= m_hi) break;
+        const int64_t mb2 = mb1 + 16 * WG_U;
+        if (mb2 < m_hi) load_batch(mb2, z0, x0);
+        mfma_batch(z1, x1);
+        if (mb2 >= m_hi) break;
+        mb = mb2;
     }
 }
 

@@ -13,11 +13,11 @@ print("molecules", nm, "edges", bmg.E.shape[0])
 mp = BondMessagePassing().to(dev).eval()
 plan = engine.GraphPlan.from_bmg(bmg)
 buf = torch.zeros(64, dtype=torch.int64, device=dev)
-fw = lambda: engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega", mfma="split16")
+fw = lambda: engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega", mfma="split16", keep=("keep" in sys.argv))
 with torch.no_grad():
     for _ in range(5): fw()
     lib.dmpnn_debug_timestamps(buf.data_ptr())
-    plan = engine.GraphPlan.from_bmg(bmg, light=len(sys.argv) > 2 and sys.argv[2] == "light")
+    plan = engine.GraphPlan.from_bmg(bmg, light=("light" in sys.argv))
     fw(); torch.cuda.synchronize()
     lib.dmpnn_debug_timestamps(None)
 st = buf.cpu().tolist()
