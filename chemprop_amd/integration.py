@@ -64,15 +64,57 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-def accelerate(model):
-    """Swap the class of every ``BondMessagePassing`` block inside ``model`` (an ``MPNN``, a
+_agg_cache = None
+
+
+def hip_aggregation_classes():
+    """``{reference class: HIP subclass}`` for ``chemprop.nn.agg`` Mean / Sum / Norm / Attentive aggregation
+    (f1: the step after the block, ``models/model.py:131``); ``forward`` only is overridden."""
+    global _agg_cache
+    if _agg_cache is not None:
+        return _agg_cache
+    try:
+        from chemprop.nn import agg as ref_agg  # noqa: WPS433
+    except Exception as e:  # pragma: no cover
+        raise ImportError("chemprop_amd.integration needs an importable `chemprop`") from e
+    from .agg import aggregation_forward
+
+    out = {}
+    for name, mode in (("MeanAggregation", "mean"), ("SumAggregation", "sum"), ("NormAggregation", "norm"),
+                       ("AttentiveAggregation", "attentive")):
+        Ref = getattr(ref_agg, name)
+
+        def make(Ref=Ref, mode=mode, name=name):
+            class Hip(Ref):  # type: ignore[misc, valid-type]
+                def __init__(self, *args, **kwargs):
+                    super().__init__(*args, **kwargs)
+                    self.hparams["cls"] = Ref  # checkpoints stay loadable by stock chemprop
+
+                def forward(self, H: Tensor, batch: Tensor) -> Tensor:
+                    return aggregation_forward(self, H, batch, mode)
+
+            Hip.__name__ = Hip.__qualname__ = "Hip" + name
+            return Hip
+
+        out[Ref] = make()
+    _agg_cache = out
+    return out
+
+
+def accelerate(model, aggregation: bool = True):
+    """Swap the class of every ``BondMessagePassing`` block (and, unless ``aggregation=False``, of every
+    Mean / Sum / Norm / Attentive aggregation) inside ``model`` (an ``MPNN``, a
     ``MulticomponentMessagePassing`` or the block itself) for the HIP subclass, in place.  No
     parameter is copied or re-created; optimizer state and checkpoints stay valid."""
     Ref = _reference_class()
     Hip = hip_bond_message_passing_class()
+    aggs = hip_aggregation_classes() if aggregation else {}
     n = 0
     for m in model.modules():
         if type(m) is Ref:
             m.__class__ = Hip
+            n += 1
+        elif type(m) in aggs:
+            m.__class__ = aggs[type(m)]
             n += 1
     return n

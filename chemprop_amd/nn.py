@@ -120,6 +120,10 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
     plan = engine.GraphPlan.from_bmg(bmg, light=_light_plan_ok(mp))
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    if n_mols and getattr(bmg, "batch", None) is not None:
+        from .agg import note_batch
+
+        note_batch(bmg.batch, n_mols)  # the aggregation that follows (model.py:131) skips its host read of batch.max()
     return mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols))
 
 

@@ -255,6 +255,25 @@ int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, 
                        float* gb, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * f1 (the step right after the path): per-molecule aggregation of the atom representations.
+ * Replaces chemprop/nn/agg.py:66-113 (MeanAggregation / SumAggregation / NormAggregation.forward: an
+ * [V, h] int64 index, a host read of batch.max() and scatter_reduce_) by a segment reduction over the
+ * SORTED `batch` vector (data/collate.py:48-62).  `n_mols` is the caller's (the reference reads it back
+ * from the device).  Molecules without atoms give zero rows (agg.py:44-46).  An invalid `batch` (id out of
+ * range, or decreasing) is detected on device and poisons the outputs with NaN.
+ *   dmpnn_molagg_bounds  first / one-past-last atom of every molecule + the validity flag -> ws
+ *   dmpnn_molagg_fwd     out[m] = sum_{v in m} H[v]   (MEAN: / count, NORM: / norm; true divisions)
+ *   dmpnn_molagg_bwd     gH[v]  = gOut[batch[v]]      (MEAN: / count, NORM: / norm)
+ * ------------------------------------------------------------------------------------------- */
+enum dmpnn_molagg_mode { DMPNN_MOLAGG_SUM = 0, DMPNN_MOLAGG_MEAN = 1, DMPNN_MOLAGG_NORM = 2 };
+size_t dmpnn_molagg_ws_bytes(int64_t n_mols);
+int dmpnn_molagg_bounds(const int64_t* batch, int64_t n_atoms, int64_t n_mols, void* ws, size_t ws_bytes, void* stream);
+int dmpnn_molagg_fwd(const float* H, int64_t ldh, int64_t n_atoms, int64_t d_h, int64_t n_mols, const void* ws, int mode,
+                     float norm, float* out, int64_t ldo, void* stream);
+int dmpnn_molagg_bwd(const float* gout, int64_t ldg, const int64_t* batch, int64_t n_atoms, int64_t d_h, int64_t n_mols,
+                     const void* ws, int mode, float norm, float* gH, int64_t ldgh, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Misc
  * ------------------------------------------------------------------------------------------- */
 int dmpnn_version(void);

@@ -109,3 +109,36 @@ def test_product_does_not_import_oracle():
     for path in glob.glob(os.path.join(root, "chemprop_amd", "**", "*.py"), recursive=True):
         src = open(path).read()
         assert "import oracle" not in src and "from oracle" not in src, path
+
+
+def test_accelerate_swaps_the_real_reference_classes():
+    """`integration.accelerate` on a model made of the REAL chemprop classes (imported through the shim,
+    build container only): the block and the aggregation become HIP subclasses in place, parameters,
+    hparams (`cls` stays the reference class) and state_dict keys untouched."""
+    import torch
+
+    from oracle import ref_shim
+
+    if not ref_shim.reference_available():
+        pytest.skip("/root/reference absent (GPU box)")
+    ref_shim.install()
+    from chemprop.nn import BondMessagePassing as RefMP
+    from chemprop.nn.agg import NormAggregation as RefNorm
+
+    from chemprop_amd import integration
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.message_passing = RefMP(d_h=16)
+            self.agg = RefNorm(norm=3.0)
+
+    m = Model()
+    keys, w = list(m.state_dict().keys()), m.message_passing.W_h.weight
+    assert integration.accelerate(m) == 2
+    assert isinstance(m.message_passing, RefMP) and type(m.message_passing) is not RefMP
+    assert isinstance(m.agg, RefNorm) and type(m.agg) is not RefNorm
+    assert m.message_passing.hparams["cls"] is RefMP and m.agg.hparams["cls"] is RefNorm and m.agg.norm == 3.0
+    assert list(m.state_dict().keys()) == keys and m.message_passing.W_h.weight is w
+    with pytest.raises(RuntimeError):  # CPU tensors: the engine has no fallback
+        m.agg(torch.zeros(3, 16), torch.zeros(3, dtype=torch.int64))
