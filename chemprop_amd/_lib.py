@@ -31,7 +31,7 @@ EXPORTS = [
     "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_prepare_light", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
     "dmpnn_linear_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
-    "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd",
+    "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -180,6 +180,8 @@ def load() -> C.CDLL:
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes",
                   "dmpnn_molagg_ws_bytes")
+    lib.dmpnn_gather_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                      C.c_void_p]
     lib.dmpnn_molagg_ws_bytes.argtypes = [C.c_int64]
     lib.dmpnn_molagg_bounds.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dmpnn_molagg_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_float,

@@ -94,6 +94,25 @@ class _Aggregate(torch.autograd.Function):
         return None, engine.aggregate_bwd(ctx.plan, gMv.contiguous())
 
 
+class _GatherSrc(torch.autograd.Function):
+    """``M[e] = S[src(e)]`` (mixins.py:30); transpose: ``gS[v] = sum_{e: src(e) = v} gM[e]`` which, on a
+    symmetric graph (src(e) = dst(rev e)), is the incoming-edge segment sum of the rows taken through rev."""
+
+    @staticmethod
+    def forward(ctx, plan, S):
+        ctx.plan = plan
+        return engine.gather_rows(S, plan.src32)
+
+    @staticmethod
+    def backward(ctx, gM):
+        plan = ctx.plan
+        return None, engine.aggregate(plan, engine.gather_rows(gM.contiguous(), plan.rev32))
+
+
+def gather_src_fn(plan, S: Tensor) -> Tensor:
+    return _GatherSrc.apply(plan, S)
+
+
 def linear_fn(A1: Tensor, W: Tensor, b: Optional[Tensor], A2: Optional[Tensor] = None,
               gather: Optional[Tensor] = None, n_rows: Optional[int] = None, Cadd: Optional[Tensor] = None) -> Tensor:
     return _Linear.apply(A1, W, b, A2, gather, n_rows, Cadd)

@@ -169,3 +169,43 @@ int dmpnn_molagg_bwd(const float* gout, int64_t ldg, const int64_t* batch, int64
 }
 
 }  // extern "C"
+
+// ---- generic row gather: out[i] = X[idx[i]] (f2, atom messages: M[e] = S[src(e)], mixins.py:30) ----------
+namespace dmpnn {
+namespace {
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ X, int64_t ldx, int64_t n_src,
+                                                     const int* __restrict__ idx, int64_t n_out, int d,
+                                                     float* __restrict__ out, int64_t ldo, int vec) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < n_out; i += gridDim.x * 4ll) {
+        const int64_t r = idx[i];
+        const bool ok = r >= 0 && r < n_src;  // an index out of range gives a NaN row, not a wild read
+        const float* src = X + (ok ? r : 0) * ldx;
+        float* dst = out + i * ldo;
+        if (vec) {
+            for (int c = lane * 4; c < d; c += 256) {
+                float4 v = *reinterpret_cast<const float4*>(src + c);
+                if (!ok) v.x = v.y = v.z = v.w = __int_as_float(0x7fc00000);
+                *reinterpret_cast<float4*>(dst + c) = v;
+            }
+        } else {
+            for (int c = lane; c < d; c += 64) dst[c] = ok ? src[c] : __int_as_float(0x7fc00000);
+        }
+    }
+}
+}  // namespace
+}  // namespace dmpnn
+
+extern "C" int dmpnn_gather_rows(const float* X, int64_t ldx, int64_t n_src, const int* idx, int64_t n_out, int64_t d,
+                                 float* out, int64_t ldo, void* stream) {
+    DMPNN_CHECK_ARG(d >= 0 && d < (1 << 24) && ldx >= d && ldo >= d && n_src >= 0 && n_out >= 0, "gather_rows: bad sizes");
+    if (n_out == 0 || d == 0) return DMPNN_OK;
+    DMPNN_CHECK_ARG(X && idx && out, "gather_rows: NULL pointer");
+    const int vec = d % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && dmpnn::aligned16(X) && dmpnn::aligned16(out);
+    int64_t blocks = (n_out + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dmpnn::k_gather_rows, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, n_src,
+                       idx, n_out, (int)d, out, ldo, vec);
+    DMPNN_CHECK_LAUNCH("k_gather_rows");
+    return DMPNN_OK;
+}

@@ -120,6 +120,10 @@ class GraphPlan:
         return self._view(1)
 
     @property
+    def rev32(self) -> Tensor:
+        return self._view(2)
+
+    @property
     def rev64(self) -> Tensor:
         return self._view(2).long()
 
@@ -158,6 +162,21 @@ def aggregate(plan: GraphPlan, H: Tensor, act_on_load: str = "none", slope: floa
             Mv.data_ptr(), Mv.stride(0), act_code(act_on_load), float(slope), _ptr(slope_t),
             _stream_ptr(H.device)), "dmpnn_aggregate_fwd")
     return Mv
+
+
+def gather_rows(X: Tensor, idx32: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """``out[i] = X[idx32[i]]`` (``dmpnn_gather_rows``; an index out of range gives a NaN row)."""
+    X = _f32c(X, "X")
+    _require_device(idx32, "idx")
+    if idx32.dtype != torch.int32:
+        raise RuntimeError("gather_rows: int32 indices (the plan's arrays)")
+    n = int(idx32.shape[0])
+    O = out if out is not None else torch.empty(n, X.shape[1], dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _lib.check(_lib.load().dmpnn_gather_rows(X.data_ptr(), X.stride(0), X.shape[0], idx32.data_ptr(), n, X.shape[1],
+                                                 O.data_ptr(), O.stride(0) if n else X.shape[1], _stream_ptr(X.device)),
+                   "dmpnn_gather_rows")
+    return O
 
 
 def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Tensor] = None,

@@ -20,7 +20,7 @@ from typing import Optional
 
 from torch import Tensor
 
-from .nn import bond_message_passing_forward
+from .nn import atom_message_passing_forward, bond_message_passing_forward
 
 _cls_cache = None
 
@@ -58,9 +58,36 @@ def hip_bond_message_passing_class():
     return HipBondMessagePassing
 
 
+_atom_cache = None
+
+
+def hip_atom_message_passing_class():
+    """``class HipAtomMessagePassing(chemprop.nn.AtomMessagePassing)`` (f2): ``forward`` only."""
+    global _atom_cache
+    if _atom_cache is not None:
+        return _atom_cache
+    try:
+        from chemprop.nn import AtomMessagePassing as Ref  # noqa: WPS433
+    except Exception as e:  # pragma: no cover
+        raise ImportError("chemprop_amd.integration needs an importable `chemprop`") from e
+
+    class HipAtomMessagePassing(Ref):  # type: ignore[misc, valid-type]
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.hparams["cls"] = Ref
+
+        def forward(self, bmg, V_d: Optional[Tensor] = None) -> Tensor:
+            return atom_message_passing_forward(self, bmg, V_d)
+
+    _atom_cache = (Ref, HipAtomMessagePassing)
+    return _atom_cache
+
+
 def __getattr__(name):
     if name == "HipBondMessagePassing":
         return hip_bond_message_passing_class()
+    if name == "HipAtomMessagePassing":
+        return hip_atom_message_passing_class()[1]
     raise AttributeError(name)
 
 
@@ -102,17 +129,21 @@ def hip_aggregation_classes():
 
 
 def accelerate(model, aggregation: bool = True):
-    """Swap the class of every ``BondMessagePassing`` block (and, unless ``aggregation=False``, of every
+    """Swap the class of every ``BondMessagePassing`` / ``AtomMessagePassing`` block (and, unless ``aggregation=False``, of every
     Mean / Sum / Norm / Attentive aggregation) inside ``model`` (an ``MPNN``, a
     ``MulticomponentMessagePassing`` or the block itself) for the HIP subclass, in place.  No
     parameter is copied or re-created; optimizer state and checkpoints stay valid."""
     Ref = _reference_class()
     Hip = hip_bond_message_passing_class()
     aggs = hip_aggregation_classes() if aggregation else {}
+    RefAtom, HipAtom = hip_atom_message_passing_class()
     n = 0
     for m in model.modules():
         if type(m) is Ref:
             m.__class__ = Hip
+            n += 1
+        elif type(m) is RefAtom:
+            m.__class__ = HipAtom
             n += 1
         elif type(m) in aggs:
             m.__class__ = aggs[type(m)]

@@ -170,3 +170,90 @@ def _route(mp, plan, n_mols: int = 0) -> int:
             object.__setattr__(mp, "_dmpnn_no_mega", True)
             return 1
     return 1 if no_mega else 2
+
+
+class AtomMessagePassing(BondMessagePassing):
+    """f2: ``chemprop.nn.AtomMessagePassing`` (``base.py:254-289``, ``mixins.py:21-30``) on the
+    same kernels — messages pass along atoms:
+
+        H0 = W_i V[src]                      (mixins.py:22-23)
+        M  = (segsum_dst [H || E])[src]      (mixins.py:25-30: no reverse-edge subtraction)
+        H  = tau(H0 + W_h M)                 (base.py:135-141; W_h is [d_h, d_h + d_e])
+
+    then the same final aggregation / finalize as the bond variant.  Every contraction and segment
+    reduction is a HIP kernel (``dmpnn_linear_fwd``, ``dmpnn_aggregate_fwd``, ``dmpnn_gather_rows``); ``tau`` and
+    dropout run as torch modules between them (the per-step route of the bond block).  The bond-feature
+    half of the message, ``(segsum_dst E)[src]``, does not change over the depth loop and is formed once.
+    Same constructor arguments, parameter shapes, ``state_dict`` keys and RNG stream as the reference."""
+
+    def __init__(self, d_v: int = DEFAULT_ATOM_FDIM, d_e: int = DEFAULT_BOND_FDIM,
+                 d_h: int = DEFAULT_HIDDEN_DIM, bias: bool = False, depth: int = 3, dropout: float = 0.0,
+                 activation="relu", undirected: bool = False, d_vd: Optional[int] = None,
+                 V_d_transform: Optional[nn.Module] = None, graph_transform: Optional[nn.Module] = None):
+        nn.Module.__init__(self)
+        self.hparams = _HParams(d_v=d_v, d_e=d_e, d_h=d_h, bias=bias, depth=depth, dropout=dropout,
+                                activation=activation, undirected=undirected, d_vd=d_vd,
+                                V_d_transform=V_d_transform, graph_transform=graph_transform,
+                                cls=self.__class__)
+        # same construction order as base.py:278-289 -> same RNG stream -> same initial weights
+        self.W_i = nn.Linear(d_v, d_h, bias)
+        self.W_h = nn.Linear(d_e + d_h, d_h, bias)
+        self.W_o = nn.Linear(d_v + d_h, d_h)
+        self.W_d = nn.Linear(d_h + d_vd, d_h + d_vd) if d_vd else None
+        self.depth = depth
+        self.undirected = undirected
+        self.dropout = nn.Dropout(dropout)
+        self.tau = get_activation_function(activation)
+        self.V_d_transform = V_d_transform if V_d_transform is not None else nn.Identity()
+        self.graph_transform = graph_transform if graph_transform is not None else nn.Identity()
+
+    def forward(self, bmg, V_d: Optional[Tensor] = None) -> Tensor:
+        return atom_message_passing_forward(self, bmg, V_d)
+
+
+def atom_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tensor:
+    """``_MessagePassingBase.forward`` (base.py:196-212) with the atom mixin (mixins.py:21-30)."""
+    from .backward import aggregate_fn, gather_src_fn, linear_fn
+
+    bmg = mp.graph_transform(bmg)
+    engine._require_device(bmg.V, "bmg.V")
+    if mp.W_i.weight.device != bmg.V.device:
+        raise RuntimeError(f"module is on {mp.W_i.weight.device} but the batch is on {bmg.V.device}")
+    n_atoms = int(bmg.V.shape[0])
+    has_vd = False
+    if V_d is not None:
+        V_d = mp.V_d_transform(V_d)
+        d_vd = (mp.W_d.in_features - mp.W_o.out_features) if mp.W_d is not None else None
+        if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
+            raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
+        has_vd = True
+    plan = engine.GraphPlan.from_bmg(bmg)
+    n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    if n_mols and getattr(bmg, "batch", None) is not None:
+        from .agg import note_batch
+
+        note_batch(bmg.batch, n_mols)
+    V, E = bmg.V, bmg.E
+    tau, drop = mp.tau, mp.dropout
+    nE = plan.n_edges
+    H0 = linear_fn(V, mp.W_i.weight, mp.W_i.bias, gather=plan.src32, n_rows=nE)
+    H = tau(H0)
+    if mp.depth > 1 and nE:
+        with torch.no_grad():
+            ME = engine.gather_rows(engine.aggregate(plan, E), plan.src32)      # [E, d_e], constant over the loop
+    rev = None
+    for _ in range(1, mp.depth):
+        if mp.undirected:
+            if rev is None:
+                rev = plan.rev64
+            H = (H + H[rev]) / 2
+        if nE:
+            MH = gather_src_fn(plan, aggregate_fn(plan, H))
+            H = drop(tau(linear_fn(MH, mp.W_h.weight, mp.W_h.bias, A2=ME, Cadd=H0)))
+        else:
+            H = drop(tau(H0))
+    Mv = aggregate_fn(plan, H)
+    Hv = drop(tau(linear_fn(V, mp.W_o.weight, mp.W_o.bias, A2=Mv)))
+    if has_vd:
+        Hv = drop(linear_fn(Hv, mp.W_d.weight, mp.W_d.bias, A2=V_d))
+    return Hv

@@ -273,6 +273,12 @@ int dmpnn_molagg_fwd(const float* H, int64_t ldh, int64_t n_atoms, int64_t d_h, 
 int dmpnn_molagg_bwd(const float* gout, int64_t ldg, const int64_t* batch, int64_t n_atoms, int64_t d_h, int64_t n_mols,
                      const void* ws, int mode, float norm, float* gH, int64_t ldgh, void* stream);
 
+/* f2 (atom messages, mixins.py:21-30): out[i] = X[idx[i]], i < n_out (an index outside [0, n_src) gives a NaN
+ * row).  M[e] = S[src(e)] with S = dmpnn_aggregate_fwd of the edge rows; its transpose is
+ * dmpnn_aggregate_fwd of the rows gathered through rev(e) (symmetric graphs).                           */
+int dmpnn_gather_rows(const float* X, int64_t ldx, int64_t n_src, const int* idx, int64_t n_out, int64_t d,
+                      float* out, int64_t ldo, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Misc
  * ------------------------------------------------------------------------------------------- */

@@ -127,3 +127,36 @@ def forward(V: Tensor, E: Tensor, edge_index: Tensor, rev: Tensor, w: MPWeights,
 
 def forward_bmg(bmg, w: MPWeights, **kw):
     return forward(bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, w, **kw)
+
+
+# ---- f2: AtomMessagePassing (base.py:254-289 with the atom mixin, mixins.py:21-30) --------------------------
+def atom_initialize(V: Tensor, src: Tensor, w: MPWeights) -> Tensor:
+    """mixins.py:22-23: ``W_i(V[src])``."""
+    return F.linear(V[src], w.W_i, w.b_i)
+
+
+def atom_message(H: Tensor, E: Tensor, src: Tensor, dst: Tensor, n_atoms: int) -> Tensor:
+    """mixins.py:25-30: segment-sum of ``[H || E]`` over incoming edges, gathered at the source atom."""
+    HE = torch.cat((H, E), dim=1)
+    return segment_sum_dst(HE, dst, n_atoms)[src]
+
+
+def atom_forward(V: Tensor, E: Tensor, edge_index: Tensor, rev: Tensor, w: MPWeights, depth: int = 3,
+                 activation="relu", undirected: bool = False, V_d: Optional[Tensor] = None,
+                 prelu_weight: Optional[Tensor] = None, return_intermediates: bool = False):
+    """base.py:196-212 for the atom variant (dropout 0, Identity transforms)."""
+    tau = activation if callable(activation) else activation_fn(activation, prelu_weight)
+    src, dst = edge_index[0], edge_index[1]
+    n_atoms = V.shape[0]
+    H0 = atom_initialize(V, src, w)
+    H = tau(H0)
+    inter = {"H0": H0, "M": []}
+    for _ in range(1, depth):
+        if undirected:
+            H = (H + H[rev]) / 2
+        M = atom_message(H, E, src, dst, n_atoms)
+        H = update(M, H0, w, tau)
+        inter["M"].append(M)
+    Mv = segment_sum_dst(H, dst, n_atoms)
+    out = finalize(Mv, V, V_d, w, tau)
+    return (out, inter) if return_intermediates else out
