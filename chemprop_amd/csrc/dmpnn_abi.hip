@@ -160,9 +160,17 @@ int dmpnn_update_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t
     return launch_linear_ex(g, x, static_cast<hipStream_t>(stream));
 }
 
+// per-step routes with DMPNN_F_SPLIT16: W_i | W_h | W_o (| W_d) pre-split one after the other
+static size_t steps16_wsplit_bytes(const dmpnn_fwd_args& a) {
+    const int64_t h = a.d_h;
+    size_t n = linear16_wsplit_bytes(h, a.d_v + a.d_e) + linear16_wsplit_bytes(h, h) + linear16_wsplit_bytes(h, a.d_v + h);
+    if (a.W_d && a.d_vd > 0) n += linear16_wsplit_bytes(h + a.d_vd, h + a.d_vd);
+    return n;
+}
+
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a) {
     if (!a || a->d_h <= 0 || a->d_v <= 0 || a->d_e < 0) return 0;
-    return mega16_wsplit_bytes(*a);
+    return (a->flags & DMPNN_F_MEGA) ? mega16_wsplit_bytes(*a) : steps16_wsplit_bytes(*a);
 }
 
 static bool al_ptr(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
@@ -306,6 +314,27 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     }
 
     // ---- general route: any index arrays, undirected, edge tensors in the caller's edge order ----
+    // With DMPNN_F_SPLIT16 the contractions run on the f16 pipe with the exact operand split (dmpnn_rows16.hip) where
+    // the shapes / alignments allow it; the weights are pre-split into `wsplit` first (or found there: WSPLIT_READY).
+    const bool use16 = (a->flags & DMPNN_F_SPLIT16) != 0;
+    SplitWView w16[4];
+    if (use16) {
+        DMPNN_CHECK_ARG(a->wsplit && a->wsplit_bytes >= steps16_wsplit_bytes(*a), "forward(split16): wsplit workspace missing or too small");
+        unsigned char* wp = static_cast<unsigned char*>(a->wsplit);
+        const bool ready = (a->flags & DMPNN_F_WSPLIT_READY) != 0;
+        const float* Ws[4] = {a->W_i, a->W_h, a->W_o, has_vd ? a->W_d : nullptr};
+        const int64_t Ns[4] = {h, h, h, h + a->d_vd}, Ks[4] = {dv + de, h, dv + h, h + a->d_vd};
+        for (int i = 0; i < 4; ++i) {
+            if (!Ws[i]) continue;
+            if (ready) w16[i] = split_weights_view_of(wp, Ns[i], Ks[i]);
+            else DMPNN_TRY(split_weights_view(Ws[i], Ks[i], Ns[i], Ks[i], 0, wp, &w16[i], s));
+            wp += linear16_wsplit_bytes(Ns[i], Ks[i]);
+        }
+    }
+    auto lin = [&](const dmpnn_gemm_args& g, int slot) -> int {
+        if (use16 && linear16_ok(g)) return launch_linear16_view(g, w16[slot], nullptr, 0, s);
+        return launch_linear(g, s);
+    };
     // K1  H0 = W_i([V[src] || E]) (+ b_i)                         mixins.py:8-9
     {
         dmpnn_gemm_args g;
@@ -315,7 +344,7 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         g.A2 = a->E; g.lda2 = a->lde;
         g.W = a->W_i; g.ldw = dv + de; g.bias = a->b_i;
         g.C = a->H0; g.ldc = a->ldh; g.act = DMPNN_ACT_NONE;
-        DMPNN_TRY(launch_linear(g, s));
+        DMPNN_TRY(lin(g, 0));
     }
     const float* Hprev = a->H0;   // H^(0) = tau(H0) is formed on load (base.py:200)
     int act_on_load = a->act;
@@ -334,7 +363,7 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         g.Cadd = a->H0; g.ldcadd = a->ldh;
         g.C = Ht; g.ldc = a->ldh;
         g.act = a->act; g.act_slope = a->act_slope; g.act_slope_ptr = a->act_slope_ptr;
-        DMPNN_TRY(launch_linear(g, s));
+        DMPNN_TRY(lin(g, 1));
         Hprev = Ht;
         act_on_load = DMPNN_ACT_NONE;
     }
@@ -351,7 +380,7 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         g.W = a->W_o; g.ldw = dv + h; g.bias = a->b_o;
         g.C = has_vd ? a->Hv : a->out; g.ldc = has_vd ? a->ldh : a->ldout;
         g.act = a->act; g.act_slope = a->act_slope; g.act_slope_ptr = a->act_slope_ptr;
-        DMPNN_TRY(launch_linear(g, s));
+        DMPNN_TRY(lin(g, 2));
     }
     if (has_vd) {
         dmpnn_gemm_args g;
@@ -361,7 +390,7 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         g.A2 = a->V_d; g.lda2 = a->ldvd;
         g.W = a->W_d; g.ldw = h + a->d_vd; g.bias = a->b_d;
         g.C = a->out; g.ldc = a->ldout; g.act = DMPNN_ACT_NONE;  // no tau on the W_d branch (base.py:187-188)
-        DMPNN_TRY(launch_linear(g, s));
+        DMPNN_TRY(lin(g, 3));
     }
     return DMPNN_OK;
 }

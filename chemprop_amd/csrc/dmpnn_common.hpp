@@ -176,6 +176,13 @@ bool mega_shapes_ok(const dmpnn_fwd_args& a);
 int launch_mega_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
 // the same on the f16 matrix pipe with the exact 3-term split (dmpnn_mega16.hip)
 size_t mega16_wsplit_bytes(const dmpnn_fwd_args& a);
+// per-step split-MFMA contraction (dmpnn_rows16.hip): pre-split weights of one matrix, shape gate, launch
+struct SplitWView { const unsigned char* p; const float* inv_scale; int nc; };
+size_t linear16_wsplit_bytes(int64_t N, int64_t K);
+int split_weights_view(const float* W, int64_t ldw, int64_t N, int64_t K, int tr, void* ws, SplitWView* out, hipStream_t s);
+SplitWView split_weights_view_of(void* ws, int64_t N, int64_t K);  // descriptor of a workspace that already holds the pre-split
+bool linear16_ok(const dmpnn_gemm_args& a);
+int launch_linear16_view(const dmpnn_gemm_args& a, const SplitWView& W, const int* poison_flags, int poison_mask, hipStream_t s);
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

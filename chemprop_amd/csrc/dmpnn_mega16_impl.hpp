@@ -71,12 +71,13 @@ struct SplitJob {
     const float* W; int ldw; int col0; int K;   // source columns [col0, col0 + K) of row n
     int scale_col0, scale_K;                    // columns the row scale is taken over (W_o: the whole row)
     unsigned char* out; int nc; float* inv_scale;
+    int tr;                                     // 1: the matrix is given transposed, element (n, k) = W[k * ldw + n]
 };
 struct SplitArgs {
     SplitJob job[4];
     int n_jobs, N;
 };
-__global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
+static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int Np = (a.N + 15) & ~15;  // whole column tiles: the padding rows of the last tile are written as zeros
@@ -84,9 +85,10 @@ __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
     if (j >= a.n_jobs) return;
     const SplitJob& J = a.job[j];
     const bool live = n < a.N;
-    const float* row = J.W + (long long)(live ? n : 0) * J.ldw;
+    const long long rs = J.tr ? 1 : J.ldw, ks = J.tr ? J.ldw : 1;  // strides of the output index n and of the reduction index k
+    const float* row = J.W + (long long)(live ? n : 0) * rs;
     float mx = 0.f;
-    for (int k = lane; k < J.scale_K; k += 64) mx = fmaxf(mx, fabsf(row[J.scale_col0 + k]));
+    for (int k = lane; k < J.scale_K; k += 64) mx = fmaxf(mx, fabsf(row[(J.scale_col0 + k) * ks]));
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     const float s = live ? scale_for(mx) : 0.f;
     if (lane == 0 && J.inv_scale && live) J.inv_scale[n] = 1.f / s;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
     _Float16* out = reinterpret_cast<_Float16*>(J.out);
     const int T = n >> 4, li = n & 15;
     for (int k = lane; k < J.nc * 32; k += 64) {
-        const float x = (k < J.K && live) ? row[J.col0 + k] * s : 0.f;
+        const float x = (k < J.K && live) ? row[(J.col0 + k) * ks] * s : 0.f;
         const _Float16 hi = (_Float16)x;
         const _Float16 lo = (_Float16)(x - (float)hi);
         const int c = k >> 5, kk = k & 31, lg = kk >> 3, j = kk & 7;

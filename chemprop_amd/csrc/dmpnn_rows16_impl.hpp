@@ -1,0 +1,324 @@
+// Per-step contraction on the f16 matrix pipe with the exact 3-term split (see dmpnn_mega16_impl.hpp):
+//     C = act([A1[gather] || A2] . W^T + bias + Cadd)        one 48-row tile x up to 512 output columns per workgroup
+// The building blocks are those of the whole-forward tile kernel — operand rows gathered ONCE through buffer
+// descriptors into registers, 128 columns per group, tile maximum -> exact power-of-two scale, split into the
+// LDS tile; weight fragments straight from L2 in the fragment-major pre-split layout; barrier-free MFMA loop;
+// groups beyond the first rescale the accumulator by the exact ratio of their scales — followed by a row-major
+// epilogue through an fp32 LDS tile (coalesced residual reads and stores).  Serves the per-step routes (large
+// batches, d_h up to 512 per column block, wider in several blocks) and the data gradients of the backward pass.
+#pragma once
+
+#include <type_traits>
+
+#include "dmpnn_mega16_impl.hpp"
+
+namespace dmpnn {
+namespace rows16 {
+
+using gemm::BK;
+using gemm::f32x4;
+using gemm::kOOB;
+using gemm::kThreads;
+using gemm::rsrc_t;
+using gemm::u32x2;
+using gemm::u32x4;
+using mega16::h2;
+using mega16::h4;
+using mega16::h8;
+using mega16::scale_for;
+using mega16::SplitW;
+
+constexpr int RT = 3, BM = 16 * RT;
+
+struct Rows16K {
+    int M, N, K1, K2;
+    const float* A1; int lda1; const int* gather1; unsigned a1_bytes;  // a1_bytes: extent of a gathered A1 (else per tile)
+    const float* A2; int lda2;
+    SplitW W;                 // pre-split weights of ALL N columns (fragment-major), nc = ceil((K1 + K2) / 32)
+    const float* bias;        // [N] or null
+    const float* Cadd; int ldcadd;
+    float* C; int ldc;
+    float* Zpre; int ldz;
+    int act; float slope; const float* slope_ptr;
+    const int* poison_flags; int poison_mask;
+    int vec_out;              // C / Zpre / Cadd rows are 16-byte aligned and N % 4 == 0: float4 epilogue
+};
+
+constexpr size_t kOperandTileBytes = (size_t)BM * (4 * 128 + 16);
+template <int WN>
+constexpr size_t tile_bytes() {  // fp32 epilogue tile and the split operand tile share one region
+    return (size_t)BM * (64 * WN + 4) * 4 > kOperandTileBytes ? (size_t)BM * (64 * WN + 4) * 4 : kOperandTileBytes;
+}
+template <int WN>
+constexpr size_t lds_bytes() {
+    return tile_bytes<WN>() + 64;  // + scale words
+}
+
+template <int WN>
+__global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
+    constexpr int BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
+    constexpr int ITEMS = BM * QN / kThreads;  // 3 WN
+    constexpr int TSG = 4 * 128 + 16;          // bytes of one row of the split operand tile (4 chunks)
+    constexpr int J = 4 * RT;                  // operand rows per thread and group
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* T = reinterpret_cast<float*>(lds);                      // [BM][LDC] fp32 epilogue tile
+    unsigned char* Ag = lds;                                       // [BM][TSG] split operand tile (overlays T)
+    unsigned* maxbits = reinterpret_cast<unsigned*>(lds + tile_bytes<WN>());  // [4] rotating tile maxima
+
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int li = lane & 15, lg = lane >> 4;
+    auto launder = [&]() {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
+    };
+    const int row0 = blockIdx.x * BM;
+    const int nrows = g.M - row0 < BM ? g.M - row0 : BM;
+    const int col0 = blockIdx.y * BN;            // column block of this workgroup
+    const int ncols = g.N - col0 < BN ? g.N - col0 : BN;
+    const int K = g.K1 + g.K2;
+    const bool poison = g.poison_flags && (g.poison_flags[0] & g.poison_mask);
+    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
+
+    if (tid < 4) maxbits[tid] = 0u;
+    __syncthreads();
+    // ---- operand rows of the tile: row wave + 4 j, column pair `lane` of a 128-column group ----
+    const bool gathered = g.gather1 != nullptr;
+    const rsrc_t rA1 = gathered ? gemm::make_rsrc(g.A1, g.a1_bytes)
+                                : gemm::make_rsrc(g.A1 + (long long)row0 * g.lda1, (unsigned)(nrows * g.lda1) * 4u);
+    const rsrc_t rA2 = gemm::make_rsrc(g.A2 ? g.A2 + (long long)row0 * g.lda2 : g.A1, g.A2 ? (unsigned)(nrows * g.lda2) * 4u : 0u);
+    unsigned ro1[J], ro2[J];
+    {
+        int idx[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int r = wave + 4 * j;
+            idx[j] = gathered ? g.gather1[r < nrows ? row0 + r : row0] : r;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const bool ok = wave + 4 * j < nrows;
+            ro1[j] = ok ? (unsigned)idx[j] * (unsigned)g.lda1 * 4u : kOOB;
+            ro2[j] = ok ? (unsigned)(wave + 4 * j) * (unsigned)g.lda2 * 4u : kOOB;
+        }
+    }
+    auto ga_load = [&](int grp, u32x2 (&v)[J]) {
+        const int k = grp * 128 + lane * 2;
+        const unsigned k1o = k < g.K1 ? (unsigned)k * 4u : kOOB;
+        const unsigned k2o = (k >= g.K1 && k < K) ? (unsigned)(k - g.K1) * 4u : kOOB;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            v[j] = __builtin_amdgcn_raw_buffer_load_b64(rA1, gemm::join_off(ro1[j], k1o), 0, 0) |
+                   __builtin_amdgcn_raw_buffer_load_b64(rA2, gemm::join_off(ro2[j], k2o), 0, 0);
+    };
+    auto wave_max = [&](float v) -> float {
+        int u = (int)__float_as_uint(v);
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0xB1, 0xf, 0xf, true));
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xf, 0xf, true));
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x141, 0xf, 0xf, true));
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x140, 0xf, 0xf, true));
+        const int m = max(max(__builtin_amdgcn_readlane(u, 0), __builtin_amdgcn_readlane(u, 16)),
+                          max(__builtin_amdgcn_readlane(u, 32), __builtin_amdgcn_readlane(u, 48)));
+        return __uint_as_float((unsigned)m);
+    };
+    int scale_phase = 0;
+    auto tile_scale = [&](float local_max) -> float {  // (see dmpnn_mega16_impl.hpp: rotating slots, one barrier)
+        const int slot = scale_phase & 3;
+        local_max = wave_max(local_max);
+        if (lane == 0) atomicMax(&maxbits[slot], __float_as_uint(local_max));
+        __syncthreads();
+        const float mx = __uint_as_float(maxbits[slot]);
+        if (tid == 0) maxbits[(slot + 2) & 3] = 0u;
+        ++scale_phase;
+        return scale_for(mx);
+    };
+
+    f32x4 acc[RT][WN];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- weight fragments of this wave's column tiles: [column tile][chunk][hi|lo][lane][16 B] ----
+    const int NT = (g.N + 15) / 16;
+    const rsrc_t rW = gemm::make_rsrc(g.W.p, (unsigned)(NT * g.W.nc * 2048));
+    unsigned offB[WN];
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int tile = col0 / 16 + wave * WN + ct;
+        offB[ct] = tile < NT ? (unsigned)tile * (unsigned)(g.W.nc * 2048) + (unsigned)lane * 16u : kOOB;
+    }
+    auto load_bfrags = [&](int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const unsigned o = offB[ct] == kOOB ? kOOB : offB[ct] + (unsigned)c * 2048u;
+            bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
+            bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o == kOOB ? kOOB : o + 1024u, 0, 0));
+        }
+    };
+    // one group of n_chunks (<= 4) k-chunks, weight chunks wc0 ..: barrier-free MFMA loop on the split tile Ag.
+    // One compact loop body (two chunks, ping-pong fragment registers): a workgroup runs one tile, so every
+    // instruction is fetched cold — code size is latency.  Fragments of chunk c+1 (A, from LDS) and c+2 (weights,
+    // from L2) are fetched under the MFMAs of chunk c; reads past the group are clamped / out of range (0).
+    auto contract = [&](int n_chunks, int wc0) {
+        h8 ah[2][RT], al[2][RT], bh[2][WN], bl[2][WN];
+        auto read_afrags = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT]) {
+            const int cc = c < n_chunks ? c : n_chunks - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const unsigned char* p = Ag + (rt * 16 + li) * TSG + cc * 128 + lg * 16;
+                xh[rt] = *reinterpret_cast<const h8*>(p);
+                xl[rt] = *reinterpret_cast<const h8*>(p + 64);
+            }
+        };
+        auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_afrags(c + 1, nh, nl);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_bfrags(wc0 + c + 2, yh, yl);
+        };
+        load_bfrags(wc0, bh[0], bl[0]);
+        load_bfrags(wc0 + 1, bh[1], bl[1]);
+        __syncthreads();  // the split tile is complete
+        launder();
+        read_afrags(0, ah[0], al[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma nounroll
+        for (int c = 0; c < n_chunks; c += 2) {
+            step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
+            if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
+        }
+    };
+
+    // ---- groups of 128 operand columns: registers -> maximum -> scale -> split tile -> MFMAs ----
+    const int n_groups = (g.W.nc + 3) / 4;
+    u32x2 v[J];
+    ga_load(0, v);
+    float s_prev = 0.f;
+#pragma nounroll
+    for (int grp = 0; grp < n_groups; ++grp) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v[j].x)), fabsf(__uint_as_float(v[j].y))));
+        const float s = tile_scale(mx);  // (barrier: every wave is past its reads of the LDS tile)
+        if (s_prev != 0.f && s_prev != s) {
+            const float f = s / s_prev;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= f;
+        }
+        s_prev = s;
+        launder();
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float x = __uint_as_float(v[j].x) * s, y = __uint_as_float(v[j].y) * s;
+            const h2 hi = h2{(_Float16)x, (_Float16)y};
+            const h2 lo = h2{(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
+            unsigned char* p = Ag + (wave + 4 * j) * TSG + (lane >> 4) * 128 + (lane & 15) * 4;
+            *reinterpret_cast<h2*>(p) = hi;
+            *reinterpret_cast<h2*>(p + 64) = lo;
+        }
+        if (grp + 1 < n_groups) ga_load(grp + 1, v);  // the next group's rows are in flight under this group's MFMAs
+        const int ncg = g.W.nc - grp * 4 < 4 ? g.W.nc - grp * 4 : 4;
+        contract(ncg, grp * 4);
+    }
+
+    // ---- epilogue: split domain -> fp32, bias; row-major pass through the LDS tile ----
+    launder();
+    const float inv_sA = 1.f / s_prev;
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int col = col0 + wave * (16 * WN) + ct * 16 + li;
+        const bool okc = col < g.N;
+        const float isw = g.W.inv_scale[okc ? col : 0] * inv_sA;
+        const float bv = (okc && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * isw + bv;
+    }
+    __syncthreads();  // every wave is done with the operand tile the epilogue tile overlays
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int cl = wave * (16 * WN) + ct * 16 + li;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(rt * 16 + lg * 4 + r) * LDC + cl] = acc[rt][ct][r];
+    }
+    __syncthreads();
+    const bool vec_out = g.vec_out != 0;
+    const float nanv = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int it = tid + kThreads * j;
+        const int r = it / QN, q = it - r * QN;
+        const int c = 4 * q;
+        if (r < nrows && c < ncols) {
+            const long long row = row0 + r;
+            float4 z = *reinterpret_cast<const float4*>(T + r * LDC + c);
+            if (vec_out) {
+                if (g.Cadd) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(g.Cadd + row * g.ldcadd + col0 + c);
+                    z.x += a4.x; z.y += a4.y; z.z += a4.z; z.w += a4.w;
+                }
+                if (poison) z = make_float4(nanv, nanv, nanv, nanv);
+                if (g.Zpre) *reinterpret_cast<float4*>(g.Zpre + row * g.ldz + col0 + c) = z;
+                if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col0 + c) = apply_act4(z, g.act, slope);
+            } else {
+                float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (c + t < ncols) {
+                        float v = zz[t] + (g.Cadd ? g.Cadd[row * g.ldcadd + col0 + c + t] : 0.f);
+                        if (poison) v = nanv;
+                        if (g.Zpre) g.Zpre[row * g.ldz + col0 + c + t] = v;
+                        if (g.C) g.C[row * g.ldc + col0 + c + t] = apply_act(v, g.act, slope);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WN>
+int launch_rows16(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s);
+
+#define DMPNN_DEFINE_ROWS16(WN)                                                                            \
+    template <>                                                                                            \
+    int launch_rows16<WN>(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s) {                \
+        constexpr size_t lds = lds_bytes<WN>();                                                            \
+        static bool attr_set = false;                                                                      \
+        if (!attr_set) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows16<WN>),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            if (e != hipSuccess) {                                                                         \
+                set_error("hipFuncSetAttribute(k_rows16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
+                return DMPNN_EHIP;                                                                         \
+            }                                                                                              \
+            attr_set = true;                                                                               \
+        }                                                                                                  \
+        hipLaunchKernelGGL((k_rows16<WN>), dim3((unsigned)row_tiles, (unsigned)col_blocks), dim3(kThreads), lds, s, g); \
+        DMPNN_CHECK_LAUNCH("k_rows16");                                                                    \
+        return DMPNN_OK;                                                                                   \
+    }
+
+}  // namespace rows16
+}  // namespace dmpnn

@@ -17,6 +17,11 @@ from . import _lib
 from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_SPLIT16, F_UNDIRECTED, F_WSPLIT_READY, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
 
 
+# From this many directed edges on, the per-step route runs its contractions on the f16 pipe (exact operand split) and is
+# preferred to the fused fp32-MFMA route (measured on MI355X: 1.3x per contraction at 36 k rows, more beyond).
+STEPS16_MIN_EDGES = 20000
+
+
 def small_plan_fits(n_atoms: int, n_edges: int) -> bool:
     """Batches the single-workgroup plan takes (mirror of csrc/dmpnn_common.hpp small_plan_fits): only
     those get piece tiles, hence the whole-forward tile kernel, and a light plan."""
@@ -182,8 +187,10 @@ def gather_rows(X: Tensor, idx32: Tensor, out: Optional[Tensor] = None) -> Tenso
 def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Tensor] = None,
            gather1: Optional[Tensor] = None, n_rows: Optional[int] = None, Cadd: Optional[Tensor] = None,
            act: str = "none", slope: float = 0.0, slope_t: Optional[Tensor] = None,
-           out: Optional[Tensor] = None, zpre: Optional[Tensor] = None) -> Tensor:
-    """``act([A1[gather] || A2] @ W.T + bias + Cadd)`` on the fp32-MFMA kernel."""
+           out: Optional[Tensor] = None, zpre: Optional[Tensor] = None, mfma: Optional[str] = None) -> Tensor:
+    """``act([A1[gather] || A2] @ W.T + bias + Cadd)``: the fp32-MFMA kernel, or with ``mfma="split16"`` the
+    f16-pipe kernel with the exact 3-term operand split (``dmpnn_linear16_fwd``; raises if the shapes /
+    alignments are not taken)."""
     A1 = _f32c(A1, "A1")
     W = _f32c(W, "W")
     if A2 is not None:
@@ -205,8 +212,16 @@ def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Te
     g.C, g.ldc = C_.data_ptr(), C_.stride(0)
     g.Zpre, g.ldz = _ptr(zpre), (zpre.stride(0) if zpre is not None else 0)
     g.act, g.act_slope, g.act_slope_ptr = act_code(act), float(slope), _ptr(slope_t)
+    lib = _lib.load()
     with torch.cuda.device(A1.device):
-        _lib.check(_lib.load().dmpnn_linear_fwd(C.byref(g), _stream_ptr(A1.device)), "dmpnn_linear_fwd")
+        if mfma == "split16":
+            if not lib.dmpnn_linear16_ok(C.byref(g)):
+                raise RuntimeError("linear(split16): shapes / alignments not taken by the split kernel")
+            nb = int(lib.dmpnn_linear16_wsplit_bytes(N, K1 + K2))
+            ws = torch.empty(nb, dtype=torch.uint8, device=A1.device)
+            _lib.check(lib.dmpnn_linear16_fwd(C.byref(g), ws.data_ptr(), nb, 0, _stream_ptr(A1.device)), "dmpnn_linear16_fwd")
+        else:
+            _lib.check(lib.dmpnn_linear_fwd(C.byref(g), _stream_ptr(A1.device)), "dmpnn_linear_fwd")
     return C_
 
 
@@ -315,6 +330,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
                            "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "
                            "<= 6144 atoms and <= 12288 edges)")
+    mf = mfma or os.environ.get("DMPNN_MFMA", "split16")
+    if (level == 1 and route is None and fused is None and mfma is None and mf == "split16" and nE >= STEPS16_MIN_EDGES
+            and not getattr(plan, "light", False)):
+        level = 0  # large batch: the per-step route on the f16 pipe beats the fused fp32-MFMA contractions
     use_fused, use_mega = level >= 1, level >= 2
     if getattr(plan, "light", False) and (not use_fused or keep):
         raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
@@ -351,25 +370,34 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     if use_fused:
         a.flags |= F_FUSED
     wsplit = None
-    if use_mega:
+    # the f16-pipe contractions with the exact operand split: always in the whole-forward tile kernel; in the per-step
+    # general route where they pay (measured crossover: wide hidden layers or >= ~20 k edge rows; they are the same
+    # arithmetic class, so this is a speed decision only).  mfma="split16" forces them, "f32" forbids them.
+    want16 = use_mega or (not use_fused and (mfma == "split16" or (mfma is None and mf == "split16" and (d_h > 320 or nE >= STEPS16_MIN_EDGES))))
+    if mf == "f32":
+        want16 = False
+    if want16:
+        if use_mega:
+            a.flags |= F_MEGA
+        a.flags |= F_SPLIT16
+        nb = int(lib.dmpnn_forward_wsplit_bytes(C.byref(a)))
+        # pre-split weights are reusable while the weight tensors are the same objects at the same
+        # autograd version (every in-place update bumps `_version`): inference with frozen weights
+        key = None
+        if wcache is not None and os.environ.get("DMPNN_WCACHE", "1") != "0":
+            key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (W_i, W_h, W_o) + ((W_d,) if d_vd else ())) \
+                + (nb, d_v, d_e, str(dev), bool(use_mega))
+            if wcache.get("key") == key:
+                wsplit = wcache["buf"]
+                a.flags |= F_WSPLIT_READY
+        if wsplit is None:
+            wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
+            if key is not None:
+                wcache["key"], wcache["buf"] = key, wsplit
+        a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
+        st.route = "mega16" if use_mega else "general16"
+    elif use_mega:
         a.flags |= F_MEGA
-        if (mfma or os.environ.get("DMPNN_MFMA", "split16")) != "f32":
-            a.flags |= F_SPLIT16
-            nb = int(lib.dmpnn_forward_wsplit_bytes(C.byref(a)))
-            # pre-split weights are reusable while the weight tensors are the same objects at the same
-            # autograd version (every in-place update bumps `_version`): inference with frozen weights
-            key = None
-            if wcache is not None and os.environ.get("DMPNN_WCACHE", "1") != "0":
-                key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (W_i, W_h, W_o)) + (nb, d_v, d_e, str(dev))
-                if wcache.get("key") == key:
-                    wsplit = wcache["buf"]
-                    a.flags |= F_WSPLIT_READY
-            if wsplit is None:
-                wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
-                if key is not None:
-                    wcache["key"], wcache["buf"] = key, wsplit
-            a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
-            st.route = "mega16"
     if keep:
         a.flags |= F_KEEP
     with torch.cuda.device(dev):

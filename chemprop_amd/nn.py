@@ -118,7 +118,7 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         d_vd = (mp.W_d.in_features - mp.W_o.out_features) if mp.W_d is not None else None
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
-    plan = engine.GraphPlan.from_bmg(bmg, light=_light_plan_ok(mp))
+    plan = engine.GraphPlan.from_bmg(bmg, light=_light_plan_ok(mp) and int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES)
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch

@@ -158,6 +158,14 @@ typedef struct dmpnn_gemm_args {
     int act; float act_slope; const float* act_slope_ptr;
 } dmpnn_gemm_args;
 int dmpnn_linear_fwd(const dmpnn_gemm_args* a, void* stream);
+/* The same contraction on the f16 matrix pipe with the exact 3-term operand split (x s = hi + lo, fp32 accumulate:
+ * fp32-class accuracy, see DMPNN_F_SPLIT16).  `wsplit` (>= dmpnn_linear16_wsplit_bytes(N, K1 + K2) bytes, caller-owned)
+ * receives the pre-split weights; wsplit_ready != 0: it still holds them from an earlier call with the same W.
+ * dmpnn_linear16_ok: 1 when the shapes / alignments are taken (even K1, K2 and row strides, 8-byte aligned operands),
+ * else the caller stays on dmpnn_linear_fwd.                                                                    */
+size_t dmpnn_linear16_wsplit_bytes(int64_t N, int64_t K);
+int dmpnn_linear16_ok(const dmpnn_gemm_args* a);
+int dmpnn_linear16_fwd(const dmpnn_gemm_args* a, void* wsplit, size_t wsplit_bytes, int wsplit_ready, void* stream);
 
 /* K3 + K2 (or + K4) fused — ONE per-depth update of the fused route, the dominant kernel of the path:
  *     H'      = tau(H0 + M . W_h^T + b_h)                                   base.py:135-141
