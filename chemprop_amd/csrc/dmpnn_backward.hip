@@ -489,6 +489,8 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct BwdLayout {
     size_t gZa, gZb, gH0, gZO, gMv, gHO, WhT, WoT, WdT, slab_h, slab_x, total;
+    size_t WhT16, WoT16;  // pre-split transposed weights of the data-gradient contractions on the f16 pipe (large batches)
+    bool use16;
     WgradPlan p_h, p_i, p_o, p_d;
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
@@ -516,6 +518,15 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     if (xo > x) x = xo;
     if (xd > x) x = xd;
     L.slab_x = o; o += align_up(x, 4);
+    // data gradients gM = gZ . W_h, gMv = gZO . W_o[:, d_v:] on the f16 pipe (exact operand split, dmpnn_rows16.hip)
+    // from the batch size where that kernel pays (the crossover of the forward's per-step route)
+    L.use16 = nE >= 20000 && h % 2 == 0 && f.ldh % 2 == 0;
+    L.WhT16 = L.WoT16 = 0;
+    if (L.use16) {
+        const size_t w = align_up((linear16_wsplit_bytes(h, h) + 3) / 4, 64);
+        L.WhT16 = o; o += w;
+        L.WoT16 = o; o += w;
+    }
     L.total = o;
     return L;
 }
@@ -681,12 +692,18 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
     }
     // gMv = gZO . W_o[:, d_v:]
     {
-        DMPNN_TRY(launch_transpose(f.W_o + dv, dv + h, WoT, h, (int)h, (int)h, s));
         dmpnn_gemm_args g;
         memset(&g, 0, sizeof(g));
         g.M = nV; g.N = h; g.K1 = h; g.A1 = gZO; g.lda1 = ldh; g.W = WoT; g.ldw = h; g.C = gMv; g.ldc = ldh;
         g.act = DMPNN_ACT_NONE;
-        DMPNN_TRY(launch_linear(g, s));
+        if (L.use16 && linear16_ok(g)) {  // W'[n][k] = W_o[k][d_v + n]: the pre-split reads the matrix transposed
+            SplitWView w;
+            DMPNN_TRY(split_weights_view(f.W_o + dv, dv + h, h, h, 1, ws + L.WoT16, &w, s));
+            DMPNN_TRY(launch_linear16_view(g, w, nullptr, 0, s));
+        } else {
+            DMPNN_TRY(launch_transpose(f.W_o + dv, dv + h, WoT, h, (int)h, (int)h, s));
+            DMPNN_TRY(launch_linear(g, s));
+        }
     }
     EdgeBwdArgs e;
     memset(&e, 0, sizeof(e));
@@ -696,7 +713,16 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
     const bool undirected = f.flags & DMPNN_F_UNDIRECTED;
     int n_slabs_h = 0;
     if (T >= 2) {
-        DMPNN_TRY(launch_transpose(f.W_h, h, WhT, h, (int)h, (int)h, s));
+        SplitWView wh16;
+        bool gm16 = false;
+        {
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = nE; g.N = h; g.K1 = h; g.A1 = gZa; g.lda1 = ldh; g.W = WhT; g.ldw = h; g.C = gZb; g.ldc = ldh;
+            gm16 = L.use16 && linear16_ok(g);
+        }
+        if (gm16) DMPNN_TRY(split_weights_view(f.W_h, h, h, h, 1, ws + L.WhT16, &wh16, s));
+        else DMPNN_TRY(launch_transpose(f.W_h, h, WhT, h, (int)h, (int)h, s));
         // gZ^(T-1) = gMv[dst] * tau'(H^(T-1));  gH0 = gZ^(T-1)
         EdgeBwdArgs g0 = e;
         g0.gin = gMv; g0.ld_gin = ldh;
@@ -720,7 +746,8 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             memset(&g, 0, sizeof(g));
             g.M = nE; g.N = h; g.K1 = h; g.A1 = gZ; g.lda1 = ldh; g.W = WhT; g.ldw = h; g.C = other; g.ldc = ldh;
             g.act = DMPNN_ACT_NONE;
-            DMPNN_TRY(launch_linear(g, s));
+            if (gm16) DMPNN_TRY(launch_linear16_view(g, wh16, nullptr, 0, s));
+            else DMPNN_TRY(launch_linear(g, s));
             // gH^(t-1) -> masked gZ^(t-1), accumulated into gH0
             const bool first = (t - 1) == 0;
             const float* Yprev = first ? f.H0 : f.Hs + (int64_t)(t - 2) * slot;
