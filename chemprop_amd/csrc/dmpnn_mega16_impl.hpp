@@ -165,6 +165,36 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         return apply_act(z, g.act, slope);
     };
 
+    // ---- weight fragments: straight from L2 to registers --------------------------------------------
+    // The four waves of a workgroup own disjoint column ranges, so a weight element is used by exactly one
+    // wave: staging the weight tile in LDS would buy no reuse and cost a write + a read + a barrier per
+    // chunk.  Lane (li, lg) of column tile ct reads its own fragment of chunk c from the pre-split layout:
+    // hi 16 B at [col][c][lg*16], lo at +64 (col = wave*16*WN + ct*16 + li; col >= N is out of range: 0).
+    auto load_bfrags = [&](rsrc_t rW, const unsigned (&offB)[WN], int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0);
+            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0);
+            bh[ct] = __builtin_bit_cast(h8, vh);
+            bl[ct] = __builtin_bit_cast(h8, vl);
+        }
+    };
+    auto bfrag_offsets = [&](const SplitW& W, unsigned (&offB)[WN]) {
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)  // fragment-major layout [column tile][chunk][hi|lo][lane][16 B]
+            offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
+    };
+    // chunk 0 of the NEXT contraction's weights, fetched into registers while the current epilogue runs
+    h8 preBh[WN], preBl[WN];
+    bool have_pre = false;
+    auto prefetch_b = [&](const SplitW& W) {
+        unsigned offB[WN];
+        bfrag_offsets(W, offB);
+        load_bfrags(gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048)), offB, 0, preBh, preBl);
+        have_pre = true;
+    };
+
     // index loads first: the tile metadata and the gather rows of the K1 operand (row wave + 4 j of the tile)
     const int revl_v = tid < nrows ? g.revp[rs + tid] - rs : 0;
     const int rp_v = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
@@ -196,6 +226,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             a_grp[j] = __builtin_amdgcn_raw_buffer_load_b64(rVg, gemm::join_off(ro1[j], k1o), 0, 0) |
                        __builtin_amdgcn_raw_buffer_load_b64(rEg, gemm::join_off(ro2[j], k2o), 0, 0);
     }
+    prefetch_b(G.Wi);  // chunk 0 of W_i: its L2 latency hides under the metadata phase
     if (tid < BM) revl[tid] = revl_v;
     if (tid <= BA) rp[tid] = rp_v;
     if (tid < 8) maxbits[tid] = 0u;
@@ -256,36 +287,6 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         if (tid == 0) maxbits[(slot + 2) & 3] = 0u;
         ++scale_phase;
         return scale_for(mx);
-    };
-
-    // ---- weight fragments: straight from L2 to registers --------------------------------------------
-    // The four waves of a workgroup own disjoint column ranges, so a weight element is used by exactly one
-    // wave: staging the weight tile in LDS would buy no reuse and cost a write + a read + a barrier per
-    // chunk.  Lane (li, lg) of column tile ct reads its own fragment of chunk c from the pre-split layout:
-    // hi 16 B at [col][c][lg*16], lo at +64 (col = wave*16*WN + ct*16 + li; col >= N is out of range: 0).
-    auto load_bfrags = [&](rsrc_t rW, const unsigned (&offB)[WN], int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0);
-            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0);
-            bh[ct] = __builtin_bit_cast(h8, vh);
-            bl[ct] = __builtin_bit_cast(h8, vl);
-        }
-    };
-    auto bfrag_offsets = [&](const SplitW& W, unsigned (&offB)[WN]) {
-        launder();
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct)  // fragment-major layout [column tile][chunk][hi|lo][lane][16 B]
-            offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
-    };
-    // chunk 0 of the NEXT contraction's weights, fetched into registers while the current epilogue runs
-    h8 preBh[WN], preBl[WN];
-    bool have_pre = false;
-    auto prefetch_b = [&](const SplitW& W) {
-        unsigned offB[WN];
-        bfrag_offsets(W, offB);
-        load_bfrags(gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048)), offB, 0, preBh, preBl);
-        have_pre = true;
     };
 
     // ---- one contraction: acc[RT][WN] += (A s_A) . (W s_W)^T in the split domain -------------------
