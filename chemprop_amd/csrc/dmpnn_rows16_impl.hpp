@@ -266,24 +266,43 @@ __global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
     __syncthreads();
     const bool vec_out = g.vec_out != 0;
     const float nanv = __int_as_float(0x7fc00000);
+    if (vec_out) {
+        // two passes: every residual quad is requested first (buffer loads, out of range -> 0: no load sits under a
+        // branch, so they are all in flight together), then the arithmetic and the stores
+        const rsrc_t rC = gemm::make_rsrc(g.Cadd ? g.Cadd + (long long)row0 * g.ldcadd + col0 : g.A1,
+                                          g.Cadd ? (unsigned)(((nrows - 1) * g.ldcadd + ncols) * 4) : 0u);
+        float4 res[ITEMS];
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int it = tid + kThreads * j;
-        const int r = it / QN, q = it - r * QN;
-        const int c = 4 * q;
-        if (r < nrows && c < ncols) {
-            const long long row = row0 + r;
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = tid + kThreads * j;
+            const int r = it / QN, q = it - r * QN;
+            const unsigned off = (r < nrows && 4 * q < ncols) ? (unsigned)(r * g.ldcadd + 4 * q) * 4u : kOOB;
+            res[j] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rC, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = tid + kThreads * j;
+            const int r = it / QN, q = it - r * QN;
+            const int c = 4 * q;
             float4 z = *reinterpret_cast<const float4*>(T + r * LDC + c);
-            if (vec_out) {
-                if (g.Cadd) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(g.Cadd + row * g.ldcadd + col0 + c);
-                    z.x += a4.x; z.y += a4.y; z.z += a4.z; z.w += a4.w;
-                }
-                if (poison) z = make_float4(nanv, nanv, nanv, nanv);
+            z.x += res[j].x; z.y += res[j].y; z.z += res[j].z; z.w += res[j].w;
+            if (poison) z = make_float4(nanv, nanv, nanv, nanv);
+            if (r < nrows && c < ncols) {
+                const long long row = row0 + r;
                 if (g.Zpre) *reinterpret_cast<float4*>(g.Zpre + row * g.ldz + col0 + c) = z;
                 if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col0 + c) = apply_act4(z, g.act, slope);
-            } else {
-                float zz[4] = {z.x, z.y, z.z, z.w};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int it = tid + kThreads * j;
+            const int r = it / QN, q = it - r * QN;
+            const int c = 4 * q;
+            if (r < nrows && c < ncols) {
+                const long long row = row0 + r;
+                const float4 z4 = *reinterpret_cast<const float4*>(T + r * LDC + c);
+                const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (c + t < ncols) {
