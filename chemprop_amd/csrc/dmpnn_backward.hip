@@ -221,15 +221,25 @@ int launch_edge_bwd(EdgeBwdArgs a, hipStream_t s, const char* name) {
 }
 
 // elementwise: gZ = g * tau'(Y)      (finalize: atoms x h)
+template <int VEC>
 __global__ void k_act_bwd(const float* __restrict__ g, int64_t ldg, const float* __restrict__ Y, int64_t ldy,
                           float* __restrict__ out, int64_t ldo, int64_t rows, int h, int act, float slope,
                           const float* slope_ptr) {
     const float sl = slope_ptr ? *slope_ptr : slope;
-    const int64_t n = rows * h;
+    const int q = h / VEC;  // column groups per row
+    const int64_t n = rows * q;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / h;
-        const int c = (int)(i % h);
-        out[r * ldo + c] = g[r * ldg + c] * act_grad_from_out(Y[r * ldy + c], act, sl);
+        const int64_t r = n < (int64_t(1) << 31) ? (int64_t)((unsigned)i / (unsigned)q) : i / q;
+        const int c = (int)(i - r * q) * VEC;
+        if (VEC == 4) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + r * ldg + c);
+            const float4 yv = *reinterpret_cast<const float4*>(Y + r * ldy + c);
+            *reinterpret_cast<float4*>(out + r * ldo + c) =
+                make_float4(gv.x * act_grad_from_out(yv.x, act, sl), gv.y * act_grad_from_out(yv.y, act, sl),
+                            gv.z * act_grad_from_out(yv.z, act, sl), gv.w * act_grad_from_out(yv.w, act, sl));
+        } else {
+            out[r * ldo + c] = g[r * ldg + c] * act_grad_from_out(Y[r * ldy + c], act, sl);
+        }
     }
 }
 
@@ -414,8 +424,19 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slab, int64_t slab_stri
     const int64_t total = (int64_t)N * Kt;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / Kt), k = (int)(i % Kt);
+        // eight slab reads in flight at a time (clamped index, masked add: no load under a branch), summed in slab order
         float s = 0.f;
-        for (int t = 0; t < n_slabs; ++t) s += slab[(int64_t)t * slab_stride + (int64_t)n * ldk + k];
+        const float* p0 = slab + (int64_t)n * ldk + k;
+        for (int t0 = 0; t0 < n_slabs; t0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u < n_slabs ? t0 + u : n_slabs - 1;
+                v[u] = p0[(int64_t)t * slab_stride];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t0 + u < n_slabs ? v[u] : 0.f;
+        }
         if (poison) s = __int_as_float(0x7fc00000);
         if (k < K) {
             if (gW) gW[(int64_t)n * ldgw + k] = s;
@@ -669,11 +690,14 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         gHO_p = gHO; ld_gHO = ldh;
     }
     {
-        const int64_t n = nV * h;
+        const bool vec = h % 4 == 0 && ld_gHO % 4 == 0 && ldHO % 4 == 0 && ldh % 4 == 0 && aligned16(gHO_p) && aligned16(HO) && aligned16(gZO);
+        const int64_t n = nV * (vec ? h / 4 : h);
         int64_t blocks = (n + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)blocks), dim3(256), 0, s, gHO_p, ld_gHO, HO, ldHO, gZO, ldh, nV, (int)h,
-                           f.act, f.act_slope, f.act_slope_ptr);
+        if (vec) hipLaunchKernelGGL(k_act_bwd<4>, dim3((unsigned)blocks), dim3(256), 0, s, gHO_p, ld_gHO, HO, ldHO, gZO, ldh, nV, (int)h,
+                                    f.act, f.act_slope, f.act_slope_ptr);
+        else hipLaunchKernelGGL(k_act_bwd<1>, dim3((unsigned)blocks), dim3(256), 0, s, gHO_p, ld_gHO, HO, ldHO, gZO, ldh, nV, (int)h,
+                                f.act, f.act_slope, f.act_slope_ptr);
         DMPNN_CHECK_LAUNCH("k_act_bwd");
     }
     if (b->gW_o || b->gb_o) {
