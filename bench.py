@@ -332,7 +332,23 @@ def main():
                                          "frac": round(2.0 * bE * h * h / (t3b * 1e-3) / 1e12 / PEAK_FP32_MFMA_TF, 4),
                                          "launch_us": round(t3b * 1e3, 3), "directed_edges": bE,
                                          "algorithmic_GBps": round((3.0 * bE * h * 4 + 12.0 * bE) / (t3b * 1e-3) / 1e9, 1)}
-                del H0b, Mn
+                # the same per-step update as two kernels of the large-batch route: K2 (above) + the contraction on the
+                # f16 pipe with the exact operand split (k_rows16), HBM bound: read M, read H0, write H
+                Cb = torch.empty(bE, h, device=dev)
+                wsb = {}
+                k3c = lambda: engine.linear(Hb, Wh, None, Cadd=H0b, act="relu", out=Cb, mfma="split16")
+                try:
+                    run_steps(k3c, 3)
+                    t3c = time_events(k3c, 10, torch)
+                    b3 = 3.0 * bE * h * 4
+                    out["roofline_steps16_large"] = {"kernel": "k_rows16<5> (+ k_split_weights): H = relu(H0 + M @ W_h^T), 3 x f16 MFMA on exactly split operands, 32768 mols",
+                                                     "bound": "hbm", "achieved": round(b3 / (t3c * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                                     "unit": "GB/s", "frac": round(b3 / (t3c * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                                     "launch_us": round(t3c * 1e3, 3), "bytes_per_launch": b3, "directed_edges": bE,
+                                                     "TFLOPs": round(2.0 * bE * h * h / (t3c * 1e-3) / 1e12, 1)}
+                except Exception as e:
+                    out["roofline_steps16_large"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                del H0b, Mn, Cb
             del big, bplan, Hb, Mb
         except Exception as e:
             out["roofline_scatter_large"] = {"error": f"{type(e).__name__}: {e}"[:200]}
