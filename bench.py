@@ -278,6 +278,9 @@ def main():
             kplan = lambda: engine.GraphPlan.from_bmg(bmg)
             run_steps(kplan, 5)
             br = {"plan_us": round(time_events(kplan, 30, torch) * 1e3, 2)}
+            ktile = lambda: engine.GraphPlan.from_bmg(bmg, light="tiles")
+            run_steps(ktile, 5)
+            br["tile_plan_us"] = round(time_events(ktile, 30, torch) * 1e3, 2)  # what the inference forward builds (K0)
             if fusable:
                 kagg = lambda: engine.update_fused(plan, Mbuf, H0buf, Wh, None, act="relu", want_M=False, want_Mv=True, Mv=Mv_)
                 run_steps(kagg, 5)

@@ -22,13 +22,13 @@ LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_rows16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_rows16_impl.hpp"]
-ABI_VERSION = 2
+ABI_VERSION = 3
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
 EXPORTS = [
     "dmpnn_version", "dmpnn_debug_timestamps", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
-    "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_prepare_light", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
+    "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_prepare_light", "dmpnn_prepare_tiles", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
     "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows",
@@ -77,6 +77,7 @@ class FwdArgs(C.Structure):
         ("Mv", C.c_void_p), ("Hv", C.c_void_p),
         ("out", C.c_void_p), ("ldout", C.c_int64),
         ("wsplit", C.c_void_p), ("wsplit_bytes", C.c_size_t),
+        ("edge_index", C.c_void_p), ("rev_edge_index", C.c_void_p),
     ]
 
 
@@ -161,6 +162,7 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_can_fuse.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dmpnn_prepare_light.argtypes = lib.dmpnn_prepare.argtypes
+    lib.dmpnn_prepare_tiles.argtypes = lib.dmpnn_prepare.argtypes
     lib.dmpnn_message_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint, C.c_void_p]
     lib.dmpnn_aggregate_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,

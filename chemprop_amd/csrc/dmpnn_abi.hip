@@ -93,6 +93,11 @@ int dmpnn_prepare_light(const int64_t* edge_index, const int64_t* rev, int64_t n
     return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 1, stream);
 }
 
+int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, int64_t n_atoms, int64_t n_edges, void* plan,
+                        size_t plan_bytes, void* stream) {
+    return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 2, stream);
+}
+
 int dmpnn_message_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h, const float* Hin,
                       int64_t ld_in, float* M, int64_t ld_m, int act_on_load, float act_slope,
                       const float* act_slope_ptr, unsigned flags, void* stream) {

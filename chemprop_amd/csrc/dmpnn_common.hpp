@@ -86,9 +86,12 @@ inline PlanLayout plan_layout(int64_t nV, int64_t nE) {
     return L;
 }
 
-enum : int { PLAN_ASYMMETRIC = 1, PLAN_RANGE_ERROR = 2, PLAN_HUGE_DEGREE = 4, PLAN_NO_PIECE_TILES = 8 };
+enum : int { PLAN_ASYMMETRIC = 1, PLAN_RANGE_ERROR = 2, PLAN_HUGE_DEGREE = 4, PLAN_NO_PIECE_TILES = 8,
+             PLAN_TILES_ONLY = 16 };  // tile plan (dmpnn_prepare_tiles): no CSR arrays, only the piece-tile tables
 // graphs the fused (row-tiled) forward cannot represent: its kernels poison their output with NaN
-constexpr int kPlanNoFuse = PLAN_ASYMMETRIC | PLAN_RANGE_ERROR | PLAN_HUGE_DEGREE;
+constexpr int kPlanNoFuse = PLAN_ASYMMETRIC | PLAN_RANGE_ERROR | PLAN_HUGE_DEGREE | PLAN_TILES_ONLY;
+// what the whole-forward tile kernel cannot take when it reads a tile plan (its own per-tile checks do the rest)
+constexpr int kPlanNoMegaLean = PLAN_RANGE_ERROR | PLAN_NO_PIECE_TILES;
 // graphs the whole-forward tile kernel cannot take (a connected piece larger than a tile, or no piece tiles built)
 constexpr int kPlanNoMega = kPlanNoFuse | PLAN_NO_PIECE_TILES;
 

@@ -80,6 +80,8 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     G.WoM = mega16::SplitW{ws + W.wom, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_h};
     G.WoV = mega16::SplitW{ws + W.wov, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_v};
     g.dbg = g_debug_stamps;
+    g.edge_index = reinterpret_cast<const long long*>(a.edge_index);
+    g.rev64 = reinterpret_cast<const long long*>(a.rev_edge_index);
     const int n_tiles = (int)L.max_mtiles;
     if (a.d_h <= 64) return mega16::launch_mega16<1>(G, n_tiles, s);
     if (a.d_h <= 128) return mega16::launch_mega16<2>(G, n_tiles, s);

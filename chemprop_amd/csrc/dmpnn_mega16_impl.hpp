@@ -109,7 +109,7 @@ static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
 
 template <int WN>
 constexpr size_t lds_bytes() {
-    return (size_t)kMegaBM * (64 * WN * 4 + 16) * 2 + (size_t)(2 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
+    return (size_t)kMegaBM * (64 * WN * 4 + 16) * 2 + (size_t)(3 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
 }
 
 template <int WN>
@@ -124,9 +124,10 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     int* revl = reinterpret_cast<int*>(lds + BM * TS + BM * LDC * 4);  // [BM]
     int* aor = revl + BM;                                   // [BM]
     int* rp = aor + BM;                                     // [BA + 1]
-    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [0..3] tile maxima (float bits, rotating), [4] spare
+    int* asrc = rp + BA + 1;                                // [BM] tile-local source atom of a row (tile plan only)
+    unsigned* maxbits = reinterpret_cast<unsigned*>(asrc + BM);  // [0..3] tile maxima (float bits, rotating), [5] tile-not-closed flag
     // [10][64] incidence fragments of the segment MFMAs (see segment_mfma): 16-byte aligned behind the metadata
-    h8* cfrag = reinterpret_cast<h8*>(lds + BM * TS + BM * LDC * 4 + (((2 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);
+    h8* cfrag = reinterpret_cast<h8*>(lds + BM * TS + BM * LDC * 4 + (((3 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);
 
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -148,7 +149,12 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
     const int nrows = re - rs, na = vb - va;
     const int N = g.h, qn = N >> 2;
-    const bool poison = (g.flags[0] & g.poison_mask) != 0;
+    // Tile plan (header LIGHT == 2): the rows of a tile are its edges in the CALLER's order, src / dst / rev come
+    // straight from the caller's int64 arrays and the tile checks by itself that it is closed (every edge id in
+    // its range has both atoms and its reverse edge inside the tile; by counting, no other edge then enters its
+    // atoms).  A tile that is not closed writes NaN to its atoms.
+    const bool lean = g.flags[DMPNN_HDR_LIGHT] == 2;
+    const bool poison = (g.flags[0] & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && (g.H0 || g.Hs || g.Ms || g.Mv || (g.nE > 0 && (!g.edge_index || !g.rev64))));
     if (poison) {
         const float nanv = __int_as_float(0x7fc00000);
         const long long total = (long long)g.nV * N;
@@ -196,16 +202,38 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     };
 
     // index loads first: the tile metadata and the gather rows of the K1 operand (row wave + 4 j of the tile)
-    const int revl_v = tid < nrows ? g.revp[rs + tid] - rs : 0;
-    const int rp_v = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
+    int revl_v = 0, rp_v = 0, aor_v = 0, asrc_v = 0;
+    bool row_bad = false;
     unsigned ro1[4 * RT_E], ro2[4 * RT_E];
     {
         int i1[4 * RT_E], i2[4 * RT_E];
+        if (lean && nrows > 0) {
+            const int e = rs + (tid < nrows ? tid : 0);
+            const long long es = g.edge_index[e], ed = g.edge_index[(long long)g.nE + e], er = g.rev64[e];
+            const long long r_l = er - rs, d_l = ed - va, s_l = es - va;
+            row_bad = tid < nrows && (r_l < 0 || r_l >= nrows || d_l < 0 || d_l >= na || s_l < 0 || s_l >= na);
+            revl_v = (tid < nrows && !row_bad) ? (int)r_l : 0;
+            aor_v = (tid < nrows && !row_bad) ? (int)d_l : 0;
+            asrc_v = (tid < nrows && !row_bad) ? (int)s_l : 0;
 #pragma unroll
-        for (int j = 0; j < 4 * RT_E; ++j) {
-            const int r = wave + 4 * j;
-            i1[j] = g.srcp[r < nrows ? rs + r : 0];
-            i2[j] = g.perm[r < nrows ? rs + r : 0];
+            for (int j = 0; j < 4 * RT_E; ++j) {
+                const int r = wave + 4 * j;
+                const long long sj = g.edge_index[r < nrows ? rs + r : rs];
+                i1[j] = (sj >= 0 && sj < g.nV) ? (int)sj : 0;
+                i2[j] = rs + r;
+            }
+        } else if (lean) {  // a tile of single atoms: no rows, nothing to read
+#pragma unroll
+            for (int j = 0; j < 4 * RT_E; ++j) { i1[j] = 0; i2[j] = 0; }
+        } else {
+            revl_v = tid < nrows ? g.revp[rs + tid] - rs : 0;
+            rp_v = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
+#pragma unroll
+            for (int j = 0; j < 4 * RT_E; ++j) {
+                const int r = wave + 4 * j;
+                i1[j] = g.srcp[r < nrows ? rs + r : 0];
+                i2[j] = g.perm[r < nrows ? rs + r : 0];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4 * RT_E; ++j) {
@@ -227,11 +255,12 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                        __builtin_amdgcn_raw_buffer_load_b64(rEg, gemm::join_off(ro2[j], k2o), 0, 0);
     }
     prefetch_b(G.Wi);  // chunk 0 of W_i: its L2 latency hides under the metadata phase
-    if (tid < BM) revl[tid] = revl_v;
+    if (tid < BM) { revl[tid] = revl_v; asrc[tid] = asrc_v; if (lean) aor[tid] = aor_v; }
     if (tid <= BA) rp[tid] = rp_v;
     if (tid < 8) maxbits[tid] = 0u;
     __syncthreads();
-    if (tid < na)
+    if (row_bad) atomicOr(&maxbits[5], 1u);
+    if (!lean && tid < na)
         for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
     __syncthreads();
     // Incidence fragments (B operands of the segment MFMAs, constant over the depth loop).  The k index of
@@ -249,14 +278,16 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             a_t = j < na ? j : -1;
         } else if (j < nrows) {
             rv = revl[j];
-            a_t = aor[rv];
+            a_t = lean ? asrc[j] : aor[rv];  // source atom of r' (CSR plan: the graph is symmetric, src r' = dst rev r')
         }
         h8 v;
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             const int row = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
-            const bool on = row >= 0 && row < nrows && aor[row < 0 ? 0 : row] == a_t && row != rv;
-            v[sl] = on ? (_Float16)1.f : (_Float16)0.f;
+            const bool in = row >= 0 && row < nrows && aor[row < 0 ? 0 : row] == a_t;
+            // [r enters src r'] - [r = rev r']: 0/1 for a symmetric graph (the reverse edge enters src r'), -1/0/1 otherwise
+            const float cv = (in ? 1.f : 0.f) - ((row >= 0 && row == rv) ? 1.f : 0.f);
+            v[sl] = (_Float16)cv;
         }
         cfrag[f * 64 + lane] = v;
     }
@@ -678,6 +709,12 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         stamp();  // finalize: V part
         unscale(RA{}, acc, 1.f / sV, cc);
         act_frags(RA{}, F_{}, acc, acc);
+        if (maxbits[5]) {  // (uniform; written before the first barrier of the kernel)
+#pragma unroll
+            for (int rt = 0; rt < RT_A; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000)};
+        }
         __syncthreads();  // (the fp32 tile may overlay the V operand tile)
         frag_to_tile(RA{}, acc);
         __syncthreads();

@@ -45,6 +45,9 @@ struct MegaK {
     float* H0; float* Hs; float* Ms; float* Mv; int ldh; long long slot;  // kept tensors (training) or null
     unsigned qmagic;
     long long* dbg;   // optional [32] cycle stamps of workgroup 0 (dmpnn_debug_timestamps), else null
+    // tile plan (dmpnn_prepare_tiles, header LIGHT == 2; split-MFMA kernel only): the caller's own index arrays
+    const long long* edge_index;  // [2, nE] row 0 = src atom, row 1 = dst atom
+    const long long* rev64;       // [nE]
 };
 
 template <int WN>

@@ -447,6 +447,14 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < nV; i += kSmallThreads) cnt[i] = 0;
     if (tid == 0) { flags_s = 0; maxdeg_s = 0; piece_bad_s = 0; }
+    // light == 2, the TILE plan: only the piece-tile tables (+ header) — what an inference forward of the whole-forward
+    // tile kernel reads; that kernel then takes src / dst / rev of a tile's edges straight from the caller's arrays
+    // (its rows are the tile's edges in the caller's order: no sort, no CSR, no permutation) and checks on its own
+    // that the tile is closed.  The boundary marks of the piece detection are set per bond while narrowing.
+    const bool lean = light == 2;
+    unsigned char* covb = reinterpret_cast<unsigned char*>(Ybuf);  // covb[u] != 0: an edge joins atoms < u with atoms >= u
+    if (lean)
+        for (int w = tid; w < (nV + 3) / 4 + 1; w += kSmallThreads) Ybuf[w] = 0;
 
     // phase 1: ONE batched read of the int64 arrays (all loads of a thread in flight together)
     int64_t s64[kSmallEPT], d64[kSmallEPT], r64[kSmallEPT];
@@ -476,19 +484,30 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
                 d = d < 0 ? 0 : (d >= nV ? nV - 1 : d);
                 r = r < 0 ? 0 : (r >= nE ? nE - 1 : r);
             }
-            src16[e] = (u16)s;
-            dst16[e] = (u16)d;
-            rev16[e] = (u16)r;
             atomicAdd(&cnt[(int)d], 1);
+            if (lean) {
+                const int lo = (int)(s < d ? s : d), hi = (int)(s < d ? d : s);
+                if (hi - lo >= kMegaBA) {
+                    atomicOr(&piece_bad_s, 1);  // this bond alone spans more atoms than a tile holds: no piece tiles
+                } else {
+                    for (int u = lo + 1; u <= hi; ++u) covb[u] = 1;
+                }
+            } else {
+                src16[e] = (u16)s;
+                dst16[e] = (u16)d;
+                rev16[e] = (u16)r;
+            }
         }
     }
     __syncthreads();
     stamp();  // 2: narrowed + histogram
     // phase 1b: symmetric-graph invariants, from LDS
-    for (int e = tid; e < nE; e += kSmallThreads) {
-        const int r = rev16[e];
-        if (rev16[r] != e || src16[r] != dst16[e] || dst16[r] != src16[e]) bad |= PLAN_ASYMMETRIC;
-    }
+    if (!lean)
+        for (int e = tid; e < nE; e += kSmallThreads) {
+            const int r = rev16[e];
+            if (rev16[r] != e || src16[r] != dst16[e] || dst16[r] != src16[e]) bad |= PLAN_ASYMMETRIC;
+        }
+    if (lean) bad &= ~PLAN_ASYMMETRIC;  // (not examined: the tile kernel's lean mode is exact for any rev map inside a tile)
     if (bad) atomicOr(&flags_s, bad);
     stamp();  // 3: validated
     // phase 2: exclusive scan of cnt[0..nV) (6 consecutive counters per thread)
@@ -518,12 +537,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
             if (i0 + j < nV) {
                 rowp[i0 + j] = run;
                 cnt[i0 + j] = run;
-                plan[L.row_ptr + i0 + j] = run;
+                if (!lean) plan[L.row_ptr + i0 + j] = run;
             }
             run += v[j];
             md = max(md, v[j]);
         }
-        if (tid == kSmallThreads - 1) { rowp[nV] = run; plan[L.row_ptr + nV] = run; }
+        if (tid == kSmallThreads - 1) { rowp[nV] = run; if (!lean) plan[L.row_ptr + nV] = run; }
         for (int off = 32; off > 0; off >>= 1) md = max(md, __shfl_xor(md, off));
         if (lane == 0 && md > 0) atomicMax(&maxdeg_s, md);
     }
@@ -531,17 +550,19 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     stamp();  // 4: scan
     // phase 3: fill rows (order inside a row is arbitrary here); the scratch of the piece tiles is zeroed for
     // the covered-boundary bytes of phase 4
-    unsigned char* covb = reinterpret_cast<unsigned char*>(Ybuf);  // covb[u] != 0: an edge joins atoms < u with atoms >= u
+    if (!lean) {
     for (int w = tid; w < (nV + 3) / 4 + 1; w += kSmallThreads) Ybuf[w] = 0;
     for (int e = tid; e < nE; e += kSmallThreads) {
         const int pos = atomicAdd(&cnt[dst16[e]], 1);
         perm16[pos] = (u16)e;
+    }
     }
     __syncthreads();
     stamp();  // 5: fill
     // phase 4, one thread per atom: restore increasing edge id inside the row (the reference's summation
     // order), record the inverse permutation, and mark the atom boundaries the row's bonds reach across
     // (for the piece tiles).  Rows of <= 4 entries (molecules) are sorted in registers.
+    if (!lean)
     for (int v = tid; v < nV; v += kSmallThreads) {
         const int b = rowp[v];
         const int n = rowp[v + 1] - b;
@@ -591,9 +612,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     // phase 6 (runs on waves 1..15 while wave 0 walks the tile chain of phase 7): everything out.  A light
     // plan (forward of the fused routes only) skips the six arrays only the general route, the backward
     // pass and the tests read.
-    const TileGeom g = tile_geom(maxdeg_s, nE);
+    TileGeom g = tile_geom(maxdeg_s, nE);
+    if (lean) g.n_tiles = 0;  // no row tiles of the per-step fused route in a tile plan: its tables are emptied
     auto outputs = [&](int i0, int n_thr) {
-        for (int i = i0; i < nE; i += n_thr) {
+        for (int i = i0; i < (lean ? 0 : nE); i += n_thr) {
             const int e = perm16[i];
             plan[L.perm + i] = e;
             plan[L.srcp + i] = src16[e];
@@ -616,7 +638,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     stamp();  // 10: piece tiles
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
-        if (tid == DMPNN_HDR_FLAGS) v = flags_s | (maxdeg_s > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0);
+        if (tid == DMPNN_HDR_FLAGS) v = flags_s | (maxdeg_s > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0) | (lean ? PLAN_TILES_ONLY : 0);
         if (tid == DMPNN_HDR_NMTILES) v = n_mtiles < 0 ? 0 : n_mtiles;
         if (tid == DMPNN_HDR_LIGHT) v = light;
         if (tid == DMPNN_HDR_MAXDEG) v = maxdeg_s;
@@ -651,6 +673,7 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
         DMPNN_CHECK_LAUNCH("k_prepare_small");
         return DMPNN_OK;
     }
+    // (beyond the single-workgroup plan: always the full plan, whatever `light` asked for)
     {
         const int64_t n = nV > DMPNN_HDR_WORDS ? nV : DMPNN_HDR_WORDS;
         int grid = (int)((n + kBlock - 1) / kBlock);

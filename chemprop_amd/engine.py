@@ -56,9 +56,9 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 class GraphPlan:
     """K0: int32 indices + stable incoming-edge CSR of one batch, built on device (no host sync)."""
 
-    __slots__ = ("buf", "n_atoms", "n_edges", "device", "light")
+    __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index")
 
-    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light: bool = False):
+    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False):
         _require_device(edge_index, "edge_index")
         lib = _lib.load()
         dev = edge_index.device
@@ -70,16 +70,20 @@ class GraphPlan:
         nbytes = lib.dmpnn_plan_bytes(n_atoms, n_edges)
         self.buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
         self.n_atoms, self.n_edges, self.device = int(n_atoms), n_edges, dev
-        # a light plan holds only what a forward of the fused routes reads (inference); batches beyond the
-        # single-workgroup plan always get the full one
-        self.light = bool(light) and small_plan_fits(n_atoms, n_edges)
-        prep = lib.dmpnn_prepare_light if self.light else lib.dmpnn_prepare
+        # light=True: only what a forward of the fused routes reads (inference); light="tiles": only the piece-tile
+        # tables — the whole-forward tile kernel then works on the caller's own index arrays (kept alive here);
+        # batches beyond the single-workgroup plan always get the full plan
+        small = small_plan_fits(n_atoms, n_edges)
+        self.tiles_only = light == "tiles" and small
+        self.light = bool(light) and small
+        self.edge_index, self.rev_edge_index = ei, rev
+        prep = lib.dmpnn_prepare_tiles if self.tiles_only else (lib.dmpnn_prepare_light if self.light else lib.dmpnn_prepare)
         with torch.cuda.device(dev):
             _lib.check(prep(ei.data_ptr(), rev.data_ptr(), n_atoms, n_edges,
                             self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
 
     @classmethod
-    def from_bmg(cls, bmg, light: bool = False) -> "GraphPlan":
+    def from_bmg(cls, bmg, light=False) -> "GraphPlan":
         return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]), light=light)
 
     # ---- views for tests / diagnostics (these synchronise) ----
@@ -297,6 +301,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
 
     a = FwdArgs()
     a.plan, a.n_atoms, a.n_edges = plan.buf.data_ptr(), nV, nE
+    a.edge_index, a.rev_edge_index = plan.edge_index.data_ptr(), plan.rev_edge_index.data_ptr()
     a.d_v, a.d_e, a.d_h, a.d_vd = d_v, d_e, d_h, d_vd
     a.depth, a.flags = int(depth), (F_UNDIRECTED if undirected else 0)
     a.act, a.act_slope, a.act_slope_ptr = act_code(act), float(slope), _ptr(slope_t)
@@ -338,6 +343,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     if getattr(plan, "light", False) and (not use_fused or keep):
         raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
                            "(build the plan with light=False for the general route or for training)")
+    if getattr(plan, "tiles_only", False) and (not use_mega or (mfma or os.environ.get("DMPNN_MFMA", "split16")) == "f32"):
+        raise RuntimeError("forward: a tile plan (light='tiles') only serves the whole-forward tile kernel on the f16 pipe")
 
     st = ForwardState()
     st.fused = use_fused

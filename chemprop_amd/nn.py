@@ -118,8 +118,11 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         d_vd = (mp.W_d.in_features - mp.W_o.out_features) if mp.W_d is not None else None
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
-    plan = engine.GraphPlan.from_bmg(bmg, light=_light_plan_ok(mp) and int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES)
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    light = _light_plan_ok(mp) and int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES
+    if light and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols):
+        light = "tiles"
+    plan = engine.GraphPlan.from_bmg(bmg, light=light)
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch
 
@@ -142,6 +145,19 @@ def _light_plan_ok(mp) -> bool:
     d_h, d_in = mp.W_h.weight.shape[0], mp.W_i.weight.shape[1]
     d_v = mp.W_o.weight.shape[1] - d_h
     return d_h % 4 == 0 and d_h <= 320 and d_v % 2 == 0 and (d_in - d_v) % 2 == 0
+
+
+def _tile_plan_ok(mp, n_atoms: int, n_edges: int, n_mols: int) -> bool:
+    """After the validated first batches, an inference forward that is going to take the whole-forward tile kernel
+    on the f16 pipe needs only the piece-tile tables (``dmpnn_prepare_tiles``): the kernel reads the batch's own
+    index arrays and checks every tile itself (a tile that is not closed returns NaN for its atoms)."""
+    if os.environ.get("DMPNN_MEGA", "1") == "0" or os.environ.get("DMPNN_MFMA", "split16") == "f32":
+        return False
+    if os.environ.get("DMPNN_TILE_PLAN", "1") == "0" or getattr(mp, "_dmpnn_no_mega", False):
+        return False
+    if os.environ.get("DMPNN_VALIDATE", "first") == "always":
+        return False  # (the per-batch verdict is read from a full plan)
+    return n_mols > 0 and n_edges <= 30 * n_mols and engine.small_plan_fits(n_atoms, n_edges)
 
 
 def _route(mp, plan, n_mols: int = 0) -> int:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 2
+#define DMPNN_ABI_VERSION 3
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -89,6 +89,17 @@ int dmpnn_prepare(const int64_t* edge_index, /* [2, n_edges] row 0 = src atom, r
 int dmpnn_prepare_light(const int64_t* edge_index, const int64_t* rev_edge_index, int64_t n_atoms, int64_t n_edges,
                         void* plan, size_t plan_bytes, void* stream);
 
+/* The TILE plan: only the piece-tile tables and the header — for an inference dmpnn_forward with
+ * DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16 (no DMPNN_F_KEEP) whose dmpnn_fwd_args carry the caller's own
+ * edge_index / rev_edge_index.  The tile kernel then takes the rows of a tile to be its edges in the caller's order
+ * (the reference's collate keeps the edges of a molecule together, data/collate.py:48-62), reads src / dst / rev straight
+ * from those int64 arrays — no sort, no CSR, no permutation is built — and verifies per tile that the tile is closed
+ * (a tile that is not writes NaN to its atoms).  No other entry point may be given a tile plan (their kernels return
+ * NaN where they check the header, and are otherwise undefined).  Batches beyond the single-workgroup plan get the
+ * full plan (header word LIGHT says which one was written).                                                      */
+int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev_edge_index, int64_t n_atoms, int64_t n_edges,
+                        void* plan, size_t plan_bytes, void* stream);
+
 /* Plan header words (int32) readable by the caller after a stream sync (diagnostics/tests). */
 enum dmpnn_plan_hdr {
     DMPNN_HDR_FLAGS = 0,   /* bit0: graph is NOT symmetric (rev is not an involution with
@@ -106,7 +117,8 @@ enum dmpnn_plan_hdr {
     DMPNN_HDR_TILE_STRIDE = 5,
     DMPNN_HDR_NMTILES = 6, /* piece tiles actually used                                            */
     DMPNN_HDR_LIGHT = 7,   /* 1: light plan (dmpnn_prepare_light): src / dst / rev / inv / dstp / ident
-                              were NOT written — valid for forwards of the fused routes only           */
+                              were NOT written — valid for forwards of the fused routes only;
+                              2: tile plan (dmpnn_prepare_tiles): only the piece-tile tables were written  */
     DMPNN_HDR_WORDS = 16
 };
 /* Word offsets of the arrays inside the plan (for tests):
@@ -220,6 +232,8 @@ typedef struct dmpnn_fwd_args {
     float* out; int64_t ldout;
     /* DMPNN_F_SPLIT16: caller-owned scratch for the pre-split weights, >= dmpnn_forward_wsplit_bytes() */
     void* wsplit; size_t wsplit_bytes;
+    /* the caller's own index arrays (device): required when `plan` is a tile plan (dmpnn_prepare_tiles), else ignored */
+    const int64_t* edge_index; const int64_t* rev_edge_index;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);

@@ -145,13 +145,14 @@ def test_forward_matches_executed_reference(golden, gpu_device):
         assert torch.equal(a, b)
 
 
-def _engine_forward(golden, dev, fused=None, keep=False, route=None, mfma=None):
+def _engine_forward(golden, dev, fused=None, keep=False, route=None, mfma=None, plan=None):
     from chemprop_amd import engine
     from chemprop_amd.nn import classify_activation
 
     mp = golden.module(dev)
     bmg = golden.bmg(dev)
-    plan = engine.GraphPlan.from_bmg(bmg)
+    if plan is None:
+        plan = engine.GraphPlan.from_bmg(bmg)
     act, slope, slope_t = classify_activation(mp.tau)
     V_d = torch.from_numpy(golden["V_d"]).to(dev) if "V_d" in golden else None
     has_vd = mp.W_d is not None and V_d is not None
@@ -257,6 +258,79 @@ def test_whole_forward_tile_kernel_split_f16(golden, gpu_device):
     assert parity_err(st_s.Mv.cpu().numpy(), st_f.Mv.cpu().numpy()) <= 3e-6
     _, out_i, _ = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16")
     assert torch.equal(out_i, out_s)
+
+
+def _closed_tile_mask(a, src, dst, rev, n_atoms):
+    """What the tile kernel checks on a tile plan, in numpy: per atom, does its tile hold exactly its own edges
+    (caller ids mtile_row[t] .. mtile_row[t+1]) with both atoms and the reverse edge inside the tile?"""
+    n_t = int(a["hdr"][6])
+    ok = np.ones(n_atoms, dtype=bool)
+    mrow, matom = a["mtile_row"].numpy(), a["mtile_atom"].numpy()
+    for t in range(n_t):
+        e0, e1, a0, a1 = mrow[t], mrow[t + 1], matom[t], matom[t + 1]
+        e = np.arange(e0, e1)
+        good = ((src[e] >= a0) & (src[e] < a1) & (dst[e] >= a0) & (dst[e] < a1) & (rev[e] >= e0) & (rev[e] < e1)).all()
+        ok[a0:a1] = good
+    return ok
+
+
+def test_tile_plan_and_forward_on_caller_order_edges(golden, gpu_device):
+    """dmpnn_prepare_tiles writes the same piece-tile tables as the full plan and nothing else; the tile kernel then
+    works on the batch's own int64 index arrays (rows = edges in the caller's order) and gives the full-plan result;
+    tiles that are not closed in the caller's edge order (shuffled edge layouts) return NaN for their atoms."""
+    from chemprop_amd import engine
+    from chemprop_amd.engine import GraphPlan, small_plan_fits
+
+    cfg = golden.cfg
+    if cfg.get("undirected") or cfg["d_h"] % 4 or cfg["d_h"] > 320 or golden["V"].shape[1] % 2 or golden["E"].shape[1] % 2:
+        pytest.skip("fused routes do not apply")
+    if str(cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
+        pytest.skip("custom activation: rows route")
+    bmg = golden.bmg(gpu_device)
+    nV, nE = bmg.V.shape[0], bmg.E.shape[0]
+    if not small_plan_fits(nV, nE):
+        pytest.skip("batch beyond the single-workgroup plan")
+    full = GraphPlan.from_bmg(bmg)
+    lean = GraphPlan.from_bmg(bmg, light="tiles")
+    assert lean.tiles_only
+    af, al = full.arrays(), lean.arrays()
+    assert al["hdr"][7] == 2 and (al["hdr"][0] & 16)
+    if af["hdr"][0] & 2:  # indices out of range: both say so, nothing else is defined
+        assert al["hdr"][0] & 2
+        return
+    assert bool(al["hdr"][0] & 8) == bool(af["hdr"][0] & 8) and al["hdr"][6] == af["hdr"][6]
+    assert torch.equal(al["mtile_row"], af["mtile_row"]) and torch.equal(al["mtile_atom"], af["mtile_atom"])
+    _, out_l, st = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16", plan=lean)
+    assert st.route == "mega16"
+    if al["hdr"][0] & 8:
+        assert torch.isnan(out_l).all()
+        return
+    closed = _closed_tile_mask(al, golden["edge_index"][0], golden["edge_index"][1], golden["rev_edge_index"], nV)
+    out_l = out_l.cpu().numpy()
+    assert np.isnan(out_l[~closed]).all(), "atoms of a tile that is not closed must be NaN"
+    if closed.any():
+        assert parity_err(out_l[closed], golden["out"][closed]) <= TOL
+        if not (af["hdr"][0] & 1):
+            _, out_f, _ = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16")
+            assert parity_err(out_l[closed], out_f.cpu().numpy()[closed]) <= 3e-6
+    assert closed.all() or "shuffled" in golden.name or "garbage" in golden.name, f"{golden.name}: unexpected open tiles"
+
+
+def test_module_switches_to_the_tile_plan_after_validation(gpu_device):
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing, _tile_plan_ok
+
+    torch.manual_seed(1)
+    mp = BondMessagePassing().to(gpu_device).eval()
+    outs = []
+    with torch.no_grad():
+        for i in range(4):
+            bmg = synth.random_batch(64, "qm9", seed=50)
+            bmg.to(gpu_device)
+            outs.append(mp(bmg))
+        assert mp._dmpnn_batches_checked >= 2 and _tile_plan_ok(mp, bmg.V.shape[0], bmg.E.shape[0], 64)
+    assert parity_err(outs[3].cpu().numpy(), outs[0].cpu().numpy()) <= 3e-6   # full plan (validated) vs tile plan
+    assert torch.equal(outs[2], outs[3])
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (16, 64, 32), (33, 300, 300), (257, 300, 86),
@@ -486,7 +560,8 @@ def test_presplit_weight_cache_follows_weight_updates(gpu_device):
         fresh.load_state_dict(mp.state_dict())
         d = fresh(bmg)
     assert not torch.equal(a, c)
-    assert torch.equal(c, d)
+    # (c ran on a tile plan, d on the fresh module's first, validated, full plan: same arithmetic class, other row order)
+    assert parity_err(c.cpu().numpy(), d.cpu().numpy()) <= 3e-6
 
 
 def test_frozen_encoder_and_no_grad(gpu_device):
