@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
             const int ec = e < nE ? e : 0;
             s64[j] = edge_index[ec];
             d64[j] = edge_index[(int64_t)nE + ec];
-            r64[j] = rev64[ec];
+            if (light != 2) r64[j] = rev64[ec];  // (a tile plan never looks at rev: the tile kernel checks it per tile)
         }
     }
     __syncthreads();  // cnt zeroed
@@ -485,21 +485,24 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
                 r = r < 0 ? 0 : (r >= nE ? nE - 1 : r);
             }
             atomicAdd(&cnt[(int)d], 1);
-            if (lean) {
-                const int lo = (int)(s < d ? s : d), hi = (int)(s < d ? d : s);
-                if (hi - lo >= kMegaBA) {
-                    atomicOr(&piece_bad_s, 1);  // this bond alone spans more atoms than a tile holds: no piece tiles
-                } else {
-                    for (int u = lo + 1; u <= hi; ++u) covb[u] = 1;
-                }
-            } else {
-                src16[e] = (u16)s;
-                dst16[e] = (u16)d;
-                rev16[e] = (u16)r;
-            }
+            src16[e] = (u16)s;
+            dst16[e] = (u16)d;
+            rev16[e] = (u16)r;
         }
     }
     __syncthreads();
+    if (lean) {  // boundary marks, once per bond (the direction with s < d), in one compact loop
+        for (int e = tid; e < nE; e += kSmallThreads) {
+            const int sa = src16[e], da = dst16[e];
+            if (sa < da) {
+                if (da - sa >= kMegaBA) {
+                    atomicOr(&piece_bad_s, 1);  // this bond alone spans more atoms than a tile holds: no piece tiles
+                } else {
+                    for (int u = sa + 1; u <= da; ++u) covb[u] = 1;
+                }
+            }
+        }
+    }
     stamp();  // 2: narrowed + histogram
     // phase 1b: symmetric-graph invariants, from LDS
     if (!lean)

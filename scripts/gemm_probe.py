@@ -37,6 +37,8 @@ fn = lambda: engine.GraphPlan.from_bmg(bmg)
 print("K0 plan (512 mols):", round(t_ms(fn) * 1e3, 2), "us")
 fn = lambda: engine.GraphPlan.from_bmg(bmg, light=True)
 print("K0 plan, light (512 mols):", round(t_ms(fn) * 1e3, 2), "us")
+fn = lambda: engine.GraphPlan.from_bmg(bmg, light="tiles")
+print("K0 plan, tiles only (512 mols):", round(t_ms(fn) * 1e3, 2), "us")
 H = torch.randn(plan.n_edges, 300, device=dev); Mo = torch.empty_like(H)
 print("K2 message:", round(t_ms(lambda: engine.message(plan, H, out=Mo)) * 1e3, 2), "us")
 print("K4 aggregate:", round(t_ms(lambda: engine.aggregate(plan, H)) * 1e3, 2), "us")

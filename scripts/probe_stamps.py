@@ -17,7 +17,7 @@ fw = lambda: engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp
 with torch.no_grad():
     for _ in range(5): fw()
     lib.dmpnn_debug_timestamps(buf.data_ptr())
-    plan = engine.GraphPlan.from_bmg(bmg, light=("light" in sys.argv))
+    plan = engine.GraphPlan.from_bmg(bmg, light=("tiles" if "tiles" in sys.argv else ("light" in sys.argv)))
     fw(); torch.cuda.synchronize()
     lib.dmpnn_debug_timestamps(None)
 st = buf.cpu().tolist()
