@@ -162,7 +162,7 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_can_fuse.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dmpnn_prepare_light.argtypes = lib.dmpnn_prepare.argtypes
-    lib.dmpnn_prepare_tiles.argtypes = lib.dmpnn_prepare.argtypes
+    lib.dmpnn_prepare_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dmpnn_message_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint, C.c_void_p]
     lib.dmpnn_aggregate_fwd.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,

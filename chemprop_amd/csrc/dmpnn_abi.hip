@@ -93,8 +93,18 @@ int dmpnn_prepare_light(const int64_t* edge_index, const int64_t* rev, int64_t n
     return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 1, stream);
 }
 
-int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, int64_t n_atoms, int64_t n_edges, void* plan,
-                        size_t plan_bytes, void* stream) {
+int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t n_atoms, int64_t n_edges,
+                        void* plan, size_t plan_bytes, void* stream) {
+    if (batch && n_atoms > 0 && small_plan_fits(n_atoms, n_edges)) {
+        DMPNN_TRY(check_graph_sizes(n_atoms, n_edges));
+        DMPNN_CHECK_ARG(plan != nullptr && aligned16(plan), "prepare_tiles: plan must be a 16-byte aligned buffer");
+        DMPNN_CHECK_ARG(n_edges == 0 || edge_index, "prepare_tiles: null edge_index");
+        if (plan_bytes < dmpnn_plan_bytes(n_atoms, n_edges)) {
+            set_error("prepare_tiles: plan buffer too small (%zu < %zu bytes)", plan_bytes, dmpnn_plan_bytes(n_atoms, n_edges));
+            return DMPNN_ENOSPC;
+        }
+        return launch_prepare_tiles_batch(edge_index, batch, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream));
+    }
     return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 2, stream);
 }
 

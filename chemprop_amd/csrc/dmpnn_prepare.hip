@@ -263,76 +263,21 @@ __device__ __forceinline__ void block_scan_inclusive(int* a, int n, int* wave_to
     __syncthreads();
 }
 
-// ---- piece tiles: row tiles made of WHOLE connected pieces (molecules) --------------------------
-// A cut after atom v is safe when no edge joins atoms <= v with atoms > v; with atoms of a molecule
-// contiguous (data/collate.py:48-56) the cuts are the molecule boundaries (and fragment boundaries).
-// Consecutive pieces are packed greedily into tiles of <= kMegaBM rows and <= kMegaBA atoms; the chain
-// of tile starts is walked per block of 64 pieces, all blocks in parallel (a tile starts at every block
-// start).  X, Y: int scratch of nV + 2 entries each; Y enters holding one byte per atom boundary
-// (byte u != 0: an edge joins atoms < u with atoms >= u).
+// ---- piece tiles: row tiles made of WHOLE pieces (connected pieces, or molecules) ----------------
+// Greedy packing of consecutive pieces into tiles of <= kMegaBM rows and <= kMegaBA atoms.  X[p] = first atom of
+// piece p (X[np] = nV), row_of(p) = first row of piece p (row_of(np) = nE).  Y: int scratch of np + 1 entries.
 // Returns the number of tiles, or -1 when a piece does not fit (the tables are then emptied).
-template <class Other>
-__device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const PlanLayout& L, const int* rowp, int* X,
-                                                 int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid,
-                                                 Other&& other_work, long long* dbg = nullptr) {
-    int n_st = 0;
+template <class RowOf, class Other>
+__device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLayout& L, const int* X, int np, RowOf&& row_of,
+                                           int* Y, int* bad_s, int nV, int nE, int tid, Other&& other_work,
+                                           long long* dbg, int n_st) {
     auto stamp = [&]() {
         if (dbg && tid == 0 && n_st < 12) dbg[n_st] = (long long)__builtin_readcyclecounter();
         ++n_st;
     };
-    stamp();
     int* mrow = plan + L.mtile_row;
     int* matom = plan + L.mtile_atom;
     const int slots = (int)L.max_mtiles + 2;
-    constexpr int kMark = 0x40000000;
-    // piece starts = uncovered boundaries.  Y enters holding one covered-flag byte per atom boundary; a
-    // ballot per 64 atoms turns them into start-bit words (behind the bytes), ranked by one wave scan over
-    // the word popcounts.
-    const int n_words = (nV + 31) >> 5;
-    const unsigned char* covb = reinterpret_cast<const unsigned char*>(Y);
-    unsigned* stw = reinterpret_cast<unsigned*>(Y + (nV + 3) / 4 + 1);  // [2 ceil(nV / 64)] start-bit words
-    int* wrank = reinterpret_cast<int*>(stw) + 2 * ((nV + 63) >> 6);    // [n_words] start bits in the words before
-    for (int u0 = (tid >> 6) * 64; u0 < nV; u0 += kSmallThreads) {
-        const int u = u0 + (tid & 63);
-        const unsigned long long m = __ballot(u < nV && covb[u] == 0);
-        if ((tid & 63) == 0) { stw[u0 >> 5] = (unsigned)m; stw[(u0 >> 5) + 1] = (unsigned)(m >> 32); }
-    }
-    __syncthreads();
-    const unsigned my_starts = tid < n_words ? stw[tid] : 0u;
-    stamp();  // p1: start bits
-    __shared__ int np_s;
-    {   // kSmallMaxAtoms / 32 = 192 words: wave w scans words 64 w .. 64 w + 63, totals through LDS
-        const int lane = tid & 63, w = tid >> 6;
-        const int pc = __popc(my_starts);
-        int inc = pc;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) wave_tot[w] = inc;
-        __syncthreads();
-        int base = 0;
-        for (int k = 0; k < w; ++k) base += wave_tot[k];
-        if (tid < n_words) wrank[tid] = base + inc - pc;
-        if (tid == n_words - 1) np_s = base + inc;
-        if (n_words == 0 && tid == 0) np_s = 0;
-    }
-    __syncthreads();
-    stamp();  // p2: start ranks
-    const int np = np_s;
-    if (tid < n_words) {                                       // X[p] = first atom of piece p (the cursors are dead)
-        int p = wrank[tid];
-        unsigned bits = my_starts;
-        while (bits) {
-            const int bpos = __ffs(bits) - 1;
-            bits &= bits - 1u;
-            X[p++] = tid * 32 + bpos;
-        }
-    }
-    if (tid == 0) X[np] = nV;
-    __syncthreads();
-    stamp();  // p3: piece starts
     // next tile start (a piece index) for every piece; Y becomes the jump / mark word
     int nx[kSmallItems];
 #pragma unroll
@@ -340,12 +285,12 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
         const int p = tid + kSmallThreads * j;
         nx[j] = np;
         if (p < np) {
-            const int v = X[p], r0 = rowp[v];
+            const int v = X[p], r0 = row_of(p);
             int q = p + 1;  // pieces p .. q-1 fit
-            if (X[q] - v > kMegaBA || rowp[X[q]] - r0 > kMegaBM) {
+            if (X[q] - v > kMegaBA || row_of(q) - r0 > kMegaBM) {
                 atomicOr(bad_s, 1);  // one piece alone exceeds a tile
             } else {
-                while (q < np && X[q + 1] - v <= kMegaBA && rowp[X[q + 1]] - r0 <= kMegaBM) ++q;
+                while (q < np && X[q + 1] - v <= kMegaBA && row_of(q + 1) - r0 <= kMegaBM) ++q;
             }
             nx[j] = q;
         }
@@ -397,9 +342,8 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
             const bool on = (mask >> lane) & 1ull;
             const int r = rank + __popcll(mask & ((1ull << lane) - 1ull));
             if (on && r < (int)L.max_mtiles) {
-                const int v = X[p];
-                mrow[r] = rowp[v];
-                matom[r] = v;
+                mrow[r] = row_of(p);
+                matom[r] = X[p];
             }
             if (blk == nblk - 1 && lane == 0) {
                 const int total = rank + __popcll(mask);
@@ -419,6 +363,74 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
     }
     for (int t = n_tiles + tid; t < slots; t += kSmallThreads) { mrow[t] = nE; matom[t] = nV; }
     return n_tiles;
+}
+
+// Pieces from connectivity.  A cut after atom v is safe when no edge joins atoms <= v with atoms > v; with atoms of a molecule
+// contiguous (data/collate.py:48-56) the cuts are the molecule boundaries (and fragment boundaries).
+// Consecutive pieces are packed greedily into tiles of <= kMegaBM rows and <= kMegaBA atoms; the chain
+// of tile starts is walked per block of 64 pieces, all blocks in parallel (a tile starts at every block
+// start).  X, Y: int scratch of nV + 2 entries each; Y enters holding one byte per atom boundary
+// (byte u != 0: an edge joins atoms < u with atoms >= u).
+// Returns the number of tiles, or -1 when a piece does not fit (the tables are then emptied).
+template <class Other>
+__device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const PlanLayout& L, const int* rowp, int* X,
+                                                 int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid,
+                                                 Other&& other_work, long long* dbg = nullptr) {
+    int n_st = 0;
+    auto stamp = [&]() {
+        if (dbg && tid == 0 && n_st < 12) dbg[n_st] = (long long)__builtin_readcyclecounter();
+        ++n_st;
+    };
+    stamp();
+    // piece starts = uncovered boundaries.  Y enters holding one covered-flag byte per atom boundary; a
+    // ballot per 64 atoms turns them into start-bit words (behind the bytes), ranked by one wave scan over
+    // the word popcounts.
+    const int n_words = (nV + 31) >> 5;
+    const unsigned char* covb = reinterpret_cast<const unsigned char*>(Y);
+    unsigned* stw = reinterpret_cast<unsigned*>(Y + (nV + 3) / 4 + 1);  // [2 ceil(nV / 64)] start-bit words
+    int* wrank = reinterpret_cast<int*>(stw) + 2 * ((nV + 63) >> 6);    // [n_words] start bits in the words before
+    for (int u0 = (tid >> 6) * 64; u0 < nV; u0 += kSmallThreads) {
+        const int u = u0 + (tid & 63);
+        const unsigned long long m = __ballot(u < nV && covb[u] == 0);
+        if ((tid & 63) == 0) { stw[u0 >> 5] = (unsigned)m; stw[(u0 >> 5) + 1] = (unsigned)(m >> 32); }
+    }
+    __syncthreads();
+    const unsigned my_starts = tid < n_words ? stw[tid] : 0u;
+    stamp();  // p1: start bits
+    __shared__ int np_s;
+    {   // kSmallMaxAtoms / 32 = 192 words: wave w scans words 64 w .. 64 w + 63, totals through LDS
+        const int lane = tid & 63, w = tid >> 6;
+        const int pc = __popc(my_starts);
+        int inc = pc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_tot[w] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < w; ++k) base += wave_tot[k];
+        if (tid < n_words) wrank[tid] = base + inc - pc;
+        if (tid == n_words - 1) np_s = base + inc;
+        if (n_words == 0 && tid == 0) np_s = 0;
+    }
+    __syncthreads();
+    stamp();  // p2: start ranks
+    const int np = np_s;
+    if (tid < n_words) {                                       // X[p] = first atom of piece p (the cursors are dead)
+        int p = wrank[tid];
+        unsigned bits = my_starts;
+        while (bits) {
+            const int bpos = __ffs(bits) - 1;
+            bits &= bits - 1u;
+            X[p++] = tid * 32 + bpos;
+        }
+    }
+    if (tid == 0) X[np] = nV;
+    __syncthreads();
+    stamp();  // p3: piece starts
+    return pack_pieces(plan, L, X, np, [&](int p) { return rowp[X[p]]; }, Y, bad_s, nV, nE, tid, other_work, dbg, n_st);
 }
 
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* __restrict__ edge_index,
@@ -653,7 +665,125 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     }
 }
 
+
+// ---- tile plan from the batch vector (dmpnn_prepare_tiles with `batch`) -----------------------------
+// BatchMolGraph.batch gives the molecule of every atom, non-decreasing, and collate concatenates the edges of the
+// molecules in the same order (data/collate.py:48-62): molecule m owns the atoms lower_bound(batch, m) .. and the
+// edges lower_bound(batch[dst[.]], m) ..  — two binary searches per molecule over arrays held in LDS, no histogram,
+// no scan, no connectivity analysis.  Pieces = molecules.  What is NOT checked here (that every edge of a molecule's
+// range has both atoms and its reverse inside) is checked by the tile kernel for every tile it runs.
+__global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int64_t* __restrict__ edge_index,
+                                                                      const int64_t* __restrict__ batch,
+                                                                      int* __restrict__ plan, PlanLayout L, int nV, int nE) {
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];
+    int* fa = lds_i;                 // [nV + 2] first atom of molecule m
+    int* fe = fa + nV + 2;           // [nV + 2] first edge of molecule m
+    int* Y = fe + nV + 2;            // [nV + 2] next-tile pointers
+    u16* bm = reinterpret_cast<u16*>(Y + nV + 2);  // [nV] molecule of an atom
+    u16* mb = bm + nV + (nV & 1);                  // [nE] molecule of an edge (of its destination atom)
+    __shared__ int bad_s, flags_s, nm_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) { bad_s = 0; flags_s = 0; nm_s = 0; }
+    // phase 1: batch -> LDS; dst -> batch[dst] -> LDS (all loads of a thread in flight together)
+    int64_t d64[kSmallEPT], b64[kSmallItems];
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int v = tid + kSmallThreads * j;
+        b64[j] = batch[v < nV ? v : 0];
+    }
+    if (nE > 0) {
+#pragma unroll
+        for (int j = 0; j < kSmallEPT; ++j) {
+            const int e = tid + kSmallThreads * j;
+            d64[j] = edge_index[(int64_t)nE + (e < nE ? e : 0)];
+        }
+#pragma unroll
+        for (int j = 0; j < kSmallEPT; ++j) {
+            const int e = tid + kSmallThreads * j;
+            const bool ok = d64[j] >= 0 && d64[j] < nV;
+            if (e < nE && !ok) bad |= PLAN_RANGE_ERROR;
+            d64[j] = batch[ok ? d64[j] : 0];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSmallItems; ++j) {
+        const int v = tid + kSmallThreads * j;
+        if (v < nV) {
+            if (b64[j] < 0 || b64[j] >= nV) { bad |= PLAN_RANGE_ERROR; b64[j] = 0; }  // at most one molecule per atom
+            bm[v] = (u16)b64[j];
+        }
+    }
+    if (nE > 0) {
+#pragma unroll
+        for (int j = 0; j < kSmallEPT; ++j) {
+            const int e = tid + kSmallThreads * j;
+            if (e < nE) mb[e] = (u16)((d64[j] < 0 || d64[j] >= nV) ? 0 : d64[j]);
+        }
+    }
+    __syncthreads();
+    // phase 2: both must be non-decreasing (else the ranges below mean nothing: no tiles)
+    for (int v = tid + 1; v < nV; v += kSmallThreads)
+        if (bm[v] < bm[v - 1]) bad |= PLAN_NO_PIECE_TILES;
+    for (int e = tid + 1; e < nE; e += kSmallThreads)
+        if (mb[e] < mb[e - 1]) bad |= PLAN_NO_PIECE_TILES;
+    if (bad) atomicOr(&flags_s, bad);
+    if (tid == 0) nm_s = nV > 0 ? (int)bm[nV - 1] + 1 : 0;
+    __syncthreads();
+    const int nm = nm_s;
+    // phase 3: first atom / first edge of every molecule (and the end markers at m = nm)
+    for (int m = tid; m <= nm; m += kSmallThreads) {
+        int lo = 0, hi = nV;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)bm[mid] < m) lo = mid + 1; else hi = mid; }
+        fa[m] = lo;
+        lo = 0; hi = nE;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)mb[mid] < m) lo = mid + 1; else hi = mid; }
+        fe[m] = lo;
+    }
+    if ((flags_s & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR)) && tid == 0) bad_s = 1;
+    __syncthreads();
+    // phase 4: greedy packing + the tables; the row tiles of the per-step fused route are emptied
+    TileGeom g;
+    g.b0 = kFusedBM; g.n_tiles = 0;
+    auto rest = [&](int i0, int n_thr) { write_tiles(plan, L, fe, nV, nE, g, i0, n_thr); };
+    const int n_mtiles = pack_pieces(plan, L, fa, nm, [&](int p) { return fe[p]; }, Y, &bad_s, nV, nE, tid, rest, nullptr, 0);
+    if (tid < DMPNN_HDR_WORDS) {
+        int v = 0;
+        if (tid == DMPNN_HDR_FLAGS) v = (flags_s & PLAN_RANGE_ERROR) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
+        if (tid == DMPNN_HDR_NMTILES) v = n_mtiles < 0 ? 0 : n_mtiles;
+        if (tid == DMPNN_HDR_LIGHT) v = 2;
+        if (tid == DMPNN_HDR_NATOMS) v = nV;
+        if (tid == DMPNN_HDR_NEDGES) v = nE;
+        if (tid == DMPNN_HDR_TILE_STRIDE) v = g.b0;
+        plan[tid] = v;
+    }
+}
+
 }  // namespace
+
+// bytes of LDS of k_prepare_tiles_batch
+static size_t tiles_batch_lds_bytes(int64_t nV, int64_t nE) {
+    return ((size_t)(3 * (nV + 2)) * 4 + (size_t)(nV + 1 + nE + 2) * 2 + 31) & ~size_t(15);
+}
+
+int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV64, int64_t nE64, int* plan, hipStream_t s) {
+    const int nV = (int)nV64, nE = (int)nE64;
+    const PlanLayout L = plan_layout(nV, nE);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_tiles_batch),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(k_prepare_tiles_batch): %s", hipGetErrorString(e));
+            return DMPNN_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_prepare_tiles_batch, dim3(1), dim3(kSmallThreads), tiles_batch_lds_bytes(nV, nE), s, edge_index, batch, plan,
+                       L, nV, nE);
+    DMPNN_CHECK_LAUNCH("k_prepare_tiles_batch");
+    return DMPNN_OK;
+}
 
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, int64_t nE64,
                    int* plan, int light, hipStream_t s) {

@@ -58,7 +58,7 @@ class GraphPlan:
 
     __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index")
 
-    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False):
+    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False, batch: Optional[Tensor] = None):
         _require_device(edge_index, "edge_index")
         lib = _lib.load()
         dev = edge_index.device
@@ -77,14 +77,23 @@ class GraphPlan:
         self.tiles_only = light == "tiles" and small
         self.light = bool(light) and small
         self.edge_index, self.rev_edge_index = ei, rev
-        prep = lib.dmpnn_prepare_tiles if self.tiles_only else (lib.dmpnn_prepare_light if self.light else lib.dmpnn_prepare)
         with torch.cuda.device(dev):
-            _lib.check(prep(ei.data_ptr(), rev.data_ptr(), n_atoms, n_edges,
-                            self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
+            if self.tiles_only:
+                # with the batch vector (int64, like the reference's) the tiles are whole molecules found by binary search
+                bt = batch if (batch is not None and batch.dtype == torch.int64 and batch.device == dev
+                               and batch.numel() == n_atoms and batch.is_contiguous()) else None
+                _lib.check(lib.dmpnn_prepare_tiles(ei.data_ptr(), rev.data_ptr(), bt.data_ptr() if bt is not None else None,
+                                                   n_atoms, n_edges, self.buf.data_ptr(), nbytes, _stream_ptr(dev)),
+                           "dmpnn_prepare_tiles")
+            else:
+                prep = lib.dmpnn_prepare_light if self.light else lib.dmpnn_prepare
+                _lib.check(prep(ei.data_ptr(), rev.data_ptr(), n_atoms, n_edges,
+                                self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
 
     @classmethod
-    def from_bmg(cls, bmg, light=False) -> "GraphPlan":
-        return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]), light=light)
+    def from_bmg(cls, bmg, light=False, use_batch: bool = True) -> "GraphPlan":
+        return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]), light=light,
+                   batch=getattr(bmg, "batch", None) if use_batch else None)
 
     # ---- views for tests / diagnostics (these synchronise) ----
     def arrays(self) -> dict:

@@ -96,9 +96,12 @@ int dmpnn_prepare_light(const int64_t* edge_index, const int64_t* rev_edge_index
  * from those int64 arrays — no sort, no CSR, no permutation is built — and verifies per tile that the tile is closed
  * (a tile that is not writes NaN to its atoms).  No other entry point may be given a tile plan (their kernels return
  * NaN where they check the header, and are otherwise undefined).  Batches beyond the single-workgroup plan get the
- * full plan (header word LIGHT says which one was written).                                                      */
-int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev_edge_index, int64_t n_atoms, int64_t n_edges,
-                        void* plan, size_t plan_bytes, void* stream);
+ * full plan (header word LIGHT says which one was written).
+ * `batch` (BatchMolGraph.batch, [n_atoms] int64, may be NULL): with it the tiles are made of whole MOLECULES found by
+ * binary search in the (non-decreasing) batch vector and in batch[dst[.]] — no histogram, no scan, no connectivity
+ * analysis; without it of whole connected pieces as in the full plan.                                            */
+int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev_edge_index, const int64_t* batch, int64_t n_atoms,
+                        int64_t n_edges, void* plan, size_t plan_bytes, void* stream);
 
 /* Plan header words (int32) readable by the caller after a stream sync (diagnostics/tests). */
 enum dmpnn_plan_hdr {

@@ -274,7 +274,8 @@ def _closed_tile_mask(a, src, dst, rev, n_atoms):
     return ok
 
 
-def test_tile_plan_and_forward_on_caller_order_edges(golden, gpu_device):
+@pytest.mark.parametrize("use_batch", [False, True], ids=["pieces", "molecules"])
+def test_tile_plan_and_forward_on_caller_order_edges(golden, use_batch, gpu_device):
     """dmpnn_prepare_tiles writes the same piece-tile tables as the full plan and nothing else; the tile kernel then
     works on the batch's own int64 index arrays (rows = edges in the caller's order) and gives the full-plan result;
     tiles that are not closed in the caller's edge order (shuffled edge layouts) return NaN for their atoms."""
@@ -291,15 +292,24 @@ def test_tile_plan_and_forward_on_caller_order_edges(golden, gpu_device):
     if not small_plan_fits(nV, nE):
         pytest.skip("batch beyond the single-workgroup plan")
     full = GraphPlan.from_bmg(bmg)
-    lean = GraphPlan.from_bmg(bmg, light="tiles")
+    lean = GraphPlan.from_bmg(bmg, light="tiles", use_batch=use_batch)  # tiles of connected pieces / of whole molecules (batch vector)
     assert lean.tiles_only
     af, al = full.arrays(), lean.arrays()
     assert al["hdr"][7] == 2 and (al["hdr"][0] & 16)
     if af["hdr"][0] & 2:  # indices out of range: both say so, nothing else is defined
         assert al["hdr"][0] & 2
         return
-    assert bool(al["hdr"][0] & 8) == bool(af["hdr"][0] & 8) and al["hdr"][6] == af["hdr"][6]
-    assert torch.equal(al["mtile_row"], af["mtile_row"]) and torch.equal(al["mtile_atom"], af["mtile_atom"])
+    if not use_batch:
+        assert bool(al["hdr"][0] & 8) == bool(af["hdr"][0] & 8) and al["hdr"][6] == af["hdr"][6]
+        assert torch.equal(al["mtile_row"], af["mtile_row"]) and torch.equal(al["mtile_atom"], af["mtile_atom"])
+    else:  # molecules: every tile boundary is a molecule boundary, tiles hold <= 48 edges / <= 32 atoms and cover the batch
+        n_t = int(al["hdr"][6])
+        ma, mr = al["mtile_atom"].numpy(), al["mtile_row"].numpy()
+        if not (al["hdr"][0] & 8):
+            b = golden["batch"]
+            assert ma[0] == 0 and ma[n_t] == nV and mr[0] == 0 and mr[n_t] == nE
+            assert (np.diff(ma[:n_t + 1]) <= 32).all() and (np.diff(mr[:n_t + 1]) <= 48).all() and (np.diff(ma[:n_t + 1]) >= 0).all()
+            assert all(v == 0 or v == nV or b[v] != b[v - 1] for v in ma[:n_t + 1])
     _, out_l, st = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16", plan=lean)
     assert st.route == "mega16"
     if al["hdr"][0] & 8:
@@ -310,7 +320,7 @@ def test_tile_plan_and_forward_on_caller_order_edges(golden, gpu_device):
     assert np.isnan(out_l[~closed]).all(), "atoms of a tile that is not closed must be NaN"
     if closed.any():
         assert parity_err(out_l[closed], golden["out"][closed]) <= TOL
-        if not (af["hdr"][0] & 1):
+        if not (af["hdr"][0] & (1 | 8)):
             _, out_f, _ = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16")
             assert parity_err(out_l[closed], out_f.cpu().numpy()[closed]) <= 3e-6
     assert closed.all() or "shuffled" in golden.name or "garbage" in golden.name, f"{golden.name}: unexpected open tiles"
