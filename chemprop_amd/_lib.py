@@ -206,6 +206,24 @@ def load() -> C.CDLL:
     return lib
 
 
+# ---- environment options on the hot path -------------------------------------------------------
+# os.environ.get encodes the key and decodes the value on every call (~1 us; a forward asks a dozen times);
+# its backing dict (bytes -> bytes, kept in step by every os.environ assignment) is a plain lookup.
+_ENV_DATA = getattr(os.environ, "_data", None)
+_ENV_KEYS: dict = {}
+
+
+def opt(name: str, default: str) -> str:
+    """``os.environ.get(name, default)`` without the per-call encode / decode."""
+    if _ENV_DATA is None or os.name != "posix":
+        return os.environ.get(name, default)
+    k = _ENV_KEYS.get(name)
+    if k is None:
+        k = _ENV_KEYS[name] = name.encode()
+    v = _ENV_DATA.get(k)
+    return default if v is None else v.decode()
+
+
 class DmpnnError(RuntimeError):
     pass
 

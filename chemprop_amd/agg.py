@@ -57,7 +57,7 @@ class MolBounds:
         lib = _lib.load()
         nb = int(lib.dmpnn_molagg_ws_bytes(self.n_mols))
         self.ws = torch.empty(nb, dtype=torch.uint8, device=batch.device)
-        with torch.cuda.device(batch.device):
+        with engine._OnDevice(batch.device):
             _lib.check(lib.dmpnn_molagg_bounds(self.batch.data_ptr(), self.n_atoms, self.n_mols, self.ws.data_ptr(), nb,
                                                engine._stream_ptr(batch.device)), "dmpnn_molagg_bounds")
 
@@ -68,7 +68,7 @@ def mol_reduce(H: Tensor, b: MolBounds, mode: str = "sum", norm: float = 1.0) ->
         raise ValueError(f"H must be [n_atoms={b.n_atoms}, d]; got {tuple(H.shape)}")
     out = torch.empty(b.n_mols, H.shape[1], dtype=torch.float32, device=H.device)
     lib = _lib.load()
-    with torch.cuda.device(H.device):
+    with engine._OnDevice(H.device):
         _lib.check(lib.dmpnn_molagg_fwd(H.data_ptr(), H.stride(0), b.n_atoms, H.shape[1], b.n_mols, b.ws.data_ptr(),
                                         MODES[mode], C.c_float(norm), out.data_ptr(), out.stride(0) if b.n_mols else H.shape[1],
                                         engine._stream_ptr(H.device)), "dmpnn_molagg_fwd")
@@ -80,7 +80,7 @@ def mol_expand(G: Tensor, b: MolBounds, mode: str = "sum", norm: float = 1.0) ->
     G = engine._f32c(G, "G")
     out = torch.empty(b.n_atoms, G.shape[1], dtype=torch.float32, device=G.device)
     lib = _lib.load()
-    with torch.cuda.device(G.device):
+    with engine._OnDevice(G.device):
         _lib.check(lib.dmpnn_molagg_bwd(G.data_ptr(), G.stride(0) if b.n_mols else G.shape[1], b.batch.data_ptr(), b.n_atoms,
                                         G.shape[1], b.n_mols, b.ws.data_ptr(), MODES[mode], C.c_float(norm), out.data_ptr(),
                                         out.stride(0) if b.n_atoms else G.shape[1], engine._stream_ptr(G.device)),

@@ -29,8 +29,33 @@ def small_plan_fits(n_atoms: int, n_edges: int) -> bool:
     return n_atoms <= 6144 and n_edges <= 10240 and lds <= 160 * 1024 - 2048
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device) -> int:
+    """Raw handle of torch's current stream on ``device`` (the launch stream of every kernel of this call)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _OnDevice:
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already the current device (the usual case costs nothing)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        idx = dev.index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _require_device(t: Tensor, name: str) -> None:
@@ -77,7 +102,7 @@ class GraphPlan:
         self.tiles_only = light == "tiles" and small
         self.light = bool(light) and small
         self.edge_index, self.rev_edge_index = ei, rev
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             if self.tiles_only:
                 # with the batch vector (int64, like the reference's) the tiles are whole molecules found by binary search
                 bt = batch if (batch is not None and batch.dtype == torch.int64 and batch.device == dev
@@ -162,7 +187,7 @@ def message(plan: GraphPlan, H: Tensor, act_on_load: str = "none", slope: float 
             slope_t: Optional[Tensor] = None, undirected: bool = False, out: Optional[Tensor] = None) -> Tensor:
     H = _f32c(H, "H")
     M = out if out is not None else torch.empty_like(H)
-    with torch.cuda.device(H.device):
+    with _OnDevice(H.device):
         _lib.check(_lib.load().dmpnn_message_fwd(
             plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, H.shape[1], H.data_ptr(), H.stride(0),
             M.data_ptr(), M.stride(0), act_code(act_on_load), float(slope), _ptr(slope_t),
@@ -174,7 +199,7 @@ def aggregate(plan: GraphPlan, H: Tensor, act_on_load: str = "none", slope: floa
               slope_t: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     H = _f32c(H, "H")
     Mv = out if out is not None else torch.empty(plan.n_atoms, H.shape[1], dtype=torch.float32, device=H.device)
-    with torch.cuda.device(H.device):
+    with _OnDevice(H.device):
         _lib.check(_lib.load().dmpnn_aggregate_fwd(
             plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, H.shape[1], H.data_ptr(), H.stride(0),
             Mv.data_ptr(), Mv.stride(0), act_code(act_on_load), float(slope), _ptr(slope_t),
@@ -190,7 +215,7 @@ def gather_rows(X: Tensor, idx32: Tensor, out: Optional[Tensor] = None) -> Tenso
         raise RuntimeError("gather_rows: int32 indices (the plan's arrays)")
     n = int(idx32.shape[0])
     O = out if out is not None else torch.empty(n, X.shape[1], dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with _OnDevice(X.device):
         _lib.check(_lib.load().dmpnn_gather_rows(X.data_ptr(), X.stride(0), X.shape[0], idx32.data_ptr(), n, X.shape[1],
                                                  O.data_ptr(), O.stride(0) if n else X.shape[1], _stream_ptr(X.device)),
                    "dmpnn_gather_rows")
@@ -226,7 +251,7 @@ def linear(A1: Tensor, W: Tensor, bias: Optional[Tensor] = None, A2: Optional[Te
     g.Zpre, g.ldz = _ptr(zpre), (zpre.stride(0) if zpre is not None else 0)
     g.act, g.act_slope, g.act_slope_ptr = act_code(act), float(slope), _ptr(slope_t)
     lib = _lib.load()
-    with torch.cuda.device(A1.device):
+    with _OnDevice(A1.device):
         if mfma == "split16":
             if not lib.dmpnn_linear16_ok(C.byref(g)):
                 raise RuntimeError("linear(split16): shapes / alignments not taken by the split kernel")
@@ -253,7 +278,7 @@ def update_fused(plan: GraphPlan, M: Tensor, H0: Tensor, W_h: Tensor, b_h: Optio
     if want_Mv and Mv is None:
         Mv = torch.empty(plan.n_atoms, h, dtype=torch.float32, device=dev)
     ld = lambda t: t.stride(0) if t is not None else 0
-    with torch.cuda.device(dev):
+    with _OnDevice(dev):
         _lib.check(_lib.load().dmpnn_update_fwd(
             plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, h, M.data_ptr(), M.stride(0), H0.data_ptr(), H0.stride(0),
             W_h.data_ptr(), _ptr(b_h), _ptr(H_out), ld(H_out), _ptr(M_next), ld(M_next), _ptr(Mv), ld(Mv),
@@ -332,11 +357,11 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     # route: the shape / alignment part of the decision is the library's (dmpnn_forward_can_fuse)
     if fused is False:
         route = "general"
-    if os.environ.get("DMPNN_GENERAL", "0") == "1":
+    if _lib.opt("DMPNN_GENERAL", "0") == "1":
         route = "general"
     a.H0 = a.Ms = a.Mv = plan.buf.data_ptr()  # any 16-byte aligned pointer: the real workspace is allocated below
     level = 0 if (route == "general" or undirected) else int(lib.dmpnn_forward_can_fuse(C.byref(a)))
-    if route == "fused" or os.environ.get("DMPNN_MEGA", "1") == "0":
+    if route == "fused" or _lib.opt("DMPNN_MEGA", "1") == "0":
         level = min(level, 1)
     if route is None:
         level = min(level, int(max_level))
@@ -344,7 +369,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
                            "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "
                            "<= 6144 atoms and <= 12288 edges)")
-    mf = mfma or os.environ.get("DMPNN_MFMA", "split16")
+    mf = mfma or _lib.opt("DMPNN_MFMA", "split16")
     if (level == 1 and route is None and fused is None and mfma is None and mf == "split16" and nE >= STEPS16_MIN_EDGES
             and not getattr(plan, "light", False)):
         level = 0  # large batch: the per-step route on the f16 pipe beats the fused fp32-MFMA contractions
@@ -352,7 +377,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     if getattr(plan, "light", False) and (not use_fused or keep):
         raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
                            "(build the plan with light=False for the general route or for training)")
-    if getattr(plan, "tiles_only", False) and (not use_mega or (mfma or os.environ.get("DMPNN_MFMA", "split16")) == "f32"):
+    if getattr(plan, "tiles_only", False) and (not use_mega or (mfma or _lib.opt("DMPNN_MFMA", "split16")) == "f32"):
         raise RuntimeError("forward: a tile plan (light='tiles') only serves the whole-forward tile kernel on the f16 pipe")
 
     st = ForwardState()
@@ -369,20 +394,28 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         n_mslots = max(n_steps, 1) if keep else 1
     st.plan, st.ldh, st.n_hslots, st.n_mslots = plan, ldh, n_hslots, n_mslots
     need_h0 = not (use_mega and not keep)
-    edge_ws = torch.empty(((1 if need_h0 else 0) + n_hslots + n_mslots, nE, ldh), dtype=torch.float32, device=dev)
-    atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
-    if ldh != d_h:  # pad columns are read by vector loads of later kernels: keep them finite
-        edge_ws.zero_()
-        atom_ws.zero_()
-    i0 = 1 if need_h0 else 0
-    st.H0, st.Hs, st.Ms = (edge_ws[0] if need_h0 else None), edge_ws[i0:i0 + n_hslots], edge_ws[i0 + n_hslots:]
-    st.Mv, st.Hv = atom_ws[0], atom_ws[1]
+    if use_mega and not keep and not d_vd:  # inference tile kernel: nothing leaves the CU but `out`
+        edge_ws = atom_ws = None
+    else:
+        edge_ws = torch.empty(((1 if need_h0 else 0) + n_hslots + n_mslots, nE, ldh), dtype=torch.float32, device=dev)
+        atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
     st.out = out
-
-    a.H0 = st.H0.data_ptr() if need_h0 else None
-    a.Hs, a.n_hslots = (st.Hs.data_ptr() if n_hslots else None), n_hslots
-    a.Ms, a.n_mslots = (st.Ms.data_ptr() if n_mslots else None), max(n_mslots, 1)
-    a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
+    if edge_ws is None:
+        st.H0 = st.Hs = st.Ms = st.Mv = st.Hv = None
+        a.H0 = a.Hs = a.Ms = None
+        a.n_hslots, a.n_mslots = 0, 1
+        a.Mv = a.Hv = plan.buf.data_ptr()  # (never written: the tile kernel stores kept tensors with DMPNN_F_KEEP only)
+    else:
+        if ldh != d_h:  # pad columns are read by vector loads of later kernels: keep them finite
+            edge_ws.zero_()
+            atom_ws.zero_()
+        i0 = 1 if need_h0 else 0
+        st.H0, st.Hs, st.Ms = (edge_ws[0] if need_h0 else None), edge_ws[i0:i0 + n_hslots], edge_ws[i0 + n_hslots:]
+        st.Mv, st.Hv = atom_ws[0], atom_ws[1]
+        a.H0 = st.H0.data_ptr() if need_h0 else None
+        a.Hs, a.n_hslots = (st.Hs.data_ptr() if n_hslots else None), n_hslots
+        a.Ms, a.n_mslots = (st.Ms.data_ptr() if n_mslots else None), max(n_mslots, 1)
+        a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
     if use_fused:
         a.flags |= F_FUSED
     wsplit = None
@@ -400,7 +433,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         # pre-split weights are reusable while the weight tensors are the same objects at the same
         # autograd version (every in-place update bumps `_version`): inference with frozen weights
         key = None
-        if wcache is not None and os.environ.get("DMPNN_WCACHE", "1") != "0":
+        if wcache is not None and _lib.opt("DMPNN_WCACHE", "1") != "0":
             key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (W_i, W_h, W_o) + ((W_d,) if d_vd else ())) \
                 + (nb, d_v, d_e, str(dev), bool(use_mega))
             if wcache.get("key") == key:
@@ -416,7 +449,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         a.flags |= F_MEGA
     if keep:
         a.flags |= F_KEEP
-    with torch.cuda.device(dev):
+    with _OnDevice(dev):
         _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
     st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, wsplit)
@@ -446,7 +479,7 @@ def backward(st: ForwardState, gout: Tensor, need: dict) -> dict:
     nbytes = lib.dmpnn_backward_ws_bytes(C.byref(st.args))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
     b.ws, b.ws_bytes = ws.data_ptr(), nbytes
-    with torch.cuda.device(dev):
+    with _OnDevice(dev):
         _lib.check(lib.dmpnn_backward(C.byref(b), _stream_ptr(dev)), "dmpnn_backward")
     return grads
 
@@ -454,7 +487,7 @@ def backward(st: ForwardState, gout: Tensor, need: dict) -> dict:
 def message_bwd(plan: GraphPlan, gM: Tensor) -> Tensor:
     gM = _f32c(gM, "gM")
     gH = torch.empty_like(gM)
-    with torch.cuda.device(gM.device):
+    with _OnDevice(gM.device):
         _lib.check(_lib.load().dmpnn_message_bwd(plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, gM.shape[1],
                                                  gM.data_ptr(), gM.stride(0), gH.data_ptr(), gH.stride(0),
                                                  _stream_ptr(gM.device)), "dmpnn_message_bwd")
@@ -464,7 +497,7 @@ def message_bwd(plan: GraphPlan, gM: Tensor) -> Tensor:
 def aggregate_bwd(plan: GraphPlan, gMv: Tensor) -> Tensor:
     gMv = _f32c(gMv, "gMv")
     gH = torch.empty(plan.n_edges, gMv.shape[1], dtype=torch.float32, device=gMv.device)
-    with torch.cuda.device(gMv.device):
+    with _OnDevice(gMv.device):
         _lib.check(_lib.load().dmpnn_aggregate_bwd(plan.buf.data_ptr(), plan.n_atoms, plan.n_edges, gMv.shape[1],
                                                    gMv.data_ptr(), gMv.stride(0), gH.data_ptr(), gH.stride(0),
                                                    _stream_ptr(gMv.device)), "dmpnn_aggregate_bwd")
@@ -490,7 +523,7 @@ def linear_wgrad(gZ: Tensor, A1: Tensor, A2: Optional[Tensor] = None, gather1: O
     gb = torch.empty(N, dtype=torch.float32, device=gZ.device) if want_bias else None
     nbytes = lib.dmpnn_linear_wgrad_ws_bytes(M, N, K1 + K2, 1 if want_bias else 0)
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=gZ.device)
-    with torch.cuda.device(gZ.device):
+    with _OnDevice(gZ.device):
         _lib.check(lib.dmpnn_linear_wgrad(C.byref(g), gZ.data_ptr(), gZ.stride(0), gW.data_ptr(), gW.stride(0),
                                           _ptr(gb), ws.data_ptr(), nbytes, _stream_ptr(gZ.device)), "dmpnn_linear_wgrad")
     return gW, gb

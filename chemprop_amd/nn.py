@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from . import engine
+from . import _lib, engine
 from .autograd import mp_forward
 
 DEFAULT_ATOM_FDIM, DEFAULT_BOND_FDIM = 72, 14  # chemprop/conf.py:8 (v2 featurizers)
@@ -140,7 +140,7 @@ def _light_plan_ok(mp) -> bool:
         return False
     if mp.undirected or (mp.training and mp.dropout.p > 0) or classify_activation(mp.tau)[0] == "custom":
         return False
-    if os.environ.get("DMPNN_GENERAL", "0") == "1" or getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N:
+    if _lib.opt("DMPNN_GENERAL", "0") == "1" or getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N:
         return False  # the first batches may still be routed to the general kernels by the validation
     d_h, d_in = mp.W_h.weight.shape[0], mp.W_i.weight.shape[1]
     d_v = mp.W_o.weight.shape[1] - d_h
@@ -151,11 +151,11 @@ def _tile_plan_ok(mp, n_atoms: int, n_edges: int, n_mols: int) -> bool:
     """After the validated first batches, an inference forward that is going to take the whole-forward tile kernel
     on the f16 pipe needs only the piece-tile tables (``dmpnn_prepare_tiles``): the kernel reads the batch's own
     index arrays and checks every tile itself (a tile that is not closed returns NaN for its atoms)."""
-    if os.environ.get("DMPNN_MEGA", "1") == "0" or os.environ.get("DMPNN_MFMA", "split16") == "f32":
+    if _lib.opt("DMPNN_MEGA", "1") == "0" or _lib.opt("DMPNN_MFMA", "split16") == "f32":
         return False
-    if os.environ.get("DMPNN_TILE_PLAN", "1") == "0" or getattr(mp, "_dmpnn_no_mega", False):
+    if _lib.opt("DMPNN_TILE_PLAN", "1") == "0" or getattr(mp, "_dmpnn_no_mega", False):
         return False
-    if os.environ.get("DMPNN_VALIDATE", "first") == "always":
+    if _lib.opt("DMPNN_VALIDATE", "first") == "always":
         return False  # (the per-batch verdict is read from a full plan)
     return n_mols > 0 and n_edges <= 30 * n_mols and engine.small_plan_fits(n_atoms, n_edges)
 
@@ -172,7 +172,7 @@ def _route(mp, plan, n_mols: int = 0) -> int:
     every batch (a sync per forward), ``never`` trusts.  A batch found in violation runs the next more
     general route; one oversize molecule switches the tile kernel off for the module (datasets of
     larger molecules use the per-step fused route)."""
-    mode = os.environ.get("DMPNN_VALIDATE", "first")
+    mode = _lib.opt("DMPNN_VALIDATE", "first")
     seen = getattr(mp, "_dmpnn_batches_checked", 0)
     no_mega = getattr(mp, "_dmpnn_no_mega", False)
     if n_mols > 0 and plan.n_edges > 30 * n_mols:  # average molecule already near the tile: do not try
