@@ -674,8 +674,15 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
 // range has both atoms and its reverse inside) is checked by the tile kernel for every tile it runs.
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int64_t* __restrict__ edge_index,
                                                                       const int64_t* __restrict__ batch,
-                                                                      int* __restrict__ plan, PlanLayout L, int nV, int nE) {
+                                                                      int* __restrict__ plan, PlanLayout L, int nV, int nE,
+                                                                      long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) int lds_i[];
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (dbg && threadIdx.x == 0 && n_stamp < 16) dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();
     int* fa = lds_i;                 // [nV + 2] first atom of molecule m
     int* fe = fa + nV + 2;           // [nV + 2] first edge of molecule m
     int* Y = fe + nV + 2;            // [nV + 2] next-tile pointers
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
     __shared__ int bad_s, flags_s, nm_s;
     const int tid = threadIdx.x;
     if (tid == 0) { bad_s = 0; flags_s = 0; nm_s = 0; }
-    // phase 1: batch -> LDS; dst -> batch[dst] -> LDS (all loads of a thread in flight together)
+    // phase 1: batch and dst in one batch of loads; batch -> LDS; then molecule of an edge = LDS lookup of its dst
     int64_t d64[kSmallEPT], b64[kSmallItems];
     int bad = 0;
 #pragma unroll
@@ -692,18 +699,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
         const int v = tid + kSmallThreads * j;
         b64[j] = batch[v < nV ? v : 0];
     }
+#pragma unroll
+    for (int j = 0; j < kSmallEPT; ++j) d64[j] = 0;
     if (nE > 0) {
 #pragma unroll
         for (int j = 0; j < kSmallEPT; ++j) {
             const int e = tid + kSmallThreads * j;
             d64[j] = edge_index[(int64_t)nE + (e < nE ? e : 0)];
-        }
-#pragma unroll
-        for (int j = 0; j < kSmallEPT; ++j) {
-            const int e = tid + kSmallThreads * j;
-            const bool ok = d64[j] >= 0 && d64[j] < nV;
-            if (e < nE && !ok) bad |= PLAN_RANGE_ERROR;
-            d64[j] = batch[ok ? d64[j] : 0];
         }
     }
 #pragma unroll
@@ -714,14 +716,18 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
             bm[v] = (u16)b64[j];
         }
     }
-    if (nE > 0) {
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kSmallEPT; ++j) {
-            const int e = tid + kSmallThreads * j;
-            if (e < nE) mb[e] = (u16)((d64[j] < 0 || d64[j] >= nV) ? 0 : d64[j]);
+    for (int j = 0; j < kSmallEPT; ++j) {
+        const int e = tid + kSmallThreads * j;
+        if (e < nE) {
+            const bool ok = d64[j] >= 0 && d64[j] < nV;
+            if (!ok) bad |= PLAN_RANGE_ERROR;
+            mb[e] = bm[ok ? (int)d64[j] : 0];
         }
     }
     __syncthreads();
+    stamp();  // 1: loaded, narrowed
     // phase 2: both must be non-decreasing (else the ranges below mean nothing: no tiles)
     for (int v = tid + 1; v < nV; v += kSmallThreads)
         if (bm[v] < bm[v - 1]) bad |= PLAN_NO_PIECE_TILES;
@@ -730,23 +736,29 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
     if (bad) atomicOr(&flags_s, bad);
     if (tid == 0) nm_s = nV > 0 ? (int)bm[nV - 1] + 1 : 0;
     __syncthreads();
+    stamp();  // 2: order checked
     const int nm = nm_s;
     // phase 3: first atom / first edge of every molecule (and the end markers at m = nm)
-    for (int m = tid; m <= nm; m += kSmallThreads) {
-        int lo = 0, hi = nV;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)bm[mid] < m) lo = mid + 1; else hi = mid; }
+    for (int m = tid; m <= nm; m += kSmallThreads) {  // both searches in one loop: their LDS reads overlap
+        int lo = 0, hi = nV, lo2 = 0, hi2 = nE;
+        while (lo < hi || lo2 < hi2) {
+            const int mid = (lo + hi) >> 1, mid2 = (lo2 + hi2) >> 1;
+            const int x = lo < hi ? (int)bm[mid] : 0, y = lo2 < hi2 ? (int)mb[mid2] : 0;
+            if (lo < hi) { if (x < m) lo = mid + 1; else hi = mid; }
+            if (lo2 < hi2) { if (y < m) lo2 = mid2 + 1; else hi2 = mid2; }
+        }
         fa[m] = lo;
-        lo = 0; hi = nE;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)mb[mid] < m) lo = mid + 1; else hi = mid; }
-        fe[m] = lo;
+        fe[m] = lo2;
     }
     if ((flags_s & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR)) && tid == 0) bad_s = 1;
     __syncthreads();
+    stamp();  // 3: molecule ranges
     // phase 4: greedy packing + the tables; the row tiles of the per-step fused route are emptied
     TileGeom g;
     g.b0 = kFusedBM; g.n_tiles = 0;
     auto rest = [&](int i0, int n_thr) { write_tiles(plan, L, fe, nV, nE, g, i0, n_thr); };
-    const int n_mtiles = pack_pieces(plan, L, fa, nm, [&](int p) { return fe[p]; }, Y, &bad_s, nV, nE, tid, rest, nullptr, 0);
+    const int n_mtiles = pack_pieces(plan, L, fa, nm, [&](int p) { return fe[p]; }, Y, &bad_s, nV, nE, tid, rest, dbg ? dbg + 16 : nullptr, 3);
+    stamp();  // 4: packed
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
         if (tid == DMPNN_HDR_FLAGS) v = (flags_s & PLAN_RANGE_ERROR) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
@@ -780,7 +792,7 @@ int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_prepare_tiles_batch, dim3(1), dim3(kSmallThreads), tiles_batch_lds_bytes(nV, nE), s, edge_index, batch, plan,
-                       L, nV, nE);
+                       L, nV, nE, g_debug_stamps ? g_debug_stamps + 32 : nullptr);
     DMPNN_CHECK_LAUNCH("k_prepare_tiles_batch");
     return DMPNN_OK;
 }

@@ -40,6 +40,8 @@ for i, n in enumerate(pn):
         print(f"{n:20s} +{(ps[i]-prev):8d} cycles   (t={(ps[i]-ps[0])})")
         prev = ps[i]
 
+if "tiles" in sys.argv:
+    print("--- (tile plan from the batch vector: entry, loaded, order checked, molecule ranges, packed;  piece stamps: next ptrs at [3], walk at [4])")
 print("--- piece tiles")
 qs = st[48:]
 prev = qs[0]
