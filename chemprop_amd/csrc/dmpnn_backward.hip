@@ -13,6 +13,7 @@
 //
 // Graph must be symmetric (every featurizer-produced graph is); on an asymmetric plan the message
 // backward writes NaN (loud) — gradients through arbitrary index arrays are not provided.
+#include <stdlib.h>
 #include <string.h>
 
 #include "dmpnn_common.hpp"
@@ -540,8 +541,10 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     if (xd > x) x = xd;
     L.slab_x = o; o += align_up(x, 4);
     // data gradients gM = gZ . W_h, gMv = gZO . W_o[:, d_v:] on the f16 pipe (exact operand split, dmpnn_rows16.hip)
-    // from the batch size where that kernel pays (the crossover of the forward's per-step route)
-    L.use16 = nE >= 20000 && h % 2 == 0 && f.ldh % 2 == 0;
+    // (about one tile per CU: the whole d_h-wide operand row in one group; large batches: 128-column groups, two
+    // workgroups per CU)
+    static const bool bwd16_all = [] { const char* e = getenv("DMPNN_BWD16"); return !(e && e[0] == '0'); }();  // 0: large batches only
+    L.use16 = nE > 0 && h % 2 == 0 && f.ldh % 2 == 0 && (bwd16_all || nE >= 20000);
     L.WhT16 = L.WoT16 = 0;
     if (L.use16) {
         const size_t w = align_up((linear16_wsplit_bytes(h, h) + 3) / 4, 64);

@@ -6,11 +6,16 @@
 
 namespace dmpnn {
 namespace rows16 {
-DMPNN_DEFINE_ROWS16(1)
-DMPNN_DEFINE_ROWS16(2)
-DMPNN_DEFINE_ROWS16(3)
-DMPNN_DEFINE_ROWS16(4)
-DMPNN_DEFINE_ROWS16(5)
+DMPNN_DEFINE_ROWS16(1, 4)
+DMPNN_DEFINE_ROWS16(2, 4)
+DMPNN_DEFINE_ROWS16(3, 4)
+DMPNN_DEFINE_ROWS16(4, 4)
+DMPNN_DEFINE_ROWS16(5, 4)
+DMPNN_DEFINE_ROWS16(1, 12)
+DMPNN_DEFINE_ROWS16(2, 12)
+DMPNN_DEFINE_ROWS16(3, 12)
+DMPNN_DEFINE_ROWS16(4, 12)
+DMPNN_DEFINE_ROWS16(5, 12)
 }  // namespace rows16
 
 static size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -69,12 +74,23 @@ int launch_linear16(const dmpnn_gemm_args& a, const mega16::SplitW& W, const int
     const int col_blocks = (int)((a.N + 319) / 320);
     const int WN = (int)((a.N + 64 * col_blocks - 1) / (64 * col_blocks));
     const int row_tiles = (int)((a.M + rows16::BM - 1) / rows16::BM);
+    // about one tile per CU: the whole (<= 384-column) operand row in one group, one workgroup per CU
+    const bool one_group = (int64_t)row_tiles * col_blocks <= 512;
+    if (one_group) {
+        switch (WN) {
+            case 1: return rows16::launch_rows16<1, 12>(g, row_tiles, col_blocks, s);
+            case 2: return rows16::launch_rows16<2, 12>(g, row_tiles, col_blocks, s);
+            case 3: return rows16::launch_rows16<3, 12>(g, row_tiles, col_blocks, s);
+            case 4: return rows16::launch_rows16<4, 12>(g, row_tiles, col_blocks, s);
+            default: return rows16::launch_rows16<5, 12>(g, row_tiles, col_blocks, s);
+        }
+    }
     switch (WN) {
-        case 1: return rows16::launch_rows16<1>(g, row_tiles, col_blocks, s);
-        case 2: return rows16::launch_rows16<2>(g, row_tiles, col_blocks, s);
-        case 3: return rows16::launch_rows16<3>(g, row_tiles, col_blocks, s);
-        case 4: return rows16::launch_rows16<4>(g, row_tiles, col_blocks, s);
-        default: return rows16::launch_rows16<5>(g, row_tiles, col_blocks, s);
+        case 1: return rows16::launch_rows16<1, 4>(g, row_tiles, col_blocks, s);
+        case 2: return rows16::launch_rows16<2, 4>(g, row_tiles, col_blocks, s);
+        case 3: return rows16::launch_rows16<3, 4>(g, row_tiles, col_blocks, s);
+        case 4: return rows16::launch_rows16<4, 4>(g, row_tiles, col_blocks, s);
+        default: return rows16::launch_rows16<5, 4>(g, row_tiles, col_blocks, s);
     }
 }
 

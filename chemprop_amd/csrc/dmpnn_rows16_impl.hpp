@@ -44,26 +44,29 @@ struct Rows16K {
     int vec_out;              // C / Zpre / Cadd rows are 16-byte aligned and N % 4 == 0: float4 epilogue
 };
 
-constexpr size_t kOperandTileBytes = (size_t)BM * (4 * 128 + 16);
-template <int WN>
+// GC: k-chunks per operand group.  4 (128 columns, 24 operand registers, two workgroups per CU) streams large batches;
+// 12 (384 columns: d_h = 300 in ONE group — one maximum, one barrier pair, one 10-chunk barrier-free contraction)
+// is the latency-optimal shape when there is about one tile per CU (the data gradients of a 512-molecule batch).
+template <int WN, int GC>
 constexpr size_t tile_bytes() {  // fp32 epilogue tile and the split operand tile share one region
-    return (size_t)BM * (64 * WN + 4) * 4 > kOperandTileBytes ? (size_t)BM * (64 * WN + 4) * 4 : kOperandTileBytes;
+    return (size_t)BM * (64 * WN + 4) * 4 > (size_t)BM * (GC * 128 + 16) ? (size_t)BM * (64 * WN + 4) * 4 : (size_t)BM * (GC * 128 + 16);
 }
-template <int WN>
+template <int WN, int GC>
 constexpr size_t lds_bytes() {
-    return tile_bytes<WN>() + 64;  // + scale words
+    return tile_bytes<WN, GC>() + 64;  // + scale words
 }
 
-template <int WN>
-__global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
+template <int WN, int GC>
+__global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g) {
     constexpr int BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
     constexpr int ITEMS = BM * QN / kThreads;  // 3 WN
-    constexpr int TSG = 4 * 128 + 16;          // bytes of one row of the split operand tile (4 chunks)
-    constexpr int J = 4 * RT;                  // operand rows per thread and group
+    constexpr int TSG = GC * 128 + 16;         // bytes of one row of the split operand tile (GC chunks)
+    constexpr int J = 4 * RT;                  // operand rows per thread
+    constexpr int NP = GC / 4;                 // 64-pair passes over a row of the group
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* T = reinterpret_cast<float*>(lds);                      // [BM][LDC] fp32 epilogue tile
     unsigned char* Ag = lds;                                       // [BM][TSG] split operand tile (overlays T)
-    unsigned* maxbits = reinterpret_cast<unsigned*>(lds + tile_bytes<WN>());  // [4] rotating tile maxima
+    unsigned* maxbits = reinterpret_cast<unsigned*>(lds + tile_bytes<WN, GC>());  // [4] rotating tile maxima
 
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int li = lane & 15, lg = lane >> 4;
@@ -101,14 +104,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
             ro2[j] = ok ? (unsigned)(wave + 4 * j) * (unsigned)g.lda2 * 4u : kOOB;
         }
     }
-    auto ga_load = [&](int grp, u32x2 (&v)[J]) {
-        const int k = grp * 128 + lane * 2;
-        const unsigned k1o = k < g.K1 ? (unsigned)k * 4u : kOOB;
-        const unsigned k2o = (k >= g.K1 && k < K) ? (unsigned)(k - g.K1) * 4u : kOOB;
+    auto ga_load = [&](int grp, u32x2 (&v)[NP][J]) {
 #pragma unroll
-        for (int j = 0; j < J; ++j)
-            v[j] = __builtin_amdgcn_raw_buffer_load_b64(rA1, gemm::join_off(ro1[j], k1o), 0, 0) |
-                   __builtin_amdgcn_raw_buffer_load_b64(rA2, gemm::join_off(ro2[j], k2o), 0, 0);
+        for (int pp = 0; pp < NP; ++pp) {
+            const int k = grp * (GC * 32) + (pp * 64 + lane) * 2;
+            const unsigned k1o = k < g.K1 ? (unsigned)k * 4u : kOOB;
+            const unsigned k2o = (k >= g.K1 && k < K) ? (unsigned)(k - g.K1) * 4u : kOOB;
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                v[pp][j] = __builtin_amdgcn_raw_buffer_load_b64(rA1, gemm::join_off(ro1[j], k1o), 0, 0) |
+                           __builtin_amdgcn_raw_buffer_load_b64(rA2, gemm::join_off(ro2[j], k2o), 0, 0);
+        }
     };
     auto wave_max = [&](float v) -> float {
         int u = (int)__float_as_uint(v);
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
             bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o == kOOB ? kOOB : o + 1024u, 0, 0));
         }
     };
-    // one group of n_chunks (<= 4) k-chunks, weight chunks wc0 ..: barrier-free MFMA loop on the split tile Ag.
+    // one group of n_chunks (<= GC) k-chunks, weight chunks wc0 ..: barrier-free MFMA loop on the split tile Ag.
     // One compact loop body (two chunks, ping-pong fragment registers): a workgroup runs one tile, so every
     // instruction is fetched cold — code size is latency.  Fragments of chunk c+1 (A, from LDS) and c+2 (weights,
     // from L2) are fetched under the MFMAs of chunk c; reads past the group are clamped / out of range (0).
@@ -205,15 +211,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
     };
 
     // ---- groups of 128 operand columns: registers -> maximum -> scale -> split tile -> MFMAs ----
-    const int n_groups = (g.W.nc + 3) / 4;
-    u32x2 v[J];
+    const int n_groups = (g.W.nc + GC - 1) / GC;
+    u32x2 v[NP][J];
     ga_load(0, v);
     float s_prev = 0.f;
 #pragma nounroll
     for (int grp = 0; grp < n_groups; ++grp) {
         float mx = 0.f;
 #pragma unroll
-        for (int j = 0; j < J; ++j) mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v[j].x)), fabsf(__uint_as_float(v[j].y))));
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int j = 0; j < J; ++j) mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v[pp][j].x)), fabsf(__uint_as_float(v[pp][j].y))));
         const float s = tile_scale(mx);  // (barrier: every wave is past its reads of the LDS tile)
         if (s_prev != 0.f && s_prev != s) {
             const float f = s / s_prev;
@@ -227,17 +235,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
         s_prev = s;
         launder();
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const float x = __uint_as_float(v[j].x) * s, y = __uint_as_float(v[j].y) * s;
-            const h2 hi = h2{(_Float16)x, (_Float16)y};
-            const h2 lo = h2{(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
-            unsigned char* p = Ag + (wave + 4 * j) * TSG + (lane >> 4) * 128 + (lane & 15) * 4;
-            *reinterpret_cast<h2*>(p) = hi;
-            *reinterpret_cast<h2*>(p + 64) = lo;
-        }
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float x = __uint_as_float(v[pp][j].x) * s, y = __uint_as_float(v[pp][j].y) * s;
+                const h2 hi = h2{(_Float16)x, (_Float16)y};
+                const h2 lo = h2{(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
+                unsigned char* p = Ag + (wave + 4 * j) * TSG + (pp * 4 + (lane >> 4)) * 128 + (lane & 15) * 4;
+                *reinterpret_cast<h2*>(p) = hi;
+                *reinterpret_cast<h2*>(p + 64) = lo;
+            }
         if (grp + 1 < n_groups) ga_load(grp + 1, v);  // the next group's rows are in flight under this group's MFMAs
-        const int ncg = g.W.nc - grp * 4 < 4 ? g.W.nc - grp * 4 : 4;
-        contract(ncg, grp * 4);
+        const int ncg = g.W.nc - grp * GC < GC ? g.W.nc - grp * GC : GC;
+        contract(ncg, grp * GC);
     }
 
     // ---- epilogue: split domain -> fp32, bias; row-major pass through the LDS tile ----
@@ -317,16 +327,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_rows16(Rows16K g) {
     }
 }
 
-template <int WN>
+template <int WN, int GC>
 int launch_rows16(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s);
 
-#define DMPNN_DEFINE_ROWS16(WN)                                                                            \
+#define DMPNN_DEFINE_ROWS16(WN, GC)                                                                        \
     template <>                                                                                            \
-    int launch_rows16<WN>(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s) {                \
-        constexpr size_t lds = lds_bytes<WN>();                                                            \
+    int launch_rows16<WN, GC>(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s) {            \
+        constexpr size_t lds = lds_bytes<WN, GC>();                                                        \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows16<WN>),               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows16<WN, GC>),           \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_rows16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
@@ -334,7 +344,7 @@ int launch_rows16(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s
             }                                                                                              \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_rows16<WN>), dim3((unsigned)row_tiles, (unsigned)col_blocks), dim3(kThreads), lds, s, g); \
+        hipLaunchKernelGGL((k_rows16<WN, GC>), dim3((unsigned)row_tiles, (unsigned)col_blocks), dim3(kThreads), lds, s, g); \
         DMPNN_CHECK_LAUNCH("k_rows16");                                                                    \
         return DMPNN_OK;                                                                                   \
     }
