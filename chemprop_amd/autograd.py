@@ -56,11 +56,12 @@ def mp_forward(mp, plan: engine.GraphPlan, V: Tensor, E: Tensor, V_d: Optional[T
 
             return FusedMP.apply(mp, plan, V, E, V_d if has_vd else None, act, slope, (slope_t, max_level),
                                  *[p[k] for k in ("W_i", "b_i", "W_h", "b_h", "W_o", "b_o", "W_d", "b_d")])
-        out, _ = engine.forward(plan, V, E, p["W_i"], p["W_h"], p["W_o"], p["b_o"], p["b_i"], p["b_h"],
-                                p["W_d"] if has_vd else None, p["b_d"] if has_vd else None,
-                                V_d if has_vd else None, depth=mp.depth, act=act, slope=slope,
-                                slope_t=slope_t, undirected=mp.undirected, keep=False, max_level=max_level,
-                                wcache=mp.__dict__.setdefault("_dmpnn_wcache", {}))
+        out, st = engine.forward(plan, V, E, p["W_i"], p["W_h"], p["W_o"], p["b_o"], p["b_i"], p["b_h"],
+                                 p["W_d"] if has_vd else None, p["b_d"] if has_vd else None,
+                                 V_d if has_vd else None, depth=mp.depth, act=act, slope=slope,
+                                 slope_t=slope_t, undirected=mp.undirected, keep=False, max_level=max_level,
+                                 wcache=mp.__dict__.setdefault("_dmpnn_wcache", {}))
+        mp.__dict__["_dmpnn_last"] = st  # (nn.py builds the replay state of the steady inference path from it)
         return out
 
     # ---- rows route: kernels for every contraction / segment op, torch modules in between ----

@@ -32,6 +32,20 @@ def small_plan_fits(n_atoms: int, n_edges: int) -> bool:
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_plan_bytes_cache: dict = {}
+
+
+def plan_bytes(n_atoms: int, n_edges: int) -> int:
+    """``dmpnn_plan_bytes`` (memoised: a pure function of the two sizes)."""
+    k = (n_atoms, n_edges)
+    v = _plan_bytes_cache.get(k)
+    if v is None:
+        if len(_plan_bytes_cache) > 4096:
+            _plan_bytes_cache.clear()
+        v = _plan_bytes_cache[k] = int(_lib.load().dmpnn_plan_bytes(n_atoms, n_edges))
+    return v
+
+
 def _stream_ptr(device) -> int:
     """Raw handle of torch's current stream on ``device`` (the launch stream of every kernel of this call)."""
     if _raw_stream is not None:
@@ -92,7 +106,7 @@ class GraphPlan:
         ei = ei.contiguous()
         rev = rev_edge_index if rev_edge_index.dtype == torch.int64 else rev_edge_index.long()
         rev = rev.contiguous()
-        nbytes = lib.dmpnn_plan_bytes(n_atoms, n_edges)
+        nbytes = plan_bytes(n_atoms, n_edges)
         self.buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
         self.n_atoms, self.n_edges, self.device = int(n_atoms), n_edges, dev
         # light=True: only what a forward of the fused routes reads (inference); light="tiles": only the piece-tile

@@ -13,6 +13,7 @@ read like the reference's own.  Where chemprop itself is importable, use
 from __future__ import annotations
 
 import copy
+import ctypes as _ctypes
 import os
 from typing import Optional
 
@@ -104,10 +105,101 @@ class BondMessagePassing(nn.Module):
         return bond_message_passing_forward(self, bmg, V_d)
 
 
+_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_TILE_PLAN", "DMPNN_VALIDATE")
+
+
+class _Replay:
+    """What a steady inference forward of the tile kernel repeats verbatim: the argument block of the last such forward
+    (every pointer that does not belong to the batch), the objects those pointers came from, and the facts the route
+    decision was taken on.  A call that finds all of them unchanged only builds the tile plan, allocates ``out`` and
+    fills in the batch's pointers — the same two C calls, without the general routing code in between."""
+
+    __slots__ = ("args", "tensors", "versions", "tau", "training", "env", "dev", "d_v", "d_e", "d_h", "wsplit", "depth")
+
+
+def _param(mp, lin: str, name: str):
+    m = mp._modules.get(lin)
+    return None if m is None else m._parameters.get(name)
+
+
+def _make_replay(mp, plan, st) -> None:
+    """After a slow-path forward that took the tile kernel on a tile plan: remember how to repeat it."""
+    mp.__dict__.pop("_dmpnn_replay", None)
+    if st is None or st.route != "mega16" or not plan.tiles_only or mp.W_d is not None:
+        return
+    r = _Replay()
+    r.args = bytes(st.args)  # template copy of the argument block
+    r.tensors = tuple(_param(mp, l, n) for l, n in (("W_i", "weight"), ("W_h", "weight"), ("W_o", "weight"), ("W_i", "bias"),
+                                                      ("W_h", "bias"), ("W_o", "bias")))
+    r.versions = tuple(t._version for t in r.tensors[:3])
+    r.tau, r.training, r.depth = mp._modules.get("tau"), mp.training, mp.depth
+    r.env = tuple(_lib.opt(k, "") for k in _ENV_KEYS)
+    r.dev = plan.device
+    r.d_v, r.d_e, r.d_h = st.dims["d_v"], st.dims["d_e"], st.dims["d_h"]
+    r.wsplit = st.refs[-1]
+    if r.wsplit is None or any(t is not None and (t.dtype != torch.float32 or not t.is_contiguous()) for t in r.tensors):
+        return
+    mp.__dict__["_dmpnn_replay"] = r
+
+
+def _replay_forward(mp, r: "_Replay", bmg):
+    """The steady inference path (see :class:`_Replay`); ``None`` when anything it rests on has changed."""
+    mods = mp._modules
+    if (mp.training != r.training or mods.get("tau") is not r.tau or mp.depth != r.depth or mp.undirected
+            or type(mods.get("graph_transform")) is not nn.Identity or mods.get("W_d") is not None):
+        return None
+    ts = r.tensors
+    if (_param(mp, "W_i", "weight") is not ts[0] or _param(mp, "W_h", "weight") is not ts[1] or _param(mp, "W_o", "weight") is not ts[2]
+            or _param(mp, "W_i", "bias") is not ts[3] or _param(mp, "W_h", "bias") is not ts[4] or _param(mp, "W_o", "bias") is not ts[5]):
+        return None
+    if ts[0]._version != r.versions[0] or ts[1]._version != r.versions[1] or ts[2]._version != r.versions[2]:
+        return None
+    if tuple(_lib.opt(k, "") for k in _ENV_KEYS) != r.env:
+        return None
+    V, E, ei, rev, batch = bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, getattr(bmg, "batch", None)
+    dev = r.dev
+    if (V.device != dev or V.dtype != torch.float32 or E.dtype != torch.float32 or not V.is_contiguous() or not E.is_contiguous()
+            or V.dim() != 2 or E.dim() != 2 or V.shape[1] != r.d_v or E.shape[1] != r.d_e or ei.dtype != torch.int64
+            or rev.dtype != torch.int64 or not ei.is_contiguous() or not rev.is_contiguous() or ei.device != dev
+            or batch is None or batch.dtype != torch.int64 or not batch.is_contiguous() or batch.device != dev):
+        return None
+    nV, nE = int(V.shape[0]), int(E.shape[0])
+    n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    if (n_mols <= 0 or nE > 30 * n_mols or nE == 0 or not engine.small_plan_fits(nV, nE) or batch.numel() != nV
+            or ei.shape[1] != nE or rev.numel() != nE or getattr(mp, "_dmpnn_no_mega", False)):
+        return None
+    lib = _lib.load()
+    nbytes = engine.plan_bytes(nV, nE)
+    buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    out = torch.empty(nV, r.d_h, dtype=torch.float32, device=dev)
+    a = _lib.FwdArgs.from_buffer_copy(r.args)
+    pb = buf.data_ptr()
+    a.plan, a.n_atoms, a.n_edges = pb, nV, nE
+    a.V, a.ldv, a.E, a.lde = V.data_ptr(), r.d_v, E.data_ptr(), r.d_e
+    a.out, a.ldout = out.data_ptr(), r.d_h
+    a.Mv = a.Hv = pb
+    a.edge_index, a.rev_edge_index = ei.data_ptr(), rev.data_ptr()
+    a.flags |= _lib.F_WSPLIT_READY
+    stream = engine._stream_ptr(dev)
+    with engine._OnDevice(dev):
+        _lib.check(lib.dmpnn_prepare_tiles(a.edge_index, a.rev_edge_index, batch.data_ptr(), nV, nE, pb, nbytes, stream), "dmpnn_prepare_tiles")
+        _lib.check(lib.dmpnn_forward(_ctypes.byref(a), stream), "dmpnn_forward")
+    from .agg import note_batch
+
+    note_batch(batch, n_mols)
+    return out
+
+
 def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tensor:
     """``_MessagePassingBase.forward`` (base.py:196-212) for any module with the reference's
     attributes (``W_i, W_h, W_o, W_d, depth, undirected, dropout, tau, graph_transform,
     V_d_transform``); shared by :class:`BondMessagePassing` and the chemprop subclass."""
+    if V_d is None and not torch.is_grad_enabled():
+        r = mp.__dict__.get("_dmpnn_replay")
+        if r is not None:
+            out = _replay_forward(mp, r, bmg)
+            if out is not None:
+                return out
     bmg = mp.graph_transform(bmg)  # Identity, or eval-only scaling on a shallow copy (transforms.py:65-74)
     engine._require_device(bmg.V, "bmg.V")
     if mp.W_i.weight.device != bmg.V.device:
@@ -127,7 +219,11 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         from .agg import note_batch
 
         note_batch(bmg.batch, n_mols)  # the aggregation that follows (model.py:131) skips its host read of batch.max()
-    return mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols))
+    mp.__dict__.pop("_dmpnn_last", None)
+    out = mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols))
+    if light == "tiles" and V_d is None and not torch.is_grad_enabled() and _lib.opt("DMPNN_REPLAY", "1") != "0":
+        _make_replay(mp, plan, mp.__dict__.pop("_dmpnn_last", None))
+    return out
 
 
 _VALIDATE_FIRST_N = 2
