@@ -513,6 +513,8 @@ struct BwdLayout {
     size_t gZa, gZb, gH0, gZO, gMv, gHO, WhT, WoT, WdT, slab_h, slab_x, total;
     size_t WhT16, WoT16;  // pre-split transposed weights of the data-gradient contractions on the f16 pipe (large batches)
     bool use16;
+    size_t mega_w, gZs;   // backward tile kernel: its two pre-split matrices; gZ^(t) slots beyond the two ping-pong buffers
+    bool mega;
     WgradPlan p_h, p_i, p_o, p_d;
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
@@ -550,6 +552,17 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
         const size_t w = align_up((linear16_wsplit_bytes(h, h) + 3) / 4, 64);
         L.WhT16 = o; o += w;
         L.WoT16 = o; o += w;
+    }
+    // The forward ran as the whole-forward tile kernel on the f16 pipe and kept its tensors: the data-gradient chain
+    // runs as ONE tile kernel too (dmpnn_mega16_bwd.hip).  It stores every gZ^(t): depth - 1 edge buffers (the two
+    // ping-pong buffers, which are adjacent, serve depth <= 3).
+    static const bool bwd_mega = [] { const char* e = getenv("DMPNN_BWD_MEGA"); return !(e && e[0] == '0'); }();
+    L.mega = bwd_mega && (f.flags & DMPNN_F_MEGA) && (f.flags & DMPNN_F_SPLIT16) && (f.flags & DMPNN_F_KEEP) && nE > 0 &&
+             f.ldh % 4 == 0 && f.act != DMPNN_ACT_PRELU;
+    L.mega_w = L.gZs = 0;
+    if (L.mega) {
+        L.mega_w = o; o += align_up((mega16_bwd_wsplit_bytes(h) + 3) / 4, 64);
+        if (f.depth - 1 > 2) { L.gZs = o; o += (size_t)(f.depth - 1) * edge; }
     }
     L.total = o;
     return L;
@@ -691,6 +704,46 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         g.W = WdT; g.ldw = h + dvd; g.C = gHO; g.ldc = ldh; g.act = DMPNN_ACT_NONE;
         DMPNN_TRY(launch_linear(g, s));
         gHO_p = gHO; ld_gHO = ldh;
+    }
+    if (L.mega && (b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO)) {
+        // ---- the whole data-gradient chain in one launch, then the four weight gradients ----
+        DMPNN_CHECK_ARG(f.H0 && (T == 1 || f.Hs), "backward: the tile-kernel forward did not keep H0 / H^(t)");
+        float* gZs = (T - 1 > 2) ? ws + L.gZs : gZa;  // slot t-1 = gZ^(t)
+        DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, s));
+        if (b->gW_o || b->gb_o) {
+            WgradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.M = nV; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)h; a.ones = 1;
+            a.gZ = gZO; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.A2 = f.Mv; a.lda2 = ldh;
+            DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, L.p_o.splits, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s, pflags, pmask));
+        }
+        if (b->gW_h || b->gb_h) {
+            if (T >= 2) {
+                int n_slabs = 0;
+                for (int t = 1; t <= T - 1; ++t) {
+                    WgradArgs a;
+                    memset(&a, 0, sizeof(a));
+                    a.M = nE; a.N = (int)h; a.K1 = (int)h; a.K2 = 0; a.ones = f.b_h ? 1 : 0;
+                    a.gZ = gZs + (int64_t)(t - 1) * slot; a.ldz = ldh; a.A1 = f.Ms + (int64_t)(t - 1) * slot; a.lda1 = ldh;
+                    DMPNN_TRY(launch_wgrad(a, L.p_h, slab_h + (int64_t)n_slabs * L.p_h.slab_stride, s));
+                    n_slabs += L.p_h.splits;
+                }
+                DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_h, n_slabs, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s, pflags, pmask));
+            } else {
+                zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h);
+            }
+        }
+        if (b->gW_i || b->gb_i) {
+            WgradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.M = nE; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)de; a.ones = f.b_i ? 1 : 0;
+            a.gZ = gH0; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.gather1 = pv.src; a.A2 = f.E; a.lda2 = f.lde;
+            a.gather2 = e_gather;
+            DMPNN_TRY(launch_wgrad(a, L.p_i, slab_x, s));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, L.p_i.splits, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s, pflags, pmask));
+        }
+        return DMPNN_OK;
     }
     {
         const bool vec = h % 4 == 0 && ld_gHO % 4 == 0 && ldHO % 4 == 0 && ldh % 4 == 0 && aligned16(gHO_p) && aligned16(HO) && aligned16(gZO);

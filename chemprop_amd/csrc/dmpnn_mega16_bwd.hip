@@ -1,0 +1,58 @@
+// Instantiations + host launcher of the backward tile kernel (dmpnn_mega16_bwd_impl.hpp).
+#include <string.h>
+
+#include "dmpnn_mega16_bwd_impl.hpp"
+
+namespace dmpnn {
+namespace mega16 {
+DMPNN_DEFINE_MEGA16_BWD(1)
+DMPNN_DEFINE_MEGA16_BWD(2)
+DMPNN_DEFINE_MEGA16_BWD(5)
+}  // namespace mega16
+
+static size_t al256b(size_t x) { return (x + 255) & ~size_t(255); }
+
+// bytes of the two pre-split transposed [h, h] matrices
+size_t mega16_bwd_wsplit_bytes(int64_t h) {
+    const size_t NT = (size_t)(h + 15) / 16, nc = (size_t)(h + 31) / 32;
+    return 2 * (al256b(NT * nc * 2048) + al256b((size_t)h * 4));
+}
+
+int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,
+                           float* gZs, float* gH0, void* wsplit, hipStream_t s) {
+    const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dv = f.d_v;
+    const size_t NT = (size_t)(h + 15) / 16, nc = (size_t)(h + 31) / 32;
+    unsigned char* ws = static_cast<unsigned char*>(wsplit);
+    const size_t one = al256b(NT * nc * 2048) + al256b((size_t)h * 4);
+    float* inv_o = reinterpret_cast<float*>(ws + al256b(NT * nc * 2048));
+    float* inv_h = reinterpret_cast<float*>(ws + one + al256b(NT * nc * 2048));
+    mega16::SplitArgs sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.N = (int)h; sp.n_jobs = 2;
+    // W'[n][k] = W_o[k][d_v + n]  and  W'[n][k] = W_h[k][n]: the matrices are read transposed
+    sp.job[0] = mega16::SplitJob{f.W_o + dv, (int)(dv + h), 0, (int)h, 0, (int)h, ws, (int)nc, inv_o, 1};
+    sp.job[1] = mega16::SplitJob{f.W_h, (int)h, 0, (int)h, 0, (int)h, ws + one, (int)nc, inv_h, 1};
+    const unsigned waves = 2u * (unsigned)(((h + 15) / 16) * 16);
+    hipLaunchKernelGGL(mega16::k_split_weights, dim3((waves + 3) / 4), dim3(256), 0, s, sp);
+    DMPNN_CHECK_LAUNCH("k_split_weights");
+
+    const PlanLayout L = plan_layout(nV, nE);
+    const int* plan_i = static_cast<const int*>(f.plan);
+    mega16::Mega16BwdK g;
+    memset(&g, 0, sizeof(g));
+    g.mtile_row = plan_i + L.mtile_row; g.mtile_atom = plan_i + L.mtile_atom; g.row_ptr = plan_i + L.row_ptr; g.revp = plan_i + L.revp;
+    g.flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoMega;
+    g.nV = (int)nV; g.nE = (int)nE; g.h = (int)h; g.depth = f.depth;
+    g.act = f.act; g.slope = f.act_slope; g.slope_ptr = f.act_slope_ptr;
+    g.gHO = gHO; g.ldg = (int)ldg; g.HO = HO; g.ldho = (int)ldho;
+    g.H0 = f.H0; g.Hs = f.Hs; g.ldh = (int)f.ldh; g.slot = (long long)nE * f.ldh;
+    g.gZO = gZO; g.gZs = gZs; g.gH0 = gH0;
+    g.WoMT = mega16::SplitW{ws, inv_o, (int)nc};
+    g.WhT = mega16::SplitW{ws + one, inv_h, (int)nc};
+    const int n_tiles = (int)L.max_mtiles;
+    if (h <= 64) return mega16::launch_mega16_bwd<1>(g, n_tiles, s);
+    if (h <= 128) return mega16::launch_mega16_bwd<2>(g, n_tiles, s);
+    return mega16::launch_mega16_bwd<5>(g, n_tiles, s);
+}
+
+}  // namespace dmpnn

@@ -1,0 +1,434 @@
+// The data-gradient chain of BondMessagePassing's backward for one tile of whole molecules in ONE launch — the mirror
+// of k_mpnn_tile16 (dmpnn_mega16_impl.hpp), same tiles, same arithmetic (f16 pipe, exact 3-term operand split):
+//
+//   gZO   = gHO * tau'(HO)                                    finalize (base.py:180-194), atoms            -> stored
+//   gMv   = gZO . W_o[:, d_v:]                                contraction with the transposed pre-split
+//   gH    = gMv[dst(r)]                                       aggregation backward (base.py:208-211): incidence MFMA
+//   for t = T-1 .. 1:
+//       gZt = gH * tau'(H^(t));  gH0 += gZt                   update backward (base.py:135-141)             -> gZt stored
+//       gM  = gZt . W_h                                       contraction
+//       gH  = C^T gM   (gH[r'] = sum_{r: src r = dst r'} gM[r] - gM[rev r'])   message backward (mixins.py:11-18)
+//   gH0  += gH * tau'(tau(H0))                                                                              -> stored
+//
+// What is left for separate launches are the four weight gradients (reductions over ALL edges): gZO with [V || Mv],
+// every gZt with M^(t-1), gH0 with [V[src] || E].  Replaces act_bwd + gMv contraction + gather + (depth-1) x (gM
+// contraction + message backward): nine launches of 4..30 us at 512 molecules.
+#pragma once
+
+#include <type_traits>
+
+#include "dmpnn_mega16_impl.hpp"
+
+namespace dmpnn {
+namespace mega16 {
+
+struct Mega16BwdK {
+    const int* mtile_row; const int* mtile_atom; const int* row_ptr; const int* revp;
+    const int* flags; int poison_mask;
+    int nV, nE, h, depth;
+    int act; float slope; const float* slope_ptr;
+    const float* gHO; int ldg;           // [V, ldg]  gradient w.r.t. the finalize output
+    const float* HO; int ldho;           // [V, ldho] finalize output (tau applied)
+    const float* H0; const float* Hs; int ldh; long long slot;  // kept by the forward: H0 (pre-activation), Hs[t-1] = H^(t)
+    float* gZO;                          // [V, ldh]
+    float* gZs;                          // [(depth-1)][E, ldh]: slot t-1 = gZ^(t)
+    float* gH0;                          // [E, ldh]
+    SplitW WoMT, WhT;                    // pre-split W_o[:, d_v:]^T and W_h^T  ([h, h] each)
+};
+
+template <int WN>
+constexpr size_t bwd_lds_bytes() {
+    return (size_t)kMegaBM * (64 * WN * 4 + 16) + (size_t)(3 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
+}
+
+template <int WN>
+__global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
+    constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, QN = BN / 4;
+    constexpr int TS = BN * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* T16 = lds;                                          // [BM][TS] split A operand
+    int* revl = reinterpret_cast<int*>(lds + BM * TS);                 // [BM]
+    int* aor = revl + BM;                                              // [BM] destination atom of a row
+    int* rp = aor + BM;                                                // [BA + 1]
+    int* asrc = rp + BA + 1;                                           // [BM] source atom of a row
+    unsigned* maxbits = reinterpret_cast<unsigned*>(asrc + BM);        // [0..3] rotating tile maxima
+    h8* cfrag = reinterpret_cast<h8*>(lds + BM * TS + (((3 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);  // [9][64]
+
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int li = lane & 15, lg = lane >> 4;
+    auto launder = [&]() {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
+    };
+    const int t = blockIdx.x;
+    const int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
+    const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
+    const int nrows = re - rs, na = vb - va;
+    const int N = g.h, qn = N >> 2;
+    const int T_steps = g.depth;
+    const float nanv = __int_as_float(0x7fc00000);
+    if ((g.flags[0] & g.poison_mask) != 0) {  // a graph this route cannot represent: every output NaN
+        const long long tot_e = (long long)g.nE * N, tot_v = (long long)g.nV * N;
+        for (long long i = (long long)blockIdx.x * kThreads + tid; i < tot_e; i += (long long)gridDim.x * kThreads) {
+            g.gH0[(i / N) * g.ldh + (i % N)] = nanv;
+            for (int s = 0; s < T_steps - 1; ++s) g.gZs[(long long)s * g.slot + (i / N) * g.ldh + (i % N)] = nanv;
+        }
+        for (long long i = (long long)blockIdx.x * kThreads + tid; i < tot_v; i += (long long)gridDim.x * kThreads)
+            g.gZO[(i / N) * g.ldh + (i % N)] = nanv;
+        return;
+    }
+    if (na <= 0 || nrows < 0 || nrows > BM || na > BA) return;
+    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
+    auto dact = [&](float gval, float y, bool preact) -> float {  // g * tau'(.) from the output (or the pre-activation)
+        if (g.act == DMPNN_ACT_NONE) return gval;
+        if (g.act == DMPNN_ACT_RELU) return y > 0.f ? gval : 0.f;
+        if (preact) y = apply_act(y, g.act, slope);
+        return gval * act_grad_from_out(y, g.act, slope);
+    };
+
+    // ---- metadata, incidence fragments ----
+    if (tid < BM) revl[tid] = tid < nrows ? g.revp[rs + tid] - rs : 0;
+    if (tid <= BA) rp[tid] = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
+    if (tid < 8) maxbits[tid] = 0u;
+    __syncthreads();
+    if (tid < na)
+        for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
+    __syncthreads();
+    if (tid < BM) asrc[tid] = tid < nrows ? aor[revl[tid]] : -1;  // src r = dst rev r (symmetric graph: checked by the plan)
+    __syncthreads();
+    // k order of the incidence MFMAs = the order C/D fragments hold rows (see dmpnn_mega16_impl.hpp):
+    //   k-step 0, lane group lg, slot s -> row lg*4+s (s<4) | 16+lg*4+(s-4);  k-step 1 -> 32+lg*4+s (s<4) | none.
+    // fragments 0..2 (jt): gather,  B[k = atom][j = row r'] = [dst r' == atom]
+    // fragments 3..8 (jt, ks): message backward,  B[k = row r][j = row r'] = [src r == dst r'] - [r == rev r']
+    for (int f = wave; f < 9; f += 4) {
+        const bool gat = f < 3;
+        const int jt = gat ? f : (f - 3) >> 1, ks = gat ? 0 : (f - 3) & 1;
+        const int j = jt * 16 + li;  // row r'
+        const int a_t = j < nrows ? aor[j] : -2, rv = j < nrows ? revl[j] : -2;
+        h8 v;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const int k = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
+            float cv = 0.f;
+            if (gat) cv = (k >= 0 && k < na && k == a_t) ? 1.f : 0.f;
+            else if (k >= 0 && k < nrows && j < nrows) cv = (asrc[k] == a_t ? 1.f : 0.f) - (k == rv ? 1.f : 0.f);
+            v[sl] = (_Float16)cv;
+        }
+        cfrag[f * 64 + lane] = v;
+    }
+    __syncthreads();
+
+    auto wave_max = [&](float v) -> float {
+        int u = (int)__float_as_uint(v);
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0xB1, 0xf, 0xf, true));
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xf, 0xf, true));
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x141, 0xf, 0xf, true));
+        u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x140, 0xf, 0xf, true));
+        const int m = max(max(__builtin_amdgcn_readlane(u, 0), __builtin_amdgcn_readlane(u, 16)),
+                          max(__builtin_amdgcn_readlane(u, 32), __builtin_amdgcn_readlane(u, 48)));
+        return __uint_as_float((unsigned)m);
+    };
+    int scale_phase = 0;
+    auto tile_scale = [&](float local_max) -> float {
+        const int slot = scale_phase & 3;
+        local_max = wave_max(local_max);
+        if (lane == 0) atomicMax(&maxbits[slot], __float_as_uint(local_max));
+        __syncthreads();
+        const float mx = __uint_as_float(maxbits[slot]);
+        if (tid == 0) maxbits[(slot + 2) & 3] = 0u;
+        ++scale_phase;
+        return scale_for(mx);
+    };
+
+    // ---- contraction acc[RT][WN] += T16 . W'^T (10 chunks for d_h = 300), weight fragments straight from L2 ----
+    auto contract = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], const SplitW& W) {
+        constexpr int RT = decltype(rt_c)::value;
+        const int n_chunks = (N + 31) / 32;
+        const gemm::rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048));
+        unsigned offB[WN];
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
+        auto load_b = [&](int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) {
+                bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0));
+                bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0));
+            }
+        };
+        auto read_a = [&](int c, h8 (&ah)[RT], h8 (&al)[RT]) {
+            const int cc = c < n_chunks ? c : n_chunks - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const unsigned char* p = T16 + (rt * 16 + li) * TS + cc * 128 + lg * 16;
+                ah[rt] = *reinterpret_cast<const h8*>(p);
+                al[rt] = *reinterpret_cast<const h8*>(p + 64);
+            }
+        };
+        h8 ah[2][RT], al[2][RT], bh[2][WN], bl[2][WN];
+        auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(c + 1, nh, nl);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(c + 2, yh, yl);  // (past the last chunk: out of range, 0)
+        };
+        load_b(0, bh[0], bl[0]);
+        load_b(1, bh[1], bl[1]);
+        __syncthreads();  // the split A tile is complete
+        launder();
+        read_a(0, ah[0], al[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma nounroll
+        for (int c = 0; c < n_chunks; c += 2) {
+            step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
+            if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
+        }
+    };
+    // split domain -> fp32 (no bias): acc / (sA sW[col])
+    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], float inv_sA, const float* inv_sW) {
+        constexpr int RT = decltype(rt_c)::value;
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const int col = wave * (16 * WN) + ct * 16 + li;
+            const float isw = inv_sW[col < N ? col : 0] * inv_sA;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= isw;
+        }
+    };
+    // incidence MFMA on C/D fragments X (RT row tiles) -> transposed fragments m[ct][jt] (row jt*16+li, 4 columns
+    // ct*16 + lg*4 ..): m = C . X.  f0: first incidence fragment; two k-steps when RT == 3, one when RT == 2.
+    auto incidence = [&](auto rt_c, const f32x4 (&X)[decltype(rt_c)::value][WN], int f0, f32x4 (&m)[WN][RT_E]) {
+        constexpr int RT = decltype(rt_c)::value;
+        launder();
+        float hm = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hm = fmaxf(hm, fabsf(X[rt][ct][r]));
+        const float sX = scale_for(wave_max(hm));
+        h8 cf[RT_E][2];
+#pragma unroll
+        for (int jt = 0; jt < RT_E; ++jt) {
+            cf[jt][0] = cfrag[(RT == 2 ? f0 + jt : f0 + 2 * jt) * 64 + lane];
+            cf[jt][1] = RT == 3 ? cfrag[(f0 + 2 * jt + 1) * 64 + lane] : cf[jt][0];
+        }
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            h8 ah0, al0, ah1, al1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x0 = X[0][ct][r] * sX, x1 = X[1][ct][r] * sX, x2 = (RT == 3 ? X[RT - 1][ct][r] : 0.f) * sX;
+                const _Float16 a0 = (_Float16)x0, a1 = (_Float16)x1, a2 = (_Float16)x2;
+                ah0[r] = a0; al0[r] = (_Float16)(x0 - (float)a0);
+                ah0[4 + r] = a1; al0[4 + r] = (_Float16)(x1 - (float)a1);
+                ah1[r] = a2; al1[r] = (_Float16)(x2 - (float)a2);
+                ah1[4 + r] = (_Float16)0.f; al1[4 + r] = (_Float16)0.f;
+            }
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, cf[jt][0], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, cf[jt][0], z, 0, 0, 0);
+                if (RT == 3) {
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, cf[jt][1], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, cf[jt][1], z, 0, 0, 0);
+                }
+                m[ct][jt] = z;
+            }
+        }
+        const float isX = 1.f / sX;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m[ct][jt][r] *= isX;
+    };
+    // m (edge gradient in transposed fragments) -> gz = m * tau'(Y rows); optional store; returns max |gz|
+    auto mask_rows = [&](f32x4 (&m)[WN][RT_E], const float* Y, bool preact, float* store) -> float {
+        launder();
+        float4 y[WN][RT_E];
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {  // all loads first (clamped addresses: no load under a branch)
+                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                const bool ok = row < nrows && col4 < N;
+                y[ct][jt] = *reinterpret_cast<const float4*>(Y + (long long)(rs + (ok ? row : 0)) * g.ldh + (ok ? col4 : 0));
+            }
+        float mx = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                const bool ok = row < nrows && col4 < N;
+                f32x4 v;
+                v[0] = ok ? dact(m[ct][jt][0], y[ct][jt].x, preact) : 0.f;
+                v[1] = ok ? dact(m[ct][jt][1], y[ct][jt].y, preact) : 0.f;
+                v[2] = ok ? dact(m[ct][jt][2], y[ct][jt].z, preact) : 0.f;
+                v[3] = ok ? dact(m[ct][jt][3], y[ct][jt].w, preact) : 0.f;
+                m[ct][jt] = v;
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                if (store && ok) *reinterpret_cast<float4*>(store + (long long)(rs + row) * g.ldh + col4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        return mx;
+    };
+    // transposed fragments -> split A tile of the next contraction (all 48 rows, zero where there is no row / column)
+    auto stage_rows = [&](const f32x4 (&m)[WN][RT_E], float s) {
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                const int row = jt * 16 + li;
+                h4 hi, lo;
+                split4(make_float4(m[ct][jt][0], m[ct][jt][1], m[ct][jt][2], m[ct][jt][3]), s, hi, lo);
+                unsigned char* p = T16 + row * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
+                *reinterpret_cast<h4*>(p) = hi;
+                *reinterpret_cast<h4*>(p + 64) = lo;
+            }
+        }
+    };
+    using RE = std::integral_constant<int, RT_E>;
+    using RA = std::integral_constant<int, RT_A>;
+
+    // ================= finalize backward: gZO = gHO * tau'(HO) on the tile's atoms, row-major =================
+    float sA;
+    {
+        constexpr int ITEMS_A = BA * QN / kThreads;
+        float4 z[ITEMS_A];
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS_A; ++j) {
+            const int it = tid + kThreads * j;
+            const int a = it / QN, q = it - a * QN;
+            const bool ok = a < na && q < qn;
+            const long long row = va + (ok ? a : 0);
+            const float4 gv = *reinterpret_cast<const float4*>(g.gHO + row * g.ldg + (ok ? 4 * q : 0));
+            const float4 yv = *reinterpret_cast<const float4*>(g.HO + row * g.ldho + (ok ? 4 * q : 0));
+            z[j] = ok ? make_float4(dact(gv.x, yv.x, false), dact(gv.y, yv.y, false), dact(gv.z, yv.z, false), dact(gv.w, yv.w, false))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(z[j].x), fabsf(z[j].y)), fmaxf(fabsf(z[j].z), fabsf(z[j].w))));
+            if (ok) *reinterpret_cast<float4*>(g.gZO + row * g.ldh + 4 * q) = z[j];
+        }
+        sA = tile_scale(mx);
+#pragma unroll
+        for (int j = 0; j < ITEMS_A; ++j) {
+            const int it = tid + kThreads * j;
+            const int a = it / QN, q = it - a * QN;
+            h4 hi, lo;
+            split4(z[j], sA, hi, lo);
+            unsigned char* p = T16 + a * TS + (q >> 3) * 128 + (q & 7) * 8;
+            *reinterpret_cast<h4*>(p) = hi;
+            *reinterpret_cast<h4*>(p + 64) = lo;
+        }
+    }
+    // gMv = gZO . W_o[:, d_v:]
+    f32x4 m[WN][RT_E];
+    {
+        f32x4 acc[RT_A][WN];
+#pragma unroll
+        for (int rt = 0; rt < RT_A; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        contract(RA{}, acc, g.WoMT);
+        unscale(RA{}, acc, 1.f / sA, g.WoMT.inv_scale);
+        incidence(RA{}, acc, 0, m);  // gH[r] = gMv[dst r]
+    }
+    f32x4 gh0[WN][RT_E];
+    if (T_steps == 1) {
+        mask_rows(m, g.H0, true, g.gH0);
+        return;
+    }
+    // gZ^(T-1) = gH * tau'(H^(T-1));  gH0 = gZ^(T-1)
+    {
+        const float mx = mask_rows(m, g.Hs + (long long)(T_steps - 2) * g.slot, false, g.gZs + (long long)(T_steps - 2) * g.slot);
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] = m[ct][jt];
+        sA = tile_scale(mx);  // (barrier: every wave is past its reads of T16)
+        stage_rows(m, sA);
+    }
+    for (int t = T_steps - 1; t >= 1; --t) {
+        f32x4 acc[RT_E][WN];
+#pragma unroll
+        for (int rt = 0; rt < RT_E; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        contract(RE{}, acc, g.WhT);              // gM = gZ^(t) . W_h
+        unscale(RE{}, acc, 1.f / sA, g.WhT.inv_scale);
+        incidence(RE{}, acc, 3, m);              // gH^(t-1) = C^T gM
+        if (t - 1 >= 1) {
+            const float mx = mask_rows(m, g.Hs + (long long)(t - 2) * g.slot, false, g.gZs + (long long)(t - 2) * g.slot);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] += m[ct][jt];
+            sA = tile_scale(mx);
+            stage_rows(m, sA);
+        } else {
+            mask_rows(m, g.H0, true, nullptr);   // through H^(0) = tau(H0)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] += m[ct][jt];
+        }
+    }
+    launder();
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+#pragma unroll
+        for (int jt = 0; jt < RT_E; ++jt) {
+            const int row = jt * 16 + li;
+            if (row < nrows && col4 < N)
+                *reinterpret_cast<float4*>(g.gH0 + (long long)(rs + row) * g.ldh + col4) =
+                    make_float4(gh0[ct][jt][0], gh0[ct][jt][1], gh0[ct][jt][2], gh0[ct][jt][3]);
+        }
+    }
+}
+
+template <int WN>
+int launch_mega16_bwd(const Mega16BwdK& g, int n_tiles, hipStream_t s);
+
+#define DMPNN_DEFINE_MEGA16_BWD(WN)                                                                         \
+    template <>                                                                                             \
+    int launch_mega16_bwd<WN>(const Mega16BwdK& g, int n_tiles, hipStream_t s) {                            \
+        constexpr size_t lds = bwd_lds_bytes<WN>();                                                         \
+        static bool attr_set = false;                                                                       \
+        if (!attr_set) {                                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16_bwd<WN>),       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            if (e != hipSuccess) {                                                                          \
+                set_error("hipFuncSetAttribute(k_mpnn_tile16_bwd<%d>): %s", WN, hipGetErrorString(e));      \
+                return DMPNN_EHIP;                                                                          \
+            }                                                                                               \
+            attr_set = true;                                                                                \
+        }                                                                                                   \
+        hipLaunchKernelGGL((k_mpnn_tile16_bwd<WN>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);    \
+        DMPNN_CHECK_LAUNCH("k_mpnn_tile16_bwd");                                                            \
+        return DMPNN_OK;                                                                                    \
+    }
+
+}  // namespace mega16
+}  // namespace dmpnn
