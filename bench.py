@@ -363,6 +363,52 @@ def main():
         except Exception as e:
             out["roofline_scatter_large"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
+        # ---- host hand-off (f3): PCIe-inclusive rates — never `value`.  (a) the reference's hand-off: five host tensors
+        # (int64 indices) moved one by one (collate.py:68-73); (b) one pinned buffer + dmpnn_collate.  Wall clock with a
+        # device synchronize on both sides; packing the buffer is the DataLoader worker's job and is not in (b). ----
+        if world == 1 and not train:
+            try:
+                from chemprop_amd.data import BatchMolGraph, PackedBatch
+
+                mgs = synth.random_molgraphs(args.mols, args.kind, seed=1000 + rank)
+                host_bmg = BatchMolGraph(mgs)
+                for k in ("V", "E", "edge_index", "rev_edge_index", "batch"):
+                    setattr(host_bmg, k, getattr(host_bmg, k).pin_memory())
+                packed = PackedBatch(mgs, pin=True)
+
+                def wall(fn, n=30):
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize(dev)
+                    return (time.perf_counter() - t0) / n * 1e6
+
+                def five():
+                    b = BatchMolGraph.from_tensors(*(getattr(host_bmg, k).to(dev, non_blocking=True)
+                                                     for k in ("V", "E", "edge_index", "rev_edge_index", "batch")), len(mgs))
+                    with torch.no_grad():
+                        return mp(b)
+
+                def one():
+                    with torch.no_grad():
+                        return mp(packed.to_device(dev))
+
+                t5, t1 = wall(five), wall(one)
+                t_c = wall(lambda: packed.to_device(dev))
+                out["host_handoff"] = {
+                    "five_tensors_us": round(t5, 1), "packed_us": round(t1, 1), "packed_copy_and_collate_us": round(t_c, 1),
+                    "wire_bytes": int(packed.buf.numel()),
+                    "five_tensor_bytes": int(sum(getattr(host_bmg, k).numel() * getattr(host_bmg, k).element_size()
+                                                 for k in ("V", "E", "edge_index", "rev_edge_index", "batch"))),
+                    "pcie_inclusive_M_edge_updates_per_s": round(updates / t1, 2),
+                    "pcie_inclusive_five_tensors_M_edge_updates_per_s": round(updates / t5, 2),
+                    "note": "pinned host buffers -> device -> forward, eager, wall clock; weights resident"}
+            except Exception as e:
+                out["host_handoff"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
         # ---- CPU baseline: the oracle (reference op sequence) on the host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
             from oracle import dmpnn_torch as ot

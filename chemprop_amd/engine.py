@@ -185,6 +185,11 @@ class GraphPlan:
         return self._view(2).long()
 
     @property
+    def inv32(self) -> Tensor:
+        """edge id -> CSR row (``X_rows[inv]`` brings a fused-forward edge tensor back to the caller's edge order)."""
+        return self._view(5)
+
+    @property
     def perm64(self) -> Tensor:
         """CSR row -> edge id (row i of a fused-forward edge tensor is edge perm[i])."""
         return self._view(4).long()

@@ -83,11 +83,49 @@ def hip_atom_message_passing_class():
     return _atom_cache
 
 
+_mab_cache = None
+
+
+def hip_mab_message_passing_classes():
+    """``{reference class: HIP subclass}`` for ``chemprop.nn.MABBondMessagePassing`` / ``MABAtomMessagePassing``
+    (f2, ``mol_atom_bond.py:284-388``): ``forward(bmg, V_d, E_d) -> (H_v, H_e)`` only is overridden."""
+    global _mab_cache
+    if _mab_cache is not None:
+        return _mab_cache
+    try:
+        from chemprop.nn import MABAtomMessagePassing, MABBondMessagePassing  # noqa: WPS433
+    except Exception as e:  # pragma: no cover
+        raise ImportError("chemprop_amd.integration needs an importable `chemprop`") from e
+    from .mab import mab_forward
+
+    out = {}
+    for Ref, atom in ((MABBondMessagePassing, False), (MABAtomMessagePassing, True)):
+        def make(Ref=Ref, atom=atom):
+            class Hip(Ref):  # type: ignore[misc, valid-type]
+                atom_messages = atom
+
+                def __init__(self, *args, **kwargs):
+                    super().__init__(*args, **kwargs)
+                    self.hparams["cls"] = Ref  # checkpoints stay loadable by stock chemprop
+
+                def forward(self, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = None):
+                    return mab_forward(self, bmg, V_d, E_d)
+
+            Hip.__name__ = Hip.__qualname__ = "Hip" + Ref.__name__
+            return Hip
+
+        out[Ref] = make()
+    _mab_cache = out
+    return out
+
+
 def __getattr__(name):
     if name == "HipBondMessagePassing":
         return hip_bond_message_passing_class()
     if name == "HipAtomMessagePassing":
         return hip_atom_message_passing_class()[1]
+    if name in ("HipMABBondMessagePassing", "HipMABAtomMessagePassing"):
+        return {c.__name__: c for c in hip_mab_message_passing_classes().values()}[name]
     raise AttributeError(name)
 
 
@@ -129,7 +167,7 @@ def hip_aggregation_classes():
 
 
 def accelerate(model, aggregation: bool = True):
-    """Swap the class of every ``BondMessagePassing`` / ``AtomMessagePassing`` block (and, unless ``aggregation=False``, of every
+    """Swap the class of every ``BondMessagePassing`` / ``AtomMessagePassing`` / ``MAB*MessagePassing`` block (and, unless ``aggregation=False``, of every
     Mean / Sum / Norm / Attentive aggregation) inside ``model`` (an ``MPNN``, a
     ``MulticomponentMessagePassing`` or the block itself) for the HIP subclass, in place.  No
     parameter is copied or re-created; optimizer state and checkpoints stay valid."""
@@ -137,6 +175,10 @@ def accelerate(model, aggregation: bool = True):
     Hip = hip_bond_message_passing_class()
     aggs = hip_aggregation_classes() if aggregation else {}
     RefAtom, HipAtom = hip_atom_message_passing_class()
+    try:
+        mabs = hip_mab_message_passing_classes()
+    except ImportError:  # (a chemprop older than the mol-atom-bond blocks)
+        mabs = {}
     n = 0
     for m in model.modules():
         if type(m) is Ref:
@@ -147,5 +189,8 @@ def accelerate(model, aggregation: bool = True):
             n += 1
         elif type(m) in aggs:
             m.__class__ = aggs[type(m)]
+            n += 1
+        elif type(m) in mabs:
+            m.__class__ = mabs[type(m)]
             n += 1
     return n

@@ -304,6 +304,17 @@ int dmpnn_molagg_bwd(const float* gout, int64_t ldg, const int64_t* batch, int64
 int dmpnn_gather_rows(const float* X, int64_t ldx, int64_t n_src, const int* idx, int64_t n_out, int64_t d,
                       float* out, int64_t ldo, void* stream);
 
+/* f3 (batching, data/collate.py:37-62): the three int64 index tensors of a BatchMolGraph from molecule-LOCAL int32
+ * indices and the running offsets (all device pointers; the loader packs them, with V and E, into one buffer and
+ * ships it with one copy — chemprop_amd/data.py PackedBatch):
+ *   edge_index[0][e] = src[e] + atom_off[m], edge_index[1][e] = dst[e] + atom_off[m], rev_edge_index[e] = rev[e] + edge_off[m]
+ *   for edge_off[m] <= e < edge_off[m+1];  batch[a] = m for atom_off[m] <= a < atom_off[m+1].
+ * atom_off / edge_off have n_mols + 1 non-decreasing entries starting at 0 and ending at n_atoms / n_edges;
+ * edge_index is [2, n_edges] row-major.  Local ids are not validated here: dmpnn_prepare* flags what they break. */
+int dmpnn_collate(const int* atom_off, const int* edge_off, int64_t n_mols, const int* src, const int* dst, const int* rev,
+                  int64_t n_atoms, int64_t n_edges, int64_t* edge_index, int64_t* rev_edge_index, int64_t* batch,
+                  void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Misc
  * ------------------------------------------------------------------------------------------- */

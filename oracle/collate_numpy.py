@@ -1,0 +1,49 @@
+"""TEST INFRASTRUCTURE — CPU restatement of the reference's batching, ``BatchMolGraph.__post_init__``
+(chemprop/data/collate.py:37-62), in numpy.  Only tests/ may import it.
+
+Pinned: checked bit-for-bit against the index tensors the EXECUTED reference ``BatchMolGraph`` produced for the same
+molecule lists (frozen in tests/golden/mab/*.npz by tests/golden/make_golden_mab.py; tests/test_collate.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def collate(mgs):
+    """-> dict(V f32 [nV,d_v], E f32 [nE,d_e], edge_index i64 [2,nE], rev_edge_index i64 [nE], batch i64 [nV])."""
+    Vs, Es, eis, revs, bs = [], [], [], [], []
+    num_nodes = num_edges = 0
+    for i, mg in enumerate(mgs):                      # collate.py:48-57
+        Vs.append(mg.V)
+        Es.append(mg.E)
+        eis.append(mg.edge_index + num_nodes)
+        revs.append(mg.rev_edge_index + num_edges)
+        bs.append(np.full(len(mg.V), i, dtype=np.int64))
+        num_nodes += mg.V.shape[0]
+        num_edges += mg.edge_index.shape[1]
+    return dict(V=np.concatenate(Vs).astype(np.float32), E=np.concatenate(Es).astype(np.float32),   # :58-62
+                edge_index=np.hstack(eis).astype(np.int64), rev_edge_index=np.concatenate(revs).astype(np.int64),
+                batch=np.concatenate(bs).astype(np.int64))
+
+
+def unpack_wire(raw: np.ndarray):
+    """Decode the one-buffer wire format of chemprop_amd/data.py (PackedBatch) on the host and batch it the reference's
+    way: what ``dmpnn_collate`` must produce from the same bytes."""
+    hdr = raw[:64].view(np.int64)
+    magic, n_mols, nV, nE, d_v, d_e = (int(x) for x in hdr[:6])
+    assert magic == 0x31424D44
+    a16 = lambda n: (n + 15) // 16 * 16
+    o = 64
+    out = {}
+    for name, dt, count in (("atom_off", np.int32, n_mols + 1), ("edge_off", np.int32, n_mols + 1), ("src", np.int32, nE),
+                            ("dst", np.int32, nE), ("rev", np.int32, nE), ("V", np.float32, nV * d_v), ("E", np.float32, nE * d_e)):
+        nbytes = count * np.dtype(dt).itemsize
+        out[name] = raw[o:o + nbytes].view(dt)
+        o = a16(o + nbytes)
+    assert o == raw.size
+    ao, eo = out["atom_off"].astype(np.int64), out["edge_off"].astype(np.int64)
+    m_of_edge = np.searchsorted(eo, np.arange(nE), side="right") - 1
+    m_of_atom = np.searchsorted(ao, np.arange(nV), side="right") - 1
+    return dict(V=out["V"].reshape(nV, d_v), E=out["E"].reshape(nE, d_e),
+                edge_index=np.stack([out["src"] + ao[m_of_edge], out["dst"] + ao[m_of_edge]]).astype(np.int64),
+                rev_edge_index=(out["rev"] + eo[m_of_edge]).astype(np.int64), batch=m_of_atom.astype(np.int64))

@@ -160,3 +160,54 @@ def atom_forward(V: Tensor, E: Tensor, edge_index: Tensor, rev: Tensor, w: MPWei
     Mv = segment_sum_dst(H, dst, n_atoms)
     out = finalize(Mv, V, V_d, w, tau)
     return (out, inter) if return_intermediates else out
+
+
+# ---- f2: the mol-atom-bond blocks (mol_atom_bond.py:16-388): the same depth loops with two read-outs ---------
+@dataclass
+class MABWeights:
+    """Parameters of one MAB block in ``nn.Linear`` layout (mol_atom_bond.py:318-335,371-388); a switched-off
+    read-out has no ``W_vo`` / ``W_eo``."""
+
+    W_i: Tensor
+    W_h: Tensor
+    W_vo: Optional[Tensor] = None
+    b_vo: Optional[Tensor] = None
+    W_eo: Optional[Tensor] = None
+    b_eo: Optional[Tensor] = None
+    b_i: Optional[Tensor] = None
+    b_h: Optional[Tensor] = None
+    W_vd: Optional[Tensor] = None
+    b_vd: Optional[Tensor] = None
+    W_ed: Optional[Tensor] = None
+    b_ed: Optional[Tensor] = None
+
+    @classmethod
+    def from_state_dict(cls, sd) -> "MABWeights":
+        g = lambda k: sd.get(k)
+        return cls(g("W_i.weight"), g("W_h.weight"), g("W_vo.weight"), g("W_vo.bias"), g("W_eo.weight"), g("W_eo.bias"),
+                   g("W_i.bias"), g("W_h.bias"), g("W_vd.weight"), g("W_vd.bias"), g("W_ed.weight"), g("W_ed.bias"))
+
+
+def mab_forward(V: Tensor, E: Tensor, edge_index: Tensor, rev: Tensor, w: MABWeights, atom_messages: bool,
+                depth: int = 3, activation="relu", undirected: bool = False, V_d: Optional[Tensor] = None,
+                E_d: Optional[Tensor] = None, prelu_weight: Optional[Tensor] = None):
+    """mol_atom_bond.py:266-282 (dropout 0, Identity transforms) -> (H_v | None, H_e | None)."""
+    tau = activation if callable(activation) else activation_fn(activation, prelu_weight)
+    src, dst = edge_index[0], edge_index[1]
+    n_atoms = V.shape[0]
+    wl = MPWeights(W_i=w.W_i, W_h=w.W_h, W_o=w.W_vo, b_o=w.b_vo, b_i=w.b_i, b_h=w.b_h, W_d=w.W_vd, b_d=w.b_vd)
+    H0 = atom_initialize(V, src, wl) if atom_messages else initialize(V, E, src, wl)
+    H = tau(H0)
+    for _ in range(1, depth):
+        if undirected:
+            H = (H + H[rev]) / 2
+        M = atom_message(H, E, src, dst, n_atoms) if atom_messages else message(H, src, dst, rev, n_atoms)
+        H = update(M, H0, wl, tau)
+    H_v = H_e = None
+    if w.W_vo is not None:  # vertex_finalize (:174-219): dropout after W_vd only — no activation there
+        H_v = finalize(segment_sum_dst(H, dst, n_atoms), V, V_d, wl, tau)
+    if w.W_eo is not None:  # edge_finalize (:221-264)
+        H_e = tau(F.linear(torch.cat((E, H), dim=1), w.W_eo, w.b_eo))
+        if E_d is not None:
+            H_e = F.linear(torch.cat((H_e, E_d), dim=1), w.W_ed, w.b_ed)
+    return H_v, H_e

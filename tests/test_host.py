@@ -123,6 +123,8 @@ def test_accelerate_swaps_the_real_reference_classes():
         pytest.skip("/root/reference absent (GPU box)")
     ref_shim.install()
     from chemprop.nn import BondMessagePassing as RefMP
+    from chemprop.nn import MABAtomMessagePassing as RefMABAtom
+    from chemprop.nn import MABBondMessagePassing as RefMABBond
     from chemprop.nn.agg import NormAggregation as RefNorm
 
     from chemprop_amd import integration
@@ -132,10 +134,15 @@ def test_accelerate_swaps_the_real_reference_classes():
             super().__init__()
             self.message_passing = RefMP(d_h=16)
             self.agg = RefNorm(norm=3.0)
+            self.mab = torch.nn.ModuleList([RefMABBond(d_h=8, return_vertex_embeddings=False), RefMABAtom(d_h=8, d_ed=2)])
 
     m = Model()
     keys, w = list(m.state_dict().keys()), m.message_passing.W_h.weight
-    assert integration.accelerate(m) == 2
+    assert integration.accelerate(m) == 4
+    for blk, Ref in zip(m.mab, (RefMABBond, RefMABAtom)):
+        assert isinstance(blk, Ref) and type(blk) is not Ref and blk.hparams["cls"] is Ref
+    assert m.mab[0].atom_messages is False and m.mab[1].atom_messages is True and m.mab[0].W_vo is None
+    assert m.mab[1].output_dims == (8, 10)
     assert isinstance(m.message_passing, RefMP) and type(m.message_passing) is not RefMP
     assert isinstance(m.agg, RefNorm) and type(m.agg) is not RefNorm
     assert m.message_passing.hparams["cls"] is RefMP and m.agg.hparams["cls"] is RefNorm and m.agg.norm == 3.0
