@@ -119,7 +119,31 @@ def hip_mab_message_passing_classes():
     return out
 
 
+_mlp_cache = None
+
+
+def hip_mlp_class():
+    """``(chemprop.nn.ffn.MLP, HipMLP)`` (f4, ``nn/ffn.py:24-68``): the predictor's feed-forward stack; ``forward`` only."""
+    global _mlp_cache
+    if _mlp_cache is not None:
+        return _mlp_cache
+    try:
+        from chemprop.nn.ffn import MLP as Ref  # noqa: WPS433
+    except Exception as e:  # pragma: no cover
+        raise ImportError("chemprop_amd.integration needs an importable `chemprop`") from e
+    from .ffn import mlp_forward
+
+    class HipMLP(Ref):  # type: ignore[misc, valid-type]
+        def forward(self, X: Tensor) -> Tensor:
+            return mlp_forward(self, X)
+
+    _mlp_cache = (Ref, HipMLP)
+    return _mlp_cache
+
+
 def __getattr__(name):
+    if name == "HipMLP":
+        return hip_mlp_class()[1]
     if name == "HipBondMessagePassing":
         return hip_bond_message_passing_class()
     if name == "HipAtomMessagePassing":
@@ -166,9 +190,9 @@ def hip_aggregation_classes():
     return out
 
 
-def accelerate(model, aggregation: bool = True):
+def accelerate(model, aggregation: bool = True, ffn: bool = True):
     """Swap the class of every ``BondMessagePassing`` / ``AtomMessagePassing`` / ``MAB*MessagePassing`` block (and, unless ``aggregation=False``, of every
-    Mean / Sum / Norm / Attentive aggregation) inside ``model`` (an ``MPNN``, a
+    Mean / Sum / Norm / Attentive aggregation and, unless ``ffn=False``, of every ``nn.ffn.MLP`` of the predictors) inside ``model`` (an ``MPNN``, a
     ``MulticomponentMessagePassing`` or the block itself) for the HIP subclass, in place.  No
     parameter is copied or re-created; optimizer state and checkpoints stay valid."""
     Ref = _reference_class()
@@ -179,6 +203,7 @@ def accelerate(model, aggregation: bool = True):
         mabs = hip_mab_message_passing_classes()
     except ImportError:  # (a chemprop older than the mol-atom-bond blocks)
         mabs = {}
+    RefMLP, HipMLP = hip_mlp_class() if ffn else (None, None)
     n = 0
     for m in model.modules():
         if type(m) is Ref:
@@ -192,5 +217,8 @@ def accelerate(model, aggregation: bool = True):
             n += 1
         elif type(m) in mabs:
             m.__class__ = mabs[type(m)]
+            n += 1
+        elif RefMLP is not None and type(m) is RefMLP:
+            m.__class__ = HipMLP
             n += 1
     return n

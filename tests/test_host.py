@@ -126,6 +126,7 @@ def test_accelerate_swaps_the_real_reference_classes():
     from chemprop.nn import MABAtomMessagePassing as RefMABAtom
     from chemprop.nn import MABBondMessagePassing as RefMABBond
     from chemprop.nn.agg import NormAggregation as RefNorm
+    from chemprop.nn.ffn import MLP as RefMLP
 
     from chemprop_amd import integration
 
@@ -134,11 +135,13 @@ def test_accelerate_swaps_the_real_reference_classes():
             super().__init__()
             self.message_passing = RefMP(d_h=16)
             self.agg = RefNorm(norm=3.0)
+            self.ffn = RefMLP.build(16, 2, hidden_dim=8)
             self.mab = torch.nn.ModuleList([RefMABBond(d_h=8, return_vertex_embeddings=False), RefMABAtom(d_h=8, d_ed=2)])
 
     m = Model()
     keys, w = list(m.state_dict().keys()), m.message_passing.W_h.weight
-    assert integration.accelerate(m) == 4
+    assert integration.accelerate(m) == 5
+    assert isinstance(m.ffn, RefMLP) and type(m.ffn) is not RefMLP and m.ffn.output_dim == 2
     for blk, Ref in zip(m.mab, (RefMABBond, RefMABAtom)):
         assert isinstance(blk, Ref) and type(blk) is not Ref and blk.hparams["cls"] is Ref
     assert m.mab[0].atom_messages is False and m.mab[1].atom_messages is True and m.mab[0].W_vo is None
