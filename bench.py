@@ -406,6 +406,30 @@ def main():
                     "pcie_inclusive_M_edge_updates_per_s": round(updates / t1, 2),
                     "pcie_inclusive_five_tensors_M_edge_updates_per_s": round(updates / t5, 2),
                     "note": "pinned host buffers -> device -> forward, eager, wall clock; weights resident"}
+                # the same forward on a RESIDENT batch that came through the packed format: its tile table was made by the
+                # loader (dmpnn_pack_tiles), so K0 is a copy of that table and the tile kernel is not limited to small batches
+                lt = {}
+                for n_m in sorted({args.mols, 4096}):
+                    mg2 = synth.random_molgraphs(n_m, args.kind, seed=1000 + rank)
+                    pb = PackedBatch(mg2, pin=True)
+                    if pb.n_tiles <= 0:
+                        lt[str(n_m)] = {"note": "a molecule exceeds a tile: no loader table"}
+                        continue
+                    res = pb.to_device(dev)
+                    plain = BatchMolGraph(mg2)
+                    plain.to(dev)
+                    upd = int(res.E.shape[0]) * (args.depth - 1)
+                    ent = {"directed_edges": int(res.E.shape[0]), "tiles": pb.n_tiles}
+                    for tag, b in (("loader_tiles", res), ("device_plan", plain)):
+                        def f(b=b):
+                            with torch.no_grad():
+                                return mp(b)
+                        run_steps(f, 10)
+                        t = time_events(f, 50, torch)
+                        ent[tag + "_us"] = round(t * 1e3, 2)
+                        ent[tag + "_M_edge_updates_per_s"] = round(upd / (t * 1e3), 2)
+                    lt[str(n_m)] = ent
+                out["loader_tiles"] = lt
             except Exception as e:
                 out["host_handoff"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 

@@ -31,7 +31,8 @@ EXPORTS = [
     "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_prepare_light", "dmpnn_prepare_tiles", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
     "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
-    "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate",
+    "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
+    "dmpnn_prepare_tiles_from_table",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -41,6 +42,7 @@ F_MEGA = 4
 F_KEEP = 8
 F_SPLIT16 = 16
 F_WSPLIT_READY = 32
+F_LOADER_TILES = 64
 PLAN_NOMEGA_MASK = 15  # ... | no piece tiles (a molecule larger than a tile)
 PLAN_NOFUSE_MASK = 7  # asymmetric | index out of range | in-degree > 24
 
@@ -78,6 +80,7 @@ class FwdArgs(C.Structure):
         ("out", C.c_void_p), ("ldout", C.c_int64),
         ("wsplit", C.c_void_p), ("wsplit_bytes", C.c_size_t),
         ("edge_index", C.c_void_p), ("rev_edge_index", C.c_void_p),
+        ("n_tiles_launch", C.c_int64),
     ]
 
 
@@ -187,6 +190,12 @@ def load() -> C.CDLL:
     lib.dmpnn_linear16_fwd.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     lib.dmpnn_gather_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_void_p]
+    lib.dmpnn_pack_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.dmpnn_pack_tiles.restype = C.c_int64
+    lib.dmpnn_max_tiles.argtypes = [C.c_int64, C.c_int64]
+    lib.dmpnn_max_tiles.restype = C.c_int64
+    lib.dmpnn_prepare_tiles_from_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                                   C.c_void_p]
     lib.dmpnn_collate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dmpnn_molagg_ws_bytes.argtypes = [C.c_int64]
@@ -200,7 +209,7 @@ def load() -> C.CDLL:
     for name in size_t_fns:
         getattr(lib, name).restype = C.c_size_t
     for name in EXPORTS:
-        if name != "dmpnn_last_error_string" and name not in size_t_fns:
+        if name != "dmpnn_last_error_string" and name not in size_t_fns and name not in ("dmpnn_pack_tiles", "dmpnn_max_tiles"):
             getattr(lib, name).restype = C.c_int
     if lib.dmpnn_version() != ABI_VERSION:
         raise RuntimeError(f"libdmpnn ABI version {lib.dmpnn_version()} != {ABI_VERSION} (stale build?)")

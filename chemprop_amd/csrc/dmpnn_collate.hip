@@ -50,8 +50,92 @@ __global__ __launch_bounds__(256) void k_collate(const int* __restrict__ atom_of
     }
 }
 
+// The piece-tile tables of a tile plan from a table the LOADER made (dmpnn_pack_tiles below): copy, pad the unused slots
+// with the (n_edges, n_atoms) sentinel, write the header of a tile plan.  Every entry is checked here for order and
+// for the tile limits (a violation sets DMPNN_PLAN_NO_PIECE_TILES: the tile kernel then returns NaN); whether a tile
+// is CLOSED (holds every edge of its atoms and nothing else) is checked by the tile kernel itself on the batch's own
+// index arrays, exactly as for a table from dmpnn_prepare_tiles.
+__global__ __launch_bounds__(256) void k_tiles_from_table(const int* __restrict__ tile_row, const int* __restrict__ tile_atom,
+                                                          int n_tiles, int nV, int nE, int* __restrict__ plan, PlanLayout L) {
+    __shared__ int bad_s;
+    if (threadIdx.x == 0) bad_s = 0;
+    __syncthreads();
+    int* mrow = plan + L.mtile_row;
+    int* matom = plan + L.mtile_atom;
+    const int slots = (int)L.max_mtiles + 2;
+    int bad = 0;
+    for (int t = threadIdx.x; t < slots; t += blockDim.x) {
+        int r = nE, a = nV;
+        if (t < n_tiles) {
+            r = tile_row[t]; a = tile_atom[t];
+            const int r1 = t + 1 < n_tiles ? tile_row[t + 1] : nE, a1 = t + 1 < n_tiles ? tile_atom[t + 1] : nV;
+            if (r < 0 || a < 0 || r1 < r || a1 < a || r1 - r > kMegaBM || a1 - a > kMegaBA || r1 > nE || a1 > nV) bad = 1;
+            if (t == 0 && (r != 0 || a != 0)) bad = 1;
+        }
+        mrow[t] = r;
+        matom[t] = a;
+    }
+    if (n_tiles == 0 && (nE > 0 || nV > 0)) bad = 1;
+    if (bad) atomicOr(&bad_s, 1);
+    __syncthreads();
+    if (threadIdx.x < DMPNN_HDR_WORDS) {
+        int v = 0;
+        const int h = threadIdx.x;
+        if (h == DMPNN_HDR_FLAGS) v = (bad_s ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
+        if (h == DMPNN_HDR_NMTILES) v = bad_s ? 0 : n_tiles;
+        if (h == DMPNN_HDR_LIGHT) v = 2;
+        if (h == DMPNN_HDR_NATOMS) v = nV;
+        if (h == DMPNN_HDR_NEDGES) v = nE;
+        if (h == DMPNN_HDR_TILE_STRIDE) v = kFusedBM;
+        plan[h] = v;
+    }
+}
+
 }  // namespace
 }  // namespace dmpnn
+
+// HOST function (no device work): greedy packing of consecutive whole molecules into tiles of <= 48 directed edges and
+// <= 32 atoms from the two running offsets of a batch.  Writes tile_row / tile_atom [n_tiles + 1] (the last entry is the
+// (n_edges, n_atoms) end) and returns n_tiles; -1 when a molecule alone exceeds a tile (such batches take the device
+// plans), -2 when `cap` entries do not suffice or an argument is bad.
+extern "C" int64_t dmpnn_pack_tiles(const int* atom_off, const int* edge_off, int64_t n_mols, int* tile_row, int* tile_atom,
+                                    int64_t cap) {
+    if (n_mols < 0 || cap < 1 || !tile_row || !tile_atom || (n_mols > 0 && (!atom_off || !edge_off))) return -2;
+    int64_t n = 0, m = 0;
+    while (m < n_mols) {
+        const int a0 = atom_off[m], e0 = edge_off[m];
+        int64_t q = m;
+        while (q < n_mols && atom_off[q + 1] - a0 <= dmpnn::kMegaBA && edge_off[q + 1] - e0 <= dmpnn::kMegaBM) ++q;
+        if (q == m) return -1;                       // molecule m alone exceeds a tile
+        if (atom_off[q] == a0 && edge_off[q] == e0) { m = q; continue; }  // only empty molecules: no tile
+        if (n + 1 >= cap) return -2;
+        tile_row[n] = e0; tile_atom[n] = a0;
+        ++n;
+        m = q;
+    }
+    tile_row[n] = n_mols ? edge_off[n_mols] : 0;
+    tile_atom[n] = n_mols ? atom_off[n_mols] : 0;
+    return n;
+}
+
+extern "C" int64_t dmpnn_max_tiles(int64_t n_atoms, int64_t n_edges) { return dmpnn::mega_max_tiles(n_atoms, n_edges); }
+
+extern "C" int dmpnn_prepare_tiles_from_table(const int* tile_row, const int* tile_atom, int64_t n_tiles, int64_t n_atoms,
+                                              int64_t n_edges, void* plan, size_t plan_bytes, void* stream) {
+    DMPNN_CHECK_ARG(n_atoms >= 0 && n_edges >= 0 && n_tiles >= 0 && n_atoms < (1ll << 31) && n_edges < (1ll << 31), "tiles_from_table: bad sizes");
+    DMPNN_CHECK_ARG(plan && (n_tiles == 0 || (tile_row && tile_atom)), "tiles_from_table: NULL pointer");
+    const dmpnn::PlanLayout L = dmpnn::plan_layout(n_atoms, n_edges);
+    if (plan_bytes < (size_t)L.words * sizeof(int)) {
+        dmpnn::set_error("tiles_from_table: plan buffer too small (%zu < %zu bytes)", plan_bytes, (size_t)L.words * sizeof(int));
+        return DMPNN_ENOSPC;
+    }
+    DMPNN_CHECK_ARG(n_tiles <= L.max_mtiles, "tiles_from_table: %lld tiles exceed the launch bound %lld of this batch size",
+                    (long long)n_tiles, (long long)L.max_mtiles);
+    hipLaunchKernelGGL(dmpnn::k_tiles_from_table, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), tile_row, tile_atom,
+                       (int)n_tiles, (int)n_atoms, (int)n_edges, static_cast<int*>(plan), L);
+    DMPNN_CHECK_LAUNCH("k_tiles_from_table");
+    return DMPNN_OK;
+}
 
 extern "C" int dmpnn_collate(const int* atom_off, const int* edge_off, int64_t n_mols, const int* src, const int* dst,
                              const int* rev, int64_t n_atoms, int64_t n_edges, int64_t* edge_index, int64_t* rev_edge_index,

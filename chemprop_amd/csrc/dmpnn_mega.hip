@@ -10,7 +10,8 @@ DMPNN_DEFINE_MEGA(5)
 
 // Shapes the tile kernel takes (graph properties are decided on the device: plan flag bit 3).
 bool mega_shapes_ok(const dmpnn_fwd_args& a) {
-    if (!small_plan_fits(a.n_atoms, a.n_edges)) return false;  // piece tiles come from the single-workgroup plan
+    // piece tiles come from the single-workgroup plan — or from the loader, at any batch size
+    if (!(a.flags & DMPNN_F_LOADER_TILES) && !small_plan_fits(a.n_atoms, a.n_edges)) return false;
     if (a.n_atoms * a.ldv * 4 > 0x7FFFFFFF || a.n_edges * a.lde * 4 > 0x7FFFFFFF) return false;
     return a.d_h % 4 == 0 && a.d_h <= 320 && a.d_v % 2 == 0 && a.d_e % 2 == 0 && a.ldv % 2 == 0 && a.lde % 2 == 0 &&
            (a.W_d != nullptr || a.ldout % 4 == 0) && a.ldh % 4 == 0 && a.depth >= 1 && !(a.flags & DMPNN_F_UNDIRECTED);

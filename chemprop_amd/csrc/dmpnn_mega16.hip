@@ -82,7 +82,7 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     g.dbg = g_debug_stamps;
     g.edge_index = reinterpret_cast<const long long*>(a.edge_index);
     g.rev64 = reinterpret_cast<const long long*>(a.rev_edge_index);
-    const int n_tiles = (int)L.max_mtiles;
+    const int n_tiles = (a.n_tiles_launch > 0 && a.n_tiles_launch < L.max_mtiles) ? (int)a.n_tiles_launch : (int)L.max_mtiles;
     if (a.d_h <= 64) return mega16::launch_mega16<1>(G, n_tiles, s);
     if (a.d_h <= 128) return mega16::launch_mega16<2>(G, n_tiles, s);
     return mega16::launch_mega16<5>(G, n_tiles, s);

@@ -34,10 +34,11 @@ class MolGraph(NamedTuple):
 class BatchMolGraph:
     """A batch of :class:`MolGraph` as five tensors.  ``len()`` is the number of molecules."""
 
-    __slots__ = ("V", "E", "edge_index", "rev_edge_index", "batch", "_size")
+    __slots__ = ("V", "E", "edge_index", "rev_edge_index", "batch", "_size", "tiles")
 
     def __init__(self, mgs: Sequence[MolGraph]):
         self._size = len(mgs)
+        self.tiles = None  # (tile_row, tile_atom, n_tiles) device int32 views: only batches from PackedBatch.to_device
         n_atoms = np.fromiter((len(mg.V) for mg in mgs), dtype=np.int64, count=len(mgs))
         n_edges = np.fromiter((mg.edge_index.shape[1] for mg in mgs), dtype=np.int64, count=len(mgs))
         atom_off = np.concatenate([[0], np.cumsum(n_atoms)[:-1]]) if len(mgs) else np.zeros(0, np.int64)
@@ -61,6 +62,7 @@ class BatchMolGraph:
         self.edge_index = self.edge_index.to(device)
         self.rev_edge_index = self.rev_edge_index.to(device)
         self.batch = self.batch.to(device)
+        self.tiles = None  # (views of the packed buffer on its own device)
 
     @classmethod
     def from_tensors(cls, V: Tensor, E: Tensor, edge_index: Tensor, rev_edge_index: Tensor,
@@ -70,16 +72,18 @@ class BatchMolGraph:
         self.V, self.E = V, E
         self.edge_index, self.rev_edge_index, self.batch = edge_index, rev_edge_index, batch
         self._size = int(size) if size is not None else (int(batch[-1]) + 1 if batch.numel() else 0)
+        self.tiles = None
         return self
 
     def __copy__(self):
-        return BatchMolGraph.from_tensors(self.V, self.E, self.edge_index, self.rev_edge_index,
-                                          self.batch, self._size)
+        b = BatchMolGraph.from_tensors(self.V, self.E, self.edge_index, self.rev_edge_index, self.batch, self._size)
+        b.tiles = self.tiles  # (a graph_transform scales V / E of a shallow copy: the connectivity is the same)
+        return b
 
 
 # ---- f3: one-buffer wire format + device-side batching (collate.py:37-62,68-73) -----------------
 _WIRE_MAGIC = 0x31424D44  # "DMB1"
-_WIRE_HEADER = 8          # int64 words: magic, n_mols, n_atoms, n_edges, d_v, d_e, 0, 0
+_WIRE_HEADER = 8          # int64 words: magic, n_mols, n_atoms, n_edges, d_v, d_e, n_tiles (-1: no table), 0
 
 
 def _align16(n: int) -> int:
@@ -89,11 +93,16 @@ def _align16(n: int) -> int:
 class PackedBatch:
     """A batch of :class:`MolGraph` in ONE host buffer, built in the DataLoader worker (``collate_fn``):
 
-        int64  header[8]            magic, n_mols, n_atoms, n_edges, d_v, d_e, 0, 0
+        int64  header[8]            magic, n_mols, n_atoms, n_edges, d_v, d_e, n_tiles (-1: no tile table), 0
         int32  atom_off[n_mols+1]   running atom count   (collate.py:46,56: ``num_nodes``)
         int32  edge_off[n_mols+1]   running edge count   (collate.py:47,57: ``num_edges``)
         int32  src[n_edges] | dst[n_edges] | rev[n_edges]      molecule-LOCAL ids, as the featurizer made them
         f32    V[n_atoms, d_v] | E[n_edges, d_e]
+        int32  tile_row[n_tiles+1] | tile_atom[n_tiles+1]     whole molecules packed greedily into tiles of <= 48 directed
+                                    edges / <= 32 atoms (``dmpnn_pack_tiles``, a host function of the library): the tile
+                                    plan of the whole-forward tile kernel, made where the molecule sizes are known
+                                    anyway — the forward then needs no plan kernel (K0) beyond a copy of this table and
+                                    takes the tile kernel at ANY batch size; absent when a molecule exceeds a tile
 
     every section 16-byte aligned.  Against the reference's hand-off (five tensors, int64 indices, five copies) this
     is one copy and 12 instead of 24 index bytes per directed edge; ``to_device`` issues that copy (asynchronous
@@ -101,9 +110,9 @@ class PackedBatch:
     ``V`` / ``E`` are views of the copied buffer and whose index tensors are the int64 tensors the reference builds,
     bit for bit.  No arithmetic of the batching happens on the host beyond the two running sums."""
 
-    __slots__ = ("buf", "n_mols", "n_atoms", "n_edges", "d_v", "d_e", "sections")
+    __slots__ = ("buf", "n_mols", "n_atoms", "n_edges", "d_v", "d_e", "sections", "n_tiles")
 
-    def __init__(self, mgs: Sequence[MolGraph], pin: bool = False):
+    def __init__(self, mgs: Sequence[MolGraph], pin: bool = False, tiles: bool = True):
         n_mols = len(mgs)
         n_at = np.fromiter((len(mg.V) for mg in mgs), dtype=np.int64, count=n_mols)
         n_ed = np.fromiter((mg.edge_index.shape[1] for mg in mgs), dtype=np.int64, count=n_mols)
@@ -112,9 +121,25 @@ class PackedBatch:
             raise ValueError("PackedBatch: more than 2^31 atoms or edges in one batch")
         d_v = int(mgs[0].V.shape[1]) if n_mols else 0
         d_e = int(mgs[0].E.shape[1]) if n_mols else 0
+        atom_off = np.zeros(n_mols + 1, dtype=np.int32)
+        edge_off = np.zeros(n_mols + 1, dtype=np.int32)
+        atom_off[1:] = np.cumsum(n_at)
+        edge_off[1:] = np.cumsum(n_ed)
+        n_tiles, trow, tatom = -1, None, None
+        if tiles and n_mols and nV:
+            from . import _lib
+
+            lib = _lib.load()
+            cap = int(lib.dmpnn_max_tiles(nV, nE)) + 1
+            trow, tatom = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
+            n_tiles = int(lib.dmpnn_pack_tiles(atom_off.ctypes.data, edge_off.ctypes.data, n_mols, trow.ctypes.data,
+                                               tatom.ctypes.data, cap))
+            if n_tiles < 0:
+                n_tiles = -1  # a molecule larger than a tile: the device plans decide the route
+        nt = n_tiles + 1 if n_tiles >= 0 else 0
         sec, o = {}, _WIRE_HEADER * 8
         for name, nbytes in (("atom_off", 4 * (n_mols + 1)), ("edge_off", 4 * (n_mols + 1)), ("src", 4 * nE), ("dst", 4 * nE),
-                             ("rev", 4 * nE), ("V", 4 * nV * d_v), ("E", 4 * nE * d_e)):
+                             ("rev", 4 * nE), ("V", 4 * nV * d_v), ("E", 4 * nE * d_e), ("tile_row", 4 * nt), ("tile_atom", 4 * nt)):
             sec[name] = (o, nbytes)
             o = _align16(o + nbytes)
         buf = torch.zeros(o, dtype=torch.uint8)
@@ -122,9 +147,12 @@ class PackedBatch:
             buf = buf.pin_memory()
         raw = buf.numpy()
         view = lambda name, dt: raw[sec[name][0]:sec[name][0] + sec[name][1]].view(dt)
-        raw[:_WIRE_HEADER * 8].view(np.int64)[:6] = (_WIRE_MAGIC, n_mols, nV, nE, d_v, d_e)
-        view("atom_off", np.int32)[1:] = np.cumsum(n_at)
-        view("edge_off", np.int32)[1:] = np.cumsum(n_ed)
+        raw[:_WIRE_HEADER * 8].view(np.int64)[:7] = (_WIRE_MAGIC, n_mols, nV, nE, d_v, d_e, n_tiles)
+        view("atom_off", np.int32)[:] = atom_off
+        view("edge_off", np.int32)[:] = edge_off
+        if nt:
+            view("tile_row", np.int32)[:] = trow[:nt]
+            view("tile_atom", np.int32)[:] = tatom[:nt]
         if n_mols:
             if nE:
                 view("src", np.int32)[:] = np.concatenate([mg.edge_index[0] for mg in mgs])
@@ -136,6 +164,7 @@ class PackedBatch:
                 view("V", np.float32).reshape(nV, d_v)[:] = np.concatenate([mg.V for mg in mgs])
         self.buf, self.sections = buf, sec
         self.n_mols, self.n_atoms, self.n_edges, self.d_v, self.d_e = n_mols, nV, nE, d_v, d_e
+        self.n_tiles = n_tiles
 
     def __len__(self) -> int:
         return self.n_mols
@@ -166,4 +195,7 @@ class PackedBatch:
             _lib.check(_lib.load().dmpnn_collate(at("atom_off"), at("edge_off"), self.n_mols, at("src"), at("dst"), at("rev"),
                                                  nV, nE, edge_index.data_ptr(), rev.data_ptr(), batch.data_ptr(),
                                                  engine._stream_ptr(device)), "dmpnn_collate")
-        return BatchMolGraph.from_tensors(V, E, edge_index, rev, batch, self.n_mols)
+        bmg = BatchMolGraph.from_tensors(V, E, edge_index, rev, batch, self.n_mols)
+        if self.n_tiles >= 0:
+            bmg.tiles = (sl("tile_row").view(torch.int32), sl("tile_atom").view(torch.int32), self.n_tiles)
+        return bmg

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT, F_FUSED, F_KEEP, F_MEGA, F_SPLIT16, F_UNDIRECTED, F_WSPLIT_READY, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
+from ._lib import ACT, F_FUSED, F_KEEP, F_LOADER_TILES, F_MEGA, F_SPLIT16, F_UNDIRECTED, F_WSPLIT_READY, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
 
 
 # From this many directed edges on, the per-step route runs its contractions on the f16 pipe (exact operand split) and is
@@ -95,9 +95,10 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 class GraphPlan:
     """K0: int32 indices + stable incoming-edge CSR of one batch, built on device (no host sync)."""
 
-    __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index")
+    __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index", "loader_tiles")
 
-    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False, batch: Optional[Tensor] = None):
+    def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False, batch: Optional[Tensor] = None,
+                 tiles: Optional[tuple] = None):
         _require_device(edge_index, "edge_index")
         lib = _lib.load()
         dev = edge_index.device
@@ -113,11 +114,23 @@ class GraphPlan:
         # tables — the whole-forward tile kernel then works on the caller's own index arrays (kept alive here);
         # batches beyond the single-workgroup plan always get the full plan
         small = small_plan_fits(n_atoms, n_edges)
-        self.tiles_only = light == "tiles" and small
-        self.light = bool(light) and small
+        # tiles = (tile_row, tile_atom, n_tiles): the loader's table (PackedBatch, dmpnn_pack_tiles) — with light="tiles" the
+        # plan is a copy of it (dmpnn_prepare_tiles_from_table), whatever the batch size
+        self.loader_tiles = 0
+        if light == "tiles" and tiles is not None:
+            tr, ta, nt = tiles
+            if (tr.dtype == torch.int32 and ta.dtype == torch.int32 and tr.device == dev and ta.device == dev
+                    and tr.is_contiguous() and ta.is_contiguous() and tr.numel() > nt and ta.numel() > nt and nt > 0):
+                self.loader_tiles = int(nt)
+        self.tiles_only = light == "tiles" and (small or self.loader_tiles > 0)
+        self.light = bool(light) and (small or self.loader_tiles > 0)
         self.edge_index, self.rev_edge_index = ei, rev
         with _OnDevice(dev):
-            if self.tiles_only:
+            if self.loader_tiles:
+                _lib.check(lib.dmpnn_prepare_tiles_from_table(tiles[0].data_ptr(), tiles[1].data_ptr(), self.loader_tiles, n_atoms,
+                                                              n_edges, self.buf.data_ptr(), nbytes, _stream_ptr(dev)),
+                           "dmpnn_prepare_tiles_from_table")
+            elif self.tiles_only:
                 # with the batch vector (int64, like the reference's) the tiles are whole molecules found by binary search
                 bt = batch if (batch is not None and batch.dtype == torch.int64 and batch.device == dev
                                and batch.numel() == n_atoms and batch.is_contiguous()) else None
@@ -132,7 +145,8 @@ class GraphPlan:
     @classmethod
     def from_bmg(cls, bmg, light=False, use_batch: bool = True) -> "GraphPlan":
         return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]), light=light,
-                   batch=getattr(bmg, "batch", None) if use_batch else None)
+                   batch=getattr(bmg, "batch", None) if use_batch else None,
+                   tiles=getattr(bmg, "tiles", None) if light == "tiles" else None)
 
     # ---- views for tests / diagnostics (these synchronise) ----
     def arrays(self) -> dict:
@@ -357,6 +371,9 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     a.edge_index, a.rev_edge_index = plan.edge_index.data_ptr(), plan.rev_edge_index.data_ptr()
     a.d_v, a.d_e, a.d_h, a.d_vd = d_v, d_e, d_h, d_vd
     a.depth, a.flags = int(depth), (F_UNDIRECTED if undirected else 0)
+    if getattr(plan, "loader_tiles", 0):
+        a.flags |= F_LOADER_TILES
+        a.n_tiles_launch = plan.loader_tiles
     a.act, a.act_slope, a.act_slope_ptr = act_code(act), float(slope), _ptr(slope_t)
     a.V, a.ldv = V.data_ptr(), V.stride(0)
     a.E, a.lde = E.data_ptr(), E.stride(0)

@@ -165,7 +165,10 @@ def _replay_forward(mp, r: "_Replay", bmg):
         return None
     nV, nE = int(V.shape[0]), int(E.shape[0])
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
-    if (n_mols <= 0 or nE > 30 * n_mols or nE == 0 or not engine.small_plan_fits(nV, nE) or batch.numel() != nV
+    tiles = getattr(bmg, "tiles", None)
+    if tiles is not None and (tiles[0].device != dev or tiles[2] <= 0):
+        tiles = None
+    if (n_mols <= 0 or nE > 30 * n_mols or nE == 0 or (tiles is None and not engine.small_plan_fits(nV, nE)) or batch.numel() != nV
             or ei.shape[1] != nE or rev.numel() != nE or getattr(mp, "_dmpnn_no_mega", False)):
         return None
     lib = _lib.load()
@@ -182,7 +185,15 @@ def _replay_forward(mp, r: "_Replay", bmg):
     a.flags |= _lib.F_WSPLIT_READY
     stream = engine._stream_ptr(dev)
     with engine._OnDevice(dev):
-        _lib.check(lib.dmpnn_prepare_tiles(a.edge_index, a.rev_edge_index, batch.data_ptr(), nV, nE, pb, nbytes, stream), "dmpnn_prepare_tiles")
+        if tiles is not None:  # the loader's table: K0 is a copy of it
+            a.flags |= _lib.F_LOADER_TILES
+            a.n_tiles_launch = tiles[2]
+            _lib.check(lib.dmpnn_prepare_tiles_from_table(tiles[0].data_ptr(), tiles[1].data_ptr(), tiles[2], nV, nE, pb, nbytes, stream),
+                       "dmpnn_prepare_tiles_from_table")
+        else:
+            a.flags &= ~_lib.F_LOADER_TILES
+            a.n_tiles_launch = 0
+            _lib.check(lib.dmpnn_prepare_tiles(a.edge_index, a.rev_edge_index, batch.data_ptr(), nV, nE, pb, nbytes, stream), "dmpnn_prepare_tiles")
         _lib.check(lib.dmpnn_forward(_ctypes.byref(a), stream), "dmpnn_forward")
     from .agg import note_batch
 
@@ -211,9 +222,12 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
-    light = _light_plan_ok(mp) and int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES
-    if light and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols):
+    loader_tiles = getattr(bmg, "tiles", None) is not None  # (PackedBatch: the tile table came with the batch)
+    light = _light_plan_ok(mp) and (int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES or loader_tiles)
+    if light and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
         light = "tiles"
+    elif light and int(bmg.E.shape[0]) >= engine.STEPS16_MIN_EDGES:
+        light = False
     plan = engine.GraphPlan.from_bmg(bmg, light=light)
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch
@@ -243,7 +257,7 @@ def _light_plan_ok(mp) -> bool:
     return d_h % 4 == 0 and d_h <= 320 and d_v % 2 == 0 and (d_in - d_v) % 2 == 0
 
 
-def _tile_plan_ok(mp, n_atoms: int, n_edges: int, n_mols: int) -> bool:
+def _tile_plan_ok(mp, n_atoms: int, n_edges: int, n_mols: int, loader_tiles: bool = False) -> bool:
     """After the validated first batches, an inference forward that is going to take the whole-forward tile kernel
     on the f16 pipe needs only the piece-tile tables (``dmpnn_prepare_tiles``): the kernel reads the batch's own
     index arrays and checks every tile itself (a tile that is not closed returns NaN for its atoms)."""
@@ -253,7 +267,7 @@ def _tile_plan_ok(mp, n_atoms: int, n_edges: int, n_mols: int) -> bool:
         return False
     if _lib.opt("DMPNN_VALIDATE", "first") == "always":
         return False  # (the per-batch verdict is read from a full plan)
-    return n_mols > 0 and n_edges <= 30 * n_mols and engine.small_plan_fits(n_atoms, n_edges)
+    return n_mols > 0 and n_edges <= 30 * n_mols and (loader_tiles or engine.small_plan_fits(n_atoms, n_edges))
 
 
 def _route(mp, plan, n_mols: int = 0) -> int:
@@ -279,7 +293,10 @@ def _route(mp, plan, n_mols: int = 0) -> int:
         if flags & 7:
             return 0
         if flags & 8:
-            object.__setattr__(mp, "_dmpnn_no_mega", True)
+            # no piece tiles: a molecule larger than a tile switches the tile kernel off for the module — but a batch
+            # beyond the single-workgroup plan has none either way, which says nothing about its molecules
+            if engine.small_plan_fits(plan.n_atoms, plan.n_edges):
+                object.__setattr__(mp, "_dmpnn_no_mega", True)
             return 1
     return 1 if no_mega else 2
 

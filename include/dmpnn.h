@@ -65,10 +65,12 @@ enum dmpnn_flags {
     DMPNN_F_SPLIT16 = 1u << 4,    /* with DMPNN_F_MEGA: contractions on the f16 matrix pipe with the exact
                                      3-term split (x s = hi + lo, fp32 accumulate): fp32-class accuracy at
                                      5.3x the fp32-MFMA rate; needs the `wsplit` workspace                */
-    DMPNN_F_WSPLIT_READY = 1u << 5 /* with DMPNN_F_SPLIT16: `wsplit` still holds the pre-split an earlier
+    DMPNN_F_WSPLIT_READY = 1u << 5, /* with DMPNN_F_SPLIT16: `wsplit` still holds the pre-split an earlier
                                      dmpnn_forward wrote for exactly these W_i / W_h / W_o values and shapes
                                      (the CALLER vouches for it, e.g. inference with frozen weights): the
                                      pre-split launch is skipped                                          */
+    DMPNN_F_LOADER_TILES = 1u << 6 /* `plan` is a tile plan made by dmpnn_prepare_tiles_from_table: DMPNN_F_MEGA is
+                                     not limited to batches the single-workgroup plan takes                 */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -237,12 +239,15 @@ typedef struct dmpnn_fwd_args {
     void* wsplit; size_t wsplit_bytes;
     /* the caller's own index arrays (device): required when `plan` is a tile plan (dmpnn_prepare_tiles), else ignored */
     const int64_t* edge_index; const int64_t* rev_edge_index;
+    /* DMPNN_F_MEGA: number of tile workgroups to launch when the caller knows the tile count (loader tiles); 0 = the
+     * launch bound of the batch size (workgroups beyond the table's tiles exit at once) */
+    int64_t n_tiles_launch;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
 /* 1 when the shapes / alignment of `a` allow DMPNN_F_FUSED (d_h % 4 == 0, d_h <= 320, even d_v and
  * d_e, directed), 2 when they also allow DMPNN_F_MEGA (batch within the single-workgroup plan:
- * <= 6144 atoms, <= 10240 edges), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
+ * <= 6144 atoms, <= 10240 edges — any size with DMPNN_F_LOADER_TILES), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
  * dmpnn_prepare: a fused forward on a graph that violates them returns NaN and leaves the plan flags
  * set (DMPNN_HDR_FLAGS) — run such graphs without DMPNN_F_FUSED. */
 int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a);
@@ -314,6 +319,22 @@ int dmpnn_gather_rows(const float* X, int64_t ldx, int64_t n_src, const int* idx
 int dmpnn_collate(const int* atom_off, const int* edge_off, int64_t n_mols, const int* src, const int* dst, const int* rev,
                   int64_t n_atoms, int64_t n_edges, int64_t* edge_index, int64_t* rev_edge_index, int64_t* batch,
                   void* stream);
+
+/* f3, second half ("pre-built tiles from the DataLoader worker feed K0 for free"): the tile plan of dmpnn_prepare_tiles
+ * from a table the loader made while packing the batch.
+ *   dmpnn_pack_tiles      HOST function (host pointers, no device work): greedy packing of consecutive whole molecules
+ *                         into tiles of <= 48 directed edges / <= 32 atoms from the running offsets; tile_row / tile_atom
+ *                         receive n_tiles + 1 entries; returns n_tiles, -1 if a molecule alone exceeds a tile, -2 on a
+ *                         bad argument / `cap` too small.  dmpnn_max_tiles(n_atoms, n_edges) + 1 entries always suffice.
+ *   dmpnn_prepare_tiles_from_table   device pointers: copies the table into `plan` (>= dmpnn_plan_bytes) and writes a
+ *                         tile-plan header; order / size violations set DMPNN_PLAN_NO_PIECE_TILES (NaN from the tile
+ *                         kernel), and the tile kernel checks on the batch's own index arrays that every tile is closed.
+ * A forward on such a plan passes DMPNN_F_LOADER_TILES (no batch-size limit from the single-workgroup plan) and may give
+ * n_tiles_launch = n_tiles so that only that many workgroups are launched.                                          */
+int64_t dmpnn_pack_tiles(const int* atom_off, const int* edge_off, int64_t n_mols, int* tile_row, int* tile_atom, int64_t cap);
+int64_t dmpnn_max_tiles(int64_t n_atoms, int64_t n_edges);
+int dmpnn_prepare_tiles_from_table(const int* tile_row, const int* tile_atom, int64_t n_tiles, int64_t n_atoms,
+                                   int64_t n_edges, void* plan, size_t plan_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Misc

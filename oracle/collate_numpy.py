@@ -30,13 +30,15 @@ def unpack_wire(raw: np.ndarray):
     """Decode the one-buffer wire format of chemprop_amd/data.py (PackedBatch) on the host and batch it the reference's
     way: what ``dmpnn_collate`` must produce from the same bytes."""
     hdr = raw[:64].view(np.int64)
-    magic, n_mols, nV, nE, d_v, d_e = (int(x) for x in hdr[:6])
+    magic, n_mols, nV, nE, d_v, d_e, n_tiles = (int(x) for x in hdr[:7])
+    nt = n_tiles + 1 if n_tiles >= 0 else 0
     assert magic == 0x31424D44
     a16 = lambda n: (n + 15) // 16 * 16
     o = 64
     out = {}
     for name, dt, count in (("atom_off", np.int32, n_mols + 1), ("edge_off", np.int32, n_mols + 1), ("src", np.int32, nE),
-                            ("dst", np.int32, nE), ("rev", np.int32, nE), ("V", np.float32, nV * d_v), ("E", np.float32, nE * d_e)):
+                            ("dst", np.int32, nE), ("rev", np.int32, nE), ("V", np.float32, nV * d_v), ("E", np.float32, nE * d_e),
+                            ("tile_row", np.int32, nt), ("tile_atom", np.int32, nt)):
         nbytes = count * np.dtype(dt).itemsize
         out[name] = raw[o:o + nbytes].view(dt)
         o = a16(o + nbytes)
@@ -44,6 +46,30 @@ def unpack_wire(raw: np.ndarray):
     ao, eo = out["atom_off"].astype(np.int64), out["edge_off"].astype(np.int64)
     m_of_edge = np.searchsorted(eo, np.arange(nE), side="right") - 1
     m_of_atom = np.searchsorted(ao, np.arange(nV), side="right") - 1
-    return dict(V=out["V"].reshape(nV, d_v), E=out["E"].reshape(nE, d_e),
+    return dict(tile_row=out["tile_row"], tile_atom=out["tile_atom"], n_tiles=n_tiles,
+                V=out["V"].reshape(nV, d_v), E=out["E"].reshape(nE, d_e),
                 edge_index=np.stack([out["src"] + ao[m_of_edge], out["dst"] + ao[m_of_edge]]).astype(np.int64),
                 rev_edge_index=(out["rev"] + eo[m_of_edge]).astype(np.int64), batch=m_of_atom.astype(np.int64))
+
+
+def greedy_molecule_tiles(n_atoms, n_edges, max_rows: int = 48, max_atoms: int = 32):
+    """The loader-side tile table (``dmpnn_pack_tiles``): consecutive whole molecules packed greedily into tiles of at most
+    ``max_rows`` directed edges and ``max_atoms`` atoms (the tile limits of the whole-forward tile kernel).
+    -> (tile_row [n+1], tile_atom [n+1]) or None when one molecule alone exceeds a tile.  Molecules without atoms and
+    bonds belong to no tile."""
+    rows, atoms = [], []
+    r = a = 0          # running offsets
+    tr = ta = 0        # start of the open tile
+    open_tile = False
+    for na, ne in zip(n_atoms, n_edges):
+        na, ne = int(na), int(ne)
+        if na > max_atoms or ne > max_rows:
+            return None
+        if open_tile and (a + na - ta > max_atoms or r + ne - tr > max_rows):
+            open_tile = False
+        if not open_tile and (na or ne):
+            rows.append(r); atoms.append(a)
+            tr, ta, open_tile = r, a, True
+        r += ne; a += na
+    rows.append(r); atoms.append(a)
+    return np.array(rows, dtype=np.int32), np.array(atoms, dtype=np.int32)

@@ -121,3 +121,128 @@ def test_device_collate_full_size_and_forward(n_mols, kind, gpu_device):
     mp = BondMessagePassing().eval().to(gpu_device)
     with torch.no_grad():
         assert torch.equal(mp(bmg), mp(host))
+
+
+# ---- the loader-side tile table (dmpnn_pack_tiles, a HOST function of the library: runs without a GPU) ----
+def _pack_tiles(n_atoms, n_edges):
+    import ctypes as C
+
+    from chemprop_amd import _lib
+
+    lib = _lib.load()
+    ao = np.zeros(len(n_atoms) + 1, np.int32); ao[1:] = np.cumsum(n_atoms)
+    eo = np.zeros(len(n_edges) + 1, np.int32); eo[1:] = np.cumsum(n_edges)
+    cap = int(lib.dmpnn_max_tiles(int(ao[-1]), int(eo[-1]))) + 1
+    tr, ta = np.empty(cap, np.int32), np.empty(cap, np.int32)
+    n = int(lib.dmpnn_pack_tiles(ao.ctypes.data, eo.ctypes.data, len(n_atoms), tr.ctypes.data, ta.ctypes.data, cap))
+    return n, tr[:max(n, 0) + 1], ta[:max(n, 0) + 1]
+
+
+@pytest.mark.parametrize("kind,n_mols,seed", [("qm9", 1, 0), ("qm9", 64, 1), ("qm9", 512, 2), ("qm9", 4096, 3), ("zinc", 40, 4)])
+def test_pack_tiles_vs_oracle(kind, n_mols, seed):
+    from chemprop_amd import synth
+    from oracle import collate_numpy as oc
+
+    mgs = synth.random_molgraphs(n_mols, kind, seed=seed)
+    n_at = [len(m.V) for m in mgs]
+    n_ed = [m.edge_index.shape[1] for m in mgs]
+    want = oc.greedy_molecule_tiles(n_at, n_ed)
+    n, tr, ta = _pack_tiles(n_at, n_ed)
+    if want is None:
+        assert n == -1
+        return
+    assert n == len(want[0]) - 1 and np.array_equal(tr, want[0]) and np.array_equal(ta, want[1])
+    # what the tile kernel needs: whole molecules, <= 48 rows and <= 32 atoms per tile, a partition of the batch
+    assert tr[0] == 0 and ta[0] == 0 and tr[-1] == sum(n_ed) and ta[-1] == sum(n_at)
+    assert (np.diff(tr) <= 48).all() and (np.diff(ta) <= 32).all() and (np.diff(ta) > 0).all()
+    assert set(ta.tolist()) <= set(np.concatenate([[0], np.cumsum(n_at)]).tolist())
+
+
+def test_pack_tiles_edge_cases():
+    from oracle import collate_numpy as oc
+
+    for n_at, n_ed in (([1, 0, 2, 5, 1, 3], [0, 0, 2, 10, 0, 4]), ([0, 0], [0, 0]), ([32], [48]), ([16, 16, 1], [24, 24, 0]), ([3], [0])):
+        want = oc.greedy_molecule_tiles(n_at, n_ed)
+        n, tr, ta = _pack_tiles(n_at, n_ed)
+        assert n == len(want[0]) - 1 and np.array_equal(tr, want[0]) and np.array_equal(ta, want[1]), (n_at, n_ed)
+    assert _pack_tiles([33], [10])[0] == -1 and _pack_tiles([4, 20], [6, 50])[0] == -1   # a molecule larger than a tile
+    assert oc.greedy_molecule_tiles([33], [10]) is None
+
+
+def test_packed_batch_carries_the_tile_table():
+    from chemprop_amd import synth
+    from chemprop_amd.data import PackedBatch
+    from oracle import collate_numpy as oc
+
+    mgs = synth.random_molgraphs(100, "qm9", seed=8)
+    pb = PackedBatch(mgs)
+    w = oc.unpack_wire(pb.buf.numpy())
+    want = oc.greedy_molecule_tiles([len(m.V) for m in mgs], [m.edge_index.shape[1] for m in mgs])
+    assert pb.n_tiles == w["n_tiles"] == len(want[0]) - 1
+    assert np.array_equal(w["tile_row"], want[0]) and np.array_equal(w["tile_atom"], want[1])
+    assert PackedBatch(mgs, tiles=False).n_tiles == -1
+    big = synth.random_molgraphs(6, "synth40", seed=1)  # 40-atom molecules: no table, the device plans decide
+    assert PackedBatch(big).n_tiles == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mols", [512, 4096])
+def test_forward_on_loader_tiles(n_mols, gpu_device):
+    """The tile plan copied from the loader's table gives the same function as the device-built plans (the tile
+    composition differs, so the per-tile f16 scales do: fp32-class agreement, not bits), at any batch size; and it is
+    the whole-forward tile kernel that runs."""
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph, PackedBatch
+    from chemprop_amd.nn import BondMessagePassing
+    from conftest import TOL, parity_err
+    from oracle import dmpnn_torch as ot
+
+    mgs = synth.random_molgraphs(n_mols, "qm9", seed=13)
+    host = BatchMolGraph(mgs)
+    torch.manual_seed(1)
+    mp = BondMessagePassing().eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(host, ot.MPWeights.from_module(mp), depth=mp.depth).numpy()
+    mp = mp.to(gpu_device)
+    packed = PackedBatch(mgs, pin=True)
+    assert packed.n_tiles > 0
+    with torch.no_grad():
+        for i in range(4):  # the first batches of a module are validated on full plans; then tile plans, then the replay path
+            bmg = packed.to_device(gpu_device)
+            out = mp(bmg)
+            assert parity_err(out.cpu().numpy(), ref) <= TOL, i
+        assert mp.__dict__.get("_dmpnn_replay") is not None
+        from chemprop_amd import engine
+
+        plan = engine.GraphPlan.from_bmg(bmg, light="tiles")
+        assert plan.loader_tiles == packed.n_tiles and plan.tiles_only
+        hdr = plan.arrays()["hdr"]
+        assert int(hdr[7]) == 2 and int(hdr[6]) == packed.n_tiles and int(hdr[0]) == 16
+
+
+@pytest.mark.gpu
+def test_a_wrong_loader_table_is_loud(gpu_device):
+    """Tiles that split a molecule (not closed) or exceed the tile limits poison the affected output with NaN."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.data import PackedBatch
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = PackedBatch(synth.random_molgraphs(64, "qm9", seed=2), pin=True).to_device(gpu_device)
+    torch.manual_seed(1)
+    mp = BondMessagePassing(d_h=64).eval().to(gpu_device)
+    p = {k: v for k, v in mp.named_parameters()}
+    fwd = lambda plan: engine.forward(plan, bmg.V, bmg.E, p["W_i.weight"], p["W_h.weight"], p["W_o.weight"], p["W_o.bias"],
+                                      depth=3, act="relu", route="mega")[0]
+    tr, ta, n = bmg.tiles
+    with torch.no_grad():
+        good = fwd(engine.GraphPlan.from_bmg(bmg, light="tiles"))
+        assert torch.isfinite(good).all()
+        tr2, ta2 = tr.clone(), ta.clone()
+        tr2[1] += 2  # tile 0 now takes two edge rows of the next molecule: neither tile is closed
+        bad = fwd(engine.GraphPlan(bmg.edge_index, bmg.rev_edge_index, bmg.V.shape[0], light="tiles", batch=bmg.batch, tiles=(tr2, ta2, n)))
+        a1, a2 = int(ta[1]), int(ta[2])
+        assert torch.isnan(bad[:a2]).any() and torch.equal(bad[a2:], good[a2:]) and a1 < a2
+        tr3, ta3 = tr.clone(), ta.clone()
+        tr3[1:n] = tr[n]; ta3[1:n] = ta[n]  # one tile of everything: exceeds the limits
+        assert torch.isnan(fwd(engine.GraphPlan(bmg.edge_index, bmg.rev_edge_index, bmg.V.shape[0], light="tiles", batch=bmg.batch,
+                                                tiles=(tr3, ta3, n)))).all()

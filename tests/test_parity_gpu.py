@@ -613,5 +613,5 @@ def test_overfit_small_regression(gpu_device):
         loss = torch.nn.functional.mse_loss(head(pooled), y)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] <= 0.05 and losses[-1] < 0.1 * losses[0], (losses[0], losses[-1])
