@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"])
     ap.add_argument("--no-graph", action="store_true", help="time eager launches only (no hipGraph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-batches", action="store_true",
+                    help="skip the side measurements at 4096 / 32768 molecules (profiler runs: keeps every kernel's launches at the headline size)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -314,6 +316,8 @@ def main():
                                    "traffic": None, "launch_us": round(t_k2 * 1e3, 3), "bytes_per_launch": bytes_k2,
                                    "note": "working set fits the 256 MiB Infinity Cache at this batch"}
         try:
+            if args.no_large_batches:
+                raise RuntimeError("skipped (--no-large-batches)")
             big = synth.random_batch(32768, args.kind, seed=5)
             big.to(dev)
             bplan = engine.GraphPlan.from_bmg(big)
@@ -409,7 +413,7 @@ def main():
                 # the same forward on a RESIDENT batch that came through the packed format: its tile table was made by the
                 # loader (dmpnn_pack_tiles), so K0 is a copy of that table and the tile kernel is not limited to small batches
                 lt = {}
-                for n_m in sorted({args.mols, 4096}):
+                for n_m in sorted({args.mols} if args.no_large_batches else {args.mols, 4096}):
                     mg2 = synth.random_molgraphs(n_m, args.kind, seed=1000 + rank)
                     pb = PackedBatch(mg2, pin=True)
                     if pb.n_tiles <= 0:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: smoke, GPU parity tests, bench, probe, rocprofv3 kernel stats + PMC traffic passes.
 # Everything lands in gpurun_out/<tag>/.
-# usage: gpurun --timeout 1500 -- 'bash scripts/gpu_check.sh [tag] [quick]'
+# usage: gpurun --timeout 1500 -- 'bash scripts/gpu_check.sh [tag] [full|quick|prof]'   (prof: only the profiler passes)
 TAG=${1:-r01}
 QUICK=${2:-full}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,6 +9,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd $REPO
 export PYTHONUNBUFFERED=1
+if [ "$QUICK" != "prof" ]; then
 echo "== smoke" | tee $OUT/summary.txt
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt
 tail -6 $OUT/smoke.log | tee -a $OUT/summary.txt
@@ -31,16 +32,20 @@ echo "== bench train" | tee -a $OUT/summary.txt
 timeout 600 python bench.py --steps 100 --warmup 10 --mode train --no-cpu-baseline > $OUT/bench_train.json 2> $OUT/bench_train.err; echo "bench train rc=$?" | tee -a $OUT/summary.txt
 cut -c1-900 $OUT/bench_train.json | tee -a $OUT/summary.txt; tail -3 $OUT/bench_train.err | tee -a $OUT/summary.txt
 fi
-echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
+fi
+echo "== rocprofv3 kernel stats (bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph --no-large-batches)" | tee -a $OUT/summary.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $OUT/prof_bench.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph --no-large-batches > $OUT/prof_bench.json 2> $OUT/prof.err
 echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -16 $f | cut -c1-260 | tee -a $OUT/summary.txt; done
 if [ "$QUICK" != "quick" ]; then
+echo "== rocprofv3 kernel stats, training step (bench.py --mode train --steps 50 --warmup 10 --no-cpu-baseline --no-graph)" | tee -a $OUT/summary.txt
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python $REPO/bench.py --mode train --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $OUT/prof_train.json 2> $OUT/prof_train.err
+for f in $(find $OUT/prof_train -name "*kernel_stats.csv"); do head -12 $f | cut -c1-200 | tee -a $OUT/summary.txt; done
 echo "== rocprofv3 PMC passes (separate runs, counters only)" | tee -a $OUT/summary.txt
-timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $OUT/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $OUT/pmc_write.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $OUT/pmc_sq -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $OUT/pmc_sq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-large-batches > $OUT/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-large-batches > $OUT/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $OUT/pmc_sq -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-large-batches > $OUT/pmc_sq.log 2>&1
 cd $REPO
 python scripts/pmc_traffic.py $OUT | tee -a $OUT/summary.txt
 fi
