@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
-           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip"]
+           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp"]
 ABI_VERSION = 3
 PLAN_NOFFSETS = 15
@@ -32,7 +32,7 @@ EXPORTS = [
     "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
-    "dmpnn_prepare_tiles_from_table",
+    "dmpnn_prepare_tiles_from_table", "dmpnn_tile_plan_any_size",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -193,6 +193,7 @@ def load() -> C.CDLL:
     lib.dmpnn_pack_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
     lib.dmpnn_pack_tiles.restype = C.c_int64
     lib.dmpnn_max_tiles.argtypes = [C.c_int64, C.c_int64]
+    lib.dmpnn_tile_plan_any_size.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_max_tiles.restype = C.c_int64
     lib.dmpnn_prepare_tiles_from_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
                                                    C.c_void_p]

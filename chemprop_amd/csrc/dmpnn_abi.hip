@@ -105,8 +105,21 @@ int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, const int
         }
         return launch_prepare_tiles_batch(edge_index, batch, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream));
     }
+    if (batch && dmpnn_tile_plan_any_size(n_atoms, n_edges) && !small_plan_fits(n_atoms, n_edges)) {
+        // a batch beyond the single-workgroup plan: the same tables from three multi-workgroup launches
+        DMPNN_TRY(check_graph_sizes(n_atoms, n_edges));
+        DMPNN_CHECK_ARG(plan != nullptr && aligned16(plan), "prepare_tiles: plan must be a 16-byte aligned buffer");
+        DMPNN_CHECK_ARG(n_edges == 0 || edge_index, "prepare_tiles: null edge_index");
+        if (plan_bytes < dmpnn_plan_bytes(n_atoms, n_edges)) {
+            set_error("prepare_tiles: plan buffer too small (%zu < %zu bytes)", plan_bytes, dmpnn_plan_bytes(n_atoms, n_edges));
+            return DMPNN_ENOSPC;
+        }
+        return launch_prepare_tiles_large(edge_index, batch, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream));
+    }
     return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 2, stream);
 }
+
+int dmpnn_tile_plan_any_size(int64_t n_atoms, int64_t n_edges) { return tiles_large_fits(n_atoms, n_edges) ? 1 : 0; }
 
 int dmpnn_message_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h, const float* Hin,
                       int64_t ld_in, float* M, int64_t ld_m, int act_on_load, float act_slope,

@@ -147,6 +147,9 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV, int64_t nE, int* plan,
                    int light, hipStream_t s);
 int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s);
+// the same tables for batches beyond the single-workgroup plan (dmpnn_tiles_large.hip)
+bool tiles_large_fits(int64_t nV, int64_t nE);
+int launch_prepare_tiles_large(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s);
 // batches the single-workgroup plan (and therefore the piece tiles / the whole-forward tile kernel) takes
 constexpr int kSmallPlanMaxAtoms = 6144, kSmallPlanMaxEdges = 10240;
 inline size_t small_plan_lds_bytes(int64_t nV, int64_t nE) {

@@ -95,7 +95,8 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 class GraphPlan:
     """K0: int32 indices + stable incoming-edge CSR of one batch, built on device (no host sync)."""
 
-    __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index", "loader_tiles")
+    __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index", "loader_tiles",
+                 "any_size")
 
     def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False, batch: Optional[Tensor] = None,
                  tiles: Optional[tuple] = None):
@@ -122,8 +123,15 @@ class GraphPlan:
             if (tr.dtype == torch.int32 and ta.dtype == torch.int32 and tr.device == dev and ta.device == dev
                     and tr.is_contiguous() and ta.is_contiguous() and tr.numel() > nt and ta.numel() > nt and nt > 0):
                 self.loader_tiles = int(nt)
-        self.tiles_only = light == "tiles" and (small or self.loader_tiles > 0)
-        self.light = bool(light) and (small or self.loader_tiles > 0)
+        # with the batch vector (int64, like the reference's) the tiles are whole molecules found by binary search — in
+        # one workgroup's LDS for small batches, by three multi-workgroup launches beyond (dmpnn_tile_plan_any_size)
+        bt = batch if (batch is not None and batch.dtype == torch.int64 and batch.device == dev
+                       and batch.numel() == n_atoms and batch.is_contiguous()) else None
+        big = (light == "tiles" and not small and not self.loader_tiles and bt is not None and n_atoms > 0
+               and bool(lib.dmpnn_tile_plan_any_size(n_atoms, n_edges)))
+        self.tiles_only = light == "tiles" and (small or self.loader_tiles > 0 or big)
+        self.light = bool(light) and (small or self.loader_tiles > 0 or big)
+        self.any_size = self.tiles_only and not small  # (the forward's DMPNN_F_LOADER_TILES)
         self.edge_index, self.rev_edge_index = ei, rev
         with _OnDevice(dev):
             if self.loader_tiles:
@@ -131,9 +139,6 @@ class GraphPlan:
                                                               n_edges, self.buf.data_ptr(), nbytes, _stream_ptr(dev)),
                            "dmpnn_prepare_tiles_from_table")
             elif self.tiles_only:
-                # with the batch vector (int64, like the reference's) the tiles are whole molecules found by binary search
-                bt = batch if (batch is not None and batch.dtype == torch.int64 and batch.device == dev
-                               and batch.numel() == n_atoms and batch.is_contiguous()) else None
                 _lib.check(lib.dmpnn_prepare_tiles(ei.data_ptr(), rev.data_ptr(), bt.data_ptr() if bt is not None else None,
                                                    n_atoms, n_edges, self.buf.data_ptr(), nbytes, _stream_ptr(dev)),
                            "dmpnn_prepare_tiles")
@@ -371,9 +376,9 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     a.edge_index, a.rev_edge_index = plan.edge_index.data_ptr(), plan.rev_edge_index.data_ptr()
     a.d_v, a.d_e, a.d_h, a.d_vd = d_v, d_e, d_h, d_vd
     a.depth, a.flags = int(depth), (F_UNDIRECTED if undirected else 0)
-    if getattr(plan, "loader_tiles", 0):
-        a.flags |= F_LOADER_TILES
-        a.n_tiles_launch = plan.loader_tiles
+    if getattr(plan, "loader_tiles", 0) or getattr(plan, "any_size", False):
+        a.flags |= F_LOADER_TILES              # a tile plan of any batch size
+        a.n_tiles_launch = plan.loader_tiles   # (0: the launch bound — the tile count is on the device only)
     a.act, a.act_slope, a.act_slope_ptr = act_code(act), float(slope), _ptr(slope_t)
     a.V, a.ldv = V.data_ptr(), V.stride(0)
     a.E, a.lde = E.data_ptr(), E.stride(0)

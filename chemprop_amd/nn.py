@@ -168,7 +168,9 @@ def _replay_forward(mp, r: "_Replay", bmg):
     tiles = getattr(bmg, "tiles", None)
     if tiles is not None and (tiles[0].device != dev or tiles[2] <= 0):
         tiles = None
-    if (n_mols <= 0 or nE > 30 * n_mols or nE == 0 or (tiles is None and not engine.small_plan_fits(nV, nE)) or batch.numel() != nV
+    small = engine.small_plan_fits(nV, nE)
+    if (n_mols <= 0 or nE > 30 * n_mols or nE == 0 or (tiles is None and not small and not _lib.load().dmpnn_tile_plan_any_size(nV, nE))
+            or batch.numel() != nV
             or ei.shape[1] != nE or rev.numel() != nE or getattr(mp, "_dmpnn_no_mega", False)):
         return None
     lib = _lib.load()
@@ -191,7 +193,7 @@ def _replay_forward(mp, r: "_Replay", bmg):
             _lib.check(lib.dmpnn_prepare_tiles_from_table(tiles[0].data_ptr(), tiles[1].data_ptr(), tiles[2], nV, nE, pb, nbytes, stream),
                        "dmpnn_prepare_tiles_from_table")
         else:
-            a.flags &= ~_lib.F_LOADER_TILES
+            a.flags = (a.flags & ~_lib.F_LOADER_TILES) | (0 if small else _lib.F_LOADER_TILES)
             a.n_tiles_launch = 0
             _lib.check(lib.dmpnn_prepare_tiles(a.edge_index, a.rev_edge_index, batch.data_ptr(), nV, nE, pb, nbytes, stream), "dmpnn_prepare_tiles")
         _lib.check(lib.dmpnn_forward(_ctypes.byref(a), stream), "dmpnn_forward")
@@ -222,7 +224,11 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
-    loader_tiles = getattr(bmg, "tiles", None) is not None  # (PackedBatch: the tile table came with the batch)
+    # a tile plan at any batch size: the table came with the batch (PackedBatch), or the batch vector is there for the
+    # multi-workgroup planner
+    loader_tiles = getattr(bmg, "tiles", None) is not None or (
+        getattr(bmg, "batch", None) is not None and not engine.small_plan_fits(int(bmg.V.shape[0]), int(bmg.E.shape[0]))
+        and bool(_lib.load().dmpnn_tile_plan_any_size(int(bmg.V.shape[0]), int(bmg.E.shape[0]))))
     light = _light_plan_ok(mp) and (int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES or loader_tiles)
     if light and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
         light = "tiles"
@@ -234,7 +240,7 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
 
         note_batch(bmg.batch, n_mols)  # the aggregation that follows (model.py:131) skips its host read of batch.max()
     mp.__dict__.pop("_dmpnn_last", None)
-    out = mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols))
+    out = mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols, getattr(bmg, "batch", None)))
     if light == "tiles" and V_d is None and not torch.is_grad_enabled() and _lib.opt("DMPNN_REPLAY", "1") != "0":
         _make_replay(mp, plan, mp.__dict__.pop("_dmpnn_last", None))
     return out
@@ -270,7 +276,7 @@ def _tile_plan_ok(mp, n_atoms: int, n_edges: int, n_mols: int, loader_tiles: boo
     return n_mols > 0 and n_edges <= 30 * n_mols and (loader_tiles or engine.small_plan_fits(n_atoms, n_edges))
 
 
-def _route(mp, plan, n_mols: int = 0) -> int:
+def _route(mp, plan, n_mols: int = 0, batch=None) -> int:
     """Cap on the route of this batch: 2 (whole-forward tile kernel), 1 (per-step fused) or 0 (general).
 
     The fused kernels assume a molecular graph (``rev`` an involution with ``src(rev e) == dst(e)``,
@@ -297,6 +303,11 @@ def _route(mp, plan, n_mols: int = 0) -> int:
             # beyond the single-workgroup plan has none either way, which says nothing about its molecules
             if engine.small_plan_fits(plan.n_atoms, plan.n_edges):
                 object.__setattr__(mp, "_dmpnn_no_mega", True)
+            elif batch is not None and not no_mega and _lib.load().dmpnn_tile_plan_any_size(plan.n_atoms, plan.n_edges):
+                # (validated batches only: the multi-workgroup tile planner's verdict on the molecule sizes of this batch)
+                tp = engine.GraphPlan(plan.edge_index, plan.rev_edge_index, plan.n_atoms, light="tiles", batch=batch)
+                if tp.tiles_only and tp.flags() & 8:
+                    object.__setattr__(mp, "_dmpnn_no_mega", True)
             return 1
     return 1 if no_mega else 2
 

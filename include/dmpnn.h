@@ -69,8 +69,9 @@ enum dmpnn_flags {
                                      dmpnn_forward wrote for exactly these W_i / W_h / W_o values and shapes
                                      (the CALLER vouches for it, e.g. inference with frozen weights): the
                                      pre-split launch is skipped                                          */
-    DMPNN_F_LOADER_TILES = 1u << 6 /* `plan` is a tile plan made by dmpnn_prepare_tiles_from_table: DMPNN_F_MEGA is
-                                     not limited to batches the single-workgroup plan takes                 */
+    DMPNN_F_LOADER_TILES = 1u << 6 /* `plan` is a tile plan of a batch of ANY size (dmpnn_prepare_tiles_from_table, or
+                                     dmpnn_prepare_tiles with a batch vector where dmpnn_tile_plan_any_size()):
+                                     DMPNN_F_MEGA is not limited to batches the single-workgroup plan takes     */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -104,6 +105,11 @@ int dmpnn_prepare_light(const int64_t* edge_index, const int64_t* rev_edge_index
  * analysis; without it of whole connected pieces as in the full plan.                                            */
 int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev_edge_index, const int64_t* batch, int64_t n_atoms,
                         int64_t n_edges, void* plan, size_t plan_bytes, void* stream);
+/* 1 when dmpnn_prepare_tiles WITH a batch vector writes a tile plan for a batch of this size even beyond the
+ * single-workgroup plan (three multi-workgroup launches; their scratch must fit the plan's unused arrays): a forward on
+ * it passes DMPNN_F_LOADER_TILES ("tile plan of any batch size") like one on a loader table.  Without a batch vector, or
+ * when this returns 0, a batch beyond the single-workgroup plan gets the full plan, which has no piece tiles. */
+int dmpnn_tile_plan_any_size(int64_t n_atoms, int64_t n_edges);
 
 /* Plan header words (int32) readable by the caller after a stream sync (diagnostics/tests). */
 enum dmpnn_plan_hdr {

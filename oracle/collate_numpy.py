@@ -73,3 +73,27 @@ def greedy_molecule_tiles(n_atoms, n_edges, max_rows: int = 48, max_atoms: int =
         r += ne; a += na
     rows.append(r); atoms.append(a)
     return np.array(rows, dtype=np.int32), np.array(atoms, dtype=np.int32)
+
+
+def blocked_molecule_tiles(n_atoms, n_edges, block: int = 64, max_rows: int = 48, max_atoms: int = 32):
+    """The DEVICE tile planners' packing (k_prepare_tiles_batch for small batches, dmpnn_tiles_large.hip beyond): greedy as
+    above, except that a tile also starts at every block of ``block`` consecutive molecules (the blocks are walked in
+    parallel).  -> (tile_row [n+1], tile_atom [n+1]) or None when a molecule alone exceeds a tile."""
+    n_atoms, n_edges = [int(x) for x in n_atoms], [int(x) for x in n_edges]
+    n = len(n_atoms)
+    ao = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
+    eo = np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int64)
+    if any(a > max_atoms for a in n_atoms) or any(e > max_rows for e in n_edges):
+        return None
+    rows, atoms = [], []
+    for base in range(0, n, block):
+        lim = min(base + block, n)
+        p = base
+        while p < lim:
+            rows.append(int(eo[p])); atoms.append(int(ao[p]))
+            q = p + 1
+            while q < n and ao[q + 1] - ao[p] <= max_atoms and eo[q + 1] - eo[p] <= max_rows:
+                q += 1
+            p = q
+    rows.append(int(eo[n])); atoms.append(int(ao[n]))
+    return np.array(rows, dtype=np.int32), np.array(atoms, dtype=np.int32)

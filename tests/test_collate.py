@@ -246,3 +246,77 @@ def test_a_wrong_loader_table_is_loud(gpu_device):
         tr3[1:n] = tr[n]; ta3[1:n] = ta[n]  # one tile of everything: exceeds the limits
         assert torch.isnan(fwd(engine.GraphPlan(bmg.edge_index, bmg.rev_edge_index, bmg.V.shape[0], light="tiles", batch=bmg.batch,
                                                 tiles=(tr3, ta3, n)))).all()
+
+
+# ---- the multi-workgroup tile planner: batches beyond the single-workgroup plan, handed over as five tensors ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mols,seed", [(2000, 5), (4096, 6), (32768, 7)])
+def test_large_tile_plan_vs_oracle(n_mols, seed, gpu_device):
+    """dmpnn_prepare_tiles with the batch vector on a batch the single-workgroup plan does not take: the blocked greedy
+    tables, bit for bit (integer work), as a tile plan."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.data import BatchMolGraph
+    from oracle import collate_numpy as oc
+
+    mgs = synth.random_molgraphs(n_mols, "qm9", seed=seed)
+    bmg = BatchMolGraph(mgs)
+    bmg.to(gpu_device)
+    nV, nE = int(bmg.V.shape[0]), int(bmg.E.shape[0])
+    assert not engine.small_plan_fits(nV, nE)
+    plan = engine.GraphPlan.from_bmg(bmg, light="tiles")
+    assert plan.tiles_only and plan.any_size and plan.loader_tiles == 0
+    arr = plan.arrays()
+    want = oc.blocked_molecule_tiles([len(m.V) for m in mgs], [m.edge_index.shape[1] for m in mgs])
+    n = len(want[0]) - 1
+    hdr = arr["hdr"]
+    assert int(hdr[0]) == 16 and int(hdr[7]) == 2 and int(hdr[6]) == n and int(hdr[2]) == nV and int(hdr[3]) == nE
+    assert np.array_equal(arr["mtile_row"][:n + 1].numpy(), want[0]) and np.array_equal(arr["mtile_atom"][:n + 1].numpy(), want[1])
+    assert (arr["mtile_row"][n:] == nE).all() and (arr["mtile_atom"][n:] == nV).all()
+
+
+@pytest.mark.gpu
+def test_large_batch_of_five_tensors_takes_the_tile_kernel(gpu_device):
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph
+    from chemprop_amd.nn import BondMessagePassing
+    from conftest import TOL, parity_err
+    from oracle import dmpnn_torch as ot
+
+    mgs = synth.random_molgraphs(4096, "qm9", seed=17)
+    host = BatchMolGraph(mgs)
+    torch.manual_seed(2)
+    mp = BondMessagePassing().eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(host, ot.MPWeights.from_module(mp), depth=mp.depth).numpy()
+    mp = mp.to(gpu_device)
+    host.to(gpu_device)
+    with torch.no_grad():
+        for i in range(4):  # validated batches (full plan, per-step route), then the tile plan, then the replay path
+            assert parity_err(mp(host).cpu().numpy(), ref) <= TOL, i
+    assert mp.__dict__.get("_dmpnn_replay") is not None and not getattr(mp, "_dmpnn_no_mega", False)
+
+
+@pytest.mark.gpu
+def test_large_tile_plan_flags_an_oversize_molecule(gpu_device):
+    """One 40-atom molecule among 3000 small ones: no piece tiles (bit 3), the module keeps the per-step route."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.data import BatchMolGraph
+    from chemprop_amd.nn import BondMessagePassing
+    from conftest import TOL, parity_err
+    from oracle import dmpnn_torch as ot
+
+    mgs = synth.random_molgraphs(3000, "qm9", seed=3)
+    mgs[1234] = synth.random_molgraphs(1, "synth40", seed=9)[0]
+    host = BatchMolGraph(mgs)
+    torch.manual_seed(2)
+    mp = BondMessagePassing().eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(host, ot.MPWeights.from_module(mp), depth=mp.depth).numpy()
+    host.to(gpu_device)
+    plan = engine.GraphPlan.from_bmg(host, light="tiles")
+    assert plan.tiles_only and plan.flags() & 8
+    mp = mp.to(gpu_device)
+    with torch.no_grad():
+        for i in range(4):
+            assert parity_err(mp(host).cpu().numpy(), ref) <= TOL, i
+    assert getattr(mp, "_dmpnn_no_mega", False)
