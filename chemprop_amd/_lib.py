@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp"]
-ABI_VERSION = 3
+ABI_VERSION = 4
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them

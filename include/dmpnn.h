@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 3
+#define DMPNN_ABI_VERSION 4
 
 enum dmpnn_status {
     DMPNN_OK = 0,
