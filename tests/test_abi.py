@@ -101,3 +101,41 @@ def test_build_is_gfx950_only():
         pytest.skip("llvm-objdump --offloading unavailable")
     assert "gfx950" in out.stdout
     assert "gfx942" not in out.stdout and "gfx90a" not in out.stdout
+
+
+def test_tile_plans_of_any_size_shape_rules_and_argument_errors():
+    """The loader-table / any-size tile plan entry points: shape rules and argument validation (no device work)."""
+    lib = _lib.load()
+    a = _lib.FwdArgs()
+    a.n_atoms, a.n_edges, a.d_v, a.d_e, a.d_h, a.depth = 100000, 200000, 72, 14, 300, 3
+    a.ldv, a.lde, a.ldh, a.ldout = 72, 14, 300, 300
+    for f in ("V", "E", "W_i", "W_h", "H0", "Ms", "Mv"):
+        setattr(a, f, 4096)
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 1
+    a.flags = _lib.F_LOADER_TILES
+    assert lib.dmpnn_forward_can_fuse(C.byref(a)) == 2   # a tile plan of any batch size lifts the single-workgroup limit
+    assert lib.dmpnn_tile_plan_any_size(37000, 73000) == 1 and lib.dmpnn_tile_plan_any_size(300000, 580000) == 1
+    assert lib.dmpnn_tile_plan_any_size(5000, 0) == 0      # no room for the planner's scratch in an edge-less plan
+    assert lib.dmpnn_tile_plan_any_size(0, 0) == 0
+    cap = lib.dmpnn_max_tiles(4636, 9120)
+    assert cap >= 2 * (9120 // 48 + 4636 // 32)
+    # from_table: null plan, more tiles than the launch bound of the batch size -> error codes, nothing launched
+    assert lib.dmpnn_prepare_tiles_from_table(4096, 4096, 10, 100, 200, None, 1 << 20, None) == -1
+    assert lib.dmpnn_prepare_tiles_from_table(4096, 4096, cap + 1, 4636, 9120, 4096, 1 << 30, None) == -1
+    assert b"launch bound" in lib.dmpnn_last_error_string()
+    assert lib.dmpnn_prepare_tiles_from_table(4096, 4096, 10, 4636, 9120, 4096, 64, None) == -3   # plan buffer too small
+    # pack_tiles (host): bad arguments
+    import numpy as np
+
+    ao = np.array([0, 3, 6], np.int32)
+    eo = np.array([0, 4, 8], np.int32)
+    tr, ta = np.zeros(8, np.int32), np.zeros(8, np.int32)
+    assert lib.dmpnn_pack_tiles(ao.ctypes.data, eo.ctypes.data, 2, tr.ctypes.data, ta.ctypes.data, 8) == 1
+    assert tr[:2].tolist() == [0, 8] and ta[:2].tolist() == [0, 6]
+    assert lib.dmpnn_pack_tiles(ao.ctypes.data, eo.ctypes.data, 2, tr.ctypes.data, ta.ctypes.data, 1) == -2   # cap too small
+    assert lib.dmpnn_pack_tiles(None, None, 2, tr.ctypes.data, ta.ctypes.data, 8) == -2
+    assert lib.dmpnn_pack_tiles(ao.ctypes.data, eo.ctypes.data, -1, tr.ctypes.data, ta.ctypes.data, 8) == -2
+    # collate: sizes
+    assert lib.dmpnn_collate(None, None, 0, None, None, None, 0, 0, None, None, None, None) == 0     # empty batch: nothing to do
+    assert lib.dmpnn_collate(None, None, 0, None, None, None, 5, 0, None, None, 4096, None) == -1    # atoms without molecules
+    assert lib.dmpnn_collate(4096, 4096, 1, None, None, None, 5, 4, None, None, 4096, None) == -1    # null edge arrays
