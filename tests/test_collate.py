@@ -320,3 +320,71 @@ def test_large_tile_plan_flags_an_oversize_molecule(gpu_device):
         for i in range(4):
             assert parity_err(mp(host).cpu().numpy(), ref) <= TOL, i
     assert getattr(mp, "_dmpnn_no_mega", False)
+
+
+# ---- properties of the host-side packers over arbitrary molecule-size sequences (hypothesis; no GPU) ----
+def test_pack_tiles_properties():
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from oracle import collate_numpy as oc
+
+    sizes = st.lists(st.tuples(st.integers(0, 34), st.integers(0, 52)), min_size=0, max_size=300)
+
+    @settings(max_examples=300, deadline=None)
+    @given(sizes)
+    def prop(mols):
+        n_at = [a for a, _ in mols]
+        n_ed = [2 * (e // 2) if a >= 2 else 0 for a, e in mols]  # directed edges come in pairs; none without two atoms
+        want = oc.greedy_molecule_tiles(n_at, n_ed)
+        n, tr, ta = _pack_tiles(n_at, n_ed)
+        if want is None:
+            assert n == -1
+            return
+        assert n == len(want[0]) - 1 and np.array_equal(tr, want[0]) and np.array_equal(ta, want[1])
+        # a partition of the batch into consecutive whole molecules within the tile limits, and greedy: no two consecutive
+        # tiles could have been one
+        ao = np.concatenate([[0], np.cumsum(n_at)]); eo = np.concatenate([[0], np.cumsum(n_ed)])
+        assert tr[-1] == eo[-1] and ta[-1] == ao[-1]
+        if n:
+            assert (np.diff(tr) <= 48).all() and (np.diff(ta) <= 32).all() and (np.diff(tr) >= 0).all() and (np.diff(ta) >= 0).all()
+            for t in range(n - 1):
+                assert tr[t + 2] - tr[t] > 48 or ta[t + 2] - ta[t] > 32 or (tr[t + 1] == tr[t] and ta[t + 1] == ta[t])
+            bounds = set(zip(ao.tolist(), eo.tolist()))
+            assert all((int(a), int(r)) in bounds for a, r in zip(ta, tr))
+        blocked = oc.blocked_molecule_tiles(n_at, n_ed)
+        assert n <= len(blocked[0]) - 1 <= n + (len(n_at) + 63) // 64 + 1
+
+    prop()
+
+
+def test_packed_batch_roundtrip_properties():
+    """Random molecule lists (including empty molecules and lone atoms): wire bytes -> oracle decode == reference batching."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from chemprop_amd.data import MolGraph, PackedBatch
+    from oracle import collate_numpy as oc
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.integers(0, 12), min_size=1, max_size=40), st.integers(0, 2 ** 31 - 1))
+    def prop(n_atoms, seed):
+        rng = np.random.default_rng(seed)
+        mgs = []
+        for n in n_atoms:
+            pairs = [(i, int(rng.integers(0, i))) for i in range(1, n)]  # a random tree
+            nb = len(pairs)
+            src = np.array([a for a, b in pairs] + [b for a, b in pairs], dtype=np.int64)
+            dst = np.array([b for a, b in pairs] + [a for a, b in pairs], dtype=np.int64)
+            rev = np.concatenate([np.arange(nb) + nb, np.arange(nb)]).astype(np.int64)
+            mgs.append(MolGraph(V=rng.random((n, 5), dtype=np.float32), E=rng.random((2 * nb, 3), dtype=np.float32),
+                                edge_index=np.stack([src, dst]) if nb else np.zeros((2, 0), np.int64), rev_edge_index=rev))
+        pb = PackedBatch(mgs)
+        got, want = oc.unpack_wire(pb.buf.numpy()), oc.collate(mgs)
+        _same(got, want)
+        assert pb.n_tiles == got["n_tiles"]
+        if sum(n_atoms):
+            tiles = oc.greedy_molecule_tiles(n_atoms, [m.edge_index.shape[1] for m in mgs])
+            assert pb.n_tiles == len(tiles[0]) - 1 and np.array_equal(got["tile_row"], tiles[0])
+
+    prop()
