@@ -316,8 +316,8 @@ def main():
                                    "traffic": None, "launch_us": round(t_k2 * 1e3, 3), "bytes_per_launch": bytes_k2,
                                    "note": "working set fits the 256 MiB Infinity Cache at this batch"}
         try:
-            if args.no_large_batches:
-                raise RuntimeError("skipped (--no-large-batches)")
+            if args.no_large_batches or world > 1:  # (multi-GPU runs: the other ranks wait at the final barrier meanwhile)
+                raise RuntimeError("skipped (--no-large-batches)" if world == 1 else "skipped (N > 1: side measurements are taken at N = 1)")
             big = synth.random_batch(32768, args.kind, seed=5)
             big.to(dev)
             bplan = engine.GraphPlan.from_bmg(big)
