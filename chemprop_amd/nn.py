@@ -256,7 +256,9 @@ def _light_plan_ok(mp) -> bool:
         return False
     if mp.undirected or (mp.training and mp.dropout.p > 0) or classify_activation(mp.tau)[0] == "custom":
         return False
-    if _lib.opt("DMPNN_GENERAL", "0") == "1" or getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N:
+    if _lib.opt("DMPNN_GENERAL", "0") == "1":
+        return False
+    if _lib.opt("DMPNN_VALIDATE", "first") != "never" and getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N:
         return False  # the first batches may still be routed to the general kernels by the validation
     d_h, d_in = mp.W_h.weight.shape[0], mp.W_i.weight.shape[1]
     d_v = mp.W_o.weight.shape[1] - d_h

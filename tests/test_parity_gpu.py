@@ -615,3 +615,27 @@ def test_overfit_small_regression(gpu_device):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] <= 0.05 and losses[-1] < 0.1 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.parametrize("mode", ["never", "always", "first"])
+def test_validate_modes_give_the_same_function(mode, gpu_device, monkeypatch):
+    """DMPNN_VALIDATE decides when the plan's verdict is read (and which plan a forward builds), not the result:
+    `never` takes the tile plan from the first batch on, `always` keeps reading a full / light plan."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    monkeypatch.setenv("DMPNN_VALIDATE", mode)
+    bmg = synth.random_batch(96, "qm9", seed=31)
+    torch.manual_seed(4)
+    mp = BondMessagePassing().eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(bmg, ot.MPWeights.from_module(mp), depth=mp.depth).numpy()
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    with torch.no_grad():
+        for i in range(4):
+            assert parity_err(mp(bmg).cpu().numpy(), ref) <= TOL, (mode, i)
+    replay = mp.__dict__.get("_dmpnn_replay") is not None
+    assert replay == (mode != "always")  # the steady tile-plan path exists unless every batch is validated
+    assert getattr(mp, "_dmpnn_batches_checked", 0) == {"never": 0, "always": 4, "first": 2}[mode]
