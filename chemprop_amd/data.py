@@ -83,7 +83,7 @@ class BatchMolGraph:
 
 # ---- f3: one-buffer wire format + device-side batching (collate.py:37-62,68-73) -----------------
 _WIRE_MAGIC = 0x31424D44  # "DMB1"
-_WIRE_HEADER = 8          # int64 words: magic, n_mols, n_atoms, n_edges, d_v, d_e, n_tiles (-1: no table), 0
+_WIRE_HEADER = 8          # int64 words: magic, n_mols, n_atoms, n_edges, d_v, d_e, n_tiles (-1: no table), rows of E
 
 
 def _align16(n: int) -> int:
@@ -93,11 +93,12 @@ def _align16(n: int) -> int:
 class PackedBatch:
     """A batch of :class:`MolGraph` in ONE host buffer, built in the DataLoader worker (``collate_fn``):
 
-        int64  header[8]            magic, n_mols, n_atoms, n_edges, d_v, d_e, n_tiles (-1: no tile table), 0
+        int64  header[8]            magic, n_mols, n_atoms, n_edges, d_v, d_e, n_tiles (-1: no tile table), rows of E
         int32  atom_off[n_mols+1]   running atom count   (collate.py:46,56: ``num_nodes``)
         int32  edge_off[n_mols+1]   running edge count   (collate.py:47,57: ``num_edges``)
         int32  src[n_edges] | dst[n_edges] | rev[n_edges]      molecule-LOCAL ids, as the featurizer made them
-        f32    V[n_atoms, d_v] | E[n_edges, d_e]
+        f32    V[n_atoms, d_v] | E[rows of E, d_e]   (the reference concatenates ``mg.E`` as given, collate.py:59: one row per
+                                    directed edge from its featurizers, whatever a hand-built MolGraph holds)
         int32  tile_row[n_tiles+1] | tile_atom[n_tiles+1]     whole molecules packed greedily into tiles of <= 48 directed
                                     edges / <= 32 atoms (``dmpnn_pack_tiles``, a host function of the library): the tile
                                     plan of the whole-forward tile kernel, made where the molecule sizes are known
@@ -110,13 +111,14 @@ class PackedBatch:
     ``V`` / ``E`` are views of the copied buffer and whose index tensors are the int64 tensors the reference builds,
     bit for bit.  No arithmetic of the batching happens on the host beyond the two running sums."""
 
-    __slots__ = ("buf", "n_mols", "n_atoms", "n_edges", "d_v", "d_e", "sections", "n_tiles")
+    __slots__ = ("buf", "n_mols", "n_atoms", "n_edges", "n_erows", "d_v", "d_e", "sections", "n_tiles")
 
     def __init__(self, mgs: Sequence[MolGraph], pin: bool = False, tiles: bool = True):
         n_mols = len(mgs)
         n_at = np.fromiter((len(mg.V) for mg in mgs), dtype=np.int64, count=n_mols)
         n_ed = np.fromiter((mg.edge_index.shape[1] for mg in mgs), dtype=np.int64, count=n_mols)
         nV, nE = int(n_at.sum()), int(n_ed.sum())
+        nEr = int(sum(len(mg.E) for mg in mgs))  # rows of E as given (== nE for featurizer-made graphs)
         if nV >= 2 ** 31 or nE >= 2 ** 31:
             raise ValueError("PackedBatch: more than 2^31 atoms or edges in one batch")
         d_v = int(mgs[0].V.shape[1]) if n_mols else 0
@@ -139,7 +141,7 @@ class PackedBatch:
         nt = n_tiles + 1 if n_tiles >= 0 else 0
         sec, o = {}, _WIRE_HEADER * 8
         for name, nbytes in (("atom_off", 4 * (n_mols + 1)), ("edge_off", 4 * (n_mols + 1)), ("src", 4 * nE), ("dst", 4 * nE),
-                             ("rev", 4 * nE), ("V", 4 * nV * d_v), ("E", 4 * nE * d_e), ("tile_row", 4 * nt), ("tile_atom", 4 * nt)):
+                             ("rev", 4 * nE), ("V", 4 * nV * d_v), ("E", 4 * nEr * d_e), ("tile_row", 4 * nt), ("tile_atom", 4 * nt)):
             sec[name] = (o, nbytes)
             o = _align16(o + nbytes)
         buf = torch.zeros(o, dtype=torch.uint8)
@@ -147,7 +149,7 @@ class PackedBatch:
             buf = buf.pin_memory()
         raw = buf.numpy()
         view = lambda name, dt: raw[sec[name][0]:sec[name][0] + sec[name][1]].view(dt)
-        raw[:_WIRE_HEADER * 8].view(np.int64)[:7] = (_WIRE_MAGIC, n_mols, nV, nE, d_v, d_e, n_tiles)
+        raw[:_WIRE_HEADER * 8].view(np.int64)[:8] = (_WIRE_MAGIC, n_mols, nV, nE, d_v, d_e, n_tiles, nEr)
         view("atom_off", np.int32)[:] = atom_off
         view("edge_off", np.int32)[:] = edge_off
         if nt:
@@ -158,13 +160,13 @@ class PackedBatch:
                 view("src", np.int32)[:] = np.concatenate([mg.edge_index[0] for mg in mgs])
                 view("dst", np.int32)[:] = np.concatenate([mg.edge_index[1] for mg in mgs])
                 view("rev", np.int32)[:] = np.concatenate([mg.rev_edge_index for mg in mgs])
-                if d_e:
-                    view("E", np.float32).reshape(nE, d_e)[:] = np.concatenate([mg.E for mg in mgs])
+            if nEr and d_e:
+                view("E", np.float32).reshape(nEr, d_e)[:] = np.concatenate([mg.E for mg in mgs])
             if nV and d_v:
                 view("V", np.float32).reshape(nV, d_v)[:] = np.concatenate([mg.V for mg in mgs])
         self.buf, self.sections = buf, sec
         self.n_mols, self.n_atoms, self.n_edges, self.d_v, self.d_e = n_mols, nV, nE, d_v, d_e
-        self.n_tiles = n_tiles
+        self.n_tiles, self.n_erows = n_tiles, nEr
 
     def __len__(self) -> int:
         return self.n_mols
@@ -185,7 +187,7 @@ class PackedBatch:
         nV, nE = self.n_atoms, self.n_edges
         sl = lambda name: dbuf[self.sections[name][0]:self.sections[name][0] + self.sections[name][1]]
         V = sl("V").view(torch.float32).view(nV, self.d_v)
-        E = sl("E").view(torch.float32).view(nE, self.d_e)
+        E = sl("E").view(torch.float32).view(self.n_erows, self.d_e)
         edge_index = torch.empty(2, nE, dtype=torch.int64, device=device)
         rev = torch.empty(nE, dtype=torch.int64, device=device)
         batch = torch.empty(nV, dtype=torch.int64, device=device)

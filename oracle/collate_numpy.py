@@ -30,14 +30,14 @@ def unpack_wire(raw: np.ndarray):
     """Decode the one-buffer wire format of chemprop_amd/data.py (PackedBatch) on the host and batch it the reference's
     way: what ``dmpnn_collate`` must produce from the same bytes."""
     hdr = raw[:64].view(np.int64)
-    magic, n_mols, nV, nE, d_v, d_e, n_tiles = (int(x) for x in hdr[:7])
+    magic, n_mols, nV, nE, d_v, d_e, n_tiles, nEr = (int(x) for x in hdr[:8])
     nt = n_tiles + 1 if n_tiles >= 0 else 0
     assert magic == 0x31424D44
     a16 = lambda n: (n + 15) // 16 * 16
     o = 64
     out = {}
     for name, dt, count in (("atom_off", np.int32, n_mols + 1), ("edge_off", np.int32, n_mols + 1), ("src", np.int32, nE),
-                            ("dst", np.int32, nE), ("rev", np.int32, nE), ("V", np.float32, nV * d_v), ("E", np.float32, nE * d_e),
+                            ("dst", np.int32, nE), ("rev", np.int32, nE), ("V", np.float32, nV * d_v), ("E", np.float32, nEr * d_e),
                             ("tile_row", np.int32, nt), ("tile_atom", np.int32, nt)):
         nbytes = count * np.dtype(dt).itemsize
         out[name] = raw[o:o + nbytes].view(dt)
@@ -47,7 +47,7 @@ def unpack_wire(raw: np.ndarray):
     m_of_edge = np.searchsorted(eo, np.arange(nE), side="right") - 1
     m_of_atom = np.searchsorted(ao, np.arange(nV), side="right") - 1
     return dict(tile_row=out["tile_row"], tile_atom=out["tile_atom"], n_tiles=n_tiles,
-                V=out["V"].reshape(nV, d_v), E=out["E"].reshape(nE, d_e),
+                V=out["V"].reshape(nV, d_v), E=out["E"].reshape(nEr, d_e),
                 edge_index=np.stack([out["src"] + ao[m_of_edge], out["dst"] + ao[m_of_edge]]).astype(np.int64),
                 rev_edge_index=(out["rev"] + eo[m_of_edge]).astype(np.int64), batch=m_of_atom.astype(np.int64))
 

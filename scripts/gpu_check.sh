@@ -39,8 +39,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o
 echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -16 $f | cut -c1-260 | tee -a $OUT/summary.txt; done
 if [ "$QUICK" != "quick" ]; then
-echo "== rocprofv3 kernel stats, training step (bench.py --mode train --steps 50 --warmup 10 --no-cpu-baseline --no-graph)" | tee -a $OUT/summary.txt
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python $REPO/bench.py --mode train --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $OUT/prof_train.json 2> $OUT/prof_train.err
+echo "== rocprofv3 kernel stats, training step (bench.py --mode train --steps 50 --warmup 10 --no-cpu-baseline --no-graph --no-large-batches)" | tee -a $OUT/summary.txt
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python $REPO/bench.py --mode train --steps 50 --warmup 10 --no-cpu-baseline --no-graph --no-large-batches > $OUT/prof_train.json 2> $OUT/prof_train.err
 for f in $(find $OUT/prof_train -name "*kernel_stats.csv"); do head -12 $f | cut -c1-200 | tee -a $OUT/summary.txt; done
 echo "== rocprofv3 PMC passes (separate runs, counters only)" | tee -a $OUT/summary.txt
 timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-large-batches > $OUT/pmc_fetch.log 2>&1

@@ -388,3 +388,43 @@ def test_packed_batch_roundtrip_properties():
             assert pb.n_tiles == len(tiles[0]) - 1 and np.array_equal(got["tile_row"], tiles[0])
 
     prop()
+
+
+# ---- the reference's own batching fixtures (tests/unit/data/test_dataloader.py:10-45: two hand-built molecules with
+# 1-dim float64 features; the first carries fewer E rows than directed edges — the reference concatenates as given) ----
+def _reference_fixture_molgraphs():
+    from chemprop_amd.data import MolGraph
+
+    m1 = MolGraph(V=np.array([[1.0], [2.0], [3.0]]), E=np.array([[0.5], [1.5]]),
+                  edge_index=np.array([[0, 1, 0, 2], [1, 0, 2, 0]]), rev_edge_index=np.array([1, 0, 3, 2]))
+    m2 = MolGraph(V=np.array([[4.0], [5.0]]), E=np.array([[2.5]]), edge_index=np.array([[0, 1], [1, 0]]),
+                  rev_edge_index=np.array([1, 0]))
+    want = dict(V=np.array([[1], [2], [3], [4], [5]], np.float32), E=np.array([[0.5], [1.5], [2.5]], np.float32),
+                edge_index=np.array([[0, 1, 0, 2, 3, 4], [1, 0, 2, 0, 4, 3]], np.int64),
+                rev_edge_index=np.array([1, 0, 3, 2, 5, 4], np.int64), batch=np.array([0, 0, 0, 1, 1], np.int64))
+    return [m1, m2], want
+
+
+def test_reference_dataloader_fixtures_on_the_wire():
+    from chemprop_amd.data import BatchMolGraph, PackedBatch
+    from oracle import collate_numpy as oc
+
+    mgs, want = _reference_fixture_molgraphs()
+    _same(oc.collate(mgs), want)
+    host = BatchMolGraph(mgs)
+    _same({k: getattr(host, k).numpy() for k in KEYS}, want)
+    pb = PackedBatch(mgs)
+    assert (pb.n_atoms, pb.n_edges, pb.n_erows, len(pb)) == (5, 6, 3, 2)
+    _same(oc.unpack_wire(pb.buf.numpy()), want)
+    single = PackedBatch(mgs[:1])
+    _same(oc.unpack_wire(single.buf.numpy()), oc.collate(mgs[:1]))
+
+
+@pytest.mark.gpu
+def test_reference_dataloader_fixtures_on_the_device(gpu_device):
+    from chemprop_amd.data import PackedBatch
+
+    mgs, want = _reference_fixture_molgraphs()
+    bmg = PackedBatch(mgs).to_device(gpu_device)
+    _same({k: getattr(bmg, k).cpu().numpy() for k in KEYS}, want)
+    assert len(bmg) == 2
