@@ -152,13 +152,19 @@ def mab_forward(mp, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = N
     tau, drop = mp.tau, mp.dropout
 
     if _tile_route_ok(mp, bmg, V_d, E_d):
+        from .nn import _route
+
         plan = engine.GraphPlan.from_bmg(bmg)
         act, slope, slope_t = classify_activation(mp.tau)
         has_vd = V_d is not None
+        # the same route policy as the bond block (nn.py: _route): the first batches of a module are checked on the plan's
+        # verdict — an oversize molecule switches the tile kernel off for the module, an unusual graph takes the general route
+        n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+        level = _route(mp, plan, n_mols, getattr(bmg, "batch", None))
         Hv, st = engine.forward(plan, V, E, mp.W_i.weight, mp.W_h.weight, mp.W_vo.weight, mp.W_vo.bias,
                                 mp.W_i.bias, mp.W_h.bias, mp.W_vd.weight if has_vd else None,
                                 mp.W_vd.bias if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
-                                slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True)
+                                slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True, max_level=level)
         H_v = Hv if want_v else None
         H_e = None
         if want_e:

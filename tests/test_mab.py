@@ -160,3 +160,29 @@ def test_full_size_vs_oracle(atom, gpu_device):
         out = mp(bmg)
     for got, want in zip(out, ref):
         assert parity_err(got.cpu().numpy(), want.numpy()) <= TOL
+
+
+@pytest.mark.gpu
+def test_inference_with_an_oversize_molecule_is_routed_not_poisoned(gpu_device):
+    """A 40-atom molecule does not fit a tile of the whole-forward kernel: the block's inference route must notice on its
+    validated first batches and use the per-step kernels (finite, correct) instead of returning NaN."""
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph
+    from chemprop_amd.mab import MABBondMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    mgs = synth.random_molgraphs(20, "qm9", seed=4) + synth.random_molgraphs(2, "synth40", seed=5)
+    bmg = BatchMolGraph(mgs)
+    torch.manual_seed(8)
+    mp = MABBondMessagePassing(d_h=64).eval()
+    with torch.no_grad():
+        ref = ot.mab_forward(bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, ot.MABWeights.from_state_dict(mp.state_dict()),
+                             atom_messages=False)
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    with torch.no_grad():
+        for i in range(3):
+            out = mp(bmg)
+            for got, want in zip(out, ref):
+                assert torch.isfinite(got).all() and parity_err(got.cpu().numpy(), want.numpy()) <= TOL, i
+    assert getattr(mp, "_dmpnn_no_mega", False)
