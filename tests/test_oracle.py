@@ -193,3 +193,41 @@ def test_golden_set_is_complete():
     names = {p.split("/")[-1][:-4] for p in golden_paths()}
     for must in ("chain5x2_default", "no_edges", "qm9x8_h300", "garbage_h24", "trained_v2_mol", "tiny_pair_h7"):
         assert must in names
+
+
+# ---- the arithmetic of the f16-pipe contractions (oracle/split16_numpy.py), on the CPU ----
+def test_split_is_exact_to_22_bits_and_scaling_is_exact():
+    from oracle import split16_numpy as sp
+
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(4096) * np.exp(rng.uniform(-6, 6, 4096))).astype(np.float32)
+    s = sp.scale_for(float(np.abs(x).max()))
+    assert np.log2(s) == np.round(np.log2(s)) and 2.0 ** 13 <= np.abs(x).max() * s < 2.0 ** 14
+    hi, lo = sp.split(x, s)
+    assert np.isfinite(hi.astype(np.float32)).all()  # nothing overflows f16 (max 65504 > 2^14)
+    xs = x.astype(np.float64) * s
+    r = np.abs(xs - hi.astype(np.float64) - lo.astype(np.float64))
+    # two 11-bit pieces: 2^-22 relative, or the f16 subnormal step for entries far below the tile maximum
+    assert (r <= np.maximum(np.abs(xs) * 2.0 ** -21, 2.0 ** -24)).all()
+    assert sp.scale_for(0.0) == 1.0 and sp.scale_for(float("inf")) == 1.0 and sp.scale_for(float("nan")) == 1.0
+
+
+@pytest.mark.parametrize("M,N,K,seed", [(96, 300, 300, 1), (100, 64, 86, 2), (48, 300, 372, 3)])
+def test_three_pass_f16_contraction_is_fp32_class(M, N, K, seed):
+    """The 3-term split contraction against exact (float64) and against plain fp32: same accuracy class, well inside the
+    1e-5 parity bar — what `dtype` in the bench line claims."""
+    from oracle import split16_numpy as sp
+
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    A[:, : K // 3] = np.maximum(A[:, : K // 3], 0)               # post-ReLU-like columns
+    A[rng.integers(0, M, 5), rng.integers(0, K, 5)] *= 40.0       # a few large entries set the tile scale
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    exact = A.astype(np.float64) @ W.astype(np.float64).T
+    got = sp.linear_split16(A, W)
+    fp32 = A @ W.T
+    scale = np.abs(exact).max()
+    e_split = np.abs(got - exact).max() / scale
+    e_fp32 = np.abs(fp32 - exact).max() / scale
+    assert e_split <= 1e-6, e_split
+    assert e_split <= 4 * max(e_fp32, 1e-7)
