@@ -152,3 +152,27 @@ def test_accelerate_swaps_the_real_reference_classes():
     assert list(m.state_dict().keys()) == keys and m.message_passing.W_h.weight is w
     with pytest.raises(RuntimeError):  # CPU tensors: the engine has no fallback
         m.agg(torch.zeros(3, 16), torch.zeros(3, dtype=torch.int64))
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench.json is a line `bench.py` printed on MI355X: the keys the driver / judge read are all there and
+    consistent with each other (roofline.frac = achieved / peak, value = units / time)."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, "profiles", "r01_bench.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference")
+    edges = d["config"]["directed_edges_per_gpu"]
+    assert abs(d["value"] - d["n_gpus"] * edges * 2 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]  # depth 3: 2 updates / edge
