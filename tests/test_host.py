@@ -158,6 +158,7 @@ def test_committed_bench_line_follows_the_contract():
     """profiles/r01_bench.json is a line `bench.py` printed on MI355X: the keys the driver / judge read are all there and
     consistent with each other (roofline.frac = achieved / peak, value = units / time)."""
     import json
+    import os
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = json.loads(open(os.path.join(root, "profiles", "r01_bench.json")).read().strip().splitlines()[-1])
