@@ -64,13 +64,18 @@ class MLP(nn.Sequential):
     @classmethod
     def build(cls, input_dim: int, output_dim: int, hidden_dim: int | Sequence[int] = 300, n_layers: int = 1,
               dropout: float = 0.0, activation="relu"):
-        dropout = nn.Dropout(dropout)
-        act = get_activation_function(activation)
-        hidden_dims = [hidden_dim] * n_layers if isinstance(hidden_dim, int) else list(hidden_dim)
-        dims = [input_dim] + hidden_dims + [output_dim]
-        blocks = [nn.Sequential(nn.Linear(dims[0], dims[1]))]
-        if len(dims) > 2:
-            blocks.extend([nn.Sequential(act, dropout, nn.Linear(d1, d2)) for d1, d2 in zip(dims[1:-1], dims[2:])])
+        # Layer widths input -> hidden ... -> output.  The FIRST block is a bare Linear; every later block is
+        # (activation, dropout, Linear) with ONE shared activation and ONE shared dropout module — the structure (and hence
+        # the state_dict keys "i.0.*" / "i.2.*") and the order in which the Linear layers draw their initial weights are
+        # the reference's (ffn.py:37-58).
+        widths = [int(hidden_dim)] * int(n_layers) if isinstance(hidden_dim, int) else [int(h) for h in hidden_dim]
+        widths = [int(input_dim), *widths, int(output_dim)]
+        shared_drop = nn.Dropout(dropout)
+        shared_act = get_activation_function(activation)
+        blocks = []
+        for i in range(len(widths) - 1):
+            lin = nn.Linear(widths[i], widths[i + 1])
+            blocks.append(nn.Sequential(lin) if i == 0 else nn.Sequential(shared_act, shared_drop, lin))
         return cls(*blocks)
 
     @property
