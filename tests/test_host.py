@@ -177,3 +177,44 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] in ("port", "reference")
     edges = d["config"]["directed_edges_per_gpu"]
     assert abs(d["value"] - d["n_gpus"] * edges * 2 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]  # depth 3: 2 updates / edge
+
+
+def test_plan_policy_decision_table(monkeypatch):
+    """Which plan an inference forward builds (chemprop_amd/nn.py): full plan while the module's first batches are being
+    validated, then the light / tile plan; the tile plan needs small molecules and either a batch the single-workgroup
+    plan takes or a table / batch vector for any size.  Host logic only."""
+    import torch
+
+    from chemprop_amd import engine
+    from chemprop_amd.nn import BondMessagePassing, _light_plan_ok, _tile_plan_ok
+
+    for k in ("DMPNN_VALIDATE", "DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_TILE_PLAN"):
+        monkeypatch.delenv(k, raising=False)
+    mp = BondMessagePassing().eval()
+    with torch.no_grad():
+        assert not _light_plan_ok(mp)                       # first batches: validated on the full plan
+        object.__setattr__(mp, "_dmpnn_batches_checked", 2)
+        assert _light_plan_ok(mp)
+        monkeypatch.setenv("DMPNN_GENERAL", "1")
+        assert not _light_plan_ok(mp)
+        monkeypatch.delenv("DMPNN_GENERAL")
+        assert not _light_plan_ok(BondMessagePassing(undirected=True).eval())
+        assert not _light_plan_ok(BondMessagePassing(d_h=512).eval())           # wider than the fused routes
+        fresh = BondMessagePassing().eval()
+        monkeypatch.setenv("DMPNN_VALIDATE", "never")
+        assert _light_plan_ok(fresh)                        # nothing to wait for
+        monkeypatch.delenv("DMPNN_VALIDATE")
+    assert not _light_plan_ok(mp)                           # grad enabled, parameters require grad: training builds the full plan
+    # the tile plan: QM9-like batches
+    assert engine.small_plan_fits(4636, 9120) and not engine.small_plan_fits(37000, 73000)
+    assert _tile_plan_ok(mp, 4636, 9120, 512)
+    assert not _tile_plan_ok(mp, 4636, 9120, 0)             # molecule count unknown
+    assert not _tile_plan_ok(mp, 12000, 25000, 512)         # ~49 directed edges per molecule: tiles would not fit them
+    assert not _tile_plan_ok(mp, 37000, 73000, 4096)        # beyond the single-workgroup plan without a table / batch vector
+    assert _tile_plan_ok(mp, 37000, 73000, 4096, True)      # ... with one
+    for k, v in (("DMPNN_TILE_PLAN", "0"), ("DMPNN_MEGA", "0"), ("DMPNN_MFMA", "f32"), ("DMPNN_VALIDATE", "always")):
+        monkeypatch.setenv(k, v)
+        assert not _tile_plan_ok(mp, 4636, 9120, 512), k
+        monkeypatch.delenv(k)
+    object.__setattr__(mp, "_dmpnn_no_mega", True)          # the module has seen an oversize molecule
+    assert not _tile_plan_ok(mp, 4636, 9120, 512)
