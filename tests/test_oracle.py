@@ -189,6 +189,45 @@ def test_oracle_vs_executed_reference_live():
         assert parity_err(out.numpy(), ref.numpy()) <= 1e-6
 
 
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("seed", range(12))
+def test_both_restatements_vs_executed_reference_on_random_cases(seed):
+    """Build container only.  Random configuration per seed (molecule kind, edge layout, depth, width, bias, activation,
+    undirected, V_d): the executed reference class, the ATen-sequence restatement and the CSR / row-coordinate restatement
+    (the form the HIP kernels compute in) give the same forward."""
+    from chemprop_amd import synth
+
+    rng = np.random.default_rng(9000 + seed)
+    kind = ["qm9", "zinc", "synth40", "cgr"][seed % 4]
+    layout = ["interleaved", "block", "shuffled"][int(rng.integers(0, 3))]
+    act = ["relu", "leakyrelu", "prelu", "tanh", "elu"][int(rng.integers(0, 5))]
+    d_vd = int(rng.integers(0, 2)) * 3
+    kw = dict(d_h=int(rng.choice([8, 24, 36, 64])), depth=int(rng.integers(1, 6)), bias=bool(rng.integers(0, 2)), activation=act,
+              undirected=bool(rng.integers(0, 2)) and layout != "shuffled", d_vd=d_vd or None)
+    if kind == "cgr":
+        kw.update(d_v=106, d_e=28)
+    BMP, BMG, _ = ref_shim.load_reference()
+    mgs = synth.random_molgraphs(int(rng.integers(1, 12)), kind, seed=500 + seed, layout=layout)
+    bmg = BMG(mgs)
+    torch.manual_seed(seed)
+    mp = BMP(**kw).eval()
+    V_d = torch.randn(bmg.V.shape[0], d_vd, generator=torch.Generator().manual_seed(seed)) if d_vd else None
+    with torch.no_grad():
+        ref = mp(bmg, V_d)
+    w = ot.MPWeights.from_module(mp)
+    prelu = mp.tau.weight.detach() if act == "prelu" else None
+    with torch.no_grad():
+        out_t = ot.forward_bmg(bmg, w, depth=mp.depth, activation=act, undirected=mp.undirected, V_d=V_d, prelu_weight=prelu)
+    assert parity_err(out_t.numpy(), ref.numpy()) <= 1e-6, kw
+    if act == "prelu":  # (its learnable slope is a torch parameter; the numpy form covers the fixed-slope activations)
+        return
+    W = {k: (None if v is None else v.numpy()) for k, v in vars(w).items()}
+    out_n = onp.forward(bmg.V.numpy(), bmg.E.numpy(), bmg.edge_index.numpy(), bmg.rev_edge_index.numpy(), W, depth=mp.depth,
+                        activation=act, undirected=mp.undirected, V_d=None if V_d is None else V_d.numpy())
+    out_n = out_n[0] if isinstance(out_n, tuple) else out_n
+    assert parity_err(np.asarray(out_n), ref.numpy()) <= 2e-6, kw
+
+
 def test_golden_set_is_complete():
     names = {p.split("/")[-1][:-4] for p in golden_paths()}
     for must in ("chain5x2_default", "no_edges", "qm9x8_h300", "garbage_h24", "trained_v2_mol", "tiny_pair_h7"):
