@@ -144,10 +144,14 @@ class PackedBatch:
                              ("rev", 4 * nE), ("V", 4 * nV * d_v), ("E", 4 * nEr * d_e), ("tile_row", 4 * nt), ("tile_atom", 4 * nt)):
             sec[name] = (o, nbytes)
             o = _align16(o + nbytes)
-        buf = torch.zeros(o, dtype=torch.uint8)
+        # (numpy's calloc-backed zeros, not torch.zeros: no intra-op thread pool is woken for a 2 MB fill in a loader worker)
         if pin:
-            buf = buf.pin_memory()
-        raw = buf.numpy()
+            buf = torch.empty(o, dtype=torch.uint8).pin_memory()
+            raw = buf.numpy()
+            raw[:] = 0
+        else:
+            raw = np.zeros(o, dtype=np.uint8)
+            buf = torch.from_numpy(raw)
         view = lambda name, dt: raw[sec[name][0]:sec[name][0] + sec[name][1]].view(dt)
         raw[:_WIRE_HEADER * 8].view(np.int64)[:8] = (_WIRE_MAGIC, n_mols, nV, nE, d_v, d_e, n_tiles, nEr)
         view("atom_off", np.int32)[:] = atom_off
