@@ -21,15 +21,15 @@ INCLUDE = os.path.join(_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip"]
-HEADERS = ["dmpnn_common.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp"]
-ABI_VERSION = 4
+HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp"]
+ABI_VERSION = 5
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
 EXPORTS = [
     "dmpnn_version", "dmpnn_debug_timestamps", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
     "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_prepare_light", "dmpnn_prepare_tiles", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
-    "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
+    "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_tile_plan_any_size",
@@ -81,6 +81,7 @@ class FwdArgs(C.Structure):
         ("wsplit", C.c_void_p), ("wsplit_bytes", C.c_size_t),
         ("edge_index", C.c_void_p), ("rev_edge_index", C.c_void_p),
         ("n_tiles_launch", C.c_int64),
+        ("spill_ws", C.c_void_p), ("spill_bytes", C.c_size_t),
     ]
 
 
@@ -183,7 +184,7 @@ def load() -> C.CDLL:
     lib.dmpnn_linear_wgrad_ws_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int]
     lib.dmpnn_linear_wgrad.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-    size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes",
+    size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes",
                   "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes")
     lib.dmpnn_linear16_wsplit_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_linear16_ok.argtypes = [C.POINTER(GemmArgs)]
@@ -206,6 +207,7 @@ def load() -> C.CDLL:
     lib.dmpnn_molagg_bwd.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int,
                                      C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     lib.dmpnn_forward_wsplit_bytes.argtypes = [C.POINTER(FwdArgs)]
+    lib.dmpnn_forward_spill_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_debug_timestamps.argtypes = [C.c_void_p]
     for name in size_t_fns:
         getattr(lib, name).restype = C.c_size_t

@@ -201,6 +201,11 @@ size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a) {
     return (a->flags & DMPNN_F_MEGA) ? mega16_wsplit_bytes(*a) : steps16_wsplit_bytes(*a);
 }
 
+size_t dmpnn_forward_spill_bytes(const dmpnn_fwd_args* a) {
+    if (!a || a->n_atoms < 0 || a->n_edges < 0 || a->ldh <= 0) return 0;
+    return (size_t)(3 * a->n_edges + a->n_atoms) * (size_t)a->ldh * sizeof(float);
+}
+
 static bool al_ptr(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
 
 int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a) {

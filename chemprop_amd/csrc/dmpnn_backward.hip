@@ -524,6 +524,7 @@ struct BwdLayout {
     size_t WhT16, WoT16;  // pre-split transposed weights of the data-gradient contractions on the f16 pipe (large batches)
     bool use16;
     size_t mega_w, gZs;   // backward tile kernel: its two pre-split matrices; gZ^(t) slots beyond the two ping-pong buffers
+    size_t sp_gM;         // backward tile kernel: edge scratch of its generic path for oversize pieces (the atom scratch is gMv)
     bool mega;
     WgradPlan p_h, p_i, p_o, p_d;
 };
@@ -569,10 +570,11 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     static const bool bwd_mega = [] { const char* e = getenv("DMPNN_BWD_MEGA"); return !(e && e[0] == '0'); }();
     L.mega = bwd_mega && (f.flags & DMPNN_F_MEGA) && (f.flags & DMPNN_F_SPLIT16) && (f.flags & DMPNN_F_KEEP) && nE > 0 &&
              f.ldh % 4 == 0 && f.act != DMPNN_ACT_PRELU;
-    L.mega_w = L.gZs = 0;
+    L.mega_w = L.gZs = L.sp_gM = 0;
     if (L.mega) {
         L.mega_w = o; o += align_up((mega16_bwd_wsplit_bytes(h) + 3) / 4, 64);
         if (f.depth - 1 > 2) { L.gZs = o; o += (size_t)(f.depth - 1) * edge; }
+        L.sp_gM = o; o += edge;
     }
     L.total = o;
     return L;
@@ -719,7 +721,7 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         // ---- the whole data-gradient chain in one launch, then the four weight gradients ----
         DMPNN_CHECK_ARG(f.H0 && (T == 1 || f.Hs), "backward: the tile-kernel forward did not keep H0 / H^(t)");
         float* gZs = (T - 1 > 2) ? ws + L.gZs : gZa;  // slot t-1 = gZ^(t)
-        DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, s));
+        DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, ws + L.sp_gM, ws + L.gMv, s));
         if (b->gW_o || b->gb_o) {
             WgradArgs a;
             memset(&a, 0, sizeof(a));

@@ -51,14 +51,15 @@ __global__ __launch_bounds__(256) void k_collate(const int* __restrict__ atom_of
 }
 
 // The piece-tile tables of a tile plan from a table the LOADER made (dmpnn_pack_tiles below): copy, pad the unused slots
-// with the (n_edges, n_atoms) sentinel, write the header of a tile plan.  Every entry is checked here for order and
-// for the tile limits (a violation sets DMPNN_PLAN_NO_PIECE_TILES: the tile kernel then returns NaN); whether a tile
+// with the (n_edges, n_atoms) sentinel, write the header of a tile plan.  Every entry is checked here for order (a
+// violation sets DMPNN_PLAN_NO_PIECE_TILES: the tile kernel then returns NaN; a tile beyond the matrix-pipe limits is
+// counted in DMPNN_HDR_NSPILL and takes the tile kernel's generic path); whether a tile
 // is CLOSED (holds every edge of its atoms and nothing else) is checked by the tile kernel itself on the batch's own
 // index arrays, exactly as for a table from dmpnn_prepare_tiles.
 __global__ __launch_bounds__(256) void k_tiles_from_table(const int* __restrict__ tile_row, const int* __restrict__ tile_atom,
                                                           int n_tiles, int nV, int nE, int* __restrict__ plan, PlanLayout L) {
-    __shared__ int bad_s;
-    if (threadIdx.x == 0) bad_s = 0;
+    __shared__ int bad_s, spill_s;
+    if (threadIdx.x == 0) { bad_s = 0; spill_s = 0; }
     __syncthreads();
     int* mrow = plan + L.mtile_row;
     int* matom = plan + L.mtile_atom;
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(256) void k_tiles_from_table(const int* __restrict_
         if (t < n_tiles) {
             r = tile_row[t]; a = tile_atom[t];
             const int r1 = t + 1 < n_tiles ? tile_row[t + 1] : nE, a1 = t + 1 < n_tiles ? tile_atom[t + 1] : nV;
-            if (r < 0 || a < 0 || r1 < r || a1 < a || r1 - r > kMegaBM || a1 - a > kMegaBA || r1 > nE || a1 > nV) bad = 1;
+            if (r < 0 || a < 0 || r1 < r || a1 < a || r1 > nE || a1 > nV) bad = 1;
+            else if (r1 - r > kMegaBM || a1 - a > kMegaBA) atomicAdd(&spill_s, 1);  // (the tile kernel's generic path; it checks closure itself)
             if (t == 0 && (r != 0 || a != 0)) bad = 1;
         }
         mrow[t] = r;
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256) void k_tiles_from_table(const int* __restrict_
         const int h = threadIdx.x;
         if (h == DMPNN_HDR_FLAGS) v = (bad_s ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
         if (h == DMPNN_HDR_NMTILES) v = bad_s ? 0 : n_tiles;
+        if (h == DMPNN_HDR_NSPILL) v = bad_s ? 0 : spill_s;
         if (h == DMPNN_HDR_LIGHT) v = 2;
         if (h == DMPNN_HDR_NATOMS) v = nV;
         if (h == DMPNN_HDR_NEDGES) v = nE;
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(256) void k_tiles_from_table(const int* __restrict_
 
 // HOST function (no device work): greedy packing of consecutive whole molecules into tiles of <= 48 directed edges and
 // <= 32 atoms from the two running offsets of a batch.  Writes tile_row / tile_atom [n_tiles + 1] (the last entry is the
-// (n_edges, n_atoms) end) and returns n_tiles; -1 when a molecule alone exceeds a tile (such batches take the device
-// plans), -2 when `cap` entries do not suffice or an argument is bad.
+// (n_edges, n_atoms) end) and returns n_tiles; a molecule that alone exceeds a tile gets a tile of its own (the tile
+// kernel carries it through its generic path); -2 when `cap` entries do not suffice or an argument is bad.
 extern "C" int64_t dmpnn_pack_tiles(const int* atom_off, const int* edge_off, int64_t n_mols, int* tile_row, int* tile_atom,
                                     int64_t cap) {
     if (n_mols < 0 || cap < 1 || !tile_row || !tile_atom || (n_mols > 0 && (!atom_off || !edge_off))) return -2;
@@ -106,7 +109,7 @@ extern "C" int64_t dmpnn_pack_tiles(const int* atom_off, const int* edge_off, in
         const int a0 = atom_off[m], e0 = edge_off[m];
         int64_t q = m;
         while (q < n_mols && atom_off[q + 1] - a0 <= dmpnn::kMegaBA && edge_off[q + 1] - e0 <= dmpnn::kMegaBM) ++q;
-        if (q == m) return -1;                       // molecule m alone exceeds a tile
+        if (q == m) q = m + 1;                       // molecule m alone exceeds a tile: a tile of its own (generic path)
         if (atom_off[q] == a0 && edge_off[q] == e0) { m = q; continue; }  // only empty molecules: no tile
         if (n + 1 >= cap) return -2;
         tile_row[n] = e0; tile_atom[n] = a0;

@@ -194,7 +194,7 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,
-                           float* gZs, float* gH0, void* wsplit, hipStream_t s);
+                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -13,6 +13,8 @@ bool mega_shapes_ok(const dmpnn_fwd_args& a) {
     // piece tiles come from the single-workgroup plan — or from the loader, at any batch size
     if (!(a.flags & DMPNN_F_LOADER_TILES) && !small_plan_fits(a.n_atoms, a.n_edges)) return false;
     if (a.n_atoms * a.ldv * 4 > 0x7FFFFFFF || a.n_edges * a.lde * 4 > 0x7FFFFFFF) return false;
+    // (the generic path for oversize pieces stages operand rows of d_v + max(d_e, d_h) floats in the kernels' LDS)
+    if (a.d_v + (a.d_e > a.d_h ? a.d_e : a.d_h) > 448) return false;
     return a.d_h % 4 == 0 && a.d_h <= 320 && a.d_v % 2 == 0 && a.d_e % 2 == 0 && a.ldv % 2 == 0 && a.lde % 2 == 0 &&
            (a.W_d != nullptr || a.ldout % 4 == 0) && a.ldh % 4 == 0 && a.depth >= 1 && !(a.flags & DMPNN_F_UNDIRECTED);
 }
@@ -34,6 +36,7 @@ int launch_mega_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipS
     g.out = out; g.ldout = (int)ldout;
     g.ldh = (int)a.ldh; g.slot = (long long)nE * a.ldh;
     if (a.flags & DMPNN_F_KEEP) { g.H0 = a.H0; g.Hs = a.Hs; g.Ms = a.Ms; g.Mv = a.Mv; }
+    g.spill = (a.spill_ws && a.spill_bytes >= dmpnn_forward_spill_bytes(&a) && aligned16(a.spill_ws)) ? a.spill_ws : nullptr;
     const unsigned qn = (unsigned)(a.d_h / 4);
     g.qmagic = qn > 1 ? (unsigned)(((1ull << 32) + qn - 1) / qn) : 0u;
     const int n_tiles = (int)L.max_mtiles;

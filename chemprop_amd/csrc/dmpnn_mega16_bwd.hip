@@ -19,7 +19,7 @@ size_t mega16_bwd_wsplit_bytes(int64_t h) {
 }
 
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,
-                           float* gZs, float* gH0, void* wsplit, hipStream_t s) {
+                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s) {
     const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dv = f.d_v;
     const size_t NT = (size_t)(h + 15) / 16, nc = (size_t)(h + 31) / 32;
     unsigned char* ws = static_cast<unsigned char*>(wsplit);
@@ -47,6 +47,7 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     g.gHO = gHO; g.ldg = (int)ldg; g.HO = HO; g.ldho = (int)ldho;
     g.H0 = f.H0; g.Hs = f.Hs; g.ldh = (int)f.ldh; g.slot = (long long)nE * f.ldh;
     g.gZO = gZO; g.gZs = gZs; g.gH0 = gH0;
+    g.srcp = plan_i + L.srcp; g.d_v = (int)dv; g.W_o = f.W_o; g.W_h = f.W_h; g.sp_gM = sp_gM; g.sp_Ta = sp_Ta;
     g.WoMT = mega16::SplitW{ws, inv_o, (int)nc};
     g.WhT = mega16::SplitW{ws + one, inv_h, (int)nc};
     const int n_tiles = (int)L.max_mtiles;

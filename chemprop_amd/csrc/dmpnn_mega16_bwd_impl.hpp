@@ -34,6 +34,9 @@ struct Mega16BwdK {
     float* gZs;                          // [(depth-1)][E, ldh]: slot t-1 = gZ^(t)
     float* gH0;                          // [E, ldh]
     SplitW WoMT, WhT;                    // pre-split W_o[:, d_v:]^T and W_h^T  ([h, h] each)
+    // the generic path for pieces larger than the tile (dmpnn_spill_impl.hpp): plain weights, two scratch tensors
+    const int* srcp; int d_v; const float* W_o; const float* W_h;
+    float* sp_gM; float* sp_Ta;          // [E, ldh], [V, ldh]
 };
 
 template <int WN>
@@ -77,8 +80,20 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             g.gZO[(i / N) * g.ldh + (i % N)] = nanv;
         return;
     }
-    if (na <= 0 || nrows < 0 || nrows > BM || na > BA) return;
+    if (na <= 0 || nrows < 0) return;
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
+    if (nrows > BM || na > BA) {  // a piece larger than the matrix-pipe tile: the generic fp32 path, any size
+        spill::BwdView v;
+        v.rs = rs; v.nrows = nrows; v.va = va; v.na = na; v.h = N; v.depth = T_steps; v.d_v = g.d_v;
+        v.row_ptr = g.row_ptr; v.srcp = g.srcp; v.revp = g.revp;
+        v.act = g.act; v.slope = slope;
+        v.gHO = g.gHO; v.ldg = g.ldg; v.HO = g.HO; v.ldho = g.ldho;
+        v.H0 = g.H0; v.Hs = g.Hs; v.ldh = g.ldh; v.slot = g.slot;
+        v.gZO = g.gZO; v.gZs = g.gZs; v.gH0 = g.gH0;
+        v.W_o = g.W_o; v.W_h = g.W_h; v.gM = g.sp_gM; v.Ta = g.sp_Ta;
+        spill::backward(v, reinterpret_cast<float*>(lds));
+        return;
+    }
     auto dact = [&](float gval, float y, bool preact) -> float {  // g * tau'(.) from the output (or the pre-activation)
         if (g.act == DMPNN_ACT_NONE) return gval;
         if (g.act == DMPNN_ACT_RELU) return y > 0.f ? gval : 0.f;

@@ -162,16 +162,14 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             g.out[(i / N) * g.ldout + (i % N)] = nanv;
         return;
     }
-    if (na <= 0) return;  // (an unused tile slot)
-    if (nrows < 0 || nrows > BM || na > BA) {
-        // cannot happen with a plan made by this library; never leave the tile's atoms unwritten
-        if (va >= 0 && vb <= g.nV) {
-            const float nanv = __int_as_float(0x7fc00000);
-            for (long long i = tid; i < (long long)na * N; i += kThreads) g.out[(va + i / N) * g.ldout + (i % N)] = nanv;
-        }
+    if (na <= 0 || nrows < 0 || va < 0 || vb > g.nV || rs < 0 || re > g.nE) return;  // (an unused tile slot)
+    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
+    if (nrows > BM || na > BA) {
+        // a piece (molecule) larger than the matrix-pipe tile — the reference has no size limit (data/collate.py:48-56):
+        // the generic fp32 path carries it, whatever its size (dmpnn_spill_impl.hpp)
+        spill::forward(mega::spill_view(g, lean, rs, nrows, va, na, slope), reinterpret_cast<float*>(lds));
         return;
     }
-    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
     const bool simple_act = !(g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU);
     auto tau = [&](float z) -> float {

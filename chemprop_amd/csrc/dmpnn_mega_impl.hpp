@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "dmpnn_gemm_impl.hpp"
+#include "dmpnn_spill_impl.hpp"
 
 namespace dmpnn {
 namespace mega {
@@ -48,7 +49,30 @@ struct MegaK {
     // tile plan (dmpnn_prepare_tiles, header LIGHT == 2; split-MFMA kernel only): the caller's own index arrays
     const long long* edge_index;  // [2, nE] row 0 = src atom, row 1 = dst atom
     const long long* rev64;       // [nE]
+    float* spill;                 // inference scratch of the generic path for oversize pieces ([3 nE + nV][ldh]) or null
 };
+
+// the view the generic path (dmpnn_spill_impl.hpp) takes of a piece tile that exceeds the matrix-pipe tile
+__device__ __forceinline__ spill::FwdView spill_view(const MegaK& g, bool lean, int rs, int nrows, int va, int na, float slope) {
+    spill::FwdView v;
+    v.lean = lean; v.rs = rs; v.nrows = nrows; v.va = va; v.na = na; v.nV = g.nV; v.nE = g.nE;
+    v.row_ptr = g.row_ptr; v.srcp = g.srcp; v.perm = g.perm; v.revp = g.revp;
+    v.edge_index = g.edge_index; v.rev64 = g.rev64;
+    v.V = g.V; v.ldv = g.ldv; v.E = g.E; v.lde = g.lde; v.d_v = g.d_v; v.d_e = g.d_e; v.h = g.h; v.depth = g.depth;
+    v.W_i = g.W_i; v.b_i = g.b_i; v.W_h = g.W_h; v.b_h = g.b_h; v.W_o = g.W_o; v.b_o = g.b_o;
+    v.act = g.act; v.slope = slope;
+    v.out = g.out; v.ldout = g.ldout;
+    v.ldh = g.ldh; v.slot = g.slot;
+    const bool kept = g.H0 != nullptr;  // DMPNN_F_KEEP: the kept tensors are the workspace
+    const int steps = g.depth > 1 ? g.depth - 1 : 1;
+    v.H0 = kept ? g.H0 : g.spill;
+    v.Hs = kept ? g.Hs : (g.spill ? g.spill + g.slot : nullptr);
+    v.Ms = kept ? g.Ms : (g.spill ? g.spill + 2 * g.slot : nullptr);
+    v.Mv = kept ? g.Mv : (g.spill ? g.spill + 3 * g.slot : nullptr);
+    v.n_hslots = kept ? steps : 1;
+    v.n_mslots = kept ? steps : 1;
+    return v;
+}
 
 template <int WN>
 constexpr size_t lds_bytes() {
@@ -90,8 +114,12 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile(MegaK g) {
             g.out[(i / N) * g.ldout + (i % N)] = nanv;
         return;
     }
-    if (na <= 0 || nrows > BM || na > BA) return;  // trailing slots of the launch bound
+    if (na <= 0 || nrows < 0) return;  // trailing slots of the launch bound
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
+    if (nrows > BM || na > BA) {  // a piece larger than the matrix-pipe tile: the generic fp32 path (any size)
+        spill::forward(spill_view(g, false, rs, nrows, va, na, slope), smem);
+        return;
+    }
     const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
     const bool simple_act = !(g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU);
     auto tau = [&](float z) -> float {

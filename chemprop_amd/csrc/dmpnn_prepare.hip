@@ -269,7 +269,7 @@ __device__ __forceinline__ void block_scan_inclusive(int* a, int n, int* wave_to
 // Returns the number of tiles, or -1 when a piece does not fit (the tables are then emptied).
 template <class RowOf, class Other>
 __device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLayout& L, const int* X, int np, RowOf&& row_of,
-                                           int* Y, int* bad_s, int nV, int nE, int tid, Other&& other_work,
+                                           int* Y, int* bad_s, int* spill_s, int nV, int nE, int tid, Other&& other_work,
                                            long long* dbg, int n_st) {
     auto stamp = [&]() {
         if (dbg && tid == 0 && n_st < 12) dbg[n_st] = (long long)__builtin_readcyclecounter();
@@ -288,7 +288,7 @@ __device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLay
             const int v = X[p], r0 = row_of(p);
             int q = p + 1;  // pieces p .. q-1 fit
             if (X[q] - v > kMegaBA || row_of(q) - r0 > kMegaBM) {
-                atomicOr(bad_s, 1);  // one piece alone exceeds a tile
+                atomicAdd(spill_s, 1);  // one piece alone exceeds a tile: a tile of its own, for the generic in-kernel path
             } else {
                 while (q < np && X[q + 1] - v <= kMegaBA && row_of(q + 1) - r0 <= kMegaBM) ++q;
             }
@@ -374,7 +374,7 @@ __device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLay
 // Returns the number of tiles, or -1 when a piece does not fit (the tables are then emptied).
 template <class Other>
 __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const PlanLayout& L, const int* rowp, int* X,
-                                                 int* Y, int* wave_tot, int* bad_s, int nV, int nE, int tid,
+                                                 int* Y, int* wave_tot, int* bad_s, int* spill_s, int nV, int nE, int tid,
                                                  Other&& other_work, long long* dbg = nullptr) {
     int n_st = 0;
     auto stamp = [&]() {
@@ -430,7 +430,7 @@ __device__ __forceinline__ int build_piece_tiles(int* __restrict__ plan, const P
     if (tid == 0) X[np] = nV;
     __syncthreads();
     stamp();  // p3: piece starts
-    return pack_pieces(plan, L, X, np, [&](int p) { return rowp[X[p]]; }, Y, bad_s, nV, nE, tid, other_work, dbg, n_st);
+    return pack_pieces(plan, L, X, np, [&](int p) { return rowp[X[p]]; }, Y, bad_s, spill_s, nV, nE, tid, other_work, dbg, n_st);
 }
 
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* __restrict__ edge_index,
@@ -455,10 +455,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     u16* inv16 = perm16 + nE;
     int* Ybuf = reinterpret_cast<int*>(lds_i) + 2 * (nV + 2) + (5 * nE + 1) / 2;  // [nV + 2] scratch of the piece tiles
     __shared__ int wave_tot[kSmallThreads / 64];
-    __shared__ int flags_s, maxdeg_s, piece_bad_s;
+    __shared__ int flags_s, maxdeg_s, piece_bad_s, spill_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < nV; i += kSmallThreads) cnt[i] = 0;
-    if (tid == 0) { flags_s = 0; maxdeg_s = 0; piece_bad_s = 0; }
+    if (tid == 0) { flags_s = 0; maxdeg_s = 0; piece_bad_s = 0; spill_s = 0; }
     // light == 2, the TILE plan: only the piece-tile tables (+ header) — what an inference forward of the whole-forward
     // tile kernel reads; that kernel then takes src / dst / rev of a tile's edges straight from the caller's arrays
     // (its rows are the tile's edges in the caller's order: no sort, no CSR, no permutation) and checks on its own
@@ -507,11 +507,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
         for (int e = tid; e < nE; e += kSmallThreads) {
             const int sa = src16[e], da = dst16[e];
             if (sa < da) {
-                if (da - sa >= kMegaBA) {
-                    atomicOr(&piece_bad_s, 1);  // this bond alone spans more atoms than a tile holds: no piece tiles
-                } else {
-                    for (int u = sa + 1; u <= da; ++u) covb[u] = 1;
-                }
+                for (int u = sa + 1; u <= da; ++u) covb[u] = 1;  // (a bond that spans more atoms than a tile holds: its piece spills)
             }
         }
     }
@@ -615,11 +611,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
                 far = max(far, (int)src16[row[k]]);
             }
         }
-        if (far - v >= kMegaBA) {
-            atomicOr(&piece_bad_s, 1);  // this bond alone spans more atoms than a tile holds: no piece tiles
-        } else {
-            for (int u = v + 1; u <= far; ++u) covb[u] = 1;
-        }
+        for (int u = v + 1; u <= far; ++u) covb[u] = 1;  // (a bond that spans more atoms than a tile holds: its piece spills)
     }
     __syncthreads();
     stamp();  // 6: sort
@@ -649,12 +641,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
     stamp();  // 8: (outputs moved into phase 7)
     stamp();  // 9: (maxnbr folded into phase 5)
     // phase 7: piece tiles (scans by the whole workgroup, chain walk by wave 0 || outputs by waves 1..15)
-    const int n_mtiles = build_piece_tiles(plan, L, rowp, cnt, Ybuf, wave_tot, &piece_bad_s, nV, nE, tid, outputs, dbg ? dbg + 16 : nullptr);
+    const int n_mtiles = build_piece_tiles(plan, L, rowp, cnt, Ybuf, wave_tot, &piece_bad_s, &spill_s, nV, nE, tid, outputs, dbg ? dbg + 16 : nullptr);
     stamp();  // 10: piece tiles
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
         if (tid == DMPNN_HDR_FLAGS) v = flags_s | (maxdeg_s > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0) | (lean ? PLAN_TILES_ONLY : 0);
         if (tid == DMPNN_HDR_NMTILES) v = n_mtiles < 0 ? 0 : n_mtiles;
+        if (tid == DMPNN_HDR_NSPILL) v = n_mtiles < 0 ? 0 : spill_s;
         if (tid == DMPNN_HDR_LIGHT) v = light;
         if (tid == DMPNN_HDR_MAXDEG) v = maxdeg_s;
         if (tid == DMPNN_HDR_NATOMS) v = nV;
@@ -688,9 +681,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
     int* Y = fe + nV + 2;            // [nV + 2] next-tile pointers
     u16* bm = reinterpret_cast<u16*>(Y + nV + 2);  // [nV] molecule of an atom
     u16* mb = bm + nV + (nV & 1);                  // [nE] molecule of an edge (of its destination atom)
-    __shared__ int bad_s, flags_s, nm_s;
+    __shared__ int bad_s, flags_s, nm_s, spill_s;
     const int tid = threadIdx.x;
-    if (tid == 0) { bad_s = 0; flags_s = 0; nm_s = 0; }
+    if (tid == 0) { bad_s = 0; flags_s = 0; nm_s = 0; spill_s = 0; }
     // phase 1: batch and dst in one batch of loads; batch -> LDS; then molecule of an edge = LDS lookup of its dst
     int64_t d64[kSmallEPT], b64[kSmallItems];
     int bad = 0;
@@ -757,12 +750,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
     TileGeom g;
     g.b0 = kFusedBM; g.n_tiles = 0;
     auto rest = [&](int i0, int n_thr) { write_tiles(plan, L, fe, nV, nE, g, i0, n_thr); };
-    const int n_mtiles = pack_pieces(plan, L, fa, nm, [&](int p) { return fe[p]; }, Y, &bad_s, nV, nE, tid, rest, dbg ? dbg + 16 : nullptr, 3);
+    const int n_mtiles = pack_pieces(plan, L, fa, nm, [&](int p) { return fe[p]; }, Y, &bad_s, &spill_s, nV, nE, tid, rest, dbg ? dbg + 16 : nullptr, 3);
     stamp();  // 4: packed
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
         if (tid == DMPNN_HDR_FLAGS) v = (flags_s & PLAN_RANGE_ERROR) | (n_mtiles < 0 ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
         if (tid == DMPNN_HDR_NMTILES) v = n_mtiles < 0 ? 0 : n_mtiles;
+        if (tid == DMPNN_HDR_NSPILL) v = n_mtiles < 0 ? 0 : spill_s;
         if (tid == DMPNN_HDR_LIGHT) v = 2;
         if (tid == DMPNN_HDR_NATOMS) v = nV;
         if (tid == DMPNN_HDR_NEDGES) v = nE;

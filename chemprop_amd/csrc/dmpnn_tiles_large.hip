@@ -15,7 +15,8 @@
 //
 // The same tables as the single-workgroup kernels produce for small batches (blocked greedy packing; restated in
 // oracle/collate_numpy.py: blocked_molecule_tiles).  Scratch lives in the arrays of the plan a tile plan never fills
-// (src ... ident).  A molecule larger than a tile, more tiles than the launch bound, or a batch vector that is not
+// (src ... ident).  A molecule larger than a tile becomes a tile of its own (counted in DMPNN_HDR_NSPILL; the tile kernel
+// runs its generic path on it); more tiles than the launch bound, or a batch vector that is not
 // 0 .. n_mols-1 non-decreasing gives DMPNN_PLAN_NO_PIECE_TILES (the tile kernel then returns NaN); everything else a
 // wrong table could do is caught by the tile kernel's own closure check on the batch's index arrays.
 #include "dmpnn_common.hpp"
@@ -41,7 +42,8 @@ LargeScratch large_scratch(const PlanLayout& L, int64_t nV) {
     return S;
 }
 
-constexpr int kOversize = 1 << 30;  // bcnt bit: a molecule of the block exceeds a tile
+constexpr int kNonMono = 1 << 30;   // bcnt bit: the offsets of the block are not monotone (not a batch vector)
+constexpr int kCountMask = 0xFF;    // bcnt bits 0..7: tiles of the block (<= 64); bits 8..15: of which oversize (spill) tiles
 
 // number of molecules from the last entry of the batch vector, clamped so that every kernel stays inside its arrays
 __device__ __forceinline__ int mol_count(const long long* __restrict__ batch, int nV) {
@@ -87,12 +89,14 @@ __global__ __launch_bounds__(256) void k_large_blocks(const long long* __restric
     const int* eoff = plan + S.eoff;
     const int p = base + lane;
     const bool valid = p < n_mols;
-    int nx = n_mols, a0 = 0, e0 = 0, over = 0;
+    int nx = n_mols, a0 = 0, e0 = 0, over = 0, bad = 0;
     if (valid) {
         a0 = aoff[p]; e0 = eoff[p];
         int q = p + 1;  // molecules p .. q-1 fit one tile
-        if (aoff[q] - a0 > kMegaBA || eoff[q] - e0 > kMegaBM || aoff[q] < a0 || eoff[q] < e0) {
-            over = 1;   // molecule p alone exceeds a tile (or the offsets are not monotone: not a batch vector)
+        if (aoff[q] < a0 || eoff[q] < e0) {
+            bad = 1;    // the offsets are not monotone: not a batch vector
+        } else if (aoff[q] - a0 > kMegaBA || eoff[q] - e0 > kMegaBM) {
+            over = 1;   // molecule p alone exceeds a tile: a tile of its own (the tile kernel's generic path)
         } else {
             while (q < n_mols && aoff[q + 1] - a0 <= kMegaBA && eoff[q + 1] - e0 <= kMegaBM && aoff[q + 1] >= aoff[q] && eoff[q + 1] >= eoff[q]) ++q;
         }
@@ -111,8 +115,8 @@ __global__ __launch_bounds__(256) void k_large_blocks(const long long* __restric
         plan[S.brow + (int64_t)blk * 64 + r] = e0;
         plan[S.batom + (int64_t)blk * 64 + r] = a0;
     }
-    const unsigned long long any_over = __ballot(over != 0);
-    if (lane == 0) plan[S.bcnt + blk] = __popcll(mask) | (any_over ? kOversize : 0);
+    const unsigned long long overs = __ballot(over != 0), any_bad = __ballot(bad != 0);
+    if (lane == 0) plan[S.bcnt + blk] = __popcll(mask) | (__popcll(overs & mask) << 8) | (any_bad ? kNonMono : 0);
 }
 
 __global__ __launch_bounds__(256) void k_large_finish(const long long* __restrict__ batch, int nV, int nE, int* __restrict__ plan,
@@ -128,22 +132,24 @@ __global__ __launch_bounds__(256) void k_large_finish(const long long* __restric
     int* matom = plan + L.mtile_atom;
     const int slots = (int)L.max_mtiles + 2;
     // one pass over the block counts: rank of this wave's block, the total, the oversize bits
-    int rank = 0, total = 0, over = 0;
+    int rank = 0, total = 0, nonmono = 0, n_spill = 0;
     for (int b2 = lane; b2 < nblk; b2 += 64) {
         const int c = bcnt[b2];
-        over |= c & kOversize;
-        const int n = c & (kOversize - 1);
+        nonmono |= c & kNonMono;
+        const int n = c & kCountMask;
+        n_spill += (c >> 8) & kCountMask;
         total += n;
         if (b2 < wave) rank += n;
     }
     for (int off = 32; off > 0; off >>= 1) {
         rank += __shfl_xor(rank, off);
         total += __shfl_xor(total, off);
-        over |= __shfl_xor(over, off);
+        n_spill += __shfl_xor(n_spill, off);
+        nonmono |= __shfl_xor(nonmono, off);
     }
-    const bool bad = bad_batch || over != 0 || total > (int)L.max_mtiles || total == 0;
+    const bool bad = bad_batch || nonmono != 0 || total > (int)L.max_mtiles || total == 0;
     if (!bad && wave < nblk) {
-        const int n = bcnt[wave] & (kOversize - 1);
+        const int n = bcnt[wave] & kCountMask;
         if (lane < n) {
             mrow[rank + lane] = plan[S.brow + (int64_t)wave * 64 + lane];
             matom[rank + lane] = plan[S.batom + (int64_t)wave * 64 + lane];
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(256) void k_large_finish(const long long* __restric
         int v = 0;
         if (lane == DMPNN_HDR_FLAGS) v = (bad ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
         if (lane == DMPNN_HDR_NMTILES) v = bad ? 0 : total;
+        if (lane == DMPNN_HDR_NSPILL) v = bad ? 0 : n_spill;
         if (lane == DMPNN_HDR_LIGHT) v = 2;
         if (lane == DMPNN_HDR_NATOMS) v = nV;
         if (lane == DMPNN_HDR_NEDGES) v = nE;

@@ -31,16 +31,29 @@ class MolGraph(NamedTuple):
     rev_edge_index: np.ndarray  # [n_edges]  id of the reverse directed edge
 
 
+TILE_MAX_ATOMS, TILE_MAX_EDGES = 32, 48  # kMegaBA / kMegaBM of csrc/dmpnn_common.hpp
+
+
+def molecules_oversize(n_atoms, n_edges) -> bool:
+    """True when a molecule of the batch exceeds the tile of the whole-forward tile kernel (host knowledge, free while batching)."""
+    n_atoms, n_edges = np.asarray(n_atoms), np.asarray(n_edges)
+    return bool(n_atoms.size and (int(n_atoms.max()) > TILE_MAX_ATOMS or int(n_edges.max()) > TILE_MAX_EDGES))
+
+
 class BatchMolGraph:
     """A batch of :class:`MolGraph` as five tensors.  ``len()`` is the number of molecules."""
 
-    __slots__ = ("V", "E", "edge_index", "rev_edge_index", "batch", "_size", "tiles")
+    __slots__ = ("V", "E", "edge_index", "rev_edge_index", "batch", "_size", "tiles", "oversize")
 
     def __init__(self, mgs: Sequence[MolGraph]):
         self._size = len(mgs)
         self.tiles = None  # (tile_row, tile_atom, n_tiles) device int32 views: only batches from PackedBatch.to_device
         n_atoms = np.fromiter((len(mg.V) for mg in mgs), dtype=np.int64, count=len(mgs))
         n_edges = np.fromiter((mg.edge_index.shape[1] for mg in mgs), dtype=np.int64, count=len(mgs))
+        # what the host knows for free while batching: does a molecule exceed the whole-forward tile kernel's tile?
+        # (True: this batch takes the per-step routes; False: the tile kernel with no oversize molecule in sight;
+        # None — batches that arrive as bare tensors — : the kernel's own generic path covers whatever turns up)
+        self.oversize = molecules_oversize(n_atoms, n_edges)
         atom_off = np.concatenate([[0], np.cumsum(n_atoms)[:-1]]) if len(mgs) else np.zeros(0, np.int64)
         edge_off = np.concatenate([[0], np.cumsum(n_edges)[:-1]]) if len(mgs) else np.zeros(0, np.int64)
 
@@ -73,11 +86,13 @@ class BatchMolGraph:
         self.edge_index, self.rev_edge_index, self.batch = edge_index, rev_edge_index, batch
         self._size = int(size) if size is not None else (int(batch[-1]) + 1 if batch.numel() else 0)
         self.tiles = None
+        self.oversize = None
         return self
 
     def __copy__(self):
         b = BatchMolGraph.from_tensors(self.V, self.E, self.edge_index, self.rev_edge_index, self.batch, self._size)
         b.tiles = self.tiles  # (a graph_transform scales V / E of a shallow copy: the connectivity is the same)
+        b.oversize = self.oversize
         return b
 
 
@@ -111,7 +126,7 @@ class PackedBatch:
     ``V`` / ``E`` are views of the copied buffer and whose index tensors are the int64 tensors the reference builds,
     bit for bit.  No arithmetic of the batching happens on the host beyond the two running sums."""
 
-    __slots__ = ("buf", "n_mols", "n_atoms", "n_edges", "n_erows", "d_v", "d_e", "sections", "n_tiles")
+    __slots__ = ("buf", "n_mols", "n_atoms", "n_edges", "n_erows", "d_v", "d_e", "sections", "n_tiles", "oversize")
 
     def __init__(self, mgs: Sequence[MolGraph], pin: bool = False, tiles: bool = True):
         n_mols = len(mgs)
@@ -128,7 +143,8 @@ class PackedBatch:
         atom_off[1:] = np.cumsum(n_at)
         edge_off[1:] = np.cumsum(n_ed)
         n_tiles, trow, tatom = -1, None, None
-        if tiles and n_mols and nV:
+        self.oversize = molecules_oversize(n_at, n_ed)  # such a batch ships no table and takes the per-step routes
+        if tiles and n_mols and nV and not self.oversize:
             from . import _lib
 
             lib = _lib.load()
@@ -137,7 +153,7 @@ class PackedBatch:
             n_tiles = int(lib.dmpnn_pack_tiles(atom_off.ctypes.data, edge_off.ctypes.data, n_mols, trow.ctypes.data,
                                                tatom.ctypes.data, cap))
             if n_tiles < 0:
-                n_tiles = -1  # a molecule larger than a tile: the device plans decide the route
+                n_tiles = -1  # (table capacity: the device plans decide)
         nt = n_tiles + 1 if n_tiles >= 0 else 0
         sec, o = {}, _WIRE_HEADER * 8
         for name, nbytes in (("atom_off", 4 * (n_mols + 1)), ("edge_off", 4 * (n_mols + 1)), ("src", 4 * nE), ("dst", 4 * nE),
@@ -202,6 +218,7 @@ class PackedBatch:
                                                  nV, nE, edge_index.data_ptr(), rev.data_ptr(), batch.data_ptr(),
                                                  engine._stream_ptr(device)), "dmpnn_collate")
         bmg = BatchMolGraph.from_tensors(V, E, edge_index, rev, batch, self.n_mols)
+        bmg.oversize = self.oversize
         if self.n_tiles >= 0:
             bmg.tiles = (sl("tile_row").view(torch.int32), sl("tile_atom").view(torch.int32), self.n_tiles)
         return bmg

@@ -96,7 +96,7 @@ class GraphPlan:
     """K0: int32 indices + stable incoming-edge CSR of one batch, built on device (no host sync)."""
 
     __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index", "loader_tiles",
-                 "any_size")
+                 "any_size", "oversize")
 
     def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False, batch: Optional[Tensor] = None,
                  tiles: Optional[tuple] = None):
@@ -111,6 +111,7 @@ class GraphPlan:
         nbytes = plan_bytes(n_atoms, n_edges)
         self.buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
         self.n_atoms, self.n_edges, self.device = int(n_atoms), n_edges, dev
+        self.oversize = None  # host knowledge of the batching code: a molecule exceeds the tile kernel's tile (True / False / unknown)
         # light=True: only what a forward of the fused routes reads (inference); light="tiles": only the piece-tile
         # tables — the whole-forward tile kernel then works on the caller's own index arrays (kept alive here);
         # batches beyond the single-workgroup plan always get the full plan
@@ -164,6 +165,10 @@ class GraphPlan:
                     dstp=cut(off[7], E), revp=cut(off[8], E), tile_row=cut(off[9], T + 2),
                     tile_atom=cut(off[10], T + 2), mtile_row=cut(off[12], int(off[14]) + 2),
                     mtile_atom=cut(off[13], int(off[14]) + 2))
+
+    def header(self) -> list:
+        """The 16 header words (synchronises): [0] flags, [6] piece tiles, [8] oversize pieces (DMPNN_HDR_NSPILL), ..."""
+        return self.buf[:16].tolist()
 
     def flags(self) -> int:
         """Plan flag word (synchronises): bit0 asymmetric, bit1 index out of range, bit2 in-degree > 24."""
@@ -435,6 +440,11 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         n_mslots = max(n_steps, 1) if keep else 1
     st.plan, st.ldh, st.n_hslots, st.n_mslots = plan, ldh, n_hslots, n_mslots
     need_h0 = not (use_mega and not keep)
+    spill_ws = None
+    if use_mega and not keep and getattr(plan, "oversize", None) is not False and nV:
+        # scratch of the tile kernel's generic path, should a molecule exceed its tile (never touched otherwise)
+        spill_ws = torch.empty((3 * nE + nV) * ldh, dtype=torch.float32, device=dev)
+        a.spill_ws, a.spill_bytes = spill_ws.data_ptr(), spill_ws.numel() * 4
     if use_mega and not keep and not d_vd:  # inference tile kernel: nothing leaves the CU but `out`
         edge_ws = atom_ws = None
     else:
@@ -493,7 +503,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     with _OnDevice(dev):
         _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
-    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, wsplit)
+    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, wsplit)
     st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)
     return out, st
 

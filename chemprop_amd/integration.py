@@ -20,7 +20,7 @@ from typing import Optional
 
 from torch import Tensor
 
-from .nn import atom_message_passing_forward, bond_message_passing_forward
+from .nn import EngineStateMixin, atom_message_passing_forward, bond_message_passing_forward
 
 _cls_cache = None
 
@@ -42,7 +42,7 @@ def hip_bond_message_passing_class():
         return _cls_cache
     Ref = _reference_class()
 
-    class HipBondMessagePassing(Ref):  # type: ignore[misc, valid-type]
+    class HipBondMessagePassing(EngineStateMixin, Ref):  # type: ignore[misc, valid-type]
         """``chemprop.nn.BondMessagePassing`` whose ``forward`` (base.py:196-212) runs on the MI355X
         HIP kernels.  Raises on non-HIP tensors: there is no CPU fallback inside the engine — keep the
         stock class for CPU runs."""

@@ -160,7 +160,10 @@ def mab_forward(mp, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = N
         # the same route policy as the bond block (nn.py: _route): the first batches of a module are checked on the plan's
         # verdict — an oversize molecule switches the tile kernel off for the module, an unusual graph takes the general route
         n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+        plan.oversize = getattr(bmg, "oversize", None)
         level = _route(mp, plan, n_mols, getattr(bmg, "batch", None))
+        if plan.oversize is True:  # (host knowledge of the batching code: per-step routes for this batch)
+            level = min(level, 1)
         Hv, st = engine.forward(plan, V, E, mp.W_i.weight, mp.W_h.weight, mp.W_vo.weight, mp.W_vo.bias,
                                 mp.W_i.bias, mp.W_h.bias, mp.W_vd.weight if has_vd else None,
                                 mp.W_vd.bias if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,

@@ -73,7 +73,34 @@ class _HParams(dict):
             raise AttributeError(k) from e
 
 
-class BondMessagePassing(nn.Module):
+_CACHE_KEYS = ("_dmpnn_replay", "_dmpnn_wcache", "_dmpnn_last", "_dmpnn_mon")
+
+
+def invalidate(module: nn.Module) -> None:
+    """Drop what the engine remembers about ``module`` between forwards (pre-split weights, the replayed argument
+    block, the spill monitor).  The caches key on the weight tensors' identity, ``data_ptr()``, device and autograd
+    ``_version``, so every in-place update through the tensor API (optimizer steps, ``load_state_dict``, ``copy_``),
+    every re-allocation and every device move is seen.  Writes through ``param.data`` (``p.data.mul_()``, EMA / SWA
+    swaps that assign ``p.data``'s storage in place) bump no version: call this after such an update, or run with
+    ``DMPNN_WCACHE=0 DMPNN_REPLAY=0``."""
+    for m in module.modules():
+        for k in _CACHE_KEYS:
+            m.__dict__.pop(k, None)
+
+
+class EngineStateMixin:
+    """``copy.deepcopy`` / pickling / ``.to()`` of a block must not carry pointers into another module's buffers."""
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in _CACHE_KEYS}
+
+    def _apply(self, fn, *args, **kwargs):
+        for k in _CACHE_KEYS:
+            self.__dict__.pop(k, None)
+        return super()._apply(fn, *args, **kwargs)
+
+
+class BondMessagePassing(EngineStateMixin, nn.Module):
     """Directed-bond message passing (D-MPNN encoder) on MI355X HIP kernels."""
 
     def __init__(self, d_v: int = DEFAULT_ATOM_FDIM, d_e: int = DEFAULT_BOND_FDIM,
@@ -114,7 +141,7 @@ class _Replay:
     decision was taken on.  A call that finds all of them unchanged only builds the tile plan, allocates ``out`` and
     fills in the batch's pointers — the same two C calls, without the general routing code in between."""
 
-    __slots__ = ("args", "tensors", "versions", "tau", "training", "env", "dev", "d_v", "d_e", "d_h", "wsplit", "depth")
+    __slots__ = ("args", "tensors", "versions", "ptrs", "tau", "training", "env", "dev", "d_v", "d_e", "d_h", "wsplit", "depth")
 
 
 def _param(mp, lin: str, name: str):
@@ -131,7 +158,8 @@ def _make_replay(mp, plan, st) -> None:
     r.args = bytes(st.args)  # template copy of the argument block
     r.tensors = tuple(_param(mp, l, n) for l, n in (("W_i", "weight"), ("W_h", "weight"), ("W_o", "weight"), ("W_i", "bias"),
                                                       ("W_h", "bias"), ("W_o", "bias")))
-    r.versions = tuple(t._version for t in r.tensors[:3])
+    r.versions = tuple(-1 if t is None else t._version for t in r.tensors)
+    r.ptrs = tuple(0 if t is None else t.data_ptr() for t in r.tensors)
     r.tau, r.training, r.depth = mp._modules.get("tau"), mp.training, mp.depth
     r.env = tuple(_lib.opt(k, "") for k in _ENV_KEYS)
     r.dev = plan.device
@@ -152,8 +180,9 @@ def _replay_forward(mp, r: "_Replay", bmg):
     if (_param(mp, "W_i", "weight") is not ts[0] or _param(mp, "W_h", "weight") is not ts[1] or _param(mp, "W_o", "weight") is not ts[2]
             or _param(mp, "W_i", "bias") is not ts[3] or _param(mp, "W_h", "bias") is not ts[4] or _param(mp, "W_o", "bias") is not ts[5]):
         return None
-    if ts[0]._version != r.versions[0] or ts[1]._version != r.versions[1] or ts[2]._version != r.versions[2]:
-        return None
+    for t, ver, ptr in zip(ts, r.versions, r.ptrs):  # same values (every tensor-API update bumps _version), same storage, same device
+        if t is not None and (t._version != ver or t.data_ptr() != ptr or t.device != r.dev):
+            return None
     if tuple(_lib.opt(k, "") for k in _ENV_KEYS) != r.env:
         return None
     V, E, ei, rev, batch = bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, getattr(bmg, "batch", None)
@@ -165,6 +194,9 @@ def _replay_forward(mp, r: "_Replay", bmg):
         return None
     nV, nE = int(V.shape[0]), int(E.shape[0])
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    oversize = getattr(bmg, "oversize", None)
+    if oversize is True:  # (the host knows a molecule of this batch exceeds the tile: per-step routes)
+        return None
     tiles = getattr(bmg, "tiles", None)
     if tiles is not None and (tiles[0].device != dev or tiles[2] <= 0):
         tiles = None
@@ -185,6 +217,12 @@ def _replay_forward(mp, r: "_Replay", bmg):
     a.Mv = a.Hv = pb
     a.edge_index, a.rev_edge_index = ei.data_ptr(), rev.data_ptr()
     a.flags |= _lib.F_WSPLIT_READY
+    spill = None
+    if oversize is None:  # bare tensors: scratch for the kernel's generic path, should a molecule exceed the tile
+        spill = torch.empty((3 * nE + nV) * a.ldh, dtype=torch.float32, device=dev)
+        a.spill_ws, a.spill_bytes = spill.data_ptr(), spill.numel() * 4
+    else:
+        a.spill_ws, a.spill_bytes = None, 0
     stream = engine._stream_ptr(dev)
     with engine._OnDevice(dev):
         if tiles is not None:  # the loader's table: K0 is a copy of it
@@ -197,10 +235,46 @@ def _replay_forward(mp, r: "_Replay", bmg):
             a.n_tiles_launch = 0
             _lib.check(lib.dmpnn_prepare_tiles(a.edge_index, a.rev_edge_index, batch.data_ptr(), nV, nE, pb, nbytes, stream), "dmpnn_prepare_tiles")
         _lib.check(lib.dmpnn_forward(_ctypes.byref(a), stream), "dmpnn_forward")
+    if oversize is None:
+        _spill_monitor(mp, buf, dev)
     from .agg import note_batch
 
     note_batch(batch, n_mols)
     return out
+
+
+class _Monitor:
+    __slots__ = ("host", "event", "pending", "calls", "observed", "with_spill")
+
+
+def _spill_monitor(mp, plan_buf: Tensor, dev) -> None:
+    """Speed heuristic only (correctness never depends on it: the tile kernels carry an oversize molecule through their
+    generic path).  Now and then the header of a tile plan is copied to pinned host memory WITHOUT a sync and read at a
+    later forward; a module that keeps meeting oversize molecules is moved to the per-step routes, whose time does not
+    hinge on the slowest molecule."""
+    m = mp.__dict__.get("_dmpnn_mon")
+    if m is None:
+        m = _Monitor()
+        m.host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        m.event = torch.cuda.Event()
+        m.pending, m.calls, m.observed, m.with_spill = False, 0, 0, 0
+        mp.__dict__["_dmpnn_mon"] = m
+    if m.pending and m.event.query():
+        m.pending = False
+        _note_spills(mp, m, int(m.host[8]))
+    m.calls += 1
+    if not m.pending and (m.calls % 8 == 0 if m.calls <= 64 else m.calls % 64 == 0):
+        m.host.copy_(plan_buf[:16], non_blocking=True)
+        m.event.record(torch.cuda.current_stream(dev))
+        m.pending = True
+
+
+def _note_spills(mp, m, n_spill: int) -> None:
+    m.observed += 1
+    if n_spill > 0:
+        m.with_spill += 1
+    if m.with_spill >= 2 and 4 * m.with_spill >= m.observed:
+        object.__setattr__(mp, "_dmpnn_no_mega", True)
 
 
 def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tensor:
@@ -229,8 +303,11 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     loader_tiles = getattr(bmg, "tiles", None) is not None or (
         getattr(bmg, "batch", None) is not None and not engine.small_plan_fits(int(bmg.V.shape[0]), int(bmg.E.shape[0]))
         and bool(_lib.load().dmpnn_tile_plan_any_size(int(bmg.V.shape[0]), int(bmg.E.shape[0]))))
+    oversize = getattr(bmg, "oversize", None)  # host knowledge of the batching code (None: bare tensors)
+    if oversize is True:
+        loader_tiles = False
     light = _light_plan_ok(mp) and (int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES or loader_tiles)
-    if light and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
+    if light and oversize is not True and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
         light = "tiles"
     elif light and int(bmg.E.shape[0]) >= engine.STEPS16_MIN_EDGES:
         light = False
@@ -240,7 +317,13 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
 
         note_batch(bmg.batch, n_mols)  # the aggregation that follows (model.py:131) skips its host read of batch.max()
     mp.__dict__.pop("_dmpnn_last", None)
-    out = mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=_route(mp, plan, n_mols, getattr(bmg, "batch", None)))
+    plan.oversize = oversize
+    level = _route(mp, plan, n_mols, getattr(bmg, "batch", None))
+    if oversize is True:
+        level = min(level, 1)
+    out = mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=level)
+    if oversize is None and plan.tiles_only and mp.__dict__.get("_dmpnn_last") is not None and mp.__dict__["_dmpnn_last"].route == "mega16":
+        _spill_monitor(mp, plan.buf, plan.device)
     if light == "tiles" and V_d is None and not torch.is_grad_enabled() and _lib.opt("DMPNN_REPLAY", "1") != "0":
         _make_replay(mp, plan, mp.__dict__.pop("_dmpnn_last", None))
     return out
@@ -289,7 +372,12 @@ def _route(mp, plan, n_mols: int = 0, batch=None) -> int:
     synchronously — featurizer-produced graphs never violate the graph invariants; ``always`` checks
     every batch (a sync per forward), ``never`` trusts.  A batch found in violation runs the next more
     general route; one oversize molecule switches the tile kernel off for the module (datasets of
-    larger molecules use the per-step fused route)."""
+    larger molecules use the per-step fused route).
+
+    Molecule SIZE is not a validity question any more: a molecule larger than a tile is a tile of its own that the
+    tile kernels run through their generic fp32 path (``csrc/dmpnn_spill_impl.hpp``) — whenever it turns up, validated
+    window or not.  The host only decides speed: a batch whose batching code knows it holds such a molecule
+    (``bmg.oversize``), and a module that keeps meeting them (``_spill_monitor``), take the per-step routes."""
     mode = _lib.opt("DMPNN_VALIDATE", "first")
     seen = getattr(mp, "_dmpnn_batches_checked", 0)
     no_mega = getattr(mp, "_dmpnn_no_mega", False)
@@ -297,9 +385,15 @@ def _route(mp, plan, n_mols: int = 0, batch=None) -> int:
         no_mega = True
     if mode == "always" or (mode == "first" and seen < _VALIDATE_FIRST_N):
         object.__setattr__(mp, "_dmpnn_batches_checked", seen + 1)
-        flags = plan.flags()
+        hdr = plan.header()
+        flags = hdr[0]
         if flags & 7:
             return 0
+        if hdr[8] > 0 and getattr(plan, "oversize", None) is None:
+            # oversize molecules (the tile kernels carry them through their generic path: correct, slow): a module whose
+            # first batches already hold some takes the per-step routes (a speed decision; _spill_monitor keeps watching)
+            no_mega = True
+            object.__setattr__(mp, "_dmpnn_no_mega", True)
         if flags & 8:
             # no piece tiles: a molecule larger than a tile switches the tile kernel off for the module — but a batch
             # beyond the single-workgroup plan has none either way, which says nothing about its molecules

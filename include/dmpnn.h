@@ -19,7 +19,9 @@
  *     allocates or frees device memory, so every call is hipGraph-capture safe.
  *   - every function returns 0 on success, a negative DMPNN_E* code otherwise, never throws,
  *     never exits; dmpnn_last_error_string() describes the last failure on the calling thread.
- *   - dtype of the arithmetic is fp32 (fp32 MFMA v_mfma_f32_16x16x4_f32 for the contractions).
+ *   - tensors are fp32; the contractions accumulate in fp32: on the f16 matrix pipe with the exact 3-term operand
+ *     split (v_mfma_f32_16x16x32_f16; DMPNN_F_SPLIT16, the default of the host side) or on the exact fp32 MFMA
+ *     (v_mfma_f32_16x16x4_f32) — both fp32-class, see DESIGN.md section 3.
  */
 #ifndef DMPNN_H
 #define DMPNN_H
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 4
+#define DMPNN_ABI_VERSION 5
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -119,8 +121,11 @@ enum dmpnn_plan_hdr {
                               bit2: an in-degree exceeds what the fused row tiling supports (24).
                               Any of bits 0-2 set: a forward with DMPNN_F_FUSED returns NaN (loud) —
                               run such graphs without DMPNN_F_FUSED;
-                              bit3: no piece tiles (a connected piece exceeds 48 rows / 32 atoms, or the
-                              batch is too large for the single-workgroup plan): DMPNN_F_MEGA returns NaN */
+                              bit3: no piece tiles (the batch is too large for the single-workgroup plan and no
+                              batch vector was given, or the batch vector / the edge order is not the one collate
+                              produces): DMPNN_F_MEGA returns NaN.  A piece (molecule) of more than 48 rows / 32 atoms
+                              is NOT an error: it becomes a tile of its own, counted in DMPNN_HDR_NSPILL, and the tile
+                              kernels carry it through their generic fp32 path (csrc/dmpnn_spill_impl.hpp)          */
     DMPNN_HDR_MAXDEG = 1,
     DMPNN_HDR_NATOMS = 2,
     DMPNN_HDR_NEDGES = 3,
@@ -130,6 +135,8 @@ enum dmpnn_plan_hdr {
     DMPNN_HDR_LIGHT = 7,   /* 1: light plan (dmpnn_prepare_light): src / dst / rev / inv / dstp / ident
                               were NOT written — valid for forwards of the fused routes only;
                               2: tile plan (dmpnn_prepare_tiles): only the piece-tile tables were written  */
+    DMPNN_HDR_NSPILL = 8,  /* piece tiles that exceed the matrix-pipe tile (48 rows / 32 atoms): slow but exact;
+                              the host reads it asynchronously to move datasets of large molecules to the per-step routes */
     DMPNN_HDR_WORDS = 16
 };
 /* Word offsets of the arrays inside the plan (for tests):
@@ -248,8 +255,14 @@ typedef struct dmpnn_fwd_args {
     /* DMPNN_F_MEGA: number of tile workgroups to launch when the caller knows the tile count (loader tiles); 0 = the
      * launch bound of the batch size (workgroups beyond the table's tiles exit at once) */
     int64_t n_tiles_launch;
+    /* DMPNN_F_MEGA without DMPNN_F_KEEP: scratch of >= dmpnn_forward_spill_bytes() bytes for molecules larger than a
+     * tile (generic in-kernel path; with DMPNN_F_KEEP the kept tensors serve).  NULL: such a molecule's atoms come back
+     * NaN (never a silently wrong number). */
+    float* spill_ws; size_t spill_bytes;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
+/* (3 n_edges + n_atoms) * ldh floats: H0 | H^(t) | M^(t) | Mv of the generic path, indexed by the batch's own rows */
+size_t dmpnn_forward_spill_bytes(const dmpnn_fwd_args* a);
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
 /* 1 when the shapes / alignment of `a` allow DMPNN_F_FUSED (d_h % 4 == 0, d_h <= 320, even d_v and
  * d_e, directed), 2 when they also allow DMPNN_F_MEGA (batch within the single-workgroup plan:

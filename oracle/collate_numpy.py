@@ -55,7 +55,7 @@ def unpack_wire(raw: np.ndarray):
 def greedy_molecule_tiles(n_atoms, n_edges, max_rows: int = 48, max_atoms: int = 32):
     """The loader-side tile table (``dmpnn_pack_tiles``): consecutive whole molecules packed greedily into tiles of at most
     ``max_rows`` directed edges and ``max_atoms`` atoms (the tile limits of the whole-forward tile kernel).
-    -> (tile_row [n+1], tile_atom [n+1]) or None when one molecule alone exceeds a tile.  Molecules without atoms and
+    -> (tile_row [n+1], tile_atom [n+1]); a molecule that alone exceeds a tile is a tile of its own.  Molecules without atoms and
     bonds belong to no tile."""
     rows, atoms = [], []
     r = a = 0          # running offsets
@@ -63,14 +63,14 @@ def greedy_molecule_tiles(n_atoms, n_edges, max_rows: int = 48, max_atoms: int =
     open_tile = False
     for na, ne in zip(n_atoms, n_edges):
         na, ne = int(na), int(ne)
-        if na > max_atoms or ne > max_rows:
-            return None
         if open_tile and (a + na - ta > max_atoms or r + ne - tr > max_rows):
             open_tile = False
         if not open_tile and (na or ne):
             rows.append(r); atoms.append(a)
             tr, ta, open_tile = r, a, True
         r += ne; a += na
+        if na > max_atoms or ne > max_rows:
+            open_tile = False  # an oversize molecule is a tile of its own (the tile kernel's generic path)
     rows.append(r); atoms.append(a)
     return np.array(rows, dtype=np.int32), np.array(atoms, dtype=np.int32)
 
@@ -78,13 +78,11 @@ def greedy_molecule_tiles(n_atoms, n_edges, max_rows: int = 48, max_atoms: int =
 def blocked_molecule_tiles(n_atoms, n_edges, block: int = 64, max_rows: int = 48, max_atoms: int = 32):
     """The DEVICE tile planners' packing (k_prepare_tiles_batch for small batches, dmpnn_tiles_large.hip beyond): greedy as
     above, except that a tile also starts at every block of ``block`` consecutive molecules (the blocks are walked in
-    parallel).  -> (tile_row [n+1], tile_atom [n+1]) or None when a molecule alone exceeds a tile."""
+    parallel).  -> (tile_row [n+1], tile_atom [n+1]); a molecule that alone exceeds a tile is a tile of its own."""
     n_atoms, n_edges = [int(x) for x in n_atoms], [int(x) for x in n_edges]
     n = len(n_atoms)
     ao = np.concatenate([[0], np.cumsum(n_atoms)]).astype(np.int64)
     eo = np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int64)
-    if any(a > max_atoms for a in n_atoms) or any(e > max_rows for e in n_edges):
-        return None
     rows, atoms = [], []
     for base in range(0, n, block):
         lim = min(base + block, n)
@@ -92,8 +90,9 @@ def blocked_molecule_tiles(n_atoms, n_edges, block: int = 64, max_rows: int = 48
         while p < lim:
             rows.append(int(eo[p])); atoms.append(int(ao[p]))
             q = p + 1
-            while q < n and ao[q + 1] - ao[p] <= max_atoms and eo[q + 1] - eo[p] <= max_rows:
-                q += 1
+            if n_atoms[p] <= max_atoms and n_edges[p] <= max_rows:  # (an oversize molecule is a tile of its own)
+                while q < n and ao[q + 1] - ao[p] <= max_atoms and eo[q + 1] - eo[p] <= max_rows:
+                    q += 1
             p = q
     rows.append(int(eo[n])); atoms.append(int(ao[n]))
     return np.array(rows, dtype=np.int32), np.array(atoms, dtype=np.int32)

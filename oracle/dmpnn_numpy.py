@@ -82,8 +82,8 @@ def piece_tiles(src, dst, row_ptr, n_slots, bm=48, ba=32, block=64):
     csrc/dmpnn_prepare.hip): a cut after atom ``v`` is safe when no edge joins atoms <= v with atoms
     > v; consecutive pieces are packed greedily into tiles of <= ``bm`` rows and <= ``ba`` atoms, and a
     tile also starts at every ``block``-th piece (the kernel walks blocks of pieces in parallel).
-    Returns (mtile_row[n_slots + 2], mtile_atom[n_slots + 2], n_tiles) or n_tiles = -1 if a piece
-    does not fit."""
+    Returns (mtile_row[n_slots + 2], mtile_atom[n_slots + 2], n_tiles); n_tiles = -1 if the table does not
+    hold them.  A piece that alone exceeds a tile gets a tile of its own (the kernels' generic path)."""
     src, dst, row_ptr = (np.asarray(a, dtype=np.int64) for a in (src, dst, row_ptr))
     n_atoms, n_edges = len(row_ptr) - 1, len(src)
     mrow = np.full(n_slots + 2, n_edges, dtype=np.int64)
@@ -98,12 +98,12 @@ def piece_tiles(src, dst, row_ptr, n_slots, bm=48, ba=32, block=64):
     tiles, p = [], 0
     while p < n_pieces:
         v = starts[p]
-        if starts[p + 1] - v > ba or row_ptr[starts[p + 1]] - row_ptr[v] > bm:
-            return mrow, matom, -1
         q = p + 1
         lim = min(n_pieces, (p // block + 1) * block)
-        while q < lim and starts[q + 1] - v <= ba and row_ptr[starts[q + 1]] - row_ptr[v] <= bm:
-            q += 1
+        # (a piece that alone exceeds a tile is a tile of its own: the tile kernels run their generic path on it)
+        if not (starts[p + 1] - v > ba or row_ptr[starts[p + 1]] - row_ptr[v] > bm):
+            while q < lim and starts[q + 1] - v <= ba and row_ptr[starts[q + 1]] - row_ptr[v] <= bm:
+                q += 1
         tiles.append(v)
         p = q
     if len(tiles) > n_slots:

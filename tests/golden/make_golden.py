@@ -98,6 +98,9 @@ CASES = {
     "mixed_single_h44": (lambda: synth.random_molgraphs(3, "qm9", seed=20) + single_atoms(2) + synth.random_molgraphs(2, "qm9", seed=21),
                          dict(d_h=44), 20),
     "synth40x4_h300": (lambda: synth.random_molgraphs(4, "synth40", seed=22), dict(), 22),
+    # BASELINE configs[4] at its own shape: 64 condensed-graph-of-reaction graphs (the notebook's batch size), d_v 106, d_e 28
+    # (featurizers/molgraph/reaction.py:77-78), d_h 300 — the wide-operand path (W_i [300, 134], W_o [300, 406])
+    "cgr64_h300": (lambda: synth.random_molgraphs(64, "cgr", seed=23), dict(d_v=106, d_e=28), 23),
 }
 
 
@@ -152,6 +155,9 @@ def run_case(name, build, kw, seed, BMP, BMG, trained=None):
     if big:
         for k in ("H0", "M1", "H_last"):
             arrs.pop(k, None)
+    if out.numel() > 200_000:  # fixture size: G is reproducible (torch.Generator().manual_seed(1000 + seed)), Mv is implied by out
+        for k in ("G", "Mv"):
+            arrs.pop(k, None)
     cfg = dict(kw)
     cfg.setdefault("d_v", 72); cfg.setdefault("d_e", 14); cfg.setdefault("d_h", 300)
     cfg.setdefault("depth", 3); cfg.setdefault("bias", False); cfg.setdefault("undirected", False)
@@ -171,14 +177,25 @@ def run_case(name, build, kw, seed, BMP, BMG, trained=None):
 def main():
     BMP, BMG, _ = ref_shim.load_reference()
     torch.set_num_threads(1)
+    only = set(sys.argv[1:])  # (names: regenerate just these)
     for name, (build, kw, seed) in CASES.items():
-        run_case(name, build, kw, seed, BMP, BMG)
+        if not only or name in only:
+            run_case(name, build, kw, seed, BMP, BMG)
     # trained weights from the reference's own fixture checkpoint (realistic weight distribution)
     ck = os.path.join(ref_shim.REFERENCE_ROOT, "tests", "data", "example_model_v2_regression_mol.pt")
     if os.path.isfile(ck):
         d = torch.load(ck, map_location="cpu", weights_only=False)
         sd = {k[len("message_passing."):]: v for k, v in d["state_dict"].items() if k.startswith("message_passing.")}
-        run_case("trained_v2_mol", lambda: synth.random_molgraphs(12, "qm9", seed=30), dict(), 30, BMP, BMG, trained=sd)
+        if not only or "trained_v2_mol" in only:
+            run_case("trained_v2_mol", lambda: synth.random_molgraphs(12, "qm9", seed=30), dict(), 30, BMP, BMG, trained=sd)
+    # ... and of the reaction model (W_i [300, 134], CGR featurization): trained weights on CGR-shaped graphs
+    ck = os.path.join(ref_shim.REFERENCE_ROOT, "tests", "data", "example_model_v2_regression_rxn.pt")
+    if os.path.isfile(ck) and (not only or "trained_v2_rxn" in only):
+        d = torch.load(ck, map_location="cpu", weights_only=False)
+        sd = {k[len("message_passing."):]: v for k, v in d["state_dict"].items() if k.startswith("message_passing.")}
+        d_in = sd["W_i.weight"].shape[1]
+        assert d_in == 106 + 28, d_in
+        run_case("trained_v2_rxn", lambda: synth.random_molgraphs(24, "cgr", seed=31), dict(d_v=106, d_e=28), 31, BMP, BMG, trained=sd)
 
 
 if __name__ == "__main__":

@@ -148,14 +148,18 @@ def test_pack_tiles_vs_oracle(kind, n_mols, seed):
     n_ed = [m.edge_index.shape[1] for m in mgs]
     want = oc.greedy_molecule_tiles(n_at, n_ed)
     n, tr, ta = _pack_tiles(n_at, n_ed)
-    if want is None:
-        assert n == -1
-        return
     assert n == len(want[0]) - 1 and np.array_equal(tr, want[0]) and np.array_equal(ta, want[1])
-    # what the tile kernel needs: whole molecules, <= 48 rows and <= 32 atoms per tile, a partition of the batch
+    # what the tile kernel needs: whole molecules, a partition of the batch; <= 48 rows and <= 32 atoms per tile — or ONE
+    # molecule beyond that (a tile of its own for the kernel's generic path)
     assert tr[0] == 0 and ta[0] == 0 and tr[-1] == sum(n_ed) and ta[-1] == sum(n_at)
-    assert (np.diff(tr) <= 48).all() and (np.diff(ta) <= 32).all() and (np.diff(ta) > 0).all()
-    assert set(ta.tolist()) <= set(np.concatenate([[0], np.cumsum(n_at)]).tolist())
+    starts = np.concatenate([[0], np.cumsum(n_at)])
+    assert set(ta.tolist()) <= set(starts.tolist()) and (np.diff(ta) > 0).all()
+    for t in range(n):
+        if tr[t + 1] - tr[t] > 48 or ta[t + 1] - ta[t] > 32:
+            m = int(np.searchsorted(starts, ta[t]))
+            assert starts[m] == ta[t] and starts[m + 1] == ta[t + 1], "an oversize tile holds exactly one molecule"
+    if kind == "zinc":
+        assert any(tr[t + 1] - tr[t] > 48 for t in range(n))
 
 
 def test_pack_tiles_edge_cases():
@@ -165,8 +169,12 @@ def test_pack_tiles_edge_cases():
         want = oc.greedy_molecule_tiles(n_at, n_ed)
         n, tr, ta = _pack_tiles(n_at, n_ed)
         assert n == len(want[0]) - 1 and np.array_equal(tr, want[0]) and np.array_equal(ta, want[1]), (n_at, n_ed)
-    assert _pack_tiles([33], [10])[0] == -1 and _pack_tiles([4, 20], [6, 50])[0] == -1   # a molecule larger than a tile
-    assert oc.greedy_molecule_tiles([33], [10]) is None
+    # a molecule larger than a tile: a tile of its own (the tile kernel's generic path), never a refusal
+    for n_at, n_ed in (([33], [10]), ([4, 20], [6, 50]), ([4, 40, 3, 3], [6, 86, 4, 4]), ([40, 40], [86, 90])):
+        want = oc.greedy_molecule_tiles(n_at, n_ed)
+        n, tr, ta = _pack_tiles(n_at, n_ed)
+        assert n == len(want[0]) - 1 and np.array_equal(tr, want[0]) and np.array_equal(ta, want[1]), (n_at, n_ed)
+    assert _pack_tiles([4, 40, 3, 3], [6, 86, 4, 4])[1].tolist() == [0, 6, 92, 100]
 
 
 def test_packed_batch_carries_the_tile_table():
@@ -181,8 +189,9 @@ def test_packed_batch_carries_the_tile_table():
     assert pb.n_tiles == w["n_tiles"] == len(want[0]) - 1
     assert np.array_equal(w["tile_row"], want[0]) and np.array_equal(w["tile_atom"], want[1])
     assert PackedBatch(mgs, tiles=False).n_tiles == -1
-    big = synth.random_molgraphs(6, "synth40", seed=1)  # 40-atom molecules: no table, the device plans decide
-    assert PackedBatch(big).n_tiles == -1
+    assert pb.oversize is False
+    big = synth.random_molgraphs(6, "synth40", seed=1)  # 40-atom molecules: the host knows, no table, per-step routes
+    assert PackedBatch(big).n_tiles == -1 and PackedBatch(big).oversize is True
 
 
 @pytest.mark.gpu
@@ -329,7 +338,7 @@ def test_pack_tiles_properties():
 
     from oracle import collate_numpy as oc
 
-    sizes = st.lists(st.tuples(st.integers(0, 34), st.integers(0, 52)), min_size=0, max_size=300)
+    sizes = st.lists(st.tuples(st.integers(0, 36), st.integers(0, 56)), min_size=0, max_size=300)
 
     @settings(max_examples=300, deadline=None)
     @given(sizes)
@@ -338,16 +347,17 @@ def test_pack_tiles_properties():
         n_ed = [2 * (e // 2) if a >= 2 else 0 for a, e in mols]  # directed edges come in pairs; none without two atoms
         want = oc.greedy_molecule_tiles(n_at, n_ed)
         n, tr, ta = _pack_tiles(n_at, n_ed)
-        if want is None:
-            assert n == -1
-            return
         assert n == len(want[0]) - 1 and np.array_equal(tr, want[0]) and np.array_equal(ta, want[1])
         # a partition of the batch into consecutive whole molecules within the tile limits, and greedy: no two consecutive
         # tiles could have been one
         ao = np.concatenate([[0], np.cumsum(n_at)]); eo = np.concatenate([[0], np.cumsum(n_ed)])
         assert tr[-1] == eo[-1] and ta[-1] == ao[-1]
         if n:
-            assert (np.diff(tr) <= 48).all() and (np.diff(ta) <= 32).all() and (np.diff(tr) >= 0).all() and (np.diff(ta) >= 0).all()
+            assert (np.diff(tr) >= 0).all() and (np.diff(ta) >= 0).all()
+            for t in range(n):  # within the tile limits, or ONE molecule beyond them
+                if tr[t + 1] - tr[t] > 48 or ta[t + 1] - ta[t] > 32:
+                    inside = [m for m in range(len(n_at)) if ta[t] <= ao[m] < ta[t + 1] and (n_at[m] or n_ed[m])]
+                    assert len(inside) == 1 and (n_at[inside[0]] > 32 or n_ed[inside[0]] > 48)
             for t in range(n - 1):
                 assert tr[t + 2] - tr[t] > 48 or ta[t + 2] - ta[t] > 32 or (tr[t + 1] == tr[t] and ta[t + 1] == ta[t])
             bounds = set(zip(ao.tolist(), eo.tolist()))

@@ -65,6 +65,9 @@ def test_plan_is_bit_exact(golden, gpu_device):
         assert bool(a["hdr"][0] & 8) == (n_m < 0)
         assert a["hdr"][6] == max(n_m, 0)
         assert np.array_equal(a["mtile_row"], mrow) and np.array_equal(a["mtile_atom"], matom)
+        # pieces beyond the matrix-pipe tile are tiles of their own, counted in DMPNN_HDR_NSPILL
+        n_spill = sum(1 for t in range(max(n_m, 0)) if mrow[t + 1] - mrow[t] > 48 or matom[t + 1] - matom[t] > 32)
+        assert a["hdr"][8] == n_spill
     elif not small:
         assert a["hdr"][0] & 8 and a["hdr"][6] == 0
 
@@ -387,16 +390,20 @@ def test_split_linear_kernel_vs_torch_fp64(M, N, K1, K2, gather, gpu_device):
     assert err <= max(TOL / 10, 2 * err32), f"{err:.3e} (torch fp32: {err32:.3e})"
 
 
-@pytest.mark.parametrize("n_mols,kind,seed", [(512, "qm9", 0), (4096, "qm9", 1), (512, "synth40", 2), (512, "zinc", 3)])
+@pytest.mark.parametrize("n_mols,kind,seed", [(512, "qm9", 0), (4096, "qm9", 1), (512, "synth40", 2), (512, "zinc", 3),
+                                              (64, "cgr", 4), (512, "cgr", 5), (4096, "synth40", 6)])
 def test_forward_full_size_vs_oracle(n_mols, kind, seed, gpu_device):
-    """BASELINE.json sizes: batch of 512 QM9-shaped molecules (configs[1]) etc., against the CPU oracle."""
+    """BASELINE.json sizes: batch of 512 QM9-shaped molecules (configs[1]), ZINC-shaped h 512 depth 6 (configs[2]), 40-atom
+    molecules (configs[3]), condensed reaction graphs d_v 106 / d_e 28 at the notebook's 64 and at 512 (configs[4],
+    featurizers/molgraph/reaction.py:77-78), against the CPU oracle."""
     from chemprop_amd import synth
     from chemprop_amd.nn import BondMessagePassing
 
     depth, d_h = (6, 512) if kind == "zinc" else (3, 300)
     bmg = synth.random_batch(n_mols, kind, seed=seed)
     torch.manual_seed(seed)
-    mp = BondMessagePassing(d_h=d_h, depth=depth).eval()
+    dims = dict(d_v=106, d_e=28) if kind == "cgr" else {}
+    mp = BondMessagePassing(d_h=d_h, depth=depth, **dims).eval()
     with torch.no_grad():
         ref = ot.forward_bmg(bmg, ot.MPWeights.from_module(mp), depth=depth)
     mp = mp.to(gpu_device)
@@ -405,6 +412,46 @@ def test_forward_full_size_vs_oracle(n_mols, kind, seed, gpu_device):
         out = mp(bmg)
     err = parity_err(out.cpu().numpy(), ref.numpy())
     assert err <= TOL, f"{kind}-{n_mols}: {err:.3e}"
+
+
+@pytest.mark.parametrize("n_mols,kind", [(4096, "qm9"), (512, "cgr")])
+def test_relu_gradients_at_size(n_mols, kind, gpu_device):
+    """ReLU gradients at BASELINE sizes (round-1 VERDICT: the at-size gradient cases used smooth activations).  A kinked
+    activation makes a gradient only as reproducible as its masks: one mask flip at |z| ~ 1e-8 between two fp32-class
+    arithmetics moves an entry by far more than 1e-5.  So the yardstick is the reference's OWN sensitivity: the same op
+    sequence in fp64 is the truth, fp32 torch (the reference) is some distance e32 from it, and the engine has to be
+    within max(2e-5, 3 e32) of the truth — i.e. as good as the reference's fp32, not bit-compatible with its masks."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    dims = dict(d_v=106, d_e=28) if kind == "cgr" else {}
+    bmg = synth.random_batch(n_mols, kind, seed=13)
+    torch.manual_seed(4)
+    ref_mp = BondMessagePassing(**dims)
+    G = torch.randn(bmg.V.shape[0], 300, generator=torch.Generator().manual_seed(6))
+
+    def oracle(dtype):
+        ps = [p.detach().to(dtype).requires_grad_(True) for p in (ref_mp.W_i.weight, ref_mp.W_h.weight, ref_mp.W_o.weight, ref_mp.W_o.bias)]
+        out = ot.forward(bmg.V.to(dtype), bmg.E.to(dtype), bmg.edge_index, bmg.rev_edge_index, ot.MPWeights(*ps), depth=3)
+        (out * G.to(dtype)).sum().backward()
+        return out.detach(), [p.grad for p in ps]
+
+    o64, g64 = oracle(torch.float64)
+    o32, g32 = oracle(torch.float32)
+    mp = BondMessagePassing(**dims)
+    mp.load_state_dict(ref_mp.state_dict())
+    mp = mp.to(gpu_device).train()
+    bmg.to(gpu_device)
+    out = mp(bmg)
+    (out * G.to(gpu_device)).sum().backward()
+    assert parity_err(out.detach().cpu().numpy(), o32.numpy()) <= TOL
+    got = [mp.W_i.weight.grad, mp.W_h.weight.grad, mp.W_o.weight.grad, mp.W_o.bias.grad]
+    for name, g, r32, r64 in zip(("W_i", "W_h", "W_o", "b_o"), got, g32, g64):
+        e32 = parity_err(r32.numpy(), r64.numpy())
+        e = parity_err(g.cpu().numpy(), r64.numpy())
+        print(f"{kind}-{n_mols} d{name}: engine vs fp64 {e:.2e}, torch fp32 vs fp64 {e32:.2e}, engine vs torch fp32 "
+              f"{parity_err(g.cpu().numpy(), r32.numpy()):.2e}")
+        assert e <= max(2e-5, 3 * e32), f"{name}: {e:.3e} (reference fp32 itself: {e32:.3e})"
 
 
 def test_size_independent_properties_at_scale(gpu_device):
