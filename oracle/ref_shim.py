@@ -3,8 +3,10 @@
 TEST INFRASTRUCTURE ONLY.  Nothing in ``chemprop_amd/`` may import this module.  It is used by
 ``tests/golden/make_golden.py`` (to freeze golden vectors from the executed reference) and by the
 ``-m "not gpu"`` tests that re-validate the restated oracle against the executed reference when
-``/root/reference`` is present.  On the GPU box ``/root/reference`` does not exist and
-:func:`reference_available` returns ``False``.
+``/root/reference`` is present.  On the GPU box ``/root/reference`` does not exist; what exists there is
+``oracle/_ref/`` — a git-ignored staging copy of exactly the reference files this shim imports, made by
+``oracle/stage_ref.py`` at build time (never committed) — so the ``-m gpu`` tests can run the REAL
+``chemprop.nn.BondMessagePassing`` subclass, ``MulticomponentMessagePassing`` and ``GraphTransform`` on a device.
 
 Why a shim: ``import chemprop`` needs rdkit / lightning / torchmetrics / cuik_molmaker / astartes /
 configargparse (none installed, no network) and Python >= 3.11 (``enum.StrEnum``, ``typing.Self``).
@@ -21,7 +23,20 @@ import sys
 import types
 import typing
 
-REFERENCE_ROOT = os.environ.get("CHEMPROP_REFERENCE_ROOT", "/root/reference")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+STAGED_ROOT = os.path.join(_HERE, "_ref")  # git-ignored copy made by oracle/stage_ref.py (travels to the GPU box)
+
+
+def _default_root() -> str:
+    env = os.environ.get("CHEMPROP_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isfile("/root/reference/chemprop/nn/message_passing/base.py"):
+        return "/root/reference"
+    return STAGED_ROOT
+
+
+REFERENCE_ROOT = _default_root()
 
 
 def reference_available() -> bool:
@@ -97,9 +112,9 @@ class _HyperparametersMixin:
         ignore = set(ignore or ())
         frame = frame or inspect.currentframe().f_back
         local = frame.f_locals
-        names = [
-            p for p in inspect.signature(type(self).__init__).parameters if p not in ("self",)
-        ]
+        # the arguments of the __init__ that called us (the frame's own: a subclass may wrap it with *args / **kwargs)
+        code = frame.f_code
+        names = [p for p in code.co_varnames[:code.co_argcount + code.co_kwonlyargcount] if p != "self"]
         hp = _AttributeDict()
         for n in names:
             if n in local and n not in ignore:
@@ -169,9 +184,46 @@ def install() -> None:
     sys.modules["lightning.pytorch"].LightningModule = LightningModule
     sys.modules["lightning.fabric.utilities.data"].AttributeDict = _AttributeDict
 
+    # torchmetrics: the reference's losses / metrics subclass torchmetrics.Metric and an MPNN keeps them in an
+    # nn.ModuleList (models/model.py:99-103), so the stand-in has to be a real nn.Module (state kept as attributes).
+    import copy as _copy
+
+    class Metric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def add_state(self, name, default, dist_reduce_fx=None, persistent=False):
+            setattr(self, name, default)
+
+        def clone(self):
+            return _copy.deepcopy(self)
+
+        def reset(self):
+            pass
+
+    tm = sys.modules["torchmetrics"]
+    tm.Metric = Metric
+    sys.modules["torchmetrics.metric"].Metric = Metric
+    for mod, names in (("torchmetrics", ("R2Score",)),
+                       ("torchmetrics.classification", ("BinaryAUROC", "BinaryPrecisionRecallCurve", "BinaryAccuracy", "BinaryF1Score")),
+                       ("torchmetrics.regression", ("R2Score",))):
+        for n in names:
+            setattr(sys.modules[mod], n, type(n, (Metric,), {"__module__": mod}))
+
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     _INSTALLED = True
+
+
+def load_reference_extras():
+    """``(MulticomponentMessagePassing, GraphTransform, ScaleTransform, MPNN, nn)`` of the reference (``nn`` = ``chemprop.nn``)."""
+    install()
+    import chemprop.nn as cnn  # noqa: E402
+    from chemprop.models.model import MPNN  # noqa: E402
+    from chemprop.nn.message_passing.multi import MulticomponentMessagePassing  # noqa: E402
+    from chemprop.nn.transforms import GraphTransform, ScaleTransform  # noqa: E402
+
+    return MulticomponentMessagePassing, GraphTransform, ScaleTransform, MPNN, cnn
 
 
 def load_reference():
