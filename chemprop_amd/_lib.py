@@ -18,7 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
-LIB_PATH = os.path.join(_HERE, "libdmpnn_gfx950.so")
+# DMPNN_LIB: an alternative build of the same sources (kernel experiments: scripts/build_variant.py), same ABI
+LIB_PATH = os.environ.get("DMPNN_LIB") or os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp"]
@@ -99,6 +100,8 @@ def sources() -> list[str]:
 
 
 def _stale() -> bool:
+    if os.environ.get("DMPNN_LIB"):
+        return False  # (a variant build is used as it is)
     if not os.path.isfile(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
@@ -106,9 +109,10 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into ``chemprop_amd/libdmpnn_gfx950.so``."""
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, defines=(), out: Optional[str] = None) -> str:
+    """Compile every HIP source for gfx950 into ``chemprop_amd/libdmpnn_gfx950.so`` (``out`` / ``defines``: a variant build)."""
+    lib_path = out or LIB_PATH
+    if not force and not _stale() and out is None:
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.isfile(hipcc):
@@ -116,7 +120,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     import concurrent.futures as cf
     import tempfile
 
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *[f"-D{d}" for d in defines]]
     with tempfile.TemporaryDirectory(prefix="dmpnn_build_") as tmp:
         def cc(src):
             obj = os.path.join(tmp, os.path.basename(src) + ".o")
@@ -130,14 +134,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
         with cf.ThreadPoolExecutor(max_workers=8) as ex:
             objs = list(ex.map(cc, sources()))
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
 
 
 _lib: Optional[C.CDLL] = None

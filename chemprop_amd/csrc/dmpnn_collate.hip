@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k_tiles_from_table(const int* __restrict_
             r = tile_row[t]; a = tile_atom[t];
             const int r1 = t + 1 < n_tiles ? tile_row[t + 1] : nE, a1 = t + 1 < n_tiles ? tile_atom[t + 1] : nV;
             if (r < 0 || a < 0 || r1 < r || a1 < a || r1 > nE || a1 > nV) bad = 1;
+            else if (a1 == a && r1 != r) bad = 1;  // edge rows in a tile without atoms: nobody would check (or compute) them
             else if (r1 - r > kMegaBM || a1 - a > kMegaBA) atomicAdd(&spill_s, 1);  // (the tile kernel's generic path; it checks closure itself)
             if (t == 0 && (r != 0 || a != 0)) bad = 1;
         }

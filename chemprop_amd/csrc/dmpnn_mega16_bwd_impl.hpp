@@ -81,8 +81,9 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         return;
     }
     if (na <= 0 || nrows < 0) return;
-    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     if (nrows > BM || na > BA) {  // a piece larger than the matrix-pipe tile: the generic fp32 path, any size
+        const Mega16BwdK& g = *spill::fresh_kernargs<Mega16BwdK>();  // (shadows the hot path's copy: see fresh_kernargs)
+        const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
         spill::BwdView v;
         v.rs = rs; v.nrows = nrows; v.va = va; v.na = na; v.h = N; v.depth = T_steps; v.d_v = g.d_v;
         v.row_ptr = g.row_ptr; v.srcp = g.srcp; v.revp = g.revp;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         spill::backward(v, reinterpret_cast<float*>(lds));
         return;
     }
+    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     auto dact = [&](float gval, float y, bool preact) -> float {  // g * tau'(.) from the output (or the pre-activation)
         if (g.act == DMPNN_ACT_NONE) return gval;
         if (g.act == DMPNN_ACT_RELU) return y > 0.f ? gval : 0.f;

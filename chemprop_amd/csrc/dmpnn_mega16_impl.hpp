@@ -163,13 +163,15 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         return;
     }
     if (na <= 0 || nrows < 0 || va < 0 || vb > g.nV || rs < 0 || re > g.nE) return;  // (an unused tile slot)
-    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     if (nrows > BM || na > BA) {
         // a piece (molecule) larger than the matrix-pipe tile — the reference has no size limit (data/collate.py:48-56):
         // the generic fp32 path carries it, whatever its size (dmpnn_spill_impl.hpp)
-        spill::forward(mega::spill_view(g, lean, rs, nrows, va, na, slope), reinterpret_cast<float*>(lds));
+        const mega::MegaK& gs = spill::fresh_kernargs<Mega16K>()->m;
+        spill::forward(mega::spill_view(gs, gs.flags[DMPNN_HDR_LIGHT] == 2, rs, nrows, va, na, gs.slope_ptr ? *gs.slope_ptr : gs.slope),
+                       reinterpret_cast<float*>(lds));
         return;
     }
+    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
     const bool simple_act = !(g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU);
     auto tau = [&](float z) -> float {

@@ -115,11 +115,12 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile(MegaK g) {
         return;
     }
     if (na <= 0 || nrows < 0) return;  // trailing slots of the launch bound
-    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     if (nrows > BM || na > BA) {  // a piece larger than the matrix-pipe tile: the generic fp32 path (any size)
-        spill::forward(spill_view(g, false, rs, nrows, va, na, slope), smem);
+        const MegaK& gs = *spill::fresh_kernargs<MegaK>();
+        spill::forward(spill_view(gs, false, rs, nrows, va, na, gs.slope_ptr ? *gs.slope_ptr : gs.slope), smem);
         return;
     }
+    const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
     const bool simple_act = !(g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU);
     auto tau = [&](float z) -> float {

@@ -20,8 +20,29 @@
 
 #include "dmpnn_common.hpp"
 
+// (kernel experiments: -DDMPNN_SPILL_NOINLINE keeps the generic path out of line, -DDMPNN_NO_SPILL compiles it away)
+#if defined(DMPNN_SPILL_NOINLINE)
+#define DMPNN_SPILL_FN __device__ __noinline__
+#else
+#define DMPNN_SPILL_FN __device__ __forceinline__
+#endif
+
 namespace dmpnn {
 namespace spill {
+
+// The kernel's own argument block, read AFRESH from the kernarg segment through a pointer the compiler cannot see
+// through: the generic path then keeps nothing of the hot path's scalar registers alive (with the by-value argument
+// struct shared by both paths hipcc spilled ~300 SGPRs around the hot path's prologue: +2.4 us per launch, measured).
+template <class KArgs>
+__device__ __forceinline__ const KArgs* fresh_kernargs() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();  // (constant address space: same 64-bit address)
+    asm volatile("" : "+s"(a));
+    return reinterpret_cast<const KArgs*>(a);
+#else
+    return nullptr;
+#endif
+}
 
 constexpr int kRB = 16;          // operand rows staged per block
 constexpr int kSpillThreads = 256;
@@ -78,7 +99,10 @@ struct FwdView {
 };
 
 // base.py:196-212 for the piece rows [rs, rs + nrows) / atoms [va, va + na)
-__device__ __forceinline__ void forward(const FwdView& g, float* xs) {
+DMPNN_SPILL_FN void forward(const FwdView& g, float* xs) {
+#if defined(DMPNN_NO_SPILL)
+    return;
+#endif
     const int tid = threadIdx.x, N = g.h, T = g.depth;
     const long long rs = g.rs, va = g.va;
     auto src_at = [&](int r) -> long long { return g.lean ? g.edge_index[rs + r] : (long long)g.srcp[rs + r]; };
@@ -94,7 +118,14 @@ __device__ __forceinline__ void forward(const FwdView& g, float* xs) {
             const long long s = g.edge_index[rs + r] - va, d = g.edge_index[(long long)g.nE + rs + r] - va, rv = g.rev64[rs + r] - rs;
             bad |= (s < 0 || s >= g.na || d < 0 || d >= g.na || rv < 0 || rv >= g.nrows) ? 1 : 0;
         }
-        if (__syncthreads_or(bad)) { nan_out(); return; }
+        int* flag = reinterpret_cast<int*>(xs);  // (a word of the staging area: no static LDS in the tile kernels)
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (bad) atomicOr(flag, 1);
+        __syncthreads();
+        const int any_bad = *flag;
+        __syncthreads();
+        if (any_bad) { nan_out(); return; }
     }
     if (!g.H0 || !g.Mv || (T > 1 && (!g.Hs || !g.Ms))) { nan_out(); return; }  // (no workspace: never silently wrong)
     // K1  H0 = W_i [V[src] || E] (+ b_i)                               mixins.py:8-9
@@ -156,7 +187,10 @@ struct BwdView {
 };
 
 // the data-gradient chain of the backward pass (what k_mpnn_tile16_bwd does for a tile) for one piece
-__device__ __forceinline__ void backward(const BwdView& g, float* xs) {
+DMPNN_SPILL_FN void backward(const BwdView& g, float* xs) {
+#if defined(DMPNN_NO_SPILL)
+    return;
+#endif
     const int tid = threadIdx.x, N = g.h, T = g.depth;
     const long long rs = g.rs, va = g.va;
     auto dact = [&](float gv, float y, bool preact) -> float {  // g * tau'(.) from the output (or the pre-activation)

@@ -231,7 +231,8 @@ def test_forward_on_loader_tiles(n_mols, gpu_device):
 
 @pytest.mark.gpu
 def test_a_wrong_loader_table_is_loud(gpu_device):
-    """Tiles that split a molecule (not closed) or exceed the tile limits poison the affected output with NaN."""
+    """Tiles that split a molecule (not closed) poison the affected output with NaN; a tile beyond the matrix-pipe limits
+    that is closed is computed by the generic path."""
     from chemprop_amd import engine, synth
     from chemprop_amd.data import PackedBatch
     from chemprop_amd.nn import BondMessagePassing
@@ -252,9 +253,14 @@ def test_a_wrong_loader_table_is_loud(gpu_device):
         a1, a2 = int(ta[1]), int(ta[2])
         assert torch.isnan(bad[:a2]).any() and torch.equal(bad[a2:], good[a2:]) and a1 < a2
         tr3, ta3 = tr.clone(), ta.clone()
-        tr3[1:n] = tr[n]; ta3[1:n] = ta[n]  # one tile of everything: exceeds the limits
+        tr3[1:n] = tr[n]; ta3[1:n] = ta[n]  # one tile of everything: beyond the matrix-pipe tile, but CLOSED — the kernel's
+        # generic path computes it (a table can only cost speed, or be loud: never a wrong number)
+        whole = fwd(engine.GraphPlan(bmg.edge_index, bmg.rev_edge_index, bmg.V.shape[0], light="tiles", batch=bmg.batch, tiles=(tr3, ta3, n)))
+        assert float((whole - good).abs().max()) <= 3e-6 * max(1.0, float(good.abs().max()))
+        tr4 = tr3.clone()
+        tr4[1:n] = tr[n] - 2  # ... the same tile without the last two edge rows: not closed -> NaN for its atoms (all of them)
         assert torch.isnan(fwd(engine.GraphPlan(bmg.edge_index, bmg.rev_edge_index, bmg.V.shape[0], light="tiles", batch=bmg.batch,
-                                                tiles=(tr3, ta3, n)))).all()
+                                                tiles=(tr4, ta3, n)))).all()
 
 
 # ---- the multi-workgroup tile planner: batches beyond the single-workgroup plan, handed over as five tensors ----
@@ -306,8 +312,10 @@ def test_large_batch_of_five_tensors_takes_the_tile_kernel(gpu_device):
 
 
 @pytest.mark.gpu
-def test_large_tile_plan_flags_an_oversize_molecule(gpu_device):
-    """One 40-atom molecule among 3000 small ones: no piece tiles (bit 3), the module keeps the per-step route."""
+def test_large_tile_plan_carries_an_oversize_molecule(gpu_device):
+    """One 40-atom molecule among 3000 small ones, handed over as bare tensors (multi-workgroup tile planner): no error flag,
+    one spill tile, the tile route computes it; the same batch from the host-side batching code (which knows) takes the
+    per-step route.  Both within the bar."""
     from chemprop_amd import engine, synth
     from chemprop_amd.data import BatchMolGraph
     from chemprop_amd.nn import BondMessagePassing
@@ -317,18 +325,26 @@ def test_large_tile_plan_flags_an_oversize_molecule(gpu_device):
     mgs = synth.random_molgraphs(3000, "qm9", seed=3)
     mgs[1234] = synth.random_molgraphs(1, "synth40", seed=9)[0]
     host = BatchMolGraph(mgs)
+    assert host.oversize is True
     torch.manual_seed(2)
     mp = BondMessagePassing().eval()
     with torch.no_grad():
         ref = ot.forward_bmg(host, ot.MPWeights.from_module(mp), depth=mp.depth).numpy()
     host.to(gpu_device)
-    plan = engine.GraphPlan.from_bmg(host, light="tiles")
-    assert plan.tiles_only and plan.flags() & 8
+    bare = BatchMolGraph.from_tensors(host.V, host.E, host.edge_index, host.rev_edge_index, host.batch, len(host))
+    plan = engine.GraphPlan.from_bmg(bare, light="tiles")
+    hdr = plan.header()
+    assert plan.tiles_only and hdr[0] & 15 == 0 and hdr[8] == 1
     mp = mp.to(gpu_device)
     with torch.no_grad():
         for i in range(4):
-            assert parity_err(mp(host).cpu().numpy(), ref) <= TOL, i
-    assert getattr(mp, "_dmpnn_no_mega", False)
+            assert parity_err(mp(bare).cpu().numpy(), ref) <= TOL, i
+        assert mp.__dict__.get("_dmpnn_replay") is not None      # (the tile route, oversize molecule included)
+        mp2 = BondMessagePassing().eval().to(gpu_device)
+        mp2.load_state_dict(mp.state_dict())
+        for i in range(3):
+            assert parity_err(mp2(host).cpu().numpy(), ref) <= TOL, i
+        assert mp2.__dict__.get("_dmpnn_replay") is None
 
 
 # ---- properties of the host-side packers over arbitrary molecule-size sequences (hypothesis; no GPU) ----

@@ -164,8 +164,8 @@ def test_full_size_vs_oracle(atom, gpu_device):
 
 @pytest.mark.gpu
 def test_inference_with_an_oversize_molecule_is_routed_not_poisoned(gpu_device):
-    """A 40-atom molecule does not fit a tile of the whole-forward kernel: the block's inference route must notice on its
-    validated first batches and use the per-step kernels (finite, correct) instead of returning NaN."""
+    """A 40-atom molecule does not fit a tile of the whole-forward kernel: the host-side batching code knows and the batch
+    takes the per-step kernels; handed over as bare tensors the tile kernel's generic path computes it.  Never NaN."""
     from chemprop_amd import synth
     from chemprop_amd.data import BatchMolGraph
     from chemprop_amd.mab import MABBondMessagePassing
@@ -185,4 +185,13 @@ def test_inference_with_an_oversize_molecule_is_routed_not_poisoned(gpu_device):
             out = mp(bmg)
             for got, want in zip(out, ref):
                 assert torch.isfinite(got).all() and parity_err(got.cpu().numpy(), want.numpy()) <= TOL, i
-    assert getattr(mp, "_dmpnn_no_mega", False)
+    # ... and as bare tensors (no host-side size knowledge): the tile kernel's generic path carries the big molecules
+    from chemprop_amd.data import BatchMolGraph as B
+
+    bare = B.from_tensors(bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, bmg.batch, len(bmg))
+    mp2 = MABBondMessagePassing(d_h=64).eval().to(gpu_device)
+    mp2.load_state_dict(mp.state_dict())
+    with torch.no_grad():
+        for i in range(3):
+            for got, want in zip(mp2(bare), ref):
+                assert torch.isfinite(got).all() and parity_err(got.cpu().numpy(), want.numpy()) <= TOL, i

@@ -204,8 +204,8 @@ def test_whole_forward_tile_kernel(golden, gpu_device):
     """Route "mega": the whole forward of a tile of whole molecules in ONE launch.  The kept
     intermediates (H0, M^(t), H^(t), Mv) are bit-identical to the per-step fused route (same MFMA / k
     order); the output differs only by the summation order of the finalize contraction (the Mv columns
-    are contracted before the V columns) and is held to the parity bar; a batch with a molecule larger
-    than a tile comes back as NaN, loudly."""
+    are contracted before the V columns) and is held to the parity bar; a molecule larger than a tile takes the
+    kernel's generic fp32 path (same bar)."""
     if golden.cfg.get("undirected") or golden.cfg["d_h"] % 4 or golden.cfg["d_h"] > 320:
         pytest.skip("fused routes do not apply (undirected / d_h)")
     if golden["V"].shape[1] % 2 or golden["E"].shape[1] % 2:
@@ -222,12 +222,16 @@ def test_whole_forward_tile_kernel(golden, gpu_device):
     assert parity_err(out_m.cpu().numpy(), golden["out"]) <= TOL
     _, out_f, st_f = _engine_forward(golden, gpu_device, route="fused", keep=True)
     assert parity_err(out_m.cpu().numpy(), out_f.cpu().numpy()) <= 2e-6
+    # bit-identical where the tile kernel ran its matrix-pipe path; a piece larger than a tile takes the generic fp32 path
+    # (ascending-k fmaf chains: another summation order), held to the fp32-rounding class
+    same = (lambda a, b, what="": torch.equal(a, b)) if plan.header()[8] == 0 else (
+        lambda a, b, what="": parity_err(a.cpu().numpy(), b.cpu().numpy()) <= 3e-6)
     if plan.n_edges:
-        assert torch.equal(st_m.H0, st_f.H0)
+        assert same(st_m.H0, st_f.H0)
         for t in range(golden.cfg["depth"] - 1):
-            assert torch.equal(st_m.Ms[t], st_f.Ms[t]), f"M^({t + 1})"
-            assert torch.equal(st_m.Hs[t], st_f.Hs[t]), f"H^({t + 1})"
-    assert torch.equal(st_m.Mv, st_f.Mv)
+            assert same(st_m.Ms[t], st_f.Ms[t]), f"M^({t + 1})"
+            assert same(st_m.Hs[t], st_f.Hs[t]), f"H^({t + 1})"
+    assert same(st_m.Mv, st_f.Mv)
     _, out_i, st_i = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="f32")
     assert st_i.H0 is None and torch.equal(out_i, out_m)   # inference: nothing but `out` leaves the CU
 
@@ -311,8 +315,14 @@ def test_tile_plan_and_forward_on_caller_order_edges(golden, use_batch, gpu_devi
         if not (al["hdr"][0] & 8):
             b = golden["batch"]
             assert ma[0] == 0 and ma[n_t] == nV and mr[0] == 0 and mr[n_t] == nE
-            assert (np.diff(ma[:n_t + 1]) <= 32).all() and (np.diff(mr[:n_t + 1]) <= 48).all() and (np.diff(ma[:n_t + 1]) >= 0).all()
+            assert (np.diff(ma[:n_t + 1]) >= 0).all()
             assert all(v == 0 or v == nV or b[v] != b[v - 1] for v in ma[:n_t + 1])
+            n_spill = 0
+            for t in range(n_t):  # <= 48 edges / <= 32 atoms, or exactly ONE molecule beyond that
+                if ma[t + 1] - ma[t] > 32 or mr[t + 1] - mr[t] > 48:
+                    assert b[ma[t]] == b[ma[t + 1] - 1], "an oversize tile is one molecule"
+                    n_spill += 1
+            assert al["hdr"][8] == n_spill
     _, out_l, st = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16", plan=lean)
     assert st.route == "mega16"
     if al["hdr"][0] & 8:
@@ -414,13 +424,17 @@ def test_forward_full_size_vs_oracle(n_mols, kind, seed, gpu_device):
     assert err <= TOL, f"{kind}-{n_mols}: {err:.3e}"
 
 
-@pytest.mark.parametrize("n_mols,kind", [(4096, "qm9"), (512, "cgr")])
+@pytest.mark.parametrize("n_mols,kind", [(4096, "qm9"), (512, "cgr"), (512, "synth40")])
 def test_relu_gradients_at_size(n_mols, kind, gpu_device):
-    """ReLU gradients at BASELINE sizes (round-1 VERDICT: the at-size gradient cases used smooth activations).  A kinked
-    activation makes a gradient only as reproducible as its masks: one mask flip at |z| ~ 1e-8 between two fp32-class
-    arithmetics moves an entry by far more than 1e-5.  So the yardstick is the reference's OWN sensitivity: the same op
-    sequence in fp64 is the truth, fp32 torch (the reference) is some distance e32 from it, and the engine has to be
-    within max(2e-5, 3 e32) of the truth — i.e. as good as the reference's fp32, not bit-compatible with its masks."""
+    """ReLU gradients at BASELINE sizes (round-1 VERDICT: the at-size gradient cases used smooth activations).
+
+    A kinked activation makes a gradient only as reproducible as its masks: ONE mask flip at |z| ~ 1e-7 moves a row of a
+    weight gradient by 1e-3 of the largest entry — measured here for the engine AND for the reference's own fp32 (its
+    gradients on the 40-atom batch are 4e-4 away from fp64 autograd of the same ops).  So the check has two halves:
+      * the masks the engine's forward actually used (from its kept tensors) differ from the masks of the fp64 forward
+        only where the fp64 pre-activation is within rounding of the kink, and only for a vanishing share of the entries;
+      * GIVEN those masks the backward pass is linear algebra: the engine's gradients equal fp64 autograd with the same
+        masks to 2e-5 (they come out at 1e-6)."""
     from chemprop_amd import synth
     from chemprop_amd.nn import BondMessagePassing
 
@@ -428,30 +442,61 @@ def test_relu_gradients_at_size(n_mols, kind, gpu_device):
     bmg = synth.random_batch(n_mols, kind, seed=13)
     torch.manual_seed(4)
     ref_mp = BondMessagePassing(**dims)
-    G = torch.randn(bmg.V.shape[0], 300, generator=torch.Generator().manual_seed(6))
+    nV, nE = bmg.V.shape[0], bmg.E.shape[0]
+    G = torch.randn(nV, 300, generator=torch.Generator().manual_seed(6))
+    src, dst, rev = bmg.edge_index[0], bmg.edge_index[1], bmg.rev_edge_index
+    V64, E64 = bmg.V.double(), bmg.E.double()
 
-    def oracle(dtype):
-        ps = [p.detach().to(dtype).requires_grad_(True) for p in (ref_mp.W_i.weight, ref_mp.W_h.weight, ref_mp.W_o.weight, ref_mp.W_o.bias)]
-        out = ot.forward(bmg.V.to(dtype), bmg.E.to(dtype), bmg.edge_index, bmg.rev_edge_index, ot.MPWeights(*ps), depth=3)
-        (out * G.to(dtype)).sum().backward()
-        return out.detach(), [p.grad for p in ps]
+    def forward64(masks=None):
+        """base.py:196-212 in fp64; ``masks`` replaces every ReLU by a fixed 0/1 factor (else records the true masks)."""
+        ps = [p.detach().double().requires_grad_(True) for p in (ref_mp.W_i.weight, ref_mp.W_h.weight, ref_mp.W_o.weight, ref_mp.W_o.bias)]
+        Wi, Wh, Wo, bo = ps
+        pre, used = [], []
 
-    o64, g64 = oracle(torch.float64)
-    o32, g32 = oracle(torch.float32)
+        def tau(z):
+            pre.append(z.detach())
+            m = (z.detach() > 0).double() if masks is None else masks[len(used)]
+            used.append(m)
+            return z * m
+
+        H0 = torch.cat((V64[src], E64), 1) @ Wi.t()
+        H = tau(H0)
+        for _ in range(2):
+            S = torch.zeros(nV, 300, dtype=torch.float64).index_add_(0, dst, H)
+            H = tau(H0 + (S[src] - H[rev]) @ Wh.t())
+        Mv = torch.zeros(nV, 300, dtype=torch.float64).index_add_(0, dst, H)
+        out = tau(torch.cat((V64, Mv), 1) @ Wo.t() + bo)
+        return out, ps, pre, used
+
     mp = BondMessagePassing(**dims)
     mp.load_state_dict(ref_mp.state_dict())
     mp = mp.to(gpu_device).train()
     bmg.to(gpu_device)
     out = mp(bmg)
+    st = out.grad_fn.st                                        # the kept tensors of this forward (FusedMP)
+    rows = st.route in ("mega", "mega16", "fused")             # kept edge tensors in CSR-row order (row i = edge perm[i])
+    to_edges = (lambda X: X[st.plan.inv32.long()]) if rows else (lambda X: X)
+    masks = [(to_edges(st.H0[:, :300]) > 0).double().cpu()]
+    masks += [(to_edges(st.Hs[t][:, :300]) > 0).double().cpu() for t in range(2)]
+    masks.append((out.detach() > 0).double().cpu())
     (out * G.to(gpu_device)).sum().backward()
-    assert parity_err(out.detach().cpu().numpy(), o32.numpy()) <= TOL
+
+    o64, _, pre, true_masks = forward64()
+    assert parity_err(out.detach().cpu().numpy(), o64.detach().numpy()) <= TOL
+    total = flips = 0
+    for z, m_true, m_eng in zip(pre, true_masks, masks):
+        diff = m_true != m_eng
+        total += diff.numel()
+        flips += int(diff.sum())
+        if diff.any():  # a differing mask sits on the kink: |z| within fp32 rounding of the values that were summed
+            assert float(z[diff].abs().max()) <= 1e-5 * max(1.0, float(z.abs().max())), "a mask differs away from the kink"
+    assert flips <= max(8, 2e-6 * total), f"{flips} mask flips of {total}"
+    om, ps, _, _ = forward64(masks)
+    (om * G.double()).sum().backward()
     got = [mp.W_i.weight.grad, mp.W_h.weight.grad, mp.W_o.weight.grad, mp.W_o.bias.grad]
-    for name, g, r32, r64 in zip(("W_i", "W_h", "W_o", "b_o"), got, g32, g64):
-        e32 = parity_err(r32.numpy(), r64.numpy())
-        e = parity_err(g.cpu().numpy(), r64.numpy())
-        print(f"{kind}-{n_mols} d{name}: engine vs fp64 {e:.2e}, torch fp32 vs fp64 {e32:.2e}, engine vs torch fp32 "
-              f"{parity_err(g.cpu().numpy(), r32.numpy()):.2e}")
-        assert e <= max(2e-5, 3 * e32), f"{name}: {e:.3e} (reference fp32 itself: {e32:.3e})"
+    errs = {n: parity_err(g.cpu().numpy(), p.grad.numpy()) for n, g, p in zip(("W_i", "W_h", "W_o", "b_o"), got, ps)}
+    print(f"{kind}-{n_mols} route={st.route} mask flips {flips}/{total}  gradient errors given the masks: {errs}")
+    assert max(errs.values()) <= 2e-5, errs
 
 
 def test_size_independent_properties_at_scale(gpu_device):

@@ -91,7 +91,8 @@ def test_late_oversize_molecule_inference(n_small, depth, act, bias, gpu_device)
         late = _bare(late)
         plan = engine.GraphPlan.from_bmg(late, light="tiles")
         hdr = plan.header()
-        assert plan.tiles_only and hdr[0] & 15 == 0 and hdr[8] == 3, hdr      # three oversize tiles, no error flag
+        n_over = sum(1 for m in late_mgs if len(m.V) > 32 or m.edge_index.shape[1] > 48)
+        assert n_over >= 2 and plan.tiles_only and hdr[0] & 15 == 0 and hdr[8] == n_over, hdr      # oversize tiles, no error flag
         out = mp(late)
         st = mp.__dict__.get("_dmpnn_replay")
         assert st is not None, "the batch must have taken the tile route (replay state present)"
