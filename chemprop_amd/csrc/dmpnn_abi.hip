@@ -249,6 +249,37 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     const int64_t slot = nE * a->ldh;
     const int* plan_i = static_cast<const int*>(a->plan);
 
+    if (fused && (a->flags & DMPNN_F_SPLIT16) && !(a->flags & DMPNN_F_MEGA)) {
+        // ---- per-step fused route on the f16 pipe: split message rows between the steps (dmpnn_step16_impl.hpp) ----
+        DMPNN_CHECK_ARG(fused16_shapes_ok(*a), "forward: DMPNN_F_FUSED | DMPNN_F_SPLIT16 given but the shapes do not allow it "
+                        "(inference, directed, d_h %% 4 == 0, d_h <= 320, even d_v / d_e)");
+        DMPNN_CHECK_ARG(nE == 0 || (a->H0 && a->Ms && a->n_mslots >= 2), "forward(fused16): H0 and two split message slots are required");
+        DMPNN_CHECK_ARG(a->wsplit && a->wsplit_bytes >= steps16_wsplit_bytes(*a), "forward(fused16): wsplit workspace missing or too small");
+        SplitWView w[4];
+        unsigned char* wp = static_cast<unsigned char*>(a->wsplit);
+        const bool ready = (a->flags & DMPNN_F_WSPLIT_READY) != 0;
+        const float* Ws[4] = {a->W_i, a->W_h, a->W_o, has_vd ? a->W_d : nullptr};
+        const int64_t Ns[4] = {h, h, h, h + a->d_vd}, Ks[4] = {dv + de, h, dv + h, h + a->d_vd};
+        for (int i = 0; i < 4; ++i) {
+            if (!Ws[i]) continue;
+            if (ready) w[i] = split_weights_view_of(wp, Ns[i], Ks[i]);
+            else DMPNN_TRY(split_weights_view(Ws[i], Ks[i], Ns[i], Ks[i], 0, wp, &w[i], s));
+            wp += linear16_wsplit_bytes(Ns[i], Ks[i]);
+        }
+        DMPNN_TRY(launch_fused16_forward(*a, w, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s));
+        if (has_vd) {
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = nV; g.N = h + a->d_vd; g.K1 = h; g.K2 = a->d_vd;
+            g.A1 = a->Hv; g.lda1 = a->ldh;
+            g.A2 = a->V_d; g.lda2 = a->ldvd;
+            g.W = a->W_d; g.ldw = h + a->d_vd; g.bias = a->b_d;
+            g.C = a->out; g.ldc = a->ldout; g.act = DMPNN_ACT_NONE;
+            if (linear16_ok(g)) DMPNN_TRY(launch_linear16_view(g, w[3], nullptr, 0, s));
+            else DMPNN_TRY(launch_linear(g, s));
+        }
+        return DMPNN_OK;
+    }
     if (fused) {
         // ---- fused route: edge tensors in CSR-row order, segment sums in the contraction epilogues ----
         DMPNN_CHECK_ARG(dmpnn_forward_can_fuse(a), "forward: DMPNN_F_FUSED given but the shapes / alignment do not allow it "

@@ -191,6 +191,10 @@ SplitWView split_weights_view_of(void* ws, int64_t N, int64_t K);  // descriptor
 bool linear16_ok(const dmpnn_gemm_args& a);
 int launch_linear16_view(const dmpnn_gemm_args& a, const SplitWView& W, const int* poison_flags, int poison_mask, hipStream_t s);
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
+// per-step fused route on the f16 pipe (dmpnn_step16.hip): inference forward, any molecule size, d_h <= 320
+bool fused16_shapes_ok(const dmpnn_fwd_args& a);
+int64_t split_row_floats(int64_t d_h);
+int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s);
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,

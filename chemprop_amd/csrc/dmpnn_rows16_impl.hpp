@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "dmpnn_mega16_impl.hpp"
+#include "dmpnn_seg16.hpp"
 
 namespace dmpnn {
 namespace rows16 {
@@ -42,6 +43,12 @@ struct Rows16K {
     int act; float slope; const float* slope_ptr;
     const int* poison_flags; int poison_mask;
     int vec_out;              // C / Zpre / Cadd rows are 16-byte aligned and N % 4 == 0: float4 epilogue
+    // SEG (the K1 launch of the per-step fused route on the f16 pipe, dmpnn_step16_impl.hpp): rows are CSR-ordered
+    // edges, a tile holds whole destination atoms (plan tile tables), A2 is gathered too, and the epilogue forms the
+    // tile's segment sums and writes the first message in split rows (or Mv)
+    const int* gather2; unsigned a2_bytes;
+    const int* tile_row; const int* tile_atom; const int* row_ptr; const int* revp;
+    unsigned char* Mout; int ts; float* Sout; int lds; unsigned qmagic;
 };
 
 // GC: k-chunks per operand group.  4 (128 columns, 24 operand registers, two workgroups per CU) streams large batches;
@@ -51,12 +58,12 @@ template <int WN, int GC>
 constexpr size_t tile_bytes() {  // fp32 epilogue tile and the split operand tile share one region
     return (size_t)BM * (64 * WN + 4) * 4 > (size_t)BM * (GC * 128 + 16) ? (size_t)BM * (64 * WN + 4) * 4 : (size_t)BM * (GC * 128 + 16);
 }
-template <int WN, int GC>
+template <int WN, int GC, bool SEG = false>
 constexpr size_t lds_bytes() {
-    return tile_bytes<WN, GC>() + 64;  // + scale words
+    return tile_bytes<WN, GC>() + 64 + (SEG ? (size_t)(BM + gemm::kAtomCache + 1) * sizeof(int) : 0);  // + scale words (+ segment metadata)
 }
 
-template <int WN, int GC>
+template <int WN, int GC, bool SEG = false>
 __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g) {
     constexpr int BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
     constexpr int ITEMS = BM * QN / kThreads;  // 3 WN
@@ -67,6 +74,7 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
     float* T = reinterpret_cast<float*>(lds);                      // [BM][LDC] fp32 epilogue tile
     unsigned char* Ag = lds;                                       // [BM][TSG] split operand tile (overlays T)
     unsigned* maxbits = reinterpret_cast<unsigned*>(lds + tile_bytes<WN, GC>());  // [4] rotating tile maxima
+    int* meta = reinterpret_cast<int*>(lds + tile_bytes<WN, GC>() + 64);          // SEG: [BM] reverse rows | [kAtomCache + 1] row pointers
 
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int li = lane & 15, lg = lane >> 4;
@@ -74,8 +82,16 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
         asm volatile("" : "+v"(tid));
         lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
     };
-    const int row0 = blockIdx.x * BM;
-    const int nrows = g.M - row0 < BM ? g.M - row0 : BM;
+    int row0 = blockIdx.x * BM;
+    int nrows = g.M - row0 < BM ? g.M - row0 : BM;
+    int seg_va = 0, seg_vb = 0;
+    if constexpr (SEG) {
+        row0 = g.tile_row[blockIdx.x];
+        nrows = g.tile_row[blockIdx.x + 1] - row0;
+        seg_va = g.tile_atom[blockIdx.x]; seg_vb = g.tile_atom[blockIdx.x + 1];
+        if (nrows <= 0 && seg_va >= seg_vb) return;  // trailing slots of the launch bound
+        if (nrows < 0 || nrows > BM) return;
+    }
     const int col0 = blockIdx.y * BN;            // column block of this workgroup
     const int ncols = g.N - col0 < BN ? g.N - col0 : BN;
     const int K = g.K1 + g.K2;
@@ -88,21 +104,33 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
     const bool gathered = g.gather1 != nullptr;
     const rsrc_t rA1 = gathered ? gemm::make_rsrc(g.A1, g.a1_bytes)
                                 : gemm::make_rsrc(g.A1 + (long long)row0 * g.lda1, (unsigned)(nrows * g.lda1) * 4u);
-    const rsrc_t rA2 = gemm::make_rsrc(g.A2 ? g.A2 + (long long)row0 * g.lda2 : g.A1, g.A2 ? (unsigned)(nrows * g.lda2) * 4u : 0u);
+    const bool gathered2 = SEG && g.gather2 != nullptr;
+    const rsrc_t rA2 = gathered2 ? gemm::make_rsrc(g.A2, g.a2_bytes)
+                                 : gemm::make_rsrc(g.A2 ? g.A2 + (long long)row0 * g.lda2 : g.A1, g.A2 ? (unsigned)(nrows * g.lda2) * 4u : 0u);
     unsigned ro1[J], ro2[J];
     {
-        int idx[J];
+        int idx[J], idx2[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int r = wave + 4 * j;
-            idx[j] = gathered ? g.gather1[r < nrows ? row0 + r : row0] : r;
+            const int rr = (r < nrows && nrows > 0) ? row0 + r : (nrows > 0 ? row0 : 0);
+            idx[j] = gathered ? g.gather1[rr] : r;
+            idx2[j] = gathered2 ? g.gather2[rr] : r;
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const bool ok = wave + 4 * j < nrows;
             ro1[j] = ok ? (unsigned)idx[j] * (unsigned)g.lda1 * 4u : kOOB;
-            ro2[j] = ok ? (unsigned)(wave + 4 * j) * (unsigned)g.lda2 * 4u : kOOB;
+            ro2[j] = ok ? (unsigned)idx2[j] * (unsigned)g.lda2 * 4u : kOOB;
         }
+    }
+    // SEG: segment metadata of the tile, fetched now, consumed by the epilogue
+    int seg_rev = 0, seg_rp = 0;
+    if constexpr (SEG) {
+        const int na0 = seg_vb - seg_va < gemm::kAtomCache ? seg_vb - seg_va : gemm::kAtomCache;
+        const int* rvp = g.Mout ? g.revp : g.row_ptr;
+        seg_rev = rvp[(g.Mout && tid < nrows) ? row0 + tid : 0];
+        seg_rp = g.row_ptr[seg_va + (tid <= na0 ? tid : 0)] - row0;
     }
     auto ga_load = [&](int grp, u32x2 (&v)[NP][J]) {
 #pragma unroll
@@ -300,8 +328,16 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
             if (r < nrows && c < ncols) {
                 const long long row = row0 + r;
                 if (g.Zpre) *reinterpret_cast<float4*>(g.Zpre + row * g.ldz + col0 + c) = z;
-                if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col0 + c) = apply_act4(z, g.act, slope);
+                const float4 y = apply_act4(z, g.act, slope);
+                if (g.C) *reinterpret_cast<float4*>(g.C + row * g.ldc + col0 + c) = y;
+                if constexpr (SEG) *reinterpret_cast<float4*>(T + r * LDC + c) = y;  // tau(z): what the segment sums run over
             }
+        }
+        if constexpr (SEG) {
+            if (tid < BM) meta[tid] = seg_rev;
+            step16::SegOut o;
+            o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.ts; o.Sout = g.Sout; o.lds = g.lds; o.N = g.N;
+            step16::seg_epilogue<LDC, BN / 4>(o, T, meta, row0, nrows, seg_va, seg_vb, seg_rp, poison, g.qmagic, tile_scale);
         }
     } else {
 #pragma unroll
@@ -327,16 +363,17 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
     }
 }
 
-template <int WN, int GC>
+template <int WN, int GC, bool SEG = false>
 int launch_rows16(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s);
 
-#define DMPNN_DEFINE_ROWS16(WN, GC)                                                                        \
+#define DMPNN_DEFINE_ROWS16(WN, GC) DMPNN_DEFINE_ROWS16_X(WN, GC, false)
+#define DMPNN_DEFINE_ROWS16_X(WN, GC, SEG)                                                                 \
     template <>                                                                                            \
-    int launch_rows16<WN, GC>(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s) {            \
-        constexpr size_t lds = lds_bytes<WN, GC>();                                                        \
+    int launch_rows16<WN, GC, SEG>(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s) {       \
+        constexpr size_t lds = lds_bytes<WN, GC, SEG>();                                                   \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows16<WN, GC>),           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows16<WN, GC, SEG>),      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_rows16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
@@ -344,7 +381,7 @@ int launch_rows16(const Rows16K& g, int row_tiles, int col_blocks, hipStream_t s
             }                                                                                              \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_rows16<WN, GC>), dim3((unsigned)row_tiles, (unsigned)col_blocks), dim3(kThreads), lds, s, g); \
+        hipLaunchKernelGGL((k_rows16<WN, GC, SEG>), dim3((unsigned)row_tiles, (unsigned)col_blocks), dim3(kThreads), lds, s, g); \
         DMPNN_CHECK_LAUNCH("k_rows16");                                                                    \
         return DMPNN_OK;                                                                                   \
     }

@@ -1,0 +1,128 @@
+// Host side of the per-step FUSED route on the f16 matrix pipe (dmpnn_step16_impl.hpp): instantiations and the launch
+// chain of one inference forward  K1 (+ first message)  ->  (depth - 1) x update (+ next message / Mv)  ->  finalize.
+#include <stdlib.h>
+#include <string.h>
+
+#include "dmpnn_step16_impl.hpp"
+
+namespace dmpnn {
+namespace step16 {
+DMPNN_DEFINE_STEP16(1)
+DMPNN_DEFINE_STEP16(2)
+DMPNN_DEFINE_STEP16(3)
+DMPNN_DEFINE_STEP16(4)
+DMPNN_DEFINE_STEP16(5)
+}  // namespace step16
+namespace rows16 {
+DMPNN_DEFINE_ROWS16_X(1, 4, true)
+DMPNN_DEFINE_ROWS16_X(2, 4, true)
+DMPNN_DEFINE_ROWS16_X(3, 4, true)
+DMPNN_DEFINE_ROWS16_X(4, 4, true)
+DMPNN_DEFINE_ROWS16_X(5, 4, true)
+}  // namespace rows16
+
+int64_t split_row_floats(int64_t d_h) { return step16::split_row_bytes((int)d_h) / 4; }
+
+bool fused16_shapes_ok(const dmpnn_fwd_args& a) {
+    const int64_t h = a.d_h;
+    if (a.flags & (DMPNN_F_UNDIRECTED | DMPNN_F_KEEP)) return false;  // inference forward of directed graphs
+    if (h <= 0 || h % 4 != 0 || h > 320 || a.ldh % 4 != 0) return false;
+    if (a.d_v % 2 || a.d_e % 2 || a.ldv % 2 || a.lde % 2) return false;
+    if (a.n_atoms * a.ldv * 4 > 0x7FFFFFFF || a.n_edges * a.lde * 4 > 0x7FFFFFFF) return false;
+    if ((a.n_edges + 64) * (int64_t)step16::split_row_bytes((int)h) > ((int64_t)1 << 40)) return false;
+    return true;
+}
+
+static unsigned qmagic_of(int64_t N) {
+    const unsigned qn = (unsigned)(N / 4);
+    return qn > 1 ? (unsigned)(((1ull << 32) + qn - 1) / qn) : 0u;
+}
+
+// K1 with the segment epilogue: H0 = W_i [V[srcp] || E[perm]] (+ b_i) stored; tau; first message (split rows) or Mv
+static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* Mout, float* Sout, hipStream_t s) {
+    const int* plan_i = static_cast<const int*>(a.plan);
+    rows16::Rows16K g;
+    memset(&g, 0, sizeof(g));
+    g.M = (int)a.n_edges; g.N = (int)a.d_h; g.K1 = (int)a.d_v; g.K2 = (int)a.d_e;
+    g.A1 = a.V; g.lda1 = (int)a.ldv; g.gather1 = plan_i + L.srcp; g.a1_bytes = (unsigned)(a.n_atoms * a.ldv * 4);
+    g.A2 = a.d_e ? a.E : nullptr; g.lda2 = (int)a.lde; g.gather2 = plan_i + L.perm; g.a2_bytes = (unsigned)(a.n_edges * a.lde * 4);
+    g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
+    g.bias = a.b_i;
+    g.Zpre = a.H0; g.ldz = (int)a.ldh;
+    g.act = a.act; g.slope = a.act_slope; g.slope_ptr = a.act_slope_ptr;
+    g.poison_flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoFuse;
+    g.vec_out = 1;
+    g.tile_row = plan_i + L.tile_row; g.tile_atom = plan_i + L.tile_atom; g.row_ptr = plan_i + L.row_ptr; g.revp = plan_i + L.revp;
+    g.Mout = Mout; g.ts = step16::split_row_bytes((int)a.d_h); g.Sout = Sout; g.lds = (int)a.ldh; g.qmagic = qmagic_of(a.d_h);
+    const int n_tiles = (int)L.max_tiles;
+    switch ((int)((a.d_h + 63) / 64)) {
+        case 1: return rows16::launch_rows16<1, 4, true>(g, n_tiles, 1, s);
+        case 2: return rows16::launch_rows16<2, 4, true>(g, n_tiles, 1, s);
+        case 3: return rows16::launch_rows16<3, 4, true>(g, n_tiles, 1, s);
+        case 4: return rows16::launch_rows16<4, 4, true>(g, n_tiles, 1, s);
+        default: return rows16::launch_rows16<5, 4, true>(g, n_tiles, 1, s);
+    }
+}
+
+static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const unsigned char* Min, unsigned char* Mout,
+                         float* Sout, hipStream_t s) {
+    const int* plan_i = static_cast<const int*>(a.plan);
+    step16::Step16K g;
+    memset(&g, 0, sizeof(g));
+    g.M = (int)a.n_edges; g.N = (int)a.d_h;
+    g.tile_row = plan_i + L.tile_row; g.tile_atom = plan_i + L.tile_atom; g.row_ptr = plan_i + L.row_ptr; g.revp = plan_i + L.revp;
+    g.A = Min; g.ts = step16::split_row_bytes((int)a.d_h);
+    g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
+    g.bias = a.b_h; g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
+    g.Mout = Mout; g.Sout = Sout; g.lds = (int)a.ldh;
+    g.act = a.act; g.slope = a.act_slope; g.slope_ptr = a.act_slope_ptr;
+    g.poison_flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoFuse;
+    g.qmagic = qmagic_of(a.d_h);
+    const int n_tiles = (int)L.max_tiles;
+    switch ((int)((a.d_h + 63) / 64)) {
+        case 1: return step16::launch_step16<1>(g, n_tiles, s);
+        case 2: return step16::launch_step16<2>(g, n_tiles, s);
+        case 3: return step16::launch_step16<3>(g, n_tiles, s);
+        case 4: return step16::launch_step16<4>(g, n_tiles, s);
+        default: return step16::launch_step16<5>(g, n_tiles, s);
+    }
+}
+
+// a.Ms: two slots of n_edges split rows (split_row_floats(d_h) floats each); a.H0 [n_edges, ldh]; a.Mv [n_atoms, ldh];
+// w16: pre-split W_i | W_h | W_o (| W_d).  `out` / `ldout`: the finalize output (Hv when W_d follows).
+int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s) {
+    const int64_t nV = a.n_atoms, nE = a.n_edges, h = a.d_h;
+    const PlanLayout L = plan_layout(nV, nE);
+    const int T = a.depth;
+    const size_t slot_bytes = (size_t)nE * step16::split_row_bytes((int)h);
+    unsigned char* Ms = reinterpret_cast<unsigned char*>(a.Ms);
+    if (nE == 0 && nV > 0) {
+        hipError_t e = hipMemsetAsync(a.Mv, 0, (size_t)nV * a.ldh * sizeof(float), s);
+        if (e != hipSuccess) { set_error("forward(fused16): memset failed: %s", hipGetErrorString(e)); return DMPNN_EHIP; }
+    }
+    if (nE > 0) {
+        DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
+        for (int t = 1; t < T; ++t) {
+            const bool last = t == T - 1;
+            DMPNN_TRY(launch_update(a, L, w16[1], Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : Ms + (t % 2) * slot_bytes,
+                                    last ? a.Mv : nullptr, s));
+        }
+    }
+    dmpnn_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.M = nV; g.N = h; g.K1 = a.d_v; g.K2 = h;
+    g.A1 = a.V; g.lda1 = a.ldv; g.A2 = a.Mv; g.lda2 = a.ldh;
+    g.W = a.W_o; g.ldw = a.d_v + h; g.bias = a.b_o;
+    g.C = out; g.ldc = ldout;
+    g.act = a.act; g.act_slope = a.act_slope; g.act_slope_ptr = a.act_slope_ptr;
+    const int* plan_i = static_cast<const int*>(a.plan);
+    if (linear16_ok(g)) return launch_linear16_view(g, w16[2], plan_i + DMPNN_HDR_FLAGS, kPlanNoFuse, s);
+    GemmExtra xf;
+    memset(&xf, 0, sizeof(xf));
+    xf.poison_flags = plan_i + DMPNN_HDR_FLAGS; xf.poison_mask = kPlanNoFuse;
+    return launch_linear_ex(g, xf, s);
+}
+
+}  // namespace dmpnn
+
+extern "C" int64_t dmpnn_split_row_floats(int64_t d_h) { return dmpnn::split_row_floats(d_h); }

@@ -20,6 +20,9 @@ from ._lib import ACT, F_FUSED, F_KEEP, F_LOADER_TILES, F_MEGA, F_SPLIT16, F_UND
 # From this many directed edges on, the per-step route runs its contractions on the f16 pipe (exact operand split) and is
 # preferred to the fused fp32-MFMA route (measured on MI355X: 1.3x per contraction at 36 k rows, more beyond).
 STEPS16_MIN_EDGES = 20000
+# From this many directed edges on, an inference forward that does not take the whole-forward tile kernel runs the per-step
+# FUSED route on the f16 pipe (one launch per depth step, split message rows) instead of the fp32-MFMA fused route.
+FUSED16_MIN_EDGES = int(os.environ.get("DMPNN_FUSED16_MIN_EDGES", "2048"))
 
 
 def small_plan_fits(n_atoms: int, n_edges: int) -> bool:
@@ -411,14 +414,25 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         level = min(level, 1)
     if route is None:
         level = min(level, int(max_level))
-    if (fused is True or route in ("fused", "mega")) and level < (2 if route == "mega" else 1):
+    if (fused is True or route in ("fused", "mega", "fused16")) and level < (2 if route == "mega" else 1):
         raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
                            "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "
                            "<= 6144 atoms and <= 12288 edges)")
     mf = mfma or _lib.opt("DMPNN_MFMA", "split16")
-    if (level == 1 and route is None and fused is None and mfma is None and mf == "split16" and nE >= STEPS16_MIN_EDGES
+    # per-step FUSED route on the f16 pipe (split message rows between the steps, dmpnn_step16_impl.hpp): inference
+    # forwards the whole-forward tile kernel does not take — large molecules (ZINC, 40-atom, reaction graphs), any batch
+    # size; `route="fused16"` demands it
+    use_fused16 = False
+    if level >= 1 and not keep and not getattr(plan, "tiles_only", False) and mf == "split16" and _lib.opt("DMPNN_FUSED16", "1") != "0":
+        if route == "fused16" or (route is None and fused is None and mfma is None and level == 1 and nE >= FUSED16_MIN_EDGES):
+            use_fused16 = True
+            level = 1
+    if route == "fused16" and not use_fused16:
+        raise RuntimeError("forward: route 'fused16' requested but not available (inference, directed, d_h % 4 == 0, d_h <= 320, "
+                           "even d_v / d_e, a full or light plan)")
+    if (level == 1 and not use_fused16 and route is None and fused is None and mfma is None and mf == "split16" and nE >= STEPS16_MIN_EDGES
             and not getattr(plan, "light", False)):
-        level = 0  # large batch: the per-step route on the f16 pipe beats the fused fp32-MFMA contractions
+        level = 0  # large batch (training): the per-step route on the f16 pipe beats the fused fp32-MFMA contractions
     use_fused, use_mega = level >= 1, level >= 2
     if getattr(plan, "light", False) and (not use_fused or keep):
         raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
@@ -428,7 +442,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
 
     st = ForwardState()
     st.fused = use_fused
-    st.route = "mega" if use_mega else ("fused" if use_fused else "general")
+    st.route = "mega" if use_mega else ("fused16" if use_fused16 else ("fused" if use_fused else "general"))
     if use_mega:
         n_hslots = n_steps if keep else 0           # inference: H / M never leave the CU
         n_mslots = n_steps if keep else 0
@@ -445,8 +459,16 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         # scratch of the tile kernel's generic path, should a molecule exceed its tile (never touched otherwise)
         spill_ws = torch.empty((3 * nE + nV) * ldh, dtype=torch.float32, device=dev)
         a.spill_ws, a.spill_bytes = spill_ws.data_ptr(), spill_ws.numel() * 4
+    split_ms = None
     if use_mega and not keep and not d_vd:  # inference tile kernel: nothing leaves the CU but `out`
         edge_ws = atom_ws = None
+    elif use_fused16:
+        # H0 fp32 | two slots of split message rows (row = chunks of [hi | lo] halfs + a 16-byte tail with the row's scale)
+        srf = int(lib.dmpnn_split_row_floats(d_h))
+        edge_ws = torch.empty((1, nE, ldh), dtype=torch.float32, device=dev)
+        split_ms = torch.empty((2, nE, srf), dtype=torch.float32, device=dev)
+        atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
+        n_hslots, n_mslots = 0, 2
     else:
         edge_ws = torch.empty(((1 if need_h0 else 0) + n_hslots + n_mslots, nE, ldh), dtype=torch.float32, device=dev)
         atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
@@ -467,13 +489,16 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         a.Hs, a.n_hslots = (st.Hs.data_ptr() if n_hslots else None), n_hslots
         a.Ms, a.n_mslots = (st.Ms.data_ptr() if n_mslots else None), max(n_mslots, 1)
         a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
+        if split_ms is not None:
+            st.Ms = split_ms
+            a.Ms, a.n_mslots = split_ms.data_ptr(), 2
     if use_fused:
         a.flags |= F_FUSED
     wsplit = None
     # the f16-pipe contractions with the exact operand split: always in the whole-forward tile kernel; in the per-step
     # general route where they pay (measured crossover: wide hidden layers or >= ~20 k edge rows; they are the same
     # arithmetic class, so this is a speed decision only).  mfma="split16" forces them, "f32" forbids them.
-    want16 = use_mega or (not use_fused and (mfma == "split16" or (mfma is None and mf == "split16" and (d_h > 320 or nE >= STEPS16_MIN_EDGES))))
+    want16 = use_mega or use_fused16 or (not use_fused and (mfma == "split16" or (mfma is None and mf == "split16" and (d_h > 320 or nE >= STEPS16_MIN_EDGES))))
     if mf == "f32":
         want16 = False
     if want16:
@@ -486,7 +511,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         key = None
         if wcache is not None and _lib.opt("DMPNN_WCACHE", "1") != "0":
             key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (W_i, W_h, W_o) + ((W_d,) if d_vd else ())) \
-                + (nb, d_v, d_e, str(dev), bool(use_mega))
+                + (nb, d_v, d_e, str(dev), bool(use_mega))  # (the per-step routes share one layout: W_i | W_h | W_o | W_d)
             if wcache.get("key") == key:
                 wsplit = wcache["buf"]
                 a.flags |= F_WSPLIT_READY
@@ -495,7 +520,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             if key is not None:
                 wcache["key"], wcache["buf"] = key, wsplit
         a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
-        st.route = "mega16" if use_mega else "general16"
+        st.route = "mega16" if use_mega else ("fused16" if use_fused16 else "general16")
     elif use_mega:
         a.flags |= F_MEGA
     if keep:

@@ -306,10 +306,11 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     oversize = getattr(bmg, "oversize", None)  # host knowledge of the batching code (None: bare tensors)
     if oversize is True:
         loader_tiles = False
-    light = _light_plan_ok(mp) and (int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES or loader_tiles)
+    # (an inference forward of the fused routes: tile kernel, per-step fused route on the f16 pipe, fp32 fused route)
+    light = _light_plan_ok(mp) and (int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES or loader_tiles or _lib.opt("DMPNN_FUSED16", "1") != "0")
     if light and oversize is not True and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
         light = "tiles"
-    elif light and int(bmg.E.shape[0]) >= engine.STEPS16_MIN_EDGES:
+    elif light and int(bmg.E.shape[0]) >= engine.STEPS16_MIN_EDGES and _lib.opt("DMPNN_FUSED16", "1") == "0":
         light = False
     plan = engine.GraphPlan.from_bmg(bmg, light=light)
     if n_mols and getattr(bmg, "batch", None) is not None:
@@ -322,10 +323,12 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     if oversize is True:
         level = min(level, 1)
     out = mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=level)
-    if oversize is None and plan.tiles_only and mp.__dict__.get("_dmpnn_last") is not None and mp.__dict__["_dmpnn_last"].route == "mega16":
+    last = mp.__dict__.pop("_dmpnn_last", None)  # (the forward's workspace must not outlive the call)
+    mp.__dict__["_dmpnn_route"] = getattr(last, "route", None)  # diagnostics: the route the last slow-path forward took
+    if oversize is None and plan.tiles_only and last is not None and last.route == "mega16":
         _spill_monitor(mp, plan.buf, plan.device)
     if light == "tiles" and V_d is None and not torch.is_grad_enabled() and _lib.opt("DMPNN_REPLAY", "1") != "0":
-        _make_replay(mp, plan, mp.__dict__.pop("_dmpnn_last", None))
+        _make_replay(mp, plan, last)
     return out
 
 

@@ -267,6 +267,31 @@ def test_whole_forward_tile_kernel_split_f16(golden, gpu_device):
     assert torch.equal(out_i, out_s)
 
 
+def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device):
+    """Route "fused16" (dmpnn_step16_impl.hpp): one launch per depth step, message rows kept between the steps in split
+    form (hi | lo halfs + the row's scale), operand tiles fetched by LDS-DMA.  Any molecule size.  Held to the same bar
+    against the executed reference as every other route; the per-atom sums it leaves in the workspace as well."""
+    cfg = golden.cfg
+    if cfg.get("undirected") or cfg["d_h"] % 4 or cfg["d_h"] > 320 or golden["V"].shape[1] % 2 or golden["E"].shape[1] % 2:
+        pytest.skip("fused routes do not apply")
+    if str(cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
+        pytest.skip("custom activation: rows route")
+    plan, out, st = _engine_forward(golden, gpu_device, route="fused16")
+    assert st.route == "fused16"
+    if not plan.fusable():
+        assert torch.isnan(out).all()      # not a molecular graph: loud
+        return
+    err = parity_err(out.cpu().numpy(), golden["out"])
+    assert err <= TOL, f"{golden.name}: {err:.3e}"
+    if "Mv" in golden and plan.n_edges:
+        assert parity_err(st.Mv[:, :cfg["d_h"]].cpu().numpy(), golden["Mv"]) <= TOL
+    if "H0" in golden and plan.n_edges:     # kept rows are the plan's CSR rows (row i = edge perm[i])
+        H0 = st.H0[:, :cfg["d_h"]][plan.inv32.long()]
+        assert parity_err(H0.cpu().numpy(), golden["H0"]) <= TOL
+    _, out2, _ = _engine_forward(golden, gpu_device, route="fused16")
+    assert torch.equal(out, out2)          # deterministic (no atomics on the data path)
+
+
 def _closed_tile_mask(a, src, dst, rev, n_atoms):
     """What the tile kernel checks on a tile plan, in numpy: per atom, does its tile hold exactly its own edges
     (caller ids mtile_row[t] .. mtile_row[t+1]) with both atoms and the reverse edge inside the tile?"""
