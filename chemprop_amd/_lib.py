@@ -33,7 +33,7 @@ EXPORTS = [
     "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
-    "dmpnn_prepare_tiles_from_table", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats",
+    "dmpnn_prepare_tiles_from_table", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -212,6 +212,7 @@ def load() -> C.CDLL:
                                      C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     lib.dmpnn_forward_wsplit_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_forward_spill_bytes.argtypes = [C.POINTER(FwdArgs)]
+    lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_split_row_floats.argtypes = [C.c_int64]
     lib.dmpnn_split_row_floats.restype = C.c_int64
     lib.dmpnn_debug_timestamps.argtypes = [C.c_void_p]

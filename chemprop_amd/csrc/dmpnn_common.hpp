@@ -127,6 +127,17 @@ __device__ __forceinline__ float apply_act(float z, int act, float slope) {
         default: return z;
     }
 }
+// The transcendental activations out of line: a fully unrolled epilogue that inlines tanhf / expm1f per element grows by
+// tens of KB, and a workgroup that runs its code once pays for code size in instruction fetches (the tile kernels:
+// 27 % of their cycles).  ReLU-class activations are a compare + select in line.
+__device__ __noinline__ float apply_act_slow(float z, int act) {
+    return act == DMPNN_ACT_TANH ? tanhf(z) : (z > 0.f ? z : expm1f(z));
+}
+__device__ __forceinline__ float apply_act_small(float z, int act, float slope) {
+    if (act == DMPNN_ACT_TANH || act == DMPNN_ACT_ELU) return apply_act_slow(z, act);
+    const float neg = act == DMPNN_ACT_NONE ? 1.f : (act == DMPNN_ACT_RELU ? 0.f : slope);
+    return (z > 0.f ? z : neg * z) + 0.f;
+}
 __device__ __forceinline__ float4 apply_act4(float4 z, int act, float slope) {
     if (act == DMPNN_ACT_NONE) return z;
     return make_float4(apply_act(z.x, act, slope), apply_act(z.y, act, slope),

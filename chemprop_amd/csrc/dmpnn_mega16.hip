@@ -3,9 +3,18 @@
 
 namespace dmpnn {
 namespace mega16 {
-DMPNN_DEFINE_MEGA16(1)
-DMPNN_DEFINE_MEGA16(2)
-DMPNN_DEFINE_MEGA16(5)
+DMPNN_DEFINE_MEGA16(1, true, true)
+DMPNN_DEFINE_MEGA16(1, true, false)
+DMPNN_DEFINE_MEGA16(1, false, true)
+DMPNN_DEFINE_MEGA16(1, false, false)
+DMPNN_DEFINE_MEGA16(2, true, true)
+DMPNN_DEFINE_MEGA16(2, true, false)
+DMPNN_DEFINE_MEGA16(2, false, true)
+DMPNN_DEFINE_MEGA16(2, false, false)
+DMPNN_DEFINE_MEGA16(5, true, true)
+DMPNN_DEFINE_MEGA16(5, true, false)
+DMPNN_DEFINE_MEGA16(5, false, true)
+DMPNN_DEFINE_MEGA16(5, false, false)
 }  // namespace mega16
 
 long long* g_debug_stamps = nullptr;
@@ -84,9 +93,14 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     g.edge_index = reinterpret_cast<const long long*>(a.edge_index);
     g.rev64 = reinterpret_cast<const long long*>(a.rev_edge_index);
     const int n_tiles = (a.n_tiles_launch > 0 && a.n_tiles_launch < L.max_mtiles) ? (int)a.n_tiles_launch : (int)L.max_mtiles;
-    if (a.d_h <= 64) return mega16::launch_mega16<1>(G, n_tiles, s);
-    if (a.d_h <= 128) return mega16::launch_mega16<2>(G, n_tiles, s);
-    return mega16::launch_mega16<5>(G, n_tiles, s);
+    const bool sa = !(a.act == DMPNN_ACT_TANH || a.act == DMPNN_ACT_ELU), kp = (a.flags & DMPNN_F_KEEP) != 0;
+    const int wn = a.d_h <= 64 ? 1 : (a.d_h <= 128 ? 2 : 5);
+#define DMPNN_PICK(WN) (sa ? (kp ? mega16::launch_mega16<WN, true, true>(G, n_tiles, s) : mega16::launch_mega16<WN, true, false>(G, n_tiles, s)) \
+                           : (kp ? mega16::launch_mega16<WN, false, true>(G, n_tiles, s) : mega16::launch_mega16<WN, false, false>(G, n_tiles, s)))
+    if (wn == 1) return DMPNN_PICK(1);
+    if (wn == 2) return DMPNN_PICK(2);
+    return DMPNN_PICK(5);
+#undef DMPNN_PICK
 }
 
 }  // namespace dmpnn

@@ -112,7 +112,12 @@ constexpr size_t lds_bytes() {
     return (size_t)kMegaBM * (64 * WN * 4 + 16) * 2 + (size_t)(3 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
 }
 
-template <int WN>
+// SA (simple activation): identity / ReLU / LeakyReLU / PReLU are a compare + select in line; tanh and ELU get their own
+// instantiation — a workgroup runs its code ONCE, cold: every KB of inlined transcendental code that the ReLU path has to
+// jump across costs instruction fetches (the kernel was 203 KB against a 64 KB instruction cache).
+// KEEP: the training forward (H0, H^(t), M^(t), Mv stream out for the backward pass); the inference instantiation carries none of
+// that code (64-bit row addresses and a divergent branch per stored fragment).
+template <int WN, bool SA, bool KEEP>
 __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     const mega::MegaK& g = G.m;
     constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
@@ -173,11 +178,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     }
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
-    const bool simple_act = !(g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU);
-    auto tau = [&](float z) -> float {
-        if (simple_act) return (z > 0.f ? z : neg_slope * z) + 0.f;
-        return apply_act(z, g.act, slope);
-    };
+    constexpr bool simple_act = SA;
 
     // ---- weight fragments: straight from L2 to registers --------------------------------------------
     // The four waves of a workgroup own disjoint column ranges, so a weight element is used by exactly one
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     auto act_frags = [&](auto rt_c, auto use_res_c, f32x4 (&z)[decltype(rt_c)::value][WN], const f32x4 (&res)[decltype(rt_c)::value][WN]) {
         constexpr int RT = decltype(rt_c)::value;
         constexpr bool USE_RES = decltype(use_res_c)::value;
-        if (simple_act) {
+        if constexpr (simple_act) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -621,7 +622,9 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                     unsigned char* p = T16 + row * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
                     *reinterpret_cast<h4*>(p) = hi;
                     *reinterpret_cast<h4*>(p + 64) = lo;
-                    if (keep && row < n_keep && col4 < N) *reinterpret_cast<float4*>(keep + (keep0 + row) * keep_ld + col4) = v;
+                    if constexpr (KEEP) {
+                        if (keep && row < n_keep && col4 < N) *reinterpret_cast<float4*>(keep + (keep0 + row) * keep_ld + col4) = v;
+                    }
                 }
             }
         }
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         unscale(RE{}, h0, 1.f / s_prev, cc);
         stamp();  // 3: K1 contraction
     }
-    if (g.H0) {  // training: the pre-activation is needed by the backward pass
+    if (KEEP && g.H0) {  // training: the pre-activation is needed by the backward pass
         __syncthreads();  // (the fp32 tile may overlay the K1 operand tile)
         frag_to_tile(RE{}, h0);
         __syncthreads();
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         unscale(RE{}, acc, 1.f / sA, cc);
         act_frags(RE{}, T_{}, acc, h0);  // tau(H0 + W_h(M)): base.py:141
         stamp();  // E: unscale + tau
-        if (g.Hs) {
+        if (KEEP && g.Hs) {
             frag_to_tile(RE{}, acc);
             __syncthreads();
             tile_to_global(g.Hs + (long long)(step - 1) * g.slot, rs, g.ldh, nrows);
@@ -731,16 +734,16 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
     }
 }
 
-template <int WN>
+template <int WN, bool SA, bool KEEP>
 int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
 
-#define DMPNN_DEFINE_MEGA16(WN)                                                                            \
+#define DMPNN_DEFINE_MEGA16(WN, SA, KEEP)                                                                  \
     template <>                                                                                            \
-    int launch_mega16<WN>(const Mega16K& g, int n_tiles, hipStream_t s) {                                  \
+    int launch_mega16<WN, SA, KEEP>(const Mega16K& g, int n_tiles, hipStream_t s) {                        \
         constexpr size_t lds = lds_bytes<WN>();                                                            \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN>),          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN, SA, KEEP>),          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_mpnn_tile16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
@@ -748,7 +751,7 @@ int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
             }                                                                                              \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_mpnn_tile16<WN>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);       \
+        hipLaunchKernelGGL((k_mpnn_tile16<WN, SA, KEEP>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);       \
         DMPNN_CHECK_LAUNCH("k_mpnn_tile16");                                                               \
         return DMPNN_OK;                                                                                   \
     }

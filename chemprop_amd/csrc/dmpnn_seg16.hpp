@@ -9,7 +9,6 @@ namespace dmpnn {
 namespace step16 {
 
 using gemm::kAtomCache;
-using gemm::kThreads;
 using mega16::h4;
 using mega16::split4;
 
@@ -27,7 +26,7 @@ struct SegOut {
 // edge | [kAtomCache + 1] tile-local row pointers.  Pass 1: S per (atom, column quad), Sout, the message S - y in place
 // and its maximum; tile scale; pass 2 (row-major): the message rows in split form to Mout[rev r].  Sums run over the rows of an atom in increasing row order = increasing
 // edge id (the reference's sequential scatter order, base.py:144-146).
-template <int LDC, int NQP, class TileScale>
+template <int LDC, int NQP, int NT, class TileScale>
 __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* meta, int rs, int nrows, int va, int vb,
                                              int seg_rp_reg, bool poison, unsigned qmagic, TileScale&& tile_scale) {
     const int tid = threadIdx.x;
@@ -43,7 +42,7 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
         if (tid <= na) rp[tid] = a0 == va ? seg_rp_reg : o.row_ptr[a0 + tid] - rs;
         __syncthreads();
         const int n_items = na * qn;
-        for (int it = tid; it < n_items; it += kThreads) {
+        for (int it = tid; it < n_items; it += NT) {
             const int al = qn == 1 ? it : (int)__umulhi((unsigned)it, qmagic);
             const int q = it - al * qn;
             const int r0 = rp[al], r1 = rp[al + 1];
@@ -71,7 +70,7 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
     // writes whole rows of the split tensor (row rev r) contiguously.  Columns beyond N are zero in T (zero weights,
     // zero residual, tau(0) = 0 for every built-in activation), so the padded chunks come out as zeros.
     constexpr int G8 = NQP / 2;  // 8-column groups of a padded row
-    for (int it = tid; it < nrows * G8; it += kThreads) {
+    for (int it = tid; it < nrows * G8; it += NT) {
         const int r = it / G8, g8 = it - r * G8;
         float4 m0 = *reinterpret_cast<const float4*>(T + r * LDC + 8 * g8);
         float4 m1 = *reinterpret_cast<const float4*>(T + r * LDC + 8 * g8 + 4);

@@ -6,12 +6,16 @@
 #include "dmpnn_step16_impl.hpp"
 
 namespace dmpnn {
+extern long long* g_debug_stamps;
 namespace step16 {
-DMPNN_DEFINE_STEP16(1)
-DMPNN_DEFINE_STEP16(2)
-DMPNN_DEFINE_STEP16(3)
-DMPNN_DEFINE_STEP16(4)
-DMPNN_DEFINE_STEP16(5)
+DMPNN_DEFINE_STEP16(1, 4)
+DMPNN_DEFINE_STEP16(2, 4)
+DMPNN_DEFINE_STEP16(3, 4)
+DMPNN_DEFINE_STEP16(4, 4)
+DMPNN_DEFINE_STEP16(5, 4)
+DMPNN_DEFINE_STEP16(3, 8)
+DMPNN_DEFINE_STEP16(4, 8)
+DMPNN_DEFINE_STEP16(5, 8)
 }  // namespace step16
 namespace rows16 {
 DMPNN_DEFINE_ROWS16_X(1, 4, true)
@@ -26,7 +30,8 @@ int64_t split_row_floats(int64_t d_h) { return step16::split_row_bytes((int)d_h)
 bool fused16_shapes_ok(const dmpnn_fwd_args& a) {
     const int64_t h = a.d_h;
     if (a.flags & (DMPNN_F_UNDIRECTED | DMPNN_F_KEEP)) return false;  // inference forward of directed graphs
-    if (h <= 0 || h % 4 != 0 || h > 320 || a.ldh % 4 != 0) return false;
+    if (h <= 0 || h % 4 != 0 || h > 640 || a.ldh % 4 != 0) return false;
+    if (h > 320 && step16::split_operand_bytes((int)(a.d_v + a.d_e)) > step16::split_row_bytes((int)h)) return false;
     if (a.d_v % 2 || a.d_e % 2 || a.ldv % 2 || a.lde % 2) return false;
     if (a.n_atoms * a.ldv * 4 > 0x7FFFFFFF || a.n_edges * a.lde * 4 > 0x7FFFFFFF) return false;
     if ((a.n_edges + 64) * (int64_t)step16::split_row_bytes((int)h) > ((int64_t)1 << 40)) return false;
@@ -64,28 +69,69 @@ static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
     }
 }
 
-static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const unsigned char* Min, unsigned char* Mout,
-                         float* Sout, hipStream_t s) {
+static int launch_step(const step16::Step16K& g0, int64_t d_h, int n_tiles, hipStream_t s) {
+    step16::Step16K g = g0;
+    const int bn = step16::block_cols((int)d_h);
+    const size_t tile_a = (size_t)step16::BM * g.ts, tile_t = (size_t)step16::BM * (bn + 4) * 4;
+    g.tile_bytes = (int)(((tile_a > tile_t ? tile_a : tile_t) + 15) & ~size_t(15));
+    if (d_h <= 320) {
+        switch (bn / 64) {
+            case 1: return step16::launch_step16<1, 4>(g, n_tiles, s);
+            case 2: return step16::launch_step16<2, 4>(g, n_tiles, s);
+            case 3: return step16::launch_step16<3, 4>(g, n_tiles, s);
+            case 4: return step16::launch_step16<4, 4>(g, n_tiles, s);
+            default: return step16::launch_step16<5, 4>(g, n_tiles, s);
+        }
+    }
+    switch (bn / 128) {
+        case 3: return step16::launch_step16<3, 8>(g, n_tiles, s);
+        case 4: return step16::launch_step16<4, 8>(g, n_tiles, s);
+        default: return step16::launch_step16<5, 8>(g, n_tiles, s);
+    }
+}
+
+static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
     const int* plan_i = static_cast<const int*>(a.plan);
     step16::Step16K g;
     memset(&g, 0, sizeof(g));
     g.M = (int)a.n_edges; g.N = (int)a.d_h;
     g.tile_row = plan_i + L.tile_row; g.tile_atom = plan_i + L.tile_atom; g.row_ptr = plan_i + L.row_ptr; g.revp = plan_i + L.revp;
-    g.A = Min; g.ts = step16::split_row_bytes((int)a.d_h);
-    g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
-    g.bias = a.b_h; g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
-    g.Mout = Mout; g.Sout = Sout; g.lds = (int)a.ldh;
+    g.lds = (int)a.ldh;
     g.act = a.act; g.slope = a.act_slope; g.slope_ptr = a.act_slope_ptr;
     g.poison_flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoFuse;
     g.qmagic = qmagic_of(a.d_h);
-    const int n_tiles = (int)L.max_tiles;
-    switch ((int)((a.d_h + 63) / 64)) {
-        case 1: return step16::launch_step16<1>(g, n_tiles, s);
-        case 2: return step16::launch_step16<2>(g, n_tiles, s);
-        case 3: return step16::launch_step16<3>(g, n_tiles, s);
-        case 4: return step16::launch_step16<4>(g, n_tiles, s);
-        default: return step16::launch_step16<5>(g, n_tiles, s);
-    }
+    g.dbg = g_debug_stamps;
+    return g;
+}
+
+static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const unsigned char* Min, unsigned char* Mout,
+                         float* Sout, hipStream_t s) {
+    step16::Step16K g = step_args(a, L);
+    g.A = Min; g.ts = step16::split_row_bytes((int)a.d_h);
+    g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
+    g.bias = a.b_h; g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
+    g.Mout = Mout; g.Sout = Sout;
+    return launch_step(g, a.d_h, (int)L.max_tiles, s);
+}
+
+// K1 on the update kernel (d_h > 320): the gathered fp32 operand is split into rows first (scratch: the second message slot)
+static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* scratch, unsigned char* Mout,
+                           float* Sout, hipStream_t s) {
+    const int* plan_i = static_cast<const int*>(a.plan);
+    step16::SplitRowsK k;
+    memset(&k, 0, sizeof(k));
+    k.tile_row = plan_i + L.tile_row; k.n_tiles = (int)L.max_tiles;
+    k.A1 = a.V; k.lda1 = (int)a.ldv; k.g1 = plan_i + L.srcp; k.K1 = (int)a.d_v; k.a1_bytes = (unsigned)(a.n_atoms * a.ldv * 4);
+    k.A2 = a.d_e ? a.E : nullptr; k.lda2 = (int)a.lde; k.g2 = plan_i + L.perm; k.K2 = (int)a.d_e; k.a2_bytes = (unsigned)(a.n_edges * a.lde * 4);
+    k.out = scratch; k.ts = step16::split_operand_bytes((int)(a.d_v + a.d_e));
+    hipLaunchKernelGGL(step16::k_split_rows, dim3((unsigned)L.max_tiles), dim3(256), 0, s, k);
+    DMPNN_CHECK_LAUNCH("k_split_rows");
+    step16::Step16K g = step_args(a, L);
+    g.A = scratch; g.ts = k.ts;
+    g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
+    g.bias = a.b_i; g.Zpre = a.H0; g.ldz = (int)a.ldh;
+    g.Mout = Mout; g.Sout = Sout;
+    return launch_step(g, a.d_h, (int)L.max_tiles, s);
 }
 
 // a.Ms: two slots of n_edges split rows (split_row_floats(d_h) floats each); a.H0 [n_edges, ldh]; a.Mv [n_atoms, ldh];
@@ -101,7 +147,9 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
         if (e != hipSuccess) { set_error("forward(fused16): memset failed: %s", hipGetErrorString(e)); return DMPNN_EHIP; }
     }
     if (nE > 0) {
-        DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
+        static const bool k1_split_all = [] { const char* e = getenv("DMPNN_K1_SPLIT"); return e && e[0] == '1'; }();
+        if (h > 320 || k1_split_all) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
+        else DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
         for (int t = 1; t < T; ++t) {
             const bool last = t == T - 1;
             DMPNN_TRY(launch_update(a, L, w16[1], Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : Ms + (t % 2) * slot_bytes,
@@ -126,3 +174,5 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
 }  // namespace dmpnn
 
 extern "C" int64_t dmpnn_split_row_floats(int64_t d_h) { return dmpnn::split_row_floats(d_h); }
+
+extern "C" int dmpnn_forward_can_fuse16(const dmpnn_fwd_args* a) { return (a && dmpnn::fused16_shapes_ok(*a)) ? 1 : 0; }

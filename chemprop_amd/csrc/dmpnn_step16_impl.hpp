@@ -34,7 +34,6 @@ namespace step16 {
 using gemm::f32x4;
 using gemm::kAtomCache;
 using gemm::kOOB;
-using gemm::kThreads;
 using gemm::rsrc_t;
 using mega16::h4;
 using mega16::h8;
@@ -45,34 +44,40 @@ using mega16::SplitW;
 constexpr int RT = 3;
 static_assert(BM == 16 * RT, "48-row tiles");
 
-// bytes of one row of a split edge tensor of d_h columns (the A-tile row of the kernels: 64-column granules + 16 B tail)
-__host__ __device__ constexpr int split_row_bytes(int d_h) { return ((d_h + 63) / 64) * 256 + 16; }
+// output columns a workgroup covers for d_h: 4 waves x 16 WN (d_h <= 320) or 8 waves x 16 WN (d_h <= 640)
+__host__ __device__ constexpr int block_cols(int d_h) { return d_h <= 320 ? ((d_h + 63) / 64) * 64 : ((d_h + 127) / 128) * 128; }
+// bytes of one row of a split edge tensor of d_h columns (the A-tile row of the kernels: whole chunk pairs + 16 B tail)
+__host__ __device__ constexpr int split_row_bytes(int d_h) { return block_cols(d_h) * 4 + 16; }
+// ... of a split operand of K columns that is only ever READ as an operand (the gathered K1 input): whole 32-column chunks
+__host__ __device__ constexpr int split_operand_bytes(int K) { return ((K + 31) / 32) * 128 + 16; }
 
 struct Step16K {
     int M, N;
     const int* tile_row; const int* tile_atom; const int* row_ptr; const int* revp;
-    const unsigned char* A; int ts;       // split operand rows [M][ts]
+    const unsigned char* A; int ts;       // split operand rows [M][ts]: W.nc chunks (+ padding) + the 16-byte tail at ts - 16
     SplitW W; const float* bias;
-    const float* Cadd; int ldcadd;        // residual H0 [M][ldcadd] fp32
+    const float* Cadd; int ldcadd;        // residual H0 [M][ldcadd] fp32 (or null)
+    float* Zpre; int ldz;                 // pre-activation rows [M][ldz] fp32 to store (K1: H0), or null
     unsigned char* Mout; float* Sout; int lds;
     int act; float slope; const float* slope_ptr;
     const int* poison_flags; int poison_mask;
     unsigned qmagic;
+    int tile_bytes;                       // bytes of the LDS region shared by the operand tile and the fp32 epilogue tile
+    long long* dbg;                       // optional [16] cycle stamps of one workgroup (dmpnn_debug_timestamps), else null
 };
 
-template <int WN>
-constexpr size_t lds_bytes() {
-    return (size_t)BM * (64 * WN * 4 + 16) + (size_t)(BM + kAtomCache + 1) * sizeof(int) + 64;
-}
+template <int WN, int NW>
+__host__ __device__ constexpr size_t meta_bytes() { return (size_t)(BM + kAtomCache + 1) * sizeof(int) + 64; }
 
-template <int WN>
-__global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
-    constexpr int BN = 64 * WN, LDC = BN + 4, TS = BN * 4 + 16;
-    static_assert(LDC * 4 == TS, "the fp32 epilogue tile overlays the split operand tile row for row");
+template <int WN, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
+    constexpr int NT = 64 * NW;
+    constexpr int BN = 16 * WN * NW, LDC = BN + 4, TSO = BN * 4 + 16;
+    static_assert(LDC * 4 == TSO, "rows of the fp32 epilogue tile and of the split output tensor have the same stride");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* Ag = lds;                                    // [BM][TS] split operand tile (DMA target)
+    unsigned char* Ag = lds;                                    // [BM][ts] split operand tile (DMA target)
     float* T = reinterpret_cast<float*>(lds);                   // [BM][LDC] fp32 epilogue tile (overlays it)
-    int* meta = reinterpret_cast<int*>(lds + (size_t)BM * TS);  // [BM] reverse rows | [kAtomCache + 1] row pointers
+    int* meta = reinterpret_cast<int*>(lds + g.tile_bytes);     // [BM] reverse rows | [kAtomCache + 1] row pointers
     unsigned* maxbits = reinterpret_cast<unsigned*>(meta + BM + kAtomCache + 1);
 
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,6 +86,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
     };
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (g.dbg && blockIdx.x == 37 && threadIdx.x == 0 && n_stamp < 16) g.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();  // 0 entry
     const int t = blockIdx.x;
     const int rs = g.tile_row[t], re = g.tile_row[t + 1];
     const int va = g.tile_atom[t], vb = g.tile_atom[t + 1];
@@ -89,17 +100,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
     if (nrows < 0 || nrows > BM) return;  // (cannot happen with a valid tile table)
     const bool poison = g.poison_flags && (g.poison_flags[0] & g.poison_mask);
     if (tid < 4) maxbits[tid] = 0u;
+    const int TS = g.ts;
 
     // ---- everything the tile needs is requested now: operand rows by LDS-DMA, residual into the accumulators ----
     {
-        const unsigned nbytes = (unsigned)(nrows * g.ts);
-        const rsrc_t rA = gemm::make_rsrc(g.A + (long long)rs * g.ts, nbytes);
+        const unsigned nbytes = (unsigned)(nrows * TS);
+        const rsrc_t rA = gemm::make_rsrc(g.A + (long long)rs * TS, nbytes);
         const int n_inst = (int)((nbytes + 1023u) >> 10);
-#ifndef DMPNN_X_NOLOAD
-        for (int i = wave; i < n_inst; i += 4)
+        for (int i = wave; i < n_inst; i += NW)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(Ag + i * 1024), 16,
                                                      (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
-#endif
     }
     f32x4 acc[RT][WN];
     {
@@ -112,11 +122,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = rt * 16 + lg * 4 + r, col = wave * (16 * WN) + ct * 16 + li;
-#ifdef DMPNN_X_NOLOAD
-                    const unsigned off = kOOB;
-#else
                     const unsigned off = (row < nrows && col < g.N) ? (unsigned)(row * g.ldcadd + col) * 4u : kOOB;
-#endif
                     acc[rt][ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, off, 0, 0));
                 }
     }
@@ -128,13 +134,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
 
     // ---- weight fragments: [column tile][chunk][hi|lo][lane][16 B], straight from L2 ----
-    const int NT = (g.N + 15) / 16;
-    const rsrc_t rW = gemm::make_rsrc(g.W.p, (unsigned)(NT * g.W.nc * 2048));
+    const int NTL = (g.N + 15) / 16;
+    const rsrc_t rW = gemm::make_rsrc(g.W.p, (unsigned)(NTL * g.W.nc * 2048));
     unsigned offB[WN];
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
         const int tile = wave * WN + ct;
-        offB[ct] = tile < NT ? (unsigned)tile * (unsigned)(g.W.nc * 2048) + (unsigned)lane * 16u : kOOB;
+        offB[ct] = tile < NTL ? (unsigned)tile * (unsigned)(g.W.nc * 2048) + (unsigned)lane * 16u : kOOB;
     }
     auto load_bfrags = [&](int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
 #pragma unroll
@@ -155,7 +161,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
         isw[ct] = g.W.inv_scale[okc ? col : 0];
         bv[ct] = (okc && g.bias) ? g.bias[col] : 0.f;
     }
+    stamp();  // 1 everything requested
     __syncthreads();  // the operand tile has landed (the barrier's release waits for the DMA: vmcnt(0))
+    stamp();  // 2 landed
     launder();
     // the rows' own scales (tail of every operand row); rows beyond the tile: 1
     float sr[RT][4], isr[RT][4];
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + lg * 4 + r;
-            const float v = *reinterpret_cast<const float*>(Ag + row * TS + BN * 4);
+            const float v = *reinterpret_cast<const float*>(Ag + row * TS + (TS - 16));
             sr[rt][r] = (row < nrows && v > 0.f && v < 3.0e38f) ? v : 1.f;
             isr[rt][r] = 1.f / sr[rt][r];
         }
@@ -208,37 +216,59 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
     };
     read_afrags(0, ah[0], al[0]);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef DMPNN_X_NOMFMA
 #pragma nounroll
     for (int c = 0; c < n_chunks; c += 2) {
         step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
         if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
     }
-#endif
 
-    // ---- epilogue: split domain -> fp32, tau; tile -> segment sums -> next message (split rows) / Mv ----
+    stamp();  // 3 MFMA loop issued
+    // ---- epilogue: split domain -> fp32 (+ bias); [pre-activation rows out]; tau; tile -> segment sums -> message / Mv ----
     launder();
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = acc[rt][ct][r] * (isw[ct] * isr[rt][r]) + bv[ct];
-                acc[rt][ct][r] = apply_act(z, g.act, slope);
-            }
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * (isw[ct] * isr[rt][r]) + bv[ct];
+    stamp();  // 4 unscaled
     __syncthreads();  // every wave is done with the operand tile the epilogue tile overlays
+    stamp();  // 5 all waves through the contraction
+    // ReLU-class activations: a compare + select on the fragments.  tanh / ELU (and K1, whose pre-activation H0 leaves as
+    // rows) go through ONE row-major pass over the tile instead: no transcendental code unrolled 60 times (code size is
+    // latency for a workgroup that runs its code once).
+    const bool zpre = g.Zpre != nullptr;
+    const bool tpass = zpre || g.act == DMPNN_ACT_TANH || g.act == DMPNN_ACT_ELU;
+    const float neg = tpass ? 1.f : (g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope));
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
         const int cl = wave * (16 * WN) + ct * 16 + li;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T[(rt * 16 + lg * 4 + r) * LDC + cl] = acc[rt][ct][r];
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[rt][ct][r];
+                T[(rt * 16 + lg * 4 + r) * LDC + cl] = (z > 0.f ? z : neg * z) + 0.f;
+            }
     }
     if (tid < BM) meta[tid] = seg_rev;
+    if (tpass) {  // (K1: the pre-activation H0 leaves as coalesced rows;) the tile becomes tau(z)
+        __syncthreads();
+        const int qn = g.N >> 2;
+        const float nanv = __int_as_float(0x7fc00000);
+        for (int it = tid; it < nrows * qn; it += NT) {
+            const int r = qn == 1 ? it : (int)__umulhi((unsigned)it, g.qmagic), q = it - r * qn;
+            float4* cell = reinterpret_cast<float4*>(T + r * LDC + 4 * q);
+            float4 z = *cell;
+            if (poison) z = make_float4(nanv, nanv, nanv, nanv);
+            if (zpre) *reinterpret_cast<float4*>(g.Zpre + (long long)(rs + r) * g.ldz + 4 * q) = z;
+            *cell = apply_act4(z, g.act, slope);
+        }
+    }
+    stamp();  // 6 tile written (+ pre-activation rows)
     int scale_phase = 0;
     auto tile_scale = [&](float local_max) -> float {
+        stamp();  // 7 pass 1 done
         int u = (int)__float_as_uint(local_max);
         u = max(u, __builtin_amdgcn_update_dpp(0, u, 0xB1, 0xf, 0xf, true));
         u = max(u, __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xf, 0xf, true));
@@ -253,31 +283,84 @@ __global__ __launch_bounds__(kThreads, 2) void k_step16(Step16K g) {
         return scale_for(mxv);
     };
     SegOut o;
-    o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.ts; o.Sout = g.Sout; o.lds = g.lds;
+    o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = TSO; o.Sout = g.Sout; o.lds = g.lds;
     o.N = g.N;
-#ifndef DMPNN_X_NOSEG
-    seg_epilogue<LDC, BN / 4>(o, T, meta, rs, nrows, va, vb, seg_rp, poison, g.qmagic, tile_scale);
-#endif
+    seg_epilogue<LDC, BN / 4, NT>(o, T, meta, rs, nrows, va, vb, seg_rp, poison, g.qmagic, tile_scale);
+    stamp();  // 8 (7 without a message) end
 }
 
-template <int WN>
+// ---- the K1 operand [A1[g1[r]] || A2[g2[r]]] (fp32, gathered) as split rows: one workgroup per row tile of the plan ----
+// (used where K1 runs on k_step16 itself: d_h > 320; narrower blocks take k_rows16<.., SEG>, which splits on the fly)
+struct SplitRowsK {
+    const int* tile_row; int n_tiles;
+    const float* A1; int lda1; const int* g1; int K1; unsigned a1_bytes;
+    const float* A2; int lda2; const int* g2; int K2; unsigned a2_bytes;
+    unsigned char* out; int ts;
+};
+__global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
+    __shared__ unsigned maxbits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rs = g.tile_row[blockIdx.x], nrows = g.tile_row[blockIdx.x + 1] - rs;
+    if (nrows <= 0 || nrows > BM) return;
+    if (tid == 0) maxbits = 0u;
+    __syncthreads();
+    const int K = g.K1 + g.K2, nc = (g.ts - 16) / 128;
+    const rsrc_t r1 = gemm::make_rsrc(g.A1, g.a1_bytes), r2 = gemm::make_rsrc(g.A2 ? g.A2 : g.A1, g.A2 ? g.a2_bytes : 0u);
+    constexpr int J = BM / 4;
+    float mx = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        float s = 1.f;
+        if (pass == 1) {
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            if (lane == 0) atomicMax(&maxbits, __float_as_uint(mx));
+            __syncthreads();
+            s = scale_for(__uint_as_float(maxbits));
+        }
+        for (int j = 0; j < J; ++j) {
+            const int r = wave + 4 * j;
+            if (r >= nrows) continue;
+            const unsigned o1 = (unsigned)g.g1[rs + r] * (unsigned)g.lda1 * 4u;
+            const unsigned o2 = g.A2 ? (unsigned)g.g2[rs + r] * (unsigned)g.lda2 * 4u : kOOB;
+            for (int k = lane * 2; k < nc * 32; k += 128) {
+                const unsigned k1o = k < g.K1 ? (unsigned)k * 4u : kOOB;
+                const unsigned k2o = (k >= g.K1 && k < K) ? (unsigned)(k - g.K1) * 4u : kOOB;
+                const gemm::u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r1, gemm::join_off(o1, k1o), 0, 0) |
+                                      __builtin_amdgcn_raw_buffer_load_b64(r2, gemm::join_off(o2, k2o), 0, 0);
+                const float x = __uint_as_float(v.x), y = __uint_as_float(v.y);
+                if (pass == 0) {
+                    mx = fmaxf(mx, fmaxf(fabsf(x), fabsf(y)));
+                } else {
+                    const float xs = x * s, ys = y * s;
+                    const mega16::h2 hi = mega16::h2{(_Float16)xs, (_Float16)ys};
+                    const mega16::h2 lo = mega16::h2{(_Float16)(xs - (float)hi[0]), (_Float16)(ys - (float)hi[1])};
+                    unsigned char* p = g.out + (long long)(rs + r) * g.ts + (k >> 5) * 128 + (k & 31) * 2;
+                    *reinterpret_cast<mega16::h2*>(p) = hi;
+                    *reinterpret_cast<mega16::h2*>(p + 64) = lo;
+                }
+            }
+            if (pass == 1 && lane == 0) *reinterpret_cast<float4*>(g.out + (long long)(rs + r) * g.ts + (g.ts - 16)) = make_float4(s, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+template <int WN, int NW>
 int launch_step16(const Step16K& g, int n_tiles, hipStream_t s);
 
-#define DMPNN_DEFINE_STEP16(WN)                                                                            \
+#define DMPNN_DEFINE_STEP16(WN, NW)                                                                        \
     template <>                                                                                            \
-    int launch_step16<WN>(const Step16K& g, int n_tiles, hipStream_t s) {                                  \
-        constexpr size_t lds = lds_bytes<WN>();                                                            \
-        static bool attr_set = false;                                                                      \
-        if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN>),               \
+    int launch_step16<WN, NW>(const Step16K& g, int n_tiles, hipStream_t s) {                              \
+        const size_t lds = (size_t)g.tile_bytes + meta_bytes<WN, NW>();                                    \
+        static size_t attr_set = 0;                                                                        \
+        if (attr_set < lds) {                                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN, NW>),           \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             if (e != hipSuccess) {                                                                         \
-                set_error("hipFuncSetAttribute(k_step16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
+                set_error("hipFuncSetAttribute(k_step16<%d,%d>, %zu B LDS): %s", WN, NW, lds, hipGetErrorString(e)); \
                 return DMPNN_EHIP;                                                                         \
             }                                                                                              \
-            attr_set = true;                                                                               \
+            attr_set = lds;                                                                                \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_step16<WN>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);            \
+        hipLaunchKernelGGL((k_step16<WN, NW>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g);         \
         DMPNN_CHECK_LAUNCH("k_step16");                                                                    \
         return DMPNN_OK;                                                                                   \
     }

@@ -414,7 +414,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         level = min(level, 1)
     if route is None:
         level = min(level, int(max_level))
-    if (fused is True or route in ("fused", "mega", "fused16")) and level < (2 if route == "mega" else 1):
+    if (fused is True or route in ("fused", "mega")) and level < (2 if route == "mega" else 1):
         raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
                            "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "
                            "<= 6144 atoms and <= 12288 edges)")
@@ -423,8 +423,11 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     # forwards the whole-forward tile kernel does not take — large molecules (ZINC, 40-atom, reaction graphs), any batch
     # size; `route="fused16"` demands it
     use_fused16 = False
-    if level >= 1 and not keep and not getattr(plan, "tiles_only", False) and mf == "split16" and _lib.opt("DMPNN_FUSED16", "1") != "0":
-        if route == "fused16" or (route is None and fused is None and mfma is None and level == 1 and nE >= FUSED16_MIN_EDGES):
+    if (not keep and not undirected and route in (None, "fused16") and not getattr(plan, "tiles_only", False) and mf == "split16"
+            and _lib.opt("DMPNN_FUSED16", "1") != "0" and _lib.opt("DMPNN_GENERAL", "0") != "1" and lib.dmpnn_forward_can_fuse16(C.byref(a))):
+        # (d_h <= 320: where the fp32 fused route applies too; wider hidden layers, up to 640, only here)
+        if route == "fused16" or (fused is None and mfma is None and (level == 1 or (level == 0 and d_h > 320 and max_level >= 1))
+                                  and nE >= FUSED16_MIN_EDGES):
             use_fused16 = True
             level = 1
     if route == "fused16" and not use_fused16:

@@ -262,12 +262,14 @@ typedef struct dmpnn_fwd_args {
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 /* DMPNN_F_FUSED | DMPNN_F_SPLIT16 (without DMPNN_F_MEGA): the per-step fused route on the f16 matrix pipe — inference
- * forward of batches of ANY molecule size (d_h <= 320): one launch per depth step, the message tensor kept between the
+ * forward of batches of ANY molecule size (d_h <= 640): one launch per depth step, the message tensor kept between the
  * steps as SPLIT rows (per row: chunks of [hi 32 halfs | lo 32 halfs] + a 16-byte tail with the row's power-of-two scale;
  * x s = hi + lo exactly as in DMPNN_F_SPLIT16's contractions).  `Ms` must then hold n_mslots >= 2 slots of
  * n_edges * dmpnn_split_row_floats(d_h) floats each (instead of n_edges * ldh); H0 and Mv as usual; plan: dmpnn_prepare
  * or dmpnn_prepare_light. */
 int64_t dmpnn_split_row_floats(int64_t d_h);
+/* 1 when the shapes of `a` allow DMPNN_F_FUSED | DMPNN_F_SPLIT16 (inference, directed, d_h % 4 == 0, d_h <= 640, even d_v / d_e) */
+int dmpnn_forward_can_fuse16(const dmpnn_fwd_args* a);
 /* (3 n_edges + n_atoms) * ldh floats: H0 | H^(t) | M^(t) | Mv of the generic path, indexed by the batch's own rows */
 size_t dmpnn_forward_spill_bytes(const dmpnn_fwd_args* a);
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);

@@ -292,6 +292,31 @@ def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device):
     assert torch.equal(out, out2)          # deterministic (no atomics on the data path)
 
 
+@pytest.mark.parametrize("d_h,depth,act,bias,kind,n", [(384, 3, "relu", False, "zinc", 40), (448, 2, "tanh", True, "qm9", 80),
+                                                       (512, 4, "leakyrelu", False, "synth40", 24), (640, 3, "elu", True, "cgr", 30),
+                                                       (324, 3, "relu", False, "qm9", 60), (64, 1, "relu", False, "zinc", 30)])
+def test_per_step_fused_route_wide_hidden_layers(d_h, depth, act, bias, kind, n, gpu_device, monkeypatch):
+    """d_h beyond the 320 columns of a 4-wave workgroup (hpopt searches 300-2400, cli/hpopt.py:73): 8-wave workgroups cover
+    up to 640 columns, K1 runs on the update kernel over an operand split into rows first.  Against the oracle."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    monkeypatch.setattr(engine, "FUSED16_MIN_EDGES", 0)
+    dims = dict(d_v=106, d_e=28) if kind == "cgr" else {}
+    bmg = synth.random_batch(n, kind, seed=d_h)
+    torch.manual_seed(d_h)
+    mp = BondMessagePassing(d_h=d_h, depth=depth, activation=act, bias=bias, **dims).eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(bmg, ot.MPWeights.from_module(mp), depth=depth, activation=act).numpy()
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    with torch.no_grad():
+        for i in range(3):
+            out = mp(bmg)
+            assert mp.__dict__.get("_dmpnn_route") == "fused16", mp.__dict__.get("_dmpnn_route")
+            assert parity_err(out.cpu().numpy(), ref) <= TOL, (d_h, i)
+
+
 def _closed_tile_mask(a, src, dst, rev, n_atoms):
     """What the tile kernel checks on a tile plan, in numpy: per atom, does its tile hold exactly its own edges
     (caller ids mtile_row[t] .. mtile_row[t+1]) with both atoms and the reverse edge inside the tile?"""
