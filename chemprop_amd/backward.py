@@ -27,17 +27,35 @@ class FusedMP(torch.autograd.Function):
                                  slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True, max_level=max_level)
         ctx.st = st
         ctx.has_vd = has_vd
+        ctx.mp = mp
         return out
 
     @staticmethod
     def backward(ctx, gout):
         st = ctx.st
+        if st is None:
+            raise RuntimeError("chemprop_amd: backward through this BondMessagePassing forward a second time — the kept workspace "
+                               "is released after the first backward (run the forward again; retain_graph=True is honoured only "
+                               "with DMPNN_KEEP_WORKSPACE=1)")
         need = {k: ctx.needs_input_grad[8 + i] for i, k in enumerate(_PARAM_ORDER)}
         if not ctx.has_vd:
             need["W_d"] = need["b_d"] = False
-        grads = engine.backward(st, gout.contiguous(), need)
-        ctx.st = None  # release the kept workspace
-        return (None,) * 8 + tuple(grads[k] for k in _PARAM_ORDER)
+        # a flat gradient buffer registered on the module (distributed.GradSync): the kernels write straight into its views
+        # a flat gradient buffer registered on the module (distributed.GradSync): where a parameter's .grad IS its view of
+        # that buffer, the kernels write straight into it and autograd is told there is nothing to accumulate (None) —
+        # the step's gradient OVERWRITES the view (GradSync's contract: one backward per exchange)
+        views = ctx.mp.__dict__.get("_dmpnn_grad_views") if ctx.mp is not None else None
+        direct = {}
+        if views:
+            for k, v in views.items():
+                lin = getattr(ctx.mp, "W_" + k[2:], None)
+                prm = None if lin is None else (lin.weight if k[0] == "W" else lin.bias)
+                if prm is not None and prm.grad is not None and prm.grad.data_ptr() == v.data_ptr() and need.get(k):
+                    direct[k] = v
+        grads = engine.backward(st, gout.contiguous(), need, out=direct)
+        if engine._lib.opt("DMPNN_KEEP_WORKSPACE", "0") != "1":
+            ctx.st = None  # release the kept workspace
+        return (None,) * 8 + tuple(None if k in direct else grads[k] for k in _PARAM_ORDER)
 
 
 class _Linear(torch.autograd.Function):

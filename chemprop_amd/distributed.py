@@ -24,12 +24,13 @@ def _splitmix64(x: np.ndarray) -> np.ndarray:
 
 
 def hash_partition(n_items: int, rank: int, world: int, seed: int = 0, equalize: bool = True,
-                   weights: Optional[Sequence[float]] = None) -> np.ndarray:
+                   weights: Optional[Sequence[float]] = None, pad: bool = False) -> np.ndarray:
     """Indices of the molecules owned by ``rank``: ``hash(molecule id) mod world`` (BASELINE.json
     north_star), independent of any sampler state, identical on every rank without communication.
 
     ``equalize`` trims every shard to the smallest one so that all ranks run the same number of
-    steps (a rank with an extra batch would dead-lock the gradient all-reduce).  With ``weights``
+    steps (a rank with an extra batch would dead-lock the gradient all-reduce) — for TRAINING; it drops molecules, so
+    prediction / evaluation sharding passes ``pad=True`` (shards are padded with repeats instead) or ``equalize=False``.  With ``weights``
     (e.g. directed-edge counts) shards are instead built greedily in hash order so that the summed
     weight — the actual work — is balanced (ZINC-like size spread).
     """
@@ -51,31 +52,143 @@ def hash_partition(n_items: int, rank: int, world: int, seed: int = 0, equalize:
             buckets[r].append(int(i))
             load[r] += w[i]
         shards = [np.sort(np.asarray(b, dtype=np.int64)) for b in buckets]
-    if equalize:
+    if equalize and pad:
+        # prediction / evaluation: nothing may be dropped — short shards repeat their first molecules up to the longest
+        # (the caller discards the padded tail: the returned indices beyond the shard's own length are duplicates)
+        m = max(len(s) for s in shards)
+        shards = [np.concatenate([s, np.resize(s, m - len(s))]) if 0 < len(s) < m else s for s in shards]
+    elif equalize:
         m = min(len(s) for s in shards)
         shards = [s[:m] for s in shards]
     return shards[rank]
 
 
 def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> None:
-    """Sum (or mean) the gradients of ``params`` over all ranks with ONE flat all-reduce."""
+    """Sum (or mean) the gradients of ``params`` over all ranks with ONE flat all-reduce (the simple, sequential form:
+    :class:`GradSync` is the one a training loop keeps).  EVERY parameter that requires a gradient takes part on every rank
+    — one whose gradient is ``None`` here (an unused W_d, a rank whose shard was empty) contributes zeros — so the flat sizes
+    agree across ranks whatever each rank's batch touched."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     world = dist.get_world_size(group)
     if world == 1:
         return
-    ps = [p for p in params if p.grad is not None]
+    ps = [p for p in params if p.requires_grad]
     if not ps:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
         flat.div_(world)
     o = 0
     for p in ps:
-        n = p.grad.numel()
-        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        n = p.numel()
+        g = flat[o:o + n].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
         o += n
+
+
+class GradSync:
+    """The gradient exchange of a data-parallel training step, SURVEY 8e: ONE pre-allocated flat fp32 buffer holds every
+    gradient, ``p.grad`` of every parameter is a view into it, and the message-passing block's backward kernels
+    (``dmpnn_backward``) write their results straight into those views — no ``cat``, no copies back.  (Those kernels
+    OVERWRITE their views: one backward per exchange; gradients of other modules accumulate into theirs as usual, so call
+    ``zero_grad()`` of this class once per step.)  ``allreduce()``
+    launches ONE all-reduce of the whole buffer on a communication stream behind the work already queued on the compute
+    stream and returns at once; ``wait()`` (call it before the optimizer reads the gradients, or before the next backward
+    overwrites them) makes the compute stream wait for it — a stream dependency, not a host sync.  RCCL over xGMI is
+    latency-bound at 1.3 MB, so one bucket (DDP's 25 MB multi-bucket default is tuned for other fabrics and sizes).
+
+    Works with any process group (``gloo`` on the CPU in the tests).  Parameters whose gradient was produced elsewhere
+    (autograd of other modules assigns fresh tensors) are folded into the buffer at ``allreduce()``."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], modules: Iterable[torch.nn.Module] = (), group=None, average: bool = False):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradSync: no parameter requires a gradient")
+        self.group, self.average = group, average
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4  # (16-byte aligned views: the kernels store float4)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.work = None
+        self._done = None
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        # the engine's blocks write their gradients into the views directly (backward.FusedMP reads this attribute)
+        by_id = {id(p): v for p, v in zip(self.params, self.views)}
+        for m in modules:
+            for blk in m.modules():
+                names = {}
+                for lin, short in (("W_i", "i"), ("W_h", "h"), ("W_o", "o"), ("W_d", "d")):
+                    layer = getattr(blk, lin, None)
+                    if isinstance(layer, torch.nn.Linear):
+                        if id(layer.weight) in by_id:
+                            names["W_" + short] = by_id[id(layer.weight)]
+                        if layer.bias is not None and id(layer.bias) in by_id:
+                            names["b_" + short] = by_id[id(layer.bias)]
+                if names:
+                    blk.__dict__["_dmpnn_grad_views"] = names
+
+    def zero_grad(self) -> None:
+        """One fill of the flat buffer; every ``p.grad`` stays (or becomes again) its view.  Use this instead of
+        ``optimizer.zero_grad()`` (whose ``set_to_none`` would detach the parameters from the buffer: still correct —
+        ``allreduce`` folds stray gradients back in — but it costs the copies this class exists to avoid)."""
+        self.wait()
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def _gather(self) -> None:
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+            p.grad = v
+
+    def allreduce(self) -> None:
+        """Launch the exchange of this step's gradients (returns at once)."""
+        self.wait()
+        self._gather()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        if self.stream is None:
+            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.stream):
+            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.average:
+                self.work.wait()  # (stream-level on the communication stream)
+                self.flat.div_(dist.get_world_size(self.group))
+            self._done = torch.cuda.Event()
+            self._done.record(self.stream)
+
+    def wait(self) -> None:
+        """Order everything queued on the compute stream from here on behind the exchange (no host sync on a GPU)."""
+        if self.work is None:
+            return
+        if self.stream is None:
+            self.work.wait()
+            if self.average:
+                self.flat.div_(dist.get_world_size(self.group))
+        else:
+            if not self.average:
+                with torch.cuda.stream(self.stream):
+                    self.work.wait()
+                    self._done = torch.cuda.Event()
+                    self._done.record(self.stream)
+            torch.cuda.current_stream(self.flat.device).wait_event(self._done)
+        self.work = None
 
 
 def broadcast_params(module: torch.nn.Module, src: int = 0, group=None) -> None:
@@ -85,10 +198,16 @@ def broadcast_params(module: torch.nn.Module, src: int = 0, group=None) -> None:
     ts = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     if not ts:
         return
-    flat = torch.cat([t.reshape(-1).float() for t in ts])
-    dist.broadcast(flat, src=src, group=group)
-    o = 0
+    # floating-point tensors travel as one flat fp32 buffer; anything else (integer buffers: step counters, ...) in its own dtype
+    fl = [t for t in ts if t.is_floating_point()]
+    if fl:
+        flat = torch.cat([t.reshape(-1).float() for t in fl])
+        dist.broadcast(flat, src=src, group=group)
+        o = 0
+        for t in fl:
+            n = t.numel()
+            t.copy_(flat[o:o + n].view_as(t).to(t.dtype))
+            o += n
     for t in ts:
-        n = t.numel()
-        t.copy_(flat[o:o + n].view_as(t).to(t.dtype))
-        o += n
+        if not t.is_floating_point():
+            dist.broadcast(t, src=src, group=group)

@@ -536,8 +536,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     return out, st
 
 
-def backward(st: ForwardState, gout: Tensor, need: dict) -> dict:
-    """K6: parameter gradients of a kept forward.  ``need`` maps W_i/b_i/W_h/b_h/W_o/b_o/W_d/b_d -> bool."""
+def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = None) -> dict:
+    """K6: parameter gradients of a kept forward.  ``need`` maps W_i/b_i/W_h/b_h/W_o/b_o/W_d/b_d -> bool.
+    ``out``: optional ``{name: tensor}`` the kernels write the gradients INTO (contiguous fp32 of the parameter's shape, on
+    the device — e.g. views of one flat gradient buffer, ``distributed.GradSync``); names missing there are allocated."""
     from ._lib import BwdArgs
 
     lib = _lib.load()
@@ -548,8 +550,13 @@ def backward(st: ForwardState, gout: Tensor, need: dict) -> dict:
     shapes = dict(W_i=(h, dv + de), b_i=(h,), W_h=(h, h), b_h=(h,), W_o=(h, dv + h), b_o=(h,),
                   W_d=(h + dvd, h + dvd), b_d=(h + dvd,))
     present = dict(W_i=True, b_i=d["has_bi"], W_h=True, b_h=d["has_bh"], W_o=True, b_o=True, W_d=dvd > 0, b_d=dvd > 0)
-    grads = {k: (torch.empty(shapes[k], dtype=torch.float32, device=dev) if (need.get(k) and present[k]) else None)
-             for k in shapes}
+    def _buf(k):
+        t = out.get(k) if out else None
+        if (t is not None and t.dtype == torch.float32 and t.device == dev and tuple(t.shape) == shapes[k] and t.is_contiguous()):
+            return t
+        return torch.empty(shapes[k], dtype=torch.float32, device=dev)
+
+    grads = {k: (_buf(k) if (need.get(k) and present[k]) else None) for k in shapes}
     b = BwdArgs()
     b.f = st.args
     b.gout, b.ldgout = gout.data_ptr(), gout.stride(0)

@@ -94,3 +94,89 @@ def test_two_rank_gradient_allreduce_equals_union_batch(tmp_path):
     for k, p in ref.named_parameters():
         err = float((p.grad - r0[k]).abs().max() / max(1.0, float(p.grad.abs().max())))
         assert err <= 1e-5, (k, err)
+
+
+def _worker_sync(rank, world, port, n_mols, out_dir):
+    """The same step through GradSync (flat buffer, asynchronous exchange) and through the sequential allreduce_grads; a
+    parameter without a gradient on one rank only (frozen W_d branch unused there) must not dead-lock or shift the buffer."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    mgs = synth.random_molgraphs(n_mols, "qm9", seed=1)
+    torch.manual_seed(7)
+    mp_ = BondMessagePassing(d_h=32, d_vd=3, bias=True)
+    idx = ddp.hash_partition(n_mols, rank, world, equalize=False)
+    bmg = BatchMolGraph([mgs[i] for i in idx])
+    params = list(mp_.parameters())
+
+    def backward():
+        w = ot.MPWeights(mp_.W_i.weight, mp_.W_h.weight, mp_.W_o.weight, mp_.W_o.bias, mp_.W_i.bias, mp_.W_h.bias,
+                         mp_.W_d.weight, mp_.W_d.bias)
+        V_d = torch.ones(bmg.V.shape[0], 3) if rank == 0 else None     # rank 1 never touches W_d: its gradient stays None
+        out = ot.forward_bmg(bmg, w, depth=mp_.depth, V_d=V_d)
+        (out * (1.0 + rank)).sum().backward()
+
+    for p in params:
+        p.grad = None
+    backward()
+    ddp.allreduce_grads(params)
+    seq = [p.grad.clone() for p in params]
+    sync = ddp.GradSync(params, modules=[mp_])
+    for rep in range(2):      # twice: the views survive a step, the second exchange waits for the first
+        sync.zero_grad()
+        backward()
+        sync.allreduce()
+        sync.wait()
+        for p, v, want in zip(params, sync.views, seq):
+            assert p.grad.data_ptr() == v.data_ptr()
+            assert torch.allclose(p.grad, want, rtol=0, atol=0), rep
+    # optimizer.zero_grad(set_to_none=True) detaches the parameters; the next exchange folds the stray gradients back in
+    for p in params:
+        p.grad = None
+    backward()
+    sync.allreduce(); sync.wait()
+    for p, want in zip(params, seq):
+        assert torch.equal(p.grad, want)
+    torch.save({"ok": True}, os.path.join(out_dir, f"sync{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_equals_sequential_allreduce(tmp_path):
+    world = 2
+    mp.spawn(_worker_sync, args=(world, _free_port(), 16, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "sync0.pt").exists() and (tmp_path / "sync1.pt").exists()
+
+
+def test_hash_partition_padding_keeps_every_molecule():
+    n, world = 37, 4
+    padded = [ddp.hash_partition(n, r, world, pad=True) for r in range(world)]
+    assert len({len(s) for s in padded}) == 1
+    assert set(np.concatenate(padded).tolist()) == set(range(n))          # nothing dropped (prediction / evaluation)
+    trimmed = [ddp.hash_partition(n, r, world) for r in range(world)]
+    assert len(np.concatenate(trimmed)) <= n
+
+
+@pytest.mark.gpu
+def test_backward_writes_into_the_flat_gradient_buffer(gpu_device):
+    """GradSync on one GPU: the block's backward kernels write straight into the views of the flat buffer (p.grad IS the
+    view, autograd gets None for them), and the values equal the ordinary path's."""
+    from conftest import parity_err
+
+    bmg = synth.random_batch(64, "qm9", seed=3)
+    torch.manual_seed(1)
+    a = BondMessagePassing(d_h=128, bias=True).to(gpu_device).train()
+    b = BondMessagePassing(d_h=128, bias=True).to(gpu_device).train()
+    b.load_state_dict(a.state_dict())
+    bmg.to(gpu_device)
+    G = torch.randn(bmg.V.shape[0], 128, device=gpu_device)
+    a(bmg).backward(G)
+    sync = ddp.GradSync(list(b.parameters()), modules=[b])
+    for rep in range(2):
+        sync.flat.fill_(float("nan"))       # the kernels must overwrite every entry of their views
+        b(bmg).backward(G)
+        sync.allreduce(); sync.wait()
+        for (k, p), (_, q), v in zip(b.named_parameters(), a.named_parameters(), sync.views):
+            assert p.grad.data_ptr() == v.data_ptr(), k
+            assert parity_err(p.grad.cpu().numpy(), q.grad.cpu().numpy()) == 0.0, (k, rep)
