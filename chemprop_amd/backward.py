@@ -124,7 +124,11 @@ class _GatherSrc(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gM):
         plan = ctx.plan
-        return None, engine.aggregate(plan, engine.gather_rows(gM.contiguous(), plan.rev32))
+        gS = engine.aggregate(plan, engine.gather_rows(gM.contiguous(), plan.rev32))
+        # this transpose holds on a symmetric graph only (src(e) == dst(rev e)); the plan knows (header bit 0, on the
+        # device): an asymmetric / hand-built graph gets NaN gradients here — loud, never silently wrong — without a host sync
+        asym = (plan.buf[0] & 1).bool()
+        return None, torch.where(asym, torch.full_like(gS, float("nan")), gS)
 
 
 def gather_src_fn(plan, S: Tensor) -> Tensor:
