@@ -25,6 +25,8 @@
 //     one multiply per element in the epilogue.
 #pragma once
 
+#include <stdlib.h>
+
 #include "dmpnn_rows16_impl.hpp"
 #include "dmpnn_seg16.hpp"
 
@@ -349,7 +351,8 @@ int launch_step16(const Step16K& g, int n_tiles, hipStream_t s);
 #define DMPNN_DEFINE_STEP16(WN, NW)                                                                        \
     template <>                                                                                            \
     int launch_step16<WN, NW>(const Step16K& g, int n_tiles, hipStream_t s) {                              \
-        const size_t lds = (size_t)g.tile_bytes + meta_bytes<WN, NW>();                                    \
+        static const size_t pad_lds = [] { const char* e = getenv("DMPNN_STEP16_PAD_LDS"); return e ? (size_t)atoi(e) * 1024 : 0; }(); \
+        const size_t lds = (size_t)g.tile_bytes + meta_bytes<WN, NW>() + pad_lds;  /* (experiment: occupancy) */ \
         static size_t attr_set = 0;                                                                        \
         if (attr_set < lds) {                                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN, NW>),           \
