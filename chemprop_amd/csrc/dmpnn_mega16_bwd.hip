@@ -5,9 +5,12 @@
 
 namespace dmpnn {
 namespace mega16 {
-DMPNN_DEFINE_MEGA16_BWD(1)
-DMPNN_DEFINE_MEGA16_BWD(2)
-DMPNN_DEFINE_MEGA16_BWD(5)
+DMPNN_DEFINE_MEGA16_BWD(1, true)
+DMPNN_DEFINE_MEGA16_BWD(2, true)
+DMPNN_DEFINE_MEGA16_BWD(5, true)
+DMPNN_DEFINE_MEGA16_BWD(1, false)
+DMPNN_DEFINE_MEGA16_BWD(2, false)
+DMPNN_DEFINE_MEGA16_BWD(5, false)
 }  // namespace mega16
 
 static size_t al256b(size_t x) { return (x + 255) & ~size_t(255); }
@@ -51,9 +54,10 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     g.WoMT = mega16::SplitW{ws, inv_o, (int)nc};
     g.WhT = mega16::SplitW{ws + one, inv_h, (int)nc};
     const int n_tiles = (int)L.max_mtiles;
-    if (h <= 64) return mega16::launch_mega16_bwd<1>(g, n_tiles, s);
-    if (h <= 128) return mega16::launch_mega16_bwd<2>(g, n_tiles, s);
-    return mega16::launch_mega16_bwd<5>(g, n_tiles, s);
+    const bool sa = f.act == DMPNN_ACT_NONE || f.act == DMPNN_ACT_RELU || f.act == DMPNN_ACT_LEAKYRELU;
+    if (h <= 64) return sa ? mega16::launch_mega16_bwd<1, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<1, false>(g, n_tiles, s);
+    if (h <= 128) return sa ? mega16::launch_mega16_bwd<2, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<2, false>(g, n_tiles, s);
+    return sa ? mega16::launch_mega16_bwd<5, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<5, false>(g, n_tiles, s);
 }
 
 }  // namespace dmpnn

@@ -44,7 +44,10 @@ constexpr size_t bwd_lds_bytes() {
     return (size_t)kMegaBM * (64 * WN * 4 + 16) + (size_t)(3 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
 }
 
-template <int WN>
+// SA: identity / ReLU / LeakyReLU (mask from the sign of the output: compare + select); tanh / ELU — whose derivative code
+// would otherwise be inlined per fragment element at every call site — get their own instantiation (code size is
+// instruction-fetch latency for a kernel that runs its code once per tile).
+template <int WN, bool SA>
 __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, QN = BN / 4;
     constexpr int TS = BN * 4 + 16;
@@ -97,10 +100,15 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     }
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
     auto dact = [&](float gval, float y, bool preact) -> float {  // g * tau'(.) from the output (or the pre-activation)
-        if (g.act == DMPNN_ACT_NONE) return gval;
-        if (g.act == DMPNN_ACT_RELU) return y > 0.f ? gval : 0.f;
-        if (preact) y = apply_act(y, g.act, slope);
-        return gval * act_grad_from_out(y, g.act, slope);
+        if constexpr (SA) {
+            // identity: 1; ReLU: [y > 0]; LeakyReLU: y > 0 ? 1 : slope  (sign(tau(z)) == sign(z) for slope > 0, so the
+            // pre-activation serves as well as the output)
+            const float neg = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
+            return (g.act == DMPNN_ACT_NONE || y > 0.f) ? gval : neg * gval;
+        } else {
+            if (preact) y = apply_act(y, g.act, slope);
+            return gval * act_grad_from_out(y, g.act, slope);
+        }
     };
 
     // ---- metadata, incidence fragments ----
@@ -425,16 +433,16 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     }
 }
 
-template <int WN>
+template <int WN, bool SA>
 int launch_mega16_bwd(const Mega16BwdK& g, int n_tiles, hipStream_t s);
 
-#define DMPNN_DEFINE_MEGA16_BWD(WN)                                                                         \
+#define DMPNN_DEFINE_MEGA16_BWD(WN, SA)                                                                     \
     template <>                                                                                             \
-    int launch_mega16_bwd<WN>(const Mega16BwdK& g, int n_tiles, hipStream_t s) {                            \
+    int launch_mega16_bwd<WN, SA>(const Mega16BwdK& g, int n_tiles, hipStream_t s) {                        \
         constexpr size_t lds = bwd_lds_bytes<WN>();                                                         \
         static bool attr_set = false;                                                                       \
         if (!attr_set) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16_bwd<WN>),       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16_bwd<WN, SA>),       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             if (e != hipSuccess) {                                                                          \
                 set_error("hipFuncSetAttribute(k_mpnn_tile16_bwd<%d>): %s", WN, hipGetErrorString(e));      \
@@ -442,7 +450,7 @@ int launch_mega16_bwd(const Mega16BwdK& g, int n_tiles, hipStream_t s);
             }                                                                                               \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        hipLaunchKernelGGL((k_mpnn_tile16_bwd<WN>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);    \
+        hipLaunchKernelGGL((k_mpnn_tile16_bwd<WN, SA>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);    \
         DMPNN_CHECK_LAUNCH("k_mpnn_tile16_bwd");                                                            \
         return DMPNN_OK;                                                                                    \
     }
