@@ -44,7 +44,7 @@ static int check_graph_sizes(int64_t nV, int64_t nE) {
 }  // namespace dmpnn
 
 using namespace dmpnn;
-namespace dmpnn { extern long long* g_debug_stamps; }
+namespace dmpnn { extern thread_local long long* g_debug_stamps; }
 
 extern "C" {
 

@@ -17,7 +17,8 @@ DMPNN_DEFINE_MEGA16(5, false, true)
 DMPNN_DEFINE_MEGA16(5, false, false)
 }  // namespace mega16
 
-long long* g_debug_stamps = nullptr;
+// (per calling thread: a diagnostic hook, never shared mutable state between threads that drive the library)
+thread_local long long* g_debug_stamps = nullptr;
 
 namespace {
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }

@@ -20,7 +20,7 @@
 
 namespace dmpnn {
 
-extern long long* g_debug_stamps;
+extern thread_local long long* g_debug_stamps;
 
 namespace {
 

@@ -6,7 +6,7 @@
 #include "dmpnn_step16_impl.hpp"
 
 namespace dmpnn {
-extern long long* g_debug_stamps;
+extern thread_local long long* g_debug_stamps;
 namespace step16 {
 DMPNN_DEFINE_STEP16(1, 4)
 DMPNN_DEFINE_STEP16(2, 4)

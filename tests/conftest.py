@@ -103,6 +103,17 @@ def parity_err(got, ref):
     return float(np.max(np.abs(got - ref)) / max(1.0, float(np.max(np.abs(ref)))))
 
 
+def parity_err_unfloored(got, ref):
+    """max|got-ref| / max|ref| — the same ratio WITHOUT the floor of 1 in the denominator (round-1 VERDICT: with
+    max|ref| < 1 the floored metric is an absolute 1e-5; the at-size tests report and hold both)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if ref.size == 0:
+        return 0.0
+    m = float(np.max(np.abs(ref)))
+    return float(np.max(np.abs(got - ref)) / m) if m > 0 else float(np.max(np.abs(got - ref)))
+
+
 TOL = 1e-5  # BASELINE.json north_star: "<= 1e-5 relative fp32"
 
 

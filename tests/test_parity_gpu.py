@@ -471,7 +471,12 @@ def test_forward_full_size_vs_oracle(n_mols, kind, seed, gpu_device):
     with torch.no_grad():
         out = mp(bmg)
     err = parity_err(out.cpu().numpy(), ref.numpy())
+    from conftest import parity_err_unfloored
+
+    err_u = parity_err_unfloored(out.cpu().numpy(), ref.numpy())
+    print(f"{kind}-{n_mols}: max|out - ref| / max(1, max|ref|) = {err:.2e};  / max|ref| (un-floored) = {err_u:.2e};  max|ref| = {float(ref.abs().max()):.3g}")
     assert err <= TOL, f"{kind}-{n_mols}: {err:.3e}"
+    assert err_u <= TOL, f"{kind}-{n_mols}: un-floored {err_u:.3e}"
 
 
 @pytest.mark.parametrize("n_mols,kind", [(4096, "qm9"), (512, "cgr"), (512, "synth40")])
