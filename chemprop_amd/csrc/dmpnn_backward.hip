@@ -527,6 +527,7 @@ struct BwdLayout {
     size_t sp_gM;         // backward tile kernel: edge scratch of its generic path for oversize pieces (the atom scratch is gMv)
     bool mega;
     WgradPlan p_h, p_i, p_o, p_d;
+    WgradPlan p_hm;       // backward tile kernel: gW_h over ALL steps' rows in one launch (the gZ^(t) / M^(t) slots are adjacent)
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     BwdLayout L;
@@ -547,7 +548,11 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     L.p_o = plan_wgrad(nV, (int)h, (int)(f.d_v + h) + 1);
     L.p_d = plan_wgrad(nV, (int)(h + dvd), (int)(h + dvd) + 1);
     const int steps = f.depth > 1 ? f.depth - 1 : 1;
-    L.slab_h = o; o += align_up((size_t)L.p_h.splits * steps * L.p_h.slab_stride, 4);
+    L.p_hm = plan_wgrad(nE * steps, (int)h, (int)h + (f.b_h ? 1 : 0));
+    {
+        const size_t per_step = (size_t)L.p_h.splits * steps * L.p_h.slab_stride, merged = (size_t)L.p_hm.splits * L.p_hm.slab_stride;
+        L.slab_h = o; o += align_up(per_step > merged ? per_step : merged, 4);
+    }
     size_t x = (size_t)L.p_i.splits * L.p_i.slab_stride;
     const size_t xo = (size_t)L.p_o.splits * L.p_o.slab_stride, xd = dvd ? (size_t)L.p_d.splits * L.p_d.slab_stride : 0;
     if (xo > x) x = xo;
@@ -732,16 +737,15 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         }
         if (b->gW_h || b->gb_h) {
             if (T >= 2) {
-                int n_slabs = 0;
-                for (int t = 1; t <= T - 1; ++t) {
-                    WgradArgs a;
-                    memset(&a, 0, sizeof(a));
-                    a.M = nE; a.N = (int)h; a.K1 = (int)h; a.K2 = 0; a.ones = f.b_h ? 1 : 0;
-                    a.gZ = gZs + (int64_t)(t - 1) * slot; a.ldz = ldh; a.A1 = f.Ms + (int64_t)(t - 1) * slot; a.lda1 = ldh;
-                    DMPNN_TRY(launch_wgrad(a, L.p_h, slab_h + (int64_t)n_slabs * L.p_h.slab_stride, s));
-                    n_slabs += L.p_h.splits;
-                }
-                DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_h, n_slabs, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s, pflags, pmask));
+                // gW_h = sum_t gZ^(t)^T M^(t) = [gZ^(1); ...; gZ^(T-1)]^T [M^(1); ...; M^(T-1)]: the kept slots are adjacent
+                // (row stride ldh, slot stride n_edges * ldh), so ONE product over (T - 1) n_edges rows — one launch instead of
+                // T - 1 (each has a fixed cost of ~13 us at 9 120 rows: scripts/probe_wgrad.py)
+                WgradArgs a;
+                memset(&a, 0, sizeof(a));
+                a.M = nE * (T - 1); a.N = (int)h; a.K1 = (int)h; a.K2 = 0; a.ones = f.b_h ? 1 : 0;
+                a.gZ = gZs; a.ldz = ldh; a.A1 = f.Ms; a.lda1 = ldh;
+                DMPNN_TRY(launch_wgrad(a, L.p_hm, slab_h, s));
+                DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_hm, L.p_hm.splits, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s, pflags, pmask));
             } else {
                 zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h);
             }

@@ -281,6 +281,11 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     """``_MessagePassingBase.forward`` (base.py:196-212) for any module with the reference's
     attributes (``W_i, W_h, W_o, W_d, depth, undirected, dropout, tau, graph_transform,
     V_d_transform``); shared by :class:`BondMessagePassing` and the chemprop subclass."""
+    if torch.compiler.is_compiling() or torch.compiler.is_exporting():
+        # torch.export / torch.compile: the whole block is one opaque operator with a shape-only fake (chemprop_amd/export.py)
+        from .export import traced_forward
+
+        return traced_forward(mp, bmg, V_d)
     if V_d is None and not torch.is_grad_enabled():
         r = mp.__dict__.get("_dmpnn_replay")
         if r is not None:
