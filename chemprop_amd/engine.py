@@ -88,6 +88,10 @@ def _f32c(t: Tensor, name: str) -> Tensor:
         t = t.float()
     if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
         return t
+    if t.dim() == 2 and t.shape[0] <= 1:
+        # an empty or one-row matrix counts as contiguous whatever its strides say (a [0, d_e] tensor out of a numpy
+        # concatenation has strides (0, 0)): the C ABI wants a leading dimension >= the row length
+        return torch.empty(t.shape, dtype=t.dtype, device=t.device).copy_(t)
     return t.contiguous()
 
 
