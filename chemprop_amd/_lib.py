@@ -134,12 +134,16 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: Optional[
 
         with cf.ThreadPoolExecutor(max_workers=8) as ex:
             objs = list(ex.map(cc, sources()))
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path + ".tmp"]
+        # (linked inside the scratch directory: the link step leaves per-object unbundling temporaries next to its output)
+        linked = os.path.join(os.path.dirname(objs[0]), "libdmpnn.so")
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", linked]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+        shutil.copyfile(linked, lib_path + ".tmp")
+        os.chmod(lib_path + ".tmp", 0o755)
     os.replace(lib_path + ".tmp", lib_path)
     return lib_path
 
