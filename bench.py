@@ -11,13 +11,17 @@ The metric is BASELINE.json's: million directed-edge-updates / s = E * (depth - 
 
 For N > 1 the driver launches one process per GPU (torch.distributed.run); molecules are sharded
 across ranks (every rank owns its own batch: weak scaling) and the forward needs no collective.
+``value`` is the SAME metric at every N (the forward, so the per-N values of a scaling sweep can be
+divided by each other); the step that does hold a collective — forward + backward + ONE RCCL
+all-reduce of the flat gradient buffer — is timed on all ranks as well and reported as ``train_step``
+in the same line, at every N.
 
-Rank 0 prints ONE JSON line, with two extra objects:
-  roofline      dominant kernel (the fused per-depth update: fp32-MFMA W_h contraction with the
-                segment-sum / reverse-subtract epilogue) timed live with HIP events on the launch
-                stream: achieved = algorithmic FLOP / mean launch time
-  cpu_baseline  the oracle (same ATen op sequence as the reference) timed on the host cores,
-                bounded to ~15 s (kind "port")
+Rank 0 prints ONE JSON line, with extra objects:
+  roofline      dominant kernel (the whole-forward tile kernel on the f16 pipe) timed live with HIP
+                events on the launch stream: achieved = algorithmic FLOP / mean launch time
+  cpu_baseline  the oracle (same ATen op sequence as the reference) timed on the host cores at
+                {1, 8, 16, 32, all} threads, bounded to ~20 s (kind "port"); N = 1 only
+  train_step    forward (kept tensors) + backward (+ all-reduce at N > 1) of the same shard
 """
 from __future__ import annotations
 
@@ -44,18 +48,17 @@ def parse():
     ap.add_argument("--kind", default="qm9", choices=["qm9", "zinc", "synth40", "cgr"])
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--hidden", type=int, default=300)
-    ap.add_argument("--mode", default=None, choices=["fwd", "train"],
-                    help="default: fwd at N = 1 (BASELINE configs[1], the headline), train at N > 1 (BASELINE configs[3]: data-parallel "
-                         "shards with the RCCL gradient all-reduce inside the step; a forward needs no collective, so its scaling says nothing)")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+                    help="what `value` times.  fwd (default at EVERY N, so that the per-N values of one scaling sweep are the same "
+                         "metric — BASELINE's forward edge-updates/s; molecule shards, no data-path collective); at N > 1 the same "
+                         "line also carries `train_step`: forward + backward + the RCCL gradient all-reduce of BASELINE configs[3], "
+                         "timed on all ranks with the same barrier / max-over-ranks rule.  train: `value` is that step instead")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches only (no hipGraph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-batches", action="store_true",
                     help="skip the side measurements at 4096 / 32768 molecules (profiler runs: keeps every kernel's launches at the headline size)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    a = ap.parse_args()
-    if a.mode is None:
-        a.mode = "fwd" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "train"
-    return a
+    return ap.parse_args()
 
 
 def time_events(fn, reps, torch):
@@ -215,6 +218,39 @@ def main():
         out["eager_ms_presplit_every_step"] = round(uncached_ms, 5)
     if graph_err:
         out["graph_error"] = graph_err
+
+    # ---- the training step of the same shard: forward with kept tensors + backward into the flat gradient buffer + (N > 1) ONE
+    # RCCL all-reduce on the communication stream (chemprop_amd/distributed.py: GradSync).  On ALL ranks, same timing rule as
+    # `value` at N > 1 (barrier + synchronize on both sides, maximum over the ranks); HIP events at N = 1 ----
+    if not train:
+        try:
+            from chemprop_amd import distributed as ddp
+
+            tmp = BondMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth).to(dev).train()
+            tmp.load_state_dict(mp.state_dict())
+            tps = list(tmp.parameters())
+            tsync = ddp.GradSync(tps, modules=[tmp])
+            Gt = torch.randn(nV, tmp.output_dim, device=dev)
+
+            def tstep():
+                o = tmp(bmg)
+                tsync.wait()
+                o.backward(Gt)
+                tsync.allreduce()
+
+            run_steps(tstep, 10)
+            if world > 1:
+                t_tr = timed(tstep, args.steps) / args.steps * 1e3
+            else:
+                t_tr = time_events(tstep, 50, torch)
+            tsync.wait()
+            out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(world * updates / (t_tr * 1e-3) / 1e6, 2),
+                                 "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else None,
+                                 "note": "forward (kept tensors) + backward of the same shard, eager; weak scaling of THIS figure is the "
+                                         "data-parallel training claim (BASELINE configs[3])"}
+            del tmp, tsync
+        except Exception as e:
+            out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     if rank == 0:
         # ---- roofline of the dominant kernel, live HIP-event timing on the launch stream ----
@@ -447,30 +483,6 @@ def main():
                 out["loader_tiles"] = lt
             except Exception as e:
                 out["host_handoff"] = {"error": f"{type(e).__name__}: {e}"[:200]}
-
-        # ---- the training step of the same batch at N = 1 (what `value` means at N > 1, where the default mode is train):
-        # forward with kept tensors + backward, gradients into the flat buffer ----
-        if world == 1 and not train:
-            try:
-                from chemprop_amd import distributed as ddp
-
-                tmp = BondMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth).to(dev).train()
-                tmp.load_state_dict(mp.state_dict())
-                tps = list(tmp.parameters())
-                tsync = ddp.GradSync(tps, modules=[tmp])
-                Gt = torch.randn(nV, tmp.output_dim, device=dev)
-
-                def tstep():
-                    tmp(bmg).backward(Gt)
-                    tsync.allreduce()
-
-                run_steps(tstep, 10)
-                t_tr = time_events(tstep, 50, torch)
-                out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(updates / (t_tr * 1e-3) / 1e6, 2),
-                                     "note": "forward (kept tensors) + backward of the same batch, eager; the N > 1 default of this script"}
-                del tmp, tsync
-            except Exception as e:
-                out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
         # ---- BASELINE configs[2..4] at their own shapes (inference forward of the module, inputs resident): molecules that
         # do not fit the tiles of the whole-forward kernel take the per-step fused route on the f16 pipe ----
