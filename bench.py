@@ -506,6 +506,16 @@ def main():
                     e2 = int(b2.E.shape[0])
                     oc[name] = {"directed_edges": e2, "us": round(t2 * 1e3, 1), "M_edge_updates_per_s": round(e2 * (m2.depth - 1) / (t2 * 1e3), 1),
                                 "route": m2.__dict__.get("_dmpnn_route")}
+                    # the same forward with the OPT-IN half storage of the messages (DMPNN_F_STORE16: NOT fp32-class, ~1e-4
+                    # relative; reported beside the exact figure, never instead of it)
+                    os.environ["DMPNN_STORE"] = "f16"
+                    try:
+                        run_steps(f2, 5)
+                        t3 = time_events(f2, 20, torch)
+                        oc[name]["f16_storage_us"] = round(t3 * 1e3, 1)
+                        oc[name]["f16_storage_route"] = m2.__dict__.get("_dmpnn_route")
+                    finally:
+                        os.environ["DMPNN_STORE"] = "f32"
                     del b2, m2
                 except Exception as e:
                     oc[name] = {"error": f"{type(e).__name__}: {e}"[:200]}

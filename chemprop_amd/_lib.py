@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("DMPNN_LIB") or os.path.join(_HERE, "libdmpnn_gfx950.s
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_step16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp", "dmpnn_seg16.hpp", "dmpnn_step16_impl.hpp"]
-ABI_VERSION = 5
+ABI_VERSION = 6
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
@@ -44,6 +44,7 @@ F_KEEP = 8
 F_SPLIT16 = 16
 F_WSPLIT_READY = 32
 F_LOADER_TILES = 64
+F_STORE16 = 128
 PLAN_NOMEGA_MASK = 15  # ... | no piece tiles (a molecule larger than a tile)
 PLAN_NOFUSE_MASK = 7  # asymmetric | index out of range | in-degree > 24
 

@@ -19,6 +19,7 @@ struct SegOut {
     unsigned char* Mout; int ts;   // next message, split rows [E][ts] (or null)
     float* Sout; int lds;          // per-atom sums [V][lds] fp32 (or null)
     int N;                         // live columns (the padded row holds NQP column quads, zero-filled beyond N)
+    int half;                      // 1: half storage — rows of [hi 32 halfs] chunks only (DMPNN_F_STORE16), else [hi | lo] chunk pairs
 };
 
 // ---- segment epilogue shared by the K1 kernel (k_rows16<.., SEG>) and the update kernel -----------------------------
@@ -78,8 +79,14 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
         h4 h0, l0, h1, l1;
         split4(m0, s, h0, l0);
         split4(m1, s, h1, l1);
-        unsigned char* p = o.Mout + (long long)meta[r] * o.ts + (g8 >> 2) * 128 + (g8 & 3) * 16;
         typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+        if (o.half) {  // (uniform) half storage: the rounded hi part alone — 2 bytes per element, 11-bit significands
+            unsigned char* p = o.Mout + (long long)meta[r] * o.ts + (g8 >> 2) * 64 + (g8 & 3) * 16;
+            *reinterpret_cast<h8v*>(p) = h8v{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            if (g8 == 0) *reinterpret_cast<float4*>(o.Mout + (long long)meta[r] * o.ts + (NQP >> 3) * 64) = make_float4(s, 0.f, 0.f, 0.f);
+            continue;
+        }
+        unsigned char* p = o.Mout + (long long)meta[r] * o.ts + (g8 >> 2) * 128 + (g8 & 3) * 16;
         *reinterpret_cast<h8v*>(p) = h8v{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
         *reinterpret_cast<h8v*>(p + 64) = h8v{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         if (g8 == 0) *reinterpret_cast<float4*>(o.Mout + (long long)meta[r] * o.ts + (NQP >> 3) * 128) = make_float4(s, 0.f, 0.f, 0.f);

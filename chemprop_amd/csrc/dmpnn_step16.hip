@@ -26,6 +26,8 @@ DMPNN_DEFINE_ROWS16_X(5, 4, true)
 }  // namespace rows16
 
 int64_t split_row_floats(int64_t d_h) { return step16::split_row_bytes((int)d_h) / 4; }
+static inline bool half_store(const dmpnn_fwd_args& a) { return (a.flags & DMPNN_F_STORE16) != 0; }
+static inline int msg_row_bytes(const dmpnn_fwd_args& a) { return half_store(a) ? step16::half_row_bytes((int)a.d_h) : step16::split_row_bytes((int)a.d_h); }
 
 bool fused16_shapes_ok(const dmpnn_fwd_args& a) {
     const int64_t h = a.d_h;
@@ -58,7 +60,7 @@ static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
     g.poison_flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoFuse;
     g.vec_out = 1;
     g.tile_row = plan_i + L.tile_row; g.tile_atom = plan_i + L.tile_atom; g.row_ptr = plan_i + L.row_ptr; g.revp = plan_i + L.revp;
-    g.Mout = Mout; g.ts = step16::split_row_bytes((int)a.d_h); g.Sout = Sout; g.lds = (int)a.ldh; g.qmagic = qmagic_of(a.d_h);
+    g.Mout = Mout; g.ts = msg_row_bytes(a); g.half_out = half_store(a) ? 1 : 0; g.Sout = Sout; g.lds = (int)a.ldh; g.qmagic = qmagic_of(a.d_h);
     const int n_tiles = (int)L.max_tiles;
     switch ((int)((a.d_h + 63) / 64)) {
         case 1: return rows16::launch_rows16<1, 4, true>(g, n_tiles, 1, s);
@@ -69,25 +71,28 @@ static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
     }
 }
 
-static int launch_step(const step16::Step16K& g0, int64_t d_h, int n_tiles, hipStream_t s) {
+// hin: the operand rows (g.A, g.ts) are in half storage
+static int launch_step(const step16::Step16K& g0, int64_t d_h, int n_tiles, bool hin, hipStream_t s) {
     step16::Step16K g = g0;
     const int bn = step16::block_cols((int)d_h);
     const size_t tile_a = (size_t)step16::BM * g.ts, tile_t = (size_t)step16::BM * (bn + 4) * 4;
     g.tile_bytes = (int)(((tile_a > tile_t ? tile_a : tile_t) + 15) & ~size_t(15));
+#define DMPNN_STEP(WN, NW) (hin ? step16::launch_step16<WN, NW, true>(g, n_tiles, s) : step16::launch_step16<WN, NW, false>(g, n_tiles, s))
     if (d_h <= 320) {
         switch (bn / 64) {
-            case 1: return step16::launch_step16<1, 4>(g, n_tiles, s);
-            case 2: return step16::launch_step16<2, 4>(g, n_tiles, s);
-            case 3: return step16::launch_step16<3, 4>(g, n_tiles, s);
-            case 4: return step16::launch_step16<4, 4>(g, n_tiles, s);
-            default: return step16::launch_step16<5, 4>(g, n_tiles, s);
+            case 1: return DMPNN_STEP(1, 4);
+            case 2: return DMPNN_STEP(2, 4);
+            case 3: return DMPNN_STEP(3, 4);
+            case 4: return DMPNN_STEP(4, 4);
+            default: return DMPNN_STEP(5, 4);
         }
     }
     switch (bn / 128) {
-        case 3: return step16::launch_step16<3, 8>(g, n_tiles, s);
-        case 4: return step16::launch_step16<4, 8>(g, n_tiles, s);
-        default: return step16::launch_step16<5, 8>(g, n_tiles, s);
+        case 3: return DMPNN_STEP(3, 8);
+        case 4: return DMPNN_STEP(4, 8);
+        default: return DMPNN_STEP(5, 8);
     }
+#undef DMPNN_STEP
 }
 
 static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
@@ -107,11 +112,11 @@ static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
 static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const unsigned char* Min, unsigned char* Mout,
                          float* Sout, hipStream_t s) {
     step16::Step16K g = step_args(a, L);
-    g.A = Min; g.ts = step16::split_row_bytes((int)a.d_h);
+    g.A = Min; g.ts = msg_row_bytes(a);
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
     g.bias = a.b_h; g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
-    g.Mout = Mout; g.Sout = Sout;
-    return launch_step(g, a.d_h, (int)L.max_tiles, s);
+    g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
+    return launch_step(g, a.d_h, (int)L.max_tiles, half_store(a), s);
 }
 
 // K1 on the update kernel (d_h > 320): the gathered fp32 operand is split into rows first (scratch: the second message slot)
@@ -130,8 +135,8 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
     g.A = scratch; g.ts = k.ts;
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
     g.bias = a.b_i; g.Zpre = a.H0; g.ldz = (int)a.ldh;
-    g.Mout = Mout; g.Sout = Sout;
-    return launch_step(g, a.d_h, (int)L.max_tiles, s);
+    g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
+    return launch_step(g, a.d_h, (int)L.max_tiles, false, s);  // (the K1 operand [V || E] is always split exactly)
 }
 
 // a.Ms: two slots of n_edges split rows (split_row_floats(d_h) floats each); a.H0 [n_edges, ldh]; a.Mv [n_atoms, ldh];
@@ -140,6 +145,7 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
     const int64_t nV = a.n_atoms, nE = a.n_edges, h = a.d_h;
     const PlanLayout L = plan_layout(nV, nE);
     const int T = a.depth;
+    // (a slot is n_edges message rows; the first always spans split_row_bytes per edge — the K1 operand scratch of wide layers lives in the second)
     const size_t slot_bytes = (size_t)nE * step16::split_row_bytes((int)h);
     unsigned char* Ms = reinterpret_cast<unsigned char*>(a.Ms);
     if (nE == 0 && nV > 0) {

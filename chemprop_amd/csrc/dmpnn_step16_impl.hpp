@@ -50,6 +50,8 @@ static_assert(BM == 16 * RT, "48-row tiles");
 __host__ __device__ constexpr int block_cols(int d_h) { return d_h <= 320 ? ((d_h + 63) / 64) * 64 : ((d_h + 127) / 128) * 128; }
 // bytes of one row of a split edge tensor of d_h columns (the A-tile row of the kernels: whole chunk pairs + 16 B tail)
 __host__ __device__ constexpr int split_row_bytes(int d_h) { return block_cols(d_h) * 4 + 16; }
+// ... in half storage (DMPNN_F_STORE16): the hi halfs alone, 2 bytes per element + the 16-byte tail
+__host__ __device__ constexpr int half_row_bytes(int d_h) { return block_cols(d_h) * 2 + 16; }
 // ... of a split operand of K columns that is only ever READ as an operand (the gathered K1 input): whole 32-column chunks
 __host__ __device__ constexpr int split_operand_bytes(int K) { return ((K + 31) / 32) * 128 + 16; }
 
@@ -64,6 +66,7 @@ struct Step16K {
     int act; float slope; const float* slope_ptr;
     const int* poison_flags; int poison_mask;
     unsigned qmagic;
+    int half_out;                         // Mout in half storage (DMPNN_F_STORE16); the operand's own format is the template parameter HIN
     int tile_bytes;                       // bytes of the LDS region shared by the operand tile and the fp32 epilogue tile
     long long* dbg;                       // optional [16] cycle stamps of one workgroup (dmpnn_debug_timestamps), else null
 };
@@ -71,7 +74,8 @@ struct Step16K {
 template <int WN, int NW>
 __host__ __device__ constexpr size_t meta_bytes() { return (size_t)(BM + kAtomCache + 1) * sizeof(int) + 64; }
 
-template <int WN, int NW>
+// HIN: the operand rows are in half storage ([hi 32 halfs] chunks; two MFMA passes a_hi (b_hi + b_lo) instead of three)
+template <int WN, int NW, bool HIN>
 __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     constexpr int NT = 64 * NW;
     constexpr int BN = 16 * WN * NW, LDC = BN + 4, TSO = BN * 4 + 16;
@@ -193,9 +197,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         const int cc = c < n_chunks ? c : n_chunks - 1;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const unsigned char* p = Ag + (rt * 16 + li) * TS + cc * 128 + lg * 16;
-            xh[rt] = *reinterpret_cast<const h8*>(p);
-            xl[rt] = *reinterpret_cast<const h8*>(p + 64);
+            if constexpr (HIN) {
+                xh[rt] = *reinterpret_cast<const h8*>(Ag + (rt * 16 + li) * TS + cc * 64 + lg * 16);
+            } else {
+                const unsigned char* p = Ag + (rt * 16 + li) * TS + cc * 128 + lg * 16;
+                xh[rt] = *reinterpret_cast<const h8*>(p);
+                xl[rt] = *reinterpret_cast<const h8*>(p + 64);
+            }
         }
     };
     auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
@@ -209,10 +217,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
+        if constexpr (!HIN) {
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         load_bfrags(c + 2, yh, yl);
     };
@@ -285,8 +295,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         return scale_for(mxv);
     };
     SegOut o;
-    o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = TSO; o.Sout = g.Sout; o.lds = g.lds;
-    o.N = g.N;
+    o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.half_out ? BN * 2 + 16 : TSO; o.Sout = g.Sout; o.lds = g.lds;
+    o.N = g.N; o.half = g.half_out;
     seg_epilogue<LDC, BN / 4, NT>(o, T, meta, rs, nrows, va, vb, seg_rp, poison, g.qmagic, tile_scale);
     stamp();  // 8 (7 without a message) end
 }
@@ -345,17 +355,17 @@ __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
     }
 }
 
-template <int WN, int NW>
+template <int WN, int NW, bool HIN>
 int launch_step16(const Step16K& g, int n_tiles, hipStream_t s);
 
-#define DMPNN_DEFINE_STEP16(WN, NW)                                                                        \
+#define DMPNN_DEFINE_STEP16_H(WN, NW, HIN)                                                                 \
     template <>                                                                                            \
-    int launch_step16<WN, NW>(const Step16K& g, int n_tiles, hipStream_t s) {                              \
+    int launch_step16<WN, NW, HIN>(const Step16K& g, int n_tiles, hipStream_t s) {                         \
         static const size_t pad_lds = [] { const char* e = getenv("DMPNN_STEP16_PAD_LDS"); return e ? (size_t)atoi(e) * 1024 : 0; }(); \
         const size_t lds = (size_t)g.tile_bytes + meta_bytes<WN, NW>() + pad_lds;  /* (experiment: occupancy) */ \
         static size_t attr_set = 0;                                                                        \
         if (attr_set < lds) {                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN, NW>),           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN, NW, HIN>),      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_step16<%d,%d>, %zu B LDS): %s", WN, NW, lds, hipGetErrorString(e)); \
@@ -363,10 +373,11 @@ int launch_step16(const Step16K& g, int n_tiles, hipStream_t s);
             }                                                                                              \
             attr_set = lds;                                                                                \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_step16<WN, NW>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g);         \
+        hipLaunchKernelGGL((k_step16<WN, NW, HIN>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g);    \
         DMPNN_CHECK_LAUNCH("k_step16");                                                                    \
         return DMPNN_OK;                                                                                   \
     }
+#define DMPNN_DEFINE_STEP16(WN, NW) DMPNN_DEFINE_STEP16_H(WN, NW, false) DMPNN_DEFINE_STEP16_H(WN, NW, true)
 
 }  // namespace step16
 }  // namespace dmpnn

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT, F_FUSED, F_KEEP, F_LOADER_TILES, F_MEGA, F_SPLIT16, F_UNDIRECTED, F_WSPLIT_READY, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
+from ._lib import ACT, F_FUSED, F_KEEP, F_LOADER_TILES, F_MEGA, F_SPLIT16, F_STORE16, F_UNDIRECTED, F_WSPLIT_READY, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
 
 
 # From this many directed edges on, the per-step route runs its contractions on the f16 pipe (exact operand split) and is
@@ -233,6 +233,14 @@ def act_code(name: str) -> int:
 # ------------------------------------------------------------------------------------------------
 # row kernels (used by per-row parity tests, by the custom-activation / dropout path, and by bench)
 # ------------------------------------------------------------------------------------------------
+def storage_f16() -> bool:
+    """``DMPNN_STORE=f16``: the per-step fused route keeps the message tensor between the depth steps as one f16 per element
+    with a power-of-two row scale (2 bytes instead of the exact 4-byte hi + lo pair) — an opt-in storage mode in the spirit of
+    BASELINE configs[1]'s "bf16" (11-bit significands instead of bf16's 8).  NOT fp32-class: ~1e-4 relative on the output
+    (tests hold 2e-3); everything else — H0, weights, accumulation, the output, every other route — is unchanged."""
+    return _lib.opt("DMPNN_STORE", "f32") == "f16"
+
+
 def message(plan: GraphPlan, H: Tensor, act_on_load: str = "none", slope: float = 0.0,
             slope_t: Optional[Tensor] = None, undirected: bool = False, out: Optional[Tensor] = None) -> Tensor:
     H = _f32c(H, "H")
@@ -528,6 +536,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
                 wcache["key"], wcache["buf"] = key, wsplit
         a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
         st.route = "mega16" if use_mega else ("fused16" if use_fused16 else "general16")
+        if use_fused16 and storage_f16():
+            # OPT-IN half storage of the message tensor between the steps (DMPNN_F_STORE16): not fp32-class, see include/dmpnn.h
+            a.flags |= F_STORE16
+            st.route = "fused16/f16-storage"
     elif use_mega:
         a.flags |= F_MEGA
     if keep:

@@ -132,7 +132,7 @@ class BondMessagePassing(EngineStateMixin, nn.Module):
         return bond_message_passing_forward(self, bmg, V_d)
 
 
-_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_TILE_PLAN", "DMPNN_VALIDATE")
+_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_TILE_PLAN", "DMPNN_VALIDATE", "DMPNN_STORE")
 
 
 class _Replay:

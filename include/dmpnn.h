@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 5
+#define DMPNN_ABI_VERSION 6
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -71,9 +71,17 @@ enum dmpnn_flags {
                                      dmpnn_forward wrote for exactly these W_i / W_h / W_o values and shapes
                                      (the CALLER vouches for it, e.g. inference with frozen weights): the
                                      pre-split launch is skipped                                          */
-    DMPNN_F_LOADER_TILES = 1u << 6 /* `plan` is a tile plan of a batch of ANY size (dmpnn_prepare_tiles_from_table, or
+    DMPNN_F_LOADER_TILES = 1u << 6, /* `plan` is a tile plan of a batch of ANY size (dmpnn_prepare_tiles_from_table, or
                                      dmpnn_prepare_tiles with a batch vector where dmpnn_tile_plan_any_size()):
                                      DMPNN_F_MEGA is not limited to batches the single-workgroup plan takes     */
+    DMPNN_F_STORE16 = 1u << 7     /* OPT-IN, NOT fp32-class.  With DMPNN_F_FUSED | DMPNN_F_SPLIT16 (the per-step fused route):
+                                     the message tensor between the depth steps is stored as ONE f16 per element with a
+                                     power-of-two row scale (2 bytes instead of the exact hi + lo pair of 4) and contracted
+                                     in two MFMA passes a_hi (w_hi + w_lo) instead of three.  Every message element is
+                                     rounded to an 11-bit significand once per step (bf16, which BASELINE configs[1] names,
+                                     has 8): outputs differ from the fp32 reference by ~1e-4 relative, the tests hold
+                                     2e-3.  H0, the weights, every accumulation and the output stay fp32 / exact-split.
+                                     Same workspace layout as without the flag (the slots are simply not filled)        */
 };
 
 /* ---------------------------------------------------------------------------------------------

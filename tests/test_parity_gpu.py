@@ -292,6 +292,63 @@ def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device):
     assert torch.equal(out, out2)          # deterministic (no atomics on the data path)
 
 
+HALF_TOL = 2e-3  # DMPNN_F_STORE16: one rounding of every message element to an 11-bit significand per depth step (stated in include/dmpnn.h)
+
+
+def test_half_storage_of_the_messages_golden(golden, gpu_device, monkeypatch):
+    """OPT-IN half storage (``DMPNN_STORE=f16`` -> ``DMPNN_F_STORE16``): the per-step fused route keeps the message tensor
+    between the steps as one f16 per element + a power-of-two row scale.  Not fp32-class — held to its own stated bar
+    (2e-3, norm-wise) on every golden the fused routes take, and it must NOT be what runs by default."""
+    cfg = golden.cfg
+    if cfg.get("undirected") or cfg["d_h"] % 4 or cfg["d_h"] > 320 or golden["V"].shape[1] % 2 or golden["E"].shape[1] % 2:
+        pytest.skip("fused routes do not apply")
+    if str(cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
+        pytest.skip("custom activation: rows route")
+    plan, out_exact, st = _engine_forward(golden, gpu_device, route="fused16")
+    assert st.route == "fused16"                      # (the default storage: exact hi + lo pairs)
+    if not plan.fusable():
+        pytest.skip("not a molecular graph")
+    monkeypatch.setenv("DMPNN_STORE", "f16")
+    _, out, st_h = _engine_forward(golden, gpu_device, route="fused16")
+    assert st_h.route == "fused16/f16-storage"
+    err = parity_err(out.cpu().numpy(), golden["out"])
+    assert err <= HALF_TOL, f"{golden.name}: {err:.3e}"
+    if cfg["depth"] > 1 and plan.n_edges:
+        assert not torch.equal(out, out_exact)        # the flag did change the arithmetic
+    _, out2, _ = _engine_forward(golden, gpu_device, route="fused16")
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("kind,n_mols,kw", [("synth40", 512, dict()), ("zinc", 512, dict(d_h=512, depth=6)), ("cgr", 256, dict(d_v=106, d_e=28)),
+                                            ("qm9", 4096, dict(activation="tanh", bias=True))])
+def test_half_storage_at_size(kind, n_mols, kw, gpu_device, monkeypatch):
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    torch.manual_seed(12)
+    mp = BondMessagePassing(**kw).eval()
+    b = synth.random_batch(n_mols, kind, seed=21)
+    with torch.no_grad():
+        ref = ot.forward_bmg(b, ot.MPWeights.from_module(mp), depth=mp.depth, activation=kw.get("activation", "relu"))
+    mp = mp.to(gpu_device)
+    b.to(gpu_device)
+    monkeypatch.setenv("DMPNN_STORE", "f16")
+    monkeypatch.setenv("DMPNN_MEGA", "0")             # (QM9-sized molecules would take the whole-forward tile kernel, which has no messages in memory)
+    with torch.no_grad():
+        for _ in range(3):                            # past the validated first batches
+            out = mp(b)
+    assert mp.__dict__.get("_dmpnn_route") == "fused16/f16-storage", mp.__dict__.get("_dmpnn_route")
+    err = parity_err(out.cpu().numpy(), ref.numpy())
+    print(f"half storage {kind}-{n_mols}: {err:.2e}")
+    assert err <= HALF_TOL, f"{kind}-{n_mols}: {err:.3e}"
+    monkeypatch.setenv("DMPNN_STORE", "f32")
+    with torch.no_grad():
+        out_exact = mp(b)
+    assert parity_err(out_exact.cpu().numpy(), ref.numpy()) <= TOL
+    assert mp.__dict__.get("_dmpnn_route") == "fused16"
+
+
 @pytest.mark.parametrize("d_h,depth,act,bias,kind,n", [(384, 3, "relu", False, "zinc", 40), (448, 2, "tanh", True, "qm9", 80),
                                                        (512, 4, "leakyrelu", False, "synth40", 24), (640, 3, "elu", True, "cgr", 30),
                                                        (324, 3, "relu", False, "qm9", 60), (64, 1, "relu", False, "zinc", 30)])
