@@ -48,6 +48,16 @@ timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OU
 timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $OUT/pmc_sq -o p -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-large-batches > $OUT/pmc_sq.log 2>&1
 cd $REPO
 python scripts/pmc_traffic.py $OUT | tee -a $OUT/summary.txt
+echo "== 32 768 molecules (working set beyond the Infinity Cache): rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE passes of scripts/prof_large.py" | tee -a $OUT/summary.txt
+mkdir -p $OUT/large
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/large/prof -o large -- python $REPO/scripts/prof_large.py > $OUT/large/prof_large.json 2> $OUT/large/prof.err
+cat $OUT/large/prof_large.json | tee -a $OUT/summary.txt
+for f in $(find $OUT/large/prof -name "*kernel_stats.csv"); do head -8 $f | cut -c1-200 | tee -a $OUT/summary.txt; done
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/large/pmc_fetch -o p -- python $REPO/scripts/prof_large.py > $OUT/large/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/large/pmc_write -o p -- python $REPO/scripts/prof_large.py > $OUT/large/pmc_write.log 2>&1
+cd $REPO
+python scripts/pmc_traffic.py $OUT/large | tee -a $OUT/summary.txt
 fi
 # keep the merge small
 find $OUT -name "*.db" -size +20M -delete; find $OUT -name "*trace.csv" -size +30M -delete
