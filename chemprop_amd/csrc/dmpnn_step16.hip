@@ -75,9 +75,12 @@ static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
 static int launch_step(const step16::Step16K& g0, int64_t d_h, int n_tiles, bool hin, hipStream_t s) {
     step16::Step16K g = g0;
     const int bn = step16::block_cols((int)d_h);
-    const size_t tile_a = (size_t)step16::BM * g.ts, tile_t = (size_t)step16::BM * (bn + 4) * 4;
+    if (!g.A2) g.ts2 = 0;
+    const size_t tile_a = g.A ? (size_t)step16::BM * g.ts : 0, tile_t = (size_t)step16::BM * (bn + 4) * 4;
     g.tile_bytes = (int)(((tile_a > tile_t ? tile_a : tile_t) + 15) & ~size_t(15));
-#define DMPNN_STEP(WN, NW) (hin ? step16::launch_step16<WN, NW, true>(g, n_tiles, s) : step16::launch_step16<WN, NW, false>(g, n_tiles, s))
+    const bool xp = g.A2 != nullptr;
+#define DMPNN_STEP(WN, NW) (xp ? (hin ? step16::launch_step16<WN, NW, true, true>(g, n_tiles, s) : step16::launch_step16<WN, NW, false, true>(g, n_tiles, s)) \
+                               : (hin ? step16::launch_step16<WN, NW, true, false>(g, n_tiles, s) : step16::launch_step16<WN, NW, false, false>(g, n_tiles, s)))
     if (d_h <= 320) {
         switch (bn / 64) {
             case 1: return DMPNN_STEP(1, 4);
@@ -109,19 +112,40 @@ static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
     return g;
 }
 
-static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const unsigned char* Min, unsigned char* Mout,
-                         float* Sout, hipStream_t s) {
+// `xrows` (or null): the K1 operand [V[src] || E] of every row, exactly split (k_split_rows) — the residual H0 = W_i x + b_i is
+// then recomputed inside the step instead of read back (x_path_ok)
+static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const SplitWView* Wi, const unsigned char* xrows,
+                         const unsigned char* Min, unsigned char* Mout, float* Sout, hipStream_t s) {
     step16::Step16K g = step_args(a, L);
     g.A = Min; g.ts = msg_row_bytes(a);
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
-    g.bias = a.b_h; g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
+    g.bias = a.b_h;
+    if (xrows) {
+        g.A2 = xrows; g.ts2 = step16::split_operand_bytes((int)(a.d_v + a.d_e));
+        g.W2.p = Wi->p; g.W2.inv_scale = Wi->inv_scale; g.W2.nc = Wi->nc; g.bias2 = a.b_i;
+    } else {
+        g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
+    }
     g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
     return launch_step(g, a.d_h, (int)L.max_tiles, half_store(a), s);
 }
 
-// K1 on the update kernel (d_h > 320): the gathered fp32 operand is split into rows first (scratch: the second message slot)
-static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* scratch, unsigned char* Mout,
-                           float* Sout, hipStream_t s) {
+// The step kernel with the K1 operand as a second operand held in registers: its rows must fit the H0 buffer they are kept
+// in (which holds no H0 then) and their chunks the lane's fragment registers.  DMPNN_XPATH=0: off (H0 written and read back).
+// Measured (MI355X, same box): 40-atom x 4096 molecules 1 743 -> 1 669 us, CGR-512 305 -> 299, 40-atom x 512 345 -> 326; ZINC-512
+// h 512 depth 6 (the 8-wave workgroups) 616 -> 649 — so it is the default for d_h <= 320 only (DMPNN_XPATH=1 forces it).
+static bool x_path_ok(const dmpnn_fwd_args& a) {
+    const char* e = getenv("DMPNN_XPATH");
+    if ((e && e[0] == '0') || a.depth < 2) return false;
+    if (a.d_h > 320 && !(e && e[0] == '1')) return false;
+    const int ts2 = step16::split_operand_bytes((int)(a.d_v + a.d_e));
+    return (int64_t)ts2 <= a.ldh * 4 && (a.d_v + a.d_e + 31) / 32 <= step16::kXChunks;
+}
+
+// K1 on the update kernel (d_h > 320, and the x path): the gathered fp32 operand is split into rows first (`scratch`: the second
+// message slot, or — x path, keep_h0 false — the H0 buffer, where the rows stay for the depth steps and no H0 is written)
+static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* scratch, bool keep_h0,
+                           unsigned char* Mout, float* Sout, hipStream_t s) {
     const int* plan_i = static_cast<const int*>(a.plan);
     step16::SplitRowsK k;
     memset(&k, 0, sizeof(k));
@@ -134,7 +158,8 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
     step16::Step16K g = step_args(a, L);
     g.A = scratch; g.ts = k.ts;
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
-    g.bias = a.b_i; g.Zpre = a.H0; g.ldz = (int)a.ldh;
+    g.bias = a.b_i;
+    if (keep_h0) { g.Zpre = a.H0; g.ldz = (int)a.ldh; }
     g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
     return launch_step(g, a.d_h, (int)L.max_tiles, false, s);  // (the K1 operand [V || E] is always split exactly)
 }
@@ -154,11 +179,14 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
     }
     if (nE > 0) {
         static const bool k1_split_all = [] { const char* e = getenv("DMPNN_K1_SPLIT"); return e && e[0] == '1'; }();
-        if (h > 320 || k1_split_all) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
+        const bool xpath = x_path_ok(a);
+        unsigned char* xrows = xpath ? reinterpret_cast<unsigned char*>(a.H0) : nullptr;
+        if (xpath) DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
+        else if (h > 320 || k1_split_all) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, true, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
         else DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
         for (int t = 1; t < T; ++t) {
             const bool last = t == T - 1;
-            DMPNN_TRY(launch_update(a, L, w16[1], Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : Ms + (t % 2) * slot_bytes,
+            DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], xrows, Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : Ms + (t % 2) * slot_bytes,
                                     last ? a.Mv : nullptr, s));
         }
     }

@@ -45,6 +45,7 @@ using mega16::SplitW;
 
 constexpr int RT = 3;
 static_assert(BM == 16 * RT, "48-row tiles");
+constexpr int kXChunks = 8;  // most chunks (of 32 columns) of the second operand: d_v + d_e <= 256
 
 // output columns a workgroup covers for d_h: 4 waves x 16 WN (d_h <= 320) or 8 waves x 16 WN (d_h <= 640)
 __host__ __device__ constexpr int block_cols(int d_h) { return d_h <= 320 ? ((d_h + 63) / 64) * 64 : ((d_h + 127) / 128) * 128; }
@@ -61,6 +62,13 @@ struct Step16K {
     const unsigned char* A; int ts;       // split operand rows [M][ts]: W.nc chunks (+ padding) + the 16-byte tail at ts - 16
     SplitW W; const float* bias;
     const float* Cadd; int ldcadd;        // residual H0 [M][ldcadd] fp32 (or null)
+    // second operand (or null): the K1 operand [V[src] || E] of the same rows, exactly split once per forward (k_split_rows):
+    // z = W2 x (+ bias2) + W A (+ bias) — the residual H0 = W_i x + b_i is RECOMPUTED per step from 400-byte rows instead of
+    // being written once and read back every step as 1 200-byte fp32 rows through 60 scattered 4-byte loads per lane
+    // The x tile does not go through LDS (62 KB operand tile + 19 KB would push two workgroups past the CU's 160 KB): every
+    // lane fetches its own A fragments of the <= kXChunks chunks straight from the rows at kernel entry (16-byte loads).
+    const unsigned char* A2; int ts2;     // rows [M][ts2]
+    SplitW W2; const float* bias2;
     float* Zpre; int ldz;                 // pre-activation rows [M][ldz] fp32 to store (K1: H0), or null
     unsigned char* Mout; float* Sout; int lds;
     int act; float slope; const float* slope_ptr;
@@ -75,7 +83,9 @@ template <int WN, int NW>
 __host__ __device__ constexpr size_t meta_bytes() { return (size_t)(BM + kAtomCache + 1) * sizeof(int) + 64; }
 
 // HIN: the operand rows are in half storage ([hi 32 halfs] chunks; two MFMA passes a_hi (b_hi + b_lo) instead of three)
-template <int WN, int NW, bool HIN>
+// XP:  the second operand x is there (g.A2) and the fp32 residual is not (g.Cadd): separate instantiations, so that neither
+//      path carries the other's registers (the kernel sits at the 256-register limit of two workgroups per CU)
+template <int WN, int NW, bool HIN, bool XP>
 __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     constexpr int NT = 64 * NW;
     constexpr int BN = 16 * WN * NW, LDC = BN + 4, TSO = BN * 4 + 16;
@@ -109,7 +119,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     const int TS = g.ts;
 
     // ---- everything the tile needs is requested now: operand rows by LDS-DMA, residual into the accumulators ----
-    {
+    const int TS2 = g.ts2;
+    if (g.A) {
         const unsigned nbytes = (unsigned)(nrows * TS);
         const rsrc_t rA = gemm::make_rsrc(g.A + (long long)rs * TS, nbytes);
         const int n_inst = (int)((nbytes + 1023u) >> 10);
@@ -117,10 +128,29 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(Ag + i * 1024), 16,
                                                      (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
     }
+    // second operand: this lane's A fragments (row rt * 16 + li, 8 reduction columns from lg * 8 of a chunk) of chunks 0 and 1,
+    // and the rows' scales; chunk c + 2 is fetched into the registers of chunk c behind its MFMAs
+    h8 xh[2][RT], xl[2][RT];
+    float s2 = 1.f;  // (k_split_rows scales a whole tile at once: every row's tail holds the same value)
+    const rsrc_t rX = gemm::make_rsrc(XP ? g.A2 + (long long)rs * TS2 : g.A, XP ? (unsigned)(nrows * TS2) : 0u);
+    auto load_xfrags = [&](int c, h8 (&h)[RT], h8 (&l)[RT]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = rt * 16 + li;
+            const unsigned off = (c < g.W2.nc && row < nrows) ? (unsigned)(row * TS2 + c * 128 + lg * 16) : kOOB;
+            h[rt] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rX, off, 0, 0));
+            l[rt] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rX, off == kOOB ? kOOB : off + 64u, 0, 0));
+        }
+    };
+    if constexpr (XP) {
+        load_xfrags(0, xh[0], xl[0]);
+        load_xfrags(1, xh[1], xl[1]);
+        const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, nrows > 0 ? (unsigned)(TS2 - 16) : kOOB, 0, 0));
+        s2 = (v2 > 0.f && v2 < 3.0e38f) ? v2 : 1.f;
+    }
     f32x4 acc[RT][WN];
-    {
-        const rsrc_t rC = gemm::make_rsrc(g.Cadd ? g.Cadd + (long long)rs * g.ldcadd : reinterpret_cast<const float*>(g.A),
-                                          (g.Cadd && nrows > 0) ? (unsigned)(((nrows - 1) * g.ldcadd + g.N) * 4) : 0u);
+    if (!XP && g.Cadd) {
+        const rsrc_t rC = gemm::make_rsrc(g.Cadd + (long long)rs * g.ldcadd, nrows > 0 ? (unsigned)(((nrows - 1) * g.ldcadd + g.N) * 4) : 0u);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -131,6 +161,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
                     const unsigned off = (row < nrows && col < g.N) ? (unsigned)(row * g.ldcadd + col) * 4u : kOOB;
                     acc[rt][ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, off, 0, 0));
                 }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // segment metadata (consumed by the epilogue)
     const int na0 = vb - va < kAtomCache ? vb - va : kAtomCache;
@@ -141,98 +176,144 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
 
     // ---- weight fragments: [column tile][chunk][hi|lo][lane][16 B], straight from L2 ----
     const int NTL = (g.N + 15) / 16;
-    const rsrc_t rW = gemm::make_rsrc(g.W.p, (unsigned)(NTL * g.W.nc * 2048));
-    unsigned offB[WN];
+    const rsrc_t rW = gemm::make_rsrc(g.W.p, g.A ? (unsigned)(NTL * g.W.nc * 2048) : 0u);
+    const rsrc_t rW2 = gemm::make_rsrc(XP ? g.W2.p : g.W.p, XP ? (unsigned)(NTL * g.W2.nc * 2048) : 0u);
+    unsigned offB[WN], offB2[WN];
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
         const int tile = wave * WN + ct;
         offB[ct] = tile < NTL ? (unsigned)tile * (unsigned)(g.W.nc * 2048) + (unsigned)lane * 16u : kOOB;
+        offB2[ct] = (tile < NTL && XP) ? (unsigned)tile * (unsigned)(g.W2.nc * 2048) + (unsigned)lane * 16u : kOOB;
     }
-    auto load_bfrags = [&](int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
+    auto load_bfrags = [&](const rsrc_t& rw, const unsigned (&off)[WN], int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) {
-            const unsigned o = offB[ct] == kOOB ? kOOB : offB[ct] + (unsigned)c * 2048u;
-            bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
-            bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o == kOOB ? kOOB : o + 1024u, 0, 0));
+            const unsigned o = off[ct] == kOOB ? kOOB : off[ct] + (unsigned)c * 2048u;
+            bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rw, o, 0, 0));
+            bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rw, o == kOOB ? kOOB : o + 1024u, 0, 0));
         }
     };
     h8 ah[2][RT], al[2][RT], bh[2][WN], bl[2][WN];
-    load_bfrags(0, bh[0], bl[0]);
-    load_bfrags(1, bh[1], bl[1]);
-    float isw[WN], bv[WN];
+    // (the first contraction's first two weight chunks: in flight under the DMA)
+    if (XP) { load_bfrags(rW2, offB2, 0, bh[0], bl[0]); load_bfrags(rW2, offB2, 1, bh[1], bl[1]); }
+    else { load_bfrags(rW, offB, 0, bh[0], bl[0]); load_bfrags(rW, offB, 1, bh[1], bl[1]); }
+    float isw[WN], isw2[WN], bv[WN];
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
         const int col = wave * (16 * WN) + ct * 16 + li;
         const bool okc = col < g.N;
-        isw[ct] = g.W.inv_scale[okc ? col : 0];
-        bv[ct] = (okc && g.bias) ? g.bias[col] : 0.f;
+        isw[ct] = g.A ? g.W.inv_scale[okc ? col : 0] : 1.f;
+        isw2[ct] = XP ? g.W2.inv_scale[okc ? col : 0] : 1.f;
+        bv[ct] = ((okc && g.bias) ? g.bias[col] : 0.f) + ((okc && g.bias2) ? g.bias2[col] : 0.f);
+    }
+    if constexpr (XP) {
+        // z = W2 x first, in the scale s_r2 s_W2 of its own rows and columns (no LDS involved: runs while the DMA of the main operand is still landing;
+        // weight chunks 0 and 1 were requested with them, chunk c + 2 goes out behind chunk c) ...
+        auto xstep = [&](int c, h8 (&h)[RT], h8 (&l)[RT], h8 (&yh)[WN], h8 (&yl)[WN]) {
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[rt], yl[ct], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < g.W2.nc) { load_xfrags(c + 2, h, l); load_bfrags(rW2, offB2, c + 2, yh, yl); }
+        };
+#pragma nounroll
+        for (int c = 0; c < g.W2.nc; c += 2) {
+            xstep(c, xh[0], xl[0], bh[0], bl[0]);
+            if (c + 1 < g.W2.nc) xstep(c + 1, xh[1], xl[1], bh[1], bl[1]);
+        }
     }
     stamp();  // 1 everything requested
-    __syncthreads();  // the operand tile has landed (the barrier's release waits for the DMA: vmcnt(0))
+    __syncthreads();  // the operand tiles have landed (the barrier's release waits for the DMA: vmcnt(0))
     stamp();  // 2 landed
     launder();
-    // the rows' own scales (tail of every operand row); rows beyond the tile: 1
-    float sr[RT][4], isr[RT][4];
+    // ---- barrier-free MFMA loops on the static operand tiles ----
+    auto contract = [&](auto hin_c, const unsigned char* Ab, int ts, const rsrc_t& rw, const unsigned (&off)[WN], int n_chunks, bool prefetched) {
+        constexpr bool H = decltype(hin_c)::value;
+        auto read_afrags = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT]) {
+            const int cc = c < n_chunks ? c : n_chunks - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (H) {
+                    xh[rt] = *reinterpret_cast<const h8*>(Ab + (rt * 16 + li) * ts + cc * 64 + lg * 16);
+                } else {
+                    const unsigned char* p = Ab + (rt * 16 + li) * ts + cc * 128 + lg * 16;
+                    xh[rt] = *reinterpret_cast<const h8*>(p);
+                    xl[rt] = *reinterpret_cast<const h8*>(p + 64);
+                }
+            }
+        };
+        auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_afrags(c + 1, nh, nl);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
+            if constexpr (!H) {
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_bfrags(rw, off, c + 2, yh, yl);
+        };
+        if (!prefetched) { load_bfrags(rw, off, 0, bh[0], bl[0]); load_bfrags(rw, off, 1, bh[1], bl[1]); }
+        read_afrags(0, ah[0], al[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma nounroll
+        for (int c = 0; c < n_chunks; c += 2) {
+            step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
+            if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
+        }
+    };
+    // the rows' own scales (tail of every operand row of the main operand; K1 without one: the scales of x); rows beyond the tile: 1
+    float sr[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + lg * 4 + r;
-            const float v = *reinterpret_cast<const float*>(Ag + row * TS + (TS - 16));
+            const float v = g.A ? *reinterpret_cast<const float*>(Ag + row * TS + (TS - 16)) : s2;
             sr[rt][r] = (row < nrows && v > 0.f && v < 3.0e38f) ? v : 1.f;
-            isr[rt][r] = 1.f / sr[rt][r];
         }
-    // residual into the split domain of its row and column: acc = H0 s_r s_W (powers of two: exact)
-#pragma unroll
-    for (int ct = 0; ct < WN; ++ct) {
-        const float sw = 1.f / isw[ct];
+    if (XP && g.A) {
+        // ... then into the scale of the main operand (exact: powers of two)
+        const float is2 = 1.f / s2;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= sr[rt][r] * sw;
-    }
-    // ---- barrier-free MFMA loop on the static operand tile ----
-    const int n_chunks = g.W.nc;
-    auto read_afrags = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT]) {
-        const int cc = c < n_chunks ? c : n_chunks - 1;
+            for (int r = 0; r < 4; ++r) {
+                const float f = sr[rt][r] * is2;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if constexpr (HIN) {
-                xh[rt] = *reinterpret_cast<const h8*>(Ag + (rt * 16 + li) * TS + cc * 64 + lg * 16);
-            } else {
-                const unsigned char* p = Ag + (rt * 16 + li) * TS + cc * 128 + lg * 16;
-                xh[rt] = *reinterpret_cast<const h8*>(p);
-                xl[rt] = *reinterpret_cast<const h8*>(p + 64);
+                for (int ct = 0; ct < WN; ++ct) acc[rt][ct][r] *= f * (isw2[ct] / isw[ct]);
             }
-        }
-    };
-    auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yh[ct], acc[rt][ct], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_afrags(c + 1, nh, nl);
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
-        if constexpr (!HIN) {
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        load_bfrags(c + 2, yh, yl);
-    };
-    read_afrags(0, ah[0], al[0]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma nounroll
-    for (int c = 0; c < n_chunks; c += 2) {
-        step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
-        if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
     }
+    if (XP && !g.A) {  // (K1: the scale of x IS the final one)
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) isw[ct] = isw2[ct];
+    }
+    if (!XP && g.Cadd) {
+        // residual into the split domain of its row and column: acc = H0 s_r s_W (powers of two: exact)
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const float sw = 1.f / isw[ct];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= sr[rt][r] * sw;
+        }
+    }
+    if (g.A) contract(std::integral_constant<bool, HIN>{}, Ag, TS, rW, offB, g.W.nc, !XP);
 
     stamp();  // 3 MFMA loop issued
     // ---- epilogue: split domain -> fp32 (+ bias); [pre-activation rows out]; tau; tile -> segment sums -> message / Mv ----
@@ -242,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * (isw[ct] * isr[rt][r]) + bv[ct];
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * (isw[ct] / sr[rt][r]) + bv[ct];
     stamp();  // 4 unscaled
     __syncthreads();  // every wave is done with the operand tile the epilogue tile overlays
     stamp();  // 5 all waves through the contraction
@@ -355,17 +436,17 @@ __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
     }
 }
 
-template <int WN, int NW, bool HIN>
+template <int WN, int NW, bool HIN, bool XP>
 int launch_step16(const Step16K& g, int n_tiles, hipStream_t s);
 
-#define DMPNN_DEFINE_STEP16_H(WN, NW, HIN)                                                                 \
+#define DMPNN_DEFINE_STEP16_H(WN, NW, HIN, XP)                                                             \
     template <>                                                                                            \
-    int launch_step16<WN, NW, HIN>(const Step16K& g, int n_tiles, hipStream_t s) {                         \
+    int launch_step16<WN, NW, HIN, XP>(const Step16K& g, int n_tiles, hipStream_t s) {                     \
         static const size_t pad_lds = [] { const char* e = getenv("DMPNN_STEP16_PAD_LDS"); return e ? (size_t)atoi(e) * 1024 : 0; }(); \
         const size_t lds = (size_t)g.tile_bytes + meta_bytes<WN, NW>() + pad_lds;  /* (experiment: occupancy) */ \
         static size_t attr_set = 0;                                                                        \
         if (attr_set < lds) {                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN, NW, HIN>),      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN, NW, HIN, XP>),  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_step16<%d,%d>, %zu B LDS): %s", WN, NW, lds, hipGetErrorString(e)); \
@@ -373,11 +454,13 @@ int launch_step16(const Step16K& g, int n_tiles, hipStream_t s);
             }                                                                                              \
             attr_set = lds;                                                                                \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_step16<WN, NW, HIN>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g);    \
+        hipLaunchKernelGGL((k_step16<WN, NW, HIN, XP>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g); \
         DMPNN_CHECK_LAUNCH("k_step16");                                                                    \
         return DMPNN_OK;                                                                                   \
     }
-#define DMPNN_DEFINE_STEP16(WN, NW) DMPNN_DEFINE_STEP16_H(WN, NW, false) DMPNN_DEFINE_STEP16_H(WN, NW, true)
+#define DMPNN_DEFINE_STEP16(WN, NW)                                                                        \
+    DMPNN_DEFINE_STEP16_H(WN, NW, false, false) DMPNN_DEFINE_STEP16_H(WN, NW, true, false)                 \
+    DMPNN_DEFINE_STEP16_H(WN, NW, false, true) DMPNN_DEFINE_STEP16_H(WN, NW, true, true)
 
 }  // namespace step16
 }  // namespace dmpnn

@@ -267,7 +267,7 @@ def test_whole_forward_tile_kernel_split_f16(golden, gpu_device):
     assert torch.equal(out_i, out_s)
 
 
-def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device):
+def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device, monkeypatch):
     """Route "fused16" (dmpnn_step16_impl.hpp): one launch per depth step, message rows kept between the steps in split
     form (hi | lo halfs + the row's scale), operand tiles fetched by LDS-DMA.  Any molecule size.  Held to the same bar
     against the executed reference as every other route; the per-atom sums it leaves in the workspace as well."""
@@ -276,20 +276,25 @@ def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device):
         pytest.skip("fused routes do not apply")
     if str(cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
         pytest.skip("custom activation: rows route")
-    plan, out, st = _engine_forward(golden, gpu_device, route="fused16")
-    assert st.route == "fused16"
-    if not plan.fusable():
-        assert torch.isnan(out).all()      # not a molecular graph: loud
-        return
-    err = parity_err(out.cpu().numpy(), golden["out"])
-    assert err <= TOL, f"{golden.name}: {err:.3e}"
-    if "Mv" in golden and plan.n_edges:
-        assert parity_err(st.Mv[:, :cfg["d_h"]].cpu().numpy(), golden["Mv"]) <= TOL
-    if "H0" in golden and plan.n_edges:     # kept rows are the plan's CSR rows (row i = edge perm[i])
-        H0 = st.H0[:, :cfg["d_h"]][plan.inv32.long()]
-        assert parity_err(H0.cpu().numpy(), golden["H0"]) <= TOL
-    _, out2, _ = _engine_forward(golden, gpu_device, route="fused16")
-    assert torch.equal(out, out2)          # deterministic (no atomics on the data path)
+    # Two forms of the residual H0 = W_i [V[src] || E] + b_i in the depth steps: recomputed per step from the exactly split K1
+    # operand (the default where d_v + d_e <= 256 and depth >= 2: no H0 tensor exists) and written once / read back
+    # (DMPNN_XPATH=0).  Same bar for both.
+    for xpath in ("1", "0"):
+        monkeypatch.setenv("DMPNN_XPATH", xpath)   # ("1" also forces it for the 8-wave workgroups of wide hidden layers)
+        plan, out, st = _engine_forward(golden, gpu_device, route="fused16")
+        assert st.route == "fused16"
+        if not plan.fusable():
+            assert torch.isnan(out).all()      # not a molecular graph: loud
+            return
+        err = parity_err(out.cpu().numpy(), golden["out"])
+        assert err <= TOL, f"{golden.name} (xpath {xpath}): {err:.3e}"
+        if "Mv" in golden and plan.n_edges:
+            assert parity_err(st.Mv[:, :cfg["d_h"]].cpu().numpy(), golden["Mv"]) <= TOL
+        if xpath == "0" and "H0" in golden and plan.n_edges:     # kept rows are the plan's CSR rows (row i = edge perm[i])
+            H0 = st.H0[:, :cfg["d_h"]][plan.inv32.long()]
+            assert parity_err(H0.cpu().numpy(), golden["H0"]) <= TOL
+        _, out2, _ = _engine_forward(golden, gpu_device, route="fused16")
+        assert torch.equal(out, out2)          # deterministic (no atomics on the data path)
 
 
 HALF_TOL = 2e-3  # DMPNN_F_STORE16: one rounding of every message element to an 11-bit significand per depth step (stated in include/dmpnn.h)
@@ -372,6 +377,9 @@ def test_per_step_fused_route_wide_hidden_layers(d_h, depth, act, bias, kind, n,
             out = mp(bmg)
             assert mp.__dict__.get("_dmpnn_route") == "fused16", mp.__dict__.get("_dmpnn_route")
             assert parity_err(out.cpu().numpy(), ref) <= TOL, (d_h, i)
+        # the residual recomputed from the split K1 operand (the default up to d_h = 320 only) forced for these shapes as well
+        monkeypatch.setenv("DMPNN_XPATH", "1")
+        assert parity_err(mp(bmg).cpu().numpy(), ref) <= TOL, (d_h, "x path")
 
 
 def _closed_tile_mask(a, src, dst, rev, n_atoms):
