@@ -6,7 +6,8 @@ import torch
 from chemprop_amd import synth
 from chemprop_amd.nn import BondMessagePassing
 dev = torch.device("cuda:0")
-bmg = synth.random_batch(512, "qm9", seed=1000); bmg.to(dev)
+nm = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+bmg = synth.random_batch(nm, "qm9", seed=1000); bmg.to(dev)
 mp = BondMessagePassing().to(dev).eval()
 with torch.no_grad():
     for _ in range(50): mp(bmg)

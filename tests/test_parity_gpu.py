@@ -648,6 +648,57 @@ def test_size_independent_properties_at_scale(gpu_device):
     assert torch.equal(engine.message(plan, H), M)
 
 
+@pytest.mark.parametrize("kind,n_mols,kw,route", [("qm9", 32768, dict(), "mega16"), ("synth40", 8192, dict(), "fused16"),
+                                                   ("zinc", 4096, dict(d_h=512, depth=6), "fused16")])
+def test_whole_forward_properties_at_scale(kind, n_mols, kw, route, gpu_device):
+    """The WHOLE forward at sizes no CPU oracle run is cheap for (0.6 M - 0.7 M directed edges), through properties the
+    domain gives for free — molecules do not interact (no edge crosses a molecule, data/collate.py:48-56):
+      * the atoms of the first 512 molecules get the same output inside the big batch as in a batch of their own, which IS
+        checked against the oracle (tiles, row tiles and scales differ between the two: rounding class, <= 1e-5);
+      * a permutation of the molecules permutes the output;
+      * a checksum of checksums: the per-molecule output sums of the permuted batch match, molecule by molecule;
+      * two runs are bit-identical (no atomics on the data path)."""
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph
+    from chemprop_amd.nn import BondMessagePassing
+
+    mgs = synth.random_molgraphs(n_mols, kind, seed=31)
+    torch.manual_seed(31)
+    mp = BondMessagePassing(**kw).eval()
+    head = BatchMolGraph(mgs[:512])
+    with torch.no_grad():
+        ref_head = ot.forward_bmg(head, ot.MPWeights.from_module(mp), depth=mp.depth).numpy()
+    mp = mp.to(gpu_device)
+    big = BatchMolGraph(mgs)
+    perm = np.random.default_rng(5).permutation(n_mols)
+    shuffled = BatchMolGraph([mgs[i] for i in perm])
+    n_at = np.array([len(m.V) for m in mgs])
+    off = np.concatenate([[0], np.cumsum(n_at)])
+    for b in (head, big, shuffled):
+        b.to(gpu_device)
+    with torch.no_grad():
+        for _ in range(3):                      # (past the synchronously validated first batches: the steady routes)
+            out_head = mp(head)
+        for _ in range(2):
+            out_big = mp(big)
+        assert str(mp.__dict__.get("_dmpnn_route") or route).startswith(route[:5]) or mp.__dict__.get("_dmpnn_replay") is not None
+        out_shuf = mp(shuffled)
+        assert torch.equal(mp(big), out_big)
+    assert parity_err(out_head.cpu().numpy(), ref_head) <= TOL
+    n_head = int(off[512])
+    assert parity_err(out_big[:n_head].cpu().numpy(), ref_head) <= TOL
+    # atom rows of molecule perm[j] in the shuffled batch = rows off[perm[j]] .. of the original
+    idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in perm])
+    want = out_big.cpu().numpy()[idx]
+    got = out_shuf.cpu().numpy()
+    assert parity_err(got, want) <= TOL
+    mol_of_atom = torch.from_numpy(np.repeat(np.arange(n_mols), n_at[perm])).to(gpu_device)
+    sums_shuf = torch.zeros(n_mols, out_shuf.shape[1], device=gpu_device, dtype=torch.float64).index_add_(0, mol_of_atom, out_shuf.double())
+    mol_of_atom0 = torch.from_numpy(np.repeat(np.arange(n_mols), n_at)).to(gpu_device)
+    sums_big = torch.zeros(n_mols, out_big.shape[1], device=gpu_device, dtype=torch.float64).index_add_(0, mol_of_atom0, out_big.double())
+    assert parity_err(sums_shuf.cpu().numpy(), sums_big[torch.from_numpy(perm).to(gpu_device)].cpu().numpy()) <= TOL
+
+
 def test_cpu_tensors_fail_loudly(gpu_device):
     from chemprop_amd import synth
     from chemprop_amd.nn import BondMessagePassing
