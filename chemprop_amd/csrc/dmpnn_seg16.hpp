@@ -48,6 +48,29 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
             const int q = it - al * qn;
             const int r0 = rp[al], r1 = rp[al + 1];
             float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r1 - r0 <= 4) {
+                // an atom of a molecule has <= 4 bonds (the common case by far): its rows are requested TOGETHER — a loop with a
+                // data-dependent trip count waits one LDS latency per row, twice — summed in the same increasing row order, and
+                // the messages go back without being read again
+                float4 y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const float4*>(T + (r0 + i < r1 ? r0 + i : (r1 > r0 ? r0 : 0)) * LDC + 4 * q);
+                if (r1 > r0) S = y[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+                    if (r0 + i < r1) { S.x += y[i].x; S.y += y[i].y; S.z += y[i].z; S.w += y[i].w; }
+                if (o.Sout) *reinterpret_cast<float4*>(o.Sout + (long long)(a0 + al) * o.lds + 4 * q) = poison ? make_float4(nanv, nanv, nanv, nanv) : S;
+                if (o.Mout) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r0 + i < r1) {
+                            const float4 m = make_float4(S.x - y[i].x, S.y - y[i].y, S.z - y[i].z, S.w - y[i].w);
+                            *reinterpret_cast<float4*>(T + (r0 + i) * LDC + 4 * q) = m;
+                            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w))));
+                        }
+                }
+                continue;
+            }
             for (int r = r0; r < r1; ++r) {
                 const float4 y = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
                 if (r == r0) S = y;

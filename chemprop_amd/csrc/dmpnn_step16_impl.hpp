@@ -400,7 +400,58 @@ __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
     const int K = g.K1 + g.K2, nc = (g.ts - 16) / 128;
     const rsrc_t r1 = gemm::make_rsrc(g.A1, g.a1_bytes), r2 = gemm::make_rsrc(g.A2 ? g.A2 : g.A1, g.A2 ? g.a2_bytes : 0u);
     constexpr int J = BM / 4;
+    auto fetch = [&](unsigned o1, unsigned o2, int k) -> gemm::u32x2 {
+        const unsigned k1o = k < g.K1 ? (unsigned)k * 4u : kOOB;
+        const unsigned k2o = (k >= g.K1 && k < K) ? (unsigned)(k - g.K1) * 4u : kOOB;
+        return __builtin_amdgcn_raw_buffer_load_b64(r1, gemm::join_off(o1, k1o), 0, 0) |
+               __builtin_amdgcn_raw_buffer_load_b64(r2, gemm::join_off(o2, k2o), 0, 0);
+    };
+    auto put = [&](int r, int k, float x, float y, float s) {
+        const float xs = x * s, ys = y * s;
+        const mega16::h2 hi = mega16::h2{(_Float16)xs, (_Float16)ys};
+        const mega16::h2 lo = mega16::h2{(_Float16)(xs - (float)hi[0]), (_Float16)(ys - (float)hi[1])};
+        unsigned char* p = g.out + (long long)(rs + r) * g.ts + (k >> 5) * 128 + (k & 31) * 2;
+        *reinterpret_cast<mega16::h2*>(p) = hi;
+        *reinterpret_cast<mega16::h2*>(p + 64) = lo;
+    };
     float mx = 0.f;
+    if (nc * 32 <= 256) {
+        // one pass: the tile's gathered operand (<= 48 rows x 256 columns) is held in registers between the maximum and the split
+        gemm::u32x2 v[J][2];
+        unsigned o1[J], o2[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int r = wave + 4 * j;
+            const bool ok = r < nrows;
+            o1[j] = ok ? (unsigned)g.g1[rs + r] * (unsigned)g.lda1 * 4u : kOOB;
+            o2[j] = (ok && g.A2) ? (unsigned)g.g2[rs + r] * (unsigned)g.lda2 * 4u : kOOB;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = lane * 2 + 128 * i;
+                v[j][i] = (k < nc * 32) ? fetch(o1[j], o2[j], k) : gemm::u32x2{0u, 0u};
+                mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v[j][i].x)), fabsf(__uint_as_float(v[j][i].y))));
+            }
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) atomicMax(&maxbits, __float_as_uint(mx));
+        __syncthreads();
+        const float s = scale_for(__uint_as_float(maxbits));
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int r = wave + 4 * j;
+            if (r >= nrows) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = lane * 2 + 128 * i;
+                if (k < nc * 32) put(r, k, __uint_as_float(v[j][i].x), __uint_as_float(v[j][i].y), s);
+            }
+            if (lane == 0) *reinterpret_cast<float4*>(g.out + (long long)(rs + r) * g.ts + (g.ts - 16)) = make_float4(s, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    // wider operands: two passes over the (L2-resident) rows
     for (int pass = 0; pass < 2; ++pass) {
         float s = 1.f;
         if (pass == 1) {
@@ -415,21 +466,10 @@ __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
             const unsigned o1 = (unsigned)g.g1[rs + r] * (unsigned)g.lda1 * 4u;
             const unsigned o2 = g.A2 ? (unsigned)g.g2[rs + r] * (unsigned)g.lda2 * 4u : kOOB;
             for (int k = lane * 2; k < nc * 32; k += 128) {
-                const unsigned k1o = k < g.K1 ? (unsigned)k * 4u : kOOB;
-                const unsigned k2o = (k >= g.K1 && k < K) ? (unsigned)(k - g.K1) * 4u : kOOB;
-                const gemm::u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r1, gemm::join_off(o1, k1o), 0, 0) |
-                                      __builtin_amdgcn_raw_buffer_load_b64(r2, gemm::join_off(o2, k2o), 0, 0);
+                const gemm::u32x2 v = fetch(o1, o2, k);
                 const float x = __uint_as_float(v.x), y = __uint_as_float(v.y);
-                if (pass == 0) {
-                    mx = fmaxf(mx, fmaxf(fabsf(x), fabsf(y)));
-                } else {
-                    const float xs = x * s, ys = y * s;
-                    const mega16::h2 hi = mega16::h2{(_Float16)xs, (_Float16)ys};
-                    const mega16::h2 lo = mega16::h2{(_Float16)(xs - (float)hi[0]), (_Float16)(ys - (float)hi[1])};
-                    unsigned char* p = g.out + (long long)(rs + r) * g.ts + (k >> 5) * 128 + (k & 31) * 2;
-                    *reinterpret_cast<mega16::h2*>(p) = hi;
-                    *reinterpret_cast<mega16::h2*>(p + 64) = lo;
-                }
+                if (pass == 0) mx = fmaxf(mx, fmaxf(fabsf(x), fabsf(y)));
+                else put(r, k, x, y, s);
             }
             if (pass == 1 && lane == 0) *reinterpret_cast<float4*>(g.out + (long long)(rs + r) * g.ts + (g.ts - 16)) = make_float4(s, 0.f, 0.f, 0.f);
         }
