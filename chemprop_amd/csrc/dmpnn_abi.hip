@@ -192,7 +192,8 @@ int dmpnn_update_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t
 static size_t steps16_wsplit_bytes(const dmpnn_fwd_args& a) {
     const int64_t h = a.d_h;
     size_t n = linear16_wsplit_bytes(h, a.d_v + a.d_e) + linear16_wsplit_bytes(h, h) + linear16_wsplit_bytes(h, a.d_v + h);
-    if (a.W_d && a.d_vd > 0) n += linear16_wsplit_bytes(h + a.d_vd, h + a.d_vd);
+    n += linear16_wsplit_bytes(h + a.d_vd, h + a.d_vd) * ((a.W_d && a.d_vd > 0) ? 1 : 0);
+    n += linear16_wsplit_bytes(h, h) + linear16_wsplit_bytes(h, a.d_v);  // W_o[:, d_v:] | W_o[:, :d_v] on their own (the finalize on the step kernel)
     return n;
 }
 
@@ -257,15 +258,17 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
                         "(inference, directed, d_h %% 4 == 0, d_h <= 640, even d_v / d_e)");
         DMPNN_CHECK_ARG(nE == 0 || (a->H0 && a->Ms && a->n_mslots >= 2), "forward(fused16): H0 and two split message slots are required");
         DMPNN_CHECK_ARG(a->wsplit && a->wsplit_bytes >= steps16_wsplit_bytes(*a), "forward(fused16): wsplit workspace missing or too small");
-        SplitWView w[4];
+        SplitWView w[6];
         unsigned char* wp = static_cast<unsigned char*>(a->wsplit);
         const bool ready = (a->flags & DMPNN_F_WSPLIT_READY) != 0;
-        const float* Ws[4] = {a->W_i, a->W_h, a->W_o, has_vd ? a->W_d : nullptr};
-        const int64_t Ns[4] = {h, h, h, h + a->d_vd}, Ks[4] = {dv + de, h, dv + h, h + a->d_vd};
-        for (int i = 0; i < 4; ++i) {
+        // W_i | W_h | W_o | W_d | W_o[:, d_v:] | W_o[:, :d_v]   (the last two: column blocks of W_o, leading dimension d_v + h)
+        const float* Ws[6] = {a->W_i, a->W_h, a->W_o, has_vd ? a->W_d : nullptr, a->W_o + dv, a->W_o};
+        const int64_t Ns[6] = {h, h, h, h + a->d_vd, h, h}, Ks[6] = {dv + de, h, dv + h, h + a->d_vd, h, dv};
+        const int64_t Ls[6] = {dv + de, h, dv + h, h + a->d_vd, dv + h, dv + h};
+        for (int i = 0; i < 6; ++i) {
             if (!Ws[i]) continue;
             if (ready) w[i] = split_weights_view_of(wp, Ns[i], Ks[i]);
-            else DMPNN_TRY(split_weights_view(Ws[i], Ks[i], Ns[i], Ks[i], 0, wp, &w[i], s));
+            else DMPNN_TRY(split_weights_view(Ws[i], Ls[i], Ns[i], Ks[i], 0, wp, &w[i], s));
             wp += linear16_wsplit_bytes(Ns[i], Ks[i]);
         }
         DMPNN_TRY(launch_fused16_forward(*a, w, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s));

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
         if constexpr (SEG) {
             if (tid < BM) meta[tid] = seg_rev;
             step16::SegOut o;
-            o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.ts; o.Sout = g.Sout; o.lds = g.lds; o.N = g.N; o.half = g.half_out;
+            o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.ts; o.Sout = g.Sout; o.lds = g.lds; o.N = g.N; o.half = g.half_out; o.SoutS = nullptr; o.tss = 0;
             step16::seg_epilogue<LDC, BN / 4, kThreads>(o, T, meta, row0, nrows, seg_va, seg_vb, seg_rp, poison, g.qmagic, tile_scale);
         }
     } else {

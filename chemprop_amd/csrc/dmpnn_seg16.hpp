@@ -20,6 +20,8 @@ struct SegOut {
     float* Sout; int lds;          // per-atom sums [V][lds] fp32 (or null)
     int N;                         // live columns (the padded row holds NQP column quads, zero-filled beyond N)
     int half;                      // 1: half storage — rows of [hi 32 halfs] chunks only (DMPNN_F_STORE16), else [hi | lo] chunk pairs
+    unsigned char* SoutS; int tss; // per-atom sums as SPLIT rows [V][tss] (exact hi | lo, each row's scale in its tail) instead of
+                                   // fp32 Sout: what the finalize contraction on the step kernel consumes (or null)
 };
 
 // ---- segment epilogue shared by the K1 kernel (k_rows16<.., SEG>) and the update kernel -----------------------------
@@ -60,6 +62,10 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
                 for (int i = 1; i < 4; ++i)
                     if (r0 + i < r1) { S.x += y[i].x; S.y += y[i].y; S.z += y[i].z; S.w += y[i].w; }
                 if (o.Sout) *reinterpret_cast<float4*>(o.Sout + (long long)(a0 + al) * o.lds + 4 * q) = poison ? make_float4(nanv, nanv, nanv, nanv) : S;
+                if (o.SoutS) {  // kept in the atom's first row for the split pass below (an atom without rows: zeros, nothing to keep)
+                    if (r1 > r0) *reinterpret_cast<float4*>(T + r0 * LDC + 4 * q) = S;
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(S.x), fabsf(S.y)), fmaxf(fabsf(S.z), fabsf(S.w))));
+                }
                 if (o.Mout) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -77,6 +83,10 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
                 else { S.x += y.x; S.y += y.y; S.z += y.z; S.w += y.w; }
             }
             if (o.Sout) *reinterpret_cast<float4*>(o.Sout + (long long)(a0 + al) * o.lds + 4 * q) = poison ? make_float4(nanv, nanv, nanv, nanv) : S;
+            if (o.SoutS) {
+                if (r1 > r0) *reinterpret_cast<float4*>(T + r0 * LDC + 4 * q) = S;
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(S.x), fabsf(S.y)), fmaxf(fabsf(S.z), fabsf(S.w))));
+            }
             if (o.Mout) {
                 for (int r = r0; r < r1; ++r) {
                     float4* cell = reinterpret_cast<float4*>(T + r * LDC + 4 * q);
@@ -85,6 +95,31 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
                     *cell = m;
                     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w))));
                 }
+            }
+        }
+        if (o.SoutS) {
+            // the sums of this chunk of atoms as split rows (their own power-of-two scale, in the rows' tails): row-major,
+            // item = (atom, 8 columns); an atom without rows writes zeros
+            const float sS = poison ? 1.f : tile_scale(mx);  // (uniform; contains a barrier: every sum of the chunk is in the tile)
+            mx = 0.f;
+            constexpr int G8S = NQP / 2;
+            typedef _Float16 h8s __attribute__((ext_vector_type(8)));
+            for (int it = tid; it < na * G8S; it += NT) {
+                const int al = it / G8S, g8 = it - al * G8S;
+                const int r0 = rp[al], r1 = rp[al + 1];
+                float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+                if (r1 > r0) {
+                    m0 = *reinterpret_cast<const float4*>(T + r0 * LDC + 8 * g8);
+                    m1 = *reinterpret_cast<const float4*>(T + r0 * LDC + 8 * g8 + 4);
+                }
+                if (poison) { m0 = make_float4(nanv, nanv, nanv, nanv); m1 = m0; }
+                h4 h0, l0, h1, l1;
+                split4(m0, sS, h0, l0);
+                split4(m1, sS, h1, l1);
+                unsigned char* p = o.SoutS + (long long)(a0 + al) * o.tss + (g8 >> 2) * 128 + (g8 & 3) * 16;
+                *reinterpret_cast<h8s*>(p) = h8s{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                *reinterpret_cast<h8s*>(p + 64) = h8s{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                if (g8 == 0) *reinterpret_cast<float4*>(o.SoutS + (long long)(a0 + al) * o.tss + (NQP >> 3) * 128) = make_float4(sS, 0.f, 0.f, 0.f);
             }
         }
     }

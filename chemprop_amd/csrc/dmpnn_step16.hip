@@ -115,7 +115,7 @@ static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
 // `xrows` (or null): the K1 operand [V[src] || E] of every row, exactly split (k_split_rows) — the residual H0 = W_i x + b_i is
 // then recomputed inside the step instead of read back (x_path_ok)
 static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const SplitWView* Wi, const unsigned char* xrows,
-                         const unsigned char* Min, unsigned char* Mout, float* Sout, hipStream_t s) {
+                         const unsigned char* Min, unsigned char* Mout, float* Sout, unsigned char* SoutS, hipStream_t s) {
     step16::Step16K g = step_args(a, L);
     g.A = Min; g.ts = msg_row_bytes(a);
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
@@ -126,7 +126,7 @@ static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
     } else {
         g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
     }
-    g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
+    g.Mout = Mout; g.Sout = Sout; g.SoutS = SoutS; g.half_out = half_store(a) ? 1 : 0;
     return launch_step(g, a.d_h, (int)L.max_tiles, half_store(a), s);
 }
 
@@ -164,6 +164,44 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
     return launch_step(g, a.d_h, (int)L.max_tiles, false, s);  // (the K1 operand [V || E] is always split exactly)
 }
 
+// The finalize on the step kernel: out = tau(W_o[:, d_v:] Mv + W_o[:, :d_v] V + b_o) over uniform 48-atom tiles — the last depth
+// step leaves Mv as split rows (in the message slot it does not read), V is split once into 400-byte rows (where the fp32 Mv
+// would have been), the atoms' rows arrive by LDS-DMA like any operand tile.  Replaces the row kernel (k_rows16: three
+// dependent load -> maximum -> split -> contract groups per tile, 18 % of a large forward).  DMPNN_FIN16=0: off.
+static bool fin16_ok(const dmpnn_fwd_args& a, const float* out, int64_t ldout) {
+    const char* e = getenv("DMPNN_FIN16");
+    if ((e && e[0] == '0') || a.depth < 2 || a.n_edges <= 0 || a.n_atoms > a.n_edges) return false;
+    if ((a.d_v + 31) / 32 > step16::kXChunks || (int64_t)step16::split_operand_bytes((int)a.d_v) > a.ldh * 4) return false;
+    return ldout % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && a.d_h % 4 == 0;
+}
+
+static int launch_fin16(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& WoM, const SplitWView& WoV, const unsigned char* MvS,
+                        float* out, int64_t ldout, hipStream_t s) {
+    const int* plan_i = static_cast<const int*>(a.plan);
+    unsigned char* VS = reinterpret_cast<unsigned char*>(a.Mv);  // (no fp32 Mv on this path)
+    const int n_tiles = (int)((a.n_atoms + step16::BM - 1) / step16::BM);
+    step16::SplitRowsK k;
+    memset(&k, 0, sizeof(k));
+    k.n_tiles = n_tiles; k.n_rows = (int)a.n_atoms;
+    k.A1 = a.V; k.lda1 = (int)a.ldv; k.K1 = (int)a.d_v; k.a1_bytes = (unsigned)(a.n_atoms * a.ldv * 4);
+    k.out = VS; k.ts = step16::split_operand_bytes((int)a.d_v);
+    hipLaunchKernelGGL(step16::k_split_rows, dim3((unsigned)n_tiles), dim3(256), 0, s, k);
+    DMPNN_CHECK_LAUNCH("k_split_rows");
+    step16::Step16K g;
+    memset(&g, 0, sizeof(g));
+    g.M = (int)a.n_atoms; g.N = (int)a.d_h; g.uniform = 1;
+    g.A = MvS; g.ts = step16::split_row_bytes((int)a.d_h);
+    g.W.p = WoM.p; g.W.inv_scale = WoM.inv_scale; g.W.nc = WoM.nc; g.bias = a.b_o;
+    g.A2 = VS; g.ts2 = k.ts; g.W2.p = WoV.p; g.W2.inv_scale = WoV.inv_scale; g.W2.nc = WoV.nc;
+    g.Yout = out; g.ldy = (int)ldout;
+    g.act = a.act; g.slope = a.act_slope; g.slope_ptr = a.act_slope_ptr;
+    g.poison_flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoFuse;
+    g.qmagic = qmagic_of(a.d_h);
+    g.dbg = nullptr;
+    (void)L;
+    return launch_step(g, a.d_h, n_tiles, false, s);
+}
+
 // a.Ms: two slots of n_edges split rows (split_row_floats(d_h) floats each); a.H0 [n_edges, ldh]; a.Mv [n_atoms, ldh];
 // w16: pre-split W_i | W_h | W_o (| W_d).  `out` / `ldout`: the finalize output (Hv when W_d follows).
 int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s) {
@@ -177,6 +215,7 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
         hipError_t e = hipMemsetAsync(a.Mv, 0, (size_t)nV * a.ldh * sizeof(float), s);
         if (e != hipSuccess) { set_error("forward(fused16): memset failed: %s", hipGetErrorString(e)); return DMPNN_EHIP; }
     }
+    const bool fin16 = fin16_ok(a, out, ldout);
     if (nE > 0) {
         static const bool k1_split_all = [] { const char* e = getenv("DMPNN_K1_SPLIT"); return e && e[0] == '1'; }();
         const bool xpath = x_path_ok(a);
@@ -186,9 +225,11 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
         else DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
         for (int t = 1; t < T; ++t) {
             const bool last = t == T - 1;
-            DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], xrows, Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : Ms + (t % 2) * slot_bytes,
-                                    last ? a.Mv : nullptr, s));
+            unsigned char* free_slot = Ms + (t % 2) * slot_bytes;  // (the slot this step does not read)
+            DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], xrows, Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : free_slot,
+                                    (last && !fin16) ? a.Mv : nullptr, (last && fin16) ? free_slot : nullptr, s));
         }
+        if (fin16) return launch_fin16(a, L, w16[4], w16[5], Ms + ((T - 1) % 2) * slot_bytes, out, ldout, s);
     }
     dmpnn_gemm_args g;
     memset(&g, 0, sizeof(g));

@@ -71,6 +71,9 @@ struct Step16K {
     SplitW W2; const float* bias2;
     float* Zpre; int ldz;                 // pre-activation rows [M][ldz] fp32 to store (K1: H0), or null
     unsigned char* Mout; float* Sout; int lds;
+    unsigned char* SoutS;                 // the per-atom sums as split rows [V][TSO] instead of fp32 Sout (or null)
+    int uniform;                          // 1: no tile table — tile t = rows 48 t .. (the finalize over atoms: no segments)
+    float* Yout; int ldy;                 // 1: plain epilogue — tau(z) rows [M][ldy] fp32, nothing else (or null)
     int act; float slope; const float* slope_ptr;
     const int* poison_flags; int poison_mask;
     unsigned qmagic;
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     };
     stamp();  // 0 entry
     const int t = blockIdx.x;
-    const int rs = g.tile_row[t], re = g.tile_row[t + 1];
-    const int va = g.tile_atom[t], vb = g.tile_atom[t + 1];
+    const int rs = g.uniform ? BM * t : g.tile_row[t], re = g.uniform ? (BM * t + BM < g.M ? BM * t + BM : g.M) : g.tile_row[t + 1];
+    const int va = g.uniform ? 0 : g.tile_atom[t], vb = g.uniform ? 0 : g.tile_atom[t + 1];
     const int nrows = re - rs;
     if (nrows <= 0 && va >= vb) return;   // trailing slots of the launch bound
     if (nrows < 0 || nrows > BM) return;  // (cannot happen with a valid tile table)
@@ -170,8 +173,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     // segment metadata (consumed by the epilogue)
     const int na0 = vb - va < kAtomCache ? vb - va : kAtomCache;
     const int* rvp = g.Mout ? g.revp : g.row_ptr;
-    const int seg_rev = rvp[(g.Mout && tid < nrows) ? rs + tid : 0];
-    const int seg_rp = g.row_ptr[va + (tid <= na0 ? tid : 0)] - rs;
+    const int seg_rev = g.uniform ? 0 : rvp[(g.Mout && tid < nrows) ? rs + tid : 0];
+    const int seg_rp = g.uniform ? 0 : g.row_ptr[va + (tid <= na0 ? tid : 0)] - rs;
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
 
     // ---- weight fragments: [column tile][chunk][hi|lo][lane][16 B], straight from L2 ----
@@ -359,6 +362,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         }
     }
     stamp();  // 6 tile written (+ pre-activation rows)
+    if (g.Yout) {  // (uniform) plain epilogue: the rows of tau(z), coalesced — the finalize over atoms
+        __syncthreads();
+        const int qn = g.N >> 2;
+        const float nanv = __int_as_float(0x7fc00000);
+        for (int it = tid; it < nrows * qn; it += NT) {
+            const int r = qn == 1 ? it : (int)__umulhi((unsigned)it, g.qmagic), q = it - r * qn;
+            float4 z = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
+            if (poison) z = make_float4(nanv, nanv, nanv, nanv);
+            *reinterpret_cast<float4*>(g.Yout + (long long)(rs + r) * g.ldy + 4 * q) = z;
+        }
+        return;
+    }
     int scale_phase = 0;
     auto tile_scale = [&](float local_max) -> float {
         stamp();  // 7 pass 1 done
@@ -372,12 +387,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[scale_phase & 3], (unsigned)m);
         __syncthreads();
         const float mxv = __uint_as_float(maxbits[scale_phase & 3]);
+        if (tid == 0) maxbits[(scale_phase + 2) & 3] = 0u;  // (re-armed two calls ahead: last read before the previous call's barrier)
         ++scale_phase;
         return scale_for(mxv);
     };
     SegOut o;
     o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.half_out ? BN * 2 + 16 : TSO; o.Sout = g.Sout; o.lds = g.lds;
-    o.N = g.N; o.half = g.half_out;
+    o.N = g.N; o.half = g.half_out; o.SoutS = g.SoutS; o.tss = TSO;
     seg_epilogue<LDC, BN / 4, NT>(o, T, meta, rs, nrows, va, vb, seg_rp, poison, g.qmagic, tile_scale);
     stamp();  // 8 (7 without a message) end
 }
@@ -385,15 +401,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
 // ---- the K1 operand [A1[g1[r]] || A2[g2[r]]] (fp32, gathered) as split rows: one workgroup per row tile of the plan ----
 // (used where K1 runs on k_step16 itself: d_h > 320; narrower blocks take k_rows16<.., SEG>, which splits on the fly)
 struct SplitRowsK {
-    const int* tile_row; int n_tiles;
-    const float* A1; int lda1; const int* g1; int K1; unsigned a1_bytes;
+    const int* tile_row; int n_tiles; int n_rows;   // (tile_row null: uniform 48-row tiles over n_rows rows)
+    const float* A1; int lda1; const int* g1; int K1; unsigned a1_bytes;   // (g1 / g2 null: rows in place)
     const float* A2; int lda2; const int* g2; int K2; unsigned a2_bytes;
     unsigned char* out; int ts;
 };
 __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
     __shared__ unsigned maxbits;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rs = g.tile_row[blockIdx.x], nrows = g.tile_row[blockIdx.x + 1] - rs;
+    // (no tile table: uniform 48-row tiles over n_rows rows; no gather arrays: the rows in place)
+    const int rs = g.tile_row ? g.tile_row[blockIdx.x] : BM * (int)blockIdx.x;
+    const int nrows = g.tile_row ? g.tile_row[blockIdx.x + 1] - rs : (rs + BM < g.n_rows ? BM : g.n_rows - rs);
     if (nrows <= 0 || nrows > BM) return;
     if (tid == 0) maxbits = 0u;
     __syncthreads();
@@ -423,8 +441,8 @@ __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
         for (int j = 0; j < J; ++j) {
             const int r = wave + 4 * j;
             const bool ok = r < nrows;
-            o1[j] = ok ? (unsigned)g.g1[rs + r] * (unsigned)g.lda1 * 4u : kOOB;
-            o2[j] = (ok && g.A2) ? (unsigned)g.g2[rs + r] * (unsigned)g.lda2 * 4u : kOOB;
+            o1[j] = ok ? (unsigned)(g.g1 ? g.g1[rs + r] : rs + r) * (unsigned)g.lda1 * 4u : kOOB;
+            o2[j] = (ok && g.A2) ? (unsigned)(g.g2 ? g.g2[rs + r] : rs + r) * (unsigned)g.lda2 * 4u : kOOB;
         }
 #pragma unroll
         for (int j = 0; j < J; ++j)
@@ -463,8 +481,8 @@ __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
         for (int j = 0; j < J; ++j) {
             const int r = wave + 4 * j;
             if (r >= nrows) continue;
-            const unsigned o1 = (unsigned)g.g1[rs + r] * (unsigned)g.lda1 * 4u;
-            const unsigned o2 = g.A2 ? (unsigned)g.g2[rs + r] * (unsigned)g.lda2 * 4u : kOOB;
+            const unsigned o1 = (unsigned)(g.g1 ? g.g1[rs + r] : rs + r) * (unsigned)g.lda1 * 4u;
+            const unsigned o2 = g.A2 ? (unsigned)(g.g2 ? g.g2[rs + r] : rs + r) * (unsigned)g.lda2 * 4u : kOOB;
             for (int k = lane * 2; k < nc * 32; k += 128) {
                 const gemm::u32x2 v = fetch(o1, o2, k);
                 const float x = __uint_as_float(v.x), y = __uint_as_float(v.y);

@@ -279,16 +279,19 @@ def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device, monkeypatch):
     # Two forms of the residual H0 = W_i [V[src] || E] + b_i in the depth steps: recomputed per step from the exactly split K1
     # operand (the default where d_v + d_e <= 256 and depth >= 2: no H0 tensor exists) and written once / read back
     # (DMPNN_XPATH=0).  Same bar for both.
-    for xpath in ("1", "0"):
+    # The finalize likewise has two forms: on the step kernel over 48-atom tiles, fed by the last step's per-atom sums as split
+    # rows (the default from depth 2 on: no fp32 Mv tensor exists), and the row kernel on fp32 Mv (DMPNN_FIN16=0).
+    for xpath, fin16 in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("DMPNN_XPATH", xpath)   # ("1" also forces it for the 8-wave workgroups of wide hidden layers)
+        monkeypatch.setenv("DMPNN_FIN16", fin16)
         plan, out, st = _engine_forward(golden, gpu_device, route="fused16")
         assert st.route == "fused16"
         if not plan.fusable():
             assert torch.isnan(out).all()      # not a molecular graph: loud
             return
         err = parity_err(out.cpu().numpy(), golden["out"])
-        assert err <= TOL, f"{golden.name} (xpath {xpath}): {err:.3e}"
-        if "Mv" in golden and plan.n_edges:
+        assert err <= TOL, f"{golden.name} (xpath {xpath}, fin16 {fin16}): {err:.3e}"
+        if fin16 == "0" and "Mv" in golden and plan.n_edges:
             assert parity_err(st.Mv[:, :cfg["d_h"]].cpu().numpy(), golden["Mv"]) <= TOL
         if xpath == "0" and "H0" in golden and plan.n_edges:     # kept rows are the plan's CSR rows (row i = edge perm[i])
             H0 = st.H0[:, :cfg["d_h"]][plan.inv32.long()]
@@ -380,6 +383,8 @@ def test_per_step_fused_route_wide_hidden_layers(d_h, depth, act, bias, kind, n,
         # the residual recomputed from the split K1 operand (the default up to d_h = 320 only) forced for these shapes as well
         monkeypatch.setenv("DMPNN_XPATH", "1")
         assert parity_err(mp(bmg).cpu().numpy(), ref) <= TOL, (d_h, "x path")
+        monkeypatch.setenv("DMPNN_FIN16", "0")         # (the finalize on the row kernel; the default above was the step kernel)
+        assert parity_err(mp(bmg).cpu().numpy(), ref) <= TOL, (d_h, "row-kernel finalize")
 
 
 def _closed_tile_mask(a, src, dst, rev, n_atoms):
