@@ -273,8 +273,10 @@ size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
  * forward of batches of ANY molecule size (d_h <= 640): one launch per depth step, the message tensor kept between the
  * steps as SPLIT rows (per row: chunks of [hi 32 halfs | lo 32 halfs] + a 16-byte tail with the row's power-of-two scale;
  * x s = hi + lo exactly as in DMPNN_F_SPLIT16's contractions).  `Ms` must then hold n_mslots >= 2 slots of
- * n_edges * dmpnn_split_row_floats(d_h) floats each (instead of n_edges * ldh); Mv as usual; plan: dmpnn_prepare
- * or dmpnn_prepare_light.  `H0` ([n_edges, ldh] floats) is this route's SCRATCH: for d_h <= 320 and depth >= 2 it holds the
+ * n_edges * dmpnn_split_row_floats(d_h) floats each (instead of n_edges * ldh); plan: dmpnn_prepare
+ * or dmpnn_prepare_light.  `Mv` ([n_atoms, ldh] floats) and `H0` ([n_edges, ldh] floats) are this route's SCRATCH: from depth 2
+ * on the finalize runs on the step kernel, fed by per-atom sums kept as split rows in a message slot, and `Mv` holds the split
+ * rows of V (DMPNN_FIN16=0 in the environment: fp32 Mv and the row kernel); for d_h <= 320 and depth >= 2 it holds the
  * exactly split K1 operand [V[src] || E] of every row (the residual W_i x + b_i is recomputed inside every step), not
  * H0 — a caller that wants the H0 tensor of this route sets DMPNN_XPATH=0 in the environment. */
 int64_t dmpnn_split_row_floats(int64_t d_h);
