@@ -103,3 +103,32 @@ def test_exported_program_runs_the_kernels_on_other_sizes(act, bias, gpu_device)
         pooled = torch.zeros(len(b), ref_h.shape[1]).index_add_(0, b.batch.cpu(), ref_h)
         want = pooled @ model.head.weight.detach().cpu().T + model.head.bias.detach().cpu()
         torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_chain_graphs_of_the_reference_unit_test(gpu_device):
+    """``tests/unit/nn/test_message_passing.py:29-49`` for the bond encoder: exported on the 3-atom chain, run on the 5-atom
+    chain — all-ones features, BLOCK edge layout (all forward edges, then all reverse edges: ``rev[e] != e ^ 1``)."""
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph
+    from chemprop_amd.nn import BondMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    _register_pytree()
+    torch.manual_seed(3)
+    mp = BondMessagePassing().eval()
+    w = ot.MPWeights.from_module(mp)
+    export_graph, inference_graph = BatchMolGraph([synth.chain_molgraph(3)]), BatchMolGraph([synth.chain_molgraph(5)])
+    with torch.no_grad():
+        want = ot.forward_bmg(inference_graph, w, depth=3)
+    mp = mp.to(gpu_device)
+    export_graph.to(gpu_device)
+    inference_graph.to(gpu_device)
+    num_atoms, num_edges = torch.export.Dim("num_atoms", min=2), torch.export.Dim("num_edges", min=2)
+    shapes = {"bmg": [{0: num_atoms}, {0: num_edges}, {1: num_edges}, {0: num_edges}, {0: num_atoms}]}
+    exported = torch.export.export(mp, (export_graph,), dynamic_shapes=shapes, strict=False)
+    with torch.inference_mode():
+        expected = mp(inference_graph)
+        actual = exported.module()(inference_graph)
+    torch.testing.assert_close(actual, expected)
+    torch.testing.assert_close(actual.cpu(), want, rtol=1e-5, atol=1e-5)
