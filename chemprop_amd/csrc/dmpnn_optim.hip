@@ -1,0 +1,64 @@
+// f4: the optimizer step of a data-parallel training step as ONE launch over the flat buffers.
+//
+// chemprop trains with torch.optim.Adam (models/model.py:208-231, Noam learning-rate schedule on top).  torch's foreach Adam
+// is ~8 launches over the parameter list; with the gradients already in ONE flat buffer (distributed.GradSync) and the
+// parameters as views of another, the update is one HBM-bound elementwise pass — 0.3 M parameters: launch-bound, ~3 us.
+// Arithmetic = torch.optim.Adam (amsgrad = false, maximize = false), in this order:
+//     g   = grad + weight_decay * p
+//     m   = beta1 * m + (1 - beta1) * g
+//     v   = beta2 * v + (1 - beta2) * g * g
+//     p  -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)          bc_i = 1 - beta_i^step
+// `lr` and the two bias corrections come from a 4-float DEVICE array (lr, bc1, sqrt(bc2), grad_scale) when `dev_scalars` is
+// given — a captured hipGraph replays with fresh values written by a 16-byte copy — else from the arguments.
+// `grad_scale` multiplies the gradient first (1 / world_size after a SUM all-reduce).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dmpnn_common.hpp"
+
+namespace dmpnn {
+namespace {
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n4, float lr, float beta1, float beta2, float eps,
+                                              float wd, float bc1, float sqrt_bc2, float grad_scale, const float* __restrict__ dev) {
+    if (dev) { lr = dev[0]; bc1 = dev[1]; sqrt_bc2 = dev[2]; grad_scale = dev[3]; }
+    const float step = lr / bc1, inv = 1.f / sqrt_bc2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float* P = &pp.x; float* M = &mm.x; float* V = &vv.x;
+        const float* G = &gg.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gr = G[c] * grad_scale + wd * P[c];
+            M[c] = beta1 * M[c] + (1.f - beta1) * gr;
+            V[c] = beta2 * V[c] + (1.f - beta2) * gr * gr;
+            P[c] -= step * (M[c] / (sqrtf(V[c]) * inv + eps));
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+}  // namespace
+}  // namespace dmpnn
+
+using namespace dmpnn;
+
+extern "C" int dmpnn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float bias_corr1, float sqrt_bias_corr2, float grad_scale, const float* dev_scalars,
+                               void* stream) {
+    DMPNN_CHECK_ARG(n >= 0 && n % 4 == 0, "adam_step: the flat buffers hold whole 16-byte groups");
+    if (n == 0) return DMPNN_OK;
+    DMPNN_CHECK_ARG(p && g && m && v, "adam_step: null buffer");
+    DMPNN_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adam_step: buffers must be 16-byte aligned");
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n4, lr, beta1, beta2, eps,
+                       weight_decay, bias_corr1, sqrt_bias_corr2, grad_scale, dev_scalars);
+    DMPNN_CHECK_LAUNCH("k_adam");
+    return DMPNN_OK;
+}

@@ -379,6 +379,19 @@ int dmpnn_prepare_tiles_from_table(const int* tile_row, const int* tile_atom, in
 /* ---------------------------------------------------------------------------------------------
  * Misc
  * ------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * f4: the optimizer step of the training loop (chemprop/models/model.py:208-231 trains with torch.optim.Adam) as ONE
+ * launch over flat buffers: `p`, `g`, `m`, `v` are [n] fp32, n % 4 == 0, 16-byte aligned (the parameters of a model as
+ * views of one buffer, their gradients as views of another: distributed.GradSync).  Arithmetic of torch.optim.Adam
+ * (amsgrad = false):  g' = grad_scale * g + weight_decay * p;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;
+ * p -= (lr / bias_corr1) * m / (sqrt(v) / sqrt_bias_corr2 + eps).  With `dev_scalars` (4 device floats: lr, bias_corr1,
+ * sqrt_bias_corr2, grad_scale) those four come from memory instead of the arguments, so that a captured graph replays
+ * with the values of its own step.
+ * ------------------------------------------------------------------------------------------- */
+int dmpnn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float bias_corr1, float sqrt_bias_corr2, float grad_scale, const float* dev_scalars,
+                    void* stream);
+
 int dmpnn_version(void);
 /* Debug aid: a device buffer of 32 int64 that workgroup 0 of the whole-forward tile kernel fills with
  * shader-clock stamps at its phase boundaries (NULL switches it off; never set in production). */
