@@ -224,7 +224,7 @@ def main():
 
     # ---- the training step of the same shard: forward with kept tensors + backward into the flat gradient buffer + (N > 1) ONE
     # RCCL all-reduce on the communication stream (chemprop_amd/distributed.py: GradSync).  On ALL ranks, same timing rule as
-    # `value` at N > 1 (barrier + synchronize on both sides, maximum over the ranks); HIP events at N = 1 ----
+    # `value` (barrier + synchronize on both sides, maximum over the ranks) ----
     if not train:
         try:
             from chemprop_amd import distributed as ddp
@@ -245,10 +245,7 @@ def main():
                 topt.step()                      # (waits for the exchange on the stream, divides by the world size, updates)
 
             run_steps(tstep, 10)
-            if world > 1:
-                t_tr = timed(tstep, args.steps) / args.steps * 1e3
-            else:
-                t_tr = time_events(tstep, 50, torch)
+            t_tr = timed(tstep, args.steps) / args.steps * 1e3  # (the rule of `value`: K steps, synchronize on both sides, max over ranks)
             tsync.wait()
             out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(world * updates / (t_tr * 1e-3) / 1e6, 2),
                                  "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else None,
