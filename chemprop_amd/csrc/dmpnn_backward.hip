@@ -455,6 +455,44 @@ __global__ void k_wgrad_reduce(const float* __restrict__ slab, int64_t slab_stri
     }
 }
 
+// the same for up to four products in ONE launch (the backward's weight gradients are ready together): job j owns the
+// workgroups [wg0[j], wg0[j + 1])
+struct ReduceJob {
+    const float* slab; int64_t slab_stride; int n_slabs, ldk, N, K, ones;
+    float* gW; int64_t ldgw; float* gb;
+};
+struct ReduceJobs { ReduceJob job[4]; int wg0[5]; int n_jobs; const int* poison_flags; int poison_mask; };
+__global__ void k_wgrad_reduce_multi(ReduceJobs a) {
+    int j = 0;
+    while (j + 1 < a.n_jobs && (int)blockIdx.x >= a.wg0[j + 1]) ++j;
+    const ReduceJob& J = a.job[j];
+    const int Kt = J.K + J.ones;
+    const bool poison = a.poison_flags && (a.poison_flags[0] & a.poison_mask);
+    const int64_t total = (int64_t)J.N * Kt;
+    const int nblk = a.wg0[j + 1] - a.wg0[j];
+    for (int64_t i = ((int64_t)blockIdx.x - a.wg0[j]) * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+        const int n = (int)(i / Kt), k = (int)(i % Kt);
+        float s = 0.f;
+        const float* p0 = J.slab + (int64_t)n * J.ldk + k;
+        for (int t0 = 0; t0 < J.n_slabs; t0 += 8) {  // (summed in slab order, eight reads in flight: as k_wgrad_reduce)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u < J.n_slabs ? t0 + u : J.n_slabs - 1;
+                v[u] = p0[(int64_t)t * J.slab_stride];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t0 + u < J.n_slabs ? v[u] : 0.f;
+        }
+        if (poison) s = __int_as_float(0x7fc00000);
+        if (k < J.K) {
+            if (J.gW) J.gW[(int64_t)n * J.ldgw + k] = s;
+        } else if (J.gb) {
+            J.gb[n] = s;
+        }
+    }
+}
+
 struct WgradPlan {
     int splits, rows_per_wg, ldk;
     int64_t slab_stride;
@@ -528,6 +566,10 @@ struct BwdLayout {
     bool mega;
     WgradPlan p_h, p_i, p_o, p_d;
     WgradPlan p_hm;       // backward tile kernel: gW_h over ALL steps' rows in one launch (the gZ^(t) / M^(t) slots are adjacent)
+    // backward tile kernel: the three weight gradients on the f16 pipe (dmpnn_wgrad16.hip): six split operands + slabs
+    bool w16;
+    size_t w16_z[3], w16_a[3], w16_slab[3];   // o, h, i (float offsets)
+    WProdPlan q[3];
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     BwdLayout L;
@@ -580,6 +622,23 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
         L.mega_w = o; o += align_up((mega16_bwd_wsplit_bytes(h) + 3) / 4, 64);
         if (f.depth - 1 > 2) { L.gZs = o; o += (size_t)(f.depth - 1) * edge; }
         L.sp_gM = o; o += edge;
+    }
+    L.w16 = false;
+    {
+        static const bool on = [] { const char* e = getenv("DMPNN_WGRAD16"); return !(e && e[0] == '0'); }();
+        const int kt_o = (int)(f.d_v + h) + 1, kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(f.d_v + f.d_e) + (f.b_i ? 1 : 0);
+        if (on && L.mega && h % 2 == 0 && f.ldh % 2 == 0 && wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, nullptr, f.ldh, (int)h) &&
+            (f.d_e == 0 || wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, f.E, f.lde, (int)f.d_e))) {
+            L.w16 = true;
+            const int64_t Ms[3] = {nV, nE * steps, nE};
+            const int Ks[3] = {kt_o, kt_h, kt_i};
+            for (int i = 0; i < 3; ++i) {
+                L.q[i] = plan_wgrad16(Ms[i], (int)h, Ks[i]);
+                L.w16_z[i] = o; o += align_up((wsplit16_bytes(Ms[i], h) + 3) / 4, 64);
+                L.w16_a[i] = o; o += align_up((wsplit16_bytes(Ms[i], Ks[i]) + 3) / 4, 64);
+                L.w16_slab[i] = o; o += align_up((size_t)L.q[i].splits * L.q[i].slab_stride, 64);
+            }
+        }
     }
     L.total = o;
     return L;
@@ -727,6 +786,52 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         DMPNN_CHECK_ARG(f.H0 && (T == 1 || f.Hs), "backward: the tile-kernel forward did not keep H0 / H^(t)");
         float* gZs = (T - 1 > 2) ? ws + L.gZs : gZa;  // slot t-1 = gZ^(t)
         DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, ws + L.sp_gM, ws + L.gMv, s));
+        if (L.w16 && aligned16(f.Mv) && (T < 2 || (aligned16(f.Ms) && aligned16(gZs))) && aligned16(gH0) && aligned16(gZO)) {
+            // ---- the three weight gradients on the f16 pipe: every operand split ONCE (one launch), three products, three reduces ----
+            const bool want[3] = {b->gW_o || b->gb_o, (b->gW_h || b->gb_h) && T >= 2, b->gW_i || b->gb_i};
+            WSplitArgs sp;
+            memset(&sp, 0, sizeof(sp));
+            WSplitJob* Zj[3] = {nullptr, nullptr, nullptr};
+            WSplitJob* Aj[3] = {nullptr, nullptr, nullptr};
+            const int Ks[3] = {(int)(dv + h) + 1, (int)h + (f.b_h ? 1 : 0), (int)(dv + de) + (f.b_i ? 1 : 0)};
+            if (want[0]) {
+                Zj[0] = &sp.job[sp.n_jobs++]; wsplit16_job(Zj[0], nV, (int)h, gZO, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, 0, ws + L.w16_z[0]);
+                Aj[0] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[0], nV, Ks[0], f.V, f.ldv, nullptr, (int)dv, f.Mv, ldh, nullptr, (int)h, 1, ws + L.w16_a[0]);
+            }
+            if (want[1]) {
+                Zj[1] = &sp.job[sp.n_jobs++]; wsplit16_job(Zj[1], nE * (T - 1), (int)h, gZs, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, 0, ws + L.w16_z[1]);
+                Aj[1] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[1], nE * (T - 1), Ks[1], f.Ms, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, f.b_h ? 1 : 0, ws + L.w16_a[1]);
+            }
+            if (want[2]) {
+                Zj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Zj[2], nE, (int)h, gH0, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, 0, ws + L.w16_z[2]);
+                Aj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[2], nE, Ks[2], f.V, f.ldv, pv.src, (int)dv, f.E, f.lde, e_gather, (int)de, f.b_i ? 1 : 0, ws + L.w16_a[2]);
+            }
+            DMPNN_TRY(launch_wsplit16(sp, s));
+            float* gWs[3] = {b->gW_o, b->gW_h, b->gW_i};
+            float* gbs[3] = {b->gb_o, b->gb_h, b->gb_i};
+            const int64_t ldg[3] = {dv + h, h, dv + de};
+            const int ones[3] = {1, f.b_h ? 1 : 0, f.b_i ? 1 : 0};
+            ReduceJobs rj;
+            memset(&rj, 0, sizeof(rj));
+            rj.poison_flags = pflags; rj.poison_mask = pmask;
+            for (int i = 0; i < 3; ++i) {
+                if (!want[i]) continue;
+                DMPNN_TRY(launch_wgrad16(*Zj[i], *Aj[i], L.q[i], (int)h, Ks[i], ws + L.w16_slab[i], s));
+                ReduceJob& r = rj.job[rj.n_jobs];
+                r.slab = ws + L.w16_slab[i]; r.slab_stride = L.q[i].slab_stride; r.n_slabs = L.q[i].splits; r.ldk = L.q[i].ldk;
+                r.N = (int)h; r.K = Ks[i] - ones[i]; r.ones = ones[i]; r.gW = gWs[i]; r.ldgw = ldg[i]; r.gb = gbs[i];
+                int64_t blocks = ((int64_t)r.N * Ks[i] + 255) / 256;
+                if (blocks > 1024) blocks = 1024;
+                rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
+                ++rj.n_jobs;
+            }
+            if (rj.n_jobs > 0) {  // one reduce launch for all of them
+                hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
+                DMPNN_CHECK_LAUNCH("k_wgrad_reduce_multi");
+            }
+            if ((b->gW_h || b->gb_h) && T < 2) { zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h); }
+            return DMPNN_OK;
+        }
         if (b->gW_o || b->gb_o) {
             WgradArgs a;
             memset(&a, 0, sizeof(a));

@@ -205,6 +205,30 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
 // per-step fused route on the f16 pipe (dmpnn_step16.hip): inference forward, any molecule size, d_h <= 320
 bool fused16_shapes_ok(const dmpnn_fwd_args& a);
 int64_t split_row_floats(int64_t d_h);
+
+// ---- weight gradients on the f16 pipe (dmpnn_wgrad16.hip): operands split once into transposed blocks, then the products ----
+struct WSplitJob {
+    int64_t M; int C;                                            // reduction rows; logical columns (incl. the column of ones)
+    const float* A1; int64_t lda1; const int* g1; int K1;        // columns [0, K1): A1[g1(m)] (g1 null: rows in place)
+    const float* A2; int64_t lda2; const int* g2; int K2;        // columns [K1, K1 + K2): A2[g2(m)]
+    int ones;                                                    // column K1 + K2 is 1 (the bias gradient = column sums)
+    unsigned char* out; float* scales;                           // [column tile][chunk][8 KB]; [column tile][chunk]
+    int n_ct, n_chunks, wg0;
+};
+struct WSplitArgs { WSplitJob job[8]; int n_jobs; };
+struct WProdArgs {
+    const unsigned char* Z; const float* sZ; const unsigned char* A; const float* sA;
+    int n_nt, n_kt, n_chunks, chunks_per_split, splits;
+    int N, Kt; float* slab; int ldk; int64_t slab_stride;
+};
+struct WProdPlan { int n_nt, n_kt, n_chunks, chunks_per_split, splits, ldk; int64_t slab_stride; };
+size_t wsplit16_bytes(int64_t M, int64_t C);
+void wsplit16_job(WSplitJob* j, int64_t M, int C, const float* A1, int64_t lda1, const int* g1, int K1, const float* A2, int64_t lda2,
+                  const int* g2, int K2, int ones, void* ws);
+int launch_wsplit16(WSplitArgs& a, hipStream_t s);
+bool wgrad16_operand_ok(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2);
+WProdPlan plan_wgrad16(int64_t M, int N, int Kt);
+int launch_wgrad16(const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab, hipStream_t s);
 int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s);
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);

@@ -1,0 +1,275 @@
+// Weight gradients on the f16 matrix pipe (round 2):  gW[n][k] = sum_m gZ[m][n] * Acat[m][k],  Acat = [A1[g1(m)] || A2[g2(m)] || 1].
+//
+// The reduction index m is the ROW index of both operands; v_mfma_f32_16x16x32_f16 wants 8 consecutive reduction elements per
+// lane, i.e. both operands TRANSPOSED, and the exact 3-term split (x s = hi + lo, s a power of two) needs a scale that is
+// uniform along the reduction.  Doing transpose + split inside the product kernel was built first and is a wash: every
+// operand element is read — and then split — by each of the N/64 (or K/64) workgroups that need it, and the VALU cost of the
+// splits replaces the matrix-pipe time saved (30.5 us per launch against 30.6 us, branch exp/mol-tiles).  So the operands are
+// split ONCE:
+//
+//   k_wsplit16   one launch for all operands of a backward pass.  Block (column tile ct of 64 outputs, chunk c of 32 rows)
+//                of an operand becomes 64 rows x [hi 32 halfs | lo 32 halfs] = 8 KB, contiguous, in exactly the byte order
+//                the product kernel's LDS reads want (the 16-byte pieces of a row are XOR-swizzled with (row >> 1) & 7: a
+//                plain 128-byte row stride would put the 16 rows of a ds_read_b128 on the same banks, and an LDS-DMA cannot
+//                pad), + one power-of-two scale per block (block maximum).  A workgroup does 4 chunks of one column tile:
+//                four coalesced row loads per thread and chunk pair, register transpose (4 consecutive reduction rows of
+//                one output = one 8-byte store), gather and concatenation of [A1[g1] || A2[g2] || 1] on the fly.
+//   k_wgrad16    (output tile 64 x 64, row split) per 2-chunk stage: both operand blocks by LDS-DMA (16 KB + 16 KB, no
+//                registers, no VALU), barrier, 24 MFMAs per wave into fresh accumulators, fp32 sums += product / (s_z s_a)
+//                (exact inverse: scales never mix).  Wave w owns output rows 16 w .. of the tile.  Slab per split, reduced
+//                by k_wgrad_reduce as before (deterministic: no atomics).
+#include <stdlib.h>
+#include <string.h>
+
+#include "dmpnn_common.hpp"
+#include "dmpnn_gemm_impl.hpp"
+
+namespace dmpnn {
+namespace wg16 {
+
+using gemm::f32x4;
+using gemm::rsrc_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlk = 8192;  // bytes of one (64 outputs x 32 reduction rows) block
+
+__device__ __forceinline__ float scale_for(float maxabs) {  // exact power of two that puts maxabs at [2^13, 2^14); 1 for 0 / inf / nan
+    if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(maxabs, &e);
+    return ldexpf(1.f, 14 - e);
+}
+
+// k_wsplit16 ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wsplit16(WSplitArgs a) {
+    __shared__ unsigned mx[4];
+    int j = 0;
+    while (j + 1 < a.n_jobs && (int)blockIdx.x >= a.job[j + 1].wg0) ++j;
+    const WSplitJob& J = a.job[j];
+    const int local = (int)blockIdx.x - J.wg0;
+    const int n_cg = (J.n_chunks + 3) >> 2;
+    const int ct = local / n_cg, cg = local - ct * n_cg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mb = tid >> 4, cb = tid & 15;  // rows 4 mb .. + 3 of a 64-row half, outputs 4 cb .. + 3 of the column tile
+    const int K = J.K1 + J.K2;
+    if (tid < 4) mx[tid] = 0u;
+    __syncthreads();
+    // the two column pairs of this thread: where they come from is fixed for the whole workgroup
+    const float* src[2];
+    int64_t ld[2];
+    const int* gth[2];
+    int kind[2];  // 0: read, 1: (1, 0) — the bias column of ones, 2: zeros
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = 64 * ct + 4 * cb + 2 * h;
+        if (c < J.K1) { src[h] = J.A1 + c; ld[h] = J.lda1; gth[h] = J.g1; kind[h] = 0; }
+        else if (c < K) { src[h] = J.A2 + (c - J.K1); ld[h] = J.lda2; gth[h] = J.g2; kind[h] = 0; }
+        else { src[h] = J.A1; ld[h] = 0; gth[h] = nullptr; kind[h] = (J.ones && c == K) ? 1 : 2; }
+    }
+    float2 v[2][4][2];  // [half of 64 rows][row][column pair]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t m = (int64_t)128 * cg + 64 * q + 4 * mb + r;
+            const int64_t mc = m < J.M ? m : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t row = gth[h] ? (int64_t)gth[h][mc] : mc;
+                v[q][r][h] = *reinterpret_cast<const float2*>(src[h] + row * ld[h]);
+            }
+        }
+    float mloc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool mok = (int64_t)128 * cg + 64 * q + 4 * mb + r < J.M;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float2 x = v[q][r][h];
+                if (!mok || kind[h] == 2) x = make_float2(0.f, 0.f);
+                else if (kind[h] == 1) x = make_float2(1.f, 0.f);
+                v[q][r][h] = x;
+                mloc[q] = fmaxf(mloc[q], fmaxf(fabsf(x.x), fabsf(x.y)));
+            }
+        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float m = mloc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) atomicMax(&mx[2 * q + (wave >> 1)], __float_as_uint(m));  // (waves 0, 1 hold rows 0..31 of a half, waves 2, 3 rows 32..63)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int chunk = 4 * cg + 2 * q + (wave >> 1);
+        if (chunk >= J.n_chunks) continue;
+        const float s = scale_for(__uint_as_float(mx[2 * q + (wave >> 1)]));
+        unsigned char* blk = J.out + ((int64_t)ct * J.n_chunks + chunk) * kBlk;
+        const int p = (mb & 7) >> 1, sub = (mb & 1) * 8;  // 16-byte piece of the 4 reduction rows, and the half of it
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {  // the register transpose: 4 consecutive reduction rows of one output
+            const int n = 4 * cb + cc, key = (n >> 1) & 7;
+            float x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = ((cc & 1) ? v[q][r][cc >> 1].y : v[q][r][cc >> 1].x) * s;
+            const h4 hi = h4{(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+            const h4 lo = h4{(_Float16)(x[0] - (float)hi[0]), (_Float16)(x[1] - (float)hi[1]), (_Float16)(x[2] - (float)hi[2]), (_Float16)(x[3] - (float)hi[3])};
+            *reinterpret_cast<h4*>(blk + n * 128 + ((p ^ key) << 4) + sub) = hi;
+            *reinterpret_cast<h4*>(blk + n * 128 + (((p + 4) ^ key) << 4) + sub) = lo;
+        }
+        if ((tid & 127) == 0) J.scales[(int64_t)ct * J.n_chunks + chunk] = s;
+    }
+}
+
+// k_wgrad16 -------------------------------------------------------------------------------------------------------------
+constexpr int kStage = 2;  // chunks per stage
+
+__global__ __launch_bounds__(256) void k_wgrad16(WProdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage * kBlk];  // [Z blocks of the stage | A blocks of the stage]
+    const int tiles = a.n_nt * a.n_kt;
+    const int per = gridDim.x >> 3;  // XCD-aware order of the (split, tile) ranks: the workgroups of one row split share an L2
+    const int rank = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (rank >= tiles * a.splits) return;
+    const int split = rank / tiles, tile = rank - split * tiles;
+    const int nt = tile / a.n_kt, kt0 = tile - nt * a.n_kt;
+    const int c_lo = split * a.chunks_per_split;
+    const int c_hi = c_lo + a.chunks_per_split < a.n_chunks ? c_lo + a.chunks_per_split : a.n_chunks;
+    if (c_lo >= c_hi) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned char* Zb = a.Z + (int64_t)nt * a.n_chunks * kBlk;
+    const unsigned char* Ab = a.A + (int64_t)kt0 * a.n_chunks * kBlk;
+    const float* sz = a.sZ + (int64_t)nt * a.n_chunks;
+    const float* sa = a.sA + (int64_t)kt0 * a.n_chunks;
+    const rsrc_t rZ = gemm::make_rsrc(Zb, (unsigned)(a.n_chunks * kBlk)), rA = gemm::make_rsrc(Ab, (unsigned)(a.n_chunks * kBlk));
+    f32x4 acc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses inside a block: row (16 w + li | 16 kt + li), pieces lg (hi) and lg + 4 (lo), swizzled with (row >> 1) & 7
+    const int zrow = 16 * wave + li, zkey = (zrow >> 1) & 7;
+    const int zoff_h = zrow * 128 + ((lg ^ zkey) << 4), zoff_l = zrow * 128 + (((lg + 4) ^ zkey) << 4);
+    int aoff_h[4], aoff_l[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int arow = 16 * kt + li, akey = (arow >> 1) & 7;
+        aoff_h[kt] = arow * 128 + ((lg ^ akey) << 4);
+        aoff_l[kt] = arow * 128 + (((lg + 4) ^ akey) << 4);
+    }
+    for (int c = c_lo; c < c_hi; c += kStage) {
+        const int nst = c_hi - c < kStage ? c_hi - c : kStage;
+        // both operands' blocks of the stage: contiguous in memory, 1 KiB per wave instruction
+        for (int i = wave; i < nst * 8; i += 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rZ, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
+                                                     (unsigned)(c * kBlk + i * 1024 + lane * 16), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(lds + kStage * kBlk + i * 1024), 16,
+                                                     (unsigned)(c * kBlk + i * 1024 + lane * 16), 0, 0, 0);
+        }
+        float inv[kStage];
+#pragma unroll
+        for (int s = 0; s < kStage; ++s) inv[s] = s < nst ? 1.f / (sz[c + s] * sa[c + s]) : 0.f;
+        __syncthreads();  // (the barrier's release waits for the DMA)
+#pragma unroll
+        for (int s = 0; s < kStage; ++s) {
+            if (s < nst) {
+                const unsigned char* zb = lds + s * kBlk;
+                const unsigned char* ab = lds + kStage * kBlk + s * kBlk;
+                const h8 ah = *reinterpret_cast<const h8*>(zb + zoff_h), al = *reinterpret_cast<const h8*>(zb + zoff_l);
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const h8 bh = *reinterpret_cast<const h8*>(ab + aoff_h[kt]), bl = *reinterpret_cast<const h8*>(ab + aoff_l[kt]);
+                    f32x4 p = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, p, 0, 0, 0);
+                    p = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, p, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[kt][r] = fmaf(p[r], inv[s], acc[kt][r]);
+                }
+            }
+        }
+        __syncthreads();  // (every wave is done with the stage before the next DMA overwrites it)
+    }
+    // D fragment: lane (li, lg) holds rows 16 wave + 4 lg + r, column 16 kt + li of the tile
+    float* slab = a.slab + (int64_t)split * a.slab_stride;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 64 * nt + 16 * wave + 4 * lg + r, k = 64 * kt0 + 16 * kt + li;
+            if (n < a.N && k < a.Kt) slab[(int64_t)n * a.ldk + k] = acc[kt][r];
+        }
+}
+
+}  // namespace wg16
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+size_t wsplit16_bytes(int64_t M, int64_t C) {  // one operand: blocks + scales
+    const int64_t n_ct = (C + 63) / 64, n_chunks = (M + 31) / 32;
+    return (size_t)(n_ct * n_chunks) * wg16::kBlk + (((size_t)(n_ct * n_chunks) * 4 + 255) & ~size_t(255));
+}
+
+void wsplit16_job(WSplitJob* j, int64_t M, int C, const float* A1, int64_t lda1, const int* g1, int K1, const float* A2, int64_t lda2,
+                  const int* g2, int K2, int ones, void* ws) {
+    memset(j, 0, sizeof(*j));
+    j->M = M; j->C = C;
+    j->A1 = A1; j->lda1 = lda1; j->g1 = g1; j->K1 = K1;
+    j->A2 = K2 ? A2 : A1; j->lda2 = K2 ? lda2 : lda1; j->g2 = K2 ? g2 : g1; j->K2 = K2;
+    j->ones = ones;
+    j->n_ct = (C + 63) / 64; j->n_chunks = (int)((M + 31) / 32);
+    j->out = static_cast<unsigned char*>(ws);
+    j->scales = reinterpret_cast<float*>(j->out + (size_t)j->n_ct * j->n_chunks * wg16::kBlk);
+}
+
+int launch_wsplit16(WSplitArgs& a, hipStream_t s) {
+    int total = 0;
+    for (int i = 0; i < a.n_jobs; ++i) {
+        a.job[i].wg0 = total;
+        total += a.job[i].n_ct * ((a.job[i].n_chunks + 3) / 4);
+    }
+    if (total == 0) return DMPNN_OK;
+    hipLaunchKernelGGL(wg16::k_wsplit16, dim3((unsigned)total), dim3(256), 0, s, a);
+    DMPNN_CHECK_LAUNCH("k_wsplit16");
+    return DMPNN_OK;
+}
+
+// rows of both operands must be 8-byte loadable as pairs of columns: even column counts and leading dimensions, 8-byte aligned bases
+bool wgrad16_operand_ok(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2) {
+    auto ok8 = [](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0 && ld % 2 == 0; };
+    if (K1 <= 0 || K1 % 2 || !ok8(A1, lda1)) return false;
+    if (K2 > 0 && (K2 % 2 || !ok8(A2, lda2))) return false;
+    return true;
+}
+
+// the product of two split operands (Z: [M][N], A: [M][Kt]) into `splits` slabs; chunks_per_split a multiple of the stage
+WProdPlan plan_wgrad16(int64_t M, int N, int Kt) {
+    WProdPlan p;
+    p.n_nt = (N + 63) / 64; p.n_kt = (Kt + 63) / 64; p.n_chunks = (int)((M + 31) / 32);
+    static const int target = [] { const char* e = getenv("DMPNN_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+    int splits = target / (p.n_nt * p.n_kt);
+    if (splits < 1) splits = 1;
+    int cps = (p.n_chunks + splits - 1) / splits;
+    cps = (cps + wg16::kStage - 1) / wg16::kStage * wg16::kStage;
+    if (cps < wg16::kStage) cps = wg16::kStage;
+    p.chunks_per_split = cps;
+    p.splits = (p.n_chunks + cps - 1) / cps;
+    if (p.splits < 1) p.splits = 1;
+    p.ldk = (Kt + 3) / 4 * 4;
+    p.slab_stride = (int64_t)N * p.ldk;
+    return p;
+}
+
+int launch_wgrad16(const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab, hipStream_t s) {
+    WProdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Z = Z.out; a.sZ = Z.scales; a.A = A.out; a.sA = A.scales;
+    a.n_nt = p.n_nt; a.n_kt = p.n_kt; a.n_chunks = p.n_chunks; a.chunks_per_split = p.chunks_per_split; a.splits = p.splits;
+    a.N = N; a.Kt = Kt; a.slab = slab; a.ldk = p.ldk; a.slab_stride = p.slab_stride;
+    const int total = p.n_nt * p.n_kt * p.splits;
+    hipLaunchKernelGGL(wg16::k_wgrad16, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, s, a);
+    DMPNN_CHECK_LAUNCH("k_wgrad16");
+    return DMPNN_OK;
+}
+
+}  // namespace dmpnn
