@@ -814,9 +814,13 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             ReduceJobs rj;
             memset(&rj, 0, sizeof(rj));
             rj.poison_flags = pflags; rj.poison_mask = pmask;
+            WProdJobs pj;
+            memset(&pj, 0, sizeof(pj));
+            for (int i = 0; i < 3; ++i)  // (the big product first: the small ones fill its tail)
+                if (want[(i + 1) % 3]) wgrad16_add(&pj, *Zj[(i + 1) % 3], *Aj[(i + 1) % 3], L.q[(i + 1) % 3], (int)h, Ks[(i + 1) % 3], ws + L.w16_slab[(i + 1) % 3]);
+            DMPNN_TRY(launch_wgrad16(pj, s));  // the three products in one launch
             for (int i = 0; i < 3; ++i) {
                 if (!want[i]) continue;
-                DMPNN_TRY(launch_wgrad16(*Zj[i], *Aj[i], L.q[i], (int)h, Ks[i], ws + L.w16_slab[i], s));
                 ReduceJob& r = rj.job[rj.n_jobs];
                 r.slab = ws + L.w16_slab[i]; r.slab_stride = L.q[i].slab_stride; r.n_slabs = L.q[i].splits; r.ldk = L.q[i].ldk;
                 r.N = (int)h; r.K = Ks[i] - ones[i]; r.ones = ones[i]; r.gW = gWs[i]; r.ldgw = ldg[i]; r.gb = gbs[i];

@@ -194,6 +194,7 @@ bool mega_shapes_ok(const dmpnn_fwd_args& a);
 int launch_mega_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
 // the same on the f16 matrix pipe with the exact 3-term split (dmpnn_mega16.hip)
 size_t mega16_wsplit_bytes(const dmpnn_fwd_args& a);
+size_t mega16_fwd_wsplit_bytes(const dmpnn_fwd_args& a);
 // per-step split-MFMA contraction (dmpnn_rows16.hip): pre-split weights of one matrix, shape gate, launch
 struct SplitWView { const unsigned char* p; const float* inv_scale; int nc; };
 size_t linear16_wsplit_bytes(int64_t N, int64_t K);
@@ -222,13 +223,15 @@ struct WProdArgs {
     int N, Kt; float* slab; int ldk; int64_t slab_stride;
 };
 struct WProdPlan { int n_nt, n_kt, n_chunks, chunks_per_split, splits, ldk; int64_t slab_stride; };
+struct WProdJobs { WProdArgs job[4]; int wg0[5]; int n_jobs; };  // several products in one launch: job j owns workgroups [wg0[j], wg0[j + 1]), multiples of 8
 size_t wsplit16_bytes(int64_t M, int64_t C);
 void wsplit16_job(WSplitJob* j, int64_t M, int C, const float* A1, int64_t lda1, const int* g1, int K1, const float* A2, int64_t lda2,
                   const int* g2, int K2, int ones, void* ws);
 int launch_wsplit16(WSplitArgs& a, hipStream_t s);
 bool wgrad16_operand_ok(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2);
 WProdPlan plan_wgrad16(int64_t M, int N, int Kt);
-int launch_wgrad16(const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab, hipStream_t s);
+void wgrad16_add(WProdJobs* jobs, const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab);
+int launch_wgrad16(const WProdJobs& jobs, hipStream_t s);
 int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s);
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);

@@ -44,7 +44,12 @@ WsLayout ws_layout(const dmpnn_fwd_args& a) {
 }
 }  // namespace
 
-size_t mega16_wsplit_bytes(const dmpnn_fwd_args& a) { return ws_layout(a).total; }
+// (a training forward — DMPNN_F_KEEP — also splits the two transposed matrices of the backward tile kernel: one launch for both
+//  passes; the backward finds them behind the forward's own part)
+size_t mega16_wsplit_bytes(const dmpnn_fwd_args& a) {
+    return ws_layout(a).total + ((a.flags & DMPNN_F_KEEP) ? mega16_bwd_wsplit_bytes(a.d_h) : 0);
+}
+size_t mega16_fwd_wsplit_bytes(const dmpnn_fwd_args& a) { return ws_layout(a).total; }
 
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s) {
     const int64_t nV = a.n_atoms, nE = a.n_edges;
@@ -65,7 +70,16 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     sp.job[1] = mega16::SplitJob{a.W_h, N, 0, N, 0, N, ws + W.wh, W.nc_h, reinterpret_cast<float*>(ws + W.sc_h)};
     sp.job[2] = mega16::SplitJob{a.W_o, dv + N, dv, N, 0, dv + N, ws + W.wom, W.nc_h, reinterpret_cast<float*>(ws + W.sc_o)};
     sp.job[3] = mega16::SplitJob{a.W_o, dv + N, 0, dv, 0, dv + N, ws + W.wov, W.nc_v, nullptr};
-    hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)(((N + 15) / 16) * 16)), dim3(256), 0, s, sp);  // 4 jobs x whole column tiles, 4 waves per block
+    if ((a.flags & DMPNN_F_KEEP) && a.wsplit_bytes >= W.total + mega16_bwd_wsplit_bytes(N)) {
+        // W'[n][k] = W_o[k][d_v + n]  and  W'[n][k] = W_h[k][n]: what k_mpnn_tile16_bwd contracts with, read transposed
+        const size_t NT = (size_t)(N + 15) / 16, nch = (size_t)(N + 31) / 32;
+        const size_t one = al256(NT * nch * 2048) + al256((size_t)N * 4);
+        unsigned char* wb = ws + W.total;
+        sp.job[4] = mega16::SplitJob{a.W_o + dv, dv + N, 0, N, 0, N, wb, (int)nch, reinterpret_cast<float*>(wb + al256(NT * nch * 2048)), 1};
+        sp.job[5] = mega16::SplitJob{a.W_h, N, 0, N, 0, N, wb + one, (int)nch, reinterpret_cast<float*>(wb + one + al256(NT * nch * 2048)), 1};
+        sp.n_jobs = 6;
+    }
+    hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)(((N + 15) / 16) * 4 * sp.n_jobs)), dim3(256), 0, s, sp);  // jobs x whole column tiles, 4 waves per block
     DMPNN_CHECK_LAUNCH("k_split_weights");
     }
 

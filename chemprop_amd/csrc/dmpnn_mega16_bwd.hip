@@ -25,7 +25,12 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
                            float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s) {
     const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dv = f.d_v;
     const size_t NT = (size_t)(h + 15) / 16, nc = (size_t)(h + 31) / 32;
-    unsigned char* ws = static_cast<unsigned char*>(wsplit);
+    // the training forward already split both matrices behind its own pre-split weights (one launch for both passes) — unless the
+    // caller vouched for a cached pre-split (DMPNN_F_WSPLIT_READY), which says nothing about this part
+    const size_t fwd_part = mega16_fwd_wsplit_bytes(f);
+    const bool from_fwd = (f.flags & DMPNN_F_KEEP) && !(f.flags & DMPNN_F_WSPLIT_READY) && f.wsplit &&
+                          f.wsplit_bytes >= fwd_part + mega16_bwd_wsplit_bytes(h);
+    unsigned char* ws = from_fwd ? static_cast<unsigned char*>(f.wsplit) + fwd_part : static_cast<unsigned char*>(wsplit);
     const size_t one = al256b(NT * nc * 2048) + al256b((size_t)h * 4);
     float* inv_o = reinterpret_cast<float*>(ws + al256b(NT * nc * 2048));
     float* inv_h = reinterpret_cast<float*>(ws + one + al256b(NT * nc * 2048));
@@ -35,9 +40,11 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     // W'[n][k] = W_o[k][d_v + n]  and  W'[n][k] = W_h[k][n]: the matrices are read transposed
     sp.job[0] = mega16::SplitJob{f.W_o + dv, (int)(dv + h), 0, (int)h, 0, (int)h, ws, (int)nc, inv_o, 1};
     sp.job[1] = mega16::SplitJob{f.W_h, (int)h, 0, (int)h, 0, (int)h, ws + one, (int)nc, inv_h, 1};
-    const unsigned waves = 2u * (unsigned)(((h + 15) / 16) * 16);
-    hipLaunchKernelGGL(mega16::k_split_weights, dim3((waves + 3) / 4), dim3(256), 0, s, sp);
-    DMPNN_CHECK_LAUNCH("k_split_weights");
+    if (!from_fwd) {
+        const unsigned waves = 2u * (unsigned)(((h + 15) / 16) * 16);
+        hipLaunchKernelGGL(mega16::k_split_weights, dim3((waves + 3) / 4), dim3(256), 0, s, sp);
+        DMPNN_CHECK_LAUNCH("k_split_weights");
+    }
 
     const PlanLayout L = plan_layout(nV, nE);
     const int* plan_i = static_cast<const int*>(f.plan);

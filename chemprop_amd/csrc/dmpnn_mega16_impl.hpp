@@ -74,7 +74,7 @@ struct SplitJob {
     int tr;                                     // 1: the matrix is given transposed, element (n, k) = W[k * ldw + n]
 };
 struct SplitArgs {
-    SplitJob job[4];
+    SplitJob job[6];
     int n_jobs, N;
 };
 static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {

@@ -128,11 +128,15 @@ __global__ __launch_bounds__(256) void k_wsplit16(WSplitArgs a) {
 // k_wgrad16 -------------------------------------------------------------------------------------------------------------
 constexpr int kStage = 2;  // chunks per stage
 
-__global__ __launch_bounds__(256) void k_wgrad16(WProdArgs a) {
+__global__ __launch_bounds__(256) void k_wgrad16(WProdJobs jobs) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage * kBlk];  // [Z blocks of the stage | A blocks of the stage]
+    int j = 0;
+    while (j + 1 < jobs.n_jobs && (int)blockIdx.x >= jobs.wg0[j + 1]) ++j;
+    const WProdArgs& a = jobs.job[j];
+    const int local = (int)blockIdx.x - jobs.wg0[j];  // (wg0 is a multiple of 8: local & 7 is still the XCD)
     const int tiles = a.n_nt * a.n_kt;
-    const int per = gridDim.x >> 3;  // XCD-aware order of the (split, tile) ranks: the workgroups of one row split share an L2
-    const int rank = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const int per = (jobs.wg0[j + 1] - jobs.wg0[j]) >> 3;  // XCD-aware order of the (split, tile) ranks: the workgroups of one row split share an L2
+    const int rank = (local & 7) * per + (local >> 3);
     if (rank >= tiles * a.splits) return;
     const int split = rank / tiles, tile = rank - split * tiles;
     const int nt = tile / a.n_kt, kt0 = tile - nt * a.n_kt;
@@ -260,14 +264,20 @@ WProdPlan plan_wgrad16(int64_t M, int N, int Kt) {
     return p;
 }
 
-int launch_wgrad16(const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab, hipStream_t s) {
-    WProdArgs a;
+void wgrad16_add(WProdJobs* jobs, const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab) {
+    WProdArgs& a = jobs->job[jobs->n_jobs];
     memset(&a, 0, sizeof(a));
     a.Z = Z.out; a.sZ = Z.scales; a.A = A.out; a.sA = A.scales;
     a.n_nt = p.n_nt; a.n_kt = p.n_kt; a.n_chunks = p.n_chunks; a.chunks_per_split = p.chunks_per_split; a.splits = p.splits;
     a.N = N; a.Kt = Kt; a.slab = slab; a.ldk = p.ldk; a.slab_stride = p.slab_stride;
     const int total = p.n_nt * p.n_kt * p.splits;
-    hipLaunchKernelGGL(wg16::k_wgrad16, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, s, a);
+    jobs->wg0[jobs->n_jobs + 1] = jobs->wg0[jobs->n_jobs] + (total + 7) / 8 * 8;
+    ++jobs->n_jobs;
+}
+
+int launch_wgrad16(const WProdJobs& jobs, hipStream_t s) {
+    if (jobs.n_jobs == 0) return DMPNN_OK;
+    hipLaunchKernelGGL(wg16::k_wgrad16, dim3((unsigned)jobs.wg0[jobs.n_jobs]), dim3(256), 0, s, jobs);
     DMPNN_CHECK_LAUNCH("k_wgrad16");
     return DMPNN_OK;
 }

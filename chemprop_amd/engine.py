@@ -520,6 +520,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if use_mega:
             a.flags |= F_MEGA
         a.flags |= F_SPLIT16
+        if keep:
+            a.flags |= F_KEEP  # (the size below then includes the backward tile kernel's two transposed matrices)
         nb = int(lib.dmpnn_forward_wsplit_bytes(C.byref(a)))
         # pre-split weights are reusable while the weight tensors are the same objects at the same
         # autograd version (every in-place update bumps `_version`): inference with frozen weights
