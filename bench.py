@@ -519,6 +519,25 @@ def main():
                         oc[name]["f16_storage_route"] = m2.__dict__.get("_dmpnn_route")
                     finally:
                         os.environ["DMPNN_STORE"] = "f32"
+                    if kind == "synth40":
+                        # BASELINE configs[3] is a TRAINING workload: forward (kept tensors) + backward + fused Adam of this shape
+                        from chemprop_amd import distributed as ddp2
+                        from chemprop_amd.optim import FlatAdam as FlatAdam2
+
+                        m3 = BondMessagePassing(**kw).to(dev).train()
+                        s3 = ddp2.GradSync(list(m3.parameters()), modules=[m3])
+                        o3 = FlatAdam2(s3, lr=1e-4)
+                        G3 = torch.randn(int(b2.V.shape[0]), m3.output_dim, device=dev)
+
+                        def f3():
+                            m3(b2).backward(G3)
+                            s3.allreduce()
+                            o3.step()
+                        run_steps(f3, 3)
+                        t4 = time_events(f3, 10, torch)
+                        oc[name]["train_step_us"] = round(t4 * 1e3, 1)
+                        oc[name]["train_M_edge_updates_per_s"] = round(e2 * (m3.depth - 1) / (t4 * 1e3), 1)
+                        del m3, s3, o3, G3
                     del b2, m2
                 except Exception as e:
                     oc[name] = {"error": f"{type(e).__name__}: {e}"[:200]}

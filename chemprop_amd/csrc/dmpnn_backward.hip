@@ -493,9 +493,15 @@ __global__ void k_wgrad_reduce_multi(ReduceJobs a) {
     }
 }
 
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 struct WgradPlan {
     int splits, rows_per_wg, ldk;
     int64_t slab_stride;
+    // the same product on the f16 pipe (dmpnn_wgrad16.hip: operands split once, then LDS-DMA + 3-pass MFMA) where it pays — from
+    // ~1 k reduction rows on; taken at launch when the operands allow it (pairs of columns 8-byte loadable), else the fp32 kernel
+    bool can16; WProdPlan q; size_t split_floats;
+    int max_splits() const { return can16 && q.splits > splits ? q.splits : splits; }
 };
 WgradPlan plan_wgrad(int64_t M, int N, int Kt) {
     WgradPlan p;
@@ -512,13 +518,37 @@ WgradPlan plan_wgrad(int64_t M, int N, int Kt) {
     p.rows_per_wg = (int)rows;
     p.ldk = (Kt + 3) / 4 * 4;
     p.slab_stride = (int64_t)N * p.ldk;
+    static const bool on16 = [] { const char* e = getenv("DMPNN_WGRAD16"); return !(e && e[0] == '0'); }();
+    p.can16 = on16 && M >= 1024 && N % 2 == 0;
+    p.q = plan_wgrad16(M, N, Kt);
+    p.split_floats = p.can16 ? align_up((wsplit16_bytes(M, N) + 3) / 4, 64) + align_up((wsplit16_bytes(M, Kt) + 3) / 4, 64) : 0;
     return p;
 }
 
-int launch_wgrad(WgradArgs a, const WgradPlan& p, float* slab, hipStream_t s) {
+// -> *n_slabs (when given): how many slabs were written (the f16 and the fp32 kernel split the rows differently)
+int launch_wgrad(WgradArgs a, const WgradPlan& p, float* slab, hipStream_t s, float* split_ws = nullptr, int* n_slabs = nullptr) {
+    if (n_slabs) *n_slabs = p.splits;
     if (a.N == 0) return DMPNN_OK;
     const int Kt = a.K1 + a.K2 + a.ones;
     if (Kt == 0) return DMPNN_OK;
+    if (p.can16 && split_ws && n_slabs && aligned16(split_ws) && wgrad16_operand_ok(a.gZ, a.ldz, a.N, nullptr, 0, 0) &&
+        ((a.K1 > 0 && wgrad16_operand_ok(a.A1, a.lda1, a.K1, a.A2, a.lda2, a.K2)) ||
+         (a.K1 == 0 && wgrad16_operand_ok(a.A2, a.lda2, a.K2, nullptr, 0, 0)))) {
+        WSplitArgs sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.n_jobs = 2;
+        wsplit16_job(&sp.job[0], a.M, a.N, a.gZ, a.ldz, nullptr, a.N, nullptr, 0, nullptr, 0, 0, split_ws);
+        float* aw = split_ws + align_up((wsplit16_bytes(a.M, a.N) + 3) / 4, 64);
+        if (a.K1 > 0) wsplit16_job(&sp.job[1], a.M, Kt, a.A1, a.lda1, a.gather1, a.K1, a.A2, a.lda2, a.gather2, a.K2, a.ones, aw);
+        else wsplit16_job(&sp.job[1], a.M, Kt, a.A2, a.lda2, a.gather2, a.K2, nullptr, 0, nullptr, 0, a.ones, aw);
+        DMPNN_TRY(launch_wsplit16(sp, s));
+        WProdJobs pj;
+        memset(&pj, 0, sizeof(pj));
+        wgrad16_add(&pj, sp.job[0], sp.job[1], p.q, a.N, Kt, slab);
+        DMPNN_TRY(launch_wgrad16(pj, s));
+        *n_slabs = p.q.splits;
+        return DMPNN_OK;
+    }
     a.slab = slab; a.ldk = p.ldk; a.slab_stride = p.slab_stride; a.rows_per_wg = p.rows_per_wg;
     a.vecZ = aligned16(a.gZ) && a.ldz % 4 == 0;
     a.vecA = (a.K1 == 0 || (aligned16(a.A1) && a.lda1 % 4 == 0)) && a.K1 % 4 == 0 &&
@@ -555,8 +585,6 @@ int launch_wgrad_reduce(const float* slab, const WgradPlan& p, int n_slabs, int 
     return DMPNN_OK;
 }
 
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
 struct BwdLayout {
     size_t gZa, gZb, gH0, gZO, gMv, gHO, WhT, WoT, WdT, slab_h, slab_x, total;
     size_t WhT16, WoT16;  // pre-split transposed weights of the data-gradient contractions on the f16 pipe (large batches)
@@ -568,6 +596,7 @@ struct BwdLayout {
     WgradPlan p_hm;       // backward tile kernel: gW_h over ALL steps' rows in one launch (the gZ^(t) / M^(t) slots are adjacent)
     // backward tile kernel: the three weight gradients on the f16 pipe (dmpnn_wgrad16.hip): six split operands + slabs
     bool w16;
+    size_t w16g;                              // per-step path: split operands of one product at a time
     size_t w16_z[3], w16_a[3], w16_slab[3];   // o, h, i (float offsets)
     WProdPlan q[3];
 };
@@ -592,11 +621,11 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     const int steps = f.depth > 1 ? f.depth - 1 : 1;
     L.p_hm = plan_wgrad(nE * steps, (int)h, (int)h + (f.b_h ? 1 : 0));
     {
-        const size_t per_step = (size_t)L.p_h.splits * steps * L.p_h.slab_stride, merged = (size_t)L.p_hm.splits * L.p_hm.slab_stride;
+        const size_t per_step = (size_t)L.p_h.max_splits() * steps * L.p_h.slab_stride, merged = (size_t)L.p_hm.max_splits() * L.p_hm.slab_stride;
         L.slab_h = o; o += align_up(per_step > merged ? per_step : merged, 4);
     }
-    size_t x = (size_t)L.p_i.splits * L.p_i.slab_stride;
-    const size_t xo = (size_t)L.p_o.splits * L.p_o.slab_stride, xd = dvd ? (size_t)L.p_d.splits * L.p_d.slab_stride : 0;
+    size_t x = (size_t)L.p_i.max_splits() * L.p_i.slab_stride;
+    const size_t xo = (size_t)L.p_o.max_splits() * L.p_o.slab_stride, xd = dvd ? (size_t)L.p_d.max_splits() * L.p_d.slab_stride : 0;
     if (xo > x) x = xo;
     if (xd > x) x = xd;
     L.slab_x = o; o += align_up(x, 4);
@@ -622,6 +651,12 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
         L.mega_w = o; o += align_up((mega16_bwd_wsplit_bytes(h) + 3) / 4, 64);
         if (f.depth - 1 > 2) { L.gZs = o; o += (size_t)(f.depth - 1) * edge; }
         L.sp_gM = o; o += edge;
+    }
+    // split operands of ONE product at a time on the per-step path (the products run one after the other on the stream)
+    {
+        size_t m = L.p_h.split_floats;
+        for (size_t v : {L.p_i.split_floats, L.p_o.split_floats, dvd ? L.p_d.split_floats : (size_t)0, L.p_hm.split_floats}) m = v > m ? v : m;
+        L.w16g = o; o += m;
     }
     L.w16 = false;
     {
@@ -683,7 +718,7 @@ int dmpnn_aggregate_bwd(const void* plan, int64_t n_atoms, int64_t n_edges, int6
 
 size_t dmpnn_linear_wgrad_ws_bytes(int64_t M, int64_t N, int64_t K, int has_bias) {
     const WgradPlan p = plan_wgrad(M, (int)N, (int)K + (has_bias ? 1 : 0));
-    return (size_t)p.splits * p.slab_stride * sizeof(float);
+    return (align_up((size_t)p.max_splits() * p.slab_stride, 64) + p.split_floats) * sizeof(float);  // slabs | split operands (f16 pipe)
 }
 
 /* gW[N, K1+K2] = gZ^T . [A1[gather] || A2],  gb[N] = colsum(gZ)   (either output may be NULL) */
@@ -695,7 +730,8 @@ int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, 
     const int K = (int)(g->K1 + g->K2);
     const int ones = gb ? 1 : 0;
     const WgradPlan p = plan_wgrad(g->M, (int)g->N, K + ones);
-    if (ws_bytes < (size_t)p.splits * p.slab_stride * sizeof(float)) {
+    const size_t slab_floats = align_up((size_t)p.max_splits() * p.slab_stride, 64);
+    if (ws_bytes < (slab_floats + p.split_floats) * sizeof(float)) {
         set_error("linear_wgrad: workspace too small");
         return DMPNN_ENOSPC;
     }
@@ -710,8 +746,9 @@ int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, 
     a.gZ = gZ; a.ldz = ldgz;
     a.A1 = g->A1; a.lda1 = g->lda1; a.gather1 = g->gather1;
     a.A2 = g->A2; a.lda2 = g->lda2;
-    DMPNN_TRY(launch_wgrad(a, p, static_cast<float*>(ws), s));
-    return launch_wgrad_reduce(static_cast<float*>(ws), p, p.splits, (int)g->N, K, ones, gW, ldgw, gb, s);
+    int ns = 0;
+    DMPNN_TRY(launch_wgrad(a, p, static_cast<float*>(ws), s, p.split_floats ? static_cast<float*>(ws) + slab_floats : nullptr, &ns));
+    return launch_wgrad_reduce(static_cast<float*>(ws), p, ns, (int)g->N, K, ones, gW, ldgw, gb, s);
 }
 
 int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
@@ -769,8 +806,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             a.M = nV; a.N = (int)(h + dvd); a.K1 = (int)h; a.K2 = (int)dvd; a.ones = 1;
             a.gZ = b->gout; a.ldz = b->ldgout;
             a.A1 = f.Hv; a.lda1 = ldh; a.A2 = f.V_d; a.lda2 = f.ldvd;
-            DMPNN_TRY(launch_wgrad(a, L.p_d, slab_x, s));
-            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_d, L.p_d.splits, (int)(h + dvd), (int)(h + dvd), 1, b->gW_d, h + dvd, b->gb_d, s, pflags, pmask));
+            int ns = 0;
+            DMPNN_TRY(launch_wgrad(a, L.p_d, slab_x, s, ws + L.w16g, &ns));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_d, ns, (int)(h + dvd), (int)(h + dvd), 1, b->gW_d, h + dvd, b->gb_d, s, pflags, pmask));
         }
         // gHO = gout . W_d[:, :h]      via WdT[k][n] = W_d[n][k]
         DMPNN_TRY(launch_transpose(f.W_d, h + dvd, WdT, h + dvd, (int)(h + dvd), (int)h, s));
@@ -841,8 +879,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             memset(&a, 0, sizeof(a));
             a.M = nV; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)h; a.ones = 1;
             a.gZ = gZO; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.A2 = f.Mv; a.lda2 = ldh;
-            DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s));
-            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, L.p_o.splits, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s, pflags, pmask));
+            int ns = 0;
+            DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s, ws + L.w16g, &ns));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, ns, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s, pflags, pmask));
         }
         if (b->gW_h || b->gb_h) {
             if (T >= 2) {
@@ -853,8 +892,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
                 memset(&a, 0, sizeof(a));
                 a.M = nE * (T - 1); a.N = (int)h; a.K1 = (int)h; a.K2 = 0; a.ones = f.b_h ? 1 : 0;
                 a.gZ = gZs; a.ldz = ldh; a.A1 = f.Ms; a.lda1 = ldh;
-                DMPNN_TRY(launch_wgrad(a, L.p_hm, slab_h, s));
-                DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_hm, L.p_hm.splits, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s, pflags, pmask));
+                int ns = 0;
+                DMPNN_TRY(launch_wgrad(a, L.p_hm, slab_h, s, ws + L.w16g, &ns));
+                DMPNN_TRY(launch_wgrad_reduce(slab_h, L.p_hm, ns, (int)h, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h, s, pflags, pmask));
             } else {
                 zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h);
             }
@@ -865,8 +905,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             a.M = nE; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)de; a.ones = f.b_i ? 1 : 0;
             a.gZ = gH0; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.gather1 = pv.src; a.A2 = f.E; a.lda2 = f.lde;
             a.gather2 = e_gather;
-            DMPNN_TRY(launch_wgrad(a, L.p_i, slab_x, s));
-            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, L.p_i.splits, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s, pflags, pmask));
+            int ns = 0;
+            DMPNN_TRY(launch_wgrad(a, L.p_i, slab_x, s, ws + L.w16g, &ns));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, ns, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s, pflags, pmask));
         }
         return DMPNN_OK;
     }
@@ -886,8 +927,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         memset(&a, 0, sizeof(a));
         a.M = nV; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)h; a.ones = 1;
         a.gZ = gZO; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.A2 = f.Mv; a.lda2 = ldh;
-        DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s));
-        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, L.p_o.splits, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s, pflags, pmask));
+        int ns = 0;
+        DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s, ws + L.w16g, &ns));
+        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, ns, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s, pflags, pmask));
     }
     const bool need_edges = b->gW_i || b->gb_i || b->gW_h || b->gb_h;
     if (!need_edges) return DMPNN_OK;
@@ -943,8 +985,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
                 memset(&a, 0, sizeof(a));
                 a.M = nE; a.N = (int)h; a.K1 = (int)h; a.K2 = 0; a.ones = f.b_h ? 1 : 0;
                 a.gZ = gZ; a.ldz = ldh; a.A1 = Mt; a.lda1 = ldh;
-                DMPNN_TRY(launch_wgrad(a, L.p_h, slab_h + (int64_t)n_slabs_h * L.p_h.slab_stride, s));
-                n_slabs_h += L.p_h.splits;
+                int ns = 0;
+                DMPNN_TRY(launch_wgrad(a, L.p_h, slab_h + (int64_t)n_slabs_h * L.p_h.slab_stride, s, ws + L.w16g, &ns));
+                n_slabs_h += ns;
             }
             // gM = gZ . W_h
             dmpnn_gemm_args g;
@@ -992,8 +1035,9 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         a.M = nE; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)de; a.ones = f.b_i ? 1 : 0;
         a.gZ = gH0; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.gather1 = pv.src; a.A2 = f.E; a.lda2 = f.lde;
         a.gather2 = e_gather;
-        DMPNN_TRY(launch_wgrad(a, L.p_i, slab_x, s));
-        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, L.p_i.splits, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s, pflags, pmask));
+        int ns = 0;
+        DMPNN_TRY(launch_wgrad(a, L.p_i, slab_x, s, ws + L.w16g, &ns));
+        DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_i, ns, (int)h, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i, s, pflags, pmask));
     }
     return DMPNN_OK;
 }
