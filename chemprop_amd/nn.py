@@ -263,7 +263,8 @@ def _spill_monitor(mp, plan_buf: Tensor, dev) -> None:
         m.pending = False
         _note_spills(mp, m, int(m.host[8]))
     m.calls += 1
-    if not m.pending and (m.calls % 8 == 0 if m.calls <= 64 else m.calls % 64 == 0):
+    # (never while a hipGraph is being captured: the copy and the event would become nodes of the graph, and the event could not be queried)
+    if not m.pending and (m.calls % 8 == 0 if m.calls <= 64 else m.calls % 64 == 0) and not torch.cuda.is_current_stream_capturing():
         m.host.copy_(plan_buf[:16], non_blocking=True)
         m.event.record(torch.cuda.current_stream(dev))
         m.pending = True
