@@ -704,6 +704,37 @@ def test_whole_forward_properties_at_scale(kind, n_mols, kw, route, gpu_device):
     assert parity_err(sums_shuf.cpu().numpy(), sums_big[torch.from_numpy(perm).to(gpu_device)].cpu().numpy()) <= TOL
 
 
+@pytest.mark.parametrize("warm", [3, 7, 8])
+def test_steady_forward_under_hipgraph_capture(warm, gpu_device):
+    """The steady inference forward is capture safe at ANY call count (the C ABI neither allocates nor synchronises; the spill
+    monitor's occasional host copy must stay out of a capture): captured after `warm` eager calls, replayed, same bits."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    torch.manual_seed(9)
+    mp = BondMessagePassing().eval().to(gpu_device)
+    b = synth.random_batch(256, "qm9", seed=4)
+    b.to(gpu_device)
+    from chemprop_amd.data import BatchMolGraph
+
+    b = BatchMolGraph.from_tensors(b.V, b.E, b.edge_index, b.rev_edge_index, b.batch, len(b))  # (bare tensors: the monitor is live)
+    with torch.no_grad():
+        side = torch.cuda.Stream(device=gpu_device)
+        side.wait_stream(torch.cuda.current_stream(gpu_device))
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                eager = mp(b)
+        torch.cuda.current_stream(gpu_device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = mp(b)
+        g.replay()
+        torch.cuda.synchronize(gpu_device)
+        assert torch.equal(out, eager)
+        for _ in range(20):
+            assert torch.equal(mp(b), eager)      # and the eager path (monitor included) goes on working afterwards
+
+
 def test_cpu_tensors_fail_loudly(gpu_device):
     from chemprop_amd import synth
     from chemprop_amd.nn import BondMessagePassing
