@@ -96,10 +96,16 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    dev = torch.device("cuda", local_rank)
+    # (DMPNN_BENCH_BACKEND=gloo DMPNN_BENCH_DEVICE=0: a dry run of the N > 1 control flow on a one-GPU box — every rank on the same
+    #  device, collectives through the host; the numbers of such a run mean nothing)
+    backend = os.environ.get("DMPNN_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", int(os.environ.get("DMPNN_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     _lib.load()
 
     # ---- workload: this rank's shard (molecules hash-partitioned by id -> independent batches) ----
