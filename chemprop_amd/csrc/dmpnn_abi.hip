@@ -121,6 +121,23 @@ int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, const int
 
 int dmpnn_tile_plan_any_size(int64_t n_atoms, int64_t n_edges) { return tiles_large_fits(n_atoms, n_edges) ? 1 : 0; }
 
+int dmpnn_prepare_with_batch(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t n_atoms, int64_t n_edges,
+                             void* plan, size_t plan_bytes, void* stream) {
+    if (!batch || n_atoms <= 0 || n_edges <= 0 || small_plan_fits(n_atoms, n_edges) || !tiles_large_fits(n_atoms, n_edges) ||
+        !prepare_can_keep_mtiles(n_atoms, n_edges))
+        return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 0, stream);
+    DMPNN_TRY(check_graph_sizes(n_atoms, n_edges));
+    DMPNN_CHECK_ARG(plan != nullptr && aligned16(plan), "prepare_with_batch: plan must be a 16-byte aligned buffer");
+    DMPNN_CHECK_ARG(edge_index && rev, "prepare_with_batch: null index arrays");
+    if (plan_bytes < dmpnn_plan_bytes(n_atoms, n_edges)) {
+        set_error("prepare_with_batch: plan buffer too small (%zu < %zu bytes)", plan_bytes, dmpnn_plan_bytes(n_atoms, n_edges));
+        return DMPNN_ENOSPC;
+    }
+    // the tiles first (their scratch is the arrays the full plan fills afterwards), then the full plan around them
+    DMPNN_TRY(launch_prepare_tiles_large(edge_index, batch, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream)));
+    return launch_prepare(edge_index, rev, n_atoms, n_edges, static_cast<int*>(plan), 0, static_cast<hipStream_t>(stream), true);
+}
+
 int dmpnn_message_fwd(const void* plan, int64_t n_atoms, int64_t n_edges, int64_t d_h, const float* Hin,
                       int64_t ld_in, float* M, int64_t ld_m, int act_on_load, float act_slope,
                       const float* act_slope_ptr, unsigned flags, void* stream) {

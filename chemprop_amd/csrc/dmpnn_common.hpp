@@ -155,8 +155,11 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
 }
 
 // ---- host launchers implemented in the .hip files -------------------------------------------
+// keep_mtiles (batches beyond the single-workgroup plan only): launch_prepare_tiles_large wrote the molecule tiles of
+// this plan just before on the same stream — the full plan keeps and verifies them instead of writing "no piece tiles"
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV, int64_t nE, int* plan,
-                   int light, hipStream_t s);
+                   int light, hipStream_t s, bool keep_mtiles = false);
+bool prepare_can_keep_mtiles(int64_t nV, int64_t nE);
 int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s);
 // the same tables for batches beyond the single-workgroup plan (dmpnn_tiles_large.hip)
 bool tiles_large_fits(int64_t nV, int64_t nE);

@@ -26,12 +26,18 @@ namespace {
 
 constexpr int kBlock = 256;
 
-__global__ void k_plan_init(int* __restrict__ plan, int64_t cursor_off, int nV, int nE) {
+// keep_mtiles: the molecule tiles are already in the plan (launch_prepare_tiles_large ran before on the same stream):
+// their three header words survive — the verdict bit of the flag word, the tile count, the oversize count
+__global__ void k_plan_init(int* __restrict__ plan, int64_t cursor_off, int nV, int nE, int keep_mtiles) {
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (tid < DMPNN_HDR_WORDS) {
         int v = 0;
         if (tid == DMPNN_HDR_NATOMS) v = nV;
         if (tid == DMPNN_HDR_NEDGES) v = nE;
+        if (keep_mtiles) {
+            if (tid == DMPNN_HDR_FLAGS) v = plan[tid] & PLAN_NO_PIECE_TILES;
+            if (tid == DMPNN_HDR_NMTILES || tid == DMPNN_HDR_NSPILL) v = plan[tid];
+        }
         plan[tid] = v;
     }
     for (int64_t i = tid; i < nV; i += (int64_t)gridDim.x * blockDim.x) plan[cursor_off + i] = 0;
@@ -222,7 +228,13 @@ __device__ __forceinline__ void write_tiles(int* __restrict__ plan, const PlanLa
 }
 
 // CSR-row coordinates + tile tables + final header words (general path, after k_inverse).
-__global__ void k_rows_tiles(int* __restrict__ plan, PlanLayout L, int nV, int nE) {
+// keep_mtiles: the molecule tiles came from the batch vector (dmpnn_tiles_large.hip), in the caller's edge order; the
+// tile kernels read a FULL plan by rows, so a tile must also be the rows [row_ptr[first atom], row_ptr[end atom]) — which
+// it is when the edges come in molecule order (collate.py:51-56): verified here for every table slot — and closed: every
+// row's source atom inside the tile of its destination (with the reverse-edge invariants k_convert_count checks, the
+// reverse row is then inside too).  A violation sets DMPNN_PLAN_NO_PIECE_TILES: the tile kernels return NaN, the
+// per-step routes are untouched.
+__global__ void k_rows_tiles(int* __restrict__ plan, PlanLayout L, int nV, int nE, int keep_mtiles) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_threads = gridDim.x * blockDim.x;
     const int maxdeg = plan[DMPNN_HDR_MAXDEG];
@@ -235,13 +247,38 @@ __global__ void k_rows_tiles(int* __restrict__ plan, PlanLayout L, int nV, int n
         plan[L.ident + r] = r;
     }
     write_tiles(plan, L, plan + L.row_ptr, nV, nE, g, i, n_threads);
-    // piece tiles are built by the single-workgroup plan only (round 1): none here
-    for (int t = i; t < (int)L.max_mtiles + 2; t += n_threads) { plan[L.mtile_row + t] = nE; plan[L.mtile_atom + t] = nV; }
+    if (keep_mtiles) {
+        const int* matom = plan + L.mtile_atom;
+        const int* mrow = plan + L.mtile_row;
+        const int* row_ptr = plan + L.row_ptr;
+        const int nmt = plan[DMPNN_HDR_NMTILES];  // (not written by this kernel in this mode)
+        int bad = 0;
+        for (int t = i; t < (int)L.max_mtiles + 2; t += n_threads) {
+            const int a = matom[t];
+            if (a < 0 || a > nV || mrow[t] != row_ptr[a]) bad = 1;
+        }
+        if (nmt > 0) {
+            for (int r = i; r < nE; r += n_threads) {
+                const int e = plan[L.perm + r];
+                const int d = plan[L.dst + e], sa = plan[L.src + e];
+                int lo = 0, hi = nmt;  // last tile whose first atom is <= d (the table ends with the n_atoms sentinel)
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (matom[mid] <= d) lo = mid; else hi = mid;
+                }
+                if (sa < matom[lo] || sa >= matom[lo + 1]) bad = 1;
+            }
+        }
+        if (bad) atomicOr(&plan[DMPNN_HDR_FLAGS], PLAN_NO_PIECE_TILES);
+    } else {
+        // no batch vector: piece tiles are built by the single-workgroup plan only — none here
+        for (int t = i; t < (int)L.max_mtiles + 2; t += n_threads) { plan[L.mtile_row + t] = nE; plan[L.mtile_atom + t] = nV; }
+    }
     if (i == 0) {
         plan[DMPNN_HDR_NTILES] = g.n_tiles;
         plan[DMPNN_HDR_TILE_STRIDE] = g.b0;
-        plan[DMPNN_HDR_NMTILES] = 0;
-        atomicOr(&plan[DMPNN_HDR_FLAGS], PLAN_NO_PIECE_TILES | (maxdeg > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0));
+        if (!keep_mtiles) plan[DMPNN_HDR_NMTILES] = 0;
+        atomicOr(&plan[DMPNN_HDR_FLAGS], (keep_mtiles ? 0 : PLAN_NO_PIECE_TILES) | (maxdeg > kFusedMaxDeg ? PLAN_HUGE_DEGREE : 0));
     }
 }
 
@@ -815,8 +852,14 @@ int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, 
     return DMPNN_OK;
 }
 
+// (the scan's per-block scratch moves to the row-tile table in that mode: it must hold one int per scan block)
+bool prepare_can_keep_mtiles(int64_t nV, int64_t nE) {
+    const PlanLayout L = plan_layout(nV, nE);
+    return (nV + kScanThreads * kScanItems - 1) / (kScanThreads * kScanItems) <= L.max_tiles + 2;
+}
+
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, int64_t nE64,
-                   int* plan, int light, hipStream_t s) {
+                   int* plan, int light, hipStream_t s, bool keep_mtiles) {
     const int nV = (int)nV64, nE = (int)nE64;
     const PlanLayout L = plan_layout(nV, nE);
     if (small_plan_fits(nV, nE)) {
@@ -841,7 +884,7 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
         const int64_t n = nV > DMPNN_HDR_WORDS ? nV : DMPNN_HDR_WORDS;
         int grid = (int)((n + kBlock - 1) / kBlock);
         if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(k_plan_init, dim3(grid), dim3(kBlock), 0, s, plan, L.cursor, nV, nE);
+        hipLaunchKernelGGL(k_plan_init, dim3(grid), dim3(kBlock), 0, s, plan, L.cursor, nV, nE, keep_mtiles ? 1 : 0);
         DMPNN_CHECK_LAUNCH("k_plan_init");
     }
     if (nE > 0) {
@@ -851,7 +894,8 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
     }
     {
         const int nblk = nV > 0 ? (nV + kScanThreads * kScanItems - 1) / (kScanThreads * kScanItems) : 1;
-        int* part = plan + L.mtile_row;  // scratch: one int per block (rewritten by k_rows_tiles)
+        // scratch: one int per block, in a table k_rows_tiles (re)writes at the end
+        int* part = plan + (keep_mtiles ? L.tile_row : L.mtile_row);
         if (nblk > 1) {
             hipLaunchKernelGGL(k_scan_totals, dim3(nblk), dim3(kScanThreads), 0, s, plan, L, nV, part);
             DMPNN_CHECK_LAUNCH("k_scan_totals");
@@ -874,7 +918,7 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV64, 
         int grid = (int)((n + kBlock - 1) / kBlock);
         if (grid < 1) grid = 1;
         if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(k_rows_tiles, dim3(grid), dim3(kBlock), 0, s, plan, L, nV, nE);
+        hipLaunchKernelGGL(k_rows_tiles, dim3(grid), dim3(kBlock), 0, s, plan, L, nV, nE, keep_mtiles ? 1 : 0);
         DMPNN_CHECK_LAUNCH("k_rows_tiles");
     }
     return DMPNN_OK;

@@ -139,7 +139,11 @@ class GraphPlan:
                and bool(lib.dmpnn_tile_plan_any_size(n_atoms, n_edges)))
         self.tiles_only = light == "tiles" and (small or self.loader_tiles > 0 or big)
         self.light = bool(light) and (small or self.loader_tiles > 0 or big)
-        self.any_size = self.tiles_only and not small  # (the forward's DMPNN_F_LOADER_TILES)
+        # a FULL plan beyond the single-workgroup plan: with the batch vector it carries molecule tiles too
+        # (dmpnn_prepare_with_batch) — training on the tile kernels at any batch size
+        full_tiles = (not light and not small and bt is not None and n_atoms > 0 and n_edges > 0
+                      and _lib.opt("DMPNN_TRAIN_TILES", "1") != "0" and bool(lib.dmpnn_tile_plan_any_size(n_atoms, n_edges)))
+        self.any_size = (self.tiles_only and not small) or full_tiles  # (the forward's DMPNN_F_LOADER_TILES)
         self.edge_index, self.rev_edge_index = ei, rev
         with _OnDevice(dev):
             if self.loader_tiles:
@@ -150,6 +154,9 @@ class GraphPlan:
                 _lib.check(lib.dmpnn_prepare_tiles(ei.data_ptr(), rev.data_ptr(), bt.data_ptr() if bt is not None else None,
                                                    n_atoms, n_edges, self.buf.data_ptr(), nbytes, _stream_ptr(dev)),
                            "dmpnn_prepare_tiles")
+            elif full_tiles:
+                _lib.check(lib.dmpnn_prepare_with_batch(ei.data_ptr(), rev.data_ptr(), bt.data_ptr(), n_atoms, n_edges,
+                                                        self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare_with_batch")
             else:
                 prep = lib.dmpnn_prepare_light if self.light else lib.dmpnn_prepare
                 _lib.check(prep(ei.data_ptr(), rev.data_ptr(), n_atoms, n_edges,

@@ -132,7 +132,7 @@ class BondMessagePassing(EngineStateMixin, nn.Module):
         return bond_message_passing_forward(self, bmg, V_d)
 
 
-_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_TILE_PLAN", "DMPNN_VALIDATE", "DMPNN_STORE")
+_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_TILE_PLAN", "DMPNN_VALIDATE", "DMPNN_STORE", "DMPNN_TRAIN_TILES")
 
 
 class _Replay:
@@ -406,7 +406,8 @@ def _route(mp, plan, n_mols: int = 0, batch=None) -> int:
         if flags & 8:
             # no piece tiles: a molecule larger than a tile switches the tile kernel off for the module — but a batch
             # beyond the single-workgroup plan has none either way, which says nothing about its molecules
-            if engine.small_plan_fits(plan.n_atoms, plan.n_edges):
+            if engine.small_plan_fits(plan.n_atoms, plan.n_edges) or (getattr(plan, "any_size", False) and not plan.tiles_only):
+                # (a full plan with tiles from the batch vector, dmpnn_prepare_with_batch, carries the verdict itself)
                 object.__setattr__(mp, "_dmpnn_no_mega", True)
             elif batch is not None and not no_mega and _lib.load().dmpnn_tile_plan_any_size(plan.n_atoms, plan.n_edges):
                 # (validated batches only: the multi-workgroup tile planner's verdict on the molecule sizes of this batch)

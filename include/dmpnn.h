@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 6
+#define DMPNN_ABI_VERSION 7
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -71,8 +71,9 @@ enum dmpnn_flags {
                                      dmpnn_forward wrote for exactly these W_i / W_h / W_o values and shapes
                                      (the CALLER vouches for it, e.g. inference with frozen weights): the
                                      pre-split launch is skipped                                          */
-    DMPNN_F_LOADER_TILES = 1u << 6, /* `plan` is a tile plan of a batch of ANY size (dmpnn_prepare_tiles_from_table, or
-                                     dmpnn_prepare_tiles with a batch vector where dmpnn_tile_plan_any_size()):
+    DMPNN_F_LOADER_TILES = 1u << 6, /* `plan` carries molecule tiles for a batch of ANY size: a tile plan
+                                     (dmpnn_prepare_tiles_from_table, or dmpnn_prepare_tiles with a batch vector where
+                                     dmpnn_tile_plan_any_size()) or a full plan with tiles (dmpnn_prepare_with_batch):
                                      DMPNN_F_MEGA is not limited to batches the single-workgroup plan takes     */
     DMPNN_F_STORE16 = 1u << 7     /* OPT-IN, NOT fp32-class.  With DMPNN_F_FUSED | DMPNN_F_SPLIT16 (the per-step fused route):
                                      the message tensor between the depth steps is stored as ONE f16 per element with a
@@ -120,6 +121,18 @@ int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev_edge_index
  * it passes DMPNN_F_LOADER_TILES ("tile plan of any batch size") like one on a loader table.  Without a batch vector, or
  * when this returns 0, a batch beyond the single-workgroup plan gets the full plan, which has no piece tiles. */
 int dmpnn_tile_plan_any_size(int64_t n_atoms, int64_t n_edges);
+
+/* The FULL plan (as dmpnn_prepare) WITH molecule tiles at any batch size — what TRAINING on the tile kernels needs
+ * (DMPNN_F_MEGA | DMPNN_F_KEEP, then dmpnn_backward) beyond the single-workgroup plan, whose connectivity analysis stops
+ * at 10240 directed edges.  `batch` as for dmpnn_prepare_tiles.  Within the single-workgroup plan, or with batch == NULL,
+ * or where !dmpnn_tile_plan_any_size(): exactly dmpnn_prepare.  Otherwise the tiles come from the batch vector (the
+ * multi-workgroup planner of dmpnn_prepare_tiles) and the full plan's last kernel verifies, on the device, what a full
+ * plan's tiles must satisfy: every tile is the row range [row_ptr[first atom], row_ptr[end atom]) (true when the edges
+ * come in molecule order, data/collate.py:51-56) and every row's source atom lies in the tile of its destination; a
+ * violation sets DMPNN_PLAN_NO_PIECE_TILES (the tile kernels return NaN; every other route is unaffected).  A forward
+ * on such a plan passes DMPNN_F_LOADER_TILES.                                                                       */
+int dmpnn_prepare_with_batch(const int64_t* edge_index, const int64_t* rev_edge_index, const int64_t* batch, int64_t n_atoms,
+                             int64_t n_edges, void* plan, size_t plan_bytes, void* stream);
 
 /* Plan header words (int32) readable by the caller after a stream sync (diagnostics/tests). */
 enum dmpnn_plan_hdr {

@@ -459,6 +459,67 @@ def test_tile_plan_and_forward_on_caller_order_edges(golden, use_batch, gpu_devi
     assert closed.all() or "shuffled" in golden.name or "garbage" in golden.name, f"{golden.name}: unexpected open tiles"
 
 
+def test_full_plan_with_molecule_tiles_beyond_the_single_workgroup_plan(gpu_device, monkeypatch):
+    """dmpnn_prepare_with_batch: the FULL plan of a batch beyond the single-workgroup plan, with the molecule tiles of the
+    batch-vector planner in it — the tables of the tile plan of the same batch (a tile's first edge in the caller's order
+    IS its first row, collate.py:51-56), row_ptr-consistent; the same forward as the tile plan; training takes the tile
+    kernels.  A batch whose edges are not in molecule order, or with a bond between two molecules, has no piece tiles
+    (the tile kernels return NaN) and every other route is unaffected."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.engine import GraphPlan, small_plan_fits
+
+    bmg = synth.random_batch(1024, "qm9", seed=21)
+    bmg.to(gpu_device)
+    nV, nE = bmg.V.shape[0], bmg.E.shape[0]
+    assert not small_plan_fits(nV, nE)
+    full = GraphPlan.from_bmg(bmg)
+    lean = GraphPlan.from_bmg(bmg, light="tiles")
+    assert full.any_size and not full.tiles_only and not full.light and lean.tiles_only
+    af, al = full.arrays(), lean.arrays()
+    assert af["hdr"][0] == 0 and af["hdr"][7] == 0 and al["hdr"][0] == 16
+    assert af["hdr"][6] == al["hdr"][6] > 0 and af["hdr"][8] == al["hdr"][8] == 0
+    assert torch.equal(af["mtile_row"], al["mtile_row"]) and torch.equal(af["mtile_atom"], al["mtile_atom"])
+    n_t = int(af["hdr"][6])
+    assert torch.equal(af["mtile_row"][:n_t + 1].long(), af["row_ptr"][af["mtile_atom"][:n_t + 1].long()].long())
+    monkeypatch.setenv("DMPNN_TRAIN_TILES", "0")
+    plain = GraphPlan.from_bmg(bmg)
+    monkeypatch.delenv("DMPNN_TRAIN_TILES")
+    ap = plain.arrays()
+    assert not plain.any_size and ap["hdr"][0] == 8 and ap["hdr"][6] == 0
+    for k in ("src", "dst", "rev", "row_ptr", "perm", "inv", "srcp", "dstp", "revp", "tile_row", "tile_atom"):
+        assert torch.equal(af[k], ap[k]), k
+    torch.manual_seed(2)
+    W = dict(W_i=torch.randn(300, bmg.V.shape[1] + bmg.E.shape[1]) * 0.1, W_h=torch.randn(300, 300) * 0.05,
+             W_o=torch.randn(300, bmg.V.shape[1] + 300) * 0.05, b_o=torch.randn(300) * 0.1)
+    W = {k: v.to(gpu_device) for k, v in W.items()}
+    run = lambda plan, **kw: engine.forward(plan, bmg.V, bmg.E, W["W_i"], W["W_h"], W["W_o"], W["b_o"], None, None, depth=3, act="relu", **kw)
+    out_t, st_t = run(lean, route="mega", mfma="split16")
+    out_f, st_f = run(full, keep=True)
+    out_g, st_g = run(plain, keep=True)
+    assert st_t.route == st_f.route == "mega16" and st_g.route in ("general16", "fused")
+    assert parity_err(out_t.cpu().numpy(), out_f.cpu().numpy()) <= 3e-6  # (rows of a tile in the caller's order vs in row order)
+    assert parity_err(out_f.cpu().numpy(), out_g.cpu().numpy()) <= 3e-6
+
+    # a bond between two molecules of different tiles: no piece tiles
+    ei, rev, batch = bmg.edge_index.clone(), bmg.rev_edge_index.clone(), bmg.batch
+    e = int(nE // 2)
+    r = int(rev[e])
+    far = int(af["mtile_atom"][n_t - 1])  # an atom of the last tile
+    ei[0, e] = far
+    ei[1, r] = far
+    bad = GraphPlan(ei, rev, nV, batch=batch)
+    assert bad.any_size and bad.flags() & 8
+    out_b, st_b = run(bad, keep=True, max_level=1)
+    assert st_b.route in ("general16", "fused") and torch.isfinite(out_b).all()
+    # the edges of the batch in another order (pairs kept): row ranges no longer match the caller-order edge ranges
+    perm = torch.arange(nE, device=ei.device).view(-1, 2).flip(0).reshape(-1)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nE, device=ei.device)
+    ei2, rev2 = bmg.edge_index[:, perm].contiguous(), inv[bmg.rev_edge_index[perm]].contiguous()
+    bad2 = GraphPlan(ei2, rev2, nV, batch=batch)
+    assert bad2.flags() & 8 and not bad2.flags() & 7
+
+
 def test_module_switches_to_the_tile_plan_after_validation(gpu_device):
     from chemprop_amd import engine, synth
     from chemprop_amd.nn import BondMessagePassing, _tile_plan_ok
@@ -605,6 +666,8 @@ def test_relu_gradients_at_size(n_mols, kind, gpu_device):
     masks += [(to_edges(st.Hs[t][:, :300]) > 0).double().cpu() for t in range(2)]
     masks.append((out.detach() > 0).double().cpu())
     (out * G.to(gpu_device)).sum().backward()
+    if kind == "qm9":  # beyond the single-workgroup plan: the full plan carries molecule tiles (dmpnn_prepare_with_batch)
+        assert st.route == "mega16" and st.plan.any_size, st.route
 
     o64, _, pre, true_masks = forward64()
     assert parity_err(out.detach().cpu().numpy(), o64.detach().numpy()) <= TOL
@@ -813,6 +876,7 @@ def test_backward_matches_executed_reference(golden, gpu_device):
 
 @pytest.mark.parametrize("n_mols,kind,kw", [
     (512, "qm9", dict()),
+    (2048, "qm9", dict(activation="tanh", bias=True)),   # beyond the single-workgroup plan: tile kernels on a full plan with tiles
     # (smooth activation: at this size a single ReLU mask flip at |z| ~ 1e-8 between two fp32-class arithmetics moves
     #  a bias-gradient entry by ~1e-3 of the largest one, which says nothing about the kernels)
     (256, "synth40", dict(bias=True, undirected=True, activation="tanh")),
