@@ -500,7 +500,8 @@ def main():
             for name, kind, n_m, kw in (("zinc-512 h512 d6 (configs[2])", "zinc", 512, dict(d_h=512, depth=6)),
                                         ("synth40-512 (configs[3], 512 mols/GPU)", "synth40", 512, dict()),
                                         ("synth40-4096 (configs[3], 4096 mols/GPU)", "synth40", 4096, dict()),
-                                        ("cgr-512 (configs[4])", "cgr", 512, dict(d_v=106, d_e=28))):
+                                        ("cgr-512 (configs[4])", "cgr", 512, dict(d_v=106, d_e=28)),
+                                        ("qm9-4096 (the headline shape at 4096 mols/GPU)", "qm9", 4096, dict())):
                 try:
                     b2 = synth.random_batch(n_m, kind, seed=1)
                     b2.to(dev)
@@ -525,8 +526,9 @@ def main():
                         oc[name]["f16_storage_route"] = m2.__dict__.get("_dmpnn_route")
                     finally:
                         os.environ["DMPNN_STORE"] = "f32"
-                    if kind == "synth40":
+                    if kind in ("synth40", "qm9"):
                         # BASELINE configs[3] is a TRAINING workload: forward (kept tensors) + backward + fused Adam of this shape
+                        # (qm9-4096: beyond the single-workgroup plan — the tile kernels on a full plan with molecule tiles)
                         from chemprop_amd import distributed as ddp2
                         from chemprop_amd.optim import FlatAdam as FlatAdam2
 
@@ -543,6 +545,10 @@ def main():
                         t4 = time_events(f3, 10, torch)
                         oc[name]["train_step_us"] = round(t4 * 1e3, 1)
                         oc[name]["train_M_edge_updates_per_s"] = round(e2 * (m3.depth - 1) / (t4 * 1e3), 1)
+                        try:
+                            oc[name]["train_route"] = m3(b2).grad_fn.st.route   # (the forward state of the autograd node)
+                        except AttributeError:
+                            oc[name]["train_route"] = None
                         del m3, s3, o3, G3
                     del b2, m2
                 except Exception as e:

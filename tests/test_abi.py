@@ -124,6 +124,13 @@ def test_tile_plans_of_any_size_shape_rules_and_argument_errors():
     assert lib.dmpnn_prepare_tiles_from_table(4096, 4096, cap + 1, 4636, 9120, 4096, 1 << 30, None) == -1
     assert b"launch bound" in lib.dmpnn_last_error_string()
     assert lib.dmpnn_prepare_tiles_from_table(4096, 4096, 10, 4636, 9120, 4096, 64, None) == -3   # plan buffer too small
+    # prepare_with_batch (full plan + molecule tiles): the same argument rules as dmpnn_prepare, at sizes on both sides of the
+    # single-workgroup plan; nothing launched
+    for nV, nE in ((100, 200), (37000, 73000)):
+        assert lib.dmpnn_prepare_with_batch(4096, 4096, 4096, nV, nE, None, 1 << 30, None) == -1       # null plan
+        assert lib.dmpnn_prepare_with_batch(4096, 4096, 4096, nV, nE, 4096, 64, None) == -3            # plan buffer too small
+        assert lib.dmpnn_prepare_with_batch(4096, 4096, 4096, nV, nE, 4100, 1 << 30, None) == -1       # plan not 16-byte aligned
+        assert lib.dmpnn_prepare_with_batch(None, None, 4096, nV, nE, 4096, 1 << 30, None) == -1       # null index arrays
     # pack_tiles (host): bad arguments
     import numpy as np
 

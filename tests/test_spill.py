@@ -133,8 +133,10 @@ def test_oversize_molecule_fp32_build_and_full_plan(gpu_device, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("act", ["relu", "elu"])
-def test_training_step_with_a_late_oversize_molecule(act, gpu_device):
+@pytest.mark.parametrize("act,n_small", [("relu", 60), ("elu", 60), ("tanh", 1200)])
+def test_training_step_with_a_late_oversize_molecule(act, n_small, gpu_device):
+    """(n_small = 1200: a batch beyond the single-workgroup plan — the full plan with the molecule tiles of the batch
+    vector, dmpnn_prepare_with_batch, the oversize molecules as tiles of their own.)"""
     """Gradients through forward + backward tile kernels when the batch holds molecules larger than the tile
     (both generic paths), against autograd of the reference's op sequence."""
     from chemprop_amd import synth
@@ -143,7 +145,7 @@ def test_training_step_with_a_late_oversize_molecule(act, gpu_device):
 
     torch.manual_seed(7)
     cpu = BondMessagePassing(d_h=128, depth=3, activation=act, bias=True)
-    mgs, late = _mixed(60, [("synth40", 5), ("zinc", 6)], seed=2)
+    mgs, late = _mixed(n_small, [("synth40", 5), ("zinc", 6)], seed=2)
     G = torch.randn(late.V.shape[0], 128, generator=torch.Generator().manual_seed(1))
     w = ot.MPWeights(cpu.W_i.weight, cpu.W_h.weight, cpu.W_o.weight, cpu.W_o.bias, cpu.W_i.bias, cpu.W_h.bias)
     ref = ot.forward_bmg(late, w, depth=3, activation=act)
@@ -159,6 +161,8 @@ def test_training_step_with_a_late_oversize_molecule(act, gpu_device):
     mp.zero_grad()
     late.to(gpu_device)
     out = mp(_bare(late))
+    st = out.grad_fn.st
+    assert st.route == "mega16" and st.plan.header()[8] == 2 and st.plan.any_size == (n_small > 500)
     assert parity_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
     (out * G.to(gpu_device)).sum().backward()
     for n, p in mp.named_parameters():
