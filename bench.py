@@ -136,8 +136,9 @@ def main():
         opt = FlatAdam(sync, lr=1e-4)  # (chemprop trains with Adam, models/model.py:208-231: one fused launch over the flat buffers)
 
         def step():
-            out = mp(bmg)
-            out.backward(G)
+            with ddp.backward_on_calling_thread():  # (one process per GPU: no hand-off to autograd's device thread, ~95 µs of host time)
+                out = mp(bmg)
+                out.backward(G)
             sync.allreduce()
             opt.step()             # (waits for the exchange on the stream, folds in 1 / world, updates: nothing is skipped)
     else:
@@ -245,8 +246,9 @@ def main():
             Gt = torch.randn(nV, tmp.output_dim, device=dev)
 
             def tstep():
-                o = tmp(bmg)
-                o.backward(Gt)
+                with ddp.backward_on_calling_thread():  # (see chemprop_amd/distributed.py: the step was host-bound without it)
+                    o = tmp(bmg)
+                    o.backward(Gt)
                 tsync.allreduce()
                 topt.step()                      # (waits for the exchange on the stream, divides by the world size, updates)
 
@@ -255,6 +257,7 @@ def main():
             tsync.wait()
             out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(world * updates / (t_tr * 1e-3) / 1e6, 2),
                                  "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else None,
+                                 "autograd": "backward on the calling thread (torch.autograd.set_multithreading_enabled(False): one process per GPU)",
                                  "note": "forward (kept tensors) + backward + gradient exchange + fused Adam step of the block's parameters, same "
                                          "shard, eager; weak scaling of THIS figure is the data-parallel training claim (BASELINE configs[3])"}
             del tmp, tsync
@@ -538,7 +541,8 @@ def main():
                         G3 = torch.randn(int(b2.V.shape[0]), m3.output_dim, device=dev)
 
                         def f3():
-                            m3(b2).backward(G3)
+                            with ddp2.backward_on_calling_thread():
+                                m3(b2).backward(G3)
                             s3.allreduce()
                             o3.step()
                         run_steps(f3, 3)

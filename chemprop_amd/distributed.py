@@ -63,6 +63,19 @@ def hash_partition(n_items: int, rank: int, world: int, seed: int = 0, equalize:
     return shards[rank]
 
 
+def backward_on_calling_thread():
+    """Context manager for the training loop of a one-process-per-GPU job: ``loss.backward()`` runs on the thread that calls
+    it (``torch.autograd.set_multithreading_enabled(False)``).
+
+    By default the autograd engine hands the backward pass of a graph that lives on a device to that device's worker thread
+    and waits for it.  With one device per process the worker buys nothing, and the hand-off — two thread wake-ups and a GIL
+    transfer for a Python ``autograd.Function`` such as the block's — costs ~95 µs per backward on the MI355X hosts: more
+    than any kernel of a 512-molecule training step, which was HOST-bound because of it (237–345 µs per step over the hosts
+    of the pool; 210 µs, the device time, inside this context: ``scripts/probe_train_host2.py``).  Nothing about the
+    arithmetic or the order of the kernels changes."""
+    return torch.autograd.set_multithreading_enabled(False)
+
+
 def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> None:
     """Sum (or mean) the gradients of ``params`` over all ranks with ONE flat all-reduce (the simple, sequential form:
     :class:`GradSync` is the one a training loop keeps).  EVERY parameter that requires a gradient takes part on every rank

@@ -149,6 +149,25 @@ def test_grad_sync_equals_sequential_allreduce(tmp_path):
     assert (tmp_path / "sync0.pt").exists() and (tmp_path / "sync1.pt").exists()
 
 
+def test_backward_on_calling_thread_is_scoped_and_changes_no_gradient():
+    """The training-loop context (one process per GPU): autograd multithreading off inside, restored outside, same gradients."""
+    from chemprop_amd.distributed import backward_on_calling_thread
+
+    assert torch.autograd.is_multithreading_enabled()
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    x = torch.randn(7, 5)
+    lin(x).square().sum().backward()
+    want = [p.grad.clone() for p in lin.parameters()]
+    lin.zero_grad()
+    with backward_on_calling_thread():
+        assert not torch.autograd.is_multithreading_enabled()
+        lin(x).square().sum().backward()
+    assert torch.autograd.is_multithreading_enabled()
+    for p, w in zip(lin.parameters(), want):
+        assert torch.equal(p.grad, w)
+
+
 def test_hash_partition_padding_keeps_every_molecule():
     n, world = 37, 4
     padded = [ddp.hash_partition(n, r, world, pad=True) for r in range(world)]
