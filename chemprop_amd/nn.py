@@ -261,9 +261,7 @@ def _spill_monitor(mp, plan_buf: Tensor, dev) -> None:
         mp.__dict__["_dmpnn_mon"] = m
     if m.pending and m.event.query():
         m.pending = False
-        # (the same rule as _route: a few oversize molecules in a batch of several rounds of tiles per CU cost nothing)
-        n_sp, n_ti, n_ed = int(m.host[8]), int(m.host[6]), int(m.host[3])
-        _note_spills(mp, m, n_sp if (n_ed < _SPILL_HIDDEN_MIN_EDGES or n_sp * 32 > n_ti) else 0)
+        _note_spills(mp, m, int(m.host[8]))
     m.calls += 1
     # (never while a hipGraph is being captured: the copy and the event would become nodes of the graph, and the event could not be queried)
     if not m.pending and (m.calls % 8 == 0 if m.calls <= 64 else m.calls % 64 == 0) and not torch.cuda.is_current_stream_capturing():
@@ -341,7 +339,6 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
 
 
 _VALIDATE_FIRST_N = 2
-_SPILL_HIDDEN_MIN_EDGES = 32768   # ~ three rounds of tiles per CU (≈ 110 µs of tile kernel): see _route
 
 
 def _light_plan_ok(mp) -> bool:
@@ -401,11 +398,11 @@ def _route(mp, plan, n_mols: int = 0, batch=None) -> int:
         flags = hdr[0]
         if flags & 7:
             return 0
-        if hdr[8] > 0 and getattr(plan, "oversize", None) is None and (plan.n_edges < _SPILL_HIDDEN_MIN_EDGES or hdr[8] * 32 > hdr[6]):
-            # oversize molecules (the tile kernels carry them through their generic path: correct, slow — one workgroup, ≈ 100 µs
-            # for a 60-edge molecule): a module whose first batches already hold some takes the per-step routes (a speed
-            # decision; _spill_monitor keeps watching).  Not so for a batch whose other tiles keep the chip busy for longer
-            # than that chain anyway (several rounds of tiles per CU) as long as such molecules are few: there the chain hides.
+        if hdr[8] > 0 and getattr(plan, "oversize", None) is None:
+            # oversize molecules (the tile kernels carry them through their generic path: correct, SLOW — one workgroup, 1.7 ms
+            # for a 40-atom molecule at d_h = 300, whatever the size of the batch around it: scripts/probe_spill_policy.py): a
+            # module whose first batches already hold some takes the per-step routes (a speed decision; _spill_monitor keeps
+            # watching)
             no_mega = True
             object.__setattr__(mp, "_dmpnn_no_mega", True)
         if flags & 8:
