@@ -138,6 +138,7 @@ def main():
         def step():
             with ddp.backward_on_calling_thread():  # (one process per GPU: no hand-off to autograd's device thread, ~95 µs of host time)
                 out = mp(bmg)
+                mp.prefetch_plan(bmg)  # K0 of the NEXT step (a loader holds that batch already) beside this step's backward kernels
                 out.backward(G)
             sync.allreduce()
             opt.step()             # (waits for the exchange on the stream, folds in 1 / world, updates: nothing is skipped)
@@ -248,6 +249,7 @@ def main():
             def tstep():
                 with ddp.backward_on_calling_thread():  # (see chemprop_amd/distributed.py: the step was host-bound without it)
                     o = tmp(bmg)
+                    tmp.prefetch_plan(bmg)            # (the next step's K0 on a side stream, beside this step's backward)
                     o.backward(Gt)
                 tsync.allreduce()
                 topt.step()                      # (waits for the exchange on the stream, divides by the world size, updates)
@@ -258,6 +260,7 @@ def main():
             out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(world * updates / (t_tr * 1e-3) / 1e6, 2),
                                  "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else None,
                                  "autograd": "backward on the calling thread (torch.autograd.set_multithreading_enabled(False): one process per GPU)",
+                                 "plan": "K0 of step n + 1 issued on a side stream during step n (prefetch_plan: one K0 per step, off the critical path)",
                                  "note": "forward (kept tensors) + backward + gradient exchange + fused Adam step of the block's parameters, same "
                                          "shard, eager; weak scaling of THIS figure is the data-parallel training claim (BASELINE configs[3])"}
             del tmp, tsync
@@ -542,7 +545,9 @@ def main():
 
                         def f3():
                             with ddp2.backward_on_calling_thread():
-                                m3(b2).backward(G3)
+                                o3_ = m3(b2)
+                                m3.prefetch_plan(b2)
+                                o3_.backward(G3)
                             s3.allreduce()
                             o3.step()
                         run_steps(f3, 3)
