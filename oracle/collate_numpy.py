@@ -96,3 +96,20 @@ def blocked_molecule_tiles(n_atoms, n_edges, block: int = 64, max_rows: int = 48
             p = q
     rows.append(int(eo[n])); atoms.append(int(ao[n]))
     return np.array(rows, dtype=np.int32), np.array(atoms, dtype=np.int32)
+
+
+def full_plan_tiles_ok(src, dst, n_atoms: int, tile_row, tile_atom) -> bool:
+    """What the full plan WITH molecule tiles (``dmpnn_prepare_with_batch``; csrc/dmpnn_prepare.hip: k_rows_tiles, keep_mtiles)
+    verifies on the device before the tile kernels may read it by rows: every table entry is the row offset of its atom in
+    the incoming-edge CSR (the caller-order edge range of a tile IS its row range: edges in molecule order,
+    ``chemprop/data/collate.py:51-56``), and every edge's source atom lies in the tile of its destination atom (no bond
+    between two tiles).  ``tile_row`` / ``tile_atom``: [n_tiles + 1] as returned by :func:`blocked_molecule_tiles`."""
+    src, dst = np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)
+    tile_row, tile_atom = np.asarray(tile_row, dtype=np.int64), np.asarray(tile_atom, dtype=np.int64)
+    row_ptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n_atoms))]).astype(np.int64)
+    if (tile_atom < 0).any() or (tile_atom > n_atoms).any() or not np.array_equal(tile_row, row_ptr[tile_atom]):
+        return False
+    t_dst = np.searchsorted(tile_atom, dst, side="right") - 1   # last tile whose first atom is <= dst
+    t_dst = np.clip(t_dst, 0, len(tile_atom) - 2)
+    return bool(((src >= tile_atom[t_dst]) & (src < tile_atom[t_dst + 1])).all())
+

@@ -353,6 +353,34 @@ def test_large_tile_plan_carries_an_oversize_molecule(gpu_device):
         assert mp2.__dict__.get("_dmpnn_replay") is None
 
 
+def test_oracle_statement_of_the_full_plan_tile_check():
+    """The device check of ``dmpnn_prepare_with_batch`` restated (oracle/collate_numpy.py: full_plan_tiles_ok): molecule
+    tiles of a collated batch pass; a bond between two tiles, or edges out of molecule order, do not."""
+    from chemprop_amd import synth
+    from oracle import collate_numpy as oc
+
+    mgs = synth.random_molgraphs(700, "qm9", seed=8)
+    b = oc.collate(mgs)
+    src, dst = b["edge_index"][0], b["edge_index"][1]
+    nV = len(b["batch"])
+    tr, ta = oc.blocked_molecule_tiles([len(m.V) for m in mgs], [m.edge_index.shape[1] for m in mgs])
+    assert oc.full_plan_tiles_ok(src, dst, nV, tr, ta)
+    # a bond between an atom of the first tile and one of the last
+    s2, d2 = src.copy(), dst.copy()
+    e = int(len(src) // 2)
+    r = int(b["rev_edge_index"][e])
+    s2[e] = ta[-2]
+    d2[r] = ta[-2]
+    assert not oc.full_plan_tiles_ok(s2, d2, nV, tr, ta)
+    # a table whose row offsets are not the CSR offsets of its atoms (what a planner working on edges that are NOT in molecule
+    # order would produce): rejected; the CSR itself does not depend on the order of the edges
+    tr2 = tr.copy()
+    tr2[len(tr2) // 2] += 2
+    assert not oc.full_plan_tiles_ok(src, dst, nV, tr2, ta)
+    perm = np.arange(len(src)).reshape(-1, 2)[::-1].reshape(-1)
+    assert oc.full_plan_tiles_ok(src[perm], dst[perm], nV, tr, ta)
+
+
 # ---- properties of the host-side packers over arbitrary molecule-size sequences (hypothesis; no GPU) ----
 def test_pack_tiles_properties():
     from hypothesis import given, settings

@@ -481,6 +481,9 @@ def test_full_plan_with_molecule_tiles_beyond_the_single_workgroup_plan(gpu_devi
     assert torch.equal(af["mtile_row"], al["mtile_row"]) and torch.equal(af["mtile_atom"], al["mtile_atom"])
     n_t = int(af["hdr"][6])
     assert torch.equal(af["mtile_row"][:n_t + 1].long(), af["row_ptr"][af["mtile_atom"][:n_t + 1].long()].long())
+    from oracle import collate_numpy as oc
+    ei_h = bmg.edge_index.cpu().numpy()
+    assert oc.full_plan_tiles_ok(ei_h[0], ei_h[1], nV, af["mtile_row"][:n_t + 1].numpy(), af["mtile_atom"][:n_t + 1].numpy())
     monkeypatch.setenv("DMPNN_TRAIN_TILES", "0")
     plain = GraphPlan.from_bmg(bmg)
     monkeypatch.delenv("DMPNN_TRAIN_TILES")
@@ -509,6 +512,7 @@ def test_full_plan_with_molecule_tiles_beyond_the_single_workgroup_plan(gpu_devi
     ei[1, r] = far
     bad = GraphPlan(ei, rev, nV, batch=batch)
     assert bad.any_size and bad.flags() & 8
+    assert not oc.full_plan_tiles_ok(ei[0].cpu().numpy(), ei[1].cpu().numpy(), nV, af["mtile_row"][:n_t + 1].numpy(), af["mtile_atom"][:n_t + 1].numpy())
     out_b, st_b = run(bad, keep=True, max_level=1)
     assert st_b.route in ("general16", "fused") and torch.isfinite(out_b).all()
     # the edges of the batch in another order (pairs kept): row ranges no longer match the caller-order edge ranges
