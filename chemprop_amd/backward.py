@@ -40,22 +40,30 @@ class FusedMP(torch.autograd.Function):
         need = {k: ctx.needs_input_grad[8 + i] for i, k in enumerate(_PARAM_ORDER)}
         if not ctx.has_vd:
             need["W_d"] = need["b_d"] = False
-        # a flat gradient buffer registered on the module (distributed.GradSync): the kernels write straight into its views
         # a flat gradient buffer registered on the module (distributed.GradSync): where a parameter's .grad IS its view of
-        # that buffer, the kernels write straight into it and autograd is told there is nothing to accumulate (None) —
-        # the step's gradient OVERWRITES the view (GradSync's contract: one backward per exchange)
-        views = ctx.mp.__dict__.get("_dmpnn_grad_views") if ctx.mp is not None else None
+        # that buffer, the kernels write straight into it and autograd is told there is nothing to accumulate (None).  The
+        # kernels OVERWRITE, so only the FIRST backward through a view since the last zero_grad() / allreduce() / optimizer
+        # step may do that: a block that runs twice in one step (MulticomponentMessagePassing(shared=True), two forwards
+        # before one backward, gradient accumulation) hands its later gradients to autograd, which adds them into the view.
+        mp = ctx.mp
+        views = mp.__dict__.get("_dmpnn_grad_views") if mp is not None else None
+        written = mp.__dict__.get("_dmpnn_grad_written") if mp is not None else None
         direct = {}
         if views:
             for k, v in views.items():
-                lin = getattr(ctx.mp, "W_" + k[2:], None)
+                lin = getattr(mp, "W_" + k[2:], None)
                 prm = None if lin is None else (lin.weight if k[0] == "W" else lin.bias)
-                if prm is not None and prm.grad is not None and prm.grad.data_ptr() == v.data_ptr() and need.get(k):
+                if (prm is not None and prm.grad is not None and prm.grad.data_ptr() == v.data_ptr() and need.get(k)
+                        and (written is None or v.data_ptr() not in written)):
                     direct[k] = v
         grads = engine.backward(st, gout.contiguous(), need, out=direct)
         if engine._lib.opt("DMPNN_KEEP_WORKSPACE", "0") != "1":
             ctx.st = None  # release the kept workspace
-        return (None,) * 8 + tuple(None if k in direct else grads[k] for k in _PARAM_ORDER)
+        # (a view the engine did not take — wrong dtype / layout — got a fresh tensor instead: that one goes to autograd)
+        took = {k for k, v in direct.items() if grads.get(k) is v}
+        if written is not None:
+            written.update(direct[k].data_ptr() for k in took)
+        return (None,) * 8 + tuple(None if k in took else grads[k] for k in _PARAM_ORDER)
 
 
 class _Linear(torch.autograd.Function):

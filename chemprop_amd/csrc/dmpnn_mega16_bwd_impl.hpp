@@ -48,7 +48,7 @@ constexpr size_t bwd_lds_bytes() {
 // would otherwise be inlined per fragment element at every call site — get their own instantiation (code size is
 // instruction-fetch latency for a kernel that runs its code once per tile).
 template <int WN, bool SA>
-__global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
+__global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, QN = BN / 4;
     constexpr int TS = BN * 4 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -174,51 +174,47 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         launder();
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
-        auto load_b = [&](int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct) {
-                bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0));
-                bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0));
-            }
-        };
         auto read_a = [&](int c, h8 (&ah)[RT], h8 (&al)[RT]) {
-            const int cc = c < n_chunks ? c : n_chunks - 1;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const unsigned char* p = T16 + (rt * 16 + li) * TS + cc * 128 + lg * 16;
+                const unsigned char* p = T16 + (rt * 16 + li) * TS + c * 128 + lg * 16;
                 ah[rt] = *reinterpret_cast<const h8*>(p);
                 al[rt] = *reinterpret_cast<const h8*>(p + 64);
             }
         };
-        h8 ah[2][RT], al[2][RT], bh[2][WN], bl[2][WN];
-        auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
+        // the forward tile kernel's contraction (dmpnn_mega16_impl.hpp): one set of weight fragments as a ring over the column
+        // tiles, two workgroups per CU (73 KB of LDS, <= 256 registers)
+        h8 bh[WN], bl[WN], a0h[RT], a0l[RT], a1h[RT], a1l[RT];
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(c + 1, nh, nl);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_b(c + 2, yh, yl);  // (past the last chunk: out of range, 0)
-        };
-        load_b(0, bh[0], bl[0]);
-        load_b(1, bh[1], bl[1]);
+        for (int ct = 0; ct < WN; ++ct) {
+            bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct], 0, 0));
+            bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + 1024u, 0, 0));
+        }
         __syncthreads();  // the split A tile is complete
         launder();
-        read_a(0, ah[0], al[0]);
-        __builtin_amdgcn_sched_barrier(0);
+        read_a(0, a0h, a0l);
+        auto chunk = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&nah)[RT], h8 (&nal)[RT]) {
+            const bool more = c + 1 < n_chunks;
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned o = more ? offB[ct] + (unsigned)(c + 1) * 2048u : gemm::kOOB;
+                bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
+                bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more ? o + 1024u : gemm::kOOB, 0, 0));
+                if (ct == (WN > 1 ? WN - 2 : 0)) read_a(more ? c + 1 : c, nah, nal);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
 #pragma nounroll
         for (int c = 0; c < n_chunks; c += 2) {
-            step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
-            if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
+            chunk(c, a0h, a0l, a1h, a1l);
+            if (c + 1 < n_chunks) chunk(c + 1, a1h, a1l, a0h, a0l);
         }
     };
     // split domain -> fp32 (no bias): acc / (sA sW[col])
@@ -289,31 +285,37 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     // m (edge gradient in transposed fragments) -> gz = m * tau'(Y rows); optional store; returns max |gz|
     auto mask_rows = [&](f32x4 (&m)[WN][RT_E], const float* Y, bool preact, float* store) -> float {
         launder();
-        float4 y[WN][RT_E];
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-            for (int jt = 0; jt < RT_E; ++jt) {  // all loads first (clamped addresses: no load under a branch)
-                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
-                const bool ok = row < nrows && col4 < N;
-                y[ct][jt] = *reinterpret_cast<const float4*>(Y + (long long)(rs + (ok ? row : 0)) * g.ldh + (ok ? col4 : 0));
-            }
-        float mx = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
+        // the kept rows of column tile ct + 1 are requested while column tile ct is processed (clamped addresses: no load under a
+        // branch); two column tiles in flight instead of all five: the registers are the second workgroup's
+        auto load_y = [&](int ct, float4 (&y)[RT_E]) {
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
                 const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
                 const bool ok = row < nrows && col4 < N;
+                y[jt] = *reinterpret_cast<const float4*>(Y + (long long)(rs + (ok ? row : 0)) * g.ldh + (ok ? col4 : 0));
+            }
+        };
+        float4 y[2][RT_E];
+        load_y(0, y[0]);
+        float mx = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            if (ct + 1 < WN) load_y(ct + 1, y[(ct + 1) & 1]);
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                const bool ok = row < nrows && col4 < N;
+                const float4 yv = y[ct & 1][jt];
                 f32x4 v;
-                v[0] = ok ? dact(m[ct][jt][0], y[ct][jt].x, preact) : 0.f;
-                v[1] = ok ? dact(m[ct][jt][1], y[ct][jt].y, preact) : 0.f;
-                v[2] = ok ? dact(m[ct][jt][2], y[ct][jt].z, preact) : 0.f;
-                v[3] = ok ? dact(m[ct][jt][3], y[ct][jt].w, preact) : 0.f;
+                v[0] = ok ? dact(m[ct][jt][0], yv.x, preact) : 0.f;
+                v[1] = ok ? dact(m[ct][jt][1], yv.y, preact) : 0.f;
+                v[2] = ok ? dact(m[ct][jt][2], yv.z, preact) : 0.f;
+                v[3] = ok ? dact(m[ct][jt][3], yv.w, preact) : 0.f;
                 m[ct][jt] = v;
                 mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                if (store && ok) *reinterpret_cast<float4*>(store + (long long)(rs + row) * g.ldh + col4) = make_float4(v[0], v[1], v[2], v[3]);
+                if (store && ok) store_keep4(store + (long long)(rs + row) * g.ldh + col4, make_float4(v[0], v[1], v[2], v[3]));
             }
+        }
         return mx;
     };
     // transposed fragments -> split A tile of the next contraction (all 48 rows, zero where there is no row / column)
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             z[j] = ok ? make_float4(dact(gv.x, yv.x, false), dact(gv.y, yv.y, false), dact(gv.z, yv.z, false), dact(gv.w, yv.w, false))
                       : make_float4(0.f, 0.f, 0.f, 0.f);
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(z[j].x), fabsf(z[j].y)), fmaxf(fabsf(z[j].z), fabsf(z[j].w))));
-            if (ok) *reinterpret_cast<float4*>(g.gZO + row * g.ldh + 4 * q) = z[j];
+            if (ok) store_keep4(g.gZO + row * g.ldh + 4 * q, z[j]);
         }
         sA = tile_scale(mx);
 #pragma unroll
@@ -427,8 +429,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         for (int jt = 0; jt < RT_E; ++jt) {
             const int row = jt * 16 + li;
             if (row < nrows && col4 < N)
-                *reinterpret_cast<float4*>(g.gH0 + (long long)(rs + row) * g.ldh + col4) =
-                    make_float4(gh0[ct][jt][0], gh0[ct][jt][1], gh0[ct][jt][2], gh0[ct][jt][3]);
+                store_keep4(g.gH0 + (long long)(rs + row) * g.ldh + col4, make_float4(gh0[ct][jt][0], gh0[ct][jt][1], gh0[ct][jt][2], gh0[ct][jt][3]));
         }
     }
 }

@@ -60,6 +60,15 @@ __device__ __forceinline__ float scale_for(float maxabs) {
     frexpf(maxabs, &e);  // maxabs = m 2^e, m in [0.5, 1)
     return ldexpf(1.f, 14 - e);
 }
+// store of a kept / gradient tensor row piece (16 bytes).  DMPNN_NT_KEEP (experiment): non-temporal — the tensors a training step
+// streams out are read again only by a later launch
+__device__ __forceinline__ void store_keep4(float* p, float4 v) {
+#if defined(DMPNN_NT_KEEP)
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ void split4(float4 x, float s, h4& hi, h4& lo) {
     const float a = x.x * s, b = x.y * s, c = x.z * s, d = x.w * s;
     hi = h4{(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
@@ -107,9 +116,20 @@ static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
     }
 }
 
+// LDS: ONE tile region holds, at different times, the split A tile of a contraction, the K1 / V operand staging tile and
+// the fp32 tile of a row-major store (the barriers that separate those uses are in the kernel) + metadata + incidence
+// fragments: 73 KB at d_h = 300, so TWO workgroups fit a CU.  With the register budget of two waves per SIMD
+// (__launch_bounds__(256, 2)) consecutive tiles on one CU overlap their latency-bound phases: measured on MI355X
+// 41.1 -> 35.4 us at 512 molecules (one tile per CU: fewer registers, a compact contraction loop) and 301.6 -> 183.6 us at
+// 4 096 molecules (1 839 tiles, 7.2 per CU).
+template <int WN>
+constexpr size_t tile_region_bytes() {
+    constexpr size_t ts = 64 * WN * 4 + 16, tsg = 4 * 128 + 16;  // split A tile row | staging tile row (the larger one for d_h <= 64)
+    return (size_t)kMegaBM * (ts > tsg ? ts : tsg);
+}
 template <int WN>
 constexpr size_t lds_bytes() {
-    return (size_t)kMegaBM * (64 * WN * 4 + 16) * 2 + (size_t)(3 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
+    return tile_region_bytes<WN>() + (size_t)(3 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
 }
 
 // SA (simple activation): identity / ReLU / LeakyReLU / PReLU are a compare + select in line; tanh and ELU get their own
@@ -118,21 +138,23 @@ constexpr size_t lds_bytes() {
 // KEEP: the training forward (H0, H^(t), M^(t), Mv stream out for the backward pass); the inference instantiation carries none of
 // that code (64-bit row addresses and a divergent branch per stored fragment).
 template <int WN, bool SA, bool KEEP>
-__global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
+__global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     const mega::MegaK& g = G.m;
     constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
     constexpr int TS = BN * 4 + 16;            // bytes of one row of the split A tile: BN/32 chunks x 128 + 16
     constexpr int ITEMS = BM * QN / kThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* T16 = lds;                               // [BM][TS]   split A operand of the LDS-A contractions
-    float* T = reinterpret_cast<float*>(lds + BM * TS);     // [BM][LDC] fp32 epilogue tile
-    int* revl = reinterpret_cast<int*>(lds + BM * TS + BM * LDC * 4);  // [BM]
+    static_assert(LDC * 4 == TS, "the fp32 tile and the split A tile have the same footprint");
+    constexpr int META_OFF = (int)tile_region_bytes<WN>();
+    float* T = reinterpret_cast<float*>(lds);               // [BM][LDC] fp32 tile of the row-major stores: overlays T16 / Ag
+    int* revl = reinterpret_cast<int*>(lds + META_OFF);     // [BM]
     int* aor = revl + BM;                                   // [BM]
     int* rp = aor + BM;                                     // [BA + 1]
     int* asrc = rp + BA + 1;                                // [BM] tile-local source atom of a row (tile plan only)
     unsigned* maxbits = reinterpret_cast<unsigned*>(asrc + BM);  // [0..3] tile maxima (float bits, rotating), [5] tile-not-closed flag
     // [10][64] incidence fragments of the segment MFMAs (see segment_mfma): 16-byte aligned behind the metadata
-    h8* cfrag = reinterpret_cast<h8*>(lds + BM * TS + BM * LDC * 4 + (((3 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);
+    h8* cfrag = reinterpret_cast<h8*>(lds + META_OFF + (((3 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);
 
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -200,16 +222,6 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         for (int ct = 0; ct < WN; ++ct)  // fragment-major layout [column tile][chunk][hi|lo][lane][16 B]
             offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
     };
-    // chunk 0 of the NEXT contraction's weights, fetched into registers while the current epilogue runs
-    h8 preBh[WN], preBl[WN];
-    bool have_pre = false;
-    auto prefetch_b = [&](const SplitW& W) {
-        unsigned offB[WN];
-        bfrag_offsets(W, offB);
-        load_bfrags(gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048)), offB, 0, preBh, preBl);
-        have_pre = true;
-    };
-
     // index loads first: the tile metadata and the gather rows of the K1 operand (row wave + 4 j of the tile)
     int revl_v = 0, rp_v = 0, aor_v = 0, asrc_v = 0;
     bool row_bad = false;
@@ -263,7 +275,6 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             a_grp[j] = __builtin_amdgcn_raw_buffer_load_b64(rVg, gemm::join_off(ro1[j], k1o), 0, 0) |
                        __builtin_amdgcn_raw_buffer_load_b64(rEg, gemm::join_off(ro2[j], k2o), 0, 0);
     }
-    prefetch_b(G.Wi);  // chunk 0 of W_i: its L2 latency hides under the metadata phase
     if (tid < BM) { revl[tid] = revl_v; asrc[tid] = asrc_v; if (lean) aor[tid] = aor_v; }
     if (tid <= BA) rp[tid] = rp_v;
     if (tid < 8) maxbits[tid] = 0u;
@@ -349,99 +360,38 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                 al[rt] = *reinterpret_cast<const h8*>(p + 64);
             }
         };
-        // One k-chunk = 3 x RT x WN MFMAs on (ah, al, bh, bl).  While they run: the A fragments of chunk c+1
-        // into (nah, nal), and — once the last MFMA that reads (bh, bl) has been issued — the weight
-        // fragments of chunk c+2 into the same registers.
-        auto chunk = [&](auto has_next, auto has_next2, int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN],
-                         h8 (&nah)[RT], h8 (&nal)[RT]) {
-            constexpr bool NEXT = decltype(has_next)::value, NEXT2 = decltype(has_next2)::value;
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NEXT) read_afrags(c + 1, nah, nal);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NEXT2) load_bfrags(rW, offB, c + 2, bh, bl);
-        };
-        h8 a0h[RT], a0l[RT], b0h[WN], b0l[WN], a1h[RT], a1l[RT], b1h[WN], b1l[WN];
-        if (have_pre && wc0 == 0) {  // (uniform) the weights of chunk 0 were fetched during the previous epilogue
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct) { b0h[ct] = preBh[ct]; b0l[ct] = preBl[ct]; }
-            have_pre = false;
-        } else {
-            load_bfrags(rW, offB, 0, b0h, b0l);
-        }
-        if (n_chunks > 1) load_bfrags(rW, offB, 1, b1h, b1l);
+        // ONE set of weight fragments, used as a ring over the column tiles (the register budget of two workgroups per CU is
+        // 256): the three products of column tile ct are issued together and its fragments of chunk c + 1 are requested right
+        // behind them (distance: the 9 RT MFMAs of each of the other column tiles, exact vmcnt in the compact loop); the A
+        // fragments of chunk c + 1 are read from LDS under the last-but-one column tile.  What latency is left uncovered is the
+        // other workgroup's to fill.
+        h8 bh[WN], bl[WN], a0h[RT], a0l[RT], a1h[RT], a1l[RT];
+        load_bfrags(rW, offB, 0, bh, bl);
         __syncthreads();  // the split A tile is complete
         launder();
         read_afrags(0, a0h, a0l);
-        __builtin_amdgcn_sched_barrier(0);
-#if defined(DMPNN_COMPACT_CONTRACT)
-        // (experiment, measured and NOT adopted: one compact loop body — two chunks, ping-pong fragment registers — per call
-        // site instead of eight specialised chunk bodies shrinks the kernel from 121 to 95 KB and frees 90 registers, but
-        // hipcc then waits vmcnt(0) at the loop's back edge, so the weight prefetch of chunk c+2 is exposed every chunk:
-        // update contraction 12.6 k -> 18.9 k cycles, kernel 38.4 -> 43.3 us.  Straight-line code keeps exact vmcnt(N).)
-        auto chunk2 = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&bh)[WN], h8 (&bl)[WN], h8 (&nah)[RT], h8 (&nal)[RT]) {
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_afrags(c + 1 < n_chunks ? c + 1 : n_chunks - 1, nah, nal);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const bool more = c + 2 < n_chunks;
+        auto chunk = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&nah)[RT], h8 (&nal)[RT]) {
+            const bool more = c + 1 < n_chunks;
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct) {
-                const unsigned o = more ? offB[ct] + (unsigned)(c + 2) * 2048u : kOOB;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned o = more ? offB[ct] + (unsigned)(c + 1) * 2048u : kOOB;  // (past the last chunk: out of range, 0)
                 bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
                 bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more ? o + 1024u : kOOB, 0, 0));
+                if (ct == (WN > 1 ? WN - 2 : 0)) read_afrags(more ? c + 1 : c, nah, nal);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
 #pragma nounroll
         for (int c = 0; c < n_chunks; c += 2) {
-            chunk2(c, a0h, a0l, b0h, b0l, a1h, a1l);
-            if (c + 1 < n_chunks) chunk2(c + 1, a1h, a1l, b1h, b1l, a0h, a0l);
-        }
-        return;
-#endif
-        int c = 0;
-        for (; c + 3 < n_chunks; c += 2) {
-            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
-            chunk(T_{}, T_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l);
-        }
-        const int left = n_chunks - c;
-        if (left == 3) {
-            chunk(T_{}, T_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
-            chunk(T_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l);
-            chunk(F_{}, F_{}, c + 2, a0h, a0l, b0h, b0l, a1h, a1l);
-        } else if (left == 2) {
-            chunk(T_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
-            chunk(F_{}, F_{}, c + 1, a1h, a1l, b1h, b1l, a0h, a0l);
-        } else {
-            chunk(F_{}, F_{}, c, a0h, a0l, b0h, b0l, a1h, a1l);
+            chunk(c, a0h, a0l, a1h, a1l);
+            if (c + 1 < n_chunks) chunk(c + 1, a1h, a1l, a0h, a0l);
         }
         // (no trailing barrier: every writer of the A tile sits behind the barrier of a tile_scale call)
     };
@@ -578,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             const int it = tid + kThreads * j;
             const int r = it / QN, q = it - r * QN;
             if (r < n_r && q < qn)
-                *reinterpret_cast<float4*>(dst + (row0 + r) * ld + 4 * q) = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
+                store_keep4(dst + (row0 + r) * ld + 4 * q, *reinterpret_cast<const float4*>(T + r * LDC + 4 * q));
         }
     };
     // message / aggregate as MFMAs on the contraction's own C/D fragments (no LDS round trip, no barrier):
@@ -662,7 +612,7 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
                     *reinterpret_cast<h4*>(p) = hi;
                     *reinterpret_cast<h4*>(p + 64) = lo;
                     if constexpr (KEEP) {
-                        if (keep && row < n_keep && col4 < N) *reinterpret_cast<float4*>(keep + (keep0 + row) * keep_ld + col4) = v;
+                        if (keep && row < n_keep && col4 < N) store_keep4(keep + (keep0 + row) * keep_ld + col4, v);
                     }
                 }
             }
@@ -688,7 +638,6 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
             const int ncg = G.Wi.nc - grp * 4 < 4 ? G.Wi.nc - grp * 4 : 4;
             contract(RE{}, h0, Ag, TSG, ncg, grp * 4, G.Wi);
         }
-        prefetch_b(T_steps > 1 ? G.Wh : G.WoM);
         unscale(RE{}, h0, 1.f / s_prev, cc);
         stamp();  // 3: K1 contraction
     }
@@ -717,11 +666,11 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         const ColConst cc = col_consts(G.Wh.inv_scale, g.b_h);
         contract(RE{}, acc, T16, TS, (N + BK - 1) / BK, 0, G.Wh);
         stamp();  // 5, 7, ...: update contraction
-        prefetch_b(step + 1 < T_steps ? G.Wh : G.WoM);
         unscale(RE{}, acc, 1.f / sA, cc);
         act_frags(RE{}, T_{}, acc, h0);  // tau(H0 + W_h(M)): base.py:141
         stamp();  // E: unscale + tau
         if (KEEP && g.Hs) {
+            __syncthreads();  // (the fp32 tile overlays the split A tile: every wave is past its contraction)
             frag_to_tile(RE{}, acc);
             __syncthreads();
             tile_to_global(g.Hs + (long long)(step - 1) * g.slot, rs, g.ldh, nrows);
@@ -747,7 +696,6 @@ __global__ __launch_bounds__(kThreads) void k_mpnn_tile16(Mega16K G) {
         // Mv part first (A = T16 rows 0..atoms-1), then the V part in the scale of its own groups
         contract(RA{}, acc, T16, TS, (N + BK - 1) / BK, 0, G.WoM);
         stamp();  // finalize: Mv part
-        prefetch_b(G.WoV);
         float sV = sA;
         for (int grp = 0; grp * 4 < G.WoV.nc; ++grp) {
             if (grp > 0) ga_load(RA{}, F_{}, grp, g.d_v, 0, rV, rnull, rov, rov, v_grp);
@@ -779,7 +727,7 @@ int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
 #define DMPNN_DEFINE_MEGA16(WN, SA, KEEP)                                                                  \
     template <>                                                                                            \
     int launch_mega16<WN, SA, KEEP>(const Mega16K& g, int n_tiles, hipStream_t s) {                        \
-        constexpr size_t lds = lds_bytes<WN>();                                                            \
+        constexpr size_t lds = lds_bytes<WN>();                                                      \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN, SA, KEEP>),          \

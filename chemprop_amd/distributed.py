@@ -24,13 +24,14 @@ def _splitmix64(x: np.ndarray) -> np.ndarray:
 
 
 def hash_partition(n_items: int, rank: int, world: int, seed: int = 0, equalize: bool = True,
-                   weights: Optional[Sequence[float]] = None, pad: bool = False) -> np.ndarray:
+                   weights: Optional[Sequence[float]] = None, pad: bool = False, return_own: bool = False):
     """Indices of the molecules owned by ``rank``: ``hash(molecule id) mod world`` (BASELINE.json
     north_star), independent of any sampler state, identical on every rank without communication.
 
     ``equalize`` trims every shard to the smallest one so that all ranks run the same number of
     steps (a rank with an extra batch would dead-lock the gradient all-reduce) — for TRAINING; it drops molecules, so
-    prediction / evaluation sharding passes ``pad=True`` (shards are padded with repeats instead) or ``equalize=False``.  With ``weights``
+    prediction / evaluation sharding passes ``pad=True`` (shards are padded with repeats instead; ``return_own=True`` then returns
+    ``(indices, n_own)`` so that the caller can drop the padded tail) or ``equalize=False``.  With ``weights``
     (e.g. directed-edge counts) shards are instead built greedily in hash order so that the summed
     weight — the actual work — is balanced (ZINC-like size spread).
     """
@@ -55,12 +56,17 @@ def hash_partition(n_items: int, rank: int, world: int, seed: int = 0, equalize:
     if equalize and pad:
         # prediction / evaluation: nothing may be dropped — short shards repeat their first molecules up to the longest
         # (the caller discards the padded tail: the returned indices beyond the shard's own length are duplicates)
+        # ``return_own=True`` also returns how many leading indices are the shard's OWN (everything behind them is padding); an
+        # empty shard is padded from the first non-empty one with n_own = 0 — every rank then runs the same number of steps
         m = max(len(s) for s in shards)
-        shards = [np.concatenate([s, np.resize(s, m - len(s))]) if 0 < len(s) < m else s for s in shards]
+        own = [len(s) for s in shards]
+        donor = next((s for s in shards if len(s)), np.zeros(0, dtype=np.int64))
+        shards = [np.concatenate([s, np.resize(s if len(s) else donor, m - len(s))]) if (len(s) < m and len(donor)) else s for s in shards]
+        return (shards[rank], own[rank]) if return_own else shards[rank]
     elif equalize:
         m = min(len(s) for s in shards)
         shards = [s[:m] for s in shards]
-    return shards[rank]
+    return (shards[rank], len(shards[rank])) if return_own else shards[rank]
 
 
 def backward_on_calling_thread():
@@ -135,6 +141,9 @@ class GradSync:
         self._done = None
         for p, v in zip(self.params, self.views):
             p.grad = v
+        # views a block's backward kernels have OVERWRITTEN since the last zero_grad() / allreduce() / optimizer step (shared
+        # with every block below): a second backward through the same view in one step must accumulate instead
+        self._written: set = set()
         # the engine's blocks write their gradients into the views directly (backward.FusedMP reads this attribute)
         by_id = {id(p): v for p, v in zip(self.params, self.views)}
         for m in modules:
@@ -149,6 +158,7 @@ class GradSync:
                             names["b_" + short] = by_id[id(layer.bias)]
                 if names:
                     blk.__dict__["_dmpnn_grad_views"] = names
+                    blk.__dict__["_dmpnn_grad_written"] = self._written
 
     def zero_grad(self) -> None:
         """One fill of the flat buffer; every ``p.grad`` stays (or becomes again) its view.  Use this instead of
@@ -156,8 +166,14 @@ class GradSync:
         ``allreduce`` folds stray gradients back in — but it costs the copies this class exists to avoid)."""
         self.wait()
         self.flat.zero_()
+        self._written.clear()
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    def new_step(self) -> None:
+        """The gradients of this step have been consumed (optimizer step, or an exchange has been launched): the next backward
+        through a block may overwrite its views again.  ``FlatAdam.step`` and ``allreduce`` call it."""
+        self._written.clear()
 
     def _gather(self) -> None:
         for p, v in zip(self.params, self.views):
@@ -172,6 +188,7 @@ class GradSync:
         """Launch the exchange of this step's gradients (returns at once)."""
         self.wait()
         self._gather()
+        self._written.clear()  # (the step's gradient is complete: the next backward starts a new one)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return
         if self.stream is None:

@@ -74,6 +74,8 @@ class _HParams(dict):
 
 
 _CACHE_KEYS = ("_dmpnn_replay", "_dmpnn_wcache", "_dmpnn_last", "_dmpnn_mon", "_dmpnn_prefetched", "_dmpnn_side")
+# what a GradSync hangs on a block (views into ITS flat buffer): never pickled / deep-copied along with the module
+_STATE_SKIP_KEYS = _CACHE_KEYS + ("_dmpnn_grad_views", "_dmpnn_grad_written")
 
 
 def invalidate(module: nn.Module) -> None:
@@ -92,7 +94,7 @@ class EngineStateMixin:
     """``copy.deepcopy`` / pickling / ``.to()`` of a block must not carry pointers into another module's buffers."""
 
     def __getstate__(self):
-        return {k: v for k, v in self.__dict__.items() if k not in _CACHE_KEYS}
+        return {k: v for k, v in self.__dict__.items() if k not in _STATE_SKIP_KEYS}
 
     def _apply(self, fn, *args, **kwargs):
         for k in _CACHE_KEYS:

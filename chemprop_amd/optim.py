@@ -70,6 +70,7 @@ class FlatAdam:
                 engine._stream_ptr(self._dev)), "dmpnn_adam_step")
         for p in s.params:  # (the engine's weight caches key on the autograd version)
             torch.autograd.graph.increment_version(p)
+        s.new_step()  # (the gradients are consumed: the next backward may overwrite the views again)
 
     def zero_grad(self) -> None:
         self.sync.zero_grad()

@@ -614,8 +614,9 @@ def test_forward_full_size_vs_oracle(n_mols, kind, seed, gpu_device):
     assert err_u <= TOL, f"{kind}-{n_mols}: un-floored {err_u:.3e}"
 
 
-@pytest.mark.parametrize("n_mols,kind", [(4096, "qm9"), (512, "cgr"), (512, "synth40")])
-def test_relu_gradients_at_size(n_mols, kind, gpu_device):
+@pytest.mark.parametrize("n_mols,kind,kw", [(4096, "qm9", {}), (512, "cgr", {}), (512, "synth40", {}),
+                                            (512, "zinc", dict(d_h=512, depth=6))])   # BASELINE configs[2] at its own shape
+def test_relu_gradients_at_size(n_mols, kind, kw, gpu_device):
     """ReLU gradients at BASELINE sizes (round-1 VERDICT: the at-size gradient cases used smooth activations).
 
     A kinked activation makes a gradient only as reproducible as its masks: ONE mask flip at |z| ~ 1e-7 moves a row of a
@@ -628,12 +629,13 @@ def test_relu_gradients_at_size(n_mols, kind, gpu_device):
     from chemprop_amd import synth
     from chemprop_amd.nn import BondMessagePassing
 
-    dims = dict(d_v=106, d_e=28) if kind == "cgr" else {}
+    dims = dict(dict(d_v=106, d_e=28) if kind == "cgr" else {}, **kw)
+    h, n_upd = dims.get("d_h", 300), dims.get("depth", 3) - 1
     bmg = synth.random_batch(n_mols, kind, seed=13)
     torch.manual_seed(4)
     ref_mp = BondMessagePassing(**dims)
     nV, nE = bmg.V.shape[0], bmg.E.shape[0]
-    G = torch.randn(nV, 300, generator=torch.Generator().manual_seed(6))
+    G = torch.randn(nV, h, generator=torch.Generator().manual_seed(6))
     src, dst, rev = bmg.edge_index[0], bmg.edge_index[1], bmg.rev_edge_index
     V64, E64 = bmg.V.double(), bmg.E.double()
 
@@ -651,10 +653,10 @@ def test_relu_gradients_at_size(n_mols, kind, gpu_device):
 
         H0 = torch.cat((V64[src], E64), 1) @ Wi.t()
         H = tau(H0)
-        for _ in range(2):
-            S = torch.zeros(nV, 300, dtype=torch.float64).index_add_(0, dst, H)
+        for _ in range(n_upd):
+            S = torch.zeros(nV, h, dtype=torch.float64).index_add_(0, dst, H)
             H = tau(H0 + (S[src] - H[rev]) @ Wh.t())
-        Mv = torch.zeros(nV, 300, dtype=torch.float64).index_add_(0, dst, H)
+        Mv = torch.zeros(nV, h, dtype=torch.float64).index_add_(0, dst, H)
         out = tau(torch.cat((V64, Mv), 1) @ Wo.t() + bo)
         return out, ps, pre, used
 
@@ -666,8 +668,8 @@ def test_relu_gradients_at_size(n_mols, kind, gpu_device):
     st = out.grad_fn.st                                        # the kept tensors of this forward (FusedMP)
     rows = st.route in ("mega", "mega16", "fused")             # kept edge tensors in CSR-row order (row i = edge perm[i])
     to_edges = (lambda X: X[st.plan.inv32.long()]) if rows else (lambda X: X)
-    masks = [(to_edges(st.H0[:, :300]) > 0).double().cpu()]
-    masks += [(to_edges(st.Hs[t][:, :300]) > 0).double().cpu() for t in range(2)]
+    masks = [(to_edges(st.H0[:, :h]) > 0).double().cpu()]
+    masks += [(to_edges(st.Hs[t][:, :h]) > 0).double().cpu() for t in range(n_upd)]
     masks.append((out.detach() > 0).double().cpu())
     (out * G.to(gpu_device)).sum().backward()
     if kind == "qm9":  # beyond the single-workgroup plan: the full plan carries molecule tiles (dmpnn_prepare_with_batch)
@@ -885,6 +887,7 @@ def test_backward_matches_executed_reference(golden, gpu_device):
     #  a bias-gradient entry by ~1e-3 of the largest one, which says nothing about the kernels)
     (256, "synth40", dict(bias=True, undirected=True, activation="tanh")),
     (64, "zinc", dict(d_h=128, depth=5, activation="elu")),
+    (512, "zinc", dict(d_h=512, depth=6, activation="tanh")),              # BASELINE configs[2] at its own shape (d_h > 320 training route)
     (64, "qm9", dict(d_h=96, depth=4, activation=torch.nn.Softplus())),   # rows route (custom module)
     (64, "qm9", dict(d_h=64, activation="prelu")),                         # rows route (learnable slope)
 ])
