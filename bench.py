@@ -281,6 +281,52 @@ def main():
         except Exception as e:
             out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
+    # ---- f4: the WHOLE model's training step (models/model.py:148-161 + Adam): block + aggregation + batch norm + predictor +
+    # loss + backward of all of it + optimizer.  (a) the module path: the same kernels driven from Python through autograd, torch
+    # modules for batch norm / criterion, torch.optim.Adam;  (b) FusedTrainer: ONE dmpnn_train_step call.  N = 1 only. ----
+    if not train and world == 1 and args.hidden == 300:
+        try:
+            from chemprop_amd import agg as cagg
+            from chemprop_amd import distributed as ddp
+            from chemprop_amd.model import MPNN, FusedTrainer, RegressionFFN
+
+            def make_model():
+                torch.manual_seed(0)
+                return MPNN(BondMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth), cagg.NormAggregation(),
+                            RegressionFFN(n_tasks=1, input_dim=args.hidden), batch_norm=True).to(dev).train()
+
+            y = torch.randn(args.mols, 1, device=dev)
+            m_a = make_model()
+            opt_a = torch.optim.Adam(m_a.parameters(), 1e-4)
+
+            def step_module():
+                with ddp.backward_on_calling_thread():
+                    opt_a.zero_grad(set_to_none=True)
+                    m_a.loss(bmg, y).backward()
+                opt_a.step()
+
+            m_b = make_model()
+            tr_b = FusedTrainer(m_b, lr=1e-4)
+
+            def step_fused():
+                tr_b.step(bmg, y)
+
+            run_steps(step_module, 10)
+            t_mod = timed_groups(step_module, args.steps, args.groups)[0] / args.steps * 1e3
+            run_steps(step_fused, 10)
+            t_fus = timed_groups(step_fused, args.steps, args.groups)[0] / args.steps * 1e3
+            out["model_step"] = {"fused_ms_per_step": round(t_fus, 5), "module_path_ms_per_step": round(t_mod, 5),
+                                 "fused_M_edge_updates_per_s": round(updates / (t_fus * 1e-3) / 1e6, 2),
+                                 "route": tr_b.last_route,
+                                 "model": f"MPNN(BondMessagePassing(d_h={args.hidden}, depth={args.depth}), NormAggregation, BatchNorm1d, "
+                                          "RegressionFFN(1 task, hidden 300), MSE) + Adam",
+                                 "note": "fused: ONE C call (dmpnn_train_step) enqueues K0, the block's forward, aggregation, batch norm, the "
+                                         "predictor, the loss, the backward pass of all of it and the Adam update; module path: the same block "
+                                         "kernels through torch autograd with torch's batch norm / loss / Adam launches around them"}
+            del m_a, m_b, tr_b, opt_a
+        except Exception as e:
+            out["model_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         # ---- roofline of the dominant kernel, live HIP-event timing on the launch stream ----
         h = args.hidden

@@ -21,9 +21,9 @@ INCLUDE = os.path.join(_ROOT, "include")
 # DMPNN_LIB: an alternative build of the same sources (kernel experiments: scripts/build_variant.py), same ABI
 LIB_PATH = os.environ.get("DMPNN_LIB") or os.path.join(_HERE, "libdmpnn_gfx950.so")
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
-           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_step16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip", "dmpnn_optim.hip", "dmpnn_wgrad16.hip"]
+           "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_step16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip", "dmpnn_optim.hip", "dmpnn_wgrad16.hip", "dmpnn_head.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp", "dmpnn_seg16.hpp", "dmpnn_step16_impl.hpp"]
-ABI_VERSION = 7
+ABI_VERSION = 8
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
@@ -34,6 +34,7 @@ EXPORTS = [
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
+    "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -93,6 +94,38 @@ class BwdArgs(C.Structure):
         ("gW_i", C.c_void_p), ("gb_i", C.c_void_p), ("gW_h", C.c_void_p), ("gb_h", C.c_void_p),
         ("gW_o", C.c_void_p), ("gb_o", C.c_void_p), ("gW_d", C.c_void_p), ("gb_d", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+    ]
+
+
+MAX_FFN_LAYERS = 8
+LOSS = {"mse": 0, "mae": 1}
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [
+        ("n_atoms", C.c_int64), ("n_mols", C.c_int64), ("d_h", C.c_int64),
+        ("batch", C.c_void_p),
+        ("agg_mode", C.c_int32), ("agg_norm", C.c_float),
+        ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p), ("bn_running_mean", C.c_void_p), ("bn_running_var", C.c_void_p),
+        ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("bn_training", C.c_int32),
+        ("n_layers", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+        ("W", C.c_void_p * MAX_FFN_LAYERS), ("b", C.c_void_p * MAX_FFN_LAYERS), ("dims", C.c_int64 * (MAX_FFN_LAYERS + 1)),
+        ("loss", C.c_int32),
+        ("targets", C.c_void_p), ("weights", C.c_void_p), ("task_weights", C.c_void_p), ("lt_mask", C.c_void_p), ("gt_mask", C.c_void_p),
+        ("preds", C.c_void_p), ("loss_out", C.c_void_p),
+        ("gW", C.c_void_p * MAX_FFN_LAYERS), ("gb", C.c_void_p * MAX_FFN_LAYERS), ("g_bn_weight", C.c_void_p), ("g_bn_bias", C.c_void_p),
+        ("gHv", C.c_void_p), ("ldg", C.c_int64),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+    ]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ("edge_index", C.c_void_p), ("rev_edge_index", C.c_void_p), ("batch", C.c_void_p), ("plan_bytes", C.c_size_t), ("plan_ready", C.c_int32),
+        ("bwd", BwdArgs), ("head", HeadArgs),
+        ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n_params", C.c_int64),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+        ("bias_corr1", C.c_float), ("sqrt_bias_corr2", C.c_float), ("grad_scale", C.c_float), ("dev_scalars", C.c_void_p),
     ]
 
 
@@ -194,7 +227,7 @@ def load() -> C.CDLL:
     lib.dmpnn_linear_wgrad.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes",
-                  "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes")
+                  "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes", "dmpnn_head_ws_bytes")
     lib.dmpnn_linear16_wsplit_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_linear16_ok.argtypes = [C.POINTER(GemmArgs)]
     lib.dmpnn_linear16_fwd.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -222,6 +255,10 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.dmpnn_full_plan_keeps_tiles.argtypes = [C.c_int64, C.c_int64]
+    lib.dmpnn_head_ws_bytes.argtypes = [C.POINTER(HeadArgs)]
+    lib.dmpnn_head.argtypes = [C.POINTER(HeadArgs), C.c_void_p, C.c_int64, C.c_void_p]
+    lib.dmpnn_train_step.argtypes = [C.POINTER(StepArgs), C.c_void_p]
     lib.dmpnn_split_row_floats.argtypes = [C.c_int64]
     lib.dmpnn_split_row_floats.restype = C.c_int64
     lib.dmpnn_debug_timestamps.argtypes = [C.c_void_p]

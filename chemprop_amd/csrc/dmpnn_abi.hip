@@ -120,6 +120,11 @@ int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, const int
 }
 
 int dmpnn_tile_plan_any_size(int64_t n_atoms, int64_t n_edges) { return tiles_large_fits(n_atoms, n_edges) ? 1 : 0; }
+int dmpnn_full_plan_keeps_tiles(int64_t n_atoms, int64_t n_edges) {
+    if (n_atoms <= 0 || n_edges <= 0) return 0;
+    if (small_plan_fits(n_atoms, n_edges)) return 1;
+    return (tiles_large_fits(n_atoms, n_edges) && prepare_can_keep_mtiles(n_atoms, n_edges)) ? 1 : 0;
+}
 
 int dmpnn_prepare_with_batch(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t n_atoms, int64_t n_edges,
                              void* plan, size_t plan_bytes, void* stream) {

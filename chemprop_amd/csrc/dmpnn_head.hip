@@ -1,0 +1,369 @@
+// f4: what chemprop.models.MPNN does AFTER the message-passing block in a training step, as kernels chained
+// by ONE C call — and the whole step (K0 + forward + this + backward + optimizer) as one more (dmpnn_train_step):
+//
+//     H   = agg(H_v, batch)                     models/model.py:131      nn/agg.py:66-113     (dmpnn_molagg_*)
+//     Z   = bn(H)                               models/model.py:132      nn.BatchNorm1d, batch statistics in training
+//     P   = ffn(Z)                              models/model.py:146,155  nn/ffn.py:24-68, nn/predictors.py:161-169
+//     l   = sum(L w_i t_j mask) / sum(mask)     models/model.py:156      nn/metrics.py:78-127 (MSE :137-141, MAE :146-148,
+//                                                                         bounded variants :157-163)
+// and the gradients of l with respect to every parameter above and to H_v (the `gout` of dmpnn_backward).
+//
+// The reference runs this as ~60 ATen launches from Python (forward + autograd); at 512 molecules every one of them is
+// launch latency.  Here: segment reduction, one batch-norm kernel, one fp32-MFMA contraction per layer (activation fused),
+// one loss kernel that also emits dl/dP; backward: per layer one weight-gradient product (+ reduce), one transposed
+// contraction with the activation derivative fused into a small elementwise pass, one batch-norm kernel, one gather.
+#include "dmpnn_common.hpp"
+
+namespace dmpnn {
+namespace {
+
+inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// ---- BatchNorm1d over the rows of X [B, d] -------------------------------------------------------------------------
+// One workgroup per 64 columns, 4 row lanes per column (256 threads): two passes over the rows for the statistics
+// (mean, then the mean squared deviation: the arithmetic of torch's batch_norm on a [B, d] input to fp32 rounding), a
+// third for y.  B x d is ~0.6 MB: it lives in L2.
+struct BnArgs {
+    const float* X; int64_t ldx; float* Y; int64_t ldy;
+    const float* gamma; const float* beta; float* run_mean; float* run_var;
+    float* save_mean; float* save_invstd;      // [d] each (training: for the backward pass)
+    int64_t B; int d; float eps, momentum; int training;
+};
+__global__ __launch_bounds__(256) void k_bn_fwd(BnArgs a) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool ok = c < a.d;
+    float mean, invstd;
+    if (a.training) {
+        float s = 0.f;
+        if (ok) for (int64_t r = ty; r < a.B; r += 4) s += a.X[r * a.ldx + c];
+        red[ty][tx] = s;
+        __syncthreads();
+        mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)a.B;
+        __syncthreads();
+        float q = 0.f;
+        if (ok) for (int64_t r = ty; r < a.B; r += 4) { const float dlt = a.X[r * a.ldx + c] - mean; q += dlt * dlt; }
+        red[ty][tx] = q;
+        __syncthreads();
+        const float ss = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        const float var = ss / (float)a.B;                       // biased: what normalises (nn.BatchNorm1d)
+        invstd = 1.f / sqrtf(var + a.eps);
+        if (ok && ty == 0) {
+            a.save_mean[c] = mean; a.save_invstd[c] = invstd;
+            if (a.run_mean) a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * mean;
+            // running_var takes the UNBIASED estimate (torch: var * B / (B - 1))
+            if (a.run_var) a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * (a.B > 1 ? ss / (float)(a.B - 1) : var);
+        }
+    } else {
+        mean = ok ? a.run_mean[c] : 0.f;
+        invstd = ok ? 1.f / sqrtf(a.run_var[c] + a.eps) : 0.f;
+    }
+    if (ok) {
+        const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+        for (int64_t r = ty; r < a.B; r += 4) a.Y[r * a.ldy + c] = (a.X[r * a.ldx + c] - mean) * invstd * g + b;
+    }
+}
+
+// gX = gamma invstd / B (B gY - sum gY - xhat sum(gY xhat));  g_gamma = sum gY xhat;  g_beta = sum gY      (training)
+// gX = gY gamma invstd                                                                                     (eval statistics)
+struct BnBwdArgs {
+    const float* gY; int64_t ldgy; const float* X; int64_t ldx; float* gX; int64_t ldgx;
+    const float* gamma; const float* save_mean; const float* save_invstd; const float* run_mean; const float* run_var;
+    float* g_gamma; float* g_beta;
+    int64_t B; int d; float eps; int training;
+};
+__global__ __launch_bounds__(256) void k_bn_bwd(BnBwdArgs a) {
+    __shared__ float red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const bool ok = c < a.d;
+    const float mean = ok ? (a.training ? a.save_mean[c] : a.run_mean[c]) : 0.f;
+    const float invstd = ok ? (a.training ? a.save_invstd[c] : 1.f / sqrtf(a.run_var[c] + a.eps)) : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) for (int64_t r = ty; r < a.B; r += 4) {
+        const float g = a.gY[r * a.ldgy + c];
+        s1 += g;
+        s2 += g * ((a.X[r * a.ldx + c] - mean) * invstd);
+    }
+    red[0][ty][tx] = s1; red[1][ty][tx] = s2;
+    __syncthreads();
+    s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+    s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    if (!ok) return;
+    if (ty == 0) {
+        if (a.g_gamma) a.g_gamma[c] = s2;
+        if (a.g_beta) a.g_beta[c] = s1;
+    }
+    const float gam = a.gamma ? a.gamma[c] : 1.f;
+    const float k = gam * invstd, invB = 1.f / (float)a.B;
+    for (int64_t r = ty; r < a.B; r += 4) {
+        const float g = a.gY[r * a.ldgy + c];
+        if (a.training) {
+            const float xh = (a.X[r * a.ldx + c] - mean) * invstd;
+            a.gX[r * a.ldgx + c] = k * (g - invB * s1 - xh * invB * s2);
+        } else {
+            a.gX[r * a.ldgx + c] = k * g;
+        }
+    }
+}
+
+// ---- criterion (nn/metrics.py:78-127): ONE workgroup ----------------------------------------------------------------
+//   mask = isfinite(target) (models/model.py:152-153), target = nan_to_num(target)
+//   bounded: P' = T where (P < T and lt) or (P > T and gt)   (metrics.py:157-161)
+//   L = (P' - T)^2 | |P' - T|;   loss = sum(L w_i t_j mask) / sum(mask);   gP = dL/dP w_i t_j mask / sum(mask)
+struct LossArgs {
+    const float* P; int64_t ldp; const float* T; int64_t ldt; const float* w; const float* tw;
+    const unsigned char* lt; const unsigned char* gt;
+    float* gP; int64_t ldg; float* out;   // out[0] = loss, out[1] = number of finite targets
+    int64_t B; int t; int kind;
+};
+__global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
+    __shared__ float red[2][16];
+    __shared__ float tot[2];
+    const int64_t n = a.B * a.t;
+    float sl = 0.f, sm = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t r = i / a.t; const int j = (int)(i - r * a.t);
+        const float y = a.T[r * a.ldt + j];
+        const bool m = isfinite(y);
+        if (!m) continue;
+        float p = a.P[r * a.ldp + j];
+        if ((a.lt && a.lt[r * a.t + j] && p < y) || (a.gt && a.gt[r * a.t + j] && p > y)) p = y;
+        const float d = p - y;
+        const float L = a.kind == DMPNN_LOSS_MAE ? fabsf(d) : d * d;
+        sl += L * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f);
+        sm += 1.f;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sl += __shfl_xor(sl, off); sm += __shfl_xor(sm, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sl; red[1][threadIdx.x >> 6] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int i = 0; i < 16; ++i) { a0 += red[0][i]; a1 += red[1][i]; }
+        tot[0] = a0; tot[1] = a1;
+        a.out[0] = a0 / a1;   // (no finite target: 0 / 0 = NaN, like the reference)
+        a.out[1] = a1;
+    }
+    __syncthreads();
+    if (!a.gP) return;
+    const float inv = 1.f / tot[1];
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t r = i / a.t; const int j = (int)(i - r * a.t);
+        const float y = a.T[r * a.ldt + j];
+        float g = 0.f;
+        if (isfinite(y)) {
+            float p = a.P[r * a.ldp + j];
+            if ((a.lt && a.lt[r * a.t + j] && p < y) || (a.gt && a.gt[r * a.t + j] && p > y)) p = y;
+            const float d = p - y;
+            const float dl = a.kind == DMPNN_LOSS_MAE ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+            g = dl * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f) * inv;
+        }
+        a.gP[r * a.ldg + j] = g;
+    }
+}
+
+// out[c][r] = in[r][c] for a weight matrix (<= a few hundred KB)
+__global__ void k_head_transpose(const float* __restrict__ in, int64_t ldi, float* __restrict__ out, int64_t ldo, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(int64_t)r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (c < cols && r < rows) out[(int64_t)c * ldo + r] = tile[threadIdx.x][j];
+    }
+}
+// g[r][c] *= tau'(Y[r][c])   (Y = the activated output the next layer consumed)
+__global__ void k_head_act_bwd(float* __restrict__ g, int64_t ldg, const float* __restrict__ Y, int64_t ldy, int64_t rows, int cols,
+                               int act, float slope) {
+    const int64_t n = rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols; const int c = (int)(i - r * cols);
+        g[r * ldg + c] *= act_grad_from_out(Y[r * ldy + c], act, slope);
+    }
+}
+
+struct HeadLayout {
+    size_t bounds, Hm, Z, mean, invstd, act[DMPNN_MAX_FFN_LAYERS], gP, gA, gB, Wt, wgrad, gHm, total;
+    size_t wgrad_bytes;
+    int64_t maxd;
+};
+HeadLayout head_layout(const dmpnn_head_args& h) {
+    HeadLayout L;
+    memset(&L, 0, sizeof(L));
+    const int64_t B = h.n_mols > 0 ? h.n_mols : 0, d = h.d_h;
+    size_t o = 0;
+    L.bounds = o; o += al256(dmpnn_molagg_ws_bytes(B));
+    L.Hm = o; o += al256((size_t)B * d * 4);
+    L.Z = o; o += al256(h.bn_weight ? (size_t)B * d * 4 : 0);
+    L.mean = o; o += al256((size_t)d * 4);
+    L.invstd = o; o += al256((size_t)d * 4);
+    int64_t maxd = d;
+    for (int l = 0; l < h.n_layers; ++l) {
+        if (h.dims[l + 1] > maxd) maxd = h.dims[l + 1];
+        L.act[l] = o;
+        if (l + 1 < h.n_layers) o += al256((size_t)B * h.dims[l + 1] * 4);   // (the last layer writes `preds`)
+    }
+    L.maxd = maxd;
+    const int64_t t = h.n_layers > 0 ? h.dims[h.n_layers] : d;
+    L.gP = o; o += al256((size_t)B * t * 4);
+    L.gA = o; o += al256((size_t)B * maxd * 4);
+    L.gB = o; o += al256((size_t)B * maxd * 4);
+    L.Wt = o; o += al256((size_t)maxd * maxd * 4);
+    size_t wg = 0;
+    for (int l = 0; l < h.n_layers; ++l) {
+        const size_t b = dmpnn_linear_wgrad_ws_bytes(B, h.dims[l + 1], h.dims[l], 1);
+        if (b > wg) wg = b;
+    }
+    L.wgrad = o; L.wgrad_bytes = al256(wg); o += L.wgrad_bytes;
+    L.gHm = o; o += al256((size_t)B * d * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+}  // namespace dmpnn
+
+using namespace dmpnn;
+
+extern "C" {
+
+size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h) {
+    if (!h || h->n_layers < 0 || h->n_layers > DMPNN_MAX_FFN_LAYERS || h->d_h <= 0) return 0;
+    return head_layout(*h).total;
+}
+
+int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream) {
+    DMPNN_CHECK_ARG(hp != nullptr, "head: null args");
+    const dmpnn_head_args& h = *hp;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t B = h.n_mols, d = h.d_h, nV = h.n_atoms;
+    const int Ln = h.n_layers;
+    DMPNN_CHECK_ARG(B >= 0 && nV >= 0 && d > 0 && ldhv >= d, "head: bad sizes");
+    DMPNN_CHECK_ARG(Ln >= 1 && Ln <= DMPNN_MAX_FFN_LAYERS && h.dims[0] == d, "head: 1..%d predictor layers, dims[0] == d_h", DMPNN_MAX_FFN_LAYERS);
+    for (int l = 0; l < Ln; ++l) DMPNN_CHECK_ARG(h.W[l] && h.dims[l + 1] > 0, "head: layer %d has no weight / width", l);
+    DMPNN_CHECK_ARG(h.act >= DMPNN_ACT_NONE && h.act <= DMPNN_ACT_ELU && h.act != DMPNN_ACT_PRELU, "head: activation %d is not built in", h.act);
+    DMPNN_CHECK_ARG(h.loss == DMPNN_LOSS_MSE || h.loss == DMPNN_LOSS_MAE, "head: unknown criterion %d", h.loss);
+    DMPNN_CHECK_ARG(h.preds && (nV == 0 || (Hv && h.batch)), "head: null H_v / batch / preds");
+    DMPNN_CHECK_ARG(!h.bn_weight || (h.bn_running_mean && h.bn_running_var), "head: batch norm without running statistics");
+    const bool want_grad = h.gHv != nullptr;
+    DMPNN_CHECK_ARG(!want_grad || (h.targets && h.loss_out && h.ldg >= d), "head: gradients need targets, loss_out and ldg >= d_h");
+    const HeadLayout L = head_layout(h);
+    if (!h.ws || h.ws_bytes < L.total) {
+        set_error("head: workspace missing or too small (%zu < %zu bytes)", h.ws_bytes, L.total);
+        return DMPNN_ENOSPC;
+    }
+    DMPNN_CHECK_ARG(aligned16(h.ws), "head: workspace must be 16-byte aligned");
+    if (B == 0) return DMPNN_OK;
+    unsigned char* ws = static_cast<unsigned char*>(h.ws);
+    float* Hm = reinterpret_cast<float*>(ws + L.Hm);
+    const int t = (int)h.dims[Ln];
+
+    // ---- forward ----
+    DMPNN_TRY(dmpnn_molagg_bounds(h.batch, nV, B, ws + L.bounds, dmpnn_molagg_ws_bytes(B), stream));
+    DMPNN_TRY(dmpnn_molagg_fwd(Hv, ldhv, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, Hm, d, stream));
+    const float* Z = Hm;
+    float* mean = reinterpret_cast<float*>(ws + L.mean);
+    float* invstd = reinterpret_cast<float*>(ws + L.invstd);
+    if (h.bn_weight) {
+        BnArgs b{Hm, d, reinterpret_cast<float*>(ws + L.Z), d, h.bn_weight, h.bn_bias, h.bn_running_mean, h.bn_running_var, mean, invstd,
+                 B, (int)d, h.bn_eps, h.bn_momentum, h.bn_training};
+        hipLaunchKernelGGL(k_bn_fwd, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, b);
+        DMPNN_CHECK_LAUNCH("k_bn_fwd");
+        Z = reinterpret_cast<float*>(ws + L.Z);
+    }
+    const float* A[DMPNN_MAX_FFN_LAYERS + 1];
+    A[0] = Z;
+    for (int l = 0; l < Ln; ++l) {
+        dmpnn_gemm_args g;
+        memset(&g, 0, sizeof(g));
+        g.M = B; g.N = h.dims[l + 1]; g.K1 = h.dims[l];
+        g.A1 = A[l]; g.lda1 = h.dims[l];
+        g.W = h.W[l]; g.ldw = h.dims[l]; g.bias = h.b[l];
+        float* out = l + 1 < Ln ? reinterpret_cast<float*>(ws + L.act[l]) : h.preds;
+        g.C = out; g.ldc = h.dims[l + 1];
+        g.act = l + 1 < Ln ? h.act : DMPNN_ACT_NONE;   // sigma of the NEXT block fused here (ffn.py:49-58)
+        g.act_slope = h.act_slope;
+        DMPNN_TRY(dmpnn_linear_fwd(&g, stream));
+        A[l + 1] = out;
+    }
+    if (!h.targets) return DMPNN_OK;
+    float* gP = reinterpret_cast<float*>(ws + L.gP);
+    {
+        LossArgs q{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, want_grad ? gP : nullptr, t, h.loss_out, B, t, h.loss};
+        DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
+        hipLaunchKernelGGL(k_loss, dim3(1), dim3(1024), 0, s, q);
+        DMPNN_CHECK_LAUNCH("k_loss");
+    }
+    if (!want_grad) return DMPNN_OK;
+
+    // ---- backward ----
+    float* bufs[2] = {reinterpret_cast<float*>(ws + L.gA), reinterpret_cast<float*>(ws + L.gB)};
+    float* Wt = reinterpret_cast<float*>(ws + L.Wt);
+    const float* g_cur = gP;   // gradient w.r.t. the pre-activation of layer l's output
+    int pp = 0;
+    for (int l = Ln - 1; l >= 0; --l) {
+        const int64_t N = h.dims[l + 1], K = h.dims[l];
+        if (h.gW[l] || h.gb[l]) {
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = B; g.N = N; g.K1 = K; g.A1 = A[l]; g.lda1 = K;
+            float* gw = h.gW[l] ? h.gW[l] : Wt;  // (the product writes both; an unwanted one lands in scratch)
+            DMPNN_TRY(dmpnn_linear_wgrad(&g, g_cur, N, gw, K, h.b[l] ? h.gb[l] : nullptr, ws + L.wgrad, L.wgrad_bytes, stream));
+        }
+        // data gradient: gA[l] = g . W_l   (the contraction kernel on W_l^T)
+        hipLaunchKernelGGL(k_head_transpose, dim3((unsigned)((K + 31) / 32), (unsigned)((N + 31) / 32)), dim3(32, 8), 0, s, h.W[l], K, Wt, N, (int)N, (int)K);
+        DMPNN_CHECK_LAUNCH("k_head_transpose");
+        dmpnn_gemm_args g;
+        memset(&g, 0, sizeof(g));
+        g.M = B; g.N = K; g.K1 = N; g.A1 = g_cur; g.lda1 = N; g.W = Wt; g.ldw = N;
+        float* out = bufs[pp]; pp ^= 1;
+        g.C = out; g.ldc = K; g.act = DMPNN_ACT_NONE;
+        DMPNN_TRY(dmpnn_linear_fwd(&g, stream));
+        if (l > 0 && h.act != DMPNN_ACT_NONE) {
+            const int64_t n = B * K;
+            int64_t blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(k_head_act_bwd, dim3((unsigned)blocks), dim3(256), 0, s, out, K, A[l], K, B, (int)K, h.act, h.act_slope);
+            DMPNN_CHECK_LAUNCH("k_head_act_bwd");
+        }
+        g_cur = out;
+    }
+    const float* gZ = g_cur;   // [B, d]: gradient w.r.t. the fingerprint
+    float* gHm = reinterpret_cast<float*>(ws + L.gHm);
+    if (h.bn_weight) {
+        BnBwdArgs b{gZ, d, Hm, d, gHm, d, h.bn_weight, mean, invstd, h.bn_running_mean, h.bn_running_var, h.g_bn_weight, h.g_bn_bias,
+                    B, (int)d, h.bn_eps, h.bn_training};
+        hipLaunchKernelGGL(k_bn_bwd, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, b);
+        DMPNN_CHECK_LAUNCH("k_bn_bwd");
+        gZ = gHm;
+    }
+    return dmpnn_molagg_bwd(gZ, d, h.batch, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, h.gHv, h.ldg, stream);
+}
+
+// K0 + forward (kept tensors) + the head above + backward + optimizer: one training step of models/model.py:148-161 with
+// torch.optim.Adam (model.py:208-231), every kernel enqueued by this one call.
+int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
+    DMPNN_CHECK_ARG(a != nullptr, "train_step: null args");
+    const dmpnn_fwd_args& f = a->bwd.f;
+    DMPNN_CHECK_ARG((f.flags & DMPNN_F_KEEP) != 0, "train_step: the forward must keep its tensors (DMPNN_F_KEEP)");
+    DMPNN_CHECK_ARG(a->head.gHv == a->bwd.gout && a->head.ldg == a->bwd.ldgout, "train_step: head.gHv must be the backward's gout");
+    DMPNN_CHECK_ARG(a->head.n_atoms == f.n_atoms && a->head.d_h == f.d_h + (f.W_d ? f.d_vd : 0), "train_step: head and block sizes differ");
+    if (!a->plan_ready) {
+        DMPNN_CHECK_ARG(a->edge_index && a->rev_edge_index, "train_step: null index arrays");
+        DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
+                                           a->plan_bytes, stream));
+    }
+    DMPNN_TRY(dmpnn_forward(&f, stream));
+    DMPNN_TRY(dmpnn_head(&a->head, f.out, f.ldout, stream));
+    DMPNN_TRY(dmpnn_backward(&a->bwd, stream));
+    if (a->n_params > 0)
+        DMPNN_TRY(dmpnn_adam_step(a->p, a->g, a->m, a->v, a->n_params, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->bias_corr1,
+                                  a->sqrt_bias_corr2, a->grad_scale, a->dev_scalars, stream));
+    return DMPNN_OK;
+}
+
+}  // extern "C"

@@ -106,7 +106,7 @@ class GraphPlan:
                  "any_size", "oversize")
 
     def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False, batch: Optional[Tensor] = None,
-                 tiles: Optional[tuple] = None):
+                 tiles: Optional[tuple] = None, launch: bool = True):
         _require_device(edge_index, "edge_index")
         lib = _lib.load()
         dev = edge_index.device
@@ -142,9 +142,15 @@ class GraphPlan:
         # a FULL plan beyond the single-workgroup plan: with the batch vector it carries molecule tiles too
         # (dmpnn_prepare_with_batch) — training on the tile kernels at any batch size
         full_tiles = (not light and not small and bt is not None and n_atoms > 0 and n_edges > 0
-                      and _lib.opt("DMPNN_TRAIN_TILES", "1") != "0" and bool(lib.dmpnn_tile_plan_any_size(n_atoms, n_edges)))
+                      and _lib.opt("DMPNN_TRAIN_TILES", "1") != "0" and bool(lib.dmpnn_full_plan_keeps_tiles(n_atoms, n_edges)))
         self.any_size = (self.tiles_only and not small) or full_tiles  # (the forward's DMPNN_F_LOADER_TILES)
         self.edge_index, self.rev_edge_index = ei, rev
+        if not launch:
+            # the buffer and the facts only: dmpnn_train_step runs K0 itself (dmpnn_prepare_with_batch: a FULL plan — with
+            # molecule tiles where full_tiles says so)
+            if light:
+                raise RuntimeError("GraphPlan(launch=False) is the full plan of a training step")
+            return
         with _OnDevice(dev):
             if self.loader_tiles:
                 _lib.check(lib.dmpnn_prepare_tiles_from_table(tiles[0].data_ptr(), tiles[1].data_ptr(), self.loader_tiles, n_atoms,
@@ -163,10 +169,10 @@ class GraphPlan:
                                 self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
 
     @classmethod
-    def from_bmg(cls, bmg, light=False, use_batch: bool = True) -> "GraphPlan":
+    def from_bmg(cls, bmg, light=False, use_batch: bool = True, launch: bool = True) -> "GraphPlan":
         return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]), light=light,
                    batch=getattr(bmg, "batch", None) if use_batch else None,
-                   tiles=getattr(bmg, "tiles", None) if light == "tiles" else None)
+                   tiles=getattr(bmg, "tiles", None) if light == "tiles" else None, launch=launch)
 
     # ---- views for tests / diagnostics (these synchronise) ----
     def arrays(self) -> dict:
@@ -366,7 +372,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             b_d: Optional[Tensor] = None, V_d: Optional[Tensor] = None, depth: int = 3, act: str = "relu",
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
             keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
-            max_level: int = 2, mfma: Optional[str] = None, wcache: Optional[dict] = None) -> tuple[Tensor, ForwardState]:
+            max_level: int = 2, mfma: Optional[str] = None, wcache: Optional[dict] = None,
+            launch: bool = True) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -381,6 +388,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
 
     ``mfma`` picks the matrix arithmetic of the mega route: ``"split16"`` (default; fp32-equivalent exact
     3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
+    ``launch=False`` prepares the argument block and the workspace without enqueuing anything (``trainer.FusedTrainer``).
     ``route`` is a demand (raises when the shapes do not allow it); ``max_level`` (0 general, 1 fused,
     2 mega) only caps the automatic choice.  ``fused=False`` is shorthand for ``route="general"``;
     ``fused=True`` demands at least ``fused``.
@@ -553,15 +561,16 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         a.flags |= F_MEGA
     if keep:
         a.flags |= F_KEEP
-    with _OnDevice(dev):
-        _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
+    if launch:  # (launch=False: the argument block and the workspace only — dmpnn_train_step enqueues the forward itself)
+        with _OnDevice(dev):
+            _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
     st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, wsplit)
     st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)
     return out, st
 
 
-def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = None) -> dict:
+def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = None, launch: bool = True):
     """K6: parameter gradients of a kept forward.  ``need`` maps W_i/b_i/W_h/b_h/W_o/b_o/W_d/b_d -> bool.
     ``out``: optional ``{name: tensor}`` the kernels write the gradients INTO (contiguous fp32 of the parameter's shape, on
     the device — e.g. views of one flat gradient buffer, ``distributed.GradSync``); names missing there are allocated."""
@@ -590,6 +599,8 @@ def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = N
     nbytes = lib.dmpnn_backward_ws_bytes(C.byref(st.args))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
     b.ws, b.ws_bytes = ws.data_ptr(), nbytes
+    if not launch:  # (trainer.FusedTrainer: the argument block only; `refs` keeps the scratch alive)
+        return grads, b, (ws, gout)
     with _OnDevice(dev):
         _lib.check(lib.dmpnn_backward(C.byref(b), _stream_ptr(dev)), "dmpnn_backward")
     return grads

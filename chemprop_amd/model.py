@@ -1,0 +1,323 @@
+"""f4: the model around the block — ``chemprop.models.MPNN`` (``models/model.py:60-161``) with a regression
+predictor (``nn/predictors.py:101-169``) — and its training step as ONE C call.
+
+:class:`MPNN` mirrors the reference's attribute names (``message_passing``, ``agg``, ``bn``, ``predictor``; ``predictor.ffn``,
+``predictor.criterion.task_weights``), so a state dict moves between the two for those keys, and its ``forward`` /
+``fingerprint`` / ``loss`` run on the engine's kernels through autograd like any torch module (the drop-in path).
+
+:class:`FusedTrainer` is the MI355X-native form of ``training_step`` + ``optimizer.step()`` (``model.py:148-161,208-231``):
+every parameter lives in ONE flat buffer, every gradient in another (``distributed.GradSync`` / ``optim.FlatAdam``), and a
+step is ``dmpnn_train_step`` — K0, the block's forward with kept tensors, aggregation, batch norm, the predictor's layers, the
+loss and its gradient, the backward pass of all of it and the Adam update are enqueued by one call (``csrc/dmpnn_head.hip``);
+nothing of the step runs in Python or in ATen.  With more than one rank the gradient all-reduce sits between the backward pass
+and the update (the step is then two calls around ``GradSync.allreduce``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Iterable, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib, engine
+from .agg import MODES, Aggregation, NormAggregation, note_batch
+from .distributed import GradSync
+from .ffn import MLP
+from .nn import BondMessagePassing, classify_activation
+from .optim import FlatAdam
+
+__all__ = ["MSE", "RegressionFFN", "MPNN", "FusedTrainer", "masked_loss"]
+
+
+def masked_loss(preds: Tensor, targets: Tensor, weights: Optional[Tensor] = None, task_weights: Optional[Tensor] = None,
+                lt_mask: Optional[Tensor] = None, gt_mask: Optional[Tensor] = None, kind: str = "mse") -> Tensor:
+    """``ChempropMetric.update`` + ``compute`` on one batch (``nn/metrics.py:78-127``) with the masking of
+    ``MPNN.training_step`` (``models/model.py:152-156``): torch ops, differentiable — the module path's criterion."""
+    mask = targets.isfinite()
+    targets = targets.nan_to_num(nan=0.0)
+    if lt_mask is not None:
+        preds = torch.where((preds < targets) & lt_mask, targets, preds)
+    if gt_mask is not None:
+        preds = torch.where((preds > targets) & gt_mask, targets, preds)
+    L = (preds - targets).abs() if kind == "mae" else torch.nn.functional.mse_loss(preds, targets, reduction="none")
+    w = torch.ones(targets.shape[0], dtype=torch.float, device=targets.device) if weights is None else weights
+    tw = 1.0 if task_weights is None else task_weights.view(1, -1)
+    L = L * w.view(-1, 1) * tw * mask
+    return L.sum() / mask.sum()
+
+
+class MSE(nn.Module):
+    """The criterion's state (``nn/metrics.py:60-76``: a ``task_weights`` buffer of shape ``[1, t]``) and its batch value."""
+
+    kind = "mse"
+
+    def __init__(self, task_weights=1.0):
+        super().__init__()
+        self.register_buffer("task_weights", torch.as_tensor(task_weights, dtype=torch.float).view(1, -1))
+
+    def forward(self, preds, targets, mask=None, weights=None, lt_mask=None, gt_mask=None):
+        t = targets if mask is None else torch.where(mask, targets, torch.full_like(targets, float("nan")))
+        return masked_loss(preds, t, weights, self.task_weights, lt_mask, gt_mask, self.kind)
+
+
+class MAE(MSE):
+    kind = "mae"
+
+
+class RegressionFFN(nn.Module):
+    """``chemprop.nn.predictors.RegressionFFN`` (``predictors.py:101-169``): ``ffn = MLP.build(input_dim, n_tasks, hidden_dim,
+    n_layers, dropout, activation)``, criterion MSE, identity output transform while training."""
+
+    n_targets = 1
+
+    def __init__(self, n_tasks: int = 1, input_dim: int = 300, hidden_dim: int = 300, n_layers: int = 1, dropout: float = 0.0,
+                 activation="relu", criterion: Optional[nn.Module] = None, task_weights: Optional[Tensor] = None):
+        super().__init__()
+        self.hparams = dict(n_tasks=n_tasks, input_dim=input_dim, hidden_dim=hidden_dim, n_layers=n_layers, dropout=dropout,
+                            activation=activation, cls=self.__class__)
+        self.ffn = MLP.build(input_dim, n_tasks * self.n_targets, hidden_dim, n_layers, dropout, activation)
+        self.criterion = criterion if criterion is not None else MSE(torch.ones(n_tasks) if task_weights is None else task_weights)
+        self.output_transform = nn.Identity()
+
+    @property
+    def input_dim(self) -> int:
+        return self.ffn.input_dim
+
+    @property
+    def output_dim(self) -> int:
+        return self.ffn.output_dim
+
+    @property
+    def n_tasks(self) -> int:
+        return self.output_dim // self.n_targets
+
+    def forward(self, Z: Tensor) -> Tensor:
+        return self.output_transform(self.ffn(Z))
+
+    train_step = forward
+
+
+class MPNN(nn.Module):
+    """``chemprop.models.MPNN`` (``models/model.py:60-146``) without Lightning: the four sub-modules under the reference's
+    names and ``fingerprint`` / ``forward``; ``loss(batch)`` is the arithmetic of ``training_step`` (``model.py:148-161``)."""
+
+    def __init__(self, message_passing: nn.Module, agg: nn.Module, predictor: nn.Module, batch_norm: bool = False):
+        super().__init__()
+        if message_passing.output_dim != predictor.input_dim:
+            raise ValueError(f"message passing output dim {message_passing.output_dim} != predictor input dim {predictor.input_dim}")
+        self.message_passing = message_passing
+        self.agg = agg
+        self.bn = nn.BatchNorm1d(message_passing.output_dim) if batch_norm else nn.Identity()
+        self.predictor = predictor
+
+    @property
+    def criterion(self):
+        return self.predictor.criterion
+
+    def fingerprint(self, bmg, V_d: Optional[Tensor] = None, X_d: Optional[Tensor] = None) -> Tensor:
+        H = self.bn(self.agg(self.message_passing(bmg, V_d), bmg.batch))
+        return H if X_d is None else torch.cat((H, X_d), dim=1)
+
+    def forward(self, bmg, V_d: Optional[Tensor] = None, X_d: Optional[Tensor] = None) -> Tensor:
+        return self.predictor(self.fingerprint(bmg, V_d, X_d))
+
+    def loss(self, bmg, targets: Tensor, weights: Optional[Tensor] = None, lt_mask: Optional[Tensor] = None,
+             gt_mask: Optional[Tensor] = None, V_d: Optional[Tensor] = None, X_d: Optional[Tensor] = None) -> Tensor:
+        preds = self.predictor.train_step(self.fingerprint(bmg, V_d, X_d))
+        c = self.criterion
+        return masked_loss(preds, targets, weights, getattr(c, "task_weights", None), lt_mask, gt_mask, getattr(c, "kind", "mse"))
+
+
+class FusedTrainer:
+    """``training_step`` + ``Adam.step`` of an :class:`MPNN` as one ``dmpnn_train_step`` call per batch.
+
+    Takes what the kernels implement and refuses the rest loudly (those models train through the module path): a
+    :class:`~chemprop_amd.nn.BondMessagePassing` block with a built-in activation, no ``V_d``, dropout 0, directed; sum / mean /
+    norm aggregation; optional ``nn.BatchNorm1d``; an MLP predictor with a built-in activation and dropout 0; MSE / MAE.
+    """
+
+    def __init__(self, model: MPNN, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, group=None):
+        mp, agg, pred = model.message_passing, model.agg, model.predictor
+        # a bond block: this package's mirror, or the subclass of the reference's own class (integration.HipBondMessagePassing):
+        # W_h is [d_h, d_h] there (the atom variant's takes d_e + d_h columns, the mol-atom-bond ones have a second read-out)
+        bond = (all(isinstance(getattr(mp, n, None), nn.Linear) for n in ("W_i", "W_h", "W_o"))
+                and mp.W_h.in_features == mp.W_h.out_features and mp.W_o.in_features > mp.W_h.out_features)
+        if not bond:
+            raise NotImplementedError("FusedTrainer: a BondMessagePassing block (W_i / W_h [d_h, d_h] / W_o)")
+        act, slope, slope_t = classify_activation(mp.tau)
+        if act in ("custom", "prelu") or mp.dropout.p > 0 or mp.undirected or mp.W_d is not None:
+            raise NotImplementedError("FusedTrainer: built-in activation (not PReLU), dropout 0, directed, no V_d — other blocks train "
+                                      "through the module path (MPNN.loss + autograd)")
+        mode = getattr(agg, "mode", None)
+        if mode not in MODES:
+            raise NotImplementedError(f"FusedTrainer: sum / mean / norm aggregation (got {type(agg).__name__})")
+        blocks = list(pred.ffn)
+        if len(blocks) > _lib.MAX_FFN_LAYERS:
+            raise NotImplementedError(f"FusedTrainer: at most {_lib.MAX_FFN_LAYERS} predictor layers")
+        f_act, f_slope = "none", 0.0
+        for b in blocks[1:]:
+            code, sl, _ = classify_activation(b[0])
+            if code in ("custom", "prelu") or b[1].p > 0:
+                raise NotImplementedError("FusedTrainer: predictor with a built-in activation (not PReLU) and dropout 0")
+            f_act, f_slope = code, sl
+        if not isinstance(pred.output_transform, nn.Identity):
+            raise NotImplementedError("FusedTrainer: the output transform is the identity while training (predictors.py:166-169)")
+        kind = getattr(pred.criterion, "kind", None)
+        if kind not in _lib.LOSS:
+            raise NotImplementedError("FusedTrainer: MSE / MAE criterion")
+        self.model, self.mp = model, mp
+        self.act, self.slope = act, slope
+        self.agg_mode, self.agg_norm = MODES[mode], float(getattr(agg, "norm", 1.0))
+        self.f_act, self.f_slope, self.kind = f_act, f_slope, kind
+        self.layers = [b[-1] for b in blocks]
+        self.bn = model.bn if isinstance(model.bn, nn.BatchNorm1d) else None
+        if self.bn is not None and (self.bn.momentum is None or not self.bn.affine or not self.bn.track_running_stats):
+            raise NotImplementedError("FusedTrainer: nn.BatchNorm1d with a fixed momentum, affine, running statistics")
+        params = [p for p in model.parameters() if p.requires_grad]
+        engine._require_device(params[0], "model parameters")
+        self.sync = GradSync(params, modules=[model], group=group)
+        self.opt = FlatAdam(self.sync, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.dev = params[0].device
+        self._views = {id(p): v for p, v in zip(self.sync.params, self.sync.views)}
+        self._checked = 0
+        self._level = None
+        self.last_route = None
+
+    # ---- helpers ----
+    def _gv(self, p: Optional[Tensor]) -> Optional[int]:
+        if p is None or not p.requires_grad:
+            return None
+        return self._views[id(p)].data_ptr()
+
+    def _world(self) -> int:
+        d = torch.distributed
+        return d.get_world_size(self.sync.group) if (d.is_available() and d.is_initialized()) else 1
+
+    def step(self, bmg, targets: Tensor, weights: Optional[Tensor] = None, lt_mask: Optional[Tensor] = None,
+             gt_mask: Optional[Tensor] = None, lr: Optional[float] = None) -> Tensor:
+        """One optimisation step on ``(bmg, targets, ...)`` (a ``TrainingBatch`` without ``V_d`` / ``X_d``); returns the device
+        tensor ``[loss, number of finite targets]`` of THIS step (no host sync).  ``model.train()`` semantics (batch norm uses
+        and updates batch statistics)."""
+        from .nn import _VALIDATE_FIRST_N, _route
+
+        lib = _lib.load()
+        mp, dev = self.mp, self.dev
+        engine._require_device(bmg.V, "bmg.V")
+        batch = bmg.batch
+        n_mols = len(bmg)
+        nV, nE = int(bmg.V.shape[0]), int(bmg.E.shape[0])
+        T = engine._f32c(targets, "targets")
+        if T.dim() != 2 or T.shape[0] != n_mols or T.shape[1] != self.layers[-1].out_features or not T.is_contiguous():
+            raise ValueError(f"targets must be a contiguous [{n_mols}, {self.layers[-1].out_features}] matrix, got {tuple(targets.shape)}")
+        validate = _lib.opt("DMPNN_VALIDATE", "first") != "never" and self._checked < _VALIDATE_FIRST_N
+        world = self._world()
+        self.sync.wait()
+
+        # ---- K0: a launched plan while the first batches are validated (host read of the verdict), else inside the C call ----
+        plan = engine.GraphPlan.from_bmg(bmg, light=False, launch=validate)
+        plan.oversize = getattr(bmg, "oversize", None)
+        if validate:
+            self._checked += 1
+            level = _route(mp, plan, n_mols, batch)
+        else:
+            no_mega = getattr(mp, "_dmpnn_no_mega", False) or (n_mols > 0 and nE > 30 * n_mols)
+            level = 1 if no_mega else 2
+        if plan.oversize is True:
+            level = min(level, 1)
+        note_batch(batch, n_mols)
+
+        # ---- argument blocks of the block's forward / backward (workspace allocated, nothing enqueued) ----
+        W = lambda lin, n: getattr(getattr(mp, lin), n)
+        out, st = engine.forward(plan, bmg.V, bmg.E, W("W_i", "weight"), W("W_h", "weight"), W("W_o", "weight"), W("W_o", "bias"),
+                                 W("W_i", "bias"), W("W_h", "bias"), depth=mp.depth, act=self.act, slope=self.slope, keep=True,
+                                 max_level=level, launch=False)
+        self.last_route = st.route
+        d_out = int(out.shape[1])
+        gout = torch.empty(nV, d_out, dtype=torch.float32, device=dev)
+        need, views = {}, {}
+        for k, (lin, n) in dict(W_i=("W_i", "weight"), b_i=("W_i", "bias"), W_h=("W_h", "weight"), b_h=("W_h", "bias"),
+                                W_o=("W_o", "weight"), b_o=("W_o", "bias")).items():
+            p = W(lin, n)
+            need[k] = p is not None and p.requires_grad
+            if need[k]:
+                views[k] = self._views[id(p)]
+        grads, b, keep_b = engine.backward(st, gout, need, out=views, launch=False)
+        for k, g in grads.items():  # (a view the engine did not take would silently drop the gradient)
+            if g is not None and g is not views.get(k):
+                raise RuntimeError(f"FusedTrainer: the gradient view of {k} was not accepted (dtype / layout)")
+
+        # ---- the head ----
+        h = _lib.HeadArgs()
+        h.n_atoms, h.n_mols, h.d_h = nV, n_mols, d_out
+        h.batch = batch.data_ptr()
+        h.agg_mode, h.agg_norm = self.agg_mode, self.agg_norm
+        bn = self.bn
+        if bn is not None:
+            h.bn_weight, h.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
+            h.bn_running_mean, h.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            h.bn_eps, h.bn_momentum, h.bn_training = float(bn.eps), float(bn.momentum), 1
+            h.g_bn_weight, h.g_bn_bias = self._gv(bn.weight), self._gv(bn.bias)
+        h.n_layers, h.act, h.act_slope = len(self.layers), _lib.ACT[self.f_act], float(self.f_slope)
+        h.dims[0] = d_out
+        for l, lin in enumerate(self.layers):
+            h.W[l], h.b[l] = lin.weight.data_ptr(), (None if lin.bias is None else lin.bias.data_ptr())
+            h.dims[l + 1] = lin.out_features
+            h.gW[l], h.gb[l] = self._gv(lin.weight), self._gv(lin.bias)
+        h.loss = _lib.LOSS[self.kind]
+        h.targets = T.data_ptr()
+        keep = [T, gout, keep_b, st, plan]
+        if weights is not None:
+            wt = engine._f32c(weights.reshape(-1, 1), "weights").reshape(-1).contiguous()
+            h.weights = wt.data_ptr()
+            keep.append(wt)
+        tw = getattr(self.model.predictor.criterion, "task_weights", None)
+        if tw is not None:
+            tw = tw.reshape(-1).float()
+            if tw.numel() == 1 and int(self.layers[-1].out_features) > 1:  # (task_weights = 1.0 broadcasts over the tasks, metrics.py:69-70)
+                tw = tw.expand(int(self.layers[-1].out_features))
+            tw = tw.contiguous()
+            h.task_weights = tw.data_ptr()
+            keep.append(tw)
+        for name, m in (("lt_mask", lt_mask), ("gt_mask", gt_mask)):
+            if m is not None:
+                m8 = m.to(torch.uint8).contiguous()
+                setattr(h, name, m8.data_ptr())
+                keep.append(m8)
+        t = int(self.layers[-1].out_features)
+        preds = torch.empty(n_mols, t, dtype=torch.float32, device=dev)
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        h.preds, h.loss_out = preds.data_ptr(), loss.data_ptr()
+        h.gHv, h.ldg = gout.data_ptr(), d_out
+        nb = int(lib.dmpnn_head_ws_bytes(C.byref(h)))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        h.ws, h.ws_bytes = ws.data_ptr(), nb
+
+        s = _lib.StepArgs()
+        s.edge_index, s.rev_edge_index = plan.edge_index.data_ptr(), plan.rev_edge_index.data_ptr()
+        bt = batch if (batch.dtype == torch.int64 and batch.is_contiguous()) else None
+        s.batch = None if bt is None else bt.data_ptr()
+        s.plan_bytes, s.plan_ready = plan.buf.numel() * 4, (1 if validate else 0)
+        s.bwd, s.head = b, h
+        opt = self.opt
+        fused_update = world == 1
+        if fused_update:
+            opt.steps += 1
+            b1, b2 = opt.betas
+            s.p, s.g, s.m, s.v, s.n_params = opt.flat.data_ptr(), self.sync.flat.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr(), opt.flat.numel()
+            s.lr, s.beta1, s.beta2, s.eps, s.weight_decay = float(opt.lr if lr is None else lr), b1, b2, opt.eps, opt.weight_decay
+            s.bias_corr1, s.sqrt_bias_corr2, s.grad_scale = 1.0 - b1 ** opt.steps, math.sqrt(1.0 - b2 ** opt.steps), 1.0
+        with engine._OnDevice(dev):
+            _lib.check(lib.dmpnn_train_step(C.byref(s), engine._stream_ptr(dev)), "dmpnn_train_step")
+        if bn is not None:
+            bn.num_batches_tracked += 1
+        self.preds = preds
+        if fused_update:
+            for p in self.sync.params:  # (the engine's weight caches key on the autograd version)
+                torch.autograd.graph.increment_version(p)
+            self.sync.new_step()
+        else:
+            self.sync.allreduce()
+            opt.step(lr)
+        return loss

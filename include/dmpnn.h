@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 7
+#define DMPNN_ABI_VERSION 8
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -133,6 +133,10 @@ int dmpnn_tile_plan_any_size(int64_t n_atoms, int64_t n_edges);
  * on such a plan passes DMPNN_F_LOADER_TILES.                                                                       */
 int dmpnn_prepare_with_batch(const int64_t* edge_index, const int64_t* rev_edge_index, const int64_t* batch, int64_t n_atoms,
                              int64_t n_edges, void* plan, size_t plan_bytes, void* stream);
+/* 1 when dmpnn_prepare_with_batch (batch != NULL) leaves molecule tiles in the full plan of a batch of this size — within the
+ * single-workgroup plan always (piece tiles), beyond it where the multi-workgroup planner's scratch fits — i.e. when a forward on
+ * that plan may pass DMPNN_F_MEGA (| DMPNN_F_LOADER_TILES beyond the single-workgroup plan); 0: plain dmpnn_prepare, no tiles. */
+int dmpnn_full_plan_keeps_tiles(int64_t n_atoms, int64_t n_edges);
 
 /* Plan header words (int32) readable by the caller after a stream sync (diagnostics/tests). */
 enum dmpnn_plan_hdr {
@@ -404,6 +408,58 @@ int dmpnn_prepare_tiles_from_table(const int* tile_row, const int* tile_atom, in
 int dmpnn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float bias_corr1, float sqrt_bias_corr2, float grad_scale, const float* dev_scalars,
                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f4, the rest of the model: what chemprop.models.MPNN does after the block in a training step (models/model.py:126-134,
+ * 148-161) as ONE call —  H = agg(H_v, batch) (nn/agg.py:66-113);  Z = bn(H) (nn.BatchNorm1d, model.py:94,132);
+ * P = ffn(Z) (nn/ffn.py:24-68 under nn/predictors.py:161-169: Linear, then (act, dropout = 0, Linear) blocks);
+ * loss = sum(L w_i t_j mask) / sum(mask), mask = isfinite(targets) (model.py:152-156, nn/metrics.py:78-127; L: MSE :137-141,
+ * MAE :146-148, with lt_mask / gt_mask the bounded variants :157-163) — and, when gHv != NULL, the gradients of the loss
+ * with respect to every parameter and to H_v (the `gout` of dmpnn_backward).  All pointers device pointers, fp32, dense
+ * row-major (ld = width) unless an ld is given.  bn_training != 0: batch statistics, running statistics updated in place
+ * (momentum; unbiased variance); 0: running statistics.  The reference's nn.BatchNorm1d also counts num_batches_tracked: the
+ * caller's business (an int64 buffer that does not enter the arithmetic with a fixed momentum).
+ * ------------------------------------------------------------------------------------------- */
+#define DMPNN_MAX_FFN_LAYERS 8
+enum dmpnn_loss { DMPNN_LOSS_MSE = 0, DMPNN_LOSS_MAE = 1 };
+typedef struct dmpnn_head_args {
+    int64_t n_atoms, n_mols, d_h;           /* rows of H_v, molecules, width of H_v                              */
+    const int64_t* batch;                   /* [n_atoms] molecule of every atom, non-decreasing (BatchMolGraph.batch) */
+    int32_t agg_mode; float agg_norm;       /* enum dmpnn_molagg_mode; the norm of NormAggregation                  */
+    const float* bn_weight; const float* bn_bias;  /* [d_h] each; bn_weight == NULL: no batch norm (nn.Identity)   */
+    float* bn_running_mean; float* bn_running_var; /* [d_h] each, updated in place when bn_training               */
+    float bn_eps, bn_momentum; int32_t bn_training;
+    int32_t n_layers; int32_t act; float act_slope;       /* Linear layers of the predictor; enum dmpnn_activation */
+    const float* W[DMPNN_MAX_FFN_LAYERS];   /* W[l]: [dims[l+1], dims[l]]  (nn.Linear layout)                       */
+    const float* b[DMPNN_MAX_FFN_LAYERS];   /* [dims[l+1]] or NULL                                                  */
+    int64_t dims[DMPNN_MAX_FFN_LAYERS + 1]; /* dims[0] = d_h ... dims[n_layers] = n_tasks                           */
+    int32_t loss;                           /* enum dmpnn_loss                                                      */
+    const float* targets;                   /* [n_mols, n_tasks], NaN / inf = missing; NULL: predictions only       */
+    const float* weights;                   /* [n_mols] or NULL (ones)                                              */
+    const float* task_weights;              /* [n_tasks] or NULL (ones)                                             */
+    const unsigned char* lt_mask; const unsigned char* gt_mask;  /* [n_mols, n_tasks] bytes or NULL (unbounded)    */
+    float* preds;                           /* out [n_mols, n_tasks]                                                */
+    float* loss_out;                        /* out, 2 floats: the loss, the number of finite targets                */
+    float* gW[DMPNN_MAX_FFN_LAYERS]; float* gb[DMPNN_MAX_FFN_LAYERS];  /* out (NULL: not wanted), nn.Linear layout  */
+    float* g_bn_weight; float* g_bn_bias;   /* out [d_h] or NULL                                                    */
+    float* gHv; int64_t ldg;                /* out [n_atoms, ldg] dloss / dH_v; NULL: forward (and loss) only       */
+    void* ws; size_t ws_bytes;              /* caller-owned scratch, >= dmpnn_head_ws_bytes()                       */
+} dmpnn_head_args;
+size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h);
+int dmpnn_head(const dmpnn_head_args* h, const float* Hv, int64_t ldhv, void* stream);
+
+/* One training step of models/model.py:148-161 with torch.optim.Adam (model.py:208-231), every kernel enqueued by ONE call:
+ * K0 (dmpnn_prepare_with_batch into bwd.f.plan unless plan_ready) -> dmpnn_forward(&bwd.f) (DMPNN_F_KEEP) -> dmpnn_head on
+ * bwd.f.out (head.gHv must be bwd.gout) -> dmpnn_backward(&bwd) -> dmpnn_adam_step over the flat buffers (n_params == 0: no
+ * optimizer step).  The argument structs are exactly those of the separate entry points; nothing is allocated. */
+typedef struct dmpnn_step_args {
+    const int64_t* edge_index; const int64_t* rev_edge_index; const int64_t* batch; size_t plan_bytes; int32_t plan_ready;
+    dmpnn_bwd_args bwd;                     /* bwd.f: the forward of the block                                     */
+    dmpnn_head_args head;
+    float* p; const float* g; float* m; float* v; int64_t n_params;   /* flat parameter / gradient / moment buffers */
+    float lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrt_bias_corr2, grad_scale; const float* dev_scalars;
+} dmpnn_step_args;
+int dmpnn_train_step(const dmpnn_step_args* a, void* stream);
 
 int dmpnn_version(void);
 /* Debug aid: a device buffer of 32 int64 that workgroup 0 of the whole-forward tile kernel fills with

@@ -179,7 +179,8 @@ def install() -> None:
     mixins.HyperparametersMixin = _HyperparametersMixin
 
     class LightningModule(nn.Module, _HyperparametersMixin):
-        pass
+        def log(self, *a, **k):  # (Lightning's logger hook: bookkeeping, no arithmetic — models/model.py:159)
+            pass
 
     sys.modules["lightning.pytorch"].LightningModule = LightningModule
     sys.modules["lightning.fabric.utilities.data"].AttributeDict = _AttributeDict
@@ -191,9 +192,24 @@ def install() -> None:
     class Metric(nn.Module):
         def __init__(self, *a, **k):
             super().__init__()
+            self._shim_states = {}
 
         def add_state(self, name, default, dist_reduce_fx=None, persistent=False):
-            setattr(self, name, default)
+            self._shim_states[name] = default
+            setattr(self, name, default.clone() if hasattr(default, "clone") else default)
+
+        def forward(self, *a, **k):
+            """``torchmetrics.Metric.forward`` for ``full_state_update = False`` (what ChempropMetric declares, metrics.py:62-63):
+            the value of THIS batch — ``update`` on a fresh state, ``compute`` — while the batch's state is also added to the
+            accumulated one (``dist_reduce_fx="sum"`` states).  ``MPNN.training_step`` back-propagates through this value."""
+            acc = {n: getattr(self, n) for n in self._shim_states}
+            for n, d in self._shim_states.items():
+                setattr(self, n, d.clone() if hasattr(d, "clone") else d)
+            self.update(*a, **k)
+            val = self.compute()
+            for n in self._shim_states:
+                setattr(self, n, acc[n] + getattr(self, n).detach())
+            return val
 
         def clone(self):
             return _copy.deepcopy(self)

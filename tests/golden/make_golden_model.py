@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Freeze golden vectors of ``chemprop.models.MPNN.training_step`` + ``torch.optim.Adam`` (f4: the whole training step) from
+the EXECUTED reference.
+
+    python tests/golden/make_golden_model.py        # rewrites tests/golden/model/*.npz   (build container only)
+
+The reference's own ``MPNN`` (``models/model.py:60-161``) with its own ``BondMessagePassing``, aggregation, ``nn.BatchNorm1d``,
+``RegressionFFN`` and criterion, imported through ``oracle/ref_shim.py`` (Lightning's ``self.log`` is a no-op there and the
+criterion's ``torchmetrics.Metric.forward`` is the batch value of ``update`` + ``compute``, see the shim); CPU torch, fp32,
+``model.train()``.  Two optimisation steps with ``torch.optim.Adam(model.parameters(), lr)`` (what ``configure_optimizers``
+builds, ``model.py:208-231``; the learning rate is held constant): the batch, the initial parameters, and per step the loss,
+the predictions, every parameter gradient; the parameters and batch-norm buffers after the last step.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from chemprop_amd import synth  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "model")
+
+# name -> dict(n_mols, kind, mp kwargs, agg, bn, predictor kwargs, criterion, nan targets, sample weights, bounds, seed)
+CASES = {
+    "qm9_norm_default": dict(n=24, kind="qm9", mp=dict(d_h=64), agg="norm", bn=False, ffn=dict(n_tasks=1, hidden_dim=48), seed=90),
+    "qm9_mean_bn_multitask": dict(n=20, kind="qm9", mp=dict(d_h=48, depth=4, bias=True), agg="mean", bn=True,
+                                  ffn=dict(n_tasks=3, hidden_dim=40, n_layers=2), task_weights=[1.0, 2.0, 0.5], nan=0.2, weights=True, seed=91),
+    "zinc_sum_bn_mae_tanh": dict(n=6, kind="zinc", mp=dict(d_h=40, activation="tanh"), agg="sum", bn=True,
+                                 ffn=dict(n_tasks=2, hidden_dim=32, activation="tanh"), criterion="mae", nan=0.1, seed=92),
+    "qm9_bounded_mse": dict(n=16, kind="qm9", mp=dict(d_h=32, activation="leakyrelu"), agg="norm", bn=False,
+                            ffn=dict(n_tasks=2, hidden_dim=24, activation="elu"), criterion="bounded-mse", bounds=True, seed=93),
+    # (the CLI's default widths — d_h 300, hidden 300 — are checked at size on the GPU against the restatement these cases pin and
+    #  against the staged reference executed live: tests/test_model.py)
+}
+LR = 1e-3
+STEPS = 2
+
+
+def build(R, cfg):
+    BMP, cnn, MPNN = R["BMP"], R["nn"], R["MPNN"]
+    agg = dict(norm=cnn.NormAggregation, mean=cnn.MeanAggregation, sum=cnn.SumAggregation)[cfg["agg"]]()
+    mp = BMP(**cfg["mp"])
+    crit = None
+    tw = cfg.get("task_weights")
+    kind = cfg.get("criterion", "mse")
+    if kind != "mse" or tw is not None:
+        cls = {"mse": cnn.MSE, "mae": cnn.MAE, "bounded-mse": cnn.BoundedMSE}[kind]
+        crit = cls(task_weights=tw if tw is not None else 1.0)
+    pred = cnn.RegressionFFN(input_dim=mp.output_dim, criterion=crit, **cfg["ffn"])
+    return MPNN(mp, agg, pred, batch_norm=cfg["bn"])
+
+
+def main():
+    BMP, BMG, _ = ref_shim.load_reference()
+    _, _, _, MPNN, cnn = ref_shim.load_reference_extras()
+    R = dict(BMP=BMP, nn=cnn, MPNN=MPNN)
+    torch.set_num_threads(1)
+    os.makedirs(OUT, exist_ok=True)
+    for name, cfg in CASES.items():
+        seed = cfg["seed"]
+        torch.manual_seed(seed)
+        model = build(R, cfg).train()
+        bmg = BMG(synth.random_molgraphs(cfg["n"], cfg["kind"], seed=seed))
+        gen = torch.Generator().manual_seed(5000 + seed)
+        t = cfg["ffn"]["n_tasks"]
+        targets = torch.randn(cfg["n"], t, generator=gen)
+        if cfg.get("nan"):
+            drop = torch.rand(cfg["n"], t, generator=gen) < cfg["nan"]
+            drop[0, 0] = False
+            targets[drop] = float("nan")
+        weights = (0.5 + torch.rand(cfg["n"], 1, generator=gen)) if cfg.get("weights") else torch.ones(cfg["n"], 1)
+        lt = (torch.rand(cfg["n"], t, generator=gen) < 0.3) if cfg.get("bounds") else torch.zeros(cfg["n"], t, dtype=torch.bool)
+        gt = (torch.rand(cfg["n"], t, generator=gen) < 0.3) if cfg.get("bounds") else torch.zeros(cfg["n"], t, dtype=torch.bool)
+        arrs = dict(V=bmg.V.numpy(), E=bmg.E.numpy(), edge_index=bmg.edge_index.numpy(), rev_edge_index=bmg.rev_edge_index.numpy(),
+                    batch=bmg.batch.numpy(), targets=targets.numpy(), weights=weights.numpy(), lt_mask=lt.numpy(), gt_mask=gt.numpy())
+        for k, v in model.state_dict().items():
+            if not k.startswith("metrics."):
+                arrs["w0." + k] = v.detach().numpy().copy()
+        opt = torch.optim.Adam(model.parameters(), LR)
+        losses = []
+        for step in range(STEPS):
+            opt.zero_grad()
+            loss = model.training_step((bmg, None, None, targets, weights, lt, gt), step)   # models/model.py:148-161, verbatim
+            loss.backward()
+            with torch.no_grad():
+                preds = None
+            for k, p in model.named_parameters():
+                arrs[f"g{step}." + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            arrs[f"loss{step}"] = np.float32(loss.item())
+            losses.append(float(loss))
+            opt.step()
+        for k, v in model.state_dict().items():
+            if not k.startswith("metrics."):
+                arrs["w2." + k] = v.detach().numpy().copy()
+        model.eval()
+        with torch.no_grad():
+            arrs["preds_eval"] = model(bmg).numpy()           # predictions of the trained model (eval: running statistics)
+        meta = dict(name=name, seed=seed, cfg={k: v for k, v in cfg.items()}, lr=LR, steps=STEPS, torch=torch.__version__,
+                    losses=losses, n_mols=cfg["n"])
+        arrs["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+        print(f"{name:26s} mols={cfg['n']:3d} V={bmg.V.shape[0]:4d} E={bmg.E.shape[0]:4d} losses={losses}")
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_version_and_plan_bytes():
     lib = _lib.load()
-    assert lib.dmpnn_version() == _lib.ABI_VERSION == 7
+    assert lib.dmpnn_version() == _lib.ABI_VERSION == 8
     assert lib.dmpnn_plan_bytes(0, 0) >= 64
     b = lib.dmpnn_plan_bytes(4319, 8328)
     assert b % 16 == 0 and b >= 4 * (16 + 9 * 8328 + 2 * 4319)
@@ -79,7 +79,8 @@ def test_argument_errors_are_codes_not_crashes():
 def test_struct_layout_matches_header_field_order():
     """ctypes mirrors must list the fields in the order of the C structs."""
     src = open(os.path.join(ROOT, "include", "dmpnn.h")).read()
-    for struct, mirror in (("dmpnn_gemm_args", _lib.GemmArgs), ("dmpnn_fwd_args", _lib.FwdArgs)):
+    for struct, mirror in (("dmpnn_gemm_args", _lib.GemmArgs), ("dmpnn_fwd_args", _lib.FwdArgs), ("dmpnn_bwd_args", _lib.BwdArgs),
+                           ("dmpnn_head_args", _lib.HeadArgs), ("dmpnn_step_args", _lib.StepArgs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), src, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
@@ -88,8 +89,36 @@ def test_struct_layout_matches_header_field_order():
             if not decl:
                 continue
             for part in decl.split(","):
+                part = re.sub(r"\[[^\]]*\]\s*$", "", part.strip())   # (array members: W[DMPNN_MAX_FFN_LAYERS])
                 fields.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
         assert fields == [f[0] for f in mirror._fields_], struct
+
+
+def test_struct_sizes_and_offsets_match_a_c_compiler(tmp_path):
+    """sizeof / offsetof of every argument struct as gcc lays out include/dmpnn.h == the ctypes mirrors."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    mirrors = dict(dmpnn_gemm_args=_lib.GemmArgs, dmpnn_fwd_args=_lib.FwdArgs, dmpnn_bwd_args=_lib.BwdArgs, dmpnn_head_args=_lib.HeadArgs,
+                   dmpnn_step_args=_lib.StepArgs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dmpnn.h"', "int main(void) {"]
+    for name, m in mirrors.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f in m._fields_:
+            lines.append(f'printf("{name}.{f[0]} %zu\\n", offsetof({name}, {f[0]}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, m in mirrors.items():
+        assert int(out[name]) == C.sizeof(m), name
+        for f in m._fields_:
+            assert int(out[f"{name}.{f[0]}"]) == getattr(m, f[0]).offset, f"{name}.{f[0]}"
+    assert _lib.MAX_FFN_LAYERS == 8
 
 
 def test_build_is_gfx950_only():

@@ -1,0 +1,264 @@
+"""f4 — the whole training step (``models/model.py:148-161`` + ``torch.optim.Adam``): the restatement against goldens frozen from
+the executed reference (CPU), the fused ``dmpnn_train_step`` against goldens, restatement, module path and — where the staged
+reference travelled — the reference's own ``MPNN.training_step`` executed live (GPU)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, parity_err
+from oracle import model_torch as om
+from oracle import ref_shim
+
+CASES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "model", "*.npz")))
+
+
+class G:
+    def __init__(self, path):
+        z = np.load(path)
+        self.a = {k: z[k] for k in z.files}
+        self.meta = json.loads(bytes(self.a.pop("meta")).decode())
+        self.cfg = self.meta["cfg"]
+        self.name = self.meta["name"]
+
+    def t(self, k):
+        return torch.from_numpy(np.array(self.a[k]))
+
+    def state(self, prefix):
+        return {k[len(prefix):]: torch.from_numpy(np.array(v)) for k, v in self.a.items() if k.startswith(prefix)}
+
+    def bmg(self, device="cpu"):
+        from chemprop_amd.data import BatchMolGraph
+
+        b = BatchMolGraph.from_tensors(self.t("V"), self.t("E"), self.t("edge_index"), self.t("rev_edge_index"), self.t("batch"), self.meta["n_mols"])
+        if device != "cpu":
+            b.to(device)
+        return b
+
+    def batch_args(self, device="cpu"):
+        bounded = self.cfg.get("criterion", "mse").startswith("bounded")
+        mv = lambda x: x.to(device)
+        return (mv(self.t("targets")), mv(self.t("weights")), mv(self.t("lt_mask")) if bounded else None, mv(self.t("gt_mask")) if bounded else None)
+
+
+@pytest.fixture(params=CASES, ids=[os.path.basename(c)[:-4] for c in CASES])
+def g(request):
+    return G(request.param)
+
+
+def test_goldens_exist():
+    assert len(CASES) >= 4
+
+
+def test_restatement_matches_executed_reference(g):
+    """oracle/model_torch.py == the reference's own training_step + Adam: losses, every gradient of both steps, the parameters
+    and batch-norm buffers after the second step."""
+    targets, weights, lt, gt = g.batch_args()
+    m, losses, grads = om.train_steps(g.state("w0."), g.cfg, g.bmg(), targets, weights, g.t("lt_mask"), g.t("gt_mask"), g.meta["lr"], g.meta["steps"])
+    for s in range(g.meta["steps"]):
+        assert abs(losses[s] - float(g.a[f"loss{s}"])) <= 1e-6 * max(1.0, abs(losses[s])), (s, losses[s], float(g.a[f"loss{s}"]))
+        for k, v in grads[s].items():
+            assert parity_err(v.numpy(), g.a[f"g{s}.{k}"]) <= 1e-6, (s, k)
+    for k, v in m.state().items():
+        ref = g.a["w2." + k]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref)
+        elif k.endswith("task_weights"):
+            assert np.array_equal(v.numpy().reshape(-1), ref.reshape(-1))
+        else:
+            assert parity_err(v.numpy(), ref) <= 2e-6, k
+
+
+def test_module_criterion_is_the_reference_formula():
+    """chemprop_amd.model.masked_loss (the module path's criterion, torch ops) == the restated criterion, all variants."""
+    from chemprop_amd.model import masked_loss
+
+    gen = torch.Generator().manual_seed(0)
+    P, T = torch.randn(30, 4, generator=gen), torch.randn(30, 4, generator=gen)
+    T[torch.rand(30, 4, generator=gen) < 0.2] = float("nan")
+    w, tw = torch.rand(30, 1, generator=gen) + 0.5, torch.tensor([1.0, 0.3, 2.0, 1.5])
+    lt, gt = torch.rand(30, 4, generator=gen) < 0.3, torch.rand(30, 4, generator=gen) < 0.3
+    for kind, bounded in (("mse", False), ("mae", False), ("mse", True), ("mae", True)):
+        a = masked_loss(P, T, w, tw, lt if bounded else None, gt if bounded else None, kind)
+        b = om.criterion(P, T, w, tw, lt, gt, ("bounded-" if bounded else "") + kind)
+        assert abs(float(a) - float(b)) <= 1e-7 * max(1.0, abs(float(b)))
+
+
+def build_mirror(cfg):
+    """The mirror model of a golden's configuration, constructed in the reference's order (same RNG stream)."""
+    from chemprop_amd import agg as cagg
+    from chemprop_amd.model import MAE, MPNN, MSE, RegressionFFN
+    from chemprop_amd.nn import BondMessagePassing
+
+    mp = BondMessagePassing(**cfg["mp"])
+    agg = dict(norm=cagg.NormAggregation, mean=cagg.MeanAggregation, sum=cagg.SumAggregation)[cfg["agg"]]()
+    kind = cfg.get("criterion", "mse")
+    t = cfg["ffn"]["n_tasks"]
+    crit = None
+    if kind != "mse" or cfg.get("task_weights") is not None:   # (an explicit criterion: task_weights as given, 1.0 -> shape [1, 1], broadcast)
+        crit = (MAE if kind.endswith("mae") else MSE)(cfg.get("task_weights") or 1.0)
+    pred = RegressionFFN(input_dim=mp.output_dim, criterion=crit, **cfg["ffn"])
+    return MPNN(mp, agg, pred, batch_norm=cfg["bn"])
+
+
+def test_mirror_state_dict_is_the_reference_s(g):
+    """Same keys and shapes as the reference's MPNN state dict (the bookkeeping ``metrics.*`` buffers aside), same initial
+    weights for the same seed: a checkpoint moves between the two."""
+    torch.manual_seed(g.meta["seed"])
+    model = build_mirror(g.cfg)
+    ref = g.state("w0.")
+    mine = model.state_dict()
+    assert set(mine.keys()) == set(ref.keys()), set(mine.keys()) ^ set(ref.keys())
+    for k, v in ref.items():
+        assert tuple(mine[k].shape) == tuple(v.shape), k
+        if "task_weights" not in k and "num_batches" not in k:
+            assert torch.equal(mine[k], v), k
+    model.load_state_dict(ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the fused step
+# ------------------------------------------------------------------------------------------------
+def _adam_reference(params0, grads_per_step, lr):
+    """torch.optim.Adam on the CPU driven by GIVEN gradients (checks the fused update's arithmetic on its own)."""
+    ps = [p.clone().requires_grad_(True) for p in params0]
+    opt = torch.optim.Adam(ps, lr)
+    for gs in grads_per_step:
+        for p, gr in zip(ps, gs):
+            p.grad = gr.clone()
+        opt.step()
+    return [p.detach() for p in ps]
+
+
+@pytest.mark.gpu
+def test_fused_step_matches_goldens(g, gpu_device):
+    from chemprop_amd.model import FusedTrainer
+
+    model = build_mirror(g.cfg)
+    model.load_state_dict(g.state("w0."))
+    model = model.to(gpu_device).train()
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    p0 = [p.detach().cpu().clone() for _, p in model.named_parameters() if p.requires_grad]
+    tr = FusedTrainer(model, lr=g.meta["lr"])
+    bmg = g.bmg(gpu_device)
+    targets, weights, lt, gt = g.batch_args(gpu_device)
+    bounded = g.cfg.get("criterion", "mse").startswith("bounded")
+    my_grads = []
+    for s in range(g.meta["steps"]):
+        out = tr.step(bmg, targets, weights, lt if bounded else None, gt if bounded else None)
+        torch.cuda.synchronize()
+        loss, n_fin = float(out[0]), float(out[1])
+        ref = float(g.a[f"loss{s}"])
+        # step 0: same parameters as the reference -> the fp32 bar; step 1: parameters after ONE Adam step, whose update
+        # g / (|g| + eps) amplifies 1e-7 differences of near-zero gradients -> a functional bar
+        assert abs(loss - ref) <= (1e-5 if s == 0 else 5e-4) * max(1.0, abs(ref)), (s, loss, ref)
+        assert n_fin == float(np.isfinite(g.a["targets"]).sum())
+        grads = [tr.sync.views[i].detach().cpu().clone() for i in range(len(tr.sync.params))]
+        my_grads.append(grads)
+        if s == 0:
+            by_name = dict(zip(names, grads))
+            for k, v in by_name.items():
+                err = parity_err(v.numpy(), g.a[f"g0.{k}"])
+                assert err <= 2e-5, f"{g.name} d{k}: {err:.3e}"
+    # the update itself: Adam on the CPU fed with the gradients the kernels produced
+    want = _adam_reference(p0, my_grads, g.meta["lr"])
+    for k, p, w in zip(names, [p for _, p in model.named_parameters() if p.requires_grad], want):
+        assert parity_err(p.detach().cpu().numpy(), w.numpy()) <= 2e-6, k
+    if g.cfg["bn"]:
+        for k in ("running_mean", "running_var"):
+            assert parity_err(getattr(model.bn, k).cpu().numpy(), g.a[f"w2.bn.{k}"]) <= 2e-5, k
+        assert int(model.bn.num_batches_tracked) == g.meta["steps"]
+    # and the trained model predicts like the reference's trained model (eval: running statistics, the inference kernels)
+    model.eval()
+    with torch.no_grad():
+        pe = model(bmg)
+    assert parity_err(pe.cpu().numpy(), g.a["preds_eval"]) <= 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mols,kind,bn,agg,tasks", [(512, "qm9", True, "norm", 1), (512, "qm9", False, "mean", 12), (128, "synth40", True, "sum", 2)])
+def test_fused_step_at_size_vs_restatement_and_module_path(n_mols, kind, bn, agg, tasks, gpu_device):
+    """The CLI's default widths (d_h 300, hidden 300) at BASELINE's batch size: loss and every gradient of the fused step against
+    (a) the restatement on the CPU, (b) autograd through the module path (the same kernels driven from Python), and — where the
+    staged reference is present — (c) the reference's own ``MPNN.training_step`` executed live."""
+    from chemprop_amd import synth
+    from chemprop_amd.model import FusedTrainer
+
+    cfg = dict(mp=dict(), agg=agg, bn=bn, ffn=dict(n_tasks=tasks))
+    torch.manual_seed(17)
+    model = build_mirror(cfg)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(23)
+    targets = torch.randn(n_mols, tasks, generator=gen)
+    if tasks > 1:
+        targets[torch.rand(n_mols, tasks, generator=gen) < 0.15] = float("nan")
+    weights = 0.5 + torch.rand(n_mols, 1, generator=gen)
+    cpu_bmg = synth.random_batch(n_mols, kind, seed=31)
+    ref_model = om.Model(state, cfg)
+    ref_loss = ref_model.loss(cpu_bmg, targets, weights, None, None)
+    ref_loss.backward()
+
+    model = model.to(gpu_device).train()
+    bmg = synth.random_batch(n_mols, kind, seed=31)
+    bmg.to(gpu_device)
+    tg, wg = targets.to(gpu_device), weights.to(gpu_device)
+    # (b) module path first (it does not touch the parameters)
+    loss_mod = model.loss(bmg, tg, wg)
+    loss_mod.backward()
+    mod_grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+    if bn:  # the module path's forward updated the running statistics once: restore, the fused step must do the same update itself
+        model.bn.load_state_dict({k[3:]: v for k, v in state.items() if k.startswith("bn.")})
+    model.zero_grad(set_to_none=True)
+    tr = FusedTrainer(model, lr=1e-4)
+    out = tr.step(bmg, tg, wg)
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss)))
+    assert abs(float(loss_mod) - float(ref_loss)) <= 1e-5 * max(1.0, abs(float(ref_loss)))
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    for i, k in enumerate(names):
+        gf = tr.sync.views[i].detach().cpu().numpy()
+        e_ref = parity_err(gf, ref_model.p[k].grad.numpy())
+        e_mod = parity_err(gf, mod_grads[k].numpy())
+        assert e_ref <= 2e-5 and e_mod <= 2e-5, f"{k}: vs restatement {e_ref:.2e}, vs module path {e_mod:.2e}"
+    if bn:
+        want = om.Model(state, cfg)
+        want.loss(cpu_bmg, targets, weights, None, None)
+        assert parity_err(model.bn.running_var.cpu().numpy(), want.buf["bn.running_var"].numpy()) <= 1e-5
+    if ref_shim.reference_available() and tasks == 1:
+        BMP, BMG, _ = ref_shim.load_reference()
+        _, _, _, RefMPNN, cnn = ref_shim.load_reference_extras()
+        ref = RefMPNN(BMP(), dict(norm=cnn.NormAggregation, mean=cnn.MeanAggregation, sum=cnn.SumAggregation)[agg](), cnn.RegressionFFN(n_tasks=tasks), batch_norm=bn)
+        ref.load_state_dict(state, strict=False)
+        ref.train()
+        rb = BMG(synth.random_molgraphs(n_mols, kind, seed=31))
+        l = ref.training_step((rb, None, None, targets, weights, torch.zeros_like(targets, dtype=torch.bool), torch.zeros_like(targets, dtype=torch.bool)), 0)
+        l.backward()
+        assert abs(float(out[0]) - float(l)) <= 1e-5 * max(1.0, abs(float(l)))
+        rg = dict(ref.named_parameters())
+        for i, k in enumerate(names):
+            assert parity_err(tr.sync.views[i].detach().cpu().numpy(), rg[k].grad.numpy()) <= 2e-5, k
+
+
+@pytest.mark.gpu
+def test_fused_trainer_learns_and_refuses_what_it_does_not_implement(gpu_device):
+    from chemprop_amd import agg as cagg, synth
+    from chemprop_amd.model import MPNN, FusedTrainer, RegressionFFN
+    from chemprop_amd.nn import BondMessagePassing
+
+    torch.manual_seed(0)
+    model = MPNN(BondMessagePassing(d_h=64), cagg.MeanAggregation(), RegressionFFN(n_tasks=1, input_dim=64, hidden_dim=64), batch_norm=True).to(gpu_device).train()
+    bmg = synth.random_batch(64, "qm9", seed=2)
+    bmg.to(gpu_device)
+    y = torch.randn(64, 1, device=gpu_device)
+    tr = FusedTrainer(model, lr=3e-3)
+    losses = [float(tr.step(bmg, y)[0]) for _ in range(60)]
+    assert np.mean(losses[-5:]) < 0.5 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+    with pytest.raises(NotImplementedError):
+        FusedTrainer(MPNN(BondMessagePassing(d_h=64, dropout=0.1), cagg.MeanAggregation(), RegressionFFN(input_dim=64)).to(gpu_device))
+    with pytest.raises(NotImplementedError):
+        FusedTrainer(MPNN(BondMessagePassing(d_h=64), cagg.AttentiveAggregation(output_size=64), RegressionFFN(input_dim=64)).to(gpu_device))
+    with pytest.raises(ValueError):
+        tr.step(bmg, torch.randn(63, 1, device=gpu_device))
