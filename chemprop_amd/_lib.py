@@ -99,6 +99,7 @@ class BwdArgs(C.Structure):
 
 MAX_FFN_LAYERS = 8
 LOSS = {"mse": 0, "mae": 1}
+STEP_FORWARD, STEP_BACKWARD, STEP_UPDATE = 1, 2, 4
 
 
 class HeadArgs(C.Structure):
@@ -122,6 +123,7 @@ class HeadArgs(C.Structure):
 class StepArgs(C.Structure):
     _fields_ = [
         ("edge_index", C.c_void_p), ("rev_edge_index", C.c_void_p), ("batch", C.c_void_p), ("plan_bytes", C.c_size_t), ("plan_ready", C.c_int32),
+        ("stages", C.c_int32),
         ("bwd", BwdArgs), ("head", HeadArgs),
         ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n_params", C.c_int64),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),

@@ -20,33 +20,39 @@ namespace {
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 
 // ---- BatchNorm1d over the rows of X [B, d] -------------------------------------------------------------------------
-// One workgroup per 64 columns, 4 row lanes per column (256 threads): two passes over the rows for the statistics
-// (mean, then the mean squared deviation: the arithmetic of torch's batch_norm on a [B, d] input to fp32 rounding), a
-// third for y.  B x d is ~0.6 MB: it lives in L2.
+// One workgroup of 1024 threads per 16 columns: 64 row lanes per column, so a thread walks B / 64 rows (8 at 512 molecules;
+// the first version — 4 row lanes, 128 dependent iterations per pass — took 65 us for 0.6 MB).  Two passes over the rows for
+// the statistics (mean, then the mean squared deviation: the arithmetic of torch's batch_norm on a [B, d] input to fp32
+// rounding), a third for y.  B x d is ~0.6 MB: it lives in L2.
+constexpr int kBnCols = 16, kBnLanes = 64;
 struct BnArgs {
     const float* X; int64_t ldx; float* Y; int64_t ldy;
     const float* gamma; const float* beta; float* run_mean; float* run_var;
     float* save_mean; float* save_invstd;      // [d] each (training: for the backward pass)
     int64_t B; int d; float eps, momentum; int training;
 };
-__global__ __launch_bounds__(256) void k_bn_fwd(BnArgs a) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+__device__ __forceinline__ float bn_col_sum(float (*red)[kBnCols], int tx, int ty, float v) {
+    __syncthreads();            // (the previous use of `red` is over)
+    red[ty][tx] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < kBnLanes; ++i) s += red[i][tx];
+    return s;
+}
+__global__ __launch_bounds__(1024) void k_bn_fwd(BnArgs a) {
+    __shared__ float red[kBnLanes][kBnCols];
+    const int tx = threadIdx.x & (kBnCols - 1), ty = threadIdx.x / kBnCols;
+    const int c = blockIdx.x * kBnCols + tx;
     const bool ok = c < a.d;
     float mean, invstd;
     if (a.training) {
         float s = 0.f;
-        if (ok) for (int64_t r = ty; r < a.B; r += 4) s += a.X[r * a.ldx + c];
-        red[ty][tx] = s;
-        __syncthreads();
-        mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)a.B;
-        __syncthreads();
+        if (ok) for (int64_t r = ty; r < a.B; r += kBnLanes) s += a.X[r * a.ldx + c];
+        mean = bn_col_sum(red, tx, ty, s) / (float)a.B;
         float q = 0.f;
-        if (ok) for (int64_t r = ty; r < a.B; r += 4) { const float dlt = a.X[r * a.ldx + c] - mean; q += dlt * dlt; }
-        red[ty][tx] = q;
-        __syncthreads();
-        const float ss = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        if (ok) for (int64_t r = ty; r < a.B; r += kBnLanes) { const float dlt = a.X[r * a.ldx + c] - mean; q += dlt * dlt; }
+        const float ss = bn_col_sum(red, tx, ty, q);
         const float var = ss / (float)a.B;                       // biased: what normalises (nn.BatchNorm1d)
         invstd = 1.f / sqrtf(var + a.eps);
         if (ok && ty == 0) {
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void k_bn_fwd(BnArgs a) {
     }
     if (ok) {
         const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
-        for (int64_t r = ty; r < a.B; r += 4) a.Y[r * a.ldy + c] = (a.X[r * a.ldx + c] - mean) * invstd * g + b;
+        for (int64_t r = ty; r < a.B; r += kBnLanes) a.Y[r * a.ldy + c] = (a.X[r * a.ldx + c] - mean) * invstd * g + b;
     }
 }
 
@@ -73,23 +79,21 @@ struct BnBwdArgs {
     float* g_gamma; float* g_beta;
     int64_t B; int d; float eps; int training;
 };
-__global__ __launch_bounds__(256) void k_bn_bwd(BnBwdArgs a) {
-    __shared__ float red[2][4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+__global__ __launch_bounds__(1024) void k_bn_bwd(BnBwdArgs a) {
+    __shared__ float red[kBnLanes][kBnCols];
+    const int tx = threadIdx.x & (kBnCols - 1), ty = threadIdx.x / kBnCols;
+    const int c = blockIdx.x * kBnCols + tx;
     const bool ok = c < a.d;
     const float mean = ok ? (a.training ? a.save_mean[c] : a.run_mean[c]) : 0.f;
     const float invstd = ok ? (a.training ? a.save_invstd[c] : 1.f / sqrtf(a.run_var[c] + a.eps)) : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int64_t r = ty; r < a.B; r += 4) {
+    if (ok) for (int64_t r = ty; r < a.B; r += kBnLanes) {
         const float g = a.gY[r * a.ldgy + c];
         s1 += g;
         s2 += g * ((a.X[r * a.ldx + c] - mean) * invstd);
     }
-    red[0][ty][tx] = s1; red[1][ty][tx] = s2;
-    __syncthreads();
-    s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-    s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    s1 = bn_col_sum(red, tx, ty, s1);
+    s2 = bn_col_sum(red, tx, ty, s2);
     if (!ok) return;
     if (ty == 0) {
         if (a.g_gamma) a.g_gamma[c] = s2;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd(BnBwdArgs a) {
     }
     const float gam = a.gamma ? a.gamma[c] : 1.f;
     const float k = gam * invstd, invB = 1.f / (float)a.B;
-    for (int64_t r = ty; r < a.B; r += 4) {
+    for (int64_t r = ty; r < a.B; r += kBnLanes) {
         const float g = a.gY[r * a.ldgy + c];
         if (a.training) {
             const float xh = (a.X[r * a.ldx + c] - mean) * invstd;
@@ -160,6 +164,62 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
             g = dl * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f) * inv;
         }
         a.gP[r * a.ldg + j] = g;
+    }
+}
+
+// ---- the predictor's OUTPUT layer for a handful of tasks (n_tasks <= kOutMaxTasks: the usual regression head) ----------------
+// P = A W^T + b with W [t, K]: t dot products per row — one wave per row, lanes over K (a 16 x 16 MFMA tile would be 1/16 full
+// and the generic contraction kernel spends 17 us on its pipeline for 0.3 MFLOP).
+constexpr int kOutMaxTasks = 4;
+struct OutFwdArgs { const float* A; int64_t lda; const float* W; const float* b; float* P; int64_t B; int K, t; };
+__global__ __launch_bounds__(256) void k_out_fwd(OutFwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.B) return;
+    float acc[kOutMaxTasks] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < a.K; k += 64) {
+        const float x = a.A[r * a.lda + k];
+#pragma unroll
+        for (int j = 0; j < kOutMaxTasks; ++j)
+            if (j < a.t) acc[j] += x * a.W[(int64_t)j * a.K + k];
+    }
+#pragma unroll
+    for (int j = 0; j < kOutMaxTasks; ++j) {
+        float v = acc[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && j < a.t) a.P[r * a.t + j] = v + (a.b ? a.b[j] : 0.f);
+    }
+}
+// Its whole backward in one launch (16 columns x 64 row lanes per workgroup, like the batch-norm kernels):
+//   gA[r][k] = (sum_j gP[r][j] W[j][k]) tau'(A[r][k])      (A = tau(previous layer): the derivative from the output)
+//   gW[j][k] = sum_r gP[r][j] A[r][k],   gb[j] = sum_r gP[r][j]
+struct OutBwdArgs {
+    const float* gP; const float* A; int64_t lda; const float* W; float* gA; int64_t ldga; float* gW; float* gb;
+    int64_t B; int K, t, act; float slope;
+};
+__global__ __launch_bounds__(1024) void k_out_bwd(OutBwdArgs a) {
+    __shared__ float red[kBnLanes][kBnCols];
+    const int tx = threadIdx.x & (kBnCols - 1), ty = threadIdx.x / kBnCols;
+    const int k = blockIdx.x * kBnCols + tx;
+    const bool ok = k < a.K;
+    float w[kOutMaxTasks], gw[kOutMaxTasks], gbs[kOutMaxTasks];
+#pragma unroll
+    for (int j = 0; j < kOutMaxTasks; ++j) { w[j] = (ok && j < a.t) ? a.W[(int64_t)j * a.K + k] : 0.f; gw[j] = 0.f; gbs[j] = 0.f; }
+    for (int64_t r = ty; r < a.B; r += kBnLanes) {
+        const float x = ok ? a.A[r * a.lda + k] : 0.f;
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < kOutMaxTasks; ++j)
+            if (j < a.t) { const float gp = a.gP[r * a.t + j]; g += gp * w[j]; gw[j] += gp * x; gbs[j] += gp; }
+        if (ok && a.gA) a.gA[r * a.ldga + k] = g * act_grad_from_out(x, a.act, a.slope);
+    }
+    for (int j = 0; j < a.t; ++j) {
+        const float sw = bn_col_sum(red, tx, ty, gw[j]);
+        if (ok && ty == 0 && a.gW) a.gW[(int64_t)j * a.K + k] = sw;
+        if (a.gb && blockIdx.x == 0) {     // (uniform per workgroup: every thread of workgroup 0 takes part in the reduction)
+            const float sb = bn_col_sum(red, tx, ty, gbs[j]);
+            if (tx == 0 && ty == 0) a.gb[j] = sb;
+        }
     }
 }
 
@@ -272,13 +332,21 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
     if (h.bn_weight) {
         BnArgs b{Hm, d, reinterpret_cast<float*>(ws + L.Z), d, h.bn_weight, h.bn_bias, h.bn_running_mean, h.bn_running_var, mean, invstd,
                  B, (int)d, h.bn_eps, h.bn_momentum, h.bn_training};
-        hipLaunchKernelGGL(k_bn_fwd, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(k_bn_fwd, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
         DMPNN_CHECK_LAUNCH("k_bn_fwd");
         Z = reinterpret_cast<float*>(ws + L.Z);
     }
     const float* A[DMPNN_MAX_FFN_LAYERS + 1];
     A[0] = Z;
+    const bool small_out = h.dims[Ln] <= kOutMaxTasks && Ln >= 1;   // the output layer as dot products (k_out_fwd / k_out_bwd)
     for (int l = 0; l < Ln; ++l) {
+        if (small_out && l == Ln - 1) {
+            OutFwdArgs q{A[l], h.dims[l], h.W[l], h.b[l], h.preds, B, (int)h.dims[l], (int)h.dims[Ln]};
+            hipLaunchKernelGGL(k_out_fwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, q);
+            DMPNN_CHECK_LAUNCH("k_out_fwd");
+            A[l + 1] = h.preds;
+            break;
+        }
         dmpnn_gemm_args g;
         memset(&g, 0, sizeof(g));
         g.M = B; g.N = h.dims[l + 1]; g.K1 = h.dims[l];
@@ -308,6 +376,15 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
     int pp = 0;
     for (int l = Ln - 1; l >= 0; --l) {
         const int64_t N = h.dims[l + 1], K = h.dims[l];
+        if (small_out && l == Ln - 1) {
+            float* out = bufs[pp]; pp ^= 1;
+            // (l == 0: no activation in front of the only layer — the derivative factor is 1)
+            OutBwdArgs q{g_cur, A[l], K, h.W[l], out, K, h.gW[l], h.b[l] ? h.gb[l] : nullptr, B, (int)K, (int)N, l > 0 ? h.act : DMPNN_ACT_NONE, h.act_slope};
+            hipLaunchKernelGGL(k_out_bwd, dim3((unsigned)((K + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, q);
+            DMPNN_CHECK_LAUNCH("k_out_bwd");
+            g_cur = out;
+            continue;
+        }
         if (h.gW[l] || h.gb[l]) {
             dmpnn_gemm_args g;
             memset(&g, 0, sizeof(g));
@@ -337,7 +414,7 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
     if (h.bn_weight) {
         BnBwdArgs b{gZ, d, Hm, d, gHm, d, h.bn_weight, mean, invstd, h.bn_running_mean, h.bn_running_var, h.g_bn_weight, h.g_bn_bias,
                     B, (int)d, h.bn_eps, h.bn_training};
-        hipLaunchKernelGGL(k_bn_bwd, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(k_bn_bwd, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
         DMPNN_CHECK_LAUNCH("k_bn_bwd");
         gZ = gHm;
     }
@@ -352,15 +429,18 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
     DMPNN_CHECK_ARG((f.flags & DMPNN_F_KEEP) != 0, "train_step: the forward must keep its tensors (DMPNN_F_KEEP)");
     DMPNN_CHECK_ARG(a->head.gHv == a->bwd.gout && a->head.ldg == a->bwd.ldgout, "train_step: head.gHv must be the backward's gout");
     DMPNN_CHECK_ARG(a->head.n_atoms == f.n_atoms && a->head.d_h == f.d_h + (f.W_d ? f.d_vd : 0), "train_step: head and block sizes differ");
-    if (!a->plan_ready) {
-        DMPNN_CHECK_ARG(a->edge_index && a->rev_edge_index, "train_step: null index arrays");
-        DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
-                                           a->plan_bytes, stream));
+    const int stages = a->stages ? a->stages : (DMPNN_STEP_FORWARD | DMPNN_STEP_BACKWARD | DMPNN_STEP_UPDATE);
+    if (stages & DMPNN_STEP_FORWARD) {
+        if (!a->plan_ready) {
+            DMPNN_CHECK_ARG(a->edge_index && a->rev_edge_index, "train_step: null index arrays");
+            DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
+                                               a->plan_bytes, stream));
+        }
+        DMPNN_TRY(dmpnn_forward(&f, stream));
+        DMPNN_TRY(dmpnn_head(&a->head, f.out, f.ldout, stream));
     }
-    DMPNN_TRY(dmpnn_forward(&f, stream));
-    DMPNN_TRY(dmpnn_head(&a->head, f.out, f.ldout, stream));
-    DMPNN_TRY(dmpnn_backward(&a->bwd, stream));
-    if (a->n_params > 0)
+    if (stages & DMPNN_STEP_BACKWARD) DMPNN_TRY(dmpnn_backward(&a->bwd, stream));
+    if ((stages & DMPNN_STEP_UPDATE) && a->n_params > 0)
         DMPNN_TRY(dmpnn_adam_step(a->p, a->g, a->m, a->v, a->n_params, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->bias_corr1,
                                   a->sqrt_bias_corr2, a->grad_scale, a->dev_scalars, stream));
     return DMPNN_OK;

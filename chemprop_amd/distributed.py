@@ -137,8 +137,7 @@ class GradSync:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.work = None
-        self._done = None
+        self.works: list = []   # pending exchanges of this step: (work, slice of the flat buffer, event on the communication stream)
         for p, v in zip(self.params, self.views):
             p.grad = v
         # views a block's backward kernels have OVERWRITTEN since the last zero_grad() / allreduce() / optimizer step (shared
@@ -175,8 +174,11 @@ class GradSync:
         through a block may overwrite its views again.  ``FlatAdam.step`` and ``allreduce`` call it."""
         self._written.clear()
 
-    def _gather(self) -> None:
-        for p, v in zip(self.params, self.views):
+    def _gather(self, lo: int = 0, hi: Optional[int] = None) -> None:
+        hi = self.flat.numel() if hi is None else hi
+        for p, v, o in zip(self.params, self.views, self.offsets):
+            if o < lo or o >= hi:
+                continue
             g = p.grad
             if g is None:
                 v.zero_()
@@ -184,41 +186,57 @@ class GradSync:
                 v.copy_(g)
             p.grad = v
 
-    def allreduce(self) -> None:
-        """Launch the exchange of this step's gradients (returns at once)."""
-        self.wait()
-        self._gather()
-        self._written.clear()  # (the step's gradient is complete: the next backward starts a new one)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+    def range_of(self, params: Iterable[torch.nn.Parameter]) -> tuple[int, int]:
+        """``(lo, hi)`` of the flat buffer covering ``params`` — which must be a contiguous run of this exchange's parameters (a
+        sub-module's, in ``model.parameters()`` order) — for a partial ``allreduce(lo, hi)``."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)) or len(idx) != len(ids):
+            raise ValueError("range_of: the parameters must be a contiguous run of the exchange's parameters")
+        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.offsets) else self.flat.numel()
+        return self.offsets[idx[0]], hi
+
+    def allreduce(self, lo: Optional[int] = None, hi: Optional[int] = None) -> None:
+        """Launch the exchange of this step's gradients (returns at once).  With ``(lo, hi)``: of that slice of the flat buffer
+        only — a step may exchange disjoint slices one after the other, each as soon as its gradients are final (the
+        predictor's and batch norm's, complete before the block's backward pass starts, go out while that pass runs:
+        ``model.FusedTrainer``); ``wait()`` waits for all of them."""
+        whole = lo is None and hi is None
+        lo = 0 if lo is None else int(lo)
+        hi = self.flat.numel() if hi is None else int(hi)
+        if whole:
+            self.wait()
+        self._gather(lo, hi)
+        if whole or hi == self.flat.numel():
+            self._written.clear()  # (the step's gradient is complete: the next backward starts a new one)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1 or hi <= lo:
             return
+        buf = self.flat[lo:hi]
         if self.stream is None:
-            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, None))
             return
         self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
         with torch.cuda.stream(self.stream):
-            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.wait()  # (stream-level on the communication stream: what follows there is ordered behind the collective)
             if self.average:
-                self.work.wait()  # (stream-level on the communication stream)
-                self.flat.div_(dist.get_world_size(self.group))
-            self._done = torch.cuda.Event()
-            self._done.record(self.stream)
+                buf.div_(dist.get_world_size(self.group))
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.works.append((work, buf, done))
 
     def wait(self) -> None:
-        """Order everything queued on the compute stream from here on behind the exchange (no host sync on a GPU)."""
-        if self.work is None:
+        """Order everything queued on the compute stream from here on behind the exchange(s) (no host sync on a GPU)."""
+        if not self.works:
             return
-        if self.stream is None:
-            self.work.wait()
-            if self.average:
-                self.flat.div_(dist.get_world_size(self.group))
-        else:
-            if not self.average:
-                with torch.cuda.stream(self.stream):
-                    self.work.wait()
-                    self._done = torch.cuda.Event()
-                    self._done.record(self.stream)
-            torch.cuda.current_stream(self.flat.device).wait_event(self._done)
-        self.work = None
+        for work, buf, done in self.works:
+            if done is None:
+                work.wait()
+                if self.average:
+                    buf.div_(dist.get_world_size(self.group))
+            else:
+                torch.cuda.current_stream(self.flat.device).wait_event(done)
+        self.works = []
 
 
 def broadcast_params(module: torch.nn.Module, src: int = 0, group=None) -> None:

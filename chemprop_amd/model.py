@@ -181,6 +181,12 @@ class FusedTrainer:
         self.opt = FlatAdam(self.sync, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.dev = params[0].device
         self._views = {id(p): v for p, v in zip(self.sync.params, self.sync.views)}
+        # the two slices of the flat gradient buffer a data-parallel step exchanges one after the other (see step())
+        blk = [p for p in mp.parameters() if p.requires_grad]
+        blk_ids = {id(p) for p in blk}
+        rest = [p for p in params if id(p) not in blk_ids]
+        self._block_range = self.sync.range_of(blk) if blk else (0, 0)
+        self._head_range = self.sync.range_of(rest) if rest else (0, 0)
         self._checked = 0
         self._level = None
         self.last_route = None
@@ -309,7 +315,18 @@ class FusedTrainer:
             s.lr, s.beta1, s.beta2, s.eps, s.weight_decay = float(opt.lr if lr is None else lr), b1, b2, opt.eps, opt.weight_decay
             s.bias_corr1, s.sqrt_bias_corr2, s.grad_scale = 1.0 - b1 ** opt.steps, math.sqrt(1.0 - b2 ** opt.steps), 1.0
         with engine._OnDevice(dev):
-            _lib.check(lib.dmpnn_train_step(C.byref(s), engine._stream_ptr(dev)), "dmpnn_train_step")
+            if fused_update:
+                _lib.check(lib.dmpnn_train_step(C.byref(s), engine._stream_ptr(dev)), "dmpnn_train_step")
+            else:
+                # data parallel: the head's gradients (predictor, batch norm) are final before the block's backward pass starts —
+                # their slice of the flat buffer goes out on the communication stream while that pass runs; the block's slice
+                # follows it; the update waits (stream dependency) for both
+                s.stages = _lib.STEP_FORWARD
+                _lib.check(lib.dmpnn_train_step(C.byref(s), engine._stream_ptr(dev)), "dmpnn_train_step(forward)")
+                self.sync.allreduce(*self._head_range)
+                s.stages = _lib.STEP_BACKWARD
+                _lib.check(lib.dmpnn_train_step(C.byref(s), engine._stream_ptr(dev)), "dmpnn_train_step(backward)")
+                self.sync.allreduce(*self._block_range)
         if bn is not None:
             bn.num_batches_tracked += 1
         self.preds = preds
@@ -318,6 +335,5 @@ class FusedTrainer:
                 torch.autograd.graph.increment_version(p)
             self.sync.new_step()
         else:
-            self.sync.allreduce()
             opt.step(lr)
         return loss

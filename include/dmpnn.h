@@ -452,8 +452,15 @@ int dmpnn_head(const dmpnn_head_args* h, const float* Hv, int64_t ldhv, void* st
  * K0 (dmpnn_prepare_with_batch into bwd.f.plan unless plan_ready) -> dmpnn_forward(&bwd.f) (DMPNN_F_KEEP) -> dmpnn_head on
  * bwd.f.out (head.gHv must be bwd.gout) -> dmpnn_backward(&bwd) -> dmpnn_adam_step over the flat buffers (n_params == 0: no
  * optimizer step).  The argument structs are exactly those of the separate entry points; nothing is allocated. */
+enum dmpnn_step_stage {                     /* dmpnn_step_args.stages: which part of the step this call enqueues (0 = all)  */
+    DMPNN_STEP_FORWARD = 1,                 /* K0 + the block's forward + the head (forward AND backward: the head's gradients
+                                               are final after this stage — a data-parallel job exchanges them while ...)    */
+    DMPNN_STEP_BACKWARD = 2,                /* ... the block's backward pass runs                                             */
+    DMPNN_STEP_UPDATE = 4                   /* the optimizer step                                                             */
+};
 typedef struct dmpnn_step_args {
     const int64_t* edge_index; const int64_t* rev_edge_index; const int64_t* batch; size_t plan_bytes; int32_t plan_ready;
+    int32_t stages;
     dmpnn_bwd_args bwd;                     /* bwd.f: the forward of the block                                     */
     dmpnn_head_args head;
     float* p; const float* g; float* m; float* v; int64_t n_params;   /* flat parameter / gradient / moment buffers */

@@ -143,6 +143,67 @@ def _worker_sync(rank, world, port, n_mols, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_sliced(rank, world, port, n_mols, out_dir):
+    """A step that exchanges its gradients in TWO slices, each as soon as it is final (model.FusedTrainer at N > 1: the head's
+    while the block's backward still runs), against the sequential all-reduce of everything."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    mgs = synth.random_molgraphs(n_mols, "qm9", seed=3)
+    torch.manual_seed(5)
+    mp_ = BondMessagePassing(d_h=40, bias=True)
+    head = torch.nn.Sequential(torch.nn.Linear(40, 24), torch.nn.ReLU(), torch.nn.Linear(24, 2))
+    idx = ddp.hash_partition(n_mols, rank, world, equalize=False)
+    bmg = BatchMolGraph([mgs[i] for i in idx])
+    params = list(mp_.parameters()) + list(head.parameters())
+
+    def backward():
+        w = ot.MPWeights(mp_.W_i.weight, mp_.W_h.weight, mp_.W_o.weight, mp_.W_o.bias, mp_.W_i.bias, mp_.W_h.bias)
+        out = head(ot.forward_bmg(bmg, w, depth=mp_.depth))
+        (out * (1.0 + rank)).sum().backward()
+
+    for p in params:
+        p.grad = None
+    backward()
+    ddp.allreduce_grads(params)
+    seq = [p.grad.clone() for p in params]
+    sync = ddp.GradSync(params, modules=[mp_])
+    lo_h, hi_h = sync.range_of(list(head.parameters()))
+    lo_b, hi_b = sync.range_of(list(mp_.parameters()))
+    assert (lo_b, hi_h) == (0, sync.flat.numel()) and hi_b == lo_h          # two adjacent slices cover the buffer
+    with pytest.raises(ValueError):
+        sync.range_of([params[0], params[-1]])                              # not a contiguous run
+    for rep in range(2):
+        sync.zero_grad()
+        backward()
+        sync.allreduce(lo_h, hi_h)      # the head's slice first ...
+        sync.allreduce(lo_b, hi_b)      # ... then the block's: two collectives in flight
+        assert len(sync.works) == 2
+        sync.wait()
+        assert not sync.works
+        for p, want in zip(params, seq):
+            assert torch.equal(p.grad, want), rep
+    torch.save({"ok": True}, os.path.join(out_dir, f"sliced{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_sliced_exchange_equals_sequential(tmp_path):
+    world = 2
+    mp.spawn(_worker_sliced, args=(world, _free_port(), 14, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "sliced0.pt").exists() and (tmp_path / "sliced1.pt").exists()
+
+
+def test_hash_partition_padding_reports_the_own_length():
+    n, world = 5, 8      # more ranks than molecules: some shards are empty and must still be padded to the common length
+    got = [ddp.hash_partition(n, r, world, pad=True, return_own=True) for r in range(world)]
+    assert len({len(idx) for idx, _ in got}) == 1 and len(got[0][0]) >= 1
+    own = np.concatenate([idx[:k] for idx, k in got])
+    assert sorted(own.tolist()) == list(range(n))                     # every molecule owned exactly once ...
+    assert any(k == 0 for _, k in got)                                # ... although some ranks own none (all padding)
+
+
 def test_grad_sync_equals_sequential_allreduce(tmp_path):
     world = 2
     mp.spawn(_worker_sync, args=(world, _free_port(), 16, str(tmp_path)), nprocs=world, join=True)
