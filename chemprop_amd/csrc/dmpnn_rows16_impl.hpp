@@ -205,37 +205,33 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
                 xl[rt] = *reinterpret_cast<const h8*>(p + 64);
             }
         };
-        auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
+        auto ring = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&nh)[RT], h8 (&nl)[RT]) {
+            const bool more = c + 1 < n_chunks;
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WN; ++ct) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_afrags(c + 1, nh, nl);
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], bh[0][ct], acc[rt][ct], 0, 0, 0);
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], bl[0][ct], acc[rt][ct], 0, 0, 0);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_bfrags(wc0 + c + 2, yh, yl);
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], bh[0][ct], acc[rt][ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned o = (more && offB[ct] != kOOB) ? offB[ct] + (unsigned)(wc0 + c + 1) * 2048u : kOOB;
+                bh[0][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
+                bl[0][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o == kOOB ? kOOB : o + 1024u, 0, 0));
+                if (ct == (WN > 1 ? WN - 2 : 0)) read_afrags(c + 1, nh, nl);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         load_bfrags(wc0, bh[0], bl[0]);
-        load_bfrags(wc0 + 1, bh[1], bl[1]);
         __syncthreads();  // the split tile is complete
         launder();
         read_afrags(0, ah[0], al[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma nounroll
         for (int c = 0; c < n_chunks; c += 2) {
-            step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
-            if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
+            ring(c, ah[0], al[0], ah[1], al[1]);
+            if (c + 1 < n_chunks) ring(c + 1, ah[1], al[1], ah[0], al[0]);
         }
     };
 

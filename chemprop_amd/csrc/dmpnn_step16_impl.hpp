@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     h8 ah[2][RT], al[2][RT], bh[2][WN], bl[2][WN];
     // (the first contraction's first two weight chunks: in flight under the DMA)
     if (XP) { load_bfrags(rW2, offB2, 0, bh[0], bl[0]); load_bfrags(rW2, offB2, 1, bh[1], bl[1]); }
-    else { load_bfrags(rW, offB, 0, bh[0], bl[0]); load_bfrags(rW, offB, 1, bh[1], bl[1]); }
+    else load_bfrags(rW, offB, 0, bh[0], bl[0]);   // (chunk 0 of the main contraction: the ring takes it from there)
     float isw[WN], isw2[WN], bv[WN];
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
@@ -250,33 +250,35 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
                 }
             }
         };
-        auto step = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&yh)[WN], h8 (&yl)[WN], h8 (&nh)[RT], h8 (&nl)[RT]) {
+        // the tile kernels' contraction (dmpnn_mega16_impl.hpp): ONE set of weight fragments as a ring over the column tiles — column
+        // tile ct's three products together, its fragments of chunk c + 1 requested right behind them (+1.5 .. 3 % on BASELINE configs 2-4)
+        auto ring = [&](int c, h8 (&xh)[RT], h8 (&xl)[RT], h8 (&nh)[RT], h8 (&nl)[RT]) {
+            const bool more = c + 1 < n_chunks;
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WN; ++ct) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yh[ct], acc[rt][ct], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_afrags(c + 1, nh, nl);
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], bh[0][ct], acc[rt][ct], 0, 0, 0);
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], bl[0][ct], acc[rt][ct], 0, 0, 0);
+                if constexpr (!H) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[rt], yl[ct], acc[rt][ct], 0, 0, 0);
-            if constexpr (!H) {
-#pragma unroll
-                for (int ct = 0; ct < WN; ++ct)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], yh[ct], acc[rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], bh[0][ct], acc[rt][ct], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned o = (more && off[ct] != kOOB) ? off[ct] + (unsigned)(c + 1) * 2048u : kOOB;
+                bh[0][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rw, o, 0, 0));
+                bl[0][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rw, o == kOOB ? kOOB : o + 1024u, 0, 0));
+                if (ct == (WN > 1 ? WN - 2 : 0)) read_afrags(c + 1, nh, nl);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            load_bfrags(rw, off, c + 2, yh, yl);
         };
-        if (!prefetched) { load_bfrags(rw, off, 0, bh[0], bl[0]); load_bfrags(rw, off, 1, bh[1], bl[1]); }
+        if (!prefetched) load_bfrags(rw, off, 0, bh[0], bl[0]);
         read_afrags(0, ah[0], al[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma nounroll
         for (int c = 0; c < n_chunks; c += 2) {
-            step(c, ah[0], al[0], bh[0], bl[0], ah[1], al[1]);
-            if (c + 1 < n_chunks) step(c + 1, ah[1], al[1], bh[1], bl[1], ah[0], al[0]);
+            ring(c, ah[0], al[0], ah[1], al[1]);
+            if (c + 1 < n_chunks) ring(c + 1, ah[1], al[1], ah[0], al[0]);
         }
     };
     // the rows' own scales (tail of every operand row of the main operand; K1 without one: the scales of x); rows beyond the tile: 1
