@@ -34,7 +34,7 @@ EXPORTS = [
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
-    "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step",
+    "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -257,6 +257,7 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.dmpnn_forward_tiles.argtypes = [C.POINTER(FwdArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p]
     lib.dmpnn_full_plan_keeps_tiles.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_head_ws_bytes.argtypes = [C.POINTER(HeadArgs)]
     lib.dmpnn_head.argtypes = [C.POINTER(HeadArgs), C.c_void_p, C.c_int64, C.c_void_p]

@@ -243,6 +243,17 @@ int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a) {
     return mega_shapes_ok(*a) ? 2 : 1;
 }
 
+int dmpnn_forward_tiles(const dmpnn_fwd_args* a, const int64_t* batch, const int* tile_row, const int* tile_atom, int64_t n_tiles,
+                        size_t plan_bytes, void* stream) {
+    DMPNN_CHECK_ARG(a != nullptr && a->plan != nullptr, "forward_tiles: null args / plan");
+    void* plan = const_cast<void*>(a->plan);
+    if (tile_row && tile_atom && n_tiles > 0)
+        DMPNN_TRY(dmpnn_prepare_tiles_from_table(tile_row, tile_atom, n_tiles, a->n_atoms, a->n_edges, plan, plan_bytes, stream));
+    else
+        DMPNN_TRY(dmpnn_prepare_tiles(a->edge_index, a->rev_edge_index, batch, a->n_atoms, a->n_edges, plan, plan_bytes, stream));
+    return dmpnn_forward(a, stream);
+}
+
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     g_launches = 0;
     DMPNN_CHECK_ARG(a != nullptr, "forward: null args");

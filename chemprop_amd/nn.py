@@ -22,6 +22,7 @@ from torch import Tensor, nn
 
 from . import _lib, engine
 from .autograd import mp_forward
+from .data import BatchMolGraph as _OwnBatch
 
 DEFAULT_ATOM_FDIM, DEFAULT_BOND_FDIM = 72, 14  # chemprop/conf.py:8 (v2 featurizers)
 DEFAULT_HIDDEN_DIM = 300  # chemprop/conf.py:9
@@ -186,7 +187,8 @@ class _Replay:
     decision was taken on.  A call that finds all of them unchanged only builds the tile plan, allocates ``out`` and
     fills in the batch's pointers — the same two C calls, without the general routing code in between."""
 
-    __slots__ = ("args", "tensors", "versions", "ptrs", "tau", "training", "env", "dev", "d_v", "d_e", "d_h", "wsplit", "depth")
+    __slots__ = ("args", "tensors", "versions", "ptrs", "tau", "training", "env", "dev", "d_v", "d_e", "d_h", "wsplit", "depth", "block", "flags",
+                 "ldh", "spill")
 
 
 def _param(mp, lin: str, name: str):
@@ -212,11 +214,22 @@ def _make_replay(mp, plan, st) -> None:
     r.wsplit = st.refs[-1]
     if r.wsplit is None or any(t is not None and (t.dtype != torch.float32 or not t.is_contiguous()) for t in r.tensors):
         return
+    # the live argument block of the steady path: everything that does not belong to a batch is set here, once
+    blk = r.block = _lib.FwdArgs.from_buffer_copy(r.args)
+    blk.ldv, blk.lde, blk.ldout = r.d_v, r.d_e, r.d_h
+    r.flags = (int(blk.flags) | _lib.F_WSPLIT_READY) & ~_lib.F_LOADER_TILES
+    r.ldh, r.spill = int(blk.ldh), None
     mp.__dict__["_dmpnn_replay"] = r
 
 
 def _replay_forward(mp, r: "_Replay", bmg):
-    """The steady inference path (see :class:`_Replay`); ``None`` when anything it rests on has changed."""
+    """The steady inference path (see :class:`_Replay`); ``None`` when anything it rests on has changed.
+
+    Its host side is as long as its device side (two launches, ~45 us at 512 molecules), so it is kept lean: the argument block
+    lives in the replay state and only the batch's fields are rewritten, K0 and the forward are ONE foreign call
+    (``dmpnn_forward_tiles``), the scratch of the kernel's generic path is allocated once per module and grows, and a batch made
+    by this package's own batching code (``data.BatchMolGraph``: float32 / int64 / contiguous by construction) is not
+    re-inspected tensor by tensor."""
     mods = mp._modules
     if (mp.training != r.training or mods.get("tau") is not r.tau or mp.depth != r.depth or mp.undirected
             or type(mods.get("graph_transform")) is not nn.Identity or mods.get("W_d") is not None):
@@ -232,12 +245,16 @@ def _replay_forward(mp, r: "_Replay", bmg):
         return None
     V, E, ei, rev, batch = bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, getattr(bmg, "batch", None)
     dev = r.dev
-    if (V.device != dev or V.dtype != torch.float32 or E.dtype != torch.float32 or not V.is_contiguous() or not E.is_contiguous()
-            or V.dim() != 2 or E.dim() != 2 or V.shape[1] != r.d_v or E.shape[1] != r.d_e or ei.dtype != torch.int64
-            or rev.dtype != torch.int64 or not ei.is_contiguous() or not rev.is_contiguous() or ei.device != dev
-            or batch is None or batch.dtype != torch.int64 or not batch.is_contiguous() or batch.device != dev):
+    if V.device != dev or batch is None or V.dim() != 2 or E.dim() != 2 or V.shape[1] != r.d_v or E.shape[1] != r.d_e:
         return None
-    nV, nE = int(V.shape[0]), int(E.shape[0])
+    # (`oversize` is set — True / False — only by this package's batching code, whose tensors are float32 / int64 / contiguous by
+    #  construction; a batch wrapped around foreign tensors, `from_tensors`, carries None and is inspected)
+    if (type(bmg) is not _OwnBatch or bmg.oversize is None) and (
+            V.dtype != torch.float32 or E.dtype != torch.float32 or not V.is_contiguous() or not E.is_contiguous() or ei.dtype != torch.int64
+            or rev.dtype != torch.int64 or not ei.is_contiguous() or not rev.is_contiguous() or ei.device != dev
+            or batch.dtype != torch.int64 or not batch.is_contiguous() or batch.device != dev):
+        return None
+    nV, nE = V.shape[0], E.shape[0]
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
     oversize = getattr(bmg, "oversize", None)
     if oversize is True:  # (the host knows a molecule of this batch exceeds the tile: per-step routes)
@@ -246,40 +263,48 @@ def _replay_forward(mp, r: "_Replay", bmg):
     if tiles is not None and (tiles[0].device != dev or tiles[2] <= 0):
         tiles = None
     small = engine.small_plan_fits(nV, nE)
-    if (n_mols <= 0 or nE > 30 * n_mols or nE == 0 or (tiles is None and not small and not _lib.load().dmpnn_tile_plan_any_size(nV, nE))
+    lib = _lib.load()
+    if (n_mols <= 0 or nE > 30 * n_mols or nE == 0 or (tiles is None and not small and not lib.dmpnn_tile_plan_any_size(nV, nE))
             or batch.numel() != nV
             or ei.shape[1] != nE or rev.numel() != nE or getattr(mp, "_dmpnn_no_mega", False)):
         return None
-    lib = _lib.load()
     nbytes = engine.plan_bytes(nV, nE)
     buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
     out = torch.empty(nV, r.d_h, dtype=torch.float32, device=dev)
-    a = _lib.FwdArgs.from_buffer_copy(r.args)
+    a = r.block  # (the module's own argument block: consumed by the call below before it returns)
     pb = buf.data_ptr()
     a.plan, a.n_atoms, a.n_edges = pb, nV, nE
-    a.V, a.ldv, a.E, a.lde = V.data_ptr(), r.d_v, E.data_ptr(), r.d_e
-    a.out, a.ldout = out.data_ptr(), r.d_h
+    a.V, a.E = V.data_ptr(), E.data_ptr()
+    a.out = out.data_ptr()
     a.Mv = a.Hv = pb
     a.edge_index, a.rev_edge_index = ei.data_ptr(), rev.data_ptr()
-    a.flags |= _lib.F_WSPLIT_READY
-    spill = None
-    if oversize is None:  # bare tensors: scratch for the kernel's generic path, should a molecule exceed the tile
-        spill = torch.empty((3 * nE + nV) * a.ldh, dtype=torch.float32, device=dev)
-        a.spill_ws, a.spill_bytes = spill.data_ptr(), spill.numel() * 4
+    if oversize is None:  # bare tensors: scratch for the kernel's generic path, should a molecule exceed the tile (never touched else)
+        need = (3 * nE + nV) * r.ldh
+        sp = r.spill
+        if sp is None or sp.numel() < need:
+            sp = r.spill = torch.empty(need + need // 4, dtype=torch.float32, device=dev)
+        a.spill_ws, a.spill_bytes = sp.data_ptr(), need * 4
     else:
         a.spill_ws, a.spill_bytes = None, 0
-    stream = engine._stream_ptr(dev)
-    with engine._OnDevice(dev):
+    cur = torch.cuda.current_device()
+    ctx = None if dev.index is None or dev.index == cur else torch.cuda.device(dev)
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        stream = engine._raw_stream(dev.index if dev.index is not None else cur) if engine._raw_stream is not None else engine._stream_ptr(dev)
         if tiles is not None:  # the loader's table: K0 is a copy of it
-            a.flags |= _lib.F_LOADER_TILES
+            a.flags = r.flags | _lib.F_LOADER_TILES
             a.n_tiles_launch = tiles[2]
-            _lib.check(lib.dmpnn_prepare_tiles_from_table(tiles[0].data_ptr(), tiles[1].data_ptr(), tiles[2], nV, nE, pb, nbytes, stream),
-                       "dmpnn_prepare_tiles_from_table")
+            rc = lib.dmpnn_forward_tiles(_ctypes.byref(a), None, tiles[0].data_ptr(), tiles[1].data_ptr(), tiles[2], nbytes, stream)
         else:
-            a.flags = (a.flags & ~_lib.F_LOADER_TILES) | (0 if small else _lib.F_LOADER_TILES)
+            a.flags = r.flags if small else (r.flags | _lib.F_LOADER_TILES)
             a.n_tiles_launch = 0
-            _lib.check(lib.dmpnn_prepare_tiles(a.edge_index, a.rev_edge_index, batch.data_ptr(), nV, nE, pb, nbytes, stream), "dmpnn_prepare_tiles")
-        _lib.check(lib.dmpnn_forward(_ctypes.byref(a), stream), "dmpnn_forward")
+            rc = lib.dmpnn_forward_tiles(_ctypes.byref(a), batch.data_ptr(), None, None, 0, nbytes, stream)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    if rc:
+        _lib.check(rc, "dmpnn_forward_tiles")
     if oversize is None:
         _spill_monitor(mp, buf, dev)
     from .agg import note_batch

@@ -302,6 +302,12 @@ int dmpnn_forward_can_fuse16(const dmpnn_fwd_args* a);
 /* (3 n_edges + n_atoms) * ldh floats: H0 | H^(t) | M^(t) | Mv of the generic path, indexed by the batch's own rows */
 size_t dmpnn_forward_spill_bytes(const dmpnn_fwd_args* a);
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream);
+/* K0 + forward of the steady inference path in ONE call (one foreign-function transition instead of two on a path whose host
+ * side is as long as its device side): the tile plan of `a->plan` — from the loader's table when tile_row / tile_atom (n_tiles
+ * entries + 1) are given (dmpnn_prepare_tiles_from_table), else from the batch vector / connectivity (dmpnn_prepare_tiles with
+ * a->edge_index, a->rev_edge_index, `batch`) — then dmpnn_forward(a).  `a` as for an inference dmpnn_forward on a tile plan. */
+int dmpnn_forward_tiles(const dmpnn_fwd_args* a, const int64_t* batch, const int* tile_row, const int* tile_atom, int64_t n_tiles,
+                        size_t plan_bytes, void* stream);
 /* 1 when the shapes / alignment of `a` allow DMPNN_F_FUSED (d_h % 4 == 0, d_h <= 320, even d_v and
  * d_e, directed), 2 when they also allow DMPNN_F_MEGA (batch within the single-workgroup plan:
  * <= 6144 atoms, <= 10240 edges — any size with DMPNN_F_LOADER_TILES), else 0.  Graph properties (symmetry, in-degree <= 24) are decided on the device by
