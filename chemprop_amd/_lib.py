@@ -85,6 +85,7 @@ class FwdArgs(C.Structure):
         ("edge_index", C.c_void_p), ("rev_edge_index", C.c_void_p),
         ("n_tiles_launch", C.c_int64),
         ("spill_ws", C.c_void_p), ("spill_bytes", C.c_size_t),
+        ("msplit", C.c_void_p), ("msplit_bytes", C.c_size_t),
     ]
 
 

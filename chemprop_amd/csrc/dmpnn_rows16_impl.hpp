@@ -50,6 +50,7 @@ struct Rows16K {
     const int* tile_row; const int* tile_atom; const int* row_ptr; const int* revp;
     unsigned char* Mout; int ts; float* Sout; int lds; unsigned qmagic;
     int half_out;  // Mout in half storage (DMPNN_F_STORE16)
+    float* M32; int ldm32;  // training: the first message also as fp32 rows (or null)
 };
 
 // GC: k-chunks per operand group.  4 (128 columns, 24 operand registers, two workgroups per CU) streams large batches;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
         if constexpr (SEG) {
             if (tid < BM) meta[tid] = seg_rev;
             step16::SegOut o;
-            o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.ts; o.Sout = g.Sout; o.lds = g.lds; o.N = g.N; o.half = g.half_out; o.SoutS = nullptr; o.tss = 0;
+            o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.ts; o.Sout = g.Sout; o.lds = g.lds; o.N = g.N; o.half = g.half_out; o.SoutS = nullptr; o.tss = 0; o.M32 = g.M32; o.ldm32 = g.ldm32;
             step16::seg_epilogue<LDC, BN / 4, kThreads>(o, T, meta, row0, nrows, seg_va, seg_vb, seg_rp, poison, g.qmagic, tile_scale);
         }
     } else {

@@ -20,6 +20,7 @@ struct SegOut {
     float* Sout; int lds;          // per-atom sums [V][lds] fp32 (or null)
     int N;                         // live columns (the padded row holds NQP column quads, zero-filled beyond N)
     int half;                      // 1: half storage — rows of [hi 32 halfs] chunks only (DMPNN_F_STORE16), else [hi | lo] chunk pairs
+    float* M32; int ldm32;         // training: the message ALSO as fp32 rows [E][ldm32] (what the weight gradients read), or null
     unsigned char* SoutS; int tss; // per-atom sums as SPLIT rows [V][tss] (exact hi | lo, each row's scale in its tail) instead of
                                    // fp32 Sout: what the finalize contraction on the step kernel consumes (or null)
 };
@@ -134,6 +135,11 @@ __device__ __forceinline__ void seg_epilogue(const SegOut& o, float* T, int* met
         float4 m0 = *reinterpret_cast<const float4*>(T + r * LDC + 8 * g8);
         float4 m1 = *reinterpret_cast<const float4*>(T + r * LDC + 8 * g8 + 4);
         if (poison) { m0 = make_float4(nanv, nanv, nanv, nanv); m1 = m0; }
+        if (o.M32 && 8 * g8 < o.N) {  // (columns beyond N: padding of the split row only)
+            float* q = o.M32 + (long long)meta[r] * o.ldm32 + 8 * g8;
+            *reinterpret_cast<float4*>(q) = m0;
+            if (8 * g8 + 4 < o.N) *reinterpret_cast<float4*>(q + 4) = m1;
+        }
         h4 h0, l0, h1, l1;
         split4(m0, s, h0, l0);
         split4(m1, s, h1, l1);

@@ -31,7 +31,14 @@ static inline int msg_row_bytes(const dmpnn_fwd_args& a) { return half_store(a) 
 
 bool fused16_shapes_ok(const dmpnn_fwd_args& a) {
     const int64_t h = a.d_h;
-    if (a.flags & (DMPNN_F_UNDIRECTED | DMPNN_F_KEEP)) return false;  // inference forward of directed graphs
+    if (a.flags & DMPNN_F_UNDIRECTED) return false;  // directed graphs
+    if (a.flags & DMPNN_F_KEEP) {
+        // training: the kept fp32 tensors the backward pass reads + the two split ping-pong slots in `msplit`
+        if (a.flags & DMPNN_F_STORE16) return false;
+        if (a.n_edges > 0 && a.depth > 1 && (!a.Hs || a.n_hslots < a.depth - 1 || !a.Ms || a.n_mslots < a.depth - 1)) return false;
+        if (a.n_edges > 0 && (!a.msplit || a.msplit_bytes < 2 * (size_t)a.n_edges * step16::split_row_bytes((int)a.d_h))) return false;
+        if ((reinterpret_cast<uintptr_t>(a.msplit) & 15u) || (a.Hs && (reinterpret_cast<uintptr_t>(a.Hs) & 15u)) || (reinterpret_cast<uintptr_t>(a.Ms) & 15u)) return false;
+    }
     if (h <= 0 || h % 4 != 0 || h > 640 || a.ldh % 4 != 0) return false;
     if (h > 320 && step16::split_operand_bytes((int)(a.d_v + a.d_e)) > step16::split_row_bytes((int)h)) return false;
     if (a.d_v % 2 || a.d_e % 2 || a.ldv % 2 || a.lde % 2) return false;
@@ -46,7 +53,7 @@ static unsigned qmagic_of(int64_t N) {
 }
 
 // K1 with the segment epilogue: H0 = W_i [V[srcp] || E[perm]] (+ b_i) stored; tau; first message (split rows) or Mv
-static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* Mout, float* Sout, hipStream_t s) {
+static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* Mout, float* Sout, float* M32, hipStream_t s) {
     const int* plan_i = static_cast<const int*>(a.plan);
     rows16::Rows16K g;
     memset(&g, 0, sizeof(g));
@@ -61,6 +68,7 @@ static int launch_k1_seg(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
     g.vec_out = 1;
     g.tile_row = plan_i + L.tile_row; g.tile_atom = plan_i + L.tile_atom; g.row_ptr = plan_i + L.row_ptr; g.revp = plan_i + L.revp;
     g.Mout = Mout; g.ts = msg_row_bytes(a); g.half_out = half_store(a) ? 1 : 0; g.Sout = Sout; g.lds = (int)a.ldh; g.qmagic = qmagic_of(a.d_h);
+    g.M32 = Mout ? M32 : nullptr; g.ldm32 = (int)a.ldh;
     const int n_tiles = (int)L.max_tiles;
     switch ((int)((a.d_h + 63) / 64)) {
         case 1: return rows16::launch_rows16<1, 4, true>(g, n_tiles, 1, s);
@@ -115,7 +123,7 @@ static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
 // `xrows` (or null): the K1 operand [V[src] || E] of every row, exactly split (k_split_rows) — the residual H0 = W_i x + b_i is
 // then recomputed inside the step instead of read back (x_path_ok)
 static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const SplitWView* Wi, const unsigned char* xrows,
-                         const unsigned char* Min, unsigned char* Mout, float* Sout, unsigned char* SoutS, hipStream_t s) {
+                         const unsigned char* Min, unsigned char* Mout, float* Sout, unsigned char* SoutS, float* Hout, float* M32, hipStream_t s) {
     step16::Step16K g = step_args(a, L);
     g.A = Min; g.ts = msg_row_bytes(a);
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
@@ -127,6 +135,7 @@ static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
         g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
     }
     g.Mout = Mout; g.Sout = Sout; g.SoutS = SoutS; g.half_out = half_store(a) ? 1 : 0;
+    g.Hout = Hout; g.ldho = (int)a.ldh; g.M32 = Mout ? M32 : nullptr; g.ldm32 = (int)a.ldh;
     return launch_step(g, a.d_h, (int)L.max_tiles, half_store(a), s);
 }
 
@@ -145,7 +154,7 @@ static bool x_path_ok(const dmpnn_fwd_args& a) {
 // K1 on the update kernel (d_h > 320, and the x path): the gathered fp32 operand is split into rows first (`scratch`: the second
 // message slot, or — x path, keep_h0 false — the H0 buffer, where the rows stay for the depth steps and no H0 is written)
 static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* scratch, bool keep_h0,
-                           unsigned char* Mout, float* Sout, hipStream_t s) {
+                           unsigned char* Mout, float* Sout, float* M32, hipStream_t s) {
     const int* plan_i = static_cast<const int*>(a.plan);
     step16::SplitRowsK k;
     memset(&k, 0, sizeof(k));
@@ -161,6 +170,7 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
     g.bias = a.b_i;
     if (keep_h0) { g.Zpre = a.H0; g.ldz = (int)a.ldh; }
     g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
+    g.M32 = Mout ? M32 : nullptr; g.ldm32 = (int)a.ldh;
     return launch_step(g, a.d_h, (int)L.max_tiles, false, s);  // (the K1 operand [V || E] is always split exactly)
 }
 
@@ -210,24 +220,30 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
     const int T = a.depth;
     // (a slot is n_edges message rows; the first always spans split_row_bytes per edge — the K1 operand scratch of wide layers lives in the second)
     const size_t slot_bytes = (size_t)nE * step16::split_row_bytes((int)h);
-    unsigned char* Ms = reinterpret_cast<unsigned char*>(a.Ms);
+    // training (DMPNN_F_KEEP): the split ping-pong slots live in `msplit`; H0 / Hs / Ms / Mv are the fp32 tensors the backward reads
+    const bool keep = (a.flags & DMPNN_F_KEEP) != 0;
+    unsigned char* Ms = reinterpret_cast<unsigned char*>(keep ? a.msplit : a.Ms);
+    const int64_t slot32 = nE * a.ldh;
     if (nE == 0 && nV > 0) {
         hipError_t e = hipMemsetAsync(a.Mv, 0, (size_t)nV * a.ldh * sizeof(float), s);
         if (e != hipSuccess) { set_error("forward(fused16): memset failed: %s", hipGetErrorString(e)); return DMPNN_EHIP; }
     }
-    const bool fin16 = fin16_ok(a, out, ldout);
+    // (training keeps H0 and an fp32 Mv — the residual is read back, the finalize runs on the row kernel)
+    const bool fin16 = !keep && fin16_ok(a, out, ldout);
     if (nE > 0) {
         static const bool k1_split_all = [] { const char* e = getenv("DMPNN_K1_SPLIT"); return e && e[0] == '1'; }();
-        const bool xpath = x_path_ok(a);
+        const bool xpath = !keep && x_path_ok(a);
         unsigned char* xrows = xpath ? reinterpret_cast<unsigned char*>(a.H0) : nullptr;
-        if (xpath) DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
-        else if (h > 320 || k1_split_all) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, true, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
-        else DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, s));
+        float* m32_0 = (keep && T > 1) ? a.Ms : nullptr;  // M^(1): what update step 1 consumes, what gW_h's first product reads
+        if (xpath) DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, nullptr, s));
+        else if (h > 320 || k1_split_all) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, true, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s));
+        else DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s));
         for (int t = 1; t < T; ++t) {
             const bool last = t == T - 1;
             unsigned char* free_slot = Ms + (t % 2) * slot_bytes;  // (the slot this step does not read)
             DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], xrows, Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : free_slot,
-                                    (last && !fin16) ? a.Mv : nullptr, (last && fin16) ? free_slot : nullptr, s));
+                                    (last && !fin16) ? a.Mv : nullptr, (last && fin16) ? free_slot : nullptr,
+                                    keep ? a.Hs + (int64_t)(t - 1) * slot32 : nullptr, (keep && !last) ? a.Ms + (int64_t)t * slot32 : nullptr, s));
         }
         if (fin16) return launch_fin16(a, L, w16[4], w16[5], Ms + ((T - 1) % 2) * slot_bytes, out, ldout, s);
     }

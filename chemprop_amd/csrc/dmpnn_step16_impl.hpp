@@ -74,6 +74,8 @@ struct Step16K {
     unsigned char* SoutS;                 // the per-atom sums as split rows [V][TSO] instead of fp32 Sout (or null)
     int uniform;                          // 1: no tile table — tile t = rows 48 t .. (the finalize over atoms: no segments)
     float* Yout; int ldy;                 // 1: plain epilogue — tau(z) rows [M][ldy] fp32, nothing else (or null)
+    float* Hout; int ldho;                // training: H' = tau(z) rows [M][ldho] fp32 kept for the backward pass (or null)
+    float* M32; int ldm32;                // training: the next message also as fp32 rows (the weight gradients' operand) (or null)
     int act; float slope; const float* slope_ptr;
     const int* poison_flags; int poison_mask;
     unsigned qmagic;
@@ -376,6 +378,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         }
         return;
     }
+    if (g.Hout) {  // (uniform) training: the rows of H' = tau(z) leave coalesced before the segment pass turns the tile into the message
+        __syncthreads();
+        const int qn = g.N >> 2;
+        const float nanv = __int_as_float(0x7fc00000);
+        for (int it = tid; it < nrows * qn; it += NT) {
+            const int r = qn == 1 ? it : (int)__umulhi((unsigned)it, g.qmagic), q = it - r * qn;
+            float4 z = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
+            if (poison) z = make_float4(nanv, nanv, nanv, nanv);
+            *reinterpret_cast<float4*>(g.Hout + (long long)(rs + r) * g.ldho + 4 * q) = z;
+        }
+    }
     int scale_phase = 0;
     auto tile_scale = [&](float local_max) -> float {
         stamp();  // 7 pass 1 done
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     };
     SegOut o;
     o.row_ptr = g.row_ptr; o.revp = g.revp; o.Mout = g.Mout; o.ts = g.half_out ? BN * 2 + 16 : TSO; o.Sout = g.Sout; o.lds = g.lds;
-    o.N = g.N; o.half = g.half_out; o.SoutS = g.SoutS; o.tss = TSO;
+    o.N = g.N; o.half = g.half_out; o.SoutS = g.SoutS; o.tss = TSO; o.M32 = g.M32; o.ldm32 = g.ldm32;
     seg_epilogue<LDC, BN / 4, NT>(o, T, meta, rs, nrows, va, vb, seg_rp, poison, g.qmagic, tile_scale);
     stamp();  // 8 (7 without a message) end
 }

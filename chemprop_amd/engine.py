@@ -239,6 +239,17 @@ class GraphPlan:
         return self._view(4).long()
 
 
+def fuse16_shapes(a) -> bool:
+    """``dmpnn_forward_can_fuse16`` on the SHAPES of ``a`` (for a training forward its workspace requirements — kept slots,
+    ``msplit`` — are met by the allocation that follows the route decision, so they are left out of the question here)."""
+    flags = a.flags
+    a.flags = flags & ~_lib.F_KEEP
+    try:
+        return bool(_lib.load().dmpnn_forward_can_fuse16(C.byref(a)))
+    finally:
+        a.flags = flags
+
+
 def act_code(name: str) -> int:
     return ACT[str(name).lower()]
 
@@ -450,16 +461,19 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     # forwards the whole-forward tile kernel does not take — large molecules (ZINC, 40-atom, reaction graphs), any batch
     # size; `route="fused16"` demands it
     use_fused16 = False
-    if (not keep and not undirected and route in (None, "fused16") and not getattr(plan, "tiles_only", False) and mf == "split16"
-            and _lib.opt("DMPNN_FUSED16", "1") != "0" and _lib.opt("DMPNN_GENERAL", "0") != "1" and lib.dmpnn_forward_can_fuse16(C.byref(a))):
-        # (d_h <= 320: where the fp32 fused route applies too; wider hidden layers, up to 640, only here)
+    if (not undirected and route in (None, "fused16") and not getattr(plan, "tiles_only", False) and mf == "split16"
+            and (not keep or not getattr(plan, "light", False))
+            and _lib.opt("DMPNN_FUSED16", "1") != "0" and _lib.opt("DMPNN_GENERAL", "0") != "1" and fuse16_shapes(a)):
+        # (d_h <= 320: where the fp32 fused route applies too; wider hidden layers, up to 640, only here).  Training (keep) takes it
+        # where the per-step GENERAL route on the f16 pipe used to run — large batches, wide hidden layers (round 3: the forward
+        # of a 40-atom x 4 096 training step 2.96 -> ~2.1 ms)
         if route == "fused16" or (fused is None and mfma is None and (level == 1 or (level == 0 and d_h > 320 and max_level >= 1))
-                                  and nE >= FUSED16_MIN_EDGES):
+                                  and nE >= (FUSED16_MIN_EDGES if not keep else (0 if d_h > 320 else STEPS16_MIN_EDGES))):
             use_fused16 = True
             level = 1
     if route == "fused16" and not use_fused16:
-        raise RuntimeError("forward: route 'fused16' requested but not available (inference, directed, d_h % 4 == 0, d_h <= 320, "
-                           "even d_v / d_e, a full or light plan)")
+        raise RuntimeError("forward: route 'fused16' requested but not available (directed, d_h % 4 == 0, d_h <= 640, "
+                           "even d_v / d_e, a full or light plan — training: a full plan)")
     if (level == 1 and not use_fused16 and route is None and fused is None and mfma is None and mf == "split16" and nE >= STEPS16_MIN_EDGES
             and not getattr(plan, "light", False)):
         level = 0  # large batch (training): the per-step route on the f16 pipe beats the fused fp32-MFMA contractions
@@ -492,6 +506,13 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     split_ms = None
     if use_mega and not keep and not d_vd:  # inference tile kernel: nothing leaves the CU but `out`
         edge_ws = atom_ws = None
+    elif use_fused16 and keep:
+        # training: H0 | H^(t) | M^(t) fp32 (what dmpnn_backward reads, CSR-row order) + the two split ping-pong slots in `msplit`
+        srf = int(lib.dmpnn_split_row_floats(d_h))
+        n_hslots = n_mslots = n_steps
+        edge_ws = torch.empty((1 + 2 * n_steps, nE, ldh), dtype=torch.float32, device=dev)
+        split_ms = torch.empty((2, nE, srf), dtype=torch.float32, device=dev)
+        atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
     elif use_fused16:
         # H0 fp32 | two slots of split message rows (row = chunks of [hi | lo] halfs + a 16-byte tail with the row's scale)
         srf = int(lib.dmpnn_split_row_floats(d_h))
@@ -519,7 +540,9 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         a.Hs, a.n_hslots = (st.Hs.data_ptr() if n_hslots else None), n_hslots
         a.Ms, a.n_mslots = (st.Ms.data_ptr() if n_mslots else None), max(n_mslots, 1)
         a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
-        if split_ms is not None:
+        if split_ms is not None and keep:
+            a.msplit, a.msplit_bytes = split_ms.data_ptr(), split_ms.numel() * 4
+        elif split_ms is not None:
             st.Ms = split_ms
             a.Ms, a.n_mslots = split_ms.data_ptr(), 2
     if use_fused:
@@ -553,7 +576,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
                 wcache["key"], wcache["buf"] = key, wsplit
         a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
         st.route = "mega16" if use_mega else ("fused16" if use_fused16 else "general16")
-        if use_fused16 and storage_f16():
+        if use_fused16 and storage_f16() and not keep:
             # OPT-IN half storage of the message tensor between the steps (DMPNN_F_STORE16): not fp32-class, see include/dmpnn.h
             a.flags |= F_STORE16
             st.route = "fused16/f16-storage"
@@ -565,7 +588,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         with _OnDevice(dev):
             _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
-    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, wsplit)
+    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, split_ms, wsplit)
     st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)
     return out, st
 

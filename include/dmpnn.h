@@ -284,6 +284,11 @@ typedef struct dmpnn_fwd_args {
      * tile (generic in-kernel path; with DMPNN_F_KEEP the kept tensors serve).  NULL: such a molecule's atoms come back
      * NaN (never a silently wrong number). */
     float* spill_ws; size_t spill_bytes;
+    /* DMPNN_F_FUSED | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (training on the per-step fused route, molecules of any size): the two
+     * ping-pong slots of split message rows (n_edges * dmpnn_split_row_floats(d_h) floats each) live HERE, and H0 / Hs / Ms /
+     * Mv are the fp32 tensors dmpnn_backward reads (n_hslots = n_mslots = depth - 1, rows in the plan's CSR-row order):
+     * every step writes its H^(t) and the fp32 copy of its message beside the split rows the next step consumes. */
+    void* msplit; size_t msplit_bytes;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 /* DMPNN_F_FUSED | DMPNN_F_SPLIT16 (without DMPNN_F_MEGA): the per-step fused route on the f16 matrix pipe — inference

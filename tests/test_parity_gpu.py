@@ -666,7 +666,7 @@ def test_relu_gradients_at_size(n_mols, kind, kw, gpu_device):
     bmg.to(gpu_device)
     out = mp(bmg)
     st = out.grad_fn.st                                        # the kept tensors of this forward (FusedMP)
-    rows = st.route in ("mega", "mega16", "fused")             # kept edge tensors in CSR-row order (row i = edge perm[i])
+    rows = st.route in ("mega", "mega16", "fused", "fused16")  # kept edge tensors in CSR-row order (row i = edge perm[i])
     to_edges = (lambda X: X[st.plan.inv32.long()]) if rows else (lambda X: X)
     masks = [(to_edges(st.H0[:, :h]) > 0).double().cpu()]
     masks += [(to_edges(st.Hs[t][:, :h]) > 0).double().cpu() for t in range(n_upd)]
