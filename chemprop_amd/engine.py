@@ -464,11 +464,13 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     if (not undirected and route in (None, "fused16") and not getattr(plan, "tiles_only", False) and mf == "split16"
             and (not keep or not getattr(plan, "light", False))
             and _lib.opt("DMPNN_FUSED16", "1") != "0" and _lib.opt("DMPNN_GENERAL", "0") != "1" and fuse16_shapes(a)):
-        # (d_h <= 320: where the fp32 fused route applies too; wider hidden layers, up to 640, only here).  Training (keep) takes it
-        # where the per-step GENERAL route on the f16 pipe used to run — large batches, wide hidden layers (round 3: the forward
-        # of a 40-atom x 4 096 training step 2.96 -> ~2.1 ms)
-        if route == "fused16" or (fused is None and mfma is None and (level == 1 or (level == 0 and d_h > 320 and max_level >= 1))
-                                  and nE >= (FUSED16_MIN_EDGES if not keep else (0 if d_h > 320 else STEPS16_MIN_EDGES))):
+        # (d_h <= 320: where the fp32 fused route applies too; wider hidden layers, up to 640, only here).  A TRAINING forward
+        # (keep) takes it on demand only (route="fused16"): k_step16 then also writes H^(t) and an fp32 copy of every message for
+        # the backward pass — built and measured in round 3 (40-atom x 4 096: step 6 989 us against 6 949 us with the general
+        # forward; x 512: 1 269 against 1 230): those stores eat what the fused forward saves, the time of that step is in its
+        # backward, so the default policy is unchanged
+        if route == "fused16" or (not keep and fused is None and mfma is None and (level == 1 or (level == 0 and d_h > 320 and max_level >= 1))
+                                  and nE >= FUSED16_MIN_EDGES):
             use_fused16 = True
             level = 1
     if route == "fused16" and not use_fused16:

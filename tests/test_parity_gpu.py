@@ -917,6 +917,48 @@ def test_backward_full_size_vs_oracle_autograd(n_mols, kind, kw, gpu_device):
         assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
+@pytest.mark.parametrize("n_mols,kind,kw", [(96, "synth40", dict(activation="tanh", bias=True)), (64, "zinc", dict(d_h=512, depth=4, activation="elu")),
+                                            (200, "qm9", dict(depth=1))])
+def test_training_forward_on_the_per_step_fused_route(n_mols, kind, kw, gpu_device):
+    """DMPNN_F_FUSED | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (on demand, ``route="fused16"``): k_step16 keeps H^(t) and an fp32 copy of each
+    message beside the split rows; dmpnn_backward reads them in the plan's row order.  Output and every gradient against the
+    general route of the same build (both fp32-class) and against the restated reference."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing, classify_activation
+
+    bmg = synth.random_batch(n_mols, kind, seed=19)
+    torch.manual_seed(6)
+    ref_mp = BondMessagePassing(**kw)
+    G = torch.randn(bmg.V.shape[0], ref_mp.output_dim, generator=torch.Generator().manual_seed(8))
+    w = ot.MPWeights(ref_mp.W_i.weight, ref_mp.W_h.weight, ref_mp.W_o.weight, ref_mp.W_o.bias, ref_mp.W_i.bias, ref_mp.W_h.bias)
+    ref = ot.forward_bmg(bmg, w, depth=ref_mp.depth, activation=kw.get("activation", "relu"))
+    (ref * G).sum().backward()
+    mp = BondMessagePassing(**kw)
+    mp.load_state_dict(ref_mp.state_dict())
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    act, slope, slope_t = classify_activation(mp.tau)
+    need = dict(W_i=True, b_i=mp.W_i.bias is not None, W_h=True, b_h=mp.W_h.bias is not None, W_o=True, b_o=True)
+    got = {}
+    for route in ("fused16", "general"):
+        plan = engine.GraphPlan.from_bmg(bmg)
+        out, st = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, mp.W_i.bias, mp.W_h.bias,
+                                 depth=mp.depth, act=act, slope=slope, keep=True, route=route)
+        assert st.route == ("fused16" if route == "fused16" else st.route) and (route != "fused16" or st.args.msplit)
+        got[route] = (out, engine.backward(st, G.to(gpu_device), need))
+    out16, g16 = got["fused16"]
+    outg, gg = got["general"]
+    assert parity_err(out16.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
+    assert parity_err(out16.detach().cpu().numpy(), outg.detach().cpu().numpy()) <= 3e-6
+    names = dict(W_i=ref_mp.W_i.weight, b_i=ref_mp.W_i.bias, W_h=ref_mp.W_h.weight, b_h=ref_mp.W_h.bias, W_o=ref_mp.W_o.weight, b_o=ref_mp.W_o.bias)
+    for k, p in names.items():
+        if p is None or g16[k] is None:
+            continue
+        e_ref = parity_err(g16[k].cpu().numpy(), p.grad.numpy())
+        e_gen = parity_err(g16[k].cpu().numpy(), gg[k].cpu().numpy())
+        assert e_ref <= 2e-5 and e_gen <= 2e-5, f"{k}: vs reference {e_ref:.2e}, vs general route {e_gen:.2e}"
+
+
 def test_presplit_weight_cache_follows_weight_updates(gpu_device):
     """Inference reuses the pre-split weights of the split-MFMA route between calls (same tensors, same
     ``_version``); any in-place update (optimizer step, load_state_dict) must invalidate them."""
