@@ -34,7 +34,7 @@ EXPORTS = [
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
-    "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles",
+    "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles", "dmpnn_forward_route",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -46,6 +46,9 @@ F_SPLIT16 = 16
 F_WSPLIT_READY = 32
 F_LOADER_TILES = 64
 F_STORE16 = 128
+F_H0_RESIDUAL = 256
+F_ROW_FINALIZE = 512
+ROUTES = ("general", "general16", "fused", "fused16", "mega", "mega16")  # enum dmpnn_route
 PLAN_NOMEGA_MASK = 15  # ... | no piece tiles (a molecule larger than a tile)
 PLAN_NOFUSE_MASK = 7  # asymmetric | index out of range | in-degree > 24
 
@@ -258,6 +261,7 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.dmpnn_forward_route.argtypes = [C.POINTER(FwdArgs), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.dmpnn_forward_tiles.argtypes = [C.POINTER(FwdArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p]
     lib.dmpnn_full_plan_keeps_tiles.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_head_ws_bytes.argtypes = [C.POINTER(HeadArgs)]

@@ -243,6 +243,30 @@ int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a) {
     return mega_shapes_ok(*a) ? 2 : 1;
 }
 
+// measured crossovers (MI355X): from this many directed edges on the per-step routes run their contractions on the f16 pipe /
+// an inference forward that is not the tile kernel's takes the per-step fused route on the f16 pipe
+static const int64_t kSteps16MinEdges = 20000, kFused16MinEdges = 2048;
+
+int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int plan_kind, int arith) {
+    if (!a || max_level < 0 || plan_kind < 0 || plan_kind > 2 || arith < 0 || arith > 1) return -1;
+    const bool undirected = (a->flags & DMPNN_F_UNDIRECTED) != 0;
+    int level = undirected ? 0 : dmpnn_forward_can_fuse(a);
+    if (level > max_level) level = max_level;
+    if (plan_kind == 2) return (level == 2 && arith == 0 && !keep) ? DMPNN_ROUTE_MEGA16 : -1;
+    if (plan_kind == 1 && keep) return -1;
+    const int64_t nE = a->n_edges, h = a->d_h;
+    if (!keep && !undirected && arith == 0 && nE >= kFused16MinEdges && (level == 1 || (level == 0 && h > 320 && max_level >= 1))) {
+        dmpnn_fwd_args t = *a;
+        t.flags &= ~(unsigned)(DMPNN_F_KEEP | DMPNN_F_STORE16);
+        if (fused16_shapes_ok(t)) return DMPNN_ROUTE_FUSED16;
+    }
+    if (level == 1 && arith == 0 && nE >= kSteps16MinEdges && plan_kind != 1) level = 0;  // (training at size: the per-step route on the f16 pipe)
+    if (level == 2) return arith == 0 ? DMPNN_ROUTE_MEGA16 : DMPNN_ROUTE_MEGA;
+    if (level == 1) return DMPNN_ROUTE_FUSED;
+    if (plan_kind == 1) return -1;
+    return (arith == 0 && (h > 320 || nE >= kSteps16MinEdges)) ? DMPNN_ROUTE_GENERAL16 : DMPNN_ROUTE_GENERAL;
+}
+
 int dmpnn_forward_tiles(const dmpnn_fwd_args* a, const int64_t* batch, const int* tile_row, const int* tile_atom, int64_t n_tiles,
                         size_t plan_bytes, void* stream) {
     DMPNN_CHECK_ARG(a != nullptr && a->plan != nullptr, "forward_tiles: null args / plan");

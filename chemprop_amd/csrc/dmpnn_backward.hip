@@ -518,8 +518,7 @@ WgradPlan plan_wgrad(int64_t M, int N, int Kt) {
     p.rows_per_wg = (int)rows;
     p.ldk = (Kt + 3) / 4 * 4;
     p.slab_stride = (int64_t)N * p.ldk;
-    static const bool on16 = [] { const char* e = getenv("DMPNN_WGRAD16"); return !(e && e[0] == '0'); }();
-    p.can16 = on16 && M >= 1024 && N % 2 == 0;
+    p.can16 = M >= 1024 && N % 2 == 0;
     p.q = plan_wgrad16(M, N, Kt);
     p.split_floats = p.can16 ? align_up((wsplit16_bytes(M, N) + 3) / 4, 64) + align_up((wsplit16_bytes(M, Kt) + 3) / 4, 64) : 0;
     return p;
@@ -632,8 +631,7 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     // data gradients gM = gZ . W_h, gMv = gZO . W_o[:, d_v:] on the f16 pipe (exact operand split, dmpnn_rows16.hip)
     // (about one tile per CU: the whole d_h-wide operand row in one group; large batches: 128-column groups, two
     // workgroups per CU)
-    static const bool bwd16_all = [] { const char* e = getenv("DMPNN_BWD16"); return !(e && e[0] == '0'); }();  // 0: large batches only
-    L.use16 = nE > 0 && h % 2 == 0 && f.ldh % 2 == 0 && (bwd16_all || nE >= 20000);
+    L.use16 = nE > 0 && h % 2 == 0 && f.ldh % 2 == 0;
     L.WhT16 = L.WoT16 = 0;
     if (L.use16) {
         const size_t w = align_up((linear16_wsplit_bytes(h, h) + 3) / 4, 64);
@@ -643,8 +641,7 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     // The forward ran as the whole-forward tile kernel on the f16 pipe and kept its tensors: the data-gradient chain
     // runs as ONE tile kernel too (dmpnn_mega16_bwd.hip).  It stores every gZ^(t): depth - 1 edge buffers (the two
     // ping-pong buffers, which are adjacent, serve depth <= 3).
-    static const bool bwd_mega = [] { const char* e = getenv("DMPNN_BWD_MEGA"); return !(e && e[0] == '0'); }();
-    L.mega = bwd_mega && (f.flags & DMPNN_F_MEGA) && (f.flags & DMPNN_F_SPLIT16) && (f.flags & DMPNN_F_KEEP) && nE > 0 &&
+    L.mega = (f.flags & DMPNN_F_MEGA) && (f.flags & DMPNN_F_SPLIT16) && (f.flags & DMPNN_F_KEEP) && nE > 0 &&
              f.ldh % 4 == 0 && f.act != DMPNN_ACT_PRELU;
     L.mega_w = L.gZs = L.sp_gM = 0;
     if (L.mega) {
@@ -660,9 +657,8 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     }
     L.w16 = false;
     {
-        static const bool on = [] { const char* e = getenv("DMPNN_WGRAD16"); return !(e && e[0] == '0'); }();
         const int kt_o = (int)(f.d_v + h) + 1, kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(f.d_v + f.d_e) + (f.b_i ? 1 : 0);
-        if (on && L.mega && h % 2 == 0 && f.ldh % 2 == 0 && wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, nullptr, f.ldh, (int)h) &&
+        if (L.mega && h % 2 == 0 && f.ldh % 2 == 0 && wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, nullptr, f.ldh, (int)h) &&
             (f.d_e == 0 || wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, f.E, f.lde, (int)f.d_e))) {
             L.w16 = true;
             const int64_t Ms[3] = {nV, nE * steps, nE};

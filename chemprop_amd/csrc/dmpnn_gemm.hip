@@ -28,26 +28,6 @@ namespace {
 
 using gemm::GemmK;
 
-// Plain one-thread-per-output kernel.  NOT a product path: selected only by the environment
-// variable DMPNN_DEBUG_VALU_GEMM=1 to triage an MFMA-layout failure on real hardware.
-__global__ void k_linear_valu(dmpnn_gemm_args a, const int* gather2) {
-    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (idx >= a.M * a.N) return;
-    const int64_t row = idx / a.N, col = idx % a.N;
-    const int K1 = (int)a.K1, K = (int)(a.K1 + a.K2);
-    const int64_t arow1 = a.gather1 ? (int64_t)a.gather1[row] : row;
-    const int64_t arow2 = gather2 ? (int64_t)gather2[row] : row;
-    float z = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float x = k < K1 ? a.A1[arow1 * a.lda1 + k] : a.A2[arow2 * a.lda2 + (k - K1)];
-        z = fmaf(x, a.W[col * a.ldw + k], z);
-    }
-    if (a.bias) z += a.bias[col];
-    if (a.Cadd) z = a.Cadd[row * a.ldcadd + col] + z;
-    if (a.Zpre) a.Zpre[row * a.ldz + col] = z;
-    const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
-    if (a.C) a.C[row * a.ldc + col] = apply_act(z, a.act, slope);
-}
 
 inline bool al(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
 
@@ -119,17 +99,6 @@ int launch_linear_ex(const dmpnn_gemm_args& a0, const GemmExtra& x, hipStream_t 
     }
     DMPNN_CHECK_ARG(a.N * a.ldw * 4 <= lim, "linear: weight matrix >= 2 GiB");
     DMPNN_CHECK_ARG(a.lda1 * 4 * 64 <= lim && a.lda2 * 4 * 64 <= lim && a.ldcadd * 4 * 64 <= lim, "linear: leading dimension too large");
-
-    static const bool debug_valu = [] {
-        const char* e = getenv("DMPNN_DEBUG_VALU_GEMM");
-        return e && e[0] == '1';
-    }();
-    if (debug_valu && !x.seg) {
-        const int64_t n = a.M * a.N;
-        hipLaunchKernelGGL(k_linear_valu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, gather2);
-        DMPNN_CHECK_LAUNCH("k_linear_valu");
-        return DMPNN_OK;
-    }
 
     GemmK g;
     memset(&g, 0, sizeof(g));

@@ -140,13 +140,11 @@ static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
 }
 
 // The step kernel with the K1 operand as a second operand held in registers: its rows must fit the H0 buffer they are kept
-// in (which holds no H0 then) and their chunks the lane's fragment registers.  DMPNN_XPATH=0: off (H0 written and read back).
+// in (which holds no H0 then) and their chunks the lane's fragment registers.  DMPNN_F_H0_RESIDUAL: off (H0 written and read back).
 // Measured (MI355X, same box): 40-atom x 4096 molecules 1 743 -> 1 669 us, CGR-512 305 -> 299, 40-atom x 512 345 -> 326; ZINC-512
-// h 512 depth 6 (the 8-wave workgroups) 616 -> 649 — so it is the default for d_h <= 320 only (DMPNN_XPATH=1 forces it).
+// h 512 depth 6 (the 8-wave workgroups) 616 -> 649 — so it is the rule for d_h <= 320 only.
 static bool x_path_ok(const dmpnn_fwd_args& a) {
-    const char* e = getenv("DMPNN_XPATH");
-    if ((e && e[0] == '0') || a.depth < 2) return false;
-    if (a.d_h > 320 && !(e && e[0] == '1')) return false;
+    if ((a.flags & DMPNN_F_H0_RESIDUAL) || a.depth < 2 || a.d_h > 320) return false;
     const int ts2 = step16::split_operand_bytes((int)(a.d_v + a.d_e));
     return (int64_t)ts2 <= a.ldh * 4 && (a.d_v + a.d_e + 31) / 32 <= step16::kXChunks;
 }
@@ -177,10 +175,9 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
 // The finalize on the step kernel: out = tau(W_o[:, d_v:] Mv + W_o[:, :d_v] V + b_o) over uniform 48-atom tiles — the last depth
 // step leaves Mv as split rows (in the message slot it does not read), V is split once into 400-byte rows (where the fp32 Mv
 // would have been), the atoms' rows arrive by LDS-DMA like any operand tile.  Replaces the row kernel (k_rows16: three
-// dependent load -> maximum -> split -> contract groups per tile, 18 % of a large forward).  DMPNN_FIN16=0: off.
+// dependent load -> maximum -> split -> contract groups per tile, 18 % of a large forward).  DMPNN_F_ROW_FINALIZE: off.
 static bool fin16_ok(const dmpnn_fwd_args& a, const float* out, int64_t ldout) {
-    const char* e = getenv("DMPNN_FIN16");
-    if ((e && e[0] == '0') || a.depth < 2 || a.n_edges <= 0 || a.n_atoms > a.n_edges) return false;
+    if ((a.flags & DMPNN_F_ROW_FINALIZE) || a.depth < 2 || a.n_edges <= 0 || a.n_atoms > a.n_edges) return false;
     if ((a.d_v + 31) / 32 > step16::kXChunks || (int64_t)step16::split_operand_bytes((int)a.d_v) > a.ldh * 4) return false;
     return ldout % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && a.d_h % 4 == 0;
 }
@@ -231,12 +228,11 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
     // (training keeps H0 and an fp32 Mv — the residual is read back, the finalize runs on the row kernel)
     const bool fin16 = !keep && fin16_ok(a, out, ldout);
     if (nE > 0) {
-        static const bool k1_split_all = [] { const char* e = getenv("DMPNN_K1_SPLIT"); return e && e[0] == '1'; }();
         const bool xpath = !keep && x_path_ok(a);
         unsigned char* xrows = xpath ? reinterpret_cast<unsigned char*>(a.H0) : nullptr;
         float* m32_0 = (keep && T > 1) ? a.Ms : nullptr;  // M^(1): what update step 1 consumes, what gW_h's first product reads
         if (xpath) DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, nullptr, s));
-        else if (h > 320 || k1_split_all) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, true, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s));
+        else if (h > 320) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, true, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s));
         else DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s));
         for (int t = 1; t < T; ++t) {
             const bool last = t == T - 1;

@@ -515,8 +515,7 @@ int launch_step16(const Step16K& g, int n_tiles, hipStream_t s);
 #define DMPNN_DEFINE_STEP16_H(WN, NW, HIN, XP)                                                             \
     template <>                                                                                            \
     int launch_step16<WN, NW, HIN, XP>(const Step16K& g, int n_tiles, hipStream_t s) {                     \
-        static const size_t pad_lds = [] { const char* e = getenv("DMPNN_STEP16_PAD_LDS"); return e ? (size_t)atoi(e) * 1024 : 0; }(); \
-        const size_t lds = (size_t)g.tile_bytes + meta_bytes<WN, NW>() + pad_lds;  /* (experiment: occupancy) */ \
+        const size_t lds = (size_t)g.tile_bytes + meta_bytes<WN, NW>();                                    \
         static size_t attr_set = 0;                                                                        \
         if (attr_set < lds) {                                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step16<WN, NW, HIN, XP>),  \

@@ -250,7 +250,7 @@ bool wgrad16_operand_ok(const float* A1, int64_t lda1, int K1, const float* A2, 
 WProdPlan plan_wgrad16(int64_t M, int N, int Kt) {
     WProdPlan p;
     p.n_nt = (N + 63) / 64; p.n_kt = (Kt + 63) / 64; p.n_chunks = (int)((M + 31) / 32);
-    static const int target = [] { const char* e = getenv("DMPNN_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
+    constexpr int target = 768;  // workgroups of a product launch (3 per CU: measured best of {256 .. 1536})
     int splits = target / (p.n_nt * p.n_kt);
     if (splits < 1) splits = 1;
     int cps = (p.n_chunks + splits - 1) / splits;

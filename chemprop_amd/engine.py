@@ -14,15 +14,15 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT, F_FUSED, F_KEEP, F_LOADER_TILES, F_MEGA, F_SPLIT16, F_STORE16, F_UNDIRECTED, F_WSPLIT_READY, PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs
+from ._lib import (ACT, F_FUSED, F_H0_RESIDUAL, F_KEEP, F_LOADER_TILES, F_MEGA, F_ROW_FINALIZE, F_SPLIT16, F_STORE16, F_UNDIRECTED, F_WSPLIT_READY,
+                   PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs)
 
 
-# From this many directed edges on, the per-step route runs its contractions on the f16 pipe (exact operand split) and is
-# preferred to the fused fp32-MFMA route (measured on MI355X: 1.3x per contraction at 36 k rows, more beyond).
+# The measured crossovers of the route rule live in the library (dmpnn_forward_route, csrc/dmpnn_abi.hip): from 20 000 directed
+# edges on the per-step routes run their contractions on the f16 pipe; from 2 048 on an inference forward that is not the tile
+# kernel's takes the per-step fused route on the f16 pipe.  (Mirrors for the host-side plan choice of nn.py.)
 STEPS16_MIN_EDGES = 20000
-# From this many directed edges on, an inference forward that does not take the whole-forward tile kernel runs the per-step
-# FUSED route on the f16 pipe (one launch per depth step, split message rows) instead of the fp32-MFMA fused route.
-FUSED16_MIN_EDGES = int(os.environ.get("DMPNN_FUSED16_MIN_EDGES", "2048"))
+FUSED16_MIN_EDGES = 2048
 
 
 def small_plan_fits(n_atoms: int, n_edges: int) -> bool:
@@ -142,7 +142,7 @@ class GraphPlan:
         # a FULL plan beyond the single-workgroup plan: with the batch vector it carries molecule tiles too
         # (dmpnn_prepare_with_batch) — training on the tile kernels at any batch size
         full_tiles = (not light and not small and bt is not None and n_atoms > 0 and n_edges > 0
-                      and _lib.opt("DMPNN_TRAIN_TILES", "1") != "0" and bool(lib.dmpnn_full_plan_keeps_tiles(n_atoms, n_edges)))
+                      and bool(lib.dmpnn_full_plan_keeps_tiles(n_atoms, n_edges)))
         self.any_size = (self.tiles_only and not small) or full_tiles  # (the forward's DMPNN_F_LOADER_TILES)
         self.edge_index, self.rev_edge_index = ei, rev
         if not launch:
@@ -384,7 +384,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
             keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
             max_level: int = 2, mfma: Optional[str] = None, wcache: Optional[dict] = None,
-            launch: bool = True) -> tuple[Tensor, ForwardState]:
+            launch: bool = True, form: int = 0) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -399,6 +399,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
 
     ``mfma`` picks the matrix arithmetic of the mega route: ``"split16"`` (default; fp32-equivalent exact
     3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
+    ``form``: ``DMPNN_F_H0_RESIDUAL`` / ``DMPNN_F_ROW_FINALIZE`` bits for the per-step fused route on the f16 pipe (its other
+    form of the residual / of the finalize, include/dmpnn.h; what training and wide hidden layers use anyway).
     ``launch=False`` prepares the argument block and the workspace without enqueuing anything (``trainer.FusedTrainer``).
     ``route`` is a demand (raises when the shapes do not allow it); ``max_level`` (0 general, 1 fused,
     2 mega) only caps the automatic choice.  ``fused=False`` is shorthand for ``route="general"``;
@@ -421,7 +423,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     a.plan, a.n_atoms, a.n_edges = plan.buf.data_ptr(), nV, nE
     a.edge_index, a.rev_edge_index = plan.edge_index.data_ptr(), plan.rev_edge_index.data_ptr()
     a.d_v, a.d_e, a.d_h, a.d_vd = d_v, d_e, d_h, d_vd
-    a.depth, a.flags = int(depth), (F_UNDIRECTED if undirected else 0)
+    a.depth, a.flags = int(depth), (F_UNDIRECTED if undirected else 0) | (int(form) & (F_H0_RESIDUAL | F_ROW_FINALIZE))
     if getattr(plan, "loader_tiles", 0) or getattr(plan, "any_size", False):
         a.flags |= F_LOADER_TILES              # a tile plan of any batch size
         a.n_tiles_launch = plan.loader_tiles   # (0: the launch bound — the tile count is on the device only)
@@ -441,50 +443,53 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     out = torch.empty(nV, d_h + d_vd, dtype=torch.float32, device=dev)
     a.out, a.ldout = out.data_ptr(), out.stride(0)
 
-    # route: the shape / alignment part of the decision is the library's (dmpnn_forward_can_fuse)
+    # ---- route.  The DEFAULT policy is ONE shape rule in the library (dmpnn_forward_route: the measured crossovers are its
+    # constants, tests/test_host.py enumerates it); `route` / `fused` / `mfma` are demands of tests and A/B measurements ----
     if fused is False:
         route = "general"
     if _lib.opt("DMPNN_GENERAL", "0") == "1":
         route = "general"
     a.H0 = a.Ms = a.Mv = plan.buf.data_ptr()  # any 16-byte aligned pointer: the real workspace is allocated below
-    level = 0 if (route == "general" or undirected) else int(lib.dmpnn_forward_can_fuse(C.byref(a)))
-    if route == "fused" or _lib.opt("DMPNN_MEGA", "1") == "0":
-        level = min(level, 1)
-    if route is None:
-        level = min(level, int(max_level))
-    if (fused is True or route in ("fused", "mega")) and level < (2 if route == "mega" else 1):
-        raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
-                           "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally "
-                           "<= 6144 atoms and <= 12288 edges)")
     mf = mfma or _lib.opt("DMPNN_MFMA", "split16")
-    # per-step FUSED route on the f16 pipe (split message rows between the steps, dmpnn_step16_impl.hpp): inference
-    # forwards the whole-forward tile kernel does not take — large molecules (ZINC, 40-atom, reaction graphs), any batch
-    # size; `route="fused16"` demands it
-    use_fused16 = False
-    if (not undirected and route in (None, "fused16") and not getattr(plan, "tiles_only", False) and mf == "split16"
-            and (not keep or not getattr(plan, "light", False))
-            and _lib.opt("DMPNN_FUSED16", "1") != "0" and _lib.opt("DMPNN_GENERAL", "0") != "1" and fuse16_shapes(a)):
-        # (d_h <= 320: where the fp32 fused route applies too; wider hidden layers, up to 640, only here).  A TRAINING forward
-        # (keep) takes it on demand only (route="fused16"): k_step16 then also writes H^(t) and an fp32 copy of every message for
-        # the backward pass — built and measured in round 3 (40-atom x 4 096: step 6 989 us against 6 949 us with the general
-        # forward; x 512: 1 269 against 1 230): those stores eat what the fused forward saves, the time of that step is in its
-        # backward, so the default policy is unchanged
-        if route == "fused16" or (not keep and fused is None and mfma is None and (level == 1 or (level == 0 and d_h > 320 and max_level >= 1))
-                                  and nE >= FUSED16_MIN_EDGES):
-            use_fused16 = True
+    light, tiles_only = bool(getattr(plan, "light", False)), bool(getattr(plan, "tiles_only", False))
+    if route is None and fused is None and mfma is None:
+        cap = min(int(max_level), 1) if _lib.opt("DMPNN_MEGA", "1") == "0" else int(max_level)
+        rc = int(lib.dmpnn_forward_route(C.byref(a), 1 if keep else 0, cap, 2 if tiles_only else (1 if light else 0), 1 if mf == "f32" else 0))
+        if rc < 0:
+            raise RuntimeError("forward: " + ("a tile plan (light='tiles') only serves the whole-forward tile kernel on the f16 pipe" if tiles_only else
+                                              "a light GraphPlan only serves inference forwards of the fused routes (build the plan with "
+                                              "light=False for the general route or for training)"))
+        name = _lib.ROUTES[rc]
+        use_mega, use_fused16 = name.startswith("mega"), name == "fused16"
+        use_fused = use_mega or use_fused16 or name == "fused"
+        want16 = name.endswith("16")
+    else:
+        level = 0 if (route == "general" or undirected) else int(lib.dmpnn_forward_can_fuse(C.byref(a)))
+        if route == "fused" or _lib.opt("DMPNN_MEGA", "1") == "0":
+            level = min(level, 1)
+        if (fused is True or route in ("fused", "mega")) and level < (2 if route == "mega" else 1):
+            raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
+                               "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally a batch within the "
+                               "single-workgroup plan, or a plan with molecule tiles)")
+        # the per-step FUSED route on the f16 pipe on demand — also for a TRAINING forward (keep): k_step16 then writes H^(t) and an
+        # fp32 copy of every message for the backward pass.  Built and measured in round 3 (40-atom x 4 096: step 6 989 us against
+        # 6 949 us with the general forward): those stores eat what the fused forward saves, so the default rule does not take it
+        use_fused16 = (route == "fused16" and not undirected and not tiles_only and mf == "split16" and not (keep and light) and fuse16_shapes(a))
+        if route == "fused16" and not use_fused16:
+            raise RuntimeError("forward: route 'fused16' requested but not available (directed, d_h % 4 == 0, d_h <= 640, "
+                               "even d_v / d_e, a full or light plan — training: a full plan)")
+        if use_fused16:
             level = 1
-    if route == "fused16" and not use_fused16:
-        raise RuntimeError("forward: route 'fused16' requested but not available (directed, d_h % 4 == 0, d_h <= 640, "
-                           "even d_v / d_e, a full or light plan — training: a full plan)")
-    if (level == 1 and not use_fused16 and route is None and fused is None and mfma is None and mf == "split16" and nE >= STEPS16_MIN_EDGES
-            and not getattr(plan, "light", False)):
-        level = 0  # large batch (training): the per-step route on the f16 pipe beats the fused fp32-MFMA contractions
-    use_fused, use_mega = level >= 1, level >= 2
-    if getattr(plan, "light", False) and (not use_fused or keep):
-        raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
-                           "(build the plan with light=False for the general route or for training)")
-    if getattr(plan, "tiles_only", False) and (not use_mega or (mfma or _lib.opt("DMPNN_MFMA", "split16")) == "f32"):
-        raise RuntimeError("forward: a tile plan (light='tiles') only serves the whole-forward tile kernel on the f16 pipe")
+        use_fused, use_mega = level >= 1, level >= 2
+        if light and (not use_fused or keep):
+            raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
+                               "(build the plan with light=False for the general route or for training)")
+        if tiles_only and (not use_mega or mf == "f32"):
+            raise RuntimeError("forward: a tile plan (light='tiles') only serves the whole-forward tile kernel on the f16 pipe")
+        # the per-step routes' contractions on the f16 pipe: mfma="split16" forces them, "f32" forbids them, else the rule's crossover
+        want16 = use_mega or use_fused16 or (not use_fused and (mfma == "split16" or (mfma is None and mf == "split16" and (d_h > 320 or nE >= STEPS16_MIN_EDGES))))
+        if mf == "f32":
+            want16 = False
 
     st = ForwardState()
     st.fused = use_fused
@@ -550,12 +555,6 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     if use_fused:
         a.flags |= F_FUSED
     wsplit = None
-    # the f16-pipe contractions with the exact operand split: always in the whole-forward tile kernel; in the per-step
-    # general route where they pay (measured crossover: wide hidden layers or >= ~20 k edge rows; they are the same
-    # arithmetic class, so this is a speed decision only).  mfma="split16" forces them, "f32" forbids them.
-    want16 = use_mega or use_fused16 or (not use_fused and (mfma == "split16" or (mfma is None and mf == "split16" and (d_h > 320 or nE >= STEPS16_MIN_EDGES))))
-    if mf == "f32":
-        want16 = False
     if want16:
         if use_mega:
             a.flags |= F_MEGA

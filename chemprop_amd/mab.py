@@ -129,7 +129,7 @@ def _tile_route_ok(mp, bmg, V_d, E_d) -> bool:
     act, _, _ = classify_activation(mp.tau)
     if act == "custom":
         return False
-    return engine._lib.opt("DMPNN_MAB_TILE", "1") != "0"
+    return True
 
 
 def mab_forward(mp, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = None):

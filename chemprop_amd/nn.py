@@ -178,7 +178,7 @@ def _take_prefetched(mp, bmg, light):
     return pf[1]
 
 
-_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_TILE_PLAN", "DMPNN_VALIDATE", "DMPNN_STORE", "DMPNN_TRAIN_TILES")
+_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_VALIDATE", "DMPNN_STORE")
 
 
 class _Replay:
@@ -384,11 +384,9 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     if oversize is True:
         loader_tiles = False
     # (an inference forward of the fused routes: tile kernel, per-step fused route on the f16 pipe, fp32 fused route)
-    light = _light_plan_ok(mp) and (int(bmg.E.shape[0]) < engine.STEPS16_MIN_EDGES or loader_tiles or _lib.opt("DMPNN_FUSED16", "1") != "0")
+    light = _light_plan_ok(mp)
     if light and oversize is not True and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
         light = "tiles"
-    elif light and int(bmg.E.shape[0]) >= engine.STEPS16_MIN_EDGES and _lib.opt("DMPNN_FUSED16", "1") == "0":
-        light = False
     plan = (_take_prefetched(mp, bmg, light) if "_dmpnn_prefetched" in mp.__dict__ else None) or engine.GraphPlan.from_bmg(bmg, light=light)
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch
@@ -434,7 +432,7 @@ def _tile_plan_ok(mp, n_atoms: int, n_edges: int, n_mols: int, loader_tiles: boo
     index arrays and checks every tile itself (a tile that is not closed returns NaN for its atoms)."""
     if _lib.opt("DMPNN_MEGA", "1") == "0" or _lib.opt("DMPNN_MFMA", "split16") == "f32":
         return False
-    if _lib.opt("DMPNN_TILE_PLAN", "1") == "0" or getattr(mp, "_dmpnn_no_mega", False):
+    if getattr(mp, "_dmpnn_no_mega", False):
         return False
     if _lib.opt("DMPNN_VALIDATE", "first") == "always":
         return False  # (the per-batch verdict is read from a full plan)

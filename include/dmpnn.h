@@ -75,6 +75,11 @@ enum dmpnn_flags {
                                      (dmpnn_prepare_tiles_from_table, or dmpnn_prepare_tiles with a batch vector where
                                      dmpnn_tile_plan_any_size()) or a full plan with tiles (dmpnn_prepare_with_batch):
                                      DMPNN_F_MEGA is not limited to batches the single-workgroup plan takes     */
+    DMPNN_F_H0_RESIDUAL = 1u << 8,  /* with DMPNN_F_FUSED | DMPNN_F_SPLIT16 (the per-step fused route): the residual H0 = W_i x + b_i is
+                                     written once by K1 and read back in every step, instead of being recomputed per step from the
+                                     exactly split K1 operand (the default for d_h <= 320).  Implied by DMPNN_F_KEEP and for d_h > 320 */
+    DMPNN_F_ROW_FINALIZE = 1u << 9, /* the same route: the finalize on the row kernel from an fp32 Mv, instead of on the step kernel
+                                     over 48-atom tiles fed by split rows (the default from depth 2 on).  Implied by DMPNN_F_KEEP    */
     DMPNN_F_STORE16 = 1u << 7     /* OPT-IN, NOT fp32-class.  With DMPNN_F_FUSED | DMPNN_F_SPLIT16 (the per-step fused route):
                                      the message tensor between the depth steps is stored as ONE f16 per element with a
                                      power-of-two row scale (2 bytes instead of the exact hi + lo pair of 4) and contracted
@@ -298,9 +303,9 @@ size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
  * n_edges * dmpnn_split_row_floats(d_h) floats each (instead of n_edges * ldh); plan: dmpnn_prepare
  * or dmpnn_prepare_light.  `Mv` ([n_atoms, ldh] floats) and `H0` ([n_edges, ldh] floats) are this route's SCRATCH: from depth 2
  * on the finalize runs on the step kernel, fed by per-atom sums kept as split rows in a message slot, and `Mv` holds the split
- * rows of V (DMPNN_FIN16=0 in the environment: fp32 Mv and the row kernel); for d_h <= 320 and depth >= 2 it holds the
+ * rows of V (DMPNN_F_ROW_FINALIZE: fp32 Mv and the row kernel); for d_h <= 320 and depth >= 2 it holds the
  * exactly split K1 operand [V[src] || E] of every row (the residual W_i x + b_i is recomputed inside every step), not
- * H0 — a caller that wants the H0 tensor of this route sets DMPNN_XPATH=0 in the environment. */
+ * H0 — a caller that wants the H0 tensor of this route passes DMPNN_F_H0_RESIDUAL. */
 int64_t dmpnn_split_row_floats(int64_t d_h);
 /* 1 when the shapes of `a` allow DMPNN_F_FUSED | DMPNN_F_SPLIT16 (inference, directed, d_h % 4 == 0, d_h <= 640, even d_v / d_e) */
 int dmpnn_forward_can_fuse16(const dmpnn_fwd_args* a);
@@ -319,6 +324,17 @@ int dmpnn_forward_tiles(const dmpnn_fwd_args* a, const int64_t* batch, const int
  * dmpnn_prepare: a fused forward on a graph that violates them returns NaN and leaves the plan flags
  * set (DMPNN_HDR_FLAGS) — run such graphs without DMPNN_F_FUSED. */
 int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a);
+/* The route the default policy takes for these shapes — ONE rule, in the library (the measured crossovers are its constants):
+ *   keep       != 0: a training forward (dmpnn_backward will follow)
+ *   max_level  cap from what the caller knows about the batch: 2 whole-forward tile kernel allowed, 1 per-step fused routes,
+ *              0 general route only (a graph the fused kernels cannot represent; molecules beyond the tile: 1)
+ *   plan_kind  0 full plan, 1 light plan (dmpnn_prepare_light), 2 tile plan (dmpnn_prepare_tiles*)
+ *   arith      0: contractions on the f16 pipe with the exact operand split (default), 1: exact fp32 MFMA
+ * Returns an enum dmpnn_route, or -1 when no route serves the combination (a tile plan without the tile kernel, a light plan for
+ * the general route or for training).  The flags of `a` other than DMPNN_F_UNDIRECTED / DMPNN_F_LOADER_TILES are ignored. */
+enum dmpnn_route { DMPNN_ROUTE_GENERAL = 0, DMPNN_ROUTE_GENERAL16 = 1, DMPNN_ROUTE_FUSED = 2, DMPNN_ROUTE_FUSED16 = 3,
+                   DMPNN_ROUTE_MEGA = 4, DMPNN_ROUTE_MEGA16 = 5 };
+int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int plan_kind, int arith);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  backward.  The reference has no backward code of its own: gradients come from torch autograd

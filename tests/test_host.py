@@ -188,7 +188,7 @@ def test_plan_policy_decision_table(monkeypatch):
     from chemprop_amd import engine
     from chemprop_amd.nn import BondMessagePassing, _light_plan_ok, _tile_plan_ok
 
-    for k in ("DMPNN_VALIDATE", "DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_TILE_PLAN"):
+    for k in ("DMPNN_VALIDATE", "DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA"):
         monkeypatch.delenv(k, raising=False)
     mp = BondMessagePassing().eval()
     with torch.no_grad():
@@ -212,9 +212,49 @@ def test_plan_policy_decision_table(monkeypatch):
     assert not _tile_plan_ok(mp, 12000, 25000, 512)         # ~49 directed edges per molecule: tiles would not fit them
     assert not _tile_plan_ok(mp, 37000, 73000, 4096)        # beyond the single-workgroup plan without a table / batch vector
     assert _tile_plan_ok(mp, 37000, 73000, 4096, True)      # ... with one
-    for k, v in (("DMPNN_TILE_PLAN", "0"), ("DMPNN_MEGA", "0"), ("DMPNN_MFMA", "f32"), ("DMPNN_VALIDATE", "always")):
+    for k, v in (("DMPNN_MEGA", "0"), ("DMPNN_MFMA", "f32"), ("DMPNN_VALIDATE", "always")):
         monkeypatch.setenv(k, v)
         assert not _tile_plan_ok(mp, 4636, 9120, 512), k
         monkeypatch.delenv(k)
     object.__setattr__(mp, "_dmpnn_no_mega", True)          # the module has seen an oversize molecule
     assert not _tile_plan_ok(mp, 4636, 9120, 512)
+
+
+def test_forward_route_is_one_shape_rule():
+    """dmpnn_forward_route (include/dmpnn.h): the default policy as a pure function of shapes, enumerated (no GPU)."""
+    import ctypes as C
+
+    from chemprop_amd import _lib
+
+    lib = _lib.load()
+    R = {n: i for i, n in enumerate(_lib.ROUTES)}
+
+    def args(nV, nE, d_h=300, d_v=72, d_e=14, flags=0):
+        a = _lib.FwdArgs()
+        a.n_atoms, a.n_edges, a.d_v, a.d_e, a.d_h, a.depth, a.flags = nV, nE, d_v, d_e, d_h, 3, flags
+        a.ldv, a.lde, a.ldh, a.ldout = d_v, d_e, (d_h + 3) // 4 * 4, d_h
+        for f in ("V", "E", "W_i", "W_h", "H0", "Ms", "Mv"):
+            setattr(a, f, 4096)
+        return a
+
+    route = lambda a, keep=0, cap=2, plan=0, arith=0: lib.dmpnn_forward_route(C.byref(a), keep, cap, plan, arith)
+    qm9, big = args(4636, 9120), args(37000, 73000, flags=_lib.F_LOADER_TILES)
+    # QM9-sized molecules: the whole-forward tile kernel, inference and training, at any batch size with molecule tiles
+    assert route(qm9) == route(qm9, keep=1) == route(qm9, plan=2) == R["mega16"] and route(qm9, arith=1) == R["mega"]
+    assert route(big) == route(big, keep=1) == R["mega16"]
+    # molecules beyond the tile (cap 1): per-step fused route on the f16 pipe for inference, per-step general16 for training at size
+    assert route(big, cap=1) == route(big, cap=1, plan=1) == R["fused16"]
+    assert route(big, keep=1, cap=1) == R["general16"]
+    assert route(qm9, cap=1) == R["fused16"] and route(qm9, keep=1, cap=1) == R["fused"] and route(qm9, cap=1, arith=1) == R["fused"]
+    small = args(300, 600)
+    assert route(small, cap=1) == R["fused"] and route(small, cap=0) == R["general"]          # below the crossover: fp32-MFMA kernels
+    # wide hidden layers: no fp32 fused route; fused16 up to 640 columns, general16 beyond and for training
+    assert route(args(12000, 25000, d_h=512)) == R["fused16"] and route(args(12000, 25000, d_h=512), keep=1) == R["general16"]
+    assert route(args(12000, 25000, d_h=1024)) == R["general16"] and route(args(300, 600, d_h=1024), arith=1) == R["general"]
+    # undirected, odd widths: the general route
+    assert route(args(4636, 9120, flags=_lib.F_UNDIRECTED)) == R["general"] and route(args(37000, 73000, flags=_lib.F_UNDIRECTED)) == R["general16"]
+    assert route(args(4636, 9120, d_e=13)) == R["general"]
+    # plans that cannot serve: a tile plan without the tile kernel, a light plan for training / the general route
+    assert route(qm9, cap=1, plan=2) == -1 and route(qm9, keep=1, plan=2) == -1 and route(qm9, arith=1, plan=2) == -1
+    assert route(qm9, keep=1, plan=1) == -1 and route(args(4636, 9120, d_e=13), plan=1) == -1
+    assert lib.dmpnn_forward_route(None, 0, 2, 0, 0) == -1 and route(qm9, cap=-1) == -1

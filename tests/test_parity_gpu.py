@@ -148,7 +148,7 @@ def test_forward_matches_executed_reference(golden, gpu_device):
         assert torch.equal(a, b)
 
 
-def _engine_forward(golden, dev, fused=None, keep=False, route=None, mfma=None, plan=None):
+def _engine_forward(golden, dev, fused=None, keep=False, route=None, mfma=None, plan=None, form=0):
     from chemprop_amd import engine
     from chemprop_amd.nn import classify_activation
 
@@ -164,7 +164,7 @@ def _engine_forward(golden, dev, fused=None, keep=False, route=None, mfma=None, 
                                  mp.W_i.bias, mp.W_h.bias, mp.W_d.weight if has_vd else None,
                                  mp.W_d.bias if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
                                  slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=keep, fused=fused,
-                                 route=route, mfma=mfma)
+                                 route=route, mfma=mfma, form=form)
     return plan, out, st
 
 
@@ -277,14 +277,14 @@ def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device, monkeypatch):
     if str(cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
         pytest.skip("custom activation: rows route")
     # Two forms of the residual H0 = W_i [V[src] || E] + b_i in the depth steps: recomputed per step from the exactly split K1
-    # operand (the default where d_v + d_e <= 256 and depth >= 2: no H0 tensor exists) and written once / read back
-    # (DMPNN_XPATH=0).  Same bar for both.
+    # operand (the default where d_v + d_e <= 256, d_h <= 320 and depth >= 2: no H0 tensor exists) and written once / read back
+    # (DMPNN_F_H0_RESIDUAL: what wide hidden layers and training use).  Same bar for both.
     # The finalize likewise has two forms: on the step kernel over 48-atom tiles, fed by the last step's per-atom sums as split
-    # rows (the default from depth 2 on: no fp32 Mv tensor exists), and the row kernel on fp32 Mv (DMPNN_FIN16=0).
-    for xpath, fin16 in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("DMPNN_XPATH", xpath)   # ("1" also forces it for the 8-wave workgroups of wide hidden layers)
-        monkeypatch.setenv("DMPNN_FIN16", fin16)
-        plan, out, st = _engine_forward(golden, gpu_device, route="fused16")
+    # rows (the default from depth 2 on: no fp32 Mv tensor exists), and the row kernel on fp32 Mv (DMPNN_F_ROW_FINALIZE).
+    from chemprop_amd._lib import F_H0_RESIDUAL, F_ROW_FINALIZE
+
+    for form in (0, F_H0_RESIDUAL | F_ROW_FINALIZE, F_ROW_FINALIZE, F_H0_RESIDUAL):
+        plan, out, st = _engine_forward(golden, gpu_device, route="fused16", form=form)
         assert st.route == "fused16"
         if not plan.fusable():
             assert torch.isnan(out).all()      # not a molecular graph: loud
@@ -357,18 +357,18 @@ def test_half_storage_at_size(kind, n_mols, kw, gpu_device, monkeypatch):
     assert mp.__dict__.get("_dmpnn_route") == "fused16"
 
 
-@pytest.mark.parametrize("d_h,depth,act,bias,kind,n", [(384, 3, "relu", False, "zinc", 40), (448, 2, "tanh", True, "qm9", 80),
-                                                       (512, 4, "leakyrelu", False, "synth40", 24), (640, 3, "elu", True, "cgr", 30),
-                                                       (324, 3, "relu", False, "qm9", 60), (64, 1, "relu", False, "zinc", 30)])
-def test_per_step_fused_route_wide_hidden_layers(d_h, depth, act, bias, kind, n, gpu_device, monkeypatch):
+@pytest.mark.parametrize("d_h,depth,act,bias,kind,n", [(384, 3, "relu", False, "zinc", 64), (448, 2, "tanh", True, "qm9", 160),
+                                                       (512, 4, "leakyrelu", False, "synth40", 36), (640, 3, "elu", True, "cgr", 80),
+                                                       (324, 3, "relu", False, "qm9", 160), (64, 1, "relu", False, "zinc", 64)])
+def test_per_step_fused_route_wide_hidden_layers(d_h, depth, act, bias, kind, n, gpu_device):
     """d_h beyond the 320 columns of a 4-wave workgroup (hpopt searches 300-2400, cli/hpopt.py:73): 8-wave workgroups cover
     up to 640 columns, K1 runs on the update kernel over an operand split into rows first.  Against the oracle."""
-    from chemprop_amd import engine, synth
+    from chemprop_amd import synth
     from chemprop_amd.nn import BondMessagePassing
 
-    monkeypatch.setattr(engine, "FUSED16_MIN_EDGES", 0)
     dims = dict(d_v=106, d_e=28) if kind == "cgr" else {}
-    bmg = synth.random_batch(n, kind, seed=d_h)
+    bmg = synth.random_batch(n, kind, seed=d_h)   # (>= 2 048 directed edges: where the route rule takes the per-step fused route)
+    assert bmg.E.shape[0] >= 2048
     torch.manual_seed(d_h)
     mp = BondMessagePassing(d_h=d_h, depth=depth, activation=act, bias=bias, **dims).eval()
     with torch.no_grad():
@@ -380,11 +380,6 @@ def test_per_step_fused_route_wide_hidden_layers(d_h, depth, act, bias, kind, n,
             out = mp(bmg)
             assert mp.__dict__.get("_dmpnn_route") == "fused16", mp.__dict__.get("_dmpnn_route")
             assert parity_err(out.cpu().numpy(), ref) <= TOL, (d_h, i)
-        # the residual recomputed from the split K1 operand (the default up to d_h = 320 only) forced for these shapes as well
-        monkeypatch.setenv("DMPNN_XPATH", "1")
-        assert parity_err(mp(bmg).cpu().numpy(), ref) <= TOL, (d_h, "x path")
-        monkeypatch.setenv("DMPNN_FIN16", "0")         # (the finalize on the row kernel; the default above was the step kernel)
-        assert parity_err(mp(bmg).cpu().numpy(), ref) <= TOL, (d_h, "row-kernel finalize")
 
 
 def _closed_tile_mask(a, src, dst, rev, n_atoms):
@@ -484,9 +479,7 @@ def test_full_plan_with_molecule_tiles_beyond_the_single_workgroup_plan(gpu_devi
     from oracle import collate_numpy as oc
     ei_h = bmg.edge_index.cpu().numpy()
     assert oc.full_plan_tiles_ok(ei_h[0], ei_h[1], nV, af["mtile_row"][:n_t + 1].numpy(), af["mtile_atom"][:n_t + 1].numpy())
-    monkeypatch.setenv("DMPNN_TRAIN_TILES", "0")
-    plain = GraphPlan.from_bmg(bmg)
-    monkeypatch.delenv("DMPNN_TRAIN_TILES")
+    plain = GraphPlan.from_bmg(bmg, use_batch=False)   # (without the batch vector: the plain full plan, no molecule tiles)
     ap = plain.arrays()
     assert not plain.any_size and ap["hdr"][0] == 8 and ap["hdr"][6] == 0
     for k in ("src", "dst", "rev", "row_ptr", "perm", "inv", "srcp", "dstp", "revp", "tile_row", "tile_atom"):
