@@ -313,7 +313,8 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         // ---- per-step fused route on the f16 pipe: split message rows between the steps (dmpnn_step16_impl.hpp) ----
         DMPNN_CHECK_ARG(fused16_shapes_ok(*a), "forward: DMPNN_F_FUSED | DMPNN_F_SPLIT16 given but the shapes do not allow it "
                         "(directed, d_h %% 4 == 0, d_h <= 640, even d_v / d_e; with DMPNN_F_KEEP: depth - 1 kept H / M slots and `msplit`)");
-        DMPNN_CHECK_ARG(nE == 0 || (a->H0 && a->Ms && (a->n_mslots >= 2 || (a->flags & DMPNN_F_KEEP))), "forward(fused16): H0 and two split message slots are required");
+        DMPNN_CHECK_ARG(nE == 0 || (a->H0 && ((a->flags & DMPNN_F_KEEP) ? (a->Ms || a->depth == 1) : (a->Ms && a->n_mslots >= 2))),
+                        "forward(fused16): H0 and two split message slots (training: `msplit` + the kept fp32 slots) are required");
         DMPNN_CHECK_ARG(a->wsplit && a->wsplit_bytes >= steps16_wsplit_bytes(*a), "forward(fused16): wsplit workspace missing or too small");
         SplitWView w[6];
         unsigned char* wp = static_cast<unsigned char*>(a->wsplit);

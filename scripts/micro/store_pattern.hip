@@ -41,7 +41,56 @@ __global__ __launch_bounds__(256) void k(float* __restrict__ base, long long slo
     if (acc == 12345.f) *sink = acc;
 }
 
+// Latency chain: per iteration one 16-byte store to the workgroup's own rows, then one dependent 16-byte LOAD (from another buffer)
+// whose result feeds the next address — s_waitcnt vmcnt(0) per iteration, so an iteration costs max(load latency, store ACK latency).
+// mode 0: load only; 1: store + load; 2: store (nt) + load.  One wave per workgroup, `wgs` workgroups.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_lat(float* __restrict__ out, const float* __restrict__ in, int iters, long long* cycles) {
+    const int lane = threadIdx.x;
+    float* o = out + (long long)blockIdx.x * 64 * 1024;
+    const float* p = in + (long long)blockIdx.x * 64 * 1024;
+    unsigned off = lane * 4;
+    float acc = 0.f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 1) *reinterpret_cast<float4*>(o + ((i * 64 * 4 + lane * 4) & (64 * 1024 - 1))) = make_float4(acc, i, lane, 1.f);
+        if (MODE == 2) __builtin_nontemporal_store(acc + i, o + ((i * 64 * 4 + lane * 4) & (64 * 1024 - 1)));
+        const float4 v = *reinterpret_cast<const float4*>(p + (off & (64 * 1024 - 4)));
+        acc += v.x;
+        off = off + 256 + ((unsigned)(v.y) & 3u) * 4u;   // (dependent address: the next load cannot issue before this one returns)
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) cycles[blockIdx.x] = t1 - t0;
+    if (acc == 12345.f) out[0] = acc;
+}
+
+static void latency_test() {
+    const int wgs_list[3] = {1, 64, 840};
+    float* out; float* in; long long* cyc;
+    const size_t n = (size_t)840 * 64 * 1024;
+    CHECK(hipMalloc(&out, n * 4)); CHECK(hipMalloc(&in, n * 4)); CHECK(hipMalloc(&cyc, 840 * 8));
+    CHECK(hipMemset(in, 0, n * 4)); CHECK(hipMemset(out, 0, n * 4));
+    const char* names[3] = {"load only", "store + dependent load", "nt store + dependent load"};
+    for (int w = 0; w < 3; ++w)
+        for (int mode = 0; mode < 3; ++mode) {
+            const int iters = 200;
+            for (int rep = 0; rep < 3; ++rep) {
+                if (mode == 0) hipLaunchKernelGGL(k_lat<0>, dim3(wgs_list[w]), dim3(64), 0, 0, out, in, iters, cyc);
+                else if (mode == 1) hipLaunchKernelGGL(k_lat<1>, dim3(wgs_list[w]), dim3(64), 0, 0, out, in, iters, cyc);
+                else hipLaunchKernelGGL(k_lat<2>, dim3(wgs_list[w]), dim3(64), 0, 0, out, in, iters, cyc);
+                CHECK(hipDeviceSynchronize());
+            }
+            long long h[840];
+            CHECK(hipMemcpy(h, cyc, wgs_list[w] * 8, hipMemcpyDeviceToHost));
+            double s = 0; long long mx = 0;
+            for (int i = 0; i < wgs_list[w]; ++i) { s += h[i]; if (h[i] > mx) mx = h[i]; }
+            printf("latency chain, %3d waves: %-26s  %7.0f cycles / iteration (mean), %7.0f (slowest wave)   [cycle counter ticks]\n", wgs_list[w], names[mode],
+                   s / wgs_list[w] / iters, (double)mx / iters);
+        }
+}
+
 int main() {
+    latency_test();
     const int tiles = 210;
     const long long slot = (long long)tiles * ROWS * LD;
     float* buf; float* sink;

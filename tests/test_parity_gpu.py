@@ -290,13 +290,13 @@ def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device, monkeypatch):
             assert torch.isnan(out).all()      # not a molecular graph: loud
             return
         err = parity_err(out.cpu().numpy(), golden["out"])
-        assert err <= TOL, f"{golden.name} (xpath {xpath}, fin16 {fin16}): {err:.3e}"
-        if fin16 == "0" and "Mv" in golden and plan.n_edges:
+        assert err <= TOL, f"{golden.name} (form {form:#x}): {err:.3e}"
+        if (form & F_ROW_FINALIZE) and "Mv" in golden and plan.n_edges:
             assert parity_err(st.Mv[:, :cfg["d_h"]].cpu().numpy(), golden["Mv"]) <= TOL
-        if xpath == "0" and "H0" in golden and plan.n_edges:     # kept rows are the plan's CSR rows (row i = edge perm[i])
+        if (form & F_H0_RESIDUAL) and "H0" in golden and plan.n_edges:     # kept rows are the plan's CSR rows (row i = edge perm[i])
             H0 = st.H0[:, :cfg["d_h"]][plan.inv32.long()]
             assert parity_err(H0.cpu().numpy(), golden["H0"]) <= TOL
-        _, out2, _ = _engine_forward(golden, gpu_device, route="fused16")
+        _, out2, _ = _engine_forward(golden, gpu_device, route="fused16", form=form)
         assert torch.equal(out, out2)          # deterministic (no atomics on the data path)
 
 
