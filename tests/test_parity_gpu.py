@@ -911,7 +911,7 @@ def test_backward_full_size_vs_oracle_autograd(n_mols, kind, kw, gpu_device):
 
 
 @pytest.mark.parametrize("n_mols,kind,kw", [(96, "synth40", dict(activation="tanh", bias=True)), (64, "zinc", dict(d_h=512, depth=4, activation="elu")),
-                                            (200, "qm9", dict(depth=1))])
+                                            (200, "qm9", dict(depth=1, activation="elu"))])   # (smooth activations: kinks are test_relu_gradients_at_size's)
 def test_training_forward_on_the_per_step_fused_route(n_mols, kind, kw, gpu_device):
     """DMPNN_F_FUSED | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (on demand, ``route="fused16"``): k_step16 keeps H^(t) and an fp32 copy of each
     message beside the split rows; dmpnn_backward reads them in the plan's row order.  Output and every gradient against the
