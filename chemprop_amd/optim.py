@@ -74,3 +74,38 @@ class FlatAdam:
 
     def zero_grad(self) -> None:
         self.sync.zero_grad()
+
+    # ---- checkpointing (the reference's Lightning checkpoints carry the optimizer state: moments and step count) ----
+    def state_dict(self) -> dict:
+        """The flat moments, the step count and the hyper-parameters; ``layout`` (names are positions: shapes in flat-buffer order)
+        lets ``load_state_dict`` refuse a model of another shape."""
+        return {"step": self.steps, "exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(),
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                "layout": [tuple(p.shape) for p in self.sync.params]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        layout = [tuple(p.shape) for p in self.sync.params]
+        if [tuple(x) for x in sd["layout"]] != layout or sd["exp_avg"].numel() != self.m.numel():
+            raise ValueError("FlatAdam.load_state_dict: the state belongs to parameters of another shape / order")
+        self.steps = int(sd["step"])
+        self.m.copy_(sd["exp_avg"].to(self.m.device))
+        self.v.copy_(sd["exp_avg_sq"].to(self.v.device))
+        self.lr, self.betas, self.eps, self.weight_decay = float(sd["lr"]), (float(sd["betas"][0]), float(sd["betas"][1])), float(sd["eps"]), float(sd["weight_decay"])
+
+    def torch_state(self) -> dict:
+        """The same state in ``torch.optim.Adam.state_dict()['state']`` form (per parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``,
+        keyed by position): what a checkpoint written by the reference's trainer holds, for moving a run between the two."""
+        out = {}
+        for i, (p, o) in enumerate(zip(self.sync.params, self.sync.offsets)):
+            n = p.numel()
+            out[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.m[o:o + n].view_as(p).clone(),
+                      "exp_avg_sq": self.v[o:o + n].view_as(p).clone()}
+        return out
+
+    def load_torch_state(self, state: dict) -> None:
+        for i, (p, o) in enumerate(zip(self.sync.params, self.sync.offsets)):
+            st = state[i]
+            n = p.numel()
+            self.m[o:o + n].view_as(p).copy_(st["exp_avg"].to(self.m.device))
+            self.v[o:o + n].view_as(p).copy_(st["exp_avg_sq"].to(self.v.device))
+            self.steps = int(st["step"])

@@ -72,3 +72,49 @@ def test_training_with_the_fused_step_follows_torch_adam(gpu_device):
     a.eval(); b.eval()
     with torch.no_grad():
         torch.testing.assert_close(a(bmg), b(bmg), rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_flat_adam_checkpoint_round_trip(gpu_device):
+    """state_dict / load_state_dict (the reference's checkpoints carry the optimizer state): a resumed run continues bit for bit;
+    torch_state / load_torch_state exchange the moments with ``torch.optim.Adam``."""
+    from chemprop_amd import distributed as ddp
+    from chemprop_amd.nn import BondMessagePassing
+    from chemprop_amd.optim import FlatAdam
+
+    def make():
+        torch.manual_seed(0)
+        m = BondMessagePassing(d_h=32, depth=2, bias=True).to(gpu_device)
+        s = ddp.GradSync(list(m.parameters()), modules=[m])
+        return m, s, FlatAdam(s, lr=2e-3, betas=(0.9, 0.98))
+
+    g = torch.Generator(device=gpu_device).manual_seed(3)
+    grads = [[torch.randn(p.shape, device=gpu_device, generator=g) for p in make()[0].parameters()] for _ in range(5)]
+
+    def run(m, opt, steps):
+        for gs in steps:
+            for p, gr in zip(m.parameters(), gs):
+                p.grad.copy_(gr)
+            opt.step()
+
+    a, _, oa = make()
+    run(a, oa, grads)                              # five steps straight
+    b, _, ob = make()
+    run(b, ob, grads[:3])                          # three steps, checkpoint, a fresh process, two more
+    ck = {"model": {k: v.clone() for k, v in b.state_dict().items()}, "opt": ob.state_dict()}
+    c, _, oc = make()
+    c.load_state_dict(ck["model"])
+    oc.load_state_dict(ck["opt"])
+    assert oc.steps == 3
+    run(c, oc, grads[3:])
+    for (n, pa), pc in zip(a.named_parameters(), c.parameters()):
+        assert torch.equal(pa, pc), n
+    with pytest.raises(ValueError):
+        wrong = BondMessagePassing(d_h=16, depth=2).to(gpu_device)
+        FlatAdam(ddp.GradSync(list(wrong.parameters()))).load_state_dict(ck["opt"])
+    # moments to torch.optim.Adam and back
+    ts = oa.torch_state()
+    assert float(ts[0]["step"]) == 5 and ts[0]["exp_avg"].shape == next(a.parameters()).shape
+    d, _, od = make()
+    od.load_torch_state(ts)
+    assert od.steps == 5 and torch.equal(od.m, oa.m) and torch.equal(od.v, oa.v)
