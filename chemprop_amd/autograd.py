@@ -46,9 +46,21 @@ def mp_forward(mp, plan: engine.GraphPlan, V: Tensor, E: Tensor, V_d: Optional[T
                 raise NotImplementedError(
                     f"chemprop_amd: gradient w.r.t. `{name}` is not provided by the engine "
                     "(the reference never asks for it: features are data)")
-    use_rows = act == "custom" or drop_active or (act == "prelu" and grad)
     p = _params(mp)
     has_vd = mp.W_d is not None and V_d is not None
+    if drop_active and grad and act in ("relu", "leakyrelu") and not has_vd and max_level >= 2:
+        # ACTIVE dropout inside the tile kernels (round 3): the mask is a counter-based hash of (seed, site, row, column), the seed
+        # one draw from torch's CPU generator (so torch.manual_seed fixes the run); a batch that takes another route falls
+        # through to the rows route below, where the block's own nn.Dropout runs between the kernels
+        from .backward import FusedMP
+
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        try:
+            return FusedMP.apply(mp, plan, V, E, None, act, slope, (slope_t, max_level, (float(mp.dropout.p), seed)),
+                                 *[p[k] for k in ("W_i", "b_i", "W_h", "b_h", "W_o", "b_o", "W_d", "b_d")])
+        except engine.RouteUnavailable:
+            pass
+    use_rows = act == "custom" or drop_active or (act == "prelu" and grad)
 
     if not use_rows:
         if grad:

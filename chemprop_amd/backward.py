@@ -20,11 +20,12 @@ _PARAM_ORDER = ("W_i", "b_i", "W_h", "b_h", "W_o", "b_o", "W_d", "b_d")
 class FusedMP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mp, plan, V, E, V_d, act, slope, slope_and_route, W_i, b_i, W_h, b_h, W_o, b_o, W_d, b_d):
-        slope_t, max_level = slope_and_route
+        slope_t, max_level = slope_and_route[0], slope_and_route[1]
+        dropout = slope_and_route[2] if len(slope_and_route) > 2 else None
         has_vd = V_d is not None and W_d is not None
         out, st = engine.forward(plan, V, E, W_i, W_h, W_o, b_o, b_i, b_h, W_d if has_vd else None,
                                  b_d if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
-                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True, max_level=max_level)
+                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True, max_level=max_level, dropout=dropout)
         ctx.st = st
         ctx.has_vd = has_vd
         ctx.mp = mp

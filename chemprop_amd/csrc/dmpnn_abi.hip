@@ -49,6 +49,10 @@ namespace dmpnn { extern thread_local long long* g_debug_stamps; }
 extern "C" {
 
 int dmpnn_version(void) { return DMPNN_ABI_VERSION; }
+int dmpnn_dropout_keep(uint64_t seed, int32_t site, int64_t row, int64_t col, float p) {
+    if (!(p > 0.f && p < 1.f)) return p <= 0.f ? 1 : 0;
+    return drop_hash((unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (unsigned)site, (unsigned)row, (unsigned)col) >= drop_threshold(p) ? 1 : 0;
+}
 int dmpnn_debug_timestamps(void* device_buf) {
     g_debug_stamps = static_cast<long long*>(device_buf);
     return DMPNN_OK;
@@ -304,6 +308,13 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         DMPNN_CHECK_ARG(fused || (a->Hs && a->n_hslots >= 1), "forward: missing Hs workspace");
     }
 
+    if (a->dropout_p != 0.f) {
+        DMPNN_CHECK_ARG(a->dropout_p > 0.f && a->dropout_p < 1.f, "forward: dropout_p must lie in [0, 1)");
+        const bool tile_train = (a->flags & DMPNN_F_MEGA) && (a->flags & DMPNN_F_SPLIT16) && (a->flags & DMPNN_F_KEEP);
+        DMPNN_CHECK_ARG(tile_train && !has_vd && (a->act == DMPNN_ACT_RELU || a->act == DMPNN_ACT_LEAKYRELU || a->act == DMPNN_ACT_PRELU),
+                        "forward: dropout inside the kernels needs the training forward of the tile kernel (DMPNN_F_MEGA | DMPNN_F_SPLIT16 | "
+                        "DMPNN_F_KEEP), a ReLU-class activation and no W_d — run dropout between the row kernels otherwise");
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const PlanView pv = plan_view(a->plan, nV, nE);
     const int64_t slot = nE * a->ldh;

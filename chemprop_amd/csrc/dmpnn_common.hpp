@@ -116,6 +116,20 @@ inline PlanView plan_view_rows(const void* plan, int64_t nV, int64_t nE) {
     return PlanView{p, p + L.srcp, p + L.dstp, p + L.revp, p + L.row_ptr, p + L.ident};
 }
 
+// ---- dropout mask: a counter-based hash (restated in oracle/dropout_hash.py) -----------------------------------------
+// keep(seed, site, row, col) = mix32(...) >= thr,  thr = floor(p 2^32).  Two rounds of a multiply-xorshift mixer over a key
+// that is unique per element (row * 1024 + col: d_h <= 1024), the 64-bit seed folded in before and between the rounds.
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed_lo, unsigned seed_hi, unsigned site, unsigned row, unsigned col) {
+    unsigned h = (row * 1024u + col) ^ seed_lo ^ (site * 0x9E3779B9u);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h += seed_hi; h *= 0x846CA68Bu; h ^= h >> 16;
+    h *= 0x9E3779B1u; h ^= h >> 15;
+    return h;
+}
+inline unsigned drop_threshold(float p) {  // floor(p 2^32), p in (0, 1)
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+}
+
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float apply_act(float z, int act, float slope) {
     switch (act) {

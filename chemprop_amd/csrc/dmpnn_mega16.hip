@@ -105,6 +105,10 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     G.WoM = mega16::SplitW{ws + W.wom, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_h};
     G.WoV = mega16::SplitW{ws + W.wov, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_v};
     g.dbg = g_debug_stamps;
+    if (a.dropout_p > 0.f && a.dropout_p < 1.f) {  // (validated by dmpnn_forward: training forward, ReLU-class activation, no W_d)
+        g.drop_thr = drop_threshold(a.dropout_p); g.drop_scale = 1.f / (1.f - a.dropout_p);
+        g.seed_lo = (unsigned)(a.dropout_seed & 0xFFFFFFFFull); g.seed_hi = (unsigned)(a.dropout_seed >> 32);
+    }
     g.edge_index = reinterpret_cast<const long long*>(a.edge_index);
     g.rev64 = reinterpret_cast<const long long*>(a.rev_edge_index);
     const int n_tiles = (a.n_tiles_launch > 0 && a.n_tiles_launch < L.max_mtiles) ? (int)a.n_tiles_launch : (int)L.max_mtiles;

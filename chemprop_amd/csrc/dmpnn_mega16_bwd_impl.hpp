@@ -37,6 +37,8 @@ struct Mega16BwdK {
     // the generic path for pieces larger than the tile (dmpnn_spill_impl.hpp): plain weights, two scratch tensors
     const int* srcp; int d_v; const float* W_o; const float* W_h;
     float* sp_gM; float* sp_Ta;          // [E, ldh], [V, ldh]
+    float drop_scale;                    // active dropout in the forward: 1 / (1 - p) (else 0).  The kept H^(t) and the finalize output
+                                         // are POST-dropout; for a ReLU-class activation their sign carries the mask (0: dropped or inactive)
 };
 
 template <int WN>
@@ -104,6 +106,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             // identity: 1; ReLU: [y > 0]; LeakyReLU: y > 0 ? 1 : slope  (sign(tau(z)) == sign(z) for slope > 0, so the
             // pre-activation serves as well as the output)
             const float neg = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
+            if (g.drop_scale != 0.f && !preact) {
+                // y = dropout(tau(z)): exactly 0 where dropped (or inactive), else tau(z) / (1 - p) with the sign of z
+                return y > 0.f ? gval * g.drop_scale : (y < 0.f ? neg * gval * g.drop_scale : 0.f);
+            }
             return (g.act == DMPNN_ACT_NONE || y > 0.f) ? gval : neg * gval;
         } else {
             if (preact) y = apply_act(y, g.act, slope);

@@ -194,6 +194,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         // a piece (molecule) larger than the matrix-pipe tile — the reference has no size limit (data/collate.py:48-56):
         // the generic fp32 path carries it, whatever its size (dmpnn_spill_impl.hpp)
         const mega::MegaK& gs = spill::fresh_kernargs<Mega16K>()->m;
+        if (KEEP && gs.drop_thr) {  // the generic path has no dropout: an oversize molecule of a dropout batch is LOUD (NaN), never unmasked
+            const float nanv = __int_as_float(0x7fc00000);
+            for (int i = tid; i < na * N; i += kThreads) gs.out[(long long)(va + i / N) * gs.ldout + (i % N)] = nanv;
+            return;
+        }
         spill::forward(mega::spill_view(gs, gs.flags[DMPNN_HDR_LIGHT] == 2, rs, nrows, va, na, gs.slope_ptr ? *gs.slope_ptr : gs.slope),
                        reinterpret_cast<float*>(lds));
         return;
@@ -507,6 +512,28 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                     }
         }
     };
+    // active dropout on C/D fragments (training forward only): element (row0 + rt 16 + lg 4 + r, column) is kept iff its hash
+    // clears the threshold, and scaled by 1 / (1 - p)   (base.py:139,182)
+    auto dropout_frags = [&](auto rt_c, f32x4 (&y)[decltype(rt_c)::value][WN], unsigned site, int row0) {
+        constexpr int RT = decltype(rt_c)::value;
+        if constexpr (KEEP) {
+            if (g.drop_thr) {  // (uniform)
+                launder();
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct) {
+                    const unsigned col = (unsigned)(wave * (16 * WN) + ct * 16 + li);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned row = (unsigned)(row0 + rt * 16 + lg * 4 + r);
+                            const bool keep = drop_hash(g.seed_lo, g.seed_hi, site, row, col) >= g.drop_thr;
+                            y[rt][ct][r] = keep ? y[rt][ct][r] * g.drop_scale : 0.f;
+                        }
+                }
+            }
+        }
+    };
     auto frag_to_tile = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WN]) {
         constexpr int RT = decltype(rt_c)::value;
         launder();
@@ -668,6 +695,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         stamp();  // 5, 7, ...: update contraction
         unscale(RE{}, acc, 1.f / sA, cc);
         act_frags(RE{}, T_{}, acc, h0);  // tau(H0 + W_h(M)): base.py:141
+        dropout_frags(RE{}, acc, (unsigned)(step - 1), rs);  // dropout(H_t): base.py:139 (training, p > 0)
         stamp();  // E: unscale + tau
         if (KEEP && g.Hs) {
             __syncthreads();  // (the fp32 tile overlays the split A tile: every wave is past its contraction)
@@ -707,6 +735,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         stamp();  // finalize: V part
         unscale(RA{}, acc, 1.f / sV, cc);
         act_frags(RA{}, F_{}, acc, acc);
+        dropout_frags(RA{}, acc, (unsigned)(T_steps - 1), va);  // dropout(tau(W_o [...])): base.py:182
         if (maxbits[5]) {  // (uniform; written before the first barrier of the kernel)
 #pragma unroll
             for (int rt = 0; rt < RT_A; ++rt)

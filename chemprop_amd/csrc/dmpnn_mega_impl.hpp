@@ -50,6 +50,8 @@ struct MegaK {
     const long long* edge_index;  // [2, nE] row 0 = src atom, row 1 = dst atom
     const long long* rev64;       // [nE]
     float* spill;                 // inference scratch of the generic path for oversize pieces ([3 nE + nV][ldh]) or null
+    // active dropout (dmpnn_fwd_args.dropout_p; split-MFMA training forward only): threshold floor(p 2^32) (0: off), 1 / (1 - p), seed
+    unsigned drop_thr; float drop_scale; unsigned seed_lo, seed_hi;
 };
 
 // the view the generic path (dmpnn_spill_impl.hpp) takes of a piece tile that exceeds the matrix-pipe tile

@@ -250,6 +250,10 @@ def fuse16_shapes(a) -> bool:
         a.flags = flags
 
 
+class RouteUnavailable(RuntimeError):
+    """A demanded kernel feature does not exist on the route this batch takes (the caller has another way)."""
+
+
 def act_code(name: str) -> int:
     return ACT[str(name).lower()]
 
@@ -384,7 +388,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
             keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
             max_level: int = 2, mfma: Optional[str] = None, wcache: Optional[dict] = None,
-            launch: bool = True, form: int = 0) -> tuple[Tensor, ForwardState]:
+            launch: bool = True, form: int = 0, dropout: Optional[tuple] = None) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -401,6 +405,9 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
     ``form``: ``DMPNN_F_H0_RESIDUAL`` / ``DMPNN_F_ROW_FINALIZE`` bits for the per-step fused route on the f16 pipe (its other
     form of the residual / of the finalize, include/dmpnn.h; what training and wide hidden layers use anyway).
+    ``dropout = (p, seed)``: ACTIVE dropout inside the kernels (``dmpnn_fwd_args.dropout_p``) — a training forward (``keep``) of
+    the tile kernel with a ReLU-class activation and no ``W_d``; raises :class:`RouteUnavailable` when this batch takes another
+    route (the caller then runs its own ``nn.Dropout`` between the row kernels).
     ``launch=False`` prepares the argument block and the workspace without enqueuing anything (``trainer.FusedTrainer``).
     ``route`` is a demand (raises when the shapes do not allow it); ``max_level`` (0 general, 1 fused,
     2 mega) only caps the automatic choice.  ``fused=False`` is shorthand for ``route="general"``;
@@ -491,6 +498,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if mf == "f32":
             want16 = False
 
+    if dropout is not None and float(dropout[0]) > 0.0:
+        if not (use_mega and want16 and keep and not d_vd and act in ("relu", "leakyrelu", "prelu")):
+            raise RouteUnavailable("dropout inside the kernels: training forward of the tile kernel, ReLU-class activation, no W_d")
+        a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
     st = ForwardState()
     st.fused = use_fused
     st.route = "mega" if use_mega else ("fused16" if use_fused16 else ("fused" if use_fused else "general"))

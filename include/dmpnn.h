@@ -294,6 +294,15 @@ typedef struct dmpnn_fwd_args {
      * Mv are the fp32 tensors dmpnn_backward reads (n_hslots = n_mslots = depth - 1, rows in the plan's CSR-row order):
      * every step writes its H^(t) and the fp32 copy of its message beside the split rows the next step consumes. */
     void* msplit; size_t msplit_bytes;
+    /* ACTIVE DROPOUT inside the kernels (base.py:135-141 `self.dropout(H_t)` after every update, :182 after the finalize's tau):
+     * with DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (a training forward of the tile kernel), a ReLU-class activation
+     * (none / relu / leakyrelu / prelu) and no W_d: dropout_p in (0, 1) zeroes every element of H^(t), t >= 1, and of the
+     * finalize output with probability p and scales the rest by 1 / (1 - p).  The mask is a counter-based hash of
+     * (dropout_seed, site, row, column) — site = t - 1 for the update steps, depth - 1 for the finalize; row = the plan's
+     * row (edge sites) / the atom (finalize) — restated in oracle/dropout_hash.py; dmpnn_backward regenerates nothing: the
+     * kept tensors are post-dropout, and for a ReLU-class activation their sign carries the mask.  0: no dropout.
+     * Any other route / activation with dropout_p != 0: DMPNN_EINVAL (the caller runs its own dropout between the row kernels). */
+    float dropout_p; uint64_t dropout_seed;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 /* DMPNN_F_FUSED | DMPNN_F_SPLIT16 (without DMPNN_F_MEGA): the per-step fused route on the f16 matrix pipe — inference
@@ -494,6 +503,10 @@ typedef struct dmpnn_step_args {
     float lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrt_bias_corr2, grad_scale; const float* dev_scalars;
 } dmpnn_step_args;
 int dmpnn_train_step(const dmpnn_step_args* a, void* stream);
+
+/* The dropout mask of dmpnn_fwd_args.dropout_p as a HOST function (tests pin oracle/dropout_hash.py on it): 1 when element
+ * (site, row, col) is kept under `seed` and `p`. */
+int dmpnn_dropout_keep(uint64_t seed, int32_t site, int64_t row, int64_t col, float p);
 
 int dmpnn_version(void);
 /* Debug aid: a device buffer of 32 int64 that workgroup 0 of the whole-forward tile kernel fills with

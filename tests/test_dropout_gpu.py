@@ -211,3 +211,83 @@ def test_dropout_training_gradients_flow_and_eval_is_deterministic(gpu_device):
     mp.eval()
     with torch.no_grad():
         assert torch.equal(mp(bmg), mp(bmg))
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: dropout INSIDE the tile kernels (dmpnn_fwd_args.dropout_p) — the mask is a counter-based hash, restated in oracle/
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_mols,kw,p", [(64, dict(), 0.25), (96, dict(d_h=128, depth=4, activation="leakyrelu", bias=True), 0.4),
+                                         (512, dict(), 0.1), (2048, dict(), 0.3)])
+def test_fused_dropout_on_the_tile_kernels_given_its_masks(n_mols, kw, p, gpu_device):
+    """``.train()`` with p > 0 on the tile route: ONE forward launch and ONE backward tile launch carry the dropout.  The masks are
+    the oracle's restatement of the kernels' hash for the seed the forward drew; the executed reference with those masks replayed
+    gives the output and every gradient."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+    from oracle import dropout_hash as dh
+
+    cpu_bmg = synth.random_batch(n_mols, "qm9", seed=33)
+    torch.manual_seed(4)
+    mp = BondMessagePassing(dropout=p, **kw)
+    state = {k: v.clone() for k, v in mp.state_dict().items()}
+    G = torch.randn(cpu_bmg.V.shape[0], mp.output_dim, generator=torch.Generator().manual_seed(6))
+    mp = mp.to(gpu_device).train()
+    bmg = synth.random_batch(n_mols, "qm9", seed=33)
+    bmg.to(gpu_device)
+    for _ in range(2):   # (the module's first batches are validated; the steady path must do the same)
+        mp.zero_grad()
+        torch.manual_seed(1234)
+        out = mp(bmg)
+        st = out.grad_fn.st
+        assert st.route == "mega16", st.route
+        seed, p_used = int(st.args.dropout_seed), float(st.args.dropout_p)
+        assert abs(p_used - p) < 1e-7 and seed > 0
+        (out * G.to(gpu_device)).sum().backward()
+    torch.manual_seed(1234)
+    again = mp(bmg)
+    assert torch.equal(again.detach(), out.detach())                     # torch.manual_seed fixes the masks
+    assert not torch.equal(mp(bmg).detach(), out.detach())               # ... and the next forward draws new ones
+    inv = st.plan.inv32.long().cpu().numpy()                             # edge id -> plan row (the hash is keyed on plan rows)
+    d_h, nE, nV = mp.W_h.weight.shape[0], cpu_bmg.E.shape[0], cpu_bmg.V.shape[0]
+    scale = 1.0 / (1.0 - p)
+    masks = [torch.from_numpy(dh.keep_mask(seed, t, nE, d_h, p, rows=inv).astype(np.float32) * np.float32(scale)) for t in range(mp.depth - 1)]
+    masks.append(torch.from_numpy(dh.keep_mask(seed, mp.depth - 1, nV, d_h, p).astype(np.float32) * np.float32(scale)))
+    # what the kernel zeroed is what the hash says (the output's zero pattern at kept-and-active entries aside)
+    fin = masks[-1] > 0
+    assert bool((out.detach().cpu()[~fin] == 0).all())
+    keep_frac = float(fin.float().mean())
+    assert abs(keep_frac - (1 - p)) <= 5 * np.sqrt(p * (1 - p) / fin.numel()) + 1e-4
+    ref = _reference_block(dict(dropout=p, **kw), state)
+    if ref is not None:
+        ref.train()
+        ref.dropout = ReplayDropout(p, masks)
+        _, BMG, _ = ref_shim.load_reference()
+        ref_out = ref(BMG(synth.random_molgraphs(n_mols, "qm9", seed=33)))
+        named_ref = dict(ref.named_parameters())
+    else:
+        ref = BondMessagePassing(dropout=p, **kw)
+        ref.load_state_dict(state)
+        ref.train()
+        ref_out = _restated_forward(cpu_bmg, ref, ReplayDropout(p, masks))
+        named_ref = dict(ref.named_parameters())
+    (ref_out * G).sum().backward()
+    assert parity_err(out.detach().cpu().numpy(), ref_out.detach().numpy()) <= TOL
+    for k, prm in mp.named_parameters():
+        err = parity_err(prm.grad.cpu().numpy(), named_ref[k].grad.numpy())
+        assert err <= 2e-5, f"{k}: {err:.3e}"
+
+
+def test_fused_dropout_falls_back_where_the_tile_kernel_does_not_apply(gpu_device):
+    """Molecules beyond the tile, a smooth activation, a V_d branch: the block's own nn.Dropout between the row kernels, as before."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    for kind, kw in (("zinc", dict(d_h=64)), ("qm9", dict(d_h=64, activation="tanh"))):
+        bmg = synth.random_batch(24, kind, seed=1)
+        bmg.to(gpu_device)
+        mp = BondMessagePassing(dropout=0.2, **kw).to(gpu_device).train()
+        for _ in range(3):
+            out = mp(bmg)
+            assert not hasattr(out.grad_fn, "st") or out.grad_fn.st.args.dropout_p == 0.0
+            out.sum().backward()
+            assert all(torch.isfinite(p.grad).all() for p in mp.parameters())

@@ -258,3 +258,34 @@ def test_forward_route_is_one_shape_rule():
     assert route(qm9, cap=1, plan=2) == -1 and route(qm9, keep=1, plan=2) == -1 and route(qm9, arith=1, plan=2) == -1
     assert route(qm9, keep=1, plan=1) == -1 and route(args(4636, 9120, d_e=13), plan=1) == -1
     assert lib.dmpnn_forward_route(None, 0, 2, 0, 0) == -1 and route(qm9, cap=-1) == -1
+
+
+def test_dropout_hash_restatement_is_the_library_s_and_behaves_like_bernoulli():
+    """oracle/dropout_hash.py == dmpnn_dropout_keep (the host twin of the device hash), element for element; keep fraction 1 - p;
+    sites, seeds and neighbouring elements are uncorrelated (what nn.Dropout's Bernoulli mask guarantees, base.py:85)."""
+    import numpy as np
+
+    from chemprop_amd import _lib
+    from oracle import dropout_hash as dh
+
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for seed, site, p in ((1, 0, 0.25), (0x1234_5678_9ABC_DEF0, 3, 0.5), (2 ** 62 - 1, 1, 0.1), (77, 2, 0.9)):
+        rows = rng.integers(0, 2 ** 31 - 1, size=40)
+        cols = rng.integers(0, 1024, size=24)
+        want = dh.drop_hash(seed, site, rows, cols) >= np.uint32(dh.threshold(p))
+        got = np.array([[lib.dmpnn_dropout_keep(seed, site, int(r), int(c), p) for c in cols] for r in rows], dtype=bool)
+        assert np.array_equal(want, got), (seed, site, p)
+    assert lib.dmpnn_dropout_keep(5, 0, 1, 1, 0.0) == 1            # p = 0: everything is kept
+    for p in (0.1, 0.25, 0.5):
+        m0 = dh.keep_mask(42, 0, 4096, 300, p)
+        m1 = dh.keep_mask(42, 1, 4096, 300, p)          # another site
+        m2 = dh.keep_mask(43, 0, 4096, 300, p)          # another seed
+        n = m0.size
+        tol = 5 * np.sqrt(p * (1 - p) / n)
+        for m in (m0, m1, m2):
+            assert abs(m.mean() - (1 - p)) <= tol
+        for a, b in ((m0, m1), (m0, m2), (m0[:, :-1], m0[:, 1:]), (m0[:-1], m0[1:])):
+            assert abs((a & b).mean() - (1 - p) ** 2) <= 6 / np.sqrt(a.size) + 1e-3      # independent: P(both kept) = (1 - p)^2
+        assert abs(m0.mean(axis=0).std() - np.sqrt(p * (1 - p) / 4096)) <= 0.3 * np.sqrt(p * (1 - p) / 4096)   # columns look alike
+    assert np.array_equal(dh.keep_mask(9, 0, 50, 64, 0.3), dh.keep_mask(9, 0, 50, 64, 0.3))      # a function of its arguments
