@@ -48,10 +48,11 @@ def mp_forward(mp, plan: engine.GraphPlan, V: Tensor, E: Tensor, V_d: Optional[T
                     "(the reference never asks for it: features are data)")
     p = _params(mp)
     has_vd = mp.W_d is not None and V_d is not None
-    if drop_active and grad and act in ("relu", "leakyrelu") and not has_vd and max_level >= 2:
+    if drop_active and grad and act in ("relu", "leakyrelu") and not has_vd and max_level >= 2 and type(mp.dropout) is torch.nn.Dropout:
         # ACTIVE dropout inside the tile kernels (round 3): the mask is a counter-based hash of (seed, site, row, column), the seed
         # one draw from torch's CPU generator (so torch.manual_seed fixes the run); a batch that takes another route falls
-        # through to the rows route below, where the block's own nn.Dropout runs between the kernels
+        # through to the rows route below, where the block's own nn.Dropout runs between the kernels (as does any module that is not
+        # exactly nn.Dropout: a subclass has its own semantics)
         from .backward import FusedMP
 
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
