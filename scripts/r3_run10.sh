@@ -20,14 +20,14 @@ for p, act in ((0.0, "relu"), (0.2, "relu"), (0.2, "tanh")):
     s = ddp.GradSync(list(m.parameters()), modules=[m]); o = FlatAdam(s, lr=1e-4)
     def step():
         with ddp.backward_on_calling_thread():
-            out = m(b); out.backward(G)
+            out = m(b); r = out.grad_fn.st.route if hasattr(out.grad_fn, "st") else "rows"; out.backward(G)
         s.allreduce(); o.step()
-        return out
+        return r
     for _ in range(10): out = step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(100): step()
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    route = out.grad_fn.st.route if hasattr(out.grad_fn, "st") else "rows"
+    route = out
     print(f"train step p={p} act={act}: {(t1 - t0) * 1e4:.1f} us  route={route}")
 PY
 python /tmp/drop_time.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT/summary.txt
