@@ -327,6 +327,40 @@ def main():
         except Exception as e:
             out["model_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- the block's training step with ACTIVE dropout (CLI --dropout; hpopt searches it): inside the tile kernels (hash mask,
+    # round 3) against the rows route (the block's own nn.Dropout between row kernels chained from Python: what every round before
+    # did, and what a dropout module that is not exactly nn.Dropout still gets) ----
+    if not train and world == 1 and args.hidden == 300 and not args.no_large_batches:
+        try:
+            from chemprop_amd import distributed as ddp
+            from chemprop_amd.optim import FlatAdam
+
+            class _RowsDropout(torch.nn.Dropout):  # (a subclass keeps its own semantics: the engine leaves it to torch)
+                pass
+
+            res = {}
+            Gd = torch.randn(nV, args.hidden, device=dev)
+            for tag, drop_cls in (("fused_us", None), ("rows_route_us", _RowsDropout)):
+                torch.manual_seed(0)
+                md = BondMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth, dropout=0.2).to(dev).train()
+                if drop_cls is not None:
+                    md.dropout = drop_cls(0.2)
+                sd = ddp.GradSync(list(md.parameters()), modules=[md])
+                od = FlatAdam(sd, lr=1e-4)
+
+                def dstep():
+                    with ddp.backward_on_calling_thread():
+                        md(bmg).backward(Gd)
+                    sd.allreduce()
+                    od.step()
+                run_steps(dstep, 10)
+                res[tag] = round(timed_groups(dstep, args.steps, args.groups)[0] / args.steps * 1e6, 1)
+                del md, sd, od
+            res["p"] = 0.2
+            out["train_step_dropout"] = res
+        except Exception as e:
+            out["train_step_dropout"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     if rank == 0:
         # ---- roofline of the dominant kernel, live HIP-event timing on the launch stream ----
         h = args.hidden
