@@ -308,6 +308,12 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         DMPNN_CHECK_ARG(fused || (a->Hs && a->n_hslots >= 1), "forward: missing Hs workspace");
     }
 
+    if (a->flags & DMPNN_F_ATOM) {
+        DMPNN_CHECK_ARG((a->flags & DMPNN_F_FUSED) && (a->flags & DMPNN_F_MEGA) && (a->flags & DMPNN_F_SPLIT16) && !(a->flags & DMPNN_F_KEEP) &&
+                        !has_vd && de >= 1 && de <= 16 && a->dropout_p == 0.f,
+                        "forward: DMPNN_F_ATOM (atom messages) runs on the whole-forward tile kernel only (DMPNN_F_FUSED | DMPNN_F_MEGA | "
+                        "DMPNN_F_SPLIT16, inference, 1 <= d_e <= 16, no W_d) — chain the row kernels otherwise");
+    }
     if (a->dropout_p != 0.f) {
         DMPNN_CHECK_ARG(a->dropout_p > 0.f && a->dropout_p < 1.f, "forward: dropout_p must lie in [0, 1)");
         const bool tile_train = (a->flags & DMPNN_F_MEGA) && (a->flags & DMPNN_F_SPLIT16) && (a->flags & DMPNN_F_KEEP);

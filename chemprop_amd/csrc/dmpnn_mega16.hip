@@ -23,13 +23,14 @@ thread_local long long* g_debug_stamps = nullptr;
 namespace {
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 struct WsLayout {
-    size_t wi, wh, wom, wov, sc_i, sc_h, sc_o, total;
+    size_t wi, wh, wom, wov, sc_i, sc_h, sc_o, whe, sc_e, total;
     int nc_i, nc_h, nc_v;
 };
 WsLayout ws_layout(const dmpnn_fwd_args& a) {
     WsLayout L;
     const size_t N = (size_t)a.d_h;
-    L.nc_i = (int)((a.d_v + a.d_e + 31) / 32); L.nc_h = (int)((a.d_h + 31) / 32); L.nc_v = (int)((a.d_v + 31) / 32);
+    const bool atom = (a.flags & DMPNN_F_ATOM) != 0;  // atom messages: W_i is [N, d_v]; W_h[:, N:N + d_e] gets a block of its own (one chunk)
+    L.nc_i = (int)((a.d_v + (atom ? 0 : a.d_e) + 31) / 32); L.nc_h = (int)((a.d_h + 31) / 32); L.nc_v = (int)((a.d_v + 31) / 32);
     size_t o = 0;
     const size_t NT = (N + 15) / 16;  // column tiles: the packed layout is [tile][chunk][hi|lo][64 lanes][16 B]
     L.wi = o; o += al256(NT * L.nc_i * 2048);
@@ -39,6 +40,8 @@ WsLayout ws_layout(const dmpnn_fwd_args& a) {
     L.sc_i = o; o += al256(N * 4);
     L.sc_h = o; o += al256(N * 4);
     L.sc_o = o; o += al256(N * 4);
+    L.whe = o; o += atom ? al256(NT * 1 * 2048) : 0;
+    L.sc_e = o; o += atom ? al256(N * 4) : 0;
     L.total = o;
     return L;
 }
@@ -66,8 +69,10 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     mega16::SplitArgs sp;
     memset(&sp, 0, sizeof(sp));
     sp.N = N; sp.n_jobs = 4;
-    sp.job[0] = mega16::SplitJob{a.W_i, dv + de, 0, dv + de, 0, dv + de, ws + W.wi, W.nc_i, reinterpret_cast<float*>(ws + W.sc_i)};
-    sp.job[1] = mega16::SplitJob{a.W_h, N, 0, N, 0, N, ws + W.wh, W.nc_h, reinterpret_cast<float*>(ws + W.sc_h)};
+    const bool atom = (a.flags & DMPNN_F_ATOM) != 0;
+    const int ki = atom ? dv : dv + de, ldwh = atom ? N + de : N;   // (atom messages: W_i [N, d_v], W_h [N, N + d_e])
+    sp.job[0] = mega16::SplitJob{a.W_i, ki, 0, ki, 0, ki, ws + W.wi, W.nc_i, reinterpret_cast<float*>(ws + W.sc_i)};
+    sp.job[1] = mega16::SplitJob{a.W_h, ldwh, 0, N, 0, N, ws + W.wh, W.nc_h, reinterpret_cast<float*>(ws + W.sc_h)};
     sp.job[2] = mega16::SplitJob{a.W_o, dv + N, dv, N, 0, dv + N, ws + W.wom, W.nc_h, reinterpret_cast<float*>(ws + W.sc_o)};
     sp.job[3] = mega16::SplitJob{a.W_o, dv + N, 0, dv, 0, dv + N, ws + W.wov, W.nc_v, nullptr};
     if ((a.flags & DMPNN_F_KEEP) && a.wsplit_bytes >= W.total + mega16_bwd_wsplit_bytes(N)) {
@@ -78,6 +83,10 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
         sp.job[4] = mega16::SplitJob{a.W_o + dv, dv + N, 0, N, 0, N, wb, (int)nch, reinterpret_cast<float*>(wb + al256(NT * nch * 2048)), 1};
         sp.job[5] = mega16::SplitJob{a.W_h, N, 0, N, 0, N, wb + one, (int)nch, reinterpret_cast<float*>(wb + one + al256(NT * nch * 2048)), 1};
         sp.n_jobs = 6;
+    }
+    if (atom) {  // (inference only: slots 4, 5 are free) the bond-feature block W_h[:, N:N + d_e], its own row scales
+        sp.job[sp.n_jobs] = mega16::SplitJob{a.W_h, ldwh, N, de, N, de, ws + W.whe, 1, reinterpret_cast<float*>(ws + W.sc_e)};
+        ++sp.n_jobs;
     }
     hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)(((N + 15) / 16) * 4 * sp.n_jobs)), dim3(256), 0, s, sp);  // jobs x whole column tiles, 4 waves per block
     DMPNN_CHECK_LAUNCH("k_split_weights");
@@ -91,7 +100,7 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     g.mtile_row = plan_i + L.mtile_row; g.mtile_atom = plan_i + L.mtile_atom; g.row_ptr = plan_i + L.row_ptr;
     g.srcp = plan_i + L.srcp; g.perm = plan_i + L.perm; g.revp = plan_i + L.revp;
     g.flags = plan_i + DMPNN_HDR_FLAGS; g.poison_mask = kPlanNoMega;
-    g.nV = (int)nV; g.nE = (int)nE; g.d_v = dv; g.d_e = de; g.h = N; g.depth = a.depth;
+    g.nV = (int)nV; g.nE = (int)nE; g.d_v = dv; g.d_e = (a.flags & DMPNN_F_ATOM) ? 0 : de; g.h = N; g.depth = a.depth;  // (atom: E is not a K1 operand)
     g.V = a.V; g.ldv = (int)a.ldv; g.E = a.E ? a.E : a.V; g.lde = (int)a.lde;
     g.v_bytes = (unsigned)(nV * a.ldv * 4); g.e_bytes = a.E ? (unsigned)(nE * a.lde * 4) : 0u;
     g.W_i = a.W_i; g.b_i = a.b_i; g.W_h = a.W_h; g.b_h = a.b_h; g.W_o = a.W_o; g.b_o = a.b_o;
@@ -104,6 +113,10 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     G.Wh = mega16::SplitW{ws + W.wh, reinterpret_cast<const float*>(ws + W.sc_h), W.nc_h};
     G.WoM = mega16::SplitW{ws + W.wom, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_h};
     G.WoV = mega16::SplitW{ws + W.wov, reinterpret_cast<const float*>(ws + W.sc_o), W.nc_v};
+    if (a.flags & DMPNN_F_ATOM) {
+        G.WhE = mega16::SplitW{ws + W.whe, reinterpret_cast<const float*>(ws + W.sc_e), 1};
+        G.atom_de = de;
+    }
     g.dbg = g_debug_stamps;
     if (a.dropout_p > 0.f && a.dropout_p < 1.f) {  // (validated by dmpnn_forward: training forward, ReLU-class activation, no W_d)
         g.drop_thr = drop_threshold(a.dropout_p); g.drop_scale = 1.f / (1.f - a.dropout_p);

@@ -51,6 +51,9 @@ struct SplitW {
 struct Mega16K {
     mega::MegaK m;           // same graph / feature / output description as the fp32 kernel
     SplitW Wi, Wh, WoM, WoV; // W_i [N, d_v + d_e], W_h [N, N], W_o[:, d_v:], W_o[:, :d_v]  (WoM and WoV share inv_scale)
+    // DMPNN_F_ATOM (atom messages, inference): W_i is [N, d_v], Wh holds W_h[:, :N] and WhE the bond-feature block W_h[:, N:N + d_e]
+    // (one chunk: d_e <= 32); atom_de = d_e (the kernel's own d_e is 0: E is not part of the K1 operand), 0 = the bond variant
+    SplitW WhE; int atom_de;
 };
 
 // exact power-of-two scale that puts `maxabs` at [2^13, 2^14); 1 for 0 / inf / nan
@@ -127,10 +130,14 @@ constexpr size_t tile_region_bytes() {
     constexpr size_t ts = 64 * WN * 4 + 16, tsg = 4 * 128 + 16;  // split A tile row | staging tile row (the larger one for d_h <= 64)
     return (size_t)kMegaBM * (ts > tsg ? ts : tsg);
 }
+constexpr int kAtomK = 16;  // atom variant: bond features per row it stages (d_e <= 16: the v2 featurizer has 14)
+constexpr size_t kAtomLds = (size_t)(kMegaBM + kMegaBA) * kAtomK * sizeof(float);  // E rows of the tile [48][16] | per-atom sums [32][16]: 5 KB
 template <int WN>
 constexpr size_t lds_bytes() {
     return tile_region_bytes<WN>() + (size_t)(3 * kMegaBM + kMegaBA + 24) * sizeof(int) + 10 * 64 * 16;
 }
+template <int WN>
+constexpr size_t lds_bytes_atom() { return lds_bytes<WN>() + kAtomLds; }
 
 // SA (simple activation): identity / ReLU / LeakyReLU / PReLU are a compare + select in line; tanh and ELU get their own
 // instantiation — a workgroup runs its code ONCE, cold: every KB of inlined transcendental code that the ReLU path has to
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         // a piece (molecule) larger than the matrix-pipe tile — the reference has no size limit (data/collate.py:48-56):
         // the generic fp32 path carries it, whatever its size (dmpnn_spill_impl.hpp)
         const mega::MegaK& gs = spill::fresh_kernargs<Mega16K>()->m;
-        if (KEEP && gs.drop_thr) {  // the generic path has no dropout: an oversize molecule of a dropout batch is LOUD (NaN), never unmasked
+        if ((KEEP && gs.drop_thr) || G.atom_de) {  // the generic path has neither dropout nor atom messages: such a molecule is LOUD (NaN), never wrong
             const float nanv = __int_as_float(0x7fc00000);
             for (int i = tid; i < na * N; i += kThreads) gs.out[(long long)(va + i / N) * gs.ldout + (i % N)] = nanv;
             return;
@@ -311,7 +318,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             const int row = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
             const bool in = row >= 0 && row < nrows && aor[row < 0 ? 0 : row] == a_t;
             // [r enters src r'] - [r = rev r']: 0/1 for a symmetric graph (the reverse edge enters src r'), -1/0/1 otherwise
-            const float cv = (in ? 1.f : 0.f) - ((row >= 0 && row == rv) ? 1.f : 0.f);
+            // (atom messages, mixins.py:25-30: the plain sum — no reverse-edge term)
+            const float cv = (in ? 1.f : 0.f) - ((row >= 0 && row == rv && !G.atom_de) ? 1.f : 0.f);
             v[sl] = (_Float16)cv;
         }
         cfrag[f * 64 + lane] = v;
@@ -685,6 +693,75 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         sA = segment_mfma(y, T_steps == 1, T_steps == 1 ? g.Mv : g.Ms, g.ldh);
     }
     stamp();  // 4: K1 epilogue + first message
+    if (G.atom_de) {
+        // (uniform) atom messages, mixins.py:25-30: M[r'] = sum_{r enters src r'} [H[r] || E[r]].  The bond-feature half does not change
+        // over the depth loop: x[r'] = W_h[:, N:] (sum E)[src r'] is formed ONCE per tile and joins the residual of every update
+        // (the first activation above saw the pure H0 = W_i V[src], base.py:200).
+        const int de = G.atom_de;
+        float* Et = reinterpret_cast<float*>(cfrag + 10 * 64);   // [BM][kAtomK] E rows of the tile
+        float* SE = Et + BM * kAtomK;                            // [BA][kAtomK] per-atom sums of the incoming rows' E
+        for (int i = tid; i < BM * kAtomK; i += kThreads) {
+            const int r = i / kAtomK, k = i - r * kAtomK;
+            float v = 0.f;
+            if (r < nrows && k < de) {
+                const long long e = lean ? (long long)(rs + r) : (long long)g.perm[rs + r];
+                v = g.E[e * g.lde + k];
+            }
+            Et[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < BA * kAtomK; i += kThreads) {      // increasing row order = the reference's sequential scatter order
+            const int a_ = i / kAtomK, k = i - a_ * kAtomK;
+            float sum = 0.f;
+            if (a_ < na && k < de)
+                for (int r = 0; r < nrows; ++r)
+                    if (aor[r] == a_) sum += Et[r * kAtomK + k];
+            SE[i] = sum;
+        }
+        __syncthreads();
+        launder();
+        // A fragments of ME[r'] = SE[src r'] (row rt 16 + li, k = lg 8 .. lg 8 + 7 of the one chunk) straight into registers
+        float xv[RT_E][8];
+        float mx = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT_E; ++rt) {
+            const int row = rt * 16 + li;
+            const int a_s = row < nrows ? (lean ? asrc[row] : aor[revl[row]]) : -1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = lg * 8 + j;
+                xv[rt][j] = (a_s >= 0 && k < kAtomK) ? SE[a_s * kAtomK + (k < kAtomK ? k : 0)] : 0.f;
+                mx = fmaxf(mx, fabsf(xv[rt][j]));
+            }
+        }
+        const float sE = tile_scale(mx);
+        h8 eh[RT_E], el[RT_E];
+#pragma unroll
+        for (int rt = 0; rt < RT_E; ++rt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = xv[rt][j] * sE;
+                const _Float16 hi = (_Float16)x;
+                eh[rt][j] = hi; el[rt][j] = (_Float16)(x - (float)hi);
+            }
+        unsigned offE[WN];
+        bfrag_offsets(G.WhE, offE);
+        h8 wh[WN], wl[WN];
+        load_bfrags(gemm::make_rsrc(G.WhE.p, (unsigned)(((N + 15) / 16) * G.WhE.nc * 2048)), offE, 0, wh, wl);
+        const ColConst ce = col_consts(G.WhE.inv_scale, nullptr);
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < RT_E; ++rt) {
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[rt], wh[ct], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[rt], wl[ct], z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(el[rt], wh[ct], z, 0, 0, 0);
+                const float isw = ce.isw[ct] / sE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h0[rt][ct][r] += z[r] * isw;
+            }
+    }
 
     // ================= K3 x (depth - 1): H = tau(H0 + W_h M) =================
     for (int step = 1; step < T_steps; ++step) {
@@ -756,11 +833,11 @@ int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
 #define DMPNN_DEFINE_MEGA16(WN, SA, KEEP)                                                                  \
     template <>                                                                                            \
     int launch_mega16<WN, SA, KEEP>(const Mega16K& g, int n_tiles, hipStream_t s) {                        \
-        constexpr size_t lds = lds_bytes<WN>();                                                      \
+        const size_t lds = g.atom_de ? lds_bytes_atom<WN>() : lds_bytes<WN>();                             \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN, SA, KEEP>),          \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_atom<WN>()); \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_mpnn_tile16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
                 return DMPNN_EHIP;                                                                         \

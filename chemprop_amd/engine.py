@@ -388,7 +388,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
             keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
             max_level: int = 2, mfma: Optional[str] = None, wcache: Optional[dict] = None,
-            launch: bool = True, form: int = 0, dropout: Optional[tuple] = None) -> tuple[Tensor, ForwardState]:
+            launch: bool = True, form: int = 0, dropout: Optional[tuple] = None, atom: bool = False) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -405,6 +405,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
     ``form``: ``DMPNN_F_H0_RESIDUAL`` / ``DMPNN_F_ROW_FINALIZE`` bits for the per-step fused route on the f16 pipe (its other
     form of the residual / of the finalize, include/dmpnn.h; what training and wide hidden layers use anyway).
+    ``atom=True``: ``AtomMessagePassing`` semantics (``DMPNN_F_ATOM``: ``W_i [d_h, d_v]``, ``W_h [d_h, d_h + d_e]``) — an inference
+    forward of the tile kernel; raises :class:`RouteUnavailable` when this batch takes another route.
     ``dropout = (p, seed)``: ACTIVE dropout inside the kernels (``dmpnn_fwd_args.dropout_p``) — a training forward (``keep``) of
     the tile kernel with a ReLU-class activation and no ``W_d``; raises :class:`RouteUnavailable` when this batch takes another
     route (the caller then runs its own ``nn.Dropout`` between the row kernels).
@@ -422,6 +424,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     if V.shape[0] != nV or E.shape[0] != nE:
         raise RuntimeError(f"forward: plan is for V={nV}, E={nE} but got V={V.shape[0]}, E={E.shape[0]}")
     d_v, d_e, d_h = int(V.shape[1]), int(E.shape[1]), int(W_h.shape[0])
+    if atom and (int(W_i.shape[1]) != d_v or int(W_h.shape[1]) != d_h + d_e):
+        raise RuntimeError("forward(atom): W_i must be [d_h, d_v] and W_h [d_h, d_h + d_e] (base.py:278-289)")
     d_vd = int(V_d.shape[1]) if (W_d is not None and V_d is not None) else 0
     ldh = (d_h + 3) // 4 * 4
     n_steps = max(depth - 1, 0)
@@ -498,6 +502,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if mf == "f32":
             want16 = False
 
+    if atom:
+        if not (use_mega and want16 and not keep and not d_vd and 1 <= d_e <= 16):
+            raise RouteUnavailable("atom messages inside the kernels: inference forward of the tile kernel, 1 <= d_e <= 16, no W_d")
+        a.flags |= _lib.F_ATOM
     if dropout is not None and float(dropout[0]) > 0.0:
         if not (use_mega and want16 and keep and not d_vd and act in ("relu", "leakyrelu", "prelu")):
             raise RouteUnavailable("dropout inside the kernels: training forward of the tile kernel, ReLU-class activation, no W_d")

@@ -544,13 +544,38 @@ def atom_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         if mp.W_d is None or V_d.dim() != 2 or V_d.shape[0] != n_atoms or V_d.shape[1] != d_vd:
             raise InvalidShapeError("V_d", V_d.shape, [n_atoms, d_vd if d_vd is not None else 0])
         has_vd = True
-    plan = engine.GraphPlan.from_bmg(bmg)
     n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch
 
         note_batch(bmg.batch, n_mols)
     V, E = bmg.V, bmg.E
+    # ---- round 3: the whole forward of a tile of molecules in ONE launch (DMPNN_F_ATOM of the tile kernel) — inference, built-in
+    # activation, molecules that fit a tile, d_e <= 16.  Everything else: the per-step kernels chained below. ----
+    act, slope, slope_t = classify_activation(mp.tau)
+    grad = torch.is_grad_enabled() and any(p.requires_grad for p in mp.parameters())
+    if (not grad and not has_vd and act != "custom" and not mp.undirected and not (mp.training and mp.dropout.p > 0)
+            and 1 <= int(E.shape[1]) <= 16 and int(E.shape[0]) > 0 and getattr(bmg, "oversize", None) is not True):
+        nV_, nE_ = int(V.shape[0]), int(E.shape[0])
+        loader_tiles = getattr(bmg, "tiles", None) is not None or (
+            getattr(bmg, "batch", None) is not None and not engine.small_plan_fits(nV_, nE_) and bool(_lib.load().dmpnn_tile_plan_any_size(nV_, nE_)))
+        light = "tiles" if (_light_plan_ok(mp) and _tile_plan_ok(mp, nV_, nE_, n_mols, loader_tiles)) else False
+        plan = engine.GraphPlan.from_bmg(bmg, light=light)
+        plan.oversize = getattr(bmg, "oversize", None)
+        if _route(mp, plan, n_mols, getattr(bmg, "batch", None)) >= 2:
+            try:
+                out, st = engine.forward(plan, V, E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, mp.W_i.bias, mp.W_h.bias,
+                                         depth=mp.depth, act=act, slope=slope, slope_t=slope_t, atom=True,
+                                         wcache=mp.__dict__.setdefault("_dmpnn_wcache", {}))
+                mp.__dict__["_dmpnn_route"] = st.route + "/atom"
+                return out
+            except engine.RouteUnavailable:
+                pass
+        if light:
+            plan = engine.GraphPlan.from_bmg(bmg)
+    else:
+        plan = engine.GraphPlan.from_bmg(bmg)
+    mp.__dict__["_dmpnn_route"] = "rows/atom"
     tau, drop = mp.tau, mp.dropout
     nE = plan.n_edges
     H0 = linear_fn(V, mp.W_i.weight, mp.W_i.bias, gather=plan.src32, n_rows=nE)

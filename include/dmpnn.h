@@ -80,6 +80,12 @@ enum dmpnn_flags {
                                      exactly split K1 operand (the default for d_h <= 320).  Implied by DMPNN_F_KEEP and for d_h > 320 */
     DMPNN_F_ROW_FINALIZE = 1u << 9, /* the same route: the finalize on the row kernel from an fp32 Mv, instead of on the step kernel
                                      over 48-atom tiles fed by split rows (the default from depth 2 on).  Implied by DMPNN_F_KEEP    */
+    DMPNN_F_ATOM = 1u << 10,      /* AtomMessagePassing (base.py:254-289, mixins.py:21-30) instead of the bond variant: W_i is [d_h, d_v]
+                                     (H0 = W_i V[src]), W_h is [d_h, d_h + d_e], the message is M[e] = (sum_{e': dst e' = src e} [H[e'] || E[e']])
+                                     — no reverse-edge term.  With DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16, inference (no
+                                     DMPNN_F_KEEP), d_e <= 32: the whole-forward tile kernel — the bond-feature half of the message
+                                     is constant over the depth loop, so W_h[:, d_h:] (sum E)[src] is formed once per tile and joins
+                                     the residual.  Any other combination: DMPNN_EINVAL (chain the row kernels)                      */
     DMPNN_F_STORE16 = 1u << 7     /* OPT-IN, NOT fp32-class.  With DMPNN_F_FUSED | DMPNN_F_SPLIT16 (the per-step fused route):
                                      the message tensor between the depth steps is stored as ONE f16 per element with a
                                      power-of-two row scale (2 bytes instead of the exact hi + lo pair of 4) and contracted

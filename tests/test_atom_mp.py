@@ -97,7 +97,16 @@ def test_forward_and_gradients_vs_executed_reference(atom_case, gpu_device):
         got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
         assert parity_err(got, ref) <= 2e-5, k
     with torch.no_grad():
-        assert torch.equal(mp(bmg, V_d), out.detach())  # deterministic; no_grad takes the same kernels
+        # inference takes the whole-forward tile kernel where it applies (round 3: DMPNN_F_ATOM) — another fp32-class arithmetic than
+        # the per-step chain above — else the same chain; deterministic either way
+        a, b = mp(bmg, V_d), mp(bmg, V_d)
+        assert torch.equal(a, b)
+        assert parity_err(a.cpu().numpy(), atom_case["out"]) <= TOL
+        route = mp.__dict__.get("_dmpnn_route")
+        cfg = atom_case.cfg
+        tile_ok = (not cfg["undirected"] and V_d is None and cfg["d_h"] % 4 == 0 and cfg["d_h"] <= 320 and atom_case["E"].shape[1] <= 16
+                   and atom_case["E"].shape[1] % 2 == 0 and atom_case["V"].shape[1] % 2 == 0 and atom_case["E"].shape[0] > 0)
+        assert route == ("mega16/atom" if tile_ok else "rows/atom"), (route, cfg)
 
 
 @pytest.mark.gpu
@@ -116,3 +125,34 @@ def test_full_size_vs_oracle(gpu_device):
     with torch.no_grad():
         out = mp(bmg)
     assert parity_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mols,kw", [(512, dict()), (4096, dict(activation="leakyrelu", bias=True)), (300, dict(d_h=128, depth=5, activation="elu")),
+                                        (64, dict(d_h=64, depth=1))])
+def test_atom_messages_on_the_tile_kernel(n_mols, kw, gpu_device):
+    """Inference of AtomMessagePassing as ONE launch per tile of molecules (DMPNN_F_ATOM): the incidence without the reverse-edge
+    term, the constant bond-feature half of the message folded into the residual once per tile.  Steady path (tile plan) included."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import AtomMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    bmg = synth.random_batch(n_mols, "qm9", seed=78)
+    torch.manual_seed(6)
+    mp = AtomMessagePassing(**kw).eval()
+    with torch.no_grad():
+        ref = ot.atom_forward(bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, ot.MPWeights.from_module(mp), depth=mp.depth,
+                              activation=kw.get("activation", "relu"))
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    with torch.no_grad():
+        for i in range(4):   # (two validated batches on the full plan, then the tile plan)
+            out = mp(bmg)
+            assert mp.__dict__.get("_dmpnn_route") == "mega16/atom", (i, mp.__dict__.get("_dmpnn_route"))
+            assert parity_err(out.cpu().numpy(), ref.numpy()) <= TOL, i
+    # a batch with a molecule beyond the tile keeps the per-step chain
+    big = synth.random_batch(8, "synth40", seed=1)
+    big.to(gpu_device)
+    with torch.no_grad():
+        o2 = mp(big)
+    assert torch.isfinite(o2).all() and mp.__dict__.get("_dmpnn_route") == "rows/atom"
