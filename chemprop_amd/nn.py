@@ -532,6 +532,12 @@ def atom_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     """``_MessagePassingBase.forward`` (base.py:196-212) with the atom mixin (mixins.py:21-30)."""
     from .backward import aggregate_fn, gather_src_fn, linear_fn
 
+    if V_d is None and not torch.is_grad_enabled():
+        r = mp.__dict__.get("_dmpnn_replay")   # the steady inference path of the tile kernel (the bond block's: the argument block carries DMPNN_F_ATOM)
+        if r is not None:
+            out = _replay_forward(mp, r, bmg)
+            if out is not None:
+                return out
     bmg = mp.graph_transform(bmg)
     engine._require_device(bmg.V, "bmg.V")
     if mp.W_i.weight.device != bmg.V.device:
@@ -568,6 +574,8 @@ def atom_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
                                          depth=mp.depth, act=act, slope=slope, slope_t=slope_t, atom=True,
                                          wcache=mp.__dict__.setdefault("_dmpnn_wcache", {}))
                 mp.__dict__["_dmpnn_route"] = st.route + "/atom"
+                if light == "tiles" and not torch.is_grad_enabled() and _lib.opt("DMPNN_REPLAY", "1") != "0":
+                    _make_replay(mp, plan, st)
                 return out
             except engine.RouteUnavailable:
                 pass
