@@ -658,6 +658,23 @@ def main():
                     del b2, m2
                 except Exception as e:
                     oc[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            try:  # f2: AtomMessagePassing inference at the headline shape (the tile kernel with DMPNN_F_ATOM) beside the bond block
+                from chemprop_amd.nn import AtomMessagePassing
+
+                torch.manual_seed(0)
+                am = AtomMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth).eval().to(dev)
+
+                def fa():
+                    with torch.no_grad():
+                        return am(bmg)
+                run_steps(fa, 6)
+                ta = time_events(fa, 50, torch)
+                oc[f"atom-{args.kind}-{args.mols} (AtomMessagePassing, inference)"] = {
+                    "directed_edges": nE, "us": round(ta * 1e3, 1), "M_edge_updates_per_s": round(updates / (ta * 1e3), 1),
+                    "route": am.__dict__.get("_dmpnn_route"), "bond_block_us": round(ms_per_step * 1e3, 1)}
+                del am
+            except Exception as e:
+                oc["atom"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             out["other_configs"] = oc
 
         # ---- CPU baseline: the EXECUTED reference (chemprop.nn.BondMessagePassing from oracle/_ref or /root/reference under the
