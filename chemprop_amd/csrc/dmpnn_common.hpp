@@ -130,6 +130,24 @@ inline unsigned drop_threshold(float p) {  // floor(p 2^32), p in (0, 1)
     return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
 }
 
+// ---- kernel arguments: one round trip -------------------------------------------------------
+// A kernel whose argument block spans several 64-byte lines reads them lazily — one scalar load next to each first use, each a
+// cold miss behind the branch before it (the block was written by the host a moment ago: the lines are in HBM, not in any cache).
+// Touching every line at entry turns that chain into ONE round trip; the later loads hit the scalar cache.  (The tile kernels
+// run one workgroup per CU at the headline size: nothing else hides that chain — profiles/r03_kernarg_warm.txt.)
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int L = (BYTES + 63) / 64;
+    static_assert(L <= 12, "argument block larger than the warm-up covers");
+    int d[12];
+#define DMPNN_WARM(i) if constexpr (L > i) asm volatile("s_load_dword %0, %1, %2" : "=s"(d[i]) : "s"(kp), "n"(i * 64));
+    DMPNN_WARM(0) DMPNN_WARM(1) DMPNN_WARM(2) DMPNN_WARM(3) DMPNN_WARM(4) DMPNN_WARM(5)
+    DMPNN_WARM(6) DMPNN_WARM(7) DMPNN_WARM(8) DMPNN_WARM(9) DMPNN_WARM(10) DMPNN_WARM(11)
+#undef DMPNN_WARM
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float apply_act(float z, int act, float slope) {
     switch (act) {

@@ -57,11 +57,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     unsigned char* T16 = lds;                                          // [BM][TS] split A operand
     int* revl = reinterpret_cast<int*>(lds + BM * TS);                 // [BM]
     int* aor = revl + BM;                                              // [BM] destination atom of a row
-    int* rp = aor + BM;                                                // [BA + 1]
-    int* asrc = rp + BA + 1;                                           // [BM] source atom of a row
-    unsigned* maxbits = reinterpret_cast<unsigned*>(asrc + BM);        // [0..3] rotating tile maxima
+    int* asrc = aor + BM;                                           // [BM] source atom of a row
+    int* rp = asrc + BM;                                                // [BA + 1]
+    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);        // [0..3] rotating tile maxima
     h8* cfrag = reinterpret_cast<h8*>(lds + BM * TS + (((3 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);  // [9][64]
 
+#if !defined(DMPNN_NO_KERNARG_WARM)
+    warm_kernargs<(int)sizeof(Mega16BwdK)>();
+#endif
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int li = lane & 15, lg = lane >> 4;
     auto launder = [&]() {
@@ -131,21 +134,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     //   k-step 0, lane group lg, slot s -> row lg*4+s (s<4) | 16+lg*4+(s-4);  k-step 1 -> 32+lg*4+s (s<4) | none.
     // fragments 0..2 (jt): gather,  B[k = atom][j = row r'] = [dst r' == atom]
     // fragments 3..8 (jt, ks): message backward,  B[k = row r][j = row r'] = [src r == dst r'] - [r == rev r']
+    // (a lane's k rows depend on (k-step, lg) only: their source atoms are read once; f16 bit patterns 1.0 = 0x3C00, -1.0 = 0xBC00)
+    int as_[12];
+    {
+        const int4 q0 = *reinterpret_cast<const int4*>(asrc + lg * 4), q1 = *reinterpret_cast<const int4*>(asrc + 16 + lg * 4),
+                   q2 = *reinterpret_cast<const int4*>(asrc + 32 + lg * 4);
+        const int qa[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) as_[i] = ((i >> 2) * 16 + lg * 4 + (i & 3)) < nrows ? qa[i] : -3;
+    }
     for (int f = wave; f < 9; f += 4) {
         const bool gat = f < 3;
         const int jt = gat ? f : (f - 3) >> 1, ks = gat ? 0 : (f - 3) & 1;
         const int j = jt * 16 + li;  // row r'
         const int a_t = j < nrows ? aor[j] : -2, rv = j < nrows ? revl[j] : -2;
-        h8 v;
+        unsigned hb[8];
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             const int k = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
-            float cv = 0.f;
-            if (gat) cv = (k >= 0 && k < na && k == a_t) ? 1.f : 0.f;
-            else if (k >= 0 && k < nrows && j < nrows) cv = (asrc[k] == a_t ? 1.f : 0.f) - (k == rv ? 1.f : 0.f);
-            v[sl] = (_Float16)cv;
+            const int sk = ks == 0 ? as_[sl] : (sl < 4 ? as_[8 + sl] : -3);
+            const bool in = gat ? (k < na && k == a_t) : sk == a_t, isrev = !gat && k == rv;
+            hb[sl] = in ? (isrev ? 0u : 0x3C00u) : (isrev ? 0xBC00u : 0u);
         }
-        cfrag[f * 64 + lane] = v;
+        const u32x4 pk = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+        cfrag[f * 64 + lane] = __builtin_bit_cast(h8, pk);
     }
     __syncthreads();
 

@@ -157,9 +157,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     float* T = reinterpret_cast<float*>(lds);               // [BM][LDC] fp32 tile of the row-major stores: overlays T16 / Ag
     int* revl = reinterpret_cast<int*>(lds + META_OFF);     // [BM]
     int* aor = revl + BM;                                   // [BM]
-    int* rp = aor + BM;                                     // [BA + 1]
-    int* asrc = rp + BA + 1;                                // [BM] tile-local source atom of a row (tile plan only)
-    unsigned* maxbits = reinterpret_cast<unsigned*>(asrc + BM);  // [0..3] tile maxima (float bits, rotating), [5] tile-not-closed flag
+    int* asrc = aor + BM;                                // [BM] tile-local source atom of a row (tile plan only)
+    int* rp = asrc + BM;                                     // [BA + 1]
+    unsigned* maxbits = reinterpret_cast<unsigned*>(rp + BA + 1);  // [0..3] tile maxima (float bits, rotating), [5] tile-not-closed flag
     // [10][64] incidence fragments of the segment MFMAs (see segment_mfma): 16-byte aligned behind the metadata
     h8* cfrag = reinterpret_cast<h8*>(lds + META_OFF + (((3 * BM + BA + 1 + 8) * 4 + 15) / 16) * 16);
 
@@ -172,6 +172,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4; kq = tid & 7;
     };
+#if !defined(DMPNN_NO_KERNARG_WARM)
+    warm_kernargs<(int)sizeof(Mega16K)>();
+#endif
     int n_stamp = 0;
     auto stamp = [&]() {
         if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0 && n_stamp < 32) g.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
@@ -287,20 +290,39 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             a_grp[j] = __builtin_amdgcn_raw_buffer_load_b64(rVg, gemm::join_off(ro1[j], k1o), 0, 0) |
                        __builtin_amdgcn_raw_buffer_load_b64(rEg, gemm::join_off(ro2[j], k2o), 0, 0);
     }
+#if defined(DMPNN_META_STAMPS)
+    stamp();  // m1: tile table + index loads issued, operand gather in flight
+#endif
     if (tid < BM) { revl[tid] = revl_v; asrc[tid] = asrc_v; if (lean) aor[tid] = aor_v; }
     if (tid <= BA) rp[tid] = rp_v;
     if (tid < 8) maxbits[tid] = 0u;
     __syncthreads();
+#if defined(DMPNN_META_STAMPS)
+    stamp();  // m2: index values arrived, LDS metadata written
+#endif
     if (row_bad) atomicOr(&maxbits[5], 1u);
     if (!lean && tid < na)
         for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
     __syncthreads();
+#if defined(DMPNN_META_STAMPS)
+    stamp();  // m3: atom-of-row table complete
+#endif
     // Incidence fragments (B operands of the segment MFMAs, constant over the depth loop).  The k index of
     // those MFMAs runs over the tile's rows in the order the C/D fragments of a contraction already hold
     // them: k-step 0, lane group lg, slot s -> row lg*4+s (s<4) | 16+lg*4+(s-4);  k-step 1 -> row 32+lg*4+s
     // (s<4) | none.  Fragments 0..5: message, C[r'][r] = 1 iff r enters the source atom of r' and r != rev(r')
     // (message_passing/base.py:144-146 with the reverse edge's cancelling term left out of the sum);
     // 6..9: aggregate, C[a][r] = 1 iff r enters atom a (base.py:208-211).
+    // A lane's eight k rows depend on (k-step, lg) only: their atoms are read once (three 16-byte LDS reads), a fragment is then
+    // one column lookup + eight integer compares, packed as f16 bit patterns (1.0 = 0x3C00, -1.0 = 0xBC00).
+    int ar[12];
+    {
+        const int4 q0 = *reinterpret_cast<const int4*>(aor + lg * 4), q1 = *reinterpret_cast<const int4*>(aor + 16 + lg * 4),
+                   q2 = *reinterpret_cast<const int4*>(aor + 32 + lg * 4);
+        const int qa[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ar[i] = ((i >> 2) * 16 + lg * 4 + (i & 3)) < nrows ? qa[i] : -2;  // (a row past the tile matches no atom)
+    }
     for (int f = wave; f < 10; f += 4) {
         const bool agg = f >= 6;
         const int ff = agg ? f - 6 : f, jt = ff >> 1, ks = ff & 1;
@@ -312,17 +334,18 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             rv = revl[j];
             a_t = lean ? asrc[j] : aor[rv];  // source atom of r' (CSR plan: the graph is symmetric, src r' = dst rev r')
         }
-        h8 v;
+        if (G.atom_de) rv = -1;  // atom messages, mixins.py:25-30: the plain sum — no reverse-edge term
+        unsigned hb[8];
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
-            const int row = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
-            const bool in = row >= 0 && row < nrows && aor[row < 0 ? 0 : row] == a_t;
+            const int row = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -2);
+            const int av = ks == 0 ? ar[sl] : (sl < 4 ? ar[8 + sl] : -2);
             // [r enters src r'] - [r = rev r']: 0/1 for a symmetric graph (the reverse edge enters src r'), -1/0/1 otherwise
-            // (atom messages, mixins.py:25-30: the plain sum — no reverse-edge term)
-            const float cv = (in ? 1.f : 0.f) - ((row >= 0 && row == rv && !G.atom_de) ? 1.f : 0.f);
-            v[sl] = (_Float16)cv;
+            const bool in = av == a_t, isrev = row == rv;
+            hb[sl] = in ? (isrev ? 0u : 0x3C00u) : (isrev ? 0xBC00u : 0u);
         }
-        cfrag[f * 64 + lane] = v;
+        const u32x4 pk = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
+        cfrag[f * 64 + lane] = __builtin_bit_cast(h8, pk);
     }
     __syncthreads();
 

@@ -21,7 +21,7 @@ with torch.no_grad():
     fw(); torch.cuda.synchronize()
     lib.dmpnn_debug_timestamps(None)
 st = buf.cpu().tolist()
-names = ["entry", "meta", "init A staged", "K1 contract", "K1 seg mfma", "K1 tile scale", "K1 split written"]
+names = ["entry"] + (["m1 loads issued", "m2 LDS metadata", "m3 atom table"] if os.environ.get("DMPNN_LIB", "").endswith("metastamps.so") else []) + ["meta", "init A staged", "K1 contract", "K1 seg mfma", "K1 tile scale", "K1 split written"]
 for u in (1, 2):
     names += [f"upd{u} contract", f"upd{u} unscale+tau", f"upd{u} seg mfma", f"upd{u} tile scale", f"upd{u} split written"]
 names += ["fin Mv part", "fin V staged", "fin V part", "out stored"]
