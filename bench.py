@@ -311,15 +311,33 @@ def main():
             def step_fused():
                 tr_b.step(bmg, y)
 
+            import copy
+            pair = [bmg, copy.copy(bmg)]   # two batch objects with their OWN index tensors: a plan belongs to its batch's tensors
+            pair[1].edge_index, pair[1].rev_edge_index, pair[1].batch = bmg.edge_index.clone(), bmg.rev_edge_index.clone(), bmg.batch.clone()
+            turn = [0]
+
+            def step_fused_prefetch():  # (a loader with a look-ahead batch: K0 of step n + 1 on a side stream beside step n)
+                cur, nxt = pair[turn[0] & 1], pair[(turn[0] + 1) & 1]
+                turn[0] += 1
+                tr_b.prefetch_plan(nxt)   # issued in front of step n: the side stream waits for step n - 1 only
+                tr_b.step(cur, y)
+
             run_steps(step_module, 10)
             t_mod = timed_groups(step_module, args.steps, args.groups)[0] / args.steps * 1e3
             run_steps(step_fused, 10)
             t_fus = timed_groups(step_fused, args.steps, args.groups)[0] / args.steps * 1e3
-            out["model_step"] = {"fused_ms_per_step": round(t_fus, 5), "module_path_ms_per_step": round(t_mod, 5),
+            run_steps(step_fused_prefetch, 10)
+            t_pre = timed_groups(step_fused_prefetch, args.steps, args.groups)[0] / args.steps * 1e3
+            m_b.message_passing.__dict__.pop("_dmpnn_prefetched", None)
+            out["model_step"] = {"fused_ms_per_step": round(t_fus, 5), "fused_prefetched_plan_ms_per_step": round(t_pre, 5),
+                                 "module_path_ms_per_step": round(t_mod, 5),
                                  "fused_M_edge_updates_per_s": round(updates / (t_fus * 1e-3) / 1e6, 2),
                                  "route": tr_b.last_route,
                                  "model": f"MPNN(BondMessagePassing(d_h={args.hidden}, depth={args.depth}), NormAggregation, BatchNorm1d, "
                                           "RegressionFFN(1 task, hidden 300), MSE) + Adam",
+                                 "plan": "fused_ms_per_step: K0 inside the step's C call, on the critical path (28 us); fused_prefetched_plan: one K0 "
+                                         "per step as well, issued for step n + 1 on a side stream during step n (FusedTrainer.prefetch_plan) — on "
+                                         "this runtime the cross-queue synchronisation costs what the hidden K0 saves (profiles/r03_side_stream_ab.txt)",
                                  "note": "fused: ONE C call (dmpnn_train_step) enqueues K0, the block's forward, aggregation, batch norm, the "
                                          "predictor, the loss, the backward pass of all of it and the Adam update; module path: the same block "
                                          "kernels through torch autograd with torch's batch norm / loss / Adam launches around them"}

@@ -44,7 +44,7 @@ int pick_g(const dmpnn_gemm_args& a) {
     return 1;
 }
 
-int pick_wn(int64_t N) {
+int pick_wn(int64_t N, int64_t M) {
     static const int cand[] = {5, 4, 2, 1};
     int best = 5;
     int64_t best_cost = INT64_MAX;
@@ -52,6 +52,14 @@ int pick_wn(int64_t N) {
         const int64_t cost = ((N + 64 * wn - 1) / (64 * wn)) * wn;
         if (cost < best_cost) { best_cost = cost; best = wn; }
     }
+    // A short operand (a predictor layer on 512 molecules: 32 row tiles) leaves most of the chip idle behind one column block per
+    // row tile, and each of those workgroups streams the WHOLE weight matrix through a latency-bound chunk loop.  The narrowest
+    // build with the same padded width gives every 64-column slice its own workgroup (same arithmetic per output element:
+    // row-tile scale, per-column weight scale, chunk order).
+    const int64_t row_tiles = (M + 15) / 16;
+    if (row_tiles * ((N + 64 * best - 1) / (64 * best)) <= 128)
+        for (int wn : {1, 2, 4})
+            if (wn < best && ((N + 64 * wn - 1) / (64 * wn)) * wn == best_cost && row_tiles * ((N + 64 * wn - 1) / (64 * wn)) <= 512) return wn;
     return best;
 }
 
@@ -148,7 +156,7 @@ int launch_linear_ex(const dmpnn_gemm_args& a0, const GemmExtra& x, hipStream_t 
     }
 
     if (x.tile_row) { g.tile_row = x.tile_row; }
-    const int wn = pick_wn(a.N);
+    const int wn = pick_wn(a.N, x.tile_row ? (int64_t(1) << 40) : a.M);
     const int64_t ncb = (a.N + 64 * wn - 1) / (64 * wn);
     int rt = x.tile_row ? 3 : pick_rt(a.M, ncb);
     if (rt == 2 && G != 4) rt = 3;  // 32-row panels are only built for the 16-byte operand path

@@ -30,28 +30,54 @@ struct BnArgs {
     const float* gamma; const float* beta; float* run_mean; float* run_var;
     float* save_mean; float* save_invstd;      // [d] each (training: for the backward pass)
     int64_t B; int d; float eps, momentum; int training;
+    int64_t* n_tracked;                        // nn.BatchNorm1d.num_batches_tracked (training: += 1) or NULL
 };
+// column sums over the 64 row lanes: the four row lanes of a wave by lane shuffles, the sixteen waves through LDS
 __device__ __forceinline__ float bn_col_sum(float (*red)[kBnCols], int tx, int ty, float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     __syncthreads();            // (the previous use of `red` is over)
-    red[ty][tx] = v;
+    if ((ty & 3) == 0) red[ty >> 2][tx] = v;
     __syncthreads();
     float s = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < kBnLanes; ++i) s += red[i][tx];
+#pragma unroll
+    for (int i = 0; i < kBnLanes / 4; ++i) s += red[i][tx];
     return s;
 }
+// REG: B <= 8 x 64 rows — a thread's rows stay in registers (X is read once instead of three times)
+constexpr int kBnRegRows = 8;
+template <bool REG>
 __global__ __launch_bounds__(1024) void k_bn_fwd(BnArgs a) {
-    __shared__ float red[kBnLanes][kBnCols];
+    __shared__ float red[kBnLanes / 4][kBnCols];
     const int tx = threadIdx.x & (kBnCols - 1), ty = threadIdx.x / kBnCols;
     const int c = blockIdx.x * kBnCols + tx;
     const bool ok = c < a.d;
     float mean, invstd;
+    float xs[kBnRegRows];
+    if constexpr (REG) {
+#pragma unroll
+        for (int i = 0; i < kBnRegRows; ++i) {
+            const int64_t r = ty + (int64_t)kBnLanes * i;
+            xs[i] = (ok && r < a.B) ? a.X[r * a.ldx + c] : 0.f;
+        }
+    }
     if (a.training) {
+        if (a.n_tracked && blockIdx.x == 0 && threadIdx.x == 0) *a.n_tracked += 1;
         float s = 0.f;
-        if (ok) for (int64_t r = ty; r < a.B; r += kBnLanes) s += a.X[r * a.ldx + c];
+        if constexpr (REG) {
+#pragma unroll
+            for (int i = 0; i < kBnRegRows; ++i) s += xs[i];
+        } else if (ok) {
+            for (int64_t r = ty; r < a.B; r += kBnLanes) s += a.X[r * a.ldx + c];
+        }
         mean = bn_col_sum(red, tx, ty, s) / (float)a.B;
         float q = 0.f;
-        if (ok) for (int64_t r = ty; r < a.B; r += kBnLanes) { const float dlt = a.X[r * a.ldx + c] - mean; q += dlt * dlt; }
+        if constexpr (REG) {
+#pragma unroll
+            for (int i = 0; i < kBnRegRows; ++i) { const float dlt = xs[i] - mean; q += (ty + (int64_t)kBnLanes * i < a.B) ? dlt * dlt : 0.f; }
+        } else if (ok) {
+            for (int64_t r = ty; r < a.B; r += kBnLanes) { const float dlt = a.X[r * a.ldx + c] - mean; q += dlt * dlt; }
+        }
         const float ss = bn_col_sum(red, tx, ty, q);
         const float var = ss / (float)a.B;                       // biased: what normalises (nn.BatchNorm1d)
         invstd = 1.f / sqrtf(var + a.eps);
@@ -67,7 +93,15 @@ __global__ __launch_bounds__(1024) void k_bn_fwd(BnArgs a) {
     }
     if (ok) {
         const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
-        for (int64_t r = ty; r < a.B; r += kBnLanes) a.Y[r * a.ldy + c] = (a.X[r * a.ldx + c] - mean) * invstd * g + b;
+        if constexpr (REG) {
+#pragma unroll
+            for (int i = 0; i < kBnRegRows; ++i) {
+                const int64_t r = ty + (int64_t)kBnLanes * i;
+                if (r < a.B) a.Y[r * a.ldy + c] = (xs[i] - mean) * invstd * g + b;
+            }
+        } else {
+            for (int64_t r = ty; r < a.B; r += kBnLanes) a.Y[r * a.ldy + c] = (a.X[r * a.ldx + c] - mean) * invstd * g + b;
+        }
     }
 }
 
@@ -79,18 +113,32 @@ struct BnBwdArgs {
     float* g_gamma; float* g_beta;
     int64_t B; int d; float eps; int training;
 };
+template <bool REG>
 __global__ __launch_bounds__(1024) void k_bn_bwd(BnBwdArgs a) {
-    __shared__ float red[kBnLanes][kBnCols];
+    __shared__ float red[kBnLanes / 4][kBnCols];
     const int tx = threadIdx.x & (kBnCols - 1), ty = threadIdx.x / kBnCols;
     const int c = blockIdx.x * kBnCols + tx;
     const bool ok = c < a.d;
     const float mean = ok ? (a.training ? a.save_mean[c] : a.run_mean[c]) : 0.f;
     const float invstd = ok ? (a.training ? a.save_invstd[c] : 1.f / sqrtf(a.run_var[c] + a.eps)) : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int64_t r = ty; r < a.B; r += kBnLanes) {
-        const float g = a.gY[r * a.ldgy + c];
-        s1 += g;
-        s2 += g * ((a.X[r * a.ldx + c] - mean) * invstd);
+    float gs[kBnRegRows], xh[kBnRegRows];
+    if constexpr (REG) {
+#pragma unroll
+        for (int i = 0; i < kBnRegRows; ++i) {
+            const int64_t r = ty + (int64_t)kBnLanes * i;
+            const bool in = ok && r < a.B;
+            gs[i] = in ? a.gY[r * a.ldgy + c] : 0.f;
+            xh[i] = in ? (a.X[r * a.ldx + c] - mean) * invstd : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < kBnRegRows; ++i) { s1 += gs[i]; s2 += gs[i] * xh[i]; }
+    } else if (ok) {
+        for (int64_t r = ty; r < a.B; r += kBnLanes) {
+            const float g = a.gY[r * a.ldgy + c];
+            s1 += g;
+            s2 += g * ((a.X[r * a.ldx + c] - mean) * invstd);
+        }
     }
     s1 = bn_col_sum(red, tx, ty, s1);
     s2 = bn_col_sum(red, tx, ty, s2);
@@ -101,13 +149,21 @@ __global__ __launch_bounds__(1024) void k_bn_bwd(BnBwdArgs a) {
     }
     const float gam = a.gamma ? a.gamma[c] : 1.f;
     const float k = gam * invstd, invB = 1.f / (float)a.B;
-    for (int64_t r = ty; r < a.B; r += kBnLanes) {
-        const float g = a.gY[r * a.ldgy + c];
-        if (a.training) {
-            const float xh = (a.X[r * a.ldx + c] - mean) * invstd;
-            a.gX[r * a.ldgx + c] = k * (g - invB * s1 - xh * invB * s2);
-        } else {
-            a.gX[r * a.ldgx + c] = k * g;
+    if constexpr (REG) {
+#pragma unroll
+        for (int i = 0; i < kBnRegRows; ++i) {
+            const int64_t r = ty + (int64_t)kBnLanes * i;
+            if (r < a.B) a.gX[r * a.ldgx + c] = a.training ? k * (gs[i] - invB * s1 - xh[i] * invB * s2) : k * gs[i];
+        }
+    } else {
+        for (int64_t r = ty; r < a.B; r += kBnLanes) {
+            const float g = a.gY[r * a.ldgy + c];
+            if (a.training) {
+                const float xhat = (a.X[r * a.ldx + c] - mean) * invstd;
+                a.gX[r * a.ldgx + c] = k * (g - invB * s1 - xhat * invB * s2);
+            } else {
+                a.gX[r * a.ldgx + c] = k * g;
+            }
         }
     }
 }
@@ -223,6 +279,93 @@ __global__ __launch_bounds__(1024) void k_out_bwd(OutBwdArgs a) {
     }
 }
 
+// Criterion + the output layer's backward in ONE launch (training, <= kOutAllMaxRows molecules).  Every workgroup (16 columns of
+// the layer's input, like k_out_bwd) first forms dl/dP for ALL molecules in its own LDS from the predictions k_out_fwd wrote —
+// B t values, cheaper to redo per workgroup than a launch of its own — then runs its slice of the backward on them.  Workgroup
+// 0 writes the loss and the count.  Same arithmetic as the two kernels it replaces (k_loss's lane / wave order, k_out_bwd's
+// column sums).  (Recomputing the predictions per workgroup as well was tried: 89 us — 16 waves walking 512 rows each is a
+// latency chain, where k_out_fwd's one wave per row is 5 us.)
+constexpr int64_t kOutAllMaxRows = 1024;
+struct OutAllArgs {
+    OutBwdArgs o;                   // (o.gP unused: dl/dP lives in LDS)
+    LossArgs l;                     // (l.gP / l.ldg unused)
+};
+__global__ __launch_bounds__(1024) void k_out_all(OutAllArgs q) {
+    __shared__ float Ps[kOutAllMaxRows * kOutMaxTasks];
+    __shared__ float gPs[kOutAllMaxRows * kOutMaxTasks];
+    __shared__ float red[kBnLanes][kBnCols];
+    __shared__ float red2[2][16];
+    __shared__ float tot[2];
+    const OutBwdArgs& a = q.o;
+    const LossArgs& L = q.l;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = a.t;
+    for (int64_t i = threadIdx.x; i < a.B * t; i += 1024) Ps[i] = L.P[(i / t) * L.ldp + (i % t)];
+    __syncthreads();
+    // ---- criterion (k_loss's arithmetic) ----
+    const int64_t n = a.B * t;
+    float sl = 0.f, sm = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t r = i / t; const int j = (int)(i - r * t);
+        const float y = L.T[r * L.ldt + j];
+        if (!isfinite(y)) continue;
+        float p = Ps[i];
+        if ((L.lt && L.lt[i] && p < y) || (L.gt && L.gt[i] && p > y)) p = y;
+        const float d = p - y;
+        const float Lv = L.kind == DMPNN_LOSS_MAE ? fabsf(d) : d * d;
+        sl += Lv * (L.w ? L.w[r] : 1.f) * (L.tw ? L.tw[j] : 1.f);
+        sm += 1.f;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sl += __shfl_xor(sl, off); sm += __shfl_xor(sm, off); }
+    if (lane == 0) { red2[0][wave] = sl; red2[1][wave] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int i = 0; i < 16; ++i) { a0 += red2[0][i]; a1 += red2[1][i]; }
+        tot[0] = a0; tot[1] = a1;
+        if (blockIdx.x == 0) { L.out[0] = a0 / a1; L.out[1] = a1; }
+    }
+    __syncthreads();
+    const float inv = 1.f / tot[1];
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t r = i / t; const int j = (int)(i - r * t);
+        const float y = L.T[r * L.ldt + j];
+        float g = 0.f;
+        if (isfinite(y)) {
+            float p = Ps[i];
+            if ((L.lt && L.lt[i] && p < y) || (L.gt && L.gt[i] && p > y)) p = y;
+            const float d = p - y;
+            const float dl = L.kind == DMPNN_LOSS_MAE ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+            g = dl * (L.w ? L.w[r] : 1.f) * (L.tw ? L.tw[j] : 1.f) * inv;
+        }
+        gPs[i] = g;
+    }
+    __syncthreads();
+    // ---- the layer's backward on this workgroup's 16 columns (k_out_bwd's arithmetic) ----
+    const int tx = threadIdx.x & (kBnCols - 1), ty = threadIdx.x / kBnCols;
+    const int k = blockIdx.x * kBnCols + tx;
+    const bool ok = k < a.K;
+    float w[kOutMaxTasks], gw[kOutMaxTasks], gbs[kOutMaxTasks];
+#pragma unroll
+    for (int j = 0; j < kOutMaxTasks; ++j) { w[j] = (ok && j < t) ? a.W[(int64_t)j * a.K + k] : 0.f; gw[j] = 0.f; gbs[j] = 0.f; }
+    for (int64_t r = ty; r < a.B; r += kBnLanes) {
+        const float x = ok ? a.A[r * a.lda + k] : 0.f;
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < kOutMaxTasks; ++j)
+            if (j < t) { const float gp = gPs[r * t + j]; g += gp * w[j]; gw[j] += gp * x; gbs[j] += gp; }
+        if (ok && a.gA) a.gA[r * a.ldga + k] = g * act_grad_from_out(x, a.act, a.slope);
+    }
+    for (int j = 0; j < t; ++j) {
+        const float sw = bn_col_sum(red, tx, ty, gw[j]);
+        if (ok && ty == 0 && a.gW) a.gW[(int64_t)j * a.K + k] = sw;
+        if (a.gb && blockIdx.x == 0) {
+            const float sb = bn_col_sum(red, tx, ty, gbs[j]);
+            if (tx == 0 && ty == 0) a.gb[j] = sb;
+        }
+    }
+}
+
 // out[c][r] = in[r][c] for a weight matrix (<= a few hundred KB)
 __global__ void k_head_transpose(const float* __restrict__ in, int64_t ldi, float* __restrict__ out, int64_t ldo, int rows, int cols) {
     __shared__ float tile[32][33];
@@ -297,7 +440,20 @@ size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h) {
     return head_layout(*h).total;
 }
 
-int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream) {
+}  // extern "C"
+
+namespace {
+int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done);
+}  // namespace
+
+extern "C" {
+
+int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream) { return head_run(hp, Hv, ldhv, stream, false); }
+
+}  // extern "C"
+
+namespace {
+int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done) {
     DMPNN_CHECK_ARG(hp != nullptr, "head: null args");
     const dmpnn_head_args& h = *hp;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -324,21 +480,24 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
     const int t = (int)h.dims[Ln];
 
     // ---- forward ----
-    DMPNN_TRY(dmpnn_molagg_bounds(h.batch, nV, B, ws + L.bounds, dmpnn_molagg_ws_bytes(B), stream));
+    if (!bounds_done) DMPNN_TRY(dmpnn_molagg_bounds(h.batch, nV, B, ws + L.bounds, dmpnn_molagg_ws_bytes(B), stream));
     DMPNN_TRY(dmpnn_molagg_fwd(Hv, ldhv, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, Hm, d, stream));
     const float* Z = Hm;
     float* mean = reinterpret_cast<float*>(ws + L.mean);
     float* invstd = reinterpret_cast<float*>(ws + L.invstd);
     if (h.bn_weight) {
         BnArgs b{Hm, d, reinterpret_cast<float*>(ws + L.Z), d, h.bn_weight, h.bn_bias, h.bn_running_mean, h.bn_running_var, mean, invstd,
-                 B, (int)d, h.bn_eps, h.bn_momentum, h.bn_training};
-        hipLaunchKernelGGL(k_bn_fwd, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
+                 B, (int)d, h.bn_eps, h.bn_momentum, h.bn_training, h.bn_num_batches_tracked};
+        if (B <= kBnRegRows * kBnLanes) hipLaunchKernelGGL(k_bn_fwd<true>, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
+        else hipLaunchKernelGGL(k_bn_fwd<false>, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
         DMPNN_CHECK_LAUNCH("k_bn_fwd");
         Z = reinterpret_cast<float*>(ws + L.Z);
     }
     const float* A[DMPNN_MAX_FFN_LAYERS + 1];
     A[0] = Z;
     const bool small_out = h.dims[Ln] <= kOutMaxTasks && Ln >= 1;   // the output layer as dot products (k_out_fwd / k_out_bwd)
+    // training on a short batch: the criterion and the output layer's backward are ONE launch further down (k_out_all)
+    const bool out_all = small_out && want_grad && h.targets && B <= kOutAllMaxRows;
     for (int l = 0; l < Ln; ++l) {
         if (small_out && l == Ln - 1) {
             OutFwdArgs q{A[l], h.dims[l], h.W[l], h.b[l], h.preds, B, (int)h.dims[l], (int)h.dims[Ln]};
@@ -361,7 +520,7 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
     }
     if (!h.targets) return DMPNN_OK;
     float* gP = reinterpret_cast<float*>(ws + L.gP);
-    {
+    if (!out_all) {
         LossArgs q{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, want_grad ? gP : nullptr, t, h.loss_out, B, t, h.loss};
         DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
         hipLaunchKernelGGL(k_loss, dim3(1), dim3(1024), 0, s, q);
@@ -380,6 +539,15 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
             float* out = bufs[pp]; pp ^= 1;
             // (l == 0: no activation in front of the only layer — the derivative factor is 1)
             OutBwdArgs q{g_cur, A[l], K, h.W[l], out, K, h.gW[l], h.b[l] ? h.gb[l] : nullptr, B, (int)K, (int)N, l > 0 ? h.act : DMPNN_ACT_NONE, h.act_slope};
+            if (out_all) {
+                DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
+                OutAllArgs qa{q, LossArgs{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, nullptr, t, h.loss_out, B, t, h.loss}};
+                qa.o.gP = nullptr;
+                hipLaunchKernelGGL(k_out_all, dim3((unsigned)((K + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, qa);
+                DMPNN_CHECK_LAUNCH("k_out_all");
+                g_cur = out;
+                continue;
+            }
             hipLaunchKernelGGL(k_out_bwd, dim3((unsigned)((K + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, q);
             DMPNN_CHECK_LAUNCH("k_out_bwd");
             g_cur = out;
@@ -414,12 +582,19 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
     if (h.bn_weight) {
         BnBwdArgs b{gZ, d, Hm, d, gHm, d, h.bn_weight, mean, invstd, h.bn_running_mean, h.bn_running_var, h.g_bn_weight, h.g_bn_bias,
                     B, (int)d, h.bn_eps, h.bn_training};
-        hipLaunchKernelGGL(k_bn_bwd, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
+        if (B <= kBnRegRows * kBnLanes) hipLaunchKernelGGL(k_bn_bwd<true>, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
+        else hipLaunchKernelGGL(k_bn_bwd<false>, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
         DMPNN_CHECK_LAUNCH("k_bn_bwd");
         gZ = gHm;
     }
+    // (Running the hidden layers' weight-gradient products and the molecule bounds on a second stream of the library's own was
+    //  built and measured: each fork / join pair costs ~6 us of cross-queue synchronisation on this runtime — the step got 12 us
+    //  SLOWER, profiles/r03_side_stream_ab.txt.  One stream.)
     return dmpnn_molagg_bwd(gZ, d, h.batch, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, h.gHv, h.ldg, stream);
 }
+}  // namespace
+
+extern "C" {
 
 // K0 + forward (kept tensors) + the head above + backward + optimizer: one training step of models/model.py:148-161 with
 // torch.optim.Adam (model.py:208-231), every kernel enqueued by this one call.
@@ -437,7 +612,7 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
                                                a->plan_bytes, stream));
         }
         DMPNN_TRY(dmpnn_forward(&f, stream));
-        DMPNN_TRY(dmpnn_head(&a->head, f.out, f.ldout, stream));
+        DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, false));
     }
     if (stages & DMPNN_STEP_BACKWARD) DMPNN_TRY(dmpnn_backward(&a->bwd, stream));
     if ((stages & DMPNN_STEP_UPDATE) && a->n_params > 0)

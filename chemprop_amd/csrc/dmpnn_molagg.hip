@@ -39,6 +39,27 @@ __global__ void k_mol_bounds(const int64_t* __restrict__ batch, int64_t nV, int6
     if (bad) atomicOr(flag, bad);
 }
 
+// The same pass by ONE workgroup that zeroes its own tables first (no memset launch in front of it): a batch of up to 32 768 atoms.
+constexpr int64_t kBoundsOneMaxAtoms = 32768;
+__global__ __launch_bounds__(1024) void k_mol_bounds_one(const int64_t* __restrict__ batch, int64_t nV, int64_t n_mols, int* __restrict__ ws) {
+    for (int64_t i = threadIdx.x; i < 2 * n_mols + 4; i += 1024) ws[i] = 0;
+    __threadfence();   // (the zeroes are in memory before any thread of this workgroup writes a bound over them)
+    __syncthreads();
+    int* first = ws;
+    int* end = ws + n_mols;
+    int bad = 0;
+    for (int64_t v = threadIdx.x; v < nV; v += 1024) {
+        const int64_t b = batch[v];
+        const int64_t prev = v > 0 ? batch[v - 1] : -1;
+        const int64_t next = v + 1 < nV ? batch[v + 1] : n_mols;
+        if (b < 0 || b >= n_mols) { bad |= MOLAGG_RANGE; continue; }
+        if (b < prev) bad |= MOLAGG_UNSORTED;
+        if (b != prev) first[b] = (int)v;
+        if (b != next) end[b] = (int)(v + 1);
+    }
+    if (bad) atomicOr(ws + 2 * n_mols, bad);
+}
+
 struct MolAggArgs {
     const float* H; int64_t ldh;
     float* out; int64_t ldo;
@@ -126,6 +147,11 @@ int dmpnn_molagg_bounds(const int64_t* batch, int64_t n_atoms, int64_t n_mols, v
     DMPNN_CHECK_ARG(ws && ws_bytes >= dmpnn_molagg_ws_bytes(n_mols), "molagg_bounds: workspace missing or too small");
     DMPNN_CHECK_ARG(n_atoms == 0 || batch, "molagg_bounds: batch is NULL");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_atoms > 0 && n_atoms <= kBoundsOneMaxAtoms) {
+        hipLaunchKernelGGL(k_mol_bounds_one, dim3(1), dim3(1024), 0, s, batch, n_atoms, n_mols, static_cast<int*>(ws));
+        DMPNN_CHECK_LAUNCH("k_mol_bounds_one");
+        return DMPNN_OK;
+    }
     if (hipMemsetAsync(ws, 0, dmpnn_molagg_ws_bytes(n_mols), s) != hipSuccess) {
         set_error("molagg_bounds: hipMemsetAsync failed");
         return DMPNN_EHIP;

@@ -152,8 +152,8 @@ def prefetch_plan(mp, bmg) -> None:
     ``out.backward()`` with the batch the loader already holds for step n + 1, it runs beside the backward kernels of step n
     (the side stream first waits for what is queued on the current stream, so the index tensors are complete); the next
     ``mp(batch_{n+1})`` finds it (same index tensors), makes its stream wait for it and skips its own K0.  A prefetched plan
-    is used once; one that does not match the next forward's batch, or a forward that needs another kind of plan (inference on
-    the tile plan), is dropped.  The work is the same — it only leaves the critical path."""
+    is used once, by the batch it was built for; at most two are held (the oldest goes first), and a forward that needs another
+    kind of plan (inference on the tile plan) drops them.  The work is the same — it only leaves the critical path."""
     engine._require_device(bmg.V, "bmg.V")
     dev = bmg.V.device
     side = mp.__dict__.get("_dmpnn_side")
@@ -165,17 +165,31 @@ def prefetch_plan(mp, bmg) -> None:
         plan = engine.GraphPlan.from_bmg(bmg, light=False)
         done = torch.cuda.Event()
         done.record(side)
-    mp.__dict__["_dmpnn_prefetched"] = (_plan_key(bmg), plan, done)
+    # two slots: FusedTrainer issues the plan of batch n + 1 BEFORE step n consumes the plan of batch n (the side stream waits
+    # for what is queued on the current stream — issued in front of step n, that is step n - 1, not step n)
+    slots = mp.__dict__.setdefault("_dmpnn_prefetched", {})
+    slots.pop(_plan_key(bmg), None)
+    while len(slots) >= 2:
+        slots.pop(next(iter(slots)))
+    slots[_plan_key(bmg)] = (plan, done)
 
 
 def _take_prefetched(mp, bmg, light):
-    pf = mp.__dict__.pop("_dmpnn_prefetched", None)
-    if pf is None or light is not False or pf[0] != _plan_key(bmg):
+    slots = mp.__dict__.get("_dmpnn_prefetched")
+    if not slots:
         return None
-    cur = torch.cuda.current_stream(pf[1].device)
-    cur.wait_event(pf[2])
-    pf[1].buf.record_stream(cur)  # (allocated on the side stream's pool, consumed here)
-    return pf[1]
+    if light is not False:  # (a forward on another kind of plan: the prefetched full plans are not this forward's)
+        mp.__dict__.pop("_dmpnn_prefetched", None)
+        return None
+    pf = slots.pop(_plan_key(bmg), None)
+    if not slots:
+        mp.__dict__.pop("_dmpnn_prefetched", None)
+    if pf is None:
+        return None
+    cur = torch.cuda.current_stream(pf[0].device)
+    cur.wait_event(pf[1])
+    pf[0].buf.record_stream(cur)  # (allocated on the side stream's pool, consumed here)
+    return pf[0]
 
 
 _ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_VALIDATE", "DMPNN_STORE")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DMPNN_ABI_VERSION 8
+#define DMPNN_ABI_VERSION 9
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -486,6 +486,7 @@ typedef struct dmpnn_head_args {
     float* g_bn_weight; float* g_bn_bias;   /* out [d_h] or NULL                                                    */
     float* gHv; int64_t ldg;                /* out [n_atoms, ldg] dloss / dH_v; NULL: forward (and loss) only       */
     void* ws; size_t ws_bytes;              /* caller-owned scratch, >= dmpnn_head_ws_bytes()                       */
+    int64_t* bn_num_batches_tracked;        /* nn.BatchNorm1d's counter: += 1 on device when bn_training (NULL: not kept) — v9 */
 } dmpnn_head_args;
 size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h);
 int dmpnn_head(const dmpnn_head_args* h, const float* Hv, int64_t ldhv, void* stream);

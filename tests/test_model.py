@@ -179,11 +179,52 @@ def test_fused_step_matches_goldens(g, gpu_device):
 
 
 @pytest.mark.gpu
+def test_fused_step_with_prefetched_plan_is_the_same_step(gpu_device):
+    """K0 of step n + 1 on a side stream (FusedTrainer.prefetch_plan) changes WHEN the plan is built, not what the step computes:
+    the parameters after three steps are bit-identical to a trainer that plans inside each step; a plan prefetched for another
+    batch is dropped."""
+    from chemprop_amd import agg as cagg, synth
+    from chemprop_amd.model import MPNN, FusedTrainer, RegressionFFN
+    from chemprop_amd.nn import BondMessagePassing
+
+    batches = [synth.random_batch(96, "qm9", seed=70 + i) for i in range(3)]
+    for b in batches:
+        b.to(gpu_device)
+    ys = [torch.randn(96, 2, generator=torch.Generator().manual_seed(i)).to(gpu_device) for i in range(3)]
+
+    def run(prefetch):
+        torch.manual_seed(3)
+        m = MPNN(BondMessagePassing(d_h=64), cagg.MeanAggregation(), RegressionFFN(n_tasks=2, input_dim=64, hidden_dim=32),
+                 batch_norm=True).to(gpu_device).train()
+        tr = FusedTrainer(m, lr=1e-3)
+        losses = []
+        if prefetch == "next":
+            tr.prefetch_plan(batches[0])
+        for i in range(3):
+            if prefetch == "next" and i + 1 < 3:
+                tr.prefetch_plan(batches[i + 1])   # (in front of step i: beside it)
+            if prefetch == "wrong" and i > 0:
+                tr.prefetch_plan(batches[i - 1])   # (not the batch this step gets)
+            losses.append(tr.step(batches[i], ys[i]))
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), tr.opt.flat.detach().cpu().clone()
+
+    l0, p0 = run(None)
+    for mode in ("next", "wrong"):
+        l1, p1 = run(mode)
+        assert torch.equal(l0, l1), mode
+        assert torch.equal(p0, p1), mode
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_mols,kind,bn,agg,tasks,act", [(512, "qm9", True, "norm", 1, "elu"), (512, "qm9", False, "mean", 12, "tanh"),
                                                           # (40-atom molecules: the per-step routes; a smooth activation — at this size ONE
                                                           #  ReLU mask flip between two fp32-class arithmetics moves a gradient row by 1e-3,
                                                           #  DESIGN.md section 5 — the engine and the module path agree to 5e-8 either way)
-                                                          (128, "synth40", True, "sum", 2, "tanh")])
+                                                          (128, "synth40", True, "sum", 2, "tanh"),
+                                                          # (beyond the one-launch kernels of a short batch — k_out_all <= 1024 molecules,
+                                                          #  k_layer_bwd <= 2048: the row-split weight gradients and the MFMA contractions)
+                                                          (2304, "qm9", True, "mean", 2, "elu")])
 def test_fused_step_at_size_vs_restatement_and_module_path(n_mols, kind, bn, agg, tasks, act, gpu_device):
     """The CLI's default widths (d_h 300, hidden 300) at BASELINE's batch size: loss and every gradient of the fused step against
     (a) the restatement on the CPU, (b) autograd through the module path (the same kernels driven from Python), and — where the

@@ -984,7 +984,7 @@ def test_prefetched_plan_is_the_plan_of_the_next_forward(gpu_device):
     used once; a prefetched plan of another batch, or one an inference forward cannot use, is dropped."""
     from chemprop_amd import synth
     from chemprop_amd.engine import GraphPlan
-    from chemprop_amd.nn import BondMessagePassing
+    from chemprop_amd.nn import BondMessagePassing, _plan_key
 
     torch.manual_seed(11)
     mp = BondMessagePassing(bias=True).to(gpu_device).train()
@@ -1006,7 +1006,7 @@ def test_prefetched_plan_is_the_plan_of_the_next_forward(gpu_device):
             mp.prefetch_plan(batches[i])
             assert "_dmpnn_prefetched" in mp.__dict__
         out = mp(batches[i])
-        assert "_dmpnn_prefetched" not in mp.__dict__        # consumed (or dropped) by the forward
+        assert _plan_key(batches[i]) not in mp.__dict__.get("_dmpnn_prefetched", {})        # consumed by the forward
         st = out.grad_fn.st
         out.backward(G[i])
         return out.detach().clone(), [p.grad.clone() for p in mp.parameters()], st.plan
@@ -1022,7 +1022,8 @@ def test_prefetched_plan_is_the_plan_of_the_next_forward(gpu_device):
     o, g, p = grads(1, False)
     ref = GraphPlan.from_bmg(batches[1])
     torch.cuda.synchronize()
-    assert same_plan(p, ref) and "_dmpnn_prefetched" not in mp.__dict__
+    assert same_plan(p, ref) and list(mp.__dict__["_dmpnn_prefetched"]) == [_plan_key(batches[0])]   # (held for ITS batch: two slots at most)
+    mp.__dict__.pop("_dmpnn_prefetched")
     # the loop shape it is meant for: prefetch the next batch between forward and backward
     mp.zero_grad()
     out = mp(batches[0])
