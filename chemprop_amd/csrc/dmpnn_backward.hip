@@ -518,7 +518,7 @@ WgradPlan plan_wgrad(int64_t M, int N, int Kt) {
     p.rows_per_wg = (int)rows;
     p.ldk = (Kt + 3) / 4 * 4;
     p.slab_stride = (int64_t)N * p.ldk;
-    p.can16 = M >= 1024 && N % 2 == 0;
+    p.can16 = M >= 1024 && N % 2 == 0;  // (at 355 702 rows as well: the fp32-MFMA product there is 8.4 ms per step against 7.0, scripts/ab_configs.py)
     p.q = plan_wgrad16(M, N, Kt);
     p.split_floats = p.can16 ? align_up((wsplit16_bytes(M, N) + 3) / 4, 64) + align_up((wsplit16_bytes(M, Kt) + 3) / 4, 64) : 0;
     return p;
