@@ -134,8 +134,9 @@ class FusedTrainer:
     """``training_step`` + ``Adam.step`` of an :class:`MPNN` as one ``dmpnn_train_step`` call per batch.
 
     Takes what the kernels implement and refuses the rest loudly (those models train through the module path): a
-    :class:`~chemprop_amd.nn.BondMessagePassing` block with a built-in activation, no ``V_d``, dropout 0, directed; sum / mean /
-    norm aggregation; optional ``nn.BatchNorm1d``; an MLP predictor with a built-in activation and dropout 0; MSE / MAE.
+    :class:`~chemprop_amd.nn.BondMessagePassing` block with a built-in activation, no ``V_d``, directed, dropout 0 or — with a
+    ReLU-class activation — ``nn.Dropout`` inside the tile kernels (hash mask, one seed per step from torch's CPU generator); sum /
+    mean / norm aggregation; optional ``nn.BatchNorm1d``; an MLP predictor with a built-in activation and dropout 0; MSE / MAE.
     """
 
     def __init__(self, model: MPNN, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, group=None):
@@ -147,9 +148,13 @@ class FusedTrainer:
         if not bond:
             raise NotImplementedError("FusedTrainer: a BondMessagePassing block (W_i / W_h [d_h, d_h] / W_o)")
         act, slope, slope_t = classify_activation(mp.tau)
-        if act in ("custom", "prelu") or mp.dropout.p > 0 or mp.undirected or mp.W_d is not None:
-            raise NotImplementedError("FusedTrainer: built-in activation (not PReLU), dropout 0, directed, no V_d — other blocks train "
+        if act in ("custom", "prelu") or mp.undirected or mp.W_d is not None:
+            raise NotImplementedError("FusedTrainer: built-in activation (not PReLU), directed, no V_d — other blocks train "
                                       "through the module path (MPNN.loss + autograd)")
+        if mp.dropout.p > 0 and not (type(mp.dropout) is nn.Dropout and act in ("relu", "leakyrelu")):
+            # (active dropout lives inside the tile kernels for ReLU-class activations: dmpnn_fwd_args.dropout_p; a dropout module
+            #  that is not exactly nn.Dropout has its own semantics and stays on the module path)
+            raise NotImplementedError("FusedTrainer: dropout inside the block needs nn.Dropout and a ReLU / LeakyReLU activation")
         mode = getattr(agg, "mode", None)
         if mode not in MODES:
             raise NotImplementedError(f"FusedTrainer: sum / mean / norm aggregation (got {type(agg).__name__})")
@@ -248,9 +253,18 @@ class FusedTrainer:
 
         # ---- argument blocks of the block's forward / backward (workspace allocated, nothing enqueued) ----
         W = lambda lin, n: getattr(getattr(mp, lin), n)
-        out, st = engine.forward(plan, bmg.V, bmg.E, W("W_i", "weight"), W("W_h", "weight"), W("W_o", "weight"), W("W_o", "bias"),
-                                 W("W_i", "bias"), W("W_h", "bias"), depth=mp.depth, act=self.act, slope=self.slope, keep=True,
-                                 max_level=level, launch=False)
+        drop = None
+        if mp.dropout.p > 0 and self.model.training:
+            # one seed per step from torch's CPU generator (torch.manual_seed fixes the run), like the module path's fused dropout
+            drop = (float(mp.dropout.p), int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()))
+            self.last_dropout_seed = drop[1]
+        try:
+            out, st = engine.forward(plan, bmg.V, bmg.E, W("W_i", "weight"), W("W_h", "weight"), W("W_o", "weight"), W("W_o", "bias"),
+                                     W("W_i", "bias"), W("W_h", "bias"), depth=mp.depth, act=self.act, slope=self.slope, keep=True,
+                                     max_level=level, launch=False, dropout=drop)
+        except engine.RouteUnavailable as e:
+            raise NotImplementedError(f"FusedTrainer: this batch does not take the tile kernels ({e}); dropout on the other routes "
+                                      "runs through the module path (MPNN.loss + autograd)") from None
         self.last_route = st.route
         d_out = int(out.shape[1])
         gout = torch.empty(nV, d_out, dtype=torch.float32, device=dev)

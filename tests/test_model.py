@@ -291,6 +291,56 @@ def test_fused_step_at_size_vs_restatement_and_module_path(n_mols, kind, bn, agg
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_mols", [64, 512])
+def test_fused_step_with_block_dropout_equals_module_path_on_the_same_masks(n_mols, gpu_device):
+    """CLI ``--dropout`` on the block (base.py:139,182): the fused step draws ONE seed from torch's CPU generator like the module
+    path's fused dropout (autograd.py), so after the same ``torch.manual_seed`` both see the same hash masks — loss and every
+    gradient agree (the module path itself is checked against the executed reference given those masks: tests/test_dropout_gpu.py);
+    and the masks are live (the loss differs from the p = 0 step, the seed changes from step to step)."""
+    from chemprop_amd import agg as cagg, synth
+    from chemprop_amd.model import MPNN, FusedTrainer, RegressionFFN
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = synth.random_batch(n_mols, "qm9", seed=77)
+    bmg.to(gpu_device)
+    y = torch.randn(n_mols, 1, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+
+    def make(p):
+        torch.manual_seed(9)
+        return MPNN(BondMessagePassing(d_h=300, dropout=p), cagg.MeanAggregation(), RegressionFFN(n_tasks=1, input_dim=300), batch_norm=False).to(gpu_device).train()
+
+    m_mod = make(0.25)
+    torch.manual_seed(123)
+    loss_mod = m_mod.loss(bmg, y)
+    loss_mod.backward()
+    m_fus = make(0.25)
+    tr = FusedTrainer(m_fus, lr=1e-4)
+    torch.manual_seed(123)
+    out = tr.step(bmg, y)
+    torch.cuda.synchronize()
+    seed0 = tr.last_dropout_seed
+    assert abs(float(out[0]) - float(loss_mod)) <= 1e-5 * max(1.0, abs(float(loss_mod)))
+    names = [k for k, p in m_fus.named_parameters() if p.requires_grad]
+    mod = dict(m_mod.named_parameters())
+    for i, k in enumerate(names):
+        e = parity_err(tr.sync.views[i].detach().cpu().numpy(), mod[k].grad.detach().cpu().numpy())
+        assert e <= 2e-5, f"{k}: {e:.2e}"
+    # live masks: another seed, another loss; p = 0 gives yet another
+    out2 = tr.step(bmg, y)
+    torch.cuda.synchronize()
+    assert tr.last_dropout_seed != seed0
+    m0 = make(0.0)
+    l0 = FusedTrainer(m0, lr=1e-4).step(bmg, y)
+    torch.cuda.synchronize()
+    assert abs(float(l0[0]) - float(out[0])) > 1e-4 * max(1.0, abs(float(l0[0])))
+    # eval: dropout is the identity (nn.Dropout in eval mode), the trainer refuses nothing and the module predicts deterministically
+    m_fus.eval()
+    with torch.no_grad():
+        a, b = m_fus(bmg), m_fus(bmg)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_default_relu_model_at_size_fused_equals_module_path(gpu_device):
     """The CLI's default model (ReLU everywhere, d_h 300, norm aggregation, batch norm) at 512 molecules: loss to 1e-5 and gradients
     against the restatement to the kink-aware bar 2e-4 (a flipped ReLU mask of ONE predictor unit moves entries by ~2e-5, see above),
