@@ -47,6 +47,7 @@ F_WSPLIT_READY = 32
 F_LOADER_TILES = 64
 F_STORE16 = 128
 F_ATOM = 1024
+F_TILE_PLAN = 2048
 F_H0_RESIDUAL = 256
 F_ROW_FINALIZE = 512
 ROUTES = ("general", "general16", "fused", "fused16", "mega", "mega16")  # enum dmpnn_route

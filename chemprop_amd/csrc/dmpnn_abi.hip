@@ -256,7 +256,9 @@ int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int pl
     const bool undirected = (a->flags & DMPNN_F_UNDIRECTED) != 0;
     int level = undirected ? 0 : dmpnn_forward_can_fuse(a);
     if (level > max_level) level = max_level;
-    if (plan_kind == 2) return (level == 2 && arith == 0 && !keep) ? DMPNN_ROUTE_MEGA16 : -1;
+    // a tile plan: the whole-forward tile kernel on the f16 pipe or nothing — inference, and training without W_d (the kept tensors
+    // are then in the caller's edge order: the forward is given DMPNN_F_TILE_PLAN for dmpnn_backward to know)
+    if (plan_kind == 2) return (level == 2 && arith == 0 && !(keep && a->W_d)) ? DMPNN_ROUTE_MEGA16 : -1;
     if (plan_kind == 1 && keep) return -1;
     const int64_t nE = a->n_edges, h = a->d_h;
     if (!keep && !undirected && arith == 0 && nE >= kFused16MinEdges && (level == 1 || (level == 0 && h > 320 && max_level >= 1))) {

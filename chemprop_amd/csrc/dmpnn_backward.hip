@@ -772,10 +772,15 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
     float *slab_h = ws + L.slab_h, *slab_x = ws + L.slab_x;
     // fused forward: the kept edge tensors (H0, H^(t), M^(t)) are in CSR-row order -> the graph in row coordinates
     const bool fused = f.flags & DMPNN_F_FUSED;
+    // tile plan (DMPNN_F_TILE_PLAN): the kept tensors are in the caller's edge order, there are no CSR tables — only the tile
+    // kernel + the f16 weight-gradient products below can run, with the caller's own src array as the gather of W_i's operand
+    const bool lean = (f.flags & DMPNN_F_TILE_PLAN) != 0;
+    DMPNN_CHECK_ARG(!lean || (fused && (f.flags & DMPNN_F_MEGA) && (f.flags & DMPNN_F_SPLIT16) && !has_vd && (nE == 0 || (f.edge_index && f.rev_edge_index))),
+                    "backward: DMPNN_F_TILE_PLAN needs the tile-kernel forward (FUSED | MEGA | SPLIT16), no W_d, and the caller's index arrays");
     const PlanView pv = fused ? plan_view_rows(f.plan, nV, nE) : plan_view(f.plan, nV, nE);
     const int* pflags = fused ? static_cast<const int*>(f.plan) + DMPNN_HDR_FLAGS : nullptr;
-    const int pmask = fused ? kPlanNoFuse : 0;
-    const int* e_gather = fused ? static_cast<const int*>(f.plan) + plan_layout(nV, nE).perm : nullptr;
+    const int pmask = lean ? kPlanNoMegaLean : (fused ? kPlanNoFuse : 0);
+    const int* e_gather = (fused && !lean) ? static_cast<const int*>(f.plan) + plan_layout(nV, nE).perm : nullptr;
     DMPNN_CHECK_ARG(!fused || !(f.flags & DMPNN_F_UNDIRECTED), "backward: fused + undirected is not a valid forward");
     DMPNN_CHECK_ARG(!fused || T == 1 || nE == 0 || f.Hs, "backward: the fused forward did not keep H^(t) (Hs was NULL)");
     const int64_t ldh = f.ldh, slot = nE * ldh;
@@ -838,7 +843,8 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             }
             if (want[2]) {
                 Zj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Zj[2], nE, (int)h, gH0, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, 0, ws + L.w16_z[2]);
-                Aj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[2], nE, Ks[2], f.V, f.ldv, pv.src, (int)dv, f.E, f.lde, e_gather, (int)de, f.b_i ? 1 : 0, ws + L.w16_a[2]);
+                Aj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[2], nE, Ks[2], f.V, f.ldv, lean ? nullptr : pv.src, (int)dv, f.E, f.lde, e_gather, (int)de, f.b_i ? 1 : 0, ws + L.w16_a[2]);
+                if (lean) { Aj[2]->g1_64 = reinterpret_cast<const long long*>(f.edge_index); Aj[2]->g1_rows = nV; }  // (row 0 of edge_index: src)
             }
             DMPNN_TRY(launch_wsplit16(sp, s));
             float* gWs[3] = {b->gW_o, b->gW_h, b->gW_i};
@@ -870,6 +876,7 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             if ((b->gW_h || b->gb_h) && T < 2) { zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h); }
             return DMPNN_OK;
         }
+        DMPNN_CHECK_ARG(!lean, "backward(DMPNN_F_TILE_PLAN): the weight-gradient products on the f16 pipe do not take these shapes / alignments");
         if (b->gW_o || b->gb_o) {
             WgradArgs a;
             memset(&a, 0, sizeof(a));
@@ -907,6 +914,8 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
         }
         return DMPNN_OK;
     }
+    DMPNN_CHECK_ARG(!lean, "backward(DMPNN_F_TILE_PLAN): only the tile-kernel backward can read a tile plan — it needs a gradient of W_i or "
+                    "W_h to be wanted, 16-byte aligned gout / out with leading dimensions that are multiples of 4");
     {
         const bool vec = h % 4 == 0 && ld_gHO % 4 == 0 && ldHO % 4 == 0 && ldh % 4 == 0 && aligned16(gHO_p) && aligned16(HO) && aligned16(gZO);
         const int64_t n = nV * (vec ? h / 4 : h);

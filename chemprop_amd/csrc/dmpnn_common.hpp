@@ -250,6 +250,8 @@ struct WSplitJob {
     int ones;                                                    // column K1 + K2 is 1 (the bias gradient = column sums)
     unsigned char* out; float* scales;                           // [column tile][chunk][8 KB]; [column tile][chunk]
     int n_ct, n_chunks, wg0;
+    const long long* g1_64; int64_t g1_rows;                     // A1's row gather as int64 (the caller's own src array under a tile plan) when g1
+                                                                 // is null: unvalidated, so clamped into [0, g1_rows)
 };
 struct WSplitArgs { WSplitJob job[8]; int n_jobs; };
 struct WProdArgs {

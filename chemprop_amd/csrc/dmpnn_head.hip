@@ -608,8 +608,12 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
     if (stages & DMPNN_STEP_FORWARD) {
         if (!a->plan_ready) {
             DMPNN_CHECK_ARG(a->edge_index && a->rev_edge_index, "train_step: null index arrays");
-            DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
-                                               a->plan_bytes, stream));
+            if (f.flags & DMPNN_F_TILE_PLAN)  // (the tile table alone: the kept tensors stay in the caller's edge order, dmpnn.h)
+                DMPNN_TRY(dmpnn_prepare_tiles(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
+                                              a->plan_bytes, stream));
+            else
+                DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
+                                                   a->plan_bytes, stream));
         }
         DMPNN_TRY(dmpnn_forward(&f, stream));
         DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, false));

@@ -39,6 +39,9 @@ struct Mega16BwdK {
     float* sp_gM; float* sp_Ta;          // [E, ldh], [V, ldh]
     float drop_scale;                    // active dropout in the forward: 1 / (1 - p) (else 0).  The kept H^(t) and the finalize output
                                          // are POST-dropout; for a ReLU-class activation their sign carries the mask (0: dropped or inactive)
+    // tile plan (header LIGHT == 2, dmpnn_prepare_tiles): the forward kept its tensors in the CALLER's edge order and the rows of a
+    // tile are its edges in that order — src / dst / rev straight from the caller's arrays, no CSR tables (row_ptr / revp / srcp unused)
+    const long long* edge_index; const long long* rev64;
 };
 
 template <int WN>
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     const int N = g.h, qn = N >> 2;
     const int T_steps = g.depth;
     const float nanv = __int_as_float(0x7fc00000);
-    if ((g.flags[0] & g.poison_mask) != 0) {  // a graph this route cannot represent: every output NaN
+    const bool lean = g.flags[DMPNN_HDR_LIGHT] == 2;
+    if ((g.flags[0] & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64))) {  // a graph this route cannot represent: every output NaN
         const long long tot_e = (long long)g.nE * N, tot_v = (long long)g.nV * N;
         for (long long i = (long long)blockIdx.x * kThreads + tid; i < tot_e; i += (long long)gridDim.x * kThreads) {
             g.gH0[(i / N) * g.ldh + (i % N)] = nanv;
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         spill::BwdView v;
         v.rs = rs; v.nrows = nrows; v.va = va; v.na = na; v.h = N; v.depth = T_steps; v.d_v = g.d_v;
         v.row_ptr = g.row_ptr; v.srcp = g.srcp; v.revp = g.revp;
+        v.lean = lean; v.edge_index = g.edge_index; v.rev64 = g.rev64; v.nE = g.nE;
         v.act = g.act; v.slope = slope;
         v.gHO = g.gHO; v.ldg = g.ldg; v.HO = g.HO; v.ldho = g.ldho;
         v.H0 = g.H0; v.Hs = g.Hs; v.ldh = g.ldh; v.slot = g.slot;
@@ -121,19 +126,46 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     };
 
     // ---- metadata, incidence fragments ----
-    if (tid < BM) revl[tid] = tid < nrows ? g.revp[rs + tid] - rs : 0;
-    if (tid <= BA) rp[tid] = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
-    if (tid < 8) maxbits[tid] = 0u;
-    __syncthreads();
-    if (tid < na)
-        for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
-    __syncthreads();
-    if (tid < BM) asrc[tid] = tid < nrows ? aor[revl[tid]] : -1;  // src r = dst rev r (symmetric graph: checked by the plan)
-    __syncthreads();
+    if (lean) {
+        // the tile's rows are its edges in the caller's order; the tile checks that it is closed, like the forward (a tile that is
+        // not gives NaN gradients for its rows and atoms — its forward output was NaN already)
+        bool row_bad = false;
+        int rv = 0, ad = 0, as = -1;
+        if (tid < nrows) {
+            const long long e = rs + tid;
+            const long long r_l = g.rev64[e] - rs, s_l = g.edge_index[e] - va, d_l = g.edge_index[(long long)g.nE + e] - va;
+            row_bad = r_l < 0 || r_l >= nrows || d_l < 0 || d_l >= na || s_l < 0 || s_l >= na;
+            if (!row_bad) { rv = (int)r_l; ad = (int)d_l; as = (int)s_l; }
+        }
+        if (tid < BM) { revl[tid] = rv; aor[tid] = ad; asrc[tid] = as; }
+        if (tid < 8) maxbits[tid] = 0u;
+        __syncthreads();
+        if (row_bad) atomicOr(&maxbits[5], 1u);
+        __syncthreads();
+        if (maxbits[5]) {  // (uniform)
+            for (int i = tid; i < nrows * N; i += kThreads) {
+                const long long o = (long long)(rs + i / N) * g.ldh + (i % N);
+                g.gH0[o] = nanv;
+                for (int s = 0; s < T_steps - 1; ++s) g.gZs[(long long)s * g.slot + o] = nanv;
+            }
+            for (int i = tid; i < na * N; i += kThreads) g.gZO[(long long)(va + i / N) * g.ldh + (i % N)] = nanv;
+            return;
+        }
+    } else {
+        if (tid < BM) revl[tid] = tid < nrows ? g.revp[rs + tid] - rs : 0;
+        if (tid <= BA) rp[tid] = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
+        if (tid < 8) maxbits[tid] = 0u;
+        __syncthreads();
+        if (tid < na)
+            for (int r = rp[tid]; r < rp[tid + 1]; ++r) aor[r] = tid;
+        __syncthreads();
+        if (tid < BM) asrc[tid] = tid < nrows ? aor[revl[tid]] : -1;  // src r = dst rev r (symmetric graph: checked by the plan)
+        __syncthreads();
+    }
     // k order of the incidence MFMAs = the order C/D fragments hold rows (see dmpnn_mega16_impl.hpp):
     //   k-step 0, lane group lg, slot s -> row lg*4+s (s<4) | 16+lg*4+(s-4);  k-step 1 -> 32+lg*4+s (s<4) | none.
     // fragments 0..2 (jt): gather,  B[k = atom][j = row r'] = [dst r' == atom]
-    // fragments 3..8 (jt, ks): message backward,  B[k = row r][j = row r'] = [src r == dst r'] - [r == rev r']
+    // fragments 3..8 (jt, ks): message backward,  B[k = row r][j = row r'] = [src r == dst r'] - [r' == rev r]
     // (a lane's k rows depend on (k-step, lg) only: their source atoms are read once; f16 bit patterns 1.0 = 0x3C00, -1.0 = 0xBC00)
     int as_[12];
     {
@@ -143,17 +175,28 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) as_[i] = ((i >> 2) * 16 + lg * 4 + (i & 3)) < nrows ? qa[i] : -3;
     }
+    // ... and their reverse rows: the transpose of the forward's  - [r = rev r']  is  - [r' = rev r]  — the same thing for an
+    // involution (every molecular graph), and exact for any rev map inside the tile (a tile plan does not examine symmetry)
+    int rk_[12];
+    {
+        const int4 q0 = *reinterpret_cast<const int4*>(revl + lg * 4), q1 = *reinterpret_cast<const int4*>(revl + 16 + lg * 4),
+                   q2 = *reinterpret_cast<const int4*>(revl + 32 + lg * 4);
+        const int qa[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rk_[i] = ((i >> 2) * 16 + lg * 4 + (i & 3)) < nrows ? qa[i] : -3;
+    }
     for (int f = wave; f < 9; f += 4) {
         const bool gat = f < 3;
         const int jt = gat ? f : (f - 3) >> 1, ks = gat ? 0 : (f - 3) & 1;
         const int j = jt * 16 + li;  // row r'
-        const int a_t = j < nrows ? aor[j] : -2, rv = j < nrows ? revl[j] : -2;
+        const int a_t = j < nrows ? aor[j] : -2;
         unsigned hb[8];
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             const int k = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
             const int sk = ks == 0 ? as_[sl] : (sl < 4 ? as_[8 + sl] : -3);
-            const bool in = gat ? (k < na && k == a_t) : sk == a_t, isrev = !gat && k == rv;
+            const int rk = ks == 0 ? rk_[sl] : (sl < 4 ? rk_[8 + sl] : -3);
+            const bool in = gat ? (k < na && k == a_t) : sk == a_t, isrev = !gat && j < nrows && rk == j;
             hb[sl] = in ? (isrev ? 0u : 0x3C00u) : (isrev ? 0xBC00u : 0u);
         }
         const u32x4 pk = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};

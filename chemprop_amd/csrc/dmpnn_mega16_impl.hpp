@@ -191,7 +191,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     // its range has both atoms and its reverse edge inside the tile; by counting, no other edge then enters its
     // atoms).  A tile that is not closed writes NaN to its atoms.
     const bool lean = g.flags[DMPNN_HDR_LIGHT] == 2;
-    const bool poison = (g.flags[0] & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && (g.H0 || g.Hs || g.Ms || g.Mv || (g.nE > 0 && (!g.edge_index || !g.rev64))));
+    // (a training forward on a tile plan keeps its tensors in the caller's edge order: dmpnn_backward takes them so when told
+    //  DMPNN_F_TILE_PLAN, dmpnn_mega16_bwd_impl.hpp)
+    const bool poison = (g.flags[0] & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64));
     if (poison) {
         const float nanv = __int_as_float(0x7fc00000);
         const long long total = (long long)g.nV * N;

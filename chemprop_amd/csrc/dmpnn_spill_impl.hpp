@@ -178,6 +178,7 @@ DMPNN_SPILL_FN void forward(const FwdView& g, float* xs) {
 struct BwdView {
     int rs, nrows, va, na, h, depth, d_v;
     const int* row_ptr; const int* srcp; const int* revp;  // CSR-row plan (the forward kept its tensors in row order)
+    bool lean; const long long* edge_index; const long long* rev64; int nE;  // tile plan: rows = the caller's edges, its own arrays
     int act; float slope;
     const float* gHO; int ldg; const float* HO; int ldho;
     const float* H0; const float* Hs; int ldh; long long slot;
@@ -206,21 +207,58 @@ DMPNN_SPILL_FN void backward(const BwdView& g, float* xs) {
     contract(xs, g.na, N, N, g.W_o + g.d_v, 1, g.d_v + N, nullptr,
              [&](int a, int k) -> float { return g.gZO[(va + a) * g.ldh + k]; },
              [&](int a, int c, float z) { g.Ta[(va + a) * g.ldh + c] = z; });
+    // the graph of the piece in row coordinates: CSR tables, or (tile plan) the caller's arrays.  Every loop below walks the rows in
+    // increasing order and looks up the row's atoms — the same sums in the same order either way, except the per-atom totals of the
+    // message backward, whose addends come in row order (CSR rows are sorted by destination, the caller's are not)
+    auto dst_of = [&](int r) -> long long { return g.edge_index[(long long)g.nE + rs + r]; };   // (lean)
+    auto src_of = [&](int r) -> long long { return g.lean ? g.edge_index[rs + r] : (long long)g.srcp[rs + r]; };
+    auto rev_of = [&](int r) -> long long { return g.lean ? g.rev64[rs + r] : (long long)g.revp[rs + r]; };
+    if (g.lean) {  // closure of the piece, as the forward's generic path checks it: a piece that is not closed gets NaN gradients
+        int bad = 0;
+        for (int r = tid; r < g.nrows; r += kSpillThreads) {
+            const long long s_ = src_of(r) - va, d_ = dst_of(r) - va, rv = rev_of(r) - rs;
+            bad |= (s_ < 0 || s_ >= g.na || d_ < 0 || d_ >= g.na || rv < 0 || rv >= g.nrows) ? 1 : 0;
+        }
+        int* flag = reinterpret_cast<int*>(xs);
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (bad) atomicOr(flag, 1);
+        __syncthreads();
+        const int any_bad = *flag;
+        __syncthreads();
+        if (any_bad) {
+            const float nanv = __int_as_float(0x7fc00000);
+            for (int c = tid; c < N; c += kSpillThreads) {
+                for (int r = 0; r < g.nrows; ++r) {
+                    g.gH0[(rs + r) * g.ldh + c] = nanv;
+                    for (int t = 0; t < T - 1; ++t) g.gZs[(long long)t * g.slot + (rs + r) * g.ldh + c] = nanv;
+                }
+                for (int a = 0; a < g.na; ++a) g.gZO[(va + a) * g.ldh + c] = nanv;
+            }
+            return;
+        }
+    }
+    // fn(a, r) for every row r of the piece with its destination atom a (piece-local), rows in increasing order per atom
+    auto for_rows = [&](auto&& fn) {
+        if (g.lean) {
+            for (int r = 0; r < g.nrows; ++r) fn((int)(dst_of(r) - va), r);
+        } else {
+            for (int a = 0; a < g.na; ++a)
+                for (int r = g.row_ptr[va + a] - g.rs; r < g.row_ptr[va + a + 1] - g.rs; ++r) fn(a, r);
+        }
+    };
     // gH^(T-1)[r] = gMv[dst r]                                          (aggregation backward)
     if (T == 1) {
         for (int c = tid; c < N; c += kSpillThreads)
-            for (int a = 0; a < g.na; ++a)
-                for (int r = g.row_ptr[va + a] - g.rs; r < g.row_ptr[va + a + 1] - g.rs; ++r)
-                    g.gH0[(rs + r) * g.ldh + c] = dact(g.Ta[(va + a) * g.ldh + c], g.H0[(rs + r) * g.ldh + c], true);
+            for_rows([&](int a, int r) { g.gH0[(rs + r) * g.ldh + c] = dact(g.Ta[(va + a) * g.ldh + c], g.H0[(rs + r) * g.ldh + c], true); });
         return;
     }
     for (int c = tid; c < N; c += kSpillThreads)
-        for (int a = 0; a < g.na; ++a)
-            for (int r = g.row_ptr[va + a] - g.rs; r < g.row_ptr[va + a + 1] - g.rs; ++r) {
-                const float gz = dact(g.Ta[(va + a) * g.ldh + c], g.Hs[(long long)(T - 2) * g.slot + (rs + r) * g.ldh + c], false);
-                g.gZs[(long long)(T - 2) * g.slot + (rs + r) * g.ldh + c] = gz;
-                g.gH0[(rs + r) * g.ldh + c] = gz;
-            }
+        for_rows([&](int a, int r) {
+            const float gz = dact(g.Ta[(va + a) * g.ldh + c], g.Hs[(long long)(T - 2) * g.slot + (rs + r) * g.ldh + c], false);
+            g.gZs[(long long)(T - 2) * g.slot + (rs + r) * g.ldh + c] = gz;
+            g.gH0[(rs + r) * g.ldh + c] = gz;
+        });
     for (int t = T - 1; t >= 1; --t) {
         const float* gZt = g.gZs + (long long)(t - 1) * g.slot;
         // gM = gZ^(t) . W_h
@@ -230,18 +268,17 @@ DMPNN_SPILL_FN void backward(const BwdView& g, float* xs) {
         // gH^(t-1)[r'] = sum_{r: src r = dst r'} gM[r] - gM[rev r']     (message backward)
         for (int c = tid; c < N; c += kSpillThreads) {
             for (int a = 0; a < g.na; ++a) g.Ta[(va + a) * g.ldh + c] = 0.f;
-            for (int r = 0; r < g.nrows; ++r) g.Ta[(long long)g.srcp[rs + r] * g.ldh + c] += g.gM[(rs + r) * g.ldh + c];
-            for (int a = 0; a < g.na; ++a)
-                for (int r = g.row_ptr[va + a] - g.rs; r < g.row_ptr[va + a + 1] - g.rs; ++r) {
-                    const float gh = g.Ta[(va + a) * g.ldh + c] - g.gM[(long long)g.revp[rs + r] * g.ldh + c];
-                    if (t - 1 >= 1) {
-                        const float gz = dact(gh, g.Hs[(long long)(t - 2) * g.slot + (rs + r) * g.ldh + c], false);
-                        g.gZs[(long long)(t - 2) * g.slot + (rs + r) * g.ldh + c] = gz;
-                        g.gH0[(rs + r) * g.ldh + c] += gz;
-                    } else {
-                        g.gH0[(rs + r) * g.ldh + c] += dact(gh, g.H0[(rs + r) * g.ldh + c], true);  // through H^(0) = tau(H0)
-                    }
+            for (int r = 0; r < g.nrows; ++r) g.Ta[src_of(r) * g.ldh + c] += g.gM[(rs + r) * g.ldh + c];
+            for_rows([&](int a, int r) {
+                const float gh = g.Ta[(va + a) * g.ldh + c] - g.gM[rev_of(r) * g.ldh + c];
+                if (t - 1 >= 1) {
+                    const float gz = dact(gh, g.Hs[(long long)(t - 2) * g.slot + (rs + r) * g.ldh + c], false);
+                    g.gZs[(long long)(t - 2) * g.slot + (rs + r) * g.ldh + c] = gz;
+                    g.gH0[(rs + r) * g.ldh + c] += gz;
+                } else {
+                    g.gH0[(rs + r) * g.ldh + c] += dact(gh, g.H0[(rs + r) * g.ldh + c], true);  // through H^(0) = tau(H0)
                 }
+            });
         }
     }
 }

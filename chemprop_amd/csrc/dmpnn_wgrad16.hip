@@ -59,11 +59,13 @@ __global__ __launch_bounds__(256) void k_wsplit16(WSplitArgs a) {
     const float* src[2];
     int64_t ld[2];
     const int* gth[2];
+    const long long* gth64[2];
     int kind[2];  // 0: read, 1: (1, 0) — the bias column of ones, 2: zeros
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = 64 * ct + 4 * cb + 2 * h;
-        if (c < J.K1) { src[h] = J.A1 + c; ld[h] = J.lda1; gth[h] = J.g1; kind[h] = 0; }
+        gth64[h] = nullptr;
+        if (c < J.K1) { src[h] = J.A1 + c; ld[h] = J.lda1; gth[h] = J.g1; gth64[h] = J.g1 ? nullptr : J.g1_64; kind[h] = 0; }
         else if (c < K) { src[h] = J.A2 + (c - J.K1); ld[h] = J.lda2; gth[h] = J.g2; kind[h] = 0; }
         else { src[h] = J.A1; ld[h] = 0; gth[h] = nullptr; kind[h] = (J.ones && c == K) ? 1 : 2; }
     }
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void k_wsplit16(WSplitArgs a) {
             const int64_t mc = m < J.M ? m : 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int64_t row = gth[h] ? (int64_t)gth[h][mc] : mc;
+                int64_t row = gth[h] ? (int64_t)gth[h][mc] : mc;
+                if (gth64[h]) { row = (int64_t)gth64[h][mc]; row = row < 0 ? 0 : (row >= J.g1_rows ? J.g1_rows - 1 : row); }
                 v[q][r][h] = *reinterpret_cast<const float2*>(src[h] + row * ld[h]);
             }
         }

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import (ACT, F_FUSED, F_H0_RESIDUAL, F_KEEP, F_LOADER_TILES, F_MEGA, F_ROW_FINALIZE, F_SPLIT16, F_STORE16, F_UNDIRECTED, F_WSPLIT_READY,
+from ._lib import (ACT, F_FUSED, F_H0_RESIDUAL, F_KEEP, F_LOADER_TILES, F_MEGA, F_ROW_FINALIZE, F_SPLIT16, F_STORE16, F_TILE_PLAN, F_UNDIRECTED, F_WSPLIT_READY,
                    PLAN_NOFUSE_MASK, PLAN_NOMEGA_MASK, FwdArgs, GemmArgs)
 
 
@@ -147,9 +147,10 @@ class GraphPlan:
         self.edge_index, self.rev_edge_index = ei, rev
         if not launch:
             # the buffer and the facts only: dmpnn_train_step runs K0 itself (dmpnn_prepare_with_batch: a FULL plan — with
-            # molecule tiles where full_tiles says so)
-            if light:
-                raise RuntimeError("GraphPlan(launch=False) is the full plan of a training step")
+            # molecule tiles where full_tiles says so; dmpnn_prepare_tiles for a tile plan, DMPNN_F_TILE_PLAN)
+            if light and not self.tiles_only:
+                raise RuntimeError("GraphPlan(launch=False) is the plan of a training step: full, or the tile plan (light='tiles')")
+            self.loader_tiles = 0  # (the C call plans from the batch vector: the launch bound of the batch size, not a loader's count)
             return
         with _OnDevice(dev):
             if self.loader_tiles:
@@ -492,9 +493,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if use_fused16:
             level = 1
         use_fused, use_mega = level >= 1, level >= 2
-        if light and (not use_fused or keep):
+        if light and (not use_fused or (keep and not (tiles_only and use_mega and not d_vd))):
             raise RuntimeError("forward: a light GraphPlan only serves inference forwards of the fused routes "
-                               "(build the plan with light=False for the general route or for training)")
+                               "(build the plan with light=False for the general route or for training; the tile plan also "
+                               "serves a training forward of the tile kernel without W_d)")
         if tiles_only and (not use_mega or mf == "f32"):
             raise RuntimeError("forward: a tile plan (light='tiles') only serves the whole-forward tile kernel on the f16 pipe")
         # the per-step routes' contractions on the f16 pipe: mfma="split16" forces them, "f32" forbids them, else the rule's crossover
@@ -604,6 +606,12 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         a.flags |= F_MEGA
     if keep:
         a.flags |= F_KEEP
+        if tiles_only:
+            # training on a tile plan: K0 is the tile table alone; the kept tensors are in the caller's edge order and
+            # dmpnn_backward runs the tile kernel on the caller's index arrays (it cannot see the plan's kind: this flag says so)
+            if not (use_mega and want16 and not d_vd):
+                raise RuntimeError("forward: a tile plan serves a training forward only on the tile kernel (f16 pipe), without W_d")
+            a.flags |= F_TILE_PLAN
     if launch:  # (launch=False: the argument block and the workspace only — dmpnn_train_step enqueues the forward itself)
         with _OnDevice(dev):
             _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")

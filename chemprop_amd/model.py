@@ -139,7 +139,8 @@ class FusedTrainer:
     mean / norm aggregation; optional ``nn.BatchNorm1d``; an MLP predictor with a built-in activation and dropout 0; MSE / MAE.
     """
 
-    def __init__(self, model: MPNN, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, group=None):
+    def __init__(self, model: MPNN, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, group=None,
+                 tile_plan: bool = True):
         mp, agg, pred = model.message_passing, model.agg, model.predictor
         # a bond block: this package's mirror, or the subclass of the reference's own class (integration.HipBondMessagePassing):
         # W_h is [d_h, d_h] there (the atom variant's takes d_e + d_h columns, the mol-atom-bond ones have a second read-out)
@@ -194,6 +195,7 @@ class FusedTrainer:
         self._head_range = self.sync.range_of(rest) if rest else (0, 0)
         self._checked = 0
         self._level = None
+        self.tile_plan = bool(tile_plan)   # False: always the full (CSR) plan — what every round before used; tests keep both alive
         self.last_route = None
 
     # ---- helpers ----
@@ -236,19 +238,29 @@ class FusedTrainer:
         self.sync.wait()
 
         # ---- K0: a launched plan while the first batches are validated (host read of the verdict), else inside the C call ----
-        plan = _take_prefetched(mp, bmg, False) if "_dmpnn_prefetched" in mp.__dict__ else None
+        # The kind of plan: once the first batches are validated (on full plans: their verdict on the graph invariants is read on
+        # the host), a batch bound for the tile kernels gets the TILE plan — K0 is then the 11 us tile table instead of the 28 us
+        # CSR plan, the kept tensors stay in the caller's edge order and the backward tile kernel reads the batch's own index
+        # arrays (DMPNN_F_TILE_PLAN; every tile checks itself, a molecule beyond the tile takes the kernels' generic path).
+        no_mega = getattr(mp, "_dmpnn_no_mega", False) or (n_mols > 0 and nE > 30 * n_mols)
+        level = 1 if (no_mega or getattr(bmg, "oversize", None) is True) else 2
+        want_tiles = (self.tile_plan and not validate and level == 2 and nE > 0 and mp.W_h.weight.shape[0] % 4 == 0
+                      and (mp.W_i.weight.requires_grad or mp.W_h.weight.requires_grad)
+                      and (engine.small_plan_fits(nV, nE) or (batch is not None and batch.dtype == torch.int64 and batch.is_contiguous())))
+        kind = "tiles" if want_tiles else False
+        plan = _take_prefetched(mp, bmg, kind) if "_dmpnn_prefetched" in mp.__dict__ else None
         staged = plan is not None  # (K0 of this batch ran on the side stream; this stream now waits for it)
         if plan is None:
-            plan = engine.GraphPlan.from_bmg(bmg, light=False, launch=validate)
+            plan = engine.GraphPlan.from_bmg(bmg, light=kind, launch=validate)
         plan.oversize = getattr(bmg, "oversize", None)
         if validate:
             self._checked += 1
             level = _route(mp, plan, n_mols, batch)
-        else:
-            no_mega = getattr(mp, "_dmpnn_no_mega", False) or (n_mols > 0 and nE > 30 * n_mols)
-            level = 1 if no_mega else 2
-        if plan.oversize is True:
-            level = min(level, 1)
+            if plan.oversize is True:
+                level = min(level, 1)
+        self._last_plan_tiles = bool(plan.tiles_only)
+        if plan.tiles_only and level < 2:  # (cannot happen: the tile plan was only asked for at level 2)
+            raise RuntimeError("FusedTrainer: a tile plan without the tile kernels")
         note_batch(batch, n_mols)
 
         # ---- argument blocks of the block's forward / backward (workspace allocated, nothing enqueued) ----

@@ -161,8 +161,9 @@ def prefetch_plan(mp, bmg) -> None:
         side = torch.cuda.Stream(device=dev)
         mp.__dict__["_dmpnn_side"] = side
     side.wait_stream(torch.cuda.current_stream(dev))
+    kind = _training_plan_kind(mp, bmg)   # (the kind the training forward of this batch will ask for: full, or the tile plan)
     with torch.cuda.stream(side):
-        plan = engine.GraphPlan.from_bmg(bmg, light=False)
+        plan = engine.GraphPlan.from_bmg(bmg, light=kind)
         done = torch.cuda.Event()
         done.record(side)
     # two slots: FusedTrainer issues the plan of batch n + 1 BEFORE step n consumes the plan of batch n (the side stream waits
@@ -171,20 +172,50 @@ def prefetch_plan(mp, bmg) -> None:
     slots.pop(_plan_key(bmg), None)
     while len(slots) >= 2:
         slots.pop(next(iter(slots)))
-    slots[_plan_key(bmg)] = (plan, done)
+    slots[_plan_key(bmg)] = (plan, done, "tiles" if plan.tiles_only else False)
+
+
+def _training_plan_kind(mp, bmg):
+    """``"tiles"`` when a TRAINING forward of ``mp`` on ``bmg`` runs on the tile plan (K0 = the tile table alone, kept tensors in the
+    caller's edge order, ``DMPNN_F_TILE_PLAN``), else ``False`` (the full CSR plan).  The tile plan after the validated first
+    batches, for batches bound for the tile kernels: directed, built-in activation, no ``W_d``, a gradient of ``W_i`` or ``W_h``
+    wanted, the shapes of the tile kernel, and a plan the library can build from what the batch carries."""
+    if _lib.opt("DMPNN_GENERAL", "0") == "1" or _lib.opt("DMPNN_TRAIN_PLAN", "tiles") == "full":
+        return False
+    if mp.undirected or mp.W_d is not None or classify_activation(mp.tau)[0] in ("custom", "prelu"):
+        return False
+    if mp.training and mp.dropout.p > 0 and not (type(mp.dropout) is nn.Dropout and classify_activation(mp.tau)[0] in ("relu", "leakyrelu")):
+        return False
+    if _lib.opt("DMPNN_VALIDATE", "first") != "never" and getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N:
+        return False
+    if not (mp.W_i.weight.requires_grad or mp.W_h.weight.requires_grad):
+        return False
+    d_h, d_in = mp.W_h.weight.shape[0], mp.W_i.weight.shape[1]
+    d_v = mp.W_o.weight.shape[1] - d_h
+    if not (d_h % 4 == 0 and d_h <= 320 and d_v % 2 == 0 and (d_in - d_v) % 2 == 0):
+        return False
+    n_atoms, n_edges = int(bmg.V.shape[0]), int(bmg.E.shape[0])
+    n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    batch = getattr(bmg, "batch", None)
+    if n_edges == 0 or getattr(bmg, "oversize", None) is True:
+        return False
+    buildable = engine.small_plan_fits(n_atoms, n_edges) or getattr(bmg, "tiles", None) is not None or (
+        batch is not None and batch.dtype == torch.int64 and batch.is_contiguous()
+        and bool(_lib.load().dmpnn_tile_plan_any_size(n_atoms, n_edges)))
+    return "tiles" if (buildable and _tile_plan_ok(mp, n_atoms, n_edges, n_mols, True)) else False
 
 
 def _take_prefetched(mp, bmg, light):
     slots = mp.__dict__.get("_dmpnn_prefetched")
     if not slots:
         return None
-    if light is not False:  # (a forward on another kind of plan: the prefetched full plans are not this forward's)
+    if light is True:  # (an inference forward on a light plan: the prefetched training plans are not this forward's)
         mp.__dict__.pop("_dmpnn_prefetched", None)
         return None
     pf = slots.pop(_plan_key(bmg), None)
     if not slots:
         mp.__dict__.pop("_dmpnn_prefetched", None)
-    if pf is None:
+    if pf is None or pf[2] != light:
         return None
     cur = torch.cuda.current_stream(pf[0].device)
     cur.wait_event(pf[1])
@@ -401,6 +432,8 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     light = _light_plan_ok(mp)
     if light and oversize is not True and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
         light = "tiles"
+    if not light and torch.is_grad_enabled() and V_d is None:
+        light = _training_plan_kind(mp, bmg)   # a training forward bound for the tile kernels: the tile plan (DMPNN_F_TILE_PLAN)
     plan = (_take_prefetched(mp, bmg, light) if "_dmpnn_prefetched" in mp.__dict__ else None) or engine.GraphPlan.from_bmg(bmg, light=light)
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch

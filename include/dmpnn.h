@@ -86,6 +86,14 @@ enum dmpnn_flags {
                                      DMPNN_F_KEEP), d_e <= 32: the whole-forward tile kernel — the bond-feature half of the message
                                      is constant over the depth loop, so W_h[:, d_h:] (sum E)[src] is formed once per tile and joins
                                      the residual.  Any other combination: DMPNN_EINVAL (chain the row kernels)                      */
+    DMPNN_F_TILE_PLAN = 1u << 11, /* with DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP: `plan` is a TILE plan
+                                     (dmpnn_prepare_tiles: K0 is the 11 us tile table instead of the 28 us CSR plan at 512 molecules)
+                                     — the kept tensors H0 / Hs / Ms are in the CALLER's edge order and dmpnn_backward runs on
+                                     the tile kernel with the caller's index arrays (edge_index, rev_edge_index: required).  The
+                                     host cannot see what kind of plan a device buffer holds: this flag is how dmpnn_backward
+                                     (and dmpnn_train_step's K0) are told.  A backward pass the tile kernel cannot take
+                                     (frozen W_i and W_h, odd leading dimensions) is DMPNN_EINVAL with this flag, never a
+                                     silent use of CSR tables that are not there                                           */
     DMPNN_F_STORE16 = 1u << 7     /* OPT-IN, NOT fp32-class.  With DMPNN_F_FUSED | DMPNN_F_SPLIT16 (the per-step fused route):
                                      the message tensor between the depth steps is stored as ONE f16 per element with a
                                      power-of-two row scale (2 bytes instead of the exact hi + lo pair of 4) and contracted

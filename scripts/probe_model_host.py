@@ -22,12 +22,12 @@ def pref(i):
 
 from chemprop_amd import engine
 from chemprop_amd.nn import _plan_key
-plans = [engine.GraphPlan.from_bmg(x, light=False) for x in pair]
+plans = [engine.GraphPlan.from_bmg(x, light="tiles") for x in pair]
 torch.cuda.synchronize()
 ev = torch.cuda.Event(); ev.record(); torch.cuda.synchronize()
 def noplan(i):   # (K0 not run at all: the plan of the batch built once, handed over as if prefetched long ago)
     x = pair[i & 1]
-    m.message_passing.__dict__["_dmpnn_prefetched"] = {_plan_key(x): (plans[i & 1], ev)}
+    m.message_passing.__dict__["_dmpnn_prefetched"] = {_plan_key(x): (plans[i & 1], ev, "tiles")}
     tr.step(x, y)
 
 for name, fn in (("plain", plain), ("prefetch", pref), ("no K0", noplan), ("plain", plain)):

@@ -255,7 +255,10 @@ def test_forward_route_is_one_shape_rule():
     assert route(args(4636, 9120, flags=_lib.F_UNDIRECTED)) == R["general"] and route(args(37000, 73000, flags=_lib.F_UNDIRECTED)) == R["general16"]
     assert route(args(4636, 9120, d_e=13)) == R["general"]
     # plans that cannot serve: a tile plan without the tile kernel, a light plan for training / the general route
-    assert route(qm9, cap=1, plan=2) == -1 and route(qm9, keep=1, plan=2) == -1 and route(qm9, arith=1, plan=2) == -1
+    assert route(qm9, cap=1, plan=2) == -1 and route(qm9, arith=1, plan=2) == -1
+    assert route(qm9, keep=1, plan=2) == R["mega16"]          # training on a tile plan (DMPNN_F_TILE_PLAN) ...
+    vd = args(4636, 9120); vd.W_d = 4096; vd.d_vd = 8; vd.V_d = 4096; vd.ldvd = 8
+    assert route(vd, keep=1, plan=2) == -1 and route(vd, plan=2) == R["mega16"]   # ... but not with W_d
     assert route(qm9, keep=1, plan=1) == -1 and route(args(4636, 9120, d_e=13), plan=1) == -1
     assert lib.dmpnn_forward_route(None, 0, 2, 0, 0) == -1 and route(qm9, cap=-1) == -1
 

@@ -291,6 +291,40 @@ def test_fused_step_at_size_vs_restatement_and_module_path(n_mols, kind, bn, agg
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_mols", [96, 512])
+def test_fused_step_on_the_tile_plan_equals_the_full_plan(n_mols, gpu_device):
+    """After the validated first batches the trainer plans with the tile table alone (DMPNN_F_TILE_PLAN: K0 11 us instead of 28,
+    kept tensors in the caller's edge order).  Same losses and parameters as a trainer held on the full CSR plan, to summation
+    order (the weight-gradient products walk the rows in another order)."""
+    from chemprop_amd import _lib, agg as cagg, synth
+    from chemprop_amd.model import MPNN, FusedTrainer, RegressionFFN
+    from chemprop_amd.nn import BondMessagePassing
+
+    batches = [synth.random_batch(n_mols, "qm9", seed=300 + i) for i in range(5)]
+    for b in batches:
+        b.to(gpu_device)
+    ys = [torch.randn(n_mols, 1, generator=torch.Generator().manual_seed(i)).to(gpu_device) for i in range(5)]
+
+    def run(tile_plan):
+        torch.manual_seed(5)
+        m = MPNN(BondMessagePassing(d_h=300, activation="elu"), cagg.NormAggregation(), RegressionFFN(n_tasks=1, input_dim=300, activation="elu"),
+                 batch_norm=True).to(gpu_device).train()
+        tr = FusedTrainer(m, lr=1e-3, tile_plan=tile_plan)
+        losses, kinds = [], []
+        for i in range(5):
+            losses.append(tr.step(batches[i], ys[i]))
+            kinds.append(bool(tr._last_plan_tiles))
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu()[:, 0], tr.opt.flat.detach().cpu().clone(), kinds
+
+    l_t, p_t, k_t = run(True)
+    l_f, p_f, k_f = run(False)
+    assert k_f == [False] * 5 and k_t[:2] == [False, False] and all(k_t[2:]), (k_t, k_f)
+    assert torch.allclose(l_t, l_f, rtol=2e-5, atol=1e-6), (l_t, l_f)
+    assert parity_err(p_t.numpy(), p_f.numpy()) <= 1e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_mols", [64, 512])
 def test_fused_step_with_block_dropout_equals_module_path_on_the_same_masks(n_mols, gpu_device):
     """CLI ``--dropout`` on the block (base.py:139,182): the fused step draws ONE seed from torch's CPU generator like the module
@@ -384,8 +418,10 @@ def test_fused_trainer_learns_and_refuses_what_it_does_not_implement(gpu_device)
     tr = FusedTrainer(model, lr=3e-3)
     losses = [float(tr.step(bmg, y)[0]) for _ in range(60)]
     assert np.mean(losses[-5:]) < 0.5 * np.mean(losses[:5]), (losses[:5], losses[-5:])
-    with pytest.raises(NotImplementedError):
-        FusedTrainer(MPNN(BondMessagePassing(d_h=64, dropout=0.1), cagg.MeanAggregation(), RegressionFFN(input_dim=64)).to(gpu_device))
+    with pytest.raises(NotImplementedError):   # (dropout inside the block: ReLU-class activations only — the sign of the kept tensor carries the mask)
+        FusedTrainer(MPNN(BondMessagePassing(d_h=64, dropout=0.1, activation="tanh"), cagg.MeanAggregation(), RegressionFFN(input_dim=64)).to(gpu_device))
+    with pytest.raises(NotImplementedError):   # (dropout in the predictor: the module path)
+        FusedTrainer(MPNN(BondMessagePassing(d_h=64), cagg.MeanAggregation(), RegressionFFN(input_dim=64, dropout=0.1)).to(gpu_device))
     with pytest.raises(NotImplementedError):
         FusedTrainer(MPNN(BondMessagePassing(d_h=64), cagg.AttentiveAggregation(output_size=64), RegressionFFN(input_dim=64)).to(gpu_device))
     with pytest.raises(ValueError):

@@ -910,6 +910,82 @@ def test_backward_full_size_vs_oracle_autograd(n_mols, kind, kw, gpu_device):
         assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
+def _mixed_batch(n_small, big_kind, seed):
+    """QM9-shaped molecules with ONE molecule beyond the tile in the middle, as bare tensors (``oversize`` unknown to the host)."""
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph
+
+    mgs = synth.random_molgraphs(n_small, "qm9", seed=seed)
+    mgs.insert(n_small // 2, synth.random_molgraphs(1, big_kind, seed=seed + 1)[0])
+    b = BatchMolGraph(mgs)
+    return BatchMolGraph.from_tensors(b.V, b.E, b.edge_index, b.rev_edge_index, b.batch, len(mgs))
+
+
+@pytest.mark.parametrize("case,kw", [
+    ("qm9-512", dict(activation="elu")),
+    ("qm9-96", dict(d_h=64, depth=4, activation="leakyrelu", bias=True)),
+    ("qm9-2048", dict(activation="tanh", bias=True)),      # beyond the single-workgroup plan: the tile table from the batch vector
+    ("qm9-200-depth1", dict(depth=1, activation="elu")),
+    ("mixed-40+1", dict(activation="tanh")),               # a molecule beyond the tile: the kernels' generic path, forward and backward
+    ("shuffled-rev-64", dict(activation="tanh", bias=True)),  # rev is NOT an involution inside the molecules: exact all the same
+])
+def test_training_on_the_tile_plan(case, kw, gpu_device, monkeypatch):
+    """DMPNN_F_TILE_PLAN: a training forward + backward whose K0 is the tile table alone — kept tensors in the caller's edge order,
+    src / dst / rev of a tile read from the batch's own arrays by both tile kernels, the caller's src array as the gather of W_i's
+    weight-gradient operand.  Output and every gradient against the oracle's autograd, and against the same step on the full
+    (CSR) plan."""
+    from chemprop_amd import _lib, synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    monkeypatch.setenv("DMPNN_VALIDATE", "never")   # (the first batches of a module are validated on full plans)
+    if case.startswith("mixed"):
+        bmg = _mixed_batch(40, "synth40", 21)
+    else:
+        bmg = synth.random_batch({"qm9-512": 512, "qm9-96": 96, "qm9-2048": 2048, "qm9-200-depth1": 200, "shuffled-rev-64": 64}[case], "qm9", seed=12)
+    if case.startswith("shuffled"):
+        # a rev map that permutes the edges of each molecule at random (closed inside the molecule, not an involution, src(rev e) != dst e)
+        g = torch.Generator().manual_seed(2)
+        e_mol = bmg.batch[bmg.edge_index[0]]
+        rev = bmg.rev_edge_index.clone()
+        for m in range(len(bmg)):
+            idx = (e_mol == m).nonzero().flatten()
+            rev[idx] = idx[torch.randperm(idx.numel(), generator=g)]
+        from chemprop_amd.data import BatchMolGraph
+        bmg = BatchMolGraph.from_tensors(bmg.V, bmg.E, bmg.edge_index, rev, bmg.batch, len(bmg))
+    torch.manual_seed(4)
+    ref_mp = BondMessagePassing(**kw)
+    G = torch.randn(bmg.V.shape[0], ref_mp.output_dim, generator=torch.Generator().manual_seed(6))
+    w = ot.MPWeights(ref_mp.W_i.weight, ref_mp.W_h.weight, ref_mp.W_o.weight, ref_mp.W_o.bias, ref_mp.W_i.bias, ref_mp.W_h.bias)
+    ref = ot.forward_bmg(bmg, w, depth=ref_mp.depth, activation=kw.get("activation", "relu"))
+    (ref * G).sum().backward()
+    bmg.to(gpu_device)
+    Gd = G.to(gpu_device)
+    res = {}
+    for plan_kind in ("tiles", "full"):
+        if case.startswith("shuffled") and plan_kind == "full":
+            continue   # (the CSR plan's kernels assume a molecular graph and say NaN otherwise: nothing to compare)
+        monkeypatch.setenv("DMPNN_TRAIN_PLAN", plan_kind)
+        mp = BondMessagePassing(**kw)
+        mp.load_state_dict(ref_mp.state_dict())
+        mp = mp.to(gpu_device).train()
+        out = mp(bmg)
+        st = out.grad_fn.st
+        assert st.route == "mega16" and bool(st.plan.tiles_only) == (plan_kind == "tiles")
+        assert bool(st.args.flags & _lib.F_TILE_PLAN) == (plan_kind == "tiles")
+        (out * Gd).sum().backward()
+        res[plan_kind] = (out.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in mp.named_parameters()})
+        assert parity_err(res[plan_kind][0], ref.detach().numpy()) <= TOL, plan_kind
+        for k, q in ref_mp.named_parameters():
+            if q.grad is None:   # (depth 1: W_h takes no part)
+                continue
+            err = parity_err(res[plan_kind][1][k], q.grad.numpy())
+            assert err <= 2e-5, f"{plan_kind} {k}: {err:.3e}"
+    if "full" in res:
+        assert parity_err(res["tiles"][0], res["full"][0]) <= 2e-6
+        for k in res["full"][1]:
+            assert parity_err(res["tiles"][1][k], res["full"][1][k]) <= 5e-6, k
+
+
 @pytest.mark.parametrize("n_mols,kind,kw", [(96, "synth40", dict(activation="tanh", bias=True)), (64, "zinc", dict(d_h=512, depth=4, activation="elu")),
                                             (200, "qm9", dict(depth=1, activation="elu"))])   # (smooth activations: kinks are test_relu_gradients_at_size's)
 def test_training_forward_on_the_per_step_fused_route(n_mols, kind, kw, gpu_device):
@@ -979,13 +1055,14 @@ def test_presplit_weight_cache_follows_weight_updates(gpu_device):
     assert parity_err(c.cpu().numpy(), d.cpu().numpy()) <= 3e-6
 
 
-def test_prefetched_plan_is_the_plan_of_the_next_forward(gpu_device):
+def test_prefetched_plan_is_the_plan_of_the_next_forward(gpu_device, monkeypatch):
     """prefetch_plan: K0 of the next training step on a side stream.  Same plan bytes, same output and gradients as without;
     used once; a prefetched plan of another batch, or one an inference forward cannot use, is dropped."""
     from chemprop_amd import synth
     from chemprop_amd.engine import GraphPlan
     from chemprop_amd.nn import BondMessagePassing, _plan_key
 
+    monkeypatch.setenv("DMPNN_TRAIN_PLAN", "full")   # (this test compares the CSR tables of the plans byte for byte)
     torch.manual_seed(11)
     mp = BondMessagePassing(bias=True).to(gpu_device).train()
     batches = [synth.random_batch(n, "qm9", seed=60 + i) for i, n in enumerate((96, 130, 1500))]
