@@ -139,8 +139,7 @@ def main():
 
         def step():
             with ddp.backward_on_calling_thread():  # (one process per GPU: no hand-off to autograd's device thread, ~95 µs of host time)
-                out = mp(bmg)
-                mp.prefetch_plan(bmg)  # K0 of the NEXT step (a loader holds that batch already) beside this step's backward kernels
+                out = mp(bmg)   # (after the module's first validated batches K0 is the 11 us tile table: DMPNN_F_TILE_PLAN)
                 out.backward(G)
             sync.allreduce()
             opt.step()             # (waits for the exchange on the stream, folds in 1 / world, updates: nothing is skipped)
@@ -263,7 +262,6 @@ def main():
             def tstep():
                 with ddp.backward_on_calling_thread():  # (see chemprop_amd/distributed.py: the step was host-bound without it)
                     o = tmp(bmg)
-                    tmp.prefetch_plan(bmg)            # (the next step's K0 on a side stream, beside this step's backward)
                     o.backward(Gt)
                 tsync.allreduce()
                 topt.step()                      # (waits for the exchange on the stream, divides by the world size, updates)
@@ -274,7 +272,9 @@ def main():
             out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(world * updates / (t_tr * 1e-3) / 1e6, 2),
                                  "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else None,
                                  "autograd": "backward on the calling thread (torch.autograd.set_multithreading_enabled(False): one process per GPU)",
-                                 "plan": "K0 of step n + 1 issued on a side stream during step n (prefetch_plan: one K0 per step, off the critical path)",
+                                 "plan": "K0 inside every step, on the stream: the tile table (dmpnn_prepare_tiles, 11 us; the kept tensors stay in the "
+                                         "caller's edge order, DMPNN_F_TILE_PLAN).  prefetch_plan (K0 of step n + 1 on a side stream) is not used here: "
+                                         "its host cost makes this 200 us step host-bound (profiles/r03_tile_plan_training.txt)",
                                  "note": "forward (kept tensors) + backward + gradient exchange + fused Adam step of the block's parameters, same "
                                          "shard, eager; weak scaling of THIS figure is the data-parallel training claim (BASELINE configs[3])"}
             del tmp, tsync
@@ -335,7 +335,7 @@ def main():
                                  "route": tr_b.last_route,
                                  "model": f"MPNN(BondMessagePassing(d_h={args.hidden}, depth={args.depth}), NormAggregation, BatchNorm1d, "
                                           "RegressionFFN(1 task, hidden 300), MSE) + Adam",
-                                 "plan": "fused_ms_per_step: K0 inside the step's C call, on the critical path (28 us); fused_prefetched_plan: one K0 "
+                                 "plan": "fused_ms_per_step: K0 inside the step's C call, on the critical path (the tile table, 11 us); fused_prefetched_plan: one K0 "
                                          "per step as well, issued for step n + 1 on a side stream during step n (FusedTrainer.prefetch_plan) — on "
                                          "this runtime the cross-queue synchronisation costs what the hidden K0 saves (profiles/r03_side_stream_ab.txt)",
                                  "note": "fused: ONE C call (dmpnn_train_step) enqueues K0, the block's forward, aggregation, batch norm, the "
