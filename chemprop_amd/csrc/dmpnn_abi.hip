@@ -123,6 +123,22 @@ int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, const int
     return prepare_impl(edge_index, rev, n_atoms, n_edges, plan, plan_bytes, 2, stream);
 }
 
+}  // extern "C"
+namespace dmpnn {
+int prepare_tiles_and_bounds(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t n_atoms, int64_t n_edges, void* plan,
+                             size_t plan_bytes, int* mol_bounds, int64_t n_mols, void* stream, bool* wrote_bounds) {
+    *wrote_bounds = false;
+    if (mol_bounds && batch && n_atoms > 0 && n_mols > 0 && n_mols < (1 << 30) && small_plan_fits(n_atoms, n_edges) && check_graph_sizes(n_atoms, n_edges) == DMPNN_OK &&
+        plan != nullptr && aligned16(plan) && (n_edges == 0 || edge_index) && plan_bytes >= dmpnn_plan_bytes(n_atoms, n_edges)) {
+        DMPNN_TRY(launch_prepare_tiles_batch(edge_index, batch, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream), mol_bounds, n_mols));
+        *wrote_bounds = true;
+        return DMPNN_OK;
+    }
+    return dmpnn_prepare_tiles(edge_index, rev, batch, n_atoms, n_edges, plan, plan_bytes, stream);
+}
+}  // namespace dmpnn
+extern "C" {
+
 int dmpnn_tile_plan_any_size(int64_t n_atoms, int64_t n_edges) { return tiles_large_fits(n_atoms, n_edges) ? 1 : 0; }
 int dmpnn_full_plan_keeps_tiles(int64_t n_atoms, int64_t n_edges) {
     if (n_atoms <= 0 || n_edges <= 0) return 0;

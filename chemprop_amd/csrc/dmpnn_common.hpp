@@ -192,7 +192,13 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV, int64_t nE, int* plan,
                    int light, hipStream_t s, bool keep_mtiles = false);
 bool prepare_can_keep_mtiles(int64_t nV, int64_t nE);
-int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s);
+// mol_bounds (optional): the molecule ranges also as the table dmpnn_molagg_* read (first[n_mols] | end[n_mols] | flag)
+int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s,
+                               int* mol_bounds = nullptr, int64_t n_mols = 0);
+// dmpnn_prepare_tiles for a training step that also aggregates per molecule: *wrote_bounds says whether `mol_bounds` was filled
+// (the single-workgroup planner from the batch vector does it on the side; every other planner leaves it to dmpnn_molagg_bounds)
+int prepare_tiles_and_bounds(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t nV, int64_t nE, void* plan,
+                             size_t plan_bytes, int* mol_bounds, int64_t n_mols, void* stream, bool* wrote_bounds);
 // the same tables for batches beyond the single-workgroup plan (dmpnn_tiles_large.hip)
 bool tiles_large_fits(int64_t nV, int64_t nE);
 int launch_prepare_tiles_large(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s);

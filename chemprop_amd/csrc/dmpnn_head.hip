@@ -606,17 +606,25 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
     DMPNN_CHECK_ARG(a->head.n_atoms == f.n_atoms && a->head.d_h == f.d_h + (f.W_d ? f.d_vd : 0), "train_step: head and block sizes differ");
     const int stages = a->stages ? a->stages : (DMPNN_STEP_FORWARD | DMPNN_STEP_BACKWARD | DMPNN_STEP_UPDATE);
     if (stages & DMPNN_STEP_FORWARD) {
+        bool bounds_done = false;
         if (!a->plan_ready) {
             DMPNN_CHECK_ARG(a->edge_index && a->rev_edge_index, "train_step: null index arrays");
-            if (f.flags & DMPNN_F_TILE_PLAN)  // (the tile table alone: the kept tensors stay in the caller's edge order, dmpnn.h)
-                DMPNN_TRY(dmpnn_prepare_tiles(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
-                                              a->plan_bytes, stream));
-            else
+            if (f.flags & DMPNN_F_TILE_PLAN) {  // (the tile table alone: the kept tensors stay in the caller's edge order, dmpnn.h)
+                // ... and the planner already holds every molecule's atom range: it writes the aggregation's bounds table on the side
+                const dmpnn_head_args& h = a->head;
+                int* mb = nullptr;
+                if (h.ws && h.n_mols > 0 && h.batch == a->batch && h.n_atoms == f.n_atoms) {
+                    const HeadLayout HL = head_layout(h);
+                    if (h.ws_bytes >= HL.total) mb = reinterpret_cast<int*>(static_cast<unsigned char*>(h.ws) + HL.bounds);
+                }
+                DMPNN_TRY(prepare_tiles_and_bounds(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
+                                                   a->plan_bytes, mb, h.n_mols, stream, &bounds_done));
+            } else
                 DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
                                                    a->plan_bytes, stream));
         }
         DMPNN_TRY(dmpnn_forward(&f, stream));
-        DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, false));
+        DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, bounds_done));
     }
     if (stages & DMPNN_STEP_BACKWARD) DMPNN_TRY(dmpnn_backward(&a->bwd, stream));
     if ((stages & DMPNN_STEP_UPDATE) && a->n_params > 0)

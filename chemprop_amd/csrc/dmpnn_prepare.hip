@@ -729,7 +729,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int64_t* __restrict__ edge_index,
                                                                       const int64_t* __restrict__ batch,
                                                                       int* __restrict__ plan, PlanLayout L, int nV, int nE,
-                                                                      long long* dbg) {
+                                                                      long long* dbg, int* __restrict__ mol_bounds, int n_mols_out) {
     extern __shared__ __attribute__((aligned(16))) int lds_i[];
     int n_stamp = 0;
     auto stamp = [&]() {
@@ -807,6 +807,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
     if ((flags_s & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR)) && tid == 0) bad_s = 1;
     __syncthreads();
     stamp();  // 3: molecule ranges
+    // (optional) the same ranges as the table the per-molecule aggregation reads (dmpnn_molagg.hip: first[n] | end[n] | flag) — a
+    // training step that plans with this kernel does not launch k_mol_bounds for it
+    if (mol_bounds) {
+        for (int m = tid; m < n_mols_out; m += kSmallThreads) {
+            mol_bounds[m] = m <= nm ? fa[m] : nV;
+            mol_bounds[n_mols_out + m] = m + 1 <= nm ? fa[m + 1] : nV;
+        }
+        if (tid == 0)   // 1: an id out of range (or beyond the caller's molecule count), 2: not sorted — any non-zero value poisons the aggregation
+            mol_bounds[2 * n_mols_out] = ((flags_s & PLAN_RANGE_ERROR) || nm > n_mols_out ? 1 : 0) | ((flags_s & PLAN_NO_PIECE_TILES) ? 2 : 0);
+    }
     // phase 4: greedy packing + the tables; the row tiles of the per-step fused route are emptied
     TileGeom g;
     g.b0 = kFusedBM; g.n_tiles = 0;
@@ -833,7 +843,8 @@ static size_t tiles_batch_lds_bytes(int64_t nV, int64_t nE) {
     return ((size_t)(3 * (nV + 2)) * 4 + (size_t)(nV + 1 + nE + 2) * 2 + 31) & ~size_t(15);
 }
 
-int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV64, int64_t nE64, int* plan, hipStream_t s) {
+int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV64, int64_t nE64, int* plan, hipStream_t s,
+                               int* mol_bounds, int64_t n_mols) {
     const int nV = (int)nV64, nE = (int)nE64;
     const PlanLayout L = plan_layout(nV, nE);
     static bool attr_set = false;
@@ -847,7 +858,7 @@ int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_prepare_tiles_batch, dim3(1), dim3(kSmallThreads), tiles_batch_lds_bytes(nV, nE), s, edge_index, batch, plan,
-                       L, nV, nE, g_debug_stamps ? g_debug_stamps + 32 : nullptr);
+                       L, nV, nE, g_debug_stamps ? g_debug_stamps + 32 : nullptr, mol_bounds, (int)n_mols);
     DMPNN_CHECK_LAUNCH("k_prepare_tiles_batch");
     return DMPNN_OK;
 }
