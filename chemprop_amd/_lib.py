@@ -30,7 +30,7 @@ PLAN_NOFFSETS = 15
 EXPORTS = [
     "dmpnn_version", "dmpnn_debug_timestamps", "dmpnn_last_error_string", "dmpnn_last_launch_count", "dmpnn_plan_bytes",
     "dmpnn_plan_layout", "dmpnn_prepare", "dmpnn_prepare_light", "dmpnn_prepare_tiles", "dmpnn_message_fwd", "dmpnn_aggregate_fwd",
-    "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
+    "dmpnn_linear_fwd", "dmpnn_linear16_wsplit_bytes", "dmpnn_linear16_ok", "dmpnn_linear16_fwd", "dmpnn_update_fwd", "dmpnn_forward", "dmpnn_forward_can_fuse", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_keep_bits_bytes", "dmpnn_forward_spill_bytes", "dmpnn_backward_ws_bytes", "dmpnn_backward", "dmpnn_message_bwd",
     "dmpnn_aggregate_bwd", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_linear_wgrad",
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
@@ -92,6 +92,7 @@ class FwdArgs(C.Structure):
         ("spill_ws", C.c_void_p), ("spill_bytes", C.c_size_t),
         ("msplit", C.c_void_p), ("msplit_bytes", C.c_size_t),
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+        ("keep_bits", C.c_void_p), ("keep_bits_bytes", C.c_size_t),
     ]
 
 
@@ -237,6 +238,7 @@ def load() -> C.CDLL:
     lib.dmpnn_linear_wgrad.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes",
+                  "dmpnn_forward_keep_bits_bytes",
                   "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes", "dmpnn_head_ws_bytes")
     lib.dmpnn_linear16_wsplit_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_linear16_ok.argtypes = [C.POINTER(GemmArgs)]
@@ -261,6 +263,7 @@ def load() -> C.CDLL:
     lib.dmpnn_molagg_bwd.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int,
                                      C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     lib.dmpnn_forward_wsplit_bytes.argtypes = [C.POINTER(FwdArgs)]
+    lib.dmpnn_forward_keep_bits_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_forward_spill_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,

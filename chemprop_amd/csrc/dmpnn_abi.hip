@@ -244,6 +244,17 @@ size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a) {
     return (a->flags & DMPNN_F_MEGA) ? mega16_wsplit_bytes(*a) : steps16_wsplit_bytes(*a);
 }
 
+// one bit per element of H0 and of every kept H^(t): 256 words of 8 bytes per tile (64 per wave, RT_E WN 4 <= 60 of them used)
+static bool keep_bits_apply(const dmpnn_fwd_args& a) {
+    const unsigned need = DMPNN_F_TILE_PLAN | DMPNN_F_KEEP | DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_FUSED;
+    return (a.flags & need) == need && (a.act == DMPNN_ACT_NONE || a.act == DMPNN_ACT_RELU || a.act == DMPNN_ACT_LEAKYRELU) &&
+           !(a.dropout_p > 0.f) && !a.W_d && a.n_atoms > 0 && a.n_edges > 0;
+}
+size_t dmpnn_forward_keep_bits_bytes(const dmpnn_fwd_args* a) {
+    if (!a || !keep_bits_apply(*a)) return 0;
+    return (size_t)a->depth * (size_t)plan_layout(a->n_atoms, a->n_edges).max_mtiles * 256u * 8u;
+}
+
 size_t dmpnn_forward_spill_bytes(const dmpnn_fwd_args* a) {
     if (!a || a->n_atoms < 0 || a->n_edges < 0 || a->ldh <= 0) return 0;
     return (size_t)(3 * a->n_edges + a->n_atoms) * (size_t)a->ldh * sizeof(float);
@@ -388,6 +399,9 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         if (a->flags & DMPNN_F_MEGA) {
             // ---- whole forward of every tile of whole molecules in one launch ----
             DMPNN_CHECK_ARG(mega_shapes_ok(*a), "forward: DMPNN_F_MEGA given but the shapes do not allow it");
+            DMPNN_CHECK_ARG(!a->keep_bits || (keep_bits_apply(*a) && aligned16(a->keep_bits) && a->keep_bits_bytes >= dmpnn_forward_keep_bits_bytes(a)),
+                            "forward: keep_bits needs DMPNN_F_TILE_PLAN | DMPNN_F_KEEP on the tile kernel (f16 pipe), a ReLU-class activation, no "
+                            "dropout, no W_d, and dmpnn_forward_keep_bits_bytes() bytes");
             DMPNN_CHECK_ARG(!(a->flags & DMPNN_F_KEEP) || a->depth == 1 || nE == 0 ||
                             (a->Hs && a->n_hslots >= a->depth - 1 && a->n_mslots >= a->depth - 1),
                             "forward(mega, keep): needs depth-1 H and M slots");

@@ -747,7 +747,18 @@ int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, 
     return launch_wgrad_reduce(static_cast<float*>(ws), p, ns, (int)g->N, K, ones, gW, ldgw, gb, s);
 }
 
-int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
+int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) { return backward_impl(b, stream, nullptr, nullptr); }
+
+}  // extern "C"
+
+namespace dmpnn {
+size_t extra_wgrad_ws_floats(int64_t M, int N, int Kt) {
+    const WProdPlan q = plan_wgrad16(M, N, Kt);
+    return align_up((wsplit16_bytes(M, N) + 3) / 4, 64) + align_up((wsplit16_bytes(M, Kt) + 3) / 4, 64) + align_up((size_t)q.splits * q.slab_stride, 64);
+}
+
+int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra, bool* extra_done) {
+    if (extra_done) *extra_done = false;
     DMPNN_CHECK_ARG(b != nullptr, "backward: null args");
     const dmpnn_fwd_args& f = b->f;
     const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dv = f.d_v, de = f.d_e;
@@ -846,6 +857,22 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
                 Aj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[2], nE, Ks[2], f.V, f.ldv, lean ? nullptr : pv.src, (int)dv, f.E, f.lde, e_gather, (int)de, f.b_i ? 1 : 0, ws + L.w16_a[2]);
                 if (lean) { Aj[2]->g1_64 = reinterpret_cast<const long long*>(f.edge_index); Aj[2]->g1_rows = nV; }  // (row 0 of edge_index: src)
             }
+            // the rider (see ExtraWgrad): two more operands to split, one more product, one more reduce job
+            WSplitJob *Zx = nullptr, *Ax = nullptr;
+            WProdPlan qx;
+            float* slab_x16 = nullptr;
+            const bool ride = extra && extra->Z && extra->A && extra->ws && (extra->gW || extra->gb) && extra->M > 0 && extra->N % 2 == 0 &&
+                              wgrad16_operand_ok(extra->Z, extra->ldz, extra->N, nullptr, 0, 0) && wgrad16_operand_ok(extra->A, extra->lda, extra->K, nullptr, 0, 0) &&
+                              aligned16(extra->ws) && sp.n_jobs + 2 <= 8;
+            if (ride) {
+                const int Ktx = extra->K + extra->ones;
+                qx = plan_wgrad16(extra->M, extra->N, Ktx);
+                float* wz = extra->ws;
+                float* wa = wz + align_up((wsplit16_bytes(extra->M, extra->N) + 3) / 4, 64);
+                slab_x16 = wa + align_up((wsplit16_bytes(extra->M, Ktx) + 3) / 4, 64);
+                Zx = &sp.job[sp.n_jobs++]; wsplit16_job(Zx, extra->M, extra->N, extra->Z, extra->ldz, nullptr, extra->N, nullptr, 0, nullptr, 0, 0, wz);
+                Ax = &sp.job[sp.n_jobs++]; wsplit16_job(Ax, extra->M, Ktx, extra->A, extra->lda, nullptr, extra->K, nullptr, 0, nullptr, 0, extra->ones, wa);
+            }
             DMPNN_TRY(launch_wsplit16(sp, s));
             float* gWs[3] = {b->gW_o, b->gW_h, b->gW_i};
             float* gbs[3] = {b->gb_o, b->gb_h, b->gb_i};
@@ -858,7 +885,8 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
             memset(&pj, 0, sizeof(pj));
             for (int i = 0; i < 3; ++i)  // (the big product first: the small ones fill its tail)
                 if (want[(i + 1) % 3]) wgrad16_add(&pj, *Zj[(i + 1) % 3], *Aj[(i + 1) % 3], L.q[(i + 1) % 3], (int)h, Ks[(i + 1) % 3], ws + L.w16_slab[(i + 1) % 3]);
-            DMPNN_TRY(launch_wgrad16(pj, s));  // the three products in one launch
+            if (ride) wgrad16_add(&pj, *Zx, *Ax, qx, extra->N, extra->K + extra->ones, slab_x16);
+            DMPNN_TRY(launch_wgrad16(pj, s));  // the three products (+ the rider) in one launch
             for (int i = 0; i < 3; ++i) {
                 if (!want[i]) continue;
                 ReduceJob& r = rj.job[rj.n_jobs];
@@ -868,6 +896,16 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
                 if (blocks > 1024) blocks = 1024;
                 rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
                 ++rj.n_jobs;
+            }
+            if (ride && rj.n_jobs < 4) {
+                ReduceJob& r = rj.job[rj.n_jobs];
+                r.slab = slab_x16; r.slab_stride = qx.slab_stride; r.n_slabs = qx.splits; r.ldk = qx.ldk;
+                r.N = extra->N; r.K = extra->K; r.ones = extra->ones; r.gW = extra->gW; r.ldgw = extra->ldgw; r.gb = extra->gb;
+                int64_t blocks = ((int64_t)r.N * (extra->K + extra->ones) + 255) / 256;
+                if (blocks > 1024) blocks = 1024;
+                rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
+                ++rj.n_jobs;
+                if (extra_done) *extra_done = true;
             }
             if (rj.n_jobs > 0) {  // one reduce launch for all of them
                 hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
@@ -1047,4 +1085,5 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) {
     return DMPNN_OK;
 }
 
-}  // extern "C"
+}  // namespace dmpnn
+

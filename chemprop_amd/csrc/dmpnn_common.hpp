@@ -268,6 +268,15 @@ struct WProdArgs {
 struct WProdPlan { int n_nt, n_kt, n_chunks, chunks_per_split, splits, ldk; int64_t slab_stride; };
 struct WProdJobs { WProdArgs job[4]; int wg0[5]; int n_jobs; };  // several products in one launch: job j owns workgroups [wg0[j], wg0[j + 1]), multiples of 8
 size_t wsplit16_bytes(int64_t M, int64_t C);
+// One more weight-gradient product for the launches of a backward pass on the f16 pipe (the predictor's first layer in a training
+// step: gW[N, K] = Z^T A, gb = colsum(Z) — 512 rows are 16 chunks beside the block's 1 140): rides in k_wsplit16 / k_wgrad16 /
+// k_wgrad_reduce_multi instead of three launches of its own.  ws: >= extra_wgrad_ws_floats(M, N, K + ones) floats, 16-byte aligned.
+struct ExtraWgrad {
+    const float* Z; int64_t ldz; const float* A; int64_t lda; int64_t M; int N, K, ones;
+    float* gW; int64_t ldgw; float* gb; float* ws;
+};
+size_t extra_wgrad_ws_floats(int64_t M, int N, int Kt);
+int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra, bool* extra_done);
 void wsplit16_job(WSplitJob* j, int64_t M, int C, const float* A1, int64_t lda1, const int* g1, int K1, const float* A2, int64_t lda2,
                   const int* g2, int K2, int ones, void* ws);
 int launch_wsplit16(WSplitArgs& a, hipStream_t s);

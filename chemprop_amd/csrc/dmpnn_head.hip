@@ -422,6 +422,10 @@ HeadLayout head_layout(const dmpnn_head_args& h) {
         const size_t b = dmpnn_linear_wgrad_ws_bytes(B, h.dims[l + 1], h.dims[l], 1);
         if (b > wg) wg = b;
     }
+    if (h.n_layers > 0) {  // (the first layer's weight gradient may ride in the block's backward launches: its split operands + slabs)
+        const size_t b = extra_wgrad_ws_floats(B, (int)h.dims[1], (int)h.dims[0] + 1) * sizeof(float);
+        if (b > wg) wg = b;
+    }
     L.wgrad = o; L.wgrad_bytes = al256(wg); o += L.wgrad_bytes;
     L.gHm = o; o += al256((size_t)B * d * 4);
     L.total = o;
@@ -443,17 +447,20 @@ size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h) {
 }  // extern "C"
 
 namespace {
-int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done);
+int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done, ExtraWgrad* defer);
 }  // namespace
 
 extern "C" {
 
-int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream) { return head_run(hp, Hv, ldhv, stream, false); }
+int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream) { return head_run(hp, Hv, ldhv, stream, false, nullptr); }
 
 }  // extern "C"
 
 namespace {
-int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done) {
+// defer (a whole training step only): the weight gradient of the predictor's FIRST layer is not launched here but described in
+// *defer — it rides in the launches of the block's backward pass (ExtraWgrad); its inputs (the layer's output gradient, the
+// layer's input) stay untouched in the workspace until then
+int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done, ExtraWgrad* defer) {
     DMPNN_CHECK_ARG(hp != nullptr, "head: null args");
     const dmpnn_head_args& h = *hp;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -558,7 +565,12 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
             memset(&g, 0, sizeof(g));
             g.M = B; g.N = N; g.K1 = K; g.A1 = A[l]; g.lda1 = K;
             float* gw = h.gW[l] ? h.gW[l] : Wt;  // (the product writes both; an unwanted one lands in scratch)
-            DMPNN_TRY(dmpnn_linear_wgrad(&g, g_cur, N, gw, K, h.b[l] ? h.gb[l] : nullptr, ws + L.wgrad, L.wgrad_bytes, stream));
+            if (defer && l == 0 && h.gW[l] && N % 2 == 0 && K % 2 == 0) {
+                *defer = ExtraWgrad{g_cur, N, A[l], K, B, (int)N, (int)K, h.b[l] ? 1 : 0, h.gW[l], K, h.b[l] ? h.gb[l] : nullptr,
+                                    reinterpret_cast<float*>(ws + L.wgrad)};
+            } else {
+                DMPNN_TRY(dmpnn_linear_wgrad(&g, g_cur, N, gw, K, h.b[l] ? h.gb[l] : nullptr, ws + L.wgrad, L.wgrad_bytes, stream));
+            }
         }
         // data gradient: gA[l] = g . W_l   (the contraction kernel on W_l^T)
         hipLaunchKernelGGL(k_head_transpose, dim3((unsigned)((K + 31) / 32), (unsigned)((N + 31) / 32)), dim3(32, 8), 0, s, h.W[l], K, Wt, N, (int)N, (int)K);
@@ -605,6 +617,8 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
     DMPNN_CHECK_ARG(a->head.gHv == a->bwd.gout && a->head.ldg == a->bwd.ldgout, "train_step: head.gHv must be the backward's gout");
     DMPNN_CHECK_ARG(a->head.n_atoms == f.n_atoms && a->head.d_h == f.d_h + (f.W_d ? f.d_vd : 0), "train_step: head and block sizes differ");
     const int stages = a->stages ? a->stages : (DMPNN_STEP_FORWARD | DMPNN_STEP_BACKWARD | DMPNN_STEP_UPDATE);
+    ExtraWgrad rider;
+    memset(&rider, 0, sizeof(rider));
     if (stages & DMPNN_STEP_FORWARD) {
         bool bounds_done = false;
         if (!a->plan_ready) {
@@ -624,9 +638,21 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
                                                    a->plan_bytes, stream));
         }
         DMPNN_TRY(dmpnn_forward(&f, stream));
-        DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, bounds_done));
+        // (a whole step in one call: the first predictor layer's weight gradient rides in the block's backward launches; a staged
+        //  step — data parallel — has the head's gradients final after this stage, so nothing is deferred there)
+        DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, bounds_done, (stages & DMPNN_STEP_BACKWARD) ? &rider : nullptr));
     }
-    if (stages & DMPNN_STEP_BACKWARD) DMPNN_TRY(dmpnn_backward(&a->bwd, stream));
+    if (stages & DMPNN_STEP_BACKWARD) {
+        bool rode = false;
+        DMPNN_TRY(backward_impl(&a->bwd, stream, rider.Z ? &rider : nullptr, &rode));
+        if (rider.Z && !rode) {  // (the backward pass did not take the f16 products: the product of its own, as dmpnn_head would have run it)
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = rider.M; g.N = rider.N; g.K1 = rider.K; g.A1 = rider.A; g.lda1 = rider.lda;
+            const HeadLayout HL = head_layout(a->head);
+            DMPNN_TRY(dmpnn_linear_wgrad(&g, rider.Z, rider.ldz, rider.gW, rider.ldgw, rider.gb, rider.ws, HL.wgrad_bytes, stream));
+        }
+    }
     if ((stages & DMPNN_STEP_UPDATE) && a->n_params > 0)
         DMPNN_TRY(dmpnn_adam_step(a->p, a->g, a->m, a->v, a->n_params, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->bias_corr1,
                                   a->sqrt_bias_corr2, a->grad_scale, a->dev_scalars, stream));

@@ -108,6 +108,10 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     g.out = out; g.ldout = (int)ldout;
     g.ldh = (int)a.ldh; g.slot = (long long)nE * a.ldh;
     if (a.flags & DMPNN_F_KEEP) { g.H0 = a.H0; g.Hs = a.Hs; g.Ms = a.Ms; g.Mv = a.Mv; }
+    if ((a.flags & DMPNN_F_KEEP) && a.keep_bits) {  // (validated by dmpnn_forward) H0 / H^(t) as sign bits: slot 0 = H0, slot t = H^(t)
+        G.keep_bits = static_cast<unsigned long long*>(a.keep_bits);
+        G.bits_slot = (long long)L.max_mtiles * 256;
+    }
     g.spill = (a.spill_ws && a.spill_bytes >= dmpnn_forward_spill_bytes(&a) && aligned16(a.spill_ws)) ? a.spill_ws : nullptr;
     G.Wi = mega16::SplitW{ws + W.wi, reinterpret_cast<const float*>(ws + W.sc_i), W.nc_i};
     G.Wh = mega16::SplitW{ws + W.wh, reinterpret_cast<const float*>(ws + W.sc_h), W.nc_h};

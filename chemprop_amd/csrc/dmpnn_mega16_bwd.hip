@@ -59,6 +59,10 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     g.gZO = gZO; g.gZs = gZs; g.gH0 = gH0;
     g.srcp = plan_i + L.srcp; g.d_v = (int)dv; g.W_o = f.W_o; g.W_h = f.W_h; g.sp_gM = sp_gM; g.sp_Ta = sp_Ta;
     g.drop_scale = (f.dropout_p > 0.f && f.dropout_p < 1.f) ? 1.f / (1.f - f.dropout_p) : 0.f;
+    if (f.keep_bits && (f.flags & DMPNN_F_TILE_PLAN)) {  // the forward kept H0 / H^(t) as sign bits (dmpnn_fwd_args.keep_bits)
+        g.keep_bits = static_cast<const unsigned long long*>(f.keep_bits);
+        g.bits_slot = (long long)L.max_mtiles * 256;
+    }
     g.edge_index = reinterpret_cast<const long long*>(f.edge_index);   // (read only under a tile plan: header LIGHT == 2)
     g.rev64 = reinterpret_cast<const long long*>(f.rev_edge_index);
     g.WoMT = mega16::SplitW{ws, inv_o, (int)nc};

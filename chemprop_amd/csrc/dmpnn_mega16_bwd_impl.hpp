@@ -42,6 +42,9 @@ struct Mega16BwdK {
     // tile plan (header LIGHT == 2, dmpnn_prepare_tiles): the forward kept its tensors in the CALLER's edge order and the rows of a
     // tile are its edges in that order — src / dst / rev straight from the caller's arrays, no CSR tables (row_ptr / revp / srcp unused)
     const long long* edge_index; const long long* rev64;
+    // the forward kept H0 / H^(t) as sign bits (Mega16K::keep_bits: slot 0 = H0, slot t = H^(t), bits_slot words per slot) — the
+    // fp32 rows H0 / Hs then only hold the molecules beyond the tile
+    const unsigned long long* keep_bits; long long bits_slot;
 };
 
 template <int WN>
@@ -344,8 +347,38 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
                 for (int r = 0; r < 4; ++r) m[ct][jt][r] *= isX;
     };
     // m (edge gradient in transposed fragments) -> gz = m * tau'(Y rows); optional store; returns max |gz|
-    auto mask_rows = [&](f32x4 (&m)[WN][RT_E], const float* Y, bool preact, float* store) -> float {
+    auto mask_rows = [&](f32x4 (&m)[WN][RT_E], const float* Y, bool preact, float* store, int bslot) -> float {
         launder();
+        if constexpr (SA) {
+            if (g.keep_bits) {  // (uniform) the kept tensor as sign bits in the forward's fragment order: this lane's element (row jt 16 + li,
+                // column ct 16 + 4 lg + c) is bit (li >> 2) 16 + 4 lg + c of word (jt WN + ct) 4 + (li & 3) of its wave
+                const unsigned long long* bw = g.keep_bits + (long long)bslot * g.bits_slot + (long long)t * 256 + wave * 64 + (li & 3);
+                const int sh = (li >> 2) * 16 + lg * 4;
+                const float neg = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
+                float mxb = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct) {
+                    unsigned nib[RT_E];
+#pragma unroll
+                    for (int jt = 0; jt < RT_E; ++jt) nib[jt] = (unsigned)(bw[(jt * WN + ct) * 4] >> sh) & 0xFu;
+#pragma unroll
+                    for (int jt = 0; jt < RT_E; ++jt) {
+                        const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                        const bool ok = row < nrows && col4 < N;
+                        f32x4 v;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float gv = m[ct][jt][c];
+                            v[c] = ok ? ((g.act == DMPNN_ACT_NONE || ((nib[jt] >> c) & 1u)) ? gv : neg * gv) : 0.f;
+                        }
+                        m[ct][jt] = v;
+                        mxb = fmaxf(mxb, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                        if (store && ok) store_keep4(store + (long long)(rs + row) * g.ldh + col4, make_float4(v[0], v[1], v[2], v[3]));
+                    }
+                }
+                return mxb;
+            }
+        }
         // the kept rows of column tile ct + 1 are requested while column tile ct is processed (clamped addresses: no load under a
         // branch); two column tiles in flight instead of all five: the registers are the second workgroup's
         auto load_y = [&](int ct, float4 (&y)[RT_E]) {
@@ -444,12 +477,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     }
     f32x4 gh0[WN][RT_E];
     if (T_steps == 1) {
-        mask_rows(m, g.H0, true, g.gH0);
+        mask_rows(m, g.H0, true, g.gH0, 0);
         return;
     }
     // gZ^(T-1) = gH * tau'(H^(T-1));  gH0 = gZ^(T-1)
     {
-        const float mx = mask_rows(m, g.Hs + (long long)(T_steps - 2) * g.slot, false, g.gZs + (long long)(T_steps - 2) * g.slot);
+        const float mx = mask_rows(m, g.Hs + (long long)(T_steps - 2) * g.slot, false, g.gZs + (long long)(T_steps - 2) * g.slot, T_steps - 1);
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
@@ -467,7 +500,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         unscale(RE{}, acc, 1.f / sA, g.WhT.inv_scale);
         incidence(RE{}, acc, 3, m);              // gH^(t-1) = C^T gM
         if (t - 1 >= 1) {
-            const float mx = mask_rows(m, g.Hs + (long long)(t - 2) * g.slot, false, g.gZs + (long long)(t - 2) * g.slot);
+            const float mx = mask_rows(m, g.Hs + (long long)(t - 2) * g.slot, false, g.gZs + (long long)(t - 2) * g.slot, t - 1);
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
@@ -475,7 +508,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             sA = tile_scale(mx);
             stage_rows(m, sA);
         } else {
-            mask_rows(m, g.H0, true, nullptr);   // through H^(0) = tau(H0)
+            mask_rows(m, g.H0, true, nullptr, 0);   // through H^(0) = tau(H0)
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
 #pragma unroll

@@ -54,7 +54,20 @@ struct Mega16K {
     // DMPNN_F_ATOM (atom messages, inference): W_i is [N, d_v], Wh holds W_h[:, :N] and WhE the bond-feature block W_h[:, N:N + d_e]
     // (one chunk: d_e <= 32); atom_de = d_e (the kernel's own d_e is 0: E is not part of the K1 operand), 0 = the bond variant
     SplitW WhE; int atom_de;
+    // dmpnn_fwd_args.keep_bits (training on a tile plan, ReLU-class activation, no dropout): H0 and H^(t) leave the kernel as ONE
+    // bit per element — [x > 0], all the backward tile kernel needs of them — in the order of the matrix-pipe fragments: word
+    // (rt WN + ct) 4 + r of wave w of tile t (64 words per wave, 256 per tile) is the ballot of "element (row rt 16 + 4 lg + r, column
+    // 16 (w WN + ct) + li) > 0" over the wave's lanes.  Slot 0 = H0, slot t = H^(t); bits_slot = words per slot.
+    unsigned long long* keep_bits; long long bits_slot;
 };
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // exact power-of-two scale that puts `maxabs` at [2^13, 2^14); 1 for 0 / inf / nan
 __device__ __forceinline__ float scale_for(float maxabs) {
@@ -547,11 +560,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     };
     // active dropout on C/D fragments (training forward only): element (row0 + rt 16 + lg 4 + r, column) is kept iff its hash
     // clears the threshold, and scaled by 1 / (1 - p)   (base.py:139,182)
-    auto dropout_frags = [&](auto rt_c, f32x4 (&y)[decltype(rt_c)::value][WN], unsigned site, int row0) {
+    // (edge sites are keyed on the CALLER's edge id — the same mask whatever plan the step runs on: under a CSR plan the tile's row r
+    //  is edge perm[rs + r], under a tile plan edge rs + r)
+    auto dropout_frags = [&](auto rt_c, f32x4 (&y)[decltype(rt_c)::value][WN], unsigned site, int row0, bool edge_rows) {
         constexpr int RT = decltype(rt_c)::value;
         if constexpr (KEEP) {
             if (g.drop_thr) {  // (uniform)
                 launder();
+                unsigned rowid[RT][4];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lr = rt * 16 + lg * 4 + r;
+                        rowid[rt][r] = (edge_rows && !lean) ? (unsigned)g.perm[rs + (lr < nrows ? lr : 0)] : (unsigned)(row0 + lr);
+                    }
 #pragma unroll
                 for (int ct = 0; ct < WN; ++ct) {
                     const unsigned col = (unsigned)(wave * (16 * WN) + ct * 16 + li);
@@ -559,7 +582,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const unsigned row = (unsigned)(row0 + rt * 16 + lg * 4 + r);
+                            const unsigned row = rowid[rt][r];
                             const bool keep = drop_hash(g.seed_lo, g.seed_hi, site, row, col) >= g.drop_thr;
                             y[rt][ct][r] = keep ? y[rt][ct][r] * g.drop_scale : 0.f;
                         }
@@ -580,6 +603,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                     for (int r = 0; r < 4; ++r) T[(rt * 16 + lg * 4 + r) * LDC + col] = y[rt][ct][r];
             }
         }
+    };
+    // sign bits of C/D fragments -> keep_bits (see Mega16K): 4 RT WN ballots, gathered into the lanes by v_writelane, one 8-byte
+    // store per lane — no LDS, no barrier, 2 KB per tile instead of the tile's fp32 rows
+    auto store_bits = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WN], int slot) {
+        constexpr int RT = decltype(rt_c)::value;
+        static_assert(RT * WN * 4 <= 64, "one word per lane");
+        unsigned lo = 0u, hi = 0u;
+        static_for<0, RT * WN * 4>([&](auto ic) {   // (the lane select of v_writelane_b32 must be an inline constant: one SGPR operand per VALU instruction)
+            constexpr int idx = decltype(ic)::value, r = idx & 3, ct = (idx >> 2) % WN, rt = (idx >> 2) / WN;
+            const unsigned long long b = __ballot(y[rt][ct][r] > 0.f);
+            unsigned l = lo, h = hi;   // (asm operands must be locals of this lambda)
+            const unsigned bl = (unsigned)b, bh = (unsigned)(b >> 32);
+            // (s_nop: an SGPR written by the v_cmp right in front is not yet readable by v_writelane — measured: the low halves came
+            //  out stale without it, scripts/dbg_bits.py; the compiler's hazard recognizer does not look into inline assembly)
+            asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(l) : "s"(bl), "n"(idx));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(h) : "s"(bh), "n"(idx));
+            lo = l; hi = h;
+        });
+        launder();
+        if (lane < RT * WN * 4)
+            G.keep_bits[(long long)slot * G.bits_slot + (long long)t * 256 + wave * 64 + lane] = ((unsigned long long)hi << 32) | lo;
     };
     auto tile_to_global = [&](float* dst, long long row0, int ld, int n_r) {
         launder();
@@ -701,7 +745,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         unscale(RE{}, h0, 1.f / s_prev, cc);
         stamp();  // 3: K1 contraction
     }
-    if (KEEP && g.H0) {  // training: the pre-activation is needed by the backward pass
+    if (KEEP && G.keep_bits) {  // training: the backward pass needs tau'(H0) — for a ReLU-class tau the sign, as bits
+        store_bits(RE{}, h0, 0);
+    } else if (KEEP && g.H0) {  // ... else the pre-activation itself
         __syncthreads();  // (the fp32 tile may overlay the K1 operand tile)
         frag_to_tile(RE{}, h0);
         __syncthreads();
@@ -797,9 +843,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         stamp();  // 5, 7, ...: update contraction
         unscale(RE{}, acc, 1.f / sA, cc);
         act_frags(RE{}, T_{}, acc, h0);  // tau(H0 + W_h(M)): base.py:141
-        dropout_frags(RE{}, acc, (unsigned)(step - 1), rs);  // dropout(H_t): base.py:139 (training, p > 0)
+        dropout_frags(RE{}, acc, (unsigned)(step - 1), rs, true);  // dropout(H_t): base.py:139 (training, p > 0)
         stamp();  // E: unscale + tau
-        if (KEEP && g.Hs) {
+        if (KEEP && G.keep_bits) {
+            store_bits(RE{}, acc, step);
+        } else if (KEEP && g.Hs) {
             __syncthreads();  // (the fp32 tile overlays the split A tile: every wave is past its contraction)
             frag_to_tile(RE{}, acc);
             __syncthreads();
@@ -837,7 +885,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         stamp();  // finalize: V part
         unscale(RA{}, acc, 1.f / sV, cc);
         act_frags(RA{}, F_{}, acc, acc);
-        dropout_frags(RA{}, acc, (unsigned)(T_steps - 1), va);  // dropout(tau(W_o [...])): base.py:182
+        dropout_frags(RA{}, acc, (unsigned)(T_steps - 1), va, false);  // dropout(tau(W_o [...])): base.py:182
         if (maxbits[5]) {  // (uniform; written before the first barrier of the kernel)
 #pragma unroll
             for (int rt = 0; rt < RT_A; ++rt)

@@ -389,7 +389,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             slope: float = 0.0, slope_t: Optional[Tensor] = None, undirected: bool = False,
             keep: bool = False, fused: Optional[bool] = None, route: Optional[str] = None,
             max_level: int = 2, mfma: Optional[str] = None, wcache: Optional[dict] = None,
-            launch: bool = True, form: int = 0, dropout: Optional[tuple] = None, atom: bool = False) -> tuple[Tensor, ForwardState]:
+            launch: bool = True, form: int = 0, dropout: Optional[tuple] = None, atom: bool = False,
+            keep_bits: bool = True) -> tuple[Tensor, ForwardState]:
     """One ``dmpnn_forward`` call.  Routes (``route`` = ``"mega" | "fused" | "general"``, default: the best
     the shapes allow):
 
@@ -512,6 +513,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if not (use_mega and want16 and keep and not d_vd and act in ("relu", "leakyrelu", "prelu")):
             raise RouteUnavailable("dropout inside the kernels: training forward of the tile kernel, ReLU-class activation, no W_d")
         a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
+    bits = None
     st = ForwardState()
     st.fused = use_fused
     st.route = "mega" if use_mega else ("fused16" if use_fused16 else ("fused" if use_fused else "general"))
@@ -612,11 +614,18 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             if not (use_mega and want16 and not d_vd):
                 raise RuntimeError("forward: a tile plan serves a training forward only on the tile kernel (f16 pipe), without W_d")
             a.flags |= F_TILE_PLAN
+            # ... and for a ReLU-class activation without dropout the backward tile kernel needs only the SIGN of H0 / H^(t): one bit
+            # per element straight from the matrix-pipe fragments (2 KB per tile and tensor instead of 57.6 KB of fp32 rows through an
+            # LDS transpose); the fp32 slots stay allocated — a molecule beyond the tile keeps its rows there — but are not touched
+            nbits = int(lib.dmpnn_forward_keep_bits_bytes(C.byref(a))) if keep_bits else 0
+            if nbits:
+                bits = torch.empty(nbits, dtype=torch.uint8, device=dev)
+                a.keep_bits, a.keep_bits_bytes = bits.data_ptr(), nbits
     if launch:  # (launch=False: the argument block and the workspace only — dmpnn_train_step enqueues the forward itself)
         with _OnDevice(dev):
             _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
-    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, split_ms, wsplit)
+    st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, split_ms, bits, wsplit)  # (wsplit last: nn._make_replay)
     st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)
     return out, st
 

@@ -312,13 +312,21 @@ typedef struct dmpnn_fwd_args {
      * with DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (a training forward of the tile kernel), a ReLU-class activation
      * (none / relu / leakyrelu / prelu) and no W_d: dropout_p in (0, 1) zeroes every element of H^(t), t >= 1, and of the
      * finalize output with probability p and scales the rest by 1 / (1 - p).  The mask is a counter-based hash of
-     * (dropout_seed, site, row, column) — site = t - 1 for the update steps, depth - 1 for the finalize; row = the plan's
-     * row (edge sites) / the atom (finalize) — restated in oracle/dropout_hash.py; dmpnn_backward regenerates nothing: the
+     * (dropout_seed, site, row, column) — site = t - 1 for the update steps, depth - 1 for the finalize; row = the CALLER's
+     * edge id (edge sites: the same mask on a CSR plan and on a tile plan) / the atom (finalize) — restated in oracle/dropout_hash.py; dmpnn_backward regenerates nothing: the
      * kept tensors are post-dropout, and for a ReLU-class activation their sign carries the mask.  0: no dropout.
      * Any other route / activation with dropout_p != 0: DMPNN_EINVAL (the caller runs its own dropout between the row kernels). */
     float dropout_p; uint64_t dropout_seed;
+    /* DMPNN_F_TILE_PLAN with a ReLU-class activation (none / relu / leakyrelu) and dropout_p == 0: what the backward tile kernel
+     * needs of H0 and H^(t) is the SIGN of every element (tau' is a step).  With `keep_bits` (>= dmpnn_forward_keep_bits_bytes()
+     * bytes, 16-byte aligned) the forward stores one bit per element — 2 KB per tile and tensor, straight from the matrix-pipe
+     * fragments — instead of the fp32 rows (57.6 KB per tile and tensor through an LDS transpose); H0 / Hs must still be there:
+     * a molecule beyond the tile keeps its fp32 rows in them (the kernels' generic path).  NULL: fp32 rows as before. */
+    void* keep_bits; size_t keep_bits_bytes;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
+/* bytes of `keep_bits` for this forward (0: the forward does not qualify — see the field) */
+size_t dmpnn_forward_keep_bits_bytes(const dmpnn_fwd_args* a);
 /* DMPNN_F_FUSED | DMPNN_F_SPLIT16 (without DMPNN_F_MEGA): the per-step fused route on the f16 matrix pipe — inference
  * forward of batches of ANY molecule size (d_h <= 640): one launch per depth step, the message tensor kept between the
  * steps as SPLIT rows (per row: chunks of [hi 32 halfs | lo 32 halfs] + a 16-byte tail with the row's power-of-two scale;

@@ -910,6 +910,40 @@ def test_backward_full_size_vs_oracle_autograd(n_mols, kind, kw, gpu_device):
         assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
+@pytest.mark.parametrize("n_mols,act,depth,d_h,mixed", [(512, "relu", 3, 300, False), (200, "leakyrelu", 4, 128, False), (96, "relu", 2, 64, False),
+                                                       (40, "relu", 3, 300, True), (64, "relu", 1, 300, False)])
+def test_kept_sign_bits_give_the_same_gradients_as_kept_rows(n_mols, act, depth, d_h, mixed, gpu_device):
+    """dmpnn_fwd_args.keep_bits: on a tile plan with a ReLU-class activation the training forward keeps H0 / H^(t) as ONE bit per
+    element ([x > 0], straight from the matrix-pipe fragments) instead of fp32 rows.  tau' only ever looked at that sign: every
+    gradient is BIT-IDENTICAL to the run that kept the rows — at any size, kinks or not (a molecule beyond the tile keeps fp32 rows
+    either way: the kernels' generic path)."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = _mixed_batch(n_mols, "synth40", 33) if mixed else synth.random_batch(n_mols, "qm9", seed=33)
+    bmg.to(gpu_device)
+    torch.manual_seed(8)
+    mp = BondMessagePassing(d_h=d_h, depth=depth, activation=act, bias=True).to(gpu_device)
+    slope = 0.1 if act == "leakyrelu" else 0.0
+    G = torch.randn(bmg.V.shape[0], d_h, device=gpu_device)
+    need = {k: True for k in ("W_i", "b_i", "W_h", "b_h", "W_o", "b_o")}
+    res = []
+    for bits in (True, False):
+        plan = engine.GraphPlan.from_bmg(bmg, light="tiles")
+        assert plan.tiles_only
+        out, st = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, mp.W_i.bias, mp.W_h.bias,
+                                 depth=depth, act=act, slope=slope, keep=True, keep_bits=bits)
+        assert st.route == "mega16" and bool(st.args.keep_bits) == bits
+        grads = engine.backward(st, G, need)
+        grads = grads[0] if isinstance(grads, tuple) else grads
+        torch.cuda.synchronize()
+        res.append((out.clone(), {k: v.clone() for k, v in grads.items() if v is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[1][1]:
+        assert torch.isfinite(res[0][1][k]).all(), k
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 def _mixed_batch(n_small, big_kind, seed):
     """QM9-shaped molecules with ONE molecule beyond the tile in the middle, as bare tensors (``oversize`` unknown to the host)."""
     from chemprop_amd import synth
