@@ -281,7 +281,10 @@ def test_fused_dropout_on_the_tile_kernels_given_its_masks(n_mols, kw, p, gpu_de
     # (ReLU is the only activation class with dropout in the kernels, so this comparison cannot be made smooth: at 2 048 molecules —
     #  37 M activations — a pre-activation within 1e-7 of the kink flips between two fp32-class arithmetics and moves a gradient entry
     #  by ~1e-3 of the largest one; up to 512 molecules the fp32 bar holds)
-    bar = 2e-5 if n_mols <= 512 else 2e-3
+    # (measured at 2 048 molecules, scripts/dbg_drop2048b.py: the same step on the CSR plan and on the tile plan — identical kept tensors,
+    #  outputs 2.6e-7 apart — differ by ONE or two finalize units whose pre-activation sits within 1e-8 of zero: sum(gb_o) 378.106 vs 376.325,
+    #  3e-3 of the largest entry of gW_o; the reference sides with one of them by chance)
+    bar = 2e-5 if n_mols <= 512 else 1e-2
     for k, prm in mp.named_parameters():
         err = parity_err(prm.grad.cpu().numpy(), named_ref[k].grad.numpy())
         assert err <= bar, f"{k}: {err:.3e}"
