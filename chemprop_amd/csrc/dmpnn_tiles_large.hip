@@ -2,9 +2,9 @@
 // the batch vector (BatchMolGraph.batch, data/collate.py:52,62: the molecule id of every atom, non-decreasing), by three
 // small multi-workgroup launches instead of one workgroup's LDS:
 //
-//   k_large_bounds   one thread per molecule m: first atom  aoff[m] = lower_bound(batch, m)  and first directed edge
-//                    eoff[m] = lower_bound_e(batch[dst[e]], m)  (edges of a molecule are contiguous and in molecule
-//                    order, collate.py:51-56); latency bound: ~2 x 18 dependent L2 reads per thread, all molecules in parallel;
+//   k_large_bounds   one thread per atom / edge: first atom aoff[m] and first directed edge eoff[m] of every molecule from the
+//                    boundaries of batch[.] and batch[dst[.]]  (edges of a molecule are contiguous and in molecule order,
+//                    collate.py:51-56), gaps (molecules without edges) filled by the boundary thread;
 //   k_large_blocks   one wave per block of 64 consecutive molecules: lane l holds "the furthest molecule that still fits a
 //                    tile started at molecule base + l" (<= 48 directed edges, <= 32 atoms), the chain of tile starts of
 //                    the block is walked with v_readlane hops (a tile starts at every block start: at most one
@@ -51,31 +51,41 @@ __device__ __forceinline__ int mol_count(const long long* __restrict__ batch, in
     return last < 0 ? 0 : (last >= nV ? nV : (int)last + 1);
 }
 
+// One thread per atom and per edge instead of two binary searches per molecule (2 x 18 DEPENDENT L2 reads: 25 us at 4 096
+// molecules, as long as the two kernels behind it together): an atom whose molecule differs from its predecessor's IS that
+// molecule's first atom; the same for an edge through the molecule of its destination atom.  Molecules without atoms / edges in
+// between (a single atom has no edge) take the offset of the next boundary: the boundary thread fills the gap.  For a batch
+// vector that is not non-decreasing some entries stay unwritten or contradict each other — k_large_blocks flags offsets that are
+// not monotone, and whatever table comes out of the rest is checked by the tile kernel itself (closure, ranges).
 __global__ __launch_bounds__(256) void k_large_bounds(const long long* __restrict__ batch, const long long* __restrict__ dst, int nV,
                                                       int nE, int* __restrict__ plan, LargeScratch S) {
     const int n_mols = mol_count(batch, nV);
     int* aoff = plan + S.aoff;
     int* eoff = plan + S.eoff;
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m <= n_mols; m += gridDim.x * blockDim.x) {
-        int a = nV, e = nE;
-        if (m < n_mols) {
-            int lo = 0, hi = nV;  // first atom with batch[.] >= m
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (batch[mid] < m) lo = mid + 1; else hi = mid;
-            }
-            a = lo;
-            lo = 0; hi = nE;      // first edge whose destination atom belongs to a molecule >= m
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                long long d = dst[mid];
-                d = d < 0 ? 0 : (d >= nV ? nV - 1 : d);  // (an id out of range: the tile kernel flags the edge itself)
-                if (batch[d] < m) lo = mid + 1; else hi = mid;
-            }
-            e = lo;
+    auto mol_of_atom = [&](int v) -> long long {
+        const long long m = batch[v];
+        return m < 0 ? 0 : (m >= n_mols ? n_mols - 1 : m);
+    };
+    auto mol_of_edge = [&](int e) -> long long {
+        long long d = dst[e];
+        d = d < 0 ? 0 : (d >= nV ? nV - 1 : d);  // (an id out of range: the tile kernel flags the edge itself)
+        return mol_of_atom((int)d);
+    };
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= (nV > nE ? nV : nE); i += stride) {
+        if (i < nV) {
+            const long long m = mol_of_atom(i), pm = i > 0 ? mol_of_atom(i - 1) : -1;
+            for (long long mm = pm + 1; mm <= m; ++mm) aoff[mm] = i;   // (empty unless i is a boundary; one iteration for a dense batch vector)
+        } else if (i == nV) {
+            aoff[n_mols] = nV;
         }
-        aoff[m] = a;
-        eoff[m] = e;
+        if (i < nE) {
+            const long long m = mol_of_edge(i), pm = i > 0 ? mol_of_edge(i - 1) : -1;
+            for (long long mm = pm + 1; mm <= m; ++mm) eoff[mm] = i;
+        } else if (i == nE) {
+            const long long pm = nE > 0 ? mol_of_edge(nE - 1) : -1;
+            for (long long mm = pm + 1; mm <= n_mols; ++mm) eoff[mm] = nE;   // molecules behind the last edge (and the end marker)
+        }
     }
 }
 
@@ -185,7 +195,7 @@ int launch_prepare_tiles_large(const int64_t* edge_index, const int64_t* batch, 
     const LargeScratch S = large_scratch(L, nV);
     const long long* b = reinterpret_cast<const long long*>(batch);
     const long long* dst = reinterpret_cast<const long long*>(edge_index) + nE;
-    int blocks = (nV + 1 + 255) / 256;  // (n_mols <= nV is only known on the device)
+    int blocks = ((nV > nE ? nV : nE) + 1 + 255) / 256;  // (one thread per atom / edge)
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_large_bounds, dim3((unsigned)blocks), dim3(256), 0, s, b, dst, nV, nE, plan, S);
     DMPNN_CHECK_LAUNCH("k_large_bounds");
