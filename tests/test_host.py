@@ -292,3 +292,46 @@ def test_dropout_hash_restatement_is_the_library_s_and_behaves_like_bernoulli():
             assert abs((a & b).mean() - (1 - p) ** 2) <= 6 / np.sqrt(a.size) + 1e-3      # independent: P(both kept) = (1 - p)^2
         assert abs(m0.mean(axis=0).std() - np.sqrt(p * (1 - p) / 4096)) <= 0.3 * np.sqrt(p * (1 - p) / 4096)   # columns look alike
     assert np.array_equal(dh.keep_mask(9, 0, 50, 64, 0.3), dh.keep_mask(9, 0, 50, 64, 0.3))      # a function of its arguments
+
+
+def test_training_plan_kind_is_a_host_rule(monkeypatch):
+    """``nn._training_plan_kind``: which plan a TRAINING forward asks for — the tile table (``DMPNN_F_TILE_PLAN``) after the validated
+    first batches for blocks and batches bound for the tile kernels, the full CSR plan otherwise.  Pure host logic (shapes, dtypes,
+    module attributes): enumerated here without a GPU."""
+    import torch
+
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph
+    from chemprop_amd.nn import BondMessagePassing, _training_plan_kind, _VALIDATE_FIRST_N
+
+    qm9 = synth.random_batch(64, "qm9", seed=1)
+    big = synth.random_batch(8, "synth40", seed=1)            # molecules beyond the tile: the host's batching code knows (oversize True)
+    mp = BondMessagePassing().train()
+    assert _training_plan_kind(mp, qm9) is False               # the first batches of a module are validated on full plans
+    object.__setattr__(mp, "_dmpnn_batches_checked", _VALIDATE_FIRST_N)
+    assert _training_plan_kind(mp, qm9) == "tiles"
+    assert _training_plan_kind(mp, big) is False
+    bare = BatchMolGraph.from_tensors(qm9.V, qm9.E, qm9.edge_index, qm9.rev_edge_index, qm9.batch, len(qm9))
+    assert _training_plan_kind(mp, bare) == "tiles"            # (oversize unknown: the kernels' generic path covers what turns up)
+    monkeypatch.setenv("DMPNN_TRAIN_PLAN", "full")
+    assert _training_plan_kind(mp, qm9) is False
+    monkeypatch.delenv("DMPNN_TRAIN_PLAN")
+    monkeypatch.setenv("DMPNN_VALIDATE", "always")             # (the per-batch verdict is read from a full plan)
+    assert _training_plan_kind(mp, qm9) is False
+    monkeypatch.delenv("DMPNN_VALIDATE")
+    # blocks the tile kernels' backward does not take on a tile plan
+    for kw in (dict(undirected=True), dict(d_vd=4), dict(activation="prelu"), dict(activation=torch.nn.Softplus()), dict(d_h=302),
+               dict(d_h=512), dict(dropout=0.2, activation="tanh")):
+        m2 = BondMessagePassing(**kw).train()
+        object.__setattr__(m2, "_dmpnn_batches_checked", _VALIDATE_FIRST_N)
+        assert _training_plan_kind(m2, qm9) is False, kw
+    m3 = BondMessagePassing(dropout=0.2).train()               # ReLU + nn.Dropout: dropout inside the tile kernels
+    object.__setattr__(m3, "_dmpnn_batches_checked", _VALIDATE_FIRST_N)
+    assert _training_plan_kind(m3, qm9) == "tiles"
+    for p in (mp.W_i.weight, mp.W_h.weight):                    # nothing to differentiate in the edge part: the tile backward would refuse
+        p.requires_grad_(False)
+    assert _training_plan_kind(mp, qm9) is False
+    mp.W_h.weight.requires_grad_(True)
+    assert _training_plan_kind(mp, qm9) == "tiles"
+    object.__setattr__(mp, "_dmpnn_no_mega", True)             # a module that keeps meeting oversize molecules
+    assert _training_plan_kind(mp, qm9) is False
