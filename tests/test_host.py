@@ -335,3 +335,35 @@ def test_training_plan_kind_is_a_host_rule(monkeypatch):
     assert _training_plan_kind(mp, qm9) == "tiles"
     object.__setattr__(mp, "_dmpnn_no_mega", True)             # a module that keeps meeting oversize molecules
     assert _training_plan_kind(mp, qm9) is False
+
+
+def test_keep_bits_bytes_is_a_shape_rule():
+    """``dmpnn_forward_keep_bits_bytes`` (include/dmpnn.h): depth x tile bound x 2 KB for a training forward of the tile kernel on a tile
+    plan with a ReLU-class activation and no dropout / W_d — 0 for everything else (the caller then keeps fp32 rows)."""
+    import ctypes as C
+
+    from chemprop_amd import _lib
+
+    lib = _lib.load()
+    need = _lib.F_TILE_PLAN | _lib.F_KEEP | _lib.F_MEGA | _lib.F_SPLIT16 | _lib.F_FUSED
+
+    def args(flags=need, act="relu", p=0.0, depth=3, nV=4636, nE=9120, wd=0):
+        a = _lib.FwdArgs()
+        a.n_atoms, a.n_edges, a.d_v, a.d_e, a.d_h, a.depth, a.flags = nV, nE, 72, 14, 300, depth, flags
+        a.act, a.dropout_p, a.W_d = _lib.ACT[act], p, wd
+        return a
+
+    off = (C.c_int64 * _lib.PLAN_NOFFSETS)()
+    assert lib.dmpnn_plan_layout(4636, 9120, off) == 0
+    tiles = int(lib.dmpnn_max_tiles(4636, 9120)) if hasattr(lib, "dmpnn_max_tiles") else None
+    n = int(lib.dmpnn_forward_keep_bits_bytes(C.byref(args())))
+    assert n > 0 and n % (3 * 2048) == 0                         # depth slots of 2 KB per tile of the launch bound
+    if tiles:
+        assert n >= 3 * 2048 * (9120 // 48)                        # ... which covers every tile the batch can have
+    assert int(lib.dmpnn_forward_keep_bits_bytes(C.byref(args(depth=5)))) == n // 3 * 5
+    for a in (args(act="leakyrelu"), args(act="none") if "none" in _lib.ACT else args()):
+        assert int(lib.dmpnn_forward_keep_bits_bytes(C.byref(a))) == n
+    for a in (args(flags=need & ~_lib.F_TILE_PLAN), args(flags=need & ~_lib.F_KEEP), args(act="tanh"), args(act="elu"), args(p=0.1),
+              args(wd=4096), args(nE=0), args(nV=0)):
+        assert int(lib.dmpnn_forward_keep_bits_bytes(C.byref(a))) == 0
+    assert int(lib.dmpnn_forward_keep_bits_bytes(None)) == 0
