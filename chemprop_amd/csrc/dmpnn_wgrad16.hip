@@ -253,7 +253,10 @@ bool wgrad16_operand_ok(const float* A1, int64_t lda1, int K1, const float* A2, 
 WProdPlan plan_wgrad16(int64_t M, int N, int Kt) {
     WProdPlan p;
     p.n_nt = (N + 63) / 64; p.n_kt = (Kt + 63) / 64; p.n_chunks = (int)((M + 31) / 32);
-    constexpr int target = 768;  // workgroups of a product launch (3 per CU: measured best of {256 .. 1536})
+    // workgroups of a product launch: 3 per CU for long reductions (measured best of {256 .. 1536} at 36 000+ rows); 2 per CU up to
+    // 768 chunks (24 576 rows: the 512-molecule training step) — fewer row splits are fewer slabs for the reduce kernel, which is the
+    // larger effect there (block step 185.6 -> 180.2 us, model step 240.2 -> 234.7; at 355 702 rows 512 would cost 3 %: scripts/r3_ab_train.sh)
+    const int target = p.n_chunks <= 768 ? 512 : 768;
     int splits = target / (p.n_nt * p.n_kt);
     if (splits < 1) splits = 1;
     int cps = (p.n_chunks + splits - 1) / splits;
