@@ -367,6 +367,8 @@ def _spill_monitor(mp, plan_buf: Tensor, dev) -> None:
     generic path).  Now and then the header of a tile plan is copied to pinned host memory WITHOUT a sync and read at a
     later forward; a module that keeps meeting oversize molecules is moved to the per-step routes, whose time does not
     hinge on the slowest molecule."""
+    if torch.cuda.is_current_stream_capturing():
+        return  # (nothing of this — pinned allocation, event query, copy — belongs into a hipGraph capture)
     m = mp.__dict__.get("_dmpnn_mon")
     if m is None:
         m = _Monitor()

@@ -793,6 +793,12 @@ def test_steady_forward_under_hipgraph_capture(warm, gpu_device):
         g.replay()
         torch.cuda.synchronize(gpu_device)
         assert torch.equal(out, eager)
+        g3 = torch.cuda.CUDAGraph()      # several steps as ONE graph (bench.py's K-steps-per-launch leg): every step keeps its own output
+        with torch.cuda.graph(g3):
+            outs = [mp(b) for _ in range(3)]
+        g3.replay()
+        torch.cuda.synchronize(gpu_device)
+        assert all(torch.equal(o, eager) for o in outs) and len({o.data_ptr() for o in outs}) == 3
         for _ in range(20):
             assert torch.equal(mp(b), eager)      # and the eager path (monitor included) goes on working afterwards
 
