@@ -33,6 +33,10 @@
 extern "C" {
 #endif
 
+/* ABI history (dmpnn_version()): 8 — round 3: dmpnn_head / dmpnn_train_step, active dropout (dmpnn_fwd_args.dropout_p / dropout_seed),
+ * DMPNN_F_ATOM, the route rule (dmpnn_forward_route).  9 — end of round 3: dmpnn_head_args.bn_num_batches_tracked, DMPNN_F_TILE_PLAN
+ * (training on a tile plan), dmpnn_fwd_args.keep_bits / keep_bits_bytes + dmpnn_forward_keep_bits_bytes.  Structs only ever grow at
+ * their end; a host built against another version is refused by its own check of dmpnn_version() (chemprop_amd/_lib.py). */
 #define DMPNN_ABI_VERSION 9
 
 enum dmpnn_status {
