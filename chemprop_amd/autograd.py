@@ -48,7 +48,11 @@ def mp_forward(mp, plan: engine.GraphPlan, V: Tensor, E: Tensor, V_d: Optional[T
                     "(the reference never asks for it: features are data)")
     p = _params(mp)
     has_vd = mp.W_d is not None and V_d is not None
-    if drop_active and grad and act in ("relu", "leakyrelu") and not has_vd and max_level >= 2 and type(mp.dropout) is torch.nn.Dropout:
+    # (the dropout scale of the backward pass lives in the backward TILE kernel, which only runs when a gradient of W_i or W_h is
+    #  wanted: a block with both frozen — W_o alone trainable — keeps the rows route)
+    edge_grad = any(t is not None and t.requires_grad for t in (p["W_i"], p["b_i"], p["W_h"], p["b_h"]))
+    if (drop_active and grad and edge_grad and act in ("relu", "leakyrelu") and not has_vd and max_level >= 2
+            and type(mp.dropout) is torch.nn.Dropout):
         # ACTIVE dropout inside the tile kernels (round 3): the mask is a counter-based hash of (seed, site, row, column), the seed
         # one draw from torch's CPU generator (so torch.manual_seed fixes the run); a batch that takes another route falls
         # through to the rows route below, where the block's own nn.Dropout runs between the kernels (as does any module that is not

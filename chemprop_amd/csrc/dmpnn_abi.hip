@@ -346,7 +346,7 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     if (a->dropout_p != 0.f) {
         DMPNN_CHECK_ARG(a->dropout_p > 0.f && a->dropout_p < 1.f, "forward: dropout_p must lie in [0, 1)");
         const bool tile_train = (a->flags & DMPNN_F_MEGA) && (a->flags & DMPNN_F_SPLIT16) && (a->flags & DMPNN_F_KEEP);
-        DMPNN_CHECK_ARG(tile_train && !has_vd && (a->act == DMPNN_ACT_RELU || a->act == DMPNN_ACT_LEAKYRELU || a->act == DMPNN_ACT_PRELU),
+        DMPNN_CHECK_ARG(tile_train && !has_vd && (a->act == DMPNN_ACT_RELU || a->act == DMPNN_ACT_LEAKYRELU),
                         "forward: dropout inside the kernels needs the training forward of the tile kernel (DMPNN_F_MEGA | DMPNN_F_SPLIT16 | "
                         "DMPNN_F_KEEP), a ReLU-class activation and no W_d — run dropout between the row kernels otherwise");
     }

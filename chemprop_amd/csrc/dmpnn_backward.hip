@@ -831,7 +831,13 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         DMPNN_TRY(launch_linear(g, s));
         gHO_p = gHO; ld_gHO = ldh;
     }
-    if (L.mega && (b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO)) {
+    const bool tile_bwd = L.mega && (b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO);
+    // in-kernel dropout (dmpnn_fwd_args.dropout_p): its 1 / (1 - p) lives in the backward TILE kernel alone — every other branch below
+    // would return gradients without it, silently
+    DMPNN_CHECK_ARG(!(f.dropout_p > 0.f) || tile_bwd,
+                    "backward: the forward ran with dropout inside the kernels; only the backward tile kernel carries its scale — it needs a "
+                    "gradient of W_i or W_h to be wanted and 16-byte aligned gout / out (leading dimensions multiples of 4)");
+    if (tile_bwd) {
         // ---- the whole data-gradient chain in one launch, then the four weight gradients ----
         DMPNN_CHECK_ARG(f.H0 && (T == 1 || f.Hs), "backward: the tile-kernel forward did not keep H0 / H^(t)");
         float* gZs = (T - 1 > 2) ? ws + L.gZs : gZa;  // slot t-1 = gZ^(t)

@@ -473,6 +473,9 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     DMPNN_CHECK_ARG(h.loss == DMPNN_LOSS_MSE || h.loss == DMPNN_LOSS_MAE, "head: unknown criterion %d", h.loss);
     DMPNN_CHECK_ARG(h.preds && (nV == 0 || (Hv && h.batch)), "head: null H_v / batch / preds");
     DMPNN_CHECK_ARG(!h.bn_weight || (h.bn_running_mean && h.bn_running_var), "head: batch norm without running statistics");
+    // (torch.nn.BatchNorm1d in training mode — hence the reference — raises "Expected more than 1 value per channel": a batch of one
+    //  molecule has no variance, and the output would silently be beta)
+    DMPNN_CHECK_ARG(!(h.bn_weight && h.bn_training) || B != 1, "head: batch norm in training mode needs more than 1 molecule per batch");
     const bool want_grad = h.gHv != nullptr;
     DMPNN_CHECK_ARG(!want_grad || (h.targets && h.loss_out && h.ldg >= d), "head: gradients need targets, loss_out and ldg >= d_h");
     const HeadLayout L = head_layout(h);

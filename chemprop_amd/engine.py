@@ -480,6 +480,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         level = 0 if (route == "general" or undirected) else int(lib.dmpnn_forward_can_fuse(C.byref(a)))
         if route == "fused" or _lib.opt("DMPNN_MEGA", "1") == "0":
             level = min(level, 1)
+        if route is None:  # (`fused=` / `mfma=` alone demand an arithmetic, not a route: the caller's cap still holds)
+            level = min(level, int(max_level))
         if (fused is True or route in ("fused", "mega")) and level < (2 if route == "mega" else 1):
             raise RuntimeError(f"forward: route {route or 'fused'!r} requested but the shapes do not allow it "
                                "(fused: d_h % 4 == 0, d_h <= 320, even d_v / d_e, directed; mega: additionally a batch within the "
@@ -510,7 +512,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             raise RouteUnavailable("atom messages inside the kernels: inference forward of the tile kernel, 1 <= d_e <= 16, no W_d")
         a.flags |= _lib.F_ATOM
     if dropout is not None and float(dropout[0]) > 0.0:
-        if not (use_mega and want16 and keep and not d_vd and act in ("relu", "leakyrelu", "prelu")):
+        if not (use_mega and want16 and keep and not d_vd and act in ("relu", "leakyrelu")):
             raise RouteUnavailable("dropout inside the kernels: training forward of the tile kernel, ReLU-class activation, no W_d")
         a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
     bits = None

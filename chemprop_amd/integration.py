@@ -141,7 +141,139 @@ def hip_mlp_class():
     return _mlp_cache
 
 
+_mpnn_cache = None
+
+
+def hip_mpnn_class():
+    """Build (once) ``class HipMPNN(chemprop.models.MPNN)``: the reference's LightningModule whose ``training_step``
+    (``models/model.py:148-161``) + optimizer step (``:208-231``) is ONE ``dmpnn_train_step`` call per batch.
+
+    * ``automatic_optimization = False`` (Lightning's manual optimization): the step — K0, block forward, aggregation, batch norm,
+      predictor, criterion, the backward pass of all of it, Adam — is enqueued by :class:`chemprop_amd.model.FusedTrainer`; the
+      parameters live in ONE flat buffer (``optim.FlatAdam``: ``torch.optim.Adam``'s arithmetic as one launch), the gradients in
+      another (``distributed.GradSync``: with more than one rank the step exchanges them itself over ``torch.distributed``'s
+      default group, in two slices, so run one process per GPU with a strategy that does NOT wrap the module in DDP).
+    * ``configure_optimizers`` is inherited: the reference's ``Adam`` + Noam-like ``LambdaLR`` (``schedulers.py``) stay the source
+      of the learning rate — every step reads ``optimizer.param_groups[0]["lr"]`` and advances the scheduler — but the torch
+      optimizer itself is never stepped.  The moments travel in the checkpoint under ``"hip_flat_adam"``
+      (``on_save_checkpoint`` / ``on_load_checkpoint``).
+    * What the fused step does not implement (``FusedTrainer`` refuses loudly: classification / MVE / evidential heads, predictor
+      dropout, ``V_d`` / ``X_d`` inputs, attentive aggregation, atom / mol-atom-bond blocks) trains through the MODULE path in the
+      same ``training_step``: the reference's own arithmetic (``super().training_step``) through autograd on the HIP kernels,
+      ``loss.backward()``, the same flat Adam.
+    * everything else — ``forward``, ``fingerprint``, ``validation_step``, ``predict_step``, ``load_from_checkpoint``, hparams,
+      state-dict keys — is the reference's, untouched; the blocks inside are swapped for their HIP subclasses (:func:`accelerate`).
+    """
+    global _mpnn_cache
+    if _mpnn_cache is not None:
+        return _mpnn_cache
+    try:
+        from chemprop.models.model import MPNN as Ref  # noqa: WPS433
+    except Exception as e:  # pragma: no cover
+        raise ImportError("chemprop_amd.integration needs an importable `chemprop`") from e
+
+    class HipMPNN(Ref):  # type: ignore[misc, valid-type]
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.automatic_optimization = False
+            accelerate(self)
+            self.__dict__["_hip"] = None          # (trainer state: built lazily on the device the module was moved to)
+            self.__dict__["_hip_adam_state"] = None
+
+        # ---- the flat optimizer state shared by the fused step and the module path ----
+        def _hip_state(self):
+            st = self.__dict__.get("_hip")
+            dev = next(self.parameters()).device
+            if st is not None and st["dev"] == dev:
+                return st
+            from .distributed import GradSync
+            from .model import FusedTrainer
+            from .optim import FlatAdam
+
+            st = {"dev": dev, "fused": None, "why": None}
+            try:
+                tr = FusedTrainer(self, lr=float(self.init_lr))
+                st["fused"], st["sync"], st["opt"] = tr, tr.sync, tr.opt
+            except NotImplementedError as e:   # (a model the fused step does not implement: module path on the same flat Adam)
+                st["why"] = str(e)
+                st["sync"] = GradSync([p for p in self.parameters() if p.requires_grad], modules=[self])
+                st["opt"] = FlatAdam(st["sync"], lr=float(self.init_lr))
+            saved = self.__dict__.get("_hip_adam_state")
+            if saved is not None:
+                st["opt"].load_state_dict(saved)
+                self.__dict__["_hip_adam_state"] = None
+            self.__dict__["_hip"] = st
+            return st
+
+        def _hip_lr_and_sched(self):
+            """The reference's schedule as the source of this step's learning rate (``configure_optimizers``: Adam + LambdaLR)."""
+            try:
+                opt, sch = self.optimizers(), self.lr_schedulers()
+            except Exception:   # (no trainer attached: a bare loop drives training_step)
+                return float(self.init_lr), None
+            if isinstance(opt, (list, tuple)):
+                opt = opt[0]
+            if isinstance(sch, (list, tuple)):
+                sch = sch[0]
+            return float(opt.param_groups[0]["lr"]), sch
+
+        def training_step(self, batch, batch_idx):
+            bmg, V_d, X_d, targets, weights, lt_mask, gt_mask = batch
+            st = self._hip_state()
+            lr, sch = self._hip_lr_and_sched()
+            loss = None
+            tr = st["fused"]
+            if tr is not None and V_d is None and X_d is None and self.training:
+                try:
+                    out = tr.step(bmg, targets, weights, lt_mask, gt_mask, lr=lr)
+                    loss = out[0]
+                    st["route"] = "fused:" + str(tr.last_route)
+                except NotImplementedError as e:   # (a batch the fused step refuses, e.g. dropout on a batch beyond the tile kernels)
+                    st["why"] = str(e)
+            if loss is None:
+                # the module path: the reference's own training_step arithmetic through autograd, the same flat Adam
+                sync, opt = st["sync"], st["opt"]
+                sync.wait()
+                sync.zero_grad()
+                l = Ref.training_step(self, batch, batch_idx)
+                l.backward()
+                sync.allreduce()
+                opt.step(lr)
+                loss = l.detach()
+                st["route"] = "module"
+            if sch is not None:
+                sch.step()
+            # (the reference logs the criterion Metric object — epoch value = sum L / sum mask; the batch's scalar weighted by the
+            #  batch size is the same number whenever no target is missing)
+            self.log("train_loss", loss, batch_size=len(bmg), prog_bar=True, on_epoch=True)
+            return loss
+
+        # ---- the flat Adam's moments in Lightning's checkpoint ----
+        def on_save_checkpoint(self, checkpoint) -> None:
+            st = self.__dict__.get("_hip")
+            if st is not None:
+                checkpoint["hip_flat_adam"] = {k: (v.cpu() if hasattr(v, "cpu") else v) for k, v in st["opt"].state_dict().items()}
+
+        def on_load_checkpoint(self, checkpoint) -> None:
+            sd = checkpoint.get("hip_flat_adam")
+            if sd is not None:
+                self.__dict__["_hip_adam_state"] = sd
+                self.__dict__["_hip"] = None
+
+        def _apply(self, fn, *args, **kwargs):
+            st = self.__dict__.get("_hip")
+            if st is not None:   # (a device move re-creates the flat buffers: carry the moments over)
+                self.__dict__["_hip_adam_state"] = {k: (v.cpu() if hasattr(v, "cpu") else v) for k, v in st["opt"].state_dict().items()}
+                self.__dict__["_hip"] = None
+            return super()._apply(fn, *args, **kwargs)
+
+    _mpnn_cache = (Ref, HipMPNN)
+    return _mpnn_cache
+
+
 def __getattr__(name):
+    if name == "HipMPNN":
+        return hip_mpnn_class()[1]
     if name == "HipMLP":
         return hip_mlp_class()[1]
     if name == "HipBondMessagePassing":

@@ -130,6 +130,39 @@ class MPNN(nn.Module):
         return masked_loss(preds, targets, weights, getattr(c, "task_weights", None), lt_mask, gt_mask, getattr(c, "kind", "mse"))
 
 
+def _mro_names(obj) -> set:
+    return {c.__name__ for c in type(obj).__mro__}
+
+
+def aggregation_mode(agg) -> Optional[str]:
+    """``"sum" | "mean" | "norm"`` for this package's aggregations (``.mode``) and for the reference's own classes / their HIP
+    subclasses (``chemprop/nn/agg.py:66-113``, told by class name); ``None`` for anything else (attentive, custom)."""
+    mode = getattr(agg, "mode", None)
+    if mode in MODES:
+        return mode
+    names = _mro_names(agg)
+    for cls, m in (("NormAggregation", "norm"), ("MeanAggregation", "mean"), ("SumAggregation", "sum")):  # (Norm derives from Sum)
+        if cls in names:
+            return m
+    return None
+
+
+def criterion_kind(crit) -> tuple[Optional[str], bool]:
+    """``(kind, bounded)``: ``"mse" | "mae"`` and whether the criterion applies ``lt_mask`` / ``gt_mask``.  This package's criteria
+    carry ``.kind`` (bounded iff masks are handed over); the reference's are told by class name — ``MSE`` / ``MAE`` ignore the masks
+    (``nn/metrics.py:139-150``), ``BoundedMSE`` / ``BoundedMAE`` apply them (``:158-177``); RMSE, MVE, ... are not built in."""
+    kind = getattr(crit, "kind", None)
+    if kind in _lib.LOSS:
+        return kind, True
+    names = _mro_names(crit)
+    if "RMSE" in names:
+        return None, False
+    for cls, k in (("MSE", "mse"), ("MAE", "mae")):
+        if cls in names:
+            return k, "BoundedMixin" in names
+    return None, False
+
+
 class FusedTrainer:
     """``training_step`` + ``Adam.step`` of an :class:`MPNN` as one ``dmpnn_train_step`` call per batch.
 
@@ -156,8 +189,8 @@ class FusedTrainer:
             # (active dropout lives inside the tile kernels for ReLU-class activations: dmpnn_fwd_args.dropout_p; a dropout module
             #  that is not exactly nn.Dropout has its own semantics and stays on the module path)
             raise NotImplementedError("FusedTrainer: dropout inside the block needs nn.Dropout and a ReLU / LeakyReLU activation")
-        mode = getattr(agg, "mode", None)
-        if mode not in MODES:
+        mode = aggregation_mode(agg)
+        if mode is None:
             raise NotImplementedError(f"FusedTrainer: sum / mean / norm aggregation (got {type(agg).__name__})")
         blocks = list(pred.ffn)
         if len(blocks) > _lib.MAX_FFN_LAYERS:
@@ -168,11 +201,14 @@ class FusedTrainer:
             if code in ("custom", "prelu") or b[1].p > 0:
                 raise NotImplementedError("FusedTrainer: predictor with a built-in activation (not PReLU) and dropout 0")
             f_act, f_slope = code, sl
-        if not isinstance(pred.output_transform, nn.Identity):
+        # (the reference's UnscaleTransform IS the identity in training mode, transforms.py:45-50: what a scaled regression run carries)
+        if not (isinstance(pred.output_transform, nn.Identity) or "UnscaleTransform" in _mro_names(pred.output_transform)):
             raise NotImplementedError("FusedTrainer: the output transform is the identity while training (predictors.py:166-169)")
-        kind = getattr(pred.criterion, "kind", None)
-        if kind not in _lib.LOSS:
-            raise NotImplementedError("FusedTrainer: MSE / MAE criterion")
+        if getattr(pred, "n_targets", 1) != 1:
+            raise NotImplementedError("FusedTrainer: one value per task (regression); MVE / evidential / quantile heads train through the module path")
+        kind, self.bounded = criterion_kind(pred.criterion)
+        if kind is None:
+            raise NotImplementedError("FusedTrainer: MSE / MAE criterion (bounded or not)")
         self.model, self.mp = model, mp
         self.act, self.slope = act, slope
         self.agg_mode, self.agg_norm = MODES[mode], float(getattr(agg, "norm", 1.0))
@@ -208,31 +244,37 @@ class FusedTrainer:
         d = torch.distributed
         return d.get_world_size(self.sync.group) if (d.is_available() and d.is_initialized()) else 1
 
-    def prefetch_plan(self, bmg) -> None:
-        """K0 of the NEXT step, issued now on a side stream (:func:`chemprop_amd.nn.prefetch_plan`): called right BEFORE
-        ``step(batch_n)`` with the batch the loader already holds for step n + 1 (the side stream first waits for what is queued
-        on the current stream — in front of step n that is step n - 1), the plan kernel (one workgroup, 29 µs at 512 molecules)
-        runs beside step n's kernels and ``step(batch_{n+1})`` skips its own.  A prefetched plan is used once and only by the batch
-        it was built for (same index tensors); two are held at most."""
-        from .nn import prefetch_plan
-        prefetch_plan(self.mp, bmg)
-
     def step(self, bmg, targets: Tensor, weights: Optional[Tensor] = None, lt_mask: Optional[Tensor] = None,
              gt_mask: Optional[Tensor] = None, lr: Optional[float] = None) -> Tensor:
         """One optimisation step on ``(bmg, targets, ...)`` (a ``TrainingBatch`` without ``V_d`` / ``X_d``); returns the device
         tensor ``[loss, number of finite targets]`` of THIS step (no host sync).  ``model.train()`` semantics (batch norm uses
         and updates batch statistics)."""
-        from .nn import _VALIDATE_FIRST_N, _route, _take_prefetched
+        from .nn import _VALIDATE_FIRST_N, _route, _training_plan_kind
 
         lib = _lib.load()
         mp, dev = self.mp, self.dev
         engine._require_device(bmg.V, "bmg.V")
+        if not self.model.training:
+            # (batch norm would update its running statistics while the block's dropout follows model.training: the two switches
+            #  must not disagree — and a training step of a model in eval mode is a bug of the caller, not a mode)
+            raise RuntimeError("FusedTrainer.step: the model is in eval mode — call model.train() first")
         batch = bmg.batch
         n_mols = len(bmg)
         nV, nE = int(bmg.V.shape[0]), int(bmg.E.shape[0])
+        n_tasks = int(self.layers[-1].out_features)
         T = engine._f32c(targets, "targets")
-        if T.dim() != 2 or T.shape[0] != n_mols or T.shape[1] != self.layers[-1].out_features or not T.is_contiguous():
-            raise ValueError(f"targets must be a contiguous [{n_mols}, {self.layers[-1].out_features}] matrix, got {tuple(targets.shape)}")
+        if T.dim() != 2 or T.shape[0] != n_mols or T.shape[1] != n_tasks or not T.is_contiguous():
+            raise ValueError(f"targets must be a contiguous [{n_mols}, {n_tasks}] matrix, got {tuple(targets.shape)}")
+        # the head kernels read these through raw pointers: a wrong dtype / size would be an out-of-bounds device read, not an error
+        if batch is None or batch.dtype != torch.int64 or not batch.is_contiguous() or batch.device != bmg.V.device or batch.numel() != nV:
+            raise ValueError(f"bmg.batch must be a contiguous int64 vector of {nV} molecule ids on {bmg.V.device}")
+        if weights is not None and weights.numel() != n_mols:
+            raise ValueError(f"weights must hold one value per molecule ({n_mols}), got {tuple(weights.shape)}")
+        for name, m in (("lt_mask", lt_mask), ("gt_mask", gt_mask)):
+            if m is not None and tuple(m.shape) != (n_mols, n_tasks):
+                raise ValueError(f"{name} must have the targets' shape [{n_mols}, {n_tasks}], got {tuple(m.shape)}")
+        if self.bn is not None and n_mols == 1:
+            raise ValueError("Expected more than 1 value per channel when training (batch norm on a batch of one molecule)")
         validate = _lib.opt("DMPNN_VALIDATE", "first") != "never" and self._checked < _VALIDATE_FIRST_N
         world = self._world()
         self.sync.wait()
@@ -244,14 +286,10 @@ class FusedTrainer:
         # arrays (DMPNN_F_TILE_PLAN; every tile checks itself, a molecule beyond the tile takes the kernels' generic path).
         no_mega = getattr(mp, "_dmpnn_no_mega", False) or (n_mols > 0 and nE > 30 * n_mols)
         level = 1 if (no_mega or getattr(bmg, "oversize", None) is True) else 2
-        want_tiles = (self.tile_plan and not validate and level == 2 and nE > 0 and mp.W_h.weight.shape[0] % 4 == 0
-                      and (mp.W_i.weight.requires_grad or mp.W_h.weight.requires_grad)
-                      and (engine.small_plan_fits(nV, nE) or (batch is not None and batch.dtype == torch.int64 and batch.is_contiguous())))
-        kind = "tiles" if want_tiles else False
-        plan = _take_prefetched(mp, bmg, kind) if "_dmpnn_prefetched" in mp.__dict__ else None
-        staged = plan is not None  # (K0 of this batch ran on the side stream; this stream now waits for it)
-        if plan is None:
-            plan = engine.GraphPlan.from_bmg(bmg, light=kind, launch=validate)
+        # (ONE rule for "this training forward runs on the tile plan", the module path's: shapes of the tile kernel — d_h <= 320, even
+        #  d_v / d_e —, the environment switches, a plan the library can build; anything else keeps the full plan and the per-step routes)
+        kind = _training_plan_kind(mp, bmg) if (self.tile_plan and not validate and level == 2) else False
+        plan = engine.GraphPlan.from_bmg(bmg, light=kind, launch=validate)
         plan.oversize = getattr(bmg, "oversize", None)
         if validate:
             self._checked += 1
@@ -328,7 +366,7 @@ class FusedTrainer:
             h.task_weights = tw.data_ptr()
             keep.append(tw)
         for name, m in (("lt_mask", lt_mask), ("gt_mask", gt_mask)):
-            if m is not None:
+            if m is not None and self.bounded:   # (the reference's plain MSE / MAE ignore the masks: nn/metrics.py:139-150)
                 m8 = m.to(torch.uint8).contiguous()
                 setattr(h, name, m8.data_ptr())
                 keep.append(m8)
@@ -345,19 +383,20 @@ class FusedTrainer:
         s.edge_index, s.rev_edge_index = plan.edge_index.data_ptr(), plan.rev_edge_index.data_ptr()
         bt = batch if (batch.dtype == torch.int64 and batch.is_contiguous()) else None
         s.batch = None if bt is None else bt.data_ptr()
-        s.plan_bytes, s.plan_ready = plan.buf.numel() * 4, (1 if (validate or staged) else 0)
+        s.plan_bytes, s.plan_ready = plan.buf.numel() * 4, (1 if validate else 0)
         s.bwd, s.head = b, h
         opt = self.opt
         fused_update = world == 1
         if fused_update:
-            opt.steps += 1
+            k = opt.steps + 1  # (committed below, once the call has returned OK: a refused step must not advance Adam's bias correction)
             b1, b2 = opt.betas
             s.p, s.g, s.m, s.v, s.n_params = opt.flat.data_ptr(), self.sync.flat.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr(), opt.flat.numel()
             s.lr, s.beta1, s.beta2, s.eps, s.weight_decay = float(opt.lr if lr is None else lr), b1, b2, opt.eps, opt.weight_decay
-            s.bias_corr1, s.sqrt_bias_corr2, s.grad_scale = 1.0 - b1 ** opt.steps, math.sqrt(1.0 - b2 ** opt.steps), 1.0
+            s.bias_corr1, s.sqrt_bias_corr2, s.grad_scale = 1.0 - b1 ** k, math.sqrt(1.0 - b2 ** k), 1.0
         with engine._OnDevice(dev):
             if fused_update:
                 _lib.check(lib.dmpnn_train_step(C.byref(s), engine._stream_ptr(dev)), "dmpnn_train_step")
+                opt.steps = k
             else:
                 # data parallel: the head's gradients (predictor, batch norm) are final before the block's backward pass starts —
                 # their slice of the flat buffer goes out on the communication stream while that pass runs; the block's slice

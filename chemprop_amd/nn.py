@@ -74,7 +74,7 @@ class _HParams(dict):
             raise AttributeError(k) from e
 
 
-_CACHE_KEYS = ("_dmpnn_replay", "_dmpnn_wcache", "_dmpnn_last", "_dmpnn_mon", "_dmpnn_prefetched", "_dmpnn_side")
+_CACHE_KEYS = ("_dmpnn_replay", "_dmpnn_wcache", "_dmpnn_last", "_dmpnn_mon")
 # what a GradSync hangs on a block (views into ITS flat buffer): never pickled / deep-copied along with the module
 _STATE_SKIP_KEYS = _CACHE_KEYS + ("_dmpnn_grad_views", "_dmpnn_grad_written")
 
@@ -134,46 +134,6 @@ class BondMessagePassing(EngineStateMixin, nn.Module):
     def forward(self, bmg, V_d: Optional[Tensor] = None) -> Tensor:
         return bond_message_passing_forward(self, bmg, V_d)
 
-    def prefetch_plan(self, bmg) -> None:
-        """Training loops with a look-ahead batch (any prefetching DataLoader): see :func:`prefetch_plan`."""
-        prefetch_plan(self, bmg)
-
-
-def _plan_key(bmg) -> tuple:
-    ei, rev, batch = bmg.edge_index, bmg.rev_edge_index, getattr(bmg, "batch", None)
-    return (ei.data_ptr(), rev.data_ptr(), 0 if batch is None else batch.data_ptr(), int(bmg.V.shape[0]), int(ei.shape[1]), str(ei.device))
-
-
-def prefetch_plan(mp, bmg) -> None:
-    """K0 of the NEXT training step, issued now on a side stream.
-
-    The plan (``dmpnn_prepare``: 27 µs of one workgroup at 512 molecules, 12 % of a training step) depends on the batch's
-    index tensors only — not on the weights, not on the step before.  Called between ``out = mp(batch_n)`` and
-    ``out.backward()`` with the batch the loader already holds for step n + 1, it runs beside the backward kernels of step n
-    (the side stream first waits for what is queued on the current stream, so the index tensors are complete); the next
-    ``mp(batch_{n+1})`` finds it (same index tensors), makes its stream wait for it and skips its own K0.  A prefetched plan
-    is used once, by the batch it was built for; at most two are held (the oldest goes first), and a forward that needs another
-    kind of plan (inference on the tile plan) drops them.  The work is the same — it only leaves the critical path."""
-    engine._require_device(bmg.V, "bmg.V")
-    dev = bmg.V.device
-    side = mp.__dict__.get("_dmpnn_side")
-    if side is None or side.device != dev:
-        side = torch.cuda.Stream(device=dev)
-        mp.__dict__["_dmpnn_side"] = side
-    side.wait_stream(torch.cuda.current_stream(dev))
-    kind = _training_plan_kind(mp, bmg)   # (the kind the training forward of this batch will ask for: full, or the tile plan)
-    with torch.cuda.stream(side):
-        plan = engine.GraphPlan.from_bmg(bmg, light=kind)
-        done = torch.cuda.Event()
-        done.record(side)
-    # two slots: FusedTrainer issues the plan of batch n + 1 BEFORE step n consumes the plan of batch n (the side stream waits
-    # for what is queued on the current stream — issued in front of step n, that is step n - 1, not step n)
-    slots = mp.__dict__.setdefault("_dmpnn_prefetched", {})
-    slots.pop(_plan_key(bmg), None)
-    while len(slots) >= 2:
-        slots.pop(next(iter(slots)))
-    slots[_plan_key(bmg)] = (plan, done, "tiles" if plan.tiles_only else False)
-
 
 def _training_plan_kind(mp, bmg):
     """``"tiles"`` when a TRAINING forward of ``mp`` on ``bmg`` runs on the tile plan (K0 = the tile table alone, kept tensors in the
@@ -203,24 +163,6 @@ def _training_plan_kind(mp, bmg):
         batch is not None and batch.dtype == torch.int64 and batch.is_contiguous()
         and bool(_lib.load().dmpnn_tile_plan_any_size(n_atoms, n_edges)))
     return "tiles" if (buildable and _tile_plan_ok(mp, n_atoms, n_edges, n_mols, True)) else False
-
-
-def _take_prefetched(mp, bmg, light):
-    slots = mp.__dict__.get("_dmpnn_prefetched")
-    if not slots:
-        return None
-    if light is True:  # (an inference forward on a light plan: the prefetched training plans are not this forward's)
-        mp.__dict__.pop("_dmpnn_prefetched", None)
-        return None
-    pf = slots.pop(_plan_key(bmg), None)
-    if not slots:
-        mp.__dict__.pop("_dmpnn_prefetched", None)
-    if pf is None or pf[2] != light:
-        return None
-    cur = torch.cuda.current_stream(pf[0].device)
-    cur.wait_event(pf[1])
-    pf[0].buf.record_stream(cur)  # (allocated on the side stream's pool, consumed here)
-    return pf[0]
 
 
 _ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_VALIDATE", "DMPNN_STORE")
@@ -262,7 +204,9 @@ def _make_replay(mp, plan, st) -> None:
     # the live argument block of the steady path: everything that does not belong to a batch is set here, once
     blk = r.block = _lib.FwdArgs.from_buffer_copy(r.args)
     blk.ldv, blk.lde, blk.ldout = r.d_v, r.d_e, r.d_h
-    r.flags = (int(blk.flags) | _lib.F_WSPLIT_READY) & ~_lib.F_LOADER_TILES
+    # (DMPNN_WCACHE=0: the pre-split of the weights is redone by every forward — also on this steady path; r.env pins the choice)
+    ready = _lib.F_WSPLIT_READY if _lib.opt("DMPNN_WCACHE", "1") != "0" else 0
+    r.flags = ((int(blk.flags) & ~_lib.F_WSPLIT_READY) | ready) & ~_lib.F_LOADER_TILES
     r.ldh, r.spill = int(blk.ldh), None
     mp.__dict__["_dmpnn_replay"] = r
 
@@ -407,7 +351,6 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     if V_d is None and not torch.is_grad_enabled():
         r = mp.__dict__.get("_dmpnn_replay")
         if r is not None:
-            mp.__dict__.pop("_dmpnn_prefetched", None)  # (a full plan prefetched for a training step: not this forward's)
             out = _replay_forward(mp, r, bmg)
             if out is not None:
                 return out
@@ -436,7 +379,7 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         light = "tiles"
     if not light and torch.is_grad_enabled() and V_d is None:
         light = _training_plan_kind(mp, bmg)   # a training forward bound for the tile kernels: the tile plan (DMPNN_F_TILE_PLAN)
-    plan = (_take_prefetched(mp, bmg, light) if "_dmpnn_prefetched" in mp.__dict__ else None) or engine.GraphPlan.from_bmg(bmg, light=light)
+    plan = engine.GraphPlan.from_bmg(bmg, light=light)
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch
 

@@ -211,6 +211,15 @@ def install() -> None:
                 setattr(self, n, acc[n] + getattr(self, n).detach())
             return val
 
+        def _apply(self, fn, *a, **k):
+            """``torchmetrics.Metric._apply``: the states (and their defaults) move with the module (``.to(device)``)."""
+            super()._apply(fn, *a, **k)
+            for n, d in list(self._shim_states.items()):
+                if hasattr(d, "clone"):
+                    self._shim_states[n] = fn(d)
+                    setattr(self, n, fn(getattr(self, n)))
+            return self
+
         def clone(self):
             return _copy.deepcopy(self)
 

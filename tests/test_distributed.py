@@ -260,3 +260,101 @@ def test_backward_writes_into_the_flat_gradient_buffer(gpu_device):
         for (k, p), (_, q), v in zip(b.named_parameters(), a.named_parameters(), sync.views):
             assert p.grad.data_ptr() == v.data_ptr(), k
             assert parity_err(p.grad.cpu().numpy(), q.grad.cpu().numpy()) == 0.0, (k, rep)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: the STAGED training step of a data-parallel job (model.FusedTrainer at world > 1) executed — two ranks on ONE GPU,
+# gradients exchanged through gloo: STEP_FORWARD -> all-reduce(head slice) -> STEP_BACKWARD -> all-reduce(block slice) -> update
+# ------------------------------------------------------------------------------------------------
+def _make_model(bn, dev):
+    from chemprop_amd import agg as cagg
+    from chemprop_amd.model import MPNN, RegressionFFN
+
+    torch.manual_seed(11)
+    return MPNN(BondMessagePassing(d_h=64), cagg.MeanAggregation(), RegressionFFN(n_tasks=2, input_dim=64, hidden_dim=32),
+                batch_norm=bn).to(dev).train()
+
+
+def _worker_staged(rank, world, port, n_mols, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chemprop_amd.model import FusedTrainer
+
+    dev = torch.device("cuda", 0)   # (every rank on the same device: the collectives go through the host, the kernels are the real ones)
+    torch.cuda.set_device(dev)
+    mine = dist.new_group([0])      # (every rank creates both groups, in the same order)
+    other = dist.new_group([1])
+    own = mine if rank == 0 else other
+    res = {}
+    n_steps = 3
+    for bn in (False, True):
+        batches = [[synth.random_batch(n_mols, "qm9", seed=40 + 10 * s + r) for r in range(world)] for s in range(n_steps)]
+        ys = [[torch.randn(n_mols, 2, generator=torch.Generator().manual_seed(7 + 10 * s + r)) for r in range(world)] for s in range(n_steps)]
+        staged, single = _make_model(bn, dev), _make_model(bn, dev)
+        tr_staged = FusedTrainer(staged, lr=1e-3)                 # the default group: world 2 -> the staged step
+        tr_single = FusedTrainer(single, lr=1e-3, group=own)      # a group of this rank alone: the ONE-call step
+        assert tr_staged._world() == 2 and tr_single._world() == 1
+        losses, gsum, gown = [], [], []
+        for s in range(n_steps):
+            b = batches[s][rank]
+            b.to(dev)
+            y = ys[s][rank].to(dev)
+            # the one-call step of THIS rank's batch on a twin with the SAME parameters: its gradients, summed over the ranks by an
+            # ordinary all-reduce, are what the staged step's two sliced exchanges must have left in its flat buffer
+            single.load_state_dict(staged.state_dict())
+            l1 = tr_single.step(b, y)
+            g1 = tr_single.sync.flat.detach().clone()
+            dist.all_reduce(g1)
+            l2 = tr_staged.step(b, y)
+            tr_staged.sync.wait()
+            torch.cuda.synchronize()
+            losses.append((float(l1[0]), float(l2[0])))
+            gsum.append((g1.cpu(), tr_staged.sync.flat.detach().cpu().clone()))
+        res[bn] = dict(losses=losses, gsum=gsum, params=tr_staged.opt.flat.detach().cpu().clone(),
+                       bn=None if not bn else (staged.bn.running_mean.cpu().clone(), staged.bn.running_var.cpu().clone(), int(staged.bn.num_batches_tracked),
+                                               single.bn.running_mean.cpu().clone(), single.bn.running_var.cpu().clone()))
+        if not bn:
+            # the UNION batch in one process, one call per step: molecules are independent and the loss is a mean over equally many
+            # targets per rank, so its gradient is the mean of the ranks' gradients -> the same parameters after the same steps
+            from chemprop_amd.data import BatchMolGraph
+
+            union = _make_model(False, dev)
+            tr_u = FusedTrainer(union, lr=1e-3, group=own)
+            for s in range(n_steps):
+                mgs = sum((synth.random_molgraphs(n_mols, "qm9", seed=40 + 10 * s + r) for r in range(world)), [])
+                ub = BatchMolGraph(mgs)
+                ub.to(dev)
+                tr_u.step(ub, torch.cat(ys[s]).to(dev))
+            torch.cuda.synchronize()
+            res["union_params"] = tr_u.opt.flat.detach().cpu().clone()
+    torch.save(res, os.path.join(out_dir, f"staged{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_staged_data_parallel_step_on_one_gpu(tmp_path, gpu_device):
+    """``FusedTrainer.step`` at world 2 (round-3 VERDICT: "designed but unexercised"): two processes on cuda:0, gloo.
+      * every staged step's loss = the one-call step's on the same batch and parameters;
+      * its flat gradient buffer after the two sliced exchanges = the all-reduced sum of the ranks' one-call gradients;
+      * both ranks hold the same parameters afterwards, equal to a one-process run on the UNION batch;
+      * batch-norm buffers are per-rank statistics (DDP semantics: no SyncBatchNorm in the reference), counted once per step."""
+    from conftest import parity_err
+
+    world, n_mols = 2, 48
+    mp.spawn(_worker_staged, args=(world, _free_port(), n_mols, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"staged{k}.pt") for k in range(world)]
+    for bn in (False, True):
+        for k in range(world):
+            for s, (l1, l2) in enumerate(r[k][bn]["losses"]):
+                assert abs(l1 - l2) <= 2e-6 * max(1.0, abs(l1)), (bn, k, s, l1, l2)
+            for s, (want, got) in enumerate(r[k][bn]["gsum"]):
+                assert parity_err(got.numpy(), want.numpy()) <= 5e-6, (bn, k, s)
+        assert torch.equal(r[0][bn]["params"], r[1][bn]["params"])          # the ranks stay in lock step, bit for bit
+    assert parity_err(r[0][False]["params"].numpy(), r[0]["union_params"].numpy()) <= 2e-5
+    for k in range(world):
+        m_s, v_s, n, m_1, v_1 = r[k][True]["bn"]
+        assert n == 3
+        assert parity_err(m_s.numpy(), m_1.numpy()) <= 1e-6 and parity_err(v_s.numpy(), v_1.numpy()) <= 1e-6
+    assert not torch.equal(r[0][True]["bn"][0], r[1][True]["bn"][0])         # (per-rank statistics: the batches differ)

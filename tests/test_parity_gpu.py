@@ -1095,71 +1095,6 @@ def test_presplit_weight_cache_follows_weight_updates(gpu_device):
     assert parity_err(c.cpu().numpy(), d.cpu().numpy()) <= 3e-6
 
 
-def test_prefetched_plan_is_the_plan_of_the_next_forward(gpu_device, monkeypatch):
-    """prefetch_plan: K0 of the next training step on a side stream.  Same plan bytes, same output and gradients as without;
-    used once; a prefetched plan of another batch, or one an inference forward cannot use, is dropped."""
-    from chemprop_amd import synth
-    from chemprop_amd.engine import GraphPlan
-    from chemprop_amd.nn import BondMessagePassing, _plan_key
-
-    monkeypatch.setenv("DMPNN_TRAIN_PLAN", "full")   # (this test compares the CSR tables of the plans byte for byte)
-    torch.manual_seed(11)
-    mp = BondMessagePassing(bias=True).to(gpu_device).train()
-    batches = [synth.random_batch(n, "qm9", seed=60 + i) for i, n in enumerate((96, 130, 1500))]
-    for b in batches:
-        b.to(gpu_device)
-    G = [torch.randn(int(b.V.shape[0]), 300, device=gpu_device) for b in batches]
-
-    def same_plan(a, b):
-        x, y = a.arrays(), b.arrays()
-        nt, nm = int(x["hdr"][4]), int(x["hdr"][6])
-        ok = torch.equal(x["hdr"], y["hdr"]) and all(torch.equal(x[k], y[k]) for k in ("row_ptr", "perm", "inv", "srcp", "dstp", "revp"))
-        return (ok and torch.equal(x["tile_row"][:nt + 1], y["tile_row"][:nt + 1]) and torch.equal(x["mtile_row"][:nm + 1], y["mtile_row"][:nm + 1])
-                and torch.equal(x["mtile_atom"][:nm + 1], y["mtile_atom"][:nm + 1]))
-
-    def grads(i, prefetch):
-        mp.zero_grad()
-        if prefetch:
-            mp.prefetch_plan(batches[i])
-            assert "_dmpnn_prefetched" in mp.__dict__
-        out = mp(batches[i])
-        assert _plan_key(batches[i]) not in mp.__dict__.get("_dmpnn_prefetched", {})        # consumed by the forward
-        st = out.grad_fn.st
-        out.backward(G[i])
-        return out.detach().clone(), [p.grad.clone() for p in mp.parameters()], st.plan
-
-    for i in range(len(batches)):
-        o0, g0, p0 = grads(i, False)
-        o1, g1, p1 = grads(i, True)
-        torch.cuda.synchronize()
-        assert same_plan(p0, p1) and p1.any_size == p0.any_size
-        assert torch.equal(o0, o1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
-    # a plan prefetched for ANOTHER batch is not used
-    mp.prefetch_plan(batches[0])
-    o, g, p = grads(1, False)
-    ref = GraphPlan.from_bmg(batches[1])
-    torch.cuda.synchronize()
-    assert same_plan(p, ref) and list(mp.__dict__["_dmpnn_prefetched"]) == [_plan_key(batches[0])]   # (held for ITS batch: two slots at most)
-    mp.__dict__.pop("_dmpnn_prefetched")
-    # the loop shape it is meant for: prefetch the next batch between forward and backward
-    mp.zero_grad()
-    out = mp(batches[0])
-    mp.prefetch_plan(batches[1])
-    out.backward(G[0])
-    out = mp(batches[1])
-    assert "_dmpnn_prefetched" not in mp.__dict__ and same_plan(out.grad_fn.st.plan, ref)
-    out.backward(G[1])
-    o_ref, g_ref, _ = grads(1, False)
-    assert torch.equal(out.detach(), o_ref)
-    # an inference forward takes its own (light / tile) plan: a prefetched full plan is dropped, the result is the same
-    mp.eval()
-    with torch.no_grad():
-        a = mp(batches[0])
-        mp.prefetch_plan(batches[0])
-        b = mp(batches[0])
-    assert "_dmpnn_prefetched" not in mp.__dict__ and parity_err(a.cpu().numpy(), b.cpu().numpy()) <= 3e-6
-
-
 def test_frozen_encoder_and_no_grad(gpu_device):
     """requires_grad_(False) on the block (cli/train.py:1826-1828) and torch.no_grad() both work."""
     from chemprop_amd import synth
