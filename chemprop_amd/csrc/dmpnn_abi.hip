@@ -251,7 +251,10 @@ static bool keep_bits_apply(const dmpnn_fwd_args& a) {
            !(a.dropout_p > 0.f) && !a.W_d && a.n_atoms > 0 && a.n_edges > 0;
 }
 size_t dmpnn_forward_keep_bits_bytes(const dmpnn_fwd_args* a) {
-    if (!a || !keep_bits_apply(*a)) return 0;
+    if (!a) return 0;
+    // the per-step fused route on the f16 pipe (DMPNN_F_FUSED | DMPNN_F_SPLIT16 without DMPNN_F_MEGA): its LEAN training forward
+    if ((a->flags & (DMPNN_F_FUSED | DMPNN_F_SPLIT16)) == (DMPNN_F_FUSED | DMPNN_F_SPLIT16) && !(a->flags & DMPNN_F_MEGA)) return fused16_lean_bits_bytes(*a);
+    if (!keep_bits_apply(*a)) return 0;
     return (size_t)a->depth * (size_t)plan_layout(a->n_atoms, a->n_edges).max_mtiles * 256u * 8u;
 }
 
@@ -293,6 +296,13 @@ int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int pl
         t.flags &= ~(unsigned)(DMPNN_F_KEEP | DMPNN_F_STORE16);
         if (fused16_shapes_ok(t)) return DMPNN_ROUTE_FUSED16;
     }
+    // training at size, molecules beyond the tile: the per-step FUSED route's lean forward + the backward step kernels (round 4:
+    // ReLU-class activation, no W_d, d_h <= 320) — else the per-step general route on the f16 pipe
+    if (keep && level == 1 && arith == 0 && nE >= kSteps16MinEdges && plan_kind == 0) {
+        dmpnn_fwd_args t = *a;
+        t.flags = (t.flags | DMPNN_F_FUSED | DMPNN_F_SPLIT16) & ~(unsigned)(DMPNN_F_MEGA | DMPNN_F_STORE16);
+        if (fused16_lean_shapes(t)) return DMPNN_ROUTE_FUSED16;
+    }
     if (level == 1 && arith == 0 && nE >= kSteps16MinEdges && plan_kind != 1) level = 0;  // (training at size: the per-step route on the f16 pipe)
     if (level == 2) return arith == 0 ? DMPNN_ROUTE_MEGA16 : DMPNN_ROUTE_MEGA;
     if (level == 1) return DMPNN_ROUTE_FUSED;
@@ -332,7 +342,8 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     const bool fused = a->flags & DMPNN_F_FUSED;
     DMPNN_CHECK_ARG(!(a->flags & DMPNN_F_STORE16) || (fused && (a->flags & DMPNN_F_SPLIT16) && !(a->flags & (DMPNN_F_MEGA | DMPNN_F_KEEP))),
                     "forward: DMPNN_F_STORE16 only goes with the per-step fused route on the f16 pipe (DMPNN_F_FUSED | DMPNN_F_SPLIT16, inference)");
-    if (a->depth > 1 && nE > 0 && !(a->flags & DMPNN_F_MEGA)) {
+    const bool lean16 = fused && (a->flags & DMPNN_F_SPLIT16) && (a->flags & DMPNN_F_KEEP) && !(a->flags & DMPNN_F_MEGA) && a->keep_bits;
+    if (a->depth > 1 && nE > 0 && !(a->flags & DMPNN_F_MEGA) && !lean16) {
         DMPNN_CHECK_ARG(a->Ms && a->n_mslots >= 1, "forward: missing Ms workspace");
         DMPNN_CHECK_ARG(fused || (a->Hs && a->n_hslots >= 1), "forward: missing Hs workspace");
     }
@@ -359,7 +370,7 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         // ---- per-step fused route on the f16 pipe: split message rows between the steps (dmpnn_step16_impl.hpp) ----
         DMPNN_CHECK_ARG(fused16_shapes_ok(*a), "forward: DMPNN_F_FUSED | DMPNN_F_SPLIT16 given but the shapes do not allow it "
                         "(directed, d_h %% 4 == 0, d_h <= 640, even d_v / d_e; with DMPNN_F_KEEP: depth - 1 kept H / M slots and `msplit`)");
-        DMPNN_CHECK_ARG(nE == 0 || (a->H0 && ((a->flags & DMPNN_F_KEEP) ? (a->Ms || a->depth == 1) : (a->Ms && a->n_mslots >= 2))),
+        DMPNN_CHECK_ARG(nE == 0 || (a->H0 && ((a->flags & DMPNN_F_KEEP) ? (a->Ms || a->depth == 1 || lean16) : (a->Ms && a->n_mslots >= 2))),
                         "forward(fused16): H0 and two split message slots (training: `msplit` + the kept fp32 slots) are required");
         DMPNN_CHECK_ARG(a->wsplit && a->wsplit_bytes >= steps16_wsplit_bytes(*a), "forward(fused16): wsplit workspace missing or too small");
         SplitWView w[6];

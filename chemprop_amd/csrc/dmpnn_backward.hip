@@ -598,6 +598,11 @@ struct BwdLayout {
     size_t w16g;                              // per-step path: split operands of one product at a time
     size_t w16_z[3], w16_a[3], w16_slab[3];   // o, h, i (float offsets)
     WProdPlan q[3];
+    // lean training on the per-step fused route (dmpnn_bstep16.hip): operands written by the step kernels, products over the steps
+    bool lean;
+    size_t lz, lm, lx, lz_stride, lm_stride;   // gZ blocks of every site | M^(t) blocks | x blocks (float offsets / strides per operand)
+    size_t lslab_h, lslab_i;
+    WProdTPlan qh, qi;
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     BwdLayout L;
@@ -670,6 +675,21 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
                 L.w16_slab[i] = o; o += align_up((size_t)L.q[i].splits * L.q[i].slab_stride, 64);
             }
         }
+    }
+    L.lean = fused16_lean(f);
+    L.lz = L.lm = L.lx = L.lz_stride = L.lm_stride = L.lslab_h = L.lslab_i = 0;
+    if (L.lean) {
+        const int T = f.depth;
+        const int kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(f.d_v + f.d_e) + (f.b_i ? 1 : 0);
+        L.lz_stride = align_up((bstep16_operand_bytes(nE, h) + 3) / 4, 64);
+        L.lm_stride = align_up((bstep16_operand_bytes(nE, kt_h) + 3) / 4, 64);
+        L.lz = o; o += (size_t)T * L.lz_stride;
+        L.lm = o; o += (size_t)(T - 1) * L.lm_stride;
+        L.lx = o; o += align_up((bstep16_operand_bytes(nE, kt_i) + 3) / 4, 64);
+        L.qh = plan_wgrad16t(bstep16_ld_chunks(nE), (int)h, kt_h);
+        L.qi = plan_wgrad16t(bstep16_ld_chunks(nE), (int)h, kt_i);
+        L.lslab_h = o; o += align_up((size_t)(T - 1) * L.qh.splits * L.qh.slab_stride, 64);
+        L.lslab_i = o; o += align_up((size_t)T * L.qi.splits * L.qi.slab_stride, 64);
     }
     L.total = o;
     return L;
@@ -769,9 +789,9 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
     DMPNN_CHECK_ARG(f.act >= DMPNN_ACT_RELU && f.act <= DMPNN_ACT_ELU && f.act != DMPNN_ACT_PRELU,
                     "backward: activation %d has no fused backward (use the row kernels)", f.act);
     DMPNN_CHECK_ARG(nV == 0 || b->gout, "backward: null gout");
-    DMPNN_CHECK_ARG(T == 1 || nE == 0 || (f.n_hslots >= T - 1 && f.n_mslots >= T - 1),
-                    "backward: the forward did not keep every H^(t) / M^(t) (n_hslots, n_mslots must be depth-1)");
     const BwdLayout L = bwd_layout(f);
+    DMPNN_CHECK_ARG(L.lean || T == 1 || nE == 0 || (f.n_hslots >= T - 1 && f.n_mslots >= T - 1),
+                    "backward: the forward did not keep every H^(t) / M^(t) (n_hslots, n_mslots must be depth-1)");
     if (b->ws_bytes < L.total * sizeof(float) || !b->ws) {
         set_error("backward: workspace too small (%zu < %zu bytes)", b->ws_bytes, L.total * sizeof(float));
         return DMPNN_ENOSPC;
@@ -793,7 +813,7 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
     const int pmask = lean ? kPlanNoMegaLean : (fused ? kPlanNoFuse : 0);
     const int* e_gather = (fused && !lean) ? static_cast<const int*>(f.plan) + plan_layout(nV, nE).perm : nullptr;
     DMPNN_CHECK_ARG(!fused || !(f.flags & DMPNN_F_UNDIRECTED), "backward: fused + undirected is not a valid forward");
-    DMPNN_CHECK_ARG(!fused || T == 1 || nE == 0 || f.Hs, "backward: the fused forward did not keep H^(t) (Hs was NULL)");
+    DMPNN_CHECK_ARG(!fused || T == 1 || nE == 0 || f.Hs || L.lean, "backward: the fused forward did not keep H^(t) (Hs was NULL)");
     const int64_t ldh = f.ldh, slot = nE * ldh;
 
     auto zero2d = [&](float* p, int64_t rows, int64_t cols) {
@@ -830,6 +850,102 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         g.W = WdT; g.ldw = h + dvd; g.C = gHO; g.ldc = ldh; g.act = DMPNN_ACT_NONE;
         DMPNN_TRY(launch_linear(g, s));
         gHO_p = gHO; ld_gHO = ldh;
+    }
+    if (L.lean) {
+        // ---- the per-step fused route's lean training forward: backward STEP kernels over the same tiles (dmpnn_bstep16.hip) ----
+        DMPNN_CHECK_ARG(fused && !lean && !has_vd && T >= 2 && T - 1 <= kWProdMaxJobs && T <= kWProdMaxJobs,
+                        "backward(lean fused16): depth 2 .. %d, no W_d", kWProdMaxJobs);
+        const bool vec = h % 4 == 0 && ld_gHO % 4 == 0 && ldHO % 4 == 0 && ldh % 4 == 0 && aligned16(gHO_p) && aligned16(HO) && aligned16(gZO);
+        {   // gZO = gout * tau'(out)
+            const int64_t n = nV * (vec ? h / 4 : h);
+            int64_t blocks = (n + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            if (vec) hipLaunchKernelGGL(k_act_bwd<4>, dim3((unsigned)blocks), dim3(256), 0, s, gHO_p, ld_gHO, HO, ldHO, gZO, ldh, nV, (int)h,
+                                        f.act, f.act_slope, f.act_slope_ptr);
+            else hipLaunchKernelGGL(k_act_bwd<1>, dim3((unsigned)blocks), dim3(256), 0, s, gHO_p, ld_gHO, HO, ldHO, gZO, ldh, nV, (int)h,
+                                    f.act, f.act_slope, f.act_slope_ptr);
+            DMPNN_CHECK_LAUNCH("k_act_bwd");
+        }
+        if (b->gW_o || b->gb_o) {
+            WgradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.M = nV; a.N = (int)h; a.K1 = (int)dv; a.K2 = (int)h; a.ones = 1;
+            a.gZ = gZO; a.ldz = ldh; a.A1 = f.V; a.lda1 = f.ldv; a.A2 = f.Mv; a.lda2 = ldh;
+            int ns = 0;
+            DMPNN_TRY(launch_wgrad(a, L.p_o, slab_x, s, ws + L.w16g, &ns));
+            DMPNN_TRY(launch_wgrad_reduce(slab_x, L.p_o, ns, (int)h, (int)(dv + h), 1, b->gW_o, dv + h, b->gb_o, s, pflags, pmask));
+        }
+        if (!(b->gW_i || b->gb_i || b->gW_h || b->gb_h)) return DMPNN_OK;
+        {   // gMv = gZO . W_o[:, d_v:]
+            dmpnn_gemm_args g;
+            memset(&g, 0, sizeof(g));
+            g.M = nV; g.N = h; g.K1 = h; g.A1 = gZO; g.lda1 = ldh; g.W = WoT; g.ldw = h; g.C = gMv; g.ldc = ldh;
+            g.act = DMPNN_ACT_NONE;
+            if (L.use16 && linear16_ok(g)) {
+                SplitWView w;
+                DMPNN_TRY(split_weights_view(f.W_o + dv, dv + h, h, h, 1, ws + L.WoT16, &w, s));
+                DMPNN_TRY(launch_linear16_view(g, w, nullptr, 0, s));
+            } else {
+                DMPNN_TRY(launch_transpose(f.W_o + dv, dv + h, WoT, h, (int)h, (int)h, s));
+                DMPNN_TRY(launch_linear(g, s));
+            }
+        }
+        DMPNN_CHECK_ARG(L.use16, "backward(lean fused16): even d_h");
+        SplitWView whT;
+        DMPNN_TRY(split_weights_view(f.W_h, h, h, h, 1, ws + L.WhT16, &whT, s));
+        unsigned char* Zb = reinterpret_cast<unsigned char*>(ws + L.lz);
+        unsigned char* Mb = reinterpret_cast<unsigned char*>(ws + L.lm);
+        unsigned char* Xb = reinterpret_cast<unsigned char*>(ws + L.lx);
+        const size_t zs = L.lz_stride * sizeof(float), ms = L.lm_stride * sizeof(float);
+        float* Tb[2] = {gZa, gZb};
+        // site T-1 (gather from gMv) ... site 1: gZ^(t) blocks + T_next; site 0: gZ^(0) blocks only
+        for (int t = T - 1; t >= 1; --t)
+            DMPNN_TRY(launch_bstep16(f, t, t == T - 1 ? nullptr : Tb[t & 1], gMv, &whT, Tb[(t - 1) & 1], Zb + (size_t)t * zs, s));
+        DMPNN_TRY(launch_bstep16(f, 0, Tb[0], gMv, nullptr, nullptr, Zb, s));
+        // the products' other operands from what the forward kept: M^(t) (slot t - 1 of msplit), x (in H0)
+        const int ts_m = (int)(split_row_floats(h) * 4), ts_x = ((int)((dv + de + 31) / 32)) * 128 + 16;
+        const unsigned char* Mk = static_cast<const unsigned char*>(f.msplit);
+        const bool want_h = b->gW_h || b->gb_h, want_i = b->gW_i || b->gb_i;
+        if (want_h)
+            for (int t = 1; t < T; ++t)
+                DMPNN_TRY(launch_rows2blk(f, Mk + (size_t)(t - 1) * (size_t)nE * ts_m, ts_m, (int)h, f.b_h ? 1 : 0, Mb + (size_t)(t - 1) * ms, s));
+        if (want_i) DMPNN_TRY(launch_rows2blk(f, reinterpret_cast<const unsigned char*>(f.H0), ts_x, (int)(dv + de), f.b_i ? 1 : 0, Xb, s));
+        const int ldc = (int)bstep16_ld_chunks(nE);
+        const int n_ct_z = (int)((h + 63) / 64);
+        auto operand = [&](unsigned char* blk, int n_ct) {
+            return WProdTOperand{blk, reinterpret_cast<const float*>(blk + (size_t)n_ct * (size_t)ldc * 8192)};
+        };
+        const int* n_tiles_dev = static_cast<const int*>(f.plan) + DMPNN_HDR_NTILES;
+        const int kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(dv + de) + (f.b_i ? 1 : 0);
+        ReduceJobs rj;
+        memset(&rj, 0, sizeof(rj));
+        rj.poison_flags = pflags; rj.poison_mask = pmask;
+        auto add_reduce = [&](float* slab, const WProdTPlan& q, int n_jobs, int K, int ones, float* gW, int64_t ldgw, float* gb) {
+            ReduceJob& r = rj.job[rj.n_jobs];
+            r.slab = slab; r.slab_stride = q.slab_stride; r.n_slabs = n_jobs * q.splits; r.ldk = q.ldk;
+            r.N = (int)h; r.K = K; r.ones = ones; r.gW = gW; r.ldgw = ldgw; r.gb = gb;
+            int64_t blocks = ((int64_t)r.N * (K + ones) + 255) / 256;
+            if (blocks > 1024) blocks = 1024;
+            rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
+            ++rj.n_jobs;
+        };
+        if (want_h) {   // gW_h = sum_t gZ^(t)^T M^(t)
+            WProdTOperand Zs[kWProdMaxJobs], As[kWProdMaxJobs];
+            for (int t = 1; t < T; ++t) { Zs[t - 1] = operand(Zb + (size_t)t * zs, n_ct_z); As[t - 1] = operand(Mb + (size_t)(t - 1) * ms, (kt_h + 63) / 64); }
+            DMPNN_TRY(launch_wgrad16t(Zs, As, T - 1, L.qh, (int)h, kt_h, ws + L.lslab_h, n_tiles_dev, s));
+            add_reduce(ws + L.lslab_h, L.qh, T - 1, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h);
+        }
+        if (want_i) {   // gW_i = (sum_t gZ^(t))^T x = sum_t gZ^(t)^T x
+            WProdTOperand Zs[kWProdMaxJobs], As[kWProdMaxJobs];
+            for (int t = 0; t < T; ++t) { Zs[t] = operand(Zb + (size_t)t * zs, n_ct_z); As[t] = operand(Xb, (kt_i + 63) / 64); }
+            DMPNN_TRY(launch_wgrad16t(Zs, As, T, L.qi, (int)h, kt_i, ws + L.lslab_i, n_tiles_dev, s));
+            add_reduce(ws + L.lslab_i, L.qi, T, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i);
+        }
+        if (rj.n_jobs > 0) {
+            hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
+            DMPNN_CHECK_LAUNCH("k_wgrad_reduce_multi");
+        }
+        return DMPNN_OK;
     }
     const bool tile_bwd = L.mega && (b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO);
     // in-kernel dropout (dmpnn_fwd_args.dropout_p): its 1 / (1 - p) lives in the backward TILE kernel alone — every other branch below

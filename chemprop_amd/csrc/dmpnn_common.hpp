@@ -246,6 +246,10 @@ int launch_linear16_view(const dmpnn_gemm_args& a, const SplitWView& W, const in
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
 // per-step fused route on the f16 pipe (dmpnn_step16.hip): inference forward, any molecule size, d_h <= 320
 bool fused16_shapes_ok(const dmpnn_fwd_args& a);
+// its LEAN training forward (dmpnn_step16.hip) and the backward that reads what it keeps (dmpnn_bstep16.hip)
+bool fused16_lean_shapes(const dmpnn_fwd_args& a);     // shapes / options only (the route rule)
+size_t fused16_lean_bits_bytes(const dmpnn_fwd_args& a);
+bool fused16_lean(const dmpnn_fwd_args& a);            // ... and the workspace is there (DMPNN_F_KEEP, keep_bits, msplit, H0)
 int64_t split_row_floats(int64_t d_h);
 
 // ---- weight gradients on the f16 pipe (dmpnn_wgrad16.hip): operands split once into transposed blocks, then the products ----
@@ -266,7 +270,14 @@ struct WProdArgs {
     int N, Kt; float* slab; int ldk; int64_t slab_stride;
 };
 struct WProdPlan { int n_nt, n_kt, n_chunks, chunks_per_split, splits, ldk; int64_t slab_stride; };
+constexpr int kWProdMaxJobs = 8;
 struct WProdJobs { WProdArgs job[4]; int wg0[5]; int n_jobs; };  // several products in one launch: job j owns workgroups [wg0[j], wg0[j + 1]), multiples of 8
+// products over TILE-PACKED operands (written by the backward step kernels of dmpnn_bstep16.hip; k_wgrad16t)
+struct WProdTOperand { const unsigned char* blk; const float* scale; };   // blocks [column tile][ld_chunks][8 KB]; scales [2 ld_chunks]
+struct WProdTPlan { int n_ctz, n_kt, ld_chunks, splits, ldk; int64_t slab_stride; };
+WProdTPlan plan_wgrad16t(int64_t ld_chunks, int N, int Kt);
+int launch_wgrad16t(const WProdTOperand* Z, const WProdTOperand* A, int n, const WProdTPlan& p, int N, int Kt, float* slab,
+                    const int* n_tiles_dev, hipStream_t s);
 size_t wsplit16_bytes(int64_t M, int64_t C);
 // One more weight-gradient product for the launches of a backward pass on the f16 pipe (the predictor's first layer in a training
 // step: gW[N, K] = Z^T A, gb = colsum(Z) — 512 rows are 16 chunks beside the block's 1 140): rides in k_wsplit16 / k_wgrad16 /
@@ -285,6 +296,12 @@ WProdPlan plan_wgrad16(int64_t M, int N, int Kt);
 void wgrad16_add(WProdJobs* jobs, const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab);
 int launch_wgrad16(const WProdJobs& jobs, hipStream_t s);
 int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s);
+// the backward step kernels of that route's lean training forward (dmpnn_bstep16.hip)
+int64_t bstep16_ld_chunks(int64_t n_edges);
+size_t bstep16_operand_bytes(int64_t n_edges, int64_t C);
+int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const float* gMv, const SplitWView* W, float* Tout,
+                   unsigned char* Zblk, hipStream_t s);
+int launch_rows2blk(const dmpnn_fwd_args& f, const unsigned char* rows, int ts, int C, int ones, unsigned char* blk, hipStream_t s);
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,

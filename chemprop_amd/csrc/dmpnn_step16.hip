@@ -29,9 +29,39 @@ int64_t split_row_floats(int64_t d_h) { return step16::split_row_bytes((int)d_h)
 static inline bool half_store(const dmpnn_fwd_args& a) { return (a.flags & DMPNN_F_STORE16) != 0; }
 static inline int msg_row_bytes(const dmpnn_fwd_args& a) { return half_store(a) ? step16::half_row_bytes((int)a.d_h) : step16::split_row_bytes((int)a.d_h); }
 
+// LEAN training forward (round 4): DMPNN_F_KEEP with `keep_bits` on this route.  Nothing is kept that the backward step kernels
+// (dmpnn_bstep16.hip) do not read: the split message rows of EVERY step (depth - 1 slots in `msplit` instead of two ping-pong
+// slots + an fp32 copy each), the split K1 operand (in `H0`: the residual is recomputed per step as in inference, no H0 tensor),
+// one SIGN bit per element of H0 / H^(t) (`keep_bits`, instead of fp32 rows), and the fp32 per-atom sums `Mv`.
+// (the split K1 operand's rows are packed at their own stride — split_operand_bytes(d_v + d_e) = ceil((d_v + d_e) / 32) * 128 + 16
+//  bytes — in the `H0` buffer, which in lean mode must hold n_edges * max(4 ldh, that stride) bytes: the host allocates it so)
+static bool x_path_shapes(const dmpnn_fwd_args& a) {
+    return a.d_h <= 320 && (a.d_v + a.d_e + 31) / 32 <= step16::kXChunks;
+}
+bool fused16_lean_shapes(const dmpnn_fwd_args& a) {
+    const unsigned need = DMPNN_F_FUSED | DMPNN_F_SPLIT16;
+    if ((a.flags & need) != need || (a.flags & (DMPNN_F_MEGA | DMPNN_F_UNDIRECTED | DMPNN_F_STORE16 | DMPNN_F_ATOM))) return false;
+    if (!(a.act == DMPNN_ACT_NONE || a.act == DMPNN_ACT_RELU || a.act == DMPNN_ACT_LEAKYRELU)) return false;
+    if (a.W_d || a.dropout_p > 0.f || a.depth < 2 || a.n_edges <= 0 || a.n_atoms <= 0) return false;
+    if (a.d_h <= 0 || a.d_h % 4 != 0 || a.ldh % 4 != 0 || a.d_v % 2 || a.d_e % 2 || a.ldv % 2 || a.lde % 2) return false;
+    // (the backward's tile-packed product operands are addressed through 32-bit buffer offsets)
+    if ((int64_t)((a.d_h + 63) / 64) * bstep16_ld_chunks(a.n_edges) * 8192 > 0x7FFFFFFF) return false;
+    return x_path_shapes(a);
+}
+size_t fused16_lean_bits_bytes(const dmpnn_fwd_args& a) {
+    return fused16_lean_shapes(a) ? (size_t)a.depth * (size_t)a.n_edges * (size_t)(step16::block_cols((int)a.d_h) / 8) : 0;
+}
+bool fused16_lean(const dmpnn_fwd_args& a) {
+    if (!(a.flags & DMPNN_F_KEEP) || !a.keep_bits || !fused16_lean_shapes(a)) return false;
+    if (a.keep_bits_bytes < fused16_lean_bits_bytes(a)) return false;
+    if (!a.msplit || a.msplit_bytes < (size_t)(a.depth - 1) * (size_t)a.n_edges * step16::split_row_bytes((int)a.d_h)) return false;
+    return !(reinterpret_cast<uintptr_t>(a.msplit) & 15u) && a.H0 && !(reinterpret_cast<uintptr_t>(a.H0) & 15u);
+}
+
 bool fused16_shapes_ok(const dmpnn_fwd_args& a) {
     const int64_t h = a.d_h;
     if (a.flags & DMPNN_F_UNDIRECTED) return false;  // directed graphs
+    if ((a.flags & DMPNN_F_KEEP) && a.keep_bits) return fused16_lean(a) && a.n_atoms * a.ldv * 4 <= 0x7FFFFFFF && a.n_edges * a.lde * 4 <= 0x7FFFFFFF;
     if (a.flags & DMPNN_F_KEEP) {
         // training: the kept fp32 tensors the backward pass reads + the two split ping-pong slots in `msplit`
         if (a.flags & DMPNN_F_STORE16) return false;
@@ -123,8 +153,10 @@ static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
 // `xrows` (or null): the K1 operand [V[src] || E] of every row, exactly split (k_split_rows) — the residual H0 = W_i x + b_i is
 // then recomputed inside the step instead of read back (x_path_ok)
 static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const SplitWView* Wi, const unsigned char* xrows,
-                         const unsigned char* Min, unsigned char* Mout, float* Sout, unsigned char* SoutS, float* Hout, float* M32, hipStream_t s) {
+                         const unsigned char* Min, unsigned char* Mout, float* Sout, unsigned char* SoutS, float* Hout, float* M32, hipStream_t s,
+                         unsigned char* bits = nullptr) {
     step16::Step16K g = step_args(a, L);
+    g.bits = bits; g.bstride = step16::block_cols((int)a.d_h) / 8;
     g.A = Min; g.ts = msg_row_bytes(a);
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
     g.bias = a.b_h;
@@ -152,7 +184,7 @@ static bool x_path_ok(const dmpnn_fwd_args& a) {
 // K1 on the update kernel (d_h > 320, and the x path): the gathered fp32 operand is split into rows first (`scratch`: the second
 // message slot, or — x path, keep_h0 false — the H0 buffer, where the rows stay for the depth steps and no H0 is written)
 static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* scratch, bool keep_h0,
-                           unsigned char* Mout, float* Sout, float* M32, hipStream_t s) {
+                           unsigned char* Mout, float* Sout, float* M32, hipStream_t s, unsigned char* bits = nullptr) {
     const int* plan_i = static_cast<const int*>(a.plan);
     step16::SplitRowsK k;
     memset(&k, 0, sizeof(k));
@@ -169,6 +201,7 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
     if (keep_h0) { g.Zpre = a.H0; g.ldz = (int)a.ldh; }
     g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
     g.M32 = Mout ? M32 : nullptr; g.ldm32 = (int)a.ldh;
+    g.bits = bits; g.bstride = step16::block_cols((int)a.d_h) / 8;
     return launch_step(g, a.d_h, (int)L.max_tiles, false, s);  // (the K1 operand [V || E] is always split exactly)
 }
 
@@ -227,7 +260,19 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
     }
     // (training keeps H0 and an fp32 Mv — the residual is read back, the finalize runs on the row kernel)
     const bool fin16 = !keep && fin16_ok(a, out, ldout);
-    if (nE > 0) {
+    if (nE > 0 && fused16_lean(a)) {
+        // ---- lean training forward: split rows of every step, sign bits, no fp32 copies (see fused16_lean_shapes) ----
+        unsigned char* xrows = reinterpret_cast<unsigned char*>(a.H0);
+        unsigned char* Mk = reinterpret_cast<unsigned char*>(a.msplit);
+        unsigned char* bits = static_cast<unsigned char*>(a.keep_bits);
+        const size_t bslot = (size_t)nE * (size_t)(step16::block_cols((int)h) / 8);
+        DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, Mk, nullptr, nullptr, s, bits));   // M^(1) -> slot 0; signs of H0 -> site 0
+        for (int t = 1; t < T; ++t) {
+            const bool last = t == T - 1;
+            DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], xrows, Mk + (size_t)(t - 1) * slot_bytes, last ? nullptr : Mk + (size_t)t * slot_bytes,
+                                    last ? a.Mv : nullptr, nullptr, nullptr, nullptr, s, bits + (size_t)t * bslot));
+        }
+    } else if (nE > 0) {
         const bool xpath = !keep && x_path_ok(a);
         unsigned char* xrows = xpath ? reinterpret_cast<unsigned char*>(a.H0) : nullptr;
         float* m32_0 = (keep && T > 1) ? a.Ms : nullptr;  // M^(1): what update step 1 consumes, what gW_h's first product reads

@@ -76,6 +76,8 @@ struct Step16K {
     float* Yout; int ldy;                 // 1: plain epilogue — tau(z) rows [M][ldy] fp32, nothing else (or null)
     float* Hout; int ldho;                // training: H' = tau(z) rows [M][ldho] fp32 kept for the backward pass (or null)
     float* M32; int ldm32;                // training: the next message also as fp32 rows (the weight gradients' operand) (or null)
+    unsigned char* bits; int bstride;     // lean training (ReLU-class activation): [tau(z) > 0] of every element, one bit each, rows [M][bstride]
+                                          // bytes (bit c & 7 of byte c >> 3) — all the backward step kernel needs of H' (or null)
     int act; float slope; const float* slope_ptr;
     const int* poison_flags; int poison_mask;
     unsigned qmagic;
@@ -389,6 +391,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
             *reinterpret_cast<float4*>(g.Hout + (long long)(rs + r) * g.ldho + 4 * q) = z;
         }
     }
+    if (g.bits) {  // (uniform) lean training: the sign of tau(z) — one byte per (row, 8 columns) — instead of the fp32 rows
+        __syncthreads();
+        constexpr int G8B = BN / 8;
+        for (int it = tid; it < nrows * G8B; it += NT) {
+            const int r = it / G8B, g8 = it - r * G8B;
+            const float4 m0 = *reinterpret_cast<const float4*>(T + r * LDC + 8 * g8);
+            const float4 m1 = *reinterpret_cast<const float4*>(T + r * LDC + 8 * g8 + 4);
+            const unsigned b = (m0.x > 0.f ? 1u : 0u) | (m0.y > 0.f ? 2u : 0u) | (m0.z > 0.f ? 4u : 0u) | (m0.w > 0.f ? 8u : 0u) |
+                               (m1.x > 0.f ? 16u : 0u) | (m1.y > 0.f ? 32u : 0u) | (m1.z > 0.f ? 64u : 0u) | (m1.w > 0.f ? 128u : 0u);
+            g.bits[(long long)(rs + r) * g.bstride + g8] = (unsigned char)b;
+        }
+    }
     int scale_phase = 0;
     auto tile_scale = [&](float local_max) -> float {
         stamp();  // 7 pass 1 done
@@ -421,7 +435,7 @@ struct SplitRowsK {
     const float* A2; int lda2; const int* g2; int K2; unsigned a2_bytes;
     unsigned char* out; int ts;
 };
-__global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
+static __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
     __shared__ unsigned maxbits;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (no tile table: uniform 48-row tiles over n_rows rows; no gather arrays: the rows in place)

@@ -209,6 +209,146 @@ __global__ __launch_bounds__(256) void k_wgrad16(WProdJobs jobs) {
         }
 }
 
+// k_wgrad16t ------------------------------------------------------------------------------------------------------------
+// The product over TILE-PACKED operands (dmpnn_bstep16.hip: written tile by tile by the backward step kernels, 48 slot rows per row
+// tile of the plan, one scale per 16-row half, the tile count on the device only).  Output tile: ALL n (<= 320 rows: every column
+// tile of Z) x 64 k per workgroup — wave w owns the 16-row tiles w, w + 4, ... of n (<= 5) and all four 16-column tiles of k:
+// 60 MFMAs per wave and 32-row chunk from 18 KB of LDS fragment reads (the 64 x 64 kernel above reads 10 KB per 12 MFMAs and is
+// bound by the LDS, not by the matrix pipe), Z is streamed once per k tile instead of once per (n tile, k tile).
+// Scales: within a chunk the two halves may belong to different tiles, and every chunk has its own — instead of fresh accumulators
+// and one multiply-add per chunk and element, the Z fragments are scaled DOWN by the exact power of two rho = F / (s_Z s_A) of
+// their half, F = the smallest s_Z s_A of the workgroup's whole row range: the products of all chunks then share the factor F and
+// accumulate in the matrix pipe (a half whose rho leaves the f16 range holds values negligible beside the range's largest).
+struct WProdT {
+    const unsigned char* Z; const float* sZ;   // blocks [n_ctz][ld_chunks][8 KB]; scales [2 ld_chunks]
+    const unsigned char* A; const float* sA;   // blocks [n_kt][ld_chunks][8 KB]
+    int n_ctz, n_kt, ld_chunks, splits;
+    int N, Kt; float* slab; int ldk; long long slab_stride;
+};
+struct WProdTJobs { WProdT job[kWProdMaxJobs]; int wg0[kWProdMaxJobs + 1]; int n_jobs; const int* n_tiles_dev; };
+}  // namespace wg16
+
+namespace wg16 {
+constexpr int kRTW = 5;  // 16-row tiles of n per wave (20 = 320 rows per workgroup)
+
+__global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [n_ctz Z blocks | 1 A block] of the current chunk, then 64 B
+    int j = 0;
+    while (j + 1 < jobs.n_jobs && (int)blockIdx.x >= jobs.wg0[j + 1]) ++j;
+    const WProdT& a = jobs.job[j];
+    const int local = (int)blockIdx.x - jobs.wg0[j];
+    const int per = (jobs.wg0[j + 1] - jobs.wg0[j]) >> 3;   // XCD-aware order: the k tiles of one row split share an L2 (they stream the same Z blocks)
+    const int rank = (local & 7) * per + (local >> 3);
+    if (rank >= a.n_kt * a.splits) return;
+    const int split = rank / a.n_kt, kt0 = rank - split * a.n_kt;
+    const int n_tiles = *jobs.n_tiles_dev;
+    const int n_half = 3 * n_tiles;
+    int n_act = (n_half + 1) >> 1;
+    if (n_act > a.ld_chunks) n_act = a.ld_chunks;
+    const int cps = (n_act + a.splits - 1) / a.splits;
+    const int c_lo = split * cps;
+    const int c_hi = c_lo + cps < n_act ? c_lo + cps : n_act;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    unsigned* red = reinterpret_cast<unsigned*>(lds + (a.n_ctz + 1) * kBlk);
+    // ---- F: the smallest s_Z s_A over the halves of this workgroup's range ----
+    if (tid == 0) red[0] = 0x7f7fffffu;
+    __syncthreads();
+    {
+        float f = 3.0e38f;
+        const int h_lo = 2 * c_lo, h_hi = 2 * c_hi < n_half ? 2 * c_hi : n_half;
+        for (int hh = h_lo + tid; hh < h_hi; hh += 256) f = fminf(f, a.sZ[hh] * a.sA[hh]);
+        for (int off = 32; off > 0; off >>= 1) f = fminf(f, __shfl_xor(f, off));
+        if (lane == 0 && f > 0.f) atomicMin(&red[0], __float_as_uint(f));   // (positive floats order like their bit patterns)
+    }
+    __syncthreads();
+    const float F = __uint_as_float(red[0]);
+    f32x4 acc[kRTW][4];
+#pragma unroll
+    for (int r = 0; r < kRTW; ++r)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[r][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: Z row tile g = wave + 4 r -> feature rows 16 g + li of column tile g >> 2; A rows 16 kt + li
+    const int n_rt = a.n_ctz * 4;
+    int zoff_h[kRTW], zoff_l[kRTW];
+#pragma unroll
+    for (int r = 0; r < kRTW; ++r) {
+        const int gt = wave + 4 * r;
+        const int ct = gt >> 2, nloc = ((gt & 3) << 4) + li, key = (nloc >> 1) & 7;
+        zoff_h[r] = gt < n_rt ? ct * kBlk + nloc * 128 + ((lg ^ key) << 4) : -1;
+        zoff_l[r] = gt < n_rt ? ct * kBlk + nloc * 128 + (((lg + 4) ^ key) << 4) : -1;
+    }
+    int aoff_h[4], aoff_l[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int arow = 16 * kt + li, akey = (arow >> 1) & 7;
+        aoff_h[kt] = a.n_ctz * kBlk + arow * 128 + ((lg ^ akey) << 4);
+        aoff_l[kt] = a.n_ctz * kBlk + arow * 128 + (((lg + 4) ^ akey) << 4);
+    }
+    const unsigned zbytes = (unsigned)a.n_ctz * (unsigned)a.ld_chunks * (unsigned)kBlk;
+    const rsrc_t rZ = gemm::make_rsrc(a.Z, zbytes);
+    const rsrc_t rA = gemm::make_rsrc(a.A + (long long)kt0 * a.ld_chunks * kBlk, (unsigned)a.ld_chunks * (unsigned)kBlk);
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    for (int c = c_lo; c < c_hi; ++c) {
+        // the chunk's blocks: every column tile of Z, the k tile's block of A — 1 KiB per wave instruction, no registers
+        const int n_inst = (a.n_ctz + 1) * 8;
+        for (int i = wave; i < n_inst; i += 4) {
+            const int b = i >> 3, part = i & 7;
+            if (b < a.n_ctz)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rZ, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
+                                                         (unsigned)(((long long)b * a.ld_chunks + c) * kBlk + part * 1024 + lane * 16), 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
+                                                         (unsigned)((long long)c * kBlk + part * 1024 + lane * 16), 0, 0, 0);
+        }
+        // rho of this lane's half (lanes lg = 0, 1: rows 0..15 of the chunk; lg = 2, 3: rows 16..31)
+        const int hh = 2 * c + (lg >> 1);
+        const float fh = hh < n_half ? a.sZ[hh] * a.sA[hh] : 0.f;
+        const _Float16 rho = (_Float16)(fh > 0.f ? F / fh : 0.f);
+        const h2v rho2 = h2v{rho, rho};
+        __syncthreads();  // (the barrier's release waits for the DMA)
+        h8 ah[4], al[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            ah[kt] = *reinterpret_cast<const h8*>(lds + aoff_h[kt]);
+            al[kt] = *reinterpret_cast<const h8*>(lds + aoff_l[kt]);
+        }
+#pragma unroll
+        for (int r = 0; r < kRTW; ++r) {
+            if (zoff_h[r] < 0) continue;   // (wave-uniform: fewer than 20 row tiles of n)
+            h8 zh = *reinterpret_cast<const h8*>(lds + zoff_h[r]), zl = *reinterpret_cast<const h8*>(lds + zoff_l[r]);
+            {   // scale the half's rows down by rho (exact: a power of two)
+                h2v* ph = reinterpret_cast<h2v*>(&zh);
+                h2v* pl = reinterpret_cast<h2v*>(&zl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ph[e] = ph[e] * rho2; pl[e] = pl[e] * rho2; }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, ah[kt], acc[r][kt], 0, 0, 0);
+                acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, al[kt], acc[r][kt], 0, 0, 0);
+                acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, ah[kt], acc[r][kt], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // (every wave is done with the chunk before the next DMA overwrites it)
+    }
+    // D fragment: lane (li, lg) holds rows 16 g + 4 lg + e of n, column 16 kt + li of the k tile
+    const float iF = (F > 0.f && F < 3.0e38f) ? 1.f / F : 0.f;
+    float* slab = a.slab + (long long)split * a.slab_stride;
+#pragma unroll
+    for (int r = 0; r < kRTW; ++r) {
+        const int gt = wave + 4 * r;
+        if (gt >= n_rt) continue;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = 16 * gt + 4 * lg + e, k = 64 * kt0 + 16 * kt + li;
+                if (n < a.N && k < a.Kt) slab[(long long)n * a.ldk + k] = acc[r][kt][e] * iF;
+            }
+    }
+}
+
 }  // namespace wg16
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -279,6 +419,46 @@ void wgrad16_add(WProdJobs* jobs, const WSplitJob& Z, const WSplitJob& A, const 
     const int total = p.n_nt * p.n_kt * p.splits;
     jobs->wg0[jobs->n_jobs + 1] = jobs->wg0[jobs->n_jobs] + (total + 7) / 8 * 8;
     ++jobs->n_jobs;
+}
+
+// products over tile-packed operands (dmpnn_bstep16.hip): `n` jobs Z_i^T A_i into adjacent slab sets of `splits` slabs each
+WProdTPlan plan_wgrad16t(int64_t ld_chunks, int N, int Kt) {
+    WProdTPlan p;
+    p.n_ctz = (N + 63) / 64; p.n_kt = (Kt + 63) / 64; p.ld_chunks = (int)ld_chunks;
+    int splits = 512 / p.n_kt;                       // ~512 workgroups per product: two per CU
+    if (splits > ld_chunks) splits = (int)ld_chunks;
+    if (splits < 1) splits = 1;
+    p.splits = splits;
+    p.ldk = (Kt + 3) / 4 * 4;
+    p.slab_stride = (int64_t)N * p.ldk;
+    return p;
+}
+
+int launch_wgrad16t(const WProdTOperand* Z, const WProdTOperand* A, int n, const WProdTPlan& p, int N, int Kt, float* slab,
+                    const int* n_tiles_dev, hipStream_t s) {
+    if (n <= 0) return DMPNN_OK;
+    if (n > kWProdMaxJobs || p.n_ctz > wg16::kRTW) { set_error("wgrad16t: at most %d products per launch, d_h <= 320", kWProdMaxJobs); return DMPNN_EINVAL; }
+    wg16::WProdTJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    jobs.n_tiles_dev = n_tiles_dev;
+    for (int i = 0; i < n; ++i) {
+        wg16::WProdT& a = jobs.job[i];
+        a.Z = Z[i].blk; a.sZ = Z[i].scale; a.A = A[i].blk; a.sA = A[i].scale;
+        a.n_ctz = p.n_ctz; a.n_kt = p.n_kt; a.ld_chunks = p.ld_chunks; a.splits = p.splits;
+        a.N = N; a.Kt = Kt; a.slab = slab + (int64_t)i * p.splits * p.slab_stride; a.ldk = p.ldk; a.slab_stride = p.slab_stride;
+        jobs.wg0[i + 1] = jobs.wg0[i] + (p.n_kt * p.splits + 7) / 8 * 8;
+    }
+    jobs.n_jobs = n;
+    const size_t lds = (size_t)(p.n_ctz + 1) * wg16::kBlk + 64;
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16t, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(wg16::k_wgrad16t, dim3((unsigned)jobs.wg0[n]), dim3(256), lds, s, jobs);
+    DMPNN_CHECK_LAUNCH("k_wgrad16t");
+    return DMPNN_OK;
 }
 
 int launch_wgrad16(const WProdJobs& jobs, hipStream_t s) {

@@ -251,6 +251,30 @@ def fuse16_shapes(a) -> bool:
         a.flags = flags
 
 
+def _lean16_bits(lib, a) -> int:
+    """``dmpnn_forward_keep_bits_bytes`` for the per-step fused route's LEAN training forward on the shapes / options of ``a`` (0: not
+    taken — another activation class, W_d, d_h > 320, depth 1)"""
+    flags = a.flags
+    a.flags = (flags | F_FUSED | F_SPLIT16 | F_KEEP) & ~F_MEGA
+    try:
+        return int(lib.dmpnn_forward_keep_bits_bytes(C.byref(a)))
+    finally:
+        a.flags = flags
+
+
+def lean_sign_bits(st: "ForwardState") -> Tensor:
+    """``[depth, n_edges, d_h]`` bool: ``tau(z) > 0`` at H0 (site 0) and every H^(t), rows in the plan's CSR-row order — what a lean
+    training forward of the per-step fused route keeps instead of the fp32 tensors (tests / diagnostics)."""
+    if not st.route.startswith("fused16/lean"):
+        raise RuntimeError("lean_sign_bits: not a lean forward of the per-step fused route")
+    bits = st.refs[16]
+    d_h, depth = st.dims["d_h"], int(st.args.depth)
+    bn = (d_h + 63) // 64 * 64
+    b = bits.view(depth, st.plan.n_edges, bn // 8)
+    sh = torch.arange(8, device=b.device, dtype=torch.uint8)
+    return ((b.unsqueeze(-1) >> sh) & 1).bool().reshape(depth, st.plan.n_edges, bn)[:, :, :d_h]
+
+
 class RouteUnavailable(RuntimeError):
     """A demanded kernel feature does not exist on the route this batch takes (the caller has another way)."""
 
@@ -516,6 +540,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             raise RouteUnavailable("dropout inside the kernels: training forward of the tile kernel, ReLU-class activation, no W_d")
         a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF
     bits = None
+    lean16 = False
     st = ForwardState()
     st.fused = use_fused
     st.route = "mega" if use_mega else ("fused16" if use_fused16 else ("fused" if use_fused else "general"))
@@ -538,6 +563,19 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     split_ms = None
     if use_mega and not keep and not d_vd:  # inference tile kernel: nothing leaves the CU but `out`
         edge_ws = atom_ws = None
+    elif use_fused16 and keep and keep_bits and _lean16_bits(lib, a) > 0:
+        # LEAN training forward (round 4; ReLU-class activation, no W_d, d_h <= 320): nothing is kept that the backward step kernels
+        # (csrc/dmpnn_bstep16.hip) do not read — the split message rows of every step (depth - 1 slots), the split K1 operand (in
+        # the H0 buffer: no H0 tensor, the residual is recomputed per step as in inference), one sign bit per element of H0 / H^(t)
+        srf = int(lib.dmpnn_split_row_floats(d_h))
+        lean16 = True
+        n_hslots = n_mslots = 0
+        # (the H0 buffer holds the split K1 operand, rows of ceil((d_v + d_e) / 32) * 128 + 16 bytes: include/dmpnn.h, keep_bits)
+        xrow = ((d_v + d_e + 31) // 32 * 128 + 16) // 4
+        edge_ws = torch.empty((1, nE, max(ldh, xrow)), dtype=torch.float32, device=dev)
+        split_ms = torch.empty((max(n_steps, 1), nE, srf), dtype=torch.float32, device=dev)
+        atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
+        bits = torch.empty(_lean16_bits(lib, a), dtype=torch.uint8, device=dev)
     elif use_fused16 and keep:
         # training: H0 | H^(t) | M^(t) fp32 (what dmpnn_backward reads, CSR-row order) + the two split ping-pong slots in `msplit`
         srf = int(lib.dmpnn_split_row_floats(d_h))
@@ -572,7 +610,12 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         a.Hs, a.n_hslots = (st.Hs.data_ptr() if n_hslots else None), n_hslots
         a.Ms, a.n_mslots = (st.Ms.data_ptr() if n_mslots else None), max(n_mslots, 1)
         a.Mv, a.Hv = st.Mv.data_ptr(), st.Hv.data_ptr()
-        if split_ms is not None and keep:
+        if lean16:
+            a.msplit, a.msplit_bytes = split_ms.data_ptr(), split_ms.numel() * 4
+            a.keep_bits, a.keep_bits_bytes = bits.data_ptr(), bits.numel()
+            a.Hs = a.Ms = None
+            st.Ms = split_ms      # (the kept M^(t) as split rows, CSR-row order)
+        elif split_ms is not None and keep:
             a.msplit, a.msplit_bytes = split_ms.data_ptr(), split_ms.numel() * 4
         elif split_ms is not None:
             st.Ms = split_ms
@@ -601,7 +644,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             if key is not None:
                 wcache["key"], wcache["buf"] = key, wsplit
         a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
-        st.route = "mega16" if use_mega else ("fused16" if use_fused16 else "general16")
+        st.route = "mega16" if use_mega else (("fused16/lean" if lean16 else "fused16") if use_fused16 else "general16")
         if use_fused16 and storage_f16() and not keep:
             # OPT-IN half storage of the message tensor between the steps (DMPNN_F_STORE16): not fp32-class, see include/dmpnn.h
             a.flags |= F_STORE16

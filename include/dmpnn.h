@@ -36,8 +36,11 @@ extern "C" {
 /* ABI history (dmpnn_version()): 8 — round 3: dmpnn_head / dmpnn_train_step, active dropout (dmpnn_fwd_args.dropout_p / dropout_seed),
  * DMPNN_F_ATOM, the route rule (dmpnn_forward_route).  9 — end of round 3: dmpnn_head_args.bn_num_batches_tracked, DMPNN_F_TILE_PLAN
  * (training on a tile plan), dmpnn_fwd_args.keep_bits / keep_bits_bytes + dmpnn_forward_keep_bits_bytes.  Structs only ever grow at
- * their end; a host built against another version is refused by its own check of dmpnn_version() (chemprop_amd/_lib.py). */
-#define DMPNN_ABI_VERSION 9
+ * their end; a host built against another version is refused by its own check of dmpnn_version() (chemprop_amd/_lib.py).
+ * 10 — round 4: `keep_bits` also on DMPNN_F_FUSED | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (the LEAN training forward of the per-step fused
+ * route: split message rows of every step in `msplit`, sign bits, no fp32 copies) and the backward step kernels that read it;
+ * in-kernel dropout no longer takes PReLU; dmpnn_backward refuses a dropout forward it cannot scale. */
+#define DMPNN_ABI_VERSION 10
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -326,6 +329,13 @@ typedef struct dmpnn_fwd_args {
      * bytes, 16-byte aligned) the forward stores one bit per element — 2 KB per tile and tensor, straight from the matrix-pipe
      * fragments — instead of the fp32 rows (57.6 KB per tile and tensor through an LDS transpose); H0 / Hs must still be there:
      * a molecule beyond the tile keeps its fp32 rows in them (the kernels' generic path).  NULL: fp32 rows as before. */
+    /* DMPNN_F_FUSED | DMPNN_F_SPLIT16 | DMPNN_F_KEEP with `keep_bits` (ABI 10; ReLU-class activation, no W_d, no dropout, d_h <= 320,
+     * depth >= 2, a full plan): the LEAN training forward of the per-step fused route.  `msplit` then holds depth - 1 slots of split
+     * message rows (M^(t) of every step, CSR-row order: nothing is copied to fp32), `H0` holds the split K1 operand [V[src] || E]
+     * — rows of ceil((d_v + d_e) / 32) * 128 + 16 bytes, so the buffer must span n_edges * max(4 ldh, that) bytes — (no H0
+     * tensor: the residual is recomputed per step), `keep_bits` one bit per element of H0 and of
+     * every H^(t) as rows of block_cols(d_h) / 8 bytes per site (site 0: H0), `Mv` the fp32 per-atom sums; Hs / Ms are not used.
+     * dmpnn_backward then runs the backward STEP kernels over the plan's tiles (csrc/dmpnn_bstep16.hip). */
     void* keep_bits; size_t keep_bits_bytes;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);

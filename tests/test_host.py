@@ -242,9 +242,16 @@ def test_forward_route_is_one_shape_rule():
     # QM9-sized molecules: the whole-forward tile kernel, inference and training, at any batch size with molecule tiles
     assert route(qm9) == route(qm9, keep=1) == route(qm9, plan=2) == R["mega16"] and route(qm9, arith=1) == R["mega"]
     assert route(big) == route(big, keep=1) == R["mega16"]
-    # molecules beyond the tile (cap 1): per-step fused route on the f16 pipe for inference, per-step general16 for training at size
+    # molecules beyond the tile (cap 1): per-step fused route on the f16 pipe for inference — and, round 4, for TRAINING at size with
+    # a ReLU-class activation (its lean forward + the backward step kernels); general16 for training with anything else
     assert route(big, cap=1) == route(big, cap=1, plan=1) == R["fused16"]
-    assert route(big, keep=1, cap=1) == R["general16"]
+    assert route(big, keep=1, cap=1) == R["fused16"]
+    for mod in (dict(act=_lib.ACT["tanh"]), dict(act=_lib.ACT["prelu"]), dict(depth=1), dict(dropout_p=0.5), dict(W_d=4096, d_vd=8, V_d=4096, ldvd=8)):
+        t = args(37000, 73000, flags=_lib.F_LOADER_TILES)
+        for k, v in mod.items():
+            setattr(t, k, v)
+        assert route(t, keep=1, cap=1) == R["general16"], mod
+    assert route(big, keep=1, cap=1, plan=1) == -1 and route(big, keep=1, cap=0) == R["general16"]
     assert route(qm9, cap=1) == R["fused16"] and route(qm9, keep=1, cap=1) == R["fused"] and route(qm9, cap=1, arith=1) == R["fused"]
     small = args(300, 600)
     assert route(small, cap=1) == R["fused"] and route(small, cap=0) == R["general"]          # below the crossover: fp32-MFMA kernels

@@ -659,14 +659,22 @@ def test_relu_gradients_at_size(n_mols, kind, kw, gpu_device):
     bmg.to(gpu_device)
     out = mp(bmg)
     st = out.grad_fn.st                                        # the kept tensors of this forward (FusedMP)
-    rows = st.route in ("mega", "mega16", "fused", "fused16")  # kept edge tensors in CSR-row order (row i = edge perm[i])
+    rows = st.route in ("mega", "mega16", "fused", "fused16", "fused16/lean")  # kept edge tensors in CSR-row order (row i = edge perm[i])
     to_edges = (lambda X: X[st.plan.inv32.long()]) if rows else (lambda X: X)
-    masks = [(to_edges(st.H0[:, :h]) > 0).double().cpu()]
-    masks += [(to_edges(st.Hs[t][:, :h]) > 0).double().cpu() for t in range(n_upd)]
+    if st.route == "fused16/lean":   # (round 4: molecules beyond the tile train on the per-step fused route, which keeps SIGN BITS, not rows)
+        from chemprop_amd import engine as _eng
+
+        sb = _eng.lean_sign_bits(st)
+        masks = [to_edges(sb[t]).double().cpu() for t in range(n_upd + 1)]
+    else:
+        masks = [(to_edges(st.H0[:, :h]) > 0).double().cpu()]
+        masks += [(to_edges(st.Hs[t][:, :h]) > 0).double().cpu() for t in range(n_upd)]
     masks.append((out.detach() > 0).double().cpu())
     (out * G.to(gpu_device)).sum().backward()
     if kind == "qm9":  # beyond the single-workgroup plan: the full plan carries molecule tiles (dmpnn_prepare_with_batch)
         assert st.route == "mega16" and st.plan.any_size, st.route
+    if kind in ("cgr", "synth40"):  # >= 20 000 directed edges, molecules beyond the tile, ReLU, d_h 300: the lean per-step fused route
+        assert st.route == "fused16/lean", st.route
 
     o64, _, pre, true_masks = forward64()
     assert parity_err(out.detach().cpu().numpy(), o64.detach().numpy()) <= TOL
@@ -1052,7 +1060,7 @@ def test_training_forward_on_the_per_step_fused_route(n_mols, kind, kw, gpu_devi
     for route in ("fused16", "general"):
         plan = engine.GraphPlan.from_bmg(bmg)
         out, st = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, mp.W_i.bias, mp.W_h.bias,
-                                 depth=mp.depth, act=act, slope=slope, keep=True, route=route)
+                                 depth=mp.depth, act=act, slope=slope, keep=True, route=route, keep_bits=False)   # (keep_bits=False: the fp32-copies form)
         assert st.route == ("fused16" if route == "fused16" else st.route) and (route != "fused16" or st.args.msplit)
         got[route] = (out, engine.backward(st, G.to(gpu_device), need))
     out16, g16 = got["fused16"]
@@ -1160,3 +1168,88 @@ def test_validate_modes_give_the_same_function(mode, gpu_device, monkeypatch):
     replay = mp.__dict__.get("_dmpnn_replay") is not None
     assert replay == (mode != "always")  # the steady tile-plan path exists unless every batch is validated
     assert getattr(mp, "_dmpnn_batches_checked", 0) == {"never": 0, "always": 4, "first": 2}[mode]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: training of molecules beyond the tile on the per-step FUSED route — the lean forward + the backward step kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mols,kind,kw", [(48, "synth40", dict(d_h=64)),
+                                            (24, "zinc", dict(d_h=128, depth=4, bias=True, activation="leakyrelu")),
+                                            (40, "cgr", dict(d_v=106, d_e=28, d_h=96, depth=2)),
+                                            (64, "qm9", dict(d_h=300)),
+                                            (300, "synth40", dict(d_h=300))])
+def test_lean_fused16_training_route_matches_the_general_route(n_mols, kind, kw, gpu_device):
+    """``route="fused16"`` with ``keep`` (ReLU-class activation): split message rows of every step + sign bits are all the forward
+    keeps; ``dmpnn_backward`` runs the backward step kernels (csrc/dmpnn_bstep16.hip) and the weight-gradient products on operands
+    written tile by tile.  Output, the kept signs and every gradient against the per-step GENERAL route (fp32 MFMA: the reference's
+    op order) on the same batch, and the gradients against the oracle's autograd."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing, classify_activation
+
+    bmg = synth.random_batch(n_mols, kind, seed=17)
+    torch.manual_seed(8)
+    cpu = BondMessagePassing(**kw)
+    mp = BondMessagePassing(**kw)
+    mp.load_state_dict(cpu.state_dict())
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    act, slope, _ = classify_activation(mp.tau)
+    W = lambda l, n: getattr(getattr(mp, l), n)
+    args = (bmg.V, bmg.E, W("W_i", "weight"), W("W_h", "weight"), W("W_o", "weight"), W("W_o", "bias"), W("W_i", "bias"), W("W_h", "bias"))
+    plan = engine.GraphPlan.from_bmg(bmg)
+    G = torch.randn(int(bmg.V.shape[0]), mp.output_dim, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    need = dict(W_i=True, b_i=True, W_h=True, b_h=True, W_o=True, b_o=True)
+    o_gen, st_gen = engine.forward(plan, *args, depth=mp.depth, act=act, slope=slope, keep=True, route="general", mfma="f32")
+    g_gen = engine.backward(st_gen, G, need)
+    o_lean, st = engine.forward(plan, *args, depth=mp.depth, act=act, slope=slope, keep=True, route="fused16")
+    assert st.route == "fused16/lean", st.route
+    g_lean = engine.backward(st, G, need)
+    torch.cuda.synchronize()
+    assert parity_err(o_lean.cpu().numpy(), o_gen.cpu().numpy()) <= TOL
+    # the kept signs against the general route's kept tensors (caller's edge order there, CSR rows here)
+    h = mp.W_h.weight.shape[0]
+    sb = engine.lean_sign_bits(st)[:, st.plan.inv32.long()]
+    ref_pos = [st_gen.H0[:, :h] > 0] + [st_gen.Hs[t][:, :h] > 0 for t in range(mp.depth - 1)]
+    flips = sum(int((sb[t] != ref_pos[t]).sum()) for t in range(mp.depth))
+    assert flips <= 2, flips   # (two arithmetics: a pre-activation within rounding of the kink may land on either side)
+    errs = {k: parity_err(g_lean[k].cpu().numpy(), g_gen[k].cpu().numpy()) for k in g_gen if g_gen[k] is not None}
+    print(f"lean-{kind}-{n_mols}: sign flips {flips}, gradient errors vs the general route {errs}")
+    if flips == 0:
+        assert max(errs.values()) <= 2e-5, errs
+    # ... and against the oracle's autograd (the restated ATen op sequence on the CPU)
+    w = ot.MPWeights(cpu.W_i.weight, cpu.W_h.weight, cpu.W_o.weight, cpu.W_o.bias, cpu.W_i.bias, cpu.W_h.bias)
+    cb = synth.random_batch(n_mols, kind, seed=17)
+    ref = ot.forward_bmg(cb, w, depth=cpu.depth, activation=cpu.tau)   # (a callable: the module's own activation)
+    (ref * G.cpu()).sum().backward()
+    assert parity_err(o_lean.cpu().numpy(), ref.detach().numpy()) <= TOL
+    if flips == 0:
+        for k, prm in (("W_i", cpu.W_i.weight), ("W_h", cpu.W_h.weight), ("W_o", cpu.W_o.weight), ("b_o", cpu.W_o.bias)):
+            assert parity_err(g_lean[k].cpu().numpy(), prm.grad.numpy()) <= 2e-5, k
+
+
+@pytest.mark.gpu
+def test_lean_fused16_is_the_default_for_training_at_size_and_repeats(gpu_device):
+    """The route rule: a TRAINING forward of >= 20 000 directed edges whose molecules exceed the tile (40-atom molecules: BASELINE
+    configs[3]) takes the lean per-step fused route by default; two backward passes give bit-identical gradients (no atomics); a
+    tanh block (not a ReLU-class activation) keeps the per-step general route."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = synth.random_batch(512, "synth40", seed=2)
+    bmg.to(gpu_device)
+    torch.manual_seed(0)
+    mp = BondMessagePassing().to(gpu_device).train()
+    G = torch.randn(int(bmg.V.shape[0]), 300, device=gpu_device)
+    grads = []
+    for _ in range(3):
+        mp.zero_grad()
+        out = mp(bmg)
+        assert out.grad_fn.st.route == "fused16/lean", out.grad_fn.st.route
+        out.backward(G)
+        grads.append([p.grad.clone() for p in mp.parameters()])
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(g).all() for g in grads[-1])
+    assert all(torch.equal(a, b) for a, b in zip(grads[1], grads[2]))
+    mp2 = BondMessagePassing(activation="tanh").to(gpu_device).train()
+    assert mp2(bmg).grad_fn.st.route == "general16"

@@ -250,12 +250,12 @@ def _golden_model_cases():
     return sorted(glob.glob(os.path.join(GOLDEN_DIR, "model", "*.npz")))
 
 
-def _build_hip_mpnn(R, cfg):
-    """tests/golden/make_golden_model.py: build(), with HipMPNN in place of the reference's MPNN."""
+def _build_hip_mpnn(R, cfg, stock=False):
+    """tests/golden/make_golden_model.py: build(), with HipMPNN in place of the reference's MPNN (``stock``: the reference's own)."""
     from chemprop_amd import integration
 
     cnn = R["nn"]
-    HipMPNN = integration.hip_mpnn_class()[1]
+    HipMPNN = R["MPNN"] if stock else integration.hip_mpnn_class()[1]
     agg = dict(norm=cnn.NormAggregation, mean=cnn.MeanAggregation, sum=cnn.SumAggregation)[cfg["agg"]]()
     mp = R["BMP"](**cfg["mp"])
     crit = None
@@ -316,8 +316,8 @@ def test_hip_mpnn_training_step_is_the_reference_s(path, gpu_device):
             #  of test_model.py::test_fused_step_matches_goldens)
             assert parity_err(v.cpu().numpy(), want) <= 2e-4, k
     # the trained state moves into the STOCK class (same keys), which predicts like the golden's trained reference
-    stock = R["MPNN"](R["BMP"](**cfg["mp"]), type(model.agg).__mro__[1](), model.predictor.hparams["cls"](
-        input_dim=model.message_passing.output_dim, criterion=None, **cfg["ffn"]), batch_norm=cfg["bn"])
+    stock = _build_hip_mpnn(R, cfg, stock=True)
+    assert type(stock.message_passing) is R["BMP"]
     stock.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=False)
     stock.eval()
     with torch.no_grad():
@@ -352,17 +352,17 @@ def test_hip_mpnn_falls_back_to_the_module_path_and_follows_the_schedule(gpu_dev
     no = torch.zeros(32, 1, dtype=torch.bool, device=gpu_device)
     V_d = torch.randn(int(bmg.V.shape[0]), 4, device=gpu_device)
     lrs, seen = [], []
-    real = integration.hip_mpnn_class()[1]._hip_state
     for s in range(4):
         st = model._hip_state()
         before = st["opt"].steps
         lrs.append(topt.param_groups[0]["lr"])
-        loss = model.training_step((bmg, V_d if s % 2 == 0 else None, None, y, w, no, no), s)
+        loss = model.training_step((bmg, V_d, None, y, w, no, no), s)
         seen.append(st["route"])
         assert st["opt"].steps == before + 1 and torch.isfinite(loss)
-    assert seen[0] == "module" and seen[2] == "module", seen            # V_d: the fused step does not implement the W_d branch
-    # (the block HAS a W_d: FusedTrainer refuses the model as a whole, so every step is the module path — on the flat Adam)
-    assert all(r == "module" for r in seen)
+    # (the block has a W_d branch and the batch carries V_d: FusedTrainer refuses the model, every step is the module path — on the
+    #  flat Adam)
+    assert all(r == "module" for r in seen), seen
+    assert "V_d" in (model._hip_state()["why"] or "")
     want = [1e-4, 1e-4 + (1e-3 - 1e-4) / 2, 1e-3, 1e-3 * (1e-4 / 1e-3) ** (1 / 4)]
     assert np.allclose(lrs, want, rtol=1e-6), (lrs, want)
     ck = {}
