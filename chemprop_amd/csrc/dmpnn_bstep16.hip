@@ -54,6 +54,7 @@ __device__ __forceinline__ int piece_off(int nloc, int p8, int lo) {
 struct BStepK {
     int M, N;                                  // directed edges (rows), d_h
     const int* hdr;                            // plan header: flags, the number of row tiles actually used
+    int n_atoms;
     const int* tile_row; const int* tile_atom; const int* row_ptr; const int* revp; const int* dstp;
     const float* Tin; int ldt;                 // [M][ldt] fp32: Tin[r] = gM_next[rev r] (message mode), or null:
     const float* gMv; int ldg;                 // [V][ldg] fp32: gH[r] = gMv[dst r]      (gather mode: the first launch)
@@ -100,33 +101,36 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
         constexpr int BB = BN / 8;
         for (int it = tid; it < nrows * BB; it += NT) Bt[it] = g.bits ? g.bits[(long long)rs * g.bstride + it] : (unsigned char)0xFF;
     }
-    if (gather) __syncthreads();
-    // ---- the tile's input rows: fp32, coalesced float4 loads -> the padded LDS tile ----
+    // ---- the tile's input rows by LDS-DMA (no registers, one round trip): fp32 rows at stride LDF = N in the tile region.  Message
+    // mode: the rows are contiguous in memory; gather mode: lane-linear in LDS, every lane from its own atom row ----
+    const int LDF = g.N;                                           // (ldt == N: d_h % 4 == 0 on this route, so ldh = d_h)
     {
-        const int n_items = nrows * qn;
-        for (int it0 = tid; it0 < n_items; it0 += NT * 4) {
-            float4 v[4];
-            int rr[4], qq[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int it = it0 + j * NT;
-                const bool ok = it < n_items;
-                const int r = ok ? (qn == 1 ? it : (int)__umulhi((unsigned)it, g.qmagic)) : 0;
-                const int q = ok ? it - r * qn : 0;
-                rr[j] = ok ? r : -1; qq[j] = q;
-                const float* src = gather ? g.gMv + (long long)meta[r] * g.ldg : g.Tin + (long long)(rs + r) * g.ldt;
-                v[j] = *reinterpret_cast<const float4*>(src + 4 * q);
+        const unsigned row_b = (unsigned)g.N * 4u;
+        const unsigned nbytes = (unsigned)nrows * row_b;
+        const int n_inst = (int)((nbytes + 1023u) >> 10);
+        if (!gather) {
+            const rsrc_t rT = gemm::make_rsrc(g.Tin + (long long)rs * g.ldt, nbytes);
+            for (int i = wave; i < n_inst; i += NW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rT, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
+                                                         (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
+        } else {
+            __syncthreads();                                       // meta = the rows' destination atoms
+            const rsrc_t rG = gemm::make_rsrc(g.gMv, gemm::clamp_bytes((long long)g.n_atoms * g.ldg * 4));
+            for (int i = wave; i < n_inst; i += NW) {
+                const unsigned o = (unsigned)(i * 1024 + lane * 16);
+                const unsigned r = __umulhi(o >> 4, g.qmagic);     // o / row_b  (row_b = 16 qn)
+                const unsigned cb = o - r * row_b;
+                const unsigned off = r < (unsigned)nrows ? (unsigned)meta[r] * (unsigned)g.ldg * 4u + cb : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16, off, 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (rr[j] >= 0) *reinterpret_cast<float4*>(T + rr[j] * LDC + 4 * qq[j]) = v[j];
         }
     }
     if (gather) {
-        // meta now becomes the reverse rows (the scatter of the result); every thread has consumed its dst entries above
+        // meta now becomes the reverse rows (the scatter of the result): every wave has issued its loads
         __syncthreads();
         if (tid < nrows) meta[tid] = g.Tout ? g.revp[rs + tid] : 0;
     }
+    __syncthreads();   // (the barrier's release waits for the DMA)
     // ---- gH, gZ in place ----
     const float nanv = __int_as_float(0x7fc00000);
     float mx = 0.f;
@@ -142,10 +146,9 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
         return z;
     };
     if (gather) {
-        __syncthreads();
         for (int it = tid; it < nrows * qn; it += NT) {
             const int r = qn == 1 ? it : (int)__umulhi((unsigned)it, g.qmagic), q = it - r * qn;
-            float4* cell = reinterpret_cast<float4*>(T + r * LDC + 4 * q);
+            float4* cell = reinterpret_cast<float4*>(T + r * LDF + 4 * q);
             *cell = mask4(*cell, r, q);
         }
     } else {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
                 if (r1 - r0 <= 4) {   // an atom of a molecule: its rows requested together, summed in increasing row order
                     float4 y[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const float4*>(T + (r0 + i < r1 ? r0 + i : (r1 > r0 ? r0 : 0)) * LDC + 4 * q);
+                    for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const float4*>(T + (r0 + i < r1 ? r0 + i : (r1 > r0 ? r0 : 0)) * LDF + 4 * q);
                     float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (r1 > r0) S = y[0];
 #pragma unroll
@@ -169,17 +172,17 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (r0 + i < r1)
-                            *reinterpret_cast<float4*>(T + (r0 + i) * LDC + 4 * q) =
+                            *reinterpret_cast<float4*>(T + (r0 + i) * LDF + 4 * q) =
                                 mask4(make_float4(S.x - y[i].x, S.y - y[i].y, S.z - y[i].z, S.w - y[i].w), r0 + i, q);
                     continue;
                 }
                 float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int r = r0; r < r1; ++r) {
-                    const float4 y = *reinterpret_cast<const float4*>(T + r * LDC + 4 * q);
+                    const float4 y = *reinterpret_cast<const float4*>(T + r * LDF + 4 * q);
                     S.x += y.x; S.y += y.y; S.z += y.z; S.w += y.w;
                 }
                 for (int r = r0; r < r1; ++r) {
-                    float4* cell = reinterpret_cast<float4*>(T + r * LDC + 4 * q);
+                    float4* cell = reinterpret_cast<float4*>(T + r * LDF + 4 * q);
                     const float4 y = *cell;
                     *cell = mask4(make_float4(S.x - y.x, S.y - y.y, S.z - y.z, S.w - y.w), r, q);
                 }
@@ -194,58 +197,34 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
     }
     __syncthreads();
     const float s = poison ? 1.f : scale_for(__uint_as_float(maxbits[0]));
-    // ---- gZ: (a) the product operand blocks of this tile's slot, (b) the split A tile of the contraction.  Item = (8 rows, 4
-    // columns): read as fp32 BEFORE anyone overwrites the region with the split tile (the two share the LDS) ----
-    constexpr int NQ = BN / 4;                        // column quads of the padded row
-    constexpr int ITEMS = (BM / 8) * NQ;              // 6 row groups x NQ
-    constexpr int IPT = (ITEMS + NT - 1) / NT;        // items per thread (2 at BN = 320)
-    float4 v[IPT][8];
+    // ---- gZ as product operand: the tile's slot of the tile-packed blocks.  Item = (feature, 8 slot rows): one 16-byte piece of
+    // hi and one of lo; consecutive lanes = the six row groups of a feature, then the next feature — a wave's store covers the
+    // 64 / 32 contiguous bytes a feature's pieces of one chunk make up, not 64 scattered pieces ----
+    {
+        const h8 z8 = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = tid; it < BN * 6; it += NT) {
+            const int n = it / 6, gq = it - n * 6;
+            float x[8];
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        const int it = tid + k * NT;
-        const int gq = it / NQ, q = it - gq * NQ;     // row group (8 rows), column quad
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 8 * gq + j;
-            const bool ok = it < ITEMS && r < nrows && 4 * q < g.N;
-            const float4 x = *reinterpret_cast<const float4*>(T + (ok ? r : 0) * LDC + 4 * q);
-            v[k][j] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __syncthreads();
-    const bool contract_on = g.W.p != nullptr;
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        const int it = tid + k * NT;
-        if (it >= ITEMS) continue;
-        const int gq = it / NQ, q = it - gq * NQ;
-        h4 hi[8], lo[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) mega16::split4(v[k][j], s, hi[j], lo[j]);
-        if (contract_on) {
-            const int col4 = 4 * q;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                unsigned char* p = Ag + (8 * gq + j) * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
-                *reinterpret_cast<h4*>(p) = hi[j];
-                *reinterpret_cast<h4*>(p + 64) = lo[j];
+            for (int jj = 0; jj < 8; ++jj) {
+                const int r = 8 * gq + jj;
+                const bool ok = r < nrows && n < g.N;
+                const float raw = T[(ok ? r : 0) * LDF + (ok ? n : 0)];
+                x[jj] = ok ? raw * s : 0.f;
             }
-        }
-        // blocks: feature n = 4 q + c of column tile n >> 6; slot rows 48 t + 8 gq .. + 7
-        int chunk, p8;
-        tp_piece(t, gq, chunk, p8);
+            h8 hi, lo;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = 4 * q + c, ct = n >> 6, nloc = n & 63;
+            for (int jj = 0; jj < 8; ++jj) { hi[jj] = (_Float16)x[jj]; lo[jj] = (_Float16)(x[jj] - (float)hi[jj]); }
+            int chunk, p8;
+            tp_piece(t, gq, chunk, p8);
+            const int ct = n >> 6, nloc = n & 63;
             unsigned char* blk = g.Zblk + ((long long)ct * g.ld_chunks + chunk) * kBlk;
-            *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 0)) = h8{hi[0][c], hi[1][c], hi[2][c], hi[3][c], hi[4][c], hi[5][c], hi[6][c], hi[7][c]};
-            *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 1)) = h8{lo[0][c], lo[1][c], lo[2][c], lo[3][c], lo[4][c], lo[5][c], lo[6][c], lo[7][c]};
+            *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 0)) = hi;
+            *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 1)) = lo;
         }
-    }
-    {   // the scales of the tile's three halves; the LAST tile of an odd count also zeroes the half that completes its chunk
+        // the scales of the tile's three halves; the LAST tile of an odd count also zeroes the half that completes its chunk
         if (tid < 3) g.Zscale[3 * t + tid] = s;
         if (t == n_tiles - 1 && (n_tiles & 1)) {
-            const h8 z8 = h8{0, 0, 0, 0, 0, 0, 0, 0};
             for (int it = tid; it < 2 * BN; it += NT) {       // (feature n, row group 6 | 7 = the 16 slot rows behind the tile)
                 const int n = it >> 1, ct = n >> 6, nloc = n & 63;
                 int chunk, p8;
@@ -257,7 +236,42 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
             if (tid == 0) g.Zscale[3 * n_tiles] = 1.f;
         }
     }
+    const bool contract_on = g.W.p != nullptr;
     if (!contract_on) return;
+    // ---- the split A tile of the contraction.  Item = (8 rows, 4 columns): read as fp32 BEFORE anyone overwrites the region with
+    // the split tile (the two share the LDS, at different row strides) ----
+    constexpr int NQ = BN / 4;                        // column quads of the padded row
+    constexpr int ITEMS = (BM / 8) * NQ;              // 6 row groups x NQ
+    constexpr int IPT = (ITEMS + NT - 1) / NT;        // items per thread (2 at BN = 320)
+    float4 v[IPT][8];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int it = tid + k * NT;
+        const int gq = it / NQ, q = it - gq * NQ;     // row group (8 rows), column quad
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int r = 8 * gq + jj;
+            const bool ok = it < ITEMS && r < nrows && 4 * q < g.N;
+            const float4 x = *reinterpret_cast<const float4*>(T + (ok ? r * LDF + 4 * q : 0));
+            v[k][jj] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int it = tid + k * NT;
+        if (it >= ITEMS) continue;
+        const int gq = it / NQ, q = it - gq * NQ;
+        const int col4 = 4 * q;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            h4 hi, lo;
+            mega16::split4(v[k][jj], s, hi, lo);
+            unsigned char* p = Ag + (8 * gq + jj) * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
+            *reinterpret_cast<h4*>(p) = hi;
+            *reinterpret_cast<h4*>(p + 64) = lo;
+        }
+    }
     __syncthreads();   // the split A tile is complete
 
     // ---- gM = gZ W_h: barrier-free MFMA loop, A fragments from the LDS tile, weight fragments from L2 as a ring (k_step16's loop) ----
@@ -380,40 +394,40 @@ __global__ __launch_bounds__(256) void k_rows2blk(Rows2BlkK g) {
     __syncthreads();
     float S = nrows > 0 ? __uint_as_float(minbits) : 1.f;
     if (g.ones_col >= 0 && S > 16384.f) S = 16384.f;   // (the column of ones must stay inside the f16 range: 1 * S <= 2^14)
-    const int n8 = g.n_ct * 8;                          // 8-column groups of the padded operand
     const int nc_row = (TS - 16) / 128;                 // chunks a row holds
     typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+    // per-row ratio S / s_r (a power of two <= 1; 0 beyond the tile) once, in the rows' tails' place
+    __syncthreads();
+    if (tid < BM) {
+        const float sv = tid < nrows ? *reinterpret_cast<const float*>(lds + tid * TS + (TS - 16)) : 0.f;
+        const float sr = (sv > 0.f && sv < 3.0e38f) ? sv : 1.f;
+        *reinterpret_cast<float*>(lds + tid * TS + (TS - 16)) = tid < nrows ? S / sr : 0.f;
+    }
+    __syncthreads();
     const int n_gq = (t == n_tiles - 1 && (n_tiles & 1)) ? 8 : 6;   // (the last tile of an odd count also zeroes the half behind it)
-    for (int it = tid; it < n_gq * n8; it += 256) {     // (8-row group of the slot, 8-column group)
-        const int gq = it / n8, c8 = it - gq * n8;
-        h8v hi[8], lo[8];
+    const int n_feat = g.n_ct * 64;
+    // item = (feature, 8 slot rows): consecutive lanes = the row groups of a feature, then the next feature (contiguous stores)
+    for (int it = tid; it < n_feat * n_gq; it += 256) {
+        const int n = it / n_gq, gq = it - n * n_gq;
+        const int cc = n >> 5, kk = n & 31;
+        h8v ph, pl;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 8 * gq + j;
-            const bool ok = r < nrows && (c8 >> 2) < nc_row;
-            const unsigned char* p = lds + (ok ? r : 0) * TS + (ok ? (c8 >> 2) : 0) * 128 + (c8 & 3) * 16;
-            const float sv = *reinterpret_cast<const float*>(lds + (ok ? r : 0) * TS + (TS - 16));
-            const float sr = (sv > 0.f && sv < 3.0e38f) ? sv : 1.f;
-            const _Float16 ratio = (_Float16)(ok ? S / sr : 0.f);    // a power of two <= 1 (0 beyond the tile)
-            const h8v a = *reinterpret_cast<const h8v*>(p), b = *reinterpret_cast<const h8v*>(p + 64);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { hi[j][e] = ok ? a[e] * ratio : (_Float16)0; lo[j][e] = ok ? b[e] * ratio : (_Float16)0; }
+        for (int jj = 0; jj < 8; ++jj) {
+            const int r = 8 * gq + jj;
+            const bool ok = r < nrows && cc < nc_row;
+            const unsigned char* p = lds + (ok ? r : 0) * TS + (ok ? cc : 0) * 128 + kk * 2;
+            const _Float16 ratio = (_Float16)(*reinterpret_cast<const float*>(lds + (ok ? r : 0) * TS + (TS - 16)));
+            const _Float16 a = *reinterpret_cast<const _Float16*>(p), b = *reinterpret_cast<const _Float16*>(p + 64);
+            ph[jj] = ok ? a * ratio : (_Float16)0;
+            pl[jj] = ok ? b * ratio : (_Float16)0;
+            if (n == g.ones_col) { ph[jj] = r < nrows ? (_Float16)S : (_Float16)0; pl[jj] = (_Float16)0; }
         }
         int chunk, p8;
         tp_piece(t, gq, chunk, p8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int n = 8 * c8 + e, ct = n >> 6, nloc = n & 63;
-            h8v ph = h8v{hi[0][e], hi[1][e], hi[2][e], hi[3][e], hi[4][e], hi[5][e], hi[6][e], hi[7][e]};
-            h8v pl = h8v{lo[0][e], lo[1][e], lo[2][e], lo[3][e], lo[4][e], lo[5][e], lo[6][e], lo[7][e]};
-            if (n == g.ones_col) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { ph[j] = (8 * gq + j < nrows) ? (_Float16)S : (_Float16)0; pl[j] = (_Float16)0; }
-            }
-            unsigned char* blk = g.blk + ((long long)ct * g.ld_chunks + chunk) * kBlk;
-            *reinterpret_cast<h8v*>(blk + piece_off(nloc, p8, 0)) = ph;
-            *reinterpret_cast<h8v*>(blk + piece_off(nloc, p8, 1)) = pl;
-        }
+        const int ct = n >> 6, nloc = n & 63;
+        unsigned char* blk = g.blk + ((long long)ct * g.ld_chunks + chunk) * kBlk;
+        *reinterpret_cast<h8v*>(blk + piece_off(nloc, p8, 0)) = ph;
+        *reinterpret_cast<h8v*>(blk + piece_off(nloc, p8, 1)) = pl;
     }
     if (tid < 3) g.scale[3 * t + tid] = S;
     if (tid == 3 && n_gq == 8) g.scale[3 * n_tiles] = 1.f;
@@ -459,7 +473,7 @@ int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const fl
     const int* plan_i = static_cast<const int*>(f.plan);
     bstep16::BStepK g;
     memset(&g, 0, sizeof(g));
-    g.M = (int)nE; g.N = (int)h;
+    g.M = (int)nE; g.N = (int)h; g.n_atoms = (int)nV;
     g.hdr = plan_i;
     g.tile_row = plan_i + L.tile_row; g.tile_atom = plan_i + L.tile_atom; g.row_ptr = plan_i + L.row_ptr;
     g.revp = plan_i + L.revp; g.dstp = plan_i + L.dstp;

@@ -230,17 +230,20 @@ struct WProdTJobs { WProdT job[kWProdMaxJobs]; int wg0[kWProdMaxJobs + 1]; int n
 
 namespace wg16 {
 constexpr int kRTW = 5;  // 16-row tiles of n per wave (20 = 320 rows per workgroup)
+constexpr int kKT2 = 2;  // 64-column tiles of k per workgroup: Z (all of n: up to 40 KB per chunk) is streamed once per 128 columns of k
 
 __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [n_ctz Z blocks | 1 A block] of the current chunk, then 64 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [n_ctz Z blocks | kKT2 A blocks] of the current chunk, then 64 B
     int j = 0;
     while (j + 1 < jobs.n_jobs && (int)blockIdx.x >= jobs.wg0[j + 1]) ++j;
     const WProdT& a = jobs.job[j];
     const int local = (int)blockIdx.x - jobs.wg0[j];
-    const int per = (jobs.wg0[j + 1] - jobs.wg0[j]) >> 3;   // XCD-aware order: the k tiles of one row split share an L2 (they stream the same Z blocks)
+    const int n_kg = (a.n_kt + kKT2 - 1) / kKT2;             // workgroup columns of k
+    const int per = (jobs.wg0[j + 1] - jobs.wg0[j]) >> 3;   // XCD-aware order: the k columns of one row split share an L2 (they stream the same Z blocks)
     const int rank = (local & 7) * per + (local >> 3);
-    if (rank >= a.n_kt * a.splits) return;
-    const int split = rank / a.n_kt, kt0 = rank - split * a.n_kt;
+    if (rank >= n_kg * a.splits) return;
+    const int split = rank / n_kg, kg = rank - split * n_kg;
+    const int n_ka = a.n_kt - kKT2 * kg < kKT2 ? a.n_kt - kKT2 * kg : kKT2;   // live k tiles of this column (the last one may hold fewer)
     const int n_tiles = *jobs.n_tiles_dev;
     const int n_half = 3 * n_tiles;
     int n_act = (n_half + 1) >> 1;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
     const int c_hi = c_lo + cps < n_act ? c_lo + cps : n_act;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    unsigned* red = reinterpret_cast<unsigned*>(lds + (a.n_ctz + 1) * kBlk);
+    unsigned* red = reinterpret_cast<unsigned*>(lds + (a.n_ctz + kKT2) * kBlk);
     // ---- F: the smallest s_Z s_A over the halves of this workgroup's range ----
     if (tid == 0) red[0] = 0x7f7fffffu;
     __syncthreads();
@@ -263,12 +266,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
     }
     __syncthreads();
     const float F = __uint_as_float(red[0]);
-    f32x4 acc[kRTW][4];
+    f32x4 acc[kRTW][4 * kKT2];
 #pragma unroll
     for (int r = 0; r < kRTW; ++r)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) acc[r][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // fragment addresses: Z row tile g = wave + 4 r -> feature rows 16 g + li of column tile g >> 2; A rows 16 kt + li
+        for (int kt = 0; kt < 4 * kKT2; ++kt) acc[r][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: Z row tile g = wave + 4 r -> feature rows 16 g + li of column tile g >> 2; A rows 16 kt + li of block kt >> 2
     const int n_rt = a.n_ctz * 4;
     int zoff_h[kRTW], zoff_l[kRTW];
 #pragma unroll
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
         zoff_h[r] = gt < n_rt ? ct * kBlk + nloc * 128 + ((lg ^ key) << 4) : -1;
         zoff_l[r] = gt < n_rt ? ct * kBlk + nloc * 128 + (((lg + 4) ^ key) << 4) : -1;
     }
-    int aoff_h[4], aoff_l[4];
+    int aoff_h[4], aoff_l[4];   // (inside an A block)
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         const int arow = 16 * kt + li, akey = (arow >> 1) & 7;
@@ -287,11 +290,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
     }
     const unsigned zbytes = (unsigned)a.n_ctz * (unsigned)a.ld_chunks * (unsigned)kBlk;
     const rsrc_t rZ = gemm::make_rsrc(a.Z, zbytes);
-    const rsrc_t rA = gemm::make_rsrc(a.A + (long long)kt0 * a.ld_chunks * kBlk, (unsigned)a.ld_chunks * (unsigned)kBlk);
+    const rsrc_t rA = gemm::make_rsrc(a.A + (long long)(kKT2 * kg) * a.ld_chunks * kBlk, (unsigned)n_ka * (unsigned)a.ld_chunks * (unsigned)kBlk);
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    for (int c = c_lo; c < c_hi; ++c) {
-        // the chunk's blocks: every column tile of Z, the k tile's block of A — 1 KiB per wave instruction, no registers
-        const int n_inst = (a.n_ctz + 1) * 8;
+    const int n_inst = (a.n_ctz + n_ka) * 8;
+    // (the k columns of one row split start one chunk apart: a Z block one column has just pulled into the XCD's L2 is the next
+    //  column's hit — all of them asking for the same lines at the same instant were each served from memory)
+    const int n_c = c_hi - c_lo;
+    for (int ci = 0; ci < n_c; ++ci) {
+        const int c = c_lo + (ci + kg) % n_c;
+        // the chunk's blocks: every column tile of Z, the k column's blocks of A — 1 KiB per wave instruction, no registers
         for (int i = wave; i < n_inst; i += 4) {
             const int b = i >> 3, part = i & 7;
             if (b < a.n_ctz)
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
                                                          (unsigned)(((long long)b * a.ld_chunks + c) * kBlk + part * 1024 + lane * 16), 0, 0, 0);
             else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
-                                                         (unsigned)((long long)c * kBlk + part * 1024 + lane * 16), 0, 0, 0);
+                                                         (unsigned)(((long long)(b - a.n_ctz) * a.ld_chunks + c) * kBlk + part * 1024 + lane * 16), 0, 0, 0);
         }
         // rho of this lane's half (lanes lg = 0, 1: rows 0..15 of the chunk; lg = 2, 3: rows 16..31)
         const int hh = 2 * c + (lg >> 1);
@@ -307,27 +314,32 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
         const _Float16 rho = (_Float16)(fh > 0.f ? F / fh : 0.f);
         const h2v rho2 = h2v{rho, rho};
         __syncthreads();  // (the barrier's release waits for the DMA)
-        h8 ah[4], al[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            ah[kt] = *reinterpret_cast<const h8*>(lds + aoff_h[kt]);
-            al[kt] = *reinterpret_cast<const h8*>(lds + aoff_l[kt]);
-        }
-#pragma unroll
-        for (int r = 0; r < kRTW; ++r) {
-            if (zoff_h[r] < 0) continue;   // (wave-uniform: fewer than 20 row tiles of n)
-            h8 zh = *reinterpret_cast<const h8*>(lds + zoff_h[r]), zl = *reinterpret_cast<const h8*>(lds + zoff_l[r]);
-            {   // scale the half's rows down by rho (exact: a power of two)
-                h2v* ph = reinterpret_cast<h2v*>(&zh);
-                h2v* pl = reinterpret_cast<h2v*>(&zl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ph[e] = ph[e] * rho2; pl[e] = pl[e] * rho2; }
-            }
+        for (int kb = 0; kb < kKT2; ++kb) {   // one A block (64 columns of k) at a time: 8 fragment registers sets, the Z fragments re-read
+            if (kb >= n_ka) break;
+            h8 ah[4], al[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, ah[kt], acc[r][kt], 0, 0, 0);
-                acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, al[kt], acc[r][kt], 0, 0, 0);
-                acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, ah[kt], acc[r][kt], 0, 0, 0);
+                ah[kt] = *reinterpret_cast<const h8*>(lds + kb * kBlk + aoff_h[kt]);
+                al[kt] = *reinterpret_cast<const h8*>(lds + kb * kBlk + aoff_l[kt]);
+            }
+#pragma unroll
+            for (int r = 0; r < kRTW; ++r) {
+                if (zoff_h[r] < 0) continue;   // (wave-uniform: fewer than 20 row tiles of n)
+                h8 zh = *reinterpret_cast<const h8*>(lds + zoff_h[r]), zl = *reinterpret_cast<const h8*>(lds + zoff_l[r]);
+                {   // scale the half's rows down by rho (exact: a power of two)
+                    h2v* ph = reinterpret_cast<h2v*>(&zh);
+                    h2v* pl = reinterpret_cast<h2v*>(&zl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ph[e] = ph[e] * rho2; pl[e] = pl[e] * rho2; }
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    f32x4& d = acc[r][4 * kb + kt];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, ah[kt], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, al[kt], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, ah[kt], d, 0, 0, 0);
+                }
             }
         }
         __syncthreads();  // (every wave is done with the chunk before the next DMA overwrites it)
@@ -340,10 +352,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
         const int gt = wave + 4 * r;
         if (gt >= n_rt) continue;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4 * kKT2; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int n = 16 * gt + 4 * lg + e, k = 64 * kt0 + 16 * kt + li;
+                const int n = 16 * gt + 4 * lg + e, k = 64 * kKT2 * kg + 16 * kt + li;
                 if (n < a.N && k < a.Kt) slab[(long long)n * a.ldk + k] = acc[r][kt][e] * iF;
             }
     }
@@ -425,7 +437,9 @@ void wgrad16_add(WProdJobs* jobs, const WSplitJob& Z, const WSplitJob& A, const 
 WProdTPlan plan_wgrad16t(int64_t ld_chunks, int N, int Kt) {
     WProdTPlan p;
     p.n_ctz = (N + 63) / 64; p.n_kt = (Kt + 63) / 64; p.ld_chunks = (int)ld_chunks;
-    int splits = 512 / p.n_kt;                       // ~512 workgroups per product: two per CU
+    const int n_kg = (p.n_kt + wg16::kKT2 - 1) / wg16::kKT2;
+    int splits = 256 / n_kg;                         // ~256 workgroups per product (a launch holds one per depth step: two or more per CU);
+                                                     // every split is a slab the reduce kernel reads
     if (splits > ld_chunks) splits = (int)ld_chunks;
     if (splits < 1) splits = 1;
     p.splits = splits;
@@ -446,10 +460,10 @@ int launch_wgrad16t(const WProdTOperand* Z, const WProdTOperand* A, int n, const
         a.Z = Z[i].blk; a.sZ = Z[i].scale; a.A = A[i].blk; a.sA = A[i].scale;
         a.n_ctz = p.n_ctz; a.n_kt = p.n_kt; a.ld_chunks = p.ld_chunks; a.splits = p.splits;
         a.N = N; a.Kt = Kt; a.slab = slab + (int64_t)i * p.splits * p.slab_stride; a.ldk = p.ldk; a.slab_stride = p.slab_stride;
-        jobs.wg0[i + 1] = jobs.wg0[i] + (p.n_kt * p.splits + 7) / 8 * 8;
+        jobs.wg0[i + 1] = jobs.wg0[i] + ((p.n_kt + wg16::kKT2 - 1) / wg16::kKT2 * p.splits + 7) / 8 * 8;
     }
     jobs.n_jobs = n;
-    const size_t lds = (size_t)(p.n_ctz + 1) * wg16::kBlk + 64;
+    const size_t lds = (size_t)(p.n_ctz + wg16::kKT2) * wg16::kBlk + 64;
     static size_t attr_set = 0;
     if (attr_set < lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
