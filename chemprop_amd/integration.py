@@ -235,7 +235,17 @@ def hip_mpnn_class():
                 sync, opt = st["sync"], st["opt"]
                 sync.wait()
                 sync.zero_grad()
-                l = Ref.training_step(self, batch, batch_idx)
+                l = None
+                if X_d is None and self.training:
+                    # everything behind the block as ONE autograd node on the head kernels where they implement this model
+                    # (chemprop_amd.model.head_loss: aggregation, batch norm, predictor, criterion + their backward in one call)
+                    from .model import criterion_kind, head_loss
+
+                    bounded = criterion_kind(self.criterion)[1]
+                    l = head_loss(self, self.message_passing(bmg, V_d), bmg.batch, len(bmg), targets, weights,
+                                  lt_mask if bounded else None, gt_mask if bounded else None)
+                if l is None:
+                    l = Ref.training_step(self, batch, batch_idx)   # the reference's own arithmetic, torch ops behind the block
                 l.backward()
                 sync.allreduce()
                 opt.step(lr)

@@ -125,6 +125,12 @@ class MPNN(nn.Module):
 
     def loss(self, bmg, targets: Tensor, weights: Optional[Tensor] = None, lt_mask: Optional[Tensor] = None,
              gt_mask: Optional[Tensor] = None, V_d: Optional[Tensor] = None, X_d: Optional[Tensor] = None) -> Tensor:
+        if X_d is None and torch.is_grad_enabled() and self.training:
+            # the module path of a training step: the block through its own autograd node, everything behind it — aggregation, batch
+            # norm, predictor, criterion AND their backward pass — as ONE more (head_loss); None: the head kernels do not take this model
+            l = head_loss(self, self.message_passing(bmg, V_d), bmg.batch, len(bmg), targets, weights, lt_mask, gt_mask)
+            if l is not None:
+                return l
         preds = self.predictor.train_step(self.fingerprint(bmg, V_d, X_d))
         c = self.criterion
         return masked_loss(preds, targets, weights, getattr(c, "task_weights", None), lt_mask, gt_mask, getattr(c, "kind", "mse"))
@@ -163,6 +169,172 @@ def criterion_kind(crit) -> tuple[Optional[str], bool]:
     return None, False
 
 
+class HeadSpec:
+    """What ``dmpnn_head`` needs to know of the model around the block — aggregation, batch norm, the predictor's layers and
+    activation, the criterion — taken once from the modules; raises ``NotImplementedError`` for what the head kernels do not
+    implement.  Shared by :class:`FusedTrainer` (the whole step as one C call) and :func:`head_loss` (the module path's ONE
+    autograd node for everything behind the block)."""
+
+    def __init__(self, model):
+        agg, pred = model.agg, model.predictor
+        mode = aggregation_mode(agg)
+        if mode is None:
+            raise NotImplementedError(f"sum / mean / norm aggregation (got {type(agg).__name__})")
+        blocks = list(pred.ffn)
+        if len(blocks) > _lib.MAX_FFN_LAYERS:
+            raise NotImplementedError(f"at most {_lib.MAX_FFN_LAYERS} predictor layers")
+        f_act, f_slope = "none", 0.0
+        for b in blocks[1:]:
+            code, sl, _ = classify_activation(b[0])
+            if code in ("custom", "prelu") or b[1].p > 0:
+                raise NotImplementedError("predictor with a built-in activation (not PReLU) and dropout 0")
+            f_act, f_slope = code, sl
+        # (the reference's UnscaleTransform IS the identity in training mode, transforms.py:45-50: what a scaled regression run carries)
+        if not (isinstance(pred.output_transform, nn.Identity) or "UnscaleTransform" in _mro_names(pred.output_transform)):
+            raise NotImplementedError("the output transform is the identity while training (predictors.py:166-169)")
+        if getattr(pred, "n_targets", 1) != 1:
+            raise NotImplementedError("one value per task (regression); MVE / evidential / quantile heads train through torch ops")
+        kind, self.bounded = criterion_kind(pred.criterion)
+        if kind is None:
+            raise NotImplementedError("MSE / MAE criterion (bounded or not)")
+        self.agg_mode, self.agg_norm = MODES[mode], float(getattr(agg, "norm", 1.0))
+        self.f_act, self.f_slope, self.kind = f_act, f_slope, kind
+        self.layers = [b[-1] for b in blocks]
+        self.bn = model.bn if isinstance(model.bn, nn.BatchNorm1d) else None
+        if self.bn is not None and (self.bn.momentum is None or not self.bn.affine or not self.bn.track_running_stats):
+            raise NotImplementedError("nn.BatchNorm1d with a fixed momentum, affine, running statistics")
+        self.criterion = pred.criterion
+
+    @property
+    def n_tasks(self) -> int:
+        return int(self.layers[-1].out_features)
+
+    def params(self) -> list:
+        """The head's parameters in the order ``fill`` asks ``gptr`` about them."""
+        ps = [] if self.bn is None else [self.bn.weight, self.bn.bias]
+        for lin in self.layers:
+            ps.append(lin.weight)
+            if lin.bias is not None:
+                ps.append(lin.bias)
+        return ps
+
+    def fill(self, h, nV: int, n_mols: int, d_out: int, batch: Tensor, T: Tensor, weights, lt_mask, gt_mask, gptr, bn_training: bool = True) -> list:
+        """Fill ``h`` (a ``_lib.HeadArgs``) but for ``preds / loss_out / gHv / ws``; ``gptr(param)`` gives the address the gradient of
+        ``param`` goes to (``None``: not wanted).  Returns the tensors that must stay alive until the call has been enqueued."""
+        dev = T.device
+        h.n_atoms, h.n_mols, h.d_h = nV, n_mols, d_out
+        h.batch = batch.data_ptr()
+        h.agg_mode, h.agg_norm = self.agg_mode, self.agg_norm
+        bn = self.bn
+        if bn is not None:
+            h.bn_weight, h.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
+            h.bn_running_mean, h.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            h.bn_eps, h.bn_momentum, h.bn_training = float(bn.eps), float(bn.momentum), 1 if bn_training else 0
+            h.g_bn_weight, h.g_bn_bias = gptr(bn.weight), gptr(bn.bias)
+            nbt = bn.num_batches_tracked
+            if bn_training and nbt is not None and nbt.dtype == torch.int64 and nbt.device == dev:
+                h.bn_num_batches_tracked = nbt.data_ptr()  # (counted by the batch-norm kernel: no launch of its own)
+        h.n_layers, h.act, h.act_slope = len(self.layers), _lib.ACT[self.f_act], float(self.f_slope)
+        h.dims[0] = d_out
+        for l, lin in enumerate(self.layers):
+            h.W[l], h.b[l] = lin.weight.data_ptr(), (None if lin.bias is None else lin.bias.data_ptr())
+            h.dims[l + 1] = lin.out_features
+            h.gW[l], h.gb[l] = gptr(lin.weight), gptr(lin.bias)
+        h.loss = _lib.LOSS[self.kind]
+        h.targets = T.data_ptr()
+        keep = []
+        if weights is not None:
+            wt = engine._f32c(weights.reshape(-1, 1), "weights").reshape(-1).contiguous()
+            h.weights = wt.data_ptr()
+            keep.append(wt)
+        tw = getattr(self.criterion, "task_weights", None)
+        if tw is not None:
+            tw = tw.reshape(-1).float()
+            if tw.numel() == 1 and self.n_tasks > 1:  # (task_weights = 1.0 broadcasts over the tasks, metrics.py:69-70)
+                tw = tw.expand(self.n_tasks)
+            tw = tw.contiguous()
+            h.task_weights = tw.data_ptr()
+            keep.append(tw)
+        for name, m in (("lt_mask", lt_mask), ("gt_mask", gt_mask)):
+            if m is not None and self.bounded:   # (the reference's plain MSE / MAE ignore the masks: nn/metrics.py:139-150)
+                m8 = m.to(torch.uint8).contiguous()
+                setattr(h, name, m8.data_ptr())
+                keep.append(m8)
+        return keep
+
+
+class _HeadLoss(torch.autograd.Function):
+    """Everything behind the block — aggregation, batch norm, the predictor's layers, the criterion — AND its backward pass as ONE
+    ``dmpnn_head`` call in the forward of one autograd node: the loss comes back with the gradient of ``H_v`` and of every head
+    parameter already computed (for a unit upstream gradient); ``backward`` scales them by the upstream gradient (one launch over
+    one flat buffer) and hands them to autograd.  Replaces ~40 torch launches and autograd nodes of the module path."""
+
+    @staticmethod
+    def forward(ctx, spec, Hv, batch, n_mols, T, weights, lt_mask, gt_mask, *params):
+        lib = _lib.load()
+        dev = Hv.device
+        Hv = engine._f32c(Hv, "H_v")
+        nV, d_out = int(Hv.shape[0]), int(Hv.shape[1])
+        # one flat buffer for the head's parameter gradients (16-byte aligned pieces) + gH_v
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        flat = torch.empty(n + nV * d_out, dtype=torch.float32, device=dev)
+        ptr = {id(p): flat.data_ptr() + 4 * o for p, o in zip(params, offs)}
+        want = {id(p) for p, need in zip(params, ctx.needs_input_grad[8:]) if need}
+        gH = flat[n:].view(nV, d_out)
+        h = _lib.HeadArgs()
+        keep = spec.fill(h, nV, n_mols, d_out, batch, T, weights, lt_mask, gt_mask,
+                         lambda p: None if (p is None or id(p) not in want) else ptr[id(p)], bn_training=spec.bn is None or spec.bn.training)
+        preds = torch.empty(n_mols, spec.n_tasks, dtype=torch.float32, device=dev)
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        h.preds, h.loss_out = preds.data_ptr(), loss.data_ptr()
+        h.gHv, h.ldg = gH.data_ptr(), d_out
+        nb = int(lib.dmpnn_head_ws_bytes(C.byref(h)))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        h.ws, h.ws_bytes = ws.data_ptr(), nb
+        with engine._OnDevice(dev):
+            _lib.check(lib.dmpnn_head(C.byref(h), Hv.data_ptr(), Hv.stride(0), engine._stream_ptr(dev)), "dmpnn_head")
+        del keep
+        ctx.flat, ctx.n, ctx.offs, ctx.shapes, ctx.want = flat, n, offs, [tuple(p.shape) for p in params], [id(p) in want for p in params]
+        ctx.hv_shape = (nV, d_out)
+        ctx.preds = preds
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gl):
+        flat = ctx.flat * gl   # (ONE launch scales every gradient of the head by the upstream gradient)
+        n = ctx.n
+        gH = flat[n:].view(ctx.hv_shape) if ctx.needs_input_grad[1] else None
+        gp = [flat[o:o + math.prod(sh)].view(sh) if w else None for o, sh, w in zip(ctx.offs, ctx.shapes, ctx.want)]
+        return (None, gH, None, None, None, None, None, None, *gp)
+
+
+def head_loss(model, Hv: Tensor, batch: Tensor, n_mols: int, targets: Tensor, weights: Optional[Tensor] = None,
+              lt_mask: Optional[Tensor] = None, gt_mask: Optional[Tensor] = None) -> Optional[Tensor]:
+    """``criterion(predictor.train_step(bn(agg(H_v, batch))), targets, ...)`` (``models/model.py:152-157``) as ONE autograd node on the
+    head kernels (:class:`_HeadLoss`); ``None`` when the head kernels do not implement this model or these inputs (the caller then
+    runs the torch modules)."""
+    spec = model.__dict__.get("_dmpnn_head_spec")
+    if spec is None:
+        try:
+            spec = HeadSpec(model)
+        except NotImplementedError as e:
+            spec = str(e)
+        model.__dict__["_dmpnn_head_spec"] = spec
+    if isinstance(spec, str) or Hv.device.type != "cuda" or Hv.dtype != torch.float32:
+        return None
+    if batch is None or batch.dtype != torch.int64 or not batch.is_contiguous() or batch.numel() != Hv.shape[0] or batch.device != Hv.device:
+        return None
+    T = targets if (targets.dtype == torch.float32 and targets.is_contiguous()) else targets.float().contiguous()
+    if T.dim() != 2 or T.shape[0] != n_mols or T.shape[1] != spec.n_tasks or (spec.bn is not None and spec.bn.training and n_mols < 2):
+        return None
+    if weights is not None and weights.numel() != n_mols:
+        return None
+    return _HeadLoss.apply(spec, Hv, batch, int(n_mols), T, weights, lt_mask, gt_mask, *spec.params())
+
+
 class FusedTrainer:
     """``training_step`` + ``Adam.step`` of an :class:`MPNN` as one ``dmpnn_train_step`` call per batch.
 
@@ -189,34 +361,13 @@ class FusedTrainer:
             # (active dropout lives inside the tile kernels for ReLU-class activations: dmpnn_fwd_args.dropout_p; a dropout module
             #  that is not exactly nn.Dropout has its own semantics and stays on the module path)
             raise NotImplementedError("FusedTrainer: dropout inside the block needs nn.Dropout and a ReLU / LeakyReLU activation")
-        mode = aggregation_mode(agg)
-        if mode is None:
-            raise NotImplementedError(f"FusedTrainer: sum / mean / norm aggregation (got {type(agg).__name__})")
-        blocks = list(pred.ffn)
-        if len(blocks) > _lib.MAX_FFN_LAYERS:
-            raise NotImplementedError(f"FusedTrainer: at most {_lib.MAX_FFN_LAYERS} predictor layers")
-        f_act, f_slope = "none", 0.0
-        for b in blocks[1:]:
-            code, sl, _ = classify_activation(b[0])
-            if code in ("custom", "prelu") or b[1].p > 0:
-                raise NotImplementedError("FusedTrainer: predictor with a built-in activation (not PReLU) and dropout 0")
-            f_act, f_slope = code, sl
-        # (the reference's UnscaleTransform IS the identity in training mode, transforms.py:45-50: what a scaled regression run carries)
-        if not (isinstance(pred.output_transform, nn.Identity) or "UnscaleTransform" in _mro_names(pred.output_transform)):
-            raise NotImplementedError("FusedTrainer: the output transform is the identity while training (predictors.py:166-169)")
-        if getattr(pred, "n_targets", 1) != 1:
-            raise NotImplementedError("FusedTrainer: one value per task (regression); MVE / evidential / quantile heads train through the module path")
-        kind, self.bounded = criterion_kind(pred.criterion)
-        if kind is None:
-            raise NotImplementedError("FusedTrainer: MSE / MAE criterion (bounded or not)")
+        try:
+            self.head = HeadSpec(model)
+        except NotImplementedError as e:
+            raise NotImplementedError(f"FusedTrainer: {e}") from None
         self.model, self.mp = model, mp
         self.act, self.slope = act, slope
-        self.agg_mode, self.agg_norm = MODES[mode], float(getattr(agg, "norm", 1.0))
-        self.f_act, self.f_slope, self.kind = f_act, f_slope, kind
-        self.layers = [b[-1] for b in blocks]
-        self.bn = model.bn if isinstance(model.bn, nn.BatchNorm1d) else None
-        if self.bn is not None and (self.bn.momentum is None or not self.bn.affine or not self.bn.track_running_stats):
-            raise NotImplementedError("FusedTrainer: nn.BatchNorm1d with a fixed momentum, affine, running statistics")
+        self.layers, self.bn, self.bounded = self.head.layers, self.head.bn, self.head.bounded
         params = [p for p in model.parameters() if p.requires_grad]
         engine._require_device(params[0], "model parameters")
         self.sync = GradSync(params, modules=[model], group=group)
@@ -332,44 +483,9 @@ class FusedTrainer:
 
         # ---- the head ----
         h = _lib.HeadArgs()
-        h.n_atoms, h.n_mols, h.d_h = nV, n_mols, d_out
-        h.batch = batch.data_ptr()
-        h.agg_mode, h.agg_norm = self.agg_mode, self.agg_norm
-        bn = self.bn
-        if bn is not None:
-            h.bn_weight, h.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
-            h.bn_running_mean, h.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-            h.bn_eps, h.bn_momentum, h.bn_training = float(bn.eps), float(bn.momentum), 1
-            h.g_bn_weight, h.g_bn_bias = self._gv(bn.weight), self._gv(bn.bias)
-            nbt = bn.num_batches_tracked
-            if nbt is not None and nbt.dtype == torch.int64 and nbt.device == dev:
-                h.bn_num_batches_tracked = nbt.data_ptr()  # (counted by the batch-norm kernel: no launch of its own)
-        h.n_layers, h.act, h.act_slope = len(self.layers), _lib.ACT[self.f_act], float(self.f_slope)
-        h.dims[0] = d_out
-        for l, lin in enumerate(self.layers):
-            h.W[l], h.b[l] = lin.weight.data_ptr(), (None if lin.bias is None else lin.bias.data_ptr())
-            h.dims[l + 1] = lin.out_features
-            h.gW[l], h.gb[l] = self._gv(lin.weight), self._gv(lin.bias)
-        h.loss = _lib.LOSS[self.kind]
-        h.targets = T.data_ptr()
         keep = [T, gout, keep_b, st, plan]
-        if weights is not None:
-            wt = engine._f32c(weights.reshape(-1, 1), "weights").reshape(-1).contiguous()
-            h.weights = wt.data_ptr()
-            keep.append(wt)
-        tw = getattr(self.model.predictor.criterion, "task_weights", None)
-        if tw is not None:
-            tw = tw.reshape(-1).float()
-            if tw.numel() == 1 and int(self.layers[-1].out_features) > 1:  # (task_weights = 1.0 broadcasts over the tasks, metrics.py:69-70)
-                tw = tw.expand(int(self.layers[-1].out_features))
-            tw = tw.contiguous()
-            h.task_weights = tw.data_ptr()
-            keep.append(tw)
-        for name, m in (("lt_mask", lt_mask), ("gt_mask", gt_mask)):
-            if m is not None and self.bounded:   # (the reference's plain MSE / MAE ignore the masks: nn/metrics.py:139-150)
-                m8 = m.to(torch.uint8).contiguous()
-                setattr(h, name, m8.data_ptr())
-                keep.append(m8)
+        keep += self.head.fill(h, nV, n_mols, d_out, batch, T, weights, lt_mask, gt_mask, self._gv)
+        bn = self.bn
         t = int(self.layers[-1].out_features)
         preds = torch.empty(n_mols, t, dtype=torch.float32, device=dev)
         loss = torch.empty(2, dtype=torch.float32, device=dev)

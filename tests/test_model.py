@@ -530,3 +530,52 @@ def test_fused_trainer_validates_what_it_hands_over_as_raw_pointers(gpu_device):
     with pytest.raises(ValueError, match="more than 1 value per channel"):
         tr.step(one, torch.randn(1, 2, device=gpu_device))
     assert tr.opt.steps == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bn,agg,tasks,kind,act", [(True, "norm", 1, "mse", "relu"), (False, "mean", 3, "mae", "tanh"), (True, "sum", 2, "bounded-mse", "elu")])
+def test_module_path_head_is_one_autograd_node(bn, agg, tasks, kind, act, gpu_device):
+    """``MPNN.loss`` (the module path of a training step): everything behind the block — aggregation, batch norm, predictor, criterion
+    and their backward — is ONE autograd node on the head kernels (``model.head_loss``).  Loss, every gradient and the batch-norm
+    buffers against the same model run through the torch modules (``fingerprint`` / ``predictor`` / ``masked_loss``: the reference's
+    op sequence), missing targets, sample weights and bounds included; a loss scaled before ``backward`` scales every gradient."""
+    from chemprop_amd import synth
+    from chemprop_amd.model import head_loss, masked_loss
+
+    cfg = dict(mp=dict(d_h=64, activation=act), agg=agg, bn=bn, ffn=dict(n_tasks=tasks, hidden_dim=48, n_layers=2, activation=act), criterion=kind)
+    torch.manual_seed(3)
+    a = build_mirror(cfg).to(gpu_device).train()
+    b = build_mirror(cfg).to(gpu_device).train()
+    b.load_state_dict(a.state_dict())
+    bmg = synth.random_batch(40, "qm9", seed=6)
+    bmg.to(gpu_device)
+    gen = torch.Generator().manual_seed(1)
+    y = torch.randn(40, tasks, generator=gen)
+    if tasks > 1:
+        y[torch.rand(40, tasks, generator=gen) < 0.2] = float("nan")
+    w = (0.5 + torch.rand(40, 1, generator=gen)).to(gpu_device)
+    bounded = kind.startswith("bounded")
+    lt = (torch.rand(40, tasks, generator=gen) < 0.3).to(gpu_device) if bounded else None
+    gt = (torch.rand(40, tasks, generator=gen) < 0.3).to(gpu_device) if bounded else None
+    y = y.to(gpu_device)
+    la = a.loss(bmg, y, w, lt, gt)
+    assert type(la.grad_fn).__name__ == "_HeadLossBackward", type(la.grad_fn).__name__
+    (2.5 * la).backward()
+    # the torch modules, op by op (what MPNN.loss ran before round 4)
+    preds = b.predictor.train_step(b.fingerprint(bmg))
+    c = b.criterion
+    lb = masked_loss(preds, y, w, getattr(c, "task_weights", None), lt, gt, getattr(c, "kind", "mse"))
+    (2.5 * lb).backward()
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb))), (float(la), float(lb))
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None), k
+        if pa.grad is not None:
+            assert parity_err(pa.grad.cpu().numpy(), pb.grad.cpu().numpy()) <= 2e-5, k
+    if bn:
+        for k in ("running_mean", "running_var"):
+            assert parity_err(getattr(a.bn, k).cpu().numpy(), getattr(b.bn, k).cpu().numpy()) <= 1e-6, k
+        assert int(a.bn.num_batches_tracked) == int(b.bn.num_batches_tracked) == 1
+    # what the head kernels do not implement falls back to the torch modules: extra descriptors X_d, a frozen-in-eval model
+    a.eval()
+    assert type(a.loss(bmg, y, w, lt, gt).grad_fn).__name__ != "_HeadLossBackward"
