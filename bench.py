@@ -221,15 +221,6 @@ def main():
     value = world * updates / (ms_per_step * 1e-3) / 1e6
     if train:
         sync.wait()
-    # inference keeps the f16 pre-split of the (frozen) weights between steps; the same K steps with the
-    # pre-split redone every step (what a training step pays) are timed beside it
-    uncached_ms = None
-    if not train:
-        os.environ["DMPNN_WCACHE"] = "0"
-        run_steps(step, 3)
-        uncached_ms = timed(step, args.steps) / args.steps * 1e3
-        os.environ["DMPNN_WCACHE"] = "1"
-        run_steps(step, 2)
 
     out = {
         "metric": "million directed-edge-updates/sec (depth=%d, hidden=%d)" % (args.depth, args.hidden),
@@ -257,10 +248,8 @@ def main():
         "graph_k_steps_ms_per_step": None if graphk_ms is None else round(graphk_ms, 5),
         "edges_per_s_M": round(world * nE / (ms_per_step * 1e-3) / 1e6, 3),
     }
-    if uncached_ms is not None:
-        out["weights"] = ("frozen (inference): the pre-split (hi + lo f16) of W_i / W_h / W_o is kept between steps, keyed on the "
-                          "weight tensors' autograd versions; eager_ms_presplit_every_step redoes it each step")
-        out["eager_ms_presplit_every_step"] = round(uncached_ms, 5)
+    out["weights"] = ("the pre-split (hi + lo f16) of W_i / W_h / W_o is redone by EVERY step — it rides in K0's launch (workgroup 0 plans, "
+                      "the others split): nothing about the weights is cached between forwards (round 3 kept it keyed on autograd versions)")
     if graph_err:
         out["graph_error"] = graph_err
     if graphk_err:
@@ -410,12 +399,18 @@ def main():
         out["route"] = route_used
         if route_used in ("mega16", "mega"):
             # ONE launch = the whole forward of every tile of whole molecules (k_mpnn_tile16 / k_mpnn_tile)
-            wc = {}
+            # (the tile kernel ALONE: the argument block of one forward, replayed with DMPNN_F_WSPLIT_READY — its workspace holds the
+            #  pre-split of these very weights; K0 and the weight pre-split are the step's other launch and are not part of this figure)
+            import ctypes as _C
+
+            with torch.no_grad():
+                _, st_dom = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=args.depth)
+            blk_dom = _lib.FwdArgs.from_buffer_copy(bytes(st_dom.args))
+            blk_dom.flags |= _lib.F_WSPLIT_READY
+            lib_dom = _lib.load()
 
             def kdom():
-                with torch.no_grad():
-                    engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=args.depth,
-                                   wcache=wc)
+                _lib.check(lib_dom.dmpnn_forward(_C.byref(blk_dom), engine._stream_ptr(dev)), "dmpnn_forward")
             run_steps(kdom, 10)
             t_dom = time_events(kdom, 50, torch)
             if route_used == "mega16":

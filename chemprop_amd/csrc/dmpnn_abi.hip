@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "dmpnn_common.hpp"
+#include "dmpnn_mega16_impl.hpp"   // (mega16::SplitArgs: the argument block of the weight pre-split)
 
 namespace dmpnn {
 
@@ -126,12 +127,17 @@ int dmpnn_prepare_tiles(const int64_t* edge_index, const int64_t* rev, const int
 }  // extern "C"
 namespace dmpnn {
 int prepare_tiles_and_bounds(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t n_atoms, int64_t n_edges, void* plan,
-                             size_t plan_bytes, int* mol_bounds, int64_t n_mols, void* stream, bool* wrote_bounds) {
-    *wrote_bounds = false;
-    if (mol_bounds && batch && n_atoms > 0 && n_mols > 0 && n_mols < (1 << 30) && small_plan_fits(n_atoms, n_edges) && check_graph_sizes(n_atoms, n_edges) == DMPNN_OK &&
+                             size_t plan_bytes, int* mol_bounds, int64_t n_mols, void* stream, bool* wrote_bounds,
+                             const dmpnn_fwd_args* split_for, bool* did_split) {
+    if (wrote_bounds) *wrote_bounds = false;
+    if (did_split) *did_split = false;
+    if (mol_bounds && (n_mols <= 0 || n_mols >= (1 << 30))) mol_bounds = nullptr;
+    // the single-workgroup planner from the batch vector: the aggregation's bounds on the side, the weight pre-split in the same launch
+    if ((mol_bounds || split_for) && batch && n_atoms > 0 && small_plan_fits(n_atoms, n_edges) && check_graph_sizes(n_atoms, n_edges) == DMPNN_OK &&
         plan != nullptr && aligned16(plan) && (n_edges == 0 || edge_index) && plan_bytes >= dmpnn_plan_bytes(n_atoms, n_edges)) {
-        DMPNN_TRY(launch_prepare_tiles_batch(edge_index, batch, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream), mol_bounds, n_mols));
-        *wrote_bounds = true;
+        DMPNN_TRY(launch_prepare_tiles_batch(edge_index, batch, n_atoms, n_edges, static_cast<int*>(plan), static_cast<hipStream_t>(stream), mol_bounds,
+                                             mol_bounds ? n_mols : 0, split_for, did_split));
+        if (wrote_bounds) *wrote_bounds = mol_bounds != nullptr;
         return DMPNN_OK;
     }
     return dmpnn_prepare_tiles(edge_index, rev, batch, n_atoms, n_edges, plan, plan_bytes, stream);
@@ -314,11 +320,15 @@ int dmpnn_forward_tiles(const dmpnn_fwd_args* a, const int64_t* batch, const int
                         size_t plan_bytes, void* stream) {
     DMPNN_CHECK_ARG(a != nullptr && a->plan != nullptr, "forward_tiles: null args / plan");
     void* plan = const_cast<void*>(a->plan);
+    bool did_split = false;
     if (tile_row && tile_atom && n_tiles > 0)
         DMPNN_TRY(dmpnn_prepare_tiles_from_table(tile_row, tile_atom, n_tiles, a->n_atoms, a->n_edges, plan, plan_bytes, stream));
-    else
-        DMPNN_TRY(dmpnn_prepare_tiles(a->edge_index, a->rev_edge_index, batch, a->n_atoms, a->n_edges, plan, plan_bytes, stream));
-    return dmpnn_forward(a, stream);
+    else   // (from the batch vector within the single-workgroup plan: the weight pre-split rides in K0's launch)
+        DMPNN_TRY(prepare_tiles_and_bounds(a->edge_index, a->rev_edge_index, batch, a->n_atoms, a->n_edges, plan, plan_bytes, nullptr, 0, stream, nullptr, a, &did_split));
+    if (!did_split) return dmpnn_forward(a, stream);
+    dmpnn_fwd_args f = *a;
+    f.flags |= DMPNN_F_WSPLIT_READY;
+    return dmpnn_forward(&f, stream);
 }
 
 int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
@@ -380,13 +390,19 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         const float* Ws[6] = {a->W_i, a->W_h, a->W_o, has_vd ? a->W_d : nullptr, a->W_o + dv, a->W_o};
         const int64_t Ns[6] = {h, h, h, h + a->d_vd, h, h}, Ks[6] = {dv + de, h, dv + h, h + a->d_vd, h, dv};
         const int64_t Ls[6] = {dv + de, h, dv + h, h + a->d_vd, dv + h, dv + h};
+        SplitWJob jobs[6];
+        SplitWView views[6];
+        int idx[6], nj = 0;
         for (int i = 0; i < 6; ++i) {
             if (!Ws[i]) continue;
             if (ready) w[i] = split_weights_view_of(wp, Ns[i], Ks[i]);
-            else DMPNN_TRY(split_weights_view(Ws[i], Ls[i], Ns[i], Ks[i], 0, wp, &w[i], s));
+            else { jobs[nj] = SplitWJob{Ws[i], Ls[i], Ns[i], Ks[i], 0, wp}; idx[nj++] = i; }
             wp += linear16_wsplit_bytes(Ns[i], Ks[i]);
         }
-        DMPNN_TRY(launch_fused16_forward(*a, w, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s));
+        mega16::SplitArgs sp;   // (one launch for all of them — or none: it rides in the forward's first launch, k_split_rows)
+        const bool pend = nj > 0 && split_weights_args(jobs, nj, views, &sp);
+        for (int k = 0; k < nj; ++k) w[idx[k]] = views[k];
+        DMPNN_TRY(launch_fused16_forward(*a, w, has_vd ? a->Hv : a->out, has_vd ? a->ldh : a->ldout, s, pend ? &sp : nullptr));
         if (has_vd) {
             dmpnn_gemm_args g;
             memset(&g, 0, sizeof(g));
@@ -511,12 +527,17 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
         const bool ready = (a->flags & DMPNN_F_WSPLIT_READY) != 0;
         const float* Ws[4] = {a->W_i, a->W_h, a->W_o, has_vd ? a->W_d : nullptr};
         const int64_t Ns[4] = {h, h, h, h + a->d_vd}, Ks[4] = {dv + de, h, dv + h, h + a->d_vd};
+        SplitWJob jobs[4];
+        SplitWView views[4];
+        int idx[4], nj = 0;
         for (int i = 0; i < 4; ++i) {
             if (!Ws[i]) continue;
             if (ready) w16[i] = split_weights_view_of(wp, Ns[i], Ks[i]);
-            else DMPNN_TRY(split_weights_view(Ws[i], Ks[i], Ns[i], Ks[i], 0, wp, &w16[i], s));
+            else { jobs[nj] = SplitWJob{Ws[i], Ks[i], Ns[i], Ks[i], 0, wp}; idx[nj++] = i; }
             wp += linear16_wsplit_bytes(Ns[i], Ks[i]);
         }
+        DMPNN_TRY(split_weights_views(jobs, nj, views, s));   // (one launch for all of them)
+        for (int k = 0; k < nj; ++k) w16[idx[k]] = views[k];
     }
     auto lin = [&](const dmpnn_gemm_args& g, int slot) -> int {
         if (use16 && linear16_ok(g)) return launch_linear16_view(g, w16[slot], nullptr, 0, s);

@@ -10,6 +10,8 @@
 
 namespace dmpnn {
 
+namespace mega16 { struct SplitArgs; }   // (argument block of the weight pre-split: dmpnn_mega16_impl.hpp)
+
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 void count_launch(const char* name);
@@ -193,12 +195,16 @@ int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV, in
                    int light, hipStream_t s, bool keep_mtiles = false);
 bool prepare_can_keep_mtiles(int64_t nV, int64_t nE);
 // mol_bounds (optional): the molecule ranges also as the table dmpnn_molagg_* read (first[n_mols] | end[n_mols] | flag)
+// split_for / did_split: the pre-split of that forward's weights (tile kernel on the f16 pipe) rides in the same launch — workgroup 0
+// plans, the others split; *did_split tells the caller to pass DMPNN_F_WSPLIT_READY to the forward
 int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s,
-                               int* mol_bounds = nullptr, int64_t n_mols = 0);
+                               int* mol_bounds = nullptr, int64_t n_mols = 0, const dmpnn_fwd_args* split_for = nullptr, bool* did_split = nullptr);
+bool mega16_split_args(const dmpnn_fwd_args& a, mega16::SplitArgs* sp);
 // dmpnn_prepare_tiles for a training step that also aggregates per molecule: *wrote_bounds says whether `mol_bounds` was filled
 // (the single-workgroup planner from the batch vector does it on the side; every other planner leaves it to dmpnn_molagg_bounds)
 int prepare_tiles_and_bounds(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t nV, int64_t nE, void* plan,
-                             size_t plan_bytes, int* mol_bounds, int64_t n_mols, void* stream, bool* wrote_bounds);
+                             size_t plan_bytes, int* mol_bounds, int64_t n_mols, void* stream, bool* wrote_bounds,
+                             const dmpnn_fwd_args* split_for = nullptr, bool* did_split = nullptr);
 // the same tables for batches beyond the single-workgroup plan (dmpnn_tiles_large.hip)
 bool tiles_large_fits(int64_t nV, int64_t nE);
 int launch_prepare_tiles_large(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s);
@@ -241,6 +247,10 @@ struct SplitWView { const unsigned char* p; const float* inv_scale; int nc; };
 size_t linear16_wsplit_bytes(int64_t N, int64_t K);
 int split_weights_view(const float* W, int64_t ldw, int64_t N, int64_t K, int tr, void* ws, SplitWView* out, hipStream_t s);
 SplitWView split_weights_view_of(void* ws, int64_t N, int64_t K);  // descriptor of a workspace that already holds the pre-split
+struct SplitWJob { const float* W; int64_t ldw, N, K; int tr; void* ws; };
+int split_weights_views(const SplitWJob* jobs, int n, SplitWView* out, hipStream_t s);   // up to 6 matrices, ONE launch
+bool split_weights_args(const SplitWJob* jobs, int n, SplitWView* out, mega16::SplitArgs* sp);   // ... the argument block only
+int launch_split_args(const mega16::SplitArgs& sp, hipStream_t s);
 bool linear16_ok(const dmpnn_gemm_args& a);
 int launch_linear16_view(const dmpnn_gemm_args& a, const SplitWView& W, const int* poison_flags, int poison_mask, hipStream_t s);
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
@@ -295,7 +305,10 @@ bool wgrad16_operand_ok(const float* A1, int64_t lda1, int K1, const float* A2, 
 WProdPlan plan_wgrad16(int64_t M, int N, int Kt);
 void wgrad16_add(WProdJobs* jobs, const WSplitJob& Z, const WSplitJob& A, const WProdPlan& p, int N, int Kt, float* slab);
 int launch_wgrad16(const WProdJobs& jobs, hipStream_t s);
-int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s);
+// pending (or null): the pre-split of the weights, not launched yet — it rides in the forward's first launch when that launch does
+// not read the weights (k_split_rows), else it is launched first
+int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s,
+                           const mega16::SplitArgs* pending = nullptr);
 // the backward step kernels of that route's lean training forward (dmpnn_bstep16.hip)
 int64_t bstep16_ld_chunks(int64_t n_edges);
 size_t bstep16_operand_bytes(int64_t n_edges, int64_t C);

@@ -623,7 +623,7 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
     ExtraWgrad rider;
     memset(&rider, 0, sizeof(rider));
     if (stages & DMPNN_STEP_FORWARD) {
-        bool bounds_done = false;
+        bool bounds_done = false, split_done = false;
         if (!a->plan_ready) {
             DMPNN_CHECK_ARG(a->edge_index && a->rev_edge_index, "train_step: null index arrays");
             if (f.flags & DMPNN_F_TILE_PLAN) {  // (the tile table alone: the kept tensors stay in the caller's edge order, dmpnn.h)
@@ -635,12 +635,17 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
                     if (h.ws_bytes >= HL.total) mb = reinterpret_cast<int*>(static_cast<unsigned char*>(h.ws) + HL.bounds);
                 }
                 DMPNN_TRY(prepare_tiles_and_bounds(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
-                                                   a->plan_bytes, mb, h.n_mols, stream, &bounds_done));
+                                                   a->plan_bytes, mb, h.n_mols, stream, &bounds_done, &f, &split_done));
             } else
                 DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
                                                    a->plan_bytes, stream));
         }
-        DMPNN_TRY(dmpnn_forward(&f, stream));
+        if (split_done) {   // (the weight pre-split rode in K0's launch)
+            dmpnn_fwd_args f2 = f;
+            f2.flags |= DMPNN_F_WSPLIT_READY;
+            DMPNN_TRY(dmpnn_forward(&f2, stream));
+        } else
+            DMPNN_TRY(dmpnn_forward(&f, stream));
         // (a whole step in one call: the first predictor layer's weight gradient rides in the block's backward launches; a staged
         //  step — data parallel — has the head's gradients final after this stage, so nothing is deferred there)
         DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, bounds_done, (stages & DMPNN_STEP_BACKWARD) ? &rider : nullptr));

@@ -54,19 +54,14 @@ size_t mega16_wsplit_bytes(const dmpnn_fwd_args& a) {
 }
 size_t mega16_fwd_wsplit_bytes(const dmpnn_fwd_args& a) { return ws_layout(a).total; }
 
-int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s) {
-    const int64_t nV = a.n_atoms, nE = a.n_edges;
+// the jobs of the forward's weight pre-split (W_i | W_h | W_o[:, d_v:] | W_o[:, :d_v]; training: + the backward tile kernel's two
+// transposed matrices; atom messages: + W_h[:, N:]) into the caller's `wsplit`; false: no workspace / too small
+bool mega16_split_args(const dmpnn_fwd_args& a, mega16::SplitArgs* spp) {
     const WsLayout W = ws_layout(a);
-    if (!a.wsplit || a.wsplit_bytes < W.total) {
-        set_error("forward(split16): wsplit workspace missing or too small (%zu < %zu bytes)", a.wsplit_bytes, W.total);
-        return DMPNN_ENOSPC;
-    }
+    if (!a.wsplit || a.wsplit_bytes < W.total) return false;
     unsigned char* ws = static_cast<unsigned char*>(a.wsplit);
     const int N = (int)a.d_h, dv = (int)a.d_v, de = (int)a.d_e;
-    // ---- pre-split of the three weight matrices: once per forward (weights change every training step) unless
-    // the caller vouches that the workspace still holds the pre-split of these weights (frozen weights) ----
-    if (!(a.flags & DMPNN_F_WSPLIT_READY)) {
-    mega16::SplitArgs sp;
+    mega16::SplitArgs& sp = *spp;
     memset(&sp, 0, sizeof(sp));
     sp.N = N; sp.n_jobs = 4;
     const bool atom = (a.flags & DMPNN_F_ATOM) != 0;
@@ -88,8 +83,25 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
         sp.job[sp.n_jobs] = mega16::SplitJob{a.W_h, ldwh, N, de, N, de, ws + W.whe, 1, reinterpret_cast<float*>(ws + W.sc_e)};
         ++sp.n_jobs;
     }
-    hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)(((N + 15) / 16) * 4 * sp.n_jobs)), dim3(256), 0, s, sp);  // jobs x whole column tiles, 4 waves per block
-    DMPNN_CHECK_LAUNCH("k_split_weights");
+    return true;
+}
+
+int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s) {
+    const int64_t nV = a.n_atoms, nE = a.n_edges;
+    const WsLayout W = ws_layout(a);
+    if (!a.wsplit || a.wsplit_bytes < W.total) {
+        set_error("forward(split16): wsplit workspace missing or too small (%zu < %zu bytes)", a.wsplit_bytes, W.total);
+        return DMPNN_ENOSPC;
+    }
+    unsigned char* ws = static_cast<unsigned char*>(a.wsplit);
+    const int N = (int)a.d_h, dv = (int)a.d_v, de = (int)a.d_e;
+    // ---- pre-split of the weight matrices: once per forward — in a launch of its own here, unless it rode in K0's launch (the
+    // caller then passes DMPNN_F_WSPLIT_READY: dmpnn_forward_tiles, dmpnn_train_step) ----
+    if (!(a.flags & DMPNN_F_WSPLIT_READY)) {
+        mega16::SplitArgs sp;
+        if (!mega16_split_args(a, &sp)) { set_error("forward(split16): wsplit workspace missing or too small"); return DMPNN_ENOSPC; }
+        hipLaunchKernelGGL(mega16::k_split_weights, dim3((unsigned)(((N + 15) / 16) * 4 * sp.n_jobs)), dim3(256), 0, s, sp);  // jobs x whole column tiles, 4 waves per block
+        DMPNN_CHECK_LAUNCH("k_split_weights");
     }
 
     const PlanLayout L = plan_layout(nV, nE);

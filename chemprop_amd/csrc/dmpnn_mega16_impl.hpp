@@ -97,19 +97,23 @@ struct SplitJob {
     int scale_col0, scale_K;                    // columns the row scale is taken over (W_o: the whole row)
     unsigned char* out; int nc; float* inv_scale;
     int tr;                                     // 1: the matrix is given transposed, element (n, k) = W[k * ldw + n]
+    int N;                                      // rows of THIS matrix (0: SplitArgs.N — jobs of one launch may differ in height)
 };
 struct SplitArgs {
     SplitJob job[6];
     int n_jobs, N;
 };
-static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+// one wave per (matrix, row).  A device function: it also rides in the launch of K0 (dmpnn_prepare.hip: workgroup 0 builds the
+// tile table, the others split the weights — the split then costs no launch and no time of its own, so NOTHING about the
+// weights is cached between forwards)
+__device__ __forceinline__ void split_weights_wave(const SplitArgs& a, int wave, int lane) {
     const int Np = (a.N + 15) & ~15;  // whole column tiles: the padding rows of the last tile are written as zeros
     const int j = wave / Np, n = wave - j * Np;
     if (j >= a.n_jobs) return;
     const SplitJob& J = a.job[j];
-    const bool live = n < a.N;
+    const int NJ = J.N > 0 ? J.N : a.N;
+    if (n >= ((NJ + 15) & ~15)) return;   // (a shorter matrix in a launch sized for the tallest)
+    const bool live = n < NJ;
     const long long rs = J.tr ? 1 : J.ldw, ks = J.tr ? J.ldw : 1;  // strides of the output index n and of the reduction index k
     const float* row = J.W + (long long)(live ? n : 0) * rs;
     float mx = 0.f;
@@ -130,6 +134,9 @@ static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
         out[base] = hi;
         out[base + 512] = lo;
     }
+}
+static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
+    split_weights_wave(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // LDS: ONE tile region holds, at different times, the split A tile of a contraction, the K1 / V operand staging tile and

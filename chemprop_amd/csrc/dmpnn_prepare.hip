@@ -17,6 +17,7 @@
 #include <limits.h>
 
 #include "dmpnn_common.hpp"
+#include "dmpnn_mega16_impl.hpp"   // (mega16::SplitArgs / split_weights_wave: the weight pre-split rides in K0's launch)
 
 namespace dmpnn {
 
@@ -726,11 +727,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_small(const int64_t* 
 // edges lower_bound(batch[dst[.]], m) ..  — two binary searches per molecule over arrays held in LDS, no histogram,
 // no scan, no connectivity analysis.  Pieces = molecules.  What is NOT checked here (that every edge of a molecule's
 // range has both atoms and its reverse inside) is checked by the tile kernel for every tile it runs.
-__global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int64_t* __restrict__ edge_index,
-                                                                      const int64_t* __restrict__ batch,
-                                                                      int* __restrict__ plan, PlanLayout L, int nV, int nE,
-                                                                      long long* dbg, int* __restrict__ mol_bounds, int n_mols_out) {
-    extern __shared__ __attribute__((aligned(16))) int lds_i[];
+__device__ __forceinline__ void prepare_tiles_batch_body(int* lds_i, const int64_t* __restrict__ edge_index,
+                                                         const int64_t* __restrict__ batch,
+                                                         int* __restrict__ plan, const PlanLayout& L, int nV, int nE,
+                                                         long long* dbg, int* __restrict__ mol_bounds, int n_mols_out) {
     int n_stamp = 0;
     auto stamp = [&]() {
         if (dbg && threadIdx.x == 0 && n_stamp < 16) dbg[n_stamp] = (long long)__builtin_readcyclecounter();
@@ -835,6 +835,24 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int
         plan[tid] = v;
     }
 }
+__global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ batch,
+                                                                      int* __restrict__ plan, PlanLayout L, int nV, int nE,
+                                                                      long long* dbg, int* __restrict__ mol_bounds, int n_mols_out) {
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];
+    prepare_tiles_batch_body(lds_i, edge_index, batch, plan, L, nV, nE, dbg, mol_bounds, n_mols_out);
+}
+// K0 and the pre-split of the forward's weights in ONE launch: workgroup 0 builds the tile table (11 us of one workgroup, 255 CUs
+// idle), the other workgroups split the weight matrices (16 waves each, one wave per matrix row) — the split used to be a launch of
+// its own (6 us) or, for frozen weights, cached between forwards on the strength of the tensors' autograd versions (a write through
+// `param.data` went stale silently).  Now it costs nothing and is never stale: no cache.
+__global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch_split(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ batch,
+                                                                            int* __restrict__ plan, PlanLayout L, int nV, int nE,
+                                                                            long long* dbg, int* __restrict__ mol_bounds, int n_mols_out,
+                                                                            mega16::SplitArgs sp) {
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];
+    if (blockIdx.x == 0) prepare_tiles_batch_body(lds_i, edge_index, batch, plan, L, nV, nE, dbg, mol_bounds, n_mols_out);
+    else mega16::split_weights_wave(sp, ((int)blockIdx.x - 1) * (kSmallThreads / 64) + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+}
 
 }  // namespace
 
@@ -844,9 +862,30 @@ static size_t tiles_batch_lds_bytes(int64_t nV, int64_t nE) {
 }
 
 int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV64, int64_t nE64, int* plan, hipStream_t s,
-                               int* mol_bounds, int64_t n_mols) {
+                               int* mol_bounds, int64_t n_mols, const dmpnn_fwd_args* split_for, bool* did_split) {
     const int nV = (int)nV64, nE = (int)nE64;
     const PlanLayout L = plan_layout(nV, nE);
+    if (did_split) *did_split = false;
+    mega16::SplitArgs sp;
+    if (split_for && did_split && (split_for->flags & DMPNN_F_MEGA) && (split_for->flags & DMPNN_F_SPLIT16) && !(split_for->flags & DMPNN_F_WSPLIT_READY) &&
+        mega16_split_args(*split_for, &sp)) {
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_tiles_batch_split),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+            if (e != hipSuccess) {
+                set_error("hipFuncSetAttribute(k_prepare_tiles_batch_split): %s", hipGetErrorString(e));
+                return DMPNN_EHIP;
+            }
+            attr2_set = true;
+        }
+        const int waves = ((sp.N + 15) & ~15) * sp.n_jobs, wpb = kSmallThreads / 64;
+        hipLaunchKernelGGL(k_prepare_tiles_batch_split, dim3((unsigned)(1 + (waves + wpb - 1) / wpb)), dim3(kSmallThreads), tiles_batch_lds_bytes(nV, nE), s,
+                           edge_index, batch, plan, L, nV, nE, g_debug_stamps ? g_debug_stamps + 32 : nullptr, mol_bounds, (int)n_mols, sp);
+        DMPNN_CHECK_LAUNCH("k_prepare_tiles_batch_split");
+        *did_split = true;
+        return DMPNN_OK;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prepare_tiles_batch),

@@ -94,6 +94,54 @@ int launch_linear16(const dmpnn_gemm_args& a, const mega16::SplitW& W, const int
     }
 }
 
+// several matrices in ONE launch (<= 6: the per-step routes' W_i | W_h | W_o | W_d | W_o[:, d_v:] | W_o[:, :d_v] — each used to be a
+// launch of its own, hidden behind the version-keyed cache of rounds 1-3; without the cache they are one launch per forward)
+// ... the argument block only (views filled in): for a caller whose first kernel does not read the weights and lets the split ride in
+// that launch (launch_fused16_forward: k_split_rows_w)
+bool split_weights_args(const SplitWJob* jobs, int n, SplitWView* out, mega16::SplitArgs* spp) {
+    if (n <= 0 || n > 6) return false;
+    mega16::SplitArgs& sp = *spp;
+    memset(&sp, 0, sizeof(sp));
+    int64_t Nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const SplitWJob& j = jobs[i];
+        const size_t NT = (size_t)(j.N + 15) / 16, nc = (size_t)(j.K + 31) / 32;
+        unsigned char* p = static_cast<unsigned char*>(j.ws);
+        float* inv = reinterpret_cast<float*>(p + al256(NT * nc * 2048));
+        sp.job[i] = mega16::SplitJob{j.W, (int)j.ldw, 0, (int)j.K, 0, (int)j.K, p, (int)nc, inv, j.tr, (int)j.N};
+        out[i].p = p; out[i].inv_scale = inv; out[i].nc = (int)nc;
+        if (j.N > Nmax) Nmax = j.N;
+    }
+    sp.N = (int)Nmax; sp.n_jobs = n;
+    return true;
+}
+int launch_split_args(const mega16::SplitArgs& sp, hipStream_t s) {
+    const unsigned waves = (unsigned)(((sp.N + 15) / 16) * 16) * (unsigned)sp.n_jobs;
+    hipLaunchKernelGGL(mega16::k_split_weights, dim3((waves + 3) / 4), dim3(256), 0, s, sp);
+    DMPNN_CHECK_LAUNCH("k_split_weights");
+    return DMPNN_OK;
+}
+int split_weights_views(const SplitWJob* jobs, int n, SplitWView* out, hipStream_t s) {
+    if (n <= 0) return DMPNN_OK;
+    if (n > 6) { set_error("split_weights_views: at most 6 matrices per launch"); return DMPNN_EINVAL; }
+    mega16::SplitArgs sp;
+    memset(&sp, 0, sizeof(sp));
+    int64_t Nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const SplitWJob& j = jobs[i];
+        const size_t NT = (size_t)(j.N + 15) / 16, nc = (size_t)(j.K + 31) / 32;
+        unsigned char* p = static_cast<unsigned char*>(j.ws);
+        float* inv = reinterpret_cast<float*>(p + al256(NT * nc * 2048));
+        sp.job[i] = mega16::SplitJob{j.W, (int)j.ldw, 0, (int)j.K, 0, (int)j.K, p, (int)nc, inv, j.tr, (int)j.N};
+        out[i].p = p; out[i].inv_scale = inv; out[i].nc = (int)nc;
+        if (j.N > Nmax) Nmax = j.N;
+    }
+    sp.N = (int)Nmax; sp.n_jobs = n;
+    const unsigned waves = (unsigned)(((Nmax + 15) / 16) * 16) * (unsigned)n;
+    hipLaunchKernelGGL(mega16::k_split_weights, dim3((waves + 3) / 4), dim3(256), 0, s, sp);
+    DMPNN_CHECK_LAUNCH("k_split_weights");
+    return DMPNN_OK;
+}
 int split_weights_view(const float* W, int64_t ldw, int64_t N, int64_t K, int tr, void* ws, SplitWView* out, hipStream_t s) {
     mega16::SplitW w;
     DMPNN_TRY(split_weights(W, ldw, N, K, tr, ws, &w, s));

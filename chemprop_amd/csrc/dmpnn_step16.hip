@@ -184,7 +184,8 @@ static bool x_path_ok(const dmpnn_fwd_args& a) {
 // K1 on the update kernel (d_h > 320, and the x path): the gathered fp32 operand is split into rows first (`scratch`: the second
 // message slot, or — x path, keep_h0 false — the H0 buffer, where the rows stay for the depth steps and no H0 is written)
 static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* scratch, bool keep_h0,
-                           unsigned char* Mout, float* Sout, float* M32, hipStream_t s, unsigned char* bits = nullptr) {
+                           unsigned char* Mout, float* Sout, float* M32, hipStream_t s, unsigned char* bits = nullptr,
+                           const mega16::SplitArgs** pending = nullptr) {
     const int* plan_i = static_cast<const int*>(a.plan);
     step16::SplitRowsK k;
     memset(&k, 0, sizeof(k));
@@ -192,8 +193,16 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
     k.A1 = a.V; k.lda1 = (int)a.ldv; k.g1 = plan_i + L.srcp; k.K1 = (int)a.d_v; k.a1_bytes = (unsigned)(a.n_atoms * a.ldv * 4);
     k.A2 = a.d_e ? a.E : nullptr; k.lda2 = (int)a.lde; k.g2 = plan_i + L.perm; k.K2 = (int)a.d_e; k.a2_bytes = (unsigned)(a.n_edges * a.lde * 4);
     k.out = scratch; k.ts = step16::split_operand_bytes((int)(a.d_v + a.d_e));
-    hipLaunchKernelGGL(step16::k_split_rows, dim3((unsigned)L.max_tiles), dim3(256), 0, s, k);
-    DMPNN_CHECK_LAUNCH("k_split_rows");
+    if (pending && *pending) {   // the weights' pre-split rides in this launch (which does not read them)
+        const mega16::SplitArgs& sp = **pending;
+        const unsigned waves = (unsigned)(((sp.N + 15) / 16) * 16) * (unsigned)sp.n_jobs;
+        hipLaunchKernelGGL(step16::k_split_rows_w, dim3((unsigned)L.max_tiles + (waves + 3) / 4), dim3(256), 0, s, k, sp, (int)L.max_tiles);
+        DMPNN_CHECK_LAUNCH("k_split_rows_w");
+        *pending = nullptr;
+    } else {
+        hipLaunchKernelGGL(step16::k_split_rows, dim3((unsigned)L.max_tiles), dim3(256), 0, s, k);
+        DMPNN_CHECK_LAUNCH("k_split_rows");
+    }
     step16::Step16K g = step_args(a, L);
     g.A = scratch; g.ts = k.ts;
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
@@ -244,8 +253,13 @@ static int launch_fin16(const dmpnn_fwd_args& a, const PlanLayout& L, const Spli
 
 // a.Ms: two slots of n_edges split rows (split_row_floats(d_h) floats each); a.H0 [n_edges, ldh]; a.Mv [n_atoms, ldh];
 // w16: pre-split W_i | W_h | W_o (| W_d).  `out` / `ldout`: the finalize output (Hv when W_d follows).
-int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s) {
+int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s,
+                           const mega16::SplitArgs* pending_in) {
     const int64_t nV = a.n_atoms, nE = a.n_edges, h = a.d_h;
+    const mega16::SplitArgs* pending = pending_in;
+    // the weights' pre-split: in the first launch of the chain when that launch is k_split_rows (it does not read them), else now
+    const bool rides = nE > 0 && (fused16_lean(a) || (!(a.flags & DMPNN_F_KEEP) && x_path_ok(a)) || h > 320);
+    if (pending && !rides) { DMPNN_TRY(launch_split_args(*pending, s)); pending = nullptr; }
     const PlanLayout L = plan_layout(nV, nE);
     const int T = a.depth;
     // (a slot is n_edges message rows; the first always spans split_row_bytes per edge — the K1 operand scratch of wide layers lives in the second)
@@ -266,7 +280,7 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
         unsigned char* Mk = reinterpret_cast<unsigned char*>(a.msplit);
         unsigned char* bits = static_cast<unsigned char*>(a.keep_bits);
         const size_t bslot = (size_t)nE * (size_t)(step16::block_cols((int)h) / 8);
-        DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, Mk, nullptr, nullptr, s, bits));   // M^(1) -> slot 0; signs of H0 -> site 0
+        DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, Mk, nullptr, nullptr, s, bits, &pending));   // M^(1) -> slot 0; signs of H0 -> site 0
         for (int t = 1; t < T; ++t) {
             const bool last = t == T - 1;
             DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], xrows, Mk + (size_t)(t - 1) * slot_bytes, last ? nullptr : Mk + (size_t)t * slot_bytes,
@@ -276,8 +290,8 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
         const bool xpath = !keep && x_path_ok(a);
         unsigned char* xrows = xpath ? reinterpret_cast<unsigned char*>(a.H0) : nullptr;
         float* m32_0 = (keep && T > 1) ? a.Ms : nullptr;  // M^(1): what update step 1 consumes, what gW_h's first product reads
-        if (xpath) DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, nullptr, s));
-        else if (h > 320) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, true, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s));
+        if (xpath) DMPNN_TRY(launch_k1_split(a, L, w16[0], xrows, false, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, nullptr, s, nullptr, &pending));
+        else if (h > 320) DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, true, T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s, nullptr, &pending));
         else DMPNN_TRY(launch_k1_seg(a, L, w16[0], T > 1 ? Ms : nullptr, T > 1 ? nullptr : a.Mv, m32_0, s));
         for (int t = 1; t < T; ++t) {
             const bool last = t == T - 1;

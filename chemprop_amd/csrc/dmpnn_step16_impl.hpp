@@ -435,7 +435,7 @@ struct SplitRowsK {
     const float* A2; int lda2; const int* g2; int K2; unsigned a2_bytes;
     unsigned char* out; int ts;
 };
-static __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
+__device__ __forceinline__ void split_rows_body(const SplitRowsK& g) {
     __shared__ unsigned maxbits;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (no tile table: uniform 48-row tiles over n_rows rows; no gather arrays: the rows in place)
@@ -521,6 +521,14 @@ static __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) {
             if (pass == 1 && lane == 0) *reinterpret_cast<float4*>(g.out + (long long)(rs + r) * g.ts + (g.ts - 16)) = make_float4(s, 0.f, 0.f, 0.f);
         }
     }
+}
+
+static __global__ __launch_bounds__(256) void k_split_rows(SplitRowsK g) { split_rows_body(g); }
+// ... with the pre-split of the forward's weights riding in the same launch (workgroups beyond the row tiles: 4 waves each, one wave
+// per matrix row): this launch does not read the weights, the next one does — the split costs no launch of its own
+static __global__ __launch_bounds__(256) void k_split_rows_w(SplitRowsK g, mega16::SplitArgs sp, int n_row_blocks) {
+    if ((int)blockIdx.x < n_row_blocks) split_rows_body(g);
+    else mega16::split_weights_wave(sp, ((int)blockIdx.x - n_row_blocks) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 
 template <int WN, int NW, bool HIN, bool XP>

@@ -103,7 +103,7 @@ class GraphPlan:
     """K0: int32 indices + stable incoming-edge CSR of one batch, built on device (no host sync)."""
 
     __slots__ = ("buf", "n_atoms", "n_edges", "device", "light", "tiles_only", "edge_index", "rev_edge_index", "loader_tiles",
-                 "any_size", "oversize")
+                 "any_size", "oversize", "pending", "_job")
 
     def __init__(self, edge_index: Tensor, rev_edge_index: Tensor, n_atoms: int, light=False, batch: Optional[Tensor] = None,
                  tiles: Optional[tuple] = None, launch: bool = True):
@@ -145,6 +145,16 @@ class GraphPlan:
                       and bool(lib.dmpnn_full_plan_keeps_tiles(n_atoms, n_edges)))
         self.any_size = (self.tiles_only and not small) or full_tiles  # (the forward's DMPNN_F_LOADER_TILES)
         self.edge_index, self.rev_edge_index = ei, rev
+        self.pending, self._job = None, None
+        if launch == "defer":
+            # K0 NOT launched yet: a tile plan from the batch vector within the single-workgroup plan — the forward that follows
+            # runs K0, the pre-split of its weights (in K0's launch) and the tile kernel as ONE foreign call (dmpnn_forward_tiles);
+            # anything else that wants the plan first calls ensure_launched()
+            if self.tiles_only and small and not self.loader_tiles and bt is not None:
+                self.pending = bt
+                self._job = (tiles, bt, full_tiles, nbytes)
+                return
+            launch = True
         if not launch:
             # the buffer and the facts only: dmpnn_train_step runs K0 itself (dmpnn_prepare_with_batch: a FULL plan — with
             # molecule tiles where full_tiles says so; dmpnn_prepare_tiles for a tile plan, DMPNN_F_TILE_PLAN)
@@ -152,6 +162,20 @@ class GraphPlan:
                 raise RuntimeError("GraphPlan(launch=False) is the plan of a training step: full, or the tile plan (light='tiles')")
             self.loader_tiles = 0  # (the C call plans from the batch vector: the launch bound of the batch size, not a loader's count)
             return
+        self._job = (tiles, bt, full_tiles, nbytes)
+        self._launch()
+
+    def ensure_launched(self) -> None:
+        """Run a deferred K0 now (``launch="defer"``: the forward would have run it inside its own call)."""
+        if self.pending is not None:
+            self.pending = None
+            self._launch()
+
+    def _launch(self) -> None:
+        lib = _lib.load()
+        tiles, bt, full_tiles, nbytes = self._job
+        self._job = None
+        dev, ei, rev, n_atoms, n_edges = self.device, self.edge_index, self.rev_edge_index, self.n_atoms, self.n_edges
         with _OnDevice(dev):
             if self.loader_tiles:
                 _lib.check(lib.dmpnn_prepare_tiles_from_table(tiles[0].data_ptr(), tiles[1].data_ptr(), self.loader_tiles, n_atoms,
@@ -170,13 +194,14 @@ class GraphPlan:
                                 self.buf.data_ptr(), nbytes, _stream_ptr(dev)), "dmpnn_prepare")
 
     @classmethod
-    def from_bmg(cls, bmg, light=False, use_batch: bool = True, launch: bool = True) -> "GraphPlan":
+    def from_bmg(cls, bmg, light=False, use_batch: bool = True, launch=True) -> "GraphPlan":
         return cls(bmg.edge_index, bmg.rev_edge_index, int(bmg.V.shape[0]), light=light,
                    batch=getattr(bmg, "batch", None) if use_batch else None,
                    tiles=getattr(bmg, "tiles", None) if light == "tiles" else None, launch=launch)
 
     # ---- views for tests / diagnostics (these synchronise) ----
     def arrays(self) -> dict:
+        self.ensure_launched()
         off = self._offsets()
         b = self.buf.cpu()
         E, V, T = self.n_edges, self.n_atoms, int(off[11])
@@ -189,10 +214,12 @@ class GraphPlan:
 
     def header(self) -> list:
         """The 16 header words (synchronises): [0] flags, [6] piece tiles, [8] oversize pieces (DMPNN_HDR_NSPILL), ..."""
+        self.ensure_launched()
         return self.buf[:16].tolist()
 
     def flags(self) -> int:
         """Plan flag word (synchronises): bit0 asymmetric, bit1 index out of range, bit2 in-degree > 24."""
+        self.ensure_launched()
         return int(self.buf[0].item())
 
     def fusable(self) -> bool:
@@ -210,6 +237,7 @@ class GraphPlan:
         return off
 
     def _view(self, k: int) -> Tensor:
+        self.ensure_launched()
         off = self._offsets()
         return self.buf[off[k]:off[k] + self.n_edges]
 
@@ -423,9 +451,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     * ``fused``   — per depth step one contraction whose epilogue forms the segment sums (CSR-row order);
     * ``general`` — arbitrary index arrays / undirected / any ``d_h`` (caller's edge order).
 
-    ``wcache``: a dict owned by the caller (one per module) in which the pre-split weights of the split-MFMA
-    route survive between calls; they are reused while W_i / W_h / W_o are the same tensors at the same
-    ``_version`` (frozen weights; ``DMPNN_WCACHE=0`` disables it).
+    ``wcache``: a dict owned by the caller (one per module) that keeps the SCRATCH BUFFER of the weights' pre-split between calls
+    (no allocation per forward); its contents are rewritten by every forward — nothing about the weights is cached.
 
     ``mfma`` picks the matrix arithmetic of the mega route: ``"split16"`` (default; fp32-equivalent exact
     3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
@@ -630,19 +657,15 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if keep:
             a.flags |= F_KEEP  # (the size below then includes the backward tile kernel's two transposed matrices)
         nb = int(lib.dmpnn_forward_wsplit_bytes(C.byref(a)))
-        # pre-split weights are reusable while the weight tensors are the same objects at the same
-        # autograd version (every in-place update bumps `_version`): inference with frozen weights
-        key = None
-        if wcache is not None and _lib.opt("DMPNN_WCACHE", "1") != "0":
-            key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (W_i, W_h, W_o) + ((W_d,) if d_vd else ())) \
-                + (nb, d_v, d_e, str(dev), bool(use_mega))  # (the per-step routes share one layout: W_i | W_h | W_o | W_d)
-            if wcache.get("key") == key:
-                wsplit = wcache["buf"]
-                a.flags |= F_WSPLIT_READY
-        if wsplit is None:
+        # scratch of the weights' pre-split — redone by EVERY forward (round 4: it rides in K0's launch on the steady path, so keeping
+        # it between forwards on the strength of the tensors' autograd versions — which a write through `param.data` does not bump —
+        # bought nothing and could go stale silently); `wcache`, when given, only keeps the BUFFER of a module between its calls
+        # (a TRAINING forward gets a buffer of its own: the backward pass reads the transposed matrices in it later)
+        wsplit = wcache.get("buf") if (wcache is not None and not keep) else None
+        if wsplit is None or wsplit.numel() != nb or wsplit.device != dev:
             wsplit = torch.empty(nb, dtype=torch.uint8, device=dev)
-            if key is not None:
-                wcache["key"], wcache["buf"] = key, wsplit
+            if wcache is not None and not keep:
+                wcache["buf"] = wsplit
         a.wsplit, a.wsplit_bytes = wsplit.data_ptr(), nb
         st.route = "mega16" if use_mega else (("fused16/lean" if lean16 else "fused16") if use_fused16 else "general16")
         if use_fused16 and storage_f16() and not keep:
@@ -667,8 +690,16 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
                 bits = torch.empty(nbits, dtype=torch.uint8, device=dev)
                 a.keep_bits, a.keep_bits_bytes = bits.data_ptr(), nbits
     if launch:  # (launch=False: the argument block and the workspace only — dmpnn_train_step enqueues the forward itself)
+        pend = getattr(plan, "pending", None)
         with _OnDevice(dev):
-            _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
+            if pend is not None and use_mega and want16 and tiles_only:
+                # K0 was deferred to this call: tile table + weight pre-split (ONE launch) + tile kernel as one foreign call
+                plan.pending = None
+                _lib.check(lib.dmpnn_forward_tiles(C.byref(a), pend.data_ptr(), None, None, 0, plan.buf.numel() * 4, _stream_ptr(dev)), "dmpnn_forward_tiles")
+            else:
+                if pend is not None:
+                    plan.ensure_launched()
+                _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
     st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, split_ms, bits, wsplit)  # (wsplit last: nn._make_replay)
     st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)

@@ -80,12 +80,10 @@ _STATE_SKIP_KEYS = _CACHE_KEYS + ("_dmpnn_grad_views", "_dmpnn_grad_written")
 
 
 def invalidate(module: nn.Module) -> None:
-    """Drop what the engine remembers about ``module`` between forwards (pre-split weights, the replayed argument
-    block, the spill monitor).  The caches key on the weight tensors' identity, ``data_ptr()``, device and autograd
-    ``_version``, so every in-place update through the tensor API (optimizer steps, ``load_state_dict``, ``copy_``),
-    every re-allocation and every device move is seen.  Writes through ``param.data`` (``p.data.mul_()``, EMA / SWA
-    swaps that assign ``p.data``'s storage in place) bump no version: call this after such an update, or run with
-    ``DMPNN_WCACHE=0 DMPNN_REPLAY=0``."""
+    """Drop what the engine remembers about ``module`` between forwards (the replayed argument block, the scratch buffers, the
+    spill monitor).  Nothing of it depends on the weights' VALUES — every forward pre-splits the weights afresh (round 4: in K0's
+    launch, for free), so an update through ``param.data`` (EMA / SWA swaps) is seen like any other; the replayed argument block
+    keys on the parameter tensors' identity, ``data_ptr()`` and device, which a re-allocation or a device move changes."""
     for m in module.modules():
         for k in _CACHE_KEYS:
             m.__dict__.pop(k, None)
@@ -165,7 +163,7 @@ def _training_plan_kind(mp, bmg):
     return "tiles" if (buildable and _tile_plan_ok(mp, n_atoms, n_edges, n_mols, True)) else False
 
 
-_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_WCACHE", "DMPNN_VALIDATE", "DMPNN_STORE")
+_ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_VALIDATE", "DMPNN_STORE")
 
 
 class _Replay:
@@ -174,7 +172,7 @@ class _Replay:
     decision was taken on.  A call that finds all of them unchanged only builds the tile plan, allocates ``out`` and
     fills in the batch's pointers — the same two C calls, without the general routing code in between."""
 
-    __slots__ = ("args", "tensors", "versions", "ptrs", "tau", "training", "env", "dev", "d_v", "d_e", "d_h", "wsplit", "depth", "block", "flags",
+    __slots__ = ("args", "tensors", "ptrs", "tau", "training", "env", "dev", "d_v", "d_e", "d_h", "wsplit", "depth", "block", "flags",
                  "ldh", "spill")
 
 
@@ -192,7 +190,6 @@ def _make_replay(mp, plan, st) -> None:
     r.args = bytes(st.args)  # template copy of the argument block
     r.tensors = tuple(_param(mp, l, n) for l, n in (("W_i", "weight"), ("W_h", "weight"), ("W_o", "weight"), ("W_i", "bias"),
                                                       ("W_h", "bias"), ("W_o", "bias")))
-    r.versions = tuple(-1 if t is None else t._version for t in r.tensors)
     r.ptrs = tuple(0 if t is None else t.data_ptr() for t in r.tensors)
     r.tau, r.training, r.depth = mp._modules.get("tau"), mp.training, mp.depth
     r.env = tuple(_lib.opt(k, "") for k in _ENV_KEYS)
@@ -204,9 +201,9 @@ def _make_replay(mp, plan, st) -> None:
     # the live argument block of the steady path: everything that does not belong to a batch is set here, once
     blk = r.block = _lib.FwdArgs.from_buffer_copy(r.args)
     blk.ldv, blk.lde, blk.ldout = r.d_v, r.d_e, r.d_h
-    # (DMPNN_WCACHE=0: the pre-split of the weights is redone by every forward — also on this steady path; r.env pins the choice)
-    ready = _lib.F_WSPLIT_READY if _lib.opt("DMPNN_WCACHE", "1") != "0" else 0
-    r.flags = ((int(blk.flags) & ~_lib.F_WSPLIT_READY) | ready) & ~_lib.F_LOADER_TILES
+    # (the pre-split of the weights is redone by every forward — it rides in K0's launch, dmpnn_forward_tiles — so the steady path
+    #  needs no promise about the weights' VALUES: the checks below are about identity, shape and layout only)
+    r.flags = int(blk.flags) & ~_lib.F_WSPLIT_READY & ~_lib.F_LOADER_TILES
     r.ldh, r.spill = int(blk.ldh), None
     mp.__dict__["_dmpnn_replay"] = r
 
@@ -227,8 +224,8 @@ def _replay_forward(mp, r: "_Replay", bmg):
     if (_param(mp, "W_i", "weight") is not ts[0] or _param(mp, "W_h", "weight") is not ts[1] or _param(mp, "W_o", "weight") is not ts[2]
             or _param(mp, "W_i", "bias") is not ts[3] or _param(mp, "W_h", "bias") is not ts[4] or _param(mp, "W_o", "bias") is not ts[5]):
         return None
-    for t, ver, ptr in zip(ts, r.versions, r.ptrs):  # same values (every tensor-API update bumps _version), same storage, same device
-        if t is not None and (t._version != ver or t.data_ptr() != ptr or t.device != r.dev):
+    for t, ptr in zip(ts, r.ptrs):  # same storage, same device (the VALUES may have changed: every forward splits the weights afresh)
+        if t is not None and (t.data_ptr() != ptr or t.device != r.dev):
             return None
     if tuple(_lib.opt(k, "") for k in _ENV_KEYS) != r.env:
         return None
@@ -379,7 +376,8 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         light = "tiles"
     if not light and torch.is_grad_enabled() and V_d is None:
         light = _training_plan_kind(mp, bmg)   # a training forward bound for the tile kernels: the tile plan (DMPNN_F_TILE_PLAN)
-    plan = engine.GraphPlan.from_bmg(bmg, light=light)
+    # (a tile plan: K0 is deferred into the forward's own call where the library can run it with the weight pre-split in ONE launch)
+    plan = engine.GraphPlan.from_bmg(bmg, light=light, launch="defer" if light == "tiles" else True)
     if n_mols and getattr(bmg, "batch", None) is not None:
         from .agg import note_batch
 
@@ -392,6 +390,7 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     out = mp_forward(mp, plan, bmg.V, bmg.E, V_d, max_level=level)
     last = mp.__dict__.pop("_dmpnn_last", None)  # (the forward's workspace must not outlive the call)
     mp.__dict__["_dmpnn_route"] = getattr(last, "route", None)  # diagnostics: the route the last slow-path forward took
+    plan.ensure_launched()   # (nothing ran the deferred K0: a route that does not read the plan at all)
     if oversize is None and plan.tiles_only and last is not None and last.route == "mega16":
         _spill_monitor(mp, plan.buf, plan.device)
     if light == "tiles" and V_d is None and not torch.is_grad_enabled() and _lib.opt("DMPNN_REPLAY", "1") != "0":

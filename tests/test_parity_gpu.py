@@ -1076,9 +1076,11 @@ def test_training_forward_on_the_per_step_fused_route(n_mols, kind, kw, gpu_devi
         assert e_ref <= 2e-5 and e_gen <= 2e-5, f"{k}: vs reference {e_ref:.2e}, vs general route {e_gen:.2e}"
 
 
-def test_presplit_weight_cache_follows_weight_updates(gpu_device):
-    """Inference reuses the pre-split weights of the split-MFMA route between calls (same tensors, same
-    ``_version``); any in-place update (optimizer step, load_state_dict) must invalidate them."""
+def test_every_weight_update_is_seen_also_through_param_data(gpu_device):
+    """Nothing about the weights is cached between forwards (round 4: the f16 pre-split rides in K0's launch, every call): an update
+    through the tensor API, ``load_state_dict`` AND a write through ``param.data`` — which bumps no autograd version: the EMA / SWA
+    swap that went stale silently behind rounds 1-3's version-keyed cache — change the very next forward, on the steady (replayed)
+    path and on the slow path alike."""
     from chemprop_amd import synth
     from chemprop_amd.nn import BondMessagePassing
 
@@ -1086,21 +1088,31 @@ def test_presplit_weight_cache_follows_weight_updates(gpu_device):
     bmg.to(gpu_device)
     torch.manual_seed(3)
     mp = BondMessagePassing(d_h=300).to(gpu_device).eval()
+
+    def fresh_out():
+        f = BondMessagePassing(d_h=300).to(gpu_device).eval()
+        f.load_state_dict(mp.state_dict())
+        return f(bmg)
+
     with torch.no_grad():
-        a = mp(bmg)
-        b = mp(bmg)  # second call: cached pre-split
-        cache = mp.__dict__.get("_dmpnn_wcache")
-        assert cache and cache.get("buf") is not None, "the default route of this batch is the split-MFMA tile kernel"
-        assert torch.equal(a, b)
-        mp.W_h.weight.mul_(1.5)
-        mp.W_o.weight.add_(0.01)
+        for _ in range(4):   # validated batches, then the steady path
+            a = mp(bmg)
+        assert mp.__dict__.get("_dmpnn_replay") is not None and torch.equal(a, mp(bmg))
+        mp.W_h.weight.mul_(1.5)                       # the tensor API
         c = mp(bmg)
-        fresh = BondMessagePassing(d_h=300).to(gpu_device).eval()
-        fresh.load_state_dict(mp.state_dict())
-        d = fresh(bmg)
-    assert not torch.equal(a, c)
-    # (c ran on a tile plan, d on the fresh module's first, validated, full plan: same arithmetic class, other row order)
-    assert parity_err(c.cpu().numpy(), d.cpu().numpy()) <= 3e-6
+        assert not torch.equal(a, c) and parity_err(c.cpu().numpy(), fresh_out().cpu().numpy()) <= 3e-6
+        v = mp.W_o.weight._version
+        mp.W_o.weight.data.mul_(0.5)                  # through .data: no version bump
+        mp.W_i.weight.data.add_(0.01)
+        assert mp.W_o.weight._version == v
+        d = mp(bmg)
+        assert mp.__dict__.get("_dmpnn_replay") is not None          # (still the steady path)
+        assert not torch.equal(c, d) and parity_err(d.cpu().numpy(), fresh_out().cpu().numpy()) <= 3e-6
+        ema = {k: t * 0.9 for k, t in mp.state_dict().items()}
+        for k, p in mp.named_parameters():            # an EMA swap the way callbacks do it
+            p.data.copy_(ema[k])
+        e = mp(bmg)
+        assert parity_err(e.cpu().numpy(), fresh_out().cpu().numpy()) <= 3e-6 and not torch.equal(d, e)
 
 
 def test_frozen_encoder_and_no_grad(gpu_device):
