@@ -281,7 +281,23 @@ def main():
             run_steps(tstep, 10)
             t_tr = timed_groups(tstep, args.steps, args.groups)[0] / args.steps * 1e3  # (the rule of `value`: groups of K steps, synchronize on both sides, max over ranks, median group)
             tsync.wait()
+            exposed_us = None
+            if world > 1:
+                # what the exchange COSTS the step: the same step with the all-reduce left out (every rank updates with its own
+                # gradients: numerically another run, the same kernels), same timing rule — the difference is the part of the
+                # collective the backward pass does not hide
+                def tstep_noex():
+                    with ddp.backward_on_calling_thread():
+                        o = tmp(bmg)
+                        o.backward(Gt)
+                    topt.step()
+                run_steps(tstep_noex, 5)
+                t_no = timed_groups(tstep_noex, args.steps, args.groups)[0] / args.steps * 1e3
+                exposed_us = round((t_tr - t_no) * 1e3, 1)
+                run_steps(tstep, 2)
+                tsync.wait()
             out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(world * updates / (t_tr * 1e-3) / 1e6, 2),
+                                 "allreduce_exposed_us": exposed_us,
                                  "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else None,
                                  "autograd": "backward on the calling thread (torch.autograd.set_multithreading_enabled(False): one process per GPU)",
                                  "plan": "K0 inside every step, on the stream: the tile table (dmpnn_prepare_tiles, 11 us; the kept tensors stay in the "
