@@ -713,6 +713,27 @@ def main():
                     "directed_edges": nE, "us": round(ta * 1e3, 1), "M_edge_updates_per_s": round(updates / (ta * 1e3), 1),
                     "route": am.__dict__.get("_dmpnn_route"), "bond_block_us": round(ms_per_step * 1e3, 1)}
                 del am
+                # ... and its TRAINING step on the tile kernels (round 4: DMPNN_F_ATOM | DMPNN_F_KEEP + the backward tile kernel), measured
+                # like `train_step` of the bond block: forward (kept) + backward + gradient exchange + flat Adam
+                from chemprop_amd import distributed as ddp3
+                from chemprop_amd.optim import FlatAdam as FlatAdam3
+
+                at = AtomMessagePassing(d_v=d_v, d_e=d_e, d_h=args.hidden, depth=args.depth).to(dev).train()
+                s4 = ddp3.GradSync(list(at.parameters()), modules=[at])
+                o4 = FlatAdam3(s4, lr=1e-4)
+                G4 = torch.randn(nV, args.hidden, device=dev)
+
+                def ft():
+                    with ddp3.backward_on_calling_thread():
+                        at(bmg).backward(G4)
+                    s4.allreduce()
+                    o4.step()
+                run_steps(ft, 6)
+                tt = time_events(ft, 30, torch)
+                oc[f"atom-{args.kind}-{args.mols} (AtomMessagePassing, inference)"].update(
+                    {"train_step_us": round(tt * 1e3, 1), "train_route": at.__dict__.get("_dmpnn_route"),
+                     "bond_block_train_step_us": (round(out["train_step"]["ms_per_step"] * 1e3, 1) if "ms_per_step" in out.get("train_step", {}) else None)})
+                del at, s4, o4, G4
             except Exception as e:
                 oc["atom"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             out["other_configs"] = oc

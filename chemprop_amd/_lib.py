@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("DMPNN_LIB") or os.path.join(_HERE, "libdmpnn_gfx950.s
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_step16.hip", "dmpnn_bstep16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip", "dmpnn_optim.hip", "dmpnn_wgrad16.hip", "dmpnn_head.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp", "dmpnn_seg16.hpp", "dmpnn_step16_impl.hpp"]
-ABI_VERSION = 10
+ABI_VERSION = 11
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
@@ -102,6 +102,7 @@ class BwdArgs(C.Structure):
         ("gW_i", C.c_void_p), ("gb_i", C.c_void_p), ("gW_h", C.c_void_p), ("gb_h", C.c_void_p),
         ("gW_o", C.c_void_p), ("gb_o", C.c_void_p), ("gW_d", C.c_void_p), ("gb_d", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("g_edge", C.c_void_p), ("ld_gedge", C.c_int64),
     ]
 
 

@@ -22,17 +22,32 @@ class FusedMP(torch.autograd.Function):
     def forward(ctx, mp, plan, V, E, V_d, act, slope, slope_and_route, W_i, b_i, W_h, b_h, W_o, b_o, W_d, b_d):
         slope_t, max_level = slope_and_route[0], slope_and_route[1]
         dropout = slope_and_route[2] if len(slope_and_route) > 2 else None
+        atom = bool(slope_and_route[3]) if len(slope_and_route) > 3 else False   # AtomMessagePassing on the tile kernels (DMPNN_F_ATOM)
+        # the mol-atom-bond blocks (mab.py): the kept H^(depth-1) is a second OUTPUT, for the edge read-out — in the caller's edge order —
+        # and its gradient a second input of the backward tile kernel (dmpnn_bwd_args.g_edge); tile-kernel forwards only, depth >= 2
+        want_edge = bool(slope_and_route[4]) if len(slope_and_route) > 4 else False
         has_vd = V_d is not None and W_d is not None
         out, st = engine.forward(plan, V, E, W_i, W_h, W_o, b_o, b_i, b_h, W_d if has_vd else None,
                                  b_d if has_vd else None, V_d if has_vd else None, depth=mp.depth, act=act,
-                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True, max_level=max_level, dropout=dropout)
+                                 slope=slope, slope_t=slope_t, undirected=mp.undirected, keep=True, max_level=max_level, dropout=dropout,
+                                 atom=atom, keep_bits=not want_edge)
         ctx.st = st
         ctx.has_vd = has_vd
         ctx.mp = mp
+        ctx.edge_rows = None
+        if want_edge:
+            if st.route != "mega16" or mp.depth < 2:
+                raise engine.RouteUnavailable("the edge states as an output: a training forward of the tile kernel, depth >= 2")
+            ctx.set_materialize_grads(False)
+            H = st.Hs[mp.depth - 2][:, :int(W_h.shape[0])]
+            ctx.edge_rows = "caller" if plan.tiles_only else "csr"   # (a tile plan keeps its tensors in the caller's edge order)
+            if ctx.edge_rows == "csr":
+                H = engine.gather_rows(H, plan.inv32)
+            return out, H
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, g_edge=None):
         st = ctx.st
         if st is None:
             raise RuntimeError("chemprop_amd: backward through this BondMessagePassing forward a second time — the kept workspace "
@@ -57,7 +72,12 @@ class FusedMP(torch.autograd.Function):
                 if (prm is not None and prm.grad is not None and prm.grad.data_ptr() == v.data_ptr() and need.get(k)
                         and (written is None or v.data_ptr() not in written)):
                     direct[k] = v
-        grads = engine.backward(st, gout.contiguous(), need, out=direct)
+        if ctx.edge_rows is not None:
+            if gout is None:   # (only the edge read-out reached the loss)
+                gout = torch.zeros_like(st.out)
+            if g_edge is not None and ctx.edge_rows == "csr":
+                g_edge = engine.gather_rows(g_edge.contiguous(), st.plan.perm32)
+        grads = engine.backward(st, gout.contiguous(), need, out=direct, g_edge=g_edge)
         if engine._lib.opt("DMPNN_KEEP_WORKSPACE", "0") != "1":
             ctx.st = None  # release the kept workspace
         # (a view the engine did not take — wrong dtype / layout — got a fresh tensor instead: that one goes to autograd)

@@ -359,10 +359,14 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
     }
 
     if (a->flags & DMPNN_F_ATOM) {
-        DMPNN_CHECK_ARG((a->flags & DMPNN_F_FUSED) && (a->flags & DMPNN_F_MEGA) && (a->flags & DMPNN_F_SPLIT16) && !(a->flags & DMPNN_F_KEEP) &&
+        DMPNN_CHECK_ARG((a->flags & DMPNN_F_FUSED) && (a->flags & DMPNN_F_MEGA) && (a->flags & DMPNN_F_SPLIT16) &&
                         !has_vd && de >= 1 && de <= 16 && a->dropout_p == 0.f,
                         "forward: DMPNN_F_ATOM (atom messages) runs on the whole-forward tile kernel only (DMPNN_F_FUSED | DMPNN_F_MEGA | "
-                        "DMPNN_F_SPLIT16, inference, 1 <= d_e <= 16, no W_d) — chain the row kernels otherwise");
+                        "DMPNN_F_SPLIT16, 1 <= d_e <= 16, no W_d, no dropout inside the kernels) — chain the row kernels otherwise");
+        // a TRAINING forward (round 4): the bond-feature half of the messages is kept for W_h's gradient — depth - 1 slots of [n_edges][16] in `msplit`
+        DMPNN_CHECK_ARG(!(a->flags & DMPNN_F_KEEP) || (de % 2 == 0 && dv % 2 == 0 && h % 2 == 0 &&
+                        (a->depth < 2 || nE == 0 || (a->msplit && aligned16(a->msplit) && a->msplit_bytes >= (size_t)(a->depth - 1) * (size_t)nE * 16 * sizeof(float)))),
+                        "forward: DMPNN_F_ATOM | DMPNN_F_KEEP needs even d_v / d_e / d_h and `msplit` >= (depth - 1) * n_edges * 64 bytes, 16-byte aligned");
     }
     if (a->dropout_p != 0.f) {
         DMPNN_CHECK_ARG(a->dropout_p > 0.f && a->dropout_p < 1.f, "forward: dropout_p must lie in [0, 1)");

@@ -662,9 +662,11 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     }
     L.w16 = false;
     {
-        const int kt_o = (int)(f.d_v + h) + 1, kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(f.d_v + f.d_e) + (f.b_i ? 1 : 0);
+        // (atom messages, DMPNN_F_ATOM: W_i is [h, d_v], W_h [h, h + d_e] — its product reads [M^(t) || ME], ME the kept [.][16] rows)
+        const bool atom = (f.flags & DMPNN_F_ATOM) != 0;
+        const int kt_o = (int)(f.d_v + h) + 1, kt_h = (int)h + (atom ? (int)f.d_e : 0) + (f.b_h ? 1 : 0), kt_i = (int)f.d_v + (atom ? 0 : (int)f.d_e) + (f.b_i ? 1 : 0);
         if (L.mega && h % 2 == 0 && f.ldh % 2 == 0 && wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, nullptr, f.ldh, (int)h) &&
-            (f.d_e == 0 || wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, f.E, f.lde, (int)f.d_e))) {
+            (atom ? (f.d_e % 2 == 0 && f.d_e >= 2 && f.d_e <= 16) : (f.d_e == 0 || wgrad16_operand_ok(f.V, f.ldv, (int)f.d_v, f.E, f.lde, (int)f.d_e)))) {
             L.w16 = true;
             const int64_t Ms[3] = {nV, nE * steps, nE};
             const int Ks[3] = {kt_o, kt_h, kt_i};
@@ -785,6 +787,9 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
     const bool has_vd = f.W_d != nullptr;
     const int64_t dvd = has_vd ? f.d_vd : 0;
     const int T = f.depth;
+    // atom messages (DMPNN_F_ATOM, base.py:254-289): gW_i is [h, d_v], gW_h [h, h + d_e]; only the tile kernels carry them
+    const bool atom = (f.flags & DMPNN_F_ATOM) != 0;
+    const int64_t de_i = atom ? 0 : de, de_h = atom ? de : 0;
     DMPNN_CHECK_ARG(f.plan && h > 0 && dv > 0 && T >= 1, "backward: bad forward description");
     DMPNN_CHECK_ARG(f.act >= DMPNN_ACT_RELU && f.act <= DMPNN_ACT_ELU && f.act != DMPNN_ACT_PRELU,
                     "backward: activation %d has no fused backward (use the row kernels)", f.act);
@@ -820,7 +825,7 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         if (p && rows * cols > 0) hipMemsetAsync(p, 0, (size_t)(rows * cols) * sizeof(float), s);
     };
     if (nV == 0) {
-        zero2d(b->gW_i, h, dv + de); zero2d(b->gb_i, 1, h); zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h);
+        zero2d(b->gW_i, h, dv + de_i); zero2d(b->gb_i, 1, h); zero2d(b->gW_h, h, h + de_h); zero2d(b->gb_h, 1, h);
         zero2d(b->gW_o, h, dv + h); zero2d(b->gb_o, 1, h); zero2d(b->gW_d, h + dvd, h + dvd); zero2d(b->gb_d, 1, h + dvd);
         return DMPNN_OK;
     }
@@ -947,7 +952,13 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         }
         return DMPNN_OK;
     }
-    const bool tile_bwd = L.mega && (b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO);
+    const bool tile_bwd = L.mega && (atom || b->g_edge || b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO);
+    DMPNN_CHECK_ARG(!b->g_edge || nE == 0 || (tile_bwd && b->ld_gedge >= h && b->ld_gedge % 4 == 0 && aligned16(b->g_edge)),
+                    "backward: g_edge (a gradient w.r.t. the kept H^(depth-1)) is taken by the backward tile kernel only (tile-kernel forward with "
+                    "DMPNN_F_KEEP), as 16-byte aligned rows with a leading dimension that is a multiple of 4");
+    DMPNN_CHECK_ARG(!atom || (tile_bwd && L.w16 && !has_vd && (T < 2 || nE == 0 || f.msplit)),
+                    "backward: DMPNN_F_ATOM needs the tile-kernel forward (FUSED | MEGA | SPLIT16 | KEEP with `msplit`), even d_v / d_e / d_h and "
+                    "16-byte aligned gout / out (leading dimensions multiples of 4)");
     // in-kernel dropout (dmpnn_fwd_args.dropout_p): its 1 / (1 - p) lives in the backward TILE kernel alone — every other branch below
     // would return gradients without it, silently
     DMPNN_CHECK_ARG(!(f.dropout_p > 0.f) || tile_bwd,
@@ -957,7 +968,7 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         // ---- the whole data-gradient chain in one launch, then the four weight gradients ----
         DMPNN_CHECK_ARG(f.H0 && (T == 1 || f.Hs), "backward: the tile-kernel forward did not keep H0 / H^(t)");
         float* gZs = (T - 1 > 2) ? ws + L.gZs : gZa;  // slot t-1 = gZ^(t)
-        DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, ws + L.sp_gM, ws + L.gMv, s));
+        DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, ws + L.sp_gM, ws + L.gMv, s, b->g_edge, b->ld_gedge));
         if (L.w16 && aligned16(f.Mv) && (T < 2 || (aligned16(f.Ms) && aligned16(gZs))) && aligned16(gH0) && aligned16(gZO)) {
             // ---- the three weight gradients on the f16 pipe: every operand split ONCE (one launch), three products, three reduces ----
             const bool want[3] = {b->gW_o || b->gb_o, (b->gW_h || b->gb_h) && T >= 2, b->gW_i || b->gb_i};
@@ -965,18 +976,20 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
             memset(&sp, 0, sizeof(sp));
             WSplitJob* Zj[3] = {nullptr, nullptr, nullptr};
             WSplitJob* Aj[3] = {nullptr, nullptr, nullptr};
-            const int Ks[3] = {(int)(dv + h) + 1, (int)h + (f.b_h ? 1 : 0), (int)(dv + de) + (f.b_i ? 1 : 0)};
+            const int Ks[3] = {(int)(dv + h) + 1, (int)(h + de_h) + (f.b_h ? 1 : 0), (int)(dv + de_i) + (f.b_i ? 1 : 0)};
             if (want[0]) {
                 Zj[0] = &sp.job[sp.n_jobs++]; wsplit16_job(Zj[0], nV, (int)h, gZO, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, 0, ws + L.w16_z[0]);
                 Aj[0] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[0], nV, Ks[0], f.V, f.ldv, nullptr, (int)dv, f.Mv, ldh, nullptr, (int)h, 1, ws + L.w16_a[0]);
             }
             if (want[1]) {
                 Zj[1] = &sp.job[sp.n_jobs++]; wsplit16_job(Zj[1], nE * (T - 1), (int)h, gZs, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, 0, ws + L.w16_z[1]);
-                Aj[1] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[1], nE * (T - 1), Ks[1], f.Ms, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, f.b_h ? 1 : 0, ws + L.w16_a[1]);
+                // (atom messages: the bond-feature half of every step's message, the forward's [depth - 1][n_edges][16] rows in `msplit`)
+                Aj[1] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[1], nE * (T - 1), Ks[1], f.Ms, ldh, nullptr, (int)h, static_cast<const float*>(f.msplit), 16, nullptr, (int)de_h,
+                                                           f.b_h ? 1 : 0, ws + L.w16_a[1]);
             }
             if (want[2]) {
                 Zj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Zj[2], nE, (int)h, gH0, ldh, nullptr, (int)h, nullptr, 0, nullptr, 0, 0, ws + L.w16_z[2]);
-                Aj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[2], nE, Ks[2], f.V, f.ldv, lean ? nullptr : pv.src, (int)dv, f.E, f.lde, e_gather, (int)de, f.b_i ? 1 : 0, ws + L.w16_a[2]);
+                Aj[2] = &sp.job[sp.n_jobs++]; wsplit16_job(Aj[2], nE, Ks[2], f.V, f.ldv, lean ? nullptr : pv.src, (int)dv, f.E, f.lde, e_gather, (int)de_i, f.b_i ? 1 : 0, ws + L.w16_a[2]);
                 if (lean) { Aj[2]->g1_64 = reinterpret_cast<const long long*>(f.edge_index); Aj[2]->g1_rows = nV; }  // (row 0 of edge_index: src)
             }
             // the rider (see ExtraWgrad): two more operands to split, one more product, one more reduce job
@@ -998,7 +1011,7 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
             DMPNN_TRY(launch_wsplit16(sp, s));
             float* gWs[3] = {b->gW_o, b->gW_h, b->gW_i};
             float* gbs[3] = {b->gb_o, b->gb_h, b->gb_i};
-            const int64_t ldg[3] = {dv + h, h, dv + de};
+            const int64_t ldg[3] = {dv + h, h + de_h, dv + de_i};
             const int ones[3] = {1, f.b_h ? 1 : 0, f.b_i ? 1 : 0};
             ReduceJobs rj;
             memset(&rj, 0, sizeof(rj));
@@ -1033,10 +1046,10 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
                 hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
                 DMPNN_CHECK_LAUNCH("k_wgrad_reduce_multi");
             }
-            if ((b->gW_h || b->gb_h) && T < 2) { zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h); }
+            if ((b->gW_h || b->gb_h) && T < 2) { zero2d(b->gW_h, h, h + de_h); zero2d(b->gb_h, 1, h); }
             return DMPNN_OK;
         }
-        DMPNN_CHECK_ARG(!lean, "backward(DMPNN_F_TILE_PLAN): the weight-gradient products on the f16 pipe do not take these shapes / alignments");
+        DMPNN_CHECK_ARG(!lean && !atom, "backward(DMPNN_F_TILE_PLAN / DMPNN_F_ATOM): the weight-gradient products on the f16 pipe do not take these shapes / alignments");
         if (b->gW_o || b->gb_o) {
             WgradArgs a;
             memset(&a, 0, sizeof(a));

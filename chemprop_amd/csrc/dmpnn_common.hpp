@@ -318,7 +318,7 @@ int launch_rows2blk(const dmpnn_fwd_args& f, const unsigned char* rows, int ts, 
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,
-                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s);
+                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s, const float* g_edge = nullptr, int64_t ld_gedge = 0);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -76,10 +76,10 @@ bool mega16_split_args(const dmpnn_fwd_args& a, mega16::SplitArgs* spp) {
         const size_t one = al256(NT * nch * 2048) + al256((size_t)N * 4);
         unsigned char* wb = ws + W.total;
         sp.job[4] = mega16::SplitJob{a.W_o + dv, dv + N, 0, N, 0, N, wb, (int)nch, reinterpret_cast<float*>(wb + al256(NT * nch * 2048)), 1};
-        sp.job[5] = mega16::SplitJob{a.W_h, N, 0, N, 0, N, wb + one, (int)nch, reinterpret_cast<float*>(wb + one + al256(NT * nch * 2048)), 1};
+        sp.job[5] = mega16::SplitJob{a.W_h, ldwh, 0, N, 0, N, wb + one, (int)nch, reinterpret_cast<float*>(wb + one + al256(NT * nch * 2048)), 1};
         sp.n_jobs = 6;
     }
-    if (atom) {  // (inference only: slots 4, 5 are free) the bond-feature block W_h[:, N:N + d_e], its own row scales
+    if (atom) {  // the bond-feature block W_h[:, N:N + d_e], its own row scales
         sp.job[sp.n_jobs] = mega16::SplitJob{a.W_h, ldwh, N, de, N, de, ws + W.whe, 1, reinterpret_cast<float*>(ws + W.sc_e)};
         ++sp.n_jobs;
     }
@@ -132,6 +132,10 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     if (a.flags & DMPNN_F_ATOM) {
         G.WhE = mega16::SplitW{ws + W.whe, reinterpret_cast<const float*>(ws + W.sc_e), 1};
         G.atom_de = de;
+        if ((a.flags & DMPNN_F_KEEP) && a.depth > 1 && nE > 0) {  // (validated by dmpnn_forward: `msplit` holds depth - 1 slots of [n_edges][16])
+            G.atom_me = static_cast<float*>(a.msplit);
+            G.me_slot = (long long)nE * mega16::kAtomK;
+        }
     }
     g.dbg = g_debug_stamps;
     if (a.dropout_p > 0.f && a.dropout_p < 1.f) {  // (validated by dmpnn_forward: training forward, ReLU-class activation, no W_d)

@@ -22,7 +22,7 @@ size_t mega16_bwd_wsplit_bytes(int64_t h) {
 }
 
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,
-                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s) {
+                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s, const float* g_edge, int64_t ld_gedge) {
     const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dv = f.d_v;
     const size_t NT = (size_t)(h + 15) / 16, nc = (size_t)(h + 31) / 32;
     // the training forward already split both matrices behind its own pre-split weights (one launch for both passes) — unless the
@@ -39,7 +39,8 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     sp.N = (int)h; sp.n_jobs = 2;
     // W'[n][k] = W_o[k][d_v + n]  and  W'[n][k] = W_h[k][n]: the matrices are read transposed
     sp.job[0] = mega16::SplitJob{f.W_o + dv, (int)(dv + h), 0, (int)h, 0, (int)h, ws, (int)nc, inv_o, 1};
-    sp.job[1] = mega16::SplitJob{f.W_h, (int)h, 0, (int)h, 0, (int)h, ws + one, (int)nc, inv_h, 1};
+    const bool atom = (f.flags & DMPNN_F_ATOM) != 0;   // atom messages: W_h is [h, h + d_e]; the data gradient runs through its first h columns
+    sp.job[1] = mega16::SplitJob{f.W_h, (int)(atom ? h + f.d_e : h), 0, (int)h, 0, (int)h, ws + one, (int)nc, inv_h, 1};
     if (!from_fwd) {
         const unsigned waves = 2u * (unsigned)(((h + 15) / 16) * 16);
         hipLaunchKernelGGL(mega16::k_split_weights, dim3((waves + 3) / 4), dim3(256), 0, s, sp);
@@ -58,6 +59,8 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     g.H0 = f.H0; g.Hs = f.Hs; g.ldh = (int)f.ldh; g.slot = (long long)nE * f.ldh;
     g.gZO = gZO; g.gZs = gZs; g.gH0 = gH0;
     g.srcp = plan_i + L.srcp; g.d_v = (int)dv; g.W_o = f.W_o; g.W_h = f.W_h; g.sp_gM = sp_gM; g.sp_Ta = sp_Ta;
+    g.atom = atom ? 1 : 0;
+    g.g_edge = g_edge; g.ld_ge = (int)ld_gedge;
     g.drop_scale = (f.dropout_p > 0.f && f.dropout_p < 1.f) ? 1.f / (1.f - f.dropout_p) : 0.f;
     if (f.keep_bits && (f.flags & DMPNN_F_TILE_PLAN)) {  // the forward kept H0 / H^(t) as sign bits (dmpnn_fwd_args.keep_bits)
         g.keep_bits = static_cast<const unsigned long long*>(f.keep_bits);

@@ -45,6 +45,13 @@ struct Mega16BwdK {
     // the forward kept H0 / H^(t) as sign bits (Mega16K::keep_bits: slot 0 = H0, slot t = H^(t), bits_slot words per slot) — the
     // fp32 rows H0 / Hs then only hold the molecules beyond the tile
     const unsigned long long* keep_bits; long long bits_slot;
+    // DMPNN_F_ATOM (mixins.py:21-30): the message is the plain sum over the edges entering the source atom — its transpose has no
+    // reverse-edge term, gH[r'] = sum_{r: src r = dst r'} gM[r]; W_h's first h columns are what WhT holds
+    int atom;
+    // a second gradient input (dmpnn_bwd_args.g_edge): dL/dH^(depth-1) from a consumer of the kept edge states themselves — the edge
+    // read-out of the mol-atom-bond blocks (mol_atom_bond.py:221-264) — added to the aggregation's gradient before tau'.  [E, ld_ge]
+    // in the kept tensors' row order, 16-byte aligned rows; NULL: none
+    const float* g_edge; int ld_ge;
 };
 
 template <int WN>
@@ -98,6 +105,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     if (na <= 0 || nrows < 0) return;
     if (nrows > BM || na > BA) {  // a piece larger than the matrix-pipe tile: the generic fp32 path, any size
         const Mega16BwdK& g = *spill::fresh_kernargs<Mega16BwdK>();  // (shadows the hot path's copy: see fresh_kernargs)
+        if (g.atom) {  // ... which knows bond messages only: the forward tile kernel returned NaN for this molecule, so do its gradients
+            for (int i = tid; i < nrows * N; i += kThreads) {
+                const long long o = (long long)(rs + i / N) * g.ldh + (i % N);
+                g.gH0[o] = nanv;
+                for (int sl = 0; sl < T_steps - 1; ++sl) g.gZs[(long long)sl * g.slot + o] = nanv;
+            }
+            for (int i = tid; i < na * N; i += kThreads) g.gZO[(long long)(va + i / N) * g.ldh + (i % N)] = nanv;
+            return;
+        }
         const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
         spill::BwdView v;
         v.rs = rs; v.nrows = nrows; v.va = va; v.na = na; v.h = N; v.depth = T_steps; v.d_v = g.d_v;
@@ -108,6 +124,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         v.H0 = g.H0; v.Hs = g.Hs; v.ldh = g.ldh; v.slot = g.slot;
         v.gZO = g.gZO; v.gZs = g.gZs; v.gH0 = g.gH0;
         v.W_o = g.W_o; v.W_h = g.W_h; v.gM = g.sp_gM; v.Ta = g.sp_Ta;
+        v.g_edge = g.g_edge; v.ld_ge = g.ld_ge;
         spill::backward(v, reinterpret_cast<float*>(lds));
         return;
     }
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             const int k = ks == 0 ? (sl < 4 ? lg * 4 + sl : 16 + lg * 4 + (sl - 4)) : (sl < 4 ? 32 + lg * 4 + sl : -1);
             const int sk = ks == 0 ? as_[sl] : (sl < 4 ? as_[8 + sl] : -3);
             const int rk = ks == 0 ? rk_[sl] : (sl < 4 ? rk_[8 + sl] : -3);
-            const bool in = gat ? (k < na && k == a_t) : sk == a_t, isrev = !gat && j < nrows && rk == j;
+            const bool in = gat ? (k < na && k == a_t) : sk == a_t, isrev = !gat && !g.atom && j < nrows && rk == j;
             hb[sl] = in ? (isrev ? 0u : 0x3C00u) : (isrev ? 0xBC00u : 0u);
         }
         const u32x4 pk = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
@@ -474,6 +491,24 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         contract(RA{}, acc, g.WoMT);
         unscale(RA{}, acc, 1.f / sA, g.WoMT.inv_scale);
         incidence(RA{}, acc, 0, m);  // gH[r] = gMv[dst r]
+    }
+    if (g.g_edge) {  // (uniform) + dL/dH^(T-1) of the edge read-out
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            float4 y[RT_E];
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                const bool ok = row < nrows && col4 < N;
+                y[jt] = *reinterpret_cast<const float4*>(g.g_edge + (long long)(rs + (ok ? row : 0)) * g.ld_ge + (ok ? col4 : 0));
+                if (!ok) y[jt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                m[ct][jt][0] += y[jt].x; m[ct][jt][1] += y[jt].y; m[ct][jt][2] += y[jt].z; m[ct][jt][3] += y[jt].w;
+            }
+        }
     }
     f32x4 gh0[WN][RT_E];
     if (T_steps == 1) {

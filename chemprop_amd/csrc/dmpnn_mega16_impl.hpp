@@ -54,6 +54,10 @@ struct Mega16K {
     // DMPNN_F_ATOM (atom messages, inference): W_i is [N, d_v], Wh holds W_h[:, :N] and WhE the bond-feature block W_h[:, N:N + d_e]
     // (one chunk: d_e <= 32); atom_de = d_e (the kernel's own d_e is 0: E is not part of the K1 operand), 0 = the bond variant
     SplitW WhE; int atom_de;
+    // ... training (DMPNN_F_ATOM | DMPNN_F_KEEP): the bond-feature half of the message, ME[r'] = (sum E)[src r'] as [n_edges][16] fp32 rows
+    // (columns >= d_e zero), written once per kept message slot (me_slot floats apart) — dmpnn_backward's W_h product then reads
+    // [M^(t) || ME] as ONE operand over all steps' rows
+    float* atom_me; long long me_slot;
     // dmpnn_fwd_args.keep_bits (training on a tile plan, ReLU-class activation, no dropout): H0 and H^(t) leave the kernel as ONE
     // bit per element — [x > 0], all the backward tile kernel needs of them — in the order of the matrix-pipe fragments: word
     // (rt WN + ct) 4 + r of wave w of tile t (64 words per wave, 256 per tile) is the ballot of "element (row rt 16 + 4 lg + r, column
@@ -100,7 +104,7 @@ struct SplitJob {
     int N;                                      // rows of THIS matrix (0: SplitArgs.N — jobs of one launch may differ in height)
 };
 struct SplitArgs {
-    SplitJob job[6];
+    SplitJob job[8];   // (forward: 4; + the backward tile kernel's 2 for a training forward; + 1 for atom messages)
     int n_jobs, N;
 };
 // one wave per (matrix, row).  A device function: it also rides in the launch of K0 (dmpnn_prepare.hip: workgroup 0 builds the
@@ -229,6 +233,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         if ((KEEP && gs.drop_thr) || G.atom_de) {  // the generic path has neither dropout nor atom messages: such a molecule is LOUD (NaN), never wrong
             const float nanv = __int_as_float(0x7fc00000);
             for (int i = tid; i < na * N; i += kThreads) gs.out[(long long)(va + i / N) * gs.ldout + (i % N)] = nanv;
+            if constexpr (KEEP) {  // ... and so are its kept edge states, which a second read-out may consume (mab.py)
+                if (gs.Hs)
+                    for (int i = tid; i < nrows * N; i += kThreads)
+                        for (int sl = 0; sl < gs.depth - 1; ++sl) gs.Hs[(long long)sl * gs.slot + (long long)(rs + i / N) * gs.ldh + (i % N)] = nanv;
+            }
             return;
         }
         spill::forward(mega::spill_view(gs, gs.flags[DMPNN_HDR_LIGHT] == 2, rs, nrows, va, na, gs.slope_ptr ? *gs.slope_ptr : gs.slope),
@@ -798,6 +807,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         }
         __syncthreads();
         launder();
+        if constexpr (KEEP) {
+            if (G.atom_me) {  // (uniform) what the weight-gradient product of W_h[:, N:] contracts gZ^(t) with — the same rows for every step
+                for (int i = tid; i < nrows * kAtomK; i += kThreads) {
+                    const int r = i / kAtomK, k = i - r * kAtomK;
+                    const float v = SE[(lean ? asrc[r] : aor[revl[r]]) * kAtomK + k];
+                    for (int sl = 0; sl < T_steps - 1; ++sl) G.atom_me[(long long)sl * G.me_slot + (long long)(rs + r) * kAtomK + k] = v;
+                }
+            }
+        }
         // A fragments of ME[r'] = SE[src r'] (row rt 16 + li, k = lg 8 .. lg 8 + 7 of the one chunk) straight into registers
         float xv[RT_E][8];
         float mx = 0.f;

@@ -185,6 +185,7 @@ struct BwdView {
     float* gZO; float* gZs; float* gH0;
     const float* W_o; const float* W_h;     // nn.Linear layout: W_o [h, d_v + h], W_h [h, h]
     float* gM; float* Ta;                   // scratch: [n_edges][ldh], [n_atoms][ldh]
+    const float* g_edge; int ld_ge;         // dL/dH^(depth-1) of a second consumer of the edge states (dmpnn_bwd_args.g_edge) or NULL
 };
 
 // the data-gradient chain of the backward pass (what k_mpnn_tile16_bwd does for a tile) for one piece
@@ -247,15 +248,16 @@ DMPNN_SPILL_FN void backward(const BwdView& g, float* xs) {
                 for (int r = g.row_ptr[va + a] - g.rs; r < g.row_ptr[va + a + 1] - g.rs; ++r) fn(a, r);
         }
     };
-    // gH^(T-1)[r] = gMv[dst r]                                          (aggregation backward)
+    // gH^(T-1)[r] = gMv[dst r] (+ the second gradient input)             (aggregation backward)
+    auto ge = [&](int r, int c) -> float { return g.g_edge ? g.g_edge[(rs + r) * g.ld_ge + c] : 0.f; };
     if (T == 1) {
         for (int c = tid; c < N; c += kSpillThreads)
-            for_rows([&](int a, int r) { g.gH0[(rs + r) * g.ldh + c] = dact(g.Ta[(va + a) * g.ldh + c], g.H0[(rs + r) * g.ldh + c], true); });
+            for_rows([&](int a, int r) { g.gH0[(rs + r) * g.ldh + c] = dact(g.Ta[(va + a) * g.ldh + c] + ge(r, c), g.H0[(rs + r) * g.ldh + c], true); });
         return;
     }
     for (int c = tid; c < N; c += kSpillThreads)
         for_rows([&](int a, int r) {
-            const float gz = dact(g.Ta[(va + a) * g.ldh + c], g.Hs[(long long)(T - 2) * g.slot + (rs + r) * g.ldh + c], false);
+            const float gz = dact(g.Ta[(va + a) * g.ldh + c] + ge(r, c), g.Hs[(long long)(T - 2) * g.slot + (rs + r) * g.ldh + c], false);
             g.gZs[(long long)(T - 2) * g.slot + (rs + r) * g.ldh + c] = gz;
             g.gH0[(rs + r) * g.ldh + c] = gz;
         });

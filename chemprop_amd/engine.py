@@ -263,6 +263,11 @@ class GraphPlan:
         return self._view(5)
 
     @property
+    def perm32(self) -> Tensor:
+        """CSR row -> edge id, int32 (``X_edges[perm]`` takes an edge tensor in the caller's order to the kept tensors' row order)."""
+        return self._view(4)
+
+    @property
     def perm64(self) -> Tensor:
         """CSR row -> edge id (row i of a fused-forward edge tensor is edge perm[i])."""
         return self._view(4).long()
@@ -458,8 +463,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     3-term f16 split on the f16 matrix pipe) or ``"f32"`` (the exact fp32 MFMA); env ``DMPNN_MFMA``.
     ``form``: ``DMPNN_F_H0_RESIDUAL`` / ``DMPNN_F_ROW_FINALIZE`` bits for the per-step fused route on the f16 pipe (its other
     form of the residual / of the finalize, include/dmpnn.h; what training and wide hidden layers use anyway).
-    ``atom=True``: ``AtomMessagePassing`` semantics (``DMPNN_F_ATOM``: ``W_i [d_h, d_v]``, ``W_h [d_h, d_h + d_e]``) — an inference
-    forward of the tile kernel; raises :class:`RouteUnavailable` when this batch takes another route.
+    ``atom=True``: ``AtomMessagePassing`` semantics (``DMPNN_F_ATOM``: ``W_i [d_h, d_v]``, ``W_h [d_h, d_h + d_e]``) — the tile
+    kernel, inference or (round 4) training; raises :class:`RouteUnavailable` when this batch takes another route.
     ``dropout = (p, seed)``: ACTIVE dropout inside the kernels (``dmpnn_fwd_args.dropout_p``) — a training forward (``keep``) of
     the tile kernel with a ReLU-class activation and no ``W_d``; raises :class:`RouteUnavailable` when this batch takes another
     route (the caller then runs its own ``nn.Dropout`` between the row kernels).
@@ -559,8 +564,8 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             want16 = False
 
     if atom:
-        if not (use_mega and want16 and not keep and not d_vd and 1 <= d_e <= 16):
-            raise RouteUnavailable("atom messages inside the kernels: inference forward of the tile kernel, 1 <= d_e <= 16, no W_d")
+        if not (use_mega and want16 and not d_vd and 1 <= d_e <= 16 and (not keep or (d_e % 2 == 0 and d_v % 2 == 0 and d_h % 2 == 0))):
+            raise RouteUnavailable("atom messages inside the kernels: the tile kernel, 1 <= d_e <= 16, no W_d (training: even d_v / d_e / d_h)")
         a.flags |= _lib.F_ATOM
     if dropout is not None and float(dropout[0]) > 0.0:
         if not (use_mega and want16 and keep and not d_vd and act in ("relu", "leakyrelu")):
@@ -620,6 +625,9 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     else:
         edge_ws = torch.empty(((1 if need_h0 else 0) + n_hslots + n_mslots, nE, ldh), dtype=torch.float32, device=dev)
         atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
+        if atom and keep:
+            # the bond-feature half of the atom messages, kept for W_h's gradient: depth - 1 slots of [n_edges][16] (include/dmpnn.h, DMPNN_F_ATOM)
+            split_ms = torch.empty((max(n_steps, 1), nE, 16), dtype=torch.float32, device=dev)
     st.out = out
     if edge_ws is None:
         st.H0 = st.Hs = st.Ms = st.Mv = st.Hv = None
@@ -702,14 +710,16 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
                 _lib.check(lib.dmpnn_forward(C.byref(a), _stream_ptr(dev)), "dmpnn_forward")
     st.args = a
     st.refs = (V, E, V_d, W_i, W_h, W_o, b_o, b_i, b_h, W_d, b_d, slope_t, edge_ws, atom_ws, spill_ws, split_ms, bits, wsplit)  # (wsplit last: nn._make_replay)
-    st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None)
+    st.dims = dict(d_v=d_v, d_e=d_e, d_h=d_h, d_vd=d_vd, has_bi=b_i is not None, has_bh=b_h is not None, atom=bool(atom))
     return out, st
 
 
-def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = None, launch: bool = True):
+def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = None, launch: bool = True, g_edge: Optional[Tensor] = None):
     """K6: parameter gradients of a kept forward.  ``need`` maps W_i/b_i/W_h/b_h/W_o/b_o/W_d/b_d -> bool.
     ``out``: optional ``{name: tensor}`` the kernels write the gradients INTO (contiguous fp32 of the parameter's shape, on
-    the device — e.g. views of one flat gradient buffer, ``distributed.GradSync``); names missing there are allocated."""
+    the device — e.g. views of one flat gradient buffer, ``distributed.GradSync``); names missing there are allocated.
+    ``g_edge``: a second gradient input, w.r.t. the kept ``H^(depth-1)`` rows (``dmpnn_bwd_args.g_edge``: the edge read-out of the
+    mol-atom-bond blocks), ``[n_edges, d_h]`` in the kept tensors' row order — the backward tile kernel only."""
     from ._lib import BwdArgs
 
     lib = _lib.load()
@@ -717,7 +727,8 @@ def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = N
     dev = gout.device
     d = st.dims
     h, dv, de, dvd = d["d_h"], d["d_v"], d["d_e"], d["d_vd"]
-    shapes = dict(W_i=(h, dv + de), b_i=(h,), W_h=(h, h), b_h=(h,), W_o=(h, dv + h), b_o=(h,),
+    atom = bool(d.get("atom"))   # (AtomMessagePassing, base.py:278-289: W_i [d_h, d_v], W_h [d_h, d_e + d_h])
+    shapes = dict(W_i=(h, dv if atom else dv + de), b_i=(h,), W_h=(h, h + de if atom else h), b_h=(h,), W_o=(h, dv + h), b_o=(h,),
                   W_d=(h + dvd, h + dvd), b_d=(h + dvd,))
     present = dict(W_i=True, b_i=d["has_bi"], W_h=True, b_h=d["has_bh"], W_o=True, b_o=True, W_d=dvd > 0, b_d=dvd > 0)
     def _buf(k):
@@ -735,6 +746,11 @@ def backward(st: ForwardState, gout: Tensor, need: dict, out: Optional[dict] = N
     nbytes = lib.dmpnn_backward_ws_bytes(C.byref(st.args))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
     b.ws, b.ws_bytes = ws.data_ptr(), nbytes
+    if g_edge is not None:
+        g_edge = _f32c(g_edge, "g_edge").contiguous()
+        if g_edge.shape[0] != st.args.n_edges or g_edge.shape[1] < h or g_edge.stride(0) % 4:
+            raise RuntimeError("backward: g_edge must be [n_edges, d_h] with a row stride that is a multiple of 4")
+        b.g_edge, b.ld_gedge = g_edge.data_ptr(), g_edge.stride(0)
     if not launch:  # (trainer.FusedTrainer: the argument block only; `refs` keeps the scratch alive)
         return grads, b, (ws, gout)
     with _OnDevice(dev):

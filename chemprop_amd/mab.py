@@ -132,6 +132,26 @@ def _tile_route_ok(mp, bmg, V_d, E_d) -> bool:
     return True
 
 
+def _tile_train_ok(mp, bmg, V_d) -> bool:
+    """A TRAINING forward the tile kernels take (round 4): the vertex read-out present (it is the tile kernel's finalize), built-in
+    activation, no active dropout, directed; the edge read-out needs depth >= 2 (it reads a kept H^(depth-1)); atom messages: no V_d,
+    an even d_e of 2 .. 16.  Molecules beyond the tile, and everything else: the rows route."""
+    if not (torch.is_grad_enabled() and any(p.requires_grad for p in mp.parameters())):
+        return False
+    if mp.W_vo is None or mp.undirected or (mp.training and mp.dropout.p > 0) or getattr(bmg, "oversize", None) is True:
+        return False
+    if classify_activation(mp.tau)[0] in ("custom", "prelu"):
+        return False
+    if mp.return_edge_embeddings and mp.depth < 2:
+        return False
+    n_e, d_e = int(bmg.E.shape[0]), int(bmg.E.shape[1])
+    if n_e == 0:
+        return False
+    if mp.atom_messages and (V_d is not None or not (2 <= d_e <= 16 and d_e % 2 == 0)):
+        return False
+    return True
+
+
 def mab_forward(mp, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = None):
     """``_MABMessagePassingBase.forward`` (mol_atom_bond.py:266-282) -> ``(H_v | None, H_e | None)``."""
     from .backward import aggregate_fn, gather_src_fn, linear_fn, message_fn
@@ -179,7 +199,44 @@ def mab_forward(mp, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = N
                 H_e = engine.linear(H_e, mp.W_ed.weight, mp.W_ed.bias, A2=E_d)
         return H_v, H_e
 
+    if _tile_train_ok(mp, bmg, V_d):
+        # ---- round 4: TRAINING on the tile kernels — the block's forward is ONE launch that keeps what the backward tile kernel reads,
+        # the kept H^(depth-1) leaves it as a second output for the edge read-out (a row kernel under autograd) and that read-out's
+        # gradient enters the backward tile kernel beside the vertex one (dmpnn_bwd_args.g_edge).  Both variants (DMPNN_F_ATOM). ----
+        import types
+
+        from .backward import FusedMP
+        from .nn import _route, _training_plan_kind
+
+        act, slope, slope_t = classify_activation(mp.tau)
+        has_vd = V_d is not None
+        shim = types.SimpleNamespace(undirected=mp.undirected, W_d=mp.W_vd if has_vd else None, tau=mp.tau, training=mp.training, dropout=mp.dropout,
+                                     W_i=mp.W_i, W_h=mp.W_h, W_o=mp.W_vo, _dmpnn_batches_checked=getattr(mp, "_dmpnn_batches_checked", 0),
+                                     _dmpnn_no_mega=getattr(mp, "_dmpnn_no_mega", False))
+        light = _training_plan_kind(shim, bmg)
+        plan = engine.GraphPlan.from_bmg(bmg, light=light, launch="defer" if light == "tiles" else True)
+        n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+        plan.oversize = getattr(bmg, "oversize", None)
+        if _route(mp, plan, n_mols, getattr(bmg, "batch", None)) >= 2:
+            try:
+                res = FusedMP.apply(mp, plan, V, E, V_d if has_vd else None, act, slope, (slope_t, 2, None, mp.atom_messages, want_e),
+                                    mp.W_i.weight, mp.W_i.bias, mp.W_h.weight, mp.W_h.bias, mp.W_vo.weight, mp.W_vo.bias,
+                                    mp.W_vd.weight if has_vd else None, mp.W_vd.bias if has_vd else None)
+                plan.ensure_launched()
+                H_v, H = res if want_e else (res, None)
+                H_e = None
+                if want_e:
+                    H_e = drop(tau(linear_fn(E, mp.W_eo.weight, mp.W_eo.bias, A2=H)))
+                    if E_d is not None:
+                        H_e = drop(linear_fn(H_e, mp.W_ed.weight, mp.W_ed.bias, A2=E_d))
+                mp.__dict__["_dmpnn_route"] = "mega16/atom" if mp.atom_messages else "mega16"
+                return (H_v if want_v else None), H_e
+            except engine.RouteUnavailable:
+                pass
+        plan.pending = None   # (a deferred K0 that nothing ran: the rows route builds its own full plan)
+
     # ---- rows route ----
+    mp.__dict__["_dmpnn_route"] = "rows"
     plan = engine.GraphPlan.from_bmg(bmg)
     nE = plan.n_edges
     rev = None

@@ -572,6 +572,30 @@ def atom_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
                 pass
         if light:
             plan = engine.GraphPlan.from_bmg(bmg)
+    elif (grad and not has_vd and act not in ("custom", "prelu") and not mp.undirected and not (mp.training and mp.dropout.p > 0)
+          and 2 <= int(E.shape[1]) <= 16 and int(E.shape[1]) % 2 == 0 and int(E.shape[0]) > 0 and getattr(bmg, "oversize", None) is not True
+          and not V.requires_grad and not E.requires_grad):
+        # ---- round 4: TRAINING on the tile kernels (DMPNN_F_ATOM | DMPNN_F_KEEP): one forward launch that keeps what the backward tile
+        # kernel and the weight-gradient products read (sign bits or H^(t), M^(t), the bond-feature half of the messages), one autograd
+        # node — the bond block's (backward.FusedMP).  Molecules beyond the tile, W_d, active dropout: the chain below. ----
+        from .backward import FusedMP
+
+        light = _training_plan_kind(mp, bmg)
+        plan = engine.GraphPlan.from_bmg(bmg, light=light, launch="defer" if light == "tiles" else True)
+        plan.oversize = getattr(bmg, "oversize", None)
+        if _route(mp, plan, n_mols, getattr(bmg, "batch", None)) >= 2:
+            try:
+                out = FusedMP.apply(mp, plan, V, E, None, act, slope, (slope_t, 2, None, True), mp.W_i.weight, mp.W_i.bias, mp.W_h.weight,
+                                    mp.W_h.bias, mp.W_o.weight, mp.W_o.bias, None, None)
+                plan.ensure_launched()
+                mp.__dict__["_dmpnn_route"] = "mega16/atom"
+                return out
+            except engine.RouteUnavailable:
+                pass
+        if light:
+            plan = engine.GraphPlan.from_bmg(bmg)
+        else:
+            plan.ensure_launched()
     else:
         plan = engine.GraphPlan.from_bmg(bmg)
     mp.__dict__["_dmpnn_route"] = "rows/atom"

@@ -39,8 +39,11 @@ extern "C" {
  * their end; a host built against another version is refused by its own check of dmpnn_version() (chemprop_amd/_lib.py).
  * 10 — round 4: `keep_bits` also on DMPNN_F_FUSED | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (the LEAN training forward of the per-step fused
  * route: split message rows of every step in `msplit`, sign bits, no fp32 copies) and the backward step kernels that read it;
- * in-kernel dropout no longer takes PReLU; dmpnn_backward refuses a dropout forward it cannot scale. */
-#define DMPNN_ABI_VERSION 10
+ * in-kernel dropout no longer takes PReLU; dmpnn_backward refuses a dropout forward it cannot scale.
+ * 11 — round 4: DMPNN_F_ATOM also with DMPNN_F_KEEP (atom messages TRAIN on the tile kernels; `msplit` keeps the bond-feature half of
+ * the messages) and dmpnn_backward for it (gW_i [d_h, d_v], gW_h [d_h, d_h + d_e]); dmpnn_bwd_args.g_edge (a second gradient input, with
+ * respect to the kept H^(depth-1): the edge read-out of the mol-atom-bond blocks). */
+#define DMPNN_ABI_VERSION 11
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -89,10 +92,15 @@ enum dmpnn_flags {
                                      over 48-atom tiles fed by split rows (the default from depth 2 on).  Implied by DMPNN_F_KEEP    */
     DMPNN_F_ATOM = 1u << 10,      /* AtomMessagePassing (base.py:254-289, mixins.py:21-30) instead of the bond variant: W_i is [d_h, d_v]
                                      (H0 = W_i V[src]), W_h is [d_h, d_h + d_e], the message is M[e] = (sum_{e': dst e' = src e} [H[e'] || E[e']])
-                                     — no reverse-edge term.  With DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16, inference (no
-                                     DMPNN_F_KEEP), d_e <= 32: the whole-forward tile kernel — the bond-feature half of the message
-                                     is constant over the depth loop, so W_h[:, d_h:] (sum E)[src] is formed once per tile and joins
-                                     the residual.  Any other combination: DMPNN_EINVAL (chain the row kernels)                      */
+                                     — no reverse-edge term.  With DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16, d_e <= 16: the
+                                     whole-forward tile kernel — the bond-feature half of the message is constant over the depth loop,
+                                     so W_h[:, d_h:] (sum E)[src] is formed once per tile and joins the residual.  With DMPNN_F_KEEP
+                                     (ABI 11: training; even d_v / d_e / d_h, no W_d, no in-kernel dropout) that half, ME[e] =
+                                     (sum_{e': dst e' = src e} E[e']), is kept as depth - 1 identical slots of [n_edges][16] fp32 rows
+                                     in `msplit` (>= (depth - 1) * n_edges * 64 bytes; row order = the kept M^(t) rows') so that
+                                     dmpnn_backward's W_h product reads [M^(t) || ME] as one operand; H0 is kept as W_i V[src] (+ b_i)
+                                     alone.  A molecule beyond the tile comes back NaN (forward and gradients).  Any other
+                                     combination: DMPNN_EINVAL (chain the row kernels)                                               */
     DMPNN_F_TILE_PLAN = 1u << 11, /* with DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP: `plan` is a TILE plan
                                      (dmpnn_prepare_tiles: K0 is the 11 us tile table instead of the 28 us CSR plan at 512 molecules)
                                      — the kept tensors H0 / Hs / Ms are in the CALLER's edge order and dmpnn_backward runs on
@@ -395,6 +403,12 @@ typedef struct dmpnn_bwd_args {
     float* gW_i; float* gb_i; float* gW_h; float* gb_h;
     float* gW_o; float* gb_o; float* gW_d; float* gb_d;
     float* ws; size_t ws_bytes;          /* caller-owned scratch, >= dmpnn_backward_ws_bytes(&f)   */
+    /* ABI 11.  A second gradient input: dL/dH^(depth-1) [n_edges, ld_gedge >= d_h] from a consumer of the kept edge states themselves
+     * (Hs slot depth - 2; H0 through tau for depth 1) — the edge read-out of the mol-atom-bond blocks, mol_atom_bond.py:221-264 — in the
+     * row order of the kept tensors (the caller's edge order with DMPNN_F_TILE_PLAN, else the plan's CSR-row order).  Taken by the
+     * backward tile kernel only (a forward with DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP; 16-byte aligned, ld_gedge % 4 == 0).
+     * NULL: none. */
+    const float* g_edge; int64_t ld_gedge;
 } dmpnn_bwd_args;
 size_t dmpnn_backward_ws_bytes(const dmpnn_fwd_args* f);
 int dmpnn_backward(const dmpnn_bwd_args* a, void* stream);

@@ -195,3 +195,102 @@ def test_inference_with_an_oversize_molecule_is_routed_not_poisoned(gpu_device):
         for i in range(3):
             for got, want in zip(mp2(bare), ref):
                 assert torch.isfinite(got).all() and parity_err(got.cpu().numpy(), want.numpy()) <= TOL, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("atom,n_mols,kw", [
+    (False, 512, dict()), (True, 512, dict()),
+    (False, 300, dict(activation="elu", bias=True, depth=4, d_h=128)), (True, 300, dict(activation="tanh", bias=True, depth=2, d_h=64)),
+    (False, 200, dict(activation="tanh", d_vd=3, d_ed=2)),                  # descriptors: W_vd inside the block's chain, W_ed behind the read-out
+    (True, 200, dict(activation="elu", return_edge_embeddings=False)),     # vertex read-out only: the atom block itself
+], ids=["bond-512-relu", "atom-512-relu", "bond-300-elu-d4-h128", "atom-300-tanh-d2-h64", "bond-200-vd-ed", "atom-200-vertex-only"])
+def test_training_on_the_tile_kernels(atom, n_mols, kw, gpu_device, monkeypatch):
+    """Round 4 (round-3 VERDICT item 8): a TRAINING step of the mol-atom-bond blocks on the tile kernels.  The block's forward is one
+    launch (DMPNN_F_KEEP; DMPNN_F_ATOM for the atom variant); the kept H^(depth-1) is its second output, the edge read-out a row
+    kernel under autograd, and that read-out's gradient enters the backward tile kernel beside the vertex one
+    (dmpnn_bwd_args.g_edge).  Both read-outs and every gradient against the oracle's autograd (mol_atom_bond.py:266-282), on the
+    tile plan (caller's edge order) and on the full plan (CSR-row order: the edge states are permuted on the way out and back)."""
+    from chemprop_amd import synth
+    from chemprop_amd.mab import MABAtomMessagePassing, MABBondMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    monkeypatch.setenv("DMPNN_VALIDATE", "never")
+    cls = MABAtomMessagePassing if atom else MABBondMessagePassing
+    bmg = synth.random_batch(n_mols, "qm9", seed=14)
+    torch.manual_seed(9)
+    ref_mp = cls(**kw)
+    nV, nE = bmg.V.shape[0], bmg.E.shape[0]
+    gen = torch.Generator().manual_seed(3)
+    V_d = torch.randn(nV, kw["d_vd"], generator=gen) if kw.get("d_vd") else None
+    E_d = torch.randn(nE, kw["d_ed"], generator=gen) if kw.get("d_ed") else None
+    w = ot.MABWeights.from_state_dict(dict(ref_mp.named_parameters()))
+    ref = ot.mab_forward(bmg.V, bmg.E, bmg.edge_index, bmg.rev_edge_index, w, atom_messages=atom, depth=ref_mp.depth,
+                         activation=kw.get("activation", "relu"), V_d=V_d, E_d=E_d)
+    Gs = [None if r is None else torch.randn(r.shape, generator=gen) for r in ref]
+    sum((r * g).sum() for r, g in zip(ref, Gs) if r is not None).backward()
+    bmg.to(gpu_device)
+    dev = lambda t: None if t is None else t.to(gpu_device)
+    res = {}
+    for plan_kind in ("tiles", "full"):
+        if kw.get("d_vd") and plan_kind == "tiles":
+            continue   # (W_vd inside the block: the full plan only)
+        monkeypatch.setenv("DMPNN_TRAIN_PLAN", plan_kind)
+        mp = cls(**kw)
+        mp.load_state_dict(ref_mp.state_dict())
+        mp = mp.to(gpu_device).train()
+        out = mp(bmg, dev(V_d), dev(E_d))
+        assert mp.__dict__.get("_dmpnn_route") == ("mega16/atom" if atom else "mega16"), (plan_kind, mp.__dict__.get("_dmpnn_route"))
+        for got, want in zip(out, ref):
+            assert (got is None) == (want is None)
+            if got is not None:
+                assert parity_err(got.detach().cpu().numpy(), want.detach().numpy()) <= TOL, plan_kind
+        sum((o * dev(g)).sum() for o, g in zip(out, Gs) if o is not None).backward()
+        res[plan_kind] = {k: p.grad.cpu().numpy() for k, p in mp.named_parameters()}
+        for k, q in ref_mp.named_parameters():
+            err = parity_err(res[plan_kind][k], q.grad.numpy())
+            assert err <= 2e-5, f"{plan_kind} {k}: {err:.3e}"
+    if len(res) == 2:
+        for k in res["full"]:
+            assert parity_err(res["tiles"][k], res["full"][k]) <= 5e-6, k
+
+
+@pytest.mark.gpu
+def test_training_with_an_oversize_molecule_as_bare_tensors(gpu_device, monkeypatch):
+    """A molecule beyond the tile inside a batch of bare tensors (no host-side size knowledge), trusted plan: the bond variant's tile
+    kernels carry it through their generic path — forward, and backward WITH the edge read-out's gradient; the atom variant, whose
+    generic path does not exist, says NaN (loud) instead of a wrong number."""
+    from chemprop_amd import synth
+    from chemprop_amd.data import BatchMolGraph
+    from chemprop_amd.mab import MABAtomMessagePassing, MABBondMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    monkeypatch.setenv("DMPNN_VALIDATE", "never")
+    mgs = synth.random_molgraphs(20, "qm9", seed=4)
+    mgs.insert(7, synth.random_molgraphs(1, "synth40", seed=5)[0])
+    b = BatchMolGraph(mgs)
+    bare = BatchMolGraph.from_tensors(b.V, b.E, b.edge_index, b.rev_edge_index, b.batch, len(mgs))
+    torch.manual_seed(8)
+    ref_mp = MABBondMessagePassing(d_h=64, activation="tanh")
+    w = ot.MABWeights.from_state_dict(dict(ref_mp.named_parameters()))
+    ref = ot.mab_forward(bare.V, bare.E, bare.edge_index, bare.rev_edge_index, w, atom_messages=False, activation="tanh")
+    gen = torch.Generator().manual_seed(1)
+    Gs = [torch.randn(r.shape, generator=gen) for r in ref]
+    sum((r * g).sum() for r, g in zip(ref, Gs)).backward()
+    bare.to(gpu_device)
+    mp = MABBondMessagePassing(d_h=64, activation="tanh")
+    mp.load_state_dict(ref_mp.state_dict())
+    mp = mp.to(gpu_device).train()
+    out = mp(bare)
+    assert mp.__dict__.get("_dmpnn_route") == "mega16"
+    sum((o * g.to(gpu_device)).sum() for o, g in zip(out, Gs)).backward()
+    for got, want in zip(out, ref):
+        assert parity_err(got.detach().cpu().numpy(), want.detach().numpy()) <= TOL
+    for (k, p), (_, q) in zip(mp.named_parameters(), ref_mp.named_parameters()):
+        assert parity_err(p.grad.cpu().numpy(), q.grad.numpy()) <= 2e-5, k
+    mpa = MABAtomMessagePassing(d_h=64, activation="tanh").to(gpu_device).train()
+    H_v, H_e = mpa(bare)
+    assert mpa.__dict__.get("_dmpnn_route") == "mega16/atom"
+    big_atoms = (bare.batch == 7)
+    assert torch.isnan(H_v[big_atoms]).all() and torch.isfinite(H_v[~big_atoms]).all()
+    big_edges = big_atoms[bare.edge_index[0]]
+    assert torch.isnan(H_e[big_edges]).all() and torch.isfinite(H_e[~big_edges]).all()
