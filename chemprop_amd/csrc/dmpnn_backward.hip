@@ -584,6 +584,14 @@ int launch_wgrad_reduce(const float* slab, const WgradPlan& p, int n_slabs, int 
     return DMPNN_OK;
 }
 
+// DMPNN_WGRAD_BLOCKS=1 (A/B measurements): the lean route's products on tile-packed BLOCK operands (k_rows2blk + k_wgrad16t) also
+// where the split-row product (k_wgrad16r) applies
+static int _getenv_blocks() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DMPNN_WGRAD_BLOCKS"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
 struct BwdLayout {
     size_t gZa, gZb, gH0, gZO, gMv, gHO, WhT, WoT, WdT, slab_h, slab_x, total;
     size_t WhT16, WoT16;  // pre-split transposed weights of the data-gradient contractions on the f16 pipe (large batches)
@@ -603,6 +611,10 @@ struct BwdLayout {
     size_t lz, lm, lx, lz_stride, lm_stride;   // gZ blocks of every site | M^(t) blocks | x blocks (float offsets / strides per operand)
     size_t lslab_h, lslab_i;
     WProdTPlan qh, qi;
+    // ... without bias columns (b_i, b_h absent: chemprop's default) the products read SPLIT ROWS (k_wgrad16r): gZ rows written by the step
+    // kernels into the same region, the kept M^(t) / x rows as they are — no block operands at all
+    bool lrows;
+    WProdRPlan rh, ri;
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     BwdLayout L;
@@ -680,18 +692,30 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     }
     L.lean = fused16_lean(f);
     L.lz = L.lm = L.lx = L.lz_stride = L.lm_stride = L.lslab_h = L.lslab_i = 0;
+    L.lrows = false;
     if (L.lean) {
         const int T = f.depth;
         const int kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(f.d_v + f.d_e) + (f.b_i ? 1 : 0);
+        L.lrows = !f.b_h && !f.b_i;
+        L.rh = plan_wgrad16r(nE, (int)h, (int)h);
+        L.ri = plan_wgrad16r(nE, (int)h, (int)(f.d_v + f.d_e));
         L.lz_stride = align_up((bstep16_operand_bytes(nE, h) + 3) / 4, 64);
+        if (L.lrows) {
+            const size_t rows = align_up(((size_t)nE * (size_t)(split_row_floats(h) * 4) + 3) / 4, 64);
+            if (rows > L.lz_stride) L.lz_stride = rows;
+        }
         L.lm_stride = align_up((bstep16_operand_bytes(nE, kt_h) + 3) / 4, 64);
         L.lz = o; o += (size_t)T * L.lz_stride;
         L.lm = o; o += (size_t)(T - 1) * L.lm_stride;
         L.lx = o; o += align_up((bstep16_operand_bytes(nE, kt_i) + 3) / 4, 64);
         L.qh = plan_wgrad16t(bstep16_ld_chunks(nE), (int)h, kt_h);
         L.qi = plan_wgrad16t(bstep16_ld_chunks(nE), (int)h, kt_i);
-        L.lslab_h = o; o += align_up((size_t)(T - 1) * L.qh.splits * L.qh.slab_stride, 64);
-        L.lslab_i = o; o += align_up((size_t)T * L.qi.splits * L.qi.slab_stride, 64);
+        {
+            size_t a = (size_t)(T - 1) * L.qh.splits * L.qh.slab_stride, b = (size_t)(T - 1) * L.rh.splits * L.rh.slab_stride;
+            L.lslab_h = o; o += align_up(a > b ? a : b, 64);
+            a = (size_t)T * L.qi.splits * L.qi.slab_stride; b = (size_t)T * L.ri.splits * L.ri.slab_stride;
+            L.lslab_i = o; o += align_up(a > b ? a : b, 64);
+        }
     }
     L.total = o;
     return L;
@@ -904,13 +928,46 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         const size_t zs = L.lz_stride * sizeof(float), ms = L.lm_stride * sizeof(float);
         float* Tb[2] = {gZa, gZb};
         // site T-1 (gather from gMv) ... site 1: gZ^(t) blocks + T_next; site 0: gZ^(0) blocks only
+        const bool rows = L.lrows && _getenv_blocks() == 0;   // the products on split rows (no bias columns): nothing is re-blocked
         for (int t = T - 1; t >= 1; --t)
-            DMPNN_TRY(launch_bstep16(f, t, t == T - 1 ? nullptr : Tb[t & 1], gMv, &whT, Tb[(t - 1) & 1], Zb + (size_t)t * zs, s));
-        DMPNN_TRY(launch_bstep16(f, 0, Tb[0], gMv, nullptr, nullptr, Zb, s));
+            DMPNN_TRY(launch_bstep16(f, t, t == T - 1 ? nullptr : Tb[t & 1], gMv, &whT, Tb[(t - 1) & 1], Zb + (size_t)t * zs, s, rows));
+        DMPNN_TRY(launch_bstep16(f, 0, Tb[0], gMv, nullptr, nullptr, Zb, s, rows));
         // the products' other operands from what the forward kept: M^(t) (slot t - 1 of msplit), x (in H0)
         const int ts_m = (int)(split_row_floats(h) * 4), ts_x = ((int)((dv + de + 31) / 32)) * 128 + 16;
         const unsigned char* Mk = static_cast<const unsigned char*>(f.msplit);
         const bool want_h = b->gW_h || b->gb_h, want_i = b->gW_i || b->gb_i;
+        if (rows) {
+            // gW_h = sum_t gZ^(t)^T M^(t), gW_i = sum_t gZ^(t)^T x: every operand as its producer left it
+            ReduceJobs rj;
+            memset(&rj, 0, sizeof(rj));
+            rj.poison_flags = pflags; rj.poison_mask = pmask;
+            auto add_reduce_r = [&](float* slab, const WProdRPlan& q, int n_jobs, int K, float* gW, int64_t ldgw) {
+                ReduceJob& r = rj.job[rj.n_jobs];
+                r.slab = slab; r.slab_stride = q.slab_stride; r.n_slabs = n_jobs * q.splits; r.ldk = q.ldk;
+                r.N = (int)h; r.K = K; r.ones = 0; r.gW = gW; r.ldgw = ldgw; r.gb = nullptr;
+                int64_t blocks = ((int64_t)r.N * K + 255) / 256;
+                if (blocks > 1024) blocks = 1024;
+                rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
+                ++rj.n_jobs;
+            };
+            const unsigned char* Zs[kWProdMaxJobs];
+            const unsigned char* As[kWProdMaxJobs];
+            if (want_h) {
+                for (int t = 1; t < T; ++t) { Zs[t - 1] = Zb + (size_t)t * zs; As[t - 1] = Mk + (size_t)(t - 1) * (size_t)nE * ts_m; }
+                DMPNN_TRY(launch_wgrad16r(Zs, ts_m, As, ts_m, T - 1, L.rh, nE, (int)h, (int)h, ws + L.lslab_h, s));
+                add_reduce_r(ws + L.lslab_h, L.rh, T - 1, (int)h, b->gW_h, h);
+            }
+            if (want_i) {
+                for (int t = 0; t < T; ++t) { Zs[t] = Zb + (size_t)t * zs; As[t] = reinterpret_cast<const unsigned char*>(f.H0); }
+                DMPNN_TRY(launch_wgrad16r(Zs, ts_m, As, ts_x, T, L.ri, nE, (int)h, (int)(dv + de), ws + L.lslab_i, s));
+                add_reduce_r(ws + L.lslab_i, L.ri, T, (int)(dv + de), b->gW_i, dv + de);
+            }
+            if (rj.n_jobs > 0) {
+                hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
+                DMPNN_CHECK_LAUNCH("k_wgrad_reduce_multi");
+            }
+            return DMPNN_OK;
+        }
         if (want_h)
             for (int t = 1; t < T; ++t)
                 DMPNN_TRY(launch_rows2blk(f, Mk + (size_t)(t - 1) * (size_t)nE * ts_m, ts_m, (int)h, f.b_h ? 1 : 0, Mb + (size_t)(t - 1) * ms, s));

@@ -61,6 +61,7 @@ struct BStepK {
     const unsigned char* bits; int bstride;    // [tau(z) > 0] of this site's rows, [M][bstride] bytes (null: tau' = 1)
     float neg;                                 // tau' where the bit is 0: 0 (ReLU), the slope (LeakyReLU)
     unsigned char* Zblk; float* Zscale; int ld_chunks;   // gZ as tile-packed product operand: [column tile][ld_chunks][8 KB], scales [2 ld_chunks] (per 16-row half)
+    unsigned char* Zrows; int tsz;             // ... or (round 4, k_wgrad16r) as split ROWS [M][tsz]: the contraction's own A tile, row by row, the tile's scale in the tails
     SplitW W;                                  // pre-split W_h^T (fragment-major); p null: no contraction (the last site: gZ^(0) only)
     float* Tout; int ldo;                      // Tout[revp[r]] = gM[r]
     unsigned qmagic;                           // ceil(2^32 / (N / 4))
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
     // ---- gZ as product operand: the tile's slot of the tile-packed blocks.  Item = (feature, 8 slot rows): one 16-byte piece of
     // hi and one of lo; consecutive lanes = the six row groups of a feature, then the next feature — a wave's store covers the
     // 64 / 32 contiguous bytes a feature's pieces of one chunk make up, not 64 scattered pieces ----
-    {
+    if (g.Zblk) {
         const h8 z8 = h8{0, 0, 0, 0, 0, 0, 0, 0};
         for (int it = tid; it < BN * 6; it += NT) {
             const int n = it / 6, gq = it - n * 6;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
         }
     }
     const bool contract_on = g.W.p != nullptr;
-    if (!contract_on) return;
+    if (!contract_on && !g.Zrows) return;
     // ---- the split A tile of the contraction.  Item = (8 rows, 4 columns): read as fp32 BEFORE anyone overwrites the region with
     // the split tile (the two share the LDS, at different row strides) ----
     constexpr int NQ = BN / 4;                        // column quads of the padded row
@@ -273,6 +274,16 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
         }
     }
     __syncthreads();   // the split A tile is complete
+    if (g.Zrows) {
+        // gZ as a product operand = this tile, row by row (k_wgrad16r reads split rows as they are): 16-byte pieces, whole 128-byte lines
+        const int npc = ((g.N + 31) >> 5) * 8;   // pieces of a row's live chunks
+        for (int it = tid; it < nrows * npc; it += NT) {
+            const int r = it / npc, pc = it - r * npc;
+            *reinterpret_cast<uint4*>(g.Zrows + (long long)(rs + r) * g.tsz + pc * 16) = *reinterpret_cast<const uint4*>(Ag + r * TS + pc * 16);
+        }
+        if (tid < nrows) *reinterpret_cast<float4*>(g.Zrows + (long long)(rs + tid) * g.tsz + (g.tsz - 16)) = make_float4(s, 0.f, 0.f, 0.f);
+    }
+    if (!contract_on) return;
 
     // ---- gM = gZ W_h: barrier-free MFMA loop, A fragments from the LDS tile, weight fragments from L2 as a ring (k_step16's loop) ----
     asm volatile("" : "+v"(tid));
@@ -467,7 +478,7 @@ static unsigned qmagic_of(int64_t N) {
 
 // One backward step launch.  site: whose sign bits / which gZ; Tin null = gather mode (gH = gMv[dst]); W null = last site.
 int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const float* gMv, const SplitWView* W, float* Tout,
-                   unsigned char* Zblk, hipStream_t s) {
+                   unsigned char* Zblk, hipStream_t s, bool as_rows) {
     const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h;
     const PlanLayout L = plan_layout(nV, nE);
     const int* plan_i = static_cast<const int*>(f.plan);
@@ -483,8 +494,12 @@ int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const fl
     g.bits = f.act == DMPNN_ACT_NONE ? nullptr : static_cast<const unsigned char*>(f.keep_bits) + (size_t)site * (size_t)nE * (size_t)g.bstride;
     g.neg = f.act == DMPNN_ACT_RELU ? 0.f : (f.act == DMPNN_ACT_LEAKYRELU ? f.act_slope : 1.f);
     g.ld_chunks = (int)bstep16_ld_chunks(nE);
-    g.Zblk = Zblk;
-    g.Zscale = reinterpret_cast<float*>(Zblk + (size_t)((h + 63) / 64) * (size_t)g.ld_chunks * bstep16::kBlk);
+    if (as_rows) {   // (split rows [n_edges][split_row_bytes(d_h)] for k_wgrad16r)
+        g.Zrows = Zblk; g.tsz = step16::split_row_bytes((int)h);
+    } else {
+        g.Zblk = Zblk;
+        g.Zscale = reinterpret_cast<float*>(Zblk + (size_t)((h + 63) / 64) * (size_t)g.ld_chunks * bstep16::kBlk);
+    }
     if (W) { g.W.p = W->p; g.W.inv_scale = W->inv_scale; g.W.nc = W->nc; }
     g.Tout = W ? Tout : nullptr; g.ldo = (int)f.ldh;
     g.qmagic = qmagic_of(h);

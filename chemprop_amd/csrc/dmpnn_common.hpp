@@ -288,6 +288,12 @@ struct WProdTPlan { int n_ctz, n_kt, ld_chunks, splits, ldk; int64_t slab_stride
 WProdTPlan plan_wgrad16t(int64_t ld_chunks, int N, int Kt);
 int launch_wgrad16t(const WProdTOperand* Z, const WProdTOperand* A, int n, const WProdTPlan& p, int N, int Kt, float* slab,
                     const int* n_tiles_dev, hipStream_t s);
+// products over operands in SPLIT-ROW form (rows of [hi 32 | lo 32] chunks + a tail with the row's scale: k_wgrad16r, round 4) — the
+// operands are consumed as the step kernels keep them, nothing is re-blocked
+struct WProdRPlan { int n_kg, splits, rows_per_split, ldk; int64_t slab_stride; };
+WProdRPlan plan_wgrad16r(int64_t M, int N, int K);
+int launch_wgrad16r(const unsigned char* const* Z, int tsz, const unsigned char* const* A, int tsa, int n, const WProdRPlan& p, int64_t M, int N, int K,
+                    float* slab, hipStream_t s);
 size_t wsplit16_bytes(int64_t M, int64_t C);
 // One more weight-gradient product for the launches of a backward pass on the f16 pipe (the predictor's first layer in a training
 // step: gW[N, K] = Z^T A, gb = colsum(Z) — 512 rows are 16 chunks beside the block's 1 140): rides in k_wsplit16 / k_wgrad16 /
@@ -313,7 +319,7 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
 int64_t bstep16_ld_chunks(int64_t n_edges);
 size_t bstep16_operand_bytes(int64_t n_edges, int64_t C);
 int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const float* gMv, const SplitWView* W, float* Tout,
-                   unsigned char* Zblk, hipStream_t s);
+                   unsigned char* Zblk, hipStream_t s, bool as_rows = false);
 int launch_rows2blk(const dmpnn_fwd_args& f, const unsigned char* rows, int ts, int C, int ones, unsigned char* blk, hipStream_t s);
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);

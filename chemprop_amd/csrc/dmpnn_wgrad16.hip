@@ -361,6 +361,175 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
     }
 }
 
+
+// k_wgrad16r ------------------------------------------------------------------------------------------------------------
+// The product over operands in SPLIT-ROW form (round 4): rows of [hi 32 halfs | lo 32 halfs] chunks + a 16-byte tail with the row's
+// power-of-two scale — the form the step kernels keep their message rows in and contract them from (dmpnn_step16_impl.hpp), row-major,
+// nothing transposed or re-blocked by anyone.  v_mfma_f32_16x16x32_f16 wants 8 consecutive REDUCTION elements (rows) per lane; gfx950's
+// LDS transpose read (ds_read_b64_tr_b16: lane i of a 16-lane group receives column i of the 4 x 16 block whose sixteen 8-byte pieces
+// the group's lanes address, lane 4 row + column quad) delivers exactly that from a row-major image, so both operands go from memory
+// to LDS by DMA as they are — 32 rows per stage — and leave it as fragments.
+//   LDS image of a stage: chunk c of row r (128 bytes = 8 pieces of 16) at c 4096 + r 128, piece p at slot p ^ swz(r),
+//   swz(r) = 2 ((r >> 1) & 1) + 4 ((r >> 3) & 1): the 32 lanes of a transpose read's pass (two 16-lane groups: rows 8 g + 4 half + 0..3)
+//   then cover all 64 banks exactly once.  The DMA builds it: lane l of unit u (rows 8 u .. 8 u + 7) fetches piece (l & 7) ^ swz(r)
+//   of row r = 8 u + (l >> 3) and lands at the unit's byte 16 l.
+// Output tile, waves and accumulation as k_wgrad16t: all n x 128 k per workgroup, wave w owns the 16-row tiles w, w + 4, .. of n.
+// Scales are per ROW here: the Z fragments (8 reduction rows per lane) are scaled down by the rows' rho = F / (s_Z s_A) (an h8 per
+// lane group from LDS, four v_pk_mul_f16), F = the smallest s_Z s_A of the workgroup's row range.
+struct WProdR {
+    const unsigned char* Z; const unsigned char* A;   // split rows [M][tsz], [M][tsa]
+    float* slab;                                      // this job's slabs [splits][N][ldk]
+};
+struct WProdRJobs {
+    WProdR job[kWProdMaxJobs];
+    int n_jobs;
+    long long M; int N, K;
+    int tsz, ncz, tsa, nca;                           // row bytes and live chunks of Z (ceil(N / 32)) and A (ceil(K / 32))
+    int n_kg, splits, rows_per_split, per8;           // per8: workgroups per job / 8 (launch order)
+    int ldk; long long slab_stride;
+};
+}  // namespace wg16
+
+namespace wg16 {
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 f16x4_t;
+constexpr int kRChunk = 4096;   // bytes of one chunk of a stage: 32 rows x 128
+
+__device__ __forceinline__ h8 tr_pair(const unsigned char* base, int off) {   // rows 8 g .. 8 g + 7 of one 16-column tile: two transpose reads
+    const f16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) f16x4_t*)(base + off));
+    const f16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) f16x4_t*)(base + off + 512));
+    const h4 x = __builtin_bit_cast(h4, a), y = __builtin_bit_cast(h4, b);
+    return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [ncz chunks of Z | 4 chunks of A] of the stage, rho16[2][32], red
+    const int per_job = P.per8 * 8;
+    const int j = (int)blockIdx.x / per_job;
+    const int local = (int)blockIdx.x - j * per_job;
+    const int rank = (local & 7) * P.per8 + (local >> 3);   // XCD-aware: the k columns of one row split share an L2 (they stream the same Z rows)
+    if (rank >= P.n_kg * P.splits) return;
+    const int split = rank / P.n_kg, kg = rank - split * P.n_kg;
+    const WProdR& a = P.job[j];
+    const long long m_lo = (long long)split * P.rows_per_split;
+    const long long m_hi = m_lo + P.rows_per_split < P.M ? m_lo + P.rows_per_split : P.M;
+    const int n_rows = (int)(m_hi - m_lo);   // (> 0: the host sizes `splits` so that every split holds rows)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    unsigned char* Zt = lds;
+    unsigned char* At = lds + P.ncz * kRChunk;
+    _Float16* rho16 = reinterpret_cast<_Float16*>(At + 4 * kRChunk);           // [2][32]
+    unsigned* red = reinterpret_cast<unsigned*>(rho16 + 64);
+    const unsigned char* Zr = a.Z + m_lo * P.tsz;
+    const unsigned char* Ar = a.A + m_lo * P.tsa;
+    // ---- F: the smallest s_Z s_A over the rows of this workgroup's range (the rows' tails) ----
+    if (tid == 0) red[0] = 0x7f7fffffu;
+    __syncthreads();
+    {
+        float f = 3.0e38f;
+        for (int r = tid; r < n_rows; r += 256)
+            f = fminf(f, *reinterpret_cast<const float*>(Zr + (long long)r * P.tsz + (P.tsz - 16)) * *reinterpret_cast<const float*>(Ar + (long long)r * P.tsa + (P.tsa - 16)));
+        for (int off = 32; off > 0; off >>= 1) f = fminf(f, __shfl_xor(f, off));
+        if (lane == 0 && f > 0.f) atomicMin(&red[0], __float_as_uint(f));   // (positive floats order like their bit patterns)
+    }
+    // rho of a stage's rows: thread t < 32 owns row t of the stage; the scales of stage s + 1 are requested while stage s computes
+    float sz_n = 0.f, sa_n = 0.f;
+    auto ask_scales = [&](int m0) {
+        const int r = m0 + tid;
+        const bool ok = tid < 32 && r < n_rows;
+        sz_n = ok ? *reinterpret_cast<const float*>(Zr + (long long)r * P.tsz + (P.tsz - 16)) : 0.f;
+        sa_n = ok ? *reinterpret_cast<const float*>(Ar + (long long)r * P.tsa + (P.tsa - 16)) : 0.f;
+    };
+    ask_scales(0);
+    __syncthreads();
+    const float F = __uint_as_float(red[0]);
+    auto put_rho = [&](int buf) {
+        if (tid < 32) {
+            const float fh = sz_n * sa_n;
+            rho16[buf * 32 + tid] = (_Float16)(fh > 0.f ? F / fh : 0.f);
+        }
+    };
+    put_rho(0);
+    f32x4 acc[kRTW][8];
+#pragma unroll
+    for (int r = 0; r < kRTW; ++r)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) acc[r][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transpose-read addresses inside a chunk image: rows 8 lg + (li >> 2) (+ 4 for the second read: + 512 bytes), piece
+    // (part 4 + h2 2 + ((li >> 1) & 1)) ^ swz, 8-byte half li & 1;  swz = 4 (lg & 1) + 2 ((li >> 3) & 1) for all of them
+    const int rowb = (8 * lg + (li >> 2)) * 128 + (li & 1) * 8;
+    int px[2][2];   // [part: hi | lo][h2: columns 0..15 | 16..31 of the chunk]
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) px[part][h2] = rowb + ((((part ^ (lg & 1)) << 2) + ((h2 ^ ((li >> 3) & 1)) << 1) + ((li >> 1) & 1)) << 4);
+    const int n_nt = (P.N + 15) >> 4;                       // 16-row tiles of n
+    const int kt_live = ((P.K - 128 * kg + 15) >> 4) < 8 ? ((P.K - 128 * kg + 15) >> 4) : 8;   // live 16-column tiles of this k column
+    const int ca_live = (P.nca - 4 * kg) < 4 ? (P.nca - 4 * kg) : 4;                          // ... and its chunks of A
+    // the DMA's lane: row (lane >> 3) of a unit of 8 rows, LDS slot lane & 7 <- piece (lane & 7) ^ swz(row)
+    const rsrc_t rZ = gemm::make_rsrc(Zr, gemm::clamp_bytes((long long)n_rows * P.tsz));
+    const rsrc_t rA = gemm::make_rsrc(Ar, gemm::clamp_bytes((long long)n_rows * P.tsa));
+    const int n_inst = (P.ncz + ca_live) * 4;
+    int stage = 0;
+    for (int m0 = 0; m0 < n_rows; m0 += 32, ++stage) {
+        for (int i = wave; i < n_inst; i += 4) {
+            const int c = i >> 2, u = i & 3;
+            const int r = 8 * u + (lane >> 3);
+            const int piece = (lane & 7) ^ (2 * ((r >> 1) & 1) + 4 * ((r >> 3) & 1));
+            const bool live = m0 + r < n_rows;
+            if (c < P.ncz)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rZ, (__attribute__((address_space(3))) void*)(Zt + c * kRChunk + u * 1024), 16,
+                                                         live ? (unsigned)((m0 + r) * P.tsz + c * 128 + piece * 16) : gemm::kOOB, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(At + (c - P.ncz) * kRChunk + u * 1024), 16,
+                                                         live ? (unsigned)((m0 + r) * P.tsa + (4 * kg + c - P.ncz) * 128 + piece * 16) : gemm::kOOB, 0, 0, 0);
+        }
+        ask_scales(m0 + 32);
+        __syncthreads();  // (the barrier's release waits for the DMA; rho of this stage was written before the last barrier)
+        const h8 rho = *reinterpret_cast<const h8*>(rho16 + (stage & 1) * 32 + 8 * lg);
+        h8 zh[kRTW], zl[kRTW];
+#pragma unroll
+        for (int r = 0; r < kRTW; ++r) {
+            const int nt = wave + 4 * r;
+            if (nt < n_nt) {   // (wave-uniform)
+                const unsigned char* zc = Zt + (nt >> 1) * kRChunk;
+                zh[r] = tr_pair(zc, px[0][nt & 1]) * rho;
+                zl[r] = tr_pair(zc, px[1][nt & 1]) * rho;
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            if (kt >= kt_live) break;   // (uniform)
+            const unsigned char* ac = At + (kt >> 1) * kRChunk;
+            const h8 bh = tr_pair(ac, px[0][kt & 1]), bl = tr_pair(ac, px[1][kt & 1]);
+#pragma unroll
+            for (int r = 0; r < kRTW; ++r) {
+                if (wave + 4 * r >= n_nt) continue;
+                f32x4& d = acc[r][kt];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], bh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], bl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[r], bh, d, 0, 0, 0);
+            }
+        }
+        put_rho((stage + 1) & 1);
+        __syncthreads();  // (every wave is done with the stage before the next DMA overwrites it; the next stage's rho is in place)
+    }
+    // D fragment: lane (li, lg) holds rows 16 nt + 4 lg + e of n, column 16 kt + li of this workgroup's k column
+    const float iF = (F > 0.f && F < 3.0e38f) ? 1.f / F : 0.f;
+    float* slab = a.slab + (long long)split * P.slab_stride;
+#pragma unroll
+    for (int r = 0; r < kRTW; ++r) {
+        const int nt = wave + 4 * r;
+        if (nt >= n_nt) continue;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = 16 * nt + 4 * lg + e, k = 128 * kg + 16 * kt + li;
+                if (n < P.N && k < P.K) slab[(long long)n * P.ldk + k] = acc[r][kt][e] * iF;
+            }
+    }
+}
+
 }  // namespace wg16
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -472,6 +641,50 @@ int launch_wgrad16t(const WProdTOperand* Z, const WProdTOperand* A, int n, const
     }
     hipLaunchKernelGGL(wg16::k_wgrad16t, dim3((unsigned)jobs.wg0[n]), dim3(256), lds, s, jobs);
     DMPNN_CHECK_LAUNCH("k_wgrad16t");
+    return DMPNN_OK;
+}
+
+// products over split-row operands (k_wgrad16r): `n` jobs Z_i^T A_i (all of M rows, N x K) into adjacent slab sets of `splits` slabs each
+WProdRPlan plan_wgrad16r(int64_t M, int N, int K) {
+    WProdRPlan p;
+    p.n_kg = (K + 127) / 128;
+    int splits = 256 / p.n_kg;                      // ~256 workgroups per product, two or more per CU over the jobs of a launch
+    if (splits < 1) splits = 1;
+    int64_t rps = (M + splits - 1) / splits;
+    rps = (rps + 31) / 32 * 32;
+    if (rps < 32) rps = 32;
+    p.rows_per_split = (int)rps;
+    p.splits = (int)((M + rps - 1) / rps);
+    if (p.splits < 1) p.splits = 1;
+    p.ldk = (K + 3) / 4 * 4;
+    p.slab_stride = (int64_t)N * p.ldk;
+    return p;
+}
+
+int launch_wgrad16r(const unsigned char* const* Z, int tsz, const unsigned char* const* A, int tsa, int n, const WProdRPlan& p, int64_t M, int N, int K,
+                    float* slab, hipStream_t s) {
+    if (n <= 0 || M <= 0) return DMPNN_OK;
+    const int ncz = (N + 31) / 32, nca = (K + 31) / 32;
+    if (n > kWProdMaxJobs || (N + 15) / 16 > 4 * wg16::kRTW || tsz < ncz * 128 + 16 || tsa < nca * 128 + 16 || (int64_t)p.rows_per_split * (tsz > tsa ? tsz : tsa) > ((int64_t)1 << 31)) {
+        set_error("wgrad16r: at most %d products per launch, d_h <= 320, whole chunks + tail per row", kWProdMaxJobs);
+        return DMPNN_EINVAL;
+    }
+    wg16::WProdRJobs P;
+    memset(&P, 0, sizeof(P));
+    for (int i = 0; i < n; ++i) { P.job[i].Z = Z[i]; P.job[i].A = A[i]; P.job[i].slab = slab + (int64_t)i * p.splits * p.slab_stride; }
+    P.n_jobs = n; P.M = M; P.N = N; P.K = K;
+    P.tsz = tsz; P.ncz = ncz; P.tsa = tsa; P.nca = nca;
+    P.n_kg = p.n_kg; P.splits = p.splits; P.rows_per_split = p.rows_per_split; P.per8 = (p.n_kg * p.splits + 7) / 8;
+    P.ldk = p.ldk; P.slab_stride = p.slab_stride;
+    const size_t lds = (size_t)(ncz + 4) * wg16::kRChunk + 128 + 64;
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16r, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(wg16::k_wgrad16r, dim3((unsigned)(n * P.per8 * 8)), dim3(256), lds, s, P);
+    DMPNN_CHECK_LAUNCH("k_wgrad16r");
     return DMPNN_OK;
 }
 
