@@ -461,7 +461,7 @@ struct ReduceJob {
     const float* slab; int64_t slab_stride; int n_slabs, ldk, N, K, ones;
     float* gW; int64_t ldgw; float* gb;
 };
-struct ReduceJobs { ReduceJob job[4]; int wg0[5]; int n_jobs; const int* poison_flags; int poison_mask; };
+struct ReduceJobs { ReduceJob job[8]; int wg0[9]; int n_jobs; const int* poison_flags; int poison_mask; };
 __global__ void k_wgrad_reduce_multi(ReduceJobs a) {
     int j = 0;
     while (j + 1 < a.n_jobs && (int)blockIdx.x >= a.wg0[j + 1]) ++j;
@@ -584,14 +584,6 @@ int launch_wgrad_reduce(const float* slab, const WgradPlan& p, int n_slabs, int 
     return DMPNN_OK;
 }
 
-// DMPNN_WGRAD_BLOCKS=1 (A/B measurements): the lean route's products on tile-packed BLOCK operands (k_rows2blk + k_wgrad16t) also
-// where the split-row product (k_wgrad16r) applies
-static int _getenv_blocks() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DMPNN_WGRAD_BLOCKS"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-
 struct BwdLayout {
     size_t gZa, gZb, gH0, gZO, gMv, gHO, WhT, WoT, WdT, slab_h, slab_x, total;
     size_t WhT16, WoT16;  // pre-split transposed weights of the data-gradient contractions on the f16 pipe (large batches)
@@ -606,15 +598,17 @@ struct BwdLayout {
     size_t w16g;                              // per-step path: split operands of one product at a time
     size_t w16_z[3], w16_a[3], w16_slab[3];   // o, h, i (float offsets)
     WProdPlan q[3];
-    // lean training on the per-step fused route (dmpnn_bstep16.hip): operands written by the step kernels, products over the steps
+    // tile kernels with the kept messages as split rows (mega16_keeps_rows): every weight-gradient operand as split rows — the gradients
+    // written so by the backward tile kernel, [V[src] || E] and [V || Mv] by k_rows2sr — and ALL products in one k_wgrad16r launch
+    bool sr;
+    int tsr, tsx, tsv;                          // row bytes: d_h columns | d_v + d_e | d_v + d_h
+    size_t sr_gz, sr_gh0, sr_gzo, sr_x, sr_vm, sr_slab;
+    WProdRPlan r_h, r_i, r_o, r_bh, r_bi, r_bo;
+    // lean training on the per-step fused route (dmpnn_bstep16.hip): gZ of every site as split rows, written by the step kernels; the
+    // products (k_wgrad16r) read them and the forward's kept M^(t) / x rows as they are
     bool lean;
-    size_t lz, lm, lx, lz_stride, lm_stride;   // gZ blocks of every site | M^(t) blocks | x blocks (float offsets / strides per operand)
-    size_t lslab_h, lslab_i;
-    WProdTPlan qh, qi;
-    // ... without bias columns (b_i, b_h absent: chemprop's default) the products read SPLIT ROWS (k_wgrad16r): gZ rows written by the step
-    // kernels into the same region, the kept M^(t) / x rows as they are — no block operands at all
-    bool lrows;
-    WProdRPlan rh, ri;
+    size_t lz, lz_stride, lslab;               // gZ rows of every site | slabs (W_h | b_h | W_i | b_i)
+    WProdRPlan rh, ri, rb;                     // (rb: the column-sum jobs of the bias gradients)
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     BwdLayout L;
@@ -690,32 +684,40 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
             }
         }
     }
+    L.sr = L.mega && mega16_keeps_rows(f) && f.d_v + f.d_e <= 512 && f.d_v + h <= 512;
+    L.tsr = L.tsx = L.tsv = 0;
+    L.sr_gz = L.sr_gh0 = L.sr_gzo = L.sr_x = L.sr_vm = L.sr_slab = 0;
+    if (L.sr) {
+        const int T = f.depth;
+        const auto row_bytes = [](int64_t K) { return (int)(((K + 31) / 32) * 128 + 16); };
+        L.tsr = (int)(split_row_floats(h) * 4); L.tsx = row_bytes(f.d_v + f.d_e); L.tsv = row_bytes(f.d_v + h);
+        const auto fl = [&](size_t bytes) { return align_up((bytes + 3) / 4, 64); };
+        L.sr_gz = o; o += fl((size_t)(T - 1) * nE * L.tsr);
+        L.sr_gh0 = o; o += fl((size_t)nE * L.tsr);
+        L.sr_gzo = o; o += fl((size_t)nV * L.tsr);
+        L.sr_x = o; o += fl((size_t)nE * L.tsx);
+        L.sr_vm = o; o += fl((size_t)nV * L.tsv);
+        L.r_h = plan_wgrad16r(nE * (T - 1), (int)h, (int)h);
+        L.r_i = plan_wgrad16r(nE, (int)h, (int)(f.d_v + f.d_e));
+        L.r_o = plan_wgrad16r(nV, (int)h, (int)(f.d_v + h));
+        L.r_bh = plan_wgrad16r(nE * (T - 1), (int)h, 1);
+        L.r_bi = plan_wgrad16r(nE, (int)h, 1);
+        L.r_bo = plan_wgrad16r(nV, (int)h, 1);
+        L.sr_slab = o;
+        for (const WProdRPlan* q : {&L.r_h, &L.r_i, &L.r_o, &L.r_bh, &L.r_bi, &L.r_bo}) o += align_up((size_t)q->splits * q->slab_stride, 64);
+    }
     L.lean = fused16_lean(f);
-    L.lz = L.lm = L.lx = L.lz_stride = L.lm_stride = L.lslab_h = L.lslab_i = 0;
-    L.lrows = false;
+    L.lz = L.lz_stride = L.lslab = 0;
     if (L.lean) {
         const int T = f.depth;
-        const int kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(f.d_v + f.d_e) + (f.b_i ? 1 : 0);
-        L.lrows = !f.b_h && !f.b_i;
         L.rh = plan_wgrad16r(nE, (int)h, (int)h);
         L.ri = plan_wgrad16r(nE, (int)h, (int)(f.d_v + f.d_e));
-        L.lz_stride = align_up((bstep16_operand_bytes(nE, h) + 3) / 4, 64);
-        if (L.lrows) {
-            const size_t rows = align_up(((size_t)nE * (size_t)(split_row_floats(h) * 4) + 3) / 4, 64);
-            if (rows > L.lz_stride) L.lz_stride = rows;
-        }
-        L.lm_stride = align_up((bstep16_operand_bytes(nE, kt_h) + 3) / 4, 64);
+        L.rb = plan_wgrad16r(nE, (int)h, 1);
+        L.lz_stride = align_up(((size_t)nE * (size_t)(split_row_floats(h) * 4) + 3) / 4, 64);
         L.lz = o; o += (size_t)T * L.lz_stride;
-        L.lm = o; o += (size_t)(T - 1) * L.lm_stride;
-        L.lx = o; o += align_up((bstep16_operand_bytes(nE, kt_i) + 3) / 4, 64);
-        L.qh = plan_wgrad16t(bstep16_ld_chunks(nE), (int)h, kt_h);
-        L.qi = plan_wgrad16t(bstep16_ld_chunks(nE), (int)h, kt_i);
-        {
-            size_t a = (size_t)(T - 1) * L.qh.splits * L.qh.slab_stride, b = (size_t)(T - 1) * L.rh.splits * L.rh.slab_stride;
-            L.lslab_h = o; o += align_up(a > b ? a : b, 64);
-            a = (size_t)T * L.qi.splits * L.qi.slab_stride; b = (size_t)T * L.ri.splits * L.ri.slab_stride;
-            L.lslab_i = o; o += align_up(a > b ? a : b, 64);
-        }
+        L.lslab = o;
+        o += align_up((size_t)(T - 1) * L.rh.splits * L.rh.slab_stride, 64) + align_up((size_t)T * L.ri.splits * L.ri.slab_stride, 64) +
+             align_up((size_t)(T - 1) * L.rb.splits * L.rb.slab_stride, 64) + align_up((size_t)T * L.rb.splits * L.rb.slab_stride, 64);
     }
     L.total = o;
     return L;
@@ -800,7 +802,13 @@ int dmpnn_backward(const dmpnn_bwd_args* b, void* stream) { return backward_impl
 namespace dmpnn {
 size_t extra_wgrad_ws_floats(int64_t M, int N, int Kt) {
     const WProdPlan q = plan_wgrad16(M, N, Kt);
-    return align_up((wsplit16_bytes(M, N) + 3) / 4, 64) + align_up((wsplit16_bytes(M, Kt) + 3) / 4, 64) + align_up((size_t)q.splits * q.slab_stride, 64);
+    const size_t blocks = align_up((wsplit16_bytes(M, N) + 3) / 4, 64) + align_up((wsplit16_bytes(M, Kt) + 3) / 4, 64) + align_up((size_t)q.splits * q.slab_stride, 64);
+    // ... or, on the split-row path (k_rows2sr + k_wgrad16r): both operands as split rows, the product's slabs and the column sums'
+    const WProdRPlan r = plan_wgrad16r(M, N, Kt), rb = plan_wgrad16r(M, N, 1);
+    const auto row_bytes = [](int64_t K) { return (size_t)(((K + 31) / 32) * 128 + 16); };
+    const size_t rows = (align_up((size_t)M * row_bytes(N), 256) + align_up((size_t)M * row_bytes(Kt), 256)) / 4 + align_up((size_t)r.splits * r.slab_stride, 64) +
+                        align_up((size_t)rb.splits * rb.slab_stride, 64) + 64;
+    return blocks > rows ? blocks : rows;
 }
 
 int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra, bool* extra_done) {
@@ -923,66 +931,20 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         SplitWView whT;
         DMPNN_TRY(split_weights_view(f.W_h, h, h, h, 1, ws + L.WhT16, &whT, s));
         unsigned char* Zb = reinterpret_cast<unsigned char*>(ws + L.lz);
-        unsigned char* Mb = reinterpret_cast<unsigned char*>(ws + L.lm);
-        unsigned char* Xb = reinterpret_cast<unsigned char*>(ws + L.lx);
-        const size_t zs = L.lz_stride * sizeof(float), ms = L.lm_stride * sizeof(float);
+        const size_t zs = L.lz_stride * sizeof(float);
         float* Tb[2] = {gZa, gZb};
-        // site T-1 (gather from gMv) ... site 1: gZ^(t) blocks + T_next; site 0: gZ^(0) blocks only
-        const bool rows = L.lrows && _getenv_blocks() == 0;   // the products on split rows (no bias columns): nothing is re-blocked
+        // site T-1 (gather from gMv) ... site 1: gZ^(t) rows + T_next; site 0: gZ^(0) rows only
         for (int t = T - 1; t >= 1; --t)
-            DMPNN_TRY(launch_bstep16(f, t, t == T - 1 ? nullptr : Tb[t & 1], gMv, &whT, Tb[(t - 1) & 1], Zb + (size_t)t * zs, s, rows));
-        DMPNN_TRY(launch_bstep16(f, 0, Tb[0], gMv, nullptr, nullptr, Zb, s, rows));
-        // the products' other operands from what the forward kept: M^(t) (slot t - 1 of msplit), x (in H0)
+            DMPNN_TRY(launch_bstep16(f, t, t == T - 1 ? nullptr : Tb[t & 1], gMv, &whT, Tb[(t - 1) & 1], Zb + (size_t)t * zs, s));
+        DMPNN_TRY(launch_bstep16(f, 0, Tb[0], gMv, nullptr, nullptr, Zb, s));
+        // the products' other operands are what the forward kept: M^(t) (slot t - 1 of msplit), x (in H0) — split rows, read as they are.
+        // gW_h = sum_t gZ^(t)^T M^(t), gW_i = sum_t gZ^(t)^T x, the bias gradients = column sums of the gZ^(t): ALL jobs in one launch
         const int ts_m = (int)(split_row_floats(h) * 4), ts_x = ((int)((dv + de + 31) / 32)) * 128 + 16;
         const unsigned char* Mk = static_cast<const unsigned char*>(f.msplit);
-        const bool want_h = b->gW_h || b->gb_h, want_i = b->gW_i || b->gb_i;
-        if (rows) {
-            // gW_h = sum_t gZ^(t)^T M^(t), gW_i = sum_t gZ^(t)^T x: every operand as its producer left it
-            ReduceJobs rj;
-            memset(&rj, 0, sizeof(rj));
-            rj.poison_flags = pflags; rj.poison_mask = pmask;
-            auto add_reduce_r = [&](float* slab, const WProdRPlan& q, int n_jobs, int K, float* gW, int64_t ldgw) {
-                ReduceJob& r = rj.job[rj.n_jobs];
-                r.slab = slab; r.slab_stride = q.slab_stride; r.n_slabs = n_jobs * q.splits; r.ldk = q.ldk;
-                r.N = (int)h; r.K = K; r.ones = 0; r.gW = gW; r.ldgw = ldgw; r.gb = nullptr;
-                int64_t blocks = ((int64_t)r.N * K + 255) / 256;
-                if (blocks > 1024) blocks = 1024;
-                rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
-                ++rj.n_jobs;
-            };
-            const unsigned char* Zs[kWProdMaxJobs];
-            const unsigned char* As[kWProdMaxJobs];
-            if (want_h) {
-                for (int t = 1; t < T; ++t) { Zs[t - 1] = Zb + (size_t)t * zs; As[t - 1] = Mk + (size_t)(t - 1) * (size_t)nE * ts_m; }
-                DMPNN_TRY(launch_wgrad16r(Zs, ts_m, As, ts_m, T - 1, L.rh, nE, (int)h, (int)h, ws + L.lslab_h, s));
-                add_reduce_r(ws + L.lslab_h, L.rh, T - 1, (int)h, b->gW_h, h);
-            }
-            if (want_i) {
-                for (int t = 0; t < T; ++t) { Zs[t] = Zb + (size_t)t * zs; As[t] = reinterpret_cast<const unsigned char*>(f.H0); }
-                DMPNN_TRY(launch_wgrad16r(Zs, ts_m, As, ts_x, T, L.ri, nE, (int)h, (int)(dv + de), ws + L.lslab_i, s));
-                add_reduce_r(ws + L.lslab_i, L.ri, T, (int)(dv + de), b->gW_i, dv + de);
-            }
-            if (rj.n_jobs > 0) {
-                hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
-                DMPNN_CHECK_LAUNCH("k_wgrad_reduce_multi");
-            }
-            return DMPNN_OK;
-        }
-        if (want_h)
-            for (int t = 1; t < T; ++t)
-                DMPNN_TRY(launch_rows2blk(f, Mk + (size_t)(t - 1) * (size_t)nE * ts_m, ts_m, (int)h, f.b_h ? 1 : 0, Mb + (size_t)(t - 1) * ms, s));
-        if (want_i) DMPNN_TRY(launch_rows2blk(f, reinterpret_cast<const unsigned char*>(f.H0), ts_x, (int)(dv + de), f.b_i ? 1 : 0, Xb, s));
-        const int ldc = (int)bstep16_ld_chunks(nE);
-        const int n_ct_z = (int)((h + 63) / 64);
-        auto operand = [&](unsigned char* blk, int n_ct) {
-            return WProdTOperand{blk, reinterpret_cast<const float*>(blk + (size_t)n_ct * (size_t)ldc * 8192)};
-        };
-        const int* n_tiles_dev = static_cast<const int*>(f.plan) + DMPNN_HDR_NTILES;
-        const int kt_h = (int)h + (f.b_h ? 1 : 0), kt_i = (int)(dv + de) + (f.b_i ? 1 : 0);
         ReduceJobs rj;
         memset(&rj, 0, sizeof(rj));
         rj.poison_flags = pflags; rj.poison_mask = pmask;
-        auto add_reduce = [&](float* slab, const WProdTPlan& q, int n_jobs, int K, int ones, float* gW, int64_t ldgw, float* gb) {
+        auto add_reduce_r = [&](float* slab, const WProdRPlan& q, int n_jobs, int K, int ones, float* gW, int64_t ldgw, float* gb) {
             ReduceJob& r = rj.job[rj.n_jobs];
             r.slab = slab; r.slab_stride = q.slab_stride; r.n_slabs = n_jobs * q.splits; r.ldk = q.ldk;
             r.N = (int)h; r.K = K; r.ones = ones; r.gW = gW; r.ldgw = ldgw; r.gb = gb;
@@ -991,28 +953,41 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
             rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
             ++rj.n_jobs;
         };
-        if (want_h) {   // gW_h = sum_t gZ^(t)^T M^(t)
-            WProdTOperand Zs[kWProdMaxJobs], As[kWProdMaxJobs];
-            for (int t = 1; t < T; ++t) { Zs[t - 1] = operand(Zb + (size_t)t * zs, n_ct_z); As[t - 1] = operand(Mb + (size_t)(t - 1) * ms, (kt_h + 63) / 64); }
-            DMPNN_TRY(launch_wgrad16t(Zs, As, T - 1, L.qh, (int)h, kt_h, ws + L.lslab_h, n_tiles_dev, s));
-            add_reduce(ws + L.lslab_h, L.qh, T - 1, (int)h, f.b_h ? 1 : 0, b->gW_h, h, b->gb_h);
-        }
-        if (want_i) {   // gW_i = (sum_t gZ^(t))^T x = sum_t gZ^(t)^T x
-            WProdTOperand Zs[kWProdMaxJobs], As[kWProdMaxJobs];
-            for (int t = 0; t < T; ++t) { Zs[t] = operand(Zb + (size_t)t * zs, n_ct_z); As[t] = operand(Xb, (kt_i + 63) / 64); }
-            DMPNN_TRY(launch_wgrad16t(Zs, As, T, L.qi, (int)h, kt_i, ws + L.lslab_i, n_tiles_dev, s));
-            add_reduce(ws + L.lslab_i, L.qi, T, (int)(dv + de), f.b_i ? 1 : 0, b->gW_i, dv + de, b->gb_i);
-        }
+        WProdRJob pj[4 * kWProdMaxJobs];
+        int np = 0;
+        float* slab = ws + L.lslab;
+        auto add_jobs = [&](int t0, int t1, const unsigned char* A, size_t a_stride, int tsa, int K, const WProdRPlan& q, float* gW, int64_t ldgw) {
+            if (!gW) return;
+            for (int t = t0; t < t1; ++t)
+                pj[np++] = WProdRJob{Zb + (size_t)t * zs, ts_m, A + (size_t)(t - t0) * a_stride, tsa, nE, (int)h, K, slab + (size_t)(t - t0) * q.splits * q.slab_stride, q};
+            add_reduce_r(slab, q, t1 - t0, K, 0, gW, ldgw, nullptr);
+            slab += align_up((size_t)(t1 - t0) * q.splits * q.slab_stride, 64);
+        };
+        auto add_colsums = [&](int t0, int t1, float* gb) {   // gb = sum_t colsum(gZ^(t))
+            if (!gb) return;
+            for (int t = t0; t < t1; ++t)
+                pj[np++] = WProdRJob{Zb + (size_t)t * zs, ts_m, nullptr, 0, nE, (int)h, 1, slab + (size_t)(t - t0) * L.rb.splits * L.rb.slab_stride, L.rb};
+            add_reduce_r(slab, L.rb, t1 - t0, 0, 1, nullptr, 0, gb);
+            slab += align_up((size_t)(t1 - t0) * L.rb.splits * L.rb.slab_stride, 64);
+        };
+        add_jobs(1, T, Mk, (size_t)nE * ts_m, ts_m, (int)h, L.rh, b->gW_h, h);
+        add_colsums(1, T, f.b_h ? b->gb_h : nullptr);
+        add_jobs(0, T, reinterpret_cast<const unsigned char*>(f.H0), 0, ts_x, (int)(dv + de), L.ri, b->gW_i, dv + de);
+        add_colsums(0, T, f.b_i ? b->gb_i : nullptr);
+        DMPNN_TRY(launch_wgrad16r(pj, np, s));
         if (rj.n_jobs > 0) {
             hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
             DMPNN_CHECK_LAUNCH("k_wgrad_reduce_multi");
         }
         return DMPNN_OK;
     }
-    const bool tile_bwd = L.mega && (atom || b->g_edge || b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO);
+    const bool tile_bwd = L.mega && (atom || L.sr || b->g_edge || b->gW_i || b->gb_i || b->gW_h || b->gb_h) && ld_gHO % 4 == 0 && ldHO % 4 == 0 && aligned16(gHO_p) && aligned16(HO);
     DMPNN_CHECK_ARG(!b->g_edge || nE == 0 || (tile_bwd && b->ld_gedge >= h && b->ld_gedge % 4 == 0 && aligned16(b->g_edge)),
                     "backward: g_edge (a gradient w.r.t. the kept H^(depth-1)) is taken by the backward tile kernel only (tile-kernel forward with "
                     "DMPNN_F_KEEP), as 16-byte aligned rows with a leading dimension that is a multiple of 4");
+    DMPNN_CHECK_ARG(!mega16_keeps_rows(f) || (tile_bwd && L.sr) || !(b->gW_h || b->gb_h),
+                    "backward: the forward kept its messages as split rows (`msplit`): the weight gradient of W_h then needs the tile kernels — "
+                    "16-byte aligned gout / out with leading dimensions that are multiples of 4, d_v + d_e and d_v + d_h <= 512");
     DMPNN_CHECK_ARG(!atom || (tile_bwd && L.w16 && !has_vd && (T < 2 || nE == 0 || f.msplit)),
                     "backward: DMPNN_F_ATOM needs the tile-kernel forward (FUSED | MEGA | SPLIT16 | KEEP with `msplit`), even d_v / d_e / d_h and "
                     "16-byte aligned gout / out (leading dimensions multiples of 4)");
@@ -1025,7 +1000,85 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         // ---- the whole data-gradient chain in one launch, then the four weight gradients ----
         DMPNN_CHECK_ARG(f.H0 && (T == 1 || f.Hs), "backward: the tile-kernel forward did not keep H0 / H^(t)");
         float* gZs = (T - 1 > 2) ? ws + L.gZs : gZa;  // slot t-1 = gZ^(t)
-        DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, ws + L.sp_gM, ws + L.gMv, s, b->g_edge, b->ld_gedge));
+        Mega16BwdRows br{nullptr, nullptr, nullptr, 0};
+        if (L.sr) br = Mega16BwdRows{reinterpret_cast<unsigned char*>(ws + L.sr_gz), reinterpret_cast<unsigned char*>(ws + L.sr_gh0),
+                                     reinterpret_cast<unsigned char*>(ws + L.sr_gzo), L.tsr};
+        DMPNN_TRY(launch_mega16_backward(f, gHO_p, ld_gHO, HO, ldHO, gZO, gZs, gH0, ws + L.mega_w, ws + L.sp_gM, ws + L.gMv, s, b->g_edge, b->ld_gedge, &br));
+        if (L.sr) {
+            // ---- every weight-gradient operand is a set of split rows: the gradients left the tile kernel so, M^(t) the forward; the two
+            // input-side operands are split here (one launch, + a rider's), then ALL products in one launch, one reduce launch ----
+            unsigned char* Xr = reinterpret_cast<unsigned char*>(ws + L.sr_x);
+            unsigned char* VMr = reinterpret_cast<unsigned char*>(ws + L.sr_vm);
+            const bool want_o = b->gW_o || b->gb_o, want_h = (b->gW_h || b->gb_h) && T >= 2, want_i = b->gW_i || b->gb_i;
+            const bool ride = extra && extra->Z && extra->A && extra->ws && (extra->gW || extra->gb) && extra->M > 0 && extra->N <= 320 && extra->K <= 512 &&
+                              aligned16(extra->ws);
+            const auto row_bytes = [](int64_t K) { return (int)(((K + 31) / 32) * 128 + 16); };
+            SRJob sj[4];
+            int ns = 0;
+            if (want_i) {
+                sj[ns] = SRJob{f.V, f.ldv, (int)dv, lean ? nullptr : pv.src, lean ? reinterpret_cast<const long long*>(f.edge_index) : nullptr, nV,
+                               f.E, f.lde, (int)de, e_gather, nE, Xr, L.tsx};
+                ++ns;
+            }
+            if (want_o) { sj[ns] = SRJob{f.V, f.ldv, (int)dv, nullptr, nullptr, 0, f.Mv, ldh, (int)h, nullptr, nV, VMr, L.tsv}; ++ns; }
+            unsigned char *rZ = nullptr, *rA = nullptr;
+            float* rslab = nullptr;
+            WProdRPlan q_x, q_xb;
+            int ts_rz = 0, ts_ra = 0;
+            if (ride) {
+                ts_rz = row_bytes(extra->N); ts_ra = row_bytes(extra->K);
+                rZ = reinterpret_cast<unsigned char*>(extra->ws);
+                rA = rZ + align_up((size_t)extra->M * ts_rz, 256);
+                rslab = reinterpret_cast<float*>(rA + align_up((size_t)extra->M * ts_ra, 256));
+                q_x = plan_wgrad16r(extra->M, extra->N, extra->K);
+                q_xb = plan_wgrad16r(extra->M, extra->N, 1);
+                sj[ns] = SRJob{extra->Z, extra->ldz, extra->N, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, extra->M, rZ, ts_rz}; ++ns;
+                sj[ns] = SRJob{extra->A, extra->lda, extra->K, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, extra->M, rA, ts_ra}; ++ns;
+            }
+            DMPNN_TRY(launch_rows2sr(sj, ns, s));
+            ReduceJobs rj;
+            memset(&rj, 0, sizeof(rj));
+            rj.poison_flags = pflags; rj.poison_mask = pmask;
+            WProdRJob pj[8];
+            int np = 0;
+            float* slab = ws + L.sr_slab;
+            auto add = [&](const unsigned char* Z, int tsz, const unsigned char* A, int tsa, int64_t M, int N, int K, const WProdRPlan& q, float* sl,
+                           float* gW, int64_t ldgw, float* gb) {
+                pj[np++] = WProdRJob{Z, tsz, A, tsa, M, N, K, sl, q};
+                ReduceJob& r = rj.job[rj.n_jobs];
+                r.slab = sl; r.slab_stride = q.slab_stride; r.n_slabs = q.splits; r.ldk = q.ldk;
+                r.N = N; r.K = A ? K : 0; r.ones = A ? 0 : 1; r.gW = gW; r.ldgw = ldgw; r.gb = gb;
+                int64_t blocks = ((int64_t)N * (A ? K : 1) + 255) / 256;
+                if (blocks > 1024) blocks = 1024;
+                rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
+                ++rj.n_jobs;
+            };
+            auto next_slab = [&](const WProdRPlan& q) { float* p = slab; slab += align_up((size_t)q.splits * q.slab_stride, 64); return p; };
+            const unsigned char* gZr = br.gZ;
+            const unsigned char* Mr = static_cast<const unsigned char*>(f.msplit);
+            // (the big product first: the small ones fill its tail)
+            if (want_h && b->gW_h) add(gZr, L.tsr, Mr, L.tsr, nE * (T - 1), (int)h, (int)h, L.r_h, next_slab(L.r_h), b->gW_h, h, nullptr);
+            if (want_h && f.b_h && b->gb_h) add(gZr, L.tsr, nullptr, 0, nE * (T - 1), (int)h, 1, L.r_bh, next_slab(L.r_bh), nullptr, 0, b->gb_h);
+            if (want_o && b->gW_o) add(br.gZO, L.tsr, VMr, L.tsv, nV, (int)h, (int)(dv + h), L.r_o, next_slab(L.r_o), b->gW_o, dv + h, nullptr);
+            if (want_o && b->gb_o) add(br.gZO, L.tsr, nullptr, 0, nV, (int)h, 1, L.r_bo, next_slab(L.r_bo), nullptr, 0, b->gb_o);
+            if (want_i && b->gW_i) add(br.gH0, L.tsr, Xr, L.tsx, nE, (int)h, (int)(dv + de), L.r_i, next_slab(L.r_i), b->gW_i, dv + de, nullptr);
+            if (want_i && f.b_i && b->gb_i) add(br.gH0, L.tsr, nullptr, 0, nE, (int)h, 1, L.r_bi, next_slab(L.r_bi), nullptr, 0, b->gb_i);
+            if (ride) {
+                float* sl2 = rslab + align_up((size_t)q_x.splits * q_x.slab_stride, 64);
+                if (extra->gW) add(rZ, ts_rz, rA, ts_ra, extra->M, extra->N, extra->K, q_x, rslab, extra->gW, extra->ldgw, nullptr);
+                if (extra->gb && extra->ones) add(rZ, ts_rz, nullptr, 0, extra->M, extra->N, 1, q_xb, sl2, nullptr, 0, extra->gb);
+                if (extra_done) *extra_done = true;
+            }
+            DMPNN_TRY(launch_wgrad16r(pj, np, s));
+            if (rj.n_jobs > 0) {
+                hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
+                DMPNN_CHECK_LAUNCH("k_wgrad_reduce_multi");
+            }
+            if ((b->gW_h || b->gb_h) && T < 2) { zero2d(b->gW_h, h, h); zero2d(b->gb_h, 1, h); }
+            if (!f.b_h) zero2d(b->gb_h, 1, h);
+            if (!f.b_i) zero2d(b->gb_i, 1, h);
+            return DMPNN_OK;
+        }
         if (L.w16 && aligned16(f.Mv) && (T < 2 || (aligned16(f.Ms) && aligned16(gZs))) && aligned16(gH0) && aligned16(gZO)) {
             // ---- the three weight gradients on the f16 pipe: every operand split ONCE (one launch), three products, three reduces ----
             const bool want[3] = {b->gW_o || b->gb_o, (b->gW_h || b->gb_h) && T >= 2, b->gW_i || b->gb_i};

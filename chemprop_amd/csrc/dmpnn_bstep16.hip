@@ -8,13 +8,15 @@
 //       gH^(t)[r] = S'[dst r] - T[r],   S'[v] = sum of T over the rows of v          (first launch: gH^(T-1)[r] = gMv[dst r])
 //       gZ^(t)    = gH^(t) * tau'(z^(t))                                              (tau' from the kept sign bits: ReLU class)
 //       gM^(t)    = gZ^(t) W_h            -> T_next[rev r] = gM^(t)[r]                (base.py:135-141 transposed; f16 pipe, exact split)
-//   and gZ^(t) leaves as the OPERAND of the weight-gradient products (dmpnn_wgrad16.hip: tile-packed blocks, k_wgrad16t):
+//   and gZ^(t) leaves as the OPERAND of the weight-gradient products (dmpnn_wgrad16.hip, k_wgrad16r) — as split rows, the very A tile
+//   of the contraction copied out row by row:
 //       gW_h = sum_t gZ^(t)^T M^(t),   gW_i = (sum_t gZ^(t))^T x = sum_t gZ^(t)^T x   (no gH0 tensor: products over the steps)
 //
 // It replaces, per depth step of the per-step general route, one contraction launch (k_rows16: read gZ, write gM), one
 // k_edge_bwd launch (read gM, H, gH0; write gZ, gH0) and the gZ half of k_wsplit16 (read gZ, write blocks) by ONE launch that
-// reads T once and writes T_next and the gZ blocks once.  k_rows2blk turns the kept split rows (M^(t), x) into the products'
-// other operand: the A half of k_wsplit16 without the fp32 round trip.
+// reads T once and writes T_next and the gZ rows once.  The products' other operands are the forward's kept split rows (M^(t), x) as
+// they are: nothing is re-blocked (an earlier form of this file wrote tile-packed 8 KB blocks and converted the kept rows to them:
+// 0.57 ms per step of 40-atom x 4 096 for k_rows2blk alone, profiles/r04_train40_kernel_stats.txt).
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,23 +36,6 @@ using mega16::SplitW;
 using step16::BM;
 
 constexpr int RT = 3;
-constexpr int kBlk = 8192;       // bytes of one (64 features x 32 rows) block of a weight-gradient operand (dmpnn_wgrad16.hip)
-// TILE-PACKED operand of the products (k_wgrad16t): row tile t of the plan owns the slot rows [48 t, 48 t + 48) — rows beyond the
-// tile's own are zero — cut into 32-row chunks of one 8 KB block per 64-feature column tile; one power-of-two scale per 16-row
-// HALF of a chunk (a chunk may hold rows of two tiles: halves 3 t .. 3 t + 2 are tile t's).  ~45 of 48 slot rows are live.
-// slot rows 48 t + 8 gq .. + 7 (gq = 0..5): chunk and 16-byte piece (8 rows) inside the chunk's 32 rows
-__device__ __forceinline__ void tp_piece(int t, int gq, int& chunk, int& p8) {
-    const int R0 = 48 * t + 8 * gq;
-    chunk = R0 >> 5;
-    p8 = (R0 & 31) >> 3;
-}
-
-// byte offset of the 16-byte piece of feature n (of a 64-feature column tile), rows 8 p8 .. 8 p8 + 7 of a 32-row chunk (p8 = 0..3), hi / lo
-__device__ __forceinline__ int piece_off(int nloc, int p8, int lo) {
-    const int key = (nloc >> 1) & 7;
-    return nloc * 128 + (((p8 + (lo ? 4 : 0)) ^ key) << 4);
-}
-
 struct BStepK {
     int M, N;                                  // directed edges (rows), d_h
     const int* hdr;                            // plan header: flags, the number of row tiles actually used
@@ -60,8 +45,7 @@ struct BStepK {
     const float* gMv; int ldg;                 // [V][ldg] fp32: gH[r] = gMv[dst r]      (gather mode: the first launch)
     const unsigned char* bits; int bstride;    // [tau(z) > 0] of this site's rows, [M][bstride] bytes (null: tau' = 1)
     float neg;                                 // tau' where the bit is 0: 0 (ReLU), the slope (LeakyReLU)
-    unsigned char* Zblk; float* Zscale; int ld_chunks;   // gZ as tile-packed product operand: [column tile][ld_chunks][8 KB], scales [2 ld_chunks] (per 16-row half)
-    unsigned char* Zrows; int tsz;             // ... or (round 4, k_wgrad16r) as split ROWS [M][tsz]: the contraction's own A tile, row by row, the tile's scale in the tails
+    unsigned char* Zrows; int tsz;             // gZ as a product operand (k_wgrad16r): split ROWS [M][tsz] — the contraction's own A tile, row by row, the tile's scale in the tails
     SplitW W;                                  // pre-split W_h^T (fragment-major); p null: no contraction (the last site: gZ^(0) only)
     float* Tout; int ldo;                      // Tout[revp[r]] = gM[r]
     unsigned qmagic;                           // ceil(2^32 / (N / 4))
@@ -198,45 +182,6 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
     }
     __syncthreads();
     const float s = poison ? 1.f : scale_for(__uint_as_float(maxbits[0]));
-    // ---- gZ as product operand: the tile's slot of the tile-packed blocks.  Item = (feature, 8 slot rows): one 16-byte piece of
-    // hi and one of lo; consecutive lanes = the six row groups of a feature, then the next feature — a wave's store covers the
-    // 64 / 32 contiguous bytes a feature's pieces of one chunk make up, not 64 scattered pieces ----
-    if (g.Zblk) {
-        const h8 z8 = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        for (int it = tid; it < BN * 6; it += NT) {
-            const int n = it / 6, gq = it - n * 6;
-            float x[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int r = 8 * gq + jj;
-                const bool ok = r < nrows && n < g.N;
-                const float raw = T[(ok ? r : 0) * LDF + (ok ? n : 0)];
-                x[jj] = ok ? raw * s : 0.f;
-            }
-            h8 hi, lo;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) { hi[jj] = (_Float16)x[jj]; lo[jj] = (_Float16)(x[jj] - (float)hi[jj]); }
-            int chunk, p8;
-            tp_piece(t, gq, chunk, p8);
-            const int ct = n >> 6, nloc = n & 63;
-            unsigned char* blk = g.Zblk + ((long long)ct * g.ld_chunks + chunk) * kBlk;
-            *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 0)) = hi;
-            *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 1)) = lo;
-        }
-        // the scales of the tile's three halves; the LAST tile of an odd count also zeroes the half that completes its chunk
-        if (tid < 3) g.Zscale[3 * t + tid] = s;
-        if (t == n_tiles - 1 && (n_tiles & 1)) {
-            for (int it = tid; it < 2 * BN; it += NT) {       // (feature n, row group 6 | 7 = the 16 slot rows behind the tile)
-                const int n = it >> 1, ct = n >> 6, nloc = n & 63;
-                int chunk, p8;
-                tp_piece(t, 6 + (it & 1), chunk, p8);
-                unsigned char* blk = g.Zblk + ((long long)ct * g.ld_chunks + chunk) * kBlk;
-                *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 0)) = z8;
-                *reinterpret_cast<h8*>(blk + piece_off(nloc, p8, 1)) = z8;
-            }
-            if (tid == 0) g.Zscale[3 * n_tiles] = 1.f;
-        }
-    }
     const bool contract_on = g.W.p != nullptr;
     if (!contract_on && !g.Zrows) return;
     // ---- the split A tile of the contraction.  Item = (8 rows, 4 columns): read as fp32 BEFORE anyone overwrites the region with
@@ -281,7 +226,9 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
             const int r = it / npc, pc = it - r * npc;
             *reinterpret_cast<uint4*>(g.Zrows + (long long)(rs + r) * g.tsz + pc * 16) = *reinterpret_cast<const uint4*>(Ag + r * TS + pc * 16);
         }
-        if (tid < nrows) *reinterpret_cast<float4*>(g.Zrows + (long long)(rs + tid) * g.tsz + (g.tsz - 16)) = make_float4(s, 0.f, 0.f, 0.f);
+        // (tail: the tile's scale, and 1 where the whole tile is zero — such rows take no part in the product's common factor)
+        if (tid < nrows) *reinterpret_cast<float4*>(g.Zrows + (long long)(rs + tid) * g.tsz + (g.tsz - 16)) =
+            make_float4(s, (poison || __uint_as_float(maxbits[0]) > 0.f) ? 0.f : 1.f, 0.f, 0.f);
     }
     if (!contract_on) return;
 
@@ -366,84 +313,6 @@ __global__ __launch_bounds__(256, 2) void k_bstep16(BStepK g) {
     }
 }
 
-// ---- split rows -> product operand blocks: the kept M^(t) (rows of [hi 32 | lo 32] chunks + a tail with the row's scale) and the
-// split K1 operand x, tile by tile into the tile's 64-row slot.  One power-of-two scale per tile: the smallest of its rows' scales
-// (rows come from different producing tiles), the halfs of the other rows scaled DOWN by the exact ratio (a half that leaves the
-// f16 range this way belongs to a row whose values are negligible beside the tile's largest). ----
-struct Rows2BlkK {
-    const int* hdr; const int* tile_row;
-    const unsigned char* A; int ts;            // split rows [M][ts]: nc chunks of 128 B (+ padding) + the 16-byte tail at ts - 16
-    int C;                                     // logical columns (multiple-of-8 groups beyond C are zero in the rows)
-    int ones_col;                              // column that is 1 in every row (the bias gradient = column sums of gZ), or -1
-    unsigned char* blk; float* scale; int ld_chunks; int n_ct;   // tile-packed operand (see tp_piece): blocks, scales [2 ld_chunks]
-};
-__global__ __launch_bounds__(256) void k_rows2blk(Rows2BlkK g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ unsigned minbits;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
-    const int n_tiles = g.hdr[DMPNN_HDR_NTILES];
-    if (t >= n_tiles) return;
-    const int rs = g.tile_row[t], nrows = g.tile_row[t + 1] - rs;
-    if (nrows < 0 || nrows > BM) return;
-    if (tid == 0) minbits = 0x7f7fffffu;
-    const int TS = g.ts;
-    {   // the tile's rows are contiguous: LDS-DMA, 1 KiB per wave instruction
-        const unsigned nbytes = (unsigned)(nrows * TS);
-        const rsrc_t rA = gemm::make_rsrc(g.A + (long long)rs * TS, nbytes);
-        const int n_inst = (int)((nbytes + 1023u) >> 10);
-        for (int i = wave; i < n_inst; i += 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
-                                                     (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
-    }
-    __syncthreads();
-    if (tid < nrows) {
-        const float sv = *reinterpret_cast<const float*>(lds + tid * TS + (TS - 16));
-        const float sr = (sv > 0.f && sv < 3.0e38f) ? sv : 1.f;
-        atomicMin(&minbits, __float_as_uint(sr));   // (positive floats order like their bit patterns)
-    }
-    __syncthreads();
-    float S = nrows > 0 ? __uint_as_float(minbits) : 1.f;
-    if (g.ones_col >= 0 && S > 16384.f) S = 16384.f;   // (the column of ones must stay inside the f16 range: 1 * S <= 2^14)
-    const int nc_row = (TS - 16) / 128;                 // chunks a row holds
-    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-    // per-row ratio S / s_r (a power of two <= 1; 0 beyond the tile) once, in the rows' tails' place
-    __syncthreads();
-    if (tid < BM) {
-        const float sv = tid < nrows ? *reinterpret_cast<const float*>(lds + tid * TS + (TS - 16)) : 0.f;
-        const float sr = (sv > 0.f && sv < 3.0e38f) ? sv : 1.f;
-        *reinterpret_cast<float*>(lds + tid * TS + (TS - 16)) = tid < nrows ? S / sr : 0.f;
-    }
-    __syncthreads();
-    const int n_gq = (t == n_tiles - 1 && (n_tiles & 1)) ? 8 : 6;   // (the last tile of an odd count also zeroes the half behind it)
-    const int n_feat = g.n_ct * 64;
-    // item = (feature, 8 slot rows): consecutive lanes = the row groups of a feature, then the next feature (contiguous stores)
-    for (int it = tid; it < n_feat * n_gq; it += 256) {
-        const int n = it / n_gq, gq = it - n * n_gq;
-        const int cc = n >> 5, kk = n & 31;
-        h8v ph, pl;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int r = 8 * gq + jj;
-            const bool ok = r < nrows && cc < nc_row;
-            const unsigned char* p = lds + (ok ? r : 0) * TS + (ok ? cc : 0) * 128 + kk * 2;
-            const _Float16 ratio = (_Float16)(*reinterpret_cast<const float*>(lds + (ok ? r : 0) * TS + (TS - 16)));
-            const _Float16 a = *reinterpret_cast<const _Float16*>(p), b = *reinterpret_cast<const _Float16*>(p + 64);
-            ph[jj] = ok ? a * ratio : (_Float16)0;
-            pl[jj] = ok ? b * ratio : (_Float16)0;
-            if (n == g.ones_col) { ph[jj] = r < nrows ? (_Float16)S : (_Float16)0; pl[jj] = (_Float16)0; }
-        }
-        int chunk, p8;
-        tp_piece(t, gq, chunk, p8);
-        const int ct = n >> 6, nloc = n & 63;
-        unsigned char* blk = g.blk + ((long long)ct * g.ld_chunks + chunk) * kBlk;
-        *reinterpret_cast<h8v*>(blk + piece_off(nloc, p8, 0)) = ph;
-        *reinterpret_cast<h8v*>(blk + piece_off(nloc, p8, 1)) = pl;
-    }
-    if (tid < 3) g.scale[3 * t + tid] = S;
-    if (tid == 3 && n_gq == 8) g.scale[3 * n_tiles] = 1.f;
-}
-
 template <int WN>
 static int launch_bstep(const BStepK& g0, int n_tiles, hipStream_t s) {
     BStepK g = g0;
@@ -464,13 +333,6 @@ static int launch_bstep(const BStepK& g0, int n_tiles, hipStream_t s) {
 }  // namespace bstep16
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-// chunks of a tile-packed operand: 48 slot rows (1.5 chunks) per row tile of the plan's launch bound
-int64_t bstep16_ld_chunks(int64_t n_edges) { return (3 * fused_max_tiles(n_edges) + 1) / 2 + 1; }
-size_t bstep16_operand_bytes(int64_t n_edges, int64_t C) {  // blocks + scales (one per 16-row half) of one operand of C logical columns
-    const int64_t n_ct = (C + 63) / 64, ldc = bstep16_ld_chunks(n_edges);
-    return (size_t)(n_ct * ldc) * bstep16::kBlk + (((size_t)(2 * ldc) * 4 + 255) & ~size_t(255));
-}
-
 static unsigned qmagic_of(int64_t N) {
     const unsigned qn = (unsigned)(N / 4);
     return qn > 1 ? (unsigned)(((1ull << 32) + qn - 1) / qn) : 0u;
@@ -478,7 +340,7 @@ static unsigned qmagic_of(int64_t N) {
 
 // One backward step launch.  site: whose sign bits / which gZ; Tin null = gather mode (gH = gMv[dst]); W null = last site.
 int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const float* gMv, const SplitWView* W, float* Tout,
-                   unsigned char* Zblk, hipStream_t s, bool as_rows) {
+                   unsigned char* Zrows, hipStream_t s) {
     const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h;
     const PlanLayout L = plan_layout(nV, nE);
     const int* plan_i = static_cast<const int*>(f.plan);
@@ -493,13 +355,7 @@ int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const fl
     g.bstride = bn / 8;
     g.bits = f.act == DMPNN_ACT_NONE ? nullptr : static_cast<const unsigned char*>(f.keep_bits) + (size_t)site * (size_t)nE * (size_t)g.bstride;
     g.neg = f.act == DMPNN_ACT_RELU ? 0.f : (f.act == DMPNN_ACT_LEAKYRELU ? f.act_slope : 1.f);
-    g.ld_chunks = (int)bstep16_ld_chunks(nE);
-    if (as_rows) {   // (split rows [n_edges][split_row_bytes(d_h)] for k_wgrad16r)
-        g.Zrows = Zblk; g.tsz = step16::split_row_bytes((int)h);
-    } else {
-        g.Zblk = Zblk;
-        g.Zscale = reinterpret_cast<float*>(Zblk + (size_t)((h + 63) / 64) * (size_t)g.ld_chunks * bstep16::kBlk);
-    }
+    g.Zrows = Zrows; g.tsz = step16::split_row_bytes((int)h);   // (split rows [n_edges][split_row_bytes(d_h)] for k_wgrad16r)
     if (W) { g.W.p = W->p; g.W.inv_scale = W->inv_scale; g.W.nc = W->nc; }
     g.Tout = W ? Tout : nullptr; g.ldo = (int)f.ldh;
     g.qmagic = qmagic_of(h);
@@ -512,31 +368,6 @@ int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const fl
         case 4: return bstep16::launch_bstep<4>(g, n_tiles, s);
         default: return bstep16::launch_bstep<5>(g, n_tiles, s);
     }
-}
-
-// split rows (rows [n_edges][ts]) -> operand blocks of C logical columns (+ the column of ones at C when `ones`)
-int launch_rows2blk(const dmpnn_fwd_args& f, const unsigned char* rows, int ts, int C, int ones, unsigned char* blk, hipStream_t s) {
-    const int64_t nV = f.n_atoms, nE = f.n_edges;
-    const PlanLayout L = plan_layout(nV, nE);
-    const int* plan_i = static_cast<const int*>(f.plan);
-    bstep16::Rows2BlkK g;
-    memset(&g, 0, sizeof(g));
-    g.hdr = plan_i; g.tile_row = plan_i + L.tile_row;
-    g.A = rows; g.ts = ts; g.C = C; g.ones_col = ones ? C : -1;
-    g.n_ct = (C + (ones ? 1 : 0) + 63) / 64;
-    g.ld_chunks = (int)bstep16_ld_chunks(nE);
-    g.blk = blk;
-    g.scale = reinterpret_cast<float*>(blk + (size_t)g.n_ct * (size_t)g.ld_chunks * bstep16::kBlk);
-    const size_t lds = (size_t)step16::BM * ts;
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bstep16::k_rows2blk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_rows2blk, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
-        attr_set = lds;
-    }
-    hipLaunchKernelGGL(bstep16::k_rows2blk, dim3((unsigned)L.max_tiles), dim3(256), lds, s, g);
-    DMPNN_CHECK_LAUNCH("k_rows2blk");
-    return DMPNN_OK;
 }
 
 }  // namespace dmpnn

@@ -200,6 +200,7 @@ bool prepare_can_keep_mtiles(int64_t nV, int64_t nE);
 int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s,
                                int* mol_bounds = nullptr, int64_t n_mols = 0, const dmpnn_fwd_args* split_for = nullptr, bool* did_split = nullptr);
 bool mega16_split_args(const dmpnn_fwd_args& a, mega16::SplitArgs* sp);
+bool mega16_keeps_rows(const dmpnn_fwd_args& a);   // M^(t) kept as split rows in `msplit` (the product operands of k_wgrad16r)
 // dmpnn_prepare_tiles for a training step that also aggregates per molecule: *wrote_bounds says whether `mol_bounds` was filled
 // (the single-workgroup planner from the batch vector does it on the side; every other planner leaves it to dmpnn_molagg_bounds)
 int prepare_tiles_and_bounds(const int64_t* edge_index, const int64_t* rev, const int64_t* batch, int64_t nV, int64_t nE, void* plan,
@@ -282,18 +283,19 @@ struct WProdArgs {
 struct WProdPlan { int n_nt, n_kt, n_chunks, chunks_per_split, splits, ldk; int64_t slab_stride; };
 constexpr int kWProdMaxJobs = 8;
 struct WProdJobs { WProdArgs job[4]; int wg0[5]; int n_jobs; };  // several products in one launch: job j owns workgroups [wg0[j], wg0[j + 1]), multiples of 8
-// products over TILE-PACKED operands (written by the backward step kernels of dmpnn_bstep16.hip; k_wgrad16t)
-struct WProdTOperand { const unsigned char* blk; const float* scale; };   // blocks [column tile][ld_chunks][8 KB]; scales [2 ld_chunks]
-struct WProdTPlan { int n_ctz, n_kt, ld_chunks, splits, ldk; int64_t slab_stride; };
-WProdTPlan plan_wgrad16t(int64_t ld_chunks, int N, int Kt);
-int launch_wgrad16t(const WProdTOperand* Z, const WProdTOperand* A, int n, const WProdTPlan& p, int N, int Kt, float* slab,
-                    const int* n_tiles_dev, hipStream_t s);
 // products over operands in SPLIT-ROW form (rows of [hi 32 | lo 32] chunks + a tail with the row's scale: k_wgrad16r, round 4) — the
 // operands are consumed as the step kernels keep them, nothing is re-blocked
 struct WProdRPlan { int n_kg, splits, rows_per_split, ldk; int64_t slab_stride; };
-WProdRPlan plan_wgrad16r(int64_t M, int N, int K);
-int launch_wgrad16r(const unsigned char* const* Z, int tsz, const unsigned char* const* A, int tsa, int n, const WProdRPlan& p, int64_t M, int N, int K,
-                    float* slab, hipStream_t s);
+WProdRPlan plan_wgrad16r(int64_t M, int N, int K);   // (K = 1: the plan of a column-sum job)
+constexpr int kWProdRMaxJobs = 16;
+// one job: gW[N][K] = Z^T A over M rows into `plan.splits` slabs [N][plan.ldk] at `slab`;  A == nullptr: the column sums of Z (a bias
+// gradient) into column 0 of slabs [N][4]
+struct WProdRJob { const unsigned char* Z; int tsz; const unsigned char* A; int tsa; int64_t M; int N, K; float* slab; WProdRPlan plan; };
+int launch_wgrad16r(const WProdRJob* jobs, int n, hipStream_t s);
+// fp32 rows [A1[g1] || A2[g2]] -> split rows [M][ts] (k_rows2sr): the product operands no kernel already holds split
+struct SRJob { const float* A1; int64_t lda1; int K1; const int* g1; const long long* g1_64; int64_t g1_rows;
+               const float* A2; int64_t lda2; int K2; const int* g2; int64_t M; unsigned char* out; int ts; };
+int launch_rows2sr(const SRJob* jobs, int n, hipStream_t s);
 size_t wsplit16_bytes(int64_t M, int64_t C);
 // One more weight-gradient product for the launches of a backward pass on the f16 pipe (the predictor's first layer in a training
 // step: gW[N, K] = Z^T A, gb = colsum(Z) — 512 rows are 16 chunks beside the block's 1 140): rides in k_wsplit16 / k_wgrad16 /
@@ -316,15 +318,16 @@ int launch_wgrad16(const WProdJobs& jobs, hipStream_t s);
 int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s,
                            const mega16::SplitArgs* pending = nullptr);
 // the backward step kernels of that route's lean training forward (dmpnn_bstep16.hip)
-int64_t bstep16_ld_chunks(int64_t n_edges);
-size_t bstep16_operand_bytes(int64_t n_edges, int64_t C);
+// (Zrows: gZ of the site as split rows [n_edges][split_row_bytes(d_h)], a product operand of k_wgrad16r)
 int launch_bstep16(const dmpnn_fwd_args& f, int site, const float* Tin, const float* gMv, const SplitWView* W, float* Tout,
-                   unsigned char* Zblk, hipStream_t s, bool as_rows = false);
-int launch_rows2blk(const dmpnn_fwd_args& f, const unsigned char* rows, int ts, int C, int ones, unsigned char* blk, hipStream_t s);
+                   unsigned char* Zrows, hipStream_t s);
 // the data-gradient chain of the backward pass as one tile kernel (dmpnn_mega16_bwd.hip)
 size_t mega16_bwd_wsplit_bytes(int64_t h);
+// (rows: gZ^(t) [depth - 1 slots] / gH0 / gZO as split rows of tsr bytes instead of the fp32 tensors — see Mega16BwdK)
+struct Mega16BwdRows { unsigned char* gZ; unsigned char* gH0; unsigned char* gZO; int tsr; };
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,
-                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s, const float* g_edge = nullptr, int64_t ld_gedge = 0);
+                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s, const float* g_edge = nullptr, int64_t ld_gedge = 0,
+                           const Mega16BwdRows* rows = nullptr);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -86,6 +86,16 @@ bool mega16_split_args(const dmpnn_fwd_args& a, mega16::SplitArgs* spp) {
     return true;
 }
 
+// A training forward of the tile kernel (bond messages) keeps M^(t) as SPLIT ROWS in `msplit` — depth - 1 slots of n_edges rows of
+// split_row_floats(d_h) floats — when the caller provides that buffer: the weight-gradient product (k_wgrad16r) reads them as they are,
+// and so does dmpnn_backward decide (the same test on the same argument block)
+bool mega16_keeps_rows(const dmpnn_fwd_args& a) {
+    const unsigned need = DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP;
+    if ((a.flags & need) != need || (a.flags & DMPNN_F_ATOM) || a.depth < 2 || a.n_edges <= 0 || a.d_h > 320) return false;
+    const size_t bytes = (size_t)(a.depth - 1) * (size_t)a.n_edges * (size_t)(split_row_floats(a.d_h) * 4);
+    return a.msplit && aligned16(a.msplit) && a.msplit_bytes >= bytes;
+}
+
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s) {
     const int64_t nV = a.n_atoms, nE = a.n_edges;
     const WsLayout W = ws_layout(a);
@@ -136,6 +146,11 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
             G.atom_me = static_cast<float*>(a.msplit);
             G.me_slot = (long long)nE * mega16::kAtomK;
         }
+    }
+    if (mega16_keeps_rows(a)) {
+        G.Mrows = static_cast<unsigned char*>(a.msplit);
+        G.tsr = (int)(split_row_floats(a.d_h) * 4);
+        G.mrow_slot = (long long)nE * G.tsr;
     }
     g.dbg = g_debug_stamps;
     if (a.dropout_p > 0.f && a.dropout_p < 1.f) {  // (validated by dmpnn_forward: training forward, ReLU-class activation, no W_d)

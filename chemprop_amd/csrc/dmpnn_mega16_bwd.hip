@@ -22,7 +22,8 @@ size_t mega16_bwd_wsplit_bytes(int64_t h) {
 }
 
 int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ldg, const float* HO, int64_t ldho, float* gZO,
-                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s, const float* g_edge, int64_t ld_gedge) {
+                           float* gZs, float* gH0, void* wsplit, float* sp_gM, float* sp_Ta, hipStream_t s, const float* g_edge, int64_t ld_gedge,
+                           const Mega16BwdRows* rows) {
     const int64_t nV = f.n_atoms, nE = f.n_edges, h = f.d_h, dv = f.d_v;
     const size_t NT = (size_t)(h + 15) / 16, nc = (size_t)(h + 31) / 32;
     // the training forward already split both matrices behind its own pre-split weights (one launch for both passes) — unless the
@@ -61,6 +62,9 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     g.srcp = plan_i + L.srcp; g.d_v = (int)dv; g.W_o = f.W_o; g.W_h = f.W_h; g.sp_gM = sp_gM; g.sp_Ta = sp_Ta;
     g.atom = atom ? 1 : 0;
     g.g_edge = g_edge; g.ld_ge = (int)ld_gedge;
+    if (rows && rows->gZ) {   // the gradients as split rows: the operands of the products on split rows (k_wgrad16r)
+        g.gZrows = rows->gZ; g.gH0rows = rows->gH0; g.gZOrows = rows->gZO; g.tsr = rows->tsr; g.zrow_slot = (long long)nE * rows->tsr;
+    }
     g.drop_scale = (f.dropout_p > 0.f && f.dropout_p < 1.f) ? 1.f / (1.f - f.dropout_p) : 0.f;
     if (f.keep_bits && (f.flags & DMPNN_F_TILE_PLAN)) {  // the forward kept H0 / H^(t) as sign bits (dmpnn_fwd_args.keep_bits)
         g.keep_bits = static_cast<const unsigned long long*>(f.keep_bits);

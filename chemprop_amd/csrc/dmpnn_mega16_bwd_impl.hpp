@@ -52,6 +52,11 @@ struct Mega16BwdK {
     // read-out of the mol-atom-bond blocks (mol_atom_bond.py:221-264) — added to the aggregation's gradient before tau'.  [E, ld_ge]
     // in the kept tensors' row order, 16-byte aligned rows; NULL: none
     const float* g_edge; int ld_ge;
+    // Round 4: gZ^(t) (slot t - 1, zrow_slot bytes apart), gH0 and gZO leave as SPLIT ROWS of `tsr` bytes — the pieces this kernel stages
+    // for its own contractions, with the tile's scale in the row tails — the operands of the weight-gradient product on split rows
+    // (k_wgrad16r); the fp32 tensors gZs / gH0 / gZO are then written by the generic path of a molecule beyond the tile only (which
+    // converts its rows at the end).  null: fp32 rows as before
+    unsigned char* gZrows; unsigned char* gH0rows; unsigned char* gZOrows; int tsr; long long zrow_slot;
 };
 
 template <int WN>
@@ -126,6 +131,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         v.W_o = g.W_o; v.W_h = g.W_h; v.gM = g.sp_gM; v.Ta = g.sp_Ta;
         v.g_edge = g.g_edge; v.ld_ge = g.ld_ge;
         spill::backward(v, reinterpret_cast<float*>(lds));
+        if (g.gZrows) {   // this molecule's gradients, fp32 rows, also as the split rows the products read
+            __threadfence_block();
+            __syncthreads();
+            const int w_ = (int)(threadIdx.x >> 6), l_ = (int)(threadIdx.x & 63);
+            for (int sl = 0; sl < T_steps - 1; ++sl)
+                rows_to_sr(g.gZs + (long long)sl * g.slot, g.ldh, rs, nrows, N, g.gZrows + (long long)sl * g.zrow_slot, g.tsr, w_, l_, kThreads / 64);
+            rows_to_sr(g.gH0, g.ldh, rs, nrows, N, g.gH0rows, g.tsr, w_, l_, kThreads / 64);
+            rows_to_sr(g.gZO, g.ldh, va, na, N, g.gZOrows, g.tsr, w_, l_, kThreads / 64);
+        }
         return;
     }
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
@@ -169,6 +183,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
                 for (int s = 0; s < T_steps - 1; ++s) g.gZs[(long long)s * g.slot + o] = nanv;
             }
             for (int i = tid; i < na * N; i += kThreads) g.gZO[(long long)(va + i / N) * g.ldh + (i % N)] = nanv;
+            if (g.gZrows) {   // ... and as split rows (what the products read): NaN in every hi half, scale 1
+                const int nh = ((N + 31) >> 5) * 32;   // hi halfs of a row's live chunks
+                const _Float16 hn = (_Float16)nanv;
+                auto nan_rows = [&](unsigned char* base, long long r0, int n) {
+                    for (int i = tid; i < n * nh; i += kThreads) {
+                        const int r = i / nh, c = i - r * nh;
+                        *reinterpret_cast<_Float16*>(base + (r0 + r) * g.tsr + (c >> 5) * 128 + (c & 31) * 2) = hn;
+                    }
+                    for (int r = tid; r < n; r += kThreads) *reinterpret_cast<float4*>(base + (r0 + r) * g.tsr + (g.tsr - 16)) = make_float4(1.f, 0.f, 0.f, 0.f);
+                };
+                for (int sl = 0; sl < T_steps - 1; ++sl) nan_rows(g.gZrows + (long long)sl * g.zrow_slot, rs, nrows);
+                nan_rows(g.gH0rows, rs, nrows);
+                nan_rows(g.gZOrows, va, na);
+            }
             return;
         }
     } else {
@@ -235,12 +263,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         return __uint_as_float((unsigned)m);
     };
     int scale_phase = 0;
+    float tile_mx = 0.f;   // the maximum the last tile_scale call saw (0: an all-zero tile — the tails of its split rows say so)
     auto tile_scale = [&](float local_max) -> float {
         const int slot = scale_phase & 3;
         local_max = wave_max(local_max);
         if (lane == 0) atomicMax(&maxbits[slot], __float_as_uint(local_max));
         __syncthreads();
         const float mx = __uint_as_float(maxbits[slot]);
+        tile_mx = mx;
         if (tid == 0) maxbits[(slot + 2) & 3] = 0u;
         ++scale_phase;
         return scale_for(mx);
@@ -430,7 +460,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         return mx;
     };
     // transposed fragments -> split A tile of the next contraction (all 48 rows, zero where there is no row / column)
-    auto stage_rows = [&](const f32x4 (&m)[WN][RT_E], float s) {
+    // `rows` (or null): the same pieces also to the split rows [n_edges][tsr] of a product operand, the scale into the rows' tails;
+    // to_lds false: those alone (gH0: nothing contracts it here)
+    auto stage_rows = [&](const f32x4 (&m)[WN][RT_E], float s, unsigned char* rows, bool to_lds) {
         launder();
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) {
@@ -440,9 +472,48 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
                 const int row = jt * 16 + li;
                 h4 hi, lo;
                 split4(make_float4(m[ct][jt][0], m[ct][jt][1], m[ct][jt][2], m[ct][jt][3]), s, hi, lo);
-                unsigned char* p = T16 + row * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
-                *reinterpret_cast<h4*>(p) = hi;
-                *reinterpret_cast<h4*>(p + 64) = lo;
+                if (to_lds) {
+                    unsigned char* p = T16 + row * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
+                    *reinterpret_cast<h4*>(p) = hi;
+                    *reinterpret_cast<h4*>(p + 64) = lo;
+                }
+                if (rows && row < nrows && col4 < N) {   // (rows: uniform)
+                    unsigned char* q = rows + (long long)(rs + row) * g.tsr + (col4 >> 5) * 128 + (col4 & 31) * 2;
+                    *reinterpret_cast<h4*>(q) = hi;
+                    *reinterpret_cast<h4*>(q + 64) = lo;
+                }
+            }
+        }
+        if (rows && wave == 0 && lg == 0) {
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt)
+                if (jt * 16 + li < nrows)
+                    *reinterpret_cast<float4*>(rows + (long long)(rs + jt * 16 + li) * g.tsr + (g.tsr - 16)) = make_float4(s, tile_mx > 0.f ? 0.f : 1.f, 0.f, 0.f);
+        }
+    };
+    // the gradient with respect to H0 leaves: fp32 rows, or (split rows) with a tile scale of its own
+    auto store_gh0 = [&](const f32x4 (&x)[WN][RT_E]) {
+        launder();
+        if (g.gH0rows) {   // (uniform)
+            float mx = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+                for (int jt = 0; jt < RT_E; ++jt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) mx = fmaxf(mx, fabsf(x[ct][jt][c]));
+            const float s0 = tile_scale(mx);
+            stage_rows(x, s0, g.gH0rows, false);
+            return;
+        }
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+#pragma unroll
+            for (int jt = 0; jt < RT_E; ++jt) {
+                const int row = jt * 16 + li;
+                if (row < nrows && col4 < N)
+                    store_keep4(g.gH0 + (long long)(rs + row) * g.ldh + col4, make_float4(x[ct][jt][0], x[ct][jt][1], x[ct][jt][2], x[ct][jt][3]));
             }
         }
     };
@@ -466,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             z[j] = ok ? make_float4(dact(gv.x, yv.x, false), dact(gv.y, yv.y, false), dact(gv.z, yv.z, false), dact(gv.w, yv.w, false))
                       : make_float4(0.f, 0.f, 0.f, 0.f);
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(z[j].x), fabsf(z[j].y)), fmaxf(fabsf(z[j].z), fabsf(z[j].w))));
-            if (ok) store_keep4(g.gZO + row * g.ldh + 4 * q, z[j]);
+            if (ok && !g.gZOrows) store_keep4(g.gZO + row * g.ldh + 4 * q, z[j]);
         }
         sA = tile_scale(mx);
 #pragma unroll
@@ -478,7 +549,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             unsigned char* p = T16 + a * TS + (q >> 3) * 128 + (q & 7) * 8;
             *reinterpret_cast<h4*>(p) = hi;
             *reinterpret_cast<h4*>(p + 64) = lo;
+            if (g.gZOrows && a < na && q < qn) {   // (gZOrows: uniform) the same pieces to the atoms' split rows
+                unsigned char* o = g.gZOrows + (long long)(va + a) * g.tsr + (q >> 3) * 128 + (q & 7) * 8;
+                *reinterpret_cast<h4*>(o) = hi;
+                *reinterpret_cast<h4*>(o + 64) = lo;
+            }
         }
+        if (g.gZOrows && tid < na) *reinterpret_cast<float4*>(g.gZOrows + (long long)(va + tid) * g.tsr + (g.tsr - 16)) = make_float4(sA, tile_mx > 0.f ? 0.f : 1.f, 0.f, 0.f);
     }
     // gMv = gZO . W_o[:, d_v:]
     f32x4 m[WN][RT_E];
@@ -512,18 +589,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     }
     f32x4 gh0[WN][RT_E];
     if (T_steps == 1) {
-        mask_rows(m, g.H0, true, g.gH0, 0);
+        mask_rows(m, g.H0, true, g.gH0rows ? nullptr : g.gH0, 0);
+        if (g.gH0rows) store_gh0(m);
         return;
     }
     // gZ^(T-1) = gH * tau'(H^(T-1));  gH0 = gZ^(T-1)
     {
-        const float mx = mask_rows(m, g.Hs + (long long)(T_steps - 2) * g.slot, false, g.gZs + (long long)(T_steps - 2) * g.slot, T_steps - 1);
+        const float mx = mask_rows(m, g.Hs + (long long)(T_steps - 2) * g.slot, false, g.gZrows ? nullptr : g.gZs + (long long)(T_steps - 2) * g.slot, T_steps - 1);
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] = m[ct][jt];
         sA = tile_scale(mx);  // (barrier: every wave is past its reads of T16)
-        stage_rows(m, sA);
+        stage_rows(m, sA, g.gZrows ? g.gZrows + (long long)(T_steps - 2) * g.zrow_slot : nullptr, true);
     }
     for (int t = T_steps - 1; t >= 1; --t) {
         f32x4 acc[RT_E][WN];
@@ -535,13 +613,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         unscale(RE{}, acc, 1.f / sA, g.WhT.inv_scale);
         incidence(RE{}, acc, 3, m);              // gH^(t-1) = C^T gM
         if (t - 1 >= 1) {
-            const float mx = mask_rows(m, g.Hs + (long long)(t - 2) * g.slot, false, g.gZs + (long long)(t - 2) * g.slot, t - 1);
+            const float mx = mask_rows(m, g.Hs + (long long)(t - 2) * g.slot, false, g.gZrows ? nullptr : g.gZs + (long long)(t - 2) * g.slot, t - 1);
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct)
 #pragma unroll
                 for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] += m[ct][jt];
             sA = tile_scale(mx);
-            stage_rows(m, sA);
+            stage_rows(m, sA, g.gZrows ? g.gZrows + (long long)(t - 2) * g.zrow_slot : nullptr, true);
         } else {
             mask_rows(m, g.H0, true, nullptr, 0);   // through H^(0) = tau(H0)
 #pragma unroll
@@ -550,17 +628,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
                 for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] += m[ct][jt];
         }
     }
-    launder();
-#pragma unroll
-    for (int ct = 0; ct < WN; ++ct) {
-        const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
-#pragma unroll
-        for (int jt = 0; jt < RT_E; ++jt) {
-            const int row = jt * 16 + li;
-            if (row < nrows && col4 < N)
-                store_keep4(g.gH0 + (long long)(rs + row) * g.ldh + col4, make_float4(gh0[ct][jt][0], gh0[ct][jt][1], gh0[ct][jt][2], gh0[ct][jt][3]));
-        }
-    }
+    store_gh0(gh0);
 }
 
 template <int WN, bool SA>

@@ -58,6 +58,11 @@ struct Mega16K {
     // (columns >= d_e zero), written once per kept message slot (me_slot floats apart) — dmpnn_backward's W_h product then reads
     // [M^(t) || ME] as ONE operand over all steps' rows
     float* atom_me; long long me_slot;
+    // Round 4 (bond messages, training): M^(t) is kept as SPLIT ROWS — the very pieces the next contraction's A tile is made of, written
+    // to memory beside it with the tile's scale in the row tails (rows of `tsr` bytes, slot t - 1 at mrow_slot bytes) — because that is
+    // what the weight-gradient product reads (k_wgrad16r): no fp32 copy, no re-blocking pass.  null: fp32 rows in m.Ms as before
+    // (atom messages; the generic path of a molecule beyond the tile still writes m.Ms and converts its rows at the end)
+    unsigned char* Mrows; int tsr; long long mrow_slot;
     // dmpnn_fwd_args.keep_bits (training on a tile plan, ReLU-class activation, no dropout): H0 and H^(t) leave the kernel as ONE
     // bit per element — [x > 0], all the backward tile kernel needs of them — in the order of the matrix-pipe fragments: word
     // (rt WN + ct) 4 + r of wave w of tile t (64 words per wave, 256 per tile) is the ballot of "element (row rt 16 + 4 lg + r, column
@@ -141,6 +146,36 @@ __device__ __forceinline__ void split_weights_wave(const SplitArgs& a, int wave,
 }
 static __global__ __launch_bounds__(256) void k_split_weights(SplitArgs a) {
     split_weights_wave(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// fp32 rows -> split rows (one wave per row, its own power-of-two scale): the generic path's kept tensors, for a molecule beyond the tile
+__device__ __forceinline__ void rows_to_sr(const float* src, long long ld, long long row0, int nrows, int N, unsigned char* dst, int ts,
+                                           int wave, int lane, int n_waves) {
+    for (int r = wave; r < nrows; r += n_waves) {
+        const float* x = src + (row0 + r) * ld;
+        float v[8];
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < N ? x[c] : 0.f;
+            mx = fmaxf(mx, fabsf(v[j]));
+        }
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float sc = scale_for(mx);
+        unsigned char* o = dst + (row0 + r) * ts;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane + 64 * j;
+            if (c < N) {
+                const float y = v[j] * sc;
+                const _Float16 hi = (_Float16)y;
+                *reinterpret_cast<_Float16*>(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
+                *reinterpret_cast<_Float16*>(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = (_Float16)(y - (float)hi);
+            }
+        }
+        if (lane == 0) *reinterpret_cast<float4*>(o + (ts - 16)) = make_float4(sc, mx > 0.f ? 0.f : 1.f, 0.f, 0.f);   // (scale, zero-row flag: k_wgrad16r)
+    }
 }
 
 // LDS: ONE tile region holds, at different times, the split A tile of a contraction, the K1 / V operand staging tile and
@@ -242,6 +277,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         }
         spill::forward(mega::spill_view(gs, gs.flags[DMPNN_HDR_LIGHT] == 2, rs, nrows, va, na, gs.slope_ptr ? *gs.slope_ptr : gs.slope),
                        reinterpret_cast<float*>(lds));
+        if constexpr (KEEP) {
+            const Mega16K& Gs = *spill::fresh_kernargs<Mega16K>();
+            if (Gs.Mrows && gs.Ms) {   // the kept messages of this molecule, fp32 rows in Ms, also as the split rows the product reads
+                __threadfence_block();
+                __syncthreads();
+                for (int sl = 0; sl < gs.depth - 1; ++sl)
+                    rows_to_sr(gs.Ms + (long long)sl * gs.slot, gs.ldh, rs, nrows, gs.h, Gs.Mrows + (long long)sl * Gs.mrow_slot, Gs.tsr,
+                               (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), kThreads / 64);
+            }
+        }
         return;
     }
     const float slope = g.slope_ptr ? *g.slope_ptr : g.slope;
@@ -396,12 +441,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     // four slots: call p uses slot p & 3 and re-arms slot (p + 2) & 3 behind its barrier (last read before
     // barrier p - 1, next written after barrier p + 1), so no extra barrier is spent on the reset.
     int scale_phase = 0;
+    float tile_mx = 0.f;   // the maximum the last tile_scale call saw (0: an all-zero tile — its kept split rows say so in their tails)
     auto tile_scale = [&](float local_max) -> float {
         const int slot = scale_phase & 3;
         local_max = wave_max(local_max);
         if (lane == 0) atomicMax(&maxbits[slot], __float_as_uint(local_max));  // non-negative floats order like their bits
         __syncthreads();
         const float mx = __uint_as_float(maxbits[slot]);
+        tile_mx = mx;
         if (tid == 0) maxbits[(slot + 2) & 3] = 0u;
         ++scale_phase;
         return scale_for(mx);
@@ -661,7 +708,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     // The result lands as 4 consecutive columns of row r' (li) per lane: split with the tile scale of the
     // next contraction and written to T16 as 8-byte pieces; the fp32 copy streams to `keep`.
     static_assert(RT_E == 3 && RT_A == 2, "segment MFMAs are laid out for 48-row / 32-atom tiles");
-    auto segment_mfma = [&](const f32x4 (&H)[RT_E][WN], bool last, float* keep, int keep_ld) -> float {
+    auto segment_mfma = [&](const f32x4 (&H)[RT_E][WN], bool last, float* keep, int keep_ld, unsigned char* keep_rows) -> float {
         launder();
         float hm = 0.f;
 #pragma unroll
@@ -732,9 +779,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                     *reinterpret_cast<h4*>(p) = hi;
                     *reinterpret_cast<h4*>(p + 64) = lo;
                     if constexpr (KEEP) {
-                        if (keep && row < n_keep && col4 < N) store_keep4(keep + (keep0 + row) * keep_ld + col4, v);
+                        if (keep_rows) {   // (uniform) the same two pieces, to the kept split row
+                            if (row < n_keep && col4 < N) {
+                                unsigned char* q = keep_rows + (keep0 + row) * G.tsr + (col4 >> 5) * 128 + (col4 & 31) * 2;
+                                *reinterpret_cast<h4*>(q) = hi;
+                                *reinterpret_cast<h4*>(q + 64) = lo;
+                            }
+                        } else if (keep && row < n_keep && col4 < N) {
+                            store_keep4(keep + (keep0 + row) * keep_ld + col4, v);
+                        }
                     }
                 }
+            }
+        }
+        if constexpr (KEEP) {
+            if (keep_rows && wave == 0 && lg == 0) {   // the rows' tails: the tile's scale
+#pragma unroll
+                for (int jt = 0; jt < RT_E; ++jt)
+                    if (jt * 16 + li < n_keep)
+                        *reinterpret_cast<float4*>(keep_rows + (keep0 + jt * 16 + li) * G.tsr + (G.tsr - 16)) = make_float4(s, tile_mx > 0.f ? 0.f : 1.f, 0.f, 0.f);
             }
         }
         return s;
@@ -777,7 +840,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
             for (int ct = 0; ct < WN; ++ct) y[rt][ct] = h0[rt][ct];
         act_frags(RE{}, F_{}, y, y);
-        sA = segment_mfma(y, T_steps == 1, T_steps == 1 ? g.Mv : g.Ms, g.ldh);
+        sA = segment_mfma(y, T_steps == 1, T_steps == 1 ? g.Mv : (G.Mrows ? nullptr : g.Ms), g.ldh, T_steps == 1 ? nullptr : G.Mrows);
     }
     stamp();  // 4: K1 epilogue + first message
     if (G.atom_de) {
@@ -879,7 +942,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             tile_to_global(g.Hs + (long long)(step - 1) * g.slot, rs, g.ldh, nrows);
         }
         const bool last = step == T_steps - 1;
-        sA = segment_mfma(acc, last, last ? g.Mv : (g.Ms ? g.Ms + (long long)step * g.slot : nullptr), g.ldh);
+        sA = segment_mfma(acc, last, last ? g.Mv : ((g.Ms && !G.Mrows) ? g.Ms + (long long)step * g.slot : nullptr), g.ldh,
+                          (last || !G.Mrows) ? nullptr : G.Mrows + (long long)step * G.mrow_slot);
         stamp();  // 6, 8, ...: update epilogue + message / aggregate
     }
 

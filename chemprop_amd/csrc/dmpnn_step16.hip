@@ -44,8 +44,6 @@ bool fused16_lean_shapes(const dmpnn_fwd_args& a) {
     if (!(a.act == DMPNN_ACT_NONE || a.act == DMPNN_ACT_RELU || a.act == DMPNN_ACT_LEAKYRELU)) return false;
     if (a.W_d || a.dropout_p > 0.f || a.depth < 2 || a.n_edges <= 0 || a.n_atoms <= 0) return false;
     if (a.d_h <= 0 || a.d_h % 4 != 0 || a.ldh % 4 != 0 || a.d_v % 2 || a.d_e % 2 || a.ldv % 2 || a.lde % 2) return false;
-    // (the backward's tile-packed product operands are addressed through 32-bit buffer offsets)
-    if ((int64_t)((a.d_h + 63) / 64) * bstep16_ld_chunks(a.n_edges) * 8192 > 0x7FFFFFFF) return false;
     return x_path_shapes(a);
 }
 size_t fused16_lean_bits_bytes(const dmpnn_fwd_args& a) {

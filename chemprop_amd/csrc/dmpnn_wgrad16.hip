@@ -209,158 +209,48 @@ __global__ __launch_bounds__(256) void k_wgrad16(WProdJobs jobs) {
         }
 }
 
-// k_wgrad16t ------------------------------------------------------------------------------------------------------------
-// The product over TILE-PACKED operands (dmpnn_bstep16.hip: written tile by tile by the backward step kernels, 48 slot rows per row
-// tile of the plan, one scale per 16-row half, the tile count on the device only).  Output tile: ALL n (<= 320 rows: every column
-// tile of Z) x 64 k per workgroup — wave w owns the 16-row tiles w, w + 4, ... of n (<= 5) and all four 16-column tiles of k:
-// 60 MFMAs per wave and 32-row chunk from 18 KB of LDS fragment reads (the 64 x 64 kernel above reads 10 KB per 12 MFMAs and is
-// bound by the LDS, not by the matrix pipe), Z is streamed once per k tile instead of once per (n tile, k tile).
-// Scales: within a chunk the two halves may belong to different tiles, and every chunk has its own — instead of fresh accumulators
-// and one multiply-add per chunk and element, the Z fragments are scaled DOWN by the exact power of two rho = F / (s_Z s_A) of
-// their half, F = the smallest s_Z s_A of the workgroup's whole row range: the products of all chunks then share the factor F and
-// accumulate in the matrix pipe (a half whose rho leaves the f16 range holds values negligible beside the range's largest).
-struct WProdT {
-    const unsigned char* Z; const float* sZ;   // blocks [n_ctz][ld_chunks][8 KB]; scales [2 ld_chunks]
-    const unsigned char* A; const float* sA;   // blocks [n_kt][ld_chunks][8 KB]
-    int n_ctz, n_kt, ld_chunks, splits;
-    int N, Kt; float* slab; int ldk; long long slab_stride;
-};
-struct WProdTJobs { WProdT job[kWProdMaxJobs]; int wg0[kWProdMaxJobs + 1]; int n_jobs; const int* n_tiles_dev; };
-}  // namespace wg16
-
-namespace wg16 {
-constexpr int kRTW = 5;  // 16-row tiles of n per wave (20 = 320 rows per workgroup)
-constexpr int kKT2 = 2;  // 64-column tiles of k per workgroup: Z (all of n: up to 40 KB per chunk) is streamed once per 128 columns of k
-
-__global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [n_ctz Z blocks | kKT2 A blocks] of the current chunk, then 64 B
+// k_rows2sr ---------------------------------------------------------------------------------------------------------------
+// fp32 rows [A1[g1(m)] || A2[g2(m)]] -> split rows (whole 32-column chunks of [hi | lo] + the tail with the row's own power-of-two
+// scale): the operands of k_wgrad16r that no kernel already holds split — the K1 operand [V[src] || E], the finalize's [V || Mv], a
+// rider's plain rows.  One wave per row, several operands per launch.
+struct SRJobs { SRJob job[4]; int wg0[5]; int n_jobs; };
+__global__ __launch_bounds__(256) void k_rows2sr(SRJobs a) {
     int j = 0;
-    while (j + 1 < jobs.n_jobs && (int)blockIdx.x >= jobs.wg0[j + 1]) ++j;
-    const WProdT& a = jobs.job[j];
-    const int local = (int)blockIdx.x - jobs.wg0[j];
-    const int n_kg = (a.n_kt + kKT2 - 1) / kKT2;             // workgroup columns of k
-    const int per = (jobs.wg0[j + 1] - jobs.wg0[j]) >> 3;   // XCD-aware order: the k columns of one row split share an L2 (they stream the same Z blocks)
-    const int rank = (local & 7) * per + (local >> 3);
-    if (rank >= n_kg * a.splits) return;
-    const int split = rank / n_kg, kg = rank - split * n_kg;
-    const int n_ka = a.n_kt - kKT2 * kg < kKT2 ? a.n_kt - kKT2 * kg : kKT2;   // live k tiles of this column (the last one may hold fewer)
-    const int n_tiles = *jobs.n_tiles_dev;
-    const int n_half = 3 * n_tiles;
-    int n_act = (n_half + 1) >> 1;
-    if (n_act > a.ld_chunks) n_act = a.ld_chunks;
-    const int cps = (n_act + a.splits - 1) / a.splits;
-    const int c_lo = split * cps;
-    const int c_hi = c_lo + cps < n_act ? c_lo + cps : n_act;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    unsigned* red = reinterpret_cast<unsigned*>(lds + (a.n_ctz + kKT2) * kBlk);
-    // ---- F: the smallest s_Z s_A over the halves of this workgroup's range ----
-    if (tid == 0) red[0] = 0x7f7fffffu;
-    __syncthreads();
-    {
-        float f = 3.0e38f;
-        const int h_lo = 2 * c_lo, h_hi = 2 * c_hi < n_half ? 2 * c_hi : n_half;
-        for (int hh = h_lo + tid; hh < h_hi; hh += 256) f = fminf(f, a.sZ[hh] * a.sA[hh]);
-        for (int off = 32; off > 0; off >>= 1) f = fminf(f, __shfl_xor(f, off));
-        if (lane == 0 && f > 0.f) atomicMin(&red[0], __float_as_uint(f));   // (positive floats order like their bit patterns)
+    while (j + 1 < a.n_jobs && (int)blockIdx.x >= a.wg0[j + 1]) ++j;
+    const SRJob& J = a.job[j];
+    const int lane = threadIdx.x & 63;
+    const int64_t m = ((int64_t)blockIdx.x - a.wg0[j]) * 4 + (threadIdx.x >> 6);
+    if (m >= J.M) return;
+    int64_t r1 = J.g1 ? (int64_t)J.g1[m] : (J.g1_64 ? (int64_t)J.g1_64[m] : m);
+    if (J.g1 || J.g1_64) r1 = r1 < 0 ? 0 : (r1 >= J.g1_rows ? J.g1_rows - 1 : r1);   // (an index out of range: the plan's verdict poisons the result)
+    const int64_t r2 = J.g2 ? (int64_t)J.g2[m] : m;
+    const float* x1 = J.A1 + r1 * J.lda1;
+    const float* x2 = J.K2 ? J.A2 + r2 * J.lda2 : x1;
+    const int K = J.K1 + J.K2;
+    float v[8];
+    float mx = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int c = lane + 64 * jj;
+        v[jj] = c < J.K1 ? x1[c] : (c < K ? x2[c - J.K1] : 0.f);
+        mx = fmaxf(mx, fabsf(v[jj]));
     }
-    __syncthreads();
-    const float F = __uint_as_float(red[0]);
-    f32x4 acc[kRTW][4 * kKT2];
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float sc = scale_for(mx);
+    unsigned char* o = J.out + m * J.ts;
+    const int cols = ((K + 31) >> 5) << 5;   // whole chunks: the padding columns are written (zeros)
 #pragma unroll
-    for (int r = 0; r < kRTW; ++r)
-#pragma unroll
-        for (int kt = 0; kt < 4 * kKT2; ++kt) acc[r][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // fragment addresses: Z row tile g = wave + 4 r -> feature rows 16 g + li of column tile g >> 2; A rows 16 kt + li of block kt >> 2
-    const int n_rt = a.n_ctz * 4;
-    int zoff_h[kRTW], zoff_l[kRTW];
-#pragma unroll
-    for (int r = 0; r < kRTW; ++r) {
-        const int gt = wave + 4 * r;
-        const int ct = gt >> 2, nloc = ((gt & 3) << 4) + li, key = (nloc >> 1) & 7;
-        zoff_h[r] = gt < n_rt ? ct * kBlk + nloc * 128 + ((lg ^ key) << 4) : -1;
-        zoff_l[r] = gt < n_rt ? ct * kBlk + nloc * 128 + (((lg + 4) ^ key) << 4) : -1;
-    }
-    int aoff_h[4], aoff_l[4];   // (inside an A block)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const int arow = 16 * kt + li, akey = (arow >> 1) & 7;
-        aoff_h[kt] = a.n_ctz * kBlk + arow * 128 + ((lg ^ akey) << 4);
-        aoff_l[kt] = a.n_ctz * kBlk + arow * 128 + (((lg + 4) ^ akey) << 4);
-    }
-    const unsigned zbytes = (unsigned)a.n_ctz * (unsigned)a.ld_chunks * (unsigned)kBlk;
-    const rsrc_t rZ = gemm::make_rsrc(a.Z, zbytes);
-    const rsrc_t rA = gemm::make_rsrc(a.A + (long long)(kKT2 * kg) * a.ld_chunks * kBlk, (unsigned)n_ka * (unsigned)a.ld_chunks * (unsigned)kBlk);
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    const int n_inst = (a.n_ctz + n_ka) * 8;
-    // (the k columns of one row split start one chunk apart: a Z block one column has just pulled into the XCD's L2 is the next
-    //  column's hit — all of them asking for the same lines at the same instant were each served from memory)
-    const int n_c = c_hi - c_lo;
-    for (int ci = 0; ci < n_c; ++ci) {
-        const int c = c_lo + (ci + kg) % n_c;
-        // the chunk's blocks: every column tile of Z, the k column's blocks of A — 1 KiB per wave instruction, no registers
-        for (int i = wave; i < n_inst; i += 4) {
-            const int b = i >> 3, part = i & 7;
-            if (b < a.n_ctz)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rZ, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
-                                                         (unsigned)(((long long)b * a.ld_chunks + c) * kBlk + part * 1024 + lane * 16), 0, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(lds + i * 1024), 16,
-                                                         (unsigned)(((long long)(b - a.n_ctz) * a.ld_chunks + c) * kBlk + part * 1024 + lane * 16), 0, 0, 0);
+    for (int jj = 0; jj < 8; ++jj) {
+        const int c = lane + 64 * jj;
+        if (c < cols) {
+            const float y = v[jj] * sc;
+            const _Float16 hi = (_Float16)y;
+            *reinterpret_cast<_Float16*>(o + (c >> 5) * 128 + (c & 31) * 2) = hi;
+            *reinterpret_cast<_Float16*>(o + (c >> 5) * 128 + 64 + (c & 31) * 2) = (_Float16)(y - (float)hi);
         }
-        // rho of this lane's half (lanes lg = 0, 1: rows 0..15 of the chunk; lg = 2, 3: rows 16..31)
-        const int hh = 2 * c + (lg >> 1);
-        const float fh = hh < n_half ? a.sZ[hh] * a.sA[hh] : 0.f;
-        const _Float16 rho = (_Float16)(fh > 0.f ? F / fh : 0.f);
-        const h2v rho2 = h2v{rho, rho};
-        __syncthreads();  // (the barrier's release waits for the DMA)
-#pragma unroll
-        for (int kb = 0; kb < kKT2; ++kb) {   // one A block (64 columns of k) at a time: 8 fragment registers sets, the Z fragments re-read
-            if (kb >= n_ka) break;
-            h8 ah[4], al[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                ah[kt] = *reinterpret_cast<const h8*>(lds + kb * kBlk + aoff_h[kt]);
-                al[kt] = *reinterpret_cast<const h8*>(lds + kb * kBlk + aoff_l[kt]);
-            }
-#pragma unroll
-            for (int r = 0; r < kRTW; ++r) {
-                if (zoff_h[r] < 0) continue;   // (wave-uniform: fewer than 20 row tiles of n)
-                h8 zh = *reinterpret_cast<const h8*>(lds + zoff_h[r]), zl = *reinterpret_cast<const h8*>(lds + zoff_l[r]);
-                {   // scale the half's rows down by rho (exact: a power of two)
-                    h2v* ph = reinterpret_cast<h2v*>(&zh);
-                    h2v* pl = reinterpret_cast<h2v*>(&zl);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ph[e] = ph[e] * rho2; pl[e] = pl[e] * rho2; }
-                }
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    f32x4& d = acc[r][4 * kb + kt];
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, ah[kt], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, al[kt], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, ah[kt], d, 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();  // (every wave is done with the chunk before the next DMA overwrites it)
     }
-    // D fragment: lane (li, lg) holds rows 16 g + 4 lg + e of n, column 16 kt + li of the k tile
-    const float iF = (F > 0.f && F < 3.0e38f) ? 1.f / F : 0.f;
-    float* slab = a.slab + (long long)split * a.slab_stride;
-#pragma unroll
-    for (int r = 0; r < kRTW; ++r) {
-        const int gt = wave + 4 * r;
-        if (gt >= n_rt) continue;
-#pragma unroll
-        for (int kt = 0; kt < 4 * kKT2; ++kt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = 16 * gt + 4 * lg + e, k = 64 * kKT2 * kg + 16 * kt + li;
-                if (n < a.N && k < a.Kt) slab[(long long)n * a.ldk + k] = acc[r][kt][e] * iF;
-            }
-    }
+    if (lane == 0) *reinterpret_cast<float4*>(o + (J.ts - 16)) = make_float4(sc, mx > 0.f ? 0.f : 1.f, 0.f, 0.f);   // (scale, zero-row flag)
 }
-
 
 // k_wgrad16r ------------------------------------------------------------------------------------------------------------
 // The product over operands in SPLIT-ROW form (round 4): rows of [hi 32 halfs | lo 32 halfs] chunks + a 16-byte tail with the row's
@@ -370,28 +260,31 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16t(WProdTJobs jobs) {
 // the group's lanes address, lane 4 row + column quad) delivers exactly that from a row-major image, so both operands go from memory
 // to LDS by DMA as they are — 32 rows per stage — and leave it as fragments.
 //   LDS image of a stage: chunk c of row r (128 bytes = 8 pieces of 16) at c 4096 + r 128, piece p at slot p ^ swz(r),
-//   swz(r) = 2 ((r >> 1) & 1) + 4 ((r >> 3) & 1): the 32 lanes of a transpose read's pass (two 16-lane groups: rows 8 g + 4 half + 0..3)
-//   then cover all 64 banks exactly once.  The DMA builds it: lane l of unit u (rows 8 u .. 8 u + 7) fetches piece (l & 7) ^ swz(r)
-//   of row r = 8 u + (l >> 3) and lands at the unit's byte 16 l.
-// Output tile, waves and accumulation as k_wgrad16t: all n x 128 k per workgroup, wave w owns the 16-row tiles w, w + 4, .. of n.
-// Scales are per ROW here: the Z fragments (8 reduction rows per lane) are scaled down by the rows' rho = F / (s_Z s_A) (an h8 per
-// lane group from LDS, four v_pk_mul_f16), F = the smallest s_Z s_A of the workgroup's row range.
+//   swz(r) = 2 ((r >> 1) & 1) + 4 ((r >> 3) & 1).  The DMA builds it: lane l of unit u (rows 8 u .. 8 u + 7) fetches piece
+//   (l & 7) ^ swz(r) of row r = 8 u + (l >> 3) — whole 128-byte lines — and lands at the unit's byte 16 l.
+// Output tile: ALL n (<= 320 rows: every 16-row tile of Z's columns) x 128 k per workgroup — wave w owns the tiles w, w + 4, .. of n (<= 5)
+// and all eight 16-column tiles of k: 120 MFMAs per wave and 32-row stage from 52 transpose reads; Z is streamed once per 128
+// columns of k (the 64 x 64 kernel above reads 10 KB of LDS per 12 MFMAs and is bound by the LDS, not by the matrix pipe).
+// Scales are per ROW: instead of fresh accumulators and one multiply-add per stage and element, the Z fragments (8 reduction rows per
+// lane) are scaled DOWN by the exact powers of two rho = F / (s_Z s_A) of their rows (an h8 per lane group from LDS, four
+// v_pk_mul_f16), F = the smallest s_Z s_A of the workgroup's whole row range: the products of all stages then share the factor F and
+// accumulate in the matrix pipe (a row whose rho leaves the f16 range holds values negligible beside the range's largest).
 struct WProdR {
-    const unsigned char* Z; const unsigned char* A;   // split rows [M][tsz], [M][tsa]
+    const unsigned char* Z; const unsigned char* A;   // split rows [M][tsz], [M][tsa];  A null: the COLUMN SUMS of Z (a bias gradient) — one
+                                                      // k tile whose first column is all ones, rho = F / s_Z
     float* slab;                                      // this job's slabs [splits][N][ldk]
-};
-struct WProdRJobs {
-    WProdR job[kWProdMaxJobs];
-    int n_jobs;
-    long long M; int N, K;
+    long long M; int N, K;                            // (column sums: K = 1)
     int tsz, ncz, tsa, nca;                           // row bytes and live chunks of Z (ceil(N / 32)) and A (ceil(K / 32))
-    int n_kg, splits, rows_per_split, per8;           // per8: workgroups per job / 8 (launch order)
+    int n_kg, splits, rows_per_split, per8;           // per8: workgroups of the job / 8 (launch order)
     int ldk; long long slab_stride;
+    int wg0;                                          // the job's first workgroup
 };
+struct WProdRJobs { WProdR job[kWProdRMaxJobs]; int n_jobs; };
 }  // namespace wg16
 
 namespace wg16 {
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 f16x4_t;
+constexpr int kRTW = 5;        // 16-row tiles of n per wave (20 = 320 rows per workgroup)
 constexpr int kRChunk = 4096;   // bytes of one chunk of a stage: 32 rows x 128
 
 __device__ __forceinline__ h8 tr_pair(const unsigned char* base, int off) {   // rows 8 g .. 8 g + 7 of one 16-column tile: two transpose reads
@@ -401,15 +294,17 @@ __device__ __forceinline__ h8 tr_pair(const unsigned char* base, int off) {   //
     return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs P) {
+__global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [ncz chunks of Z | 4 chunks of A] of the stage, rho16[2][32], red
-    const int per_job = P.per8 * 8;
-    const int j = (int)blockIdx.x / per_job;
-    const int local = (int)blockIdx.x - j * per_job;
+    int j = 0;
+    while (j + 1 < jobs.n_jobs && (int)blockIdx.x >= jobs.job[j + 1].wg0) ++j;
+    const WProdR& P = jobs.job[j];
+    const WProdR& a = P;
+    const int local = (int)blockIdx.x - P.wg0;
     const int rank = (local & 7) * P.per8 + (local >> 3);   // XCD-aware: the k columns of one row split share an L2 (they stream the same Z rows)
     if (rank >= P.n_kg * P.splits) return;
     const int split = rank / P.n_kg, kg = rank - split * P.n_kg;
-    const WProdR& a = P.job[j];
+    const bool colsum = P.A == nullptr;
     const long long m_lo = (long long)split * P.rows_per_split;
     const long long m_hi = m_lo + P.rows_per_split < P.M ? m_lo + P.rows_per_split : P.M;
     const int n_rows = (int)(m_hi - m_lo);   // (> 0: the host sizes `splits` so that every split holds rows)
@@ -420,14 +315,19 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs P) {
     _Float16* rho16 = reinterpret_cast<_Float16*>(At + 4 * kRChunk);           // [2][32]
     unsigned* red = reinterpret_cast<unsigned*>(rho16 + 64);
     const unsigned char* Zr = a.Z + m_lo * P.tsz;
-    const unsigned char* Ar = a.A + m_lo * P.tsa;
+    const unsigned char* Ar = colsum ? Zr : a.A + m_lo * P.tsa;
     // ---- F: the smallest s_Z s_A over the rows of this workgroup's range (the rows' tails) ----
     if (tid == 0) red[0] = 0x7f7fffffu;
     __syncthreads();
     {
         float f = 3.0e38f;
-        for (int r = tid; r < n_rows; r += 256)
-            f = fminf(f, *reinterpret_cast<const float*>(Zr + (long long)r * P.tsz + (P.tsz - 16)) * *reinterpret_cast<const float*>(Ar + (long long)r * P.tsa + (P.tsa - 16)));
+        for (int r = tid; r < n_rows; r += 256) {
+            // tail = (scale, 1 if every element of the row's scaling unit is ZERO): such a row takes no part — its conventional scale 1
+            // would otherwise drag F down by the scale of the rows that do hold values (2^30 for gradients of 1e-5) and flush them
+            const float2 tz = *reinterpret_cast<const float2*>(Zr + (long long)r * P.tsz + (P.tsz - 16));
+            const float2 ta = colsum ? make_float2(1.f, 0.f) : *reinterpret_cast<const float2*>(Ar + (long long)r * P.tsa + (P.tsa - 16));
+            if (tz.y == 0.f && ta.y == 0.f) f = fminf(f, tz.x * ta.x);
+        }
         for (int off = 32; off > 0; off >>= 1) f = fminf(f, __shfl_xor(f, off));
         if (lane == 0 && f > 0.f) atomicMin(&red[0], __float_as_uint(f));   // (positive floats order like their bit patterns)
     }
@@ -436,8 +336,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs P) {
     auto ask_scales = [&](int m0) {
         const int r = m0 + tid;
         const bool ok = tid < 32 && r < n_rows;
-        sz_n = ok ? *reinterpret_cast<const float*>(Zr + (long long)r * P.tsz + (P.tsz - 16)) : 0.f;
-        sa_n = ok ? *reinterpret_cast<const float*>(Ar + (long long)r * P.tsa + (P.tsa - 16)) : 0.f;
+        const float2 tz = ok ? *reinterpret_cast<const float2*>(Zr + (long long)r * P.tsz + (P.tsz - 16)) : make_float2(0.f, 0.f);
+        const float2 ta = (ok && !colsum) ? *reinterpret_cast<const float2*>(Ar + (long long)r * P.tsa + (P.tsa - 16)) : make_float2(1.f, 0.f);
+        sz_n = (ok && tz.y == 0.f) ? tz.x : 0.f;    // (a zero row: rho = 0)
+        sa_n = (ok && ta.y == 0.f) ? ta.x : 0.f;
     };
     ask_scales(0);
     __syncthreads();
@@ -464,10 +366,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs P) {
         for (int h2 = 0; h2 < 2; ++h2) px[part][h2] = rowb + ((((part ^ (lg & 1)) << 2) + ((h2 ^ ((li >> 3) & 1)) << 1) + ((li >> 1) & 1)) << 4);
     const int n_nt = (P.N + 15) >> 4;                       // 16-row tiles of n
     const int kt_live = ((P.K - 128 * kg + 15) >> 4) < 8 ? ((P.K - 128 * kg + 15) >> 4) : 8;   // live 16-column tiles of this k column
-    const int ca_live = (P.nca - 4 * kg) < 4 ? (P.nca - 4 * kg) : 4;                          // ... and its chunks of A
+    const int ca_live = colsum ? 0 : ((P.nca - 4 * kg) < 4 ? (P.nca - 4 * kg) : 4);           // ... and its chunks of A
+    // column sums: the one B fragment — column 0 (lanes li = 0) all ones, exact in f16; no lo part
+    const _Float16 one = (_Float16)(li == 0 ? 1.f : 0.f);
+    const h8 ones8 = h8{one, one, one, one, one, one, one, one};
     // the DMA's lane: row (lane >> 3) of a unit of 8 rows, LDS slot lane & 7 <- piece (lane & 7) ^ swz(row)
     const rsrc_t rZ = gemm::make_rsrc(Zr, gemm::clamp_bytes((long long)n_rows * P.tsz));
-    const rsrc_t rA = gemm::make_rsrc(Ar, gemm::clamp_bytes((long long)n_rows * P.tsa));
+    const rsrc_t rA = gemm::make_rsrc(Ar, colsum ? 0u : gemm::clamp_bytes((long long)n_rows * P.tsa));
     const int n_inst = (P.ncz + ca_live) * 4;
     int stage = 0;
     for (int m0 = 0; m0 < n_rows; m0 += 32, ++stage) {
@@ -496,9 +401,18 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs P) {
                 zl[r] = tr_pair(zc, px[1][nt & 1]) * rho;
             }
         }
+        if (colsum) {   // (uniform)
+#pragma unroll
+            for (int r = 0; r < kRTW; ++r) {
+                if (wave + 4 * r >= n_nt) continue;
+                f32x4& d = acc[r][0];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], ones8, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[r], ones8, d, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
-            if (kt >= kt_live) break;   // (uniform)
+            if (colsum || kt >= kt_live) break;   // (uniform)
             const unsigned char* ac = At + (kt >> 1) * kRChunk;
             const h8 bh = tr_pair(ac, px[0][kt & 1]), bl = tr_pair(ac, px[1][kt & 1]);
 #pragma unroll
@@ -515,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs P) {
     }
     // D fragment: lane (li, lg) holds rows 16 nt + 4 lg + e of n, column 16 kt + li of this workgroup's k column
     const float iF = (F > 0.f && F < 3.0e38f) ? 1.f / F : 0.f;
-    float* slab = a.slab + (long long)split * P.slab_stride;
+    float* slab = P.slab + (long long)split * P.slab_stride;
 #pragma unroll
     for (int r = 0; r < kRTW; ++r) {
         const int nt = wave + 4 * r;
@@ -602,49 +516,25 @@ void wgrad16_add(WProdJobs* jobs, const WSplitJob& Z, const WSplitJob& A, const 
     ++jobs->n_jobs;
 }
 
-// products over tile-packed operands (dmpnn_bstep16.hip): `n` jobs Z_i^T A_i into adjacent slab sets of `splits` slabs each
-WProdTPlan plan_wgrad16t(int64_t ld_chunks, int N, int Kt) {
-    WProdTPlan p;
-    p.n_ctz = (N + 63) / 64; p.n_kt = (Kt + 63) / 64; p.ld_chunks = (int)ld_chunks;
-    const int n_kg = (p.n_kt + wg16::kKT2 - 1) / wg16::kKT2;
-    int splits = 256 / n_kg;                         // ~256 workgroups per product (a launch holds one per depth step: two or more per CU);
-                                                     // every split is a slab the reduce kernel reads
-    if (splits > ld_chunks) splits = (int)ld_chunks;
-    if (splits < 1) splits = 1;
-    p.splits = splits;
-    p.ldk = (Kt + 3) / 4 * 4;
-    p.slab_stride = (int64_t)N * p.ldk;
-    return p;
-}
-
-int launch_wgrad16t(const WProdTOperand* Z, const WProdTOperand* A, int n, const WProdTPlan& p, int N, int Kt, float* slab,
-                    const int* n_tiles_dev, hipStream_t s) {
-    if (n <= 0) return DMPNN_OK;
-    if (n > kWProdMaxJobs || p.n_ctz > wg16::kRTW) { set_error("wgrad16t: at most %d products per launch, d_h <= 320", kWProdMaxJobs); return DMPNN_EINVAL; }
-    wg16::WProdTJobs jobs;
-    memset(&jobs, 0, sizeof(jobs));
-    jobs.n_tiles_dev = n_tiles_dev;
+// fp32 rows -> split rows, up to 4 operands per launch (K1 + K2 <= 512 columns each; ts >= ceil(K / 32) * 128 + 16)
+int launch_rows2sr(const SRJob* J, int n, hipStream_t s) {
+    wg16::SRJobs a;
+    memset(&a, 0, sizeof(a));
     for (int i = 0; i < n; ++i) {
-        wg16::WProdT& a = jobs.job[i];
-        a.Z = Z[i].blk; a.sZ = Z[i].scale; a.A = A[i].blk; a.sA = A[i].scale;
-        a.n_ctz = p.n_ctz; a.n_kt = p.n_kt; a.ld_chunks = p.ld_chunks; a.splits = p.splits;
-        a.N = N; a.Kt = Kt; a.slab = slab + (int64_t)i * p.splits * p.slab_stride; a.ldk = p.ldk; a.slab_stride = p.slab_stride;
-        jobs.wg0[i + 1] = jobs.wg0[i] + ((p.n_kt + wg16::kKT2 - 1) / wg16::kKT2 * p.splits + 7) / 8 * 8;
+        if (J[i].M <= 0) continue;
+        const int K = J[i].K1 + J[i].K2;
+        if (a.n_jobs >= 4 || K <= 0 || K > 512 || J[i].ts < ((K + 31) / 32) * 128 + 16) { set_error("rows2sr: at most 4 operands of <= 512 columns per launch"); return DMPNN_EINVAL; }
+        a.job[a.n_jobs] = J[i];
+        a.wg0[a.n_jobs + 1] = a.wg0[a.n_jobs] + (int)((J[i].M + 3) / 4);
+        ++a.n_jobs;
     }
-    jobs.n_jobs = n;
-    const size_t lds = (size_t)(p.n_ctz + wg16::kKT2) * wg16::kBlk + 64;
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16t, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
-        attr_set = lds;
-    }
-    hipLaunchKernelGGL(wg16::k_wgrad16t, dim3((unsigned)jobs.wg0[n]), dim3(256), lds, s, jobs);
-    DMPNN_CHECK_LAUNCH("k_wgrad16t");
+    if (a.n_jobs == 0) return DMPNN_OK;
+    hipLaunchKernelGGL(wg16::k_rows2sr, dim3((unsigned)a.wg0[a.n_jobs]), dim3(256), 0, s, a);
+    DMPNN_CHECK_LAUNCH("k_rows2sr");
     return DMPNN_OK;
 }
 
-// products over split-row operands (k_wgrad16r): `n` jobs Z_i^T A_i (all of M rows, N x K) into adjacent slab sets of `splits` slabs each
+// products over split-row operands (k_wgrad16r).  plan: the row splits of one job — every split is a slab the reduce kernel reads
 WProdRPlan plan_wgrad16r(int64_t M, int N, int K) {
     WProdRPlan p;
     p.n_kg = (K + 127) / 128;
@@ -661,30 +551,44 @@ WProdRPlan plan_wgrad16r(int64_t M, int N, int K) {
     return p;
 }
 
-int launch_wgrad16r(const unsigned char* const* Z, int tsz, const unsigned char* const* A, int tsa, int n, const WProdRPlan& p, int64_t M, int N, int K,
-                    float* slab, hipStream_t s) {
-    if (n <= 0 || M <= 0) return DMPNN_OK;
-    const int ncz = (N + 31) / 32, nca = (K + 31) / 32;
-    if (n > kWProdMaxJobs || (N + 15) / 16 > 4 * wg16::kRTW || tsz < ncz * 128 + 16 || tsa < nca * 128 + 16 || (int64_t)p.rows_per_split * (tsz > tsa ? tsz : tsa) > ((int64_t)1 << 31)) {
-        set_error("wgrad16r: at most %d products per launch, d_h <= 320, whole chunks + tail per row", kWProdMaxJobs);
-        return DMPNN_EINVAL;
+// `n` jobs in one launch (<= kWProdRMaxJobs; more: several launches).  A job with A == nullptr: the column sums of Z (K = 1).
+int launch_wgrad16r(const WProdRJob* J, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += kWProdRMaxJobs) {
+        const int nn = n - i0 < kWProdRMaxJobs ? n - i0 : kWProdRMaxJobs;
+        wg16::WProdRJobs P;
+        memset(&P, 0, sizeof(P));
+        int wg = 0, ncz_max = 0, nj = 0;
+        for (int i = 0; i < nn; ++i) {
+            const WProdRJob& q = J[i0 + i];
+            if (q.M <= 0) continue;   // (its reduce job sums zero slabs: the caller zero-fills)
+            const int K = q.A ? q.K : 1;
+            const int ncz = (q.N + 31) / 32, nca = (K + 31) / 32;
+            const WProdRPlan& p = q.plan;
+            if ((q.N + 15) / 16 > 4 * wg16::kRTW || q.tsz < ncz * 128 + 16 || (q.A && q.tsa < nca * 128 + 16) ||
+                (int64_t)p.rows_per_split * (q.tsz > q.tsa ? q.tsz : q.tsa) > ((int64_t)1 << 31)) {
+                set_error("wgrad16r: d_h <= 320, whole chunks + tail per operand row");
+                return DMPNN_EINVAL;
+            }
+            wg16::WProdR& a = P.job[nj++];
+            a.Z = q.Z; a.A = q.A; a.slab = q.slab; a.M = q.M; a.N = q.N; a.K = K;
+            a.tsz = q.tsz; a.ncz = ncz; a.tsa = q.A ? q.tsa : q.tsz; a.nca = nca;
+            a.n_kg = p.n_kg; a.splits = p.splits; a.rows_per_split = p.rows_per_split; a.per8 = (p.n_kg * p.splits + 7) / 8;
+            a.ldk = p.ldk; a.slab_stride = p.slab_stride;
+            a.wg0 = wg; wg += a.per8 * 8;
+            if (ncz > ncz_max) ncz_max = ncz;
+        }
+        if (nj == 0) continue;
+        P.n_jobs = nj;
+        const size_t lds = (size_t)(ncz_max + 4) * wg16::kRChunk + 128 + 64;
+        static size_t attr_set = 0;
+        if (attr_set < lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16r, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
+            attr_set = lds;
+        }
+        hipLaunchKernelGGL(wg16::k_wgrad16r, dim3((unsigned)wg), dim3(256), lds, s, P);
+        DMPNN_CHECK_LAUNCH("k_wgrad16r");
     }
-    wg16::WProdRJobs P;
-    memset(&P, 0, sizeof(P));
-    for (int i = 0; i < n; ++i) { P.job[i].Z = Z[i]; P.job[i].A = A[i]; P.job[i].slab = slab + (int64_t)i * p.splits * p.slab_stride; }
-    P.n_jobs = n; P.M = M; P.N = N; P.K = K;
-    P.tsz = tsz; P.ncz = ncz; P.tsa = tsa; P.nca = nca;
-    P.n_kg = p.n_kg; P.splits = p.splits; P.rows_per_split = p.rows_per_split; P.per8 = (p.n_kg * p.splits + 7) / 8;
-    P.ldk = p.ldk; P.slab_stride = p.slab_stride;
-    const size_t lds = (size_t)(ncz + 4) * wg16::kRChunk + 128 + 64;
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16r, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
-        attr_set = lds;
-    }
-    hipLaunchKernelGGL(wg16::k_wgrad16r, dim3((unsigned)(n * P.per8 * 8)), dim3(256), lds, s, P);
-    DMPNN_CHECK_LAUNCH("k_wgrad16r");
     return DMPNN_OK;
 }
 

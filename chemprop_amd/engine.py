@@ -308,6 +308,33 @@ def lean_sign_bits(st: "ForwardState") -> Tensor:
     return ((b.unsqueeze(-1) >> sh) & 1).bool().reshape(depth, st.plan.n_edges, bn)[:, :, :d_h]
 
 
+KEEP_ROWS_MIN = 49152   # message rows (n_edges x (depth - 1)) from which a training forward of the tile kernel keeps them as split rows
+
+
+def _keep_rows(n_rows: int) -> bool:
+    v = _lib.opt("DMPNN_KEEP_ROWS", "auto")   # "1" / "0": always / never (tests, A/B measurements)
+    return v == "1" or (v != "0" and n_rows >= KEEP_ROWS_MIN)
+
+
+def split_rows_to_float(rows: Tensor, n_cols: int) -> Tensor:
+    """Split rows (``[..., n_rows, row_floats]`` float32 storage: chunks of ``[hi 32 halfs | lo 32 halfs]`` + a 16-byte tail with the row's
+    power-of-two scale, csrc/dmpnn_step16_impl.hpp) back to fp32 ``[..., n_rows, n_cols]`` (tests / diagnostics)."""
+    lead, rf = rows.shape[:-1], rows.shape[-1]
+    h = rows.contiguous().view(torch.float16).reshape(*lead, 2 * rf)
+    nc = (n_cols + 31) // 32
+    ch = h[..., :nc * 64].reshape(*lead, nc, 2, 32).float()
+    scale = rows[..., rf - 4:rf - 3]
+    return ((ch[..., 0, :] + ch[..., 1, :]).reshape(*lead, nc * 32)[..., :n_cols]) / scale
+
+
+def kept_messages(st: "ForwardState") -> Tensor:
+    """The kept ``M^(t)`` of a training forward as fp32 ``[depth - 1, n_edges, d_h]`` whatever form the route keeps them in: fp32 rows
+    (``st.Ms``) or split rows (the tile kernel with ``msplit``, the lean per-step route).  Tests / diagnostics."""
+    if st.args.msplit and st.refs[15] is not None and not st.dims.get("atom"):
+        return split_rows_to_float(st.refs[15], st.dims["d_h"])
+    return st.Ms[:, :, :st.dims["d_h"]]
+
+
 class RouteUnavailable(RuntimeError):
     """A demanded kernel feature does not exist on the route this batch takes (the caller has another way)."""
 
@@ -628,6 +655,13 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if atom and keep:
             # the bond-feature half of the atom messages, kept for W_h's gradient: depth - 1 slots of [n_edges][16] (include/dmpnn.h, DMPNN_F_ATOM)
             split_ms = torch.empty((max(n_steps, 1), nE, 16), dtype=torch.float32, device=dev)
+        elif use_mega and want16 and keep and n_steps and d_h <= 320 and _keep_rows(nE * n_steps):
+            # round 4: the tile kernel keeps M^(t) as SPLIT ROWS (depth - 1 slots of n_edges rows of dmpnn_split_row_floats(d_h) floats) —
+            # what the weight-gradient products read as they are (csrc/dmpnn_wgrad16.hip: k_wgrad16r); the fp32 Ms slots above then only
+            # serve a molecule beyond the tile.  From KEEP_ROWS_MIN message rows on: measured 1 053 -> 884 us per training step at 4 096
+            # QM9-shaped molecules (146 k rows), but 181 -> 188..193 us at 512 (18 k rows: ~200 workgroups, one per CU, each bound by what ONE
+            # CU pulls through LDS-DMA — 12 bytes per cycle — where the block products' 500 smaller workgroups spread the same bytes better)
+            split_ms = torch.empty((n_steps, nE, int(lib.dmpnn_split_row_floats(d_h))), dtype=torch.float32, device=dev)
     st.out = out
     if edge_ws is None:
         st.H0 = st.Hs = st.Ms = st.Mv = st.Hv = None

@@ -134,8 +134,13 @@ def _adam_reference(params0, grads_per_step, lr):
 
 
 @pytest.mark.gpu
-def test_fused_step_matches_goldens(g, gpu_device):
+@pytest.mark.parametrize("keep_rows", ["auto", "1"], ids=["block-products", "split-row-products"])
+def test_fused_step_matches_goldens(g, keep_rows, gpu_device, monkeypatch):
     from chemprop_amd.model import FusedTrainer
+
+    # ("1": the messages kept as split rows and EVERY weight gradient — the predictor's riding first layer included — on the split-row
+    #  product k_wgrad16r, which batches of this size do not take by themselves)
+    monkeypatch.setenv("DMPNN_KEEP_ROWS", keep_rows)
 
     model = build_mirror(g.cfg)
     model.load_state_dict(g.state("w0."))
@@ -471,11 +476,14 @@ def test_dropout_with_frozen_edge_weights_keeps_its_scale(gpu_device):
 
 
 @pytest.mark.gpu
-def test_backward_refuses_in_kernel_dropout_without_the_tile_kernel(gpu_device):
+def test_backward_refuses_in_kernel_dropout_without_the_tile_kernel(gpu_device, monkeypatch):
     """The C boundary itself: a forward that ran with dropout inside the kernels followed by a backward that cannot take the tile
-    kernel (no gradient of W_i / W_h wanted) is an argument error, not a silently unscaled gradient."""
+    kernel (no gradient of W_i / W_h wanted) is an argument error, not a silently unscaled gradient.  (With the messages kept as split
+    rows — the default since round 4 — the backward pass ALWAYS takes the tile kernel: checked below against the run that refuses.)"""
     from chemprop_amd import _lib, engine, synth
     from chemprop_amd.nn import BondMessagePassing
+
+    monkeypatch.setenv("DMPNN_KEEP_ROWS", "0")
 
     bmg = synth.random_batch(32, "qm9", seed=3)
     bmg.to(gpu_device)
@@ -489,6 +497,12 @@ def test_backward_refuses_in_kernel_dropout_without_the_tile_kernel(gpu_device):
     grads = engine.backward(st, g, dict(W_i=True, W_h=True, W_o=True, b_o=True))   # (with the edge gradients wanted: fine)
     torch.cuda.synchronize()
     assert all(torch.isfinite(v).all() for v in grads.values() if v is not None)
+    monkeypatch.setenv("DMPNN_KEEP_ROWS", "1")
+    out2, st2 = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, keep=True, dropout=(0.25, 77))
+    assert st2.args.msplit and torch.equal(out2, out)
+    g2 = engine.backward(st2, g, dict(W_o=True, b_o=True))   # split rows kept: the tile kernel whatever is wanted — the scaled gradient
+    for k in ("W_o", "b_o"):
+        assert parity_err(g2[k].cpu().numpy(), grads[k].cpu().numpy()) <= 2e-6, k
     with pytest.raises(engine.RouteUnavailable):   # PReLU is not a dropout activation of the tile kernels
         engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, keep=True, dropout=(0.25, 77),
                        act="prelu", slope_t=torch.full((1,), 0.25, device=gpu_device))

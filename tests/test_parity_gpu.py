@@ -259,8 +259,11 @@ def test_whole_forward_tile_kernel_split_f16(golden, gpu_device):
     assert parity_err(out_s.cpu().numpy(), out_f.cpu().numpy()) <= 3e-6
     if plan.n_edges:
         assert parity_err(st_s.H0.cpu().numpy(), st_f.H0.cpu().numpy()) <= 3e-6
+        from chemprop_amd import engine as _eng
+
+        Ms_s = _eng.kept_messages(st_s)   # (round 4: the tile kernel keeps M^(t) as split rows — exactly what its next contraction read)
         for t in range(golden.cfg["depth"] - 1):
-            assert parity_err(st_s.Ms[t].cpu().numpy(), st_f.Ms[t].cpu().numpy()) <= 3e-6, f"M^({t + 1})"
+            assert parity_err(Ms_s[t].cpu().numpy(), st_f.Ms[t][:, :Ms_s.shape[-1]].cpu().numpy()) <= 3e-6, f"M^({t + 1})"
             assert parity_err(st_s.Hs[t].cpu().numpy(), st_f.Hs[t].cpu().numpy()) <= 3e-6, f"H^({t + 1})"
     assert parity_err(st_s.Mv.cpu().numpy(), st_f.Mv.cpu().numpy()) <= 3e-6
     _, out_i, _ = _engine_forward(golden, gpu_device, route="mega", keep=False, mfma="split16")
@@ -1265,3 +1268,65 @@ def test_lean_fused16_is_the_default_for_training_at_size_and_repeats(gpu_device
     assert all(torch.equal(a, b) for a, b in zip(grads[1], grads[2]))
     mp2 = BondMessagePassing(activation="tanh").to(gpu_device).train()
     assert mp2(bmg).grad_fn.st.route == "general16"
+
+
+@pytest.mark.parametrize("case,kw", [
+    ("qm9-512", dict(activation="tanh", bias=True)),       # bias gradients = column sums of the gradient rows (jobs of the same launch)
+    ("qm9-512", dict()),                                    # ReLU, sign bits
+    ("qm9-96", dict(d_h=64, depth=4, activation="elu")),
+    ("mixed-40+1", dict(activation="tanh")),                # a molecule beyond the tile: its fp32 rows converted at the end of its tile
+    ("qm9-300-masked", dict(activation="tanh", bias=True)),  # half of the atoms without gradient, the rest at 1e-6: all-zero tiles beside tiny ones
+], ids=["qm9-512-tanh-bias", "qm9-512-relu", "qm9-96-d4-h64", "mixed-40+1", "masked-tiny-gradients"])
+def test_tile_kernels_with_every_weight_gradient_on_split_rows(case, kw, gpu_device, monkeypatch):
+    """Round 4: a training forward of the tile kernel that keeps M^(t) as SPLIT ROWS (`msplit`), the backward tile kernel writing gZ^(t) /
+    gH0 / gZO as split rows, [V[src] || E] and [V || Mv] split by k_rows2sr, ALL products (and the bias gradients, as column-sum jobs) in
+    one k_wgrad16r launch — against the same step on block operands (k_wsplit16 + k_wgrad16), which the executed-reference tests hold.
+    Both are exact-split fp32-class products of the same operands: equal to rounding, masks included (the kept tensors are the same)."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    monkeypatch.setenv("DMPNN_VALIDATE", "never")
+    if case.startswith("mixed"):
+        bmg = _mixed_batch(40, "synth40", 21)
+    else:
+        bmg = synth.random_batch(int(case.split("-")[1]), "qm9", seed=12)
+    bmg.to(gpu_device)
+    torch.manual_seed(4)
+    mp0 = BondMessagePassing(**kw)
+    G = torch.randn(bmg.V.shape[0], mp0.output_dim, generator=torch.Generator().manual_seed(6)).to(gpu_device)
+    if "masked" in case:
+        G = G * 1e-6
+        G[bmg.batch < len(bmg) // 2] = 0.0   # the first half of the molecules without gradient: all-zero gradient tiles (scale 1 by convention) beside 1e-6 ones
+    res = {}
+    for rows in ("1", "0"):
+        monkeypatch.setenv("DMPNN_KEEP_ROWS", rows)
+        mp = BondMessagePassing(**kw)
+        mp.load_state_dict(mp0.state_dict())
+        mp = mp.to(gpu_device).train()
+        out = mp(bmg)
+        st = out.grad_fn.st
+        assert st.route == "mega16" and bool(st.args.msplit) == (rows == "1"), (rows, st.route)
+        out.backward(G)
+        res[rows] = (out.detach(), {k: p.grad.clone() for k, p in mp.named_parameters()})
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k, v in res["0"][1].items():
+        assert torch.isfinite(res["1"][1][k]).all(), k
+        err = parity_err(res["1"][1][k].cpu().numpy(), v.cpu().numpy())
+        assert err <= 5e-6, f"{k}: {err:.3e}"
+
+
+def test_split_rows_are_kept_from_a_size_on(gpu_device):
+    """The default rule (engine.KEEP_ROWS_MIN message rows): 4 096 QM9-shaped molecules keep split rows, 512 the fp32 rows of the block path."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    mp = BondMessagePassing().to(gpu_device).train()
+    for n, want in ((512, False), (4096, True)):
+        bmg = synth.random_batch(n, "qm9", seed=3)
+        bmg.to(gpu_device)
+        out = mp(bmg)
+        st = out.grad_fn.st
+        assert st.route == "mega16" and bool(st.args.msplit) == want, (n, st.route)
+        assert (int(bmg.E.shape[0]) * 2 >= engine.KEEP_ROWS_MIN) == want
+        out.sum().backward()
+        assert all(torch.isfinite(p.grad).all() for p in mp.parameters())

@@ -129,7 +129,8 @@ def test_oversize_molecule_fp32_build_and_full_plan(gpu_device, monkeypatch):
         with torch.no_grad():
             out_k, st_k = engine.forward(plan, b.V, b.E, p["W_i.weight"], p["W_h.weight"], p["W_o.weight"], p["W_o.bias"], depth=3,
                                          route="mega", mfma=mfma, keep=True)
-        assert parity_err(out_k.cpu().numpy(), ref) <= TOL and torch.isfinite(st_k.H0).all() and torch.isfinite(st_k.Ms).all()
+        # (round 4: the f16 tile kernel keeps M^(t) as split rows; the oversize piece's fp32 rows are converted at the end of its tile)
+        assert parity_err(out_k.cpu().numpy(), ref) <= TOL and torch.isfinite(st_k.H0).all() and torch.isfinite(engine.kept_messages(st_k)).all()
 
 
 @pytest.mark.gpu
