@@ -42,7 +42,8 @@ extern "C" {
  * in-kernel dropout no longer takes PReLU; dmpnn_backward refuses a dropout forward it cannot scale.
  * 11 — round 4: DMPNN_F_ATOM also with DMPNN_F_KEEP (atom messages TRAIN on the tile kernels; `msplit` keeps the bond-feature half of
  * the messages) and dmpnn_backward for it (gW_i [d_h, d_v], gW_h [d_h, d_h + d_e]); dmpnn_bwd_args.g_edge (a second gradient input, with
- * respect to the kept H^(depth-1): the edge read-out of the mol-atom-bond blocks). */
+ * respect to the kept H^(depth-1): the edge read-out of the mol-atom-bond blocks); `msplit` on the tile kernel's training forward: M^(t)
+ * kept as split rows, every weight-gradient product of dmpnn_backward on split rows. */
 #define DMPNN_ABI_VERSION 11
 
 enum dmpnn_status {
@@ -322,6 +323,12 @@ typedef struct dmpnn_fwd_args {
      * ping-pong slots of split message rows (n_edges * dmpnn_split_row_floats(d_h) floats each) live HERE, and H0 / Hs / Ms /
      * Mv are the fp32 tensors dmpnn_backward reads (n_hslots = n_mslots = depth - 1, rows in the plan's CSR-row order):
      * every step writes its H^(t) and the fp32 copy of its message beside the split rows the next step consumes. */
+    /* ... ABI 11, DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (a training forward of the TILE kernel, bond messages,
+     * depth >= 2): given (depth - 1) * n_edges * dmpnn_split_row_floats(d_h) floats here (16-byte aligned), the kernel keeps M^(t) as
+     * split rows in it (slot t - 1; rows in the kept tensors' order) INSTEAD of the fp32 rows in Ms — which then hold the rows of
+     * molecules beyond the tile only — and dmpnn_backward, handed the same block, runs every weight-gradient product on split rows
+     * (csrc/dmpnn_wgrad16.hip: k_wgrad16r; faster from ~50 000 message rows on: the host's rule).  NULL: fp32 rows.
+     * With DMPNN_F_ATOM the same field holds the kept bond-feature half of the messages (see the flag). */
     void* msplit; size_t msplit_bytes;
     /* ACTIVE DROPOUT inside the kernels (base.py:135-141 `self.dropout(H_t)` after every update, :182 after the finalize's tau):
      * with DMPNN_F_MEGA | DMPNN_F_SPLIT16 | DMPNN_F_KEEP (a training forward of the tile kernel), a ReLU-class activation
