@@ -691,7 +691,9 @@ def main():
                         oc[name]["train_step_us"] = round(t4 * 1e3, 1)
                         oc[name]["train_M_edge_updates_per_s"] = round(e2 * (m3.depth - 1) / (t4 * 1e3), 1)
                         try:
-                            oc[name]["train_route"] = m3(b2).grad_fn.st.route   # (the forward state of the autograd node)
+                            st3 = m3(b2).grad_fn.st                             # (the forward state of the autograd node)
+                            oc[name]["train_route"] = st3.route
+                            oc[name]["train_operands"] = "split rows (k_wgrad16r)" if (st3.args.msplit or st3.route == "fused16/lean") else "blocks (k_wsplit16 + k_wgrad16)"
                         except AttributeError:
                             oc[name]["train_route"] = None
                         del m3, s3, o3, G3

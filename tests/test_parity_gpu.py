@@ -1276,7 +1276,9 @@ def test_lean_fused16_is_the_default_for_training_at_size_and_repeats(gpu_device
     ("qm9-96", dict(d_h=64, depth=4, activation="elu")),
     ("mixed-40+1", dict(activation="tanh")),                # a molecule beyond the tile: its fp32 rows converted at the end of its tile
     ("qm9-300-masked", dict(activation="tanh", bias=True)),  # half of the atoms without gradient, the rest at 1e-6: all-zero tiles beside tiny ones
-], ids=["qm9-512-tanh-bias", "qm9-512-relu", "qm9-96-d4-h64", "mixed-40+1", "masked-tiny-gradients"])
+    ("qm9-256-fullplan", dict(activation="elu", bias=True)),  # the CSR plan: kept rows in the plan's row order, the operands gathered through it
+    ("qm9-128-vd", dict(activation="tanh", d_vd=3)),          # W_d behind the finalize (full plan): gHO comes through W_d's transpose first
+], ids=["qm9-512-tanh-bias", "qm9-512-relu", "qm9-96-d4-h64", "mixed-40+1", "masked-tiny-gradients", "full-plan", "with-W_d"])
 def test_tile_kernels_with_every_weight_gradient_on_split_rows(case, kw, gpu_device, monkeypatch):
     """Round 4: a training forward of the tile kernel that keeps M^(t) as SPLIT ROWS (`msplit`), the backward tile kernel writing gZ^(t) /
     gH0 / gZO as split rows, [V[src] || E] and [V || Mv] split by k_rows2sr, ALL products (and the bias gradients, as column-sum jobs) in
@@ -1286,6 +1288,8 @@ def test_tile_kernels_with_every_weight_gradient_on_split_rows(case, kw, gpu_dev
     from chemprop_amd.nn import BondMessagePassing
 
     monkeypatch.setenv("DMPNN_VALIDATE", "never")
+    if "fullplan" in case:
+        monkeypatch.setenv("DMPNN_TRAIN_PLAN", "full")
     if case.startswith("mixed"):
         bmg = _mixed_batch(40, "synth40", 21)
     else:
@@ -1293,6 +1297,7 @@ def test_tile_kernels_with_every_weight_gradient_on_split_rows(case, kw, gpu_dev
     bmg.to(gpu_device)
     torch.manual_seed(4)
     mp0 = BondMessagePassing(**kw)
+    V_d = torch.randn(bmg.V.shape[0], kw["d_vd"], generator=torch.Generator().manual_seed(8)).to(gpu_device) if kw.get("d_vd") else None
     G = torch.randn(bmg.V.shape[0], mp0.output_dim, generator=torch.Generator().manual_seed(6)).to(gpu_device)
     if "masked" in case:
         G = G * 1e-6
@@ -1303,9 +1308,10 @@ def test_tile_kernels_with_every_weight_gradient_on_split_rows(case, kw, gpu_dev
         mp = BondMessagePassing(**kw)
         mp.load_state_dict(mp0.state_dict())
         mp = mp.to(gpu_device).train()
-        out = mp(bmg)
+        out = mp(bmg, V_d)
         st = out.grad_fn.st
         assert st.route == "mega16" and bool(st.args.msplit) == (rows == "1"), (rows, st.route)
+        assert bool(st.plan.tiles_only) == ("fullplan" not in case and V_d is None)
         out.backward(G)
         res[rows] = (out.detach(), {k: p.grad.clone() for k, p in mp.named_parameters()})
     assert torch.equal(res["1"][0], res["0"][0])
