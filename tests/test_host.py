@@ -374,3 +374,42 @@ def test_keep_bits_bytes_is_a_shape_rule():
               args(wd=4096), args(nE=0), args(nV=0)):
         assert int(lib.dmpnn_forward_keep_bits_bytes(C.byref(a))) == 0
     assert int(lib.dmpnn_forward_keep_bits_bytes(None)) == 0
+
+
+def test_split_row_format_round_trip_and_the_keep_rows_rule(monkeypatch):
+    """The split-row format of csrc/dmpnn_step16_impl.hpp (chunks of [hi 32 halfs | lo 32 halfs] + a 16-byte tail with the row's scale)
+    restated in numpy against `engine.split_rows_to_float`, and the host's size rule for keeping the tile kernel's messages so."""
+    from chemprop_amd import _lib, engine
+
+    rng = np.random.default_rng(0)
+    n_rows, d_h = 7, 300
+    srf = int(_lib.load().dmpnn_split_row_floats(d_h))
+    assert srf * 4 == ((d_h + 63) // 64 * 64) * 4 + 16
+    x = (rng.standard_normal((n_rows, d_h)) * np.array([1e-3, 1.0, 37.0, 1e3, 0.0, 2.5, 1e-6])[:, None]).astype(np.float32)
+    raw = np.zeros((n_rows, srf * 2), np.float16)
+    tails = np.zeros((n_rows, 4), np.float32)
+    for r in range(n_rows):
+        mx = float(np.abs(x[r]).max())
+        s = 1.0 if not (mx > 0) else float(2.0 ** (14 - np.frexp(mx)[1]))     # scale_for: the row maximum at [2^13, 2^14)
+        y = x[r].astype(np.float64) * s
+        hi = y.astype(np.float16)
+        lo = (y - hi.astype(np.float64)).astype(np.float16)
+        for c in range((d_h + 31) // 32):
+            n = min(32, d_h - 32 * c)
+            raw[r, 64 * c: 64 * c + n] = hi[32 * c: 32 * c + n]
+            raw[r, 64 * c + 32: 64 * c + 32 + n] = lo[32 * c: 32 * c + n]
+        tails[r] = (s, 0.0 if mx > 0 else 1.0, 0.0, 0.0)
+    rows = torch.from_numpy(raw.view(np.float32).copy())
+    rows[:, srf - 4:] = torch.from_numpy(tails)
+    back = engine.split_rows_to_float(rows, d_h).numpy()
+    # hi + lo carries 22 significant bits relative to the row's largest element: fp32-class
+    for r in range(n_rows):
+        tol = 2.0 ** -21 * float(np.abs(x[r]).max())
+        assert np.abs(back[r] - x[r]).max() <= tol, r
+    # the rule: from KEEP_ROWS_MIN message rows on, unless forced
+    monkeypatch.delenv("DMPNN_KEEP_ROWS", raising=False)
+    assert not engine._keep_rows(engine.KEEP_ROWS_MIN - 1) and engine._keep_rows(engine.KEEP_ROWS_MIN)
+    monkeypatch.setenv("DMPNN_KEEP_ROWS", "1")
+    assert engine._keep_rows(1)
+    monkeypatch.setenv("DMPNN_KEEP_ROWS", "0")
+    assert not engine._keep_rows(10 ** 9)
