@@ -45,10 +45,12 @@ for name, fn in (("fused", fused), ("module", module), ("fused", fused), ("modul
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"{name:7s}: host issue {1e6 * (t1 - t0) / n:7.1f} us/step   wall {1e6 * (t2 - t0) / n:7.1f} us/step")
-pr = cProfile.Profile()
-torch.cuda.synchronize()
-pr.enable()
-for _ in range(200): fused()
-pr.disable()
-torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(24)
+for name, fn in (("fused", fused), ("module", module)):
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(200): fn()
+    pr.disable()
+    torch.cuda.synchronize()
+    print("==== cProfile,", name, "(by own time)")
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
