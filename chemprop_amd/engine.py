@@ -308,7 +308,7 @@ def lean_sign_bits(st: "ForwardState") -> Tensor:
     return ((b.unsqueeze(-1) >> sh) & 1).bool().reshape(depth, st.plan.n_edges, bn)[:, :, :d_h]
 
 
-KEEP_ROWS_MIN = 49152   # message rows (n_edges x (depth - 1)) from which a training forward of the tile kernel keeps them as split rows
+KEEP_ROWS_MIN = 32768   # message rows (n_edges x (depth - 1)) from which a training forward of the tile kernel keeps them as split rows
 
 
 def _keep_rows(n_rows: int) -> bool:
@@ -658,9 +658,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         elif use_mega and want16 and keep and n_steps and d_h <= 320 and _keep_rows(nE * n_steps):
             # round 4: the tile kernel keeps M^(t) as SPLIT ROWS (depth - 1 slots of n_edges rows of dmpnn_split_row_floats(d_h) floats) —
             # what the weight-gradient products read as they are (csrc/dmpnn_wgrad16.hip: k_wgrad16r); the fp32 Ms slots above then only
-            # serve a molecule beyond the tile.  From KEEP_ROWS_MIN message rows on: measured 1 053 -> 884 us per training step at 4 096
-            # QM9-shaped molecules (146 k rows), but 181 -> 188..193 us at 512 (18 k rows: ~200 workgroups, one per CU, each bound by what ONE
-            # CU pulls through LDS-DMA — 12 bytes per cycle — where the block products' 500 smaller workgroups spread the same bytes better)
+            # serve a molecule beyond the tile.  From KEEP_ROWS_MIN message rows on: measured per training step 300 -> 271 us at 1 024
+            # QM9-shaped molecules (36 k rows), 1 053 -> 884 at 4 096, even at 768 (27 k), but 181 -> 188..193 us at 512 (18 k rows: ~200
+            # workgroups, one per CU, each bound by what ONE CU pulls through LDS-DMA — 12 bytes per cycle — where the block products' 500
+            # smaller workgroups spread the same bytes better): profiles/r04_split_rows_crossover.txt
             split_ms = torch.empty((n_steps, nE, int(lib.dmpnn_split_row_floats(d_h))), dtype=torch.float32, device=dev)
     st.out = out
     if edge_ws is None:

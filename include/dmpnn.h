@@ -327,7 +327,7 @@ typedef struct dmpnn_fwd_args {
      * depth >= 2): given (depth - 1) * n_edges * dmpnn_split_row_floats(d_h) floats here (16-byte aligned), the kernel keeps M^(t) as
      * split rows in it (slot t - 1; rows in the kept tensors' order) INSTEAD of the fp32 rows in Ms — which then hold the rows of
      * molecules beyond the tile only — and dmpnn_backward, handed the same block, runs every weight-gradient product on split rows
-     * (csrc/dmpnn_wgrad16.hip: k_wgrad16r; faster from ~50 000 message rows on: the host's rule).  NULL: fp32 rows.
+     * (csrc/dmpnn_wgrad16.hip: k_wgrad16r; faster from ~30 000 message rows on: the host's rule).  NULL: fp32 rows.
      * With DMPNN_F_ATOM the same field holds the kept bond-feature half of the messages (see the flag). */
     void* msplit; size_t msplit_bytes;
     /* ACTIVE DROPOUT inside the kernels (base.py:135-141 `self.dropout(H_t)` after every update, :182 after the finalize's tau):

@@ -210,7 +210,7 @@ def test_training_on_the_tile_kernels(atom, n_mols, kw, gpu_device, monkeypatch)
 
 @pytest.mark.gpu
 def test_training_on_the_tile_kernels_with_split_row_products(gpu_device, monkeypatch):
-    """The same step with the bond block's messages kept as split rows and every product on k_wgrad16r (what batches from ~1 400
+    """The same step with the bond block's messages kept as split rows and every product on k_wgrad16r (what batches from ~900
     molecules on take by themselves): the edge read-out's gradient enters the same backward tile kernel."""
     monkeypatch.setenv("DMPNN_KEEP_ROWS", "1")
     _mab_training_on_the_tile_kernels(False, 300, dict(activation="elu", bias=True, depth=4, d_h=128), gpu_device, monkeypatch)
