@@ -413,3 +413,29 @@ def test_split_row_format_round_trip_and_the_keep_rows_rule(monkeypatch):
     assert engine._keep_rows(1)
     monkeypatch.setenv("DMPNN_KEEP_ROWS", "0")
     assert not engine._keep_rows(10 ** 9)
+
+
+def test_mab_tile_training_rule_is_host_logic():
+    """`mab._tile_train_ok`: which training forwards of the mol-atom-bond blocks go to the tile kernels (everything else keeps the
+    per-step chain) — decided on the host from the module and the batch alone."""
+    from chemprop_amd import mab
+
+    bmg = synth.random_batch(4, "qm9", seed=0)
+    ok = lambda m, V_d=None, b=bmg: mab._tile_train_ok(m.train(), b, V_d)
+    assert ok(mab.MABBondMessagePassing(d_h=32)) and ok(mab.MABAtomMessagePassing(d_h=32))
+    assert ok(mab.MABBondMessagePassing(d_h=32, d_vd=3), torch.zeros(bmg.V.shape[0], 3))           # W_vd: inside the bond block's chain
+    assert not ok(mab.MABAtomMessagePassing(d_h=32, d_vd=3), torch.zeros(bmg.V.shape[0], 3))        # ... not with atom messages
+    assert not ok(mab.MABBondMessagePassing(d_h=32, return_vertex_embeddings=False))                 # the tile kernel's finalize IS the vertex read-out
+    assert ok(mab.MABBondMessagePassing(d_h=32, return_edge_embeddings=False, depth=1))
+    assert not ok(mab.MABBondMessagePassing(d_h=32, depth=1))                                        # the edge read-out reads a kept H^(depth-1)
+    assert not ok(mab.MABBondMessagePassing(d_h=32, undirected=True))
+    assert not ok(mab.MABBondMessagePassing(d_h=32, dropout=0.1))
+    assert not ok(mab.MABBondMessagePassing(d_h=32, activation="prelu")) and not ok(mab.MABBondMessagePassing(d_h=32, activation=torch.nn.Softplus()))
+    with torch.no_grad():
+        assert not ok(mab.MABBondMessagePassing(d_h=32))
+    frozen = mab.MABBondMessagePassing(d_h=32)
+    for p in frozen.parameters():
+        p.requires_grad_(False)
+    assert not ok(frozen)
+    odd = BatchMolGraph.from_tensors(bmg.V, bmg.E[:, :13].contiguous(), bmg.edge_index, bmg.rev_edge_index, bmg.batch, len(bmg))
+    assert not ok(mab.MABAtomMessagePassing(d_e=13, d_h=32), b=odd) and ok(mab.MABBondMessagePassing(d_e=13, d_h=32), b=odd)   # (the engine then refuses the odd width: RouteUnavailable -> the chain)
