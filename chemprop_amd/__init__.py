@@ -19,4 +19,27 @@ def __getattr__(name):
         from . import mab as _mab
 
         return getattr(_mab, name)
+    if name in ("enable", "enabled", "accelerate"):
+        from . import integration as _integration
+
+        return getattr(_integration, name)
     raise AttributeError(name)
+
+
+def _enable_from_env() -> None:
+    """``CHEMPROP_MI355X=1``: rebind the reference's classes at import (no new CLI flag) — when chemprop imports."""
+    import os
+
+    if os.environ.get("CHEMPROP_MI355X", "") not in ("1", "true", "on"):
+        return
+    try:
+        from .integration import enable
+
+        enable()
+    except ImportError as e:  # (chemprop is not installed next to this package: nothing to rebind)
+        import warnings
+
+        warnings.warn(f"CHEMPROP_MI355X=1 but chemprop does not import ({e}); chemprop_amd.enable() skipped")
+
+
+_enable_from_env()

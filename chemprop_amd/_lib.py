@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("DMPNN_LIB") or os.path.join(_HERE, "libdmpnn_gfx950.s
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_step16.hip", "dmpnn_bstep16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip", "dmpnn_optim.hip", "dmpnn_wgrad16.hip", "dmpnn_head.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp", "dmpnn_seg16.hpp", "dmpnn_step16_impl.hpp"]
-ABI_VERSION = 11
+ABI_VERSION = 12
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
@@ -35,6 +35,7 @@ EXPORTS = [
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
     "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles", "dmpnn_forward_route", "dmpnn_dropout_keep",
+    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -138,6 +139,7 @@ class StepArgs(C.Structure):
         ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n_params", C.c_int64),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
         ("bias_corr1", C.c_float), ("sqrt_bias_corr2", C.c_float), ("grad_scale", C.c_float), ("dev_scalars", C.c_void_p),
+        ("clip_val", C.c_float), ("clip_mode", C.c_int32), ("clip_ws", C.c_void_p),
     ]
 
 
@@ -191,7 +193,26 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: Optional[
         shutil.copyfile(linked, lib_path + ".tmp")
         os.chmod(lib_path + ".tmp", 0o755)
     os.replace(lib_path + ".tmp", lib_path)
+    _clean_unbundle_temporaries(lib_path)
     return lib_path
+
+
+def _clean_unbundle_temporaries(lib_path: str) -> int:
+    """Delete ``<lib>.N.hipv4-amdgcn-amd-amdhsa--gfx950`` / ``<lib>.N.host-x86_64-unknown-linux-gnu-``: what
+    ``clang-offload-bundler --unbundle`` / ``llvm-objdump --offloading`` leave next to the library they inspect (git-ignored, but they
+    would travel with every snapshot to the GPU box: 7 MB at the end of round 4)."""
+    import glob
+
+    n = 0
+    for f in glob.glob(glob.escape(lib_path) + ".*"):
+        tail = f[len(lib_path) + 1:]
+        if tail.split(".", 1)[0].isdigit() and ("hipv4-" in tail or "host-" in tail):
+            try:
+                os.remove(f)
+                n += 1
+            except OSError:
+                pass
+    return n
 
 
 _lib: Optional[C.CDLL] = None
@@ -240,7 +261,7 @@ def load() -> C.CDLL:
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes",
                   "dmpnn_forward_keep_bits_bytes",
-                  "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes", "dmpnn_head_ws_bytes")
+                  "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes", "dmpnn_head_ws_bytes", "dmpnn_clip_grad_ws_bytes")
     lib.dmpnn_linear16_wsplit_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_linear16_ok.argtypes = [C.POINTER(GemmArgs)]
     lib.dmpnn_linear16_fwd.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -269,6 +290,7 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.dmpnn_clip_grad.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
     lib.dmpnn_dropout_keep.argtypes = [C.c_uint64, C.c_int32, C.c_int64, C.c_int64, C.c_float]
     lib.dmpnn_forward_route.argtypes = [C.POINTER(FwdArgs), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.dmpnn_forward_tiles.argtypes = [C.POINTER(FwdArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p]

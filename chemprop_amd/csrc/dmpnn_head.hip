@@ -661,6 +661,9 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
             DMPNN_TRY(dmpnn_linear_wgrad(&g, rider.Z, rider.ldz, rider.gW, rider.ldgw, rider.gb, rider.ws, HL.wgrad_bytes, stream));
         }
     }
+    if ((stages & DMPNN_STEP_UPDATE) && a->n_params > 0 && a->clip_val > 0.f)   // Trainer(gradient_clip_val): between backward and update
+        DMPNN_TRY(dmpnn_clip_grad(const_cast<float*>(a->g), a->n_params, a->clip_val, a->clip_mode, a->grad_scale > 0.f ? a->grad_scale : 1.f,
+                                  a->clip_ws, stream));
     if ((stages & DMPNN_STEP_UPDATE) && a->n_params > 0)
         DMPNN_TRY(dmpnn_adam_step(a->p, a->g, a->m, a->v, a->n_params, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->bias_corr1,
                                   a->sqrt_bias_corr2, a->grad_scale, a->dev_scalars, stream));

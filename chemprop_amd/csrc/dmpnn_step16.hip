@@ -42,7 +42,9 @@ bool fused16_lean_shapes(const dmpnn_fwd_args& a) {
     const unsigned need = DMPNN_F_FUSED | DMPNN_F_SPLIT16;
     if ((a.flags & need) != need || (a.flags & (DMPNN_F_MEGA | DMPNN_F_UNDIRECTED | DMPNN_F_STORE16 | DMPNN_F_ATOM))) return false;
     if (!(a.act == DMPNN_ACT_NONE || a.act == DMPNN_ACT_RELU || a.act == DMPNN_ACT_LEAKYRELU)) return false;
-    if (a.W_d || a.dropout_p > 0.f || a.depth < 2 || a.n_edges <= 0 || a.n_atoms <= 0) return false;
+    // (depth <= kWProdMaxJobs: the backward pass of this route forms every weight gradient as ONE launch of at most that many product
+    //  jobs per matrix, dmpnn_backward.hip — a deeper block keeps the fp32 tensors and trains on the fused16 route as before)
+    if (a.W_d || a.dropout_p > 0.f || a.depth < 2 || a.depth > kWProdMaxJobs || a.n_edges <= 0 || a.n_atoms <= 0) return false;
     if (a.d_h <= 0 || a.d_h % 4 != 0 || a.ldh % 4 != 0 || a.d_v % 2 || a.d_e % 2 || a.ldv % 2 || a.lde % 2) return false;
     return x_path_shapes(a);
 }

@@ -110,6 +110,15 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: b
         o += n
 
 
+def force_collective() -> bool:
+    """``DMPNN_FORCE_COLLECTIVE=1`` (tests, one-GPU boxes): run the gradient exchange — the all-reduce on the communication stream, its
+    event, the stream-level wait — also at world size 1, where it is arithmetically the identity, so that the RCCL half of
+    :class:`GradSync` and the staged step of ``model.FusedTrainer`` execute on the hardware that is there."""
+    import os
+
+    return os.environ.get("DMPNN_FORCE_COLLECTIVE", "0") == "1"
+
+
 class GradSync:
     """The gradient exchange of a data-parallel training step, SURVEY 8e: ONE pre-allocated flat fp32 buffer holds every
     gradient, ``p.grad`` of every parameter is a view into it, and the message-passing block's backward kernels
@@ -137,6 +146,7 @@ class GradSync:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.n_collectives = 0  # all-reduces launched so far (diagnostics / tests)
         self.works: list = []   # pending exchanges of this step: (work, slice of the flat buffer, event on the communication stream)
         for p, v in zip(self.params, self.views):
             p.grad = v
@@ -209,8 +219,11 @@ class GradSync:
         self._gather(lo, hi)
         if whole or hi == self.flat.numel():
             self._written.clear()  # (the step's gradient is complete: the next backward starts a new one)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1 or hi <= lo:
+        if not (dist.is_available() and dist.is_initialized()) or hi <= lo:
             return
+        if dist.get_world_size(self.group) == 1 and not force_collective():
+            return
+        self.n_collectives += 1
         buf = self.flat[lo:hi]
         if self.stream is None:
             self.works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, None))

@@ -144,25 +144,125 @@ def hip_mlp_class():
 _mpnn_cache = None
 
 
+def _hip_adam_class():
+    """``torch.optim.Optimizer`` face of :class:`chemprop_amd.optim.FlatAdam` — what ``HipMPNN.configure_optimizers`` hands Lightning
+    in place of the reference's ``torch.optim.Adam`` (``models/model.py:208-209``).  Same param groups (the learning-rate scheduler
+    writes ``param_groups[0]["lr"]`` as before), ``step(closure)`` with Lightning's automatic-optimization closure semantics, and a
+    ``state_dict`` in ``torch.optim.Adam``'s own format, so a checkpoint moves between this optimizer and the stock one."""
+    import weakref
+
+    import torch
+
+    class HipAdam(torch.optim.Optimizer):
+        def __init__(self, module, param_groups, defaults):
+            groups = [{k: v for k, v in g.items()} for g in param_groups]
+            super().__init__(groups, dict(defaults))
+            self._module = weakref.ref(module)
+            self._pending = None          # (a state dict loaded before the flat buffers exist)
+
+        # -- the flat buffers live with the module (they follow its device); asked for at every use --
+        def _st(self):
+            m = self._module()
+            if m is None:
+                raise RuntimeError("HipAdam: the module it optimises is gone")
+            st = m._hip_state()
+            if self._pending is not None:
+                sd, self._pending = self._pending, None
+                self._load_torch(st, sd)
+            return st
+
+        def _all_params(self):
+            return [p for g in self.param_groups for p in g["params"]]
+
+        @torch.no_grad()
+        def step(self, closure=None):
+            loss = None
+            if closure is not None:
+                with torch.enable_grad():
+                    loss = closure()     # (Lightning, automatic optimization: training_step -> zero_grad -> backward -> clipping)
+            m = self._module()
+            if m.__dict__.pop("_hip_applied", False):
+                return loss              # the fused call of this closure already held the backward pass, the clip AND this update
+            st = self._st()
+            g, fl = self.param_groups[0], st["opt"]
+            fl.betas, fl.eps, fl.weight_decay = (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"]), float(g["weight_decay"])
+            fl.step(float(g["lr"]))
+            return loss
+
+        def zero_grad(self, set_to_none: bool = True) -> None:
+            self._st()["sync"].zero_grad()    # (one fill of the flat buffer; every p.grad stays its view)
+
+        # -- torch.optim.Adam's state-dict format: state[i] = {step, exp_avg, exp_avg_sq} for the i-th parameter of the groups --
+        def state_dict(self):
+            st = self._st()
+            fl, sync = st["opt"], st["sync"]
+            where = {id(p): (o, p.numel()) for p, o in zip(sync.params, sync.offsets)}
+            state, groups, i = {}, [], 0
+            for g in self.param_groups:
+                idx = []
+                for p in g["params"]:
+                    if fl.steps > 0 and id(p) in where:
+                        o, n = where[id(p)]
+                        state[i] = {"step": torch.tensor(float(fl.steps)), "exp_avg": fl.m[o:o + n].view_as(p).clone(),
+                                    "exp_avg_sq": fl.v[o:o + n].view_as(p).clone()}
+                    idx.append(i)
+                    i += 1
+                groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": idx})
+            return {"state": state, "param_groups": groups}
+
+        def load_state_dict(self, sd):
+            for g, sg in zip(self.param_groups, sd["param_groups"]):
+                for k, v in sg.items():
+                    if k != "params":
+                        g[k] = v
+            m = self._module()
+            if m is not None and m.__dict__.get("_hip") is not None:
+                self._load_torch(m._hip_state(), sd)
+            else:
+                self._pending = sd
+
+        def _load_torch(self, st, sd):
+            fl, sync = st["opt"], st["sync"]
+            where = {id(p): (o, p.numel()) for p, o in zip(sync.params, sync.offsets)}
+            fl.m.zero_()
+            fl.v.zero_()
+            fl.steps = 0
+            for i, p in enumerate(self._all_params()):
+                e = sd["state"].get(i)
+                if e is None or id(p) not in where:
+                    continue
+                o, n = where[id(p)]
+                fl.m[o:o + n].view_as(p).copy_(e["exp_avg"].to(fl.m.device))
+                fl.v[o:o + n].view_as(p).copy_(e["exp_avg_sq"].to(fl.v.device))
+                fl.steps = max(fl.steps, int(e["step"]))
+
+    return HipAdam
+
+
 def hip_mpnn_class():
     """Build (once) ``class HipMPNN(chemprop.models.MPNN)``: the reference's LightningModule whose ``training_step``
-    (``models/model.py:148-161``) + optimizer step (``:208-231``) is ONE ``dmpnn_train_step`` call per batch.
+    (``models/model.py:148-161``) + optimizer step (``:208-231``) is ONE ``dmpnn_train_step`` call per batch — under Lightning's
+    AUTOMATIC optimization, i.e. under the ``Trainer`` that ``chemprop train`` builds (``cli/train.py:1912-1999``) as it is:
 
-    * ``automatic_optimization = False`` (Lightning's manual optimization): the step — K0, block forward, aggregation, batch norm,
-      predictor, criterion, the backward pass of all of it, Adam — is enqueued by :class:`chemprop_amd.model.FusedTrainer`; the
-      parameters live in ONE flat buffer (``optim.FlatAdam``: ``torch.optim.Adam``'s arithmetic as one launch), the gradients in
-      another (``distributed.GradSync``: with more than one rank the step exchanges them itself over ``torch.distributed``'s
-      default group, in two slices, so run one process per GPU with a strategy that does NOT wrap the module in DDP).
-    * ``configure_optimizers`` is inherited: the reference's ``Adam`` + Noam-like ``LambdaLR`` (``schedulers.py``) stay the source
-      of the learning rate — every step reads ``optimizer.param_groups[0]["lr"]`` and advances the scheduler — but the torch
-      optimizer itself is never stepped.  The moments travel in the checkpoint under ``"hip_flat_adam"``
-      (``on_save_checkpoint`` / ``on_load_checkpoint``).
-    * What the fused step does not implement (``FusedTrainer`` refuses loudly: classification / MVE / evidential heads, predictor
-      dropout, ``V_d`` / ``X_d`` inputs, attentive aggregation, atom / mol-atom-bond blocks) trains through the MODULE path in the
-      same ``training_step``: the reference's own arithmetic (``super().training_step``) through autograd on the HIP kernels,
-      ``loss.backward()``, the same flat Adam.
-    * everything else — ``forward``, ``fingerprint``, ``validation_step``, ``predict_step``, ``load_from_checkpoint``, hparams,
-      state-dict keys — is the reference's, untouched; the blocks inside are swapped for their HIP subclasses (:func:`accelerate`).
+    * ``configure_optimizers`` returns the reference's own dictionary with the ``torch.optim.Adam`` replaced by ``HipAdam`` (same
+      param groups; one flat buffer of parameters, one of gradients, one launch per update: ``optim.FlatAdam``) and the reference's
+      Noam-like ``LambdaLR`` re-created on it with the reference's own ``lr_lambda`` (``schedulers.py``).  Lightning steps the
+      scheduler, counts ``trainer.global_step`` through ``LightningOptimizer.step`` (what ``ModelCheckpoint`` keys on,
+      ``cli/train.py:1912-1919``), saves ``optimizer.state_dict()`` (``torch.optim.Adam``'s format) in its checkpoints.
+    * ``training_step``: where :class:`chemprop_amd.model.FusedTrainer` applies (a bond block with a built-in activation, sum / mean /
+      norm aggregation, batch norm, regression MLP, MSE / MAE, no ``V_d`` / ``X_d``) the whole step — K0, forward, head, backward,
+      clip, Adam — is enqueued by that one call with this step's learning rate and ``Trainer(gradient_clip_val)``
+      (``cli/train.py:1937``); the hooks Lightning runs afterwards inside ``optimizer.step(closure)`` — ``backward``,
+      ``configure_gradient_clipping``, the optimizer's own update — find the work done and return.  Everything else is the MODULE
+      path: the reference's arithmetic through autograd on the HIP kernels, returned as a loss with a graph; Lightning's closure runs
+      ``backward`` (→ the gradient exchange), the clip over the flat buffer, ``HipAdam.step``.  ``train_loss`` is logged ONCE per step.
+    * more than one rank (``--devices N``: ``DDPStrategy`` wraps the module, ``cli/train.py:1934,1943``): the module owns the gradient
+      exchange — ONE flat all-reduce over ``torch.distributed``'s default group (RCCL), in two slices under the fused step — and
+      switches the wrapper's own reducer off (``require_backward_grad_sync = False``, what ``no_sync()`` sets): the fused step never
+      runs autograd, and the module path would otherwise reduce twice.
+    * without a ``Trainer`` ``training_step`` is the reference's: a loss with a graph, nothing updated.
+    * ``forward``, ``fingerprint``, ``validation_step``, ``predict_step``, ``load_from_checkpoint``, hparams, state-dict keys are
+      the reference's, untouched; the blocks inside are swapped for their HIP subclasses (:func:`accelerate`).
     """
     global _mpnn_cache
     if _mpnn_cache is not None:
@@ -171,14 +271,17 @@ def hip_mpnn_class():
         from chemprop.models.model import MPNN as Ref  # noqa: WPS433
     except Exception as e:  # pragma: no cover
         raise ImportError("chemprop_amd.integration needs an importable `chemprop`") from e
+    import torch
+
+    HipAdam = _hip_adam_class()
 
     class HipMPNN(Ref):  # type: ignore[misc, valid-type]
         def __init__(self, *args, **kwargs):
             super().__init__(*args, **kwargs)
-            self.automatic_optimization = False
             accelerate(self)
-            self.__dict__["_hip"] = None          # (trainer state: built lazily on the device the module was moved to)
+            self.__dict__["_hip"] = None          # (flat buffers + fused trainer: built lazily on the device the module was moved to)
             self.__dict__["_hip_adam_state"] = None
+            self.__dict__["_hip_optimizer"] = None
 
         # ---- the flat optimizer state shared by the fused step and the module path ----
         def _hip_state(self):
@@ -190,7 +293,7 @@ def hip_mpnn_class():
             from .model import FusedTrainer
             from .optim import FlatAdam
 
-            st = {"dev": dev, "fused": None, "why": None}
+            st = {"dev": dev, "fused": None, "why": None, "route": None}
             try:
                 tr = FusedTrainer(self, lr=float(self.init_lr))
                 st["fused"], st["sync"], st["opt"] = tr, tr.sync, tr.opt
@@ -205,74 +308,123 @@ def hip_mpnn_class():
             self.__dict__["_hip"] = st
             return st
 
-        def _hip_lr_and_sched(self):
-            """The reference's schedule as the source of this step's learning rate (``configure_optimizers``: Adam + LambdaLR)."""
-            try:
-                opt, sch = self.optimizers(), self.lr_schedulers()
-            except Exception:   # (no trainer attached: a bare loop drives training_step)
-                return float(self.init_lr), None
-            if isinstance(opt, (list, tuple)):
-                opt = opt[0]
-            if isinstance(sch, (list, tuple)):
-                sch = sch[0]
-            return float(opt.param_groups[0]["lr"]), sch
+        def configure_optimizers(self):
+            from torch.optim.lr_scheduler import LambdaLR
+
+            cfg = super().configure_optimizers()          # the reference's: Adam(self.parameters(), init_lr) + Noam-like LambdaLR
+            ref_opt, sc = cfg["optimizer"], cfg["lr_scheduler"]
+            sched = sc["scheduler"] if isinstance(sc, dict) else sc
+            if not isinstance(sched, LambdaLR):
+                raise TypeError(f"HipMPNN.configure_optimizers: expected the reference's LambdaLR schedule, got {type(sched).__name__}")
+            for g in ref_opt.param_groups:    # (LambdaLR's constructor stamped the start rate; the new scheduler stamps it again)
+                g.pop("initial_lr", None)
+                g["lr"] = ref_opt.defaults["lr"]
+            opt = HipAdam(self, ref_opt.param_groups, ref_opt.defaults)
+            new = LambdaLR(opt, list(sched.lr_lambdas) if len(sched.lr_lambdas) > 1 else sched.lr_lambdas[0])
+            self.__dict__["_hip_optimizer"] = opt
+            cfg["optimizer"] = opt
+            cfg["lr_scheduler"] = {**sc, "scheduler": new} if isinstance(sc, dict) else new
+            return cfg
+
+        # ---- Lightning's context ----
+        def _hip_trainer(self):
+            """``(trainer, our optimizer)`` when a Trainer drives this module with the optimizer ``configure_optimizers`` built; else
+            ``(trainer or None, None)`` — a user's own optimizer, or no Trainer: the reference's semantics."""
+            tr = getattr(self, "_trainer", None)      # (LightningModule.trainer raises when unattached: core/module.py)
+            if tr is None:
+                return None, None
+            opt = self.__dict__.get("_hip_optimizer")
+            if opt is None or not any(o is opt for o in getattr(tr, "optimizers", ())):
+                return tr, None
+            return tr, opt
+
+        def _hip_own_the_exchange(self, tr):
+            """More than one rank under a DDP wrap: the gradient exchange is this module's (``GradSync``); the wrapper's reducer stays
+            off — what ``DistributedDataParallel.no_sync()`` sets, for good."""
+            from torch.nn.parallel import DistributedDataParallel as DDP
+
+            w = getattr(getattr(tr, "strategy", None), "model", None)
+            if isinstance(w, DDP) and w.require_backward_grad_sync:
+                w.require_backward_grad_sync = False
 
         def training_step(self, batch, batch_idx):
+            tr, opt = self._hip_trainer()
+            if opt is None:
+                # no Trainer, or a Trainer with an optimizer that is not ours: the reference's step (a loss with a graph; whoever
+                # drives the loop calls backward and steps) on the HIP kernels of the swapped blocks
+                return Ref.training_step(self, batch, batch_idx)
             bmg, V_d, X_d, targets, weights, lt_mask, gt_mask = batch
-            st = self._hip_state()
-            lr, sch = self._hip_lr_and_sched()
-            loss = None
-            tr = st["fused"]
-            if tr is not None and V_d is None and X_d is None and self.training:
+            st = opt._st()     # (the flat buffers of this device; a state dict loaded before they existed goes in now)
+            self._hip_own_the_exchange(tr)
+            self.__dict__["_hip_applied"] = False
+            loss, logged = None, False
+            fused = st["fused"]
+            accumulate = int(getattr(tr, "accumulate_grad_batches", 1) or 1)
+            if fused is not None and V_d is None and X_d is None and self.training and accumulate == 1:
                 try:
-                    out = tr.step(bmg, targets, weights, lt_mask, gt_mask, lr=lr)
+                    clip = (getattr(tr, "gradient_clip_val", None), getattr(tr, "gradient_clip_algorithm", None) or "norm")
+                    g = opt.param_groups[0]
+                    fl = st["opt"]
+                    fl.betas, fl.eps, fl.weight_decay = (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"]), float(g["weight_decay"])
+                    out = fused.step(bmg, targets, weights, lt_mask, gt_mask, lr=float(g["lr"]), clip=clip)
                     loss = out[0]
-                    st["route"] = "fused:" + str(tr.last_route)
+                    self.__dict__["_hip_applied"] = True
+                    st["route"] = "fused:" + str(fused.last_route)
                 except NotImplementedError as e:   # (a batch the fused step refuses, e.g. dropout on a batch beyond the tile kernels)
                     st["why"] = str(e)
             if loss is None:
-                # the module path: the reference's own training_step arithmetic through autograd, the same flat Adam
-                sync, opt = st["sync"], st["opt"]
-                sync.wait()
-                sync.zero_grad()
-                l = None
+                # the module path: a loss with a graph; Lightning's closure runs backward() (below), the clip, HipAdam.step()
+                st["sync"].wait()
                 if X_d is None and self.training:
                     # everything behind the block as ONE autograd node on the head kernels where they implement this model
                     # (chemprop_amd.model.head_loss: aggregation, batch norm, predictor, criterion + their backward in one call)
                     from .model import criterion_kind, head_loss
 
                     bounded = criterion_kind(self.criterion)[1]
-                    l = head_loss(self, self.message_passing(bmg, V_d), bmg.batch, len(bmg), targets, weights,
-                                  lt_mask if bounded else None, gt_mask if bounded else None)
-                if l is None:
-                    l = Ref.training_step(self, batch, batch_idx)   # the reference's own arithmetic, torch ops behind the block
-                l.backward()
-                sync.allreduce()
-                opt.step(lr)
-                loss = l.detach()
+                    loss = head_loss(self, self.message_passing(bmg, V_d), bmg.batch, len(bmg), targets, weights,
+                                     lt_mask if bounded else None, gt_mask if bounded else None)
+                if loss is None:
+                    loss = Ref.training_step(self, batch, batch_idx)   # the reference's own arithmetic AND its own train_loss log
+                    logged = True
                 st["route"] = "module"
-            if sch is not None:
-                sch.step()
-            # (the reference logs the criterion Metric object — epoch value = sum L / sum mask; the batch's scalar weighted by the
-            #  batch size is the same number whenever no target is missing)
-            self.log("train_loss", loss, batch_size=len(bmg), prog_bar=True, on_epoch=True)
+            if not logged:
+                # (the reference logs the criterion Metric object — epoch value = sum L / sum mask; the batch's scalar weighted by the
+                #  batch size is the same number whenever no target is missing)
+                self.log("train_loss", loss.detach(), batch_size=len(bmg), prog_bar=True, on_epoch=True)
             return loss
 
-        # ---- the flat Adam's moments in Lightning's checkpoint ----
-        def on_save_checkpoint(self, checkpoint) -> None:
+        def on_train_start(self) -> None:
+            super().on_train_start()
+            tr, opt = self._hip_trainer()
+            if opt is not None:
+                self._hip_own_the_exchange(tr)
+
+        # ---- the hooks Lightning's automatic optimization runs inside optimizer.step(closure) ----
+        def backward(self, loss, *args, **kwargs):
+            if self.__dict__.get("_hip_applied"):
+                return                       # the fused call held the backward pass
+            from .distributed import backward_on_calling_thread
+
+            with backward_on_calling_thread():
+                super().backward(loss, *args, **kwargs)
             st = self.__dict__.get("_hip")
-            if st is not None:
-                checkpoint["hip_flat_adam"] = {k: (v.cpu() if hasattr(v, "cpu") else v) for k, v in st["opt"].state_dict().items()}
+            if st is not None and self._hip_trainer()[1] is not None:
+                st["sync"].allreduce()        # ONE flat all-reduce (no-op on one rank); the clip and the update wait for it on the stream
 
-        def on_load_checkpoint(self, checkpoint) -> None:
-            sd = checkpoint.get("hip_flat_adam")
-            if sd is not None:
-                self.__dict__["_hip_adam_state"] = sd
-                self.__dict__["_hip"] = None
+        def configure_gradient_clipping(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+            if self.__dict__.get("_hip_applied"):
+                return                       # clipped inside the fused call (dmpnn_step_args.clip_val)
+            st = self.__dict__.get("_hip")
+            if st is None or self._hip_trainer()[1] is None:
+                return super().configure_gradient_clipping(optimizer, gradient_clip_val=gradient_clip_val,
+                                                           gradient_clip_algorithm=gradient_clip_algorithm)
+            if gradient_clip_val is not None and float(gradient_clip_val) > 0:
+                st["opt"].clip_grad(float(gradient_clip_val), gradient_clip_algorithm or "norm")
 
+        # ---- device moves re-create the flat buffers: carry the moments over ----
         def _apply(self, fn, *args, **kwargs):
             st = self.__dict__.get("_hip")
-            if st is not None:   # (a device move re-creates the flat buffers: carry the moments over)
+            if st is not None:
                 self.__dict__["_hip_adam_state"] = {k: (v.cpu() if hasattr(v, "cpu") else v) for k, v in st["opt"].state_dict().items()}
                 self.__dict__["_hip"] = None
             return super()._apply(fn, *args, **kwargs)
@@ -364,3 +516,79 @@ def accelerate(model, aggregation: bool = True, ffn: bool = True):
             m.__class__ = HipMLP
             n += 1
     return n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the switch: `CHEMPROP_MI355X=1 chemprop train ...` / `chemprop-amd train ...` / chemprop_amd.enable()
+# ------------------------------------------------------------------------------------------------------------------
+_enabled = None
+
+# modules of the reference that bind the classes BY NAME at import time (cli/train.py:60-68, :1500, :1598, :1623; models/utils.py:5;
+# cli/predict.py:34-35; cli/fingerprint.py:19) — rebinding the defining module alone would not reach them
+_BINDING_MODULES = ("chemprop.nn", "chemprop.nn.message_passing", "chemprop.nn.message_passing.base", "chemprop.nn.message_passing.mol_atom_bond",
+                    "chemprop.models", "chemprop.models.model", "chemprop.models.utils", "chemprop.cli.train", "chemprop.cli.predict",
+                    "chemprop.cli.fingerprint", "chemprop.cli.hpopt", "chemprop")
+
+
+def enable(fused_step: bool = True, verbose: bool = False) -> dict:
+    """Make an installed chemprop build and load its models on the MI355X engine WITHOUT editing it (SURVEY §5 "Engine selection
+    must not need a new CLI flag"): every place the reference binds ``BondMessagePassing`` / ``AtomMessagePassing`` /
+    ``MABBondMessagePassing`` / ``MABAtomMessagePassing`` (and, with ``fused_step``, ``MPNN``) by name — ``chemprop.nn``,
+    ``chemprop.models``, ``chemprop.cli.train`` (``cli/train.py:60-68``: ``build_model`` at ``:1500,:1598,:1623``) ... — is rebound to
+    the HIP subclass, and ``load_model`` / ``MPNN.load_from_file`` (``models/utils.py:27-35``, ``models/model.py:318-329``: predict /
+    fingerprint) accelerate what they load.  Checkpoints keep naming the reference classes (``hparams["cls"]``), so they load in a
+    stock chemprop.  Idempotent; returns ``{module name: [names rebound]}``.
+
+    Triggered by ``CHEMPROP_MI355X=1`` at ``import chemprop_amd`` (when chemprop is importable), by the ``chemprop-amd`` console entry
+    (``chemprop_amd.cli: enable(); chemprop.cli.main.main()``), or by the one-line stub of INTEGRATION.md §2f in ``chemprop/__init__.py``."""
+    global _enabled
+    import importlib
+    import sys
+
+    Ref = _reference_class()
+    mapping = {Ref: hip_bond_message_passing_class()}
+    RefAtom, HipAtom = hip_atom_message_passing_class()
+    mapping[RefAtom] = HipAtom
+    try:
+        mapping.update(hip_mab_message_passing_classes())
+    except ImportError:
+        pass
+    if fused_step:
+        RefM, HipM = hip_mpnn_class()
+        mapping[RefM] = HipM
+    for name in _BINDING_MODULES:           # (the CLI modules exist only in a full install; bind them if they import)
+        if name not in sys.modules and name.startswith("chemprop.cli"):
+            try:
+                importlib.import_module(name)
+            except Exception:
+                pass
+    done: dict = {}
+    for name in _BINDING_MODULES:
+        mod = sys.modules.get(name)
+        if mod is None:
+            continue
+        for attr, val in list(vars(mod).items()):
+            if isinstance(val, type) and val in mapping:
+                setattr(mod, attr, mapping[val])
+                done.setdefault(name, []).append(attr)
+    # what predict / fingerprint load: MPNN.load_from_file builds the blocks from hparams["cls"] (the reference classes, by design)
+    RefM = hip_mpnn_class()[0]
+    if not getattr(RefM.load_from_file, "_hip_accelerated", False):
+        orig = RefM.load_from_file.__func__
+
+        def load_from_file(cls, *args, **kwargs):
+            model = orig(cls, *args, **kwargs)
+            accelerate(model)
+            return model
+
+        load_from_file._hip_accelerated = True
+        RefM.load_from_file = classmethod(load_from_file)
+        done.setdefault("chemprop.models.model", []).append("MPNN.load_from_file")
+    _enabled = done
+    if verbose:
+        print(f"chemprop_amd.enable(): {done}")
+    return done
+
+
+def enabled() -> bool:
+    return _enabled is not None

@@ -138,7 +138,7 @@ def _tile_train_ok(mp, bmg, V_d) -> bool:
     an even d_e of 2 .. 16.  Molecules beyond the tile, and everything else: the rows route."""
     if not (torch.is_grad_enabled() and any(p.requires_grad for p in mp.parameters())):
         return False
-    if mp.W_vo is None or mp.undirected or (mp.training and mp.dropout.p > 0) or getattr(bmg, "oversize", None) is True:
+    if mp.W_vo is None or mp.undirected or (mp.training and mp.dropout.p > 0):
         return False
     if classify_activation(mp.tau)[0] in ("custom", "prelu"):
         return False
@@ -149,7 +149,11 @@ def _tile_train_ok(mp, bmg, V_d) -> bool:
         return False
     if mp.atom_messages and (V_d is not None or not (2 <= d_e <= 16 and d_e % 2 == 0)):
         return False
-    return True
+    # a molecule beyond the tile is NaN on these training routes (forward and every gradient: the kernels' generic path has neither
+    # atom messages nor the second read-out's kept rows) — the host must KNOW, not guess: counted on the device for a foreign batch
+    from .nn import batch_oversize
+
+    return batch_oversize(bmg, len(bmg) if hasattr(bmg, "__len__") else 0) is False
 
 
 def mab_forward(mp, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = None):

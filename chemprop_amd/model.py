@@ -23,7 +23,7 @@ from torch import Tensor, nn
 
 from . import _lib, engine
 from .agg import MODES, Aggregation, NormAggregation, note_batch
-from .distributed import GradSync
+from .distributed import GradSync, force_collective
 from .ffn import MLP
 from .nn import BondMessagePassing, classify_activation
 from .optim import FlatAdam
@@ -316,13 +316,21 @@ def head_loss(model, Hv: Tensor, batch: Tensor, n_mols: int, targets: Tensor, we
     """``criterion(predictor.train_step(bn(agg(H_v, batch))), targets, ...)`` (``models/model.py:152-157``) as ONE autograd node on the
     head kernels (:class:`_HeadLoss`); ``None`` when the head kernels do not implement this model or these inputs (the caller then
     runs the torch modules)."""
-    spec = model.__dict__.get("_dmpnn_head_spec")
-    if spec is None:
+    # (cached on the identities of what the spec was read from — swapping model.predictor / criterion / bn / agg, or changing a
+    #  predictor dropout p, after the first step must not leave the old modules in use: round-4 ADVICE)
+    pred = model.predictor
+    key = (id(model.agg), id(model.bn), id(pred), id(getattr(pred, "criterion", None)), id(getattr(pred, "ffn", None)),
+           id(getattr(pred, "output_transform", None)),
+           tuple(float(getattr(m, "p", 0.0)) for m in pred.modules() if isinstance(m, nn.Dropout)) if isinstance(pred, nn.Module) else ())
+    cached = model.__dict__.get("_dmpnn_head_spec")
+    if cached is not None and cached[0] == key:
+        spec = cached[1]
+    else:
         try:
             spec = HeadSpec(model)
         except NotImplementedError as e:
             spec = str(e)
-        model.__dict__["_dmpnn_head_spec"] = spec
+        model.__dict__["_dmpnn_head_spec"] = (key, spec)
     if isinstance(spec, str) or Hv.device.type != "cuda" or Hv.dtype != torch.float32:
         return None
     if batch is None or batch.dtype != torch.int64 or not batch.is_contiguous() or batch.numel() != Hv.shape[0] or batch.device != Hv.device:
@@ -396,10 +404,11 @@ class FusedTrainer:
         return d.get_world_size(self.sync.group) if (d.is_available() and d.is_initialized()) else 1
 
     def step(self, bmg, targets: Tensor, weights: Optional[Tensor] = None, lt_mask: Optional[Tensor] = None,
-             gt_mask: Optional[Tensor] = None, lr: Optional[float] = None) -> Tensor:
+             gt_mask: Optional[Tensor] = None, lr: Optional[float] = None, clip: Optional[tuple] = None) -> Tensor:
         """One optimisation step on ``(bmg, targets, ...)`` (a ``TrainingBatch`` without ``V_d`` / ``X_d``); returns the device
         tensor ``[loss, number of finite targets]`` of THIS step (no host sync).  ``model.train()`` semantics (batch norm uses
-        and updates batch statistics)."""
+        and updates batch statistics).  ``clip = (value, "norm" | "value")``: Lightning's ``gradient_clip_val`` / ``_algorithm``
+        (``cli/train.py:1937``), applied between the backward pass and the update inside the same call."""
         from .nn import _VALIDATE_FIRST_N, _route, _training_plan_kind
 
         lib = _lib.load()
@@ -436,12 +445,19 @@ class FusedTrainer:
         # CSR plan, the kept tensors stay in the caller's edge order and the backward tile kernel reads the batch's own index
         # arrays (DMPNN_F_TILE_PLAN; every tile checks itself, a molecule beyond the tile takes the kernels' generic path).
         no_mega = getattr(mp, "_dmpnn_no_mega", False) or (n_mols > 0 and nE > 30 * n_mols)
-        level = 1 if (no_mega or getattr(bmg, "oversize", None) is True) else 2
+        oversize = getattr(bmg, "oversize", None)
+        if oversize is None and mp.dropout.p > 0 and not no_mega:
+            # (dropout lives inside the tile kernels only; their generic path for a molecule beyond the tile has none and answers NaN —
+            #  which this step would feed to Adam.  A foreign batch is counted on the device: nn.batch_oversize)
+            from .nn import batch_oversize
+
+            oversize = batch_oversize(bmg, n_mols)
+        level = 1 if (no_mega or oversize is True) else 2
         # (ONE rule for "this training forward runs on the tile plan", the module path's: shapes of the tile kernel — d_h <= 320, even
         #  d_v / d_e —, the environment switches, a plan the library can build; anything else keeps the full plan and the per-step routes)
         kind = _training_plan_kind(mp, bmg) if (self.tile_plan and not validate and level == 2) else False
         plan = engine.GraphPlan.from_bmg(bmg, light=kind, launch=validate)
-        plan.oversize = getattr(bmg, "oversize", None)
+        plan.oversize = oversize
         if validate:
             self._checked += 1
             level = _route(mp, plan, n_mols, batch)
@@ -502,13 +518,17 @@ class FusedTrainer:
         s.plan_bytes, s.plan_ready = plan.buf.numel() * 4, (1 if validate else 0)
         s.bwd, s.head = b, h
         opt = self.opt
-        fused_update = world == 1
+        fused_update = world == 1 and not force_collective()   # (forced: the staged data-parallel step also on one rank)
         if fused_update:
             k = opt.steps + 1  # (committed below, once the call has returned OK: a refused step must not advance Adam's bias correction)
             b1, b2 = opt.betas
             s.p, s.g, s.m, s.v, s.n_params = opt.flat.data_ptr(), self.sync.flat.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr(), opt.flat.numel()
             s.lr, s.beta1, s.beta2, s.eps, s.weight_decay = float(opt.lr if lr is None else lr), b1, b2, opt.eps, opt.weight_decay
             s.bias_corr1, s.sqrt_bias_corr2, s.grad_scale = 1.0 - b1 ** k, math.sqrt(1.0 - b2 ** k), 1.0
+            if clip is not None and clip[0] is not None and float(clip[0]) > 0:
+                from .optim import CLIP_MODES
+
+                s.clip_val, s.clip_mode, s.clip_ws = float(clip[0]), CLIP_MODES[clip[1] or "norm"], opt.clip_ws.data_ptr()
         with engine._OnDevice(dev):
             if fused_update:
                 _lib.check(lib.dmpnn_train_step(C.byref(s), engine._stream_ptr(dev)), "dmpnn_train_step")
@@ -531,5 +551,5 @@ class FusedTrainer:
                 torch.autograd.graph.increment_version(p)
             self.sync.new_step()
         else:
-            opt.step(lr)
+            opt.step(lr, clip=None if (clip is None or clip[0] is None or not float(clip[0]) > 0) else (float(clip[0]), clip[1] or "norm"))
         return loss

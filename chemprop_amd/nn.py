@@ -368,6 +368,10 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         getattr(bmg, "batch", None) is not None and not engine.small_plan_fits(int(bmg.V.shape[0]), int(bmg.E.shape[0]))
         and bool(_lib.load().dmpnn_tile_plan_any_size(int(bmg.V.shape[0]), int(bmg.E.shape[0]))))
     oversize = getattr(bmg, "oversize", None)  # host knowledge of the batching code (None: bare tensors)
+    if oversize is None and mp.training and mp.dropout.p > 0 and torch.is_grad_enabled():
+        # (active dropout lives inside the tile kernels, whose generic path for a molecule beyond the tile has none: such a molecule
+        #  would be NaN there — and the NaN loss would reach the optimizer.  Counted on the device for a foreign batch.)
+        oversize = batch_oversize(bmg, n_mols)
     if oversize is True:
         loader_tiles = False
     # (an inference forward of the fused routes: tile kernel, per-step fused route on the f16 pipe, fp32 fused route)
@@ -375,7 +379,8 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     if light and oversize is not True and _tile_plan_ok(mp, int(bmg.V.shape[0]), int(bmg.E.shape[0]), n_mols, loader_tiles):
         light = "tiles"
     if not light and torch.is_grad_enabled() and V_d is None:
-        light = _training_plan_kind(mp, bmg)   # a training forward bound for the tile kernels: the tile plan (DMPNN_F_TILE_PLAN)
+        # a training forward bound for the tile kernels: the tile plan (DMPNN_F_TILE_PLAN)
+        light = _training_plan_kind(mp, bmg) if oversize is not True else False
     # (a tile plan: K0 is deferred into the forward's own call where the library can run it with the weight pre-split in ONE launch)
     plan = engine.GraphPlan.from_bmg(bmg, light=light, launch="defer" if light == "tiles" else True)
     if n_mols and getattr(bmg, "batch", None) is not None:
@@ -399,6 +404,32 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
 
 
 _VALIDATE_FIRST_N = 2
+
+
+def batch_oversize(bmg, n_mols: int = 0):
+    """``True`` / ``False``: a molecule of this batch exceeds the tile of the whole-forward kernels (> 32 atoms or > 48 directed
+    edges).  Our own batching code knows (``bmg.oversize``, free while batching).  For a foreign batch — the reference's
+    ``BatchMolGraph`` (``slots=True``: nothing can be attached to it, ``data/collate.py:13``) — it is COUNTED on the device from
+    ``bmg.batch`` (two ``bincount`` + one host read): used only by the routes on which an oversize molecule is NaN rather than slow
+    (atom messages, the mol-atom-bond blocks, active dropout on the tile kernels: the kernels' generic path implements none of
+    them), where a NaN loss would otherwise reach the optimizer (round-4 ADVICE medium).  ``None``: no batch vector to count from."""
+    o = getattr(bmg, "oversize", None)
+    if o is not None:
+        return bool(o)
+    batch = getattr(bmg, "batch", None)
+    if batch is None or batch.dtype != torch.int64 or batch.numel() != int(bmg.V.shape[0]):
+        return None
+    from .data import TILE_MAX_ATOMS, TILE_MAX_EDGES
+
+    if batch.numel() == 0:
+        return False
+    n_mols = int(n_mols) if n_mols else 0
+    na = torch.bincount(batch, minlength=n_mols)
+    bad = na.max() > TILE_MAX_ATOMS
+    if int(bmg.E.shape[0]) > 0:
+        ne = torch.bincount(batch[bmg.edge_index[1]], minlength=n_mols)
+        bad = bad | (ne.max() > TILE_MAX_EDGES)
+    return bool(bad.item())
 
 
 def _light_plan_ok(mp) -> bool:
@@ -551,8 +582,10 @@ def atom_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     # activation, molecules that fit a tile, d_e <= 16.  Everything else: the per-step kernels chained below. ----
     act, slope, slope_t = classify_activation(mp.tau)
     grad = torch.is_grad_enabled() and any(p.requires_grad for p in mp.parameters())
+    # (an oversize molecule is NaN on the atom variant of the tile kernels — their generic path knows bond messages only — so the
+    #  host must KNOW: counted on the device for a foreign batch, batch_oversize)
     if (not grad and not has_vd and act != "custom" and not mp.undirected and not (mp.training and mp.dropout.p > 0)
-            and 1 <= int(E.shape[1]) <= 16 and int(E.shape[0]) > 0 and getattr(bmg, "oversize", None) is not True):
+            and 1 <= int(E.shape[1]) <= 16 and int(E.shape[0]) > 0 and batch_oversize(bmg, n_mols) is False):
         nV_, nE_ = int(V.shape[0]), int(E.shape[0])
         loader_tiles = getattr(bmg, "tiles", None) is not None or (
             getattr(bmg, "batch", None) is not None and not engine.small_plan_fits(nV_, nE_) and bool(_lib.load().dmpnn_tile_plan_any_size(nV_, nE_)))
@@ -573,7 +606,7 @@ def atom_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
         if light:
             plan = engine.GraphPlan.from_bmg(bmg)
     elif (grad and not has_vd and act not in ("custom", "prelu") and not mp.undirected and not (mp.training and mp.dropout.p > 0)
-          and 2 <= int(E.shape[1]) <= 16 and int(E.shape[1]) % 2 == 0 and int(E.shape[0]) > 0 and getattr(bmg, "oversize", None) is not True
+          and 2 <= int(E.shape[1]) <= 16 and int(E.shape[1]) % 2 == 0 and int(E.shape[0]) > 0 and batch_oversize(bmg, n_mols) is False
           and not V.requires_grad and not E.requires_grad):
         # ---- round 4: TRAINING on the tile kernels (DMPNN_F_ATOM | DMPNN_F_KEEP): one forward launch that keeps what the backward tile
         # kernel and the weight-gradient products read (sign bits or H^(t), M^(t), the bond-feature half of the messages), one autograd

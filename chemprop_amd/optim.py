@@ -20,7 +20,9 @@ import torch
 from . import _lib, engine
 from .distributed import GradSync
 
-__all__ = ["FlatAdam"]
+__all__ = ["FlatAdam", "CLIP_MODES"]
+
+CLIP_MODES = {"norm": 0, "value": 1}   # enum dmpnn_clip_mode
 
 
 class FlatAdam:
@@ -49,19 +51,43 @@ class FlatAdam:
         self.m = torch.zeros_like(sync.flat)
         self.v = torch.zeros_like(sync.flat)
         self._dev = dev
+        self.clip_ws = torch.zeros(int(_lib.load().dmpnn_clip_grad_ws_bytes()) // 4, dtype=torch.float32, device=dev)
 
-    def step(self, lr: Optional[float] = None) -> None:
+    def _grad_scale(self) -> float:
+        s = self.sync
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(s.group)
+        return 1.0 if (s.average or world == 1) else 1.0 / world
+
+    def clip_grad(self, clip_val: float, algorithm: str = "norm") -> None:
+        """``torch.nn.utils.clip_grad_norm_(params, clip_val)`` / ``clip_grad_value_`` over the flat gradient buffer (what Lightning's
+        ``Trainer(gradient_clip_val=..., gradient_clip_algorithm=...)`` runs between the backward pass and ``optimizer.step``,
+        ``cli/train.py:1937``): after the pending exchange, on the AVERAGED gradient, no host read.  The total norm stays on the
+        device in ``self.clip_ws[256]``."""
+        if clip_val is None or not (float(clip_val) > 0):
+            return
+        if algorithm not in CLIP_MODES:
+            raise ValueError(f"gradient_clip_algorithm must be one of {sorted(CLIP_MODES)}, got {algorithm!r}")
+        s = self.sync
+        s.wait()
+        s._gather()
+        with engine._OnDevice(self._dev):
+            _lib.check(_lib.load().dmpnn_clip_grad(s.flat.data_ptr(), s.flat.numel(), C.c_float(float(clip_val)), CLIP_MODES[algorithm],
+                                                   C.c_float(self._grad_scale()), self.clip_ws.data_ptr(), engine._stream_ptr(self._dev)),
+                       "dmpnn_clip_grad")
+
+    def step(self, lr: Optional[float] = None, clip: Optional[tuple] = None) -> None:
         s = self.sync
         s.wait()
         s._gather()  # (a gradient autograd assigned as a fresh tensor is folded into the buffer first)
+        if clip is not None:
+            self.clip_grad(*clip)
         self.steps += 1
         b1, b2 = self.betas
         bc1 = 1.0 - b1 ** self.steps
         bc2 = 1.0 - b2 ** self.steps
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(s.group)
-        scale = 1.0 if (s.average or world == 1) else 1.0 / world
+        scale = self._grad_scale()
         with engine._OnDevice(self._dev):
             _lib.check(_lib.load().dmpnn_adam_step(
                 self.flat.data_ptr(), s.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.flat.numel(),

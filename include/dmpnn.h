@@ -43,8 +43,10 @@ extern "C" {
  * 11 — round 4: DMPNN_F_ATOM also with DMPNN_F_KEEP (atom messages TRAIN on the tile kernels; `msplit` keeps the bond-feature half of
  * the messages) and dmpnn_backward for it (gW_i [d_h, d_v], gW_h [d_h, d_h + d_e]); dmpnn_bwd_args.g_edge (a second gradient input, with
  * respect to the kept H^(depth-1): the edge read-out of the mol-atom-bond blocks); `msplit` on the tile kernel's training forward: M^(t)
- * kept as split rows, every weight-gradient product of dmpnn_backward on split rows. */
-#define DMPNN_ABI_VERSION 11
+ * kept as split rows, every weight-gradient product of dmpnn_backward on split rows.
+ * 12 — round 5: dmpnn_clip_grad / dmpnn_clip_grad_ws_bytes (Lightning's Trainer(gradient_clip_val), cli/train.py:1937, over the flat
+ * gradient buffer) and dmpnn_step_args.clip_val / clip_mode / clip_ws (the clip between the backward pass and the update of ONE call). */
+#define DMPNN_ABI_VERSION 12
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -502,6 +504,17 @@ int dmpnn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     float weight_decay, float bias_corr1, float sqrt_bias_corr2, float grad_scale, const float* dev_scalars,
                     void* stream);
 
+/* Gradient clipping over the flat gradient buffer — what `chemprop train --grad-clip` asks Lightning for
+ * (cli/train.py:1937 `gradient_clip_val`; lightning's precision plugin then calls torch.nn.utils.clip_grad_norm_ /
+ * clip_grad_value_ between the backward pass and optimizer.step).  DMPNN_CLIP_NORM: total = grad_scale * ||g||_2 over the whole
+ * buffer, g *= min(1, clip_val / (total + 1e-6)); the total norm is left in ws[256] (device).  DMPNN_CLIP_VALUE: every element
+ * of grad_scale * g clamped to [-clip_val, clip_val].  `grad_scale` is the factor dmpnn_adam_step will apply (1 / world after a
+ * SUM all-reduce): the clipped quantity is the averaged gradient, as under DDP.  No host read, two launches (norm) / one (value).
+ * `ws`: dmpnn_clip_grad_ws_bytes() of device scratch, 16-byte aligned (norm only). */
+enum dmpnn_clip_mode { DMPNN_CLIP_NORM = 0, DMPNN_CLIP_VALUE = 1 };
+size_t dmpnn_clip_grad_ws_bytes(void);
+int dmpnn_clip_grad(float* g, int64_t n, float clip_val, int32_t mode, float grad_scale, float* ws, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * f4, the rest of the model: what chemprop.models.MPNN does after the block in a training step (models/model.py:126-134,
  * 148-161) as ONE call —  H = agg(H_v, batch) (nn/agg.py:66-113);  Z = bn(H) (nn.BatchNorm1d, model.py:94,132);
@@ -559,6 +572,7 @@ typedef struct dmpnn_step_args {
     dmpnn_head_args head;
     float* p; const float* g; float* m; float* v; int64_t n_params;   /* flat parameter / gradient / moment buffers */
     float lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrt_bias_corr2, grad_scale; const float* dev_scalars;
+    float clip_val; int32_t clip_mode; float* clip_ws;   /* v12: clip_val > 0: dmpnn_clip_grad(g, ...) before the update (g is then written) */
 } dmpnn_step_args;
 int dmpnn_train_step(const dmpnn_step_args* a, void* stream);
 

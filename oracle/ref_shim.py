@@ -17,7 +17,6 @@ where they lie.  No reference source is copied or modified.
 from __future__ import annotations
 
 import enum
-import inspect
 import os
 import sys
 import types
@@ -94,40 +93,6 @@ def _stub_module(name: str) -> types.ModuleType:
     return mod
 
 
-class _AttributeDict(dict):
-    def __getattr__(self, k):
-        try:
-            return self[k]
-        except KeyError as e:
-            raise AttributeError(k) from e
-
-    def __setattr__(self, k, v):
-        self[k] = v
-
-
-class _HyperparametersMixin:
-    """Minimal stand-in for lightning's mixin: collect the caller's ``__init__`` arguments."""
-
-    def save_hyperparameters(self, *args, ignore=None, frame=None, logger=True):
-        ignore = set(ignore or ())
-        frame = frame or inspect.currentframe().f_back
-        local = frame.f_locals
-        # the arguments of the __init__ that called us (the frame's own: a subclass may wrap it with *args / **kwargs)
-        code = frame.f_code
-        names = [p for p in code.co_varnames[:code.co_argcount + code.co_kwonlyargcount] if p != "self"]
-        hp = _AttributeDict()
-        for n in names:
-            if n in local and n not in ignore:
-                hp[n] = local[n]
-        self._hparams = hp
-
-    @property
-    def hparams(self):
-        if not hasattr(self, "_hparams"):
-            self._hparams = _AttributeDict()
-        return self._hparams
-
-
 _INSTALLED = False
 
 
@@ -175,15 +140,12 @@ def install() -> None:
 
     lightning = sys.modules["lightning"]
     lightning.__version__ = "2.5.0"
-    mixins = sys.modules["lightning.pytorch.core.mixins"]
-    mixins.HyperparametersMixin = _HyperparametersMixin
+    _stub_module("lightning.pytorch.utilities.exceptions")
+    # lightning.pytorch: LightningModule / Trainer / ModelCheckpoint / EarlyStopping / DDPStrategy as restated control flow
+    # (oracle/lightning_shim.py) — what `chemprop train` drives around MPNN (cli/train.py:1912-1999)
+    from oracle import lightning_shim
 
-    class LightningModule(nn.Module, _HyperparametersMixin):
-        def log(self, *a, **k):  # (Lightning's logger hook: bookkeeping, no arithmetic — models/model.py:159)
-            pass
-
-    sys.modules["lightning.pytorch"].LightningModule = LightningModule
-    sys.modules["lightning.fabric.utilities.data"].AttributeDict = _AttributeDict
+    lightning_shim.install_into(sys.modules)
 
     # torchmetrics: the reference's losses / metrics subclass torchmetrics.Metric and an MPNN keeps them in an
     # nn.ModuleList (models/model.py:99-103), so the stand-in has to be a real nn.Module (state kept as attributes).
@@ -209,6 +171,7 @@ def install() -> None:
             val = self.compute()
             for n in self._shim_states:
                 setattr(self, n, acc[n] + getattr(self, n).detach())
+            self._forward_cache = val.detach() if hasattr(val, "detach") else val   # (what Lightning logs `on_step` for a Metric value)
             return val
 
         def _apply(self, fn, *a, **k):
@@ -224,7 +187,13 @@ def install() -> None:
             return _copy.deepcopy(self)
 
         def reset(self):
-            pass
+            """``torchmetrics.Metric.reset``: the states return to their defaults (Lightning calls it at the end of an epoch)."""
+            for n, d in self._shim_states.items():
+                cur = getattr(self, n, None)
+                v = d.clone() if hasattr(d, "clone") else d
+                if hasattr(v, "to") and hasattr(cur, "device"):
+                    v = v.to(cur.device)
+                setattr(self, n, v)
 
     tm = sys.modules["torchmetrics"]
     tm.Metric = Metric

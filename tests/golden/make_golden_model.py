@@ -97,6 +97,18 @@ def main():
             arrs[f"loss{step}"] = np.float32(loss.item())
             losses.append(float(loss))
             opt.step()
+            if step == 0:
+                # the state step 2 starts from — parameters, batch-norm buffers and Adam's moments after ONE step — so that a test can
+                # pin step 2 BY ITSELF at the fp32 bar (round-4 VERDICT weak #3: through step 1 only a functional bar holds, since
+                # Adam's g / (|g| + eps) amplifies 1e-7 differences of near-zero gradients)
+                for k, v in model.state_dict().items():
+                    if not k.startswith("metrics."):
+                        arrs["w1." + k] = v.detach().numpy().copy()
+                for k, p in model.named_parameters():
+                    st = opt.state.get(p)
+                    if st:
+                        arrs["m1." + k] = st["exp_avg"].numpy().copy()
+                        arrs["v1." + k] = st["exp_avg_sq"].numpy().copy()
         for k, v in model.state_dict().items():
             if not k.startswith("metrics."):
                 arrs["w2." + k] = v.detach().numpy().copy()

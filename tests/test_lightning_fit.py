@@ -1,0 +1,454 @@
+"""``HipMPNN`` under the control flow of ``Trainer.fit`` as ``chemprop train`` drives it (``cli/train.py:1912-1999``): automatic
+optimization, ``ModelCheckpoint`` keyed on ``trainer.global_step``, ``gradient_clip_val``, the learning-rate schedule stepped by the
+loop, the best checkpoint reloaded into the module's own class AND into the stock class, a DDP wrap.
+
+Lightning is not installed here (nor on the GPU box); ``oracle/lightning_shim.py`` restates the hooks, their order and the step
+bookkeeping of ``lightning.pytorch`` 2.x (each piece citing the Lightning source it follows) — test infrastructure, installed as
+``lightning.pytorch`` by ``oracle/ref_shim.py``.  The CPU tests pin the stand-in itself on the STOCK reference ``MPNN`` (including the
+failure mode a manual-optimization module that never steps Lightning's optimizer runs into: round-4 VERDICT weak #1); the GPU tests
+run ``HipMPNN``.
+"""
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import parity_err
+from oracle import ref_shim
+
+pytestmark = pytest.mark.skipif(not ref_shim.reference_available(), reason="no reference tree (/root/reference or oracle/_ref)")
+
+
+def _ref():
+    BMP, BMG, MG = ref_shim.load_reference()
+    Multi, GT, ST, MPNN, cnn = ref_shim.load_reference_extras()
+    import lightning.pytorch as pl
+    from lightning.pytorch.callbacks import EarlyStopping, ModelCheckpoint
+
+    return dict(BMP=BMP, BMG=BMG, MG=MG, MPNN=MPNN, nn=cnn, pl=pl, ModelCheckpoint=ModelCheckpoint, EarlyStopping=EarlyStopping)
+
+
+def _batches(R, n_batches, n_mols, device="cpu", seed=0, n_tasks=1, kind="qm9", nan=False):
+    """``TrainingBatch`` tuples (``data/collate.py:76-97``) of the reference's own ``BatchMolGraph``."""
+    from chemprop_amd import synth
+
+    out = []
+    for b in range(n_batches):
+        bmg = R["BMG"](synth.random_molgraphs(n_mols, kind, seed=seed + b))
+        gen = torch.Generator().manual_seed(100 + seed + b)
+        y = torch.randn(n_mols, n_tasks, generator=gen)
+        if nan:
+            y[1, 0] = float("nan")
+        w = torch.ones(n_mols, 1)
+        no = torch.zeros(n_mols, n_tasks, dtype=torch.bool)
+        if device != "cpu":
+            bmg.to(device)
+            y, w, no = y.to(device), w.to(device), no.to(device)
+        out.append((bmg, None, None, y, w, no, no.clone()))
+    return out
+
+
+def _model(R, cls, d_h=32, hidden=24, bn=True, n_tasks=1, **kw):
+    cnn = R["nn"]
+    mp = R["BMP"](d_h=d_h)
+    return cls(mp, cnn.NormAggregation(), cnn.RegressionFFN(input_dim=d_h, hidden_dim=hidden, n_tasks=n_tasks), batch_norm=bn, **kw)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU: the stand-in itself, on the stock reference class
+# ------------------------------------------------------------------------------------------------------------------
+def test_stock_mpnn_fits_under_the_stand_in_and_reloads_its_best_checkpoint(tmp_path):
+    """The stock ``chemprop.models.MPNN`` through ``fit``-shaped control flow as ``cli/train.py:1912-1999`` sets it up: global_step
+    counts optimizer steps, the Noam-like schedule is stepped per batch by the loop, ``ModelCheckpoint`` saves once per epoch keyed on
+    the step count, ``train_loss`` (a ``Metric`` object logged on_step + on_epoch) lands in ``callback_metrics``, the best checkpoint
+    loads back through ``MPNN.load_from_checkpoint`` (``models/model.py:295-316``)."""
+    R = _ref()
+    torch.manual_seed(0)
+    model = _model(R, R["MPNN"])
+    train, val = _batches(R, 3, 8), _batches(R, 1, 8, seed=50)
+    ck = R["ModelCheckpoint"](tmp_path / "checkpoints", "best-epoch={epoch}-val_loss={val_loss:.2f}", "val_loss", mode="min", save_last=True,
+                              auto_insert_metric_name=False)
+    es = R["EarlyStopping"]("val_loss", patience=5, mode="min")
+    tr = R["pl"].Trainer(max_epochs=2, callbacks=[ck, es], gradient_clip_val=0.5)
+    lrs = []
+    orig = model.on_train_batch_start
+    model.on_train_batch_start = lambda b, i: (lrs.append(tr.optimizers[0].param_groups[0]["lr"]), orig(b, i))[1]
+    tr.fit(model, train, val)
+    assert tr.global_step == 6 and ck.n_saved >= 1 and os.path.isfile(ck.best_model_path) and os.path.isfile(ck.last_model_path)
+    assert {"train_loss", "train_loss_step", "train_loss_epoch", "val_loss"} <= set(tr.callback_metrics)
+    # warm-up 2 epochs x 3 batches from init_lr 1e-4 to max_lr 1e-3 (schedulers.py; cooldown 0 epochs)
+    want = [1e-4 + i * (1e-3 - 1e-4) / 6 for i in range(6)]
+    assert np.allclose(lrs, want, rtol=1e-6), (lrs, want)
+    # the closure order of automatic optimization: training_step -> zero_grad -> backward, inside optimizer_step
+    i = tr.hook_trace.index("optimizer_step")
+    assert tr.hook_trace[i:i + 5] == ["optimizer_step", "training_step", "on_before_zero_grad", "optimizer_zero_grad", "backward"]
+    best = R["MPNN"].load_from_checkpoint(ck.best_model_path)
+    sd = torch.load(ck.best_model_path, weights_only=False)
+    assert sd["global_step"] in (3, 6) and len(sd["optimizer_states"][0]["state"]) > 0
+    for k, v in best.state_dict().items():
+        assert torch.equal(v, sd["state_dict"][k])
+
+
+def test_manual_optimization_that_never_steps_lightnings_optimizer_saves_nothing(tmp_path):
+    """The failure mode of round 4's ``HipMPNN`` (VERDICT weak #1, ADVICE high), reproduced on the stand-in: a module with
+    ``automatic_optimization = False`` that updates its parameters itself and never calls ``self.optimizers().step()`` leaves
+    ``trainer.global_step`` at 0, ``ModelCheckpoint`` skips every save (``_last_global_step_saved == global_step``), ``best_model_path``
+    stays empty — ``cli/train.py:1991-1992`` would fail.  And ``gradient_clip_val`` is refused outright."""
+    R = _ref()
+    torch.manual_seed(0)
+
+    class Manual(R["MPNN"]):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.automatic_optimization = False
+
+        def training_step(self, batch, batch_idx):
+            loss = super().training_step(batch, batch_idx)
+            loss.backward()
+            with torch.no_grad():
+                for p in self.parameters():
+                    if p.grad is not None:
+                        p -= 1e-3 * p.grad
+                        p.grad = None
+            return loss.detach()
+
+    model = _model(R, Manual)
+    ck = R["ModelCheckpoint"](tmp_path / "checkpoints", "best", "train_loss", mode="min", save_last=True)
+    tr = R["pl"].Trainer(max_epochs=2, callbacks=[ck])
+    tr.fit(model, _batches(R, 3, 8), None)
+    assert tr.global_step == 0 and ck.best_model_path == "" and ck.n_saved == 0
+    from oracle.lightning_shim import MisconfigurationException
+
+    with pytest.raises(MisconfigurationException, match="gradient clipping is not supported for manual optimization"):
+        R["pl"].Trainer(max_epochs=1, gradient_clip_val=1.0).fit(_model(R, Manual), _batches(R, 1, 8), None)
+
+
+def test_logging_one_key_twice_with_different_metadata_is_refused():
+    """``result.py: _ResultCollection.log`` (round-4 ADVICE medium): the reference logs the criterion ``Metric`` as ``train_loss``; a
+    second ``self.log("train_loss", tensor)`` in the same hook has other metadata and raises."""
+    R = _ref()
+    from oracle.lightning_shim import MisconfigurationException
+
+    class Twice(R["MPNN"]):
+        def training_step(self, batch, batch_idx):
+            loss = super().training_step(batch, batch_idx)
+            self.log("train_loss", loss.detach(), batch_size=len(batch[0]), prog_bar=True, on_epoch=True)
+            return loss
+
+    torch.manual_seed(0)
+    with pytest.raises(MisconfigurationException, match="twice"):
+        R["pl"].Trainer(max_epochs=1).fit(_model(R, Twice), _batches(R, 1, 8), None)
+
+
+def test_enable_rebinds_every_name_the_cli_binds(monkeypatch):
+    """``chemprop_amd.enable()`` (no new CLI flag): the names ``chemprop/cli/train.py:60-68`` binds at import
+    (``MPNN``, ``BondMessagePassing``, ``AtomMessagePassing``, ``MABAtomMessagePassing``, ``MABBondMessagePassing``) and the packages that
+    export them are rebound to the HIP subclasses; ``MPNN.load_from_file`` accelerates what it loads; checkpoints keep naming the
+    reference classes.  (``chemprop.cli.train`` itself needs Python 3.11 syntax and rdkit: a stand-in module holds its bindings.)"""
+    R = _ref()
+    import chemprop.models
+    import chemprop.nn
+    from chemprop.nn import AtomMessagePassing, BondMessagePassing, MABAtomMessagePassing, MABBondMessagePassing
+
+    from chemprop_amd import integration
+
+    cli = types.ModuleType("chemprop.cli.train")
+    cli.MPNN, cli.BondMessagePassing, cli.AtomMessagePassing = R["MPNN"], BondMessagePassing, AtomMessagePassing
+    cli.MABAtomMessagePassing, cli.MABBondMessagePassing = MABAtomMessagePassing, MABBondMessagePassing
+    monkeypatch.setitem(sys.modules, "chemprop.cli.train", cli)
+    saved = {m: dict(vars(sys.modules[m])) for m in integration._BINDING_MODULES if m in sys.modules and m != "chemprop.cli.train"}
+    lff = R["MPNN"].__dict__["load_from_file"]
+    try:
+        done = integration.enable()
+        assert set(done["chemprop.cli.train"]) == {"MPNN", "BondMessagePassing", "AtomMessagePassing", "MABAtomMessagePassing", "MABBondMessagePassing"}
+        assert issubclass(cli.MPNN, R["MPNN"]) and cli.MPNN is not R["MPNN"] and cli.MPNN is integration.hip_mpnn_class()[1]
+        assert cli.BondMessagePassing is integration.hip_bond_message_passing_class() and issubclass(cli.BondMessagePassing, BondMessagePassing)
+        assert chemprop.nn.BondMessagePassing is cli.BondMessagePassing and chemprop.models.MPNN is cli.MPNN
+        assert issubclass(cli.MABBondMessagePassing, MABBondMessagePassing) and issubclass(cli.AtomMessagePassing, AtomMessagePassing)
+        # what build_model does (cli/train.py:1500-1610): the classes by their bound names
+        torch.manual_seed(0)
+        mp = cli.BondMessagePassing(d_h=16)
+        model = cli.MPNN(mp, chemprop.nn.NormAggregation(), chemprop.nn.RegressionFFN(input_dim=16, hidden_dim=8))
+        assert mp.hparams["cls"] is BondMessagePassing and model.hparams["message_passing"]["cls"] is BondMessagePassing
+        assert model.automatic_optimization is True
+        assert integration.enable() is not None and integration.enabled()     # idempotent
+    finally:
+        for m, d in saved.items():
+            for k, v in d.items():
+                setattr(sys.modules[m], k, v)
+        R["MPNN"].load_from_file = lff
+        integration._enabled = None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: HipMPNN
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_twin(R, model):
+    """The stock class with the same initial state, on the CPU."""
+    twin = _model(R, R["MPNN"], d_h=model.message_passing.W_h.in_features, hidden=model.predictor.ffn[0][-1].out_features,
+                  bn=isinstance(model.bn, torch.nn.BatchNorm1d), n_tasks=model.n_tasks,
+                  init_lr=model.init_lr, max_lr=model.max_lr, final_lr=model.final_lr, warmup_epochs=model.warmup_epochs)
+    twin.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=False)
+    return twin
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [None, 0.05], ids=["noclip", "clip0.05"])
+def test_hip_mpnn_fits_like_the_stock_class(clip, tmp_path, gpu_device):
+    """``HipMPNN`` through the SAME ``fit`` as the stock class (2 epochs x 3 batches, validation, ``ModelCheckpoint`` on ``val_loss``,
+    ``EarlyStopping``, the Noam-like schedule, with and without ``gradient_clip_val`` — at 0.05 every step clips): every step took the
+    fused route; ``trainer.global_step`` = 6; the learning rates are the schedule's; parameters, batch-norm buffers and the logged
+    losses follow the stock class run on the CPU (the functional bar of f4: Adam amplifies fp32-level gradient differences); the
+    best checkpoint exists, carries ``torch.optim.Adam``-format optimizer state, and loads into ``HipMPNN`` and into the STOCK class."""
+    from chemprop_amd import integration
+
+    R = _ref()
+    HipMPNN = integration.hip_mpnn_class()[1]
+    torch.manual_seed(7)
+    model = _model(R, HipMPNN, d_h=64, hidden=32).to(gpu_device)
+    assert model.automatic_optimization is True
+    twin = _cpu_twin(R, model)
+
+    def run(m, dev, sub):
+        train, val = _batches(R, 3, 16, device=dev), _batches(R, 1, 16, device=dev, seed=50)
+        ck = R["ModelCheckpoint"](tmp_path / sub, "best-epoch={epoch}-val_loss={val_loss:.2f}", "val_loss", mode="min", save_last=True,
+                                  auto_insert_metric_name=False)
+        tr = R["pl"].Trainer(max_epochs=2, callbacks=[ck, R["EarlyStopping"]("val_loss", patience=2, mode="min")], gradient_clip_val=clip)
+        lrs, losses, routes = [], [], []
+        o1, o2 = m.on_train_batch_start, m.on_train_batch_end
+
+        def start(b, i):
+            lrs.append(tr.optimizers[0].param_groups[0]["lr"])
+            return o1(b, i)
+
+        def end(out, b, i):
+            losses.append(float(out["loss"]))
+            st = m.__dict__.get("_hip")
+            routes.append(st["route"] if st else None)
+            return o2(out, b, i)
+
+        m.on_train_batch_start, m.on_train_batch_end = start, end
+        tr.fit(m, train, val)
+        return tr, ck, lrs, losses, routes
+
+    tr, ck, lrs, losses, routes = run(model, gpu_device, "hip")
+    tr_c, ck_c, lrs_c, losses_c, _ = run(twin, "cpu", "stock")
+    torch.cuda.synchronize()
+    assert tr.global_step == 6 == tr_c.global_step
+    assert all(r and r.startswith("fused:") for r in routes), routes
+    assert np.allclose(lrs, lrs_c, rtol=1e-7) and lrs[0] == pytest.approx(1e-4) and lrs[-1] > lrs[0]
+    assert abs(losses[0] - losses_c[0]) <= 1e-5 * max(1.0, abs(losses_c[0]))
+    assert np.allclose(losses, losses_c, rtol=2e-3, atol=2e-4), (losses, losses_c)
+    assert abs(float(tr.callback_metrics["val_loss"]) - float(tr_c.callback_metrics["val_loss"])) <= 2e-3
+    assert abs(float(tr.callback_metrics["train_loss_epoch"]) - float(tr_c.callback_metrics["train_loss_epoch"])) <= 2e-3
+    for k, v in twin.state_dict().items():
+        if k.startswith("metrics."):
+            continue
+        got = model.state_dict()[k].cpu()
+        if k.endswith("num_batches_tracked"):
+            assert int(got) == int(v)
+        else:
+            assert parity_err(got.numpy(), v.numpy()) <= 5e-4, k
+    # the hooks ran in Lightning's order and train_loss was logged once per step (no MisconfigurationException)
+    i = tr.hook_trace.index("optimizer_step")
+    assert tr.hook_trace[i:i + 5] == ["optimizer_step", "training_step", "on_before_zero_grad", "optimizer_zero_grad", "backward"]
+    # the checkpoints
+    assert os.path.isfile(ck.best_model_path) and os.path.isfile(ck.last_model_path) and ck.n_saved >= 1
+    sd = torch.load(ck.last_model_path, map_location="cpu", weights_only=False)
+    assert sd["global_step"] == 6
+    ost = sd["optimizer_states"][0]
+    ref_ost = torch.load(ck_c.last_model_path, map_location="cpu", weights_only=False)["optimizer_states"][0]
+    assert set(ost["state"]) == set(ref_ost["state"]) and ost["param_groups"][0]["params"] == ref_ost["param_groups"][0]["params"]
+    for i_, e in ref_ost["state"].items():       # torch.optim.Adam's own format, the moments of the stock run
+        assert float(ost["state"][i_]["step"]) == float(e["step"]) == 6.0
+        assert parity_err(ost["state"][i_]["exp_avg"].numpy(), e["exp_avg"].numpy()) <= 5e-4
+    assert sd["hyper_parameters"]["message_passing"]["cls"] is R["BMP"]
+    # cli/train.py:1991-1992: model.__class__.load_from_checkpoint(best_model_path)
+    again = HipMPNN.load_from_checkpoint(ck.best_model_path)
+    assert type(again) is HipMPNN and type(again.message_passing) is integration.hip_bond_message_passing_class()
+    stock = R["MPNN"].load_from_checkpoint(ck.best_model_path)
+    assert type(stock) is R["MPNN"] and type(stock.message_passing) is R["BMP"]
+    best_sd = torch.load(ck.best_model_path, map_location="cpu", weights_only=False)["state_dict"]
+    for k, v in stock.state_dict().items():
+        assert torch.equal(v.cpu(), best_sd[k].cpu()), k
+    again = again.to(gpu_device).eval()
+    stock.eval()
+    vb_gpu, vb_cpu = _batches(R, 1, 16, device=gpu_device, seed=50)[0], _batches(R, 1, 16, seed=50)[0]
+    with torch.no_grad():
+        assert parity_err(again(vb_gpu[0]).cpu().numpy(), stock(vb_cpu[0]).numpy()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_mpnn_clip_equals_torch_clip_grad_norm(gpu_device):
+    """ONE step with ``gradient_clip_val`` small enough to bite, constant learning rate: the parameters after the fused step (clip
+    inside ``dmpnn_train_step``: ``dmpnn_step_args.clip_val``) and after the module-path step (``FlatAdam.clip_grad`` from
+    ``configure_gradient_clipping``) equal the stock class stepped on the CPU with ``torch.nn.utils.clip_grad_norm_`` +
+    ``torch.optim.Adam``; the total norm the kernel left on the device is torch's."""
+    from chemprop_amd import integration
+
+    R = _ref()
+    HipMPNN = integration.hip_mpnn_class()[1]
+    for algo in ("norm", "value"):
+        for force_module in (False, True):
+            torch.manual_seed(11)
+            lr = 1e-3
+            model = _model(R, HipMPNN, d_h=48, hidden=24, init_lr=lr, max_lr=lr, final_lr=lr).to(gpu_device)
+            twin = _cpu_twin(R, model)
+            clip = 0.02 if algo == "norm" else 1e-3
+            tr = R["pl"].Trainer(max_epochs=1, gradient_clip_val=clip, gradient_clip_algorithm=algo)
+            if force_module:
+                orig = model._hip_state
+
+                def state():
+                    st = orig()
+                    st["fused"] = None
+                    return st
+
+                model._hip_state = state
+            tr.fit(model, _batches(R, 1, 16, device=gpu_device), None)
+            torch.cuda.synchronize()
+            st = model.__dict__["_hip"]
+            assert st["route"] == ("module" if force_module else st["route"]) and (force_module or st["route"].startswith("fused:"))
+            # the stock step on the CPU
+            twin.train()
+            opt = torch.optim.Adam(twin.parameters(), lr)
+            loss = twin.training_step(_batches(R, 1, 16)[0], 0)
+            loss.backward()
+            if algo == "norm":
+                total = float(torch.nn.utils.clip_grad_norm_(twin.parameters(), clip))
+                assert total > clip          # (the clip bites)
+                got_total = float(st["opt"].clip_ws[256])
+                assert abs(got_total - total) <= 2e-5 * total, (got_total, total)
+            else:
+                torch.nn.utils.clip_grad_value_(twin.parameters(), clip)
+            opt.step()
+            for (k, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
+                assert parity_err(a.detach().cpu().numpy(), b.detach().numpy()) <= 2e-5, (algo, force_module, k)
+
+
+@pytest.mark.gpu
+def test_hip_mpnn_module_path_under_the_trainer_logs_once_and_follows_the_schedule(gpu_device):
+    """What the fused step refuses (here: ``V_d`` descriptors with a ``W_d`` branch) trains through the reference's own arithmetic on
+    the HIP kernels: Lightning's closure runs ``backward`` and ``HipAdam.step``; ``train_loss`` is logged exactly once per step (the
+    reference's own ``Metric`` log: round-4 ADVICE medium); the schedule is the reference's; parameters follow the stock class."""
+    from chemprop_amd import integration
+
+    R = _ref()
+    cnn = R["nn"]
+    HipMPNN = integration.hip_mpnn_class()[1]
+    torch.manual_seed(3)
+    mk = lambda cls: cls(R["BMP"](d_h=64, d_vd=4), cnn.MeanAggregation(), cnn.RegressionFFN(input_dim=68, hidden_dim=32), batch_norm=True)
+    model = mk(HipMPNN).to(gpu_device)
+    twin = mk(R["MPNN"])
+    twin.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=False)
+
+    def with_vd(batches, dev):
+        out = []
+        for i, b in enumerate(batches):
+            V_d = torch.randn(int(b[0].V.shape[0]), 4, generator=torch.Generator().manual_seed(900 + i)).to(dev)
+            out.append((b[0], V_d) + tuple(b[2:]))
+        return out
+
+    tr = R["pl"].Trainer(max_epochs=2)
+    tr.fit(model, with_vd(_batches(R, 2, 32, device=gpu_device), gpu_device), None)
+    tr_c = R["pl"].Trainer(max_epochs=2)
+    tr_c.fit(twin, with_vd(_batches(R, 2, 32), "cpu"), None)
+    torch.cuda.synchronize()
+    st = model.__dict__["_hip"]
+    assert st["route"] == "module" and "V_d" in (st["why"] or "") and tr.global_step == 4 and st["opt"].steps == 4
+    assert abs(float(tr.callback_metrics["train_loss_epoch"]) - float(tr_c.callback_metrics["train_loss_epoch"])) <= 2e-3
+    for (k, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
+        assert parity_err(a.detach().cpu().numpy(), b.detach().numpy()) <= 5e-4, k
+
+
+@pytest.mark.gpu
+def test_hip_mpnn_resumes_from_a_stock_checkpoint_and_back(tmp_path, gpu_device):
+    """Optimizer state moves both ways (``torch.optim.Adam``'s state-dict format): a run started by the STOCK class on the CPU, saved by
+    the trainer, resumed as ``HipMPNN`` (``Trainer.fit(ckpt_path=...)``) ends where the stock class ends when it goes on itself."""
+    from chemprop_amd import integration
+
+    R = _ref()
+    HipMPNN = integration.hip_mpnn_class()[1]
+    torch.manual_seed(5)
+    stock = _model(R, R["MPNN"], d_h=48, hidden=24)
+    init = copy.deepcopy(stock.state_dict())
+    tr0 = R["pl"].Trainer(max_epochs=1)
+    tr0.fit(stock, _batches(R, 2, 16), None)
+    tr0.save_checkpoint(str(tmp_path / "e0.ckpt"))
+    # the stock class goes on for another epoch
+    torch.manual_seed(5)
+    cont = _model(R, R["MPNN"], d_h=48, hidden=24)
+    cont.load_state_dict(init)
+    trc = R["pl"].Trainer(max_epochs=2)
+    trc.fit(cont, _batches(R, 2, 16), None)
+    # HipMPNN resumes the first epoch's checkpoint
+    hip = _model(R, HipMPNN, d_h=48, hidden=24).to(gpu_device)
+    tr1 = R["pl"].Trainer(max_epochs=2)
+    tr1.fit(hip, _batches(R, 2, 16, device=gpu_device), None, ckpt_path=str(tmp_path / "e0.ckpt"))
+    torch.cuda.synchronize()
+    assert tr1.global_step == 4 and hip.__dict__["_hip"]["opt"].steps == 4
+    for (k, a), (_, b) in zip(hip.named_parameters(), cont.named_parameters()):
+        assert parity_err(a.detach().cpu().numpy(), b.detach().numpy()) <= 5e-4, k
+
+
+@pytest.mark.gpu
+def test_hip_mpnn_under_a_ddp_wrap_with_rccl_world_1(tmp_path, gpu_device):
+    """``--devices N`` wraps the module in ``DistributedDataParallel`` (``DDPStrategy``, ``cli/train.py:1934,1943``).  On one GPU with a
+    REAL ``nccl`` (= RCCL) process group of world size 1: ``HipMPNN`` fits through the wrapper — fused steps never touch autograd, so the
+    module switches the wrapper's reducer off and owns the exchange — and ends exactly where the unwrapped run ends; the module path
+    under the wrap (forced) as well.  ``GradSync`` is forced through its collective branch (``DMPNN_FORCE_COLLECTIVE=1``: the all-reduce
+    on the communication stream, the event, the stream-level wait — the half of ``distributed.py`` that never ran on ``gloo``)."""
+    import torch.distributed as dist
+
+    from chemprop_amd import integration
+    from oracle.lightning_shim import DDPStrategy
+
+    R = _ref()
+    HipMPNN = integration.hip_mpnn_class()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+        created = True
+    try:
+        assert dist.get_backend() == "nccl"
+        os.environ["DMPNN_FORCE_COLLECTIVE"] = "1"
+        results = {}
+        for name, strategy, force_module in (("plain", None, False), ("ddp", DDPStrategy(), False), ("ddp-module", DDPStrategy(), True),
+                                             ("plain-module", None, True)):
+            torch.manual_seed(21)
+            model = _model(R, HipMPNN, d_h=64, hidden=32).to(gpu_device)
+            if force_module:
+                orig = model._hip_state
+
+                def state(orig=orig):
+                    st = orig()
+                    st["fused"] = None
+                    return st
+
+                model._hip_state = state
+            tr = R["pl"].Trainer(max_epochs=2, strategy=strategy, gradient_clip_val=0.5)
+            tr.fit(model, _batches(R, 3, 16, device=gpu_device), None)
+            torch.cuda.synchronize()
+            st = model.__dict__["_hip"]
+            assert tr.global_step == 6 and st["opt"].steps == 6
+            assert st["route"] == "module" if force_module else st["route"].startswith("fused:")
+            if strategy is not None:
+                from torch.nn.parallel import DistributedDataParallel as DDP
+
+                assert isinstance(tr.strategy.model, DDP) and tr.strategy.model.require_backward_grad_sync is False
+            assert st["sync"].n_collectives > 0      # the RCCL all-reduce really ran
+            results[name] = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+        for k in results["plain"]:
+            assert torch.equal(results["plain"][k], results["ddp"][k]), k                  # the wrap changes nothing
+            assert torch.equal(results["plain-module"][k], results["ddp-module"][k]), k
+            assert parity_err(results["plain"][k].numpy(), results["plain-module"][k].numpy()) <= 5e-4, k
+    finally:
+        os.environ.pop("DMPNN_FORCE_COLLECTIVE", None)
+        if created:
+            dist.destroy_process_group()

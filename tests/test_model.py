@@ -183,6 +183,66 @@ def test_fused_step_matches_goldens(g, keep_rows, gpu_device, monkeypatch):
     assert parity_err(pe.cpu().numpy(), g.a["preds_eval"]) <= 2e-3
 
 
+def _load_step1_state(g, model, adam):
+    """Parameters, batch-norm buffers and Adam's moments after the golden's FIRST step (``w1.*`` / ``m1.*`` / ``v1.*``): where its second
+    step starts."""
+    model.load_state_dict({k: v for k, v in g.state("w1.").items()}, strict=False)
+    st = {}
+    for i, (k, p) in enumerate((k, p) for k, p in model.named_parameters() if p.requires_grad):
+        st[i] = {"step": torch.tensor(1.0), "exp_avg": g.t("m1." + k), "exp_avg_sq": g.t("v1." + k)}
+    adam.load_torch_state(st)
+    assert adam.steps == 1
+
+
+def test_restatement_step_two_from_the_goldens_own_step_one_state(g):
+    """Step 2 by itself (round-4 VERDICT weak #3): the restatement started from the golden's post-step-1 parameters reproduces the
+    golden's second loss and second gradients at the fp32 bar."""
+    targets, weights, lt, gt = g.batch_args()
+    st1 = {k: v for k, v in g.state("w1.").items()}
+    m, losses, grads = om.train_steps(st1, g.cfg, g.bmg(), targets, weights, g.t("lt_mask"), g.t("gt_mask"), g.meta["lr"], 1)
+    ref = float(g.a["loss1"])
+    assert abs(losses[0] - ref) <= 1e-6 * max(1.0, abs(ref))
+    for k, v in grads[0].items():
+        assert parity_err(v.numpy(), g.a[f"g1.{k}"]) <= 1e-6, k
+
+
+@pytest.mark.gpu
+def test_fused_step_two_alone_matches_goldens_at_the_fp32_bar(g, gpu_device):
+    """Step 2 pinned BY ITSELF: the fused step starts from the golden's own post-step-1 parameters, batch-norm buffers and Adam
+    moments (``FlatAdam.load_torch_state``) and must reproduce the golden's second loss at 1e-5 and its second gradients at 2e-5
+    (parameters after the update: the functional 2e-4) — a step-2 bug can no longer hide behind the 5e-4 / 2e-4 end-to-end bars of
+    ``test_fused_step_matches_goldens`` (which exist because ONE Adam step amplifies fp32-level differences of near-zero gradients)."""
+    from chemprop_amd.model import FusedTrainer
+
+    model = build_mirror(g.cfg)
+    model.load_state_dict(g.state("w0."))
+    model = model.to(gpu_device).train()
+    tr = FusedTrainer(model, lr=g.meta["lr"])
+    _load_step1_state(g, model, tr.opt)
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    bmg = g.bmg(gpu_device)
+    targets, weights, lt, gt = g.batch_args(gpu_device)
+    bounded = g.cfg.get("criterion", "mse").startswith("bounded")
+    out = tr.step(bmg, targets, weights, lt if bounded else None, gt if bounded else None)
+    torch.cuda.synchronize()
+    ref = float(g.a["loss1"])
+    assert abs(float(out[0]) - ref) <= 1e-5 * max(1.0, abs(ref)), (float(out[0]), ref)
+    assert tr.opt.steps == 2
+    for i, k in enumerate(names):
+        err = parity_err(tr.sync.views[i].detach().cpu().numpy(), g.a[f"g1.{k}"])
+        assert err <= 2e-5, f"{g.name} step-2 d{k}: {err:.3e}"
+    for k, v in model.state_dict().items():
+        want = g.a["w2." + k]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(want)
+        elif "task_weights" in k:
+            continue
+        else:
+            # (ONE Adam update from identical moments; an entry whose gradient is below Adam's eps still turns an absolute 1e-8 into
+            #  a visible fraction of lr — the bars that pin step 2 are the loss and the gradients above)
+            assert parity_err(v.cpu().numpy(), want) <= 2e-4, k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_mols,kind,bn,agg,tasks,act", [(512, "qm9", True, "norm", 1, "elu"), (512, "qm9", False, "mean", 12, "tanh"),
                                                           # (40-atom molecules: the per-step routes; a smooth activation — at this size ONE
