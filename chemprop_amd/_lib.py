@@ -108,7 +108,7 @@ class BwdArgs(C.Structure):
 
 
 MAX_FFN_LAYERS = 8
-LOSS = {"mse": 0, "mae": 1}
+LOSS = {"mse": 0, "mae": 1, "bce": 2}
 STEP_FORWARD, STEP_BACKWARD, STEP_UPDATE = 1, 2, 4
 
 

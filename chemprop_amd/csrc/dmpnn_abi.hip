@@ -321,9 +321,17 @@ int dmpnn_forward_tiles(const dmpnn_fwd_args* a, const int64_t* batch, const int
     DMPNN_CHECK_ARG(a != nullptr && a->plan != nullptr, "forward_tiles: null args / plan");
     void* plan = const_cast<void*>(a->plan);
     bool did_split = false;
-    if (tile_row && tile_atom && n_tiles > 0)
-        DMPNN_TRY(dmpnn_prepare_tiles_from_table(tile_row, tile_atom, n_tiles, a->n_atoms, a->n_edges, plan, plan_bytes, stream));
-    else   // (from the batch vector within the single-workgroup plan: the weight pre-split rides in K0's launch)
+    if (tile_row && tile_atom && n_tiles > 0) {
+        // the loader's table: copied / checked by ONE workgroup — with the forward's weight pre-split in the same launch where the tile
+        // kernel on the f16 pipe is going to run (the arguments are checked as dmpnn_prepare_tiles_from_table checks them)
+        const dmpnn::PlanLayout L = dmpnn::plan_layout(a->n_atoms, a->n_edges);
+        const bool ok = a->n_atoms >= 0 && a->n_edges >= 0 && a->n_atoms < (1ll << 31) && a->n_edges < (1ll << 31) &&
+                        plan_bytes >= (size_t)L.words * sizeof(int) && n_tiles <= L.max_mtiles;
+        if (ok) DMPNN_TRY(launch_tiles_from_table_split(tile_row, tile_atom, n_tiles, a->n_atoms, a->n_edges, static_cast<int*>(plan),
+                                                        static_cast<hipStream_t>(stream), a, &did_split));
+        if (!did_split)
+            DMPNN_TRY(dmpnn_prepare_tiles_from_table(tile_row, tile_atom, n_tiles, a->n_atoms, a->n_edges, plan, plan_bytes, stream));
+    } else   // (from the batch vector within the single-workgroup plan: the weight pre-split rides in K0's launch)
         DMPNN_TRY(prepare_tiles_and_bounds(a->edge_index, a->rev_edge_index, batch, a->n_atoms, a->n_edges, plan, plan_bytes, nullptr, 0, stream, nullptr, a, &did_split));
     if (!did_split) return dmpnn_forward(a, stream);
     dmpnn_fwd_args f = *a;

@@ -58,41 +58,7 @@ __global__ __launch_bounds__(256) void k_collate(const int* __restrict__ atom_of
 // index arrays, exactly as for a table from dmpnn_prepare_tiles.
 __global__ __launch_bounds__(256) void k_tiles_from_table(const int* __restrict__ tile_row, const int* __restrict__ tile_atom,
                                                           int n_tiles, int nV, int nE, int* __restrict__ plan, PlanLayout L) {
-    __shared__ int bad_s, spill_s;
-    if (threadIdx.x == 0) { bad_s = 0; spill_s = 0; }
-    __syncthreads();
-    int* mrow = plan + L.mtile_row;
-    int* matom = plan + L.mtile_atom;
-    const int slots = (int)L.max_mtiles + 2;
-    int bad = 0;
-    for (int t = threadIdx.x; t < slots; t += blockDim.x) {
-        int r = nE, a = nV;
-        if (t < n_tiles) {
-            r = tile_row[t]; a = tile_atom[t];
-            const int r1 = t + 1 < n_tiles ? tile_row[t + 1] : nE, a1 = t + 1 < n_tiles ? tile_atom[t + 1] : nV;
-            if (r < 0 || a < 0 || r1 < r || a1 < a || r1 > nE || a1 > nV) bad = 1;
-            else if (a1 == a && r1 != r) bad = 1;  // edge rows in a tile without atoms: nobody would check (or compute) them
-            else if (r1 - r > kMegaBM || a1 - a > kMegaBA) atomicAdd(&spill_s, 1);  // (the tile kernel's generic path; it checks closure itself)
-            if (t == 0 && (r != 0 || a != 0)) bad = 1;
-        }
-        mrow[t] = r;
-        matom[t] = a;
-    }
-    if (n_tiles == 0 && (nE > 0 || nV > 0)) bad = 1;
-    if (bad) atomicOr(&bad_s, 1);
-    __syncthreads();
-    if (threadIdx.x < DMPNN_HDR_WORDS) {
-        int v = 0;
-        const int h = threadIdx.x;
-        if (h == DMPNN_HDR_FLAGS) v = (bad_s ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
-        if (h == DMPNN_HDR_NMTILES) v = bad_s ? 0 : n_tiles;
-        if (h == DMPNN_HDR_NSPILL) v = bad_s ? 0 : spill_s;
-        if (h == DMPNN_HDR_LIGHT) v = 2;
-        if (h == DMPNN_HDR_NATOMS) v = nV;
-        if (h == DMPNN_HDR_NEDGES) v = nE;
-        if (h == DMPNN_HDR_TILE_STRIDE) v = kFusedBM;
-        plan[h] = v;
-    }
+    tiles_from_table_body(tile_row, tile_atom, n_tiles, nV, nE, plan, L);
 }
 
 }  // namespace

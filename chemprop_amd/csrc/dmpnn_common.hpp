@@ -194,6 +194,51 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
 int launch_prepare(const int64_t* edge_index, const int64_t* rev, int64_t nV, int64_t nE, int* plan,
                    int light, hipStream_t s, bool keep_mtiles = false);
 bool prepare_can_keep_mtiles(int64_t nV, int64_t nE);
+// The piece-tile tables of a tile plan from a table the LOADER made: the body of k_tiles_from_table (dmpnn_collate.hip), shared with
+// the launch that also carries the forward's weight pre-split (k_tiles_from_table_split, dmpnn_prepare.hip).
+__device__ __forceinline__ void tiles_from_table_body(const int* __restrict__ tile_row, const int* __restrict__ tile_atom,
+                                                          int n_tiles, int nV, int nE, int* __restrict__ plan, PlanLayout L) {
+    __shared__ int bad_s, spill_s;
+    if (threadIdx.x == 0) { bad_s = 0; spill_s = 0; }
+    __syncthreads();
+    int* mrow = plan + L.mtile_row;
+    int* matom = plan + L.mtile_atom;
+    const int slots = (int)L.max_mtiles + 2;
+    int bad = 0;
+    for (int t = threadIdx.x; t < slots; t += blockDim.x) {
+        int r = nE, a = nV;
+        if (t < n_tiles) {
+            r = tile_row[t]; a = tile_atom[t];
+            const int r1 = t + 1 < n_tiles ? tile_row[t + 1] : nE, a1 = t + 1 < n_tiles ? tile_atom[t + 1] : nV;
+            if (r < 0 || a < 0 || r1 < r || a1 < a || r1 > nE || a1 > nV) bad = 1;
+            else if (a1 == a && r1 != r) bad = 1;  // edge rows in a tile without atoms: nobody would check (or compute) them
+            else if (r1 - r > kMegaBM || a1 - a > kMegaBA) atomicAdd(&spill_s, 1);  // (the tile kernel's generic path; it checks closure itself)
+            if (t == 0 && (r != 0 || a != 0)) bad = 1;
+        }
+        mrow[t] = r;
+        matom[t] = a;
+    }
+    if (n_tiles == 0 && (nE > 0 || nV > 0)) bad = 1;
+    if (bad) atomicOr(&bad_s, 1);
+    __syncthreads();
+    if (threadIdx.x < DMPNN_HDR_WORDS) {
+        int v = 0;
+        const int h = threadIdx.x;
+        if (h == DMPNN_HDR_FLAGS) v = (bad_s ? PLAN_NO_PIECE_TILES : 0) | PLAN_TILES_ONLY;
+        if (h == DMPNN_HDR_NMTILES) v = bad_s ? 0 : n_tiles;
+        if (h == DMPNN_HDR_NSPILL) v = bad_s ? 0 : spill_s;
+        if (h == DMPNN_HDR_LIGHT) v = 2;
+        if (h == DMPNN_HDR_NATOMS) v = nV;
+        if (h == DMPNN_HDR_NEDGES) v = nE;
+        if (h == DMPNN_HDR_TILE_STRIDE) v = kFusedBM;
+        plan[h] = v;
+    }
+}
+
+// ... the same with the pre-split of the forward's weights riding in the launch (workgroups 1 ..: one wave per matrix row), as K0 from the
+// batch vector does: the loader-tiles path pays no launch for the split either.  *did_split says whether it did.
+int launch_tiles_from_table_split(const int* tile_row, const int* tile_atom, int64_t n_tiles, int64_t nV, int64_t nE, int* plan, hipStream_t s,
+                                  const dmpnn_fwd_args* split_for, bool* did_split);
 // mol_bounds (optional): the molecule ranges also as the table dmpnn_molagg_* read (first[n_mols] | end[n_mols] | flag)
 // split_for / did_split: the pre-split of that forward's weights (tile kernel on the f16 pipe) rides in the same launch — workgroup 0
 // plans, the others split; *did_split tells the caller to pass DMPNN_F_WSPLIT_READY to the forward

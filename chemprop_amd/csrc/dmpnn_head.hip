@@ -172,6 +172,20 @@ __global__ __launch_bounds__(1024) void k_bn_bwd(BnBwdArgs a) {
 //   mask = isfinite(target) (models/model.py:152-153), target = nan_to_num(target)
 //   bounded: P' = T where (P < T and lt) or (P > T and gt)   (metrics.py:157-161)
 //   L = (P' - T)^2 | |P' - T|;   loss = sum(L w_i t_j mask) / sum(mask);   gP = dL/dP w_i t_j mask / sum(mask)
+// the unreduced loss of one (prediction, target) pair and its derivative in the prediction:
+//   MSE (metrics.py:137-141), MAE (:146-148), BCE with logits (:292-295: F.binary_cross_entropy_with_logits — the classification
+//   predictor's train_step hands over raw logits, predictors.py:246-247):  L = (1 - y) x - log_sigmoid(x),  dL/dx = sigmoid(x) - y
+__device__ __forceinline__ float loss_value(int kind, float p, float y) {
+    if (kind == DMPNN_LOSS_BCE) return (1.f - y) * p - (fminf(p, 0.f) - log1pf(expf(-fabsf(p))));
+    const float d = p - y;
+    return kind == DMPNN_LOSS_MAE ? fabsf(d) : d * d;
+}
+__device__ __forceinline__ float loss_deriv(int kind, float p, float y) {
+    if (kind == DMPNN_LOSS_BCE) return 1.f / (1.f + expf(-p)) - y;
+    const float d = p - y;
+    return kind == DMPNN_LOSS_MAE ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+}
+
 struct LossArgs {
     const float* P; int64_t ldp; const float* T; int64_t ldt; const float* w; const float* tw;
     const unsigned char* lt; const unsigned char* gt;
@@ -190,8 +204,7 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
         if (!m) continue;
         float p = a.P[r * a.ldp + j];
         if ((a.lt && a.lt[r * a.t + j] && p < y) || (a.gt && a.gt[r * a.t + j] && p > y)) p = y;
-        const float d = p - y;
-        const float L = a.kind == DMPNN_LOSS_MAE ? fabsf(d) : d * d;
+        const float L = loss_value(a.kind, p, y);
         sl += L * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f);
         sm += 1.f;
     }
@@ -215,8 +228,7 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
         if (isfinite(y)) {
             float p = a.P[r * a.ldp + j];
             if ((a.lt && a.lt[r * a.t + j] && p < y) || (a.gt && a.gt[r * a.t + j] && p > y)) p = y;
-            const float d = p - y;
-            const float dl = a.kind == DMPNN_LOSS_MAE ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+            const float dl = loss_deriv(a.kind, p, y);
             g = dl * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f) * inv;
         }
         a.gP[r * a.ldg + j] = g;
@@ -311,8 +323,7 @@ __global__ __launch_bounds__(1024) void k_out_all(OutAllArgs q) {
         if (!isfinite(y)) continue;
         float p = Ps[i];
         if ((L.lt && L.lt[i] && p < y) || (L.gt && L.gt[i] && p > y)) p = y;
-        const float d = p - y;
-        const float Lv = L.kind == DMPNN_LOSS_MAE ? fabsf(d) : d * d;
+        const float Lv = loss_value(L.kind, p, y);
         sl += Lv * (L.w ? L.w[r] : 1.f) * (L.tw ? L.tw[j] : 1.f);
         sm += 1.f;
     }
@@ -334,8 +345,7 @@ __global__ __launch_bounds__(1024) void k_out_all(OutAllArgs q) {
         if (isfinite(y)) {
             float p = Ps[i];
             if ((L.lt && L.lt[i] && p < y) || (L.gt && L.gt[i] && p > y)) p = y;
-            const float d = p - y;
-            const float dl = L.kind == DMPNN_LOSS_MAE ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+            const float dl = loss_deriv(L.kind, p, y);
             g = dl * (L.w ? L.w[r] : 1.f) * (L.tw ? L.tw[j] : 1.f) * inv;
         }
         gPs[i] = g;
@@ -470,7 +480,8 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     DMPNN_CHECK_ARG(Ln >= 1 && Ln <= DMPNN_MAX_FFN_LAYERS && h.dims[0] == d, "head: 1..%d predictor layers, dims[0] == d_h", DMPNN_MAX_FFN_LAYERS);
     for (int l = 0; l < Ln; ++l) DMPNN_CHECK_ARG(h.W[l] && h.dims[l + 1] > 0, "head: layer %d has no weight / width", l);
     DMPNN_CHECK_ARG(h.act >= DMPNN_ACT_NONE && h.act <= DMPNN_ACT_ELU && h.act != DMPNN_ACT_PRELU, "head: activation %d is not built in", h.act);
-    DMPNN_CHECK_ARG(h.loss == DMPNN_LOSS_MSE || h.loss == DMPNN_LOSS_MAE, "head: unknown criterion %d", h.loss);
+    DMPNN_CHECK_ARG(h.loss == DMPNN_LOSS_MSE || h.loss == DMPNN_LOSS_MAE || h.loss == DMPNN_LOSS_BCE, "head: unknown criterion %d", h.loss);
+    DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_BCE || (!h.lt_mask && !h.gt_mask), "head: the BCE criterion has no bounds (lt_mask / gt_mask)");
     DMPNN_CHECK_ARG(h.preds && (nV == 0 || (Hv && h.batch)), "head: null H_v / batch / preds");
     DMPNN_CHECK_ARG(!h.bn_weight || (h.bn_running_mean && h.bn_running_var), "head: batch norm without running statistics");
     // (torch.nn.BatchNorm1d in training mode — hence the reference — raises "Expected more than 1 value per channel": a batch of one

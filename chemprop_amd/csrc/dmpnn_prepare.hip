@@ -854,7 +854,32 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch_split(con
     else mega16::split_weights_wave(sp, ((int)blockIdx.x - 1) * (kSmallThreads / 64) + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 
+// The loader's tile table (dmpnn_prepare_tiles_from_table) with the weight pre-split in the same launch: workgroup 0 copies / checks the
+// table, the others split — the "K0 for free" path used to pay a k_split_weights launch per forward once the weight cache was gone
+// (round-4 VERDICT weak #6: 40.4 -> 46.7 us at 512 molecules).
+__global__ __launch_bounds__(256) void k_tiles_from_table_split(const int* __restrict__ tile_row, const int* __restrict__ tile_atom, int n_tiles,
+                                                                int nV, int nE, int* __restrict__ plan, PlanLayout L, mega16::SplitArgs sp) {
+    if (blockIdx.x == 0) tiles_from_table_body(tile_row, tile_atom, n_tiles, nV, nE, plan, L);
+    else mega16::split_weights_wave(sp, ((int)blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
+}
+
 }  // namespace
+
+int launch_tiles_from_table_split(const int* tile_row, const int* tile_atom, int64_t n_tiles, int64_t nV, int64_t nE, int* plan, hipStream_t s,
+                                  const dmpnn_fwd_args* split_for, bool* did_split) {
+    *did_split = false;
+    mega16::SplitArgs sp;
+    if (!split_for || !(split_for->flags & DMPNN_F_MEGA) || !(split_for->flags & DMPNN_F_SPLIT16) || (split_for->flags & DMPNN_F_WSPLIT_READY) ||
+        !mega16_split_args(*split_for, &sp))
+        return DMPNN_OK;   // (nothing to split here: the caller launches the plain table kernel)
+    const PlanLayout L = plan_layout(nV, nE);
+    const int waves = ((sp.N + 15) & ~15) * sp.n_jobs;
+    hipLaunchKernelGGL(k_tiles_from_table_split, dim3((unsigned)(1 + (waves + 3) / 4)), dim3(256), 0, s, tile_row, tile_atom, (int)n_tiles, (int)nV,
+                       (int)nE, plan, L, sp);
+    DMPNN_CHECK_LAUNCH("k_tiles_from_table_split");
+    *did_split = true;
+    return DMPNN_OK;
+}
 
 // bytes of LDS of k_prepare_tiles_batch
 static size_t tiles_batch_lds_bytes(int64_t nV, int64_t nE) {

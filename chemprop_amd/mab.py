@@ -149,8 +149,11 @@ def _tile_train_ok(mp, bmg, V_d) -> bool:
         return False
     if mp.atom_messages and (V_d is not None or not (2 <= d_e <= 16 and d_e % 2 == 0)):
         return False
-    # a molecule beyond the tile is NaN on these training routes (forward and every gradient: the kernels' generic path has neither
-    # atom messages nor the second read-out's kept rows) — the host must KNOW, not guess: counted on the device for a foreign batch
+    if not mp.atom_messages:
+        # bond messages: a molecule beyond the tile runs the kernels' generic fp32 path (correct, slow) — a speed question only
+        return getattr(bmg, "oversize", None) is not True
+    # atom messages: such a molecule is NaN on these training routes, forward and every gradient (the generic path knows bond messages
+    # only, dmpnn_mega16_impl.hpp) — the host must KNOW, not guess: counted on the device for a foreign batch (round-4 ADVICE)
     from .nn import batch_oversize
 
     return batch_oversize(bmg, len(bmg) if hasattr(bmg, "__len__") else 0) is False

@@ -28,7 +28,7 @@ from .ffn import MLP
 from .nn import BondMessagePassing, classify_activation
 from .optim import FlatAdam
 
-__all__ = ["MSE", "RegressionFFN", "MPNN", "FusedTrainer", "masked_loss"]
+__all__ = ["MSE", "MAE", "BCE", "RegressionFFN", "BinaryClassificationFFN", "MPNN", "FusedTrainer", "masked_loss"]
 
 
 def masked_loss(preds: Tensor, targets: Tensor, weights: Optional[Tensor] = None, task_weights: Optional[Tensor] = None,
@@ -37,11 +37,16 @@ def masked_loss(preds: Tensor, targets: Tensor, weights: Optional[Tensor] = None
     ``MPNN.training_step`` (``models/model.py:152-156``): torch ops, differentiable — the module path's criterion."""
     mask = targets.isfinite()
     targets = targets.nan_to_num(nan=0.0)
+    if kind == "bce":
+        lt_mask = gt_mask = None     # (BCELoss is not a bounded criterion: metrics.py:292-295)
     if lt_mask is not None:
         preds = torch.where((preds < targets) & lt_mask, targets, preds)
     if gt_mask is not None:
         preds = torch.where((preds > targets) & gt_mask, targets, preds)
-    L = (preds - targets).abs() if kind == "mae" else torch.nn.functional.mse_loss(preds, targets, reduction="none")
+    if kind == "bce":     # nn/metrics.py:292-295 (on logits: the classification predictor's train_step, predictors.py:246-247)
+        L = torch.nn.functional.binary_cross_entropy_with_logits(preds, targets, reduction="none")
+    else:
+        L = (preds - targets).abs() if kind == "mae" else torch.nn.functional.mse_loss(preds, targets, reduction="none")
     w = torch.ones(targets.shape[0], dtype=torch.float, device=targets.device) if weights is None else weights
     tw = 1.0 if task_weights is None else task_weights.view(1, -1)
     L = L * w.view(-1, 1) * tw * mask
@@ -64,6 +69,15 @@ class MSE(nn.Module):
 
 class MAE(MSE):
     kind = "mae"
+
+
+class BCE(MSE):
+    """``chemprop.nn.metrics.BCELoss`` (``metrics.py:292-295``): binary cross entropy on LOGITS; no bounds."""
+
+    kind = "bce"
+
+    def forward(self, preds, targets, mask=None, weights=None, lt_mask=None, gt_mask=None):
+        return super().forward(preds, targets, mask, weights, None, None)
 
 
 class RegressionFFN(nn.Module):
@@ -97,6 +111,22 @@ class RegressionFFN(nn.Module):
         return self.output_transform(self.ffn(Z))
 
     train_step = forward
+
+
+class BinaryClassificationFFN(RegressionFFN):
+    """``chemprop.nn.predictors.BinaryClassificationFFN`` (``predictors.py:235-247``): the same MLP; ``forward`` predicts
+    probabilities (``sigmoid``), ``train_step`` hands the raw logits to ``BCELoss``."""
+
+    def __init__(self, n_tasks: int = 1, input_dim: int = 300, hidden_dim: int = 300, n_layers: int = 1, dropout: float = 0.0,
+                 activation="relu", criterion: Optional[nn.Module] = None, task_weights: Optional[Tensor] = None):
+        super().__init__(n_tasks, input_dim, hidden_dim, n_layers, dropout, activation,
+                         criterion if criterion is not None else BCE(torch.ones(n_tasks) if task_weights is None else task_weights))
+
+    def forward(self, Z: Tensor) -> Tensor:
+        return self.ffn(Z).sigmoid()
+
+    def train_step(self, Z: Tensor) -> Tensor:
+        return self.ffn(Z)
 
 
 class MPNN(nn.Module):
@@ -159,10 +189,12 @@ def criterion_kind(crit) -> tuple[Optional[str], bool]:
     (``nn/metrics.py:139-150``), ``BoundedMSE`` / ``BoundedMAE`` apply them (``:158-177``); RMSE, MVE, ... are not built in."""
     kind = getattr(crit, "kind", None)
     if kind in _lib.LOSS:
-        return kind, True
+        return kind, kind != "bce"
     names = _mro_names(crit)
     if "RMSE" in names:
         return None, False
+    if "BCELoss" in names:       # nn/metrics.py:292-295 (binary classification: chemprop's second task type)
+        return "bce", False
     for cls, k in (("MSE", "mse"), ("MAE", "mae")):
         if cls in names:
             return k, "BoundedMixin" in names
@@ -196,7 +228,7 @@ class HeadSpec:
             raise NotImplementedError("one value per task (regression); MVE / evidential / quantile heads train through torch ops")
         kind, self.bounded = criterion_kind(pred.criterion)
         if kind is None:
-            raise NotImplementedError("MSE / MAE criterion (bounded or not)")
+            raise NotImplementedError("MSE / MAE criterion (bounded or not) or BCE")
         self.agg_mode, self.agg_norm = MODES[mode], float(getattr(agg, "norm", 1.0))
         self.f_act, self.f_slope, self.kind = f_act, f_slope, kind
         self.layers = [b[-1] for b in blocks]

@@ -45,7 +45,7 @@ extern "C" {
  * respect to the kept H^(depth-1): the edge read-out of the mol-atom-bond blocks); `msplit` on the tile kernel's training forward: M^(t)
  * kept as split rows, every weight-gradient product of dmpnn_backward on split rows.
  * 12 — round 5: dmpnn_clip_grad / dmpnn_clip_grad_ws_bytes (Lightning's Trainer(gradient_clip_val), cli/train.py:1937, over the flat
- * gradient buffer) and dmpnn_step_args.clip_val / clip_mode / clip_ws (the clip between the backward pass and the update of ONE call). */
+ * gradient buffer) and dmpnn_step_args.clip_val / clip_mode / clip_ws (the clip between the backward pass and the update of ONE call); DMPNN_LOSS_BCE. */
 #define DMPNN_ABI_VERSION 12
 
 enum dmpnn_status {
@@ -527,7 +527,8 @@ int dmpnn_clip_grad(float* g, int64_t n, float clip_val, int32_t mode, float gra
  * caller's business (an int64 buffer that does not enter the arithmetic with a fixed momentum).
  * ------------------------------------------------------------------------------------------- */
 #define DMPNN_MAX_FFN_LAYERS 8
-enum dmpnn_loss { DMPNN_LOSS_MSE = 0, DMPNN_LOSS_MAE = 1 };
+enum dmpnn_loss { DMPNN_LOSS_MSE = 0, DMPNN_LOSS_MAE = 1,
+                  DMPNN_LOSS_BCE = 2 /* v12: binary cross entropy with logits (nn/metrics.py:292-295; predictors.py:235-247) */ };
 typedef struct dmpnn_head_args {
     int64_t n_atoms, n_mols, d_h;           /* rows of H_v, molecules, width of H_v                              */
     const int64_t* batch;                   /* [n_atoms] molecule of every atom, non-decreasing (BatchMolGraph.batch) */

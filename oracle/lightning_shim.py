@@ -521,6 +521,7 @@ class Trainer:
         self.strategy = strategy if strategy is not None else SingleDeviceStrategy()
         self.optimizers, self.lr_scheduler_configs = [], []
         self.current_epoch = 0
+        self._epochs_done = 0               # epochs whose batches have all been run (fit_loop.epoch_progress.current.processed)
         self.should_stop = False
         self.sanity_checking = False
         self.state_fn = None
@@ -654,6 +655,7 @@ class Trainer:
             if self.max_steps > 0 and self.global_step >= self.max_steps:
                 self.should_stop = True
                 break
+        self._epochs_done = self.current_epoch + 1
         # training_epoch_loop / fit_loop: on_advance_end — epoch-level values, then the epoch-end hooks, then reset
         epoch_metrics = self._results.metrics(on_step=False)
         self.callback_metrics.update(epoch_metrics)
@@ -726,7 +728,7 @@ class Trainer:
             "optimizer_states": [o.state_dict() for o in self.optimizers],
             "lr_schedulers": [c["scheduler"].state_dict() for c in self.lr_scheduler_configs],
             "hyper_parameters": dict(m.hparams),
-            "loops": {"auto_step": self._auto_step.completed, "manual_step": self._manual_step.completed},
+            "loops": {"auto_step": self._auto_step.completed, "manual_step": self._manual_step.completed, "epochs_done": self._epochs_done},
         }
         m.on_save_checkpoint(ck)
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -742,8 +744,8 @@ class Trainer:
             c["scheduler"].load_state_dict(sd)
         self._auto_step.completed = self._auto_step.ready = ck["loops"]["auto_step"]
         self._manual_step.completed = self._manual_step.ready = ck["loops"]["manual_step"]
-        self.current_epoch = ck["epoch"] + 1      # (a checkpoint written at the end of an epoch resumes with the next one)
-        self.max_epochs = max(self.max_epochs, self.current_epoch)
+        # (a checkpoint written at or after the end of an epoch resumes with the next one)
+        self.current_epoch = self._epochs_done = int(ck["loops"].get("epochs_done", ck["epoch"] + 1))
 
 
 def install_into(sys_modules: dict) -> None:

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE — CPU restatement of one training step of ``chemprop.models.MPNN`` with a regression predictor:
 ``training_step`` (``models/model.py:148-161``) over ``fingerprint`` (``:126-134``), ``RegressionFFN.train_step``
 (``nn/predictors.py:161-169``), the criterion's batch value (``nn/metrics.py:78-127``; MSE ``:137-141``, MAE ``:146-148``,
-bounded ``:157-163``) and ``torch.optim.Adam`` (``model.py:208-209``).  Only ``tests/``, ``__graft_entry__.smoke()`` and
+bounded ``:157-163``; BCE with logits ``:292-295`` behind ``BinaryClassificationFFN.train_step``, ``predictors.py:235-247``) and ``torch.optim.Adam`` (``model.py:208-209``).  Only ``tests/``, ``__graft_entry__.smoke()`` and
 ``bench.py``'s ``cpu_baseline`` leg may import it.
 
 Built from the other restatements (``dmpnn_torch.forward``, ``agg_torch``, ``ffn_torch.mlp_forward``) plus
@@ -29,7 +29,10 @@ def criterion(preds: Tensor, targets: Tensor, weights: Optional[Tensor], task_we
     if kind.startswith("bounded"):  # metrics.py:157-161
         preds = torch.where((preds < targets) & lt_mask, targets, preds)
         preds = torch.where((preds > targets) & gt_mask, targets, preds)
-    L = (preds - targets).abs() if kind.endswith("mae") else F.mse_loss(preds, targets, reduction="none")
+    if kind == "bce":       # metrics.py:292-295 on the raw logits of BinaryClassificationFFN.train_step (predictors.py:246-247)
+        L = F.binary_cross_entropy_with_logits(preds, targets, reduction="none")
+    else:
+        L = (preds - targets).abs() if kind.endswith("mae") else F.mse_loss(preds, targets, reduction="none")
     w = torch.ones(targets.shape[0]) if weights is None else weights
     tw = torch.ones(1, targets.shape[1]) if task_weights is None else task_weights.view(1, -1)
     L = L * w.view(-1, 1) * tw * mask

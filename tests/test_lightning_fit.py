@@ -93,6 +93,31 @@ def test_stock_mpnn_fits_under_the_stand_in_and_reloads_its_best_checkpoint(tmp_
         assert torch.equal(v, sd["state_dict"][k])
 
 
+def test_stock_mpnn_resumed_from_a_checkpoint_ends_where_the_uninterrupted_run_ends(tmp_path):
+    """``Trainer.fit(ckpt_path=...)`` of the stand-in: parameters, optimizer moments, scheduler and step counters come back, the next
+    epoch runs, and the stock class lands bit for bit where an uninterrupted two-epoch run lands (the CPU half of
+    ``test_hip_mpnn_resumes_from_a_stock_checkpoint_and_back``)."""
+    R = _ref()
+    torch.manual_seed(5)
+    a = _model(R, R["MPNN"], bn=False)
+    init = copy.deepcopy(a.state_dict())
+    tr0 = R["pl"].Trainer(max_epochs=1)
+    tr0.fit(a, _batches(R, 2, 8), None)
+    tr0.save_checkpoint(str(tmp_path / "e0.ckpt"))
+    torch.manual_seed(5)
+    b = _model(R, R["MPNN"], bn=False)
+    trb = R["pl"].Trainer(max_epochs=2)
+    trb.fit(b, _batches(R, 2, 8), None, ckpt_path=str(tmp_path / "e0.ckpt"))
+    torch.manual_seed(5)
+    c = _model(R, R["MPNN"], bn=False)
+    c.load_state_dict(init)
+    trc = R["pl"].Trainer(max_epochs=2)
+    trc.fit(c, _batches(R, 2, 8), None)
+    assert trb.global_step == trc.global_step == 4 and trb.current_epoch == 2
+    for (k, p), (_, q) in zip(b.named_parameters(), c.named_parameters()):
+        assert torch.equal(p, q), k
+
+
 def test_manual_optimization_that_never_steps_lightnings_optimizer_saves_nothing(tmp_path):
     """The failure mode of round 4's ``HipMPNN`` (VERDICT weak #1, ADVICE high), reproduced on the stand-in: a module with
     ``automatic_optimization = False`` that updates its parameters itself and never calls ``self.optimizers().step()`` leaves
@@ -341,7 +366,9 @@ def test_hip_mpnn_module_path_under_the_trainer_logs_once_and_follows_the_schedu
     cnn = R["nn"]
     HipMPNN = integration.hip_mpnn_class()[1]
     torch.manual_seed(3)
-    mk = lambda cls: cls(R["BMP"](d_h=64, d_vd=4), cnn.MeanAggregation(), cnn.RegressionFFN(input_dim=68, hidden_dim=32), batch_norm=True)
+    # (no batch norm here: behind one, W_d's bias has a mathematically ZERO gradient — batch norm removes any constant shift — and Adam
+    #  turns the rounding noise computed in its place into +- lr per step, differently in any two implementations)
+    mk = lambda cls: cls(R["BMP"](d_h=64, d_vd=4), cnn.MeanAggregation(), cnn.RegressionFFN(input_dim=68, hidden_dim=32), batch_norm=False)
     model = mk(HipMPNN).to(gpu_device)
     twin = mk(R["MPNN"])
     twin.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=False)
