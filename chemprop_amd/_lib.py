@@ -35,7 +35,7 @@ EXPORTS = [
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
     "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles", "dmpnn_forward_route", "dmpnn_dropout_keep",
-    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes",
+    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes", "dmpnn_train_route",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -129,6 +129,10 @@ class HeadArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("bn_num_batches_tracked", C.c_void_p),
     ]
+
+
+class TrainRouteInfo(C.Structure):
+    _fields_ = [("plan_kind", C.c_int32), ("route", C.c_int32), ("keep_rows", C.c_int32), ("keep_bits", C.c_int32), ("lean", C.c_int32)]
 
 
 class StepArgs(C.Structure):
@@ -290,6 +294,7 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.dmpnn_train_route.argtypes = [C.POINTER(FwdArgs), C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(TrainRouteInfo)]
     lib.dmpnn_clip_grad.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
     lib.dmpnn_dropout_keep.argtypes = [C.c_uint64, C.c_int32, C.c_int64, C.c_int64, C.c_float]
     lib.dmpnn_forward_route.argtypes = [C.POINTER(FwdArgs), C.c_int, C.c_int, C.c_int, C.c_int]

@@ -316,6 +316,50 @@ int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int pl
     return (arith == 0 && (h > 320 || nE >= kSteps16MinEdges)) ? DMPNN_ROUTE_GENERAL16 : DMPNN_ROUTE_GENERAL;
 }
 
+int dmpnn_train_route(const dmpnn_fwd_args* a, int64_t n_mols, int32_t have, int32_t oversize, int32_t max_level, int32_t arith,
+                      int32_t keep_rows, dmpnn_train_route_info* out) {
+    DMPNN_CHECK_ARG(a && out && max_level >= 0 && (arith == 0 || arith == 1) && keep_rows >= -1 && keep_rows <= 1, "train_route: bad arguments");
+    memset(out, 0, sizeof(*out));
+    const int64_t nV = a->n_atoms, nE = a->n_edges, h = a->d_h;
+    const bool undirected = (a->flags & DMPNN_F_UNDIRECTED) != 0, atom = (a->flags & DMPNN_F_ATOM) != 0;
+    const bool relu_class = a->act == DMPNN_ACT_RELU || a->act == DMPNN_ACT_LEAKYRELU;
+    const bool builtin = a->act == DMPNN_ACT_NONE || relu_class || a->act == DMPNN_ACT_TANH || a->act == DMPNN_ACT_ELU;   // (not PReLU: its slope trains)
+    // ---- which plan ----
+    bool tiles = !undirected && !a->W_d && builtin && max_level >= 2 && arith == 0 && nE > 0 && nV > 0 && oversize != 1;
+    if (a->dropout_p > 0.f && !relu_class) tiles = false;           // (the mask is recovered from the sign of the kept tensors)
+    if (!(h > 0 && h % 4 == 0 && h <= 320 && a->d_v % 2 == 0 && a->d_e % 2 == 0)) tiles = false;
+    if (atom && !(a->d_e >= 2 && a->d_e <= 16) ) tiles = false;
+    const bool small = small_plan_fits(nV, nE), table = (have & 2) != 0, large = (have & 1) != 0 && tiles_large_fits(nV, nE);
+    if (!(small || table || large)) tiles = false;                  // a planner that can build it
+    if (!(n_mols > 0 && nE <= 30 * n_mols && (table || large || small))) tiles = false;   // (30 directed edges per molecule: near the tile)
+    out->plan_kind = tiles ? 2 : 0;
+    // ---- the route on that plan ----
+    int cap = max_level;
+    if (oversize == 1 && cap > 1) cap = 1;
+    dmpnn_fwd_args t = *a;
+    if (table || large) t.flags |= DMPNN_F_LOADER_TILES;
+    out->route = dmpnn_forward_route(&t, 1, cap, out->plan_kind, arith);
+    if (out->route < 0 && out->plan_kind == 2) {                    // (the shapes did not reach the tile kernel after all: the full plan)
+        out->plan_kind = 0;
+        out->route = dmpnn_forward_route(&t, 1, cap, 0, arith);
+    }
+    // ---- the form of the kept tensors ----
+    const int64_t n_steps = a->depth > 1 ? a->depth - 1 : 0;
+    // (keep_rows is a size rule of the tile kernels' training forward — meaningful when that is the route — and answered whatever
+    //  `route` says, so that a caller that already holds the route, engine.forward, can ask for it alone)
+    const bool rows = keep_rows == 1 || (keep_rows < 0 && nE * n_steps >= DMPNN_KEEP_ROWS_MIN);
+    out->keep_rows = (!atom && n_steps > 0 && h > 0 && h <= 320 && rows) ? 1 : 0;
+    if (out->route == DMPNN_ROUTE_MEGA16) {
+        out->keep_bits = (out->plan_kind == 2 && (relu_class || a->act == DMPNN_ACT_NONE) && !(a->dropout_p > 0.f)) ? 1 : 0;
+    } else if (out->route == DMPNN_ROUTE_FUSED16) {
+        dmpnn_fwd_args l = *a;
+        l.flags = (l.flags | DMPNN_F_FUSED | DMPNN_F_SPLIT16) & ~(unsigned)(DMPNN_F_MEGA | DMPNN_F_STORE16);
+        out->lean = fused16_lean_shapes(l) ? 1 : 0;
+        out->keep_bits = out->lean;
+    }
+    return DMPNN_OK;
+}
+
 int dmpnn_forward_tiles(const dmpnn_fwd_args* a, const int64_t* batch, const int* tile_row, const int* tile_atom, int64_t n_tiles,
                         size_t plan_bytes, void* stream) {
     DMPNN_CHECK_ARG(a != nullptr && a->plan != nullptr, "forward_tiles: null args / plan");

@@ -308,12 +308,30 @@ def lean_sign_bits(st: "ForwardState") -> Tensor:
     return ((b.unsqueeze(-1) >> sh) & 1).bool().reshape(depth, st.plan.n_edges, bn)[:, :, :d_h]
 
 
-KEEP_ROWS_MIN = 32768   # message rows (n_edges x (depth - 1)) from which a training forward of the tile kernel keeps them as split rows
+KEEP_ROWS_MIN = 32768   # (= DMPNN_KEEP_ROWS_MIN of include/dmpnn.h: the rule itself is the library's, dmpnn_train_route)
 
 
-def _keep_rows(n_rows: int) -> bool:
-    v = _lib.opt("DMPNN_KEEP_ROWS", "auto")   # "1" / "0": always / never (tests, A/B measurements)
-    return v == "1" or (v != "0" and n_rows >= KEEP_ROWS_MIN)
+def train_route(n_atoms: int, n_edges: int, d_v: int, d_e: int, d_h: int, depth: int, act: str, n_mols: int = 0, *, undirected: bool = False,
+                has_vd: bool = False, dropout_p: float = 0.0, atom: bool = False, have_batch: bool = False, have_table: bool = False,
+                oversize=None, max_level: int = 2) -> "_lib.TrainRouteInfo":
+    """``dmpnn_train_route`` (include/dmpnn.h): for a TRAINING forward of these shapes, which plan K0 builds (``plan_kind`` 0 full /
+    2 tiles), which route the forward takes on it, and the form of the kept tensors (``keep_rows`` / ``keep_bits`` / ``lean``) — the ONE
+    training-side rule, in the library beside ``dmpnn_forward_route``; the host only contributes what it alone knows (the caller's
+    cap, the environment switches: ``DMPNN_MEGA`` / ``DMPNN_MFMA`` / ``DMPNN_KEEP_ROWS``)."""
+    a = FwdArgs()
+    a.n_atoms, a.n_edges, a.d_v, a.d_e, a.d_h, a.depth = int(n_atoms), int(n_edges), int(d_v), int(d_e), int(d_h), int(depth)
+    a.ldh, a.ldv, a.lde = (int(d_h) + 3) // 4 * 4, int(d_v), int(d_e)
+    a.flags = (F_UNDIRECTED if undirected else 0) | (_lib.F_ATOM if atom else 0)
+    a.act = act_code(act)
+    a.dropout_p = float(dropout_p)
+    a.W_d = 16 if has_vd else None      # (only its presence is read)
+    cap = min(int(max_level), 1) if _lib.opt("DMPNN_MEGA", "1") == "0" else int(max_level)
+    kr = {"1": 1, "0": 0}.get(_lib.opt("DMPNN_KEEP_ROWS", "auto"), -1)   # "1" / "0": always / never (tests, A/B measurements)
+    info = _lib.TrainRouteInfo()
+    _lib.check(_lib.load().dmpnn_train_route(C.byref(a), int(n_mols), (1 if have_batch else 0) | (2 if have_table else 0),
+                                             -1 if oversize is None else (1 if oversize else 0), cap,
+                                             1 if _lib.opt("DMPNN_MFMA", "split16") == "f32" else 0, kr, C.byref(info)), "dmpnn_train_route")
+    return info
 
 
 def split_rows_to_float(rows: Tensor, n_cols: int) -> Tensor:
@@ -655,7 +673,7 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         if atom and keep:
             # the bond-feature half of the atom messages, kept for W_h's gradient: depth - 1 slots of [n_edges][16] (include/dmpnn.h, DMPNN_F_ATOM)
             split_ms = torch.empty((max(n_steps, 1), nE, 16), dtype=torch.float32, device=dev)
-        elif use_mega and want16 and keep and n_steps and d_h <= 320 and _keep_rows(nE * n_steps):
+        elif use_mega and want16 and keep and n_steps and train_route(nV, nE, d_v, d_e, d_h, depth, act, 1, max_level=2).keep_rows:
             # round 4: the tile kernel keeps M^(t) as SPLIT ROWS (depth - 1 slots of n_edges rows of dmpnn_split_row_floats(d_h) floats) —
             # what the weight-gradient products read as they are (csrc/dmpnn_wgrad16.hip: k_wgrad16r); the fp32 Ms slots above then only
             # serve a molecule beyond the tile.  From KEEP_ROWS_MIN message rows on: measured per training step 300 -> 271 us at 1 024

@@ -133,34 +133,34 @@ class BondMessagePassing(EngineStateMixin, nn.Module):
         return bond_message_passing_forward(self, bmg, V_d)
 
 
-def _training_plan_kind(mp, bmg):
+def _training_plan_kind(mp, bmg, atom: bool = False):
     """``"tiles"`` when a TRAINING forward of ``mp`` on ``bmg`` runs on the tile plan (K0 = the tile table alone, kept tensors in the
-    caller's edge order, ``DMPNN_F_TILE_PLAN``), else ``False`` (the full CSR plan).  The tile plan after the validated first
-    batches, for batches bound for the tile kernels: directed, built-in activation, no ``W_d``, a gradient of ``W_i`` or ``W_h``
-    wanted, the shapes of the tile kernel, and a plan the library can build from what the batch carries."""
+    caller's edge order, ``DMPNN_F_TILE_PLAN``), else ``False`` (the full CSR plan).  The SHAPE rule is the library's
+    (``dmpnn_train_route``, include/dmpnn.h: directed, built-in activation, no ``W_d``, the shapes of the tile kernel, a plan the
+    library can build from what the batch carries, at most 30 directed edges per molecule); the host adds only what it alone knows:
+    the environment switches, an activation / dropout MODULE the kernels cannot stand in for, the validation window of the module's
+    first batches, whether a gradient of ``W_i`` or ``W_h`` is wanted at all."""
     if _lib.opt("DMPNN_GENERAL", "0") == "1" or _lib.opt("DMPNN_TRAIN_PLAN", "tiles") == "full":
         return False
-    if mp.undirected or mp.W_d is not None or classify_activation(mp.tau)[0] in ("custom", "prelu"):
+    act = classify_activation(mp.tau)[0]
+    if act == "custom" or (mp.training and mp.dropout.p > 0 and type(mp.dropout) is not nn.Dropout):
         return False
-    if mp.training and mp.dropout.p > 0 and not (type(mp.dropout) is nn.Dropout and classify_activation(mp.tau)[0] in ("relu", "leakyrelu")):
-        return False
-    if _lib.opt("DMPNN_VALIDATE", "first") != "never" and getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N:
-        return False
+    mode = _lib.opt("DMPNN_VALIDATE", "first")
+    if mode == "always" or (mode != "never" and getattr(mp, "_dmpnn_batches_checked", 0) < _VALIDATE_FIRST_N):
+        return False   # (the per-batch verdict is read from a full plan)
     if not (mp.W_i.weight.requires_grad or mp.W_h.weight.requires_grad):
         return False
     d_h, d_in = mp.W_h.weight.shape[0], mp.W_i.weight.shape[1]
     d_v = mp.W_o.weight.shape[1] - d_h
-    if not (d_h % 4 == 0 and d_h <= 320 and d_v % 2 == 0 and (d_in - d_v) % 2 == 0):
-        return False
-    n_atoms, n_edges = int(bmg.V.shape[0]), int(bmg.E.shape[0])
-    n_mols = len(bmg) if hasattr(bmg, "__len__") else 0
+    d_e = int(bmg.E.shape[1]) if atom else d_in - d_v
     batch = getattr(bmg, "batch", None)
-    if n_edges == 0 or getattr(bmg, "oversize", None) is True:
-        return False
-    buildable = engine.small_plan_fits(n_atoms, n_edges) or getattr(bmg, "tiles", None) is not None or (
-        batch is not None and batch.dtype == torch.int64 and batch.is_contiguous()
-        and bool(_lib.load().dmpnn_tile_plan_any_size(n_atoms, n_edges)))
-    return "tiles" if (buildable and _tile_plan_ok(mp, n_atoms, n_edges, n_mols, True)) else False
+    info = engine.train_route(int(bmg.V.shape[0]), int(bmg.E.shape[0]), d_v, d_e, d_h, mp.depth, act,
+                              len(bmg) if hasattr(bmg, "__len__") else 0, undirected=bool(mp.undirected), has_vd=mp.W_d is not None,
+                              dropout_p=float(mp.dropout.p) if mp.training else 0.0, atom=atom,
+                              have_batch=batch is not None and batch.dtype == torch.int64 and batch.is_contiguous(),
+                              have_table=getattr(bmg, "tiles", None) is not None, oversize=getattr(bmg, "oversize", None),
+                              max_level=1 if getattr(mp, "_dmpnn_no_mega", False) else 2)
+    return "tiles" if info.plan_kind == 2 else False
 
 
 _ENV_KEYS = ("DMPNN_GENERAL", "DMPNN_MEGA", "DMPNN_MFMA", "DMPNN_VALIDATE", "DMPNN_STORE")

@@ -45,7 +45,8 @@ extern "C" {
  * respect to the kept H^(depth-1): the edge read-out of the mol-atom-bond blocks); `msplit` on the tile kernel's training forward: M^(t)
  * kept as split rows, every weight-gradient product of dmpnn_backward on split rows.
  * 12 — round 5: dmpnn_clip_grad / dmpnn_clip_grad_ws_bytes (Lightning's Trainer(gradient_clip_val), cli/train.py:1937, over the flat
- * gradient buffer) and dmpnn_step_args.clip_val / clip_mode / clip_ws (the clip between the backward pass and the update of ONE call); DMPNN_LOSS_BCE. */
+ * gradient buffer) and dmpnn_step_args.clip_val / clip_mode / clip_ws (the clip between the backward pass and the update of ONE call); DMPNN_LOSS_BCE;
+ * dmpnn_train_route (the training-plan / kept-form rule beside dmpnn_forward_route). */
 #define DMPNN_ABI_VERSION 12
 
 enum dmpnn_status {
@@ -397,6 +398,31 @@ int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a);
 enum dmpnn_route { DMPNN_ROUTE_GENERAL = 0, DMPNN_ROUTE_GENERAL16 = 1, DMPNN_ROUTE_FUSED = 2, DMPNN_ROUTE_FUSED16 = 3,
                    DMPNN_ROUTE_MEGA = 4, DMPNN_ROUTE_MEGA16 = 5 };
 int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int plan_kind, int arith);
+
+/* v12 — the TRAINING side of that rule, also in the library (round-4 VERDICT weak #10: it lived in three places of the host code): for a
+ * training forward of these shapes — `a`: sizes, depth, act, DMPNN_F_UNDIRECTED / DMPNN_F_ATOM, W_d (non-NULL: the block has one),
+ * dropout_p — which PLAN K0 builds, which route the forward then takes, and in what FORM the backward pass gets its tensors:
+ *   n_mols     molecules of the batch (0: unknown)
+ *   have       bit 0: the batch vector (BatchMolGraph.batch) is there; bit 1: a loader's tile table came with the batch
+ *   oversize   what the host knows about molecules beyond the tile (48 directed edges / 32 atoms): 1 yes, 0 no, -1 unknown
+ *   max_level, arith   as for dmpnn_forward_route (the caller's cap: validation verdicts, DMPNN_MEGA / DMPNN_GENERAL; DMPNN_MFMA)
+ *   keep_rows  DMPNN_KEEP_ROWS: -1 the size rule (DMPNN_KEEP_ROWS_MIN message rows), 0 never, 1 always
+ * plan_kind 2 (the tile plan, DMPNN_F_TILE_PLAN: K0 = the tile table alone, kept tensors in the caller's edge order) needs the tile
+ * kernels' shapes (d_h % 4 == 0, d_h <= 320, even d_v / d_e, or DMPNN_F_ATOM's), a directed block without W_d and with a built-in
+ * activation other than PReLU, dropout only with a ReLU-class activation, no molecule known to exceed the tile, at most 30 directed
+ * edges per molecule on average, and a planner that can build it (the single-workgroup plan, a loader's table, or the batch vector
+ * for the multi-workgroup planner); everything else trains on the full plan (plan_kind 0).  Returns 0, or DMPNN_EINVAL. */
+#define DMPNN_KEEP_ROWS_MIN 32768
+typedef struct dmpnn_train_route_info {
+    int32_t plan_kind;      /* 0 | 2                                                                                          */
+    int32_t route;          /* enum dmpnn_route of the training forward on that plan (dmpnn_forward_route with keep)           */
+    int32_t keep_rows;      /* 1: the tile kernel keeps M^(t) as split rows in `msplit` (every weight gradient on k_wgrad16r);
+                               a size rule, answered whatever `route` is                                                      */
+    int32_t keep_bits;      /* 1: H0 / H^(t) leave as sign bits (`keep_bits`): the tile plan or the lean route, ReLU-class, no dropout */
+    int32_t lean;           /* 1: the per-step fused route's LEAN training forward (split rows of every step + sign bits)      */
+} dmpnn_train_route_info;
+int dmpnn_train_route(const dmpnn_fwd_args* a, int64_t n_mols, int32_t have, int32_t oversize, int32_t max_level, int32_t arith,
+                      int32_t keep_rows, dmpnn_train_route_info* out);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  backward.  The reference has no backward code of its own: gradients come from torch autograd
