@@ -103,7 +103,11 @@ def main():
     backend = os.environ.get("DMPNN_BENCH_BACKEND", "nccl")
     dev = torch.device("cuda", int(os.environ.get("DMPNN_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(dev)
-    if world > 1:
+    # (launched by torchrun — RANK / MASTER_ADDR in the environment — the process group is initialised also at world size 1: on a
+    #  one-GPU box `torchrun --nproc-per-node 1 bench.py --gpus 1` then runs the barriers, the MAX all-reduce of the timing and, with
+    #  DMPNN_FORCE_COLLECTIVE=1, the gradient all-reduce of the training step on RCCL itself: profiles/r05_nccl_world1.json)
+    use_pg = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_pg:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -157,16 +161,16 @@ def main():
     def timed(fn, n):
         """EXACTLY n steps between a barrier + device synchronize on both sides; the clock is read before the closing
         barrier (a collective is not part of the timed region); the maximum over the ranks is what counts."""
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(fn, n)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_pg:
             dist.barrier()
-        if world > 1:
+        if use_pg:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -237,7 +241,8 @@ def main():
                    "launch": launch_name},
         "timing": {"groups": args.groups, "steps_per_group": args.steps, "statistic": "median group",
                    "eager_ms_per_step_by_group": [round(t / args.steps * 1e3, 5) for t in eager_all]},
-        "rccl": {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else None)},
+        "rccl": {"world_size": (dist.get_world_size() if use_pg else 1), "backend": (dist.get_backend() if use_pg else None),
+                 "forced_collective_at_world_1": bool(use_pg and world == 1 and os.environ.get("DMPNN_FORCE_COLLECTIVE") == "1")},
         "parity_bar": {"forward": "<= 1e-5 norm-wise against the executed reference (tests/)",
                        "gradients": "<= 2e-5 norm-wise against the executed reference's autograd (a kinked activation's gradient is only as "
                                     "reproducible as its masks: DESIGN.md section 5)"},
@@ -298,7 +303,8 @@ def main():
                 tsync.wait()
             out["train_step"] = {"ms_per_step": round(t_tr, 5), "M_edge_updates_per_s": round(world * updates / (t_tr * 1e-3) / 1e6, 2),
                                  "allreduce_exposed_us": exposed_us,
-                                 "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else None,
+                                 "n_gpus": world, "collective": "one RCCL all-reduce of the flat gradient buffer per step" if (world > 1 or (use_pg and os.environ.get("DMPNN_FORCE_COLLECTIVE") == "1")) else None,
+                                 "collectives_launched": int(tsync.n_collectives),
                                  "autograd": "backward on the calling thread (torch.autograd.set_multithreading_enabled(False): one process per GPU)",
                                  "plan": "K0 inside every step, on the stream: the tile table (dmpnn_prepare_tiles, 11 us; the kept tensors stay in the "
                                          "caller's edge order, DMPNN_F_TILE_PLAN)",
@@ -660,6 +666,21 @@ def main():
                     e2 = int(b2.E.shape[0])
                     oc[name] = {"directed_edges": e2, "us": round(t2 * 1e3, 1), "M_edge_updates_per_s": round(e2 * (m2.depth - 1) / (t2 * 1e3), 1),
                                 "route": m2.__dict__.get("_dmpnn_route")}
+                    # its own roofline block (round-4 VERDICT item 2): SURVEY 8(d)'s forward flops against the f16 pipe's dense peak / 3
+                    # passes of the exact split, and — for the per-step routes, whose messages travel through HBM — the algorithmic bytes
+                    # of the whole forward (per depth step: read M, write M_next as split rows + the residual operand; K1 / finalize
+                    # operands; indices) against 8 TB/s.  Times are the WHOLE forward incl. K0 (the routes' kernels are not separated here:
+                    # profiles/ holds their kernel stats)
+                    v2, h2, dv2, de2, dp2 = int(b2.V.shape[0]), int(m2.W_h.weight.shape[0]), int(b2.V.shape[1]), int(b2.E.shape[1]), int(m2.depth)
+                    fl2 = 2.0 * e2 * (dv2 + de2) * h2 + 2.0 * e2 * h2 * h2 * (dp2 - 1) + 2.0 * v2 * (dv2 + h2) * h2
+                    row = 4 * h2 + 16
+                    by2 = (4.0 * (v2 * dv2 + e2 * de2) + 4.0 * v2 * h2 + 12.0 * e2 if str(oc[name]["route"]).startswith("mega") else
+                           4.0 * (v2 * dv2 + e2 * de2) + e2 * (4.0 * (dv2 + de2) + 16) * (dp2 if h2 <= 320 else 1) + (0 if h2 <= 320 else 4.0 * e2 * h2 * dp2)
+                           + 2.0 * e2 * row * (dp2 - 1) + 2.0 * v2 * row + 4.0 * v2 * (dv2 + h2) + 12.0 * e2 * dp2)
+                    oc[name]["roofline"] = {"flop": fl2, "TFLOP_per_s": round(fl2 / (t2 * 1e-3) / 1e12, 1), "peak_TFLOP_per_s": 833.3,
+                                            "frac_mfma": round(fl2 / (t2 * 1e-3) / 1e12 / 833.3, 4), "algorithmic_bytes": by2,
+                                            "GB_per_s": round(by2 / (t2 * 1e-3) / 1e9, 1), "frac_hbm": round(by2 / (t2 * 1e-3) / 8e12, 4),
+                                            "bound": "mfma" if str(oc[name]["route"]).startswith("mega") else "simd issue (MFMA + VALU epilogue), see DESIGN section 4"}
                     # the same forward with the OPT-IN half storage of the messages (DMPNN_F_STORE16: NOT fp32-class, ~1e-4
                     # relative; reported beside the exact figure, never instead of it)
                     os.environ["DMPNN_STORE"] = "f16"
@@ -831,7 +852,7 @@ def main():
                 if "M_edge_updates_per_s" in ts:
                     out["train_speedup_vs_cpu"] = round(ts["M_edge_updates_per_s"] / out["cpu_baseline_train"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

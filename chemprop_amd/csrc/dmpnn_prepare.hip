@@ -349,10 +349,13 @@ __device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLay
         if (p < np) {
             const int v = X[p], r0 = row_of(p);
             int q = p + 1;  // pieces p .. q-1 fit
+#if !defined(DMPNN_PACK_ROWS)
+#define DMPNN_PACK_ROWS kMegaBM    /* (experiment builds: a smaller packing target — more, smaller tiles for the same batch) */
+#endif
             if (X[q] - v > kMegaBA || row_of(q) - r0 > kMegaBM) {
                 atomicAdd(spill_s, 1);  // one piece alone exceeds a tile: a tile of its own, for the generic in-kernel path
             } else {
-                while (q < np && X[q + 1] - v <= kMegaBA && row_of(q + 1) - r0 <= kMegaBM) ++q;
+                while (q < np && X[q + 1] - v <= kMegaBA && row_of(q + 1) - r0 <= DMPNN_PACK_ROWS) ++q;
             }
             nx[j] = q;
         }

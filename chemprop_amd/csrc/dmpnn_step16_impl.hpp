@@ -86,15 +86,8 @@ struct Step16K {
     long long* dbg;                       // optional [16] cycle stamps of one workgroup (dmpnn_debug_timestamps), else null
 };
 
-#if defined(DMPNN_STEP16_XFIRST)
-// (experiment: the operand tile's LDS-DMA as a STATIC number of instructions per wave — those past the tile aim at 1 KiB of scratch —
-//  so that loads issued BEFORE it can be waited for with an exact vmcnt while the DMA is still in flight)
-template <int WN, int NW>
-__host__ __device__ constexpr size_t meta_bytes() { return (((size_t)(BM + kAtomCache + 1) * sizeof(int) + 64 + 15) & ~size_t(15)) + 1024; }
-#else
 template <int WN, int NW>
 __host__ __device__ constexpr size_t meta_bytes() { return (size_t)(BM + kAtomCache + 1) * sizeof(int) + 64; }
-#endif
 
 // HIN: the operand rows are in half storage ([hi 32 halfs] chunks; two MFMA passes a_hi (b_hi + b_lo) instead of three)
 // XP:  the second operand x is there (g.A2) and the fp32 residual is not (g.Cadd): separate instantiations, so that neither
@@ -132,57 +125,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     if (tid < 4) maxbits[tid] = 0u;
     const int TS = g.ts;
 
-#if defined(DMPNN_STEP16_XFIRST)
-    // (the per-column constants first: their loads sit in branches, and everything between the x path's loads and its first MFMA must
-    //  be straight-line code for the compiler to place an exact vmcnt there)
-    float isw[WN], isw2[WN], bv[WN];
-#pragma unroll
-    for (int ct = 0; ct < WN; ++ct) {
-        const int col = wave * (16 * WN) + ct * 16 + li;
-        const bool okc = col < g.N;
-        isw[ct] = g.A ? g.W.inv_scale[okc ? col : 0] : 1.f;
-        isw2[ct] = XP ? g.W2.inv_scale[okc ? col : 0] : 1.f;
-        bv[ct] = ((okc && g.bias) ? g.bias[col] : 0.f) + ((okc && g.bias2) ? g.bias2[col] : 0.f);
-    }
-#endif
     // ---- everything the tile needs is requested now: operand rows by LDS-DMA, residual into the accumulators ----
     const int TS2 = g.ts2;
+    // (DMPNN_STEP16_STAMPS2, DMPNN_STEP16_DIAG_*: measurement builds of round 5 — scripts/probe_stamps_step16b.py, scripts/gpu_r5_diag.sh;
+    //  what they found is in DESIGN.md section 4 "k_step16: where a tile's 31 k cycles go")
 #if defined(DMPNN_STEP16_STAMPS2)
     stamp();  // a: tile table read, nothing requested yet
 #endif
-    auto issue_dma = [&]() {
-#if defined(DMPNN_STEP16_XFIRST)
-        {   // (unconditional, a static number of instructions: the compiler then counts them as certainly issued when it places the
-            //  vmcnt of the loads requested before them; without an operand tile — K1 — every one of them is out of range)
-            const unsigned nbytes = g.A ? (unsigned)(nrows * TS) : 0u;
-            const rsrc_t rA = gemm::make_rsrc(g.A ? g.A + (long long)rs * TS : reinterpret_cast<const unsigned char*>(g.tile_row), nbytes);
-            const int n_inst = (int)((nbytes + 1023u) >> 10);
-            constexpr int kInst = (BM * (BN * 4 + 16) + 1023) / 1024, kPerWave = (kInst + NW - 1) / NW;
-            unsigned char* dummy = lds + g.tile_bytes + (((size_t)(BM + kAtomCache + 1) * sizeof(int) + 64 + 15) & ~size_t(15));
-#pragma unroll
-            for (int j = 0; j < kPerWave; ++j) {
-                const int i = wave + NW * j;
-                const bool ok = i < n_inst;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(ok ? Ag + i * 1024 : dummy), 16,
-                                                         ok ? (unsigned)(i * 1024 + lane * 16) : kOOB, 0, 0, 0);
-            }
-        }
-#else
-        if (g.A) {
-            const unsigned nbytes = (unsigned)(nrows * TS);
-            const rsrc_t rA = gemm::make_rsrc(g.A + (long long)rs * TS, nbytes);
-            const int n_inst = (int)((nbytes + 1023u) >> 10);
-            for (int i = wave; i < n_inst; i += NW)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(Ag + i * 1024), 16,
-                                                         (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
-        }
-#endif
-    };
-#if !defined(DMPNN_STEP16_XFIRST)
-    issue_dma();
-#endif
+    if (g.A) {
+        const unsigned nbytes = (unsigned)(nrows * TS);
+        const rsrc_t rA = gemm::make_rsrc(g.A + (long long)rs * TS, nbytes);
+        const int n_inst = (int)((nbytes + 1023u) >> 10);
+        for (int i = wave; i < n_inst; i += NW)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(Ag + i * 1024), 16,
+                                                     (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
+    }
 #if defined(DMPNN_STEP16_STAMPS2)
-    stamp();  // b: DMA issued (default order)
+    stamp();  // b: DMA issued
 #endif
     // second operand: this lane's A fragments (row rt * 16 + li, 8 reduction columns from lg * 8 of a chunk) of chunks 0 and 1,
     // and the rows' scales; chunk c + 2 is fetched into the registers of chunk c behind its MFMAs
@@ -253,19 +212,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     // (the first contraction's first two weight chunks: in flight under the DMA)
     if (XP) { load_bfrags(rW2, offB2, 0, bh[0], bl[0]); load_bfrags(rW2, offB2, 1, bh[1], bl[1]); }
     else load_bfrags(rW, offB, 0, bh[0], bl[0]);   // (chunk 0 of the main contraction: the ring takes it from there)
-#if defined(DMPNN_STEP16_XFIRST)
-    // the x path's first two chunks (operand fragments AND weights) were requested ahead of the operand tile's DMA: loads return in
-    // order per wave, so the x contraction's first two steps run while the DMA is still landing (behind it they waited for all of it)
-    __builtin_amdgcn_sched_barrier(0);   // (the scheduler sinks independent loads below the DMA otherwise: seen in the ISA)
-    issue_dma();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#if defined(DMPNN_STEP16_STAMPS2)
-    stamp();  // c: everything requested
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamp();  // d: everything requested has LANDED (measurement build only: the x contraction below then overlaps nothing)
-#endif
-#if !defined(DMPNN_STEP16_XFIRST)
     float isw[WN], isw2[WN], bv[WN];
 #pragma unroll
     for (int ct = 0; ct < WN; ++ct) {
@@ -275,6 +221,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         isw2[ct] = XP ? g.W2.inv_scale[okc ? col : 0] : 1.f;
         bv[ct] = ((okc && g.bias) ? g.bias[col] : 0.f) + ((okc && g.bias2) ? g.bias2[col] : 0.f);
     }
+#if defined(DMPNN_STEP16_STAMPS2)
+    stamp();  // c: everything requested
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();  // d: everything requested has LANDED (measurement build only: the x contraction below then overlaps nothing)
 #endif
     if constexpr (XP) {
         // z = W2 x first, in the scale s_r2 s_W2 of its own rows and columns (no LDS involved: runs while the DMA of the main operand is still landing;
@@ -291,17 +241,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
             __builtin_amdgcn_sched_barrier(0);
             if (c + 2 < g.W2.nc) { load_xfrags(c + 2, h, l); load_bfrags(rW2, offB2, c + 2, yh, yl); }
         };
-#if defined(DMPNN_STEP16_XFIRST)
-        // (the first two steps peeled out of the loop: at a loop header the compiler's one vmcnt serves the back edge as well — where only
-        //  the ten loads of the next chunk are younger than the data — and would wait for the operand tile's DMA on the way in)
-        if (g.W2.nc > 0) xstep(0, xh[0], xl[0], bh[0], bl[0]);
-        if (g.W2.nc > 1) xstep(1, xh[1], xl[1], bh[1], bl[1]);
-#pragma nounroll
-        for (int c = 2; c < g.W2.nc; c += 2) {
-            xstep(c, xh[0], xl[0], bh[0], bl[0]);
-            if (c + 1 < g.W2.nc) xstep(c + 1, xh[1], xl[1], bh[1], bl[1]);
-        }
-#else
+#if !defined(DMPNN_STEP16_DIAG_NOX)     // (timing diagnostic, WRONG numbers: no x contraction)
 #pragma nounroll
         for (int c = 0; c < g.W2.nc; c += 2) {
             xstep(c, xh[0], xl[0], bh[0], bl[0]);
@@ -344,7 +284,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
                     for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[rt], bh[0][ct], acc[rt][ct], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if defined(DMPNN_STEP16_DIAG_WSAME)   // (timing diagnostic, WRONG numbers: every weight fragment from the same 2 KiB — what does the weight stream cost?)
+                const unsigned o = more ? (unsigned)lane * 16u : kOOB;
+#else
                 const unsigned o = (more && off[ct] != kOOB) ? off[ct] + (unsigned)(c + 1) * 2048u : kOOB;
+#endif
                 bh[0][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rw, o, 0, 0));
                 bl[0][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rw, o == kOOB ? kOOB : o + 1024u, 0, 0));
                 if (ct == (WN > 1 ? WN - 2 : 0)) read_afrags(c + 1, nh, nl);
@@ -400,6 +344,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
     if (g.A) contract(std::integral_constant<bool, HIN>{}, Ag, TS, rW, offB, g.W.nc, !XP);
 
     stamp();  // 3 MFMA loop issued
+#if defined(DMPNN_STEP16_DIAG_NOEPI)   // (timing diagnostic, WRONG numbers: no epilogue — the accumulators are summed into one store per lane)
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) sum += acc[rt][ct][0] + acc[rt][ct][1] + acc[rt][ct][2] + acc[rt][ct][3];
+        if (g.Mout && nrows > 0) reinterpret_cast<float*>(g.Mout + (long long)rs * (g.half_out ? BN * 2 + 16 : TSO))[tid] = sum;
+        return;
+    }
+#endif
     // ---- epilogue: split domain -> fp32 (+ bias); [pre-activation rows out]; tau; tile -> segment sums -> message / Mv ----
     launder();
 #pragma unroll
