@@ -35,7 +35,7 @@ EXPORTS = [
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
     "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles", "dmpnn_forward_route", "dmpnn_dropout_keep",
-    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes", "dmpnn_train_route",
+    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes", "dmpnn_train_route", "dmpnn_forward_h0_bytes",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -94,6 +94,7 @@ class FwdArgs(C.Structure):
         ("msplit", C.c_void_p), ("msplit_bytes", C.c_size_t),
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("keep_bits", C.c_void_p), ("keep_bits_bytes", C.c_size_t),
+        ("h0_bytes", C.c_size_t),
     ]
 
 
@@ -265,7 +266,7 @@ def load() -> C.CDLL:
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     size_t_fns = ("dmpnn_plan_bytes", "dmpnn_backward_ws_bytes", "dmpnn_linear_wgrad_ws_bytes", "dmpnn_forward_wsplit_bytes", "dmpnn_forward_spill_bytes",
                   "dmpnn_forward_keep_bits_bytes",
-                  "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes", "dmpnn_head_ws_bytes", "dmpnn_clip_grad_ws_bytes")
+                  "dmpnn_molagg_ws_bytes", "dmpnn_linear16_wsplit_bytes", "dmpnn_head_ws_bytes", "dmpnn_clip_grad_ws_bytes", "dmpnn_forward_h0_bytes")
     lib.dmpnn_linear16_wsplit_bytes.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_linear16_ok.argtypes = [C.POINTER(GemmArgs)]
     lib.dmpnn_linear16_fwd.argtypes = [C.POINTER(GemmArgs), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -291,6 +292,7 @@ def load() -> C.CDLL:
     lib.dmpnn_forward_wsplit_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_forward_keep_bits_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_forward_spill_bytes.argtypes = [C.POINTER(FwdArgs)]
+    lib.dmpnn_forward_h0_bytes.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_forward_can_fuse16.argtypes = [C.POINTER(FwdArgs)]
     lib.dmpnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]

@@ -264,6 +264,8 @@ size_t dmpnn_forward_keep_bits_bytes(const dmpnn_fwd_args* a) {
     return (size_t)a->depth * (size_t)plan_layout(a->n_atoms, a->n_edges).max_mtiles * 256u * 8u;
 }
 
+size_t dmpnn_forward_h0_bytes(const dmpnn_fwd_args* a) { return a ? fused16_h0q_bytes(*a) : 0; }
+
 size_t dmpnn_forward_spill_bytes(const dmpnn_fwd_args* a) {
     if (!a || a->n_atoms < 0 || a->n_edges < 0 || a->ldh <= 0) return 0;
     return (size_t)(3 * a->n_edges + a->n_atoms) * (size_t)a->ldh * sizeof(float);

@@ -245,6 +245,7 @@ int launch_tiles_from_table_split(const int* tile_row, const int* tile_atom, int
 int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, int64_t nV, int64_t nE, int* plan, hipStream_t s,
                                int* mol_bounds = nullptr, int64_t n_mols = 0, const dmpnn_fwd_args* split_for = nullptr, bool* did_split = nullptr);
 bool mega16_split_args(const dmpnn_fwd_args& a, mega16::SplitArgs* sp);
+size_t fused16_h0q_bytes(const dmpnn_fwd_args& a);   // (dmpnn_step16.hip: H0 as row quads on the per-step fused route's inference forward)
 bool mega16_keeps_rows(const dmpnn_fwd_args& a);   // M^(t) kept as split rows in `msplit` (the product operands of k_wgrad16r)
 // dmpnn_prepare_tiles for a training step that also aggregates per molecule: *wrote_bounds says whether `mol_bounds` was filled
 // (the single-workgroup planner from the batch vector does it on the side; every other planner leaves it to dmpnn_molagg_bounds)

@@ -154,7 +154,7 @@ static step16::Step16K step_args(const dmpnn_fwd_args& a, const PlanLayout& L) {
 // then recomputed inside the step instead of read back (x_path_ok)
 static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, const SplitWView* Wi, const unsigned char* xrows,
                          const unsigned char* Min, unsigned char* Mout, float* Sout, unsigned char* SoutS, float* Hout, float* M32, hipStream_t s,
-                         unsigned char* bits = nullptr) {
+                         unsigned char* bits = nullptr, const float* h0q = nullptr) {
     step16::Step16K g = step_args(a, L);
     g.bits = bits; g.bstride = step16::block_cols((int)a.d_h) / 8;
     g.A = Min; g.ts = msg_row_bytes(a);
@@ -163,6 +163,8 @@ static int launch_update(const dmpnn_fwd_args& a, const PlanLayout& L, const Spl
     if (xrows) {
         g.A2 = xrows; g.ts2 = step16::split_operand_bytes((int)(a.d_v + a.d_e));
         g.W2.p = Wi->p; g.W2.inv_scale = Wi->inv_scale; g.W2.nc = Wi->nc; g.bias2 = a.b_i;
+    } else if (h0q) {
+        g.H0q_in = h0q;      // H0 as row quads (dmpnn_fwd_args.h0_bytes)
     } else {
         g.Cadd = a.H0; g.ldcadd = (int)a.ldh;
     }
@@ -185,7 +187,7 @@ static bool x_path_ok(const dmpnn_fwd_args& a) {
 // message slot, or — x path, keep_h0 false — the H0 buffer, where the rows stay for the depth steps and no H0 is written)
 static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const SplitWView& W, unsigned char* scratch, bool keep_h0,
                            unsigned char* Mout, float* Sout, float* M32, hipStream_t s, unsigned char* bits = nullptr,
-                           const mega16::SplitArgs** pending = nullptr) {
+                           const mega16::SplitArgs** pending = nullptr, float* h0q_out = nullptr) {
     const int* plan_i = static_cast<const int*>(a.plan);
     step16::SplitRowsK k;
     memset(&k, 0, sizeof(k));
@@ -208,6 +210,7 @@ static int launch_k1_split(const dmpnn_fwd_args& a, const PlanLayout& L, const S
     g.W.p = W.p; g.W.inv_scale = W.inv_scale; g.W.nc = W.nc;
     g.bias = a.b_i;
     if (keep_h0) { g.Zpre = a.H0; g.ldz = (int)a.ldh; }
+    g.H0q_out = h0q_out;
     g.Mout = Mout; g.Sout = Sout; g.half_out = half_store(a) ? 1 : 0;
     g.M32 = Mout ? M32 : nullptr; g.ldm32 = (int)a.ldh;
     g.bits = bits; g.bstride = step16::block_cols((int)a.d_h) / 8;
@@ -251,6 +254,23 @@ static int launch_fin16(const dmpnn_fwd_args& a, const PlanLayout& L, const Spli
     return launch_step(g, a.d_h, n_tiles, false, s);
 }
 
+static const int64_t kH0QuadsMaxEdges = 131072;
+// H0 as row quads (dmpnn_fwd_args.h0_bytes): bytes of the buffer — every tile owns ceil(nrows / 4) quads from ((first row + 3) >> 2) + tile on
+size_t fused16_h0q_bytes(const dmpnn_fwd_args& a) {
+    const unsigned need = DMPNN_F_FUSED | DMPNN_F_SPLIT16;
+    // (DMPNN_F_H0_RESIDUAL asks for H0 as fp32 ROWS in the buffer — what tests / diagnostics read back: not this form)
+    if ((a.flags & need) != need || (a.flags & (DMPNN_F_MEGA | DMPNN_F_KEEP | DMPNN_F_UNDIRECTED | DMPNN_F_ATOM | DMPNN_F_H0_RESIDUAL))) return 0;
+    if (a.depth < 2 || a.n_edges <= 0 || a.n_atoms <= 0 || !fused16_shapes_ok(a)) return 0;
+    // K1 runs on the step kernel over the split K1 operand, whose rows live in the second message slot meanwhile: they must fit there
+    if (step16::split_operand_bytes((int)(a.d_v + a.d_e)) > step16::split_row_bytes((int)a.d_h)) return 0;
+    // a SIZE rule (measured, profiles/r05_h0_quads_ab.txt): the quads cost 58 KB of reads per 48-row tile and step where the x path costs
+    // 19 KB + 135 MFMAs — 3-7 % faster at 20 k .. 44 k directed edges (BASELINE configs 2 / 3 at 512 molecules / 4), 1.4 % slower at 356 k
+    // (configs 3 at 4 096 molecules per GPU, where the launch runs at 2.8 TB/s already)
+    if (a.n_edges > kH0QuadsMaxEdges) return 0;
+    const PlanLayout L = plan_layout(a.n_atoms, a.n_edges);
+    return (size_t)(a.n_edges / 4 + L.max_tiles + 4) * (size_t)step16::block_cols((int)a.d_h) * 16u;
+}
+
 // a.Ms: two slots of n_edges split rows (split_row_floats(d_h) floats each); a.H0 [n_edges, ldh]; a.Mv [n_atoms, ldh];
 // w16: pre-split W_i | W_h | W_o (| W_d).  `out` / `ldout`: the finalize output (Hv when W_d follows).
 int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float* out, int64_t ldout, hipStream_t s,
@@ -258,7 +278,10 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
     const int64_t nV = a.n_atoms, nE = a.n_edges, h = a.d_h;
     const mega16::SplitArgs* pending = pending_in;
     // the weights' pre-split: in the first launch of the chain when that launch is k_split_rows (it does not read them), else now
-    const bool rides = nE > 0 && (fused16_lean(a) || (!(a.flags & DMPNN_F_KEEP) && x_path_ok(a)) || h > 320);
+    // H0 as row quads (ABI 12): an inference forward whose H0 buffer is large enough keeps the residual in the fragments' own layout
+    const size_t h0q_need = fused16_h0q_bytes(a);
+    const bool h0q = h0q_need > 0 && a.h0_bytes >= h0q_need && a.H0 && !(reinterpret_cast<uintptr_t>(a.H0) & 15u);
+    const bool rides = nE > 0 && (fused16_lean(a) || h0q || (!(a.flags & DMPNN_F_KEEP) && x_path_ok(a)) || h > 320);
     if (pending && !rides) { DMPNN_TRY(launch_split_args(*pending, s)); pending = nullptr; }
     const PlanLayout L = plan_layout(nV, nE);
     const int T = a.depth;
@@ -286,6 +309,18 @@ int launch_fused16_forward(const dmpnn_fwd_args& a, const SplitWView* w16, float
             DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], xrows, Mk + (size_t)(t - 1) * slot_bytes, last ? nullptr : Mk + (size_t)t * slot_bytes,
                                     last ? a.Mv : nullptr, nullptr, nullptr, nullptr, s, bits + (size_t)t * bslot));
         }
+    } else if (nE > 0 && h0q) {
+        // ---- inference with H0 kept as row quads: K1 on the step kernel over the split K1 operand (scratch: the second message slot,
+        // dead before update 1 writes there) leaves H0 in the fragments' layout; every update reads it back coalesced ----
+        float* H0q = a.H0;
+        DMPNN_TRY(launch_k1_split(a, L, w16[0], Ms + slot_bytes, false, Ms, nullptr, nullptr, s, nullptr, &pending, H0q));
+        for (int t = 1; t < T; ++t) {
+            const bool last = t == T - 1;
+            unsigned char* free_slot = Ms + (t % 2) * slot_bytes;
+            DMPNN_TRY(launch_update(a, L, w16[1], &w16[0], nullptr, Ms + ((t - 1) % 2) * slot_bytes, last ? nullptr : free_slot,
+                                    (last && !fin16) ? a.Mv : nullptr, (last && fin16) ? free_slot : nullptr, nullptr, nullptr, s, nullptr, H0q));
+        }
+        if (fin16) return launch_fin16(a, L, w16[4], w16[5], Ms + ((T - 1) % 2) * slot_bytes, out, ldout, s);
     } else if (nE > 0) {
         const bool xpath = !keep && x_path_ok(a);
         unsigned char* xrows = xpath ? reinterpret_cast<unsigned char*>(a.H0) : nullptr;

@@ -70,6 +70,11 @@ struct Step16K {
     const unsigned char* A2; int ts2;     // rows [M][ts2]
     SplitW W2; const float* bias2;
     float* Zpre; int ldz;                 // pre-activation rows [M][ldz] fp32 to store (K1: H0), or null
+    // round 5: H0 kept in the layout of the accumulator fragments — row QUADS [quad][BN columns][4 rows] fp32, the quads of tile t from
+    // ((first row + 3) >> 2) + t on (every tile's range is its own: ceil(nrows / 4) quads, at most one quad of padding per tile) —
+    // written by K1 straight from its registers (H0q_out), read back by every depth step as RT * WN coalesced 16-byte loads per lane
+    // (H0q_in: four 256-byte segments per wave instruction) instead of recomputing W_i x per step or gathering fp32 rows by the word
+    float* H0q_out; const float* H0q_in;
     unsigned char* Mout; float* Sout; int lds;
     unsigned char* SoutS;                 // the per-atom sums as split rows [V][TSO] instead of fp32 Sout (or null)
     int uniform;                          // 1: no tile table — tile t = rows 48 t .. (the finalize over atoms: no segments)
@@ -164,7 +169,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         s2 = (v2 > 0.f && v2 < 3.0e38f) ? v2 : 1.f;
     }
     f32x4 acc[RT][WN];
-    if (!XP && g.Cadd) {
+    if (!XP && g.H0q_in) {
+        const rsrc_t rQ = gemm::make_rsrc(g.H0q_in + ((long long)((rs + 3) >> 2) + t) * (BN * 4), (unsigned)(((nrows + 3) >> 2) * BN * 16));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) {   // (a quad past the tile's rows: out of range, zeros)
+                const unsigned off = (unsigned)((rt * 4 + lg) * (BN * 16) + (wave * (16 * WN) + ct * 16 + li) * 16);
+                acc[rt][ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, off, 0, 0));
+            }
+    } else if (!XP && g.Cadd) {
         const rsrc_t rC = gemm::make_rsrc(g.Cadd + (long long)rs * g.ldcadd, nrows > 0 ? (unsigned)(((nrows - 1) * g.ldcadd + g.N) * 4) : 0u);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) isw[ct] = isw2[ct];
     }
-    if (!XP && g.Cadd) {
+    if (!XP && (g.Cadd || g.H0q_in)) {
         // residual into the split domain of its row and column: acc = H0 s_r s_W (powers of two: exact)
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) {
@@ -364,6 +378,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * (isw[ct] / sr[rt][r]) + bv[ct];
     stamp();  // 4 unscaled
+    if (g.H0q_out) {  // (uniform; K1) the pre-activation H0 = W_i x + b_i leaves as row quads, straight from the fragments
+        float* qb = g.H0q_out + ((long long)((rs + 3) >> 2) + t) * (BN * 4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            if (rt * 16 + lg * 4 < nrows) {
+#pragma unroll
+                for (int ct = 0; ct < WN; ++ct)
+                    *reinterpret_cast<float4*>(qb + (rt * 4 + lg) * (BN * 4) + (wave * (16 * WN) + ct * 16 + li) * 4) =
+                        make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
+            }
+    }
     __syncthreads();  // every wave is done with the operand tile the epilogue tile overlays
     stamp();  // 5 all waves through the contraction
     // ReLU-class activations: a compare + select on the fragments.  tanh / ELU (and K1, whose pre-activation H0 leaves as

@@ -663,7 +663,22 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
     elif use_fused16:
         # H0 fp32 | two slots of split message rows (row = chunks of [hi | lo] halfs + a 16-byte tail with the row's scale)
         srf = int(lib.dmpnn_split_row_floats(d_h))
-        edge_ws = torch.empty((1, nE, ldh), dtype=torch.float32, device=dev)
+        # round 5: with a buffer of dmpnn_forward_h0_bytes() the route keeps H0 as ROW QUADS — the step kernel's accumulator-fragment
+        # layout, written by K1 from its registers, read back by every depth step with coalesced 16-byte loads — instead of recomputing
+        # W_i x in every step (d_h <= 320) or gathering fp32 rows word by word (d_h > 320): include/dmpnn.h, dmpnn_fwd_args.h0_bytes.
+        # DMPNN_H0=x keeps the forms of ABI <= 11 (A/B measurements)
+        h0_rows = nE
+        if _lib.opt("DMPNN_H0", "quads") != "x":
+            flags = a.flags
+            a.flags = (flags | F_FUSED | F_SPLIT16) & ~(F_MEGA | F_KEEP)   # (form bits stay: DMPNN_F_H0_RESIDUAL asks for fp32 rows)
+            try:
+                need = int(lib.dmpnn_forward_h0_bytes(C.byref(a)))
+            finally:
+                a.flags = flags
+            if need:
+                h0_rows = max(nE, (need // 4 + ldh - 1) // ldh)
+                a.h0_bytes = h0_rows * ldh * 4
+        edge_ws = torch.empty((1, h0_rows, ldh), dtype=torch.float32, device=dev)
         split_ms = torch.empty((2, nE, srf), dtype=torch.float32, device=dev)
         atom_ws = torch.empty((2, nV, ldh), dtype=torch.float32, device=dev)
         n_hslots, n_mslots = 0, 2

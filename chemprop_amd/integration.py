@@ -239,6 +239,13 @@ def _hip_adam_class():
     return HipAdam
 
 
+def _clip_algorithm(a) -> str:
+    """``"norm"`` / ``"value"`` from what Lightning holds (``None``: its default, norm; a ``GradClipAlgorithmType`` str-enum; a string)."""
+    if a is None:
+        return "norm"
+    return str(getattr(a, "value", a)).lower()
+
+
 def hip_mpnn_class():
     """Build (once) ``class HipMPNN(chemprop.models.MPNN)``: the reference's LightningModule whose ``training_step``
     (``models/model.py:148-161``) + optimizer step (``:208-231``) is ONE ``dmpnn_train_step`` call per batch — under Lightning's
@@ -362,7 +369,7 @@ def hip_mpnn_class():
             accumulate = int(getattr(tr, "accumulate_grad_batches", 1) or 1)
             if fused is not None and V_d is None and X_d is None and self.training and accumulate == 1:
                 try:
-                    clip = (getattr(tr, "gradient_clip_val", None), getattr(tr, "gradient_clip_algorithm", None) or "norm")
+                    clip = (getattr(tr, "gradient_clip_val", None), _clip_algorithm(getattr(tr, "gradient_clip_algorithm", None)))
                     g = opt.param_groups[0]
                     fl = st["opt"]
                     fl.betas, fl.eps, fl.weight_decay = (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"]), float(g["weight_decay"])
@@ -419,7 +426,7 @@ def hip_mpnn_class():
                 return super().configure_gradient_clipping(optimizer, gradient_clip_val=gradient_clip_val,
                                                            gradient_clip_algorithm=gradient_clip_algorithm)
             if gradient_clip_val is not None and float(gradient_clip_val) > 0:
-                st["opt"].clip_grad(float(gradient_clip_val), gradient_clip_algorithm or "norm")
+                st["opt"].clip_grad(float(gradient_clip_val), _clip_algorithm(gradient_clip_algorithm))
 
         # ---- device moves re-create the flat buffers: carry the moments over ----
         def _apply(self, fn, *args, **kwargs):

@@ -217,7 +217,7 @@ def mab_forward(mp, bmg, V_d: Optional[Tensor] = None, E_d: Optional[Tensor] = N
 
         act, slope, slope_t = classify_activation(mp.tau)
         has_vd = V_d is not None
-        shim = types.SimpleNamespace(undirected=mp.undirected, W_d=mp.W_vd if has_vd else None, tau=mp.tau, training=mp.training, dropout=mp.dropout,
+        shim = types.SimpleNamespace(undirected=mp.undirected, W_d=mp.W_vd if has_vd else None, tau=mp.tau, training=mp.training, dropout=mp.dropout, depth=mp.depth,
                                      W_i=mp.W_i, W_h=mp.W_h, W_o=mp.W_vo, _dmpnn_batches_checked=getattr(mp, "_dmpnn_batches_checked", 0),
                                      _dmpnn_no_mega=getattr(mp, "_dmpnn_no_mega", False))
         light = _training_plan_kind(shim, bmg)

@@ -46,7 +46,8 @@ extern "C" {
  * kept as split rows, every weight-gradient product of dmpnn_backward on split rows.
  * 12 — round 5: dmpnn_clip_grad / dmpnn_clip_grad_ws_bytes (Lightning's Trainer(gradient_clip_val), cli/train.py:1937, over the flat
  * gradient buffer) and dmpnn_step_args.clip_val / clip_mode / clip_ws (the clip between the backward pass and the update of ONE call); DMPNN_LOSS_BCE;
- * dmpnn_train_route (the training-plan / kept-form rule beside dmpnn_forward_route). */
+ * dmpnn_train_route (the training-plan / kept-form rule beside dmpnn_forward_route); dmpnn_fwd_args.h0_bytes + dmpnn_forward_h0_bytes
+ * (H0 kept as row quads on the per-step fused route's inference forward). */
 #define DMPNN_ABI_VERSION 12
 
 enum dmpnn_status {
@@ -355,10 +356,21 @@ typedef struct dmpnn_fwd_args {
      * every H^(t) as rows of block_cols(d_h) / 8 bytes per site (site 0: H0), `Mv` the fp32 per-atom sums; Hs / Ms are not used.
      * dmpnn_backward then runs the backward STEP kernels over the plan's tiles (csrc/dmpnn_bstep16.hip). */
     void* keep_bits; size_t keep_bits_bytes;
+    /* ABI 12, DMPNN_F_FUSED | DMPNN_F_SPLIT16 without DMPNN_F_KEEP (inference on the per-step fused route): the size of the buffer
+     * behind `H0`.  With >= dmpnn_forward_h0_bytes() bytes there the route keeps H0 = W_i x + b_i in the layout of the step kernel's
+     * accumulator fragments (row QUADS: [quad][column][4 rows], a tile's quads at ((first row + 3) >> 2) + tile index), written by K1
+     * straight from its registers and read back by every depth step as 15 coalesced 16-byte loads per lane — instead of recomputing it
+     * from the split K1 operand in every step (d_h <= 320: 135 MFMAs and ~140 KB of operand / weight fragments through the CU's L1
+     * path per 48-row tile) or reading fp32 rows through 48-60 scattered 4-byte loads per lane (d_h > 320).  0 (or too small): the
+     * forms of ABI <= 11. */
+    size_t h0_bytes;
 } dmpnn_fwd_args;
 size_t dmpnn_forward_wsplit_bytes(const dmpnn_fwd_args* a);
 /* bytes of `keep_bits` for this forward (0: the forward does not qualify — see the field) */
 size_t dmpnn_forward_keep_bits_bytes(const dmpnn_fwd_args* a);
+/* bytes of the `H0` buffer with which an inference forward of the per-step fused route on the f16 pipe keeps H0 as row quads
+ * (dmpnn_fwd_args.h0_bytes); 0: these shapes / flags do not take that form. */
+size_t dmpnn_forward_h0_bytes(const dmpnn_fwd_args* a);
 /* DMPNN_F_FUSED | DMPNN_F_SPLIT16 (without DMPNN_F_MEGA): the per-step fused route on the f16 matrix pipe — inference
  * forward of batches of ANY molecule size (d_h <= 640): one launch per depth step, the message tensor kept between the
  * steps as SPLIT rows (per row: chunks of [hi 32 halfs | lo 32 halfs] + a 16-byte tail with the row's power-of-two scale;

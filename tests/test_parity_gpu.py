@@ -303,6 +303,54 @@ def test_per_step_fused_route_on_the_f16_pipe(golden, gpu_device, monkeypatch):
         assert torch.equal(out, out2)          # deterministic (no atomics on the data path)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n_mols,kw", [("synth40", 96, dict()), ("zinc", 64, dict(d_h=512, depth=6)), ("cgr", 128, dict(d_v=106, d_e=28, bias=True)),
+                                             ("qm9", 300, dict(d_h=128, depth=4, activation="tanh"))])
+def test_h0_as_row_quads_on_the_per_step_fused_route(kind, n_mols, kw, gpu_device, monkeypatch):
+    """Round 5 (``dmpnn_fwd_args.h0_bytes``): an inference forward of the per-step fused route keeps H0 in the layout of the step
+    kernel's accumulator fragments (row quads, written by K1 from its registers, read back coalesced by every depth step) instead of
+    recomputing ``W_i x`` per step (d_h <= 320) or gathering fp32 rows word by word (d_h > 320).  Both forms against the oracle at the
+    1e-5 bar and against each other; tiles of every fill (partial last quads, tiles that start off a multiple of four rows); repeated
+    calls identical; beyond ``kH0QuadsMaxEdges`` the library declines the form (``dmpnn_forward_h0_bytes`` == 0)."""
+    import ctypes as C
+
+    from chemprop_amd import _lib, engine, synth
+    from chemprop_amd.nn import BondMessagePassing, classify_activation
+    from oracle import dmpnn_torch as ot
+
+    bmg = synth.random_batch(n_mols, kind, seed=11)
+    torch.manual_seed(4)
+    mp = BondMessagePassing(**kw).eval()
+    with torch.no_grad():
+        ref = ot.forward_bmg(bmg, ot.MPWeights.from_module(mp), depth=mp.depth, activation=kw.get("activation", "relu"))
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    act, slope, slope_t = classify_activation(mp.tau)
+    outs = {}
+    for mode in ("quads", "x"):
+        monkeypatch.setenv("DMPNN_H0", mode)
+        plan = engine.GraphPlan.from_bmg(bmg)
+        with torch.no_grad():
+            out, st = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, mp.W_i.bias, mp.W_h.bias,
+                                     depth=mp.depth, act=act, slope=slope, slope_t=slope_t, route="fused16")
+            out2, _ = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, mp.W_i.bias, mp.W_h.bias,
+                                     depth=mp.depth, act=act, slope=slope, slope_t=slope_t, route="fused16")
+        assert st.route == "fused16" and (int(st.args.h0_bytes) > 0) == (mode == "quads")
+        assert torch.equal(out, out2)
+        assert parity_err(out.cpu().numpy(), ref.numpy()) <= TOL, mode
+        outs[mode] = out
+    assert parity_err(outs["quads"].cpu().numpy(), outs["x"].cpu().numpy()) <= 3e-6
+    # the size rule is the library's
+    a = _lib.FwdArgs.from_buffer_copy(bytes(st.args))
+    a.flags = (a.flags | _lib.F_FUSED | _lib.F_SPLIT16) & ~(_lib.F_MEGA | _lib.F_KEEP)
+    lib = _lib.load()
+    assert lib.dmpnn_forward_h0_bytes(C.byref(a)) > 0
+    a.n_edges = 200000
+    assert lib.dmpnn_forward_h0_bytes(C.byref(a)) == 0
+    a.n_edges, a.flags = int(bmg.E.shape[0]), a.flags | _lib.F_H0_RESIDUAL
+    assert lib.dmpnn_forward_h0_bytes(C.byref(a)) == 0
+
+
 HALF_TOL = 2e-3  # DMPNN_F_STORE16: one rounding of every message element to an 11-bit significand per depth step (stated in include/dmpnn.h)
 
 
