@@ -45,6 +45,15 @@ using mega16::SplitW;
 
 constexpr int RT = 3;
 static_assert(BM == 16 * RT, "48-row tiles");
+
+// 1 / s for a power of two s (every scale of the split format is one: scale_for, k_split_weights) — EXACT, one integer subtraction.
+// (round 5: the epilogue formed acc * (isw / s_r) per element: 60 IEEE divisions of ~10 VALU instructions each per lane and tile — a
+//  third of the kernel's VALU instructions, found in the instruction histogram of the ISA)
+#if defined(DMPNN_STEP16_IEEE_DIV)   // (A/B build: the divisions as rounds 2-4 had them)
+__device__ __forceinline__ float rcp_pow2(float s) { return 1.f / s; }
+#else
+__device__ __forceinline__ float rcp_pow2(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }
+#endif
 constexpr int kXChunks = 8;  // most chunks (of 32 columns) of the second operand: d_v + d_e <= 256
 
 // output columns a workgroup covers for d_h: 4 waves x 16 WN (d_h <= 320) or 8 waves x 16 WN (d_h <= 640)
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         load_xfrags(0, xh[0], xl[0]);
         load_xfrags(1, xh[1], xl[1]);
         const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, nrows > 0 ? (unsigned)(TS2 - 16) : kOOB, 0, 0));
-        s2 = (v2 > 0.f && v2 < 3.0e38f) ? v2 : 1.f;
+        s2 = (v2 > 0.f && v2 < 3.0e38f && (__float_as_uint(v2) & 0x007FFFFFu) == 0u) ? v2 : 1.f;
     }
     f32x4 acc[RT][WN];
     if (!XP && g.H0q_in) {
@@ -319,25 +328,27 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         }
     };
     // the rows' own scales (tail of every operand row of the main operand; K1 without one: the scales of x); rows beyond the tile: 1
-    float sr[RT][4];
+    float sr[RT][4], isr[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + lg * 4 + r;
             const float v = g.A ? *reinterpret_cast<const float*>(Ag + row * TS + (TS - 16)) : s2;
-            sr[rt][r] = (row < nrows && v > 0.f && v < 3.0e38f) ? v : 1.f;
+            // (a scale is a power of two by the format's contract; anything else — a corrupted tail — counts as 1)
+            sr[rt][r] = (row < nrows && v > 0.f && v < 3.0e38f && (__float_as_uint(v) & 0x007FFFFFu) == 0u) ? v : 1.f;
+            isr[rt][r] = rcp_pow2(sr[rt][r]);
         }
     if (XP && g.A) {
         // ... then into the scale of the main operand (exact: powers of two)
-        const float is2 = 1.f / s2;
+        const float is2 = rcp_pow2(s2);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float f = sr[rt][r] * is2;
 #pragma unroll
-                for (int ct = 0; ct < WN; ++ct) acc[rt][ct][r] *= f * (isw2[ct] / isw[ct]);
+                for (int ct = 0; ct < WN; ++ct) acc[rt][ct][r] *= f * (isw2[ct] * rcp_pow2(isw[ct]));
             }
     }
     if (XP && !g.A) {  // (K1: the scale of x IS the final one)
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
         // residual into the split domain of its row and column: acc = H0 s_r s_W (powers of two: exact)
 #pragma unroll
         for (int ct = 0; ct < WN; ++ct) {
-            const float sw = 1.f / isw[ct];
+            const float sw = rcp_pow2(isw[ct]);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -376,7 +387,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_step16(Step16K g) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
+#if defined(DMPNN_STEP16_IEEE_DIV)
             for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * (isw[ct] / sr[rt][r]) + bv[ct];
+#else
+            for (int r = 0; r < 4; ++r) acc[rt][ct][r] = acc[rt][ct][r] * (isw[ct] * isr[rt][r]) + bv[ct];
+#endif
     stamp();  // 4 unscaled
     if (g.H0q_out) {  // (uniform; K1) the pre-activation H0 = W_i x + b_i leaves as row quads, straight from the fragments
         float* qb = g.H0q_out + ((long long)((rs + 3) >> 2) + t) * (BN * 4);
