@@ -109,7 +109,7 @@ class BwdArgs(C.Structure):
 
 
 MAX_FFN_LAYERS = 8
-LOSS = {"mse": 0, "mae": 1, "bce": 2}
+LOSS = {"mse": 0, "mae": 1, "bce": 2, "ce": 3}
 STEP_FORWARD, STEP_BACKWARD, STEP_UPDATE = 1, 2, 4
 
 
@@ -129,6 +129,7 @@ class HeadArgs(C.Structure):
         ("gHv", C.c_void_p), ("ldg", C.c_int64),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("bn_num_batches_tracked", C.c_void_p),
+        ("n_classes", C.c_int32),
     ]
 
 

@@ -191,6 +191,7 @@ struct LossArgs {
     const unsigned char* lt; const unsigned char* gt;
     float* gP; int64_t ldg; float* out;   // out[0] = loss, out[1] = number of finite targets
     int64_t B; int t; int kind;
+    int nc;                               // DMPNN_LOSS_CE: classes per task — P / gP rows hold t * nc logits, T the class index of every task
 };
 __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
     __shared__ float red[2][16];
@@ -202,6 +203,18 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
         const float y = a.T[r * a.ldt + j];
         const bool m = isfinite(y);
         if (!m) continue;
+        if (a.kind == DMPNN_LOSS_CE) {   // (uniform) F.cross_entropy over the task's nc logits: logsumexp - x[class]   (metrics.py:298-304)
+            const float* x = a.P + r * a.ldp + (int64_t)j * a.nc;
+            float mx = x[0];
+            for (int k = 1; k < a.nc; ++k) mx = fmaxf(mx, x[k]);
+            float se = 0.f;
+            for (int k = 0; k < a.nc; ++k) se += expf(x[k] - mx);
+            const int cls = (int)y;
+            const float L = (mx + logf(se)) - x[(cls >= 0 && cls < a.nc) ? cls : 0];
+            sl += ((cls >= 0 && cls < a.nc) ? L : __int_as_float(0x7fc00000)) * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f);
+            sm += 1.f;
+            continue;
+        }
         float p = a.P[r * a.ldp + j];
         if ((a.lt && a.lt[r * a.t + j] && p < y) || (a.gt && a.gt[r * a.t + j] && p > y)) p = y;
         const float L = loss_value(a.kind, p, y);
@@ -224,6 +237,22 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
     for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const int64_t r = i / a.t; const int j = (int)(i - r * a.t);
         const float y = a.T[r * a.ldt + j];
+        if (a.kind == DMPNN_LOSS_CE) {   // (uniform) dL/dx_k = softmax_k - [k == class]
+            const float* x = a.P + r * a.ldp + (int64_t)j * a.nc;
+            float* gx = a.gP + r * a.ldg + (int64_t)j * a.nc;
+            if (!isfinite(y)) {
+                for (int k = 0; k < a.nc; ++k) gx[k] = 0.f;
+                continue;
+            }
+            float mx = x[0];
+            for (int k = 1; k < a.nc; ++k) mx = fmaxf(mx, x[k]);
+            float se = 0.f;
+            for (int k = 0; k < a.nc; ++k) se += expf(x[k] - mx);
+            const float f = (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f) * inv, ise = 1.f / se;
+            const int cls = (int)y;
+            for (int k = 0; k < a.nc; ++k) gx[k] = (expf(x[k] - mx) * ise - (k == cls ? 1.f : 0.f)) * f;
+            continue;
+        }
         float g = 0.f;
         if (isfinite(y)) {
             float p = a.P[r * a.ldp + j];
@@ -480,8 +509,9 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     DMPNN_CHECK_ARG(Ln >= 1 && Ln <= DMPNN_MAX_FFN_LAYERS && h.dims[0] == d, "head: 1..%d predictor layers, dims[0] == d_h", DMPNN_MAX_FFN_LAYERS);
     for (int l = 0; l < Ln; ++l) DMPNN_CHECK_ARG(h.W[l] && h.dims[l + 1] > 0, "head: layer %d has no weight / width", l);
     DMPNN_CHECK_ARG(h.act >= DMPNN_ACT_NONE && h.act <= DMPNN_ACT_ELU && h.act != DMPNN_ACT_PRELU, "head: activation %d is not built in", h.act);
-    DMPNN_CHECK_ARG(h.loss == DMPNN_LOSS_MSE || h.loss == DMPNN_LOSS_MAE || h.loss == DMPNN_LOSS_BCE, "head: unknown criterion %d", h.loss);
-    DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_BCE || (!h.lt_mask && !h.gt_mask), "head: the BCE criterion has no bounds (lt_mask / gt_mask)");
+    DMPNN_CHECK_ARG(h.loss == DMPNN_LOSS_MSE || h.loss == DMPNN_LOSS_MAE || h.loss == DMPNN_LOSS_BCE || h.loss == DMPNN_LOSS_CE, "head: unknown criterion %d", h.loss);
+    DMPNN_CHECK_ARG((h.loss != DMPNN_LOSS_BCE && h.loss != DMPNN_LOSS_CE) || (!h.lt_mask && !h.gt_mask), "head: the BCE / CE criteria have no bounds (lt_mask / gt_mask)");
+    DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_CE || (h.n_classes >= 2 && h.dims[Ln] % h.n_classes == 0), "head: cross entropy needs n_classes >= 2 dividing the output width");
     DMPNN_CHECK_ARG(h.preds && (nV == 0 || (Hv && h.batch)), "head: null H_v / batch / preds");
     DMPNN_CHECK_ARG(!h.bn_weight || (h.bn_running_mean && h.bn_running_var), "head: batch norm without running statistics");
     // (torch.nn.BatchNorm1d in training mode — hence the reference — raises "Expected more than 1 value per channel": a batch of one
@@ -498,7 +528,9 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     if (B == 0) return DMPNN_OK;
     unsigned char* ws = static_cast<unsigned char*>(h.ws);
     float* Hm = reinterpret_cast<float*>(ws + L.Hm);
-    const int t = (int)h.dims[Ln];
+    const int t_out = (int)h.dims[Ln];                                  // width of the output layer
+    const int nc = h.loss == DMPNN_LOSS_CE ? h.n_classes : 1;           // logits per task
+    const int t = t_out / nc;                                           // tasks (= columns of `targets`)
 
     // ---- forward ----
     if (!bounds_done) DMPNN_TRY(dmpnn_molagg_bounds(h.batch, nV, B, ws + L.bounds, dmpnn_molagg_ws_bytes(B), stream));
@@ -518,7 +550,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     A[0] = Z;
     const bool small_out = h.dims[Ln] <= kOutMaxTasks && Ln >= 1;   // the output layer as dot products (k_out_fwd / k_out_bwd)
     // training on a short batch: the criterion and the output layer's backward are ONE launch further down (k_out_all)
-    const bool out_all = small_out && want_grad && h.targets && B <= kOutAllMaxRows;
+    const bool out_all = small_out && want_grad && h.targets && B <= kOutAllMaxRows && nc == 1;
     for (int l = 0; l < Ln; ++l) {
         if (small_out && l == Ln - 1) {
             OutFwdArgs q{A[l], h.dims[l], h.W[l], h.b[l], h.preds, B, (int)h.dims[l], (int)h.dims[Ln]};
@@ -542,7 +574,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     if (!h.targets) return DMPNN_OK;
     float* gP = reinterpret_cast<float*>(ws + L.gP);
     if (!out_all) {
-        LossArgs q{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, want_grad ? gP : nullptr, t, h.loss_out, B, t, h.loss};
+        LossArgs q{h.preds, t_out, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, want_grad ? gP : nullptr, t_out, h.loss_out, B, t, h.loss, nc};
         DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
         hipLaunchKernelGGL(k_loss, dim3(1), dim3(1024), 0, s, q);
         DMPNN_CHECK_LAUNCH("k_loss");
@@ -562,7 +594,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
             OutBwdArgs q{g_cur, A[l], K, h.W[l], out, K, h.gW[l], h.b[l] ? h.gb[l] : nullptr, B, (int)K, (int)N, l > 0 ? h.act : DMPNN_ACT_NONE, h.act_slope};
             if (out_all) {
                 DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
-                OutAllArgs qa{q, LossArgs{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, nullptr, t, h.loss_out, B, t, h.loss}};
+                OutAllArgs qa{q, LossArgs{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, nullptr, t, h.loss_out, B, t, h.loss, 1}};
                 qa.o.gP = nullptr;
                 hipLaunchKernelGGL(k_out_all, dim3((unsigned)((K + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, qa);
                 DMPNN_CHECK_LAUNCH("k_out_all");

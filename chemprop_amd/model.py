@@ -28,7 +28,7 @@ from .ffn import MLP
 from .nn import BondMessagePassing, classify_activation
 from .optim import FlatAdam
 
-__all__ = ["MSE", "MAE", "BCE", "RegressionFFN", "BinaryClassificationFFN", "MPNN", "FusedTrainer", "masked_loss"]
+__all__ = ["MSE", "MAE", "BCE", "CE", "RegressionFFN", "BinaryClassificationFFN", "MulticlassClassificationFFN", "MPNN", "FusedTrainer", "masked_loss"]
 
 
 def masked_loss(preds: Tensor, targets: Tensor, weights: Optional[Tensor] = None, task_weights: Optional[Tensor] = None,
@@ -37,8 +37,13 @@ def masked_loss(preds: Tensor, targets: Tensor, weights: Optional[Tensor] = None
     ``MPNN.training_step`` (``models/model.py:152-156``): torch ops, differentiable — the module path's criterion."""
     mask = targets.isfinite()
     targets = targets.nan_to_num(nan=0.0)
-    if kind == "bce":
-        lt_mask = gt_mask = None     # (BCELoss is not a bounded criterion: metrics.py:292-295)
+    if kind in ("bce", "ce"):
+        lt_mask = gt_mask = None     # (BCELoss / CrossEntropyLoss are not bounded criteria: metrics.py:292-304)
+    if kind == "ce":                 # preds [b, t, c] logits, targets [b, t] class indices (metrics.py:298-304)
+        L = torch.nn.functional.cross_entropy(preds.transpose(1, 2), targets.long(), reduction="none")
+        w = torch.ones(targets.shape[0], dtype=torch.float, device=targets.device) if weights is None else weights
+        tw = 1.0 if task_weights is None else task_weights.view(1, -1)
+        return (L * w.view(-1, 1) * tw * mask).sum() / mask.sum()
     if lt_mask is not None:
         preds = torch.where((preds < targets) & lt_mask, targets, preds)
     if gt_mask is not None:
@@ -111,6 +116,36 @@ class RegressionFFN(nn.Module):
         return self.output_transform(self.ffn(Z))
 
     train_step = forward
+
+
+class CE(MSE):
+    """``chemprop.nn.metrics.CrossEntropyLoss`` (``metrics.py:298-304``): ``preds [b, t, c]`` logits against class indices; no bounds."""
+
+    kind = "ce"
+
+    def forward(self, preds, targets, mask=None, weights=None, lt_mask=None, gt_mask=None):
+        return super().forward(preds, targets, mask, weights, None, None)
+
+
+class MulticlassClassificationFFN(RegressionFFN):
+    """``chemprop.nn.predictors.MulticlassClassificationFFN`` (``predictors.py:271-314``): an MLP ``n_tasks * n_classes`` wide;
+    ``forward`` predicts class probabilities ``[b, t, c]`` (softmax), ``train_step`` hands the logits ``[b, t, c]`` to ``CrossEntropyLoss``."""
+
+    def __init__(self, n_classes: int, n_tasks: int = 1, input_dim: int = 300, hidden_dim: int = 300, n_layers: int = 1, dropout: float = 0.0,
+                 activation="relu", criterion: Optional[nn.Module] = None, task_weights: Optional[Tensor] = None):
+        super().__init__(n_tasks * n_classes, input_dim, hidden_dim, n_layers, dropout, activation,
+                         criterion if criterion is not None else CE(torch.ones(n_tasks) if task_weights is None else task_weights))
+        self.n_classes = n_classes
+
+    @property
+    def n_tasks(self) -> int:
+        return self.output_dim // (self.n_targets * self.n_classes)
+
+    def forward(self, Z: Tensor) -> Tensor:
+        return self.ffn(Z).reshape(Z.shape[0], -1, self.n_classes).softmax(-1)
+
+    def train_step(self, Z: Tensor) -> Tensor:
+        return self.ffn(Z).reshape(Z.shape[0], -1, self.n_classes)
 
 
 class BinaryClassificationFFN(RegressionFFN):
@@ -189,12 +224,14 @@ def criterion_kind(crit) -> tuple[Optional[str], bool]:
     (``nn/metrics.py:139-150``), ``BoundedMSE`` / ``BoundedMAE`` apply them (``:158-177``); RMSE, MVE, ... are not built in."""
     kind = getattr(crit, "kind", None)
     if kind in _lib.LOSS:
-        return kind, kind != "bce"
+        return kind, kind not in ("bce", "ce")
     names = _mro_names(crit)
     if "RMSE" in names:
         return None, False
     if "BCELoss" in names:       # nn/metrics.py:292-295 (binary classification: chemprop's second task type)
         return "bce", False
+    if "CrossEntropyLoss" in names:   # nn/metrics.py:298-304 (multiclass: logits [b, t, c] against class indices)
+        return "ce", False
     for cls, k in (("MSE", "mse"), ("MAE", "mae")):
         if cls in names:
             return k, "BoundedMixin" in names
@@ -228,7 +265,14 @@ class HeadSpec:
             raise NotImplementedError("one value per task (regression); MVE / evidential / quantile heads train through torch ops")
         kind, self.bounded = criterion_kind(pred.criterion)
         if kind is None:
-            raise NotImplementedError("MSE / MAE criterion (bounded or not) or BCE")
+            raise NotImplementedError("MSE / MAE criterion (bounded or not), BCE or cross entropy")
+        # multiclass (predictors.py:271-314): the output layer holds n_classes logits per task, the criterion is the cross entropy
+        # over them — every other pairing of a class dimension and a criterion (Dirichlet heads, ...) trains through torch ops
+        self.n_classes = int(getattr(pred, "n_classes", 0) or 0)
+        if (kind == "ce") != (self.n_classes >= 2):
+            raise NotImplementedError("a multiclass predictor (n_classes >= 2) with CrossEntropyLoss, or neither")
+        if kind == "ce" and int(blocks[-1][-1].out_features) % self.n_classes:
+            raise NotImplementedError("the output width must be n_tasks * n_classes")
         self.agg_mode, self.agg_norm = MODES[mode], float(getattr(agg, "norm", 1.0))
         self.f_act, self.f_slope, self.kind = f_act, f_slope, kind
         self.layers = [b[-1] for b in blocks]
@@ -238,8 +282,14 @@ class HeadSpec:
         self.criterion = pred.criterion
 
     @property
-    def n_tasks(self) -> int:
+    def n_out(self) -> int:
+        """Width of the output layer (= columns of the predictions the kernels write)."""
         return int(self.layers[-1].out_features)
+
+    @property
+    def n_tasks(self) -> int:
+        """Columns of ``targets``: the output width, or — multiclass — that over ``n_classes``."""
+        return self.n_out // self.n_classes if self.n_classes >= 2 else self.n_out
 
     def params(self) -> list:
         """The head's parameters in the order ``fill`` asks ``gptr`` about them."""
@@ -273,6 +323,7 @@ class HeadSpec:
             h.dims[l + 1] = lin.out_features
             h.gW[l], h.gb[l] = gptr(lin.weight), gptr(lin.bias)
         h.loss = _lib.LOSS[self.kind]
+        h.n_classes = self.n_classes
         h.targets = T.data_ptr()
         keep = []
         if weights is not None:
@@ -319,7 +370,7 @@ class _HeadLoss(torch.autograd.Function):
         h = _lib.HeadArgs()
         keep = spec.fill(h, nV, n_mols, d_out, batch, T, weights, lt_mask, gt_mask,
                          lambda p: None if (p is None or id(p) not in want) else ptr[id(p)], bn_training=spec.bn is None or spec.bn.training)
-        preds = torch.empty(n_mols, spec.n_tasks, dtype=torch.float32, device=dev)
+        preds = torch.empty(n_mols, spec.n_out, dtype=torch.float32, device=dev)
         loss = torch.empty(2, dtype=torch.float32, device=dev)
         h.preds, h.loss_out = preds.data_ptr(), loss.data_ptr()
         h.gHv, h.ldg = gH.data_ptr(), d_out
@@ -453,7 +504,7 @@ class FusedTrainer:
         batch = bmg.batch
         n_mols = len(bmg)
         nV, nE = int(bmg.V.shape[0]), int(bmg.E.shape[0])
-        n_tasks = int(self.layers[-1].out_features)
+        n_tasks = self.head.n_tasks
         T = engine._f32c(targets, "targets")
         if T.dim() != 2 or T.shape[0] != n_mols or T.shape[1] != n_tasks or not T.is_contiguous():
             raise ValueError(f"targets must be a contiguous [{n_mols}, {n_tasks}] matrix, got {tuple(targets.shape)}")

@@ -566,7 +566,10 @@ int dmpnn_clip_grad(float* g, int64_t n, float clip_val, int32_t mode, float gra
  * ------------------------------------------------------------------------------------------- */
 #define DMPNN_MAX_FFN_LAYERS 8
 enum dmpnn_loss { DMPNN_LOSS_MSE = 0, DMPNN_LOSS_MAE = 1,
-                  DMPNN_LOSS_BCE = 2 /* v12: binary cross entropy with logits (nn/metrics.py:292-295; predictors.py:235-247) */ };
+                  DMPNN_LOSS_BCE = 2, /* v12: binary cross entropy with logits (nn/metrics.py:292-295; predictors.py:235-247) */
+                  DMPNN_LOSS_CE = 3   /* v12: cross entropy over dmpnn_head_args.n_classes logits per task (nn/metrics.py:298-304;
+                                         MulticlassClassificationFFN.train_step, predictors.py:271-314): the output layer is
+                                         [n_tasks * n_classes] wide, `targets` holds class indices as floats */ };
 typedef struct dmpnn_head_args {
     int64_t n_atoms, n_mols, d_h;           /* rows of H_v, molecules, width of H_v                              */
     const int64_t* batch;                   /* [n_atoms] molecule of every atom, non-decreasing (BatchMolGraph.batch) */
@@ -590,6 +593,7 @@ typedef struct dmpnn_head_args {
     float* gHv; int64_t ldg;                /* out [n_atoms, ldg] dloss / dH_v; NULL: forward (and loss) only       */
     void* ws; size_t ws_bytes;              /* caller-owned scratch, >= dmpnn_head_ws_bytes()                       */
     int64_t* bn_num_batches_tracked;        /* nn.BatchNorm1d's counter: += 1 on device when bn_training (NULL: not kept) — v9 */
+    int32_t n_classes;                      /* v12, DMPNN_LOSS_CE: classes per task (>= 2); the last layer's width is n_tasks * n_classes */
 } dmpnn_head_args;
 size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h);
 int dmpnn_head(const dmpnn_head_args* h, const float* Hv, int64_t ldhv, void* stream);

@@ -29,7 +29,9 @@ def criterion(preds: Tensor, targets: Tensor, weights: Optional[Tensor], task_we
     if kind.startswith("bounded"):  # metrics.py:157-161
         preds = torch.where((preds < targets) & lt_mask, targets, preds)
         preds = torch.where((preds > targets) & gt_mask, targets, preds)
-    if kind == "bce":       # metrics.py:292-295 on the raw logits of BinaryClassificationFFN.train_step (predictors.py:246-247)
+    if kind == "ce":        # metrics.py:298-304 on the logits [b, t, c] of MulticlassClassificationFFN.train_step (predictors.py:313-314)
+        L = F.cross_entropy(preds.transpose(1, 2), targets.long(), reduction="none")
+    elif kind == "bce":     # metrics.py:292-295 on the raw logits of BinaryClassificationFFN.train_step (predictors.py:246-247)
         L = F.binary_cross_entropy_with_logits(preds, targets, reduction="none")
     else:
         L = (preds - targets).abs() if kind.endswith("mae") else F.mse_loss(preds, targets, reduction="none")
@@ -75,7 +77,10 @@ class Model:
             ws.append(p[f"predictor.ffn.{i}.{j}.weight"])
             bs.append(p[f"predictor.ffn.{i}.{j}.bias"])
             i += 1
-        return ffn_torch.mlp_forward(H, ws, bs, cfg["ffn"].get("activation", "relu"))                           # predictors.py:166-169
+        P = ffn_torch.mlp_forward(H, ws, bs, cfg["ffn"].get("activation", "relu"))                              # predictors.py:166-169
+        if cfg.get("predictor") == "multiclass":                                                                  # predictors.py:313-314
+            P = P.reshape(P.shape[0], -1, cfg["ffn"]["n_classes"])
+        return P
 
     def loss(self, bmg, targets, weights, lt_mask, gt_mask) -> Tensor:
         return criterion(self.forward(bmg), targets, weights, self.buf.get("predictor.criterion.task_weights"), lt_mask, gt_mask,

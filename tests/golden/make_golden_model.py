@@ -42,6 +42,10 @@ CASES = {
     "qm9_bce_classification": dict(n=20, kind="qm9", mp=dict(d_h=48), agg="mean", bn=True, predictor="classification",
                                    ffn=dict(n_tasks=3, hidden_dim=32), criterion="bce", task_weights=[1.0, 0.5, 2.0], nan=0.15, weights=True,
                                    seed=96),
+    # multiclass (predictors.py:271-314, metrics.py:298-304): 3 classes x 2 tasks, class indices with missing entries
+    "qm9_ce_multiclass": dict(n=18, kind="qm9", mp=dict(d_h=40), agg="norm", bn=False, predictor="multiclass",
+                              ffn=dict(n_tasks=2, n_classes=3, hidden_dim=24), criterion="ce", task_weights=[1.0, 0.7], nan=0.15, weights=True,
+                              seed=97),
     # (the CLI's default widths — d_h 300, hidden 300 — are checked at size on the GPU against the restatement these cases pin and
     #  against the staged reference executed live: tests/test_model.py)
 }
@@ -57,9 +61,9 @@ def build(R, cfg):
     tw = cfg.get("task_weights")
     kind = cfg.get("criterion", "mse")
     if kind != "mse" or tw is not None:
-        cls = {"mse": cnn.MSE, "mae": cnn.MAE, "bounded-mse": cnn.BoundedMSE, "bce": cnn.BCELoss}[kind]
+        cls = {"mse": cnn.MSE, "mae": cnn.MAE, "bounded-mse": cnn.BoundedMSE, "bce": cnn.BCELoss, "ce": cnn.CrossEntropyLoss}[kind]
         crit = cls(task_weights=tw if tw is not None else 1.0)
-    FFN = cnn.BinaryClassificationFFN if cfg.get("predictor") == "classification" else cnn.RegressionFFN
+    FFN = {"classification": cnn.BinaryClassificationFFN, "multiclass": cnn.MulticlassClassificationFFN}.get(cfg.get("predictor"), cnn.RegressionFFN)
     pred = FFN(input_dim=mp.output_dim, criterion=crit, **cfg["ffn"])
     return MPNN(mp, agg, pred, batch_norm=cfg["bn"])
 
@@ -80,6 +84,8 @@ def main():
         targets = torch.randn(cfg["n"], t, generator=gen)
         if cfg.get("predictor") == "classification":
             targets = (targets > 0.3).float()
+        if cfg.get("predictor") == "multiclass":
+            targets = torch.randint(0, cfg["ffn"]["n_classes"], (cfg["n"], t), generator=gen).float()
         if cfg.get("nan"):
             drop = torch.rand(cfg["n"], t, generator=gen) < cfg["nan"]
             drop[0, 0] = False
