@@ -181,6 +181,8 @@ def _hip_adam_class():
                 with torch.enable_grad():
                     loss = closure()     # (Lightning, automatic optimization: training_step -> zero_grad -> backward -> clipping)
             m = self._module()
+            if m is None:
+                raise RuntimeError("HipAdam: the module it optimises is gone")
             if m.__dict__.pop("_hip_applied", False):
                 return loss              # the fused call of this closure already held the backward pass, the clip AND this update
             st = self._st()
