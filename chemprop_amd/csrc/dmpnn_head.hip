@@ -13,8 +13,10 @@
 // one loss kernel that also emits dl/dP; backward: per layer one weight-gradient product (+ reduce), one transposed
 // contraction with the activation derivative fused into a small elementwise pass, one batch-norm kernel, one gather.
 #include "dmpnn_common.hpp"
+#include "dmpnn_mega16_impl.hpp"   // (mega16::SplitArgs / split_weights_wave / SplitW / scale_for / split4: the predictor's first layer on the f16 pipe)
 
 namespace dmpnn {
+extern thread_local long long* g_debug_stamps;   // (dmpnn_debug_timestamps: cycle stamps of one workgroup, scripts/probe_head_rows.py)
 namespace {
 
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -27,6 +29,7 @@ inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 constexpr int kBnCols = 16, kBnLanes = 64;
 struct BnArgs {
     const float* X; int64_t ldx; float* Y; int64_t ldy;
+    __device__ float* X_out() const { return const_cast<float*>(X); }   // (k_agg_bn_fwd writes the aggregate it then normalises)
     const float* gamma; const float* beta; float* run_mean; float* run_var;
     float* save_mean; float* save_invstd;      // [d] each (training: for the backward pass)
     int64_t B; int d; float eps, momentum; int training;
@@ -405,6 +408,633 @@ __global__ __launch_bounds__(1024) void k_out_all(OutAllArgs q) {
     }
 }
 
+// =====================================================================================================================
+// Round 5: the head of a training step in THREE launches (was nine) for the usual predictor — one hidden layer, <= kOutMaxTasks
+// outputs, <= kRowsMaxB molecules, widths <= kRowsMaxWidth:
+//   k_agg_bn_fwd   per 16 columns: H = agg(H_v) (the rows added in increasing atom order, like k_mol_reduce) and Z = bn(H) on the
+//                  values still in registers; the workgroups behind those SPLIT the hidden layer's weight (fragment-major hi | lo,
+//                  both orientations) — the split rides in this launch like the block's rides in K0, nothing about weights is cached;
+//   k_head_rows    per 16 molecules, everything that is local to a row: A1 = tau(Z W0^T + b0) on the f16 pipe (3-product split,
+//                  fp32 accumulation: the block's arithmetic), P = A1 W1^T + b1, the criterion (every workgroup counts the finite
+//                  targets of the WHOLE batch itself: B t values), dl/dP, dl/dA1, dl/dZ = dl/dA1 . W0 on the f16 pipe again; what
+//                  sums over rows (gW1, gb1, the loss) leaves as one partial per workgroup;
+//   k_bn_agg_bwd   per 16 columns: batch norm backward and the broadcast of dl/dH to the atoms' rows (k_mol_bwd's arithmetic), and
+//                  the partials summed in workgroup order (deterministic).
+// The hidden layer's weight gradient rides in the block's backward launches as before (ExtraWgrad) or runs as its own product.
+// DMPNN_HEAD=chain (environment, read per call): the nine-launch chain of rounds 3-4, kept for every other shape.
+constexpr int64_t kRowsMaxB = 1024;      // (16 rows per thread of the column kernels)
+constexpr int kRowsMaxWidth = 320;       // WN <= 5 column tiles per wave
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using mega16::h4;
+using mega16::h8;
+using mega16::SplitW;
+
+// Buffer loads for the column kernels' scalars: an offset out of range (or a NULL array: a zero-length buffer) reads 0 — no branch,
+// no select on the loaded value, so a batch of requests goes out before the first wait (a conditional `ok ? p[i] : 0` compiles to a
+// branch with a full wait behind EVERY load: 16 serialised round trips for a thread's molecule bounds, 11 us).
+__device__ __forceinline__ gemm::rsrc_t col_buf(const void* p, int64_t bytes, const void* dummy) {
+    return gemm::make_rsrc(p ? p : dummy, p ? gemm::clamp_bytes(bytes) : 0u);
+}
+__device__ __forceinline__ float col_ldf(gemm::rsrc_t r, bool ok, int64_t idx) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)idx * 4u : gemm::kOOB, 0, 0));
+}
+__device__ __forceinline__ int col_ldi(gemm::rsrc_t r, bool ok, int64_t idx) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)idx * 4u : gemm::kOOB, 0, 0);
+}
+// W0 [N, K] (nn.Linear layout) -> the two operands of the row kernel, both in the tile kernels' fragment-major order
+// [column tile][chunk][hi | lo][lg][li][8 halfs] (mega16::split_weights_wave) and both from ONE power-of-two scale per row n:
+//   fwd: column index n, reduction index k — the operand of Z . W0^T;       inv_scale[n] = 1 / s_n
+//   bwd: column index k, reduction index n — the operand of dl/dA1 . W0, holding the SAME halves W0[n][k] s_n: the scale belongs to
+//        the reduction index there, so the row kernel folds 1 / s_n into the columns of dl/dA1 before it splits them (exact).
+// One workgroup per 32 rows n (= one reduction chunk of `bwd`, two column tiles of `fwd`): row maxima by the waves (coalesced),
+// then every thread converts 8 consecutive k of a row (fwd) / 8 consecutive n of a column (bwd: lanes along k, coalesced) into one
+// 16-byte store each.  (split_weights_wave with tr = 1 reads a column per wave — 64 cache lines per load instruction: 20 us here.)
+struct HeadSplit { const float* W; int N, K; unsigned char* fwd; unsigned char* bwd; float* inv_scale; int ncf, ncb; };
+__device__ __forceinline__ void head_split_block(const HeadSplit& a, int blk) {
+    __shared__ float sc[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // 1024 threads
+    const int n0 = blk * 32;
+    const gemm::rsrc_t rW = gemm::make_rsrc(a.W, (unsigned)(a.N * a.K * 4));
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int n = n0 + 2 * wave + rr;
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < kRowsMaxWidth / 64; ++u) {   // (buffer loads: out of range reads 0 — no branch, all in flight together)
+            const int k = lane + 64 * u;
+            mx = fmaxf(mx, fabsf(col_ldf(rW, n < a.N && k < a.K, (int64_t)n * a.K + k)));
+        }
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float sn = n < a.N ? mega16::scale_for(mx) : 0.f;
+        if (lane == 0) {
+            sc[2 * wave + rr] = sn;
+            if (n < a.N) a.inv_scale[n] = 1.f / sn;
+        }
+    }
+    __syncthreads();
+    auto put = [&](unsigned char* base, int T, int nc, int c, int lg, int li, const float (&x)[8]) {
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)x[j]; lo[j] = (_Float16)(x[j] - (float)hi[j]); }
+        _Float16* o = reinterpret_cast<_Float16*>(base) + (((int64_t)T * nc + c) * 2) * 512 + (lg * 16 + li) * 8;
+        *reinterpret_cast<h8*>(o) = hi;
+        *reinterpret_cast<h8*>(o + 512) = lo;
+    };
+    const int nk8 = a.ncf * 4, last_tile = (a.N - 1) >> 4;
+    for (int it = tid; it < 32 * nk8; it += 1024) {
+        const int nl = it / nk8, k8 = it - nl * nk8, n = n0 + nl, k = 8 * k8;
+        if ((n >> 4) > last_tile) continue;   // (rows past N inside the last 16-row tile are written as zeros; tiles past it do not exist)
+        const float sn = sc[nl];
+        const bool l0 = n < a.N && k < a.K, l1 = n < a.N && k + 4 < a.K;   // (K % 4 == 0)
+        const float4 v0 = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rW, l0 ? (unsigned)(n * a.K + k) * 4u : gemm::kOOB, 0, 0));
+        const float4 v1 = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rW, l1 ? (unsigned)(n * a.K + k + 4) * 4u : gemm::kOOB, 0, 0));
+        const float x[8] = {v0.x * sn, v0.y * sn, v0.z * sn, v0.w * sn, v1.x * sn, v1.y * sn, v1.z * sn, v1.w * sn};
+        put(a.fwd, n >> 4, a.ncf, k8 >> 2, k8 & 3, n & 15, x);
+    }
+    const int Kp = (a.K + 15) & ~15;
+    for (int it = tid; it < Kp * 4; it += 1024) {
+        const int lg = it / Kp, k = it - lg * Kp;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + 8 * lg + j;
+            x[j] = col_ldf(rW, n < a.N && k < a.K, (int64_t)n * a.K + k) * sc[8 * lg + j];
+        }
+        put(a.bwd, k >> 4, a.ncb, blk, lg, k & 15, x);
+    }
+}
+
+struct AggBnArgs {
+    BnArgs b;                              // X = H [B, d] (written here), Y = Z (BN only)
+    const float* Hv; int64_t ldhv; int64_t nV; const int* bounds; int agg_mode; float agg_norm;
+    int n_col_blocks;                      // workgroups [0, n_col_blocks): columns; the others: the weight split (32 rows of W0 each)
+    HeadSplit split;
+    long long* dbg;                        // optional cycle stamps: [0..5] column workgroup 1, [6..9] the first split workgroup
+};
+// Geometry of the two column kernels: a workgroup = 16 columns as 4 column QUADS (16-byte loads and stores: a quarter of the memory
+// instructions of a thread-per-column layout, whose 1 500 four-segment wave loads per CU cost the aggregation 11 us) x 256 row lanes;
+// thread (tq = tid & 3, ty = tid >> 2) holds RR = 2 | 4 molecules (B <= 256 RR) of its quad in registers.
+constexpr int kQLanes = 256;
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// sums over the 256 row lanes of every column: the 16 row lanes of a wave by shuffles, the 16 waves through LDS
+__device__ __forceinline__ float4 quad_col_sum(float4 (*red)[4], int tq, float4 v) {
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) {
+        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off); v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+    }
+    __syncthreads();   // (the previous use of `red` is over)
+    if ((threadIdx.x & 63) < 4) red[threadIdx.x >> 6][tq] = v;
+    __syncthreads();
+    float4 s = red[0][tq];
+#pragma unroll 4
+    for (int w = 1; w < 16; ++w) s = f4_add(s, red[w][tq]);
+    return s;
+}
+template <int RR, bool BN>
+__global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
+    if ((int)blockIdx.x >= q.n_col_blocks) {   // (uniform per workgroup)
+        const bool st = q.dbg && (int)blockIdx.x == q.n_col_blocks && threadIdx.x == 0;
+        if (st) q.dbg[6] = (long long)__builtin_readcyclecounter();
+        head_split_block(q.split, (int)blockIdx.x - q.n_col_blocks);
+        if (st) q.dbg[7] = (long long)__builtin_readcyclecounter();
+        return;
+    }
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (q.dbg && blockIdx.x == 1 && threadIdx.x == 0 && n_stamp < 6) q.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();  // 0 entry
+    __shared__ float4 red[16][4];
+    const BnArgs& a = q.b;
+    const int tq = threadIdx.x & 3, ty = threadIdx.x >> 2;
+    const int c = blockIdx.x * kBnCols + 4 * tq;
+    const bool ok = c < a.d;   // (d % 4 == 0: a quad is inside or outside)
+    const gemm::rsrc_t rBd = gemm::make_rsrc(q.bounds, (unsigned)((2 * a.B + 4) * 4));
+    const int flag = col_ldi(rBd, true, 2 * a.B);
+    int v0[RR], nv[RR];
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        const int64_t r = ty + (int64_t)kQLanes * i;
+        v0[i] = col_ldi(rBd, r < a.B, r);
+        nv[i] = col_ldi(rBd, r < a.B, a.B + r);
+    }
+    // (batch norm's per-column constants: requested now, used behind the statistics)
+    auto ldq = [&](const float* p) {
+        return gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(col_buf(p, (int64_t)a.d * 4, q.bounds), ok ? (unsigned)c * 4u : gemm::kOOB, 0, 0));
+    };
+    const float4 gam0 = ldq(a.gamma), bet0 = ldq(a.beta), rm0 = ldq(a.run_mean), rv0 = ldq(a.run_var);
+    stamp();  // 1 requests out
+    int nmax = 0;
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        nv[i] -= v0[i];
+        if (nv[i] < 0 || !ok) nv[i] = 0;
+        nmax = nv[i] > nmax ? nv[i] : nmax;
+    }
+    stamp();  // 2 bounds here
+    // segment sums: AT atoms of every one of the thread's molecules per round — AT RR independent 16-byte loads in flight (a molecule's
+    // rows are still added in increasing atom order: the reference's scatter order)
+    constexpr int AT = 8 / RR * 2;   // RR = 2: 8, RR = 4: 4
+    const gemm::rsrc_t rH = gemm::make_rsrc(q.Hv, gemm::clamp_bytes(((int64_t)q.nV * q.ldhv) * 4));
+    float4 xs[RR];
+#pragma unroll
+    for (int i = 0; i < RR; ++i) xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < nmax; s0 += AT) {
+        float4 tv[AT][RR];
+#pragma unroll
+        for (int u = 0; u < AT; ++u)
+#pragma unroll
+            for (int i = 0; i < RR; ++i)
+                tv[u][i] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(
+                    rH, s0 + u < nv[i] ? (unsigned)((int64_t)(v0[i] + s0 + u) * q.ldhv + c) * 4u : gemm::kOOB, 0, 0));
+#pragma unroll
+        for (int u = 0; u < AT; ++u)
+#pragma unroll
+            for (int i = 0; i < RR; ++i)
+                if (s0 + u < nv[i]) xs[i] = (s0 + u == 0) ? tv[u][i] : f4_add(xs[i], tv[u][i]);   // include_self=False: the first addend is copied
+    }
+    const float nanv = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        const int64_t r = ty + (int64_t)kQLanes * i;
+        float4 y = xs[i];
+        if (q.agg_mode == DMPNN_MOLAGG_MEAN && nv[i] > 0) { const float n = (float)nv[i]; y = make_float4(y.x / n, y.y / n, y.z / n, y.w / n); }
+        if (q.agg_mode == DMPNN_MOLAGG_NORM) y = make_float4(y.x / q.agg_norm, y.y / q.agg_norm, y.z / q.agg_norm, y.w / q.agg_norm);
+        if (flag) y = make_float4(nanv, nanv, nanv, nanv);
+        xs[i] = (ok && r < a.B) ? y : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && r < a.B) *reinterpret_cast<float4*>(a.X_out() + r * a.ldx + c) = y;
+    }
+    stamp();  // 3 aggregated
+    if constexpr (!BN) return;
+    float4 mean, invstd;
+    if (a.training) {
+        if (a.n_tracked && blockIdx.x == 0 && threadIdx.x == 0) *a.n_tracked += 1;
+        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RR; ++i) sm = f4_add(sm, xs[i]);
+        sm = quad_col_sum(red, tq, sm);
+        const float fB = (float)a.B;
+        mean = make_float4(sm.x / fB, sm.y / fB, sm.z / fB, sm.w / fB);
+        float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RR; ++i)
+            if (ty + (int64_t)kQLanes * i < a.B) {
+                const float4 dl = make_float4(xs[i].x - mean.x, xs[i].y - mean.y, xs[i].z - mean.z, xs[i].w - mean.w);
+                qq = f4_add(qq, make_float4(dl.x * dl.x, dl.y * dl.y, dl.z * dl.z, dl.w * dl.w));
+            }
+        const float4 ss = quad_col_sum(red, tq, qq);
+        const float4 var = make_float4(ss.x / fB, ss.y / fB, ss.z / fB, ss.w / fB);   // biased: what normalises (nn.BatchNorm1d)
+        invstd = make_float4(1.f / sqrtf(var.x + a.eps), 1.f / sqrtf(var.y + a.eps), 1.f / sqrtf(var.z + a.eps), 1.f / sqrtf(var.w + a.eps));
+        if (ok && ty == 0) {
+            *reinterpret_cast<float4*>(a.save_mean + c) = mean;
+            *reinterpret_cast<float4*>(a.save_invstd + c) = invstd;
+            const float m = a.momentum, om = 1.f - a.momentum, fB1 = (float)(a.B - 1);
+            if (a.run_mean) *reinterpret_cast<float4*>(a.run_mean + c) = make_float4(om * rm0.x + m * mean.x, om * rm0.y + m * mean.y, om * rm0.z + m * mean.z, om * rm0.w + m * mean.w);
+            // running_var takes the UNBIASED estimate (torch: var * B / (B - 1))
+            const float4 ub = a.B > 1 ? make_float4(ss.x / fB1, ss.y / fB1, ss.z / fB1, ss.w / fB1) : var;
+            if (a.run_var) *reinterpret_cast<float4*>(a.run_var + c) = make_float4(om * rv0.x + m * ub.x, om * rv0.y + m * ub.y, om * rv0.z + m * ub.z, om * rv0.w + m * ub.w);
+        }
+    } else {
+        mean = rm0;
+        invstd = make_float4(1.f / sqrtf(rv0.x + a.eps), 1.f / sqrtf(rv0.y + a.eps), 1.f / sqrtf(rv0.z + a.eps), 1.f / sqrtf(rv0.w + a.eps));
+    }
+    stamp();  // 4 statistics
+    if (ok) {
+        const float4 g = a.gamma ? gam0 : make_float4(1.f, 1.f, 1.f, 1.f), bb = a.beta ? bet0 : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RR; ++i) {
+            const int64_t r = ty + (int64_t)kQLanes * i;
+            if (r < a.B)
+                *reinterpret_cast<float4*>(a.Y + r * a.ldy + c) = make_float4((xs[i].x - mean.x) * invstd.x * g.x + bb.x, (xs[i].y - mean.y) * invstd.y * g.y + bb.y,
+                                                                              (xs[i].z - mean.z) * invstd.z * g.z + bb.z, (xs[i].w - mean.w) * invstd.w * g.w + bb.w);
+        }
+    }
+    stamp();  // 5 end
+}
+
+struct BnAggBwdArgs {
+    BnBwdArgs b;                           // gY = dl/dZ [B, d], X = H; gX unused (the rows go to the atoms)
+    float* gHv; int64_t ldg; const int* bounds; int64_t nV; int agg_mode; float agg_norm;
+    // the row kernel's partials (or part == NULL): out[i] = sum over workgroups of part[w * part_stride + i]
+    const float* part; int n_part, part_stride, tN, t;
+    float* gW1; float* gb1; float* loss_out;
+    long long* dbg;                        // optional cycle stamps of column workgroup 1
+};
+template <int RR, bool BN>
+__global__ __launch_bounds__(1024) void k_bn_agg_bwd(BnAggBwdArgs q) {
+    __shared__ float4 red[16][4];
+    if ((int)blockIdx.x * kBnCols >= q.b.d) {   // the workgroup behind the columns': what sums over the rows of the batch, in workgroup order
+        if (!q.part) return;
+        const int n_out = q.tN + q.t;
+        for (int i = threadIdx.x; i <= n_out; i += 1024) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int w = 0; w < q.n_part; ++w) s += q.part[(int64_t)w * q.part_stride + i];
+            if (i < q.tN) { if (q.gW1) q.gW1[i] = s; }
+            else if (i < n_out) { if (q.gb1) q.gb1[i - q.tN] = s; }
+            else {   // the loss: sum / count (no finite target: 0 / 0 = NaN, like the reference)
+                const float cnt = q.part[n_out + 1];
+                q.loss_out[0] = s / cnt;
+                q.loss_out[1] = cnt;
+            }
+        }
+        return;
+    }
+    const BnBwdArgs& a = q.b;
+    const int tq = threadIdx.x & 3, ty = threadIdx.x >> 2;
+    const int c = blockIdx.x * kBnCols + 4 * tq;
+    const bool ok = c < a.d;
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (q.dbg && blockIdx.x == 1 && threadIdx.x == 0 && n_stamp < 6) q.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();  // 0 entry
+    // every request of the kernel first (buffer loads: no branch, no wait in between)
+    float4 gs[RR], xr[RR];
+    int v0[RR], v1[RR];
+    const gemm::rsrc_t rBd = gemm::make_rsrc(q.bounds, (unsigned)((2 * a.B + 4) * 4));
+    const gemm::rsrc_t rG = gemm::make_rsrc(a.gY, gemm::clamp_bytes(a.B * a.ldgy * 4)), rX = gemm::make_rsrc(a.X, gemm::clamp_bytes(a.B * a.ldx * 4));
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        const int64_t r = ty + (int64_t)kQLanes * i;
+        const bool in = ok && r < a.B;
+        gs[i] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rG, in ? (unsigned)(r * a.ldgy + c) * 4u : gemm::kOOB, 0, 0));
+        xr[i] = BN ? gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rX, in ? (unsigned)(r * a.ldx + c) * 4u : gemm::kOOB, 0, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v0[i] = col_ldi(rBd, r < a.B, r);
+        v1[i] = col_ldi(rBd, r < a.B, a.B + r);
+    }
+    const int flag = col_ldi(rBd, true, 2 * a.B);
+    auto ldq = [&](const float* p) {
+        return gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(col_buf(p, (int64_t)a.d * 4, q.bounds), (BN && ok) ? (unsigned)c * 4u : gemm::kOOB, 0, 0));
+    };
+    const float4 mean = ldq(a.training ? a.save_mean : a.run_mean), is0 = ldq(a.training ? a.save_invstd : a.run_var), gam0 = ldq(a.gamma);
+    stamp();  // 1 requests out
+    if constexpr (BN) {
+        const float4 invstd = a.training ? is0 : make_float4(1.f / sqrtf(is0.x + a.eps), 1.f / sqrtf(is0.y + a.eps), 1.f / sqrtf(is0.z + a.eps), 1.f / sqrtf(is0.w + a.eps));
+        float4 xh[RR], s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+        for (int i = 0; i < RR; ++i) {
+            const bool in = ok && ty + (int64_t)kQLanes * i < a.B;
+            xh[i] = in ? make_float4((xr[i].x - mean.x) * invstd.x, (xr[i].y - mean.y) * invstd.y, (xr[i].z - mean.z) * invstd.z, (xr[i].w - mean.w) * invstd.w)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            s1 = f4_add(s1, gs[i]);
+            s2 = f4_add(s2, make_float4(gs[i].x * xh[i].x, gs[i].y * xh[i].y, gs[i].z * xh[i].z, gs[i].w * xh[i].w));
+        }
+        stamp();  // 2 data here
+        s1 = quad_col_sum(red, tq, s1);
+        s2 = quad_col_sum(red, tq, s2);
+        stamp();  // 3 column sums
+        if (ok && ty == 0) {
+            if (a.g_gamma) *reinterpret_cast<float4*>(a.g_gamma + c) = s2;
+            if (a.g_beta) *reinterpret_cast<float4*>(a.g_beta + c) = s1;
+        }
+        const float4 gam = a.gamma ? gam0 : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 k = make_float4(gam.x * invstd.x, gam.y * invstd.y, gam.z * invstd.z, gam.w * invstd.w);
+        const float invB = 1.f / (float)a.B;
+#pragma unroll
+        for (int i = 0; i < RR; ++i)
+            gs[i] = a.training ? make_float4(k.x * (gs[i].x - invB * s1.x - xh[i].x * invB * s2.x), k.y * (gs[i].y - invB * s1.y - xh[i].y * invB * s2.y),
+                                             k.z * (gs[i].z - invB * s1.z - xh[i].z * invB * s2.z), k.w * (gs[i].w - invB * s1.w - xh[i].w * invB * s2.w))
+                               : make_float4(k.x * gs[i].x, k.y * gs[i].y, k.z * gs[i].z, k.w * gs[i].w);
+    }
+    if (!ok) return;
+    const float nanv = __int_as_float(0x7fc00000);
+    if (flag) {   // an invalid `batch`: every row NaN (atoms outside every molecule's range included)
+        for (int64_t v = ty; v < q.nV; v += kQLanes) *reinterpret_cast<float4*>(q.gHv + v * q.ldg + c) = make_float4(nanv, nanv, nanv, nanv);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        const int64_t r = ty + (int64_t)kQLanes * i;
+        if (r >= a.B) continue;
+        float4 g = gs[i];
+        if (q.agg_mode == DMPNN_MOLAGG_MEAN) { const float n = (float)(v1[i] - v0[i]); g = make_float4(g.x / n, g.y / n, g.z / n, g.w / n); }
+        if (q.agg_mode == DMPNN_MOLAGG_NORM) g = make_float4(g.x / q.agg_norm, g.y / q.agg_norm, g.z / q.agg_norm, g.w / q.agg_norm);
+        for (int v = v0[i]; v < v1[i]; ++v) *reinterpret_cast<float4*>(q.gHv + (int64_t)v * q.ldg + c) = g;
+    }
+    stamp();  // 4 (2 without batch norm) rows issued
+}
+
+struct RowsArgs {
+    const float* Z; int64_t ldz;           // [B, K] the predictor's input
+    SplitW W0f, W0b;                       // W0 [N, K] as N rows over K (forward) and as K rows over N (data gradient)
+    const float* b0; const float* W1; const float* b1;   // [N] | NULL, [t, N], [t] | NULL
+    float* preds;                          // [B, t]
+    const float* T; const float* w; const float* tw; const unsigned char* lt; const unsigned char* gt; int kind;
+    float* gA1; float* gZ;                 // [B, N], [B, K]
+    float* part; int part_stride;          // per workgroup: gW1 [t][N] | gb1 [t] | loss sum | number of finite targets
+    int64_t B; int N, K, t, act; float slope;
+    long long* dbg;                        // optional cycle stamps of workgroup 1
+};
+template <int WN>
+__global__ __launch_bounds__(256) void k_head_rows(RowsArgs a) {
+    constexpr int BN = 64 * WN, NCH = BN / 32, TS = NCH * 128 + 16, LDA = BN + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char As[16 * TS];   // split operand tile: the rows of Z, later of dl/dA1
+    __shared__ __attribute__((aligned(16))) float A1s[16 * LDA];         // fp32 tile: A1, later dl/dA1
+    __shared__ float inv_s[16];                                          // 1 / scale of the split tile's rows
+    __shared__ float Ps[16][kOutMaxTasks], gPs[16][kOutMaxTasks];
+    __shared__ float W1s[kOutMaxTasks][BN];                              // W1 [t, N], zero beyond
+    __shared__ float red2[2][4];
+    __shared__ float tot[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int nrows = (int)(a.B - row0 < 16 ? a.B - row0 : 16);
+    const int t = a.t;
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (a.dbg && blockIdx.x == 1 && threadIdx.x == 0 && n_stamp < 12) a.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();  // 0 entry
+
+    // fp32 rows -> split tile.  Thread (row i = tid >> 4, p = tid & 15) holds columns 4 p + 64 j: the row's maximum by four shuffles.
+    auto split_rows = [&](const float4 (&x)[WN]) {
+        const int i = tid >> 4, p = tid & 15;
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[j].x), fabsf(x[j].y))), fmaxf(fabsf(x[j].z), fabsf(x[j].w)));
+        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const float s = mega16::scale_for(mx);
+        if (p == 0) inv_s[i] = 1.f / s;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = 4 * p + 64 * j;
+            h4 hi, lo;
+            mega16::split4(x[j], s, hi, lo);
+            unsigned char* d = As + i * TS + (col >> 5) * 128 + (col & 31) * 2;
+            *reinterpret_cast<h4*>(d) = hi;
+            *reinterpret_cast<h4*>(d + 64) = lo;
+        }
+    };
+    // acc[ct] += (tile s_row) . (W s_col)^T; wave w owns column tiles w WN .. w WN + WN - 1.  The weight fragments come straight from
+    // memory (L2: the split was written by the launch in front) through a register ring of HALF the contraction, requested long before
+    // they are needed — `request` goes out before the operand tile is even loaded (32 workgroups: nobody else hides this latency);
+    // branch-free and fully unrolled (chunks beyond W.nc: out-of-range loads return 0, the tile's columns there are 0).
+    constexpr int D = NCH / 2;
+    struct Ring {
+        h8 h[D][WN], l[D][WN];
+        gemm::rsrc_t rW;
+        unsigned off[WN];
+        int nc;
+    };
+    auto load_b = [&](Ring& R, int c, int slot) {
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) {
+            const unsigned o = c < R.nc ? R.off[ct] + (unsigned)c * 2048u : gemm::kOOB;
+            R.h[slot][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(R.rW, o, 0, 0));
+            R.l[slot][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(R.rW, c < R.nc ? o + 1024u : gemm::kOOB, 0, 0));
+        }
+    };
+    auto request = [&](Ring& R, const SplitW& W, int n_out) {
+        R.rW = gemm::make_rsrc(W.p, (unsigned)(((n_out + 15) / 16) * W.nc * 2048));   // column tiles beyond: 0
+        R.nc = W.nc;
+#pragma unroll
+        for (int ct = 0; ct < WN; ++ct) R.off[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
+#pragma unroll
+        for (int c = 0; c < D; ++c) load_b(R, c, c);
+    };
+    auto contract = [&](f32x4 (&acc)[WN], Ring& R) {
+        __syncthreads();   // the split tile (and inv_s) is complete
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned char* pa = As + li * TS + c * 128 + lg * 16;
+            const h8 ah = *reinterpret_cast<const h8*>(pa), al = *reinterpret_cast<const h8*>(pa + 64);
+#pragma unroll
+            for (int ct = 0; ct < WN; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, R.h[c % D][ct], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, R.l[c % D][ct], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, R.h[c % D][ct], acc[ct], 0, 0, 0);
+            }
+            if (c + D < NCH) load_b(R, c + D, c % D);
+        }
+    };
+    // ---- A1 = tau(Z W0^T + b0) ----
+    // requests in the order they are needed (vmcnt counts in order): the rows of Z, W1, then the first half of W0's fragments — all
+    // unconditional (clamped addresses, selects on the data), so that the waits in front of the split are exact
+    // (buffer loads: an offset out of range reads 0 without a branch or a select on the data — nothing here consumes a loaded value, so
+    //  every request below is out before the first wait; a NULL array is a zero-length buffer)
+    auto buf = [&](const void* ptr, int64_t bytes) { return gemm::make_rsrc(ptr ? ptr : a.Z, ptr ? (unsigned)bytes : 0u); };
+    float4 zx[WN];
+    {
+        const int i = tid >> 4, p = tid & 15;
+        const gemm::rsrc_t rZ = gemm::make_rsrc(a.Z + row0 * a.ldz, (unsigned)(nrows * a.ldz * 4));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = 4 * p + 64 * j;
+            zx[j] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rZ, (i < nrows && col < a.K) ? (unsigned)(i * a.ldz + col) * 4u : gemm::kOOB, 0, 0));
+        }
+    }
+    auto ldf = [&](gemm::rsrc_t r, bool ok, int64_t idx) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)idx * 4u : gemm::kOOB, 0, 0));
+    };
+    // the criterion's inputs: element (row ei, task ej) of this workgroup's rows on thread tid < 16 t; the targets of the WHOLE batch
+    // (B t <= 4 096 values, 16 per thread) for the count of finite ones
+    const int ei = tid / t, ej = tid - ei * t;
+    const bool elem = tid < 16 * t && ei < nrows;
+    const int64_t egi = (row0 + ei) * t + ej;
+    const gemm::rsrc_t rT = buf(a.T, a.B * t * 4);
+    const float ey = ldf(rT, elem, egi);
+    const float ewv = ldf(buf(a.w, a.B * 4), elem, row0 + ei), etv = ldf(buf(a.tw, t * 4), elem, ej);
+    const unsigned char elt = __builtin_amdgcn_raw_buffer_load_b8(buf(a.lt, a.B * t), elem ? (unsigned)egi : gemm::kOOB, 0, 0);
+    const unsigned char egt = __builtin_amdgcn_raw_buffer_load_b8(buf(a.gt, a.B * t), elem ? (unsigned)egi : gemm::kOOB, 0, 0);
+    constexpr int NCNT = (int)(kRowsMaxB * kOutMaxTasks / 256);
+    float cv[NCNT];
+#pragma unroll
+    for (int u = 0; u < NCNT; ++u) cv[u] = ldf(rT, tid + 256 * u < a.B * t, tid + 256 * u);
+    constexpr int NW1 = kOutMaxTasks * BN / 256;
+    float w1v[NW1];
+    const gemm::rsrc_t rW1 = gemm::make_rsrc(a.W1, (unsigned)(t * a.N * 4));
+#pragma unroll
+    for (int u = 0; u < NW1; ++u) {
+        const int idx = tid + 256 * u, j = idx / BN, n = idx - j * BN;
+        w1v[u] = ldf(rW1, j < t && n < a.N, j * a.N + n);
+    }
+    // per-column constants: 1 / s_n of W0's rows for the thread's columns of dl/dA1 (n = tid, tid + 256) and for its fragments' columns
+    const gemm::rsrc_t rIS = gemm::make_rsrc(a.W0f.inv_scale, (unsigned)(a.N * 4)), rB0 = buf(a.b0, a.N * 4);
+    constexpr int NCOL = (BN + 255) / 256;
+    float isn[NCOL];
+#pragma unroll
+    for (int u = 0; u < NCOL; ++u) isn[u] = ldf(rIS, tid + 256 * u < a.N, tid + 256 * u);
+    float isw1[WN], bv1[WN];
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int n = (wave * WN + ct) * 16 + li;
+        isw1[ct] = ldf(rIS, n < a.N, n);
+        bv1[ct] = ldf(rB0, n < a.N, n);
+    }
+    Ring R;
+    request(R, a.W0f, a.N);
+    __builtin_amdgcn_sched_barrier(0);   // (requests above, consumers below)
+    stamp();  // 1 requests out
+#pragma unroll
+    for (int u = 0; u < NW1; ++u) { const int idx = tid + 256 * u; W1s[idx / BN][idx % BN] = w1v[u]; }   // (read by every row of the tile, twice)
+    split_rows(zx);
+    stamp();  // 2 Z split (its rows landed)
+    f32x4 acc[WN];
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract(acc, R);
+    stamp();  // 3 first contraction issued
+    request(R, a.W0b, a.K);   // (the data gradient's first half: in flight under everything up to its contraction)
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int n = (wave * WN + ct) * 16 + li;
+        const bool okn = n < a.N;
+        const float isw = isw1[ct], bv = bv1[ct];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * lg + r;
+            const float y = apply_act_small(acc[ct][r] * (isw * inv_s[i]) + bv, a.act, a.slope);
+            A1s[i * LDA + n] = (okn && i < nrows) ? y : 0.f;
+        }
+    }
+    __syncthreads();
+    stamp();  // 4 A1 in the tile
+    // ---- P = A1 W1^T + b1: thread (row i, part p) sums the columns n = p mod 16 ----
+    {
+        const int i = tid >> 4, p = tid & 15;
+        float s[kOutMaxTasks] = {0.f, 0.f, 0.f, 0.f};
+        for (int n = p; n < a.N; n += 16) {
+            const float x = A1s[i * LDA + n];
+#pragma unroll
+            for (int j = 0; j < kOutMaxTasks; ++j) s[j] += x * W1s[j][n];
+        }
+#pragma unroll
+        for (int j = 0; j < kOutMaxTasks; ++j) {
+            for (int off = 1; off < 16; off <<= 1) s[j] += __shfl_xor(s[j], off);
+            if (p == 0 && j < t) {
+                const float v = s[j] + (a.b1 ? a.b1[j] : 0.f);
+                Ps[i][j] = v;
+                if (i < nrows) a.preds[(row0 + i) * t + j] = v;
+            }
+        }
+    }
+    stamp();  // 5 predictions
+    // ---- criterion (k_loss's arithmetic per element): this workgroup's rows; the count over the whole batch ----
+    float sm = 0.f, sl = 0.f;
+#pragma unroll
+    for (int u = 0; u < NCNT; ++u) sm += (tid + 256 * u < a.B * t && isfinite(cv[u])) ? 1.f : 0.f;
+    __syncthreads();   // Ps
+    float ef = 0.f, ep = 0.f;
+    const bool efin = elem && isfinite(ey);
+    if (elem) {
+        ep = Ps[ei][ej];
+        if ((elt && ep < ey) || (egt && ep > ey)) ep = ey;
+        ef = (a.w ? ewv : 1.f) * (a.tw ? etv : 1.f);
+        if (efin) sl = loss_value(a.kind, ep, ey) * ef;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sl += __shfl_xor(sl, off); sm += __shfl_xor(sm, off); }
+    if (lane == 0) { red2[0][wave] = sl; red2[1][wave] = sm; }
+    __syncthreads();
+    if (tid == 0) {
+        tot[0] = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
+        tot[1] = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
+        float* pp = a.part + (int64_t)blockIdx.x * a.part_stride + t * a.N + t;
+        pp[0] = tot[0]; pp[1] = tot[1];
+    }
+    __syncthreads();
+    if (tid < 16 * t) gPs[ei][ej] = efin ? loss_deriv(a.kind, ep, ey) * ef * (1.f / tot[1]) : 0.f;
+    __syncthreads();
+    stamp();  // 6 criterion
+    // ---- the output layer's backward on this workgroup's rows: thread = column n of A1 ----
+    //   dl/dA1[i][n] = (sum_j gP[i][j] W1[j][n]) tau'(A1[i][n]),  partial gW1[j][n] = sum_i gP[i][j] A1[i][n],  partial gb1[j] = sum_i gP[i][j]
+#pragma unroll
+    for (int u = 0; u < NCOL; ++u) {
+        const int n = tid + 256 * u;
+        if (n >= BN) break;
+        const bool okn = n < a.N;
+        const float isn_c = isn[u];
+        float w1[kOutMaxTasks], gw[kOutMaxTasks];
+#pragma unroll
+        for (int j = 0; j < kOutMaxTasks; ++j) { w1[j] = W1s[j][n]; gw[j] = 0.f; }
+        for (int i = 0; i < 16; ++i) {
+            const float x = A1s[i * LDA + n];
+            float g = 0.f;
+#pragma unroll
+            for (int j = 0; j < kOutMaxTasks; ++j)
+                if (j < t) { const float gp = gPs[i][j]; g += gp * w1[j]; gw[j] += gp * x; }
+            const float gv = okn ? g * act_grad_from_out(x, a.act, a.slope) : 0.f;
+            A1s[i * LDA + n] = gv * isn_c;   // (the operand of dl/dA1 . W0 carries W0's row scales on its reduction index: see HeadSplit)
+            if (okn && i < nrows) a.gA1[(row0 + i) * a.N + n] = gv;
+        }
+        if (okn)
+            for (int j = 0; j < t; ++j) a.part[(int64_t)blockIdx.x * a.part_stride + (int64_t)j * a.N + n] = gw[j];
+    }
+    if (tid < t) {
+        float sb = 0.f;
+        for (int i = 0; i < 16; ++i) sb += gPs[i][tid];
+        a.part[(int64_t)blockIdx.x * a.part_stride + t * a.N + tid] = sb;
+    }
+    __syncthreads();
+    stamp();  // 7 output layer's backward
+    // ---- dl/dZ = dl/dA1 . W0 ----
+    {
+        float4 gx[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) gx[j] = *reinterpret_cast<const float4*>(A1s + (tid >> 4) * LDA + 4 * (tid & 15) + 64 * j);
+        split_rows(gx);
+    }
+    stamp();  // 8 dl/dA1 split
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract(acc, R);
+    stamp();  // 9 second contraction issued
+#pragma unroll
+    for (int ct = 0; ct < WN; ++ct) {
+        const int k = (wave * WN + ct) * 16 + li;
+        const bool okk = k < a.K;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * lg + r;
+            if (okk && i < nrows) a.gZ[(row0 + i) * a.K + k] = acc[ct][r] * inv_s[i];
+        }
+    }
+    stamp();  // 10 end
+}
+
 // out[c][r] = in[r][c] for a weight matrix (<= a few hundred KB)
 __global__ void k_head_transpose(const float* __restrict__ in, int64_t ldi, float* __restrict__ out, int64_t ldo, int rows, int cols) {
     __shared__ float tile[32][33];
@@ -433,7 +1063,15 @@ struct HeadLayout {
     size_t bounds, Hm, Z, mean, invstd, act[DMPNN_MAX_FFN_LAYERS], gP, gA, gB, Wt, wgrad, gHm, total;
     size_t wgrad_bytes;
     int64_t maxd;
+    // the three-launch form (rows_shape): the hidden layer's split weight in both orientations, their row scales, the row kernel's partials
+    size_t W0f, W0b, isf, isb, part;
+    int part_stride, n_part;
 };
+// the shapes the three-launch form takes (training or not is the caller's business): one hidden layer, a handful of outputs
+bool rows_shape(const dmpnn_head_args& h) {
+    return h.n_layers == 2 && h.dims[2] <= kOutMaxTasks && h.dims[2] >= 1 && h.loss != DMPNN_LOSS_CE && h.n_mols <= kRowsMaxB &&
+           h.dims[0] <= kRowsMaxWidth && h.dims[1] <= kRowsMaxWidth && h.dims[0] % 4 == 0;
+}
 HeadLayout head_layout(const dmpnn_head_args& h) {
     HeadLayout L;
     memset(&L, 0, sizeof(L));
@@ -467,6 +1105,16 @@ HeadLayout head_layout(const dmpnn_head_args& h) {
     }
     L.wgrad = o; L.wgrad_bytes = al256(wg); o += L.wgrad_bytes;
     L.gHm = o; o += al256((size_t)B * d * 4);
+    if (h.n_layers == 2 && rows_shape(h)) {
+        const int64_t N = h.dims[1], K = h.dims[0], t = h.dims[2];
+        L.W0f = o; o += al256((size_t)((N + 15) / 16) * ((K + 31) / 32) * 2048);
+        L.W0b = o; o += al256((size_t)((K + 15) / 16) * ((N + 31) / 32) * 2048);
+        L.isf = o; o += al256((size_t)N * 4);
+        L.isb = o; o += al256((size_t)K * 4);
+        L.n_part = (int)((B + 15) / 16);
+        L.part_stride = (int)(t * N + t + 2);
+        L.part = o; o += al256((size_t)L.n_part * L.part_stride * 4);
+    }
     L.total = o;
     return L;
 }
@@ -496,6 +1144,18 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
 }  // extern "C"
 
 namespace {
+int launch_bn_agg_bwd(const BnAggBwdArgs& q, bool bn, hipStream_t s) {
+    const dim3 grid((unsigned)((q.b.d + kBnCols - 1) / kBnCols) + (q.part ? 1u : 0u));   // (+ 1: the row kernel's partials)
+    if (q.b.B <= 2 * kQLanes) {
+        if (bn) hipLaunchKernelGGL((k_bn_agg_bwd<2, true>), grid, dim3(1024), 0, s, q);
+        else hipLaunchKernelGGL((k_bn_agg_bwd<2, false>), grid, dim3(1024), 0, s, q);
+    } else {
+        if (bn) hipLaunchKernelGGL((k_bn_agg_bwd<4, true>), grid, dim3(1024), 0, s, q);
+        else hipLaunchKernelGGL((k_bn_agg_bwd<4, false>), grid, dim3(1024), 0, s, q);
+    }
+    DMPNN_CHECK_LAUNCH("k_bn_agg_bwd");
+    return DMPNN_OK;
+}
 // defer (a whole training step only): the weight gradient of the predictor's FIRST layer is not launched here but described in
 // *defer — it rides in the launches of the block's backward pass (ExtraWgrad); its inputs (the layer's output gradient, the
 // layer's input) stay untouched in the workspace until then
@@ -534,17 +1194,89 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
 
     // ---- forward ----
     if (!bounds_done) DMPNN_TRY(dmpnn_molagg_bounds(h.batch, nV, B, ws + L.bounds, dmpnn_molagg_ws_bytes(B), stream));
-    DMPNN_TRY(dmpnn_molagg_fwd(Hv, ldhv, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, Hm, d, stream));
+    // round 5: the three-launch form (see k_agg_bn_fwd) — aggregation + batch norm as ONE column kernel for <= kRowsMaxB molecules
+    // (forward, inference included), the whole predictor + criterion + their backward as ONE row kernel when the shape fits
+    const char* head_env = getenv("DMPNN_HEAD");
+    const bool chain = head_env && !strcmp(head_env, "chain");
+    // (the column kernels move 16-byte quads: widths and strides in multiples of 4 floats, 16-byte aligned rows)
+    const bool cols_fused = !chain && B <= kRowsMaxB && nV > 0 && d % 4 == 0 && ldhv % 4 == 0 && aligned16(Hv) &&
+                            (!want_grad || (h.ldg % 4 == 0 && aligned16(h.gHv))) && (int64_t)nV * ldhv < (1ll << 29) &&
+                            (!h.bn_weight || (aligned16(h.bn_weight) && aligned16(h.bn_bias) && aligned16(h.bn_running_mean) && aligned16(h.bn_running_var) &&
+                                              (!h.g_bn_weight || aligned16(h.g_bn_weight)) && (!h.g_bn_bias || aligned16(h.g_bn_bias))));
+    const bool rows = cols_fused && want_grad && h.targets && rows_shape(h) && aligned16(h.W[0]);
+    // (DMPNN_HEAD=rows: tests — a training call that does NOT take the three-launch form is an error instead of a silent chain)
+    DMPNN_CHECK_ARG(!(head_env && !strcmp(head_env, "rows")) || rows || !want_grad, "head: DMPNN_HEAD=rows, but this shape takes the chain");
     const float* Z = Hm;
     float* mean = reinterpret_cast<float*>(ws + L.mean);
     float* invstd = reinterpret_cast<float*>(ws + L.invstd);
-    if (h.bn_weight) {
+    SplitW W0f{ws + L.W0f, reinterpret_cast<float*>(ws + L.isf), (int)((h.dims[0] + 31) / 32)};
+    SplitW W0b{ws + L.W0b, reinterpret_cast<float*>(ws + L.isb), (int)((h.dims[1] + 31) / 32)};
+    if (cols_fused) {
+        AggBnArgs q;
+        memset(&q, 0, sizeof(q));
+        q.b = BnArgs{Hm, d, reinterpret_cast<float*>(ws + L.Z), d, h.bn_weight, h.bn_bias, h.bn_running_mean, h.bn_running_var, mean, invstd,
+                     B, (int)d, h.bn_eps, h.bn_momentum, h.bn_training, h.bn_num_batches_tracked};
+        q.Hv = Hv; q.ldhv = ldhv; q.nV = nV; q.bounds = reinterpret_cast<const int*>(ws + L.bounds); q.agg_mode = h.agg_mode; q.agg_norm = h.agg_norm;
+        q.n_col_blocks = (int)((d + kBnCols - 1) / kBnCols);
+        q.dbg = g_debug_stamps ? g_debug_stamps + 80 : nullptr;
+        int split_blocks = 0;
+        if (rows) {
+            const int N = (int)h.dims[1], K = (int)h.dims[0];
+            q.split = HeadSplit{h.W[0], N, K, ws + L.W0f, ws + L.W0b, reinterpret_cast<float*>(ws + L.isf), W0f.nc, W0b.nc};
+            split_blocks = W0b.nc;
+        }
+        const dim3 grid((unsigned)(q.n_col_blocks + split_blocks));
+        const bool bn = h.bn_weight != nullptr;
+        if (B <= 2 * kQLanes) {
+            if (bn) hipLaunchKernelGGL((k_agg_bn_fwd<2, true>), grid, dim3(1024), 0, s, q);
+            else hipLaunchKernelGGL((k_agg_bn_fwd<2, false>), grid, dim3(1024), 0, s, q);
+        } else {
+            if (bn) hipLaunchKernelGGL((k_agg_bn_fwd<4, true>), grid, dim3(1024), 0, s, q);
+            else hipLaunchKernelGGL((k_agg_bn_fwd<4, false>), grid, dim3(1024), 0, s, q);
+        }
+        DMPNN_CHECK_LAUNCH("k_agg_bn_fwd");
+        if (bn) Z = reinterpret_cast<float*>(ws + L.Z);
+    } else
+        DMPNN_TRY(dmpnn_molagg_fwd(Hv, ldhv, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, Hm, d, stream));
+    if (h.bn_weight && !cols_fused) {
         BnArgs b{Hm, d, reinterpret_cast<float*>(ws + L.Z), d, h.bn_weight, h.bn_bias, h.bn_running_mean, h.bn_running_var, mean, invstd,
                  B, (int)d, h.bn_eps, h.bn_momentum, h.bn_training, h.bn_num_batches_tracked};
         if (B <= kBnRegRows * kBnLanes) hipLaunchKernelGGL(k_bn_fwd<true>, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
         else hipLaunchKernelGGL(k_bn_fwd<false>, dim3((unsigned)((d + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, b);
         DMPNN_CHECK_LAUNCH("k_bn_fwd");
         Z = reinterpret_cast<float*>(ws + L.Z);
+    }
+    if (rows) {
+        const int N = (int)h.dims[1], K = (int)h.dims[0];
+        float* gA1 = reinterpret_cast<float*>(ws + L.gA);
+        float* gZr = reinterpret_cast<float*>(ws + L.gB);
+        RowsArgs r{Z, d, W0f, W0b, h.b[0], h.W[1], h.b[1], h.preds, h.targets, h.weights, h.task_weights, h.lt_mask, h.gt_mask, h.loss,
+                   gA1, gZr, reinterpret_cast<float*>(ws + L.part), L.part_stride, B, N, K, t, h.act, h.act_slope,
+                   g_debug_stamps ? g_debug_stamps + 64 : nullptr};
+        const int widest = N > K ? N : K;
+        if (widest <= 128) hipLaunchKernelGGL(k_head_rows<2>, dim3((unsigned)L.n_part), dim3(256), 0, s, r);
+        else hipLaunchKernelGGL(k_head_rows<5>, dim3((unsigned)L.n_part), dim3(256), 0, s, r);
+        DMPNN_CHECK_LAUNCH("k_head_rows");
+        if (h.gW[0] || h.gb[0]) {   // the hidden layer's weight gradient: in the block's backward launches, or its own product
+            if (defer && h.gW[0] && N % 2 == 0 && K % 2 == 0) {
+                *defer = ExtraWgrad{gA1, N, Z, K, B, N, K, h.b[0] ? 1 : 0, h.gW[0], K, h.b[0] ? h.gb[0] : nullptr, reinterpret_cast<float*>(ws + L.wgrad)};
+            } else {
+                dmpnn_gemm_args g;
+                memset(&g, 0, sizeof(g));
+                g.M = B; g.N = N; g.K1 = K; g.A1 = Z; g.lda1 = K;
+                float* gw = h.gW[0] ? h.gW[0] : reinterpret_cast<float*>(ws + L.Wt);
+                DMPNN_TRY(dmpnn_linear_wgrad(&g, gA1, N, gw, K, h.b[0] ? h.gb[0] : nullptr, ws + L.wgrad, L.wgrad_bytes, stream));
+            }
+        }
+        BnAggBwdArgs q;
+        memset(&q, 0, sizeof(q));
+        q.b = BnBwdArgs{gZr, d, Hm, d, nullptr, d, h.bn_weight, mean, invstd, h.bn_running_mean, h.bn_running_var, h.g_bn_weight, h.g_bn_bias,
+                        B, (int)d, h.bn_eps, h.bn_training};
+        q.gHv = h.gHv; q.ldg = h.ldg; q.bounds = reinterpret_cast<const int*>(ws + L.bounds); q.nV = nV; q.agg_mode = h.agg_mode; q.agg_norm = h.agg_norm;
+        q.part = reinterpret_cast<const float*>(ws + L.part); q.n_part = L.n_part; q.part_stride = L.part_stride; q.tN = t * N; q.t = t;
+        q.gW1 = h.gW[1]; q.gb1 = h.b[1] ? h.gb[1] : nullptr; q.loss_out = h.loss_out;
+        q.dbg = g_debug_stamps ? g_debug_stamps + 96 : nullptr;
+        return launch_bn_agg_bwd(q, h.bn_weight != nullptr, s);
     }
     const float* A[DMPNN_MAX_FFN_LAYERS + 1];
     A[0] = Z;
@@ -637,6 +1369,14 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     }
     const float* gZ = g_cur;   // [B, d]: gradient w.r.t. the fingerprint
     float* gHm = reinterpret_cast<float*>(ws + L.gHm);
+    if (cols_fused) {   // batch norm backward + the broadcast to the atoms' rows: one column kernel
+        BnAggBwdArgs q;
+        memset(&q, 0, sizeof(q));
+        q.b = BnBwdArgs{gZ, d, Hm, d, nullptr, d, h.bn_weight, mean, invstd, h.bn_running_mean, h.bn_running_var, h.g_bn_weight, h.g_bn_bias,
+                        B, (int)d, h.bn_eps, h.bn_training};
+        q.gHv = h.gHv; q.ldg = h.ldg; q.bounds = reinterpret_cast<const int*>(ws + L.bounds); q.nV = nV; q.agg_mode = h.agg_mode; q.agg_norm = h.agg_norm;
+        return launch_bn_agg_bwd(q, h.bn_weight != nullptr, s);
+    }
     if (h.bn_weight) {
         BnBwdArgs b{gZ, d, Hm, d, gHm, d, h.bn_weight, mean, invstd, h.bn_running_mean, h.bn_running_var, h.g_bn_weight, h.g_bn_bias,
                     B, (int)d, h.bn_eps, h.bn_training};

@@ -654,3 +654,56 @@ def test_module_path_head_is_one_autograd_node(bn, agg, tasks, kind, act, gpu_de
     # what the head kernels do not implement falls back to the torch modules: extra descriptors X_d, a frozen-in-eval model
     a.eval()
     assert type(a.loss(bmg, y, w, lt, gt).grad_fn).__name__ != "_HeadLossBackward"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mols,d_h,hidden,tasks,bn,agg,kind,act", [
+    (512, 300, 300, 1, True, "norm", "mse", "relu"),          # the headline model's head: 32 row workgroups, 5 column tiles per wave
+    (1000, 300, 200, 4, False, "mean", "bce", "leakyrelu"),   # 16 rows per thread in the column kernels, N != K, a last row tile of 8
+    (77, 64, 128, 3, True, "sum", "bounded-mse", "elu"),      # 2 column tiles per wave, bounds, missing targets
+    (16, 128, 36, 2, True, "mean", "mae", "tanh"),            # one row workgroup, N not a multiple of 16
+])
+def test_head_in_three_launches_equals_the_nine_launch_chain(n_mols, d_h, hidden, tasks, bn, agg, kind, act, gpu_device, monkeypatch):
+    """Round 5: aggregation + batch norm (+ the hidden layer's weight split) as one column kernel, predictor + criterion + their
+    backward as one row kernel on the f16 pipe (3-product split), batch norm backward + the broadcast to the atoms as one column kernel
+    (``csrc/dmpnn_head.hip``: ``k_agg_bn_fwd`` / ``k_head_rows`` / ``k_bn_agg_bwd``) against the chain of rounds 3-4
+    (``DMPNN_HEAD=chain``: one exact-fp32 contraction per layer): loss, predictions' effect on every gradient (the block's included —
+    ``dl/dH_v`` goes through it), batch-norm buffers."""
+    from chemprop_amd import synth
+
+    cfg = dict(mp=dict(d_h=d_h, activation="relu"), agg=agg, bn=bn, ffn=dict(n_tasks=tasks, hidden_dim=hidden, n_layers=1, activation=act),
+               criterion=kind)
+    if kind == "bce":
+        cfg["predictor"] = "classification"
+    torch.manual_seed(5)
+    a = build_mirror(cfg).to(gpu_device).train()
+    b = build_mirror(cfg).to(gpu_device).train()
+    b.load_state_dict(a.state_dict())
+    bmg = synth.random_batch(n_mols, "qm9", seed=9)
+    bmg.to(gpu_device)
+    gen = torch.Generator().manual_seed(2)
+    y = torch.rand(n_mols, tasks, generator=gen).round() if kind == "bce" else torch.randn(n_mols, tasks, generator=gen)
+    if tasks > 1:
+        y[torch.rand(n_mols, tasks, generator=gen) < 0.2] = float("nan")
+    w = (0.5 + torch.rand(n_mols, 1, generator=gen)).to(gpu_device)
+    bounded = kind.startswith("bounded")
+    lt = (torch.rand(n_mols, tasks, generator=gen) < 0.3).to(gpu_device) if bounded else None
+    gt = (torch.rand(n_mols, tasks, generator=gen) < 0.3).to(gpu_device) if bounded else None
+    y = y.to(gpu_device)
+    monkeypatch.setenv("DMPNN_HEAD", "rows")   # (a shape that falls back to the chain is an error under this value)
+    la = a.loss(bmg, y, w, lt, gt)
+    assert type(la.grad_fn).__name__ == "_HeadLossBackward"
+    la.backward()
+    monkeypatch.setenv("DMPNN_HEAD", "chain")
+    lb = b.loss(bmg, y, w, lt, gt)
+    lb.backward()
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb))), (float(la), float(lb))
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None), k
+        if pa.grad is not None:
+            assert torch.isfinite(pa.grad).all(), k
+            assert parity_err(pa.grad.cpu().numpy(), pb.grad.cpu().numpy()) <= 1e-5, k
+    if bn:
+        for k in ("running_mean", "running_var"):
+            assert parity_err(getattr(a.bn, k).cpu().numpy(), getattr(b.bn, k).cpu().numpy()) <= 1e-6, k
