@@ -409,20 +409,28 @@ __global__ __launch_bounds__(1024) void k_out_all(OutAllArgs q) {
 }
 
 // =====================================================================================================================
-// Round 5: the head of a training step in THREE launches (was nine) for the usual predictor — one hidden layer, <= kOutMaxTasks
-// outputs, <= kRowsMaxB molecules, widths <= kRowsMaxWidth:
-//   k_agg_bn_fwd   per 16 columns: H = agg(H_v) (the rows added in increasing atom order, like k_mol_reduce) and Z = bn(H) on the
-//                  values still in registers; the workgroups behind those SPLIT the hidden layer's weight (fragment-major hi | lo,
-//                  both orientations) — the split rides in this launch like the block's rides in K0, nothing about weights is cached;
-//   k_head_rows    per 16 molecules, everything that is local to a row: A1 = tau(Z W0^T + b0) on the f16 pipe (3-product split,
-//                  fp32 accumulation: the block's arithmetic), P = A1 W1^T + b1, the criterion (every workgroup counts the finite
-//                  targets of the WHOLE batch itself: B t values), dl/dP, dl/dA1, dl/dZ = dl/dA1 . W0 on the f16 pipe again; what
-//                  sums over rows (gW1, gb1, the loss) leaves as one partial per workgroup;
-//   k_bn_agg_bwd   per 16 columns: batch norm backward and the broadcast of dl/dH to the atoms' rows (k_mol_bwd's arithmetic), and
-//                  the partials summed in workgroup order (deterministic).
+// Round 5: the head of a training step in FOUR launches (was nine) for the usual predictor — one hidden layer, <= kOutMaxTasks
+// outputs, <= kRowsMaxB molecules, widths <= kRowsMaxWidth (five launches beyond kFuseAggMols molecules: the aggregation in front):
+//   k_agg_bn_fwd        per 8 | 16 columns: H = agg(H_v) (the rows added in increasing atom order, like k_mol_reduce) and Z = bn(H)
+//                       on the values still in registers; the workgroups behind those SPLIT the hidden layer's weight (fragment-major
+//                       hi | lo, both orientations) — the split rides in this launch like the block's rides in K0: nothing about
+//                       weights is cached;
+//   k_head_rows<., 1>   per (16 molecules, 64 columns): A1 = tau(Z W0^T + b0) on the f16 pipe (3-product split, fp32 accumulation:
+//                       the block's arithmetic);
+//   k_head_rows<., 2>   per (16 molecules, 64 columns), everything that is local to a row from the whole rows of A1: P = A1 W1^T + b1,
+//                       the criterion (every workgroup counts the finite targets of the WHOLE batch itself: B t values), dl/dP,
+//                       dl/dA1, then its slice of dl/dZ = dl/dA1 . W0 on the f16 pipe; what sums over rows (gW1, gb1, the loss)
+//                       leaves as one partial per row block;
+//   k_bn_agg_bwd        per 8 | 16 columns: batch norm backward and the broadcast of dl/dH to the atoms' rows (k_mol_bwd's
+//                       arithmetic); one more workgroup sums the partials in a fixed order (deterministic).
 // The hidden layer's weight gradient rides in the block's backward launches as before (ExtraWgrad) or runs as its own product.
-// DMPNN_HEAD=chain (environment, read per call): the nine-launch chain of rounds 3-4, kept for every other shape.
-constexpr int64_t kRowsMaxB = 1024;      // (16 rows per thread of the column kernels)
+// What set the shapes (profiles/r05_head_*): a CU pulls ~55 GB/s — whole rows per workgroup (32 workgroups, 820 KB of weight
+// fragments each) took 27-33 us, 16 columns x all atoms per workgroup (19 workgroups) 11 us for the aggregation alone; and a
+// conditional load `ok ? p[i] : 0` compiles to a branch with a full wait behind it — every scalar below is a buffer load instead.
+// DMPNN_HEAD=chain (environment, read per call): the nine-launch chain of rounds 3-4, kept for every other shape; =rows: a training
+// call that would take the chain is an error (tests).
+constexpr int64_t kRowsMaxB = 1024;      // (4 molecules per thread of the column kernels)
+constexpr int64_t kFuseAggMols = 512;    // batches up to this size are aggregated inside k_agg_bn_fwd
 constexpr int kRowsMaxWidth = 320;       // WN <= 5 column tiles per wave
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 using mega16::h4;
@@ -511,27 +519,44 @@ struct AggBnArgs {
     HeadSplit split;
     long long* dbg;                        // optional cycle stamps: [0..5] column workgroup 1, [6..9] the first split workgroup
 };
-// Geometry of the two column kernels: a workgroup = 16 columns as 4 column QUADS (16-byte loads and stores: a quarter of the memory
-// instructions of a thread-per-column layout, whose 1 500 four-segment wave loads per CU cost the aggregation 11 us) x 256 row lanes;
-// thread (tq = tid & 3, ty = tid >> 2) holds RR = 2 | 4 molecules (B <= 256 RR) of its quad in registers.
-constexpr int kQLanes = 256;
+// Geometry of the two column kernels: a workgroup = QPW column QUADS (16-byte loads and stores: a quarter of the memory instructions
+// of a thread-per-column layout, whose 1 500 four-segment wave loads per CU cost the aggregation 11 us) x 1024 / QPW row lanes; thread
+// (tq = tid % QPW, ty = tid / QPW) holds RR molecules (B <= RR 1024 / QPW) of its quad in registers.  QPW shrinks as the batch grows:
+// a CU moves ~55 GB/s, and what these kernels move is H_v (aggregation) / dl/dH_v (broadcast) — 5.5 MB at 512 molecules, so the
+// columns are spread over 38 workgroups there (2 quads each) where 64 molecules do with 19 (4 quads).
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-// sums over the 256 row lanes of every column: the 16 row lanes of a wave by shuffles, the 16 waves through LDS
+// sums over the row lanes of every column: the row lanes of a wave by shuffles, the 16 waves through LDS
+template <int QPW>
 __device__ __forceinline__ float4 quad_col_sum(float4 (*red)[4], int tq, float4 v) {
 #pragma unroll
-    for (int off = 4; off < 64; off <<= 1) {
+    for (int off = QPW; off < 64; off <<= 1) {
         v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off); v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
     }
     __syncthreads();   // (the previous use of `red` is over)
-    if ((threadIdx.x & 63) < 4) red[threadIdx.x >> 6][tq] = v;
+    if ((threadIdx.x & 63) < QPW) red[threadIdx.x >> 6][tq] = v;
     __syncthreads();
     float4 s = red[0][tq];
 #pragma unroll 4
     for (int w = 1; w < 16; ++w) s = f4_add(s, red[w][tq]);
     return s;
 }
-template <int RR, bool BN>
+// two sums at once (batch norm backward: sum gY and sum gY xhat): one pair of barriers
+template <int QPW>
+__device__ __forceinline__ void quad_col_sum2(float4 (*red)[2][4], int tq, float4& u, float4& v) {
+#pragma unroll
+    for (int off = QPW; off < 64; off <<= 1) {
+        u.x += __shfl_xor(u.x, off); u.y += __shfl_xor(u.y, off); u.z += __shfl_xor(u.z, off); u.w += __shfl_xor(u.w, off);
+        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off); v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+    }
+    if ((threadIdx.x & 63) < QPW) { red[threadIdx.x >> 6][0][tq] = u; red[threadIdx.x >> 6][1][tq] = v; }
+    __syncthreads();
+    u = red[0][0][tq]; v = red[0][1][tq];
+#pragma unroll 4
+    for (int w = 1; w < 16; ++w) { u = f4_add(u, red[w][0][tq]); v = f4_add(v, red[w][1][tq]); }
+}
+template <int QPW, int RR, bool BN>
 __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
+    constexpr int kQLanes = 1024 / QPW;
     if ((int)blockIdx.x >= q.n_col_blocks) {   // (uniform per workgroup)
         const bool st = q.dbg && (int)blockIdx.x == q.n_col_blocks && threadIdx.x == 0;
         if (st) q.dbg[6] = (long long)__builtin_readcyclecounter();
@@ -547,8 +572,8 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
     stamp();  // 0 entry
     __shared__ float4 red[16][4];
     const BnArgs& a = q.b;
-    const int tq = threadIdx.x & 3, ty = threadIdx.x >> 2;
-    const int c = blockIdx.x * kBnCols + 4 * tq;
+    const int tq = threadIdx.x % QPW, ty = threadIdx.x / QPW;
+    const int c = (blockIdx.x * QPW + tq) * 4;
     const bool ok = c < a.d;   // (d % 4 == 0: a quad is inside or outside)
     const gemm::rsrc_t rBd = gemm::make_rsrc(q.bounds, (unsigned)((2 * a.B + 4) * 4));
     const int flag = col_ldi(rBd, true, 2 * a.B);
@@ -575,11 +600,21 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
     stamp();  // 2 bounds here
     // segment sums: AT atoms of every one of the thread's molecules per round — AT RR independent 16-byte loads in flight (a molecule's
     // rows are still added in increasing atom order: the reference's scatter order)
-    constexpr int AT = 8 / RR * 2;   // RR = 2: 8, RR = 4: 4
+    constexpr int AT = 16 / RR;
     const gemm::rsrc_t rH = gemm::make_rsrc(q.Hv, gemm::clamp_bytes(((int64_t)q.nV * q.ldhv) * 4));
     float4 xs[RR];
 #pragma unroll
     for (int i = 0; i < RR; ++i) xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!q.Hv) {   // (uniform) the aggregate is given (dmpnn_molagg_fwd ran in front: batches whose H_v 19 CUs cannot pull fast enough)
+        if constexpr (!BN) return;
+        const gemm::rsrc_t rX = gemm::make_rsrc(a.X, gemm::clamp_bytes(a.B * a.ldx * 4));
+#pragma unroll
+        for (int i = 0; i < RR; ++i) {
+            const int64_t r = ty + (int64_t)kQLanes * i;
+            xs[i] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rX, (ok && r < a.B) ? (unsigned)(r * a.ldx + c) * 4u : gemm::kOOB, 0, 0));
+        }
+        nmax = 0;
+    }
     for (int s0 = 0; s0 < nmax; s0 += AT) {
         float4 tv[AT][RR];
 #pragma unroll
@@ -602,6 +637,7 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
         if (q.agg_mode == DMPNN_MOLAGG_MEAN && nv[i] > 0) { const float n = (float)nv[i]; y = make_float4(y.x / n, y.y / n, y.z / n, y.w / n); }
         if (q.agg_mode == DMPNN_MOLAGG_NORM) y = make_float4(y.x / q.agg_norm, y.y / q.agg_norm, y.z / q.agg_norm, y.w / q.agg_norm);
         if (flag) y = make_float4(nanv, nanv, nanv, nanv);
+        if (!q.Hv) break;
         xs[i] = (ok && r < a.B) ? y : make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok && r < a.B) *reinterpret_cast<float4*>(a.X_out() + r * a.ldx + c) = y;
     }
@@ -613,7 +649,7 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
         float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < RR; ++i) sm = f4_add(sm, xs[i]);
-        sm = quad_col_sum(red, tq, sm);
+        sm = quad_col_sum<QPW>(red, tq, sm);
         const float fB = (float)a.B;
         mean = make_float4(sm.x / fB, sm.y / fB, sm.z / fB, sm.w / fB);
         float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -623,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
                 const float4 dl = make_float4(xs[i].x - mean.x, xs[i].y - mean.y, xs[i].z - mean.z, xs[i].w - mean.w);
                 qq = f4_add(qq, make_float4(dl.x * dl.x, dl.y * dl.y, dl.z * dl.z, dl.w * dl.w));
             }
-        const float4 ss = quad_col_sum(red, tq, qq);
+        const float4 ss = quad_col_sum<QPW>(red, tq, qq);
         const float4 var = make_float4(ss.x / fB, ss.y / fB, ss.z / fB, ss.w / fB);   // biased: what normalises (nn.BatchNorm1d)
         invstd = make_float4(1.f / sqrtf(var.x + a.eps), 1.f / sqrtf(var.y + a.eps), 1.f / sqrtf(var.z + a.eps), 1.f / sqrtf(var.w + a.eps));
         if (ok && ty == 0) {
@@ -661,16 +697,29 @@ struct BnAggBwdArgs {
     float* gW1; float* gb1; float* loss_out;
     long long* dbg;                        // optional cycle stamps of column workgroup 1
 };
-template <int RR, bool BN>
+template <int QPW, int RR, bool BN>
 __global__ __launch_bounds__(1024) void k_bn_agg_bwd(BnAggBwdArgs q) {
-    __shared__ float4 red[16][4];
-    if ((int)blockIdx.x * kBnCols >= q.b.d) {   // the workgroup behind the columns': what sums over the rows of the batch, in workgroup order
+    constexpr int kQLanes = 1024 / QPW;
+    __shared__ float4 red[16][2][4];
+    if ((int)blockIdx.x * 4 * QPW >= q.b.d) {   // the workgroup behind the columns': what sums over the rows of the batch, in workgroup order
         if (!q.part) return;
-        const int n_out = q.tN + q.t;
-        for (int i = threadIdx.x; i <= n_out; i += 1024) {
+        // four threads per output, each over a quarter of the row blocks in order, joined as ((q0 + q1) + (q2 + q3)): a fixed tree
+        const int n_out = q.tN + q.t, sub = threadIdx.x & 3, per = (q.n_part + 3) / 4;
+        for (int i0 = 0; i0 <= n_out; i0 += 256) {
+            const int i = i0 + (threadIdx.x >> 2);
+            const gemm::rsrc_t rP = gemm::make_rsrc(q.part, gemm::clamp_bytes((int64_t)q.n_part * q.part_stride * 4));
+            float v[16];   // (n_part <= kRowsMaxB / 16 = 64 row blocks)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int w = sub * per + u;
+                v[u] = col_ldf(rP, i <= n_out && u < per && w < q.n_part, (int64_t)w * q.part_stride + i);
+            }
             float s = 0.f;
-#pragma unroll 8
-            for (int w = 0; w < q.n_part; ++w) s += q.part[(int64_t)w * q.part_stride + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (sub != 0 || i > n_out) continue;
             if (i < q.tN) { if (q.gW1) q.gW1[i] = s; }
             else if (i < n_out) { if (q.gb1) q.gb1[i - q.tN] = s; }
             else {   // the loss: sum / count (no finite target: 0 / 0 = NaN, like the reference)
@@ -682,8 +731,8 @@ __global__ __launch_bounds__(1024) void k_bn_agg_bwd(BnAggBwdArgs q) {
         return;
     }
     const BnBwdArgs& a = q.b;
-    const int tq = threadIdx.x & 3, ty = threadIdx.x >> 2;
-    const int c = blockIdx.x * kBnCols + 4 * tq;
+    const int tq = threadIdx.x % QPW, ty = threadIdx.x / QPW;
+    const int c = (blockIdx.x * QPW + tq) * 4;
     const bool ok = c < a.d;
     int n_stamp = 0;
     auto stamp = [&]() {
@@ -723,8 +772,7 @@ __global__ __launch_bounds__(1024) void k_bn_agg_bwd(BnAggBwdArgs q) {
             s2 = f4_add(s2, make_float4(gs[i].x * xh[i].x, gs[i].y * xh[i].y, gs[i].z * xh[i].z, gs[i].w * xh[i].w));
         }
         stamp();  // 2 data here
-        s1 = quad_col_sum(red, tq, s1);
-        s2 = quad_col_sum(red, tq, s2);
+        quad_col_sum2<QPW>(red, tq, s1, s2);
         stamp();  // 3 column sums
         if (ok && ty == 0) {
             if (a.g_gamma) *reinterpret_cast<float4*>(a.g_gamma + c) = s2;
@@ -759,280 +807,283 @@ __global__ __launch_bounds__(1024) void k_bn_agg_bwd(BnAggBwdArgs q) {
 
 struct RowsArgs {
     const float* Z; int64_t ldz;           // [B, K] the predictor's input
-    SplitW W0f, W0b;                       // W0 [N, K] as N rows over K (forward) and as K rows over N (data gradient)
+    SplitW W0f, W0b;                       // W0 [N, K] as N rows over K (forward) and as K rows over N (data gradient; see HeadSplit)
     const float* b0; const float* W1; const float* b1;   // [N] | NULL, [t, N], [t] | NULL
+    float* A1;                             // [B, N] the hidden layer's output tau(Z W0^T + b0): written by PH 1, read by PH 2
     float* preds;                          // [B, t]
     const float* T; const float* w; const float* tw; const unsigned char* lt; const unsigned char* gt; int kind;
     float* gA1; float* gZ;                 // [B, N], [B, K]
-    float* part; int part_stride;          // per workgroup: gW1 [t][N] | gb1 [t] | loss sum | number of finite targets
+    float* part; int part_stride;          // per row block: gW1 [t][N] | gb1 [t] | loss sum | number of finite targets
     int64_t B; int N, K, t, act; float slope;
-    long long* dbg;                        // optional cycle stamps of workgroup 1
+    long long* dbg;                        // optional cycle stamps of workgroup (1, 1)
 };
-template <int WN>
+// The predictor + criterion + their backward as TWO launches over (row block of 16 molecules) x (slice of 64 columns):
+//   PH 1  A1[:, slice] = tau(Z W0^T + b0)                                                          160 workgroups at 512 x 300
+//   PH 2  everything that is local to a row, redone by each of the row block's slices from the whole rows of A1 (16 x N values:
+//         cheaper than a launch): P = A1 W1^T + b1, the criterion (every workgroup counts the finite targets of the WHOLE batch
+//         itself), dl/dP, dl/dA1 — then ITS slice of dl/dZ = dl/dA1 . W0, of dl/dA1 (for the hidden layer's weight gradient) and
+//         of the row block's partial of gW1; slice 0 also writes the predictions and the partials of gb1 and of the loss.
+// Both contractions on the f16 pipe (3-product split, fp32 accumulation: the block's arithmetic), the weight fragments of a wave's 16
+// columns requested in one go at kernel entry.  (ONE launch per row block holding whole rows was built first: 27-33 us — a CU pulls
+// its 820 KB of weight fragments at ~55 GB/s, profiles/r05_head_rowblock_stamps.txt; sliced, a workgroup needs 82 KB per contraction.)
+template <int WNT, int PH>
 __global__ __launch_bounds__(256) void k_head_rows(RowsArgs a) {
-    constexpr int BN = 64 * WN, NCH = BN / 32, TS = NCH * 128 + 16, LDA = BN + 4;
-    __shared__ __attribute__((aligned(16))) unsigned char As[16 * TS];   // split operand tile: the rows of Z, later of dl/dA1
-    __shared__ __attribute__((aligned(16))) float A1s[16 * LDA];         // fp32 tile: A1, later dl/dA1
+    constexpr int BN = 64 * WNT, NCH = BN / 32, TS = NCH * 128 + 16, LDA = BN + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char As[16 * TS];   // split operand tile: the rows of Z (PH 1) / of dl/dA1 (PH 2)
+    __shared__ __attribute__((aligned(16))) float A1s[PH == 2 ? 16 * LDA : 4];   // fp32 tile: A1, later dl/dA1
     __shared__ float inv_s[16];                                          // 1 / scale of the split tile's rows
-    __shared__ float Ps[16][kOutMaxTasks], gPs[16][kOutMaxTasks];
-    __shared__ float W1s[kOutMaxTasks][BN];                              // W1 [t, N], zero beyond
+    __shared__ float Ps[16][kOutMaxTasks];
+    __shared__ __attribute__((aligned(16))) float gPs[16][kOutMaxTasks];
+    __shared__ float W1s[kOutMaxTasks][PH == 2 ? BN : 1];                // W1 [t, N], zero beyond
     __shared__ float red2[2][4];
     __shared__ float tot[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int cs = blockIdx.y;                  // column slice; wave w owns the 16 columns of tile T
+    const int T = cs * 4 + wave, col = T * 16 + li;
     const int nrows = (int)(a.B - row0 < 16 ? a.B - row0 : 16);
     const int t = a.t;
     int n_stamp = 0;
     auto stamp = [&]() {
-        if (a.dbg && blockIdx.x == 1 && threadIdx.x == 0 && n_stamp < 12) a.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        if (a.dbg && blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0 && n_stamp < 8) a.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
         ++n_stamp;
     };
     stamp();  // 0 entry
-
-    // fp32 rows -> split tile.  Thread (row i = tid >> 4, p = tid & 15) holds columns 4 p + 64 j: the row's maximum by four shuffles.
-    auto split_rows = [&](const float4 (&x)[WN]) {
+    // (buffer loads: an offset out of range reads 0 without a branch or a select on the data — nothing in the request section consumes a
+    //  loaded value, so every request is out before the first wait; a NULL array is a zero-length buffer)
+    auto buf = [&](const void* ptr, int64_t bytes) { return gemm::make_rsrc(ptr ? ptr : a.Z, ptr ? (unsigned)bytes : 0u); };
+    auto ldf = [&](gemm::rsrc_t r, bool ok, int64_t idx) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)idx * 4u : gemm::kOOB, 0, 0));
+    };
+    // rows of an fp32 [B, width] tensor: thread (row i = tid >> 4, p = tid & 15) takes columns 4 p + 64 j
+    auto load_rows = [&](const float* X, int64_t ld, int width, float4 (&x)[WNT]) {
+        const int i = tid >> 4, p = tid & 15;
+        const gemm::rsrc_t rX = gemm::make_rsrc(X + row0 * ld, (unsigned)(nrows * ld * 4));
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            const int c4 = 4 * p + 64 * j;
+            x[j] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rX, (i < nrows && c4 < width) ? (unsigned)(i * ld + c4) * 4u : gemm::kOOB, 0, 0));
+        }
+    };
+    // fp32 rows -> split tile (the row's maximum by four shuffles)
+    auto split_rows = [&](const float4 (&x)[WNT]) {
         const int i = tid >> 4, p = tid & 15;
         float mx = 0.f;
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WNT; ++j)
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[j].x), fabsf(x[j].y))), fmaxf(fabsf(x[j].z), fabsf(x[j].w)));
         for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        const float s = mega16::scale_for(mx);
-        if (p == 0) inv_s[i] = 1.f / s;
+        const float sr = mega16::scale_for(mx);
+        if (p == 0) inv_s[i] = 1.f / sr;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = 4 * p + 64 * j;
+        for (int j = 0; j < WNT; ++j) {
+            const int c4 = 4 * p + 64 * j;
             h4 hi, lo;
-            mega16::split4(x[j], s, hi, lo);
-            unsigned char* d = As + i * TS + (col >> 5) * 128 + (col & 31) * 2;
+            mega16::split4(x[j], sr, hi, lo);
+            unsigned char* d = As + i * TS + (c4 >> 5) * 128 + (c4 & 31) * 2;
             *reinterpret_cast<h4*>(d) = hi;
             *reinterpret_cast<h4*>(d + 64) = lo;
         }
     };
-    // acc[ct] += (tile s_row) . (W s_col)^T; wave w owns column tiles w WN .. w WN + WN - 1.  The weight fragments come straight from
-    // memory (L2: the split was written by the launch in front) through a register ring of HALF the contraction, requested long before
-    // they are needed — `request` goes out before the operand tile is even loaded (32 workgroups: nobody else hides this latency);
-    // branch-free and fully unrolled (chunks beyond W.nc: out-of-range loads return 0, the tile's columns there are 0).
-    constexpr int D = NCH / 2;
-    struct Ring {
-        h8 h[D][WN], l[D][WN];
-        gemm::rsrc_t rW;
-        unsigned off[WN];
-        int nc;
-    };
-    auto load_b = [&](Ring& R, int c, int slot) {
+    // the wave's weight fragments: every chunk of column tile T (chunks beyond W.nc and tiles beyond n_out: out of range, 0)
+    h8 wh[NCH], wl[NCH];
+    auto request = [&](const SplitW& W, int n_out) {
+        const gemm::rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(((n_out + 15) / 16) * W.nc * 2048));
+        const unsigned o0 = (unsigned)T * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const unsigned o = c < R.nc ? R.off[ct] + (unsigned)c * 2048u : gemm::kOOB;
-            R.h[slot][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(R.rW, o, 0, 0));
-            R.l[slot][ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(R.rW, c < R.nc ? o + 1024u : gemm::kOOB, 0, 0));
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned o = (c < W.nc && T * 16 < n_out) ? o0 + (unsigned)c * 2048u : gemm::kOOB;
+            wh[c] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
+            wl[c] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o == gemm::kOOB ? o : o + 1024u, 0, 0));
         }
     };
-    auto request = [&](Ring& R, const SplitW& W, int n_out) {
-        R.rW = gemm::make_rsrc(W.p, (unsigned)(((n_out + 15) / 16) * W.nc * 2048));   // column tiles beyond: 0
-        R.nc = W.nc;
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct) R.off[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
-#pragma unroll
-        for (int c = 0; c < D; ++c) load_b(R, c, c);
-    };
-    auto contract = [&](f32x4 (&acc)[WN], Ring& R) {
+    auto contract = [&]() {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();   // the split tile (and inv_s) is complete
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const unsigned char* pa = As + li * TS + c * 128 + lg * 16;
             const h8 ah = *reinterpret_cast<const h8*>(pa), al = *reinterpret_cast<const h8*>(pa + 64);
-#pragma unroll
-            for (int ct = 0; ct < WN; ++ct) {
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, R.h[c % D][ct], acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, R.l[c % D][ct], acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, R.h[c % D][ct], acc[ct], 0, 0, 0);
-            }
-            if (c + D < NCH) load_b(R, c + D, c % D);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[c], acc, 0, 0, 0);
         }
+        return acc;
     };
-    // ---- A1 = tau(Z W0^T + b0) ----
-    // requests in the order they are needed (vmcnt counts in order): the rows of Z, W1, then the first half of W0's fragments — all
-    // unconditional (clamped addresses, selects on the data), so that the waits in front of the split are exact
-    // (buffer loads: an offset out of range reads 0 without a branch or a select on the data — nothing here consumes a loaded value, so
-    //  every request below is out before the first wait; a NULL array is a zero-length buffer)
-    auto buf = [&](const void* ptr, int64_t bytes) { return gemm::make_rsrc(ptr ? ptr : a.Z, ptr ? (unsigned)bytes : 0u); };
-    float4 zx[WN];
-    {
-        const int i = tid >> 4, p = tid & 15;
-        const gemm::rsrc_t rZ = gemm::make_rsrc(a.Z + row0 * a.ldz, (unsigned)(nrows * a.ldz * 4));
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = 4 * p + 64 * j;
-            zx[j] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rZ, (i < nrows && col < a.K) ? (unsigned)(i * a.ldz + col) * 4u : gemm::kOOB, 0, 0));
-        }
-    }
-    auto ldf = [&](gemm::rsrc_t r, bool ok, int64_t idx) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? (unsigned)idx * 4u : gemm::kOOB, 0, 0));
-    };
-    // the criterion's inputs: element (row ei, task ej) of this workgroup's rows on thread tid < 16 t; the targets of the WHOLE batch
-    // (B t <= 4 096 values, 16 per thread) for the count of finite ones
-    const int ei = tid / t, ej = tid - ei * t;
-    const bool elem = tid < 16 * t && ei < nrows;
-    const int64_t egi = (row0 + ei) * t + ej;
-    const gemm::rsrc_t rT = buf(a.T, a.B * t * 4);
-    const float ey = ldf(rT, elem, egi);
-    const float ewv = ldf(buf(a.w, a.B * 4), elem, row0 + ei), etv = ldf(buf(a.tw, t * 4), elem, ej);
-    const unsigned char elt = __builtin_amdgcn_raw_buffer_load_b8(buf(a.lt, a.B * t), elem ? (unsigned)egi : gemm::kOOB, 0, 0);
-    const unsigned char egt = __builtin_amdgcn_raw_buffer_load_b8(buf(a.gt, a.B * t), elem ? (unsigned)egi : gemm::kOOB, 0, 0);
-    constexpr int NCNT = (int)(kRowsMaxB * kOutMaxTasks / 256);
-    float cv[NCNT];
-#pragma unroll
-    for (int u = 0; u < NCNT; ++u) cv[u] = ldf(rT, tid + 256 * u < a.B * t, tid + 256 * u);
-    constexpr int NW1 = kOutMaxTasks * BN / 256;
-    float w1v[NW1];
-    const gemm::rsrc_t rW1 = gemm::make_rsrc(a.W1, (unsigned)(t * a.N * 4));
-#pragma unroll
-    for (int u = 0; u < NW1; ++u) {
-        const int idx = tid + 256 * u, j = idx / BN, n = idx - j * BN;
-        w1v[u] = ldf(rW1, j < t && n < a.N, j * a.N + n);
-    }
-    // per-column constants: 1 / s_n of W0's rows for the thread's columns of dl/dA1 (n = tid, tid + 256) and for its fragments' columns
-    const gemm::rsrc_t rIS = gemm::make_rsrc(a.W0f.inv_scale, (unsigned)(a.N * 4)), rB0 = buf(a.b0, a.N * 4);
-    constexpr int NCOL = (BN + 255) / 256;
-    float isn[NCOL];
-#pragma unroll
-    for (int u = 0; u < NCOL; ++u) isn[u] = ldf(rIS, tid + 256 * u < a.N, tid + 256 * u);
-    float isw1[WN], bv1[WN];
-#pragma unroll
-    for (int ct = 0; ct < WN; ++ct) {
-        const int n = (wave * WN + ct) * 16 + li;
-        isw1[ct] = ldf(rIS, n < a.N, n);
-        bv1[ct] = ldf(rB0, n < a.N, n);
-    }
-    Ring R;
-    request(R, a.W0f, a.N);
-    __builtin_amdgcn_sched_barrier(0);   // (requests above, consumers below)
-    stamp();  // 1 requests out
-#pragma unroll
-    for (int u = 0; u < NW1; ++u) { const int idx = tid + 256 * u; W1s[idx / BN][idx % BN] = w1v[u]; }   // (read by every row of the tile, twice)
-    split_rows(zx);
-    stamp();  // 2 Z split (its rows landed)
-    f32x4 acc[WN];
-#pragma unroll
-    for (int ct = 0; ct < WN; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    contract(acc, R);
-    stamp();  // 3 first contraction issued
-    request(R, a.W0b, a.K);   // (the data gradient's first half: in flight under everything up to its contraction)
-#pragma unroll
-    for (int ct = 0; ct < WN; ++ct) {
-        const int n = (wave * WN + ct) * 16 + li;
-        const bool okn = n < a.N;
-        const float isw = isw1[ct], bv = bv1[ct];
+
+    if constexpr (PH == 1) {
+        float4 zx[WNT];
+        load_rows(a.Z, a.ldz, a.K, zx);
+        const float isw = ldf(gemm::make_rsrc(a.W0f.inv_scale, (unsigned)(a.N * 4)), col < a.N, col);
+        const float bv = ldf(buf(a.b0, a.N * 4), col < a.N, col);
+        request(a.W0f, a.N);
+        __builtin_amdgcn_sched_barrier(0);   // (requests above, consumers below)
+        stamp();  // 1 requests out
+        split_rows(zx);
+        const f32x4 acc = contract();
+        stamp();  // 2 contraction issued
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * lg + r;
-            const float y = apply_act_small(acc[ct][r] * (isw * inv_s[i]) + bv, a.act, a.slope);
-            A1s[i * LDA + n] = (okn && i < nrows) ? y : 0.f;
+            if (col < a.N && i < nrows) a.A1[(row0 + i) * a.N + col] = apply_act_small(acc[r] * (isw * inv_s[i]) + bv, a.act, a.slope);
         }
-    }
-    __syncthreads();
-    stamp();  // 4 A1 in the tile
-    // ---- P = A1 W1^T + b1: thread (row i, part p) sums the columns n = p mod 16 ----
-    {
-        const int i = tid >> 4, p = tid & 15;
-        float s[kOutMaxTasks] = {0.f, 0.f, 0.f, 0.f};
-        for (int n = p; n < a.N; n += 16) {
-            const float x = A1s[i * LDA + n];
+        stamp();  // 3 end
+        return;
+    } else {
+        // ---- requests: the rows of A1, the criterion's inputs (element (row ei, task ej) of this row block on thread tid < 16 t; the
+        // targets of the WHOLE batch — B t <= 4 096 values, 16 per thread — for the count of finite ones), W1, 1 / s_n of W0's rows for
+        // the thread's columns of dl/dA1 (n = tid, tid + 256), the fragments of the wave's 16 columns of W0 ----
+        float4 ax[WNT];
+        load_rows(a.A1, a.N, a.N, ax);
+        const int ei = tid / t, ej = tid - ei * t;
+        const bool elem = tid < 16 * t && ei < nrows;
+        const int64_t egi = (row0 + ei) * t + ej;
+        const gemm::rsrc_t rT = buf(a.T, a.B * t * 4);
+        const float ey = ldf(rT, elem, egi);
+        const float ewv = ldf(buf(a.w, a.B * 4), elem, row0 + ei), etv = ldf(buf(a.tw, t * 4), elem, ej);
+        const unsigned char elt = __builtin_amdgcn_raw_buffer_load_b8(buf(a.lt, a.B * t), elem ? (unsigned)egi : gemm::kOOB, 0, 0);
+        const unsigned char egt = __builtin_amdgcn_raw_buffer_load_b8(buf(a.gt, a.B * t), elem ? (unsigned)egi : gemm::kOOB, 0, 0);
+        constexpr int NCNT = (int)(kRowsMaxB * kOutMaxTasks / 256);
+        float cv[NCNT];
 #pragma unroll
-            for (int j = 0; j < kOutMaxTasks; ++j) s[j] += x * W1s[j][n];
+        for (int u = 0; u < NCNT; ++u) cv[u] = ldf(rT, tid + 256 * u < a.B * t, tid + 256 * u);
+        constexpr int NW1 = kOutMaxTasks * BN / 256;
+        float w1v[NW1];
+        const gemm::rsrc_t rW1 = gemm::make_rsrc(a.W1, (unsigned)(t * a.N * 4));
+#pragma unroll
+        for (int u = 0; u < NW1; ++u) {
+            const int idx = tid + 256 * u, j = idx / BN, n = idx - j * BN;
+            w1v[u] = ldf(rW1, j < t && n < a.N, j * a.N + n);
         }
+        const gemm::rsrc_t rIS = gemm::make_rsrc(a.W0f.inv_scale, (unsigned)(a.N * 4));
+        constexpr int NCOL = (BN + 255) / 256;
+        float isn[NCOL];
 #pragma unroll
-        for (int j = 0; j < kOutMaxTasks; ++j) {
-            for (int off = 1; off < 16; off <<= 1) s[j] += __shfl_xor(s[j], off);
-            if (p == 0 && j < t) {
-                const float v = s[j] + (a.b1 ? a.b1[j] : 0.f);
-                Ps[i][j] = v;
-                if (i < nrows) a.preds[(row0 + i) * t + j] = v;
+        for (int u = 0; u < NCOL; ++u) isn[u] = ldf(rIS, tid + 256 * u < a.N, tid + 256 * u);
+        float b1v[kOutMaxTasks];
+#pragma unroll
+        for (int j = 0; j < kOutMaxTasks; ++j) b1v[j] = ldf(buf(a.b1, t * 4), j < t, j);
+        request(a.W0b, a.K);
+        __builtin_amdgcn_sched_barrier(0);   // (requests above, consumers below)
+        stamp();  // 1 requests out
+#pragma unroll
+        for (int u = 0; u < NW1; ++u) { const int idx = tid + 256 * u; W1s[idx / BN][idx % BN] = w1v[u]; }   // (read by every row of the tile, twice)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) *reinterpret_cast<float4*>(A1s + (tid >> 4) * LDA + 4 * (tid & 15) + 64 * j) = ax[j];   // (zero beyond N and beyond the batch)
+        __syncthreads();
+        stamp();  // 2 A1 in the tile
+        // ---- P = A1 W1^T + b1: thread (row i, part p) sums the columns n = p mod 16 ----
+        {
+            const int i = tid >> 4, p = tid & 15;
+            float sp[kOutMaxTasks] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < BN / 16; ++q) {   // (columns beyond N: zeros in both tiles)
+                const int n = p + 16 * q;
+                const float x = A1s[i * LDA + n];
+#pragma unroll
+                for (int j = 0; j < kOutMaxTasks; ++j) sp[j] += x * W1s[j][n];
+            }
+#pragma unroll
+            for (int j = 0; j < kOutMaxTasks; ++j) {
+                for (int off = 1; off < 16; off <<= 1) sp[j] += __shfl_xor(sp[j], off);
+                if (p == 0 && j < t) {
+                    const float v = sp[j] + b1v[j];
+                    Ps[i][j] = v;
+                    if (cs == 0 && i < nrows) a.preds[(row0 + i) * t + j] = v;
+                }
             }
         }
-    }
-    stamp();  // 5 predictions
-    // ---- criterion (k_loss's arithmetic per element): this workgroup's rows; the count over the whole batch ----
-    float sm = 0.f, sl = 0.f;
+        // ---- criterion (k_loss's arithmetic per element): this row block's rows; the count over the whole batch ----
+        float sm = 0.f, sl = 0.f;
 #pragma unroll
-    for (int u = 0; u < NCNT; ++u) sm += (tid + 256 * u < a.B * t && isfinite(cv[u])) ? 1.f : 0.f;
-    __syncthreads();   // Ps
-    float ef = 0.f, ep = 0.f;
-    const bool efin = elem && isfinite(ey);
-    if (elem) {
-        ep = Ps[ei][ej];
-        if ((elt && ep < ey) || (egt && ep > ey)) ep = ey;
-        ef = (a.w ? ewv : 1.f) * (a.tw ? etv : 1.f);
-        if (efin) sl = loss_value(a.kind, ep, ey) * ef;
-    }
-    for (int off = 32; off > 0; off >>= 1) { sl += __shfl_xor(sl, off); sm += __shfl_xor(sm, off); }
-    if (lane == 0) { red2[0][wave] = sl; red2[1][wave] = sm; }
-    __syncthreads();
-    if (tid == 0) {
-        tot[0] = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
-        tot[1] = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
-        float* pp = a.part + (int64_t)blockIdx.x * a.part_stride + t * a.N + t;
-        pp[0] = tot[0]; pp[1] = tot[1];
-    }
-    __syncthreads();
-    if (tid < 16 * t) gPs[ei][ej] = efin ? loss_deriv(a.kind, ep, ey) * ef * (1.f / tot[1]) : 0.f;
-    __syncthreads();
-    stamp();  // 6 criterion
-    // ---- the output layer's backward on this workgroup's rows: thread = column n of A1 ----
-    //   dl/dA1[i][n] = (sum_j gP[i][j] W1[j][n]) tau'(A1[i][n]),  partial gW1[j][n] = sum_i gP[i][j] A1[i][n],  partial gb1[j] = sum_i gP[i][j]
-#pragma unroll
-    for (int u = 0; u < NCOL; ++u) {
-        const int n = tid + 256 * u;
-        if (n >= BN) break;
-        const bool okn = n < a.N;
-        const float isn_c = isn[u];
-        float w1[kOutMaxTasks], gw[kOutMaxTasks];
-#pragma unroll
-        for (int j = 0; j < kOutMaxTasks; ++j) { w1[j] = W1s[j][n]; gw[j] = 0.f; }
-        for (int i = 0; i < 16; ++i) {
-            const float x = A1s[i * LDA + n];
-            float g = 0.f;
-#pragma unroll
-            for (int j = 0; j < kOutMaxTasks; ++j)
-                if (j < t) { const float gp = gPs[i][j]; g += gp * w1[j]; gw[j] += gp * x; }
-            const float gv = okn ? g * act_grad_from_out(x, a.act, a.slope) : 0.f;
-            A1s[i * LDA + n] = gv * isn_c;   // (the operand of dl/dA1 . W0 carries W0's row scales on its reduction index: see HeadSplit)
-            if (okn && i < nrows) a.gA1[(row0 + i) * a.N + n] = gv;
+        for (int u = 0; u < NCNT; ++u) sm += (tid + 256 * u < a.B * t && isfinite(cv[u])) ? 1.f : 0.f;
+        __syncthreads();   // Ps
+        float ef = 0.f, ep = 0.f;
+        const bool efin = elem && isfinite(ey);
+        if (elem) {
+            ep = Ps[ei][ej];
+            if ((elt && ep < ey) || (egt && ep > ey)) ep = ey;
+            ef = (a.w ? ewv : 1.f) * (a.tw ? etv : 1.f);
+            if (efin) sl = loss_value(a.kind, ep, ey) * ef;
         }
-        if (okn)
-            for (int j = 0; j < t; ++j) a.part[(int64_t)blockIdx.x * a.part_stride + (int64_t)j * a.N + n] = gw[j];
-    }
-    if (tid < t) {
-        float sb = 0.f;
-        for (int i = 0; i < 16; ++i) sb += gPs[i][tid];
-        a.part[(int64_t)blockIdx.x * a.part_stride + t * a.N + tid] = sb;
-    }
-    __syncthreads();
-    stamp();  // 7 output layer's backward
-    // ---- dl/dZ = dl/dA1 . W0 ----
-    {
-        float4 gx[WN];
+        for (int off = 32; off > 0; off >>= 1) { sl += __shfl_xor(sl, off); sm += __shfl_xor(sm, off); }
+        if (lane == 0) { red2[0][wave] = sl; red2[1][wave] = sm; }
+        __syncthreads();
+        if (tid == 0) {
+            tot[0] = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
+            tot[1] = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
+            if (cs == 0) {
+                float* pp = a.part + (int64_t)blockIdx.x * a.part_stride + t * a.N + t;
+                pp[0] = tot[0]; pp[1] = tot[1];
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * t) gPs[ei][ej] = efin ? loss_deriv(a.kind, ep, ey) * ef * (1.f / tot[1]) : 0.f;
+        else if (tid < 16 * kOutMaxTasks && tid % kOutMaxTasks >= t) gPs[tid / kOutMaxTasks][tid % kOutMaxTasks] = 0.f;   // (columns beyond t: zero)
+        __syncthreads();
+        stamp();  // 3 criterion
+        // ---- the output layer's backward on this row block: thread = column n of A1 (all of them: the operand of the contraction below) ----
+        //   dl/dA1[i][n] = (sum_j gP[i][j] W1[j][n]) tau'(A1[i][n]),  partial gW1[j][n] = sum_i gP[i][j] A1[i][n],  partial gb1[j] = sum_i gP[i][j]
+        // what leaves for memory is the slice's: columns [64 cs, 64 cs + 64)
+        // (the 16 rows of a column in registers, dl/dP as 16-byte rows: straight-line code — a loop with the activation's switch inside
+        //  waited for every LDS round trip, 6 us)
+        const bool simple_act = a.act != DMPNN_ACT_TANH && a.act != DMPNN_ACT_ELU;
+        const float neg = a.act == DMPNN_ACT_NONE ? 1.f : (a.act == DMPNN_ACT_RELU ? 0.f : a.slope);   // tau' for y <= 0 (ReLU class)
+        float4 gp4[16];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) gx[j] = *reinterpret_cast<const float4*>(A1s + (tid >> 4) * LDA + 4 * (tid & 15) + 64 * j);
-        split_rows(gx);
-    }
-    stamp();  // 8 dl/dA1 split
+        for (int i = 0; i < 16; ++i) gp4[i] = *reinterpret_cast<const float4*>(&gPs[i][0]);
 #pragma unroll
-    for (int ct = 0; ct < WN; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    contract(acc, R);
-    stamp();  // 9 second contraction issued
+        for (int u = 0; u < NCOL; ++u) {
+            const int n = tid + 256 * u;
+            if (n >= BN) break;
+            const bool okn = n < a.N, mine = okn && (n >> 6) == cs;
+            const float isn_c = isn[u];
+            const float4 w1 = make_float4(W1s[0][n], W1s[1][n], W1s[2][n], W1s[3][n]);   // (rows beyond t are zero)
+            float xv[16], gv[16];
 #pragma unroll
-    for (int ct = 0; ct < WN; ++ct) {
-        const int k = (wave * WN + ct) * 16 + li;
-        const bool okk = k < a.K;
+            for (int i = 0; i < 16; ++i) xv[i] = A1s[i * LDA + n];
+            float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 gp = gp4[i];   // (columns beyond t are zero)
+                const float g = ((gp.x * w1.x + gp.y * w1.y) + gp.z * w1.z) + gp.w * w1.w;
+                gw.x += gp.x * xv[i]; gw.y += gp.y * xv[i]; gw.z += gp.z * xv[i]; gw.w += gp.w * xv[i];
+                const float dv = simple_act ? (xv[i] > 0.f ? 1.f : neg) : act_grad_from_out(xv[i], a.act, a.slope);
+                gv[i] = okn ? g * dv : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                A1s[i * LDA + n] = gv[i] * isn_c;   // (the operand of dl/dA1 . W0 carries W0's row scales on its reduction index: see HeadSplit)
+                if (mine && i < nrows) a.gA1[(row0 + i) * a.N + n] = gv[i];
+            }
+            if (mine) {
+                const float gwv[4] = {gw.x, gw.y, gw.z, gw.w};
+                for (int j = 0; j < t; ++j) a.part[(int64_t)blockIdx.x * a.part_stride + (int64_t)j * a.N + n] = gwv[j];
+            }
+        }
+        if (cs == 0 && tid < t) {
+            float sb = 0.f;
+            for (int i = 0; i < 16; ++i) sb += gPs[i][tid];
+            a.part[(int64_t)blockIdx.x * a.part_stride + t * a.N + tid] = sb;
+        }
+        __syncthreads();
+        stamp();  // 4 output layer's backward
+        // ---- dl/dZ[:, slice] = dl/dA1 . W0 ----
+        {
+            float4 gx[WNT];
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) gx[j] = *reinterpret_cast<const float4*>(A1s + (tid >> 4) * LDA + 4 * (tid & 15) + 64 * j);
+            split_rows(gx);
+        }
+        const f32x4 acc = contract();
+        stamp();  // 5 contraction issued
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * lg + r;
-            if (okk && i < nrows) a.gZ[(row0 + i) * a.K + k] = acc[ct][r] * inv_s[i];
+            if (col < a.K && i < nrows) a.gZ[(row0 + i) * a.K + col] = acc[r] * inv_s[i];
         }
+        stamp();  // 6 end
     }
-    stamp();  // 10 end
 }
 
 // out[c][r] = in[r][c] for a weight matrix (<= a few hundred KB)
@@ -1144,15 +1195,27 @@ int dmpnn_head(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* s
 }  // extern "C"
 
 namespace {
+// quads per workgroup / molecules per thread of the column kernels: (4, 1) up to 256 molecules, (2, 1) up to 512, (2, 2) up to 1 024
+// (DMPNN_HEAD_QPW=4 | 2: the A/B switch)
+int col_quads(int64_t B) {
+    const char* e = getenv("DMPNN_HEAD_QPW");
+    if (e && !strcmp(e, "4")) return 4;
+    if (e && !strcmp(e, "2")) return 2;
+    return B <= 256 ? 4 : 2;
+}
+#define DMPNN_COL_LAUNCH(KERNEL, QPW_V, B_V, BN_V, GRID, STREAM, ARGS)                                                   \
+    do {                                                                                                                \
+        const int rr_ = (int)(((B_V) * (QPW_V) + 1023) / 1024);                                                          \
+        if ((QPW_V) == 4 && rr_ <= 1) { if (BN_V) hipLaunchKernelGGL((KERNEL<4, 1, true>), GRID, dim3(1024), 0, STREAM, ARGS); else hipLaunchKernelGGL((KERNEL<4, 1, false>), GRID, dim3(1024), 0, STREAM, ARGS); } \
+        else if ((QPW_V) == 4 && rr_ <= 2) { if (BN_V) hipLaunchKernelGGL((KERNEL<4, 2, true>), GRID, dim3(1024), 0, STREAM, ARGS); else hipLaunchKernelGGL((KERNEL<4, 2, false>), GRID, dim3(1024), 0, STREAM, ARGS); } \
+        else if ((QPW_V) == 4) { if (BN_V) hipLaunchKernelGGL((KERNEL<4, 4, true>), GRID, dim3(1024), 0, STREAM, ARGS); else hipLaunchKernelGGL((KERNEL<4, 4, false>), GRID, dim3(1024), 0, STREAM, ARGS); } \
+        else if (rr_ <= 1) { if (BN_V) hipLaunchKernelGGL((KERNEL<2, 1, true>), GRID, dim3(1024), 0, STREAM, ARGS); else hipLaunchKernelGGL((KERNEL<2, 1, false>), GRID, dim3(1024), 0, STREAM, ARGS); } \
+        else { if (BN_V) hipLaunchKernelGGL((KERNEL<2, 2, true>), GRID, dim3(1024), 0, STREAM, ARGS); else hipLaunchKernelGGL((KERNEL<2, 2, false>), GRID, dim3(1024), 0, STREAM, ARGS); } \
+    } while (0)
 int launch_bn_agg_bwd(const BnAggBwdArgs& q, bool bn, hipStream_t s) {
-    const dim3 grid((unsigned)((q.b.d + kBnCols - 1) / kBnCols) + (q.part ? 1u : 0u));   // (+ 1: the row kernel's partials)
-    if (q.b.B <= 2 * kQLanes) {
-        if (bn) hipLaunchKernelGGL((k_bn_agg_bwd<2, true>), grid, dim3(1024), 0, s, q);
-        else hipLaunchKernelGGL((k_bn_agg_bwd<2, false>), grid, dim3(1024), 0, s, q);
-    } else {
-        if (bn) hipLaunchKernelGGL((k_bn_agg_bwd<4, true>), grid, dim3(1024), 0, s, q);
-        else hipLaunchKernelGGL((k_bn_agg_bwd<4, false>), grid, dim3(1024), 0, s, q);
-    }
+    const int qpw = col_quads(q.b.B);
+    const dim3 grid((unsigned)((q.b.d + 4 * qpw - 1) / (4 * qpw)) + (q.part ? 1u : 0u));   // (+ 1: the row kernels' partials)
+    DMPNN_COL_LAUNCH(k_bn_agg_bwd, qpw, q.b.B, bn, grid, s, q);
     DMPNN_CHECK_LAUNCH("k_bn_agg_bwd");
     return DMPNN_OK;
 }
@@ -1216,8 +1279,15 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
         memset(&q, 0, sizeof(q));
         q.b = BnArgs{Hm, d, reinterpret_cast<float*>(ws + L.Z), d, h.bn_weight, h.bn_bias, h.bn_running_mean, h.bn_running_var, mean, invstd,
                      B, (int)d, h.bn_eps, h.bn_momentum, h.bn_training, h.bn_num_batches_tracked};
-        q.Hv = Hv; q.ldhv = ldhv; q.nV = nV; q.bounds = reinterpret_cast<const int*>(ws + L.bounds); q.agg_mode = h.agg_mode; q.agg_norm = h.agg_norm;
-        q.n_col_blocks = (int)((d + kBnCols - 1) / kBnCols);
+        // the aggregation inside this launch up to 512 molecules (one launch less: 159 against 166 us per step at 64 molecules, 221
+        // against 220 at 512 — the column workgroups pull H_v at ~55 GB/s each, 5.5 MB over 38 of them); beyond that
+        // dmpnn_molagg_fwd — every CU — runs in front (DMPNN_HEAD_AGG=fused | split: the A/B switch)
+        const char* agg_env = getenv("DMPNN_HEAD_AGG");
+        const bool fuse_agg = agg_env ? !strcmp(agg_env, "fused") : B <= kFuseAggMols;
+        if (!fuse_agg) DMPNN_TRY(dmpnn_molagg_fwd(Hv, ldhv, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, Hm, d, stream));
+        q.Hv = fuse_agg ? Hv : nullptr; q.ldhv = ldhv; q.nV = nV; q.bounds = reinterpret_cast<const int*>(ws + L.bounds); q.agg_mode = h.agg_mode; q.agg_norm = h.agg_norm;
+        const int qpw = col_quads(B);
+        q.n_col_blocks = (int)((d + 4 * qpw - 1) / (4 * qpw));
         q.dbg = g_debug_stamps ? g_debug_stamps + 80 : nullptr;
         int split_blocks = 0;
         if (rows) {
@@ -1227,13 +1297,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
         }
         const dim3 grid((unsigned)(q.n_col_blocks + split_blocks));
         const bool bn = h.bn_weight != nullptr;
-        if (B <= 2 * kQLanes) {
-            if (bn) hipLaunchKernelGGL((k_agg_bn_fwd<2, true>), grid, dim3(1024), 0, s, q);
-            else hipLaunchKernelGGL((k_agg_bn_fwd<2, false>), grid, dim3(1024), 0, s, q);
-        } else {
-            if (bn) hipLaunchKernelGGL((k_agg_bn_fwd<4, true>), grid, dim3(1024), 0, s, q);
-            else hipLaunchKernelGGL((k_agg_bn_fwd<4, false>), grid, dim3(1024), 0, s, q);
-        }
+        if (fuse_agg || bn || split_blocks) DMPNN_COL_LAUNCH(k_agg_bn_fwd, qpw, B, bn, grid, s, q);
         DMPNN_CHECK_LAUNCH("k_agg_bn_fwd");
         if (bn) Z = reinterpret_cast<float*>(ws + L.Z);
     } else
@@ -1250,12 +1314,20 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
         const int N = (int)h.dims[1], K = (int)h.dims[0];
         float* gA1 = reinterpret_cast<float*>(ws + L.gA);
         float* gZr = reinterpret_cast<float*>(ws + L.gB);
-        RowsArgs r{Z, d, W0f, W0b, h.b[0], h.W[1], h.b[1], h.preds, h.targets, h.weights, h.task_weights, h.lt_mask, h.gt_mask, h.loss,
-                   gA1, gZr, reinterpret_cast<float*>(ws + L.part), L.part_stride, B, N, K, t, h.act, h.act_slope,
+        RowsArgs r{Z, d, W0f, W0b, h.b[0], h.W[1], h.b[1], reinterpret_cast<float*>(ws + L.act[0]), h.preds, h.targets, h.weights, h.task_weights,
+                   h.lt_mask, h.gt_mask, h.loss, gA1, gZr, reinterpret_cast<float*>(ws + L.part), L.part_stride, B, N, K, t, h.act, h.act_slope,
                    g_debug_stamps ? g_debug_stamps + 64 : nullptr};
         const int widest = N > K ? N : K;
-        if (widest <= 128) hipLaunchKernelGGL(k_head_rows<2>, dim3((unsigned)L.n_part), dim3(256), 0, s, r);
-        else hipLaunchKernelGGL(k_head_rows<5>, dim3((unsigned)L.n_part), dim3(256), 0, s, r);
+        const dim3 g1((unsigned)L.n_part, (unsigned)((N + 63) / 64)), g2((unsigned)L.n_part, (unsigned)((widest + 63) / 64));
+        if (widest <= 128) {
+            hipLaunchKernelGGL((k_head_rows<2, 1>), g1, dim3(256), 0, s, r);
+            if (r.dbg) r.dbg += 8;
+            hipLaunchKernelGGL((k_head_rows<2, 2>), g2, dim3(256), 0, s, r);
+        } else {
+            hipLaunchKernelGGL((k_head_rows<5, 1>), g1, dim3(256), 0, s, r);
+            if (r.dbg) r.dbg += 8;
+            hipLaunchKernelGGL((k_head_rows<5, 2>), g2, dim3(256), 0, s, r);
+        }
         DMPNN_CHECK_LAUNCH("k_head_rows");
         if (h.gW[0] || h.gb[0]) {   // the hidden layer's weight gradient: in the block's backward launches, or its own product
             if (defer && h.gW[0] && N % 2 == 0 && K % 2 == 0) {

@@ -1,4 +1,4 @@
-"""Round 5: the whole-model training step at 512 QM9-shaped molecules with the head in three launches (default) against the nine-launch
+"""Round 5: the whole-model training step at 512 QM9-shaped molecules with the head in the row / column kernels (default) against the nine-launch
 chain (DMPNN_HEAD=chain, read per call): wall time per step of FusedTrainer.step and of the module path, alternating; the losses of 20
 steps from the same start under both forms.  With `prof` as argument: 200 fused steps only (the target of rocprofv3 --kernel-trace)."""
 import os, sys, time
@@ -33,8 +33,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "stamps":   # cycle stamps of one workgr
     tr = FusedTrainer(model(), lr=1e-4)
     for _ in range(5): tr.step(b, y)
     buf = torch.zeros(128, dtype=torch.int64, device=dev)
-    names = {64: ("k_head_rows, workgroup 1", ["entry", "requests out", "Z split (rows landed)", "first contraction issued", "A1 in the tile", "predictions",
-                                               "criterion", "output layer's backward", "dl/dA1 split", "second contraction issued", "end"]),
+    names = {64: ("k_head_rows<.., 1>, workgroup (1, 1)", ["entry", "requests out", "contraction issued", "end"]),
+             72: ("k_head_rows<.., 2>, workgroup (1, 1)", ["entry", "requests out", "A1 in the tile", "criterion", "output layer's backward", "contraction issued", "end"]),
              80: ("k_agg_bn_fwd, column workgroup 1", ["entry", "requests out", "bounds here", "aggregated", "statistics", "end"]),
              86: ("k_agg_bn_fwd, first split workgroup", ["entry", "end"]),
              96: ("k_bn_agg_bwd, column workgroup 1", ["entry", "requests out", "data here", "column sums", "rows issued"])}
@@ -66,7 +66,7 @@ for form in ("rows", "chain"):
 for k in g1["rows"]:
     a, c = g1["rows"][k], g1["chain"][k]
     print(f"  step-1 gradient {k:34s} max|rows - chain| / max|chain| = {float((a - c).abs().max() / c.abs().max().clamp_min(1e-30)):.2e}")
-print("losses, three launches:", " ".join(f"{v:.6f}" for v in losses["rows"][::4]))
+print("losses, the row / column kernels:", " ".join(f"{v:.6f}" for v in losses["rows"][::4]))
 print("losses, chain         :", " ".join(f"{v:.6f}" for v in losses["chain"][::4]))
 print("max relative difference over 20 steps:", max(abs(a - c) / max(abs(c), 1e-12) for a, c in zip(losses["rows"], losses["chain"])))
 
@@ -86,11 +86,13 @@ def module():
     sync.allreduce(); opt.step()
 
 
-for rep in range(3):
-    for form in ("chain", "default"):
-        if form == "chain": os.environ["DMPNN_HEAD"] = "chain"
-        else: os.environ.pop("DMPNN_HEAD", None)
+FORMS = [("chain", {"DMPNN_HEAD": "chain"}), ("default", {}), ("agg-split", {"DMPNN_HEAD_AGG": "split"}), ("qpw4", {"DMPNN_HEAD_QPW": "4"})]
+for rep in range(2):
+    for form, env in FORMS:
+        for k in ("DMPNN_HEAD", "DMPNN_HEAD_AGG", "DMPNN_HEAD_QPW"): os.environ.pop(k, None)
+        os.environ.update(env)
         for name, fn in (("fused", fused), ("module", module)):
+            if name == "module" and form in ("agg-split", "qpw4"): continue
             for _ in range(30): fn()
             torch.cuda.synchronize()
             n = 300
@@ -98,4 +100,4 @@ for rep in range(3):
             for _ in range(n): fn()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            print(f"[{form:7s}] {name:7s}: {1e6 * (t2 - t0) / n:7.1f} us/step")
+            print(f"[{form:9s}] {name:7s}: {1e6 * (t2 - t0) / n:7.1f} us/step")

@@ -657,18 +657,20 @@ def test_module_path_head_is_one_autograd_node(bn, agg, tasks, kind, act, gpu_de
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_mols,d_h,hidden,tasks,bn,agg,kind,act", [
-    (512, 300, 300, 1, True, "norm", "mse", "relu"),          # the headline model's head: 32 row workgroups, 5 column tiles per wave
-    (1000, 300, 200, 4, False, "mean", "bce", "leakyrelu"),   # 16 rows per thread in the column kernels, N != K, a last row tile of 8
-    (77, 64, 128, 3, True, "sum", "bounded-mse", "elu"),      # 2 column tiles per wave, bounds, missing targets
-    (16, 128, 36, 2, True, "mean", "mae", "tanh"),            # one row workgroup, N not a multiple of 16
+@pytest.mark.parametrize("n_mols,d_h,hidden,tasks,bn,agg,kind,act,switches", [
+    (512, 300, 300, 1, True, "norm", "mse", "relu", {}),          # the headline model's head: 32 row blocks x 5 column slices, 2 quads per column workgroup
+    (1000, 300, 200, 4, False, "mean", "bce", "leakyrelu", {}),   # 2 molecules per thread in the column kernels, N != K, a last row block of 8, the aggregation in front
+    (77, 64, 128, 3, True, "sum", "bounded-mse", "elu", {}),      # 2 operand chunks of 64 columns, 4 quads per column workgroup, bounds, missing targets
+    (16, 128, 36, 2, True, "mean", "mae", "tanh", {}),            # one row block, N not a multiple of 16
+    (512, 300, 300, 2, True, "mean", "mse", "relu", {"DMPNN_HEAD_AGG": "split", "DMPNN_HEAD_QPW": "4"}),   # the forms the size rules do not pick here
+    (1000, 300, 300, 1, True, "norm", "mse", "relu", {"DMPNN_HEAD_AGG": "fused", "DMPNN_HEAD_QPW": "4"}),  # ... 4 molecules per thread
 ])
-def test_head_in_three_launches_equals_the_nine_launch_chain(n_mols, d_h, hidden, tasks, bn, agg, kind, act, gpu_device, monkeypatch):
+def test_head_in_row_and_column_kernels_equals_the_nine_launch_chain(n_mols, d_h, hidden, tasks, bn, agg, kind, act, switches, gpu_device, monkeypatch):
     """Round 5: aggregation + batch norm (+ the hidden layer's weight split) as one column kernel, predictor + criterion + their
-    backward as one row kernel on the f16 pipe (3-product split), batch norm backward + the broadcast to the atoms as one column kernel
-    (``csrc/dmpnn_head.hip``: ``k_agg_bn_fwd`` / ``k_head_rows`` / ``k_bn_agg_bwd``) against the chain of rounds 3-4
-    (``DMPNN_HEAD=chain``: one exact-fp32 contraction per layer): loss, predictions' effect on every gradient (the block's included —
-    ``dl/dH_v`` goes through it), batch-norm buffers."""
+    backward as two launches over (row block) x (column slice) on the f16 pipe (3-product split), batch norm backward + the broadcast to
+    the atoms (+ the sums over row blocks) as one column kernel (``csrc/dmpnn_head.hip``: ``k_agg_bn_fwd`` / ``k_head_rows<., 1 | 2>`` /
+    ``k_bn_agg_bwd``) against the chain of rounds 3-4 (``DMPNN_HEAD=chain``: one exact-fp32 contraction per layer): loss, every
+    gradient (the block's included — ``dl/dH_v`` goes through it), batch-norm buffers."""
     from chemprop_amd import synth
 
     cfg = dict(mp=dict(d_h=d_h, activation="relu"), agg=agg, bn=bn, ffn=dict(n_tasks=tasks, hidden_dim=hidden, n_layers=1, activation=act),
@@ -691,6 +693,8 @@ def test_head_in_three_launches_equals_the_nine_launch_chain(n_mols, d_h, hidden
     gt = (torch.rand(n_mols, tasks, generator=gen) < 0.3).to(gpu_device) if bounded else None
     y = y.to(gpu_device)
     monkeypatch.setenv("DMPNN_HEAD", "rows")   # (a shape that falls back to the chain is an error under this value)
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
     la = a.loss(bmg, y, w, lt, gt)
     assert type(la.grad_fn).__name__ == "_HeadLossBackward"
     la.backward()
