@@ -359,6 +359,9 @@ def main():
                                  "model": f"MPNN(BondMessagePassing(d_h={args.hidden}, depth={args.depth}), NormAggregation, BatchNorm1d, "
                                           "RegressionFFN(1 task, hidden 300), MSE) + Adam",
                                  "plan": "K0 inside the step's C call, on the critical path (the tile table, 11 us)",
+                                 "head": "4 launches (round 5): k_agg_bn_fwd (aggregation + batch norm + the hidden layer's weight split), "
+                                         "k_head_rows<., 1 | 2> (predictor + criterion + their backward over row block x column slice, f16 pipe), "
+                                         "k_bn_agg_bwd; DMPNN_HEAD=chain: the 9 launches of rounds 3-4",
                                  "note": "fused: ONE C call (dmpnn_train_step) enqueues K0, the block's forward, aggregation, batch norm, the "
                                          "predictor, the loss, the backward pass of all of it and the Adam update; module path (round 4): "
                                          "MPNN.loss(batch).backward() through torch autograd — TWO nodes, the block (dmpnn_forward / "

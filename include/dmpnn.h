@@ -624,8 +624,9 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream);
 int dmpnn_dropout_keep(uint64_t seed, int32_t site, int64_t row, int64_t col, float p);
 
 int dmpnn_version(void);
-/* Debug aid: a device buffer of 32 int64 that workgroup 0 of the whole-forward tile kernel fills with
- * shader-clock stamps at its phase boundaries (NULL switches it off; never set in production). */
+/* Debug aid: a device buffer of 128 int64 that one workgroup of a kernel fills with shader-clock stamps at its phase boundaries
+ * (NULL switches it off; never set in production): [0, 32) the whole-forward tile kernel / the per-step fused kernel, [32, 64) K0,
+ * [64, 80) the head's row kernels, [80, 96) and [96, 112) its column kernels (scripts/probe_stamps*.py, scripts/probe_head_rows.py). */
 int dmpnn_debug_timestamps(void* device_buf);
 const char* dmpnn_last_error_string(void);
 /* Number of kernels the last dmpnn_forward on this thread enqueued (diagnostics). */

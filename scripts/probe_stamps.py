@@ -12,7 +12,7 @@ bmg = synth.random_batch(nm, "qm9", seed=1000); bmg.to(dev)
 print("molecules", nm, "edges", bmg.E.shape[0])
 mp = BondMessagePassing().to(dev).eval()
 plan = engine.GraphPlan.from_bmg(bmg)
-buf = torch.zeros(64, dtype=torch.int64, device=dev)
+buf = torch.zeros(128, dtype=torch.int64, device=dev)
 fw = lambda: engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega", mfma="split16", keep=("keep" in sys.argv))
 with torch.no_grad():
     for _ in range(5): fw()

@@ -20,7 +20,7 @@ bmg.to(dev)
 mp = BondMessagePassing().to(dev).eval()
 plan = engine.GraphPlan.from_bmg(bmg, light=True)
 W = (mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias)
-buf = torch.zeros(64, dtype=torch.int64, device=dev)
+buf = torch.zeros(128, dtype=torch.int64, device=dev)
 names = ["entry", "everything requested (+ x contraction)", "operand tile landed", "MFMA loop issued", "unscaled", "all waves through the contraction",
          "tile written", "segment pass 1", "end (message rows written)"]
 with torch.no_grad():
