@@ -346,6 +346,13 @@ size_t wsplit16_bytes(int64_t M, int64_t C);
 // One more weight-gradient product for the launches of a backward pass on the f16 pipe (the predictor's first layer in a training
 // step: gW[N, K] = Z^T A, gb = colsum(Z) — 512 rows are 16 chunks beside the block's 1 140): rides in k_wsplit16 / k_wgrad16 /
 // k_wgrad_reduce_multi instead of three launches of its own.  ws: >= extra_wgrad_ws_floats(M, N, K + ones) floats, 16-byte aligned.
+// Round 5: what dmpnn_train_step hands the tile kernels' training forward so that it leaves the per-molecule aggregate of its output
+// (Mega16K::agg_*): set on the calling thread around its dmpnn_forward call, taken (and cleared) by the tile kernel's launcher.
+struct AggRide {
+    float* Hm; int ld; const int64_t* batch; int* table; int n_mols; int mode; float norm;   // table: dmpnn_molagg's first | end | flag | done
+    bool taken;
+};
+extern thread_local AggRide g_agg_ride;
 struct ExtraWgrad {
     const float* Z; int64_t ldz; const float* A; int64_t lda; int64_t M; int N, K, ones;
     float* gW; int64_t ldgw; float* gb; float* ws;

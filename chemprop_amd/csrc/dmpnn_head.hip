@@ -515,6 +515,7 @@ __device__ __forceinline__ void head_split_block(const HeadSplit& a, int blk) {
 struct AggBnArgs {
     BnArgs b;                              // X = H [B, d] (written here), Y = Z (BN only)
     const float* Hv; int64_t ldhv; int64_t nV; const int* bounds; int agg_mode; float agg_norm;
+    int use_done;                          // 1: bounds[2 B + 4 + m] != 0 — X already holds molecule m's aggregate (the forward tile kernel wrote it)
     int n_col_blocks;                      // workgroups [0, n_col_blocks): columns; the others: the weight split (32 rows of W0 each)
     HeadSplit split;
     long long* dbg;                        // optional cycle stamps: [0..5] column workgroup 1, [6..9] the first split workgroup
@@ -575,14 +576,15 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
     const int tq = threadIdx.x % QPW, ty = threadIdx.x / QPW;
     const int c = (blockIdx.x * QPW + tq) * 4;
     const bool ok = c < a.d;   // (d % 4 == 0: a quad is inside or outside)
-    const gemm::rsrc_t rBd = gemm::make_rsrc(q.bounds, (unsigned)((2 * a.B + 4) * 4));
+    const gemm::rsrc_t rBd = gemm::make_rsrc(q.bounds, (unsigned)((3 * a.B + 4) * 4));
     const int flag = col_ldi(rBd, true, 2 * a.B);
-    int v0[RR], nv[RR];
+    int v0[RR], nv[RR], dn[RR];
 #pragma unroll
     for (int i = 0; i < RR; ++i) {
         const int64_t r = ty + (int64_t)kQLanes * i;
         v0[i] = col_ldi(rBd, r < a.B, r);
         nv[i] = col_ldi(rBd, r < a.B, a.B + r);
+        dn[i] = col_ldi(rBd, q.use_done && r < a.B, 2 * a.B + 4 + r);
     }
     // (batch norm's per-column constants: requested now, used behind the statistics)
     auto ldq = [&](const float* p) {
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
 #pragma unroll
     for (int i = 0; i < RR; ++i) {
         nv[i] -= v0[i];
-        if (nv[i] < 0 || !ok) nv[i] = 0;
+        if (nv[i] < 0 || !ok || dn[i]) nv[i] = 0;
         nmax = nv[i] > nmax ? nv[i] : nmax;
     }
     stamp();  // 2 bounds here
@@ -605,15 +607,24 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
     float4 xs[RR];
 #pragma unroll
     for (int i = 0; i < RR; ++i) xs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const gemm::rsrc_t rX = gemm::make_rsrc(a.X, gemm::clamp_bytes(a.B * a.ldx * 4));
     if (!q.Hv) {   // (uniform) the aggregate is given (dmpnn_molagg_fwd ran in front: batches whose H_v 19 CUs cannot pull fast enough)
         if constexpr (!BN) return;
-        const gemm::rsrc_t rX = gemm::make_rsrc(a.X, gemm::clamp_bytes(a.B * a.ldx * 4));
 #pragma unroll
         for (int i = 0; i < RR; ++i) {
             const int64_t r = ty + (int64_t)kQLanes * i;
             xs[i] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rX, (ok && r < a.B) ? (unsigned)(r * a.ldx + c) * 4u : gemm::kOOB, 0, 0));
         }
         nmax = 0;
+    } else if (q.use_done) {   // (uniform) ... or given for the molecules the forward tile kernel carried (done): the others are summed below
+        float4 hx[RR];
+#pragma unroll
+        for (int i = 0; i < RR; ++i) {
+            const int64_t r = ty + (int64_t)kQLanes * i;
+            hx[i] = gemm::as_f4(__builtin_amdgcn_raw_buffer_load_b128(rX, (ok && r < a.B && dn[i]) ? (unsigned)(r * a.ldx + c) * 4u : gemm::kOOB, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < RR; ++i) xs[i] = hx[i];
     }
     for (int s0 = 0; s0 < nmax; s0 += AT) {
         float4 tv[AT][RR];
@@ -634,12 +645,14 @@ __global__ __launch_bounds__(1024) void k_agg_bn_fwd(AggBnArgs q) {
     for (int i = 0; i < RR; ++i) {
         const int64_t r = ty + (int64_t)kQLanes * i;
         float4 y = xs[i];
-        if (q.agg_mode == DMPNN_MOLAGG_MEAN && nv[i] > 0) { const float n = (float)nv[i]; y = make_float4(y.x / n, y.y / n, y.z / n, y.w / n); }
-        if (q.agg_mode == DMPNN_MOLAGG_NORM) y = make_float4(y.x / q.agg_norm, y.y / q.agg_norm, y.z / q.agg_norm, y.w / q.agg_norm);
-        if (flag) y = make_float4(nanv, nanv, nanv, nanv);
         if (!q.Hv) break;
+        if (!dn[i]) {   // (a molecule the tile kernel wrote arrives divided)
+            if (q.agg_mode == DMPNN_MOLAGG_MEAN && nv[i] > 0) { const float n = (float)nv[i]; y = make_float4(y.x / n, y.y / n, y.z / n, y.w / n); }
+            if (q.agg_mode == DMPNN_MOLAGG_NORM) y = make_float4(y.x / q.agg_norm, y.y / q.agg_norm, y.z / q.agg_norm, y.w / q.agg_norm);
+        }
+        if (flag) y = make_float4(nanv, nanv, nanv, nanv);
         xs[i] = (ok && r < a.B) ? y : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && r < a.B) *reinterpret_cast<float4*>(a.X_out() + r * a.ldx + c) = y;
+        if (ok && r < a.B && (!dn[i] || flag)) *reinterpret_cast<float4*>(a.X_out() + r * a.ldx + c) = y;
     }
     stamp();  // 3 aggregated
     if constexpr (!BN) return;
@@ -743,7 +756,7 @@ __global__ __launch_bounds__(1024) void k_bn_agg_bwd(BnAggBwdArgs q) {
     // every request of the kernel first (buffer loads: no branch, no wait in between)
     float4 gs[RR], xr[RR];
     int v0[RR], v1[RR];
-    const gemm::rsrc_t rBd = gemm::make_rsrc(q.bounds, (unsigned)((2 * a.B + 4) * 4));
+    const gemm::rsrc_t rBd = gemm::make_rsrc(q.bounds, (unsigned)((3 * a.B + 4) * 4));
     const gemm::rsrc_t rG = gemm::make_rsrc(a.gY, gemm::clamp_bytes(a.B * a.ldgy * 4)), rX = gemm::make_rsrc(a.X, gemm::clamp_bytes(a.B * a.ldx * 4));
 #pragma unroll
     for (int i = 0; i < RR; ++i) {
@@ -1185,7 +1198,7 @@ size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h) {
 }  // extern "C"
 
 namespace {
-int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done, ExtraWgrad* defer);
+int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done, ExtraWgrad* defer, bool agg_rode = false);
 }  // namespace
 
 extern "C" {
@@ -1222,7 +1235,9 @@ int launch_bn_agg_bwd(const BnAggBwdArgs& q, bool bn, hipStream_t s) {
 // defer (a whole training step only): the weight gradient of the predictor's FIRST layer is not launched here but described in
 // *defer — it rides in the launches of the block's backward pass (ExtraWgrad); its inputs (the layer's output gradient, the
 // layer's input) stay untouched in the workspace until then
-int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done, ExtraWgrad* defer) {
+// agg_rode (a whole training step only): the forward tile kernel wrote the aggregate of the molecules it carried into the workspace's H
+// and marked them in the bounds table's done[] (AggRide)
+int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* stream, bool bounds_done, ExtraWgrad* defer, bool agg_rode) {
     DMPNN_CHECK_ARG(hp != nullptr, "head: null args");
     const dmpnn_head_args& h = *hp;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1283,7 +1298,8 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
         // against 220 at 512 — the column workgroups pull H_v at ~55 GB/s each, 5.5 MB over 38 of them); beyond that
         // dmpnn_molagg_fwd — every CU — runs in front (DMPNN_HEAD_AGG=fused | split: the A/B switch)
         const char* agg_env = getenv("DMPNN_HEAD_AGG");
-        const bool fuse_agg = agg_env ? !strcmp(agg_env, "fused") : B <= kFuseAggMols;
+        const bool fuse_agg = agg_rode || (agg_env ? !strcmp(agg_env, "fused") : B <= kFuseAggMols);   // (rode: only what the tile kernel left is summed here)
+        q.use_done = agg_rode ? 1 : 0;
         if (!fuse_agg) DMPNN_TRY(dmpnn_molagg_fwd(Hv, ldhv, nV, d, B, ws + L.bounds, h.agg_mode, h.agg_norm, Hm, d, stream));
         q.Hv = fuse_agg ? Hv : nullptr; q.ldhv = ldhv; q.nV = nV; q.bounds = reinterpret_cast<const int*>(ws + L.bounds); q.agg_mode = h.agg_mode; q.agg_norm = h.agg_norm;
         const int qpw = col_quads(B);
@@ -1495,15 +1511,34 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
                 DMPNN_TRY(dmpnn_prepare_with_batch(a->edge_index, a->rev_edge_index, a->batch, f.n_atoms, f.n_edges, const_cast<void*>(f.plan),
                                                    a->plan_bytes, stream));
         }
+        // the aggregate of the block's output leaves with the tile kernel's tiles (AggRide) when K0 wrote the bounds table (and zeroed
+        // its done[]) and the head is going to take its column kernels on this shape; DMPNN_HEAD_AGG=fused | split switches it off
+        bool agg_rode = false;
+        {
+            const dmpnn_head_args& h = a->head;
+            const char* he = getenv("DMPNN_HEAD");
+            const char* ae = getenv("DMPNN_HEAD_AGG");
+            if (bounds_done && h.ws && h.n_mols > 0 && h.n_mols <= kRowsMaxB && h.d_h % 4 == 0 && h.d_h == f.d_h && !f.W_d && !(he && !strcmp(he, "chain")) &&
+                !(ae && strcmp(ae, "tile"))) {
+                const HeadLayout HL = head_layout(h);
+                unsigned char* hws = static_cast<unsigned char*>(h.ws);
+                g_agg_ride = AggRide{reinterpret_cast<float*>(hws + HL.Hm), (int)h.d_h, a->batch, reinterpret_cast<int*>(hws + HL.bounds), (int)h.n_mols,
+                                     h.agg_mode, h.agg_norm, false};
+            }
+        }
+        int frc;
         if (split_done) {   // (the weight pre-split rode in K0's launch)
             dmpnn_fwd_args f2 = f;
             f2.flags |= DMPNN_F_WSPLIT_READY;
-            DMPNN_TRY(dmpnn_forward(&f2, stream));
+            frc = dmpnn_forward(&f2, stream);
         } else
-            DMPNN_TRY(dmpnn_forward(&f, stream));
+            frc = dmpnn_forward(&f, stream);
+        agg_rode = g_agg_ride.taken;
+        g_agg_ride = AggRide{nullptr, 0, nullptr, nullptr, 0, 0, 0.f, false};
+        if (frc != DMPNN_OK) return frc;
         // (a whole step in one call: the first predictor layer's weight gradient rides in the block's backward launches; a staged
         //  step — data parallel — has the head's gradients final after this stage, so nothing is deferred there)
-        DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, bounds_done, (stages & DMPNN_STEP_BACKWARD) ? &rider : nullptr));
+        DMPNN_TRY(head_run(&a->head, f.out, f.ldout, stream, bounds_done, (stages & DMPNN_STEP_BACKWARD) ? &rider : nullptr, agg_rode));
     }
     if (stages & DMPNN_STEP_BACKWARD) {
         bool rode = false;

@@ -19,6 +19,7 @@ DMPNN_DEFINE_MEGA16(5, false, false)
 
 // (per calling thread: a diagnostic hook, never shared mutable state between threads that drive the library)
 thread_local long long* g_debug_stamps = nullptr;
+thread_local AggRide g_agg_ride = {nullptr, 0, nullptr, nullptr, 0, 0, 0.f, false};
 
 namespace {
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -153,6 +154,13 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
         G.mrow_slot = (long long)nE * G.tsr;
     }
     g.dbg = g_debug_stamps;
+    if ((a.flags & DMPNN_F_KEEP) && g_agg_ride.Hm && g_agg_ride.n_mols > 0 && out == a.out && N % 4 == 0) {
+        // (dmpnn_train_step: the aggregate of every molecule of a regular tile leaves with the tile, Mega16K::agg_*)
+        G.agg_Hm = g_agg_ride.Hm; G.agg_ld = g_agg_ride.ld; G.agg_batch = reinterpret_cast<const long long*>(g_agg_ride.batch);
+        G.agg_bounds = g_agg_ride.table; G.agg_done = g_agg_ride.table + 2 * g_agg_ride.n_mols + 4; G.agg_n_mols = g_agg_ride.n_mols;
+        G.agg_mode = g_agg_ride.mode; G.agg_norm = g_agg_ride.norm;
+        g_agg_ride.taken = true;
+    }
     if (a.dropout_p > 0.f && a.dropout_p < 1.f) {  // (validated by dmpnn_forward: training forward, ReLU-class activation, no W_d)
         g.drop_thr = drop_threshold(a.dropout_p); g.drop_scale = 1.f / (1.f - a.dropout_p);
         g.seed_lo = (unsigned)(a.dropout_seed & 0xFFFFFFFFull); g.seed_hi = (unsigned)(a.dropout_seed >> 32);

@@ -68,6 +68,12 @@ struct Mega16K {
     // (rt WN + ct) 4 + r of wave w of tile t (64 words per wave, 256 per tile) is the ballot of "element (row rt 16 + 4 lg + r, column
     // 16 (w WN + ct) + li) > 0" over the wave's lanes.  Slot 0 = H0, slot t = H^(t); bits_slot = words per slot.
     unsigned long long* keep_bits; long long bits_slot;
+    // Round 5 (a whole training step, dmpnn_train_step): the per-molecule aggregate of the finalize output straight from the tile — a tile
+    // holds whole molecules, their H_v rows are in LDS when the kernel ends.  agg_Hm [n_mols][agg_ld] receives agg(H_v) of every molecule
+    // of a regular tile (rows added in increasing atom order: dmpnn_molagg_fwd's arithmetic) and agg_done[m] = 1; a molecule the tile
+    // kernel does not carry to its end (a spill tile, an unused slot) keeps done = 0 and is aggregated by the head's column kernel from
+    // H_v as before.  agg_bounds: first[n_mols] | end[n_mols] (the table K0 wrote); null agg_Hm: off.
+    float* agg_Hm; int agg_ld; const long long* agg_batch; const int* agg_bounds; int* agg_done; int agg_n_mols; int agg_mode; float agg_norm;
 };
 
 template <int I, int N, class F>
@@ -986,6 +992,30 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         __syncthreads();
         tile_to_global(g.out, va, g.ldout, na);
         stamp();  // output stored
+        if constexpr (KEEP) {
+            if (G.agg_Hm) {   // (uniform) the tile's molecules: batch[va] .. batch[vb - 1]; T still holds their rows
+                const long long m0 = G.agg_batch[va], m1 = G.agg_batch[vb - 1];
+                if (m0 >= 0 && m1 < G.agg_n_mols && m1 - m0 < BA) {
+                    const int nm = (int)(m1 - m0) + 1;
+                    for (int it = tid; it < nm * QN; it += kThreads) {
+                        const int ml = it / QN, q = it - ml * QN;
+                        if (q >= qn) continue;
+                        const long long m = m0 + ml;
+                        const int f = G.agg_bounds[m] - va, e = G.agg_bounds[G.agg_n_mols + m] - va;
+                        if (f < 0 || e > na || e <= f) continue;   // (not inside this tile, or no atoms: the head's own aggregation)
+                        float4 sacc = *reinterpret_cast<const float4*>(T + f * LDC + 4 * q);   // include_self=False: the first addend is copied
+                        for (int a = f + 1; a < e; ++a) {
+                            const float4 x = *reinterpret_cast<const float4*>(T + a * LDC + 4 * q);
+                            sacc.x += x.x; sacc.y += x.y; sacc.z += x.z; sacc.w += x.w;
+                        }
+                        if (G.agg_mode == DMPNN_MOLAGG_MEAN) { const float n = (float)(e - f); sacc.x /= n; sacc.y /= n; sacc.z /= n; sacc.w /= n; }
+                        if (G.agg_mode == DMPNN_MOLAGG_NORM) { sacc.x /= G.agg_norm; sacc.y /= G.agg_norm; sacc.z /= G.agg_norm; sacc.w /= G.agg_norm; }
+                        *reinterpret_cast<float4*>(G.agg_Hm + m * G.agg_ld + 4 * q) = sacc;
+                        if (q == 0) G.agg_done[m] = 1;
+                    }
+                }
+            }
+        }
     }
 }
 

@@ -42,7 +42,7 @@ __global__ void k_mol_bounds(const int64_t* __restrict__ batch, int64_t nV, int6
 // The same pass by ONE workgroup that zeroes its own tables first (no memset launch in front of it): a batch of up to 32 768 atoms.
 constexpr int64_t kBoundsOneMaxAtoms = 32768;
 __global__ __launch_bounds__(1024) void k_mol_bounds_one(const int64_t* __restrict__ batch, int64_t nV, int64_t n_mols, int* __restrict__ ws) {
-    for (int64_t i = threadIdx.x; i < 2 * n_mols + 4; i += 1024) ws[i] = 0;
+    for (int64_t i = threadIdx.x; i < 3 * n_mols + 4; i += 1024) ws[i] = 0;
     __threadfence();   // (the zeroes are in memory before any thread of this workgroup writes a bound over them)
     __syncthreads();
     int* first = ws;
@@ -140,7 +140,9 @@ using namespace dmpnn;
 
 extern "C" {
 
-size_t dmpnn_molagg_ws_bytes(int64_t n_mols) { return (size_t)(2 * (n_mols > 0 ? n_mols : 0) + 4) * sizeof(int); }
+// first[n] | end[n] | flag, 3 words of padding | done[n] (round 5: 1 where the forward tile kernel already wrote the molecule's aggregate;
+// zeroed with the rest of the table — the head's column kernel reads it, dmpnn_head.hip)
+size_t dmpnn_molagg_ws_bytes(int64_t n_mols) { return (size_t)(3 * (n_mols > 0 ? n_mols : 0) + 4) * sizeof(int); }
 
 int dmpnn_molagg_bounds(const int64_t* batch, int64_t n_atoms, int64_t n_mols, void* ws, size_t ws_bytes, void* stream) {
     DMPNN_CHECK_ARG(n_atoms >= 0 && n_mols >= 0 && n_atoms < (1ll << 31) && n_mols < (1ll << 30), "molagg_bounds: sizes out of range");

@@ -816,6 +816,7 @@ __device__ __forceinline__ void prepare_tiles_batch_body(int* lds_i, const int64
         for (int m = tid; m < n_mols_out; m += kSmallThreads) {
             mol_bounds[m] = m <= nm ? fa[m] : nV;
             mol_bounds[n_mols_out + m] = m + 1 <= nm ? fa[m + 1] : nV;
+            mol_bounds[2 * n_mols_out + 4 + m] = 0;   // done[m]: set by the forward tile kernel where it writes the molecule's aggregate
         }
         if (tid == 0)   // 1: an id out of range (or beyond the caller's molecule count), 2: not sorted — any non-zero value poisons the aggregation
             mol_bounds[2 * n_mols_out] = ((flags_s & PLAN_RANGE_ERROR) || nm > n_mols_out ? 1 : 0) | ((flags_s & PLAN_NO_PIECE_TILES) ? 2 : 0);

@@ -86,13 +86,13 @@ def module():
     sync.allreduce(); opt.step()
 
 
-FORMS = [("chain", {"DMPNN_HEAD": "chain"}), ("default", {}), ("agg-split", {"DMPNN_HEAD_AGG": "split"}), ("qpw4", {"DMPNN_HEAD_QPW": "4"})]
+FORMS = [("chain", {"DMPNN_HEAD": "chain"}), ("default", {}), ("agg-fused", {"DMPNN_HEAD_AGG": "fused"}), ("agg-split", {"DMPNN_HEAD_AGG": "split"})]
 for rep in range(2):
     for form, env in FORMS:
         for k in ("DMPNN_HEAD", "DMPNN_HEAD_AGG", "DMPNN_HEAD_QPW"): os.environ.pop(k, None)
         os.environ.update(env)
         for name, fn in (("fused", fused), ("module", module)):
-            if name == "module" and form in ("agg-split", "qpw4"): continue
+            if name == "module" and form in ("agg-split", "agg-fused"): continue
             for _ in range(30): fn()
             torch.cuda.synchronize()
             n = 300

@@ -711,3 +711,33 @@ def test_head_in_row_and_column_kernels_equals_the_nine_launch_chain(n_mols, d_h
     if bn:
         for k in ("running_mean", "running_var"):
             assert parity_err(getattr(a.bn, k).cpu().numpy(), getattr(b.bn, k).cpu().numpy()) <= 1e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mols,agg,bn", [(512, "norm", True), (77, "mean", True), (200, "sum", False)])
+def test_fused_step_takes_the_aggregate_from_the_forward_tile_kernel_bit_for_bit(n_mols, agg, bn, gpu_device, monkeypatch):
+    """Round 5: inside ``dmpnn_train_step`` the forward tile kernel leaves ``agg(H_v)`` of every molecule of a regular tile with the
+    tile (rows added in increasing atom order from the tile's LDS copy — ``k_mol_reduce``'s arithmetic) and marks it in the bounds
+    table; the head's column kernel sums only what is not marked.  Against the same step with the ride switched off
+    (``DMPNN_HEAD_AGG=fused``): loss and every gradient bit for bit."""
+    from chemprop_amd import synth
+    from chemprop_amd.model import FusedTrainer
+
+    cfg = dict(mp=dict(d_h=300, activation="relu"), agg=agg, bn=bn, ffn=dict(n_tasks=2, hidden_dim=300, n_layers=1, activation="relu"))
+    bmg = synth.random_batch(n_mols, "qm9", seed=21)
+    bmg.to(gpu_device)
+    y = torch.randn(n_mols, 2, generator=torch.Generator().manual_seed(4)).to(gpu_device)
+    out = {}
+    for form in ("tile", "fused"):
+        monkeypatch.setenv("DMPNN_HEAD_AGG", form)
+        torch.manual_seed(11)
+        m = build_mirror(cfg).to(gpu_device).train()
+        tr = FusedTrainer(m, lr=1e-3)
+        l = tr.step(bmg, y)
+        torch.cuda.synchronize()
+        assert tr.last_route == "mega16"
+        out[form] = (l.detach().cpu().clone(), [v.detach().cpu().clone() for v in tr.sync.views])
+    assert torch.equal(out["tile"][0], out["fused"][0]), (out["tile"][0], out["fused"][0])
+    assert torch.isfinite(out["tile"][0]).all()
+    for i, (a, b) in enumerate(zip(out["tile"][1], out["fused"][1])):
+        assert torch.equal(a, b), i
