@@ -482,6 +482,9 @@ int dmpnn_linear_wgrad(const dmpnn_gemm_args* g, const float* gZ, int64_t ldgz, 
  * from the device).  Molecules without atoms give zero rows (agg.py:44-46).  An invalid `batch` (id out of
  * range, or decreasing) is detected on device and poisons the outputs with NaN.
  *   dmpnn_molagg_bounds  first / one-past-last atom of every molecule + the validity flag -> ws
+ *                        (ws: int first[n_mols] | end[n_mols] | flag, 3 words of padding | done[n_mols] — done[] is zeroed here and
+ *                        used only inside dmpnn_train_step, where the forward tile kernel marks the molecules whose aggregate it
+ *                        wrote itself; dmpnn_molagg_ws_bytes() covers it)
  *   dmpnn_molagg_fwd     out[m] = sum_{v in m} H[v]   (MEAN: / count, NORM: / norm; true divisions)
  *   dmpnn_molagg_bwd     gH[v]  = gOut[batch[v]]      (MEAN: / count, NORM: / norm)
  * ------------------------------------------------------------------------------------------- */

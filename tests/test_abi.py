@@ -175,3 +175,37 @@ def test_tile_plans_of_any_size_shape_rules_and_argument_errors():
     assert lib.dmpnn_collate(None, None, 0, None, None, None, 0, 0, None, None, None, None) == 0     # empty batch: nothing to do
     assert lib.dmpnn_collate(None, None, 0, None, None, None, 5, 0, None, None, 4096, None) == -1    # atoms without molecules
     assert lib.dmpnn_collate(4096, 4096, 1, None, None, None, 5, 4, None, None, 4096, None) == -1    # null edge arrays
+
+
+def test_head_workspace_covers_the_four_launch_form_and_the_bounds_table_its_done_flags():
+    """Host-only size rules (no GPU): the aggregation's bounds table is first | end | flag + 3 | done (round 5: the forward tile kernel
+    marks the molecules whose aggregate it wrote), and ``dmpnn_head_ws_bytes`` grows by the hidden layer's split weight in both
+    orientations, its row scales and the row blocks' partials exactly for the shapes the four-launch head takes (one hidden layer of at
+    most 320 columns, at most 4 outputs, at most 1 024 molecules, not cross entropy)."""
+    lib = _lib.load()
+    assert lib.dmpnn_molagg_ws_bytes(0) == 16 and lib.dmpnn_molagg_ws_bytes(10) == (3 * 10 + 4) * 4
+
+    def ws(n_mols, d, hidden, tasks, n_layers=2, loss=0):
+        h = _lib.HeadArgs()
+        h.n_atoms, h.n_mols, h.d_h = 9 * n_mols, n_mols, d
+        h.n_layers = n_layers
+        dims = [d] + [hidden] * (n_layers - 1) + [tasks]
+        for i, v in enumerate(dims):
+            h.dims[i] = v
+        h.loss = loss
+        h.n_classes = 2 if loss == _lib.LOSS["ce"] else 0
+        return int(lib.dmpnn_head_ws_bytes(C.byref(h)))
+
+    def extra(n_mols, n, k, t):   # al256 of: both split orientations, the row scales, the partials of ceil(n_mols / 16) row blocks
+        al = lambda x: (x + 255) // 256 * 256
+        return (al(-(-n // 16) * -(-k // 32) * 2048) + al(-(-k // 16) * -(-n // 32) * 2048) + al(4 * n) + al(4 * k)
+                + al(-(-n_mols // 16) * (t * n + t + 2) * 4))
+
+    base = ws(512, 300, 300, 8)                       # 8 outputs: the chain's layout
+    for n_mols, d, hidden, t in ((512, 300, 300, 1), (77, 64, 128, 3), (1024, 300, 200, 4)):
+        with_rows = ws(n_mols, d, hidden, t)
+        # the same shape with the rule switched off by ONE property at a time: too many molecules / cross entropy
+        assert with_rows - ws(n_mols, d, hidden, t, loss=_lib.LOSS["ce"]) == extra(n_mols, hidden, d, t), (n_mols, d, hidden, t)
+    assert ws(1025, 300, 300, 1) < ws(1024, 300, 300, 1) + extra(1024, 300, 300, 1)   # beyond 1 024 molecules: the chain's workspace only
+    assert ws(512, 300, 384, 1) == ws(512, 300, 384, 1, loss=_lib.LOSS["ce"])         # a hidden layer beyond 320 columns: the chain
+    assert base > 0
