@@ -1127,11 +1127,11 @@ struct HeadLayout {
     size_t bounds, Hm, Z, mean, invstd, act[DMPNN_MAX_FFN_LAYERS], gP, gA, gB, Wt, wgrad, gHm, total;
     size_t wgrad_bytes;
     int64_t maxd;
-    // the three-launch form (rows_shape): the hidden layer's split weight in both orientations, their row scales, the row kernel's partials
+    // the four-launch form (rows_shape): the hidden layer's split weight in both orientations, their row scales, the row kernel's partials
     size_t W0f, W0b, isf, isb, part;
     int part_stride, n_part;
 };
-// the shapes the three-launch form takes (training or not is the caller's business): one hidden layer, a handful of outputs
+// the shapes the four-launch form takes (training or not is the caller's business): one hidden layer, a handful of outputs
 bool rows_shape(const dmpnn_head_args& h) {
     return h.n_layers == 2 && h.dims[2] <= kOutMaxTasks && h.dims[2] >= 1 && h.loss != DMPNN_LOSS_CE && h.n_mols <= kRowsMaxB &&
            h.dims[0] <= kRowsMaxWidth && h.dims[1] <= kRowsMaxWidth && h.dims[0] % 4 == 0;
@@ -1272,7 +1272,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
 
     // ---- forward ----
     if (!bounds_done) DMPNN_TRY(dmpnn_molagg_bounds(h.batch, nV, B, ws + L.bounds, dmpnn_molagg_ws_bytes(B), stream));
-    // round 5: the three-launch form (see k_agg_bn_fwd) — aggregation + batch norm as ONE column kernel for <= kRowsMaxB molecules
+    // round 5: the four-launch form (see k_agg_bn_fwd) — aggregation + batch norm as ONE column kernel for <= kRowsMaxB molecules
     // (forward, inference included), the whole predictor + criterion + their backward as ONE row kernel when the shape fits
     const char* head_env = getenv("DMPNN_HEAD");
     const bool chain = head_env && !strcmp(head_env, "chain");
@@ -1282,7 +1282,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
                             (!h.bn_weight || (aligned16(h.bn_weight) && aligned16(h.bn_bias) && aligned16(h.bn_running_mean) && aligned16(h.bn_running_var) &&
                                               (!h.g_bn_weight || aligned16(h.g_bn_weight)) && (!h.g_bn_bias || aligned16(h.g_bn_bias))));
     const bool rows = cols_fused && want_grad && h.targets && rows_shape(h) && aligned16(h.W[0]);
-    // (DMPNN_HEAD=rows: tests — a training call that does NOT take the three-launch form is an error instead of a silent chain)
+    // (DMPNN_HEAD=rows: tests — a training call that does NOT take the four-launch form is an error instead of a silent chain)
     DMPNN_CHECK_ARG(!(head_env && !strcmp(head_env, "rows")) || rows || !want_grad, "head: DMPNN_HEAD=rows, but this shape takes the chain");
     const float* Z = Hm;
     float* mean = reinterpret_cast<float*>(ws + L.mean);
