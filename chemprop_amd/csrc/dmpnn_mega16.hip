@@ -1,4 +1,7 @@
 // Launcher + instantiations of the split-MFMA whole-forward tile kernel (dmpnn_mega16_impl.hpp).
+#include <algorithm>
+#include <cstdlib>
+
 #include "dmpnn_mega16_impl.hpp"
 
 namespace dmpnn {
@@ -15,6 +18,11 @@ DMPNN_DEFINE_MEGA16(5, true, true)
 DMPNN_DEFINE_MEGA16(5, true, false)
 DMPNN_DEFINE_MEGA16(5, false, true)
 DMPNN_DEFINE_MEGA16(5, false, false)
+// one tile as a 512-thread workgroup (launches of at most one tile per CU)
+DMPNN_DEFINE_MEGA16_NW(5, true, true, 8)
+DMPNN_DEFINE_MEGA16_NW(5, true, false, 8)
+DMPNN_DEFINE_MEGA16_NW(5, false, true, 8)
+DMPNN_DEFINE_MEGA16_NW(5, false, false, 8)
 }  // namespace mega16
 
 // (per calling thread: a diagnostic hook, never shared mutable state between threads that drive the library)
@@ -97,6 +105,24 @@ bool mega16_keeps_rows(const dmpnn_fwd_args& a) {
     return a.msplit && aligned16(a.msplit) && a.msplit_bytes >= bytes;
 }
 
+// Waves per tile workgroup (d_h in (128, 320]).  The host does not know the tile count of a plan built on the device, only its
+// launch bound; what it knows is the batch: a launch whose tiles fit the chip ONE per CU (about n_edges / 40 and n_atoms / 20 tiles
+// for molecules packed whole into 48-row / 32-atom tiles) runs each tile as 8 waves — two per SIMD out of ONE tile — and a larger
+// launch as 4-wave workgroups, two tiles per CU.  DMPNN_TILE_WAVES=4|8 overrides (measurement builds, tests of both forms).
+int tile_waves(const dmpnn_fwd_args& a, int n_tiles) {
+    static const int forced = [] { const char* e = getenv("DMPNN_TILE_WAVES"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 8) return forced;
+    if (a.d_h <= 128 || a.d_h > 320) return 4;
+    static const int n_cu = [] {   // (read-only device property, fetched once)
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    if (n_tiles <= n_cu) return 8;
+    const int64_t est = std::max<int64_t>((a.n_edges + 39) / 40, (a.n_atoms + 19) / 20);
+    return est <= n_cu ? 8 : 4;
+}
+
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s) {
     const int64_t nV = a.n_atoms, nE = a.n_edges;
     const WsLayout W = ws_layout(a);
@@ -174,6 +200,9 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
                            : (kp ? mega16::launch_mega16<WN, false, true>(G, n_tiles, s) : mega16::launch_mega16<WN, false, false>(G, n_tiles, s)))
     if (wn == 1) return DMPNN_PICK(1);
     if (wn == 2) return DMPNN_PICK(2);
+    if (tile_waves(a, n_tiles) == 8)
+        return sa ? (kp ? mega16::launch_mega16<5, true, true, 8>(G, n_tiles, s) : mega16::launch_mega16<5, true, false, 8>(G, n_tiles, s))
+                  : (kp ? mega16::launch_mega16<5, false, true, 8>(G, n_tiles, s) : mega16::launch_mega16<5, false, false, 8>(G, n_tiles, s));
     return DMPNN_PICK(5);
 #undef DMPNN_PICK
 }

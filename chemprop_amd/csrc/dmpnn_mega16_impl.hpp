@@ -190,6 +190,9 @@ __device__ __forceinline__ void rows_to_sr(const float* src, long long ld, long 
 // (__launch_bounds__(256, 2)) consecutive tiles on one CU overlap their latency-bound phases: measured on MI355X
 // 41.1 -> 35.4 us at 512 molecules (one tile per CU: fewer registers, a compact contraction loop) and 301.6 -> 183.6 us at
 // 4 096 molecules (1 839 tiles, 7.2 per CU).
+#if !defined(DMPNN_TILE8_BRING)
+#define DMPNN_TILE8_BRING 1   // weight-fragment sets of the 8-wave form's contraction: 1 = the one-set ring; 2 (chunk c + 2 behind chunk c) measured 0.7 us SLOWER at 512 molecules (profiles/r06_tile8_first_ab.txt: the stream is throughput-, not latency-bound)
+#endif
 template <int WN>
 constexpr size_t tile_region_bytes() {
     constexpr size_t ts = 64 * WN * 4 + 16, tsg = 4 * 128 + 16;  // split A tile row | staging tile row (the larger one for d_h <= 64)
@@ -209,12 +212,23 @@ constexpr size_t lds_bytes_atom() { return lds_bytes<WN>() + kAtomLds; }
 // jump across costs instruction fetches (the kernel was 203 KB against a 64 KB instruction cache).
 // KEEP: the training forward (H0, H^(t), M^(t), Mv stream out for the backward pass); the inference instantiation carries none of
 // that code (64-bit row addresses and a divergent branch per stored fragment).
-template <int WN, bool SA, bool KEEP>
-__global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
+//
+// NW (round 6): waves per workgroup.  4 = the form above (wave w owns column tiles WN w .. WN w + WN - 1; two workgroups per CU when
+// the launch has more tiles than CUs).  8 (d_h in (128, 320] only: 20 column tiles) = ONE tile as a 512-thread workgroup, the column
+// tiles split 3+3+3+3+2+2+2+2: waves w and w + 4 share a SIMD, so every SIMD still carries 5 column tiles, but as TWO waves whose
+// dependent chains are 3/5 and 2/5 as long and cover each other's waits (weight fragments, LDS, the epilogues' conversion chains).
+// Picked when the launch has at most one tile per CU (launch_mega16_forward): there the 4-wave form leaves every SIMD with ONE wave.
+// Each wave class runs its own instantiation of the tile's body (exact vmcnt waits, no guards in the MFMA loops): together they
+// are as much code as the 4-wave body.
+template <int WN, bool SA, bool KEEP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
+    static_assert(NW == 4 || (NW == 8 && WN == 5), "the 8-wave form splits 20 column tiles 3+3+3+3+2+2+2+2");
     const mega::MegaK& g = G.m;
+    constexpr int KT = 64 * NW;                // threads of the workgroup
+    constexpr int JR = 16 / NW;                // gathered operand rows per thread and row tile: row = wave + NW j
     constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, LDC = BN + 4, QN = BN / 4;
     constexpr int TS = BN * 4 + 16;            // bytes of one row of the split A tile: BN/32 chunks x 128 + 16
-    constexpr int ITEMS = BM * QN / kThreads;
+    constexpr int ITEMS = (BM * QN + KT - 1) / KT;   // (row, quad) items per thread of a row-major tile pass (guarded by r < n_r)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* T16 = lds;                               // [BM][TS]   split A operand of the LDS-A contractions
     static_assert(LDC * 4 == TS, "the fp32 tile and the split A tile have the same footprint");
@@ -262,12 +276,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     if (poison) {
         const float nanv = __int_as_float(0x7fc00000);
         const long long total = (long long)g.nV * N;
-        for (long long i = (long long)blockIdx.x * kThreads + tid; i < total; i += (long long)gridDim.x * kThreads)
+        for (long long i = (long long)blockIdx.x * KT + tid; i < total; i += (long long)gridDim.x * KT)
             g.out[(i / N) * g.ldout + (i % N)] = nanv;
         return;
     }
     if (na <= 0 || nrows < 0 || va < 0 || vb > g.nV || rs < 0 || re > g.nE) return;  // (an unused tile slot)
     if (nrows > BM || na > BA) {
+        if (NW > 4 && threadIdx.x >= kThreads) return;  // (the generic path is written for 256 threads; s_barrier counts live waves only)
         // a piece (molecule) larger than the matrix-pipe tile — the reference has no size limit (data/collate.py:48-56):
         // the generic fp32 path carries it, whatever its size (dmpnn_spill_impl.hpp)
         const mega::MegaK& gs = spill::fresh_kernargs<Mega16K>()->m;
@@ -299,32 +314,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     const float neg_slope = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
     constexpr bool simple_act = SA;
 
-    // ---- weight fragments: straight from L2 to registers --------------------------------------------
-    // The four waves of a workgroup own disjoint column ranges, so a weight element is used by exactly one
-    // wave: staging the weight tile in LDS would buy no reuse and cost a write + a read + a barrier per
-    // chunk.  Lane (li, lg) of column tile ct reads its own fragment of chunk c from the pre-split layout:
-    // hi 16 B at [col][c][lg*16], lo at +64 (col = wave*16*WN + ct*16 + li; col >= N is out of range: 0).
-    auto load_bfrags = [&](rsrc_t rW, const unsigned (&offB)[WN], int c, h8 (&bh)[WN], h8 (&bl)[WN]) {
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0);
-            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0);
-            bh[ct] = __builtin_bit_cast(h8, vh);
-            bl[ct] = __builtin_bit_cast(h8, vl);
-        }
-    };
-    auto bfrag_offsets = [&](const SplitW& W, unsigned (&offB)[WN]) {
-        launder();
-#pragma unroll
-        for (int ct = 0; ct < WN; ++ct)  // fragment-major layout [column tile][chunk][hi|lo][lane][16 B]
-            offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
-    };
-    // index loads first: the tile metadata and the gather rows of the K1 operand (row wave + 4 j of the tile)
+    // index loads first: the tile metadata and the gather rows of the K1 operand (row wave + NW j of the tile)
     int revl_v = 0, rp_v = 0, aor_v = 0, asrc_v = 0;
     bool row_bad = false;
-    unsigned ro1[4 * RT_E], ro2[4 * RT_E];
+    unsigned ro1[JR * RT_E], ro2[JR * RT_E];
     {
-        int i1[4 * RT_E], i2[4 * RT_E];
+        int i1[JR * RT_E], i2[JR * RT_E];
         if (lean && nrows > 0) {
             const int e = rs + (tid < nrows ? tid : 0);
             const long long es = g.edge_index[e], ed = g.edge_index[(long long)g.nE + e], er = g.rev64[e];
@@ -334,41 +329,41 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             aor_v = (tid < nrows && !row_bad) ? (int)d_l : 0;
             asrc_v = (tid < nrows && !row_bad) ? (int)s_l : 0;
 #pragma unroll
-            for (int j = 0; j < 4 * RT_E; ++j) {
-                const int r = wave + 4 * j;
+            for (int j = 0; j < JR * RT_E; ++j) {
+                const int r = wave + NW * j;
                 const long long sj = g.edge_index[r < nrows ? rs + r : rs];
                 i1[j] = (sj >= 0 && sj < g.nV) ? (int)sj : 0;
                 i2[j] = rs + r;
             }
         } else if (lean) {  // a tile of single atoms: no rows, nothing to read
 #pragma unroll
-            for (int j = 0; j < 4 * RT_E; ++j) { i1[j] = 0; i2[j] = 0; }
+            for (int j = 0; j < JR * RT_E; ++j) { i1[j] = 0; i2[j] = 0; }
         } else {
             revl_v = tid < nrows ? g.revp[rs + tid] - rs : 0;
             rp_v = g.row_ptr[va + (tid <= na ? tid : na)] - rs;
 #pragma unroll
-            for (int j = 0; j < 4 * RT_E; ++j) {
-                const int r = wave + 4 * j;
+            for (int j = 0; j < JR * RT_E; ++j) {
+                const int r = wave + NW * j;
                 i1[j] = g.srcp[r < nrows ? rs + r : 0];
                 i2[j] = g.perm[r < nrows ? rs + r : 0];
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4 * RT_E; ++j) {
-            const bool ok = wave + 4 * j < nrows;
+        for (int j = 0; j < JR * RT_E; ++j) {
+            const bool ok = wave + NW * j < nrows;
             ro1[j] = ok ? (unsigned)i1[j] * (unsigned)g.ldv * 4u : kOOB;
             ro2[j] = ok ? (unsigned)i2[j] * (unsigned)g.lde * 4u : kOOB;
         }
     }
     // the first 128 columns of [V[src] | E] are in flight while the LDS metadata is built
     const rsrc_t rVg = gemm::make_rsrc(g.V, g.v_bytes), rEg = gemm::make_rsrc(g.E, g.e_bytes);
-    u32x2 a_grp[4 * RT_E];
+    u32x2 a_grp[JR * RT_E];
     {
         const int k = lane * 2;
         const unsigned k1o = k < g.d_v ? (unsigned)k * 4u : kOOB;
         const unsigned k2o = (k >= g.d_v && k < g.d_v + g.d_e) ? (unsigned)(k - g.d_v) * 4u : kOOB;
 #pragma unroll
-        for (int j = 0; j < 4 * RT_E; ++j)
+        for (int j = 0; j < JR * RT_E; ++j)
             a_grp[j] = __builtin_amdgcn_raw_buffer_load_b64(rVg, gemm::join_off(ro1[j], k1o), 0, 0) |
                        __builtin_amdgcn_raw_buffer_load_b64(rEg, gemm::join_off(ro2[j], k2o), 0, 0);
     }
@@ -405,7 +400,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) ar[i] = ((i >> 2) * 16 + lg * 4 + (i & 3)) < nrows ? qa[i] : -2;  // (a row past the tile matches no atom)
     }
-    for (int f = wave; f < 10; f += 4) {
+    for (int f = wave; f < 10; f += NW) {
         const bool agg = f >= 6;
         const int ff = agg ? f - 6 : f, jt = ff >> 1, ks = ff & 1;
         const int j = jt * 16 + li;
@@ -460,18 +455,42 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         return scale_for(mx);
     };
 
-    // ---- one contraction: acc[RT][WN] += (A s_A) . (W s_W)^T in the split domain -------------------
+    // ---- the tile's body, per wave class: WL = column tiles of this wave, ct0() = its first one (NW = 4: WL = WN for every wave) ----
+    auto body = [&](auto wl_c) __attribute__((always_inline)) {
+    constexpr int WL = decltype(wl_c)::value;
+    auto ct0 = [&]() -> int { return (NW == 8 && WL == 2) ? 2 * wave + 4 : WL * wave; };
+    // ---- weight fragments: straight from L2 to registers --------------------------------------------
+    // The four waves of a workgroup own disjoint column ranges, so a weight element is used by exactly one
+    // wave: staging the weight tile in LDS would buy no reuse and cost a write + a read + a barrier per
+    // chunk.  Lane (li, lg) of column tile ct reads its own fragment of chunk c from the pre-split layout:
+    // hi 16 B at [col][c][lg*16], lo at +64 (col = (ct0 + ct)*16 + li; col >= N is out of range: 0).
+    auto load_bfrags = [&](rsrc_t rW, const unsigned (&offB)[WL], int c, h8 (&bh)[WL], h8 (&bl)[WL]) {
+#pragma unroll
+        for (int ct = 0; ct < WL; ++ct) {
+            const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0);
+            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0);
+            bh[ct] = __builtin_bit_cast(h8, vh);
+            bl[ct] = __builtin_bit_cast(h8, vl);
+        }
+    };
+    auto bfrag_offsets = [&](const SplitW& W, unsigned (&offB)[WL]) {
+        launder();
+#pragma unroll
+        for (int ct = 0; ct < WL; ++ct)  // fragment-major layout [column tile][chunk][hi|lo][lane][16 B]
+            offB[ct] = (unsigned)(ct0() + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
+    };
+    // ---- one contraction: acc[RT][WL] += (A s_A) . (W s_W)^T in the split domain -------------------
     // A fragments straight from a split tile in LDS (static during the contraction: NO barrier in the main
     // loop): row stride `astride` bytes, chunk c at +c*128 as [hi 32 halfs | lo 32 halfs].  Weight chunks
     // wc0 .. wc0 + n_chunks - 1 of W.
-    auto contract = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], const unsigned char* Ab, int astride, int n_chunks,
+    auto contract = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WL], const unsigned char* Ab, int astride, int n_chunks,
                         int wc0, const SplitW& W) {
         constexpr int RT = decltype(rt_c)::value;
         const rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048));  // column tiles beyond N: out of range, 0
-        unsigned offB[WN];
+        unsigned offB[WL];
         bfrag_offsets(W, offB);
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) offB[ct] += (unsigned)wc0 * 2048u;
+        for (int ct = 0; ct < WL; ++ct) offB[ct] += (unsigned)wc0 * 2048u;
         auto read_afrags = [&](int c, h8 (&ah)[RT], h8 (&al)[RT]) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -485,7 +504,54 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         // behind them (distance: the 9 RT MFMAs of each of the other column tiles, exact vmcnt in the compact loop); the A
         // fragments of chunk c + 1 are read from LDS under the last-but-one column tile.  What latency is left uncovered is the
         // other workgroup's to fill.
-        h8 bh[WN], bl[WN], a0h[RT], a0l[RT], a1h[RT], a1l[RT];
+        h8 a0h[RT], a0l[RT], a1h[RT], a1l[RT];
+        if constexpr (NW == 8 && DMPNN_TILE8_BRING == 2) {
+            // 8 waves: a wave owns 3 or 2 column tiles, so the one-set ring's prefetch distance (the other tiles' 9 RT MFMAs each) is
+            // 18 / 9 MFMAs — under the L2 latency.  The registers the narrower accumulators free hold a SECOND set: chunk c + 2 is
+            // requested behind the products of chunk c (distance: a whole chunk more)
+            h8 b0h[WL], b0l[WL], b1h[WL], b1l[WL];
+            load_bfrags(rW, offB, 0, b0h, b0l);
+            {   // (a select, not a branch: two paths into the loop with different load queues would make hipcc wait for the shorter one)
+                const bool two = n_chunks > 1;
+#pragma unroll
+                for (int ct = 0; ct < WL; ++ct) {
+                    b1h[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, two ? offB[ct] + 2048u : kOOB, 0, 0));
+                    b1l[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, two ? offB[ct] + 3072u : kOOB, 0, 0));
+                }
+            }
+            __syncthreads();  // the split A tile is complete
+            launder();
+            read_afrags(0, a0h, a0l);
+            auto chunk2 = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&nah)[RT], h8 (&nal)[RT], h8 (&bh)[WL], h8 (&bl)[WL]) {
+                const bool more2 = c + 2 < n_chunks;
+#pragma unroll
+                for (int ct = 0; ct < WL; ++ct) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned o = more2 ? offB[ct] + (unsigned)(c + 2) * 2048u : kOOB;  // (past the last chunk: out of range, 0)
+                    bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
+                    bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more2 ? o + 1024u : kOOB, 0, 0));
+                    if (ct == (WL > 1 ? WL - 2 : 0)) read_afrags(c + 1 < n_chunks ? c + 1 : c, nah, nal);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // whole pairs in the loop, an odd last chunk behind it: a skip INSIDE the loop would make hipcc merge the two paths' load
+            // queues at the back edge and wait for the youngest set every chunk (vmcnt(3) where 7 are legitimately in flight)
+            int c = 0;
+#pragma nounroll
+            for (; c + 1 < n_chunks; c += 2) {
+                chunk2(c, a0h, a0l, a1h, a1l, b0h, b0l);
+                chunk2(c + 1, a1h, a1l, a0h, a0l, b1h, b1l);
+            }
+            if (c < n_chunks) chunk2(c, a0h, a0l, a1h, a1l, b0h, b0l);
+            return;
+        }
+        h8 bh[WL], bl[WL];
         load_bfrags(rW, offB, 0, bh, bl);
         __syncthreads();  // the split A tile is complete
         launder();
@@ -493,7 +559,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         auto chunk = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&nah)[RT], h8 (&nal)[RT]) {
             const bool more = c + 1 < n_chunks;
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct) {
+            for (int ct = 0; ct < WL; ++ct) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
 #pragma unroll
@@ -504,7 +570,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                 const unsigned o = more ? offB[ct] + (unsigned)(c + 1) * 2048u : kOOB;  // (past the last chunk: out of range, 0)
                 bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
                 bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more ? o + 1024u : kOOB, 0, 0));
-                if (ct == (WN > 1 ? WN - 2 : 0)) read_afrags(more ? c + 1 : c, nah, nal);
+                if (ct == (WL > 1 ? WL - 2 : 0)) read_afrags(more ? c + 1 : c, nah, nal);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -517,16 +583,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     };
 
     // ---- A operand from global memory, in groups of up to 4 k-chunks (128 columns) ---------------------
-    // Item j of a thread: row wave + 4 j, column pair `lane` of the group (k = 128 grp + 2 lane), so one
+    // Item j of a thread: row wave + NW j, column pair `lane` of the group (k = 128 grp + 2 lane), so one
     // wave instruction reads 512 contiguous bytes of one (gathered) row.  The group is held in registers:
     // its maximum gives the tile scale, then it is split into the LDS tile Ag (overlays T16 / T) — the
     // operand is read from memory exactly once and the contraction over it is the barrier-free one above.
     constexpr int TSG = 4 * 128 + 16;
     unsigned char* Ag = lds;
     auto ga_load = [&](auto rt_c, auto has_a2_c, int grp, int K1, int K2, rsrc_t rA1, rsrc_t rA2,
-                       const unsigned (&ro1)[4 * decltype(rt_c)::value], const unsigned (&ro2)[4 * decltype(rt_c)::value],
-                       u32x2 (&v)[4 * decltype(rt_c)::value]) {
-        constexpr int J = 4 * decltype(rt_c)::value;
+                       const unsigned (&ro1)[JR * decltype(rt_c)::value], const unsigned (&ro2)[JR * decltype(rt_c)::value],
+                       u32x2 (&v)[JR * decltype(rt_c)::value]) {
+        constexpr int J = JR * decltype(rt_c)::value;
         constexpr bool HAS_A2 = decltype(has_a2_c)::value;
         const int k = grp * 128 + lane * 2;
         const unsigned k1o = k < K1 ? (unsigned)k * 4u : kOOB;
@@ -538,8 +604,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         }
     };
     // scale of the group, rescale of what `acc` holds from the previous scale, split + store
-    auto ga_stage = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], const u32x2 (&v)[4 * decltype(rt_c)::value], float s_prev) -> float {
-        constexpr int RT = decltype(rt_c)::value, J = 4 * RT;
+    auto ga_stage = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WL], const u32x2 (&v)[JR * decltype(rt_c)::value], float s_prev) -> float {
+        constexpr int RT = decltype(rt_c)::value, J = JR * RT;
         float mx = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) mx = fmaxf(mx, fmaxf(fabsf(__uint_as_float(v[j].x)), fabsf(__uint_as_float(v[j].y))));
@@ -549,7 +615,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < WN; ++ct)
+                for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[rt][ct][r] *= f;
         }
@@ -559,29 +625,29 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             const float x = __uint_as_float(v[j].x) * s, y = __uint_as_float(v[j].y) * s;
             const h2 hi = h2{(_Float16)x, (_Float16)y};
             const h2 lo = h2{(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
-            unsigned char* p = Ag + (wave + 4 * j) * TSG + (lane >> 4) * 128 + (lane & 15) * 4;
+            unsigned char* p = Ag + (wave + NW * j) * TSG + (lane >> 4) * 128 + (lane & 15) * 4;
             *reinterpret_cast<h2*>(p) = hi;
             *reinterpret_cast<h2*>(p + 64) = lo;
         }
         return s;
     };
-    auto zero_acc = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN]) {
+    auto zero_acc = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WL]) {
         constexpr int RT = decltype(rt_c)::value;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < WL; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     // per-lane column constants of a contraction (inverse weight scale, bias), fetched BEFORE the
     // contraction so their latency hides under it
-    struct ColConst { float isw[WN], bv[WN]; };
+    struct ColConst { float isw[WL], bv[WL]; };
     auto col_consts = [&](const float* inv_sW, const float* bias) -> ColConst {
         ColConst cc;
         launder();
         const float* bp = bias ? bias : inv_sW;
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const int col = wave * (16 * WN) + ct * 16 + li;
+        for (int ct = 0; ct < WL; ++ct) {
+            const int col = (ct0() + ct) * 16 + li;
             const bool okc = col < N;
             cc.isw[ct] = inv_sW[okc ? col : 0];
             const float braw = bp[okc ? col : 0];
@@ -590,10 +656,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         return cc;
     };
     // split domain -> fp32:  z = acc / (sA sW[col]) + bias[col]
-    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], float inv_sA, const ColConst& cc) {
+    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WL], float inv_sA, const ColConst& cc) {
         constexpr int RT = decltype(rt_c)::value;
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
+        for (int ct = 0; ct < WL; ++ct) {
             const float isw = cc.isw[ct] * inv_sA;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
@@ -602,14 +668,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         }
     };
     // y = tau(z [+ res]) elementwise on C/D fragments
-    auto act_frags = [&](auto rt_c, auto use_res_c, f32x4 (&z)[decltype(rt_c)::value][WN], const f32x4 (&res)[decltype(rt_c)::value][WN]) {
+    auto act_frags = [&](auto rt_c, auto use_res_c, f32x4 (&z)[decltype(rt_c)::value][WL], const f32x4 (&res)[decltype(rt_c)::value][WL]) {
         constexpr int RT = decltype(rt_c)::value;
         constexpr bool USE_RES = decltype(use_res_c)::value;
         if constexpr (simple_act) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < WN; ++ct)
+                for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = USE_RES ? res[rt][ct][r] + z[rt][ct][r] : z[rt][ct][r];
@@ -619,7 +685,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < WN; ++ct)
+                for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = USE_RES ? res[rt][ct][r] + z[rt][ct][r] : z[rt][ct][r];
@@ -631,7 +697,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     // clears the threshold, and scaled by 1 / (1 - p)   (base.py:139,182)
     // (edge sites are keyed on the CALLER's edge id — the same mask whatever plan the step runs on: under a CSR plan the tile's row r
     //  is edge perm[rs + r], under a tile plan edge rs + r)
-    auto dropout_frags = [&](auto rt_c, f32x4 (&y)[decltype(rt_c)::value][WN], unsigned site, int row0, bool edge_rows) {
+    auto dropout_frags = [&](auto rt_c, f32x4 (&y)[decltype(rt_c)::value][WL], unsigned site, int row0, bool edge_rows) {
         constexpr int RT = decltype(rt_c)::value;
         if constexpr (KEEP) {
             if (g.drop_thr) {  // (uniform)
@@ -645,8 +711,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                         rowid[rt][r] = (edge_rows && !lean) ? (unsigned)g.perm[rs + (lr < nrows ? lr : 0)] : (unsigned)(row0 + lr);
                     }
 #pragma unroll
-                for (int ct = 0; ct < WN; ++ct) {
-                    const unsigned col = (unsigned)(wave * (16 * WN) + ct * 16 + li);
+                for (int ct = 0; ct < WL; ++ct) {
+                    const unsigned col = (unsigned)((ct0() + ct) * 16 + li);
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -659,12 +725,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             }
         }
     };
-    auto frag_to_tile = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WN]) {
+    auto frag_to_tile = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WL]) {
         constexpr int RT = decltype(rt_c)::value;
         launder();
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const int col = wave * (16 * WN) + ct * 16 + li;
+        for (int ct = 0; ct < WL; ++ct) {
+            const int col = (ct0() + ct) * 16 + li;
             if (col < N) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
@@ -675,12 +741,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     };
     // sign bits of C/D fragments -> keep_bits (see Mega16K): 4 RT WN ballots, gathered into the lanes by v_writelane, one 8-byte
     // store per lane — no LDS, no barrier, 2 KB per tile instead of the tile's fp32 rows
-    auto store_bits = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WN], int slot) {
+    auto store_bits = [&](auto rt_c, const f32x4 (&y)[decltype(rt_c)::value][WL], int slot) {
         constexpr int RT = decltype(rt_c)::value;
-        static_assert(RT * WN * 4 <= 64, "one word per lane");
+        static_assert(RT * WL * 4 <= 64, "one word per lane");
         unsigned lo = 0u, hi = 0u;
-        static_for<0, RT * WN * 4>([&](auto ic) {   // (the lane select of v_writelane_b32 must be an inline constant: one SGPR operand per VALU instruction)
-            constexpr int idx = decltype(ic)::value, r = idx & 3, ct = (idx >> 2) % WN, rt = (idx >> 2) / WN;
+        static_for<0, RT * WL * 4>([&](auto ic) {   // (the lane select of v_writelane_b32 must be an inline constant: one SGPR operand per VALU instruction)
+            constexpr int idx = decltype(ic)::value, r = idx & 3, ct = (idx >> 2) % WL, rt = (idx >> 2) / WL;
             const unsigned long long b = __ballot(y[rt][ct][r] > 0.f);
             unsigned l = lo, h = hi;   // (asm operands must be locals of this lambda)
             const unsigned bl = (unsigned)b, bh = (unsigned)(b >> 32);
@@ -691,14 +757,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             lo = l; hi = h;
         });
         launder();
-        if (lane < RT * WN * 4)
-            G.keep_bits[(long long)slot * G.bits_slot + (long long)t * 256 + wave * 64 + lane] = ((unsigned long long)hi << 32) | lo;
+        if (lane < RT * WL * 4) {
+            // the word of (row tile rt, column tile gct = ct0 + ct, register r) sits where the 4-wave form puts it — wave gct / WN, slot
+            // (rt WN + gct % WN) 4 + r — whatever the wave split: the backward tile kernels read ONE layout
+            const int q = lane >> 2, gct = ct0() + q % WL, rt_ = q / WL;
+            const int word = NW == 4 ? wave * 64 + lane : (gct / WN) * 64 + (rt_ * WN + gct % WN) * 4 + (lane & 3);
+            G.keep_bits[(long long)slot * G.bits_slot + (long long)t * 256 + word] = ((unsigned long long)hi << 32) | lo;
+        }
     };
     auto tile_to_global = [&](float* dst, long long row0, int ld, int n_r) {
         launder();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const int it = tid + kThreads * j;
+            const int it = tid + KT * j;
             const int r = it / QN, q = it - r * QN;
             if (r < n_r && q < qn)
                 store_keep4(dst + (row0 + r) * ld + 4 * q, *reinterpret_cast<const float4*>(T + r * LDC + 4 * q));
@@ -714,13 +785,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     // The result lands as 4 consecutive columns of row r' (li) per lane: split with the tile scale of the
     // next contraction and written to T16 as 8-byte pieces; the fp32 copy streams to `keep`.
     static_assert(RT_E == 3 && RT_A == 2, "segment MFMAs are laid out for 48-row / 32-atom tiles");
-    auto segment_mfma = [&](const f32x4 (&H)[RT_E][WN], bool last, float* keep, int keep_ld, unsigned char* keep_rows) -> float {
+    auto segment_mfma = [&](const f32x4 (&H)[RT_E][WL], bool last, float* keep, int keep_ld, unsigned char* keep_rows) -> float {
         launder();
         float hm = 0.f;
 #pragma unroll
         for (int rt = 0; rt < RT_E; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hm = fmaxf(hm, fabsf(H[rt][ct][r]));
         const float sH = scale_for(wave_max(hm));
@@ -730,9 +801,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         for (int jt = 0; jt < RT_E; ++jt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) cf[jt][ks] = Cf[((jt < RT_A || !last ? jt : 0) * 2 + ks) * 64];
-        f32x4 m[WN][RT_E];
+        f32x4 m[WL][RT_E];
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
+        for (int ct = 0; ct < WL; ++ct) {
             h8 ah0, al0, ah1, al1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -759,7 +830,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         const float isH = 1.f / sH;
         float mx = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
+        for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt)
 #pragma unroll
@@ -772,8 +843,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         const int n_keep = last ? na : nrows;
         const long long keep0 = last ? va : rs;
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+        for (int ct = 0; ct < WL; ++ct) {
+            const int col4 = (ct0() + ct) * 16 + lg * 4;
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
                 if (jt < RT_A || !last) {
@@ -814,7 +885,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     const int T_steps = g.depth;
 
     // ================= K1: H0 = W_i [V[src] || E] =================
-    f32x4 h0[RT_E][WN];
+    f32x4 h0[RT_E][WL];
     {
         stamp();  // 1: metadata done
         const ColConst cc = col_consts(G.Wi.inv_scale, g.b_i);
@@ -840,11 +911,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
     }
     float sA;
     {
-        f32x4 y[RT_E][WN];
+        f32x4 y[RT_E][WL];
 #pragma unroll
         for (int rt = 0; rt < RT_E; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct) y[rt][ct] = h0[rt][ct];
+            for (int ct = 0; ct < WL; ++ct) y[rt][ct] = h0[rt][ct];
         act_frags(RE{}, F_{}, y, y);
         sA = segment_mfma(y, T_steps == 1, T_steps == 1 ? g.Mv : (G.Mrows ? nullptr : g.Ms), g.ldh, T_steps == 1 ? nullptr : G.Mrows);
     }
@@ -856,7 +927,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         const int de = G.atom_de;
         float* Et = reinterpret_cast<float*>(cfrag + 10 * 64);   // [BM][kAtomK] E rows of the tile
         float* SE = Et + BM * kAtomK;                            // [BA][kAtomK] per-atom sums of the incoming rows' E
-        for (int i = tid; i < BM * kAtomK; i += kThreads) {
+        for (int i = tid; i < BM * kAtomK; i += KT) {
             const int r = i / kAtomK, k = i - r * kAtomK;
             float v = 0.f;
             if (r < nrows && k < de) {
@@ -866,7 +937,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             Et[i] = v;
         }
         __syncthreads();
-        for (int i = tid; i < BA * kAtomK; i += kThreads) {      // increasing row order = the reference's sequential scatter order
+        for (int i = tid; i < BA * kAtomK; i += KT) {      // increasing row order = the reference's sequential scatter order
             const int a_ = i / kAtomK, k = i - a_ * kAtomK;
             float sum = 0.f;
             if (a_ < na && k < de)
@@ -878,7 +949,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
         launder();
         if constexpr (KEEP) {
             if (G.atom_me) {  // (uniform) what the weight-gradient product of W_h[:, N:] contracts gZ^(t) with — the same rows for every step
-                for (int i = tid; i < nrows * kAtomK; i += kThreads) {
+                for (int i = tid; i < nrows * kAtomK; i += KT) {
                     const int r = i / kAtomK, k = i - r * kAtomK;
                     const float v = SE[(lean ? asrc[r] : aor[revl[r]]) * kAtomK + k];
                     for (int sl = 0; sl < T_steps - 1; ++sl) G.atom_me[(long long)sl * G.me_slot + (long long)(rs + r) * kAtomK + k] = v;
@@ -909,13 +980,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                 const _Float16 hi = (_Float16)x;
                 eh[rt][j] = hi; el[rt][j] = (_Float16)(x - (float)hi);
             }
-        unsigned offE[WN];
+        unsigned offE[WL];
         bfrag_offsets(G.WhE, offE);
-        h8 wh[WN], wl[WN];
+        h8 wh[WL], wl[WL];
         load_bfrags(gemm::make_rsrc(G.WhE.p, (unsigned)(((N + 15) / 16) * G.WhE.nc * 2048)), offE, 0, wh, wl);
         const ColConst ce = col_consts(G.WhE.inv_scale, nullptr);
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
+        for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
             for (int rt = 0; rt < RT_E; ++rt) {
                 f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -930,7 +1001,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
 
     // ================= K3 x (depth - 1): H = tau(H0 + W_h M) =================
     for (int step = 1; step < T_steps; ++step) {
-        f32x4 acc[RT_E][WN];
+        f32x4 acc[RT_E][WL];
         zero_acc(RE{}, acc);
         const ColConst cc = col_consts(G.Wh.inv_scale, g.b_h);
         contract(RE{}, acc, T16, TS, (N + BK - 1) / BK, 0, G.Wh);
@@ -955,16 +1026,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
 
     // ================= K5: out = tau(W_o [V || Mv] + b_o) on the tile's atoms =================
     {
-        f32x4 acc[RT_A][WN];
+        f32x4 acc[RT_A][WL];
         zero_acc(RA{}, acc);
         const ColConst cc = col_consts(G.WoM.inv_scale, g.b_o);
         // the first 128 columns of the tile's V rows are fetched under the Mv contraction
         const rsrc_t rV = gemm::make_rsrc(g.V + (long long)va * g.ldv, (unsigned)(na * g.ldv) * 4u);
         const rsrc_t rnull = gemm::make_rsrc(g.W_o, 0);
-        unsigned rov[4 * RT_A];
+        unsigned rov[JR * RT_A];
 #pragma unroll
-        for (int j = 0; j < 4 * RT_A; ++j) rov[j] = wave + 4 * j < na ? (unsigned)(wave + 4 * j) * (unsigned)g.ldv * 4u : kOOB;
-        u32x2 v_grp[4 * RT_A];
+        for (int j = 0; j < JR * RT_A; ++j) rov[j] = wave + NW * j < na ? (unsigned)(wave + NW * j) * (unsigned)g.ldv * 4u : kOOB;
+        u32x2 v_grp[JR * RT_A];
         ga_load(RA{}, F_{}, 0, g.d_v, 0, rV, rnull, rov, rov, v_grp);
         // Mv part first (A = T16 rows 0..atoms-1), then the V part in the scale of its own groups
         contract(RA{}, acc, T16, TS, (N + BK - 1) / BK, 0, G.WoM);
@@ -985,7 +1056,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
             for (int rt = 0; rt < RT_A; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000)};
+                for (int ct = 0; ct < WL; ++ct) acc[rt][ct] = f32x4{__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000)};
         }
         __syncthreads();  // (the fp32 tile may overlay the V operand tile)
         frag_to_tile(RA{}, acc);
@@ -997,7 +1068,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
                 const long long m0 = G.agg_batch[va], m1 = G.agg_batch[vb - 1];
                 if (m0 >= 0 && m1 < G.agg_n_mols && m1 - m0 < BA) {
                     const int nm = (int)(m1 - m0) + 1;
-                    for (int it = tid; it < nm * QN; it += kThreads) {
+                    for (int it = tid; it < nm * QN; it += KT) {
                         const int ml = it / QN, q = it - ml * QN;
                         if (q >= qn) continue;
                         const long long m = m0 + ml;
@@ -1017,18 +1088,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16(Mega16K G) {
             }
         }
     }
+    };  // body
+    if constexpr (NW == 4) {
+        body(std::integral_constant<int, WN>{});
+    } else {
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < 4) body(std::integral_constant<int, 3>{});
+        else body(std::integral_constant<int, 2>{});
+    }
 }
 
-template <int WN, bool SA, bool KEEP>
+template <int WN, bool SA, bool KEEP, int NW = 4>
 int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
 
-#define DMPNN_DEFINE_MEGA16(WN, SA, KEEP)                                                                  \
+#define DMPNN_DEFINE_MEGA16(WN, SA, KEEP) DMPNN_DEFINE_MEGA16_NW(WN, SA, KEEP, 4)
+#define DMPNN_DEFINE_MEGA16_NW(WN, SA, KEEP, NW)                                                           \
     template <>                                                                                            \
-    int launch_mega16<WN, SA, KEEP>(const Mega16K& g, int n_tiles, hipStream_t s) {                        \
+    int launch_mega16<WN, SA, KEEP, NW>(const Mega16K& g, int n_tiles, hipStream_t s) {                    \
         const size_t lds = g.atom_de ? lds_bytes_atom<WN>() : lds_bytes<WN>();                             \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN, SA, KEEP>),          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN, SA, KEEP, NW>),          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_atom<WN>()); \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_mpnn_tile16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
@@ -1036,7 +1115,7 @@ int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
             }                                                                                              \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_mpnn_tile16<WN, SA, KEEP>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);       \
+        hipLaunchKernelGGL((k_mpnn_tile16<WN, SA, KEEP, NW>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g);   \
         DMPNN_CHECK_LAUNCH("k_mpnn_tile16");                                                               \
         return DMPNN_OK;                                                                                   \
     }
