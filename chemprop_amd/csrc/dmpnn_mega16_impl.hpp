@@ -261,18 +261,26 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
     };
     stamp();  // 0: kernel entry
     const int t = blockIdx.x;
-    const int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
-    const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
+    // The tile's four table words and the plan's two header words in ONE round trip: hipcc sinks the table loads below the poison
+    // branch otherwise (they are dead on that path), which made the header a dependent round trip of its own in front of them —
+    // four round trips before the first operand byte is requested instead of three (ISA, round 6).
+    int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
+    int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
+    int hdr_light = g.flags[DMPNN_HDR_LIGHT], hdr_flags = g.flags[0];
+    asm volatile("" : "+v"(rs), "+v"(re), "+v"(va), "+v"(vb), "+v"(hdr_light), "+v"(hdr_flags));
+    rs = __builtin_amdgcn_readfirstlane(rs); re = __builtin_amdgcn_readfirstlane(re);
+    va = __builtin_amdgcn_readfirstlane(va); vb = __builtin_amdgcn_readfirstlane(vb);
+    hdr_light = __builtin_amdgcn_readfirstlane(hdr_light); hdr_flags = __builtin_amdgcn_readfirstlane(hdr_flags);
     const int nrows = re - rs, na = vb - va;
     const int N = g.h, qn = N >> 2;
     // Tile plan (header LIGHT == 2): the rows of a tile are its edges in the CALLER's order, src / dst / rev come
     // straight from the caller's int64 arrays and the tile checks by itself that it is closed (every edge id in
     // its range has both atoms and its reverse edge inside the tile; by counting, no other edge then enters its
     // atoms).  A tile that is not closed writes NaN to its atoms.
-    const bool lean = g.flags[DMPNN_HDR_LIGHT] == 2;
+    const bool lean = hdr_light == 2;
     // (a training forward on a tile plan keeps its tensors in the caller's edge order: dmpnn_backward takes them so when told
     //  DMPNN_F_TILE_PLAN, dmpnn_mega16_bwd_impl.hpp)
-    const bool poison = (g.flags[0] & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64));
+    const bool poison = (hdr_flags & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64));
     if (poison) {
         const float nanv = __int_as_float(0x7fc00000);
         const long long total = (long long)g.nV * N;
