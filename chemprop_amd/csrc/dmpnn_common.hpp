@@ -301,6 +301,8 @@ int launch_split_args(const mega16::SplitArgs& sp, hipStream_t s);
 bool linear16_ok(const dmpnn_gemm_args& a);
 int launch_linear16_view(const dmpnn_gemm_args& a, const SplitWView& W, const int* poison_flags, int poison_mask, hipStream_t s);
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s);
+// waves per tile workgroup of the whole-forward / backward tile kernels for this batch (4, or 8 when the launch has at most one tile per CU)
+int tile_waves(const dmpnn_fwd_args& a, int n_tiles);
 // per-step fused route on the f16 pipe (dmpnn_step16.hip): inference forward, any molecule size, d_h <= 320
 bool fused16_shapes_ok(const dmpnn_fwd_args& a);
 // its LEAN training forward (dmpnn_step16.hip) and the backward that reads what it keeps (dmpnn_bstep16.hip)

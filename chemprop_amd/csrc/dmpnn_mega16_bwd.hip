@@ -11,6 +11,9 @@ DMPNN_DEFINE_MEGA16_BWD(5, true)
 DMPNN_DEFINE_MEGA16_BWD(1, false)
 DMPNN_DEFINE_MEGA16_BWD(2, false)
 DMPNN_DEFINE_MEGA16_BWD(5, false)
+// one tile as a 512-thread workgroup (launches of at most one tile per CU: tile_waves, dmpnn_mega16.hip)
+DMPNN_DEFINE_MEGA16_BWD_NW(5, true, 8)
+DMPNN_DEFINE_MEGA16_BWD_NW(5, false, 8)
 }  // namespace mega16
 
 static size_t al256b(size_t x) { return (x + 255) & ~size_t(255); }
@@ -78,6 +81,7 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     const bool sa = f.act == DMPNN_ACT_NONE || f.act == DMPNN_ACT_RELU || f.act == DMPNN_ACT_LEAKYRELU;
     if (h <= 64) return sa ? mega16::launch_mega16_bwd<1, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<1, false>(g, n_tiles, s);
     if (h <= 128) return sa ? mega16::launch_mega16_bwd<2, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<2, false>(g, n_tiles, s);
+    if (tile_waves(f, n_tiles) == 8) return sa ? mega16::launch_mega16_bwd<5, true, 8>(g, n_tiles, s) : mega16::launch_mega16_bwd<5, false, 8>(g, n_tiles, s);
     return sa ? mega16::launch_mega16_bwd<5, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<5, false>(g, n_tiles, s);
 }
 

@@ -67,8 +67,12 @@ constexpr size_t bwd_lds_bytes() {
 // SA: identity / ReLU / LeakyReLU (mask from the sign of the output: compare + select); tanh / ELU — whose derivative code
 // would otherwise be inlined per fragment element at every call site — get their own instantiation (code size is
 // instruction-fetch latency for a kernel that runs its code once per tile).
-template <int WN, bool SA>
-__global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
+// NW: waves per workgroup, as in the forward (dmpnn_mega16_impl.hpp): 8 = one tile as a 512-thread workgroup whose waves own 3+3+3+3+2+2+2+2
+// column tiles (d_h in (128, 320]), for launches of at most one tile per CU; each wave class runs its own instantiation of the body.
+template <int WN, bool SA, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
+    static_assert(NW == 4 || (NW == 8 && WN == 5), "the 8-wave form splits 20 column tiles 3+3+3+3+2+2+2+2");
+    constexpr int KT = 64 * NW;
     constexpr int BM = kMegaBM, BA = kMegaBA, BN = 64 * WN, QN = BN / 4;
     constexpr int TS = BN * 4 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -92,23 +96,27 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     const int t = blockIdx.x;
     const int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
     const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
+    // (the forward kernel forces these four words and the two header words into ONE round trip; the same six lines made this kernel
+    //  fault on the GPU at 230 tiles — both wave counts, not at 29 tiles — and bought nothing measurable in the forward: left alone here)
+    const int hdr_light = g.flags[DMPNN_HDR_LIGHT], hdr_flags = g.flags[0];
     const int nrows = re - rs, na = vb - va;
     const int N = g.h, qn = N >> 2;
     const int T_steps = g.depth;
     const float nanv = __int_as_float(0x7fc00000);
-    const bool lean = g.flags[DMPNN_HDR_LIGHT] == 2;
-    if ((g.flags[0] & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64))) {  // a graph this route cannot represent: every output NaN
+    const bool lean = hdr_light == 2;
+    if ((hdr_flags & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64))) {  // a graph this route cannot represent: every output NaN
         const long long tot_e = (long long)g.nE * N, tot_v = (long long)g.nV * N;
-        for (long long i = (long long)blockIdx.x * kThreads + tid; i < tot_e; i += (long long)gridDim.x * kThreads) {
+        for (long long i = (long long)blockIdx.x * KT + tid; i < tot_e; i += (long long)gridDim.x * KT) {
             g.gH0[(i / N) * g.ldh + (i % N)] = nanv;
             for (int s = 0; s < T_steps - 1; ++s) g.gZs[(long long)s * g.slot + (i / N) * g.ldh + (i % N)] = nanv;
         }
-        for (long long i = (long long)blockIdx.x * kThreads + tid; i < tot_v; i += (long long)gridDim.x * kThreads)
+        for (long long i = (long long)blockIdx.x * KT + tid; i < tot_v; i += (long long)gridDim.x * KT)
             g.gZO[(i / N) * g.ldh + (i % N)] = nanv;
         return;
     }
     if (na <= 0 || nrows < 0) return;
     if (nrows > BM || na > BA) {  // a piece larger than the matrix-pipe tile: the generic fp32 path, any size
+        if (NW > 4 && threadIdx.x >= kThreads) return;  // (written for 256 threads; s_barrier counts live waves only)
         const Mega16BwdK& g = *spill::fresh_kernargs<Mega16BwdK>();  // (shadows the hot path's copy: see fresh_kernargs)
         if (g.atom) {  // ... which knows bond messages only: the forward tile kernel returned NaN for this molecule, so do its gradients
             for (int i = tid; i < nrows * N; i += kThreads) {
@@ -177,21 +185,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         if (row_bad) atomicOr(&maxbits[5], 1u);
         __syncthreads();
         if (maxbits[5]) {  // (uniform)
-            for (int i = tid; i < nrows * N; i += kThreads) {
+            for (int i = tid; i < nrows * N; i += KT) {
                 const long long o = (long long)(rs + i / N) * g.ldh + (i % N);
                 g.gH0[o] = nanv;
                 for (int s = 0; s < T_steps - 1; ++s) g.gZs[(long long)s * g.slot + o] = nanv;
             }
-            for (int i = tid; i < na * N; i += kThreads) g.gZO[(long long)(va + i / N) * g.ldh + (i % N)] = nanv;
+            for (int i = tid; i < na * N; i += KT) g.gZO[(long long)(va + i / N) * g.ldh + (i % N)] = nanv;
             if (g.gZrows) {   // ... and as split rows (what the products read): NaN in every hi half, scale 1
                 const int nh = ((N + 31) >> 5) * 32;   // hi halfs of a row's live chunks
                 const _Float16 hn = (_Float16)nanv;
                 auto nan_rows = [&](unsigned char* base, long long r0, int n) {
-                    for (int i = tid; i < n * nh; i += kThreads) {
+                    for (int i = tid; i < n * nh; i += KT) {
                         const int r = i / nh, c = i - r * nh;
                         *reinterpret_cast<_Float16*>(base + (r0 + r) * g.tsr + (c >> 5) * 128 + (c & 31) * 2) = hn;
                     }
-                    for (int r = tid; r < n; r += kThreads) *reinterpret_cast<float4*>(base + (r0 + r) * g.tsr + (g.tsr - 16)) = make_float4(1.f, 0.f, 0.f, 0.f);
+                    for (int r = tid; r < n; r += KT) *reinterpret_cast<float4*>(base + (r0 + r) * g.tsr + (g.tsr - 16)) = make_float4(1.f, 0.f, 0.f, 0.f);
                 };
                 for (int sl = 0; sl < T_steps - 1; ++sl) nan_rows(g.gZrows + (long long)sl * g.zrow_slot, rs, nrows);
                 nan_rows(g.gH0rows, rs, nrows);
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) rk_[i] = ((i >> 2) * 16 + lg * 4 + (i & 3)) < nrows ? qa[i] : -3;
     }
-    for (int f = wave; f < 9; f += 4) {
+    for (int f = wave; f < 9; f += NW) {
         const bool gat = f < 3;
         const int jt = gat ? f : (f - 3) >> 1, ks = gat ? 0 : (f - 3) & 1;
         const int j = jt * 16 + li;  // row r'
@@ -276,15 +284,58 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         return scale_for(mx);
     };
 
-    // ---- contraction acc[RT][WN] += T16 . W'^T (10 chunks for d_h = 300), weight fragments straight from L2 ----
-    auto contract = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], const SplitW& W) {
+    using RE = std::integral_constant<int, RT_E>;
+    using RA = std::integral_constant<int, RT_A>;
+    // ================= finalize backward: gZO = gHO * tau'(HO) on the tile's atoms, row-major =================
+    float sA;
+    {
+        constexpr int ITEMS_A = BA * QN / KT;
+        float4 z[ITEMS_A];
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < ITEMS_A; ++j) {
+            const int it = tid + KT * j;
+            const int a = it / QN, q = it - a * QN;
+            const bool ok = a < na && q < qn;
+            const long long row = va + (ok ? a : 0);
+            const float4 gv = *reinterpret_cast<const float4*>(g.gHO + row * g.ldg + (ok ? 4 * q : 0));
+            const float4 yv = *reinterpret_cast<const float4*>(g.HO + row * g.ldho + (ok ? 4 * q : 0));
+            z[j] = ok ? make_float4(dact(gv.x, yv.x, false), dact(gv.y, yv.y, false), dact(gv.z, yv.z, false), dact(gv.w, yv.w, false))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(z[j].x), fabsf(z[j].y)), fmaxf(fabsf(z[j].z), fabsf(z[j].w))));
+            if (ok && !g.gZOrows) store_keep4(g.gZO + row * g.ldh + 4 * q, z[j]);
+        }
+        sA = tile_scale(mx);
+#pragma unroll
+        for (int j = 0; j < ITEMS_A; ++j) {
+            const int it = tid + KT * j;
+            const int a = it / QN, q = it - a * QN;
+            h4 hi, lo;
+            split4(z[j], sA, hi, lo);
+            unsigned char* p = T16 + a * TS + (q >> 3) * 128 + (q & 7) * 8;
+            *reinterpret_cast<h4*>(p) = hi;
+            *reinterpret_cast<h4*>(p + 64) = lo;
+            if (g.gZOrows && a < na && q < qn) {   // (gZOrows: uniform) the same pieces to the atoms' split rows
+                unsigned char* o = g.gZOrows + (long long)(va + a) * g.tsr + (q >> 3) * 128 + (q & 7) * 8;
+                *reinterpret_cast<h4*>(o) = hi;
+                *reinterpret_cast<h4*>(o + 64) = lo;
+            }
+        }
+        if (g.gZOrows && tid < na) *reinterpret_cast<float4*>(g.gZOrows + (long long)(va + tid) * g.tsr + (g.tsr - 16)) = make_float4(sA, tile_mx > 0.f ? 0.f : 1.f, 0.f, 0.f);
+    }
+    // ---- the tile's body per wave class (WL column tiles from ct0(); NW = 4: WL = WN for every wave) ----
+    auto body = [&](auto wl_c) __attribute__((always_inline)) {
+    constexpr int WL = decltype(wl_c)::value;
+    auto ct0 = [&]() -> int { return (NW == 8 && WL == 2) ? 2 * wave + 4 : WL * wave; };
+    // ---- contraction acc[RT][WL] += T16 . W'^T (10 chunks for d_h = 300), weight fragments straight from L2 ----
+    auto contract = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WL], const SplitW& W) {
         constexpr int RT = decltype(rt_c)::value;
         const int n_chunks = (N + 31) / 32;
         const gemm::rsrc_t rW = gemm::make_rsrc(W.p, (unsigned)(((N + 15) / 16) * W.nc * 2048));
-        unsigned offB[WN];
+        unsigned offB[WL];
         launder();
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) offB[ct] = (unsigned)(wave * WN + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
+        for (int ct = 0; ct < WL; ++ct) offB[ct] = (unsigned)(ct0() + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
         auto read_a = [&](int c, h8 (&ah)[RT], h8 (&al)[RT]) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -295,9 +346,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         };
         // the forward tile kernel's contraction (dmpnn_mega16_impl.hpp): one set of weight fragments as a ring over the column
         // tiles, two workgroups per CU (73 KB of LDS, <= 256 registers)
-        h8 bh[WN], bl[WN], a0h[RT], a0l[RT], a1h[RT], a1l[RT];
+        h8 bh[WL], bl[WL], a0h[RT], a0l[RT], a1h[RT], a1l[RT];
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
+        for (int ct = 0; ct < WL; ++ct) {
             bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct], 0, 0));
             bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + 1024u, 0, 0));
         }
@@ -307,7 +358,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         auto chunk = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&nah)[RT], h8 (&nal)[RT]) {
             const bool more = c + 1 < n_chunks;
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct) {
+            for (int ct = 0; ct < WL; ++ct) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
 #pragma unroll
@@ -318,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
                 const unsigned o = more ? offB[ct] + (unsigned)(c + 1) * 2048u : gemm::kOOB;
                 bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
                 bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more ? o + 1024u : gemm::kOOB, 0, 0));
-                if (ct == (WN > 1 ? WN - 2 : 0)) read_a(more ? c + 1 : c, nah, nal);
+                if (ct == (WL > 1 ? WL - 2 : 0)) read_a(more ? c + 1 : c, nah, nal);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -329,12 +380,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         }
     };
     // split domain -> fp32 (no bias): acc / (sA sW[col])
-    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WN], float inv_sA, const float* inv_sW) {
+    auto unscale = [&](auto rt_c, f32x4 (&acc)[decltype(rt_c)::value][WL], float inv_sA, const float* inv_sW) {
         constexpr int RT = decltype(rt_c)::value;
         launder();
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const int col = wave * (16 * WN) + ct * 16 + li;
+        for (int ct = 0; ct < WL; ++ct) {
+            const int col = (ct0() + ct) * 16 + li;
             const float isw = inv_sW[col < N ? col : 0] * inv_sA;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
@@ -344,14 +395,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     };
     // incidence MFMA on C/D fragments X (RT row tiles) -> transposed fragments m[ct][jt] (row jt*16+li, 4 columns
     // ct*16 + lg*4 ..): m = C . X.  f0: first incidence fragment; two k-steps when RT == 3, one when RT == 2.
-    auto incidence = [&](auto rt_c, const f32x4 (&X)[decltype(rt_c)::value][WN], int f0, f32x4 (&m)[WN][RT_E]) {
+    auto incidence = [&](auto rt_c, const f32x4 (&X)[decltype(rt_c)::value][WL], int f0, f32x4 (&m)[WL][RT_E]) {
         constexpr int RT = decltype(rt_c)::value;
         launder();
         float hm = 0.f;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hm = fmaxf(hm, fabsf(X[rt][ct][r]));
         const float sX = scale_for(wave_max(hm));
@@ -362,7 +413,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             cf[jt][1] = RT == 3 ? cfrag[(f0 + 2 * jt + 1) * 64 + lane] : cf[jt][0];
         }
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
+        for (int ct = 0; ct < WL; ++ct) {
             h8 ah0, al0, ah1, al1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -387,30 +438,34 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         }
         const float isX = 1.f / sX;
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
+        for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m[ct][jt][r] *= isX;
     };
     // m (edge gradient in transposed fragments) -> gz = m * tau'(Y rows); optional store; returns max |gz|
-    auto mask_rows = [&](f32x4 (&m)[WN][RT_E], const float* Y, bool preact, float* store, int bslot) -> float {
+    auto mask_rows = [&](f32x4 (&m)[WL][RT_E], const float* Y, bool preact, float* store, int bslot) -> float {
         launder();
         if constexpr (SA) {
             if (g.keep_bits) {  // (uniform) the kept tensor as sign bits in the forward's fragment order: this lane's element (row jt 16 + li,
                 // column ct 16 + 4 lg + c) is bit (li >> 2) 16 + 4 lg + c of word (jt WN + ct) 4 + (li & 3) of its wave
-                const unsigned long long* bw = g.keep_bits + (long long)bslot * g.bits_slot + (long long)t * 256 + wave * 64 + (li & 3);
+                // (ONE layout whatever the wave split: the word of global column tile gct sits at wave gct / WN, slot (jt WN + gct % WN) 4 + r)
+                const unsigned long long* bw = g.keep_bits + (long long)bslot * g.bits_slot + (long long)t * 256 + (li & 3);
                 const int sh = (li >> 2) * 16 + lg * 4;
                 const float neg = g.act == DMPNN_ACT_NONE ? 1.f : (g.act == DMPNN_ACT_RELU ? 0.f : slope);
                 float mxb = 0.f;
 #pragma unroll
-                for (int ct = 0; ct < WN; ++ct) {
+                for (int ct = 0; ct < WL; ++ct) {
                     unsigned nib[RT_E];
 #pragma unroll
-                    for (int jt = 0; jt < RT_E; ++jt) nib[jt] = (unsigned)(bw[(jt * WN + ct) * 4] >> sh) & 0xFu;
+                    for (int jt = 0; jt < RT_E; ++jt) {
+                        const int gct = ct0() + ct;
+                        nib[jt] = (unsigned)(bw[(gct / WN) * 64 + (jt * WN + gct % WN) * 4] >> sh) & 0xFu;
+                    }
 #pragma unroll
                     for (int jt = 0; jt < RT_E; ++jt) {
-                        const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                        const int row = jt * 16 + li, col4 = (ct0() + ct) * 16 + lg * 4;
                         const bool ok = row < nrows && col4 < N;
                         f32x4 v;
 #pragma unroll
@@ -431,7 +486,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         auto load_y = [&](int ct, float4 (&y)[RT_E]) {
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
-                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                const int row = jt * 16 + li, col4 = (ct0() + ct) * 16 + lg * 4;
                 const bool ok = row < nrows && col4 < N;
                 y[jt] = *reinterpret_cast<const float4*>(Y + (long long)(rs + (ok ? row : 0)) * g.ldh + (ok ? col4 : 0));
             }
@@ -440,11 +495,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         load_y(0, y[0]);
         float mx = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            if (ct + 1 < WN) load_y(ct + 1, y[(ct + 1) & 1]);
+        for (int ct = 0; ct < WL; ++ct) {
+            if (ct + 1 < WL) load_y(ct + 1, y[(ct + 1) & 1]);
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
-                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                const int row = jt * 16 + li, col4 = (ct0() + ct) * 16 + lg * 4;
                 const bool ok = row < nrows && col4 < N;
                 const float4 yv = y[ct & 1][jt];
                 f32x4 v;
@@ -462,11 +517,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     // transposed fragments -> split A tile of the next contraction (all 48 rows, zero where there is no row / column)
     // `rows` (or null): the same pieces also to the split rows [n_edges][tsr] of a product operand, the scale into the rows' tails;
     // to_lds false: those alone (gH0: nothing contracts it here)
-    auto stage_rows = [&](const f32x4 (&m)[WN][RT_E], float s, unsigned char* rows, bool to_lds) {
+    auto stage_rows = [&](const f32x4 (&m)[WL][RT_E], float s, unsigned char* rows, bool to_lds) {
         launder();
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+        for (int ct = 0; ct < WL; ++ct) {
+            const int col4 = (ct0() + ct) * 16 + lg * 4;
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
                 const int row = jt * 16 + li;
@@ -492,12 +547,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         }
     };
     // the gradient with respect to H0 leaves: fp32 rows, or (split rows) with a tile scale of its own
-    auto store_gh0 = [&](const f32x4 (&x)[WN][RT_E]) {
+    auto store_gh0 = [&](const f32x4 (&x)[WL][RT_E]) {
         launder();
         if (g.gH0rows) {   // (uniform)
             float mx = 0.f;
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                 for (int jt = 0; jt < RT_E; ++jt)
 #pragma unroll
@@ -507,8 +562,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             return;
         }
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
-            const int col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+        for (int ct = 0; ct < WL; ++ct) {
+            const int col4 = (ct0() + ct) * 16 + lg * 4;
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
                 const int row = jt * 16 + li;
@@ -517,54 +572,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             }
         }
     };
-    using RE = std::integral_constant<int, RT_E>;
-    using RA = std::integral_constant<int, RT_A>;
 
-    // ================= finalize backward: gZO = gHO * tau'(HO) on the tile's atoms, row-major =================
-    float sA;
-    {
-        constexpr int ITEMS_A = BA * QN / kThreads;
-        float4 z[ITEMS_A];
-        float mx = 0.f;
-#pragma unroll
-        for (int j = 0; j < ITEMS_A; ++j) {
-            const int it = tid + kThreads * j;
-            const int a = it / QN, q = it - a * QN;
-            const bool ok = a < na && q < qn;
-            const long long row = va + (ok ? a : 0);
-            const float4 gv = *reinterpret_cast<const float4*>(g.gHO + row * g.ldg + (ok ? 4 * q : 0));
-            const float4 yv = *reinterpret_cast<const float4*>(g.HO + row * g.ldho + (ok ? 4 * q : 0));
-            z[j] = ok ? make_float4(dact(gv.x, yv.x, false), dact(gv.y, yv.y, false), dact(gv.z, yv.z, false), dact(gv.w, yv.w, false))
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(z[j].x), fabsf(z[j].y)), fmaxf(fabsf(z[j].z), fabsf(z[j].w))));
-            if (ok && !g.gZOrows) store_keep4(g.gZO + row * g.ldh + 4 * q, z[j]);
-        }
-        sA = tile_scale(mx);
-#pragma unroll
-        for (int j = 0; j < ITEMS_A; ++j) {
-            const int it = tid + kThreads * j;
-            const int a = it / QN, q = it - a * QN;
-            h4 hi, lo;
-            split4(z[j], sA, hi, lo);
-            unsigned char* p = T16 + a * TS + (q >> 3) * 128 + (q & 7) * 8;
-            *reinterpret_cast<h4*>(p) = hi;
-            *reinterpret_cast<h4*>(p + 64) = lo;
-            if (g.gZOrows && a < na && q < qn) {   // (gZOrows: uniform) the same pieces to the atoms' split rows
-                unsigned char* o = g.gZOrows + (long long)(va + a) * g.tsr + (q >> 3) * 128 + (q & 7) * 8;
-                *reinterpret_cast<h4*>(o) = hi;
-                *reinterpret_cast<h4*>(o + 64) = lo;
-            }
-        }
-        if (g.gZOrows && tid < na) *reinterpret_cast<float4*>(g.gZOrows + (long long)(va + tid) * g.tsr + (g.tsr - 16)) = make_float4(sA, tile_mx > 0.f ? 0.f : 1.f, 0.f, 0.f);
-    }
     // gMv = gZO . W_o[:, d_v:]
-    f32x4 m[WN][RT_E];
+    f32x4 m[WL][RT_E];
     {
-        f32x4 acc[RT_A][WN];
+        f32x4 acc[RT_A][WL];
 #pragma unroll
         for (int rt = 0; rt < RT_A; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < WL; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         contract(RA{}, acc, g.WoMT);
         unscale(RA{}, acc, 1.f / sA, g.WoMT.inv_scale);
         incidence(RA{}, acc, 0, m);  // gH[r] = gMv[dst r]
@@ -572,11 +588,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     if (g.g_edge) {  // (uniform) + dL/dH^(T-1) of the edge read-out
         launder();
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct) {
+        for (int ct = 0; ct < WL; ++ct) {
             float4 y[RT_E];
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
-                const int row = jt * 16 + li, col4 = wave * (16 * WN) + ct * 16 + lg * 4;
+                const int row = jt * 16 + li, col4 = (ct0() + ct) * 16 + lg * 4;
                 const bool ok = row < nrows && col4 < N;
                 y[jt] = *reinterpret_cast<const float4*>(g.g_edge + (long long)(rs + (ok ? row : 0)) * g.ld_ge + (ok ? col4 : 0));
                 if (!ok) y[jt] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -587,7 +603,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
             }
         }
     }
-    f32x4 gh0[WN][RT_E];
+    f32x4 gh0[WL][RT_E];
     if (T_steps == 1) {
         mask_rows(m, g.H0, true, g.gH0rows ? nullptr : g.gH0, 0);
         if (g.gH0rows) store_gh0(m);
@@ -597,25 +613,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     {
         const float mx = mask_rows(m, g.Hs + (long long)(T_steps - 2) * g.slot, false, g.gZrows ? nullptr : g.gZs + (long long)(T_steps - 2) * g.slot, T_steps - 1);
 #pragma unroll
-        for (int ct = 0; ct < WN; ++ct)
+        for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] = m[ct][jt];
         sA = tile_scale(mx);  // (barrier: every wave is past its reads of T16)
         stage_rows(m, sA, g.gZrows ? g.gZrows + (long long)(T_steps - 2) * g.zrow_slot : nullptr, true);
     }
     for (int t = T_steps - 1; t >= 1; --t) {
-        f32x4 acc[RT_E][WN];
+        f32x4 acc[RT_E][WL];
 #pragma unroll
         for (int rt = 0; rt < RT_E; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < WL; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         contract(RE{}, acc, g.WhT);              // gM = gZ^(t) . W_h
         unscale(RE{}, acc, 1.f / sA, g.WhT.inv_scale);
         incidence(RE{}, acc, 3, m);              // gH^(t-1) = C^T gM
         if (t - 1 >= 1) {
             const float mx = mask_rows(m, g.Hs + (long long)(t - 2) * g.slot, false, g.gZrows ? nullptr : g.gZs + (long long)(t - 2) * g.slot, t - 1);
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                 for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] += m[ct][jt];
             sA = tile_scale(mx);
@@ -623,24 +639,32 @@ __global__ __launch_bounds__(kThreads, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
         } else {
             mask_rows(m, g.H0, true, nullptr, 0);   // through H^(0) = tau(H0)
 #pragma unroll
-            for (int ct = 0; ct < WN; ++ct)
+            for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
                 for (int jt = 0; jt < RT_E; ++jt) gh0[ct][jt] += m[ct][jt];
         }
     }
     store_gh0(gh0);
+    };  // body
+    if constexpr (NW == 4) {
+        body(std::integral_constant<int, WN>{});
+    } else {
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < 4) body(std::integral_constant<int, 3>{});
+        else body(std::integral_constant<int, 2>{});
+    }
 }
 
-template <int WN, bool SA>
+template <int WN, bool SA, int NW = 4>
 int launch_mega16_bwd(const Mega16BwdK& g, int n_tiles, hipStream_t s);
 
-#define DMPNN_DEFINE_MEGA16_BWD(WN, SA)                                                                     \
+#define DMPNN_DEFINE_MEGA16_BWD(WN, SA) DMPNN_DEFINE_MEGA16_BWD_NW(WN, SA, 4)
+#define DMPNN_DEFINE_MEGA16_BWD_NW(WN, SA, NW)                                                              \
     template <>                                                                                             \
-    int launch_mega16_bwd<WN, SA>(const Mega16BwdK& g, int n_tiles, hipStream_t s) {                        \
+    int launch_mega16_bwd<WN, SA, NW>(const Mega16BwdK& g, int n_tiles, hipStream_t s) {                    \
         constexpr size_t lds = bwd_lds_bytes<WN>();                                                         \
         static bool attr_set = false;                                                                       \
         if (!attr_set) {                                                                                    \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16_bwd<WN, SA>),       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16_bwd<WN, SA, NW>),       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             if (e != hipSuccess) {                                                                          \
                 set_error("hipFuncSetAttribute(k_mpnn_tile16_bwd<%d>): %s", WN, hipGetErrorString(e));      \
@@ -648,7 +672,7 @@ int launch_mega16_bwd(const Mega16BwdK& g, int n_tiles, hipStream_t s);
             }                                                                                               \
             attr_set = true;                                                                                \
         }                                                                                                   \
-        hipLaunchKernelGGL((k_mpnn_tile16_bwd<WN, SA>), dim3((unsigned)n_tiles), dim3(kThreads), lds, s, g);    \
+        hipLaunchKernelGGL((k_mpnn_tile16_bwd<WN, SA, NW>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g); \
         DMPNN_CHECK_LAUNCH("k_mpnn_tile16_bwd");                                                            \
         return DMPNN_OK;                                                                                    \
     }
