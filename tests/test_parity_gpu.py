@@ -975,6 +975,44 @@ def test_backward_full_size_vs_oracle_autograd(n_mols, kind, kw, gpu_device):
         assert err <= 2e-5, f"{k}: {err:.3e}"
 
 
+@pytest.mark.parametrize("d_h,depth,act,bias,kind,n_mols", [(800, 3, "tanh", False, "qm9", 128), (1200, 2, "tanh", True, "qm9", 160),
+                                                            (2400, 2, "elu", False, "synth40", 48), (1200, 3, "relu", False, "zinc", 64)])
+def test_hpopt_hidden_widths_forward_and_gradients(d_h, depth, act, bias, kind, n_mols, gpu_device):
+    """The widths the reference's own hyper-parameter search reaches (cli/hpopt.py:73: message_hidden_dim 300 .. 2400 in steps of
+    100; base.py:238-251 for the shapes): beyond the 640 columns of the per-step fused kernels the route rule takes the general
+    route with its contractions on the f16 pipe (k_rows16, 256-column blocks).  The whole forward (eval) AND the training forward +
+    every parameter gradient against the oracle and its autograd, at the same bars as everywhere else.  (Smooth activations for
+    the gradient cases — a ReLU mask flip at |z| ~ 1e-8 says nothing about the kernels, test_relu_gradients_at_size — and one ReLU
+    case, forward only.)"""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    bmg = synth.random_batch(n_mols, kind, seed=d_h + depth)
+    torch.manual_seed(d_h)
+    kw = dict(d_h=d_h, depth=depth, activation=act, bias=bias)
+    ref_mp = BondMessagePassing(**kw)
+    mp = BondMessagePassing(**kw)
+    mp.load_state_dict(ref_mp.state_dict())
+    G = torch.randn(bmg.V.shape[0], d_h, generator=torch.Generator().manual_seed(5))
+    w = ot.MPWeights(ref_mp.W_i.weight, ref_mp.W_h.weight, ref_mp.W_o.weight, ref_mp.W_o.bias, ref_mp.W_i.bias, ref_mp.W_h.bias)
+    ref = ot.forward_bmg(bmg, w, depth=depth, activation=act)
+    mp = mp.to(gpu_device)
+    bmg.to(gpu_device)
+    with torch.no_grad():
+        out_eval = mp.eval()(bmg)
+    assert mp.__dict__.get("_dmpnn_route") == "general16", mp.__dict__.get("_dmpnn_route")
+    assert parity_err(out_eval.cpu().numpy(), ref.detach().numpy()) <= TOL, (d_h, "eval")
+    if act == "relu":
+        return
+    (ref * G).sum().backward()
+    out = mp.train()(bmg)
+    (out * G.to(gpu_device)).sum().backward()
+    assert parity_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= TOL, (d_h, "train")
+    for (k, p_), (_, q) in zip(mp.named_parameters(), ref_mp.named_parameters()):
+        err = parity_err(p_.grad.cpu().numpy(), q.grad.numpy())
+        assert err <= 2e-5, f"d_h {d_h} {k}: {err:.3e}"
+
+
 @pytest.mark.parametrize("n_mols,act,depth,d_h,mixed", [(512, "relu", 3, 300, False), (200, "leakyrelu", 4, 128, False), (96, "relu", 2, 64, False),
                                                        (40, "relu", 3, 300, True), (64, "relu", 1, 300, False)])
 def test_kept_sign_bits_give_the_same_gradients_as_kept_rows(n_mols, act, depth, d_h, mixed, gpu_device):
