@@ -89,7 +89,10 @@ __device__ __forceinline__ float scale_for(float maxabs) {
     if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.f;
     int e;
     frexpf(maxabs, &e);  // maxabs = m 2^e, m in [0.5, 1)
-    return ldexpf(1.f, 14 - e);
+    // (the exponent is kept within +-126: the reciprocal of every scale — one integer subtraction on the exponent, rcp_pow2 in
+    //  dmpnn_step16_impl.hpp — must be a normal number too; an operand of magnitude < 2^-112 is then split with less headroom, never to 0)
+    const int k = 14 - e;
+    return ldexpf(1.f, k > 126 ? 126 : (k < -126 ? -126 : k));
 }
 // store of a kept / gradient tensor row piece (16 bytes).  DMPNN_NT_KEEP (experiment): non-temporal — the tensors a training step
 // streams out are read again only by a later launch

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void k_clip_scale(float* __restrict__ g, int64
     const float total = sqrtf(w[0] + w[1] + w[2] + w[3]) * grad_scale;
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
     const float coef = max_norm / (total + 1e-6f);
-    if (!(coef < 1.f)) return;   // (torch multiplies by the coefficient clamped to 1: the identity)
+    if (coef >= 1.f) return;     // (torch multiplies by the coefficient clamped to 1: the identity; a NaN coefficient — a non-finite
+                                 //  total norm — is NOT >= 1: it multiplies through, as in torch, and the step becomes visibly NaN)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<float4*>(g)[i];
         v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;

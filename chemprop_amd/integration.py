@@ -241,6 +241,26 @@ def _hip_adam_class():
     return HipAdam
 
 
+def _should_accumulate(tr, batch_idx: int, accumulate: int) -> bool:
+    """Does the Trainer only accumulate on this micro-batch (no optimizer step behind it)?  Lightning's own answer where it has one
+    (``loops/training_epoch_loop.py: _should_accumulate``), else its rule: step every ``accumulate`` batches and on the epoch's last."""
+    loop = getattr(getattr(tr, "fit_loop", None), "epoch_loop", None)
+    fn = getattr(loop, "_should_accumulate", None)
+    if callable(fn):
+        try:
+            return bool(fn())
+        except Exception:
+            pass
+    n = getattr(tr, "num_training_batches", None)
+    if not isinstance(n, int):
+        dl = getattr(tr, "train_dataloader", None)
+        try:
+            n = len(dl) if dl is not None else None
+        except TypeError:
+            n = None
+    return (batch_idx + 1) % accumulate != 0 and (n is None or batch_idx + 1 != n)
+
+
 def _clip_algorithm(a) -> str:
     """``"norm"`` / ``"value"`` from what Lightning holds (``None``: its default, norm; a ``GradClipAlgorithmType`` str-enum; a string)."""
     if a is None:
@@ -369,6 +389,10 @@ def hip_mpnn_class():
             loss, logged = None, False
             fused = st["fused"]
             accumulate = int(getattr(tr, "accumulate_grad_batches", 1) or 1)
+            # Trainer(accumulate_grad_batches > 1): Lightning zeroes the gradients on the FIRST micro-batch of a window and steps on
+            # the last; the block's backward kernels OVERWRITE their gradient views once per exchange (GradSync._written), so the
+            # exchange — which re-arms the views — must run on the stepping micro-batch only (backward() below)
+            self.__dict__["_hip_accumulating"] = accumulate > 1 and _should_accumulate(tr, batch_idx, accumulate)
             if fused is not None and V_d is None and X_d is None and self.training and accumulate == 1:
                 try:
                     clip = (getattr(tr, "gradient_clip_val", None), _clip_algorithm(getattr(tr, "gradient_clip_algorithm", None)))
@@ -417,8 +441,10 @@ def hip_mpnn_class():
             with backward_on_calling_thread():
                 super().backward(loss, *args, **kwargs)
             st = self.__dict__.get("_hip")
-            if st is not None and self._hip_trainer()[1] is not None:
-                st["sync"].allreduce()        # ONE flat all-reduce (no-op on one rank); the clip and the update wait for it on the stream
+            if st is not None and self._hip_trainer()[1] is not None and not self.__dict__.get("_hip_accumulating"):
+                # ONE flat all-reduce per optimizer step (no-op on one rank; the clip and the update wait for it on the stream).  Inside
+                # an accumulation window the views stay marked as written: the next micro-batch's block backward ADDS to them
+                st["sync"].allreduce()
 
         def configure_gradient_clipping(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
             if self.__dict__.get("_hip_applied"):

@@ -136,6 +136,8 @@ class MulticlassClassificationFFN(RegressionFFN):
         super().__init__(n_tasks * n_classes, input_dim, hidden_dim, n_layers, dropout, activation,
                          criterion if criterion is not None else CE(torch.ones(n_tasks) if task_weights is None else task_weights))
         self.n_classes = n_classes
+        # (predictors.py:271-314 records n_tasks AND n_classes; the base class saw their product — `cls(**hparams)` must rebuild this width)
+        self.hparams.update(n_tasks=n_tasks, n_classes=n_classes)
 
     @property
     def n_tasks(self) -> int:

@@ -308,6 +308,70 @@ def test_hip_mpnn_fits_like_the_stock_class(clip, tmp_path, gpu_device):
 
 
 @pytest.mark.gpu
+def test_hip_mpnn_accumulates_gradients_like_the_stock_class(gpu_device):
+    """``Trainer(accumulate_grad_batches=2)`` (round-5 ADVICE, medium): Lightning zeroes the gradients on the first micro-batch of a
+    window and steps on the last (and on the epoch's last batch: 5 batches -> windows 2 + 2 + 1).  Such a Trainer takes ``HipMPNN`` to
+    the module path, whose block backward kernels OVERWRITE their gradient views once per exchange — the exchange (and with it the
+    re-arming of the views) must therefore run on the stepping micro-batch only, or the block keeps the last micro-batch's gradient
+    while the predictor holds the sum.  Against the stock class on the CPU through the same loop: 3 optimizer steps, same parameters."""
+    from chemprop_amd import integration
+
+    R = _ref()
+    HipMPNN = integration.hip_mpnn_class()[1]
+    torch.manual_seed(11)
+    model = _model(R, HipMPNN, d_h=64, hidden=32).to(gpu_device)
+    twin = _cpu_twin(R, model)
+
+    def run(m, dev):
+        tr = R["pl"].Trainer(max_epochs=1, accumulate_grad_batches=2)
+        routes = []
+        o2 = m.on_train_batch_end
+
+        def end(out, b, i):
+            st = m.__dict__.get("_hip")
+            routes.append(st["route"] if st else None)
+            return o2(out, b, i)
+
+        m.on_train_batch_end = end
+        tr.fit(m, _batches(R, 5, 16, device=dev))
+        return tr, routes
+
+    tr, routes = run(model, gpu_device)
+    tr_c, _ = run(twin, "cpu")
+    torch.cuda.synchronize()
+    assert tr.global_step == 3 == tr_c.global_step
+    assert all(r == "module" for r in routes), routes
+    for k, v in twin.state_dict().items():
+        if k.startswith("metrics.") or k.endswith("num_batches_tracked"):
+            continue
+        assert parity_err(model.state_dict()[k].cpu().numpy(), v.numpy()) <= 5e-4, k
+    # ... and the block's weights did move by the SUM of the window's gradients, not by the last micro-batch's alone: one window,
+    # gradients captured just before the step, against the stock class's
+    torch.manual_seed(12)
+    m2 = _model(R, HipMPNN, d_h=64, hidden=32).to(gpu_device)
+    t2 = _cpu_twin(R, m2)
+    grads = {}
+
+    def grab(m, store):
+        o = m.on_before_optimizer_step
+
+        def hook(opt):
+            store.update({k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None})
+            return o(opt)
+
+        m.on_before_optimizer_step = hook
+
+    g_hip, g_cpu = {}, {}
+    grab(m2, g_hip)
+    grab(t2, g_cpu)
+    R["pl"].Trainer(max_epochs=1, accumulate_grad_batches=2).fit(m2, _batches(R, 2, 16, device=gpu_device, seed=30))
+    R["pl"].Trainer(max_epochs=1, accumulate_grad_batches=2).fit(t2, _batches(R, 2, 16, seed=30))
+    assert g_hip and set(g_hip) == set(g_cpu)
+    for k in g_cpu:
+        assert parity_err(g_hip[k].numpy(), g_cpu[k].numpy()) <= 2e-5, k
+
+
+@pytest.mark.gpu
 def test_hip_mpnn_clip_equals_torch_clip_grad_norm(gpu_device):
     """ONE step with ``gradient_clip_val`` small enough to bite, constant learning rate: the parameters after the fused step (clip
     inside ``dmpnn_train_step``: ``dmpnn_step_args.clip_val``) and after the module-path step (``FlatAdam.clip_grad`` from
@@ -479,3 +543,33 @@ def test_hip_mpnn_under_a_ddp_wrap_with_rccl_world_1(tmp_path, gpu_device):
         os.environ.pop("DMPNN_FORCE_COLLECTIVE", None)
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_hip_mpnn_under_the_real_lightning_trainer(tmp_path, gpu_device):
+    """The smoke test for a box that HAS ``lightning`` (this image and the GPU box do not: skipped — round-5 ADVICE): the real
+    ``Trainer.fit`` for two steps with clipping, then a resume from its checkpoint.  Everything else in this file runs against the
+    stand-in (``oracle/lightning_shim.py``); INTEGRATION.md 2e lists what a maintainer must re-check here."""
+    import importlib.metadata as md
+
+    try:
+        md.version("lightning")
+    except md.PackageNotFoundError:
+        pytest.skip("lightning is not installed (verification is against oracle/lightning_shim.py)")
+    import lightning.pytorch as pl
+    from chemprop_amd import integration
+
+    R = _ref()
+    HipMPNN = integration.hip_mpnn_class()[1]
+    torch.manual_seed(7)
+    model = _model(R, HipMPNN, d_h=64, hidden=32).to(gpu_device)
+    tr = pl.Trainer(accelerator="gpu", devices=1, max_steps=2, gradient_clip_val=0.05, default_root_dir=str(tmp_path), logger=False,
+                    enable_progress_bar=False)
+    tr.fit(model, _batches(R, 2, 16, device=gpu_device))
+    assert tr.global_step == 2
+    ck = tmp_path / "two.ckpt"
+    tr.save_checkpoint(str(ck))
+    tr2 = pl.Trainer(accelerator="gpu", devices=1, max_steps=3, default_root_dir=str(tmp_path), logger=False, enable_progress_bar=False)
+    tr2.fit(model, _batches(R, 3, 16, device=gpu_device), ckpt_path=str(ck))
+    assert tr2.global_step == 3
+
