@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("DMPNN_LIB") or os.path.join(_HERE, "libdmpnn_gfx950.s
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_step16.hip", "dmpnn_bstep16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip", "dmpnn_optim.hip", "dmpnn_wgrad16.hip", "dmpnn_head.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp", "dmpnn_seg16.hpp", "dmpnn_step16_impl.hpp"]
-ABI_VERSION = 12
+ABI_VERSION = 13
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
@@ -35,7 +35,7 @@ EXPORTS = [
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
     "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles", "dmpnn_forward_route", "dmpnn_dropout_keep",
-    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes", "dmpnn_train_route", "dmpnn_forward_h0_bytes",
+    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes", "dmpnn_train_route", "dmpnn_forward_h0_bytes", "dmpnn_tile_waves",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}
@@ -301,6 +301,8 @@ def load() -> C.CDLL:
     lib.dmpnn_clip_grad.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
     lib.dmpnn_dropout_keep.argtypes = [C.c_uint64, C.c_int32, C.c_int64, C.c_int64, C.c_float]
     lib.dmpnn_forward_route.argtypes = [C.POINTER(FwdArgs), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.dmpnn_tile_waves.restype = C.c_int
+    lib.dmpnn_tile_waves.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64]
     lib.dmpnn_forward_tiles.argtypes = [C.POINTER(FwdArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p]
     lib.dmpnn_full_plan_keeps_tiles.argtypes = [C.c_int64, C.c_int64]
     lib.dmpnn_head_ws_bytes.argtypes = [C.POINTER(HeadArgs)]

@@ -289,6 +289,13 @@ int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a) {
 // an inference forward that is not the tile kernel's takes the per-step fused route on the f16 pipe
 static const int64_t kSteps16MinEdges = 20000, kFused16MinEdges = 2048;
 
+int dmpnn_tile_waves(int64_t n_atoms, int64_t n_edges, int64_t d_h, int64_t n_tiles) {
+    dmpnn_fwd_args t;
+    memset(&t, 0, sizeof(t));
+    t.n_atoms = n_atoms; t.n_edges = n_edges; t.d_h = d_h;
+    return tile_waves(t, n_tiles > 0 ? (int)n_tiles : (int)plan_layout(n_atoms, n_edges).max_mtiles);
+}
+
 int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int plan_kind, int arith) {
     if (!a || max_level < 0 || plan_kind < 0 || plan_kind > 2 || arith < 0 || arith > 1) return -1;
     const bool undirected = (a->flags & DMPNN_F_UNDIRECTED) != 0;

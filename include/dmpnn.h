@@ -47,8 +47,10 @@ extern "C" {
  * 12 — round 5: dmpnn_clip_grad / dmpnn_clip_grad_ws_bytes (Lightning's Trainer(gradient_clip_val), cli/train.py:1937, over the flat
  * gradient buffer) and dmpnn_step_args.clip_val / clip_mode / clip_ws (the clip between the backward pass and the update of ONE call); DMPNN_LOSS_BCE;
  * dmpnn_train_route (the training-plan / kept-form rule beside dmpnn_forward_route); dmpnn_fwd_args.h0_bytes + dmpnn_forward_h0_bytes
- * (H0 kept as row quads on the per-step fused route's inference forward). */
-#define DMPNN_ABI_VERSION 12
+ * (H0 kept as row quads on the per-step fused route's inference forward).
+ * 13 — round 6: dmpnn_tile_waves (which form of the tile kernels a launch of these shapes takes); dmpnn_prepare_tiles with a batch
+ * vector runs over several workgroups and uses the plan's unused arrays as hand-off scratch (nothing for the caller to do). */
+#define DMPNN_ABI_VERSION 13
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -410,6 +412,11 @@ int dmpnn_forward_can_fuse(const dmpnn_fwd_args* a);
 enum dmpnn_route { DMPNN_ROUTE_GENERAL = 0, DMPNN_ROUTE_GENERAL16 = 1, DMPNN_ROUTE_FUSED = 2, DMPNN_ROUTE_FUSED16 = 3,
                    DMPNN_ROUTE_MEGA = 4, DMPNN_ROUTE_MEGA16 = 5 };
 int dmpnn_forward_route(const dmpnn_fwd_args* a, int keep, int max_level, int plan_kind, int arith);
+/* v13 — waves per workgroup of the whole-forward / backward tile kernels (base.py:196-212 per tile of whole molecules) for a batch of
+ * these sizes: 8 — ONE tile per 512-thread workgroup, its 20 column tiles split 3+3+3+3+2+2+2+2 over the waves (two waves per SIMD
+ * out of one tile) — when the launch has at most one tile per CU and 128 < d_h <= 320; else 4 (two 256-thread workgroups per CU).
+ * `n_tiles`: the tile count where the host knows it (a loader's table), else 0.  DMPNN_TILE_WAVES=4|8 in the environment overrides. */
+int dmpnn_tile_waves(int64_t n_atoms, int64_t n_edges, int64_t d_h, int64_t n_tiles);
 
 /* v12 — the TRAINING side of that rule, also in the library (round-4 VERDICT weak #10: it lived in three places of the host code): for a
  * training forward of these shapes — `a`: sizes, depth, act, DMPNN_F_UNDIRECTED / DMPNN_F_ATOM, W_d (non-NULL: the block has one),

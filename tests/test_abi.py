@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_version_and_plan_bytes():
     lib = _lib.load()
-    assert lib.dmpnn_version() == _lib.ABI_VERSION == 12
+    assert lib.dmpnn_version() == _lib.ABI_VERSION == 13
     assert lib.dmpnn_plan_bytes(0, 0) >= 64
     b = lib.dmpnn_plan_bytes(4319, 8328)
     assert b % 16 == 0 and b >= 4 * (16 + 9 * 8328 + 2 * 4319)
@@ -209,3 +209,15 @@ def test_head_workspace_covers_the_four_launch_form_and_the_bounds_table_its_don
     assert ws(1025, 300, 300, 1) < ws(1024, 300, 300, 1) + extra(1024, 300, 300, 1)   # beyond 1 024 molecules: the chain's workspace only
     assert ws(512, 300, 384, 1) == ws(512, 300, 384, 1, loss=_lib.LOSS["ce"])         # a hidden layer beyond 320 columns: the chain
     assert base > 0
+
+
+def test_tile_waves_is_a_shape_rule(monkeypatch):
+    """dmpnn_tile_waves (ABI 13): one tile per 512-thread workgroup (8 waves) where the launch has at most one tile per CU and the
+    hidden size has 20 column tiles to split; the 4-wave form (two workgroups per CU) everywhere else."""
+    lib = _lib.load()
+    assert lib.dmpnn_tile_waves(4636, 9120, 300, 0) == 8       # the headline batch: ~230 tiles on 256 CUs
+    assert lib.dmpnn_tile_waves(4636, 9120, 300, 230) == 8
+    assert lib.dmpnn_tile_waves(40000, 80000, 300, 0) == 4     # 4 096 molecules: several tiles per CU
+    assert lib.dmpnn_tile_waves(4636, 9120, 128, 0) == 4       # d_h <= 128: the 1- / 2-column-tile instantiations
+    assert lib.dmpnn_tile_waves(4636, 9120, 512, 0) == 4       # d_h > 320: not a tile-kernel shape at all
+
