@@ -284,7 +284,7 @@ struct WProdRJobs { WProdR job[kWProdRMaxJobs]; int n_jobs; };
 
 namespace wg16 {
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 f16x4_t;
-constexpr int kRTW = 5;        // 16-row tiles of n per wave (20 = 320 rows per workgroup)
+using gemm::u32x4;
 constexpr int kRChunk = 4096;   // bytes of one chunk of a stage: 32 rows x 128
 
 __device__ __forceinline__ h8 tr_pair(const unsigned char* base, int off) {   // rows 8 g .. 8 g + 7 of one 16-column tile: two transpose reads
@@ -294,8 +294,16 @@ __device__ __forceinline__ h8 tr_pair(const unsigned char* base, int off) {   //
     return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs jobs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [ncz chunks of Z | 4 chunks of A] of the stage, rho16[2][32], red
+// Round 6: ONE 512-thread workgroup per CU, two stage images in LDS, filled by PLAIN global loads -> registers -> ds_write_b128.
+// The round-4 form (256 threads, two workgroups per CU, one image filled by LDS-DMA) spent 4.7 k of a stage's 9.8 k cycles ISSUING
+// the 56 DMA pieces — a CU takes ~12 bytes per cycle through that path however the pieces are issued, and a wave that waits for it
+// issues no MFMA (profiles/r04_wgrad16r_stage_stamps.txt) — and hipcc orders a wave's LDS reads behind all of its outstanding DMA,
+// so a second image bought nothing.  A stage's 56 KB as 7 x 16 bytes per thread through the L1 path (64 B/clk) are requested at
+// the top of the stage, land in registers under the stage's MFMAs, and go to the OTHER image behind them: one barrier per stage,
+// no DMA.  Wave w owns the 16-row tiles w, w + 8, w + 16 of n (<= 3) and all eight 16-column tiles of k.
+constexpr int kRTW8 = 3;
+__global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // rho16[2][32] | red | image 0 | image 1  (image: ncz chunks of Z | 4 chunks of A)
     int j = 0;
     while (j + 1 < jobs.n_jobs && (int)blockIdx.x >= jobs.job[j + 1].wg0) ++j;
     const WProdR& P = jobs.job[j];
@@ -310,40 +318,83 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs jobs) {
     const int n_rows = (int)(m_hi - m_lo);   // (> 0: the host sizes `splits` so that every split holds rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    unsigned char* Zt = lds;
-    unsigned char* At = lds + P.ncz * kRChunk;
-    _Float16* rho16 = reinterpret_cast<_Float16*>(At + 4 * kRChunk);           // [2][32]
-    unsigned* red = reinterpret_cast<unsigned*>(rho16 + 64);
+    _Float16* rho16 = reinterpret_cast<_Float16*>(lds);                       // [2][32]
+    unsigned* red = reinterpret_cast<unsigned*>(lds + 128);
+    const int img_bytes = (__builtin_amdgcn_readfirstlane(P.ncz) + 4) * kRChunk;
+    unsigned char* img0 = lds + 256;
     const unsigned char* Zr = a.Z + m_lo * P.tsz;
     const unsigned char* Ar = colsum ? Zr : a.A + m_lo * P.tsa;
+    const int ca_live = colsum ? 0 : ((P.nca - 4 * kg) < 4 ? (P.nca - 4 * kg) : 4);           // live chunks of A in this k column
+    const int n_c = P.ncz + ca_live;                                                         // chunks of a stage image
+    // ---- the loader's thread: row lr of the stage, LDS slot lq of its 128-byte line <- piece lq ^ swz(lr), chunks lc0, lc0 + 2, ..
+    const int lr = (tid & 255) >> 3, lq = tid & 7, lc0 = tid >> 8;
+    const int lpiece = lq ^ (2 * ((lr >> 1) & 1) + 4 * ((lr >> 3) & 1));
+    // (the job's fields once, as scalars: `jobs.job[j]` with a computed j is kernarg MEMORY to hipcc — it re-read tsz / tsa per piece)
+    const int tsz = __builtin_amdgcn_readfirstlane(P.tsz), tsa = __builtin_amdgcn_readfirstlane(P.tsa), ncz = __builtin_amdgcn_readfirstlane(P.ncz);
+    constexpr int kPieces = 7;   // ceil(14 chunks x 256 pieces / 512 threads)
+    // piece jj of this thread: chunk c = lc0 + 2 jj of the stage image, from Z (c < ncz) or from this k column's chunks of A
+    const unsigned char* pp[kPieces];   // address in stage 0
+    int pst[kPieces];                   // bytes per row of its operand (0: no such piece)
+#pragma unroll
+    for (int jj = 0; jj < kPieces; ++jj) {
+        const int c = lc0 + 2 * jj;
+        const bool isz = c < ncz;
+        pp[jj] = (isz ? Zr + (long long)lr * tsz + c * 128 : Ar + (long long)lr * tsa + (4 * kg + c - ncz) * 128) + lpiece * 16;
+        pst[jj] = c < n_c ? (isz ? tsz : tsa) : 0;
+    }
+    const unsigned char* tzp = Zr + (long long)(tid & 31) * tsz + (tsz - 16);   // the tails of the stage's rows: thread t < 32 owns row t
+    const unsigned char* tap = Ar + (long long)(tid & 31) * tsa + (tsa - 16);
+    u32x4 R[kPieces];
+    float sz_n = 0.f, sa_n = 0.f;
+    float2 tz_n = make_float2(0.f, 0.f), ta_n = make_float2(1.f, 0.f);
+    // requests of the stage at rows m0 ..: every load of the thread goes out before anything waits (the values are looked at in take_stage)
+    auto load_stage = [&](int m0) {
+        const bool row_ok = m0 + lr < n_rows;
+#pragma unroll
+        for (int jj = 0; jj < kPieces; ++jj) {
+            const bool ok = row_ok && pst[jj] != 0;
+            R[jj] = *reinterpret_cast<const u32x4*>(ok ? pp[jj] + (long long)m0 * pst[jj] : Zr);   // (a dead piece reads the range's first bytes: zeroed in take_stage)
+        }
+        const bool ok = tid < 32 && m0 + tid < n_rows;
+        tz_n = *reinterpret_cast<const float2*>(ok ? tzp + (long long)m0 * tsz : Zr + (tsz - 16));
+        if (!colsum) ta_n = *reinterpret_cast<const float2*>(ok ? tap + (long long)m0 * tsa : Ar + (tsa - 16));
+    };
+    auto take_stage = [&](int m0) {
+        const bool row_ok = m0 + lr < n_rows;
+#pragma unroll
+        for (int jj = 0; jj < kPieces; ++jj)
+            if (!(row_ok && pst[jj] != 0)) R[jj] = u32x4{0u, 0u, 0u, 0u};
+        const bool ok = tid < 32 && m0 + tid < n_rows;
+        sz_n = (ok && tz_n.y == 0.f) ? tz_n.x : 0.f;    // (a zero row: rho = 0)
+        sa_n = ok ? (colsum ? 1.f : (ta_n.y == 0.f ? ta_n.x : 0.f)) : 0.f;
+    };
+    auto store_stage = [&](int b) {
+        unsigned char* dst = img0 + b * img_bytes + (tid & 255) * 16;
+#pragma unroll
+        for (int jj = 0; jj < kPieces; ++jj) {
+            const int c = lc0 + 2 * jj;
+            if (pst[jj] != 0) *reinterpret_cast<u32x4*>(dst + c * kRChunk) = R[jj];
+        }
+    };
+    load_stage(0);   // (in flight under the pass over the tails)
     // ---- F: the smallest s_Z s_A over the rows of this workgroup's range (the rows' tails) ----
     if (tid == 0) red[0] = 0x7f7fffffu;
     __syncthreads();
     {
         float f = 3.0e38f;
-        for (int r = tid; r < n_rows; r += 256) {
+        for (int r = tid; r < n_rows; r += 512) {
             // tail = (scale, 1 if every element of the row's scaling unit is ZERO): such a row takes no part — its conventional scale 1
             // would otherwise drag F down by the scale of the rows that do hold values (2^30 for gradients of 1e-5) and flush them
-            const float2 tz = *reinterpret_cast<const float2*>(Zr + (long long)r * P.tsz + (P.tsz - 16));
-            const float2 ta = colsum ? make_float2(1.f, 0.f) : *reinterpret_cast<const float2*>(Ar + (long long)r * P.tsa + (P.tsa - 16));
+            const float2 tz = *reinterpret_cast<const float2*>(Zr + (long long)r * tsz + (tsz - 16));
+            const float2 ta = colsum ? make_float2(1.f, 0.f) : *reinterpret_cast<const float2*>(Ar + (long long)r * tsa + (tsa - 16));
             if (tz.y == 0.f && ta.y == 0.f) f = fminf(f, tz.x * ta.x);
         }
         for (int off = 32; off > 0; off >>= 1) f = fminf(f, __shfl_xor(f, off));
         if (lane == 0 && f > 0.f) atomicMin(&red[0], __float_as_uint(f));   // (positive floats order like their bit patterns)
     }
-    // rho of a stage's rows: thread t < 32 owns row t of the stage; the scales of stage s + 1 are requested while stage s computes
-    float sz_n = 0.f, sa_n = 0.f;
-    auto ask_scales = [&](int m0) {
-        const int r = m0 + tid;
-        const bool ok = tid < 32 && r < n_rows;
-        const float2 tz = ok ? *reinterpret_cast<const float2*>(Zr + (long long)r * P.tsz + (P.tsz - 16)) : make_float2(0.f, 0.f);
-        const float2 ta = (ok && !colsum) ? *reinterpret_cast<const float2*>(Ar + (long long)r * P.tsa + (P.tsa - 16)) : make_float2(1.f, 0.f);
-        sz_n = (ok && tz.y == 0.f) ? tz.x : 0.f;    // (a zero row: rho = 0)
-        sa_n = (ok && ta.y == 0.f) ? ta.x : 0.f;
-    };
-    ask_scales(0);
     __syncthreads();
     const float F = __uint_as_float(red[0]);
+    take_stage(0);
     auto put_rho = [&](int buf) {
         if (tid < 32) {
             const float fh = sz_n * sa_n;
@@ -351,9 +402,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs jobs) {
         }
     };
     put_rho(0);
-    f32x4 acc[kRTW][8];
+    store_stage(0);
+    f32x4 acc[kRTW8][8];
 #pragma unroll
-    for (int r = 0; r < kRTW; ++r)
+    for (int r = 0; r < kRTW8; ++r)
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) acc[r][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // transpose-read addresses inside a chunk image: rows 8 lg + (li >> 2) (+ 4 for the second read: + 512 bytes), piece
@@ -366,35 +418,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs jobs) {
         for (int h2 = 0; h2 < 2; ++h2) px[part][h2] = rowb + ((((part ^ (lg & 1)) << 2) + ((h2 ^ ((li >> 3) & 1)) << 1) + ((li >> 1) & 1)) << 4);
     const int n_nt = (P.N + 15) >> 4;                       // 16-row tiles of n
     const int kt_live = ((P.K - 128 * kg + 15) >> 4) < 8 ? ((P.K - 128 * kg + 15) >> 4) : 8;   // live 16-column tiles of this k column
-    const int ca_live = colsum ? 0 : ((P.nca - 4 * kg) < 4 ? (P.nca - 4 * kg) : 4);           // ... and its chunks of A
     // column sums: the one B fragment — column 0 (lanes li = 0) all ones, exact in f16; no lo part
     const _Float16 one = (_Float16)(li == 0 ? 1.f : 0.f);
     const h8 ones8 = h8{one, one, one, one, one, one, one, one};
-    // the DMA's lane: row (lane >> 3) of a unit of 8 rows, LDS slot lane & 7 <- piece (lane & 7) ^ swz(row)
-    const rsrc_t rZ = gemm::make_rsrc(Zr, gemm::clamp_bytes((long long)n_rows * P.tsz));
-    const rsrc_t rA = gemm::make_rsrc(Ar, colsum ? 0u : gemm::clamp_bytes((long long)n_rows * P.tsa));
-    const int n_inst = (P.ncz + ca_live) * 4;
+    __syncthreads();   // image 0 and its rho are in place
     int stage = 0;
     for (int m0 = 0; m0 < n_rows; m0 += 32, ++stage) {
-        for (int i = wave; i < n_inst; i += 4) {
-            const int c = i >> 2, u = i & 3;
-            const int r = 8 * u + (lane >> 3);
-            const int piece = (lane & 7) ^ (2 * ((r >> 1) & 1) + 4 * ((r >> 3) & 1));
-            const bool live = m0 + r < n_rows;
-            if (c < P.ncz)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rZ, (__attribute__((address_space(3))) void*)(Zt + c * kRChunk + u * 1024), 16,
-                                                         live ? (unsigned)((m0 + r) * P.tsz + c * 128 + piece * 16) : gemm::kOOB, 0, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(At + (c - P.ncz) * kRChunk + u * 1024), 16,
-                                                         live ? (unsigned)((m0 + r) * P.tsa + (4 * kg + c - P.ncz) * 128 + piece * 16) : gemm::kOOB, 0, 0, 0);
-        }
-        ask_scales(m0 + 32);
-        __syncthreads();  // (the barrier's release waits for the DMA; rho of this stage was written before the last barrier)
+        const bool more = m0 + 32 < n_rows;   // (uniform)
+        if (more) load_stage(m0 + 32);
+        const unsigned char* Zt = img0 + (stage & 1) * img_bytes;
+        const unsigned char* At = Zt + ncz * kRChunk;
         const h8 rho = *reinterpret_cast<const h8*>(rho16 + (stage & 1) * 32 + 8 * lg);
-        h8 zh[kRTW], zl[kRTW];
+        h8 zh[kRTW8], zl[kRTW8];
 #pragma unroll
-        for (int r = 0; r < kRTW; ++r) {
-            const int nt = wave + 4 * r;
+        for (int r = 0; r < kRTW8; ++r) {
+            const int nt = wave + 8 * r;
             if (nt < n_nt) {   // (wave-uniform)
                 const unsigned char* zc = Zt + (nt >> 1) * kRChunk;
                 zh[r] = tr_pair(zc, px[0][nt & 1]) * rho;
@@ -403,8 +441,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs jobs) {
         }
         if (colsum) {   // (uniform)
 #pragma unroll
-            for (int r = 0; r < kRTW; ++r) {
-                if (wave + 4 * r >= n_nt) continue;
+            for (int r = 0; r < kRTW8; ++r) {
+                if (wave + 8 * r >= n_nt) continue;
                 f32x4& d = acc[r][0];
                 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], ones8, d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[r], ones8, d, 0, 0, 0);
@@ -416,23 +454,27 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16r(WProdRJobs jobs) {
             const unsigned char* ac = At + (kt >> 1) * kRChunk;
             const h8 bh = tr_pair(ac, px[0][kt & 1]), bl = tr_pair(ac, px[1][kt & 1]);
 #pragma unroll
-            for (int r = 0; r < kRTW; ++r) {
-                if (wave + 4 * r >= n_nt) continue;
+            for (int r = 0; r < kRTW8; ++r) {
+                if (wave + 8 * r >= n_nt) continue;
                 f32x4& d = acc[r][kt];
                 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], bh, d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], bl, d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[r], bh, d, 0, 0, 0);
             }
         }
-        put_rho((stage + 1) & 1);
-        __syncthreads();  // (every wave is done with the stage before the next DMA overwrites it; the next stage's rho is in place)
+        if (more) {   // the next stage's pieces have landed under the MFMAs: into the OTHER image (last read before the previous barrier)
+            take_stage(m0 + 32);
+            put_rho((stage + 1) & 1);
+            store_stage((stage + 1) & 1);
+        }
+        __syncthreads();
     }
     // D fragment: lane (li, lg) holds rows 16 nt + 4 lg + e of n, column 16 kt + li of this workgroup's k column
     const float iF = (F > 0.f && F < 3.0e38f) ? 1.f / F : 0.f;
     float* slab = P.slab + (long long)split * P.slab_stride;
 #pragma unroll
-    for (int r = 0; r < kRTW; ++r) {
-        const int nt = wave + 4 * r;
+    for (int r = 0; r < kRTW8; ++r) {
+        const int nt = wave + 8 * r;
         if (nt >= n_nt) continue;
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt)
@@ -538,7 +580,8 @@ int launch_rows2sr(const SRJob* J, int n, hipStream_t s) {
 WProdRPlan plan_wgrad16r(int64_t M, int N, int K) {
     WProdRPlan p;
     p.n_kg = (K + 127) / 128;
-    int splits = 256 / p.n_kg;                      // ~256 workgroups per product, two or more per CU over the jobs of a launch
+    static const int wgs = [] { const char* e = getenv("DMPNN_WGRADR_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    int splits = wgs / p.n_kg;                      // ~256 workgroups per product, two or more per CU over the jobs of a launch
     if (splits < 1) splits = 1;
     int64_t rps = (M + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
@@ -564,7 +607,7 @@ int launch_wgrad16r(const WProdRJob* J, int n, hipStream_t s) {
             const int K = q.A ? q.K : 1;
             const int ncz = (q.N + 31) / 32, nca = (K + 31) / 32;
             const WProdRPlan& p = q.plan;
-            if ((q.N + 15) / 16 > 4 * wg16::kRTW || q.tsz < ncz * 128 + 16 || (q.A && q.tsa < nca * 128 + 16) ||
+            if ((q.N + 15) / 16 > 8 * wg16::kRTW8 || ncz > 10 || q.tsz < ncz * 128 + 16 || (q.A && q.tsa < nca * 128 + 16) ||
                 (int64_t)p.rows_per_split * (q.tsz > q.tsa ? q.tsz : q.tsa) > ((int64_t)1 << 31)) {
                 set_error("wgrad16r: d_h <= 320, whole chunks + tail per operand row");
                 return DMPNN_EINVAL;
@@ -579,14 +622,14 @@ int launch_wgrad16r(const WProdRJob* J, int n, hipStream_t s) {
         }
         if (nj == 0) continue;
         P.n_jobs = nj;
-        const size_t lds = (size_t)(ncz_max + 4) * wg16::kRChunk + 128 + 64;
+        const size_t lds = 256 + 2 * (size_t)(ncz_max + 4) * wg16::kRChunk;   // rho / red | two stage images
         static size_t attr_set = 0;
         if (attr_set < lds) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16r, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
             attr_set = lds;
         }
-        hipLaunchKernelGGL(wg16::k_wgrad16r, dim3((unsigned)wg), dim3(256), lds, s, P);
+        hipLaunchKernelGGL(wg16::k_wgrad16r, dim3((unsigned)wg), dim3(512), lds, s, P);
         DMPNN_CHECK_LAUNCH("k_wgrad16r");
     }
     return DMPNN_OK;
