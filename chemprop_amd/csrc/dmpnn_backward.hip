@@ -604,11 +604,12 @@ struct BwdLayout {
     int tsr, tsx, tsv;                          // row bytes: d_h columns | d_v + d_e | d_v + d_h
     size_t sr_gz, sr_gh0, sr_gzo, sr_x, sr_vm, sr_slab;
     WProdRPlan r_h, r_i, r_o, r_bh, r_bi, r_bo;
+    int sr_R;                                  // rows per workgroup of the product launch (wgrad16r_rows_per_split)
     // lean training on the per-step fused route (dmpnn_bstep16.hip): gZ of every site as split rows, written by the step kernels; the
     // products (k_wgrad16r) read them and the forward's kept M^(t) / x rows as they are
     bool lean;
     size_t lz, lz_stride, lslab;               // gZ rows of every site | slabs (W_h | b_h | W_i | b_i)
-    WProdRPlan rh, ri, rb;                     // (rb: the column-sum jobs of the bias gradients)
+    WProdRPlan rh, ri, rbh, rbi;               // (rbh / rbi: the bias gradients' column sums, riding in the products of W_h / W_i: their rows)
 };
 BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     BwdLayout L;
@@ -687,6 +688,7 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     L.sr = L.mega && mega16_keeps_rows(f) && f.d_v + f.d_e <= 512 && f.d_v + h <= 512;
     L.tsr = L.tsx = L.tsv = 0;
     L.sr_gz = L.sr_gh0 = L.sr_gzo = L.sr_x = L.sr_vm = L.sr_slab = 0;
+    L.sr_R = 0;
     if (L.sr) {
         const int T = f.depth;
         const auto row_bytes = [](int64_t K) { return (int)(((K + 31) / 32) * 128 + 16); };
@@ -697,12 +699,19 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
         L.sr_gzo = o; o += fl((size_t)nV * L.tsr);
         L.sr_x = o; o += fl((size_t)nE * L.tsx);
         L.sr_vm = o; o += fl((size_t)nV * L.tsv);
-        L.r_h = plan_wgrad16r(nE * (T - 1), (int)h, (int)h);
-        L.r_i = plan_wgrad16r(nE, (int)h, (int)(f.d_v + f.d_e));
-        L.r_o = plan_wgrad16r(nV, (int)h, (int)(f.d_v + h));
-        L.r_bh = plan_wgrad16r(nE * (T - 1), (int)h, 1);
-        L.r_bi = plan_wgrad16r(nE, (int)h, 1);
-        L.r_bo = plan_wgrad16r(nV, (int)h, 1);
+        // the row counts per workgroup of the one product launch (8 workgroups left to a rider: dmpnn_train_step's first predictor layer);
+        // a bias gradient rides in its product's workgroups — same rows, same number of slabs
+        const int64_t Mj[3] = {nE * (T - 1), nV, nE};
+        const int Kj[3] = {(int)h, (int)(f.d_v + h), (int)(f.d_v + f.d_e)};
+        int Rj[3];
+        wgrad16r_plan_launch(Mj, Kj, 3, 8, Rj);
+        L.sr_R = Rj[0];
+        L.r_h = plan_wgrad16r(Mj[0], (int)h, Kj[0], Rj[0]);
+        L.r_o = plan_wgrad16r(Mj[1], (int)h, Kj[1], Rj[1]);
+        L.r_i = plan_wgrad16r(Mj[2], (int)h, Kj[2], Rj[2]);
+        L.r_bh = plan_wgrad16r(Mj[0], (int)h, 1, L.r_h.rows_per_split);
+        L.r_bo = plan_wgrad16r(Mj[1], (int)h, 1, L.r_o.rows_per_split);
+        L.r_bi = plan_wgrad16r(Mj[2], (int)h, 1, L.r_i.rows_per_split);
         L.sr_slab = o;
         for (const WProdRPlan* q : {&L.r_h, &L.r_i, &L.r_o, &L.r_bh, &L.r_bi, &L.r_bo}) o += align_up((size_t)q->splits * q->slab_stride, 64);
     }
@@ -710,14 +719,22 @@ BwdLayout bwd_layout(const dmpnn_fwd_args& f) {
     L.lz = L.lz_stride = L.lslab = 0;
     if (L.lean) {
         const int T = f.depth;
-        L.rh = plan_wgrad16r(nE, (int)h, (int)h);
-        L.ri = plan_wgrad16r(nE, (int)h, (int)(f.d_v + f.d_e));
-        L.rb = plan_wgrad16r(nE, (int)h, 1);
+        // (2 T - 1 product jobs of n_edges rows each in ONE launch, the bias gradients riding in them: the row counts per workgroup of all of them)
+        int64_t Mj[2 * kWProdMaxJobs];
+        int Kj[2 * kWProdMaxJobs], Rj[2 * kWProdMaxJobs];
+        int nj = 0;
+        for (int t = 1; t < T; ++t) { Mj[nj] = nE; Kj[nj++] = (int)h; }
+        for (int t = 0; t < T; ++t) { Mj[nj] = nE; Kj[nj++] = (int)(f.d_v + f.d_e); }
+        wgrad16r_plan_launch(Mj, Kj, nj, 0, Rj);
+        L.rh = plan_wgrad16r(nE, (int)h, (int)h, Rj[0]);
+        L.ri = plan_wgrad16r(nE, (int)h, (int)(f.d_v + f.d_e), Rj[nj - 1]);
+        L.rbh = plan_wgrad16r(nE, (int)h, 1, L.rh.rows_per_split);
+        L.rbi = plan_wgrad16r(nE, (int)h, 1, L.ri.rows_per_split);
         L.lz_stride = align_up(((size_t)nE * (size_t)(split_row_floats(h) * 4) + 3) / 4, 64);
         L.lz = o; o += (size_t)T * L.lz_stride;
         L.lslab = o;
         o += align_up((size_t)(T - 1) * L.rh.splits * L.rh.slab_stride, 64) + align_up((size_t)T * L.ri.splits * L.ri.slab_stride, 64) +
-             align_up((size_t)(T - 1) * L.rb.splits * L.rb.slab_stride, 64) + align_up((size_t)T * L.rb.splits * L.rb.slab_stride, 64);
+             align_up((size_t)(T - 1) * L.rbh.splits * L.rbh.slab_stride, 64) + align_up((size_t)T * L.rbi.splits * L.rbi.slab_stride, 64);
     }
     L.total = o;
     return L;
@@ -956,24 +973,25 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
         WProdRJob pj[4 * kWProdMaxJobs];
         int np = 0;
         float* slab = ws + L.lslab;
-        auto add_jobs = [&](int t0, int t1, const unsigned char* A, size_t a_stride, int tsa, int K, const WProdRPlan& q, float* gW, int64_t ldgw) {
-            if (!gW) return;
-            for (int t = t0; t < t1; ++t)
-                pj[np++] = WProdRJob{Zb + (size_t)t * zs, ts_m, A + (size_t)(t - t0) * a_stride, tsa, nE, (int)h, K, slab + (size_t)(t - t0) * q.splits * q.slab_stride, q};
-            add_reduce_r(slab, q, t1 - t0, K, 0, gW, ldgw, nullptr);
-            slab += align_up((size_t)(t1 - t0) * q.splits * q.slab_stride, 64);
+        // the products of steps t0 .. t1 - 1 (gW = sum_t gZ^(t)^T A^(t)); gb = sum_t colsum(gZ^(t)) rides in them (or is a job set of its own
+        // when the weight's gradient is not wanted)
+        auto add_jobs = [&](int t0, int t1, const unsigned char* A, size_t a_stride, int tsa, int K, const WProdRPlan& q, const WProdRPlan& qb,
+                            float* gW, int64_t ldgw, float* gb) {
+            if (!gW && !gb) return;
+            float* sl = slab;
+            if (gW) slab += align_up((size_t)(t1 - t0) * q.splits * q.slab_stride, 64);
+            float* slb = slab;
+            if (gb) slab += align_up((size_t)(t1 - t0) * qb.splits * qb.slab_stride, 64);
+            for (int t = t0; t < t1; ++t) {
+                float* sb_t = gb ? slb + (size_t)(t - t0) * qb.splits * qb.slab_stride : nullptr;
+                if (gW) pj[np++] = WProdRJob{Zb + (size_t)t * zs, ts_m, A + (size_t)(t - t0) * a_stride, tsa, nE, (int)h, K, sl + (size_t)(t - t0) * q.splits * q.slab_stride, q, sb_t};
+                else pj[np++] = WProdRJob{Zb + (size_t)t * zs, ts_m, nullptr, 0, nE, (int)h, 1, sb_t, qb, nullptr};
+            }
+            if (gW) add_reduce_r(sl, q, t1 - t0, K, 0, gW, ldgw, nullptr);
+            if (gb) add_reduce_r(slb, qb, t1 - t0, 0, 1, nullptr, 0, gb);
         };
-        auto add_colsums = [&](int t0, int t1, float* gb) {   // gb = sum_t colsum(gZ^(t))
-            if (!gb) return;
-            for (int t = t0; t < t1; ++t)
-                pj[np++] = WProdRJob{Zb + (size_t)t * zs, ts_m, nullptr, 0, nE, (int)h, 1, slab + (size_t)(t - t0) * L.rb.splits * L.rb.slab_stride, L.rb};
-            add_reduce_r(slab, L.rb, t1 - t0, 0, 1, nullptr, 0, gb);
-            slab += align_up((size_t)(t1 - t0) * L.rb.splits * L.rb.slab_stride, 64);
-        };
-        add_jobs(1, T, Mk, (size_t)nE * ts_m, ts_m, (int)h, L.rh, b->gW_h, h);
-        add_colsums(1, T, f.b_h ? b->gb_h : nullptr);
-        add_jobs(0, T, reinterpret_cast<const unsigned char*>(f.H0), 0, ts_x, (int)(dv + de), L.ri, b->gW_i, dv + de);
-        add_colsums(0, T, f.b_i ? b->gb_i : nullptr);
+        add_jobs(1, T, Mk, (size_t)nE * ts_m, ts_m, (int)h, L.rh, L.rbh, b->gW_h, h, f.b_h ? b->gb_h : nullptr);
+        add_jobs(0, T, reinterpret_cast<const unsigned char*>(f.H0), 0, ts_x, (int)(dv + de), L.ri, L.rbi, b->gW_i, dv + de, f.b_i ? b->gb_i : nullptr);
         DMPNN_TRY(launch_wgrad16r(pj, np, s));
         if (rj.n_jobs > 0) {
             hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)rj.wg0[rj.n_jobs]), dim3(256), 0, s, rj);
@@ -1030,8 +1048,10 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
                 rZ = reinterpret_cast<unsigned char*>(extra->ws);
                 rA = rZ + align_up((size_t)extra->M * ts_rz, 256);
                 rslab = reinterpret_cast<float*>(rA + align_up((size_t)extra->M * ts_ra, 256));
-                q_x = plan_wgrad16r(extra->M, extra->N, extra->K);
-                q_xb = plan_wgrad16r(extra->M, extra->N, 1);
+                // (the launch's row count per workgroup, but never more slabs than extra_wgrad_ws_floats sized the rider's workspace for)
+                const int r_x = plan_wgrad16r(extra->M, extra->N, extra->K).rows_per_split;
+                q_x = plan_wgrad16r(extra->M, extra->N, extra->K, L.sr_R > r_x ? L.sr_R : r_x);
+                q_xb = plan_wgrad16r(extra->M, extra->N, 1, q_x.rows_per_split);
                 sj[ns] = SRJob{extra->Z, extra->ldz, extra->N, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, extra->M, rZ, ts_rz}; ++ns;
                 sj[ns] = SRJob{extra->A, extra->lda, extra->K, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, extra->M, rA, ts_ra}; ++ns;
             }
@@ -1042,31 +1062,46 @@ int backward_impl(const dmpnn_bwd_args* b, void* stream, const ExtraWgrad* extra
             WProdRJob pj[8];
             int np = 0;
             float* slab = ws + L.sr_slab;
-            auto add = [&](const unsigned char* Z, int tsz, const unsigned char* A, int tsa, int64_t M, int N, int K, const WProdRPlan& q, float* sl,
-                           float* gW, int64_t ldgw, float* gb) {
-                pj[np++] = WProdRJob{Z, tsz, A, tsa, M, N, K, sl, q};
+            auto add_reduce = [&](float* sl, const WProdRPlan& q, int N, int K, int ones, float* gW, int64_t ldgw, float* gb) {
                 ReduceJob& r = rj.job[rj.n_jobs];
                 r.slab = sl; r.slab_stride = q.slab_stride; r.n_slabs = q.splits; r.ldk = q.ldk;
-                r.N = N; r.K = A ? K : 0; r.ones = A ? 0 : 1; r.gW = gW; r.ldgw = ldgw; r.gb = gb;
-                int64_t blocks = ((int64_t)N * (A ? K : 1) + 255) / 256;
+                r.N = N; r.K = K; r.ones = ones; r.gW = gW; r.ldgw = ldgw; r.gb = gb;
+                int64_t blocks = ((int64_t)N * (ones ? 1 : K) + 255) / 256;
                 if (blocks > 1024) blocks = 1024;
                 rj.wg0[rj.n_jobs + 1] = rj.wg0[rj.n_jobs] + (int)blocks;
                 ++rj.n_jobs;
+            };
+            // gW = Z^T A into q's slabs at sl (gW null: not wanted); gb = colsum(Z) into qb's slabs at slb — riding in the product's
+            // workgroups (qb has the product's rows), or a column-sum job of its own when there is no product
+            auto add = [&](const unsigned char* Z, int tsz, const unsigned char* A, int tsa, int64_t M, int N, int K, const WProdRPlan& q, float* sl,
+                           float* gW, int64_t ldgw, const WProdRPlan& qb, float* slb, float* gb) {
+                if (gW) {
+                    pj[np++] = WProdRJob{Z, tsz, A, tsa, M, N, K, sl, q, gb ? slb : nullptr};
+                    add_reduce(sl, q, N, K, 0, gW, ldgw, nullptr);
+                } else if (gb) {
+                    pj[np++] = WProdRJob{Z, tsz, nullptr, 0, M, N, 1, slb, qb, nullptr};
+                }
+                if (gb) add_reduce(slb, qb, N, 0, 1, nullptr, 0, gb);
             };
             auto next_slab = [&](const WProdRPlan& q) { float* p = slab; slab += align_up((size_t)q.splits * q.slab_stride, 64); return p; };
             const unsigned char* gZr = br.gZ;
             const unsigned char* Mr = static_cast<const unsigned char*>(f.msplit);
             // (the big product first: the small ones fill its tail)
-            if (want_h && b->gW_h) add(gZr, L.tsr, Mr, L.tsr, nE * (T - 1), (int)h, (int)h, L.r_h, next_slab(L.r_h), b->gW_h, h, nullptr);
-            if (want_h && f.b_h && b->gb_h) add(gZr, L.tsr, nullptr, 0, nE * (T - 1), (int)h, 1, L.r_bh, next_slab(L.r_bh), nullptr, 0, b->gb_h);
-            if (want_o && b->gW_o) add(br.gZO, L.tsr, VMr, L.tsv, nV, (int)h, (int)(dv + h), L.r_o, next_slab(L.r_o), b->gW_o, dv + h, nullptr);
-            if (want_o && b->gb_o) add(br.gZO, L.tsr, nullptr, 0, nV, (int)h, 1, L.r_bo, next_slab(L.r_bo), nullptr, 0, b->gb_o);
-            if (want_i && b->gW_i) add(br.gH0, L.tsr, Xr, L.tsx, nE, (int)h, (int)(dv + de), L.r_i, next_slab(L.r_i), b->gW_i, dv + de, nullptr);
-            if (want_i && f.b_i && b->gb_i) add(br.gH0, L.tsr, nullptr, 0, nE, (int)h, 1, L.r_bi, next_slab(L.r_bi), nullptr, 0, b->gb_i);
+            if (want_h) {
+                float* sl = next_slab(L.r_h); float* slb = next_slab(L.r_bh);
+                add(gZr, L.tsr, Mr, L.tsr, nE * (T - 1), (int)h, (int)h, L.r_h, sl, b->gW_h, h, L.r_bh, slb, f.b_h ? b->gb_h : nullptr);
+            }
+            if (want_o) {
+                float* sl = next_slab(L.r_o); float* slb = next_slab(L.r_bo);
+                add(br.gZO, L.tsr, VMr, L.tsv, nV, (int)h, (int)(dv + h), L.r_o, sl, b->gW_o, dv + h, L.r_bo, slb, b->gb_o);
+            }
+            if (want_i) {
+                float* sl = next_slab(L.r_i); float* slb = next_slab(L.r_bi);
+                add(br.gH0, L.tsr, Xr, L.tsx, nE, (int)h, (int)(dv + de), L.r_i, sl, b->gW_i, dv + de, L.r_bi, slb, f.b_i ? b->gb_i : nullptr);
+            }
             if (ride) {
                 float* sl2 = rslab + align_up((size_t)q_x.splits * q_x.slab_stride, 64);
-                if (extra->gW) add(rZ, ts_rz, rA, ts_ra, extra->M, extra->N, extra->K, q_x, rslab, extra->gW, extra->ldgw, nullptr);
-                if (extra->gb && extra->ones) add(rZ, ts_rz, nullptr, 0, extra->M, extra->N, 1, q_xb, sl2, nullptr, 0, extra->gb);
+                add(rZ, ts_rz, rA, ts_ra, extra->M, extra->N, extra->K, q_x, rslab, extra->gW, extra->ldgw, q_xb, sl2, extra->ones ? extra->gb : nullptr);
                 if (extra_done) *extra_done = true;
             }
             DMPNN_TRY(launch_wgrad16r(pj, np, s));

@@ -334,11 +334,19 @@ struct WProdJobs { WProdArgs job[4]; int wg0[5]; int n_jobs; };  // several prod
 // products over operands in SPLIT-ROW form (rows of [hi 32 | lo 32] chunks + a tail with the row's scale: k_wgrad16r, round 4) — the
 // operands are consumed as the step kernels keep them, nothing is re-blocked
 struct WProdRPlan { int n_kg, splits, rows_per_split, ldk; int64_t slab_stride; };
-WProdRPlan plan_wgrad16r(int64_t M, int N, int K);   // (K = 1: the plan of a column-sum job)
+// rows_per_split 0: the round-4 rule (~256 workgroups per JOB); else the launch's common row count per workgroup (wgrad16r_rows_per_split)
+WProdRPlan plan_wgrad16r(int64_t M, int N, int K, int rows_per_split = 0);   // (K = 1: the plan of a column-sum job)
+// Round 6: the row counts per workgroup of ALL jobs of one launch (reduction rows M[j], K[j] columns of A; K <= 1: a column-sum job):
+// rows_out[j] in inverse proportion to the job's cost per 32-row stage, sized so that the launch is one workgroup per CU (less `reserve`
+// for a rider's jobs), or whole rounds of >= 512-row workgroups for long reductions.  The slabs the products write and the reduce
+// launch reads back are splits x N x K floats per job: at ~256 workgroups per JOB (round 4) that was 84 MB per 512-molecule step
+// against 50 MB of operands.
+void wgrad16r_plan_launch(const int64_t* M, const int* K, int n, int reserve, int* rows_out);
 constexpr int kWProdRMaxJobs = 16;
 // one job: gW[N][K] = Z^T A over M rows into `plan.splits` slabs [N][plan.ldk] at `slab`;  A == nullptr: the column sums of Z (a bias
 // gradient) into column 0 of slabs [N][4]
-struct WProdRJob { const unsigned char* Z; int tsz; const unsigned char* A; int tsa; int64_t M; int N, K; float* slab; WProdRPlan plan; };
+// slab_b (or null; products only): the column sums of Z as well, into column 0 of `plan.splits` slabs [N][4] — they ride in the product's workgroups
+struct WProdRJob { const unsigned char* Z; int tsz; const unsigned char* A; int tsa; int64_t M; int N, K; float* slab; WProdRPlan plan; float* slab_b; };
 int launch_wgrad16r(const WProdRJob* jobs, int n, hipStream_t s);
 // fp32 rows [A1[g1] || A2[g2]] -> split rows [M][ts] (k_rows2sr): the product operands no kernel already holds split
 struct SRJob { const float* A1; int64_t lda1; int K1; const int* g1; const long long* g1_64; int64_t g1_rows;

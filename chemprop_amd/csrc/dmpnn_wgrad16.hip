@@ -18,6 +18,7 @@
 //                registers, no VALU), barrier, 24 MFMAs per wave into fresh accumulators, fp32 sums += product / (s_z s_a)
 //                (exact inverse: scales never mix).  Wave w owns output rows 16 w .. of the tile.  Slab per split, reduced
 //                by k_wgrad_reduce as before (deterministic: no atomics).
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -273,18 +274,20 @@ struct WProdR {
     const unsigned char* Z; const unsigned char* A;   // split rows [M][tsz], [M][tsa];  A null: the COLUMN SUMS of Z (a bias gradient) — one
                                                       // k tile whose first column is all ones, rho = F / s_Z
     float* slab;                                      // this job's slabs [splits][N][ldk]
+    float* slab_b;                                    // (or null) the column sums of Z ride in the job's k group 0: slabs [splits][N][4], column 0
     long long M; int N, K;                            // (column sums: K = 1)
     int tsz, ncz, tsa, nca;                           // row bytes and live chunks of Z (ceil(N / 32)) and A (ceil(K / 32))
     int n_kg, splits, rows_per_split, per8;           // per8: workgroups of the job / 8 (launch order)
     int ldk; long long slab_stride;
     int wg0;                                          // the job's first workgroup
 };
-struct WProdRJobs { WProdR job[kWProdRMaxJobs]; int n_jobs; };
+struct WProdRJobs { WProdR job[kWProdRMaxJobs]; int n_jobs; long long* dbg; };   // dbg: optional [64] cycle stamps of workgroup 0 (dmpnn_debug_timestamps)
 }  // namespace wg16
 
 namespace wg16 {
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 f16x4_t;
 using gemm::u32x4;
+using gemm::u32x2;
 constexpr int kRChunk = 4096;   // bytes of one chunk of a stage: 32 rows x 128
 
 __device__ __forceinline__ h8 tr_pair(const unsigned char* base, int off) {   // rows 8 g .. 8 g + 7 of one 16-column tile: two transpose reads
@@ -298,12 +301,33 @@ __device__ __forceinline__ h8 tr_pair(const unsigned char* base, int off) {   //
 // The round-4 form (256 threads, two workgroups per CU, one image filled by LDS-DMA) spent 4.7 k of a stage's 9.8 k cycles ISSUING
 // the 56 DMA pieces — a CU takes ~12 bytes per cycle through that path however the pieces are issued, and a wave that waits for it
 // issues no MFMA (profiles/r04_wgrad16r_stage_stamps.txt) — and hipcc orders a wave's LDS reads behind all of its outstanding DMA,
-// so a second image bought nothing.  A stage's 56 KB as 7 x 16 bytes per thread through the L1 path (64 B/clk) are requested at
-// the top of the stage, land in registers under the stage's MFMAs, and go to the OTHER image behind them: one barrier per stage,
-// no DMA.  Wave w owns the 16-row tiles w, w + 8, w + 16 of n (<= 3) and all eight 16-column tiles of k.
-constexpr int kRTW8 = 3;
+// so a second image bought nothing.  A stage's 56 KB as 7 x 16 bytes per thread through the L1 path are requested at the top of the
+// stage, land in registers under the stage's MFMAs, and go to the OTHER image behind them: one barrier per stage, no DMA.  (A second
+// register set — stage s + 2 in flight under stage s + 1 — does not fit beside the 96 accumulators: 44 of them spilled and the launch
+// took 170 us instead of 50, profiles/r06_wgrad16r_notes.txt; and the launch is bound by the bytes it moves — ~10 B/clk per CU when
+// every CU streams from HBM — not by one round trip per stage.)
+// Wave w owns the 16-row tiles w, w + 8, w + 16 of n (<= 3) and all (<= 8) 16-column tiles of the workgroup's k column group; the k
+// column groups of a job are whole 32-column chunks of A, as even as they come (300 columns: 3 + 3 + 4 chunks, not 4 + 4 + 2).
+// The COLUMN SUMS of Z (the bias gradient) ride in the k group 0 workgroups of a product (slab_b): the Z fragments are there — one more
+// scaling (rho_c = F_c / s_Z) and two MFMAs per tile against a fragment of ones, instead of a job that reads all of Z again.
+template <int I, int N, class Fn>
+__device__ __forceinline__ void wg_static_for(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wg_static_for<I + 1, N>(f);
+    }
+}
+constexpr int kRTW8 = 3;   // most 16-row tiles of n per wave
+constexpr int kRPiecesZ = 5, kRPiecesA = 2;   // pieces per thread and stage: chunks lc0, lc0 + 2, .. of Z (<= 10) and of the k column group's A (<= 4)
+struct RSet { u32x4 Z[kRPiecesZ]; u32x4 A[kRPiecesA]; u32x2 tz, ta; };
+// NTW: 16-row tiles of n per wave (1 .. 3; the launch's widest job: ceil(ceil(N / 16) / 8)) — a template parameter and the SAME for every
+// wave, so that no product sits under a branch: tested per product (wave + 8 r < n_nt), every MFMA was wrapped in s_and_saveexec /
+// s_cbranch_execz and issued every ~30 cycles; as per-wave variants of the stage inside one kernel hipcc shuffled the accumulators between
+// them and spilled.  A wave's tiles beyond the job's n are PHANTOMS: they multiply whatever the image holds there (always inside the image)
+// into accumulators nobody stores — 24 tiles' products for the 19 of d_h = 300.
+template <int NTW>
 __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // rho16[2][32] | red | image 0 | image 1  (image: ncz chunks of Z | 4 chunks of A)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // rho16[2][32] | rhoc16[2][32] | red | image 0 | image 1  (image: ncz chunks of Z | <= 4 chunks of A)
     int j = 0;
     while (j + 1 < jobs.n_jobs && (int)blockIdx.x >= jobs.job[j + 1].wg0) ++j;
     const WProdR& P = jobs.job[j];
@@ -313,101 +337,132 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
     if (rank >= P.n_kg * P.splits) return;
     const int split = rank / P.n_kg, kg = rank - split * P.n_kg;
     const bool colsum = P.A == nullptr;
+    const bool ride_b = !colsum && P.slab_b != nullptr && kg == 0;   // (uniform)
     const long long m_lo = (long long)split * P.rows_per_split;
     const long long m_hi = m_lo + P.rows_per_split < P.M ? m_lo + P.rows_per_split : P.M;
     const int n_rows = (int)(m_hi - m_lo);   // (> 0: the host sizes `splits` so that every split holds rows)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: what depends on it alone is a scalar branch)
     const int li = lane & 15, lg = lane >> 4;
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (jobs.dbg && blockIdx.x == 0 && threadIdx.x == 0 && n_stamp < 64) jobs.dbg[n_stamp] = (long long)__builtin_readcyclecounter();
+        ++n_stamp;
+    };
+    stamp();  // 0 entry
     _Float16* rho16 = reinterpret_cast<_Float16*>(lds);                       // [2][32]
-    unsigned* red = reinterpret_cast<unsigned*>(lds + 128);
-    const int img_bytes = (__builtin_amdgcn_readfirstlane(P.ncz) + 4) * kRChunk;
-    unsigned char* img0 = lds + 256;
-    const unsigned char* Zr = a.Z + m_lo * P.tsz;
-    const unsigned char* Ar = colsum ? Zr : a.A + m_lo * P.tsa;
-    const int ca_live = colsum ? 0 : ((P.nca - 4 * kg) < 4 ? (P.nca - 4 * kg) : 4);           // live chunks of A in this k column
-    const int n_c = P.ncz + ca_live;                                                         // chunks of a stage image
+    _Float16* rhoc16 = reinterpret_cast<_Float16*>(lds + 128);                // [2][32]
+    unsigned* red = reinterpret_cast<unsigned*>(lds + 256);
+    // (the job's fields once, as scalars: `jobs.job[j]` with a computed j is kernarg MEMORY to hipcc — it re-read tsz / tsa per piece)
+    const int tsz = __builtin_amdgcn_readfirstlane(P.tsz), tsa = __builtin_amdgcn_readfirstlane(P.tsa), ncz = __builtin_amdgcn_readfirstlane(P.ncz);
+    const int img_bytes = (ncz + 4) * kRChunk;
+    unsigned char* img0 = lds + 512;
+    // the workgroup's rows of both operands as buffers: a row past the range is out of range of its descriptor and reads as ZEROS —
+    // no address selects, no zeroing of dead pieces (the host holds rows_per_split x row bytes below 2^31)
+    const rsrc_t rZ = gemm::make_rsrc(a.Z + m_lo * tsz, (unsigned)(n_rows * tsz));
+    const rsrc_t rA = gemm::make_rsrc(colsum ? a.Z : a.A + m_lo * tsa, colsum ? 0u : (unsigned)(n_rows * tsa));
+    // this workgroup's chunks of A: [ca0, ca0 + ca_live), the job's nca chunks dealt to its n_kg column groups as evenly as they come (<= 4 each)
+    const int ca0 = colsum ? 0 : (kg * P.nca) / P.n_kg;
+    const int ca_live = colsum ? 0 : ((kg + 1) * P.nca) / P.n_kg - ca0;
     // ---- the loader's thread: row lr of the stage, LDS slot lq of its 128-byte line <- piece lq ^ swz(lr), chunks lc0, lc0 + 2, ..
     const int lr = (tid & 255) >> 3, lq = tid & 7, lc0 = tid >> 8;
     const int lpiece = lq ^ (2 * ((lr >> 1) & 1) + 4 * ((lr >> 3) & 1));
-    // (the job's fields once, as scalars: `jobs.job[j]` with a computed j is kernarg MEMORY to hipcc — it re-read tsz / tsa per piece)
-    const int tsz = __builtin_amdgcn_readfirstlane(P.tsz), tsa = __builtin_amdgcn_readfirstlane(P.tsa), ncz = __builtin_amdgcn_readfirstlane(P.ncz);
-    constexpr int kPieces = 7;   // ceil(14 chunks x 256 pieces / 512 threads)
-    // piece jj of this thread: chunk c = lc0 + 2 jj of the stage image, from Z (c < ncz) or from this k column's chunks of A
-    const unsigned char* pp[kPieces];   // address in stage 0
-    int pst[kPieces];                   // bytes per row of its operand (0: no such piece)
-#pragma unroll
-    for (int jj = 0; jj < kPieces; ++jj) {
-        const int c = lc0 + 2 * jj;
-        const bool isz = c < ncz;
-        pp[jj] = (isz ? Zr + (long long)lr * tsz + c * 128 : Ar + (long long)lr * tsa + (4 * kg + c - ncz) * 128) + lpiece * 16;
-        pst[jj] = c < n_c ? (isz ? tsz : tsa) : 0;
-    }
-    const unsigned char* tzp = Zr + (long long)(tid & 31) * tsz + (tsz - 16);   // the tails of the stage's rows: thread t < 32 owns row t
-    const unsigned char* tap = Ar + (long long)(tid & 31) * tsa + (tsa - 16);
-    u32x4 R[kPieces];
-    float sz_n = 0.f, sa_n = 0.f;
-    float2 tz_n = make_float2(0.f, 0.f), ta_n = make_float2(1.f, 0.f);
-    // requests of the stage at rows m0 ..: every load of the thread goes out before anything waits (the values are looked at in take_stage)
-    auto load_stage = [&](int m0) {
-        const bool row_ok = m0 + lr < n_rows;
-#pragma unroll
-        for (int jj = 0; jj < kPieces; ++jj) {
-            const bool ok = row_ok && pst[jj] != 0;
-            R[jj] = *reinterpret_cast<const u32x4*>(ok ? pp[jj] + (long long)m0 * pst[jj] : Zr);   // (a dead piece reads the range's first bytes: zeroed in take_stage)
+    // two 32-bit offsets per thread (its row and first piece in Z and in A; piece jj: + 256 jj, the instruction's immediate) and one for the
+    // rows' tails (thread t < 32 owns row t of the stage)
+    const unsigned offz = (unsigned)(lr * tsz + lpiece * 16 + lc0 * 128);
+    const unsigned offa = (unsigned)(lr * tsa + lpiece * 16 + (ca0 + lc0) * 128);
+    const unsigned offtz = tid < 32 ? (unsigned)(tid * tsz + (tsz - 16)) : gemm::kOOB;
+    const unsigned offta = (tid < 32 && !colsum) ? (unsigned)(tid * tsa + (tsa - 16)) : gemm::kOOB;
+    RSet S0;
+    // requests of the stage at rows m0 ..: the two tails first (loads return in order: the rows' rho is wanted first), then the pieces.
+    // Piece i of a stage (0 .. 6: Z chunks lc0, lc0 + 2, .., then A's): issued one by one BETWEEN the k tiles' products of the stage
+    // before — all nine at the top of a stage took 1.5 k cycles to go out (the CU's request queue), with every wave waiting in front of
+    // its first fragment read
+    auto load_tails = [&](int m0, RSet& S) {
+        S.tz = __builtin_amdgcn_raw_buffer_load_b64(rZ, offtz == gemm::kOOB ? gemm::kOOB : (unsigned)(m0 * tsz) + offtz, 0, 0);
+        S.ta = __builtin_amdgcn_raw_buffer_load_b64(rA, offta == gemm::kOOB ? gemm::kOOB : (unsigned)(m0 * tsa) + offta, 0, 0);
+    };
+    auto load_piece = [&](auto ic, int m0, RSet& S) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < kRPiecesZ)
+            S.Z[i] = __builtin_amdgcn_raw_buffer_load_b128(rZ, lc0 + 2 * i < ncz ? (unsigned)(m0 * tsz) + offz + 256u * i : gemm::kOOB, 0, 0);
+        else
+            S.A[i - kRPiecesZ] = __builtin_amdgcn_raw_buffer_load_b128(rA, lc0 + 2 * (i - kRPiecesZ) < ca_live ? (unsigned)(m0 * tsa) + offa + 256u * (i - kRPiecesZ) : gemm::kOOB, 0, 0);
+    };
+    auto load_stage = [&](int m0, RSet& S) {
+        load_tails(m0, S);
+        wg_static_for<0, kRPiecesZ + kRPiecesA>([&](auto ic) { load_piece(ic, m0, S); });
+    };
+    float F = 0.f, Fc = 0.f;
+    // the stage at rows m0 .. from its register set into image b: the rows' rho = F / (s_Z s_A) (rho_c = F_c / s_Z), then the pieces
+    auto put_stage = [&](int m0, RSet& S, int b) {
+        if (tid < 32) {
+            // tail = (scale, 1 if every element of the row's scaling unit is ZERO); a row past the range read zeros: rho = 0
+            const float szx = __uint_as_float(S.tz.x), szy = __uint_as_float(S.tz.y), sax = __uint_as_float(S.ta.x), say = __uint_as_float(S.ta.y);
+            const float sz = szy == 0.f ? szx : 0.f;
+            const float sa = colsum ? 1.f : (say == 0.f ? sax : 0.f);
+            const float fh = sz * sa;
+            rho16[b * 32 + tid] = (_Float16)(fh > 0.f ? F / fh : 0.f);
+            rhoc16[b * 32 + tid] = (_Float16)(sz > 0.f ? Fc / sz : 0.f);
         }
-        const bool ok = tid < 32 && m0 + tid < n_rows;
-        tz_n = *reinterpret_cast<const float2*>(ok ? tzp + (long long)m0 * tsz : Zr + (tsz - 16));
-        if (!colsum) ta_n = *reinterpret_cast<const float2*>(ok ? tap + (long long)m0 * tsa : Ar + (tsa - 16));
-    };
-    auto take_stage = [&](int m0) {
-        const bool row_ok = m0 + lr < n_rows;
+        // EVERY piece is stored — a dead one (a chunk the job does not have) into the trash chunk behind the images: a store under a
+        // condition leaves its load unwaited-for on the other path, and hipcc then guards the NEXT stage's request into the same registers
+        // with s_waitcnt vmcnt(2) — three requests in flight instead of nine (ISA, round 6)
+        unsigned char* dst = img0 + b * img_bytes + (tid & 255) * 16 + lc0 * kRChunk;
+        unsigned char* trash = img0 + 2 * img_bytes + (tid & 255) * 16;
 #pragma unroll
-        for (int jj = 0; jj < kPieces; ++jj)
-            if (!(row_ok && pst[jj] != 0)) R[jj] = u32x4{0u, 0u, 0u, 0u};
-        const bool ok = tid < 32 && m0 + tid < n_rows;
-        sz_n = (ok && tz_n.y == 0.f) ? tz_n.x : 0.f;    // (a zero row: rho = 0)
-        sa_n = ok ? (colsum ? 1.f : (ta_n.y == 0.f ? ta_n.x : 0.f)) : 0.f;
-    };
-    auto store_stage = [&](int b) {
-        unsigned char* dst = img0 + b * img_bytes + (tid & 255) * 16;
+        for (int jj = 0; jj < kRPiecesZ; ++jj)
+            *reinterpret_cast<u32x4*>(lc0 + 2 * jj < ncz ? dst + 2 * jj * kRChunk : trash) = S.Z[jj];
 #pragma unroll
-        for (int jj = 0; jj < kPieces; ++jj) {
-            const int c = lc0 + 2 * jj;
-            if (pst[jj] != 0) *reinterpret_cast<u32x4*>(dst + c * kRChunk) = R[jj];
-        }
+        for (int jj = 0; jj < kRPiecesA; ++jj)
+            *reinterpret_cast<u32x4*>(lc0 + 2 * jj < ca_live ? dst + (ncz + 2 * jj) * kRChunk : trash) = S.A[jj];
     };
-    load_stage(0);   // (in flight under the pass over the tails)
-    // ---- F: the smallest s_Z s_A over the rows of this workgroup's range (the rows' tails) ----
-    if (tid == 0) red[0] = 0x7f7fffffu;
-    __syncthreads();
+    // ---- F: the smallest s_Z s_A over the rows of this workgroup's range (the rows' tails); F_c: the smallest s_Z ----
+    // (requested BEFORE stage 0: behind its 56 KB they arrived 5 k cycles later — loads return in order)
     {
-        float f = 3.0e38f;
-        for (int r = tid; r < n_rows; r += 512) {
+        if (tid == 0) { red[0] = 0x7f7fffffu; red[1] = 0x7f7fffffu; }
+        float f = 3.0e38f, fc = 3.0e38f;
+        u32x2 tzv[2], tav[2];   // (<= 1 024 rows in one go; longer ranges loop)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = tid + 512 * i;
+            tzv[i] = __builtin_amdgcn_raw_buffer_load_b64(rZ, r < n_rows ? (unsigned)(r * tsz + (tsz - 16)) : gemm::kOOB, 0, 0);
+            tav[i] = __builtin_amdgcn_raw_buffer_load_b64(rA, (r < n_rows && !colsum) ? (unsigned)(r * tsa + (tsa - 16)) : gemm::kOOB, 0, 0);
+        }
+        stamp();  // 1 tails requested
+        load_stage(0, S0);    // (in flight under the pass over the tails)
+        stamp();  // 2 stage 0 requested
+        auto take = [&](u32x2 tz, u32x2 ta, bool live) {
             // tail = (scale, 1 if every element of the row's scaling unit is ZERO): such a row takes no part — its conventional scale 1
             // would otherwise drag F down by the scale of the rows that do hold values (2^30 for gradients of 1e-5) and flush them
-            const float2 tz = *reinterpret_cast<const float2*>(Zr + (long long)r * tsz + (tsz - 16));
-            const float2 ta = colsum ? make_float2(1.f, 0.f) : *reinterpret_cast<const float2*>(Ar + (long long)r * tsa + (tsa - 16));
-            if (tz.y == 0.f && ta.y == 0.f) f = fminf(f, tz.x * ta.x);
+            const float zx = __uint_as_float(tz.x), zy = __uint_as_float(tz.y), ax = colsum ? 1.f : __uint_as_float(ta.x), ay = colsum ? 0.f : __uint_as_float(ta.y);
+            if (live && zy == 0.f && ay == 0.f && zx * ax > 0.f) f = fminf(f, zx * ax);
+            if (live && zy == 0.f && zx > 0.f) fc = fminf(fc, zx);
+        };
+        take(tzv[0], tav[0], tid < n_rows);
+        take(tzv[1], tav[1], tid + 512 < n_rows);
+        for (int r = tid + 1024; r < n_rows; r += 512) {
+            const u32x2 tz = __builtin_amdgcn_raw_buffer_load_b64(rZ, (unsigned)(r * tsz + (tsz - 16)), 0, 0);
+            const u32x2 ta = __builtin_amdgcn_raw_buffer_load_b64(rA, colsum ? gemm::kOOB : (unsigned)(r * tsa + (tsa - 16)), 0, 0);
+            take(tz, ta, true);
         }
-        for (int off = 32; off > 0; off >>= 1) f = fminf(f, __shfl_xor(f, off));
-        if (lane == 0 && f > 0.f) atomicMin(&red[0], __float_as_uint(f));   // (positive floats order like their bit patterns)
+        for (int off = 32; off > 0; off >>= 1) { f = fminf(f, __shfl_xor(f, off)); fc = fminf(fc, __shfl_xor(fc, off)); }
+        __syncthreads();   // (red is armed)
+        if (lane == 0 && f < 3.0e38f) atomicMin(&red[0], __float_as_uint(f));   // (positive floats order like their bit patterns)
+        if (lane == 0 && fc < 3.0e38f) atomicMin(&red[1], __float_as_uint(fc));
     }
     __syncthreads();
-    const float F = __uint_as_float(red[0]);
-    take_stage(0);
-    auto put_rho = [&](int buf) {
-        if (tid < 32) {
-            const float fh = sz_n * sa_n;
-            rho16[buf * 32 + tid] = (_Float16)(fh > 0.f ? F / fh : 0.f);
-        }
-    };
-    put_rho(0);
-    store_stage(0);
-    f32x4 acc[kRTW8][8];
+    F = __uint_as_float(red[0]);
+    Fc = __uint_as_float(red[1]);
+    stamp();  // 3 F known
+    put_stage(0, S0, 0);
+    stamp();  // 4 stage 0 in its image
+    f32x4 acc[NTW][8], accb[NTW];
 #pragma unroll
-    for (int r = 0; r < kRTW8; ++r)
+    for (int r = 0; r < NTW; ++r) {
+        accb[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) acc[r][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // transpose-read addresses inside a chunk image: rows 8 lg + (li >> 2) (+ 4 for the second read: + 512 bytes), piece
     // (part 4 + h2 2 + ((li >> 1) & 1)) ^ swz, 8-byte half li & 1;  swz = 4 (lg & 1) + 2 ((li >> 3) & 1) for all of them
     const int rowb = (8 * lg + (li >> 2)) * 128 + (li & 1) * 8;
@@ -417,78 +472,120 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) px[part][h2] = rowb + ((((part ^ (lg & 1)) << 2) + ((h2 ^ ((li >> 3) & 1)) << 1) + ((li >> 1) & 1)) << 4);
     const int n_nt = (P.N + 15) >> 4;                       // 16-row tiles of n
-    const int kt_live = ((P.K - 128 * kg + 15) >> 4) < 8 ? ((P.K - 128 * kg + 15) >> 4) : 8;   // live 16-column tiles of this k column
-    // column sums: the one B fragment — column 0 (lanes li = 0) all ones, exact in f16; no lo part
+    const int k_lo = 32 * ca0;                              // first k column of this workgroup
+    const int kt_live = colsum ? 0 : (((P.K - k_lo + 15) >> 4) < 2 * ca_live ? ((P.K - k_lo + 15) >> 4) : 2 * ca_live);   // live 16-column tiles of this k column group
+    // column sums: the one fragment — row 0 (lanes li = 0) all ones, exact in f16; no lo part
     const _Float16 one = (_Float16)(li == 0 ? 1.f : 0.f);
     const h8 ones8 = h8{one, one, one, one, one, one, one, one};
-    __syncthreads();   // image 0 and its rho are in place
-    int stage = 0;
-    for (int m0 = 0; m0 < n_rows; m0 += 32, ++stage) {
-        const bool more = m0 + 32 < n_rows;   // (uniform)
-        if (more) load_stage(m0 + 32);
-        const unsigned char* Zt = img0 + (stage & 1) * img_bytes;
+    // The products are formed TRANSPOSED — the k tile of A is the matrix pipe's first operand, the n tile of Z its second — so that a
+    // lane's four accumulator registers are four CONSECUTIVE k columns of one row n of the slab: one 16-byte store per tile in the
+    // epilogue (as rows of n per lane they were 96 scattered 4-byte stores per wave, 16 k of the workgroup's 86 k cycles).
+    auto compute = [&](int b, int m0_next) {
+        load_tails(m0_next, S0);
+        const unsigned char* Zt = img0 + b * img_bytes;
         const unsigned char* At = Zt + ncz * kRChunk;
-        const h8 rho = *reinterpret_cast<const h8*>(rho16 + (stage & 1) * 32 + 8 * lg);
-        h8 zh[kRTW8], zl[kRTW8];
+        const h8 rho = *reinterpret_cast<const h8*>(rho16 + b * 32 + 8 * lg);
+        h8 zh[NTW], zl[NTW];
+        h8 bh, bl;
+        if (kt_live > 0) {   // (uniform; a column-sum job has no products)
+            bh = tr_pair(At, px[0][0]); bl = tr_pair(At, px[1][0]);   // (the first k tile's fragments with the Z fragments)
 #pragma unroll
-        for (int r = 0; r < kRTW8; ++r) {
-            const int nt = wave + 8 * r;
-            if (nt < n_nt) {   // (wave-uniform)
+            for (int r = 0; r < NTW; ++r) {
+                const int nt = wave + 8 * r;
                 const unsigned char* zc = Zt + (nt >> 1) * kRChunk;
                 zh[r] = tr_pair(zc, px[0][nt & 1]) * rho;
                 zl[r] = tr_pair(zc, px[1][nt & 1]) * rho;
             }
         }
-        if (colsum) {   // (uniform)
+        wg_static_for<0, 8>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            if (kt >= kt_live) return;   // (uniform)
+            // the next k tile's fragments are requested in front of this tile's products (hipcc left to itself hoists all eight tiles'
+            // reads — 64 registers — or none)
+            h8 nbh = bh, nbl = bl;
+            if (kt + 1 < kt_live) {
+                const unsigned char* ac = At + ((kt + 1) >> 1) * kRChunk;
+                nbh = tr_pair(ac, px[0][(kt + 1) & 1]); nbl = tr_pair(ac, px[1][(kt + 1) & 1]);
+            }
+            if constexpr (kt < kRPiecesZ + kRPiecesA) load_piece(ktc, m0_next, S0);
+            __builtin_amdgcn_sched_barrier(0);
+            // (the three products of a tile are a dependent chain on its accumulator: the tiles' chains interleaved)
 #pragma unroll
-            for (int r = 0; r < kRTW8; ++r) {
-                if (wave + 8 * r >= n_nt) continue;
-                f32x4& d = acc[r][0];
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], ones8, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[r], ones8, d, 0, 0, 0);
+            for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, zh[r], acc[r][kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, zh[r], acc[r][kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, zl[r], acc[r][kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bh = nbh; bl = nbl;
+        });
+        // (the pieces no k tile carried: fewer than seven live tiles, or a column-sum job)
+        wg_static_for<0, kRPiecesZ + kRPiecesA>([&](auto ic) { if (decltype(ic)::value >= kt_live) load_piece(ic, m0_next, S0); });
+        if (colsum || ride_b) {   // (uniform) the column sums: the Z fragments once more (the products' are dead by now), scaled by rho_c
+            const h8 rhoc = colsum ? rho : *reinterpret_cast<const h8*>(rhoc16 + b * 32 + 8 * lg);
+#pragma unroll
+            for (int r = 0; r < NTW; ++r) {
+                const int nt = wave + 8 * r;
+                const unsigned char* zc = Zt + (nt >> 1) * kRChunk;
+                const h8 rh = tr_pair(zc, px[0][nt & 1]) * rhoc, rl = tr_pair(zc, px[1][nt & 1]) * rhoc;
+                // (a column-sum job's kt_live is 0: its accb is the one accumulator set it uses — no select between two register arrays, which
+                //  would put both in scratch memory)
+                accb[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, rh, accb[r], 0, 0, 0);
+                accb[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, rl, accb[r], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            if (colsum || kt >= kt_live) break;   // (uniform)
-            const unsigned char* ac = At + (kt >> 1) * kRChunk;
-            const h8 bh = tr_pair(ac, px[0][kt & 1]), bl = tr_pair(ac, px[1][kt & 1]);
-#pragma unroll
-            for (int r = 0; r < kRTW8; ++r) {
-                if (wave + 8 * r >= n_nt) continue;
-                f32x4& d = acc[r][kt];
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], bh, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[r], bl, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[r], bh, d, 0, 0, 0);
-            }
-        }
-        if (more) {   // the next stage's pieces have landed under the MFMAs: into the OTHER image (last read before the previous barrier)
-            take_stage(m0 + 32);
-            put_rho((stage + 1) & 1);
-            store_stage((stage + 1) & 1);
-        }
+    };
+    __syncthreads();   // image 0 and its rho are in place
+    // stage s computes from image s & 1 while stage s + 1 lands in the register set, which then goes to the other image (last read
+    // before the previous barrier)
+    const int n_st = (n_rows + 31) >> 5;
+    for (int st = 0; st < n_st; ++st) {
+        stamp();  // 3 + 4 st
+        compute(st & 1, 32 * (st + 1));
+        stamp();  //   MFMAs and the next stage's requests issued
+        put_stage(32 * (st + 1), S0, (st + 1) & 1);
+        stamp();  //   next stage landed and stored
         __syncthreads();
+        stamp();  //   barrier
     }
-    // D fragment: lane (li, lg) holds rows 16 nt + 4 lg + e of n, column 16 kt + li of this workgroup's k column
+    // D fragment (transposed product): lane (li, lg) holds row n = 16 nt + li, columns k_lo + 16 kt + 4 lg .. + 3 of this workgroup's k column group
     const float iF = (F > 0.f && F < 3.0e38f) ? 1.f / F : 0.f;
     float* slab = P.slab + (long long)split * P.slab_stride;
+    if (colsum) {   // (uniform) column 0 of slabs [N][4]: row 0 of the transposed tile — lanes lg = 0, register 0
 #pragma unroll
-    for (int r = 0; r < kRTW8; ++r) {
-        const int nt = wave + 8 * r;
-        if (nt >= n_nt) continue;
+        for (int r = 0; r < NTW; ++r) {
+            const int n = 16 * (wave + 8 * r) + li;
+            if (wave + 8 * r < n_nt && lg == 0 && n < P.N) slab[(long long)n * P.ldk] = accb[r][0] * iF;
+        }
+    } else {
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
+        for (int r = 0; r < NTW; ++r) {
+            const int nt = wave + 8 * r, n = 16 * nt + li;
+            if (nt >= n_nt || n >= P.N) continue;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = 16 * nt + 4 * lg + e, k = 128 * kg + 16 * kt + li;
-                if (n < P.N && k < P.K) slab[(long long)n * P.ldk + k] = acc[r][kt][e] * iF;
+            for (int kt = 0; kt < 8; ++kt) {
+                const int k = k_lo + 16 * kt + 4 * lg;   // (a quad that starts below K ends below ldk = K rounded up to 4: the padding is never read)
+                if (kt < kt_live && k < P.K)
+                    *reinterpret_cast<float4*>(slab + (long long)n * P.ldk + k) = make_float4(acc[r][kt][0] * iF, acc[r][kt][1] * iF, acc[r][kt][2] * iF, acc[r][kt][3] * iF);
             }
+        }
+    }
+    stamp();  // slabs stored (issued)
+    if (ride_b && lg == 0) {   // the column sums: column 0 of slabs [N][4]
+        const float iFc = (Fc > 0.f && Fc < 3.0e38f) ? 1.f / Fc : 0.f;
+        float* sb = P.slab_b + (long long)split * P.N * 4;
+#pragma unroll
+        for (int r = 0; r < NTW; ++r) {
+            const int n = 16 * (wave + 8 * r) + li;
+            if (wave + 8 * r < n_nt && n < P.N) sb[n * 4] = accb[r][0] * iFc;
+        }
     }
 }
 
 }  // namespace wg16
 
 // ---- host side ------------------------------------------------------------------------------------------------------
+extern thread_local long long* g_debug_stamps;
 size_t wsplit16_bytes(int64_t M, int64_t C) {  // one operand: blocks + scales
     const int64_t n_ct = (C + 63) / 64, n_chunks = (M + 31) / 32;
     return (size_t)(n_ct * n_chunks) * wg16::kBlk + (((size_t)(n_ct * n_chunks) * 4 + 255) & ~size_t(255));
@@ -577,14 +674,74 @@ int launch_rows2sr(const SRJob* J, int n, hipStream_t s) {
 }
 
 // products over split-row operands (k_wgrad16r).  plan: the row splits of one job — every split is a slab the reduce kernel reads
-WProdRPlan plan_wgrad16r(int64_t M, int N, int K) {
+static int wgradr_target_wgs() {
+    static const int wgs = [] {
+        const char* e = getenv("DMPNN_WGRADR_WGS");   // (A/B runs: workgroups of a product launch)
+        int v = e ? atoi(e) : 0;
+        if (v > 0) return v;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) return cus;
+        return 256;
+    }();
+    return wgs;
+}
+
+// relative cost of one 32-row stage of a workgroup of a job with K columns of A (0: a column-sum job): its largest k column group's
+// 16-column tiles (<= 8; 24 MFMAs per tile and wave), not below the stage's loads (a column-sum job: ~3 tiles' worth)
+static int wgradr_stage_cost(int K) {
+    if (K <= 1) return 3;
+    const int nca = (K + 31) / 32, n_kg = (K + 127) / 128;
+    const int kt = 2 * ((nca + n_kg - 1) / n_kg);
+    return kt < 3 ? 3 : (kt > 8 ? 8 : kt);
+}
+
+void wgrad16r_plan_launch(const int64_t* M, const int* K, int n, int reserve, int* rows_out) {
+    const int cus = wgradr_target_wgs();
+    double units = 0;   // rows of a cost-8 job the launch amounts to
+    int64_t m_max = 0;
+    for (int j = 0; j < n; ++j) {
+        rows_out[j] = 32;
+        if (M[j] <= 0) continue;
+        units += (double)M[j] * ((K[j] + 127) / 128 > 0 ? (K[j] + 127) / 128 : 1) * wgradr_stage_cost(K[j]) / 8.0;
+        m_max = M[j] > m_max ? M[j] : m_max;
+    }
+    if (units <= 0) return;
+    // one workgroup per CU while that keeps a workgroup under ~1 024 rows; beyond, whole rounds of workgroups of >= 512 rows (the CUs
+    // balance the jobs' different stage costs among themselves; the slabs stay a small fraction of the operand bytes)
+    int64_t rounds = (int64_t)(units / (512.0 * cus));
+    if (rounds < 1) rounds = 1;
+    int64_t budget = rounds * cus - reserve;
+    if (budget < 8) budget = 8;
+    int64_t R0 = (int64_t)(units / (double)budget);
+    R0 = (R0 + 31) / 32 * 32;
+    if (R0 < 32) R0 = 32;
+    const int64_t R_max = ((m_max + 31) / 32 * 32) * 8;
+    for (;; R0 += 32) {
+        int64_t wg = 0;
+        for (int j = 0; j < n; ++j) {
+            if (M[j] <= 0) continue;
+            int64_t Rj = (R0 * 8 / wgradr_stage_cost(K[j]) + 31) / 32 * 32;
+            if (Rj > ((int64_t)1 << 20)) Rj = (int64_t)1 << 20;
+            rows_out[j] = (int)Rj;
+            const int n_kg = (K[j] + 127) / 128 > 0 ? (K[j] + 127) / 128 : 1;
+            wg += (n_kg * ((M[j] + Rj - 1) / Rj) + 7) / 8 * 8;   // (every job's workgroups are padded to a multiple of 8: the XCD-aware order)
+        }
+        if (wg <= budget || R0 >= R_max) break;
+    }
+}
+
+WProdRPlan plan_wgrad16r(int64_t M, int N, int K, int rows_per_split) {
     WProdRPlan p;
     p.n_kg = (K + 127) / 128;
-    static const int wgs = [] { const char* e = getenv("DMPNN_WGRADR_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
-    int splits = wgs / p.n_kg;                      // ~256 workgroups per product, two or more per CU over the jobs of a launch
-    if (splits < 1) splits = 1;
-    int64_t rps = (M + splits - 1) / splits;
-    rps = (rps + 31) / 32 * 32;
+    int64_t rps;
+    if (rows_per_split > 0) {
+        rps = (rows_per_split + 31) / 32 * 32;
+    } else {
+        int splits = 256 / p.n_kg;                  // ~256 workgroups per product, two or more per CU over the jobs of a launch
+        if (splits < 1) splits = 1;
+        rps = (M + splits - 1) / splits;
+        rps = (rps + 31) / 32 * 32;
+    }
     if (rps < 32) rps = 32;
     p.rows_per_split = (int)rps;
     p.splits = (int)((M + rps - 1) / rps);
@@ -600,7 +757,7 @@ int launch_wgrad16r(const WProdRJob* J, int n, hipStream_t s) {
         const int nn = n - i0 < kWProdRMaxJobs ? n - i0 : kWProdRMaxJobs;
         wg16::WProdRJobs P;
         memset(&P, 0, sizeof(P));
-        int wg = 0, ncz_max = 0, nj = 0;
+        int wg = 0, ncz_max = 0, nj = 0, nt_max = 1;
         for (int i = 0; i < nn; ++i) {
             const WProdRJob& q = J[i0 + i];
             if (q.M <= 0) continue;   // (its reduce job sums zero slabs: the caller zero-fills)
@@ -613,23 +770,32 @@ int launch_wgrad16r(const WProdRJob* J, int n, hipStream_t s) {
                 return DMPNN_EINVAL;
             }
             wg16::WProdR& a = P.job[nj++];
-            a.Z = q.Z; a.A = q.A; a.slab = q.slab; a.M = q.M; a.N = q.N; a.K = K;
+            a.Z = q.Z; a.A = q.A; a.slab = q.slab; a.slab_b = q.A ? q.slab_b : nullptr; a.M = q.M; a.N = q.N; a.K = K;
             a.tsz = q.tsz; a.ncz = ncz; a.tsa = q.A ? q.tsa : q.tsz; a.nca = nca;
             a.n_kg = p.n_kg; a.splits = p.splits; a.rows_per_split = p.rows_per_split; a.per8 = (p.n_kg * p.splits + 7) / 8;
             a.ldk = p.ldk; a.slab_stride = p.slab_stride;
             a.wg0 = wg; wg += a.per8 * 8;
             if (ncz > ncz_max) ncz_max = ncz;
+            if ((q.N + 15) / 16 > nt_max) nt_max = (q.N + 15) / 16;
         }
         if (nj == 0) continue;
         P.n_jobs = nj;
-        const size_t lds = 256 + 2 * (size_t)(ncz_max + 4) * wg16::kRChunk;   // rho / red | two stage images
-        static size_t attr_set = 0;
-        if (attr_set < lds) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wg16::k_wgrad16r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16r, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
-            attr_set = lds;
-        }
-        hipLaunchKernelGGL(wg16::k_wgrad16r, dim3((unsigned)wg), dim3(512), lds, s, P);
+        const size_t lds = 512 + 2 * (size_t)(ncz_max + 4) * wg16::kRChunk + wg16::kRChunk;   // rho, rho_c, red | two stage images | the trash chunk
+        P.dbg = g_debug_stamps;
+        const int ntw = (nt_max + 7) / 8;   // 16-row tiles of n per wave: the launch's widest job (1 .. 3, checked above)
+        auto go = [&](auto kern, size_t& attr_set) -> int {
+            if (attr_set < lds) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_wgrad16r, %zu B LDS): %s", lds, hipGetErrorString(e)); return DMPNN_EHIP; }
+                attr_set = lds;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)wg), dim3(512), lds, s, P);
+            return DMPNN_OK;
+        };
+        static size_t attr1 = 0, attr2 = 0, attr3 = 0;
+        if (ntw <= 1) DMPNN_TRY(go(&wg16::k_wgrad16r<1>, attr1));
+        else if (ntw == 2) DMPNN_TRY(go(&wg16::k_wgrad16r<2>, attr2));
+        else DMPNN_TRY(go(&wg16::k_wgrad16r<3>, attr3));
         DMPNN_CHECK_LAUNCH("k_wgrad16r");
     }
     return DMPNN_OK;
