@@ -278,6 +278,7 @@ struct WProdR {
     long long M; int N, K;                            // (column sums: K = 1)
     int tsz, ncz, tsa, nca;                           // row bytes and live chunks of Z (ceil(N / 32)) and A (ceil(K / 32))
     int n_kg, splits, rows_per_split, per8;           // per8: workgroups of the job / 8 (launch order)
+    int even_kt;                                      // 1: the k column groups are the job's 16-column tiles dealt evenly (each within four chunks of A)
     int ldk; long long slab_stride;
     int wg0;                                          // the job's first workgroup
 };
@@ -360,9 +361,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
     // no address selects, no zeroing of dead pieces (the host holds rows_per_split x row bytes below 2^31)
     const rsrc_t rZ = gemm::make_rsrc(a.Z + m_lo * tsz, (unsigned)(n_rows * tsz));
     const rsrc_t rA = gemm::make_rsrc(colsum ? a.Z : a.A + m_lo * tsa, colsum ? 0u : (unsigned)(n_rows * tsa));
-    // this workgroup's chunks of A: [ca0, ca0 + ca_live), the job's nca chunks dealt to its n_kg column groups as evenly as they come (<= 4 each)
-    const int ca0 = colsum ? 0 : (kg * P.nca) / P.n_kg;
-    const int ca_live = colsum ? 0 : ((kg + 1) * P.nca) / P.n_kg - ca0;
+    // this workgroup's 16-column tiles of k: [kt0, kt0 + kt_live), the job's ceil(K / 16) tiles dealt to its n_kg column groups as evenly as
+    // they come (300 columns: 7 + 6 + 6, not 8 + 8 + 3); its image holds the 32-column chunks [ca0, ca0 + ca_live) of A those tiles
+    // lie in (<= 4: a group of 7 or 8 tiles), koff = 1 when the group starts in the second half of chunk ca0
+    // (even_kt 0 — a group would then span five chunks, e.g. 23 tiles as 7 + 8 + 8 —: whole chunks per group, the tiles of the last one short)
+    const int nkt = (P.K + 15) >> 4;
+    const int kt0 = colsum ? 0 : (P.even_kt ? (kg * nkt) / P.n_kg : 2 * ((kg * P.nca) / P.n_kg));
+    const int kt1 = P.even_kt ? ((kg + 1) * nkt) / P.n_kg : (2 * (((kg + 1) * P.nca) / P.n_kg) < nkt ? 2 * (((kg + 1) * P.nca) / P.n_kg) : nkt);
+    const int kt_live = colsum ? 0 : kt1 - kt0;
+    const int ca0 = kt0 >> 1, koff = kt0 & 1;
+    const int ca_live = colsum ? 0 : ((kt0 + kt_live + 1) >> 1) - ca0;
     // ---- the loader's thread: row lr of the stage, LDS slot lq of its 128-byte line <- piece lq ^ swz(lr), chunks lc0, lc0 + 2, ..
     const int lr = (tid & 255) >> 3, lq = tid & 7, lc0 = tid >> 8;
     const int lpiece = lq ^ (2 * ((lr >> 1) & 1) + 4 * ((lr >> 3) & 1));
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
     const unsigned offa = (unsigned)(lr * tsa + lpiece * 16 + (ca0 + lc0) * 128);
     const unsigned offtz = tid < 32 ? (unsigned)(tid * tsz + (tsz - 16)) : gemm::kOOB;
     const unsigned offta = (tid < 32 && !colsum) ? (unsigned)(tid * tsa + (tsa - 16)) : gemm::kOOB;
-    RSet S0;
+    RSet S0, S1;
     // requests of the stage at rows m0 ..: the two tails first (loads return in order: the rows' rho is wanted first), then the pieces.
     // Piece i of a stage (0 .. 6: Z chunks lc0, lc0 + 2, .., then A's): issued one by one BETWEEN the k tiles' products of the stage
     // before — all nine at the top of a stage took 1.5 k cycles to go out (the CU's request queue), with every wave waiting in front of
@@ -393,8 +401,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
         wg_static_for<0, kRPiecesZ + kRPiecesA>([&](auto ic) { load_piece(ic, m0, S); });
     };
     float F = 0.f, Fc = 0.f;
-    // the stage at rows m0 .. from its register set into image b: the rows' rho = F / (s_Z s_A) (rho_c = F_c / s_Z), then the pieces
-    auto put_stage = [&](int m0, RSet& S, int b) {
+    // the stage in register set S into image b: the rows' rho = F / (s_Z s_A) (rho_c = F_c / s_Z) from its tails, and its pieces one by one
+    auto put_rho = [&](RSet& S, int b) {
         if (tid < 32) {
             // tail = (scale, 1 if every element of the row's scaling unit is ZERO); a row past the range read zeros: rho = 0
             const float szx = __uint_as_float(S.tz.x), szy = __uint_as_float(S.tz.y), sax = __uint_as_float(S.ta.x), say = __uint_as_float(S.ta.y);
@@ -404,17 +412,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
             rho16[b * 32 + tid] = (_Float16)(fh > 0.f ? F / fh : 0.f);
             rhoc16[b * 32 + tid] = (_Float16)(sz > 0.f ? Fc / sz : 0.f);
         }
-        // EVERY piece is stored — a dead one (a chunk the job does not have) into the trash chunk behind the images: a store under a
-        // condition leaves its load unwaited-for on the other path, and hipcc then guards the NEXT stage's request into the same registers
-        // with s_waitcnt vmcnt(2) — three requests in flight instead of nine (ISA, round 6)
+    };
+    // EVERY piece is stored — a dead one (a chunk the job does not have) into the trash chunk behind the images: a store under a
+    // condition leaves its load unwaited-for on the other path, and hipcc then guards the NEXT request into the same registers
+    // with s_waitcnt vmcnt(2) — three requests in flight instead of nine (ISA, round 6)
+    unsigned char* const trash = img0 + 2 * img_bytes + (tid & 255) * 16;
+    auto put_piece = [&](auto ic, RSet& S, int b) {
+        constexpr int i = decltype(ic)::value;
         unsigned char* dst = img0 + b * img_bytes + (tid & 255) * 16 + lc0 * kRChunk;
-        unsigned char* trash = img0 + 2 * img_bytes + (tid & 255) * 16;
-#pragma unroll
-        for (int jj = 0; jj < kRPiecesZ; ++jj)
-            *reinterpret_cast<u32x4*>(lc0 + 2 * jj < ncz ? dst + 2 * jj * kRChunk : trash) = S.Z[jj];
-#pragma unroll
-        for (int jj = 0; jj < kRPiecesA; ++jj)
-            *reinterpret_cast<u32x4*>(lc0 + 2 * jj < ca_live ? dst + (ncz + 2 * jj) * kRChunk : trash) = S.A[jj];
+        if constexpr (i < kRPiecesZ)
+            *reinterpret_cast<u32x4*>(lc0 + 2 * i < ncz ? dst + 2 * i * kRChunk : trash) = S.Z[i];
+        else
+            *reinterpret_cast<u32x4*>(lc0 + 2 * (i - kRPiecesZ) < ca_live ? dst + (ncz + 2 * (i - kRPiecesZ)) * kRChunk : trash) = S.A[i - kRPiecesZ];
+    };
+    auto put_stage = [&](RSet& S, int b) {
+        put_rho(S, b);
+        wg_static_for<0, kRPiecesZ + kRPiecesA>([&](auto ic) { put_piece(ic, S, b); });
     };
     // ---- F: the smallest s_Z s_A over the rows of this workgroup's range (the rows' tails); F_c: the smallest s_Z ----
     // (requested BEFORE stage 0: behind its 56 KB they arrived 5 k cycles later — loads return in order)
@@ -430,7 +443,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
         }
         stamp();  // 1 tails requested
         load_stage(0, S0);    // (in flight under the pass over the tails)
-        stamp();  // 2 stage 0 requested
+        load_stage(32, S1);
+        stamp();  // 2 stages 0 and 1 requested
         auto take = [&](u32x2 tz, u32x2 ta, bool live) {
             // tail = (scale, 1 if every element of the row's scaling unit is ZERO): such a row takes no part — its conventional scale 1
             // would otherwise drag F down by the scale of the rows that do hold values (2^30 for gradients of 1e-5) and flush them
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
     F = __uint_as_float(red[0]);
     Fc = __uint_as_float(red[1]);
     stamp();  // 3 F known
-    put_stage(0, S0, 0);
+    put_stage(S0, 0);
     stamp();  // 4 stage 0 in its image
     f32x4 acc[NTW][8], accb[NTW];
 #pragma unroll
@@ -472,23 +486,26 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) px[part][h2] = rowb + ((((part ^ (lg & 1)) << 2) + ((h2 ^ ((li >> 3) & 1)) << 1) + ((li >> 1) & 1)) << 4);
     const int n_nt = (P.N + 15) >> 4;                       // 16-row tiles of n
-    const int k_lo = 32 * ca0;                              // first k column of this workgroup
-    const int kt_live = colsum ? 0 : (((P.K - k_lo + 15) >> 4) < 2 * ca_live ? ((P.K - k_lo + 15) >> 4) : 2 * ca_live);   // live 16-column tiles of this k column group
+    const int k_lo = 16 * kt0;                              // first k column of this workgroup
     // column sums: the one fragment — row 0 (lanes li = 0) all ones, exact in f16; no lo part
     const _Float16 one = (_Float16)(li == 0 ? 1.f : 0.f);
     const h8 ones8 = h8{one, one, one, one, one, one, one, one};
     // The products are formed TRANSPOSED — the k tile of A is the matrix pipe's first operand, the n tile of Z its second — so that a
     // lane's four accumulator registers are four CONSECUTIVE k columns of one row n of the slab: one 16-byte store per tile in the
     // epilogue (as rows of n per lane they were 96 scattered 4-byte stores per wave, 16 k of the workgroup's 86 k cycles).
-    auto compute = [&](int b, int m0_next) {
-        load_tails(m0_next, S0);
+    // One stage: the products over image b, and BETWEEN the k tiles' products, piece by piece: the stage in register set X (requested a
+    // stage ago) goes to the other image (last read before the previous barrier), the stage after it is requested into set Y (whose
+    // pieces went to this image a stage ago) — two stages in flight, no store phase of its own (it was 1.2 k of a stage's 4.4 k cycles).
+    auto compute = [&](int b, RSet& X, RSet& Y, int m0_next) {
+        put_rho(X, b ^ 1);
+        load_tails(m0_next, Y);
         const unsigned char* Zt = img0 + b * img_bytes;
         const unsigned char* At = Zt + ncz * kRChunk;
         const h8 rho = *reinterpret_cast<const h8*>(rho16 + b * 32 + 8 * lg);
         h8 zh[NTW], zl[NTW];
         h8 bh, bl;
         if (kt_live > 0) {   // (uniform; a column-sum job has no products)
-            bh = tr_pair(At, px[0][0]); bl = tr_pair(At, px[1][0]);   // (the first k tile's fragments with the Z fragments)
+            bh = tr_pair(At, px[0][koff]); bl = tr_pair(At, px[1][koff]);   // (the first k tile's fragments with the Z fragments)
 #pragma unroll
             for (int r = 0; r < NTW; ++r) {
                 const int nt = wave + 8 * r;
@@ -499,28 +516,29 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
         }
         wg_static_for<0, 8>([&](auto ktc) {
             constexpr int kt = decltype(ktc)::value;
-            if (kt >= kt_live) return;   // (uniform)
             // the next k tile's fragments are requested in front of this tile's products (hipcc left to itself hoists all eight tiles'
             // reads — 64 registers — or none)
             h8 nbh = bh, nbl = bl;
-            if (kt + 1 < kt_live) {
-                const unsigned char* ac = At + ((kt + 1) >> 1) * kRChunk;
-                nbh = tr_pair(ac, px[0][(kt + 1) & 1]); nbl = tr_pair(ac, px[1][(kt + 1) & 1]);
+            if (kt + 1 < kt_live) {   // (uniform)
+                const unsigned char* ac = At + ((kt + 1 + koff) >> 1) * kRChunk;
+                nbh = tr_pair(ac, px[0][(kt + 1 + koff) & 1]); nbl = tr_pair(ac, px[1][(kt + 1 + koff) & 1]);
             }
-            if constexpr (kt < kRPiecesZ + kRPiecesA) load_piece(ktc, m0_next, S0);
+            // (piece kt moves whether or not k tile kt is live — NO memory instruction under a condition: hipcc then counts the loads in
+            //  flight exactly, s_waitcnt vmcnt(8) in front of every store, instead of the smallest count over the paths)
+            if constexpr (kt < kRPiecesZ + kRPiecesA) { put_piece(ktc, X, b ^ 1); load_piece(ktc, m0_next, Y); }
             __builtin_amdgcn_sched_barrier(0);
-            // (the three products of a tile are a dependent chain on its accumulator: the tiles' chains interleaved)
+            if (kt < kt_live) {   // (uniform)
+                // (the three products of a tile are a dependent chain on its accumulator: the tiles' chains interleaved)
 #pragma unroll
-            for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, zh[r], acc[r][kt], 0, 0, 0);
+                for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, zh[r], acc[r][kt], 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, zh[r], acc[r][kt], 0, 0, 0);
+                for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, zh[r], acc[r][kt], 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, zl[r], acc[r][kt], 0, 0, 0);
+                for (int r = 0; r < NTW; ++r) acc[r][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, zl[r], acc[r][kt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             bh = nbh; bl = nbl;
         });
-        // (the pieces no k tile carried: fewer than seven live tiles, or a column-sum job)
-        wg_static_for<0, kRPiecesZ + kRPiecesA>([&](auto ic) { if (decltype(ic)::value >= kt_live) load_piece(ic, m0_next, S0); });
         if (colsum || ride_b) {   // (uniform) the column sums: the Z fragments once more (the products' are dead by now), scaled by rho_c
             const h8 rhoc = colsum ? rho : *reinterpret_cast<const h8*>(rhoc16 + b * 32 + 8 * lg);
 #pragma unroll
@@ -536,17 +554,24 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16r(WProdRJobs jobs) {
         }
     };
     __syncthreads();   // image 0 and its rho are in place
-    // stage s computes from image s & 1 while stage s + 1 lands in the register set, which then goes to the other image (last read
-    // before the previous barrier)
+    // stage s computes from image s & 1; S1 holds stage s + 1 at even s, S0 at odd s
     const int n_st = (n_rows + 31) >> 5;
-    for (int st = 0; st < n_st; ++st) {
-        stamp();  // 3 + 4 st
-        compute(st & 1, 32 * (st + 1));
-        stamp();  //   MFMAs and the next stage's requests issued
-        put_stage(32 * (st + 1), S0, (st + 1) & 1);
-        stamp();  //   next stage landed and stored
+    int st = 0;
+    for (; st + 1 < n_st; st += 2) {
+        stamp();  // 5 + 3 st
+        compute(0, S1, S0, 32 * (st + 2));
+        stamp();  //   products, stores and requests issued
         __syncthreads();
         stamp();  //   barrier
+        compute(1, S0, S1, 32 * (st + 3));
+        stamp();
+        __syncthreads();
+        stamp();
+    }
+    if (st < n_st) {   // (an odd count's last stage: what it stores and requests is past the range — zeros, no memory traffic)
+        stamp();
+        compute(0, S1, S0, 32 * (st + 2));
+        stamp();
     }
     // D fragment (transposed product): lane (li, lg) holds row n = 16 nt + li, columns k_lo + 16 kt + 4 lg .. + 3 of this workgroup's k column group
     const float iF = (F > 0.f && F < 3.0e38f) ? 1.f / F : 0.f;
@@ -686,12 +711,22 @@ static int wgradr_target_wgs() {
     return wgs;
 }
 
+// the k column groups of a job as its 16-column tiles dealt evenly — allowed when every group lies within four 32-column chunks of A
+static bool wgradr_even_kt(int K) {
+    const int nkt = (K + 15) / 16, n_kg = (K + 127) / 128;
+    if (n_kg < 1) return false;
+    for (int g = 0; g < n_kg; ++g) {
+        const int t0 = g * nkt / n_kg, t1 = (g + 1) * nkt / n_kg;
+        if (((t1 + 1) >> 1) - (t0 >> 1) > 4) return false;
+    }
+    return true;
+}
 // relative cost of one 32-row stage of a workgroup of a job with K columns of A (0: a column-sum job): its largest k column group's
 // 16-column tiles (<= 8; 24 MFMAs per tile and wave), not below the stage's loads (a column-sum job: ~3 tiles' worth)
 static int wgradr_stage_cost(int K) {
     if (K <= 1) return 3;
-    const int nca = (K + 31) / 32, n_kg = (K + 127) / 128;
-    const int kt = 2 * ((nca + n_kg - 1) / n_kg);
+    const int nkt = (K + 15) / 16, nca = (K + 31) / 32, n_kg = (K + 127) / 128;
+    const int kt = wgradr_even_kt(K) ? (nkt + n_kg - 1) / n_kg : 2 * ((nca + n_kg - 1) / n_kg);
     return kt < 3 ? 3 : (kt > 8 ? 8 : kt);
 }
 
@@ -773,6 +808,7 @@ int launch_wgrad16r(const WProdRJob* J, int n, hipStream_t s) {
             a.Z = q.Z; a.A = q.A; a.slab = q.slab; a.slab_b = q.A ? q.slab_b : nullptr; a.M = q.M; a.N = q.N; a.K = K;
             a.tsz = q.tsz; a.ncz = ncz; a.tsa = q.A ? q.tsa : q.tsz; a.nca = nca;
             a.n_kg = p.n_kg; a.splits = p.splits; a.rows_per_split = p.rows_per_split; a.per8 = (p.n_kg * p.splits + 7) / 8;
+            a.even_kt = wgradr_even_kt(K) ? 1 : 0;
             a.ldk = p.ldk; a.slab_stride = p.slab_stride;
             a.wg0 = wg; wg += a.per8 * 8;
             if (ncz > ncz_max) ncz_max = ncz;

@@ -308,7 +308,7 @@ def lean_sign_bits(st: "ForwardState") -> Tensor:
     return ((b.unsqueeze(-1) >> sh) & 1).bool().reshape(depth, st.plan.n_edges, bn)[:, :, :d_h]
 
 
-KEEP_ROWS_MIN = 32768   # (= DMPNN_KEEP_ROWS_MIN of include/dmpnn.h: the rule itself is the library's, dmpnn_train_route)
+KEEP_ROWS_MIN = 4096   # (= DMPNN_KEEP_ROWS_MIN of include/dmpnn.h: the rule itself is the library's, dmpnn_train_route)
 
 
 def train_route(n_atoms: int, n_edges: int, d_v: int, d_e: int, d_h: int, depth: int, act: str, n_mols: int = 0, *, undirected: bool = False,
@@ -691,10 +691,10 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
         elif use_mega and want16 and keep and n_steps and train_route(nV, nE, d_v, d_e, d_h, depth, act, 1, max_level=2).keep_rows:
             # round 4: the tile kernel keeps M^(t) as SPLIT ROWS (depth - 1 slots of n_edges rows of dmpnn_split_row_floats(d_h) floats) —
             # what the weight-gradient products read as they are (csrc/dmpnn_wgrad16.hip: k_wgrad16r); the fp32 Ms slots above then only
-            # serve a molecule beyond the tile.  From KEEP_ROWS_MIN message rows on: measured per training step 300 -> 271 us at 1 024
-            # QM9-shaped molecules (36 k rows), 1 053 -> 884 at 4 096, even at 768 (27 k), but 181 -> 188..193 us at 512 (18 k rows: ~200
-            # workgroups, one per CU, each bound by what ONE CU pulls through LDS-DMA — 12 bytes per cycle — where the block products' 500
-            # smaller workgroups spread the same bytes better): profiles/r04_split_rows_crossover.txt
+            # serve a molecule beyond the tile.  From KEEP_ROWS_MIN message rows on — 4 096 since round 6 (k_wgrad16r rebuilt for one
+            # workgroup per CU: 49 -> 31.7 us per launch at 512 QM9-shaped molecules); whole-model step, split rows | blocks, same box
+            # (profiles/r06_rows_crossover.txt): 128 molecules 145 | 149 us, 256 156 | 162, 512 177 | 195, 768 253 | 300, 1 024 281 | 364;
+            # 64 molecules (2 184 message rows) 140 | 137: the rule's lower end
             split_ms = torch.empty((n_steps, nE, int(lib.dmpnn_split_row_floats(d_h))), dtype=torch.float32, device=dev)
     st.out = out
     if edge_ws is None:

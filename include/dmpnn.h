@@ -431,7 +431,7 @@ int dmpnn_tile_waves(int64_t n_atoms, int64_t n_edges, int64_t d_h, int64_t n_ti
  * activation other than PReLU, dropout only with a ReLU-class activation, no molecule known to exceed the tile, at most 30 directed
  * edges per molecule on average, and a planner that can build it (the single-workgroup plan, a loader's table, or the batch vector
  * for the multi-workgroup planner); everything else trains on the full plan (plan_kind 0).  Returns 0, or DMPNN_EINVAL. */
-#define DMPNN_KEEP_ROWS_MIN 32768
+#define DMPNN_KEEP_ROWS_MIN 4096
 typedef struct dmpnn_train_route_info {
     int32_t plan_kind;      /* 0 | 2                                                                                          */
     int32_t route;          /* enum dmpnn_route of the training forward on that plan (dmpnn_forward_route with keep)           */

@@ -34,9 +34,9 @@ for rep in range(3):
     torch.cuda.synchronize()
     st = buf.cpu().tolist()
     names = ["entry", "tails requested", "stage 0 requested", "F known", "stage 0 in its image"]
-    n_st = (len([x for x in st[:64] if x]) - 6) // 4
+    n_st = (len([x for x in st[:64] if x]) - 6) // 3
     for i in range(n_st):
-        names += [f"s{i} top", f"s{i} MFMAs + requests", f"s{i} next stored", f"s{i} barrier"]
+        names += [f"s{i} top", f"s{i} products + stores + requests", f"s{i} barrier"]
     names += ["slabs stored"]
     print(f"--- rep {rep}: molecules {n_mols}, edges {bmg.E.shape[0]}")
     prev = st[0]

@@ -1408,12 +1408,13 @@ def test_tile_kernels_with_every_weight_gradient_on_split_rows(case, kw, gpu_dev
 
 
 def test_split_rows_are_kept_from_a_size_on(gpu_device):
-    """The default rule (engine.KEEP_ROWS_MIN message rows): 4 096 QM9-shaped molecules keep split rows, 512 the fp32 rows of the block path."""
+    """The default rule (engine.KEEP_ROWS_MIN message rows; round 6: 4 096, was 32 768): 512 QM9-shaped molecules keep split rows, 64 the
+    fp32 rows of the block path."""
     from chemprop_amd import engine, synth
     from chemprop_amd.nn import BondMessagePassing
 
     mp = BondMessagePassing().to(gpu_device).train()
-    for n, want in ((512, False), (4096, True)):
+    for n, want in ((64, False), (512, True)):
         bmg = synth.random_batch(n, "qm9", seed=3)
         bmg.to(gpu_device)
         out = mp(bmg)
