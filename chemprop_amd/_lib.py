@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("DMPNN_LIB") or os.path.join(_HERE, "libdmpnn_gfx950.s
 SOURCES = ["dmpnn_abi.hip", "dmpnn_prepare.hip", "dmpnn_segment.hip", "dmpnn_gemm.hip", "dmpnn_gemm_p1.hip",
            "dmpnn_gemm_p2.hip", "dmpnn_gemm_p3.hip", "dmpnn_gemm_p4.hip", "dmpnn_gemm_s1.hip", "dmpnn_mega.hip", "dmpnn_mega16.hip", "dmpnn_mega16_bwd.hip", "dmpnn_rows16.hip", "dmpnn_step16.hip", "dmpnn_bstep16.hip", "dmpnn_backward.hip", "dmpnn_molagg.hip", "dmpnn_collate.hip", "dmpnn_tiles_large.hip", "dmpnn_optim.hip", "dmpnn_wgrad16.hip", "dmpnn_head.hip"]
 HEADERS = ["dmpnn_common.hpp", "dmpnn_spill_impl.hpp", "dmpnn_gemm_impl.hpp", "dmpnn_mega_impl.hpp", "dmpnn_mega16_impl.hpp", "dmpnn_mega16_bwd_impl.hpp", "dmpnn_rows16_impl.hpp", "dmpnn_seg16.hpp", "dmpnn_step16_impl.hpp"]
-ABI_VERSION = 13
+ABI_VERSION = 14
 PLAN_NOFFSETS = 15
 
 # every symbol include/dmpnn.h declares; tests check the .so exports all of them
@@ -109,7 +109,7 @@ class BwdArgs(C.Structure):
 
 
 MAX_FFN_LAYERS = 8
-LOSS = {"mse": 0, "mae": 1, "bce": 2, "ce": 3}
+LOSS = {"mse": 0, "mae": 1, "bce": 2, "ce": 3, "mve": 4, "evidential": 5}
 STEP_FORWARD, STEP_BACKWARD, STEP_UPDATE = 1, 2, 4
 
 
@@ -130,6 +130,7 @@ class HeadArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("bn_num_batches_tracked", C.c_void_p),
         ("n_classes", C.c_int32),
+        ("evid_v_kl", C.c_float), ("evid_eps", C.c_float),
     ]
 
 

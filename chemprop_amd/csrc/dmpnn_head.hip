@@ -195,7 +195,43 @@ struct LossArgs {
     float* gP; int64_t ldg; float* out;   // out[0] = loss, out[1] = number of finite targets
     int64_t B; int t; int kind;
     int nc;                               // DMPNN_LOSS_CE: classes per task — P / gP rows hold t * nc logits, T the class index of every task
+                                          // DMPNN_LOSS_MVE / _EVIDENTIAL: 2 / 4 — P / gP rows hold nc chunks of t columns (torch.chunk(Y, n_targets, 1))
+    float v_kl, eps;                      // DMPNN_LOSS_EVIDENTIAL
 };
+// F.softplus (beta 1, threshold 20) and its derivative
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float softplus_d(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+// digamma for x >= 1 (alpha = softplus + 1): the recurrence up to x >= 6, then the asymptotic series (error < 1e-7 there)
+__device__ __forceinline__ float digamma_f(float x) {
+    float r = 0.f;
+    while (x < 6.f) { r -= 1.f / x; x += 1.f; }
+    const float i = 1.f / x, i2 = i * i;
+    return r + logf(x) - 0.5f * i - i2 * (1.f / 12.f - i2 * (1.f / 120.f - i2 * (1.f / 252.f)));
+}
+// MVELoss (nn/metrics.py:203-219) on the raw outputs of MveFFN (predictors.py:173-190): unreduced loss, d / d mean, d / d raw variance
+__device__ __forceinline__ float mve_loss(float mean, float raw, float y, float* g_mean, float* g_raw) {
+    const float var = softplus_f(raw), d = mean - y;
+    if (g_mean) {
+        *g_mean = d / var;
+        *g_raw = (0.5f / var - d * d / (2.f * var * var)) * softplus_d(raw);
+    }
+    return d * d / (2.f * var) + 0.5f * logf(6.283185307179586f * var);
+}
+// EvidentialLoss (nn/metrics.py:222-262) on the raw outputs of EvidentialFFN (predictors.py:193-212); g[4]: d / d (mean, raw v, raw alpha, raw beta)
+__device__ __forceinline__ float evidential_loss(const float (&x)[4], float y, float v_kl, float eps, float* g) {
+    const float v = softplus_f(x[1]), al = softplus_f(x[2]) + 1.f, be = softplus_f(x[3]);
+    const float res = y - x[0], tbl = 2.f * be * (1.f + v), D = v * res * res + tbl, ares = fabsf(res);
+    const float nll = 0.5f * logf(3.141592653589793f / v) - al * logf(tbl) + (al + 0.5f) * logf(D) + lgammaf(al) - lgammaf(al + 0.5f);
+    const float reg = (2.f * v + al) * ares;
+    if (g) {
+        const float sg = res > 0.f ? 1.f : (res < 0.f ? -1.f : 0.f);
+        g[0] = -((al + 0.5f) * 2.f * v * res / D + v_kl * (2.f * v + al) * sg);
+        g[1] = (-0.5f / v - al / (1.f + v) + (al + 0.5f) * (res * res + 2.f * be) / D + v_kl * 2.f * ares) * softplus_d(x[1]);
+        g[2] = (logf(D) - logf(tbl) + digamma_f(al) - digamma_f(al + 0.5f) + v_kl * ares) * softplus_d(x[2]);
+        g[3] = (-al / be + (al + 0.5f) * 2.f * (1.f + v) / D) * softplus_d(x[3]);
+    }
+    return nll + v_kl * (reg - eps);
+}
 __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
     __shared__ float red[2][16];
     __shared__ float tot[2];
@@ -215,6 +251,15 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
             const int cls = (int)y;
             const float L = (mx + logf(se)) - x[(cls >= 0 && cls < a.nc) ? cls : 0];
             sl += ((cls >= 0 && cls < a.nc) ? L : __int_as_float(0x7fc00000)) * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f);
+            sm += 1.f;
+            continue;
+        }
+        if (a.kind == DMPNN_LOSS_MVE || a.kind == DMPNN_LOSS_EVIDENTIAL) {   // (uniform) chunked outputs: column k t + j is target k of task j
+            const float* x = a.P + r * a.ldp + j;
+            float L;
+            if (a.kind == DMPNN_LOSS_MVE) L = mve_loss(x[0], x[a.t], y, nullptr, nullptr);
+            else { const float xs[4] = {x[0], x[a.t], x[2 * a.t], x[3 * a.t]}; L = evidential_loss(xs, y, a.v_kl, a.eps, nullptr); }
+            sl += L * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f);
             sm += 1.f;
             continue;
         }
@@ -254,6 +299,18 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
             const float f = (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f) * inv, ise = 1.f / se;
             const int cls = (int)y;
             for (int k = 0; k < a.nc; ++k) gx[k] = (expf(x[k] - mx) * ise - (k == cls ? 1.f : 0.f)) * f;
+            continue;
+        }
+        if (a.kind == DMPNN_LOSS_MVE || a.kind == DMPNN_LOSS_EVIDENTIAL) {   // (uniform)
+            const float* x = a.P + r * a.ldp + j;
+            float* gx = a.gP + r * a.ldg + j;
+            float g4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (isfinite(y)) {
+                if (a.kind == DMPNN_LOSS_MVE) mve_loss(x[0], x[a.t], y, &g4[0], &g4[1]);
+                else { const float xs[4] = {x[0], x[a.t], x[2 * a.t], x[3 * a.t]}; evidential_loss(xs, y, a.v_kl, a.eps, g4); }
+            }
+            const float f = (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f) * inv;
+            for (int k = 0; k < a.nc; ++k) gx[(int64_t)k * a.t] = g4[k] * f;
             continue;
         }
         float g = 0.f;
@@ -1133,7 +1190,7 @@ struct HeadLayout {
 };
 // the shapes the four-launch form takes (training or not is the caller's business): one hidden layer, a handful of outputs
 bool rows_shape(const dmpnn_head_args& h) {
-    return h.n_layers == 2 && h.dims[2] <= kOutMaxTasks && h.dims[2] >= 1 && h.loss != DMPNN_LOSS_CE && h.n_mols <= kRowsMaxB &&
+    return h.n_layers == 2 && h.dims[2] <= kOutMaxTasks && h.dims[2] >= 1 && h.loss <= DMPNN_LOSS_BCE && h.n_mols <= kRowsMaxB &&
            h.dims[0] <= kRowsMaxWidth && h.dims[1] <= kRowsMaxWidth && h.dims[0] % 4 == 0;
 }
 HeadLayout head_layout(const dmpnn_head_args& h) {
@@ -1247,8 +1304,10 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     DMPNN_CHECK_ARG(Ln >= 1 && Ln <= DMPNN_MAX_FFN_LAYERS && h.dims[0] == d, "head: 1..%d predictor layers, dims[0] == d_h", DMPNN_MAX_FFN_LAYERS);
     for (int l = 0; l < Ln; ++l) DMPNN_CHECK_ARG(h.W[l] && h.dims[l + 1] > 0, "head: layer %d has no weight / width", l);
     DMPNN_CHECK_ARG(h.act >= DMPNN_ACT_NONE && h.act <= DMPNN_ACT_ELU && h.act != DMPNN_ACT_PRELU, "head: activation %d is not built in", h.act);
-    DMPNN_CHECK_ARG(h.loss == DMPNN_LOSS_MSE || h.loss == DMPNN_LOSS_MAE || h.loss == DMPNN_LOSS_BCE || h.loss == DMPNN_LOSS_CE, "head: unknown criterion %d", h.loss);
-    DMPNN_CHECK_ARG((h.loss != DMPNN_LOSS_BCE && h.loss != DMPNN_LOSS_CE) || (!h.lt_mask && !h.gt_mask), "head: the BCE / CE criteria have no bounds (lt_mask / gt_mask)");
+    DMPNN_CHECK_ARG(h.loss >= DMPNN_LOSS_MSE && h.loss <= DMPNN_LOSS_EVIDENTIAL, "head: unknown criterion %d", h.loss);
+    DMPNN_CHECK_ARG(h.loss <= DMPNN_LOSS_MAE || (!h.lt_mask && !h.gt_mask), "head: only the MSE / MAE criteria have bounds (lt_mask / gt_mask)");
+    DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_MVE || h.dims[Ln] % 2 == 0, "head: mean-variance estimation needs an output layer 2 n_tasks wide");
+    DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_EVIDENTIAL || h.dims[Ln] % 4 == 0, "head: the evidential criterion needs an output layer 4 n_tasks wide");
     DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_CE || (h.n_classes >= 2 && h.dims[Ln] % h.n_classes == 0), "head: cross entropy needs n_classes >= 2 dividing the output width");
     DMPNN_CHECK_ARG(h.preds && (nV == 0 || (Hv && h.batch)), "head: null H_v / batch / preds");
     DMPNN_CHECK_ARG(!h.bn_weight || (h.bn_running_mean && h.bn_running_var), "head: batch norm without running statistics");
@@ -1267,7 +1326,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     unsigned char* ws = static_cast<unsigned char*>(h.ws);
     float* Hm = reinterpret_cast<float*>(ws + L.Hm);
     const int t_out = (int)h.dims[Ln];                                  // width of the output layer
-    const int nc = h.loss == DMPNN_LOSS_CE ? h.n_classes : 1;           // logits per task
+    const int nc = h.loss == DMPNN_LOSS_CE ? h.n_classes : (h.loss == DMPNN_LOSS_MVE ? 2 : (h.loss == DMPNN_LOSS_EVIDENTIAL ? 4 : 1));   // outputs per task
     const int t = t_out / nc;                                           // tasks (= columns of `targets`)
 
     // ---- forward ----
@@ -1394,7 +1453,8 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     if (!h.targets) return DMPNN_OK;
     float* gP = reinterpret_cast<float*>(ws + L.gP);
     if (!out_all) {
-        LossArgs q{h.preds, t_out, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, want_grad ? gP : nullptr, t_out, h.loss_out, B, t, h.loss, nc};
+        LossArgs q{h.preds, t_out, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, want_grad ? gP : nullptr, t_out, h.loss_out, B, t, h.loss, nc,
+                   h.evid_v_kl, h.evid_eps};
         DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
         hipLaunchKernelGGL(k_loss, dim3(1), dim3(1024), 0, s, q);
         DMPNN_CHECK_LAUNCH("k_loss");
@@ -1414,7 +1474,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
             OutBwdArgs q{g_cur, A[l], K, h.W[l], out, K, h.gW[l], h.b[l] ? h.gb[l] : nullptr, B, (int)K, (int)N, l > 0 ? h.act : DMPNN_ACT_NONE, h.act_slope};
             if (out_all) {
                 DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
-                OutAllArgs qa{q, LossArgs{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, nullptr, t, h.loss_out, B, t, h.loss, 1}};
+                OutAllArgs qa{q, LossArgs{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, nullptr, t, h.loss_out, B, t, h.loss, 1, 0.f, 0.f}};
                 qa.o.gP = nullptr;
                 hipLaunchKernelGGL(k_out_all, dim3((unsigned)((K + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, qa);
                 DMPNN_CHECK_LAUNCH("k_out_all");

@@ -28,17 +28,32 @@ from .ffn import MLP
 from .nn import BondMessagePassing, classify_activation
 from .optim import FlatAdam
 
-__all__ = ["MSE", "MAE", "BCE", "CE", "RegressionFFN", "BinaryClassificationFFN", "MulticlassClassificationFFN", "MPNN", "FusedTrainer", "masked_loss"]
+__all__ = ["MSE", "MAE", "BCE", "CE", "MVE", "Evidential", "RegressionFFN", "BinaryClassificationFFN", "MulticlassClassificationFFN", "MveFFN", "EvidentialFFN",
+           "MPNN", "FusedTrainer", "masked_loss"]
 
 
 def masked_loss(preds: Tensor, targets: Tensor, weights: Optional[Tensor] = None, task_weights: Optional[Tensor] = None,
-                lt_mask: Optional[Tensor] = None, gt_mask: Optional[Tensor] = None, kind: str = "mse") -> Tensor:
+                lt_mask: Optional[Tensor] = None, gt_mask: Optional[Tensor] = None, kind: str = "mse", v_kl: float = 0.2, eps: float = 1e-8) -> Tensor:
     """``ChempropMetric.update`` + ``compute`` on one batch (``nn/metrics.py:78-127``) with the masking of
     ``MPNN.training_step`` (``models/model.py:152-156``): torch ops, differentiable — the module path's criterion."""
     mask = targets.isfinite()
     targets = targets.nan_to_num(nan=0.0)
-    if kind in ("bce", "ce"):
-        lt_mask = gt_mask = None     # (BCELoss / CrossEntropyLoss are not bounded criteria: metrics.py:292-304)
+    if kind in ("bce", "ce", "mve", "evidential"):
+        lt_mask = gt_mask = None     # (only the Bounded* criteria apply the masks: metrics.py:157-177)
+    if kind in ("mve", "evidential"):   # preds [b, t, 2 | 4]: what MveFFN / EvidentialFFN.train_step stack (predictors.py:173-212)
+        if kind == "mve":               # MVELoss, metrics.py:203-219
+            mean, var = torch.unbind(preds, dim=-1)
+            L = (mean - targets) ** 2 / (2 * var) + (2 * torch.pi * var).log() / 2
+        else:                           # EvidentialLoss, metrics.py:222-262
+            mean, v, alpha, beta = torch.unbind(preds, dim=-1)
+            residuals = targets - mean
+            two_b_lambda = 2 * beta * (1 + v)
+            L_nll = (0.5 * (torch.pi / v).log() - alpha * two_b_lambda.log() + (alpha + 0.5) * torch.log(v * residuals**2 + two_b_lambda)
+                     + torch.lgamma(alpha) - torch.lgamma(alpha + 0.5))
+            L = L_nll + v_kl * ((2 * v + alpha) * residuals.abs() - eps)
+        w = torch.ones(targets.shape[0], dtype=torch.float, device=targets.device) if weights is None else weights
+        tw = 1.0 if task_weights is None else task_weights.view(1, -1)
+        return (L * w.view(-1, 1) * tw * mask).sum() / mask.sum()
     if kind == "ce":                 # preds [b, t, c] logits, targets [b, t] class indices (metrics.py:298-304)
         L = torch.nn.functional.cross_entropy(preds.transpose(1, 2), targets.long(), reduction="none")
         w = torch.ones(targets.shape[0], dtype=torch.float, device=targets.device) if weights is None else weights
@@ -127,6 +142,66 @@ class CE(MSE):
         return super().forward(preds, targets, mask, weights, None, None)
 
 
+class MVE(MSE):
+    """``chemprop.nn.metrics.MVELoss`` (``metrics.py:203-219``): ``preds [b, t, 2]`` = (mean, variance); no bounds."""
+
+    kind = "mve"
+
+    def forward(self, preds, targets, mask=None, weights=None, lt_mask=None, gt_mask=None):
+        return super().forward(preds, targets, mask, weights, None, None)
+
+
+class Evidential(MSE):
+    """``chemprop.nn.metrics.EvidentialLoss`` (``metrics.py:222-262``): ``preds [b, t, 4]`` = (mean, v, alpha, beta); no bounds."""
+
+    kind = "evidential"
+
+    def __init__(self, task_weights=1.0, v_kl: float = 0.2, eps: float = 1e-8):
+        super().__init__(task_weights)
+        self.v_kl, self.eps = v_kl, eps
+
+    def forward(self, preds, targets, mask=None, weights=None, lt_mask=None, gt_mask=None):
+        t = targets if mask is None else torch.where(mask, targets, torch.full_like(targets, float("nan")))
+        return masked_loss(preds, t, weights, self.task_weights, None, None, self.kind, self.v_kl, self.eps)
+
+
+class MveFFN(RegressionFFN):
+    """``chemprop.nn.predictors.MveFFN`` (``predictors.py:173-190``): an MLP ``2 n_tasks`` wide, chunked into means and raw variances
+    (``softplus``), stacked ``[b, t, 2]``; ``train_step`` is ``forward``.  (The output transform is the identity here, as the
+    reference's ``UnscaleTransform`` is while training.)"""
+
+    n_targets = 2
+
+    def __init__(self, n_tasks: int = 1, input_dim: int = 300, hidden_dim: int = 300, n_layers: int = 1, dropout: float = 0.0,
+                 activation="relu", criterion: Optional[nn.Module] = None, task_weights: Optional[Tensor] = None):
+        # (the base class builds the MLP n_tasks * n_targets wide, predictors.py:132)
+        super().__init__(n_tasks, input_dim, hidden_dim, n_layers, dropout, activation,
+                         criterion if criterion is not None else self._default_criterion(torch.ones(n_tasks) if task_weights is None else task_weights))
+
+    _default_criterion = MVE
+
+    def forward(self, Z: Tensor) -> Tensor:
+        mean, var = torch.chunk(self.ffn(Z), 2, 1)
+        return torch.stack((mean, torch.nn.functional.softplus(var)), dim=2)
+
+    train_step = forward
+
+
+class EvidentialFFN(MveFFN):
+    """``chemprop.nn.predictors.EvidentialFFN`` (``predictors.py:193-212``): ``4 n_tasks`` wide — mean | v | alpha | beta,
+    ``v = softplus``, ``alpha = softplus + 1``, ``beta = softplus``, stacked ``[b, t, 4]``."""
+
+    n_targets = 4
+    _default_criterion = Evidential
+
+    def forward(self, Z: Tensor) -> Tensor:
+        sp = torch.nn.functional.softplus
+        mean, v, alpha, beta = torch.chunk(self.ffn(Z), 4, 1)
+        return torch.stack((mean, sp(v), sp(alpha) + 1, sp(beta)), dim=2)
+
+    train_step = forward
+
+
 class MulticlassClassificationFFN(RegressionFFN):
     """``chemprop.nn.predictors.MulticlassClassificationFFN`` (``predictors.py:271-314``): an MLP ``n_tasks * n_classes`` wide;
     ``forward`` predicts class probabilities ``[b, t, c]`` (softmax), ``train_step`` hands the logits ``[b, t, c]`` to ``CrossEntropyLoss``."""
@@ -200,7 +275,8 @@ class MPNN(nn.Module):
                 return l
         preds = self.predictor.train_step(self.fingerprint(bmg, V_d, X_d))
         c = self.criterion
-        return masked_loss(preds, targets, weights, getattr(c, "task_weights", None), lt_mask, gt_mask, getattr(c, "kind", "mse"))
+        return masked_loss(preds, targets, weights, getattr(c, "task_weights", None), lt_mask, gt_mask, getattr(c, "kind", "mse"),
+                           float(getattr(c, "v_kl", 0.2)), float(getattr(c, "eps", 1e-8)))
 
 
 def _mro_names(obj) -> set:
@@ -226,10 +302,14 @@ def criterion_kind(crit) -> tuple[Optional[str], bool]:
     (``nn/metrics.py:139-150``), ``BoundedMSE`` / ``BoundedMAE`` apply them (``:158-177``); RMSE, MVE, ... are not built in."""
     kind = getattr(crit, "kind", None)
     if kind in _lib.LOSS:
-        return kind, kind not in ("bce", "ce")
+        return kind, kind in ("mse", "mae")
     names = _mro_names(crit)
     if "RMSE" in names:
         return None, False
+    if "MVELoss" in names:            # nn/metrics.py:203-219
+        return "mve", False
+    if "EvidentialLoss" in names:     # nn/metrics.py:222-262
+        return "evidential", False
     if "BCELoss" in names:       # nn/metrics.py:292-295 (binary classification: chemprop's second task type)
         return "bce", False
     if "CrossEntropyLoss" in names:   # nn/metrics.py:298-304 (multiclass: logits [b, t, c] against class indices)
@@ -263,11 +343,19 @@ class HeadSpec:
         # (the reference's UnscaleTransform IS the identity in training mode, transforms.py:45-50: what a scaled regression run carries)
         if not (isinstance(pred.output_transform, nn.Identity) or "UnscaleTransform" in _mro_names(pred.output_transform)):
             raise NotImplementedError("the output transform is the identity while training (predictors.py:166-169)")
-        if getattr(pred, "n_targets", 1) != 1:
-            raise NotImplementedError("one value per task (regression); MVE / evidential / quantile heads train through torch ops")
         kind, self.bounded = criterion_kind(pred.criterion)
         if kind is None:
-            raise NotImplementedError("MSE / MAE criterion (bounded or not), BCE or cross entropy")
+            raise NotImplementedError("MSE / MAE criterion (bounded or not), BCE, cross entropy, MVE or evidential")
+        # values per task (predictors.py: n_targets): 1, or — round 6 — the mean-variance / evidential pairs of predictor and criterion
+        # (MveFFN + MVELoss: 2, EvidentialFFN + EvidentialLoss: 4; their softplus transforms live in the criterion kernel); quantile
+        # and Dirichlet heads train through torch ops
+        self.n_targets = int(getattr(pred, "n_targets", 1))
+        want_targets = {"mve": 2, "evidential": 4}.get(kind, 1)
+        if self.n_targets != want_targets or (want_targets > 1 and not ({"MveFFN", "EvidentialFFN"} & _mro_names(pred))):
+            raise NotImplementedError("one value per task, or MveFFN with MVELoss / EvidentialFFN with EvidentialLoss")
+        if want_targets > 1 and int(blocks[-1][-1].out_features) % want_targets:
+            raise NotImplementedError("the output width must be n_tasks * n_targets")
+        self.v_kl, self.eps = float(getattr(pred.criterion, "v_kl", 0.2)), float(getattr(pred.criterion, "eps", 1e-8))
         # multiclass (predictors.py:271-314): the output layer holds n_classes logits per task, the criterion is the cross entropy
         # over them — every other pairing of a class dimension and a criterion (Dirichlet heads, ...) trains through torch ops
         self.n_classes = int(getattr(pred, "n_classes", 0) or 0)
@@ -291,7 +379,7 @@ class HeadSpec:
     @property
     def n_tasks(self) -> int:
         """Columns of ``targets``: the output width, or — multiclass — that over ``n_classes``."""
-        return self.n_out // self.n_classes if self.n_classes >= 2 else self.n_out
+        return self.n_out // self.n_classes if self.n_classes >= 2 else self.n_out // self.n_targets
 
     def params(self) -> list:
         """The head's parameters in the order ``fill`` asks ``gptr`` about them."""
@@ -326,6 +414,7 @@ class HeadSpec:
             h.gW[l], h.gb[l] = gptr(lin.weight), gptr(lin.bias)
         h.loss = _lib.LOSS[self.kind]
         h.n_classes = self.n_classes
+        h.evid_v_kl, h.evid_eps = self.v_kl, self.eps
         h.targets = T.data_ptr()
         keep = []
         if weights is not None:

@@ -50,7 +50,7 @@ extern "C" {
  * (H0 kept as row quads on the per-step fused route's inference forward).
  * 13 — round 6: dmpnn_tile_waves (which form of the tile kernels a launch of these shapes takes); dmpnn_prepare_tiles with a batch
  * vector runs over several workgroups and uses the plan's unused arrays as hand-off scratch (nothing for the caller to do). */
-#define DMPNN_ABI_VERSION 13
+#define DMPNN_ABI_VERSION 14
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -577,9 +577,16 @@ int dmpnn_clip_grad(float* g, int64_t n, float clip_val, int32_t mode, float gra
 #define DMPNN_MAX_FFN_LAYERS 8
 enum dmpnn_loss { DMPNN_LOSS_MSE = 0, DMPNN_LOSS_MAE = 1,
                   DMPNN_LOSS_BCE = 2, /* v12: binary cross entropy with logits (nn/metrics.py:292-295; predictors.py:235-247) */
-                  DMPNN_LOSS_CE = 3   /* v12: cross entropy over dmpnn_head_args.n_classes logits per task (nn/metrics.py:298-304;
+                  DMPNN_LOSS_CE = 3,  /* v12: cross entropy over dmpnn_head_args.n_classes logits per task (nn/metrics.py:298-304;
                                          MulticlassClassificationFFN.train_step, predictors.py:271-314): the output layer is
-                                         [n_tasks * n_classes] wide, `targets` holds class indices as floats */ };
+                                         [n_tasks * n_classes] wide, `targets` holds class indices as floats */
+                  DMPNN_LOSS_MVE = 4, /* v14: mean-variance estimation (MVELoss, nn/metrics.py:203-219, on MveFFN.train_step,
+                                         predictors.py:173-190): the output layer is [2 n_tasks] wide — columns [0, t) the means,
+                                         [t, 2t) the raw variances, var = softplus(raw);  L = (mean - y)^2 / (2 var) + log(2 pi var) / 2 */
+                  DMPNN_LOSS_EVIDENTIAL = 5 /* v14: deep evidential regression (EvidentialLoss, nn/metrics.py:222-262, on
+                                         EvidentialFFN.train_step, predictors.py:193-212): the output layer is [4 n_tasks] wide — mean |
+                                         raw v | raw alpha | raw beta, v = softplus, alpha = softplus + 1, beta = softplus;
+                                         L = L_nll + evid_v_kl (L_reg - evid_eps) */ };
 typedef struct dmpnn_head_args {
     int64_t n_atoms, n_mols, d_h;           /* rows of H_v, molecules, width of H_v                              */
     const int64_t* batch;                   /* [n_atoms] molecule of every atom, non-decreasing (BatchMolGraph.batch) */
@@ -604,6 +611,7 @@ typedef struct dmpnn_head_args {
     void* ws; size_t ws_bytes;              /* caller-owned scratch, >= dmpnn_head_ws_bytes()                       */
     int64_t* bn_num_batches_tracked;        /* nn.BatchNorm1d's counter: += 1 on device when bn_training (NULL: not kept) — v9 */
     int32_t n_classes;                      /* v12, DMPNN_LOSS_CE: classes per task (>= 2); the last layer's width is n_tasks * n_classes */
+    float evid_v_kl, evid_eps;              /* v14, DMPNN_LOSS_EVIDENTIAL: EvidentialLoss.v_kl (0.2) and .eps (1e-8)                   */
 } dmpnn_head_args;
 size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h);
 int dmpnn_head(const dmpnn_head_args* h, const float* Hv, int64_t ldhv, void* stream);

@@ -21,7 +21,7 @@ from . import agg_torch, dmpnn_torch, ffn_torch
 
 
 def criterion(preds: Tensor, targets: Tensor, weights: Optional[Tensor], task_weights: Optional[Tensor], lt_mask: Optional[Tensor],
-              gt_mask: Optional[Tensor], kind: str = "mse") -> Tensor:
+              gt_mask: Optional[Tensor], kind: str = "mse", v_kl: float = 0.2, eps: float = 1e-8) -> Tensor:
     """``mask = targets.isfinite(); targets = targets.nan_to_num(nan=0.0)`` (model.py:152-153), then ``ChempropMetric.update`` +
     ``compute`` on this batch alone (metrics.py:78-127): ``sum(L * w[:, None] * task_weights * mask) / mask.sum()``."""
     mask = targets.isfinite()
@@ -29,7 +29,17 @@ def criterion(preds: Tensor, targets: Tensor, weights: Optional[Tensor], task_we
     if kind.startswith("bounded"):  # metrics.py:157-161
         preds = torch.where((preds < targets) & lt_mask, targets, preds)
         preds = torch.where((preds > targets) & gt_mask, targets, preds)
-    if kind == "ce":        # metrics.py:298-304 on the logits [b, t, c] of MulticlassClassificationFFN.train_step (predictors.py:313-314)
+    if kind == "mve":       # MVELoss, metrics.py:203-219, on MveFFN.train_step's [b, t, 2] (predictors.py:173-190)
+        mean, var = torch.unbind(preds, dim=-1)
+        L = (mean - targets) ** 2 / (2 * var) + (2 * torch.pi * var).log() / 2
+    elif kind == "evidential":   # EvidentialLoss, metrics.py:222-262, on EvidentialFFN.train_step's [b, t, 4] (predictors.py:193-212)
+        mean, v, alpha, beta = torch.unbind(preds, dim=-1)
+        residuals = targets - mean
+        twoBlambda = 2 * beta * (1 + v)
+        L_nll = (0.5 * (torch.pi / v).log() - alpha * twoBlambda.log() + (alpha + 0.5) * torch.log(v * residuals**2 + twoBlambda)
+                 + torch.lgamma(alpha) - torch.lgamma(alpha + 0.5))
+        L = L_nll + v_kl * ((2 * v + alpha) * residuals.abs() - eps)
+    elif kind == "ce":      # metrics.py:298-304 on the logits [b, t, c] of MulticlassClassificationFFN.train_step (predictors.py:313-314)
         L = F.cross_entropy(preds.transpose(1, 2), targets.long(), reduction="none")
     elif kind == "bce":     # metrics.py:292-295 on the raw logits of BinaryClassificationFFN.train_step (predictors.py:246-247)
         L = F.binary_cross_entropy_with_logits(preds, targets, reduction="none")
@@ -80,6 +90,12 @@ class Model:
         P = ffn_torch.mlp_forward(H, ws, bs, cfg["ffn"].get("activation", "relu"))                              # predictors.py:166-169
         if cfg.get("predictor") == "multiclass":                                                                  # predictors.py:313-314
             P = P.reshape(P.shape[0], -1, cfg["ffn"]["n_classes"])
+        if cfg.get("predictor") == "mve":                                                                         # predictors.py:177-188
+            mean, var = torch.chunk(P, 2, 1)
+            P = torch.stack((mean, F.softplus(var)), dim=2)
+        if cfg.get("predictor") == "evidential":                                                                  # predictors.py:197-210
+            mean, v, alpha, beta = torch.chunk(P, 4, 1)
+            P = torch.stack((mean, F.softplus(v), F.softplus(alpha) + 1, F.softplus(beta)), dim=2)
         return P
 
     def loss(self, bmg, targets, weights, lt_mask, gt_mask) -> Tensor:

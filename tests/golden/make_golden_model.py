@@ -46,6 +46,12 @@ CASES = {
     "qm9_ce_multiclass": dict(n=18, kind="qm9", mp=dict(d_h=40), agg="norm", bn=False, predictor="multiclass",
                               ffn=dict(n_tasks=2, n_classes=3, hidden_dim=24), criterion="ce", task_weights=[1.0, 0.7], nan=0.15, weights=True,
                               seed=97),
+    # mean-variance estimation (MveFFN + MVELoss, predictors.py:173-190, metrics.py:203-219) and deep evidential regression
+    # (EvidentialFFN + EvidentialLoss, predictors.py:193-212, metrics.py:222-262): 2 / 4 values per task, softplus transforms
+    "qm9_mve": dict(n=20, kind="qm9", mp=dict(d_h=48), agg="mean", bn=True, predictor="mve",
+                    ffn=dict(n_tasks=2, hidden_dim=32), criterion="mve", task_weights=[1.0, 0.6], nan=0.15, weights=True, seed=98),
+    "qm9_evidential": dict(n=18, kind="qm9", mp=dict(d_h=40), agg="norm", bn=False, predictor="evidential",
+                           ffn=dict(n_tasks=2, hidden_dim=24), criterion="evidential", task_weights=[1.0, 1.5], nan=0.15, weights=True, seed=99),
     # (the CLI's default widths — d_h 300, hidden 300 — are checked at size on the GPU against the restatement these cases pin and
     #  against the staged reference executed live: tests/test_model.py)
 }
@@ -61,9 +67,11 @@ def build(R, cfg):
     tw = cfg.get("task_weights")
     kind = cfg.get("criterion", "mse")
     if kind != "mse" or tw is not None:
-        cls = {"mse": cnn.MSE, "mae": cnn.MAE, "bounded-mse": cnn.BoundedMSE, "bce": cnn.BCELoss, "ce": cnn.CrossEntropyLoss}[kind]
+        cls = {"mse": cnn.MSE, "mae": cnn.MAE, "bounded-mse": cnn.BoundedMSE, "bce": cnn.BCELoss, "ce": cnn.CrossEntropyLoss,
+               "mve": cnn.MVELoss, "evidential": cnn.EvidentialLoss}[kind]
         crit = cls(task_weights=tw if tw is not None else 1.0)
-    FFN = {"classification": cnn.BinaryClassificationFFN, "multiclass": cnn.MulticlassClassificationFFN}.get(cfg.get("predictor"), cnn.RegressionFFN)
+    FFN = {"classification": cnn.BinaryClassificationFFN, "multiclass": cnn.MulticlassClassificationFFN, "mve": cnn.MveFFN,
+           "evidential": cnn.EvidentialFFN}.get(cfg.get("predictor"), cnn.RegressionFFN)
     pred = FFN(input_dim=mp.output_dim, criterion=crit, **cfg["ffn"])
     return MPNN(mp, agg, pred, batch_norm=cfg["bn"])
 

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_version_and_plan_bytes():
     lib = _lib.load()
-    assert lib.dmpnn_version() == _lib.ABI_VERSION == 13
+    assert lib.dmpnn_version() == _lib.ABI_VERSION == 14
     assert lib.dmpnn_plan_bytes(0, 0) >= 64
     b = lib.dmpnn_plan_bytes(4319, 8328)
     assert b % 16 == 0 and b >= 4 * (16 + 9 * 8328 + 2 * 4319)

@@ -50,7 +50,7 @@ def g(request):
 
 
 def test_goldens_exist():
-    assert len(CASES) >= 6
+    assert len(CASES) >= 8
 
 
 def test_restatement_matches_executed_reference(g):
@@ -90,7 +90,7 @@ def test_module_criterion_is_the_reference_formula():
 def build_mirror(cfg):
     """The mirror model of a golden's configuration, constructed in the reference's order (same RNG stream)."""
     from chemprop_amd import agg as cagg
-    from chemprop_amd.model import BCE, CE, MAE, MPNN, MSE, BinaryClassificationFFN, MulticlassClassificationFFN, RegressionFFN
+    from chemprop_amd.model import BCE, CE, MAE, MPNN, MSE, MVE, BinaryClassificationFFN, Evidential, EvidentialFFN, MulticlassClassificationFFN, MveFFN, RegressionFFN
     from chemprop_amd.nn import BondMessagePassing
 
     mp = BondMessagePassing(**cfg["mp"])
@@ -99,8 +99,9 @@ def build_mirror(cfg):
     t = cfg["ffn"]["n_tasks"]
     crit = None
     if kind != "mse" or cfg.get("task_weights") is not None:   # (an explicit criterion: task_weights as given, 1.0 -> shape [1, 1], broadcast)
-        crit = (CE if kind == "ce" else BCE if kind == "bce" else MAE if kind.endswith("mae") else MSE)(cfg.get("task_weights") or 1.0)
-    FFN = {"classification": BinaryClassificationFFN, "multiclass": MulticlassClassificationFFN}.get(cfg.get("predictor"), RegressionFFN)
+        crit = ({"ce": CE, "bce": BCE, "mve": MVE, "evidential": Evidential}.get(kind) or (MAE if kind.endswith("mae") else MSE))(cfg.get("task_weights") or 1.0)
+    FFN = {"classification": BinaryClassificationFFN, "multiclass": MulticlassClassificationFFN, "mve": MveFFN,
+           "evidential": EvidentialFFN}.get(cfg.get("predictor"), RegressionFFN)
     pred = FFN(input_dim=mp.output_dim, criterion=crit, **cfg["ffn"])
     return MPNN(mp, agg, pred, batch_norm=cfg["bn"])
 
