@@ -109,7 +109,7 @@ class BwdArgs(C.Structure):
 
 
 MAX_FFN_LAYERS = 8
-LOSS = {"mse": 0, "mae": 1, "bce": 2, "ce": 3, "mve": 4, "evidential": 5}
+LOSS = {"mse": 0, "mae": 1, "bce": 2, "ce": 3, "mve": 4, "evidential": 5, "quantile": 6}
 STEP_FORWARD, STEP_BACKWARD, STEP_UPDATE = 1, 2, 4
 
 
@@ -130,7 +130,7 @@ class HeadArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("bn_num_batches_tracked", C.c_void_p),
         ("n_classes", C.c_int32),
-        ("evid_v_kl", C.c_float), ("evid_eps", C.c_float),
+        ("evid_v_kl", C.c_float), ("evid_eps", C.c_float), ("quantile_alpha", C.c_float),
     ]
 
 

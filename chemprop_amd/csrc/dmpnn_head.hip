@@ -197,7 +197,15 @@ struct LossArgs {
     int nc;                               // DMPNN_LOSS_CE: classes per task — P / gP rows hold t * nc logits, T the class index of every task
                                           // DMPNN_LOSS_MVE / _EVIDENTIAL: 2 / 4 — P / gP rows hold nc chunks of t columns (torch.chunk(Y, n_targets, 1))
     float v_kl, eps;                      // DMPNN_LOSS_EVIDENTIAL
+    float q_alpha;                        // DMPNN_LOSS_QUANTILE
 };
+// QuantileLoss (nn/metrics.py:589-610) on the raw outputs of QuantileFFN (predictors.py:215-232): mean -+ interval / 2 ARE the lower and
+// upper bounds the MLP put out; per bound amax(tau e, (tau - 1) e) with e = y - bound, tau = alpha / 2 | 1 - alpha / 2
+// (its derivative in the bound: -tau for e > 0, 1 - tau for e < 0, their mean at e = 0: torch.amax shares the gradient among ties)
+__device__ __forceinline__ float pinball(float e, float tau, float* g) {
+    if (g) *g = e > 0.f ? -tau : (e < 0.f ? 1.f - tau : 0.5f - tau);
+    return fmaxf(tau * e, (tau - 1.f) * e);
+}
 // F.softplus (beta 1, threshold 20) and its derivative
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float softplus_d(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
@@ -254,10 +262,11 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
             sm += 1.f;
             continue;
         }
-        if (a.kind == DMPNN_LOSS_MVE || a.kind == DMPNN_LOSS_EVIDENTIAL) {   // (uniform) chunked outputs: column k t + j is target k of task j
+        if (a.kind >= DMPNN_LOSS_MVE) {   // (uniform) chunked outputs: column k t + j is target k of task j
             const float* x = a.P + r * a.ldp + j;
             float L;
             if (a.kind == DMPNN_LOSS_MVE) L = mve_loss(x[0], x[a.t], y, nullptr, nullptr);
+            else if (a.kind == DMPNN_LOSS_QUANTILE) L = pinball(y - x[0], 0.5f * a.q_alpha, nullptr) + pinball(y - x[a.t], 1.f - 0.5f * a.q_alpha, nullptr);
             else { const float xs[4] = {x[0], x[a.t], x[2 * a.t], x[3 * a.t]}; L = evidential_loss(xs, y, a.v_kl, a.eps, nullptr); }
             sl += L * (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f);
             sm += 1.f;
@@ -301,12 +310,13 @@ __global__ __launch_bounds__(1024) void k_loss(LossArgs a) {
             for (int k = 0; k < a.nc; ++k) gx[k] = (expf(x[k] - mx) * ise - (k == cls ? 1.f : 0.f)) * f;
             continue;
         }
-        if (a.kind == DMPNN_LOSS_MVE || a.kind == DMPNN_LOSS_EVIDENTIAL) {   // (uniform)
+        if (a.kind >= DMPNN_LOSS_MVE) {   // (uniform)
             const float* x = a.P + r * a.ldp + j;
             float* gx = a.gP + r * a.ldg + j;
             float g4[4] = {0.f, 0.f, 0.f, 0.f};
             if (isfinite(y)) {
                 if (a.kind == DMPNN_LOSS_MVE) mve_loss(x[0], x[a.t], y, &g4[0], &g4[1]);
+                else if (a.kind == DMPNN_LOSS_QUANTILE) { pinball(y - x[0], 0.5f * a.q_alpha, &g4[0]); pinball(y - x[a.t], 1.f - 0.5f * a.q_alpha, &g4[1]); }
                 else { const float xs[4] = {x[0], x[a.t], x[2 * a.t], x[3 * a.t]}; evidential_loss(xs, y, a.v_kl, a.eps, g4); }
             }
             const float f = (a.w ? a.w[r] : 1.f) * (a.tw ? a.tw[j] : 1.f) * inv;
@@ -1304,9 +1314,10 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     DMPNN_CHECK_ARG(Ln >= 1 && Ln <= DMPNN_MAX_FFN_LAYERS && h.dims[0] == d, "head: 1..%d predictor layers, dims[0] == d_h", DMPNN_MAX_FFN_LAYERS);
     for (int l = 0; l < Ln; ++l) DMPNN_CHECK_ARG(h.W[l] && h.dims[l + 1] > 0, "head: layer %d has no weight / width", l);
     DMPNN_CHECK_ARG(h.act >= DMPNN_ACT_NONE && h.act <= DMPNN_ACT_ELU && h.act != DMPNN_ACT_PRELU, "head: activation %d is not built in", h.act);
-    DMPNN_CHECK_ARG(h.loss >= DMPNN_LOSS_MSE && h.loss <= DMPNN_LOSS_EVIDENTIAL, "head: unknown criterion %d", h.loss);
+    DMPNN_CHECK_ARG(h.loss >= DMPNN_LOSS_MSE && h.loss <= DMPNN_LOSS_QUANTILE, "head: unknown criterion %d", h.loss);
     DMPNN_CHECK_ARG(h.loss <= DMPNN_LOSS_MAE || (!h.lt_mask && !h.gt_mask), "head: only the MSE / MAE criteria have bounds (lt_mask / gt_mask)");
-    DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_MVE || h.dims[Ln] % 2 == 0, "head: mean-variance estimation needs an output layer 2 n_tasks wide");
+    DMPNN_CHECK_ARG((h.loss != DMPNN_LOSS_MVE && h.loss != DMPNN_LOSS_QUANTILE) || h.dims[Ln] % 2 == 0, "head: the MVE / quantile criteria need an output layer 2 n_tasks wide");
+    DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_QUANTILE || (h.quantile_alpha > 0.f && h.quantile_alpha < 1.f), "head: the quantile criterion needs 0 < quantile_alpha < 1");
     DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_EVIDENTIAL || h.dims[Ln] % 4 == 0, "head: the evidential criterion needs an output layer 4 n_tasks wide");
     DMPNN_CHECK_ARG(h.loss != DMPNN_LOSS_CE || (h.n_classes >= 2 && h.dims[Ln] % h.n_classes == 0), "head: cross entropy needs n_classes >= 2 dividing the output width");
     DMPNN_CHECK_ARG(h.preds && (nV == 0 || (Hv && h.batch)), "head: null H_v / batch / preds");
@@ -1326,7 +1337,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     unsigned char* ws = static_cast<unsigned char*>(h.ws);
     float* Hm = reinterpret_cast<float*>(ws + L.Hm);
     const int t_out = (int)h.dims[Ln];                                  // width of the output layer
-    const int nc = h.loss == DMPNN_LOSS_CE ? h.n_classes : (h.loss == DMPNN_LOSS_MVE ? 2 : (h.loss == DMPNN_LOSS_EVIDENTIAL ? 4 : 1));   // outputs per task
+    const int nc = h.loss == DMPNN_LOSS_CE ? h.n_classes : ((h.loss == DMPNN_LOSS_MVE || h.loss == DMPNN_LOSS_QUANTILE) ? 2 : (h.loss == DMPNN_LOSS_EVIDENTIAL ? 4 : 1));   // outputs per task
     const int t = t_out / nc;                                           // tasks (= columns of `targets`)
 
     // ---- forward ----
@@ -1454,7 +1465,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
     float* gP = reinterpret_cast<float*>(ws + L.gP);
     if (!out_all) {
         LossArgs q{h.preds, t_out, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, want_grad ? gP : nullptr, t_out, h.loss_out, B, t, h.loss, nc,
-                   h.evid_v_kl, h.evid_eps};
+                   h.evid_v_kl, h.evid_eps, h.quantile_alpha};
         DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
         hipLaunchKernelGGL(k_loss, dim3(1), dim3(1024), 0, s, q);
         DMPNN_CHECK_LAUNCH("k_loss");
@@ -1474,7 +1485,7 @@ int head_run(const dmpnn_head_args* hp, const float* Hv, int64_t ldhv, void* str
             OutBwdArgs q{g_cur, A[l], K, h.W[l], out, K, h.gW[l], h.b[l] ? h.gb[l] : nullptr, B, (int)K, (int)N, l > 0 ? h.act : DMPNN_ACT_NONE, h.act_slope};
             if (out_all) {
                 DMPNN_CHECK_ARG(h.loss_out != nullptr, "head: targets without loss_out");
-                OutAllArgs qa{q, LossArgs{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, nullptr, t, h.loss_out, B, t, h.loss, 1, 0.f, 0.f}};
+                OutAllArgs qa{q, LossArgs{h.preds, t, h.targets, t, h.weights, h.task_weights, h.lt_mask, h.gt_mask, nullptr, t, h.loss_out, B, t, h.loss, 1, 0.f, 0.f, 0.f}};
                 qa.o.gP = nullptr;
                 hipLaunchKernelGGL(k_out_all, dim3((unsigned)((K + kBnCols - 1) / kBnCols)), dim3(1024), 0, s, qa);
                 DMPNN_CHECK_LAUNCH("k_out_all");

@@ -28,22 +28,28 @@ from .ffn import MLP
 from .nn import BondMessagePassing, classify_activation
 from .optim import FlatAdam
 
-__all__ = ["MSE", "MAE", "BCE", "CE", "MVE", "Evidential", "RegressionFFN", "BinaryClassificationFFN", "MulticlassClassificationFFN", "MveFFN", "EvidentialFFN",
+__all__ = ["MSE", "MAE", "BCE", "CE", "MVE", "Evidential", "Quantile", "RegressionFFN", "BinaryClassificationFFN", "MulticlassClassificationFFN", "MveFFN", "EvidentialFFN", "QuantileFFN",
            "MPNN", "FusedTrainer", "masked_loss"]
 
 
 def masked_loss(preds: Tensor, targets: Tensor, weights: Optional[Tensor] = None, task_weights: Optional[Tensor] = None,
-                lt_mask: Optional[Tensor] = None, gt_mask: Optional[Tensor] = None, kind: str = "mse", v_kl: float = 0.2, eps: float = 1e-8) -> Tensor:
+                lt_mask: Optional[Tensor] = None, gt_mask: Optional[Tensor] = None, kind: str = "mse", v_kl: float = 0.2, eps: float = 1e-8,
+                alpha: float = 0.1) -> Tensor:
     """``ChempropMetric.update`` + ``compute`` on one batch (``nn/metrics.py:78-127``) with the masking of
     ``MPNN.training_step`` (``models/model.py:152-156``): torch ops, differentiable — the module path's criterion."""
     mask = targets.isfinite()
     targets = targets.nan_to_num(nan=0.0)
-    if kind in ("bce", "ce", "mve", "evidential"):
+    if kind in ("bce", "ce", "mve", "evidential", "quantile"):
         lt_mask = gt_mask = None     # (only the Bounded* criteria apply the masks: metrics.py:157-177)
-    if kind in ("mve", "evidential"):   # preds [b, t, 2 | 4]: what MveFFN / EvidentialFFN.train_step stack (predictors.py:173-212)
+    if kind in ("mve", "evidential", "quantile"):   # preds [b, t, 2 | 4]: what MveFFN / EvidentialFFN / QuantileFFN.train_step stack (predictors.py:173-232)
         if kind == "mve":               # MVELoss, metrics.py:203-219
             mean, var = torch.unbind(preds, dim=-1)
             L = (mean - targets) ** 2 / (2 * var) + (2 * torch.pi * var).log() / 2
+        elif kind == "quantile":        # QuantileLoss, metrics.py:589-610
+            mean, interval = torch.unbind(preds, dim=-1)
+            bounds = torch.tensor([-0.5, 0.5], device=preds.device).view(-1, 1, 1)
+            tau = torch.tensor([[alpha / 2, 1 - alpha / 2], [alpha / 2 - 1, -alpha / 2]], device=preds.device).view(2, 2, 1, 1)
+            L = (tau * (targets - (mean + bounds * interval))).amax(0).sum(0)
         else:                           # EvidentialLoss, metrics.py:222-262
             mean, v, alpha, beta = torch.unbind(preds, dim=-1)
             residuals = targets - mean
@@ -165,19 +171,40 @@ class Evidential(MSE):
         return masked_loss(preds, t, weights, self.task_weights, None, None, self.kind, self.v_kl, self.eps)
 
 
-class MveFFN(RegressionFFN):
+class Quantile(MSE):
+    """``chemprop.nn.metrics.QuantileLoss`` (``metrics.py:589-610``): ``preds [b, t, 2]`` = (mean, interval); no bounds."""
+
+    kind = "quantile"
+
+    def __init__(self, task_weights=1.0, alpha: float = 0.1):
+        super().__init__(task_weights)
+        self.alpha = alpha
+        # (the reference's buffers, metrics.py:594-600: the state dicts match)
+        self.register_buffer("bounds", torch.tensor([-1 / 2, 1 / 2]).view(-1, 1, 1))
+        self.register_buffer("tau", torch.tensor([[alpha / 2, 1 - alpha / 2], [alpha / 2 - 1, -alpha / 2]]).view(2, 2, 1, 1))
+
+    def forward(self, preds, targets, mask=None, weights=None, lt_mask=None, gt_mask=None):
+        t = targets if mask is None else torch.where(mask, targets, torch.full_like(targets, float("nan")))
+        return masked_loss(preds, t, weights, self.task_weights, None, None, self.kind, alpha=self.alpha)
+
+
+class _MultiTargetFFN(RegressionFFN):
+    """A regression predictor with ``n_targets`` values per task (``predictors.py:132``: the MLP is ``n_tasks * n_targets`` wide)."""
+
+    _default_criterion = MSE
+
+    def __init__(self, n_tasks: int = 1, input_dim: int = 300, hidden_dim: int = 300, n_layers: int = 1, dropout: float = 0.0,
+                 activation="relu", criterion: Optional[nn.Module] = None, task_weights: Optional[Tensor] = None):
+        super().__init__(n_tasks, input_dim, hidden_dim, n_layers, dropout, activation,
+                         criterion if criterion is not None else self._default_criterion(torch.ones(n_tasks) if task_weights is None else task_weights))
+
+
+class MveFFN(_MultiTargetFFN):
     """``chemprop.nn.predictors.MveFFN`` (``predictors.py:173-190``): an MLP ``2 n_tasks`` wide, chunked into means and raw variances
     (``softplus``), stacked ``[b, t, 2]``; ``train_step`` is ``forward``.  (The output transform is the identity here, as the
     reference's ``UnscaleTransform`` is while training.)"""
 
     n_targets = 2
-
-    def __init__(self, n_tasks: int = 1, input_dim: int = 300, hidden_dim: int = 300, n_layers: int = 1, dropout: float = 0.0,
-                 activation="relu", criterion: Optional[nn.Module] = None, task_weights: Optional[Tensor] = None):
-        # (the base class builds the MLP n_tasks * n_targets wide, predictors.py:132)
-        super().__init__(n_tasks, input_dim, hidden_dim, n_layers, dropout, activation,
-                         criterion if criterion is not None else self._default_criterion(torch.ones(n_tasks) if task_weights is None else task_weights))
-
     _default_criterion = MVE
 
     def forward(self, Z: Tensor) -> Tensor:
@@ -187,7 +214,7 @@ class MveFFN(RegressionFFN):
     train_step = forward
 
 
-class EvidentialFFN(MveFFN):
+class EvidentialFFN(_MultiTargetFFN):
     """``chemprop.nn.predictors.EvidentialFFN`` (``predictors.py:193-212``): ``4 n_tasks`` wide — mean | v | alpha | beta,
     ``v = softplus``, ``alpha = softplus + 1``, ``beta = softplus``, stacked ``[b, t, 4]``."""
 
@@ -198,6 +225,20 @@ class EvidentialFFN(MveFFN):
         sp = torch.nn.functional.softplus
         mean, v, alpha, beta = torch.chunk(self.ffn(Z), 4, 1)
         return torch.stack((mean, sp(v), sp(alpha) + 1, sp(beta)), dim=2)
+
+    train_step = forward
+
+
+class QuantileFFN(_MultiTargetFFN):
+    """``chemprop.nn.predictors.QuantileFFN`` (``predictors.py:215-232``): ``2 n_tasks`` wide — lower | upper bounds, stacked as
+    ``(mean, interval) [b, t, 2]``."""
+
+    n_targets = 2
+    _default_criterion = Quantile
+
+    def forward(self, Z: Tensor) -> Tensor:
+        lower, upper = torch.chunk(self.ffn(Z), 2, 1)
+        return torch.stack(((lower + upper) / 2, upper - lower), dim=2)
 
     train_step = forward
 
@@ -276,7 +317,7 @@ class MPNN(nn.Module):
         preds = self.predictor.train_step(self.fingerprint(bmg, V_d, X_d))
         c = self.criterion
         return masked_loss(preds, targets, weights, getattr(c, "task_weights", None), lt_mask, gt_mask, getattr(c, "kind", "mse"),
-                           float(getattr(c, "v_kl", 0.2)), float(getattr(c, "eps", 1e-8)))
+                           float(getattr(c, "v_kl", 0.2)), float(getattr(c, "eps", 1e-8)), float(getattr(c, "alpha", 0.1)))
 
 
 def _mro_names(obj) -> set:
@@ -310,6 +351,8 @@ def criterion_kind(crit) -> tuple[Optional[str], bool]:
         return "mve", False
     if "EvidentialLoss" in names:     # nn/metrics.py:222-262
         return "evidential", False
+    if "QuantileLoss" in names and "PointQuantileLoss" not in names:   # nn/metrics.py:589-610 (the interval form; the point form takes one value per task)
+        return "quantile", False
     if "BCELoss" in names:       # nn/metrics.py:292-295 (binary classification: chemprop's second task type)
         return "bce", False
     if "CrossEntropyLoss" in names:   # nn/metrics.py:298-304 (multiclass: logits [b, t, c] against class indices)
@@ -345,17 +388,19 @@ class HeadSpec:
             raise NotImplementedError("the output transform is the identity while training (predictors.py:166-169)")
         kind, self.bounded = criterion_kind(pred.criterion)
         if kind is None:
-            raise NotImplementedError("MSE / MAE criterion (bounded or not), BCE, cross entropy, MVE or evidential")
+            raise NotImplementedError("MSE / MAE criterion (bounded or not), BCE, cross entropy, MVE, evidential or quantile")
         # values per task (predictors.py: n_targets): 1, or — round 6 — the mean-variance / evidential pairs of predictor and criterion
-        # (MveFFN + MVELoss: 2, EvidentialFFN + EvidentialLoss: 4; their softplus transforms live in the criterion kernel); quantile
-        # and Dirichlet heads train through torch ops
+        # (MveFFN + MVELoss: 2, EvidentialFFN + EvidentialLoss: 4, QuantileFFN + QuantileLoss: 2; the predictors' transforms of the
+        # raw outputs live in the criterion kernel); Dirichlet heads train through torch ops
         self.n_targets = int(getattr(pred, "n_targets", 1))
-        want_targets = {"mve": 2, "evidential": 4}.get(kind, 1)
-        if self.n_targets != want_targets or (want_targets > 1 and not ({"MveFFN", "EvidentialFFN"} & _mro_names(pred))):
-            raise NotImplementedError("one value per task, or MveFFN with MVELoss / EvidentialFFN with EvidentialLoss")
+        want_targets = {"mve": 2, "evidential": 4, "quantile": 2}.get(kind, 1)
+        want_pred = {"mve": "MveFFN", "evidential": "EvidentialFFN", "quantile": "QuantileFFN"}.get(kind)
+        if self.n_targets != want_targets or (want_pred is not None and want_pred not in _mro_names(pred)):
+            raise NotImplementedError("one value per task, or MveFFN with MVELoss / EvidentialFFN with EvidentialLoss / QuantileFFN with QuantileLoss")
         if want_targets > 1 and int(blocks[-1][-1].out_features) % want_targets:
             raise NotImplementedError("the output width must be n_tasks * n_targets")
         self.v_kl, self.eps = float(getattr(pred.criterion, "v_kl", 0.2)), float(getattr(pred.criterion, "eps", 1e-8))
+        self.q_alpha = float(getattr(pred.criterion, "alpha", 0.1))
         # multiclass (predictors.py:271-314): the output layer holds n_classes logits per task, the criterion is the cross entropy
         # over them — every other pairing of a class dimension and a criterion (Dirichlet heads, ...) trains through torch ops
         self.n_classes = int(getattr(pred, "n_classes", 0) or 0)
@@ -414,7 +459,7 @@ class HeadSpec:
             h.gW[l], h.gb[l] = gptr(lin.weight), gptr(lin.bias)
         h.loss = _lib.LOSS[self.kind]
         h.n_classes = self.n_classes
-        h.evid_v_kl, h.evid_eps = self.v_kl, self.eps
+        h.evid_v_kl, h.evid_eps, h.quantile_alpha = self.v_kl, self.eps, self.q_alpha
         h.targets = T.data_ptr()
         keep = []
         if weights is not None:

@@ -583,10 +583,13 @@ enum dmpnn_loss { DMPNN_LOSS_MSE = 0, DMPNN_LOSS_MAE = 1,
                   DMPNN_LOSS_MVE = 4, /* v14: mean-variance estimation (MVELoss, nn/metrics.py:203-219, on MveFFN.train_step,
                                          predictors.py:173-190): the output layer is [2 n_tasks] wide — columns [0, t) the means,
                                          [t, 2t) the raw variances, var = softplus(raw);  L = (mean - y)^2 / (2 var) + log(2 pi var) / 2 */
-                  DMPNN_LOSS_EVIDENTIAL = 5 /* v14: deep evidential regression (EvidentialLoss, nn/metrics.py:222-262, on
+                  DMPNN_LOSS_EVIDENTIAL = 5, /* v14: deep evidential regression (EvidentialLoss, nn/metrics.py:222-262, on
                                          EvidentialFFN.train_step, predictors.py:193-212): the output layer is [4 n_tasks] wide — mean |
                                          raw v | raw alpha | raw beta, v = softplus, alpha = softplus + 1, beta = softplus;
-                                         L = L_nll + evid_v_kl (L_reg - evid_eps) */ };
+                                         L = L_nll + evid_v_kl (L_reg - evid_eps) */
+                  DMPNN_LOSS_QUANTILE = 6 /* v14: the interval pinball loss (QuantileLoss, nn/metrics.py:589-610, on QuantileFFN.train_step,
+                                         predictors.py:215-232): the output layer is [2 n_tasks] wide — lower | upper bounds;
+                                         L = pinball(y - lower; alpha / 2) + pinball(y - upper; 1 - alpha / 2), alpha = quantile_alpha */ };
 typedef struct dmpnn_head_args {
     int64_t n_atoms, n_mols, d_h;           /* rows of H_v, molecules, width of H_v                              */
     const int64_t* batch;                   /* [n_atoms] molecule of every atom, non-decreasing (BatchMolGraph.batch) */
@@ -612,6 +615,7 @@ typedef struct dmpnn_head_args {
     int64_t* bn_num_batches_tracked;        /* nn.BatchNorm1d's counter: += 1 on device when bn_training (NULL: not kept) — v9 */
     int32_t n_classes;                      /* v12, DMPNN_LOSS_CE: classes per task (>= 2); the last layer's width is n_tasks * n_classes */
     float evid_v_kl, evid_eps;              /* v14, DMPNN_LOSS_EVIDENTIAL: EvidentialLoss.v_kl (0.2) and .eps (1e-8)                   */
+    float quantile_alpha;                   /* v14, DMPNN_LOSS_QUANTILE: QuantileLoss.alpha (0.1)                                      */
 } dmpnn_head_args;
 size_t dmpnn_head_ws_bytes(const dmpnn_head_args* h);
 int dmpnn_head(const dmpnn_head_args* h, const float* Hv, int64_t ldhv, void* stream);

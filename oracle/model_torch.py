@@ -21,7 +21,7 @@ from . import agg_torch, dmpnn_torch, ffn_torch
 
 
 def criterion(preds: Tensor, targets: Tensor, weights: Optional[Tensor], task_weights: Optional[Tensor], lt_mask: Optional[Tensor],
-              gt_mask: Optional[Tensor], kind: str = "mse", v_kl: float = 0.2, eps: float = 1e-8) -> Tensor:
+              gt_mask: Optional[Tensor], kind: str = "mse", v_kl: float = 0.2, eps: float = 1e-8, alpha: float = 0.1) -> Tensor:
     """``mask = targets.isfinite(); targets = targets.nan_to_num(nan=0.0)`` (model.py:152-153), then ``ChempropMetric.update`` +
     ``compute`` on this batch alone (metrics.py:78-127): ``sum(L * w[:, None] * task_weights * mask) / mask.sum()``."""
     mask = targets.isfinite()
@@ -39,6 +39,11 @@ def criterion(preds: Tensor, targets: Tensor, weights: Optional[Tensor], task_we
         L_nll = (0.5 * (torch.pi / v).log() - alpha * twoBlambda.log() + (alpha + 0.5) * torch.log(v * residuals**2 + twoBlambda)
                  + torch.lgamma(alpha) - torch.lgamma(alpha + 0.5))
         L = L_nll + v_kl * ((2 * v + alpha) * residuals.abs() - eps)
+    elif kind == "quantile":     # QuantileLoss, metrics.py:589-610, on QuantileFFN.train_step's [b, t, 2] = (mean, interval) (predictors.py:215-232)
+        mean, interval = torch.unbind(preds, dim=-1)
+        bounds = torch.tensor([-1 / 2, 1 / 2]).view(-1, 1, 1)
+        tau = torch.tensor([[alpha / 2, 1 - alpha / 2], [alpha / 2 - 1, -alpha / 2]]).view(2, 2, 1, 1)
+        L = (tau * (targets - (mean + bounds * interval))).amax(0).sum(0)
     elif kind == "ce":      # metrics.py:298-304 on the logits [b, t, c] of MulticlassClassificationFFN.train_step (predictors.py:313-314)
         L = F.cross_entropy(preds.transpose(1, 2), targets.long(), reduction="none")
     elif kind == "bce":     # metrics.py:292-295 on the raw logits of BinaryClassificationFFN.train_step (predictors.py:246-247)
@@ -60,7 +65,7 @@ class Model:
         self.buf = {}
         for k, v in state.items():
             t = torch.as_tensor(v).clone()
-            if k.endswith(("running_mean", "running_var", "num_batches_tracked", "task_weights")):
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked", "task_weights", "criterion.bounds", "criterion.tau")):
                 self.buf[k] = t
             else:
                 self.p[k] = t.float().requires_grad_(True)
@@ -96,11 +101,14 @@ class Model:
         if cfg.get("predictor") == "evidential":                                                                  # predictors.py:197-210
             mean, v, alpha, beta = torch.chunk(P, 4, 1)
             P = torch.stack((mean, F.softplus(v), F.softplus(alpha) + 1, F.softplus(beta)), dim=2)
+        if cfg.get("predictor") == "quantile":                                                                    # predictors.py:219-230
+            lower, upper = torch.chunk(P, 2, 1)
+            P = torch.stack(((lower + upper) / 2, upper - lower), dim=2)
         return P
 
     def loss(self, bmg, targets, weights, lt_mask, gt_mask) -> Tensor:
         return criterion(self.forward(bmg), targets, weights, self.buf.get("predictor.criterion.task_weights"), lt_mask, gt_mask,
-                         self.cfg.get("criterion", "mse"))
+                         self.cfg.get("criterion", "mse"), alpha=float(self.cfg.get("alpha", 0.1)))
 
     def state(self) -> dict:
         out = {k: v.detach().clone() for k, v in self.p.items()}

@@ -52,6 +52,9 @@ CASES = {
                     ffn=dict(n_tasks=2, hidden_dim=32), criterion="mve", task_weights=[1.0, 0.6], nan=0.15, weights=True, seed=98),
     "qm9_evidential": dict(n=18, kind="qm9", mp=dict(d_h=40), agg="norm", bn=False, predictor="evidential",
                            ffn=dict(n_tasks=2, hidden_dim=24), criterion="evidential", task_weights=[1.0, 1.5], nan=0.15, weights=True, seed=99),
+    # the interval pinball loss (QuantileFFN + QuantileLoss, predictors.py:215-232, metrics.py:589-610)
+    "qm9_quantile": dict(n=16, kind="qm9", mp=dict(d_h=32), agg="sum", bn=True, predictor="quantile",
+                         ffn=dict(n_tasks=2, hidden_dim=24), criterion="quantile", task_weights=[1.0, 2.0], nan=0.15, weights=True, seed=100),
     # (the CLI's default widths — d_h 300, hidden 300 — are checked at size on the GPU against the restatement these cases pin and
     #  against the staged reference executed live: tests/test_model.py)
 }
@@ -68,10 +71,10 @@ def build(R, cfg):
     kind = cfg.get("criterion", "mse")
     if kind != "mse" or tw is not None:
         cls = {"mse": cnn.MSE, "mae": cnn.MAE, "bounded-mse": cnn.BoundedMSE, "bce": cnn.BCELoss, "ce": cnn.CrossEntropyLoss,
-               "mve": cnn.MVELoss, "evidential": cnn.EvidentialLoss}[kind]
+               "mve": cnn.MVELoss, "evidential": cnn.EvidentialLoss, "quantile": cnn.QuantileLoss}[kind]
         crit = cls(task_weights=tw if tw is not None else 1.0)
     FFN = {"classification": cnn.BinaryClassificationFFN, "multiclass": cnn.MulticlassClassificationFFN, "mve": cnn.MveFFN,
-           "evidential": cnn.EvidentialFFN}.get(cfg.get("predictor"), cnn.RegressionFFN)
+           "evidential": cnn.EvidentialFFN, "quantile": cnn.QuantileFFN}.get(cfg.get("predictor"), cnn.RegressionFFN)
     pred = FFN(input_dim=mp.output_dim, criterion=crit, **cfg["ffn"])
     return MPNN(mp, agg, pred, batch_norm=cfg["bn"])
 

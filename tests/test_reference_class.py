@@ -262,9 +262,9 @@ def _build_hip_mpnn(R, cfg, stock=False):
     tw, kind = cfg.get("task_weights"), cfg.get("criterion", "mse")
     if kind != "mse" or tw is not None:
         crit = {"mse": cnn.MSE, "mae": cnn.MAE, "bounded-mse": cnn.BoundedMSE, "bce": cnn.BCELoss, "ce": cnn.CrossEntropyLoss,
-                "mve": cnn.MVELoss, "evidential": cnn.EvidentialLoss}[kind](task_weights=tw if tw is not None else 1.0)
+                "mve": cnn.MVELoss, "evidential": cnn.EvidentialLoss, "quantile": cnn.QuantileLoss}[kind](task_weights=tw if tw is not None else 1.0)
     FFN = {"classification": cnn.BinaryClassificationFFN, "multiclass": cnn.MulticlassClassificationFFN, "mve": cnn.MveFFN,
-           "evidential": cnn.EvidentialFFN}.get(cfg.get("predictor"), cnn.RegressionFFN)
+           "evidential": cnn.EvidentialFFN, "quantile": cnn.QuantileFFN}.get(cfg.get("predictor"), cnn.RegressionFFN)
     pred = FFN(input_dim=mp.output_dim, criterion=crit, **cfg["ffn"])
     return HipMPNN(mp, agg, pred, batch_norm=cfg["bn"])
 
