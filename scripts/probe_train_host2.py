@@ -1,4 +1,4 @@
-"""Host profile of the 512-molecule training step by own time, backward on the calling thread so that cProfile sees it."""
+"""Where the host time of the 512-molecule block training step goes: cProfile by own time, backward on the calling thread (as bench.py)."""
 import cProfile
 import pstats
 import sys
@@ -13,7 +13,8 @@ from chemprop_amd.nn import BondMessagePassing
 from chemprop_amd.optim import FlatAdam
 
 dev = torch.device("cuda:0")
-bmg = synth.random_batch(512, "qm9", seed=1000)
+n_mols = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+bmg = synth.random_batch(n_mols, "qm9", seed=1000)
 bmg.to(dev)
 torch.manual_seed(0)
 mp = BondMessagePassing().to(dev).train()
@@ -23,14 +24,15 @@ G = torch.randn(int(bmg.V.shape[0]), mp.output_dim, device=dev)
 
 
 def step():
-    mp(bmg).backward(G)
+    with ddp.backward_on_calling_thread():
+        mp(bmg).backward(G)
     sync.allreduce()
     opt.step()
 
 
-def rate(tag):
-    for _ in range(20):
-        step()
+for _ in range(30):
+    step()
+for rep in range(4):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(200):
@@ -38,17 +40,12 @@ def rate(tag):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"{tag}: enqueue {5e3 * (t1 - t0):7.1f} us/step   total {5e3 * (t2 - t0):7.1f} us/step")
-
-
-rate("autograd multithreading on ")
-with torch.autograd.set_multithreading_enabled(False):
-    rate("autograd multithreading off")
-    pr = cProfile.Profile()
-    pr.enable()
-    for _ in range(300):
-        step()
-    torch.cuda.synchronize()
-    pr.disable()
-    st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(45)
+    print(f"rep {rep}: enqueue {5e3 * (t1 - t0):7.1f} us/step   total {5e3 * (t2 - t0):7.1f} us/step")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(400):
+    step()
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(40)
