@@ -35,7 +35,7 @@ EXPORTS = [
     "dmpnn_molagg_ws_bytes", "dmpnn_molagg_bounds", "dmpnn_molagg_fwd", "dmpnn_molagg_bwd", "dmpnn_gather_rows", "dmpnn_collate", "dmpnn_pack_tiles", "dmpnn_max_tiles",
     "dmpnn_prepare_tiles_from_table", "dmpnn_prepare_with_batch", "dmpnn_tile_plan_any_size", "dmpnn_split_row_floats", "dmpnn_forward_can_fuse16", "dmpnn_adam_step",
     "dmpnn_full_plan_keeps_tiles", "dmpnn_head_ws_bytes", "dmpnn_head", "dmpnn_train_step", "dmpnn_forward_tiles", "dmpnn_forward_route", "dmpnn_dropout_keep",
-    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes", "dmpnn_train_route", "dmpnn_forward_h0_bytes", "dmpnn_tile_waves",
+    "dmpnn_clip_grad", "dmpnn_clip_grad_ws_bytes", "dmpnn_train_route", "dmpnn_forward_h0_bytes", "dmpnn_tile_waves", "dmpnn_debug_lds_poison",
 ]
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "prelu": 3, "tanh": 4, "elu": 5}

@@ -18,10 +18,36 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+// DMPNN_DEBUG_LDS_POISON=1 (debugging aid, round 6): after EVERY launch of the library the whole LDS of every CU is filled with a NaN
+// pattern (fp32 NaN = two f16 NaNs), on the legacy default stream — the stream the tests run on.  LDS is not cleared between kernels: a
+// kernel that reads LDS it never wrote multiplies, on a warm box, the previous kernel's finite leftovers (by a zero weight, typically:
+// unnoticed) and on a cold box whatever the last tenant left — round 6 met one such NaN on a fresh box (k_head_rows: three columns of
+// a 16 x 4 tile never zeroed) and found it with this switch; `pytest -m gpu` under it is the regression test.
+static __global__ __launch_bounds__(1024) void k_debug_lds_poison(unsigned pat, unsigned* sink) {
+    extern __shared__ unsigned lds_words[];
+    constexpr int n = (160 * 1024 - 64) / 4;
+    for (int i = threadIdx.x; i < n; i += 1024) lds_words[i] = pat;
+    __syncthreads();
+    if (sink && lds_words[(threadIdx.x * 7) % n] == 0x12345u) sink[0] = 1;   // (keeps the stores)
+}
+static int g_lds_poison = -1;   // -1: not decided yet (the environment), 0 off, 1 on (dmpnn_debug_lds_poison)
+static void debug_lds_poison() {
+    if (g_lds_poison < 0) {
+        const char* e = getenv("DMPNN_DEBUG_LDS_POISON");
+        g_lds_poison = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (!g_lds_poison) return;
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_lds_poison), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess;
+    if (!attr) return;
+    // (one workgroup per CU at this LDS size; three rounds' worth so that every CU is hit whatever the dispatch order)
+    hipLaunchKernelGGL(k_debug_lds_poison, dim3(768), dim3(1024), 160 * 1024 - 64, static_cast<hipStream_t>(nullptr), 0x7FC07FC0u, static_cast<unsigned*>(nullptr));
+    (void)hipGetLastError();
+}
 // DMPNN_TRACE=1: print every kernel launch and synchronise after it, so a device fault is
 // attributed to the launch that caused it (debugging aid; never set in production).
 void count_launch(const char* name) {
     ++g_launches;
+    debug_lds_poison();
     static const bool trace = [] {
         const char* e = getenv("DMPNN_TRACE");
         return e && e[0] == '1';
@@ -50,6 +76,7 @@ namespace dmpnn { extern thread_local long long* g_debug_stamps; }
 extern "C" {
 
 int dmpnn_version(void) { return DMPNN_ABI_VERSION; }
+void dmpnn_debug_lds_poison(int on) { dmpnn::g_lds_poison = on ? 1 : 0; }
 int dmpnn_dropout_keep(uint64_t seed, int32_t site, int64_t row, int64_t col, float p) {
     if (!(p > 0.f && p < 1.f)) return p <= 0.f ? 1 : 0;
     return drop_hash((unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), (unsigned)site, (unsigned)row, (unsigned)col) >= drop_threshold(p) ? 1 : 0;

@@ -1048,6 +1048,10 @@ __global__ __launch_bounds__(256) void k_head_rows(RowsArgs a) {
         stamp();  // 1 requests out
 #pragma unroll
         for (int u = 0; u < NW1; ++u) { const int idx = tid + 256 * u; W1s[idx / BN][idx % BN] = w1v[u]; }   // (read by every row of the tile, twice)
+        // dl/dP as 16 x 4: columns beyond t must be ZERO (they meet W1's zero rows below) — all of the tile first, the t live columns
+        // after the criterion.  (Round 5 zeroed them with the threads 16 t .. 63 only: the columns >= t of the rows below 4 t kept whatever
+        // the LDS held — 0 x a finite leftover on a warm box, NaN on a cold one; found in round 6 with DMPNN_DEBUG_LDS_POISON)
+        if (tid < 16 * kOutMaxTasks) gPs[tid / kOutMaxTasks][tid % kOutMaxTasks] = 0.f;
 #pragma unroll
         for (int j = 0; j < WNT; ++j) *reinterpret_cast<float4*>(A1s + (tid >> 4) * LDA + 4 * (tid & 15) + 64 * j) = ax[j];   // (zero beyond N and beyond the batch)
         __syncthreads();
@@ -1098,8 +1102,7 @@ __global__ __launch_bounds__(256) void k_head_rows(RowsArgs a) {
             }
         }
         __syncthreads();
-        if (tid < 16 * t) gPs[ei][ej] = efin ? loss_deriv(a.kind, ep, ey) * ef * (1.f / tot[1]) : 0.f;
-        else if (tid < 16 * kOutMaxTasks && tid % kOutMaxTasks >= t) gPs[tid / kOutMaxTasks][tid % kOutMaxTasks] = 0.f;   // (columns beyond t: zero)
+        if (tid < 16 * t) gPs[ei][ej] = efin ? loss_deriv(a.kind, ep, ey) * ef * (1.f / tot[1]) : 0.f;   // (columns beyond t: zeroed above)
         __syncthreads();
         stamp();  // 3 criterion
         // ---- the output layer's backward on this row block: thread = column n of A1 (all of them: the operand of the contraction below) ----

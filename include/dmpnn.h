@@ -650,6 +650,10 @@ int dmpnn_version(void);
  * (NULL switches it off; never set in production): [0, 32) the whole-forward tile kernel / the per-step fused kernel, [32, 64) K0,
  * [64, 80) the head's row kernels, [80, 96) and [96, 112) its column kernels (scripts/probe_stamps*.py, scripts/probe_head_rows.py). */
 int dmpnn_debug_timestamps(void* device_buf);
+/* Debug aid (v14): on != 0 — after EVERY kernel launch of the library the whole LDS of every CU is filled with a NaN pattern (on the
+ * legacy default stream), so that a kernel that reads LDS it never wrote shows it as a NaN instead of a leftover of the previous kernel
+ * (LDS is not cleared between launches).  Also DMPNN_DEBUG_LDS_POISON=1 in the environment.  Never set in production. */
+void dmpnn_debug_lds_poison(int on);
 const char* dmpnn_last_error_string(void);
 /* Number of kernels the last dmpnn_forward on this thread enqueued (diagnostics). */
 int dmpnn_last_launch_count(void);

@@ -745,3 +745,57 @@ def test_fused_step_takes_the_aggregate_from_the_forward_tile_kernel_bit_for_bit
     assert torch.isfinite(out["tile"][0]).all()
     for i, (a, b) in enumerate(zip(out["tile"][1], out["fused"][1])):
         assert torch.equal(a, b), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tasks,act", [(1, "relu"), (3, "elu")])
+def test_no_kernel_of_a_training_step_reads_lds_it_never_wrote(tasks, act, gpu_device):
+    """Round 6: a cold box showed a NaN that no warm box reproduced — ``k_head_rows`` read three never-written columns of an LDS tile
+    against zero weights (0 x the previous kernel's finite leftovers on a warm box, 0 x NaN on a cold one).  With the whole LDS of every
+    CU filled with NaN after EVERY launch (``dmpnn_debug_lds_poison``) the fused step, the module path (a module's first, validated
+    batches and the tile-plan ones) and the inference forward must reproduce the clean run BIT FOR BIT."""
+    from chemprop_amd import _lib, synth
+    from chemprop_amd.model import FusedTrainer
+
+    lib = _lib.load()
+    cfg = dict(mp=dict(activation=act), agg="mean", bn=True, ffn=dict(n_tasks=tasks, activation=act))
+    n_mols = 300
+    bmg = synth.random_batch(n_mols, "qm9", seed=5)
+    bmg.to(gpu_device)
+    gen = torch.Generator().manual_seed(3)
+    tg = torch.randn(n_mols, tasks, generator=gen).to(gpu_device)
+    wg = (0.5 + torch.rand(n_mols, 1, generator=gen)).to(gpu_device)
+
+    def run():
+        torch.manual_seed(11)
+        model = build_mirror(cfg).to(gpu_device).train()
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        outs = []
+        for _ in range(4):                       # batches 0, 1 on the full plan, 2, 3 on the tile plan
+            model.load_state_dict(state)
+            model.zero_grad(set_to_none=True)
+            loss = model.loss(bmg, tg, wg)
+            loss.backward()
+            outs.append([loss.detach().clone()] + [p.grad.detach().clone() for p in model.parameters()])
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        tr = FusedTrainer(model, lr=0.0)
+        for _ in range(3):
+            out = tr.step(bmg, tg, wg)
+            outs.append([out[0].detach().clone()] + [v.detach().clone() for v in tr.sync.views])
+        model.eval()
+        with torch.no_grad():
+            outs.append([model(bmg).clone()])
+        torch.cuda.synchronize()
+        return outs
+
+    clean = run()
+    lib.dmpnn_debug_lds_poison(1)
+    try:
+        poisoned = run()
+    finally:
+        lib.dmpnn_debug_lds_poison(0)
+    for i, (a, b) in enumerate(zip(clean, poisoned)):
+        for j, (x, y) in enumerate(zip(a, b)):
+            assert torch.isfinite(y).all(), f"run {i}, tensor {j}: non-finite under LDS poison"
+            assert torch.equal(x, y), f"run {i}, tensor {j}: differs under LDS poison"
