@@ -490,6 +490,24 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
         for (int ct = 0; ct < WL; ++ct)  // fragment-major layout [column tile][chunk][hi|lo][lane][16 B]
             offB[ct] = (unsigned)(ct0() + ct) * (unsigned)(W.nc * 2048) + (unsigned)lane * 16u;
     };
+    // Round 6: a kept message leaves as WHOLE ROWS of the split A tile — the tile in LDS is the kept row format (chunk pairs + the
+    // 16-byte tail with the tile's scale), so once it is complete (the contraction's barrier) every thread copies 16-byte pieces, 1 KiB
+    // per wave instruction, instead of each lane storing its own 8-byte pieces behind the segment MFMAs (18 scattered store instructions
+    // per wave and step: "split written" 1.3 k -> 4.7-5.0 k cycles of the training forward's phase stamps)
+    unsigned char* rows_pending = nullptr;
+    int rows_pending_n = 0;
+    auto flush_rows = [&]() {
+        if constexpr (KEEP) {
+            if (rows_pending) {   // (uniform)
+                constexpr int PPR = TS / 16;   // 16-byte pieces of a row, tail included
+                for (int it = tid; it < rows_pending_n * PPR; it += KT) {
+                    const int r = it / PPR, pc = it - r * PPR;
+                    *reinterpret_cast<u32x4*>(rows_pending + (long long)r * TS + pc * 16) = *reinterpret_cast<const u32x4*>(T16 + r * TS + pc * 16);
+                }
+                rows_pending = nullptr;
+            }
+        }
+    };
     // ---- one contraction: acc[RT][WL] += (A s_A) . (W s_W)^T in the split domain -------------------
     // A fragments straight from a split tile in LDS (static during the contraction: NO barrier in the main
     // loop): row stride `astride` bytes, chunk c at +c*128 as [hi 32 halfs | lo 32 halfs].  Weight chunks
@@ -531,6 +549,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
                 }
             }
             __syncthreads();  // the split A tile is complete
+            flush_rows();
             launder();
             read_afrags(0, a0h, a0l);
             auto chunk2 = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&nah)[RT], h8 (&nal)[RT], h8 (&bh)[WL], h8 (&bl)[WL]) {
@@ -565,6 +584,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
         h8 bh[WL], bl[WL];
         load_bfrags(rW, offB, 0, bh, bl);
         __syncthreads();  // the split A tile is complete
+        flush_rows();
         launder();
         read_afrags(0, a0h, a0l);
         auto chunk = [&](int c, h8 (&ah)[RT], h8 (&al)[RT], h8 (&nah)[RT], h8 (&nal)[RT]) {
@@ -867,25 +887,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
                     *reinterpret_cast<h4*>(p) = hi;
                     *reinterpret_cast<h4*>(p + 64) = lo;
                     if constexpr (KEEP) {
-                        if (keep_rows) {   // (uniform) the same two pieces, to the kept split row
-                            if (row < n_keep && col4 < N) {
-                                unsigned char* q = keep_rows + (keep0 + row) * G.tsr + (col4 >> 5) * 128 + (col4 & 31) * 2;
-                                *reinterpret_cast<h4*>(q) = hi;
-                                *reinterpret_cast<h4*>(q + 64) = lo;
-                            }
-                        } else if (keep && row < n_keep && col4 < N) {
-                            store_keep4(keep + (keep0 + row) * keep_ld + col4, v);
-                        }
+                        // (keep_rows: the kept split rows are copied out of this tile as whole rows — flush_rows)
+                        if (!keep_rows && keep && row < n_keep && col4 < N) store_keep4(keep + (keep0 + row) * keep_ld + col4, v);
                     }
                 }
             }
         }
         if constexpr (KEEP) {
-            if (keep_rows && wave == 0 && lg == 0) {   // the rows' tails: the tile's scale
+            if (keep_rows) {   // (uniform)
+                if (wave == 0 && lg == 0) {   // the rows' tails (the tile's scale, the all-zero flag) into the tile's own tail slots
 #pragma unroll
-                for (int jt = 0; jt < RT_E; ++jt)
-                    if (jt * 16 + li < n_keep)
-                        *reinterpret_cast<float4*>(keep_rows + (keep0 + jt * 16 + li) * G.tsr + (G.tsr - 16)) = make_float4(s, tile_mx > 0.f ? 0.f : 1.f, 0.f, 0.f);
+                    for (int jt = 0; jt < RT_E; ++jt)
+                        *reinterpret_cast<float4*>(T16 + (jt * 16 + li) * TS + (TS - 16)) = make_float4(s, tile_mx > 0.f ? 0.f : 1.f, 0.f, 0.f);
+                }
+                rows_pending = keep_rows + keep0 * TS;   // (G.tsr == TS: launch_mega16_forward checks)
+                rows_pending_n = n_keep;
             }
         }
         return s;
