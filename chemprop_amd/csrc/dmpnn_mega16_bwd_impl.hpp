@@ -415,14 +415,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
 #pragma unroll
         for (int ct = 0; ct < WL; ++ct) {
             h8 ah0, al0, ah1, al1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x0 = X[0][ct][r] * sX, x1 = X[1][ct][r] * sX, x2 = (RT == 3 ? X[RT - 1][ct][r] : 0.f) * sX;
-                const _Float16 a0 = (_Float16)x0, a1 = (_Float16)x1, a2 = (_Float16)x2;
-                ah0[r] = a0; al0[r] = (_Float16)(x0 - (float)a0);
-                ah0[4 + r] = a1; al0[4 + r] = (_Float16)(x1 - (float)a1);
-                ah1[r] = a2; al1[r] = (_Float16)(x2 - (float)a2);
-                ah1[4 + r] = (_Float16)0.f; al1[4 + r] = (_Float16)0.f;
+            {   // (the pair split on the mixed-precision FMA: mega16::split2)
+                unsigned wh0[4], wl0[4], wh1[4] = {0u, 0u, 0u, 0u}, wl1[4] = {0u, 0u, 0u, 0u};
+                mega16::split2(X[0][ct][0], X[0][ct][1], sX, wh0[0], wl0[0]);
+                mega16::split2(X[0][ct][2], X[0][ct][3], sX, wh0[1], wl0[1]);
+                mega16::split2(X[1][ct][0], X[1][ct][1], sX, wh0[2], wl0[2]);
+                mega16::split2(X[1][ct][2], X[1][ct][3], sX, wh0[3], wl0[3]);
+                if constexpr (RT == 3) {
+                    mega16::split2(X[RT - 1][ct][0], X[RT - 1][ct][1], sX, wh1[0], wl1[0]);
+                    mega16::split2(X[RT - 1][ct][2], X[RT - 1][ct][3], sX, wh1[1], wl1[1]);
+                }
+                ah0 = __builtin_bit_cast(h8, u32x4{wh0[0], wh0[1], wh0[2], wh0[3]}); al0 = __builtin_bit_cast(h8, u32x4{wl0[0], wl0[1], wl0[2], wl0[3]});
+                ah1 = __builtin_bit_cast(h8, u32x4{wh1[0], wh1[1], wh1[2], wh1[3]}); al1 = __builtin_bit_cast(h8, u32x4{wl1[0], wl1[1], wl1[2], wl1[3]});
             }
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
                 m[ct][jt] = z;
             }
         }
-        const float isX = 1.f / sX;
+        const float isX = mega16::rcp_pow2_exact(sX);
 #pragma unroll
         for (int ct = 0; ct < WL; ++ct)
 #pragma unroll
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
 #pragma unroll
             for (int ct = 0; ct < WL; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         contract(RA{}, acc, g.WoMT);
-        unscale(RA{}, acc, 1.f / sA, g.WoMT.inv_scale);
+        unscale(RA{}, acc, mega16::rcp_pow2_exact(sA), g.WoMT.inv_scale);
         incidence(RA{}, acc, 0, m);  // gH[r] = gMv[dst r]
     }
     if (g.g_edge) {  // (uniform) + dL/dH^(T-1) of the edge read-out
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
 #pragma unroll
             for (int ct = 0; ct < WL; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         contract(RE{}, acc, g.WhT);              // gM = gZ^(t) . W_h
-        unscale(RE{}, acc, 1.f / sA, g.WhT.inv_scale);
+        unscale(RE{}, acc, mega16::rcp_pow2_exact(sA), g.WhT.inv_scale);
         incidence(RE{}, acc, 3, m);              // gH^(t-1) = C^T gM
         if (t - 1 >= 1) {
             const float mx = mask_rows(m, g.Hs + (long long)(t - 2) * g.slot, false, g.gZrows ? nullptr : g.gZs + (long long)(t - 2) * g.slot, t - 1);

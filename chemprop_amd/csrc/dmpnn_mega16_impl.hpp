@@ -103,11 +103,29 @@ __device__ __forceinline__ void store_keep4(float* p, float4 v) {
     *reinterpret_cast<float4*>(p) = v;
 #endif
 }
-__device__ __forceinline__ void split4(float4 x, float s, h4& hi, h4& lo) {
-    const float a = x.x * s, b = x.y * s, c = x.z * s, d = x.w * s;
-    hi = h4{(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
-    lo = h4{(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1]), (_Float16)(c - (float)hi[2]), (_Float16)(d - (float)hi[3])};
+// The exact pair split of two elements, x s = hi + lo: hipcc emits v_pk_mul_f32, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_fma_f32,
+// v_cvt_pk_f16_f32 per pair (3 VALU instructions per element).  Round 6 measured the 2-per-element form on the mixed-precision FMA
+// (v_fma_mixlo/hi_f16 hi, x, s, -0;  v_fma_mixlo/hi_f16 lo, x, s, -hi.f16 — bit for bit the same words, scripts/micro/split_probe.hip):
+// the tile kernel's chain 65.3 k -> 64.5 k cycles, configs 2-4 and the training step unchanged — the phases between the contractions
+// are dependency chains, not VALU issue — and v_fma_mixhi_f16 is a partial register write whose consumer needs a wait state the
+// compiler cannot place for inline assembly (gfx940 dst-sel forwarding hazard: wrong results when the consumer followed directly).
+// Not kept (profiles/r06_split_on_fma_mix.txt).
+__device__ __forceinline__ void split2(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+    const float a = x0 * s, b = x1 * s;
+    const h2 h = h2{(_Float16)a, (_Float16)b};
+    const h2 l = h2{(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
 }
+__device__ __forceinline__ void split4(float4 x, float s, h4& hi, h4& lo) {
+    unsigned h0, l0, h1, l1;
+    split2(x.x, x.y, s, h0, l0);
+    split2(x.z, x.w, s, h1, l1);
+    hi = __builtin_bit_cast(h4, u32x2{h0, h1});
+    lo = __builtin_bit_cast(h4, u32x2{l0, l1});
+}
+// 1 / s for a power of two s in [2^-126, 2^126] (every scale of the split format is one: scale_for, k_split_weights) — EXACT, one integer
+// subtraction instead of the ~10 VALU instructions of an IEEE division
+__device__ __forceinline__ float rcp_pow2_exact(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }
 
 // ---- pre-split of the weights: one wave per (matrix, row) -----------------------------------------
 struct SplitJob {
@@ -653,12 +671,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
         launder();
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const float x = __uint_as_float(v[j].x) * s, y = __uint_as_float(v[j].y) * s;
-            const h2 hi = h2{(_Float16)x, (_Float16)y};
-            const h2 lo = h2{(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
+            unsigned hi, lo;
+            split2(__uint_as_float(v[j].x), __uint_as_float(v[j].y), s, hi, lo);
             unsigned char* p = Ag + (wave + NW * j) * TSG + (lane >> 4) * 128 + (lane & 15) * 4;
-            *reinterpret_cast<h2*>(p) = hi;
-            *reinterpret_cast<h2*>(p + 64) = lo;
+            *reinterpret_cast<unsigned*>(p) = hi;
+            *reinterpret_cast<unsigned*>(p + 64) = lo;
         }
         return s;
     };
@@ -703,6 +720,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
         constexpr int RT = decltype(rt_c)::value;
         constexpr bool USE_RES = decltype(use_res_c)::value;
         if constexpr (simple_act) {
+#if !defined(DMPNN_RELU_SELECT)
+            if (neg_slope == 0.f) {   // (uniform) ReLU: ONE v_maximum3_f32(v, 0, 0) per element instead of multiply + compare + select + add.  IEEE-754
+                                      // maximum: a NaN stays NaN (loud), -0 -> +0, and -inf -> 0 as torch.relu has it (the select form made it NaN)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < WL; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = USE_RES ? res[rt][ct][r] + z[rt][ct][r] : z[rt][ct][r];
+                            z[rt][ct][r] = __builtin_elementwise_maximum(v, 0.f);
+                        }
+                return;
+            }
+#endif
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -836,14 +868,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
         for (int ct = 0; ct < WL; ++ct) {
             h8 ah0, al0, ah1, al1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x0 = H[0][ct][r] * sH, x1 = H[1][ct][r] * sH, x2 = H[2][ct][r] * sH;
-                const _Float16 h0_ = (_Float16)x0, h1_ = (_Float16)x1, h2_ = (_Float16)x2;
-                ah0[r] = h0_; al0[r] = (_Float16)(x0 - (float)h0_);
-                ah0[4 + r] = h1_; al0[4 + r] = (_Float16)(x1 - (float)h1_);
-                ah1[r] = h2_; al1[r] = (_Float16)(x2 - (float)h2_);
-                ah1[4 + r] = (_Float16)0.f; al1[4 + r] = (_Float16)0.f;
+            {   // k-step 0: rows lg 4 .. of row tiles 0 | 1, k-step 1: of row tile 2 | none
+                unsigned wh0[4], wl0[4], wh1[4] = {0u, 0u, 0u, 0u}, wl1[4] = {0u, 0u, 0u, 0u};
+                split2(H[0][ct][0], H[0][ct][1], sH, wh0[0], wl0[0]);
+                split2(H[0][ct][2], H[0][ct][3], sH, wh0[1], wl0[1]);
+                split2(H[1][ct][0], H[1][ct][1], sH, wh0[2], wl0[2]);
+                split2(H[1][ct][2], H[1][ct][3], sH, wh0[3], wl0[3]);
+                split2(H[2][ct][0], H[2][ct][1], sH, wh1[0], wl1[0]);
+                split2(H[2][ct][2], H[2][ct][3], sH, wh1[1], wl1[1]);
+                ah0 = __builtin_bit_cast(h8, u32x4{wh0[0], wh0[1], wh0[2], wh0[3]}); al0 = __builtin_bit_cast(h8, u32x4{wl0[0], wl0[1], wl0[2], wl0[3]});
+                ah1 = __builtin_bit_cast(h8, u32x4{wh1[0], wh1[1], wh1[2], wh1[3]}); al1 = __builtin_bit_cast(h8, u32x4{wl1[0], wl1[1], wl1[2], wl1[3]});
             }
 #pragma unroll
             for (int jt = 0; jt < RT_E; ++jt) {
@@ -858,7 +892,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
             }
         }
         stamp();  // s1: segment MFMAs
-        const float isH = 1.f / sH;
+        const float isH = rcp_pow2_exact(sH);
         float mx = 0.f;
 #pragma unroll
         for (int ct = 0; ct < WL; ++ct)
@@ -925,7 +959,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
             const int ncg = G.Wi.nc - grp * 4 < 4 ? G.Wi.nc - grp * 4 : 4;
             contract(RE{}, h0, Ag, TSG, ncg, grp * 4, G.Wi);
         }
-        unscale(RE{}, h0, 1.f / s_prev, cc);
+        unscale(RE{}, h0, rcp_pow2_exact(s_prev), cc);
         stamp();  // 3: K1 contraction
     }
     if (KEEP && G.keep_bits) {  // training: the backward pass needs tau'(H0) — for a ReLU-class tau the sign, as bits
@@ -1033,7 +1067,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
         const ColConst cc = col_consts(G.Wh.inv_scale, g.b_h);
         contract(RE{}, acc, T16, TS, (N + BK - 1) / BK, 0, G.Wh);
         stamp();  // 5, 7, ...: update contraction
-        unscale(RE{}, acc, 1.f / sA, cc);
+        unscale(RE{}, acc, rcp_pow2_exact(sA), cc);
         act_frags(RE{}, T_{}, acc, h0);  // tau(H0 + W_h(M)): base.py:141
         dropout_frags(RE{}, acc, (unsigned)(step - 1), rs, true);  // dropout(H_t): base.py:139 (training, p > 0)
         stamp();  // E: unscale + tau
@@ -1076,7 +1110,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
             contract(RA{}, acc, Ag, TSG, ncg, grp * 4, G.WoV);
         }
         stamp();  // finalize: V part
-        unscale(RA{}, acc, 1.f / sV, cc);
+        unscale(RA{}, acc, rcp_pow2_exact(sV), cc);
         act_frags(RA{}, F_{}, acc, acc);
         dropout_frags(RA{}, acc, (unsigned)(T_steps - 1), va, false);  // dropout(tau(W_o [...])): base.py:182
         if (maxbits[5]) {  // (uniform; written before the first barrier of the kernel)

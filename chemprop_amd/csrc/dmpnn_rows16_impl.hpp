@@ -264,12 +264,11 @@ __global__ __launch_bounds__(kThreads, GC == 4 ? 2 : 1) void k_rows16(Rows16K g)
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const float x = __uint_as_float(v[pp][j].x) * s, y = __uint_as_float(v[pp][j].y) * s;
-                const h2 hi = h2{(_Float16)x, (_Float16)y};
-                const h2 lo = h2{(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
+                unsigned hi, lo;
+                mega16::split2(__uint_as_float(v[pp][j].x), __uint_as_float(v[pp][j].y), s, hi, lo);
                 unsigned char* p = Ag + (wave + 4 * j) * TSG + (pp * 4 + (lane >> 4)) * 128 + (lane & 15) * 4;
-                *reinterpret_cast<h2*>(p) = hi;
-                *reinterpret_cast<h2*>(p + 64) = lo;
+                *reinterpret_cast<unsigned*>(p) = hi;
+                *reinterpret_cast<unsigned*>(p + 64) = lo;
             }
         if (grp + 1 < n_groups) ga_load(grp + 1, v);  // the next group's rows are in flight under this group's MFMAs
         const int ncg = g.W.nc - grp * GC < GC ? g.W.nc - grp * GC : GC;

@@ -524,12 +524,11 @@ __device__ __forceinline__ void split_rows_body(const SplitRowsK& g) {
                __builtin_amdgcn_raw_buffer_load_b64(r2, gemm::join_off(o2, k2o), 0, 0);
     };
     auto put = [&](int r, int k, float x, float y, float s) {
-        const float xs = x * s, ys = y * s;
-        const mega16::h2 hi = mega16::h2{(_Float16)xs, (_Float16)ys};
-        const mega16::h2 lo = mega16::h2{(_Float16)(xs - (float)hi[0]), (_Float16)(ys - (float)hi[1])};
+        unsigned hi, lo;
+        mega16::split2(x, y, s, hi, lo);
         unsigned char* p = g.out + (long long)(rs + r) * g.ts + (k >> 5) * 128 + (k & 31) * 2;
-        *reinterpret_cast<mega16::h2*>(p) = hi;
-        *reinterpret_cast<mega16::h2*>(p + 64) = lo;
+        *reinterpret_cast<unsigned*>(p) = hi;
+        *reinterpret_cast<unsigned*>(p + 64) = lo;
     };
     float mx = 0.f;
     if (nc * 32 <= 256) {
