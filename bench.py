@@ -109,6 +109,8 @@ def compact_line(out):
             c[k] = pick(out[k], "frac", "achieved", "unit", "launch_us", "error")
     if "host_handoff" in out:
         c["host_handoff"] = pick(out["host_handoff"], "five_tensors_us", "packed_us", "error")
+    if "half_operands" in out:
+        c["half_operands"] = pick(out["half_operands"], "us", "M_edge_updates_per_s", "route", "max_diff_vs_exact_over_max_out", "error")
     if "loader_tiles" in out:
         c["loader_tiles"] = {k: pick(v, "loader_tiles_us", "device_plan_us") for k, v in out["loader_tiles"].items() if isinstance(v, dict)}
     if "cpu_baseline_train" in out:
@@ -704,6 +706,32 @@ def main():
                 out["loader_tiles"] = lt
             except Exception as e:
                 out["host_handoff"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
+        # ---- BASELINE configs[1] names bf16: the SAME forward with every matrix product on f16 operands (DMPNN_STORE=f16 on the tile
+        # route, round 6: operands, messages and weights as one f16 per element under the exact split's power-of-two scales, one MFMA
+        # pass instead of three; 11-bit significands, bf16 has 8).  OPT-IN, NOT fp32-class: reported beside `value`, never as it ----
+        if world == 1 and not train:
+            try:
+                def f_lp():
+                    with torch.no_grad():
+                        return mp(bmg)
+                out_exact = f_lp().clone()
+                os.environ["DMPNN_STORE"] = "f16"
+                try:
+                    run_steps(f_lp, 10)
+                    t_lp = time_events(f_lp, max(50, args.steps), torch)
+                    o_lp = f_lp()
+                    den = max(1.0, float(out_exact.abs().max()))
+                    out["half_operands"] = {"us": round(t_lp * 1e3, 2), "M_edge_updates_per_s": round(updates / (t_lp * 1e3), 2),
+                                            "route": mp.__dict__.get("_dmpnn_route"),
+                                            "max_diff_vs_exact_over_max_out": float((o_lp - out_exact).abs().max()) / den,
+                                            "note": "DMPNN_STORE=f16: opt-in, not fp32-class (tests hold 2e-3 against the oracle and <= the oracle under "
+                                                    "torch's bf16 autocast); never `value`"}
+                finally:
+                    os.environ["DMPNN_STORE"] = "f32"
+                    run_steps(f_lp, 3)
+            except Exception as e:
+                out["half_operands"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
         # ---- BASELINE configs[2..4] at their own shapes (inference forward of the module, inputs resident): molecules that
         # do not fit the tiles of the whole-forward kernel take the per-step fused route on the f16 pipe ----

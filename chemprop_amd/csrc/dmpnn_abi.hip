@@ -438,8 +438,8 @@ int dmpnn_forward(const dmpnn_fwd_args* a, void* stream) {
                     "forward: W_d given but V_d / b_d / Hv / d_vd missing");
     DMPNN_CHECK_ARG(a->ldout >= h + (has_vd ? a->d_vd : 0), "forward: ldout too small");
     const bool fused = a->flags & DMPNN_F_FUSED;
-    DMPNN_CHECK_ARG(!(a->flags & DMPNN_F_STORE16) || (fused && (a->flags & DMPNN_F_SPLIT16) && !(a->flags & (DMPNN_F_MEGA | DMPNN_F_KEEP))),
-                    "forward: DMPNN_F_STORE16 only goes with the per-step fused route on the f16 pipe (DMPNN_F_FUSED | DMPNN_F_SPLIT16, inference)");
+    DMPNN_CHECK_ARG(!(a->flags & DMPNN_F_STORE16) || (fused && (a->flags & DMPNN_F_SPLIT16) && !(a->flags & (DMPNN_F_KEEP | DMPNN_F_ATOM))),
+                    "forward: DMPNN_F_STORE16 only goes with the fused routes on the f16 pipe (DMPNN_F_FUSED | DMPNN_F_SPLIT16 [| DMPNN_F_MEGA]), inference, bond messages");
     const bool lean16 = fused && (a->flags & DMPNN_F_SPLIT16) && (a->flags & DMPNN_F_KEEP) && !(a->flags & DMPNN_F_MEGA) && a->keep_bits;
     if (a->depth > 1 && nE > 0 && !(a->flags & DMPNN_F_MEGA) && !lean16) {
         DMPNN_CHECK_ARG(a->Ms && a->n_mslots >= 1, "forward: missing Ms workspace");

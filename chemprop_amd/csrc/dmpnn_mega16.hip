@@ -23,6 +23,11 @@ DMPNN_DEFINE_MEGA16_NW(5, true, true, 8)
 DMPNN_DEFINE_MEGA16_NW(5, true, false, 8)
 DMPNN_DEFINE_MEGA16_NW(5, false, true, 8)
 DMPNN_DEFINE_MEGA16_NW(5, false, false, 8)
+// the HI-halves-alone forms (DMPNN_F_STORE16, inference): defined in dmpnn_mega16_lp.hip
+#define DMPNN_DECLARE_MEGA16_LP(WN, SA, NW) template <> int launch_mega16<WN, SA, false, NW, true>(const Mega16K& g, int n_tiles, hipStream_t s);
+DMPNN_DECLARE_MEGA16_LP(1, true, 4) DMPNN_DECLARE_MEGA16_LP(1, false, 4) DMPNN_DECLARE_MEGA16_LP(2, true, 4) DMPNN_DECLARE_MEGA16_LP(2, false, 4)
+DMPNN_DECLARE_MEGA16_LP(5, true, 4) DMPNN_DECLARE_MEGA16_LP(5, false, 4) DMPNN_DECLARE_MEGA16_LP(5, true, 8) DMPNN_DECLARE_MEGA16_LP(5, false, 8)
+#undef DMPNN_DECLARE_MEGA16_LP
 }  // namespace mega16
 
 // (per calling thread: a diagnostic hook, never shared mutable state between threads that drive the library)
@@ -119,8 +124,10 @@ int tile_waves(const dmpnn_fwd_args& a, int n_tiles) {
         return n;
     }();
     if (n_tiles <= n_cu) return 8;
+    // (with a margin of 1 / 16: 576 QM9-shaped molecules — 251 by this estimate, 259 tiles in fact — ran their last three tiles as a second
+    //  round of 8-wave workgroups, 64 us where two co-resident 4-wave tiles per CU take 45: profiles/r06_l2_warm_sizes.txt)
     const int64_t est = std::max<int64_t>((a.n_edges + 39) / 40, (a.n_atoms + 19) / 20);
-    return est <= n_cu ? 8 : 4;
+    return est + est / 16 <= n_cu ? 8 : 4;
 }
 
 int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hipStream_t s) {
@@ -196,6 +203,13 @@ int launch_mega16_forward(const dmpnn_fwd_args& a, float* out, int64_t ldout, hi
     const int n_tiles = (a.n_tiles_launch > 0 && a.n_tiles_launch < L.max_mtiles) ? (int)a.n_tiles_launch : (int)L.max_mtiles;
     const bool sa = !(a.act == DMPNN_ACT_TANH || a.act == DMPNN_ACT_ELU), kp = (a.flags & DMPNN_F_KEEP) != 0;
     const int wn = a.d_h <= 64 ? 1 : (a.d_h <= 128 ? 2 : 5);
+    if (a.flags & DMPNN_F_STORE16) {   // (validated by dmpnn_forward: inference, bond messages) every product on the hi halves alone
+        if (wn == 1) return sa ? mega16::launch_mega16<1, true, false, 4, true>(G, n_tiles, s) : mega16::launch_mega16<1, false, false, 4, true>(G, n_tiles, s);
+        if (wn == 2) return sa ? mega16::launch_mega16<2, true, false, 4, true>(G, n_tiles, s) : mega16::launch_mega16<2, false, false, 4, true>(G, n_tiles, s);
+        if (tile_waves(a, n_tiles) == 8)
+            return sa ? mega16::launch_mega16<5, true, false, 8, true>(G, n_tiles, s) : mega16::launch_mega16<5, false, false, 8, true>(G, n_tiles, s);
+        return sa ? mega16::launch_mega16<5, true, false, 4, true>(G, n_tiles, s) : mega16::launch_mega16<5, false, false, 4, true>(G, n_tiles, s);
+    }
 #define DMPNN_PICK(WN) (sa ? (kp ? mega16::launch_mega16<WN, true, true>(G, n_tiles, s) : mega16::launch_mega16<WN, true, false>(G, n_tiles, s)) \
                            : (kp ? mega16::launch_mega16<WN, false, true>(G, n_tiles, s) : mega16::launch_mega16<WN, false, false>(G, n_tiles, s)))
     if (wn == 1) return DMPNN_PICK(1);

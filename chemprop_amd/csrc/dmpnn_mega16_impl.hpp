@@ -241,8 +241,13 @@ constexpr size_t lds_bytes_atom() { return lds_bytes<WN>() + kAtomLds; }
 // Picked when the launch has at most one tile per CU (launch_mega16_forward): there the 4-wave form leaves every SIMD with ONE wave.
 // Each wave class runs its own instantiation of the tile's body (exact vmcnt waits, no guards in the MFMA loops): together they
 // are as much code as the 4-wave body.
-template <int WN, bool SA, bool KEEP, int NW = 4>
+// LP (round 6, DMPNN_F_STORE16 on this route: OPT-IN, NOT fp32-class): every matrix product on the HI halves alone — operand rows, messages,
+// weights and the H of the incidence products as ONE f16 per element (11-bit significands under the same power-of-two scales; bf16, which
+// BASELINE configs[1] names, has 8), one MFMA pass instead of three, half the weight stream; accumulation, residual, bias, activation and the
+// output stay fp32.  Inference only (KEEP = false), bond messages.
+template <int WN, bool SA, bool KEEP, int NW = 4, bool LP = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
+    static_assert(!(LP && KEEP), "the hi-halves-alone form is inference only");
     static_assert(NW == 4 || (NW == 8 && WN == 5), "the 8-wave form splits 20 column tiles 3+3+3+3+2+2+2+2");
     const mega::MegaK& g = G.m;
     constexpr int KT = 64 * NW;                // threads of the workgroup
@@ -287,11 +292,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
     // four round trips before the first operand byte is requested instead of three (ISA, round 6).
     int rs = g.mtile_row[t], re = g.mtile_row[t + 1];
     int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
-    int hdr_light = g.flags[DMPNN_HDR_LIGHT], hdr_flags = g.flags[0];
-    asm volatile("" : "+v"(rs), "+v"(re), "+v"(va), "+v"(vb), "+v"(hdr_light), "+v"(hdr_flags));
+    int hdr_light = g.flags[DMPNN_HDR_LIGHT], hdr_flags = g.flags[0], hdr_tiles = g.flags[DMPNN_HDR_NMTILES];   // (flags = the header's address)
+    asm volatile("" : "+v"(rs), "+v"(re), "+v"(va), "+v"(vb), "+v"(hdr_light), "+v"(hdr_flags), "+v"(hdr_tiles));
     rs = __builtin_amdgcn_readfirstlane(rs); re = __builtin_amdgcn_readfirstlane(re);
     va = __builtin_amdgcn_readfirstlane(va); vb = __builtin_amdgcn_readfirstlane(vb);
     hdr_light = __builtin_amdgcn_readfirstlane(hdr_light); hdr_flags = __builtin_amdgcn_readfirstlane(hdr_flags);
+    hdr_tiles = __builtin_amdgcn_readfirstlane(hdr_tiles);   // (tiles the plan really has: the launch's grid is only a bound)
     const int nrows = re - rs, na = vb - va;
     const int N = g.h, qn = N >> 2;
     // Tile plan (header LIGHT == 2): the rows of a tile are its edges in the CALLER's order, src / dst / rev come
@@ -396,6 +402,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
             a_grp[j] = __builtin_amdgcn_raw_buffer_load_b64(rVg, gemm::join_off(ro1[j], k1o), 0, 0) |
                        __builtin_amdgcn_raw_buffer_load_b64(rEg, gemm::join_off(ro2[j], k2o), 0, 0);
     }
+    unsigned pf_word[4] = {0u, 0u, 0u, 0u};   // (the L2 warm-up below, behind the K1 contraction: loaded there, looked at only when the kernel ends)
 #if defined(DMPNN_META_STAMPS)
     stamp();  // m1: tile table + index loads issued, operand gather in flight
 #endif
@@ -497,9 +504,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
         for (int ct = 0; ct < WL; ++ct) {
             const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u, 0, 0);
-            const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0);
             bh[ct] = __builtin_bit_cast(h8, vh);
-            bl[ct] = __builtin_bit_cast(h8, vl);
+            if constexpr (!LP) {
+                const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(rW, offB[ct] + (unsigned)c * 2048u + 1024u, 0, 0);
+                bl[ct] = __builtin_bit_cast(h8, vl);
+            }
         }
     };
     auto bfrag_offsets = [&](const SplitW& W, unsigned (&offB)[WL]) {
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
             for (int rt = 0; rt < RT; ++rt) {
                 const unsigned char* p = Ab + (rt * 16 + li) * astride + c * 128 + lg * 16;
                 ah[rt] = *reinterpret_cast<const h8*>(p);
-                al[rt] = *reinterpret_cast<const h8*>(p + 64);
+                if constexpr (!LP) al[rt] = *reinterpret_cast<const h8*>(p + 64);
             }
         };
         // ONE set of weight fragments, used as a ring over the column tiles (the register budget of two workgroups per CU is
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
                 for (int ct = 0; ct < WL; ++ct) {
                     b1h[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, two ? offB[ct] + 2048u : kOOB, 0, 0));
-                    b1l[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, two ? offB[ct] + 3072u : kOOB, 0, 0));
+                    if constexpr (!LP) b1l[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, two ? offB[ct] + 3072u : kOOB, 0, 0));
                 }
             }
             __syncthreads();  // the split A tile is complete
@@ -576,14 +585,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
                 for (int ct = 0; ct < WL; ++ct) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                    if constexpr (!LP) {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned o = more2 ? offB[ct] + (unsigned)(c + 2) * 2048u : kOOB;  // (past the last chunk: out of range, 0)
                     bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
-                    bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more2 ? o + 1024u : kOOB, 0, 0));
+                    if constexpr (!LP) bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more2 ? o + 1024u : kOOB, 0, 0));
                     if (ct == (WL > 1 ? WL - 2 : 0)) read_afrags(c + 1 < n_chunks ? c + 1 : c, nah, nal);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -611,14 +622,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
             for (int ct = 0; ct < WL; ++ct) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                if constexpr (!LP) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bl[ct], acc[rt][ct], 0, 0, 0);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bh[ct], acc[rt][ct], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned o = more ? offB[ct] + (unsigned)(c + 1) * 2048u : kOOB;  // (past the last chunk: out of range, 0)
                 bh[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
-                bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more ? o + 1024u : kOOB, 0, 0));
+                if constexpr (!LP) bl[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rW, more ? o + 1024u : kOOB, 0, 0));
                 if (ct == (WL > 1 ? WL - 2 : 0)) read_afrags(more ? c + 1 : c, nah, nal);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -675,7 +688,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
             split2(__uint_as_float(v[j].x), __uint_as_float(v[j].y), s, hi, lo);
             unsigned char* p = Ag + (wave + NW * j) * TSG + (lane >> 4) * 128 + (lane & 15) * 4;
             *reinterpret_cast<unsigned*>(p) = hi;
-            *reinterpret_cast<unsigned*>(p + 64) = lo;
+            if constexpr (!LP) *reinterpret_cast<unsigned*>(p + 64) = lo;
         }
         return s;
     };
@@ -885,8 +898,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
                 if (jt < RT_A || !last) {
                     z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, cf[jt][0], z, 0, 0, 0);
                     z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, cf[jt][1], z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, cf[jt][0], z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, cf[jt][1], z, 0, 0, 0);
+                    if constexpr (!LP) {
+                        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, cf[jt][0], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, cf[jt][1], z, 0, 0, 0);
+                    }
                 }
                 m[ct][jt] = z;
             }
@@ -919,7 +934,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
                     split4(v, s, hi, lo);
                     unsigned char* p = T16 + row * TS + (col4 >> 5) * 128 + (col4 & 31) * 2;
                     *reinterpret_cast<h4*>(p) = hi;
-                    *reinterpret_cast<h4*>(p + 64) = lo;
+                    if constexpr (!LP) *reinterpret_cast<h4*>(p + 64) = lo;
                     if constexpr (KEEP) {
                         // (keep_rows: the kept split rows are copied out of this tile as whole rows — flush_rows)
                         if (!keep_rows && keep && row < n_keep && col4 < N) store_keep4(keep + (keep0 + row) * keep_ld + col4, v);
@@ -962,6 +977,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
         unscale(RE{}, h0, rcp_pow2_exact(s_prev), cc);
         stamp();  // 3: K1 contraction
     }
+    // Round 6: warm THIS XCD's L2 with W_h and W_o's message part behind the K1 contraction (its own weight requests are all back), under the
+    // first message's VALU / LDS phases.  Every tile of a launch reaches its first update contraction at about the same time and all of them
+    // miss on the same lines (a forward splits the weights afresh: they are in no L2): the stamps of the hi-halves form — whose contractions
+    // are short enough to show it — had the FIRST use of W_h at 7.7 k cycles and the second at 4.6 k, the first use of W_o's message part
+    // at 7.5 k.  Workgroups go round the XCDs (t mod 8), so the t / 8-th workgroup of an XCD touches the t / 8-th share of the lines: one
+    // 4-byte load per thread and 128-byte line, consumed by nothing (the word below is never read).
+#if !defined(DMPNN_NO_L2_WARM)
+    // (measured, same box, module forward with | without: 512 molecules / 230 tiles 39.2-39.4 | 39.9 us and 30.4 | 32.9 us on the hi halves;
+    //  64 molecules / 29 tiles 38.1 | 37.4 and 1 024 molecules / 460 tiles 65.7 | 64.8: a launch of few tiles or of two rounds loses — hence the window)
+#if !defined(DMPNN_L2_WARM_MIN_TILES)
+#define DMPNN_L2_WARM_MIN_TILES 96
+#define DMPNN_L2_WARM_MAX_TILES 256
+#endif
+    if (g.depth > 1 && hdr_tiles >= DMPNN_L2_WARM_MIN_TILES && hdr_tiles <= DMPNN_L2_WARM_MAX_TILES && t < 256) {   // (uniform)
+        launder();
+        const unsigned nl = (unsigned)(((N + 15) / 16) * G.Wh.nc * 16);   // 128-byte lines of one split matrix (2 KiB per column tile and chunk)
+        const rsrc_t rWh = gemm::make_rsrc(G.Wh.p, nl * 128u), rWo = gemm::make_rsrc(G.WoM.p, nl * 128u);
+        const unsigned share = (unsigned)(((hdr_tiles < 256 ? hdr_tiles : 256) + 7) >> 3) * (unsigned)KT;
+        unsigned line = (unsigned)(t >> 3) * (unsigned)KT + (unsigned)tid;
+#pragma unroll
+        for (int k = 0; k < 2; ++k, line += share) {
+            const unsigned oh = line < nl ? line * 128u : kOOB, oo = (line >= nl && line < 2u * nl) ? (line - nl) * 128u : kOOB;
+            pf_word[2 * k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_raw_buffer_load_b32(rWh, oh, 0, 0));
+            pf_word[2 * k + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_raw_buffer_load_b32(rWo, oo, 0, 0));
+        }
+    }
+#endif
     if (KEEP && G.keep_bits) {  // training: the backward pass needs tau'(H0) — for a ReLU-class tau the sign, as bits
         store_bits(RE{}, h0, 0);
     } else if (KEEP && g.H0) {  // ... else the pre-activation itself
@@ -1119,6 +1161,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
 #pragma unroll
                 for (int ct = 0; ct < WL; ++ct) acc[rt][ct] = f32x4{__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000)};
         }
+        if ((pf_word[0] ^ pf_word[1] ^ pf_word[2] ^ pf_word[3]) == 0x7fdead01u) maxbits[7] = 1u;   // (the L2 warm-up's loads end here: a use the compiler must wait for, of a word nothing reads)
         __syncthreads();  // (the fp32 tile may overlay the V operand tile)
         frag_to_tile(RA{}, acc);
         __syncthreads();
@@ -1158,17 +1201,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
     }
 }
 
-template <int WN, bool SA, bool KEEP, int NW = 4>
+template <int WN, bool SA, bool KEEP, int NW = 4, bool LP = false>
 int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
 
 #define DMPNN_DEFINE_MEGA16(WN, SA, KEEP) DMPNN_DEFINE_MEGA16_NW(WN, SA, KEEP, 4)
-#define DMPNN_DEFINE_MEGA16_NW(WN, SA, KEEP, NW)                                                           \
+#define DMPNN_DEFINE_MEGA16_NW(WN, SA, KEEP, NW) DMPNN_DEFINE_MEGA16_LP(WN, SA, KEEP, NW, false)
+#define DMPNN_DEFINE_MEGA16_LP(WN, SA, KEEP, NW, LP)                                                       \
     template <>                                                                                            \
-    int launch_mega16<WN, SA, KEEP, NW>(const Mega16K& g, int n_tiles, hipStream_t s) {                    \
+    int launch_mega16<WN, SA, KEEP, NW, LP>(const Mega16K& g, int n_tiles, hipStream_t s) {                \
         const size_t lds = g.atom_de ? lds_bytes_atom<WN>() : lds_bytes<WN>();                             \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN, SA, KEEP, NW>),          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mpnn_tile16<WN, SA, KEEP, NW, LP>),      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_atom<WN>()); \
             if (e != hipSuccess) {                                                                         \
                 set_error("hipFuncSetAttribute(k_mpnn_tile16<%d>, %zu B LDS): %s", WN, lds, hipGetErrorString(e)); \
@@ -1176,7 +1220,7 @@ int launch_mega16(const Mega16K& g, int n_tiles, hipStream_t s);
             }                                                                                              \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_mpnn_tile16<WN, SA, KEEP, NW>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g);   \
+        hipLaunchKernelGGL((k_mpnn_tile16<WN, SA, KEEP, NW, LP>), dim3((unsigned)n_tiles), dim3(64 * NW), lds, s, g);   \
         DMPNN_CHECK_LAUNCH("k_mpnn_tile16");                                                               \
         return DMPNN_OK;                                                                                   \
     }

@@ -748,6 +748,11 @@ def forward(plan: GraphPlan, V: Tensor, E: Tensor, W_i: Tensor, W_h: Tensor, W_o
             # OPT-IN half storage of the message tensor between the steps (DMPNN_F_STORE16): not fp32-class, see include/dmpnn.h
             a.flags |= F_STORE16
             st.route = "fused16/f16-storage"
+        elif use_mega and storage_f16() and not keep and not atom:
+            # ... and on the whole-forward tile kernel (round 6): every product on the hi halves alone — operands, messages and weights as
+            # one f16 per element under the same power-of-two scales, one MFMA pass instead of three (k_mpnn_tile16<..., LP>)
+            a.flags |= F_STORE16
+            st.route = "mega16/f16-operands"
     elif use_mega:
         a.flags |= F_MEGA
     if keep:

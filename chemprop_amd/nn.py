@@ -184,7 +184,7 @@ def _param(mp, lin: str, name: str):
 def _make_replay(mp, plan, st) -> None:
     """After a slow-path forward that took the tile kernel on a tile plan: remember how to repeat it."""
     mp.__dict__.pop("_dmpnn_replay", None)
-    if st is None or st.route != "mega16" or not plan.tiles_only or mp.W_d is not None:
+    if st is None or st.route not in ("mega16", "mega16/f16-operands") or not plan.tiles_only or mp.W_d is not None:
         return
     r = _Replay()
     r.args = bytes(st.args)  # template copy of the argument block
@@ -396,7 +396,7 @@ def bond_message_passing_forward(mp, bmg, V_d: Optional[Tensor] = None) -> Tenso
     last = mp.__dict__.pop("_dmpnn_last", None)  # (the forward's workspace must not outlive the call)
     mp.__dict__["_dmpnn_route"] = getattr(last, "route", None)  # diagnostics: the route the last slow-path forward took
     plan.ensure_launched()   # (nothing ran the deferred K0: a route that does not read the plan at all)
-    if oversize is None and plan.tiles_only and last is not None and last.route == "mega16":
+    if oversize is None and plan.tiles_only and last is not None and last.route in ("mega16", "mega16/f16-operands"):
         _spill_monitor(mp, plan.buf, plan.device)
     if light == "tiles" and V_d is None and not torch.is_grad_enabled() and _lib.opt("DMPNN_REPLAY", "1") != "0":
         _make_replay(mp, plan, last)

@@ -49,8 +49,11 @@ extern "C" {
  * dmpnn_train_route (the training-plan / kept-form rule beside dmpnn_forward_route); dmpnn_fwd_args.h0_bytes + dmpnn_forward_h0_bytes
  * (H0 kept as row quads on the per-step fused route's inference forward).
  * 13 — round 6: dmpnn_tile_waves (which form of the tile kernels a launch of these shapes takes); dmpnn_prepare_tiles with a batch
- * vector runs over several workgroups and uses the plan's unused arrays as hand-off scratch (nothing for the caller to do). */
-#define DMPNN_ABI_VERSION 14
+ * vector runs over several workgroups and uses the plan's unused arrays as hand-off scratch (nothing for the caller to do).
+ * 14 — round 6: DMPNN_LOSS_MVE / DMPNN_LOSS_EVIDENTIAL / DMPNN_LOSS_QUANTILE in dmpnn_head (evid_v_kl / evid_eps / quantile_alpha).
+ * 15 — round 6: DMPNN_F_STORE16 also with DMPNN_F_MEGA (the whole-forward tile kernel on f16 operands: one MFMA pass, opt-in, not
+ * fp32-class; it was DMPNN_EINVAL there). */
+#define DMPNN_ABI_VERSION 15
 
 enum dmpnn_status {
     DMPNN_OK = 0,
@@ -123,7 +126,16 @@ enum dmpnn_flags {
                                      rounded to an 11-bit significand once per step (bf16, which BASELINE configs[1] names,
                                      has 8): outputs differ from the fp32 reference by ~1e-4 relative, the tests hold
                                      2e-3.  H0, the weights, every accumulation and the output stay fp32 / exact-split.
-                                     Same workspace layout as without the flag (the slots are simply not filled)        */
+                                     Same workspace layout as without the flag (the slots are simply not filled).
+                                     With DMPNN_F_FUSED | DMPNN_F_MEGA | DMPNN_F_SPLIT16 (ABI 15, the whole-forward tile
+                                     kernel, which has no messages in memory): EVERY matrix product runs on the hi halves
+                                     alone — operand rows, messages, weights and the H of the incidence products as one f16
+                                     per element under the exact split's power-of-two scales, ONE MFMA pass instead of
+                                     three and half the weight stream; accumulation, residual, bias, activation and the
+                                     output stay fp32.  ~3e-4 .. 9e-4 relative against the fp32 reference (the reference
+                                     under torch's bf16 autocast: 4e-3 .. 9e-3), the tests hold 2e-3; a molecule beyond the
+                                     tile still takes the generic fp32 path.  Inference only, bond messages: with
+                                     DMPNN_F_KEEP or DMPNN_F_ATOM it is DMPNN_EINVAL                                     */
 };
 
 /* ---------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_version_and_plan_bytes():
     lib = _lib.load()
-    assert lib.dmpnn_version() == _lib.ABI_VERSION == 14
+    assert lib.dmpnn_version() == _lib.ABI_VERSION == 15
     assert lib.dmpnn_plan_bytes(0, 0) >= 64
     b = lib.dmpnn_plan_bytes(4319, 8328)
     assert b % 16 == 0 and b >= 4 * (16 + 9 * 8328 + 2 * 4319)
@@ -218,6 +218,7 @@ def test_tile_waves_is_a_shape_rule(monkeypatch):
     assert lib.dmpnn_tile_waves(4636, 9120, 300, 0) == 8       # the headline batch: ~230 tiles on 256 CUs
     assert lib.dmpnn_tile_waves(4636, 9120, 300, 230) == 8
     assert lib.dmpnn_tile_waves(40000, 80000, 300, 0) == 4     # 4 096 molecules: several tiles per CU
+    assert lib.dmpnn_tile_waves(5200, 10034, 300, 0) == 4      # 576 molecules: 251 tiles by the estimate, 259 in fact — no second round of 8-wave tiles
     assert lib.dmpnn_tile_waves(4636, 9120, 128, 0) == 4       # d_h <= 128: the 1- / 2-column-tile instantiations
     assert lib.dmpnn_tile_waves(4636, 9120, 512, 0) == 4       # d_h > 320: not a tile-kernel shape at all
 

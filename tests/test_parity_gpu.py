@@ -408,6 +408,73 @@ def test_half_storage_at_size(kind, n_mols, kw, gpu_device, monkeypatch):
     assert mp.__dict__.get("_dmpnn_route") == "fused16"
 
 
+HALF_OPERANDS_TOL = 2e-3  # DMPNN_F_STORE16 on the tile route: operands, messages AND weights as one f16 per element (stated in include/dmpnn.h)
+
+
+def test_half_operands_on_the_tile_kernel_golden(golden, gpu_device, monkeypatch):
+    """``DMPNN_STORE=f16`` on the whole-forward tile kernel (round 6, ``k_mpnn_tile16<..., LP>``): every matrix product on the hi
+    halves alone — one MFMA pass instead of three, half the weight stream.  Opt-in, not fp32-class: held to its own stated bar on
+    every golden the tile route takes, deterministic, and NOT what runs by default."""
+    cfg = golden.cfg
+    if cfg.get("undirected") or cfg["d_h"] % 4 or cfg["d_h"] > 320 or golden["V"].shape[1] % 2 or golden["E"].shape[1] % 2 or "V_d" in golden:
+        pytest.skip("tile route does not apply")
+    if str(cfg["activation"]).lower() not in ("relu", "leakyrelu", "prelu", "tanh", "elu"):
+        pytest.skip("custom activation: rows route")
+    plan, out_exact, st = _engine_forward(golden, gpu_device, route="mega", mfma="split16")
+    if not plan.fusable():
+        pytest.skip("not a molecular graph")
+    assert st.route == "mega16"
+    assert parity_err(out_exact.cpu().numpy(), golden["out"]) <= TOL
+    monkeypatch.setenv("DMPNN_STORE", "f16")
+    _, out, st_h = _engine_forward(golden, gpu_device, route="mega", mfma="split16")
+    assert st_h.route == "mega16/f16-operands"
+    err = parity_err(out.cpu().numpy(), golden["out"])
+    print(f"half operands {golden.name}: {err:.2e}")
+    assert err <= HALF_OPERANDS_TOL, f"{golden.name}: {err:.3e}"
+    if plan.n_edges and golden.name.startswith("qm9"):
+        assert not torch.equal(out, out_exact)        # the flag did change the arithmetic (a molecule beyond the tile takes the generic fp32 path either way)
+    _, out2, _ = _engine_forward(golden, gpu_device, route="mega", mfma="split16")
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("n_mols,kw", [(512, dict()), (64, dict()), (2048, dict(activation="tanh", bias=True)), (300, dict(d_h=128, depth=4))])
+def test_half_operands_at_size(n_mols, kw, gpu_device, monkeypatch):
+    """The module's own forward under ``DMPNN_STORE=f16`` at BASELINE's batch: the tile kernel's hi-halves form, against the oracle —
+    and against the SAME oracle under torch's bf16 autocast (what ``configs[1]``'s "bf16" means for the reference): the f16 operands
+    (11-bit significands) must not be further from fp32 than bf16's 8 bits are."""
+    from chemprop_amd import synth
+    from chemprop_amd.nn import BondMessagePassing
+    from oracle import dmpnn_torch as ot
+
+    torch.manual_seed(13)
+    mp = BondMessagePassing(**kw).eval()
+    b = synth.random_batch(n_mols, "qm9", seed=22)
+    with torch.no_grad():
+        w = ot.MPWeights.from_module(mp)
+        ref = ot.forward_bmg(b, w, depth=mp.depth, activation=kw.get("activation", "relu"))
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref_bf16 = ot.forward_bmg(b, w, depth=mp.depth, activation=kw.get("activation", "relu")).float()
+    err_bf16 = parity_err(ref_bf16.numpy(), ref.numpy())
+    mp = mp.to(gpu_device)
+    b.to(gpu_device)
+    monkeypatch.setenv("DMPNN_STORE", "f16")
+    with torch.no_grad():
+        for _ in range(3):                            # past the validated first batches: the steady (replay) path
+            out = mp(b)
+    route = str(mp.__dict__.get("_dmpnn_route"))
+    assert route.startswith("mega16"), route
+    err = parity_err(out.cpu().numpy(), ref.numpy())
+    print(f"half operands qm9-{n_mols} {kw}: {err:.2e} (the oracle under bf16 autocast: {err_bf16:.2e})")
+    assert err <= HALF_OPERANDS_TOL, f"qm9-{n_mols}: {err:.3e}"
+    assert err <= err_bf16, f"f16 operands {err:.3e} further from fp32 than bf16 autocast {err_bf16:.3e}"
+    monkeypatch.setenv("DMPNN_STORE", "f32")
+    with torch.no_grad():
+        for _ in range(2):
+            out_exact = mp(b)
+    assert parity_err(out_exact.cpu().numpy(), ref.numpy()) <= TOL
+    assert not torch.equal(out, out_exact)
+
+
 @pytest.mark.parametrize("d_h,depth,act,bias,kind,n", [(384, 3, "relu", False, "zinc", 64), (448, 2, "tanh", True, "qm9", 160),
                                                        (512, 4, "leakyrelu", False, "synth40", 36), (640, 3, "elu", True, "cgr", 80),
                                                        (324, 3, "relu", False, "qm9", 160), (64, 1, "relu", False, "zinc", 64)])
