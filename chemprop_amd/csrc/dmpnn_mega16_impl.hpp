@@ -983,6 +983,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
     // are short enough to show it — had the FIRST use of W_h at 7.7 k cycles and the second at 4.6 k, the first use of W_o's message part
     // at 7.5 k.  Workgroups go round the XCDs (t mod 8), so the t / 8-th workgroup of an XCD touches the t / 8-th share of the lines: one
     // 4-byte load per thread and 128-byte line, consumed by nothing (the word below is never read).
+    // (Also measured, profiles/r06_l2_warm_variants.txt: the same loads as inline assembly into one sink register — invisible to hipcc's wait
+    //  counts, the first vmcnt(0) behind them waited for the whole burst, +2 us per launch; as plain global loads — hipcc cannot count a FLAT
+    //  load in order and every later wait became vmcnt(0), the update contraction 8.5 k -> 13.7 k cycles; W_i touched at kernel entry and
+    //  W_o's atom part with the two above — +0.3 us on every launch, the gain at 512 molecules down from 0.9 to 0.25 us.  Hence buffer loads,
+    //  these two matrices, behind K1.)
 #if !defined(DMPNN_NO_L2_WARM)
     // (measured, same box, module forward with | without: 512 molecules / 230 tiles 39.2-39.4 | 39.9 us and 30.4 | 32.9 us on the hi halves;
     //  64 molecules / 29 tiles 38.1 | 37.4 and 1 024 molecules / 460 tiles 65.7 | 64.8: a launch of few tiles or of two rounds loses — hence the window)
