@@ -307,7 +307,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
     const bool lean = hdr_light == 2;
     // (a training forward on a tile plan keeps its tensors in the caller's edge order: dmpnn_backward takes them so when told
     //  DMPNN_F_TILE_PLAN, dmpnn_mega16_bwd_impl.hpp)
-    const bool poison = (hdr_flags & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64));
+    // (round 6: a caller that knows an upper bound of the tile count — the batch's molecule count: a tile holds at least one — launches only
+    //  that many workgroups instead of the layout's bound, dmpnn_fwd_args.n_tiles_launch.  A plan with MORE tiles than the launch has
+    //  workgroups means that bound was wrong: every output NaN, never a batch with rows nobody computed)
+    const bool poison = (hdr_flags & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64)) ||
+                        hdr_tiles > (int)gridDim.x;
     if (poison) {
         const float nanv = __int_as_float(0x7fc00000);
         const long long total = (long long)g.nV * N;

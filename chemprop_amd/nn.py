@@ -284,7 +284,9 @@ def _replay_forward(mp, r: "_Replay", bmg):
             rc = lib.dmpnn_forward_tiles(_ctypes.byref(a), None, tiles[0].data_ptr(), tiles[1].data_ptr(), tiles[2], nbytes, stream)
         else:
             a.flags = r.flags if small else (r.flags | _lib.F_LOADER_TILES)
-            a.n_tiles_launch = 0
+            # (the tile count is on the device only; a tile holds at least one molecule, so the batch's molecule count bounds it — a third
+            #  fewer idle workgroups than the layout's bound at 512 molecules, 1 us of the launch; a plan with more tiles than that comes back NaN)
+            a.n_tiles_launch = n_mols
             rc = lib.dmpnn_forward_tiles(_ctypes.byref(a), batch.data_ptr(), None, None, 0, nbytes, stream)
     finally:
         if ctx is not None:

@@ -330,8 +330,11 @@ typedef struct dmpnn_fwd_args {
     void* wsplit; size_t wsplit_bytes;
     /* the caller's own index arrays (device): required when `plan` is a tile plan (dmpnn_prepare_tiles), else ignored */
     const int64_t* edge_index; const int64_t* rev_edge_index;
-    /* DMPNN_F_MEGA: number of tile workgroups to launch when the caller knows the tile count (loader tiles); 0 = the
-     * launch bound of the batch size (workgroups beyond the table's tiles exit at once) */
+    /* DMPNN_F_MEGA: number of tile workgroups to launch when the caller knows the tile count (loader tiles) or an upper
+     * bound of it (the batch's molecule count: a tile holds at least one molecule); 0 = the launch bound of the batch
+     * size (workgroups beyond the table's tiles exit at once — 745 workgroups for the 230 tiles of 512 QM9-shaped
+     * molecules, 1 us of a 30 us launch when the real tiles leave only 25 CUs for them).  A plan that turns out to hold
+     * MORE tiles than this: every output NaN */
     int64_t n_tiles_launch;
     /* DMPNN_F_MEGA without DMPNN_F_KEEP: scratch of >= dmpnn_forward_spill_bytes() bytes for molecules larger than a
      * tile (generic in-kernel path; with DMPNN_F_KEEP the kept tensors serve).  NULL: such a molecule's atoms come back

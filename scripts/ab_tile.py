@@ -64,6 +64,10 @@ for n_mols in sizes:
         stream = engine._stream_ptr(dev)
         k0 = lambda: lib.dmpnn_prepare_tiles(a.edge_index, a.rev_edge_index, bmg.batch.data_ptr(), nV, nE, buf.data_ptr(), nbytes, stream)
         assert k0() == 0
+        if os.environ.get("AB_EXACT_GRID"):   # launch exactly the plan's tiles (header word 6) instead of the layout's bound
+            torch.cuda.synchronize()
+            a.n_tiles_launch = int(buf[6].item()) + int(os.environ.get("AB_EXACT_GRID_EXTRA", "0"))
+            print(f"  grid: {a.n_tiles_launch} workgroups (the plan's tiles)")
         fw = lambda: lib.dmpnn_forward(C.byref(a), stream)
         assert fw() == 0
         torch.cuda.synchronize()

@@ -408,6 +408,36 @@ def test_half_storage_at_size(kind, n_mols, kw, gpu_device, monkeypatch):
     assert mp.__dict__.get("_dmpnn_route") == "fused16"
 
 
+def test_a_launch_with_fewer_workgroups_than_the_plan_has_tiles_is_loud(gpu_device):
+    """``dmpnn_fwd_args.n_tiles_launch`` may be an upper BOUND of the tile count (the module's steady path passes the batch's molecule
+    count: a tile holds at least one molecule).  A bound that turns out too small must not leave rows nobody computed: every output NaN."""
+    from chemprop_amd import engine, synth
+    from chemprop_amd.nn import BondMessagePassing
+
+    torch.manual_seed(5)
+    mp = BondMessagePassing().eval().to(gpu_device)
+    b = synth.random_batch(64, "qm9", seed=31)
+    b.to(gpu_device)
+
+    def run(n_launch):
+        plan = engine.GraphPlan.from_bmg(b, light="tiles")
+        plan.loader_tiles = n_launch   # (what engine.forward passes as n_tiles_launch; the plan itself came from the batch vector)
+        with torch.no_grad():
+            out, st = engine.forward(plan, b.V, b.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=3, route="mega", mfma="split16")
+        assert st.route == "mega16"
+        n_tiles = int(plan.buf[6].item())   # DMPNN_HDR_NMTILES
+        return out, n_tiles
+
+    ref, n_tiles = run(0)
+    assert 0 < n_tiles <= 64 and torch.isfinite(ref).all()
+    exact, _ = run(n_tiles)
+    assert torch.equal(exact, ref)                      # the exact count, and any bound above it (the molecule count): the same launch
+    bound, _ = run(64)
+    assert torch.equal(bound, ref)
+    short, _ = run(n_tiles - 1)
+    assert torch.isnan(short).all()
+
+
 HALF_OPERANDS_TOL = 2e-3  # DMPNN_F_STORE16 on the tile route: operands, messages AND weights as one f16 per element (stated in include/dmpnn.h)
 
 
