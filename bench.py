@@ -487,16 +487,24 @@ def main():
             #  pre-split of these very weights; K0 and the weight pre-split are the step's other launch and are not part of this figure)
             import ctypes as _C
 
+            # (... as the timed step launches it: on the TILE plan K0 builds from the batch vector — rows in the caller's order, no CSR
+            #  arrays — and with the batch's molecule count as the launch's workgroup bound, chemprop_amd/nn.py: _replay_forward)
+            plan_dom = engine.GraphPlan.from_bmg(bmg, light="tiles") if route_used == "mega16" else plan
             with torch.no_grad():
-                _, st_dom = engine.forward(plan, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=args.depth)
+                _, st_dom = engine.forward(plan_dom, bmg.V, bmg.E, mp.W_i.weight, mp.W_h.weight, mp.W_o.weight, mp.W_o.bias, depth=args.depth)
             blk_dom = _lib.FwdArgs.from_buffer_copy(bytes(st_dom.args))
             blk_dom.flags |= _lib.F_WSPLIT_READY
+            if route_used == "mega16" and plan_dom.tiles_only:
+                blk_dom.n_tiles_launch = args.mols
             lib_dom = _lib.load()
 
+            ref_dom, stream_dom = _C.byref(blk_dom), engine._stream_ptr(dev)   # (hoisted: the loop must stay shorter on the host than on the device)
+
             def kdom():
-                _lib.check(lib_dom.dmpnn_forward(_C.byref(blk_dom), engine._stream_ptr(dev)), "dmpnn_forward")
+                if lib_dom.dmpnn_forward(ref_dom, stream_dom):
+                    _lib.check(1, "dmpnn_forward")
             run_steps(kdom, 10)
-            t_dom = time_events(kdom, 50, torch)
+            t_dom = time_events(kdom, 200, torch)   # (five groups of 40 back-to-back launches: the first launch of a group starts behind an idle queue)
             if route_used == "mega16":
                 waves = int(lib_dom.dmpnn_tile_waves(nV, nE, h, 0))
                 kname = (f"k_mpnn_tile16<5, {waves} waves>: whole forward per tile of whole molecules in one launch"
