@@ -310,6 +310,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16(Mega16K G) {
     // (round 6: a caller that knows an upper bound of the tile count — the batch's molecule count: a tile holds at least one — launches only
     //  that many workgroups instead of the layout's bound, dmpnn_fwd_args.n_tiles_launch.  A plan with MORE tiles than the launch has
     //  workgroups means that bound was wrong: every output NaN, never a batch with rows nobody computed)
+    // (measured and not kept, profiles/r06_tile_loop_not_kept.txt: the kernel's body as a loop over tiles b, b + grid, ... so that the grid can be
+    //  an ESTIMATE of the tile count — 277 instead of 512 workgroups.  Correct on every grid down to one workgroup, but the back edge cost the
+    //  allocation 1 .. 7 registers and the schedule 0.8 us at 64 molecules, 2 us at 512: more than the 0.5 us the idle workgroups take)
     const bool poison = (hdr_flags & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64)) ||
                         hdr_tiles > (int)gridDim.x;
     if (poison) {
