@@ -14,6 +14,7 @@
 //     per-atom counters) in LDS — a 512-molecule QM9 batch (E ~ 9.6k, V ~ 4.6k) needs ~110 KB;
 //     global memory sees one batched read of the int64 arrays and one pass of int32 writes.
 //   * the general path: count | scan | fill | sort | inverse | rows+tiles, seven short launches.
+#include <atomic>
 #include <limits.h>
 
 #include "dmpnn_common.hpp"
@@ -894,19 +895,30 @@ __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch_split(con
 // the tile kernel tile by tile (closure) — never silently wrong.
 constexpr unsigned kBoundsTag = 0x6b30a11du;
 constexpr int kBoundsMaxSpins = 4096;
-struct MultiScratch { int64_t aoff, eoff, done, end; int n_bounds; };
+// Round 6 (late): the offsets themselves carry the tag — aoff / eoff are 8-byte words {tag, offset}, written with ONE agent-scope store by the
+// thread that finds the boundary, and the packing block polls THEM: a molecule's ranges are usable the moment they land, not a store drain,
+// a barrier, a published block word and one more round trip later (packing block, cycles from its entry: ranges in LDS 7.9-8.5 k -> see
+// profiles/r06_k0_tagged_offsets.txt).  The tag changes with every launch (a host counter), so a word left behind by an earlier launch on the
+// same buffer never passes; the packing block clears what it read all the same.  The blocks' words {tag, error bits} are still published —
+// behind the data, off the critical path — and the packing block looks at them LAST, before it ends: an error found there (an id out of range,
+// ids not sorted) is patched into the header it has just written, so the tile kernel still poisons the batch.
+struct MultiScratch { int64_t aoff, eoff, done, end; int n_bounds; unsigned tag; };
 static MultiScratch multi_scratch(const PlanLayout& L, int64_t nV, int64_t nE) {
     MultiScratch S;
     S.n_bounds = (int)(((nV > nE ? nV : nE) + 1 + kSmallThreads - 1) / kSmallThreads);
-    int64_t o = L.src;
-    S.aoff = o; o += align4(nV + 2);
-    S.eoff = o; o += align4(nV + 2);
+    S.tag = 0u;
+    int64_t o = (L.src + 1) & ~int64_t(1);   // (8-byte words)
+    S.aoff = o; o += align4(2 * (nV + 2));
+    S.eoff = o; o += align4(2 * (nV + 2));
     S.done = o; o += align4(2 * (int64_t)S.n_bounds);   // 8-byte words
     S.end = o;
     return S;
 }
 __device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_tagged(int* base, int m, unsigned tag, int v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(base) + m, ((unsigned long long)tag << 32) | (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ void tiles_bounds_block(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ batch, int* __restrict__ plan,
                                                    const MultiScratch& S, int nV, int nE, int b) {
@@ -931,23 +943,23 @@ __device__ __forceinline__ void tiles_bounds_block(const int64_t* __restrict__ e
         if (bm < 0 || bm >= nV) bad |= PLAN_RANGE_ERROR;   // at most one molecule per atom
         const int m = clampm(bm), pm = i > 0 ? clampm(bp) : -1;
         if (m < pm) bad |= PLAN_NO_PIECE_TILES;            // not non-decreasing: the ranges mean nothing
-        for (int mm = pm + 1; mm <= m; ++mm) st_agent(aoff + mm, i);   // (empty unless i is a boundary; the boundary thread fills a gap of empty molecules)
+        for (int mm = pm + 1; mm <= m; ++mm) st_tagged(aoff, mm, S.tag, i);   // (empty unless i is a boundary; the boundary thread fills a gap of empty molecules)
     } else if (i == nV) {
-        st_agent(aoff + n_mols, nV);
+        st_tagged(aoff, n_mols, S.tag, nV);
     }
     if (i < nE) {
         const int m = clampm(em64), pm = i > 0 ? clampm(ep64) : -1;
         if (m < pm) bad |= PLAN_NO_PIECE_TILES;
-        for (int mm = pm + 1; mm <= m; ++mm) st_agent(eoff + mm, i);
+        for (int mm = pm + 1; mm <= m; ++mm) st_tagged(eoff, mm, S.tag, i);
     } else if (i == nE) {
         const int pm = nE > 0 ? clampm(ep64) : -1;
-        for (int mm = pm + 1; mm <= n_mols; ++mm) st_agent(eoff + mm, nE);   // molecules behind the last edge, and the end marker
+        for (int mm = pm + 1; mm <= n_mols; ++mm) st_tagged(eoff, mm, S.tag, nE);   // molecules behind the last edge, and the end marker
     }
     if (bad) atomicOr(&bad_blk, bad);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have left
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(plan + S.done) + b, ((unsigned long long)kBoundsTag << 32) | (unsigned)bad_blk,
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(plan + S.done) + b, ((unsigned long long)S.tag << 32) | (unsigned)bad_blk,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -969,24 +981,28 @@ __device__ __forceinline__ void tiles_pack_block(int* lds_i, const int64_t* __re
     const int nm = last < 0 ? 0 : (last >= nV ? nV : (int)last + 1);
     __syncthreads();
     unsigned long long* done = reinterpret_cast<unsigned long long*>(plan + S.done);
-    if (tid < S.n_bounds) {
-        unsigned long long w = 0ull;
-        int spins = 0;
-        for (;;) {
-            w = __hip_atomic_load(done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(w >> 32) == kBoundsTag || ++spins >= kBoundsMaxSpins) break;
-            __builtin_amdgcn_s_sleep(8);
+    {   // every molecule's first atom / first edge as soon as its word lands (bounded spin: a word that never comes — ids not sorted — is an error)
+        unsigned long long* a64 = reinterpret_cast<unsigned long long*>(plan + S.aoff);
+        unsigned long long* e64 = reinterpret_cast<unsigned long long*>(plan + S.eoff);
+        for (int m = tid; m <= nm; m += kSmallThreads) {
+            unsigned long long wa = 0ull, we = 0ull;
+            int spins = 0;
+            for (;;) {
+                wa = __hip_atomic_load(a64 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                we = __hip_atomic_load(e64 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (((unsigned)(wa >> 32) == S.tag && (unsigned)(we >> 32) == S.tag) || ++spins >= kBoundsMaxSpins) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const bool ok = (unsigned)(wa >> 32) == S.tag && (unsigned)(we >> 32) == S.tag;
+            if (!ok) atomicOr(&flags_s, PLAN_NO_PIECE_TILES);
+            fa[m] = ok ? (int)(unsigned)wa : 0;
+            fe[m] = ok ? (int)(unsigned)we : 0;
+            __hip_atomic_store(a64 + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nothing published: the next launch's start state)
+            __hip_atomic_store(e64 + m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if ((unsigned)(w >> 32) != kBoundsTag) atomicOr(&flags_s, PLAN_NO_PIECE_TILES);
-        else if ((unsigned)w) atomicOr(&flags_s, (int)((unsigned)w & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR)));
     }
     __syncthreads();
-    stamp();  // 1: every bounds block has published
-    for (int m = tid; m <= nm; m += kSmallThreads) {
-        fa[m] = ld_agent(plan + S.aoff + m);
-        fe[m] = ld_agent(plan + S.eoff + m);
-    }
-    if (tid < S.n_bounds) __hip_atomic_store(done + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nothing published: the next launch's start state
+    stamp();  // 1: every range has landed
     __syncthreads();
     stamp();  // 2: ranges in LDS
     {   // whatever was read must at least be a pair of non-decreasing offset lists inside the arrays
@@ -1003,6 +1019,28 @@ __device__ __forceinline__ void tiles_pack_block(int* lds_i, const int64_t* __re
     __syncthreads();
     stamp();  // 3: molecule ranges
     tiles_batch_finish(fa, fe, Y, nm, &bad_s, &flags_s, &spill_s, plan, L, nV, nE, dbg, n_stamp, mol_bounds, n_mols_out);
+    // ... and what the bounds blocks found wrong, LAST: their words are behind their data (normally here long ago)
+    __shared__ int late_s;
+    if (tid == 0) late_s = 0;
+    __syncthreads();
+    if (tid < S.n_bounds) {
+        unsigned long long w = 0ull;
+        int spins = 0;
+        for (;;) {
+            w = __hip_atomic_load(done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == S.tag || ++spins >= kBoundsMaxSpins) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if ((unsigned)(w >> 32) != S.tag) atomicOr(&late_s, PLAN_NO_PIECE_TILES);
+        else if ((unsigned)w) atomicOr(&late_s, (int)((unsigned)w & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR)));
+        __hip_atomic_store(done + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0 && (late_s & ~flags_s)) {   // (an error the header does not carry yet: this block wrote the header, program order)
+        plan[DMPNN_HDR_FLAGS] |= late_s & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR);
+        if (late_s & PLAN_NO_PIECE_TILES) { plan[DMPNN_HDR_NMTILES] = 0; plan[DMPNN_HDR_NSPILL] = 0; }
+        if (mol_bounds) mol_bounds[2 * n_mols_out] |= ((late_s & PLAN_RANGE_ERROR) ? 1 : 0) | ((late_s & PLAN_NO_PIECE_TILES) ? 2 : 0);
+    }
 }
 
 __global__ __launch_bounds__(kSmallThreads) void k_prepare_tiles_batch_multi(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ batch,
@@ -1056,7 +1094,10 @@ int launch_prepare_tiles_batch(const int64_t* edge_index, const int64_t* batch, 
     mega16::SplitArgs sp;
     {   // K0 over several workgroups (k_prepare_tiles_batch_multi), with or without the weight pre-split riding in the launch
         static const bool multi_off = [] { const char* e = getenv("DMPNN_K0_SINGLE"); return e && atoi(e) != 0; }();
-        const MultiScratch S = multi_scratch(L, nV, nE);
+        MultiScratch S = multi_scratch(L, nV, nE);
+        static std::atomic<unsigned> launch_no{0u};
+        S.tag = kBoundsTag ^ (launch_no.fetch_add(1u, std::memory_order_relaxed) * 0x9E3779B1u);   // (never 0 twice in a row; a replayed graph node keeps its own)
+        if (S.tag == 0u) S.tag = kBoundsTag;
         if (!multi_off && nV > 0 && S.end <= L.tile_row) {
             const bool split = split_for && did_split && (split_for->flags & DMPNN_F_MEGA) && (split_for->flags & DMPNN_F_SPLIT16) &&
                                !(split_for->flags & DMPNN_F_WSPLIT_READY) && mega16_split_args(*split_for, &sp);
