@@ -380,7 +380,10 @@ __device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLay
     __shared__ unsigned long long blk_mask[kMaxBlocks];
     if (tid == 0) ntile_s = 0;
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    // (wave index through v_readfirstlane: hipcc takes tid >> 6 for divergent, and with it the block's base, the chain cursor and the mask —
+    //  the hop below was 14 VALU / SALU instructions with hazard nops around a v_readfirstlane + v_readlane pair, ~65 cycles; with a uniform
+    //  wave index the cursor and the mask live in scalar registers: profiles/r06_k0_scalar_walk.txt)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = (np + 63) >> 6;
     const bool walk = *bad_s == 0;
     if (walk) {
@@ -397,7 +400,13 @@ __device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLay
             if (lane == 0) { blk_mask[blk] = mask; blk_cnt[blk] = __popcll(mask); }
         }
     }
+#if defined(DMPNN_K0_STAMPS2)
+    stamp();  // a: this wave's chains walked
+#endif
     __syncthreads();
+#if defined(DMPNN_K0_STAMPS2)
+    stamp();  // b: every block's chain walked
+#endif
     if (walk) {
         for (int blk = wave; blk < nblk; blk += kSmallThreads / 64) {
             int rank = 0;
@@ -418,7 +427,13 @@ __device__ __forceinline__ int pack_pieces(int* __restrict__ plan, const PlanLay
             }
         }
     }
+#if defined(DMPNN_K0_STAMPS2)
+    stamp();  // c: ranks + the tiles' table words written
+#endif
     other_work(tid, kSmallThreads);
+#if defined(DMPNN_K0_STAMPS2)
+    stamp();  // d: the row-tile tables emptied
+#endif
     __syncthreads();
     stamp();  // p5: chain walk
     const int n_tiles = ntile_s;
