@@ -1560,7 +1560,12 @@ extern "C" {
 // torch.optim.Adam (model.py:208-231), every kernel enqueued by this one call.
 int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
     DMPNN_CHECK_ARG(a != nullptr, "train_step: null args");
-    const dmpnn_fwd_args& f = a->bwd.f;
+    // (round 6: on a tile plan built here from the batch vector, the tile kernels' launches are bounded by the batch's molecule count — a tile
+    //  holds at least one molecule — instead of the layout's bound: 512 instead of 745 workgroups at 512 molecules, forward and backward;
+    //  a plan that turns out to hold more tiles than that comes back NaN from both kernels)
+    dmpnn_bwd_args bw = a->bwd;
+    if ((bw.f.flags & DMPNN_F_TILE_PLAN) && bw.f.n_tiles_launch == 0 && a->head.n_mols > 0 && a->head.batch == a->batch) bw.f.n_tiles_launch = a->head.n_mols;
+    const dmpnn_fwd_args& f = bw.f;
     DMPNN_CHECK_ARG((f.flags & DMPNN_F_KEEP) != 0, "train_step: the forward must keep its tensors (DMPNN_F_KEEP)");
     DMPNN_CHECK_ARG(a->head.gHv == a->bwd.gout && a->head.ldg == a->bwd.ldgout, "train_step: head.gHv must be the backward's gout");
     DMPNN_CHECK_ARG(a->head.n_atoms == f.n_atoms && a->head.d_h == f.d_h + (f.W_d ? f.d_vd : 0), "train_step: head and block sizes differ");
@@ -1616,7 +1621,7 @@ int dmpnn_train_step(const dmpnn_step_args* a, void* stream) {
     }
     if (stages & DMPNN_STEP_BACKWARD) {
         bool rode = false;
-        DMPNN_TRY(backward_impl(&a->bwd, stream, rider.Z ? &rider : nullptr, &rode));
+        DMPNN_TRY(backward_impl(&bw, stream, rider.Z ? &rider : nullptr, &rode));
         if (rider.Z && !rode) {  // (the backward pass did not take the f16 products: the product of its own, as dmpnn_head would have run it)
             dmpnn_gemm_args g;
             memset(&g, 0, sizeof(g));

@@ -77,7 +77,7 @@ int launch_mega16_backward(const dmpnn_fwd_args& f, const float* gHO, int64_t ld
     g.rev64 = reinterpret_cast<const long long*>(f.rev_edge_index);
     g.WoMT = mega16::SplitW{ws, inv_o, (int)nc};
     g.WhT = mega16::SplitW{ws + one, inv_h, (int)nc};
-    const int n_tiles = (int)L.max_mtiles;
+    const int n_tiles = (f.n_tiles_launch > 0 && f.n_tiles_launch < L.max_mtiles) ? (int)f.n_tiles_launch : (int)L.max_mtiles;   // (as the forward: dmpnn_fwd_args.n_tiles_launch)
     const bool sa = f.act == DMPNN_ACT_NONE || f.act == DMPNN_ACT_RELU || f.act == DMPNN_ACT_LEAKYRELU;
     if (h <= 64) return sa ? mega16::launch_mega16_bwd<1, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<1, false>(g, n_tiles, s);
     if (h <= 128) return sa ? mega16::launch_mega16_bwd<2, true>(g, n_tiles, s) : mega16::launch_mega16_bwd<2, false>(g, n_tiles, s);

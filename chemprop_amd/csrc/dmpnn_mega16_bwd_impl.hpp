@@ -98,13 +98,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mpnn_tile16_bwd(Mega16BwdK g) {
     const int va = g.mtile_atom[t], vb = g.mtile_atom[t + 1];
     // (the forward kernel forces these four words and the two header words into ONE round trip; the same six lines made this kernel
     //  fault on the GPU at 230 tiles — both wave counts, not at 29 tiles — and bought nothing measurable in the forward: left alone here)
-    const int hdr_light = g.flags[DMPNN_HDR_LIGHT], hdr_flags = g.flags[0];
+    const int hdr_light = g.flags[DMPNN_HDR_LIGHT], hdr_flags = g.flags[0], hdr_tiles = g.flags[DMPNN_HDR_NMTILES];
     const int nrows = re - rs, na = vb - va;
     const int N = g.h, qn = N >> 2;
     const int T_steps = g.depth;
     const float nanv = __int_as_float(0x7fc00000);
     const bool lean = hdr_light == 2;
-    if ((hdr_flags & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64))) {  // a graph this route cannot represent: every output NaN
+    if ((hdr_flags & (lean ? kPlanNoMegaLean : g.poison_mask)) != 0 || (lean && g.nE > 0 && (!g.edge_index || !g.rev64)) ||
+        hdr_tiles > (int)gridDim.x) {  // a graph this route cannot represent, or a launch with fewer workgroups than the plan has tiles: every output NaN
         const long long tot_e = (long long)g.nE * N, tot_v = (long long)g.nV * N;
         for (long long i = (long long)blockIdx.x * KT + tid; i < tot_e; i += (long long)gridDim.x * KT) {
             g.gH0[(i / N) * g.ldh + (i % N)] = nanv;
