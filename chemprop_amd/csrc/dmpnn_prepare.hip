@@ -1033,18 +1033,21 @@ __device__ __forceinline__ void tiles_pack_block(int* lds_i, const int64_t* __re
     if ((flags_s & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR)) && tid == 0) bad_s = 1;
     __syncthreads();
     stamp();  // 3: molecule ranges
+    // (a first look at the blocks' words NOW: the load is in flight under the packing, and a word that is already there — the blocks publish
+    //  ~1 k cycles behind their data — costs the end of the kernel no round trip)
+    unsigned long long w_early = 0ull;
+    if (tid < S.n_bounds) w_early = __hip_atomic_load(done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tiles_batch_finish(fa, fe, Y, nm, &bad_s, &flags_s, &spill_s, plan, L, nV, nE, dbg, n_stamp, mol_bounds, n_mols_out);
     // ... and what the bounds blocks found wrong, LAST: their words are behind their data (normally here long ago)
     __shared__ int late_s;
     if (tid == 0) late_s = 0;
     __syncthreads();
     if (tid < S.n_bounds) {
-        unsigned long long w = 0ull;
+        unsigned long long w = w_early;
         int spins = 0;
-        for (;;) {
-            w = __hip_atomic_load(done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(w >> 32) == S.tag || ++spins >= kBoundsMaxSpins) break;
+        while ((unsigned)(w >> 32) != S.tag && ++spins < kBoundsMaxSpins) {
             __builtin_amdgcn_s_sleep(8);
+            w = __hip_atomic_load(done + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if ((unsigned)(w >> 32) != S.tag) atomicOr(&late_s, PLAN_NO_PIECE_TILES);
         else if ((unsigned)w) atomicOr(&late_s, (int)((unsigned)w & (PLAN_NO_PIECE_TILES | PLAN_RANGE_ERROR)));
