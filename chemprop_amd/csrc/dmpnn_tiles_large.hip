@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_large_bounds(const long long* __restric
 __global__ __launch_bounds__(256) void k_large_blocks(const long long* __restrict__ batch, int nV, int* __restrict__ plan, LargeScratch S) {
     const int n_mols = mol_count(batch, nV);
     const int lane = threadIdx.x & 63;
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int blk = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: the chain cursor and the mask below in scalar registers — dmpnn_prepare.hip, pack_pieces)
     const int base = blk * 64;
     if (base >= n_mols) return;
     const int* aoff = plan + S.aoff;
